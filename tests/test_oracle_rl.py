@@ -1,0 +1,84 @@
+"""Pins oracle/rl.py against the reference-produced vectors in tests/golden/rl_helpers.json and checks the
+JAX-only restatements for internal consistency (they are 'parity unpinned', see oracle/rl.py header)."""
+import numpy as np
+import torch
+
+from conftest import load_golden
+from oracle import rl
+
+G = load_golden("rl_helpers.json")
+
+
+def test_gae_matches_reference_numpy():
+    for c in G["gae"]:
+        dt = np.float32 if c["out_dtype"] == "float32" else np.float64
+        adv, ret = rl.gae(np.array(c["values"], dtype=dt), np.array(c["next_values"], dtype=dt),
+                          np.array(c["rewards"], dtype=dt), c["gamma"], c["lam"], dtype=dt)
+        assert adv.dtype == dt
+        np.testing.assert_array_equal(adv, np.array(c["advantages"], dtype=dt))
+        np.testing.assert_array_equal(ret, np.array(c["returns"], dtype=dt))
+
+
+def test_idxs():
+    for c in G["idxs"]:
+        a, s, n = rl.get_action_state_next_state_idxs(np.array(c["mask"], dtype=bool))
+        assert a.tolist() == c["action"] and s.tolist() == c["state"] and n.tolist() == c["next_state"]
+
+
+def test_kl_controller():
+    for c in G["kl"]["adaptive"]:
+        k = rl.AdaptiveKLController(c["init"], c["target"], c["horizon"])
+        for st in c["seq"]:
+            k.update(st["current"], st["n_steps"])
+            assert float(k.value) == st["value"]
+
+
+def test_chain_shaping():
+    for ch in G["chains"]:
+        d = rl.ilql_data_from_chain(ch["token_chain"])
+        assert d == ch["ilql_data"]
+        for ml, ref in ch["combined"].items():
+            ml = None if ml == "None" else int(ml)
+            if "error" in ref:
+                try:
+                    rl.combined_chain(ch["token_chain"], ml)
+                    assert False
+                except AssertionError as e:
+                    assert str(e) == ref["error"]
+            else:
+                assert rl.combined_chain(ch["token_chain"], ml) == ref
+
+
+def test_rtg_closed_form():
+    r = np.random.RandomState(0).randn(17)
+    for g in [1.0, 0.99, 0.5]:
+        ref = np.array([sum(g ** (j - i) * r[j] for j in range(i, 17)) for i in range(17)])
+        np.testing.assert_allclose(rl.get_rtg(r, g), ref, rtol=1e-12)
+
+
+def test_whiten():
+    x = np.random.RandomState(1).randn(100) * 3 + 2
+    w = rl.whiten(x)
+    assert abs(w.mean()) < 1e-12 and abs(w.var() - 1) < 1e-6
+    np.testing.assert_allclose(rl.whiten(x, shift_mean=False), w + x.mean())
+
+
+def test_ilql_loss_selection_equals_per_row_next_action():
+    # the flat k-th-True pairing (ilql/base_interface.py:55-74) == per-row "next action position" pairing
+    torch.manual_seed(0)
+    B, T, V = 3, 9, 11
+    sta = torch.tensor([[0, 1, 1, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 0, 0, 0], [1, 0, 1, 1, 0, 0, 0, 1]], dtype=torch.bool)
+    am = torch.ones(B, T - 1)
+    q1, q2, v, tq1, tq2, r = [torch.randn(B, T - 1, dtype=torch.float64) for _ in range(6)]
+    vf = torch.randn(B, dtype=torch.float64)
+    ql1, ql2 = torch.randn(B, T - 1, V, dtype=torch.float64), torch.randn(B, T - 1, V, dtype=torch.float64)
+    ids = torch.randint(0, V, (B, T - 1))
+    loss, logs = rl.ilql_loss(q1, q2, v, vf, tq1, tq2, ql1, ql2, ids, am, sta, r, gamma=0.99, tau=0.7, cql_weight=0.01)
+    n = sta.sum().double()
+    tot = 0.0
+    for b in range(B):
+        pos = torch.nonzero(sta[b])[:, 0].tolist()
+        for j, p in enumerate(pos):
+            vns = v[b, pos[j + 1]] if j + 1 < len(pos) else vf[b]
+            tot += 0.5 * (q1[b, p] - (r[b, p] + 0.99 * vns)) ** 2
+    torch.testing.assert_close(logs["losses"]["q1_loss"], tot / n)
