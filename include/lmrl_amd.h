@@ -1,0 +1,161 @@
+/*
+ * lmrl_amd.h — C ABI of liblmrl_amd.so, the MI355X (gfx950) engine behind LMRL-Gym's
+ * rollout-and-train hot path.
+ *
+ * The reference has no FFI: its boundary is the Python protocol in LLM_RL/environment.py and
+ * the duck-typed algorithm objects.  The entry points below are what a
+ * ctypes binding on the reference side would call (INTEGRATION.md shows the stubs); each
+ * one cites the reference code it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - every `*_d` / "device" pointer is HBM owned by the CALLER (e.g. a torch tensor);
+ *     contexts (`lmrl_*_ctx`) own only small read-only tables.
+ *   - `stream` is a hipStream_t passed as void*; NULL = the null stream.  All calls are
+ *     asynchronous with respect to the host unless stated otherwise.
+ *   - return value: 0 = ok, non-zero = error (text via lmrl_last_error()).
+ *   - batched state is struct-of-arrays over the env index so that lane i touches
+ *     consecutive addresses (coalesced HBM access); layouts are documented next to the
+ *     *_bytes() function that sizes them.
+ */
+#ifndef LMRL_AMD_H
+#define LMRL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMRL_OK 0
+#define LMRL_ERR_ARG 1
+#define LMRL_ERR_HIP 2
+
+const char *lmrl_last_error(void);
+int lmrl_version(void);
+/* Name of the device the library is running on (hipDeviceProp.gcnArchName), "" if none. */
+const char *lmrl_device_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * MT19937 streams — CPython `random.Random(seed)` bit-for-bit.
+ * Replaces: wordle/env/env.py:53 (`vocab.rng = random.Random(seed)`), wordle/env/game.py:178-179
+ * (`rng.choice`), maze/env/env.py:187-212 + randomness.py:9-19 (`random.seed` / `random.choice`).
+ *
+ * Layout of an mt buffer for N streams (uint32):  mt[624][N] then idx[N]   -> 625*N*4 bytes.
+ * ------------------------------------------------------------------------------------------ */
+size_t lmrl_mt_bytes(int n);
+/* seed streams where mask_d[i] != 0 (mask_d NULL = all). seeds_d[i] = |seed| as uint64
+ * (key length 1 if < 2^32 else 2, exactly as CPython's init_by_array over 32-bit limbs). */
+int lmrl_mt_seed(void *mt_d, const uint64_t *seeds_d, const uint8_t *mask_d, int n, void *stream);
+/* test hook: out_d[k*n + i] = k-th genrand_uint32 of stream i, k < n_out (advances the streams). */
+int lmrl_mt_stream(void *mt_d, uint32_t *out_d, int n_out, int n, void *stream);
+/* test hook: out_d[k*n + i] = _randbelow(bounds_d[k]) of stream i (random.Random.choice index). */
+int lmrl_mt_randbelow(void *mt_d, const uint32_t *bounds_d, uint32_t *out_d, int n_draws, int n, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched Wordle MDP — replaces WordleEnvironment / WordleGame / Vocabulary / WordleState
+ * (wordle/env/env.py:39-55, wordle/env/game.py:53-296) stepped in lock-step for N envs.
+ *
+ * Game-state buffer for N envs (uint32, SoA):
+ *   forb[5][N]  bit c set  <=> letter c is NOT_HERE at position i   (game.py:17-20 CharKnowledge)
+ *   must[5][N]  bit c set  <=> letter c is HERE at position i       (neither bit = POSSIBLE)
+ *   n_filtered[N]           len(vocab.filtered_vocab)
+ *   n_actions[N]            len(action_history)
+ *   hist[6][N]              packed guesses (5 x 5 bit letters), 0xFFFFFFFF = not a 5-letter a-z string
+ * -> 19*N*4 bytes.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct lmrl_wordle_ctx lmrl_wordle_ctx;
+
+#define LMRL_WORDLE_BAD_GUESS 0xFFFFFFFFu /* guess word that is not 5 letters a-z (game.py:214) */
+/* pack 5 letters 'a'..'z': sum (c_i - 'a') << (5*i) */
+
+/* words5: V*5 bytes, file order (Vocabulary.from_file, game.py:163-170). Host pointer. */
+lmrl_wordle_ctx *lmrl_wordle_create(const char *words5, int n_words, int require_words_in_vocab,
+                                    float bad_word_reward);
+void lmrl_wordle_destroy(lmrl_wordle_ctx *ctx);
+size_t lmrl_wordle_state_bytes(int n);
+/* WordleEnvironment.reset for envs with mask_d[i] != 0 (NULL = all): seeds the env's stream in mt_d
+ * (env.py:53) and sets the all-POSSIBLE state with filtered_vocab = all_vocab (game.py:208-211). */
+int lmrl_wordle_reset(lmrl_wordle_ctx *ctx, void *state_d, void *mt_d, const uint64_t *seeds_d,
+                      const uint8_t *mask_d, int n, void *stream);
+/*
+ * One env.step for every env with active_d[i] != 0 (NULL = all)  (env.py:46-50 -> game.py:213-222).
+ *   guess_d[i]  packed guess or LMRL_WORDLE_BAD_GUESS
+ *   obs_d[i]    bits [3k,3k+3) k<5: 0 none / 1 'g' / 2 'y' / 3 'b' (transition_sequence()[-1], game.py:273-288);
+ *               bits [16,19): number of symbols (0 for an invalid action -> observation text "\n")
+ *   reward_d[i] -1 / 0 (int in the reference) or bad_word_reward (game.py:290-293)
+ *   flags_d[i]  bit0 done (game.py:295-296), bit1 a target was drawn (valid transition),
+ *               bit2 reward is the float bad_word_reward
+ * Inactive envs: outputs untouched, state untouched.
+ */
+int lmrl_wordle_step(lmrl_wordle_ctx *ctx, void *state_d, void *mt_d, const uint32_t *guess_d,
+                     const uint8_t *active_d, uint32_t *obs_d, float *reward_d, uint8_t *flags_d, int n,
+                     void *stream);
+/* Export the knowledge state as the reference's 26x5 trits (0 NOT_HERE / 1 POSSIBLE / 2 HERE) + counts. */
+int lmrl_wordle_export_state(const void *state_d, uint8_t *trits_d /* [N][26][5] */,
+                             uint32_t *n_filtered_d, uint32_t *n_actions_d, int n, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched Maze MDP — replaces MazeEnv.reset/step, update_position and the reward functions
+ * (maze/env/env.py:104-131,161-214).  Text rendering of observations stays on the host.
+ *
+ * State buffer for N envs (int32, SoA): pos_r[N] pos_c[N] goal_r[N] goal_c[N] num_steps[N] -> 20*N bytes.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct lmrl_maze_ctx lmrl_maze_ctx;
+
+#define LMRL_MAZE_LEFT 0   /* 'move left\n'  (0,-1)   env.py:94-99 */
+#define LMRL_MAZE_RIGHT 1  /* 'move right\n' (0,+1) */
+#define LMRL_MAZE_UP 2     /* 'move up\n'    (-1,0) */
+#define LMRL_MAZE_DOWN 3   /* 'move down\n'  (+1,0) */
+#define LMRL_MAZE_OTHER 4  /* any other action string */
+
+#define LMRL_MAZE_KIND_OBS 0      /* history + observation, truncated to last_k      env.py:182-184 */
+#define LMRL_MAZE_KIND_FAILURE 1  /* (Text("Failure\n"),), -1.0, True                env.py:164-165 */
+#define LMRL_MAZE_KIND_SUCCESS 2  /* (Text("Success\n"),), reward, True              env.py:173-174 */
+#define LMRL_MAZE_KIND_OBS_ONLY 3 /* illegal action string: history := (observation,) env.py:179-180 */
+
+/* grid: rows*cols bytes (1 = wall); valid_goals: n_goals (row, col) int32 pairs; max_steps < 0 = None;
+ * rewards: {at_goal, illegal_action, otherwise} e.g. standard_reward = {0,-4,-1} (env.py:109-115). */
+lmrl_maze_ctx *lmrl_maze_create(const uint8_t *grid, int rows, int cols, const int32_t *valid_goals,
+                                int n_goals, int max_steps, const float rewards[3]);
+void lmrl_maze_destroy(lmrl_maze_ctx *ctx);
+size_t lmrl_maze_state_bytes(int n);
+/* MazeEnv.reset (env.py:186-214). opt_goal_d / opt_init_d: [N][2] int32, row < 0 = not given (then drawn with
+ * random.choice from the env's freshly seeded stream, goal first).  NULL = never given. */
+int lmrl_maze_reset(lmrl_maze_ctx *ctx, void *state_d, void *mt_d, const uint64_t *seeds_d,
+                    const int32_t *opt_goal_d, const int32_t *opt_init_d, const uint8_t *mask_d, int n,
+                    void *stream);
+/* MazeEnv.step (env.py:161-184). walls_d: bit0 right, bit1 left, bit2 above, bit3 below (env.py:59). */
+int lmrl_maze_step(lmrl_maze_ctx *ctx, void *state_d, const uint8_t *action_d, const uint8_t *active_d,
+                   float *reward_d, uint8_t *done_d, uint8_t *kind_d, uint8_t *walls_d, int n, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-token RL reductions (wavefront-shuffle kernels).
+ * ------------------------------------------------------------------------------------------ */
+/*
+ * GAE over compacted action tokens, one chain per row — get_advantages_and_returns
+ * (LLM_RL/algorithms/ppo/base_interface.py:253-293) fed exactly as at :586-606:
+ *   values_d  [B][Lv]   per-chain values incl. the bootstrap slot (values_chains, :554-570)
+ *   rewards_d [B][L]    per-token rewards (already KL-penalised, :580-584), L = Lv-1
+ *   sta_d     [B][L]    should_take_action (uint8)
+ *   len_d     [B]       valid length of each chain (<= L)
+ * Outputs adv_d/ret_d [B][L]: advantage / return scattered back to action-token positions, 0 elsewhere
+ * (:635-645).  The state / next-state pairing is get_action_state_next_state_idxs (:230-243).
+ */
+int lmrl_gae(const float *values_d, const float *rewards_d, const uint8_t *sta_d, const int32_t *len_d,
+             float *adv_d, float *ret_d, int b, int l, float gamma, float lam, void *stream);
+/* Reward-to-go over action tokens — get_rtg + MCData scatter (LLM_RL/algorithms/mc_returns/data.py:10-14,49-74). */
+int lmrl_rtg(const float *rewards_d, const uint8_t *sta_d, const int32_t *len_d, float *rtg_d, int b, int l,
+             float gamma, void *stream);
+/* Masked whitening over ALL selected elements of x (ppo/base_interface.py:245-251, :609-615):
+ * y = (x-mean)*rsqrt(var+1e-8) (+mean if !shift_mean) where mask, y = x elsewhere. In place allowed.
+ * moments_d (3 doubles: sum, sumsq, count) is caller scratch; when `moments_only` != 0 only the local
+ * moments are produced (so ranks can all-reduce them) and `lmrl_whiten_apply` finishes the job. */
+int lmrl_whiten_moments(const float *x_d, const uint8_t *mask_d, double *moments_d, size_t n, void *stream);
+int lmrl_whiten_apply(const float *x_d, const uint8_t *mask_d, const double *moments_d, float *y_d, size_t n,
+                      int shift_mean, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMRL_AMD_H */

@@ -1,0 +1,88 @@
+"""ctypes binding of liblmrl_amd.so — the only way the Python host reaches the HIP kernels.
+
+There is NO CPU fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "liblmrl_amd.so")
+
+_lib: Optional[ctypes.CDLL] = None
+
+c_void_p, c_int, c_float, c_size_t, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_char_p
+
+# name -> (restype, argtypes); mirrors include/lmrl_amd.h one to one
+_SIGS = {
+    "lmrl_last_error": (c_char_p, []),
+    "lmrl_version": (c_int, []),
+    "lmrl_device_arch": (c_char_p, []),
+    "lmrl_mt_bytes": (c_size_t, [c_int]),
+    "lmrl_mt_seed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_mt_stream": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "lmrl_mt_randbelow": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "lmrl_wordle_create": (c_void_p, [c_char_p, c_int, c_int, c_float]),
+    "lmrl_wordle_destroy": (None, [c_void_p]),
+    "lmrl_wordle_state_bytes": (c_size_t, [c_int]),
+    "lmrl_wordle_reset": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_wordle_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_wordle_export_state": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_maze_create": (c_void_p, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "lmrl_maze_destroy": (None, [c_void_p]),
+    "lmrl_maze_state_bytes": (c_size_t, [c_int]),
+    "lmrl_maze_reset": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_maze_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_gae": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p]),
+    "lmrl_rtg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "lmrl_whiten_moments": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lmrl_whiten_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+}
+
+
+class LmrlError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load liblmrl_amd.so (once). Raises if it has not been built — never falls back to CPU code."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise LmrlError(
+                f"{SO_PATH} not found: build it with `python lmrl-gym_amd/build.py` "
+                "(or `__graft_entry__.build()`); there is no CPU fallback for the HIP path.")
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise LmrlError(f"{what or 'lmrl call'} failed (rc={rc}): {lib().lmrl_last_error().decode()}")
+
+
+def ptr(t) -> Optional[int]:
+    """Device/host address of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "lmrl: tensors handed to the C ABI must be contiguous"
+    return t.data_ptr()
+
+
+def stream_ptr(device=None) -> Optional[int]:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu() -> "torch.device":
+    import torch
+    if not torch.cuda.is_available():
+        raise LmrlError("no MI355X visible: the lmrl_gym_amd HIP path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
