@@ -44,7 +44,8 @@ def test_mt19937_streams_bit_exact(dev):
     seeds = [abs(int(c["seed"])) for c in cases] + extra
     n, n_out = len(seeds), 1301
     mt = _mt_buf(n, dev)
-    _lib.check(L.lmrl_mt_seed(_lib.ptr(mt), _lib.ptr(_u64(seeds, dev)), None, n, _lib.stream_ptr()))
+    seeds_d0 = _u64(seeds, dev)
+    _lib.check(L.lmrl_mt_seed(_lib.ptr(mt), _lib.ptr(seeds_d0), None, n, _lib.stream_ptr()))
     out = torch.zeros((n_out, n), dtype=torch.int32, device=dev)
     _lib.check(L.lmrl_mt_stream(_lib.ptr(mt), _lib.ptr(out), n_out, n, _lib.stream_ptr()))
     out = out.cpu().numpy().view(np.uint32)
@@ -56,11 +57,12 @@ def test_mt19937_streams_bit_exact(dev):
         assert out[:, len(cases) + j].tolist() == [r.getrandbits(32) for _ in range(n_out)]
     # masked re-seed leaves the other streams alone; randbelow == random.Random.choice index
     mask = np.zeros(n, dtype=np.uint8); mask[::3] = 1
-    _lib.check(L.lmrl_mt_seed(_lib.ptr(mt), _lib.ptr(_u64(seeds, dev)), _lib.ptr(torch.from_numpy(mask).to(dev)), n, _lib.stream_ptr()))
+    seeds_d, mask_d = _u64(seeds, dev), torch.from_numpy(mask).to(dev)   # keep argument tensors alive across the launch
+    _lib.check(L.lmrl_mt_seed(_lib.ptr(mt), _lib.ptr(seeds_d), _lib.ptr(mask_d), n, _lib.stream_ptr()))
     bounds = [431, 2315, 1, 2, 3, 7, 12971, 100, 25, 24, 431, 17, 5, 2315, 64, 65]
     ob = torch.zeros((len(bounds), n), dtype=torch.int32, device=dev)
-    _lib.check(L.lmrl_mt_randbelow(_lib.ptr(mt), _lib.ptr(torch.tensor(bounds, dtype=torch.int32, device=dev)), _lib.ptr(ob),
-                                   len(bounds), n, _lib.stream_ptr()))
+    bounds_d = torch.tensor(bounds, dtype=torch.int32, device=dev)
+    _lib.check(L.lmrl_mt_randbelow(_lib.ptr(mt), _lib.ptr(bounds_d), _lib.ptr(ob), len(bounds), n, _lib.stream_ptr()))
     ob = ob.cpu().numpy()
     for i, s in enumerate(seeds):
         r = random.Random(s)
@@ -309,7 +311,8 @@ def test_gae_kernel(dev, B, L, gamma, lam):
     sta, lens, values, rewards = _chains(rng, B, L)
     dv = lambda x: torch.from_numpy(x).to(dev)
     adv = torch.full((B, L), 7.0, device=dev); ret = torch.full((B, L), 7.0, device=dev)
-    _lib.check(_lib.lib().lmrl_gae(_lib.ptr(dv(values)), _lib.ptr(dv(rewards)), _lib.ptr(dv(sta.astype(np.uint8))), _lib.ptr(dv(lens)),
+    v_d, r_d, s_d, l_d = dv(values), dv(rewards), dv(sta.astype(np.uint8)), dv(lens)
+    _lib.check(_lib.lib().lmrl_gae(_lib.ptr(v_d), _lib.ptr(r_d), _lib.ptr(s_d), _lib.ptr(l_d),
                                    _lib.ptr(adv), _lib.ptr(ret), B, L, gamma, lam, _lib.stream_ptr()))
     adv, ret = adv.cpu().numpy(), ret.cpu().numpy()
     for b in range(B):
@@ -333,7 +336,8 @@ def test_rtg_kernel(dev, B, L, gamma):
     sta, lens, _, rewards = _chains(rng, B, L)
     dv = lambda x: torch.from_numpy(x).to(dev)
     out = torch.full((B, L), 3.0, device=dev)
-    _lib.check(_lib.lib().lmrl_rtg(_lib.ptr(dv(rewards)), _lib.ptr(dv(sta.astype(np.uint8))), _lib.ptr(dv(lens)), _lib.ptr(out), B, L,
+    r_d, s_d, l_d = dv(rewards), dv(sta.astype(np.uint8)), dv(lens)
+    _lib.check(_lib.lib().lmrl_rtg(_lib.ptr(r_d), _lib.ptr(s_d), _lib.ptr(l_d), _lib.ptr(out), B, L,
                                    gamma, _lib.stream_ptr()))
     out = out.cpu().numpy()
     for b in range(B):
