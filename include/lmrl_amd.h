@@ -155,6 +155,75 @@ int lmrl_whiten_moments(const float *x_d, const uint8_t *mask_d, double *moments
 int lmrl_whiten_apply(const float *x_d, const uint8_t *mask_d, const double *moments_d, float *y_d, size_t n,
                       int shift_mean, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * GPT-2 rollout forward with a persistent per-env KV cache (csrc/gpt2.hip).
+ * Replaces the model side of GPT2PPOPolicy.act / GPT2ValuePolicy.act
+ * (LLM_RL/algorithms/ppo/gpt2/interface.py:507-546, value_rl_base/gpt2/interface.py:281-320), whose
+ * transformer lives in JaxSeq / HF-Flax (third party).
+ *
+ * Engine weight layout (all device pointers, caller-owned):
+ *   wte  bf16 [vocab_padded][d]  (rows >= vocab zero)        wpe  bf16 [n_pos][d]
+ *   per layer, 12 pointers in this order:
+ *     ln1_g f32[d], ln1_b f32[d], w_qkv bf16[3d][d], b_qkv f32[3d], w_proj bf16[d][d], b_proj f32[d],
+ *     ln2_g f32[d], ln2_b f32[d], w_fc bf16[dff][d], b_fc f32[dff], w_fc2 bf16[d][dff], b_fc2 f32[d]
+ *   i.e. every matrix is stored [out][in] (HF Conv1D weights transposed once at load time).
+ * KV cache: bf16 [n_layer][2][B][n_head][tmax][64].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t n_layer, n_head, d_model, d_ff, vocab, vocab_padded, n_pos;
+    float ln_eps;
+} lmrl_gpt2_config;
+
+typedef struct lmrl_gpt2 lmrl_gpt2;
+
+lmrl_gpt2 *lmrl_gpt2_create(const lmrl_gpt2_config *cfg, const void *wte_d, const void *wpe_d, const float *lnf_g_d,
+                            const float *lnf_b_d, const void *const *layer_ptrs /* host array [n_layer*12] */);
+void lmrl_gpt2_destroy(lmrl_gpt2 *m);
+size_t lmrl_gpt2_kv_bytes(const lmrl_gpt2 *m, int b, int tmax);
+size_t lmrl_gpt2_ws_bytes(const lmrl_gpt2 *m, int b, int c);
+/*
+ * Forward B envs x C token slots (C = 1 decode, C = 8 chunked prefill).  Env b contributes cnt_d[b] <= C new
+ * tokens tokens_d[b*C + j] at positions len_d[b] + j; their K/V rows are appended to the cache and len_d[b] is
+ * advanced by cnt_d[b].  last_hidden_d (bf16 [B][d], optional): ln_f of each env's LAST new token (row untouched
+ * when cnt_d[b] == 0).  all_hidden_d (bf16 [B*C][d], optional): ln_f of every row.
+ */
+int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int32_t *tokens_d, const int32_t *cnt_d,
+                      int32_t *len_d, int b, int c, void *last_hidden_d, void *all_hidden_d, void *stream);
+
+/* C[m][n] = A[m][k] . W[n][k]^T + bias[n]; A, W bf16.  epilogue: 0 bf16, 1 gelu_new->bf16, 2 f32 += (residual),
+ * 3 f32, 4 relu->bf16.  Used for the value heads (heads/linear_head.py:112-119, heads/mlp_head.py:139-148). */
+int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda,
+                   int ldc, int n_store, int epilogue, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused LM-head + sampling (csrc/sampler.hip).  Replaces logits[:, -1] -> warpers -> jax.random.categorical in
+ * the reference's generation loop and the ILQL perturbation logits = pi_beta + beta*min(q1,q2)
+ * (LLM_RL/algorithms/value_rl_base/gpt2/generation.py:97-119).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    float temperature;      /* <= 0: greedy (do_sample=False) */
+    int32_t top_k;          /* <= 0: off; needs logits_out_d */
+    uint64_t seed;          /* Philox key */
+    uint32_t step;          /* counter word: one per sampled token position */
+    float steer_strength;   /* added to logit[steer_tok_d[row]] (synthetic workloads only; 0 = off) */
+    float beta;             /* ILQL logit perturbation weight */
+    int32_t pad_token;      /* written for inactive rows */
+} lmrl_sample_params;
+
+size_t lmrl_sample_ws_bytes(int m, int vocab_padded);
+/* hidden_d bf16 [m][d] . wte_d bf16 [vocab_padded][d]^T -> token_d[m] (+ logprob_d[m] under the sampling
+ * distribution).  Optional ILQL operands: q_hidden{1,2}_d bf16 [m][d] (= relu(dense1(h)) of each Q head),
+ * q_w{1,2}_d bf16 [vocab_padded][d] (dense2 kernels, [out][in]), q_b{1,2}_d f32 [vocab_padded].
+ * logits_out_d (optional f32 [m][vocab_padded]) receives the combined (untempered) logits. */
+int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_hidden1_d, const void *q_w1_d,
+                        const float *q_b1_d, const void *q_hidden2_d, const void *q_w2_d, const float *q_b2_d, int m,
+                        int d_model, int vocab, int vocab_padded, const lmrl_sample_params *p, const int32_t *steer_tok_d,
+                        const uint8_t *active_d, int32_t *token_d, float *logprob_d, float *logits_out_d, void *ws_d,
+                        void *stream);
+/* Sample from materialised logits (temperature, top-k) with the same random stream. */
+int lmrl_sample_logits(const float *logits_d, int ld, int m, int vocab, const lmrl_sample_params *p,
+                       const uint8_t *active_d, int32_t *token_d, float *logprob_d, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

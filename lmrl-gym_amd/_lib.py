@@ -39,6 +39,16 @@ _SIGS = {
     "lmrl_rtg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "lmrl_whiten_moments": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lmrl_whiten_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "lmrl_gpt2_create": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lmrl_gpt2_destroy": (None, [c_void_p]),
+    "lmrl_gpt2_kv_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "lmrl_gpt2_ws_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "lmrl_gpt2_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                  c_void_p, c_void_p, c_void_p]),
+    "lmrl_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lmrl_sample_ws_bytes": (c_size_t, [c_int, c_int]),
+    "lmrl_lm_head_sample": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int] + [c_void_p] * 8),
+    "lmrl_sample_logits": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 

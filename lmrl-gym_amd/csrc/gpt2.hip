@@ -1,0 +1,390 @@
+// gpt2.hip — GPT-2 forward for lock-step rollouts on gfx950: persistent per-env KV cache,
+// chunked prefill / single-token decode through the same code path.
+//
+// Replaces, for the rollout hot path, the JaxSeq/HF-Flax GPT-2 forward that the reference reaches
+// through GPT2PPOPolicy.act -> generate_from_str (LLM_RL/algorithms/ppo/gpt2/interface.py:507-546)
+// and GPT2ValuePolicy.act (LLM_RL/algorithms/value_rl_base/gpt2/interface.py:281-320).  The
+// reference re-tokenises and re-prefills the whole left-padded history on every turn; here every
+// env keeps its K/V in HBM across turns and only the NEW tokens of a turn are forwarded.
+//
+// A forward call processes B envs x C token slots ("chunk"): env b contributes cnt[b] <= C new tokens
+// at positions len[b] .. len[b]+cnt[b]-1 (row r = b*C + j).  C = 1 is decode; C = 8 is the per-turn
+// prefill of [action terminator + observation tokens].  Rows j >= cnt[b] are padding (computed, never
+// stored to the cache, never attended to).
+//
+// Data layout in HBM
+//   residual stream x   f32  [B*C][d]
+//   GEMM activations    bf16 [B*C][d | 3d | d_ff]
+//   KV cache            bf16 [layer][2 (K,V)][B][H][Tmax][64]   (one (b,h) stream is contiguous:
+//                       a wave reads 8 rows = 1 KiB per load instruction, 16 B per lane)
+//   weights             bf16 [N][K] ("out x in", K contiguous) so activation and weight fragments are
+//                       both K-major for the MFMA operand loads (gemm_bf16.h)
+#include "../../include/lmrl_amd.h"
+#include "common.h"
+#include "gemm_bf16.h"
+
+namespace lmrl {
+
+struct Gpt2Layer {
+    const float *ln1_g, *ln1_b;
+    const uint16_t *w_qkv; const float *b_qkv;
+    const uint16_t *w_proj; const float *b_proj;
+    const float *ln2_g, *ln2_b;
+    const uint16_t *w_fc; const float *b_fc;
+    const uint16_t *w_fc2; const float *b_fc2;
+};
+
+struct Gpt2Model {
+    lmrl_gpt2_config cfg;
+    const uint16_t *wte, *wpe;
+    const float *lnf_g, *lnf_b;
+    Gpt2Layer *layers;
+};
+
+// ------------------------------------------------------------------------------------------ embedding
+// x[r][:] = wte[token][:] + wpe[pos][:]   (one wave per row, 16 B loads)
+__global__ __launch_bounds__(256) void embed_kernel(const uint16_t *__restrict__ wte, const uint16_t *__restrict__ wpe,
+                                                    const int32_t *__restrict__ tokens, const int32_t *__restrict__ cnt,
+                                                    const int32_t *__restrict__ len, float *__restrict__ x, int B, int C, int d,
+                                                    int vocab, int n_pos) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= B * C) return;
+    const int b = r / C, j = r - b * C;
+    int tok = tokens[r];
+    int pos = len[b] + j;
+    const bool valid = j < cnt[b];
+    if (!valid || tok < 0 || tok >= vocab) tok = 0;
+    if (!valid || pos >= n_pos) pos = 0;
+    const uint16_t *te = wte + (size_t)tok * d, *pe = wpe + (size_t)pos * d;
+    float *xr = x + (size_t)r * d;
+    for (int c = lane * 8; c < d; c += 64 * 8) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(te + c), p = *reinterpret_cast<const uint4 *>(pe + c);
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, pw[4] = {p.x, p.y, p.z, p.w};
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            o[2 * k] = bf16_to_f32((uint16_t)(aw[k] & 0xffff)) + bf16_to_f32((uint16_t)(pw[k] & 0xffff));
+            o[2 * k + 1] = bf16_to_f32((uint16_t)(aw[k] >> 16)) + bf16_to_f32((uint16_t)(pw[k] >> 16));
+        }
+        *reinterpret_cast<f32x4 *>(xr + c) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4 *>(xr + c + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    }
+}
+
+// ------------------------------------------------------------------------------------------ layernorm
+// y[r][:] (bf16) = (x[r][:] - mean) * rsqrt(var + eps) * g + b ; one wave per row; d <= 64*4*MAXV.
+// `rows_idx` (optional) gathers source rows (used for the final LN over each env's last token only).
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ gam,
+                                                        const float *__restrict__ bet, uint16_t *__restrict__ y,
+                                                        const int32_t *__restrict__ rows_idx, int rows, int d, float eps) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    int src = r;
+    if (rows_idx) {
+        src = rows_idx[r];
+        if (src < 0) return;   // env contributed no token
+    }
+    const float *xr = x + (size_t)src * d;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int c = (k * 64 + lane) * 4;
+        v[k] = c < d ? *reinterpret_cast<const f32x4 *>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const float t = v[k][e] - mean; q += t * t; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)d + eps);
+    uint16_t *yr = y + (size_t)r * d;
+#pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < d) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gam + c), b4 = *reinterpret_cast<const f32x4 *>(bet + c);
+            uint16_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = f32_to_bf16_rn((v[k][e] - mean) * rstd * g4[e] + b4[e]);
+            uint2 pk;
+            pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+            pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+            *reinterpret_cast<uint2 *>(yr + c) = pk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ attention
+// One wave per (env b, head h).  Keys/values stream from the KV cache (positions < len[b]) and from this
+// chunk's own qkv rows (positions >= len[b]); the new K/V rows are appended to the cache on the way.
+// Lane (rr = lane>>3, cc = lane&7) holds 8 head-dims (16 B) of row t0+rr: a load instruction covers
+// 8 rows x 128 B contiguous.  Scores are reduced over the 8 lanes of a row with 3 xor-shuffles, the
+// online-softmax state (m, l) is wave-uniform per query, and the P.V partial sums are reduced over the
+// 8 row-groups at the end (xor 8/16/32).
+template <int C>
+__global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restrict__ qkv,   // [B*C][3d]
+                                                        uint16_t *__restrict__ kcache, uint16_t *__restrict__ vcache,
+                                                        const int32_t *__restrict__ cnt, const int32_t *__restrict__ len,
+                                                        uint16_t *__restrict__ out,          // [B*C][d]
+                                                        int B, int H, int Tmax, int d) {
+    const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wave_id >= B * H) return;
+    const int b = wave_id / H, h = wave_id - b * H;
+    const int n_new = min(cnt[b], C);
+    if (n_new <= 0) return;
+    const int L0 = len[b];
+    const int T = L0 + n_new;
+    const int rr = lane >> 3, cc = lane & 7;
+    const size_t ld = (size_t)3 * d;
+    uint16_t *kc = kcache + ((size_t)b * H + h) * Tmax * 64;
+    uint16_t *vc = vcache + ((size_t)b * H + h) * Tmax * 64;
+    const uint16_t *qbase = qkv + (size_t)b * C * ld + (size_t)h * 64;
+
+    // append this chunk's K/V rows to the cache (row j -> position L0 + j)
+    for (int j = rr; j < n_new; j += 8) {
+        if (L0 + j < Tmax) {
+            const uint4 kv = *reinterpret_cast<const uint4 *>(qbase + (size_t)j * ld + d + cc * 8);
+            const uint4 vv = *reinterpret_cast<const uint4 *>(qbase + (size_t)j * ld + 2 * d + cc * 8);
+            *reinterpret_cast<uint4 *>(kc + (size_t)(L0 + j) * 64 + cc * 8) = kv;
+            *reinterpret_cast<uint4 *>(vc + (size_t)(L0 + j) * 64 + cc * 8) = vv;
+        }
+    }
+
+    // this lane's 8-dim slice of every query, pre-scaled by 1/sqrt(64)
+    float q[C][8];
+#pragma unroll
+    for (int j = 0; j < C; j++) {
+        uint4 qv = uint4{0, 0, 0, 0};
+        if (j < n_new) qv = *reinterpret_cast<const uint4 *>(qbase + (size_t)j * ld + cc * 8);
+        const uint32_t w[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            q[j][2 * k] = bf16_to_f32((uint16_t)(w[k] & 0xffff)) * 0.125f;
+            q[j][2 * k + 1] = bf16_to_f32((uint16_t)(w[k] >> 16)) * 0.125f;
+        }
+    }
+    float m[C], l[C], o[C][8];
+#pragma unroll
+    for (int j = 0; j < C; j++) {
+        m[j] = -1e30f; l[j] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[j][e] = 0.f;
+    }
+
+    for (int t0 = 0; t0 < T; t0 += 8) {
+        const int t = t0 + rr;
+        const bool in_range = t < T;
+        const int tc = in_range ? t : T - 1;
+        // position < L0: cache ; otherwise this chunk's own row
+        const uint16_t *kp = tc < L0 ? kc + (size_t)tc * 64 + cc * 8 : qbase + (size_t)(tc - L0) * ld + d + cc * 8;
+        const uint16_t *vp = tc < L0 ? vc + (size_t)tc * 64 + cc * 8 : qbase + (size_t)(tc - L0) * ld + 2 * d + cc * 8;
+        const uint4 kraw = *reinterpret_cast<const uint4 *>(kp);
+        const uint4 vraw = *reinterpret_cast<const uint4 *>(vp);
+        float kf[8], vf[8];
+        {
+            const uint32_t kw[4] = {kraw.x, kraw.y, kraw.z, kraw.w}, vw[4] = {vraw.x, vraw.y, vraw.z, vraw.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                kf[2 * k] = bf16_to_f32((uint16_t)(kw[k] & 0xffff)); kf[2 * k + 1] = bf16_to_f32((uint16_t)(kw[k] >> 16));
+                vf[2 * k] = bf16_to_f32((uint16_t)(vw[k] & 0xffff)); vf[2 * k + 1] = bf16_to_f32((uint16_t)(vw[k] >> 16));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < C; j++) {
+            if (j >= n_new) continue;   // wave-uniform
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) s = fmaf(q[j][e], kf[e], s);
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            const bool ok = in_range && t <= L0 + j;   // causal: query j sits at position L0 + j
+            s = ok ? s : -1e30f;
+            float bm = s;
+            bm = fmaxf(bm, __shfl_xor(bm, 8)); bm = fmaxf(bm, __shfl_xor(bm, 16)); bm = fmaxf(bm, __shfl_xor(bm, 32));
+            const float m_new = fmaxf(m[j], bm);
+            const float alpha = __expf(m[j] - m_new);
+            const float p = ok ? __expf(s - m_new) : 0.f;
+            l[j] = l[j] * alpha + p;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[j][e] = fmaf(p, vf[e], o[j][e] * alpha);
+            m[j] = m_new;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < C; j++) {
+        if (j >= n_new) continue;
+        float lt = l[j];
+        lt += __shfl_xor(lt, 8); lt += __shfl_xor(lt, 16); lt += __shfl_xor(lt, 32);
+        const float inv = 1.f / lt;
+        float r8[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float a = o[j][e];
+            a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+            r8[e] = a * inv;
+        }
+        if (rr == 0) {
+            uint4 pk;
+            pk.x = (uint32_t)f32_to_bf16_rn(r8[0]) | ((uint32_t)f32_to_bf16_rn(r8[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16_rn(r8[2]) | ((uint32_t)f32_to_bf16_rn(r8[3]) << 16);
+            pk.z = (uint32_t)f32_to_bf16_rn(r8[4]) | ((uint32_t)f32_to_bf16_rn(r8[5]) << 16);
+            pk.w = (uint32_t)f32_to_bf16_rn(r8[6]) | ((uint32_t)f32_to_bf16_rn(r8[7]) << 16);
+            *reinterpret_cast<uint4 *>(out + ((size_t)b * C + j) * d + (size_t)h * 64 + cc * 8) = pk;
+        }
+    }
+}
+
+// rows_idx[b] = row of env b's last new token (or -1), then len[b] += cnt[b]
+__global__ void advance_kernel(const int32_t *cnt, int32_t *len, int32_t *rows_idx, int B, int C) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int n = min(cnt[b], C);
+    rows_idx[b] = n > 0 ? b * C + n - 1 : -1;
+    if (n > 0) len[b] += n;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Gpt2Ws {
+    float *x; uint16_t *h, *qkv, *att, *ff; int32_t *rows_idx;
+    static size_t bytes(const lmrl_gpt2_config &c, size_t M, size_t B) {
+        return align256(M * c.d_model * 4) + align256(M * c.d_model * 2) + align256(M * 3 * c.d_model * 2) +
+               align256(M * c.d_model * 2) + align256(M * c.d_ff * 2) + align256(B * 4);
+    }
+    void carve(void *ws, const lmrl_gpt2_config &c, size_t M, size_t B) {
+        char *p = (char *)ws;
+        x = (float *)p; p += align256(M * c.d_model * 4);
+        h = (uint16_t *)p; p += align256(M * c.d_model * 2);
+        qkv = (uint16_t *)p; p += align256(M * 3 * c.d_model * 2);
+        att = (uint16_t *)p; p += align256(M * c.d_model * 2);
+        ff = (uint16_t *)p; p += align256(M * c.d_ff * 2);
+        rows_idx = (int32_t *)p;
+        (void)B;
+    }
+};
+
+}  // namespace lmrl
+
+using namespace lmrl;
+
+struct lmrl_gpt2 : public Gpt2Model {};
+
+extern "C" {
+
+lmrl_gpt2 *lmrl_gpt2_create(const lmrl_gpt2_config *cfg, const void *wte, const void *wpe, const float *lnf_g,
+                            const float *lnf_b, const void *const *layer_ptrs) {
+    if (!cfg || !wte || !wpe || !lnf_g || !lnf_b || !layer_ptrs) { set_error("lmrl_gpt2_create: null pointer"); return nullptr; }
+    if (cfg->d_model != cfg->n_head * 64) { set_error("lmrl_gpt2_create: head dim must be 64"); return nullptr; }
+    if (cfg->d_model % 128 || cfg->d_ff % 128 || cfg->vocab_padded % 128 || cfg->d_model > 64 * 4 * 8) {
+        set_error("lmrl_gpt2_create: d_model, d_ff, vocab_padded must be multiples of 128 (d_model <= 2048)");
+        return nullptr;
+    }
+    lmrl_gpt2 *m = new lmrl_gpt2();
+    m->cfg = *cfg;
+    m->wte = (const uint16_t *)wte; m->wpe = (const uint16_t *)wpe; m->lnf_g = lnf_g; m->lnf_b = lnf_b;
+    m->layers = new Gpt2Layer[cfg->n_layer];
+    for (int l = 0; l < cfg->n_layer; l++) {
+        const void *const *p = layer_ptrs + (size_t)l * 12;
+        for (int k = 0; k < 12; k++)
+            if (!p[k]) { set_error("lmrl_gpt2_create: layer %d pointer %d is null", l, k); delete[] m->layers; delete m; return nullptr; }
+        Gpt2Layer &L = m->layers[l];
+        L.ln1_g = (const float *)p[0]; L.ln1_b = (const float *)p[1];
+        L.w_qkv = (const uint16_t *)p[2]; L.b_qkv = (const float *)p[3];
+        L.w_proj = (const uint16_t *)p[4]; L.b_proj = (const float *)p[5];
+        L.ln2_g = (const float *)p[6]; L.ln2_b = (const float *)p[7];
+        L.w_fc = (const uint16_t *)p[8]; L.b_fc = (const float *)p[9];
+        L.w_fc2 = (const uint16_t *)p[10]; L.b_fc2 = (const float *)p[11];
+    }
+    return m;
+}
+
+void lmrl_gpt2_destroy(lmrl_gpt2 *m) {
+    if (!m) return;
+    delete[] m->layers;
+    delete m;
+}
+
+size_t lmrl_gpt2_kv_bytes(const lmrl_gpt2 *m, int b, int tmax) {
+    return (size_t)m->cfg.n_layer * 2 * b * m->cfg.n_head * tmax * 64 * sizeof(uint16_t);
+}
+
+size_t lmrl_gpt2_ws_bytes(const lmrl_gpt2 *m, int b, int c) { return Gpt2Ws::bytes(m->cfg, (size_t)b * c, b); }
+
+int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int32_t *tokens_d, const int32_t *cnt_d,
+                      int32_t *len_d, int b, int c, void *last_hidden_d, void *all_hidden_d, void *stream) {
+    LMRL_REQUIRE(m && kv_d && ws_d && tokens_d && cnt_d && len_d && b > 0, "lmrl_gpt2_forward: bad argument");
+    LMRL_REQUIRE(c == 1 || c == 8, "lmrl_gpt2_forward: chunk width must be 1 or 8");
+    const lmrl_gpt2_config &cf = m->cfg;
+    hipStream_t s = as_stream(stream);
+    const int M = b * c, d = cf.d_model;
+    Gpt2Ws w; w.carve(ws_d, cf, M, b);
+    const size_t kv_layer = (size_t)b * cf.n_head * tmax * 64;
+
+    hipLaunchKernelGGL(embed_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, s, m->wte, m->wpe, tokens_d, cnt_d, len_d, w.x, b, c, d,
+                       cf.vocab, cf.n_pos);
+    LMRL_CHECK_LAUNCH();
+    auto ln = [&](const float *g, const float *be, uint16_t *y, const int32_t *idx, int rows) {
+        if (d <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w.x, g, be, y, idx, rows, d, cf.ln_eps);
+        else hipLaunchKernelGGL(layernorm_kernel<8>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w.x, g, be, y, idx, rows, d, cf.ln_eps);
+    };
+    for (int l = 0; l < cf.n_layer; l++) {
+        const Gpt2Layer &L = m->layers[l];
+        uint16_t *kc = (uint16_t *)kv_d + (size_t)(2 * l) * kv_layer, *vc = kc + kv_layer;
+        ln(L.ln1_g, L.ln1_b, w.h, nullptr, M);
+        LMRL_CHECK_LAUNCH();
+        GemmArgs g{w.h, L.w_qkv, L.b_qkv, w.qkv, M, 3 * d, d, d, 3 * d, 3 * d};
+        LMRL_CHECK_HIP(gemm_launch<EPI_BF16>(g, s));
+        if (c == 1) hipLaunchKernelGGL(attention_kernel<1>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
+        else hipLaunchKernelGGL(attention_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
+        LMRL_CHECK_LAUNCH();
+        GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d};
+        LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(gp, s));
+        ln(L.ln2_g, L.ln2_b, w.h, nullptr, M);
+        LMRL_CHECK_LAUNCH();
+        GemmArgs gf{w.h, L.w_fc, L.b_fc, w.ff, M, cf.d_ff, d, d, cf.d_ff, cf.d_ff};
+        LMRL_CHECK_HIP(gemm_launch<EPI_GELU_BF16>(gf, s));
+        GemmArgs g2{w.ff, L.w_fc2, L.b_fc2, w.x, M, d, cf.d_ff, cf.d_ff, d, d};
+        LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(g2, s));
+    }
+    hipLaunchKernelGGL(advance_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, s, cnt_d, len_d, w.rows_idx, b, c);
+    LMRL_CHECK_LAUNCH();
+    if (last_hidden_d) {
+        ln(m->lnf_g, m->lnf_b, (uint16_t *)last_hidden_d, w.rows_idx, b);
+        LMRL_CHECK_LAUNCH();
+    }
+    if (all_hidden_d) {
+        ln(m->lnf_g, m->lnf_b, (uint16_t *)all_hidden_d, nullptr, M);
+        LMRL_CHECK_LAUNCH();
+    }
+    return LMRL_OK;
+}
+
+// Plain bf16 GEMM entry (heads, LM-head logits): C = A.W^T + bias with a selectable epilogue.
+int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda,
+                   int ldc, int n_store, int epilogue, void *stream) {
+    LMRL_REQUIRE(a_d && w_d && c_d && m > 0 && n > 0 && k > 0, "lmrl_gemm_bf16: bad argument");
+    LMRL_REQUIRE(n % 64 == 0 && k % 64 == 0 && lda % 8 == 0 && ldc % 4 == 0, "lmrl_gemm_bf16: n, k must be multiples of 64");
+    GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, bias_d, c_d, m, n, k, lda, ldc, n_store > 0 ? n_store : n};
+    hipStream_t s = as_stream(stream);
+    switch (epilogue) {
+        case EPI_BF16: LMRL_CHECK_HIP(gemm_launch<EPI_BF16>(g, s)); break;
+        case EPI_GELU_BF16: LMRL_CHECK_HIP(gemm_launch<EPI_GELU_BF16>(g, s)); break;
+        case EPI_RESID_F32: LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(g, s)); break;
+        case EPI_F32: LMRL_CHECK_HIP(gemm_launch<EPI_F32>(g, s)); break;
+        case EPI_RELU_BF16: LMRL_CHECK_HIP(gemm_launch<EPI_RELU_BF16>(g, s)); break;
+        default: LMRL_REQUIRE(false, "lmrl_gemm_bf16: unknown epilogue");
+    }
+    return LMRL_OK;
+}
+}

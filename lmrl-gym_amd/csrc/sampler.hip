@@ -1,0 +1,408 @@
+// sampler.hip — fused LM-head GEMM + token sampling for gfx950.
+//
+// Replaces the per-token sampling step of the reference's generation loop (HF-Flax `_sample` reached via
+// GPT2PPOPolicy.act, LLM_RL/algorithms/ppo/gpt2/interface.py:527-535): logits[:, -1] -> temperature ->
+// (top-k) -> jax.random.categorical, and the ILQL variant whose logits are
+//     pi_beta_logits + beta * min(q1_logits, q2_logits)
+// (LLM_RL/algorithms/value_rl_base/gpt2/generation.py:97-119).
+//
+// jax.random.categorical(logits) IS argmax(logits + Gumbel noise), so sampling needs no normalisation:
+// the LM-head GEMM tile epilogue draws the noise (Philox4x32-10, counter = (row, column/4, step)), keeps a
+// per-row running (max, sum-exp, best perturbed score, its column, its logit) and only ~10 floats per
+// (row, 128-column tile) ever reach HBM instead of the [B, 50257] fp32 logits (206 MB / token at B=1024).
+// A second tiny kernel merges the per-tile partials into (token, log-prob).
+//
+// The random stream is OUR OWN documented counter scheme, not JAX threefry: the reference's key schedule
+// lives in un-vendored third-party code so bit-matching its samples is "parity unpinned";
+// greedy decoding (temperature == 0) is deterministic and is what parity tests pin.
+#include "../../include/lmrl_amd.h"
+#include "common.h"
+#include "gemm_bf16.h"
+
+namespace lmrl {
+
+// ---- Philox4x32-10 (Salmon et al. 2011), the counter-based generator also used by cuRAND/rocRAND ----
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                       uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// u in (0,1): (x >> 8 + 0.5) * 2^-24 ; Gumbel(0,1) = -log(-log u)
+__device__ __forceinline__ float gumbel_from_bits(uint32_t x) {
+    const float u = ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-08f;
+    return -__logf(-__logf(u));
+}
+
+struct SampleParams {
+    float inv_temperature;   // 1/T ; greedy when `greedy` != 0
+    int greedy;
+    uint32_t seed_lo, seed_hi, step;
+    float steer_strength;    // added to the logit of steer_tok[row] (synthetic-workload hook, see bench.py)
+    float beta;              // ILQL: logits = pi + beta*min(q1,q2) ; 0 with no q operands
+    int vocab;               // logical vocabulary (columns >= vocab are padding -> -inf)
+};
+
+constexpr int kPartialFloats = 6;   // {max, sumexp, best_score, best_col, best_z, pad}
+
+// LM head:   z[m][n] = (h[m] . wte[n]) * invT   (+ ILQL perturbation, + steer)
+// One 128 x 128 tile per workgroup, same staging/MFMA structure as gemm_bf16_kernel, up to three GEMM passes
+// over the same output tile (pi, q1, q2) combined in registers before the sampling epilogue.
+template <int NOPS>
+__global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__restrict__ A0, const uint16_t *__restrict__ W0,
+                                                             const uint16_t *__restrict__ A1, const uint16_t *__restrict__ W1,
+                                                             const float *__restrict__ bias1,
+                                                             const uint16_t *__restrict__ A2, const uint16_t *__restrict__ W2,
+                                                             const float *__restrict__ bias2,
+                                                             const int32_t *__restrict__ steer_tok,
+                                                             float *__restrict__ partials,   // [M][2*tiles_n][kPartialFloats]
+                                                             float *__restrict__ logits_out, // optional [M][ldo] f32
+                                                             int M, int N, int K, int ldo, SampleParams sp) {
+    constexpr int BM = 128, BN = 128, BK = 64, FM = 4, FN = 4, CH = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *sA = smem;
+    char *sW = smem + 2 * BM * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int tiles_n = N / BN;
+    const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int nk = K / BK;
+
+    f32x4 z[FN][FM];     // combined logits
+    f32x4 qmin[FN][FM];  // running min(q1, q2) for the ILQL form
+
+#pragma unroll
+    for (int op = 0; op < NOPS; op++) {
+        const uint16_t *A = op == 0 ? A0 : (op == 1 ? A1 : A2);
+        const uint16_t *W = op == 0 ? W0 : (op == 1 ? W1 : W2);
+        f32x4 acc[FN][FM];
+#pragma unroll
+        for (int i = 0; i < FN; i++)
+#pragma unroll
+            for (int j = 0; j < FM; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 ra[CH], rw[CH];
+#define LMRL_LM_LOAD_TILES(KT)                                                                               \
+    do {                                                                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < CH; i_++) {                                                  \
+            const int id_ = tid + i_ * 256, row_ = id_ >> 3, c_ = id_ & 7;                                   \
+            int m_ = m0 + row_;                                                                              \
+            m_ = m_ < M ? m_ : M - 1;                                                                        \
+            ra[i_] = *reinterpret_cast<const u32x4 *>(A + (size_t)m_ * K + (size_t)(KT) * BK + c_ * 8);      \
+            rw[i_] = *reinterpret_cast<const u32x4 *>(W + (size_t)(n0 + row_) * K + (size_t)(KT) * BK + c_ * 8); \
+        }                                                                                                    \
+    } while (0)
+#define LMRL_LM_STORE_TILES(BUF)                                                                             \
+    do {                                                                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < CH; i_++) {                                                  \
+            const int id_ = tid + i_ * 256, row_ = id_ >> 3, c_ = id_ & 7;                                   \
+            *reinterpret_cast<u32x4 *>(sA + (BUF) * BM * 128 + row_ * 128 + ((c_ ^ (row_ & 7)) << 4)) = ra[i_]; \
+            *reinterpret_cast<u32x4 *>(sW + (BUF) * BN * 128 + row_ * 128 + ((c_ ^ (row_ & 7)) << 4)) = rw[i_]; \
+        }                                                                                                    \
+    } while (0)
+        __syncthreads();   // previous operand's last reads are done before buffer 0 is overwritten
+        LMRL_LM_LOAD_TILES(0);
+        LMRL_LM_STORE_TILES(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt++) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) LMRL_LM_LOAD_TILES(kt + 1);
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                bf16x8 fw[FN], fa[FM];
+                const int c = kk * 4 + lq;
+#pragma unroll
+                for (int i = 0; i < FN; i++) {
+                    const int row = wn * 64 + i * 16 + lr;
+                    fw[i] = *reinterpret_cast<const bf16x8 *>(sW + buf * BN * 128 + row * 128 + ((c ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < FM; j++) {
+                    const int row = wm * 64 + j * 16 + lr;
+                    fa[j] = *reinterpret_cast<const bf16x8 *>(sA + buf * BM * 128 + row * 128 + ((c ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < FN; i++)
+#pragma unroll
+                    for (int j = 0; j < FM; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < nk) LMRL_LM_STORE_TILES(buf ^ 1);
+            __syncthreads();
+        }
+        // fold this operand in
+#pragma unroll
+        for (int i = 0; i < FN; i++) {
+            const int n = n0 + wn * 64 + i * 16 + lq * 4;
+            f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (op == 1 && bias1) b4 = *reinterpret_cast<const f32x4 *>(bias1 + n);
+            if (op == 2 && bias2) b4 = *reinterpret_cast<const f32x4 *>(bias2 + n);
+#pragma unroll
+            for (int j = 0; j < FM; j++) {
+                if (op == 0) z[i][j] = acc[i][j];
+                else if (op == 1) qmin[i][j] = acc[i][j] + b4;
+                else {
+                    const f32x4 q2 = acc[i][j] + b4;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) qmin[i][j][r] = fminf(qmin[i][j][r], q2[r]);
+                }
+            }
+        }
+    }
+
+    // ---- sampling epilogue
+#pragma unroll
+    for (int j = 0; j < FM; j++) {
+        const int m = m0 + wm * 64 + j * 16 + lr;
+        const int st = (steer_tok && m < M) ? steer_tok[m] : -1;
+        float pmax = -INFINITY, psum = 0.f, best = -INFINITY, best_z = 0.f;
+        int best_col = 0;
+#pragma unroll
+        for (int i = 0; i < FN; i++) {
+            const int n = n0 + wn * 64 + i * 16 + lq * 4;
+            uint32_t rnd[4] = {0, 0, 0, 0};
+            if (!sp.greedy) philox4x32_10((uint32_t)m, (uint32_t)(n >> 2), sp.step, 0u, sp.seed_lo, sp.seed_hi, rnd);
+            float zz[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = z[i][j][r];
+                if (NOPS > 1) v += sp.beta * qmin[i][j][r];   // generation.py:112-117
+                if (n + r == st) v += sp.steer_strength;
+                zz[r] = v;
+            }
+            if (logits_out && m < M) *reinterpret_cast<f32x4 *>(logits_out + (size_t)m * ldo + n) = f32x4{zz[0], zz[1], zz[2], zz[3]};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const bool colok = (n + r) < sp.vocab;
+                const float v = colok ? zz[r] * sp.inv_temperature : -INFINITY;
+                const float sc = sp.greedy ? v : v + gumbel_from_bits(rnd[r]);
+                if (colok && sc > best) { best = sc; best_col = n + r; best_z = v; }
+                if (colok) {
+                    const float nm = fmaxf(pmax, v);
+                    psum = psum * __expf(pmax - nm) + __expf(v - nm);
+                    pmax = nm;
+                }
+            }
+        }
+        // merge the 4 lane groups (lq) that hold the same row: xor 16, 32
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float om = __shfl_xor(pmax, o), os = __shfl_xor(psum, o);
+            const float ob = __shfl_xor(best, o), oz = __shfl_xor(best_z, o);
+            const int oc = __shfl_xor(best_col, o);
+            const float nm = fmaxf(pmax, om);
+            const float e1 = (pmax == -INFINITY) ? 0.f : __expf(pmax - nm), e2 = (om == -INFINITY) ? 0.f : __expf(om - nm);
+            psum = psum * e1 + os * e2;
+            pmax = nm;
+            if (ob > best || (ob == best && oc < best_col)) { best = ob; best_col = oc; best_z = oz; }
+        }
+        if (lq == 0 && m < M) {
+            float *p = partials + ((size_t)m * (2 * tiles_n) + (size_t)tile_n * 2 + wn) * kPartialFloats;
+            p[0] = pmax; p[1] = psum; p[2] = best; p[3] = __int_as_float(best_col); p[4] = best_z; p[5] = 0.f;
+        }
+    }
+}
+
+// merge partials of one row: token = argmax best_score ; logprob = best_z - logsumexp(z)
+__global__ __launch_bounds__(256) void sample_reduce_kernel(const float *__restrict__ partials, const uint8_t *__restrict__ active,
+                                                            int32_t *__restrict__ token, float *__restrict__ logprob,
+                                                            int M, int np, int pad_token) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= M) return;
+    if (active && !active[m]) {
+        if (lane == 0) { token[m] = pad_token; if (logprob) logprob[m] = 0.f; }
+        return;
+    }
+    float pmax = -INFINITY, psum = 0.f, best = -INFINITY, best_z = 0.f;
+    int best_col = 0x7fffffff;
+    for (int t = lane; t < np; t += 64) {
+        const float *p = partials + ((size_t)m * np + t) * kPartialFloats;
+        const float om = p[0], os = p[1], ob = p[2], oz = p[4];
+        const int oc = __float_as_int(p[3]);
+        const float nm = fmaxf(pmax, om);
+        const float e1 = (pmax == -INFINITY) ? 0.f : __expf(pmax - nm), e2 = (om == -INFINITY) ? 0.f : __expf(om - nm);
+        psum = psum * e1 + os * e2; pmax = nm;
+        if (ob > best || (ob == best && oc < best_col)) { best = ob; best_col = oc; best_z = oz; }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float om = __shfl_xor(pmax, o), os = __shfl_xor(psum, o), ob = __shfl_xor(best, o), oz = __shfl_xor(best_z, o);
+        const int oc = __shfl_xor(best_col, o);
+        const float nm = fmaxf(pmax, om);
+        const float e1 = (pmax == -INFINITY) ? 0.f : __expf(pmax - nm), e2 = (om == -INFINITY) ? 0.f : __expf(om - nm);
+        psum = psum * e1 + os * e2; pmax = nm;
+        if (ob > best || (ob == best && oc < best_col)) { best = ob; best_col = oc; best_z = oz; }
+    }
+    if (lane == 0) {
+        token[m] = best_col;
+        if (logprob) logprob[m] = best_z - (pmax + __logf(psum));
+    }
+}
+
+// ---- top-k sampling over materialised logits: one workgroup per row.
+// Radix select (4 passes of 8 bits over the order-preserving uint key) finds the k-th largest value; tokens with
+// logit >= that value are kept (ties kept, as HF's TopKLogitsWarper `scores < kth` removal rule) and sampled with
+// the same Philox/Gumbel stream as the fused path.
+__device__ __forceinline__ uint32_t f32_order_key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void topk_sample_kernel(const float *__restrict__ logits, int ld, int vocab, int top_k,
+                                                          const uint8_t *__restrict__ active, int32_t *__restrict__ token,
+                                                          float *__restrict__ logprob, SampleParams sp, int pad_token) {
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (active && !active[m]) {
+        if (tid == 0) { token[m] = pad_token; if (logprob) logprob[m] = 0.f; }
+        return;
+    }
+    const float *row = logits + (size_t)m * ld;
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sel_prefix, sel_remaining;
+    __shared__ float red_f[4][4];
+    __shared__ int red_i[4];
+    uint32_t prefix = 0, remaining = (uint32_t)(top_k < vocab ? top_k : vocab);
+    if (top_k <= 0) remaining = (uint32_t)vocab;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        for (int n = tid; n < vocab; n += 256) {
+            const uint32_t key = f32_order_key(row[n]);
+            const bool match = pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8));
+            if (match) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t rem = remaining, b = 255;
+            for (;; b--) {
+                if (hist[b] >= rem || b == 0) break;
+                rem -= hist[b];
+            }
+            sel_prefix = prefix | (b << shift);
+            sel_remaining = rem;
+        }
+        __syncthreads();
+        prefix = sel_prefix; remaining = sel_remaining;
+        __syncthreads();
+    }
+    const uint32_t thr_key = prefix;   // key of the k-th largest logit
+    float pmax = -INFINITY, psum = 0.f, best = -INFINITY, best_z = 0.f;
+    int best_col = 0x7fffffff;
+    for (int n4 = tid * 4; n4 < vocab; n4 += 256 * 4) {
+        uint32_t rnd[4] = {0, 0, 0, 0};
+        if (!sp.greedy) philox4x32_10((uint32_t)m, (uint32_t)(n4 >> 2), sp.step, 0u, sp.seed_lo, sp.seed_hi, rnd);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int n = n4 + r;
+            if (n >= vocab) continue;
+            const float raw = row[n];
+            if (f32_order_key(raw) < thr_key) continue;
+            const float v = raw * sp.inv_temperature;
+            const float sc = sp.greedy ? v : v + gumbel_from_bits(rnd[r]);
+            if (sc > best || (sc == best && n < best_col)) { best = sc; best_col = n; best_z = v; }
+            const float nm = fmaxf(pmax, v);
+            psum = psum * ((pmax == -INFINITY) ? 0.f : __expf(pmax - nm)) + __expf(v - nm);
+            pmax = nm;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float om = __shfl_xor(pmax, o), os = __shfl_xor(psum, o), ob = __shfl_xor(best, o), oz = __shfl_xor(best_z, o);
+        const int oc = __shfl_xor(best_col, o);
+        const float nm = fmaxf(pmax, om);
+        const float e1 = (pmax == -INFINITY) ? 0.f : __expf(pmax - nm), e2 = (om == -INFINITY) ? 0.f : __expf(om - nm);
+        psum = psum * e1 + os * e2; pmax = nm;
+        if (ob > best || (ob == best && oc < best_col)) { best = ob; best_col = oc; best_z = oz; }
+    }
+    if (lane == 0) { red_f[wave][0] = pmax; red_f[wave][1] = psum; red_f[wave][2] = best; red_f[wave][3] = best_z; red_i[wave] = best_col; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++) {
+            const float om = red_f[w][0], os = red_f[w][1], ob = red_f[w][2], oz = red_f[w][3];
+            const int oc = red_i[w];
+            const float nm = fmaxf(pmax, om);
+            const float e1 = (pmax == -INFINITY) ? 0.f : __expf(pmax - nm), e2 = (om == -INFINITY) ? 0.f : __expf(om - nm);
+            psum = psum * e1 + os * e2; pmax = nm;
+            if (ob > best || (ob == best && oc < best_col)) { best = ob; best_col = oc; best_z = oz; }
+        }
+        token[m] = best_col;
+        if (logprob) logprob[m] = best_z - (pmax + __logf(psum));
+    }
+}
+
+}  // namespace lmrl
+
+using namespace lmrl;
+
+extern "C" {
+
+size_t lmrl_sample_ws_bytes(int m, int vocab_padded) {
+    return (size_t)m * (size_t)(2 * (vocab_padded / 128)) * kPartialFloats * sizeof(float);
+}
+
+int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_hidden1_d, const void *q_w1_d,
+                        const float *q_b1_d, const void *q_hidden2_d, const void *q_w2_d, const float *q_b2_d, int m,
+                        int d_model, int vocab, int vocab_padded, const lmrl_sample_params *p, const int32_t *steer_tok_d,
+                        const uint8_t *active_d, int32_t *token_d, float *logprob_d, float *logits_out_d, void *ws_d,
+                        void *stream) {
+    LMRL_REQUIRE(hidden_d && wte_d && p && token_d && ws_d && m > 0, "lmrl_lm_head_sample: null pointer");
+    LMRL_REQUIRE(vocab_padded % 128 == 0 && d_model % 64 == 0 && vocab <= vocab_padded, "lmrl_lm_head_sample: bad shape");
+    SampleParams sp;
+    sp.greedy = (p->temperature <= 0.f) ? 1 : 0;
+    sp.inv_temperature = sp.greedy ? 1.f : 1.f / p->temperature;
+    sp.seed_lo = (uint32_t)p->seed; sp.seed_hi = (uint32_t)(p->seed >> 32); sp.step = p->step;
+    sp.steer_strength = p->steer_strength; sp.beta = p->beta; sp.vocab = vocab;
+    hipStream_t s = as_stream(stream);
+    const int tiles = ((m + 127) / 128) * (vocab_padded / 128);
+    const size_t shmem = 2 * 256 * 128;
+    const int nops = (q_hidden1_d && q_w1_d) ? ((q_hidden2_d && q_w2_d) ? 3 : 2) : 1;
+    float *partials = (float *)ws_d;
+    const uint16_t *A0 = (const uint16_t *)hidden_d, *W0 = (const uint16_t *)wte_d;
+    const uint16_t *A1 = (const uint16_t *)q_hidden1_d, *W1 = (const uint16_t *)q_w1_d;
+    const uint16_t *A2 = (const uint16_t *)q_hidden2_d, *W2 = (const uint16_t *)q_w2_d;
+    if (nops == 1)
+        hipLaunchKernelGGL(lm_head_sample_kernel<1>, dim3(tiles), dim3(256), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
+                           steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp);
+    else if (nops == 2)
+        hipLaunchKernelGGL(lm_head_sample_kernel<2>, dim3(tiles), dim3(256), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
+                           steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp);
+    else
+        hipLaunchKernelGGL(lm_head_sample_kernel<3>, dim3(tiles), dim3(256), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
+                           steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp);
+    LMRL_CHECK_LAUNCH();
+    if (p->top_k > 0 && p->top_k < vocab) {
+        LMRL_REQUIRE(logits_out_d, "lmrl_lm_head_sample: top_k sampling needs logits_out_d (materialised logits)");
+        hipLaunchKernelGGL(topk_sample_kernel, dim3(m), dim3(256), 0, s, logits_out_d, vocab_padded, vocab, p->top_k, active_d,
+                           token_d, logprob_d, sp, p->pad_token);
+    } else {
+        hipLaunchKernelGGL(sample_reduce_kernel, dim3(ceil_div(m, 4)), dim3(256), 0, s, partials, active_d, token_d, logprob_d, m,
+                           2 * (vocab_padded / 128), p->pad_token);
+    }
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_sample_logits(const float *logits_d, int ld, int m, int vocab, const lmrl_sample_params *p, const uint8_t *active_d,
+                       int32_t *token_d, float *logprob_d, void *stream) {
+    LMRL_REQUIRE(logits_d && p && token_d && m > 0 && vocab > 0 && ld >= vocab, "lmrl_sample_logits: bad argument");
+    SampleParams sp;
+    sp.greedy = (p->temperature <= 0.f) ? 1 : 0;
+    sp.inv_temperature = sp.greedy ? 1.f : 1.f / p->temperature;
+    sp.seed_lo = (uint32_t)p->seed; sp.seed_hi = (uint32_t)(p->seed >> 32); sp.step = p->step;
+    sp.steer_strength = 0.f; sp.beta = 0.f; sp.vocab = vocab;
+    hipLaunchKernelGGL(topk_sample_kernel, dim3(m), dim3(256), 0, as_stream(stream), logits_d, ld, vocab, p->top_k, active_d,
+                       token_d, logprob_d, sp, p->pad_token);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+}

@@ -1,0 +1,175 @@
+"""GPT-2 on the HIP rollout engine: weights in engine layout, KV-cache sessions, fused sampling.
+
+Host-side counterpart of what the reference obtains from JaxSeq (`GPT2Inference`, `load_train_state`,
+`generate_from_str`; call sites LLM_RL/algorithms/ppo/gpt2/interface.py:507-546 and
+llm_rl_scripts/wordle/ilql/train_ilql_gpt2.py:190-200).  All compute goes through
+`lmrl_gpt2_forward` / `lmrl_lm_head_sample` (csrc/gpt2.hip, csrc/sampler.hip); torch only owns the HBM.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclass
+class GPT2Config:
+    n_layer: int = 12
+    n_head: int = 12
+    d_model: int = 768
+    d_ff: int = 3072
+    vocab: int = 50257
+    n_pos: int = 1024
+    ln_eps: float = 1e-5
+    initializer_range: float = 0.02
+
+    @property
+    def vocab_padded(self) -> int:
+        return (self.vocab + 127) // 128 * 128
+
+    @classmethod
+    def gpt2_small(cls, vocab: int = 50257) -> "GPT2Config":
+        return cls(12, 12, 768, 3072, vocab, 1024)
+
+    @classmethod
+    def gpt2_medium(cls, vocab: int = 50257) -> "GPT2Config":
+        return cls(24, 16, 1024, 4096, vocab, 1024)
+
+
+class _CConfig(ctypes.Structure):
+    _fields_ = [("n_layer", ctypes.c_int32), ("n_head", ctypes.c_int32), ("d_model", ctypes.c_int32),
+                ("d_ff", ctypes.c_int32), ("vocab", ctypes.c_int32), ("vocab_padded", ctypes.c_int32),
+                ("n_pos", ctypes.c_int32), ("ln_eps", ctypes.c_float)]
+
+
+class SampleParams(ctypes.Structure):
+    _fields_ = [("temperature", ctypes.c_float), ("top_k", ctypes.c_int32), ("seed", ctypes.c_uint64),
+                ("step", ctypes.c_uint32), ("steer_strength", ctypes.c_float), ("beta", ctypes.c_float),
+                ("pad_token", ctypes.c_int32)]
+
+
+def init_hf_style_state_dict(cfg: GPT2Config, seed: int = 0) -> Dict[str, "torch.Tensor"]:
+    """Random-init weights with HF GPT-2 names/shapes/statistics (Conv1D kernels are [in, out];
+    normal(0, initializer_range); residual projections scaled by 1/sqrt(2*n_layer); LN = 1/0)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    std = cfg.initializer_range
+    n = lambda *shape, s=std: torch.randn(*shape, generator=g) * s
+    sd = {"wte.weight": n(cfg.vocab, cfg.d_model), "wpe.weight": n(cfg.n_pos, cfg.d_model),
+          "ln_f.weight": torch.ones(cfg.d_model), "ln_f.bias": torch.zeros(cfg.d_model)}
+    ps = std / math.sqrt(2 * cfg.n_layer)
+    for l in range(cfg.n_layer):
+        p = f"h.{l}."
+        sd[p + "ln_1.weight"] = torch.ones(cfg.d_model); sd[p + "ln_1.bias"] = torch.zeros(cfg.d_model)
+        sd[p + "attn.c_attn.weight"] = n(cfg.d_model, 3 * cfg.d_model); sd[p + "attn.c_attn.bias"] = torch.zeros(3 * cfg.d_model)
+        sd[p + "attn.c_proj.weight"] = n(cfg.d_model, cfg.d_model, s=ps); sd[p + "attn.c_proj.bias"] = torch.zeros(cfg.d_model)
+        sd[p + "ln_2.weight"] = torch.ones(cfg.d_model); sd[p + "ln_2.bias"] = torch.zeros(cfg.d_model)
+        sd[p + "mlp.c_fc.weight"] = n(cfg.d_model, cfg.d_ff); sd[p + "mlp.c_fc.bias"] = torch.zeros(cfg.d_ff)
+        sd[p + "mlp.c_proj.weight"] = n(cfg.d_ff, cfg.d_model, s=ps); sd[p + "mlp.c_proj.bias"] = torch.zeros(cfg.d_model)
+    return sd
+
+
+class GPT2Engine:
+    """GPT-2 weights resident in HBM in engine layout + the C handle."""
+
+    def __init__(self, cfg: GPT2Config, state_dict: Dict[str, "torch.Tensor"], device=None):
+        import torch
+        self.cfg = cfg
+        self.device = device or _lib.require_gpu()
+        self._L = _lib.lib()
+        sd = {k[len("transformer."):] if k.startswith("transformer.") else k: v for k, v in state_dict.items()}
+        bf = lambda t: t.to(self.device, torch.float32).to(torch.bfloat16).contiguous()
+        f32 = lambda t: t.to(self.device, torch.float32).contiguous()
+        wte = torch.zeros(cfg.vocab_padded, cfg.d_model, dtype=torch.bfloat16, device=self.device)
+        wte[: cfg.vocab] = bf(sd["wte.weight"][: cfg.vocab])
+        self.wte, self.wpe = wte, bf(sd["wpe.weight"])
+        self.lnf_g, self.lnf_b = f32(sd["ln_f.weight"]), f32(sd["ln_f.bias"])
+        self.layers = []
+        ptrs = []
+        for l in range(cfg.n_layer):
+            p = f"h.{l}."
+            t = [f32(sd[p + "ln_1.weight"]), f32(sd[p + "ln_1.bias"]),
+                 bf(sd[p + "attn.c_attn.weight"].t()), f32(sd[p + "attn.c_attn.bias"]),      # [3d][d]
+                 bf(sd[p + "attn.c_proj.weight"].t()), f32(sd[p + "attn.c_proj.bias"]),      # [d][d]
+                 f32(sd[p + "ln_2.weight"]), f32(sd[p + "ln_2.bias"]),
+                 bf(sd[p + "mlp.c_fc.weight"].t()), f32(sd[p + "mlp.c_fc.bias"]),            # [dff][d]
+                 bf(sd[p + "mlp.c_proj.weight"].t()), f32(sd[p + "mlp.c_proj.bias"])]        # [d][dff]
+            self.layers.append(t)
+            ptrs += [x.data_ptr() for x in t]
+        self._ptrs = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        cc = _CConfig(cfg.n_layer, cfg.n_head, cfg.d_model, cfg.d_ff, cfg.vocab, cfg.vocab_padded, cfg.n_pos, cfg.ln_eps)
+        self._h = self._L.lmrl_gpt2_create(ctypes.byref(cc), self.wte.data_ptr(), self.wpe.data_ptr(),
+                                           self.lnf_g.data_ptr(), self.lnf_b.data_ptr(), self._ptrs)
+        if not self._h:
+            raise _lib.LmrlError(self._L.lmrl_last_error().decode())
+
+    @classmethod
+    def random_init(cls, cfg: GPT2Config, seed: int = 0, device=None) -> "GPT2Engine":
+        return cls(cfg, init_hf_style_state_dict(cfg, seed), device)
+
+    def n_params(self) -> int:
+        c = self.cfg
+        return c.vocab * c.d_model + c.n_pos * c.d_model + 2 * c.d_model + c.n_layer * (
+            4 * c.d_model + 3 * c.d_model * c.d_model + 3 * c.d_model + c.d_model * c.d_model + c.d_model +
+            2 * c.d_model * c.d_ff + c.d_ff + c.d_model)
+
+    def session(self, batch: int, tmax: int) -> "KVSession":
+        return KVSession(self, batch, tmax)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.lmrl_gpt2_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class KVSession:
+    """Persistent per-env KV cache + workspace for `batch` lock-step sequences of at most `tmax` tokens."""
+
+    def __init__(self, eng: GPT2Engine, batch: int, tmax: int):
+        import torch
+        self.eng, self.B, self.tmax = eng, batch, tmax
+        L, dev = eng._L, eng.device
+        self.kv = torch.zeros(L.lmrl_gpt2_kv_bytes(eng._h, batch, tmax), dtype=torch.uint8, device=dev)
+        self.ws = {c: torch.zeros(L.lmrl_gpt2_ws_bytes(eng._h, batch, c), dtype=torch.uint8, device=dev) for c in (1, 8)}
+        self.len = torch.zeros(batch, dtype=torch.int32, device=dev)
+        self.last_hidden = torch.zeros(batch, eng.cfg.d_model, dtype=torch.bfloat16, device=dev)
+        self.sample_ws = torch.zeros(L.lmrl_sample_ws_bytes(batch, eng.cfg.vocab_padded), dtype=torch.uint8, device=dev)
+        self.token = torch.zeros(batch, dtype=torch.int32, device=dev)
+        self.logprob = torch.zeros(batch, dtype=torch.float32, device=dev)
+
+    def reset(self):
+        self.len.zero_()
+
+    def forward(self, tokens, cnt, chunk: int, all_hidden=None):
+        """tokens int32 [B*chunk], cnt int32 [B]; updates the cache, self.len and self.last_hidden."""
+        e = self.eng
+        _lib.check(e._L.lmrl_gpt2_forward(e._h, _lib.ptr(self.kv), self.tmax, _lib.ptr(self.ws[chunk]), _lib.ptr(tokens),
+                                          _lib.ptr(cnt), _lib.ptr(self.len), self.B, chunk, _lib.ptr(self.last_hidden),
+                                          _lib.ptr(all_hidden), _lib.stream_ptr()), "lmrl_gpt2_forward")
+        return self.last_hidden
+
+    def sample(self, params: SampleParams, steer_tok=None, active=None, hidden=None, logits_out=None,
+               q1=None, q2=None):
+        """Fused LM head + sampling of one token per env from `hidden` (default: last_hidden).
+        q1/q2: optional (q_hidden bf16 [B][d], w bf16 [Vp][d], bias f32 [Vp]) ILQL operands."""
+        e = self.eng
+        h = self.last_hidden if hidden is None else hidden
+        qa = [None] * 6
+        if q1 is not None:
+            qa[0:3] = [_lib.ptr(x) for x in q1]
+        if q2 is not None:
+            qa[3:6] = [_lib.ptr(x) for x in q2]
+        _lib.check(e._L.lmrl_lm_head_sample(_lib.ptr(h), _lib.ptr(e.wte), qa[0], qa[1], qa[2], qa[3], qa[4], qa[5], self.B,
+                                            e.cfg.d_model, e.cfg.vocab, e.cfg.vocab_padded, ctypes.byref(params),
+                                            _lib.ptr(steer_tok), _lib.ptr(active), _lib.ptr(self.token), _lib.ptr(self.logprob),
+                                            _lib.ptr(logits_out), _lib.ptr(self.sample_ws), _lib.stream_ptr()),
+                   "lmrl_lm_head_sample")
+        return self.token, self.logprob

@@ -1,0 +1,202 @@
+"""GPU tier: GPT-2 rollout engine (bf16 MFMA GEMM, KV-cache attention, fused LM-head sampler) through the C ABI
+against the torch-CPU oracle (oracle/gpt2.py, itself pinned to HF PyTorch GPT-2)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import lmrl_gym_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from lmrl_gym_amd import _lib
+    return _lib.require_gpu()
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------ GEMM + epilogues
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (1024, 2304, 768), (8192, 3072, 768), (1000, 768, 3072), (77, 128, 64),
+                                   (1, 64, 64), (300, 1024, 1024)])
+def test_gemm_bf16_epilogues(dev, M, N, K):
+    from lmrl_gym_amd import _lib
+    from oracle.gpt2 import gelu_new
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = _bf(torch.randn(M, K, generator=g)); W = _bf(torch.randn(N, K, generator=g) * 0.05); b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    ref = A.double() @ W.double().t() + b.double()
+    Ad, Wd, bd = A.to(dev), W.to(dev), b.to(dev)
+    tol = dict(rtol=2e-2, atol=2e-2 * float(ref.abs().max()) / 8)   # bf16 outputs: 8 mantissa bits
+    # asymmetric inputs -> a transposed store would fail (guide §5.4 rule 16)
+    for epi, expect, out_dtype in [(0, ref, torch.bfloat16), (1, gelu_new(ref), torch.bfloat16), (3, ref, torch.float32),
+                                   (4, torch.relu(ref), torch.bfloat16), (2, ref + R.double(), torch.float32)]:
+        C = R.to(dev).clone() if epi == 2 else torch.zeros(M, N, dtype=out_dtype, device=dev)
+        _lib.check(L.lmrl_gemm_bf16(_lib.ptr(Ad), _lib.ptr(Wd), _lib.ptr(bd), _lib.ptr(C), M, N, K, K, N, N, epi, _lib.stream_ptr()))
+        got = C.cpu().double()
+        if out_dtype == torch.float32:
+            torch.testing.assert_close(got, expect, rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
+        else:
+            torch.testing.assert_close(got, expect, **tol)
+
+
+# ------------------------------------------------------------------ forward: chunked prefill + decode vs full-sequence oracle
+@pytest.mark.parametrize("cfgname", ["tiny", "small2"])
+def test_gpt2_forward_kv_cache(dev, cfgname):
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
+    from oracle import gpt2 as O
+    cfg = dict(tiny=GPT2Config(2, 2, 128, 512, 1000, 64), small2=GPT2Config(2, 12, 768, 3072, 50257, 128))[cfgname]
+    sd = init_hf_style_state_dict(cfg, seed=1)
+    g = torch.Generator().manual_seed(2)
+    for k in sd:   # non-trivial LN / bias values
+        if sd[k].dim() == 1:
+            sd[k] = sd[k] + 0.1 * torch.randn(sd[k].shape, generator=g)
+    sd = O.round_weights_to_bf16(sd)
+    eng = GPT2Engine(cfg, sd, dev)
+    B, T = 5, 40
+    ids = torch.randint(0, cfg.vocab, (B, T), generator=g)
+    ref_logits, ref_hid = O.forward(sd, ids, cfg.n_head, dtype=torch.float64, return_hidden=True)
+    ses = eng.session(B, 48)
+    # schedule: chunk of 8 with ragged counts, then single-token decode steps with some envs idle, then another chunk
+    consumed = np.zeros(B, dtype=int)
+    plan = [(8, [8, 5, 1, 0, 7]), (1, [1, 1, 1, 1, 0]), (1, [1, 0, 1, 1, 1]), (8, [8, 8, 3, 8, 2]), (1, [1, 1, 1, 1, 1]), (8, [4, 0, 8, 6, 8])]
+    for C, cnts in plan:
+        toks = torch.zeros(B, C, dtype=torch.int32)
+        for b, c in enumerate(cnts):
+            toks[b, :c] = ids[b, consumed[b]:consumed[b] + c]
+        allh = torch.zeros(B * C, cfg.d_model, dtype=torch.bfloat16, device=dev)
+        toks_d, cnt_d = toks.reshape(-1).to(dev), torch.tensor(cnts, dtype=torch.int32, device=dev)
+        last = ses.forward(toks_d, cnt_d, C, all_hidden=allh).float().cpu()
+        allh = allh.float().cpu().reshape(B, C, -1)
+        for b, c in enumerate(cnts):
+            for j in range(c):
+                torch.testing.assert_close(allh[b, j].double(), ref_hid[b, consumed[b] + j], rtol=5e-2, atol=5e-2)
+            if c:
+                torch.testing.assert_close(last[b].double(), ref_hid[b, consumed[b] + c - 1], rtol=5e-2, atol=5e-2)
+            consumed[b] += c
+        assert ses.len.cpu().tolist() == consumed.tolist()
+    # tighter aggregate check: relative Frobenius error of the final hidden states
+    err = (last.double() - torch.stack([ref_hid[b, consumed[b] - 1] for b in range(B)])).norm() / torch.stack([ref_hid[b, consumed[b] - 1] for b in range(B)]).norm()
+    assert err < 1.5e-2, float(err)
+
+
+# ------------------------------------------------------------------ fused LM head + sampler
+def _engine_and_hidden(dev, B, vocab=5003, d=128):
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
+    from oracle import gpt2 as O
+    cfg = GPT2Config(1, d // 64, d, 256, vocab, 32)
+    sd = O.round_weights_to_bf16(init_hf_style_state_dict(cfg, seed=3))
+    sd["wte.weight"] = (sd["wte.weight"] * 20).to(torch.bfloat16).float()   # spread the logits
+    eng = GPT2Engine(cfg, sd, dev)
+    hid = _bf(torch.randn(B, d, generator=torch.Generator().manual_seed(4)))
+    ses = eng.session(B, 8)
+    logits = hid.double() @ sd["wte.weight"].double().t()
+    return cfg, eng, ses, hid.to(dev), logits
+
+
+def test_sampler_greedy_logprob_and_logits(dev):
+    from lmrl_gym_amd.gpt2 import SampleParams
+    B = 300
+    cfg, eng, ses, hid, logits = _engine_and_hidden(dev, B)
+    lo = torch.zeros(B, cfg.vocab_padded, device=dev)
+    active = torch.ones(B, dtype=torch.uint8, device=dev); active[7] = 0
+    tok, lp = ses.sample(SampleParams(0.0, 0, 1, 0, 0.0, 0.0, 50256), hidden=hid, logits_out=lo, active=active)
+    tok, lp, lo = tok.cpu(), lp.cpu(), lo.cpu()[:, : cfg.vocab]
+    torch.testing.assert_close(lo.double(), logits, rtol=1e-3, atol=2e-3)
+    exp_lp = torch.log_softmax(logits, -1)
+    for b in range(B):
+        if b == 7:
+            assert tok[b] == 50256
+            continue
+        top2 = logits[b].topk(2).values
+        if top2[0] - top2[1] > 1e-2:
+            assert tok[b] == logits[b].argmax()
+        assert abs(float(lp[b]) - float(exp_lp[b, tok[b]])) < 5e-3
+
+
+def test_sampler_gumbel_stream_matches_documented_scheme(dev):
+    """Sampling == argmax(logits/T + Gumbel(philox(row, col//4, step))) on the materialised logits, for the fused
+    epilogue and the top-k kernel alike; top-k keeps exactly the k largest (ties kept)."""
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.gpt2 import SampleParams
+    from oracle.gpt2 import gumbel_noise
+    B = 200
+    cfg, eng, ses, hid, _ = _engine_and_hidden(dev, B)
+    lo = torch.zeros(B, cfg.vocab_padded, device=dev)
+    seed, step, T = 0x1234567811223344, 5, 0.7
+    tok, lp = ses.sample(SampleParams(T, 0, seed, step, 0.0, 0.0, 0), hidden=hid, logits_out=lo)
+    z = lo.cpu().numpy()[:, : cfg.vocab].astype(np.float32)
+    g = gumbel_noise(B, cfg.vocab, seed, step)
+    score = z / np.float32(T) + g
+    exp_tok = score.argmax(1)
+    tok = tok.cpu().numpy()
+    srt = np.sort(score, 1)
+    safe = (srt[:, -1] - srt[:, -2]) > 1e-3        # device log is a fast approximation
+    assert safe.mean() > 0.9 and np.array_equal(tok[safe], exp_tok[safe])
+    lse = np.log(np.exp((z / T) - (z / T).max(1, keepdims=True)).sum(1)) + (z / T).max(1)
+    np.testing.assert_allclose(lp.cpu().numpy()[safe], (z / T)[np.arange(B), tok][safe] - lse[safe], atol=5e-3)
+    # top-k path on the same logits / stream
+    for k in (1, 5, 50, cfg.vocab):
+        tk = torch.zeros(B, dtype=torch.int32, device=dev); lpk = torch.zeros(B, device=dev)
+        p = SampleParams(T, k, seed, step, 0.0, 0.0, 0)
+        _lib.check(_lib.lib().lmrl_sample_logits(_lib.ptr(lo), cfg.vocab_padded, B, cfg.vocab, ctypes.byref(p), None,
+                                                 _lib.ptr(tk), _lib.ptr(lpk), _lib.stream_ptr()))
+        tk = tk.cpu().numpy()
+        kth = np.sort(z, 1)[:, -k][:, None]
+        masked = np.where(z >= kth, score, -np.inf)
+        e = masked.argmax(1)
+        m2 = np.sort(masked, 1)
+        ok = (m2[:, -1] - m2[:, -2]) > 1e-3 if k > 1 else np.ones(B, bool)
+        assert np.array_equal(tk[ok], e[ok]), k
+        assert np.all(z[np.arange(B), tk] >= kth[:, 0])
+        if k == cfg.vocab:
+            assert np.array_equal(tk[safe], tok[safe])
+
+
+def test_sampler_distribution_chi_square(dev):
+    """Identical rows -> empirical token frequencies follow softmax(logits/T)."""
+    from lmrl_gym_amd.gpt2 import SampleParams
+    B = 8192
+    cfg, eng, ses, hid, logits = _engine_and_hidden(dev, B, vocab=300, d=128)
+    hid = hid[:1].repeat(B, 1).contiguous()
+    p = torch.softmax(logits[0] / 1.3, -1).numpy()
+    counts = np.zeros(cfg.vocab)
+    for step in range(4):
+        tok, _ = ses.sample(SampleParams(1.3, 0, 99, step, 0.0, 0.0, 0), hidden=hid)
+        counts += np.bincount(tok.cpu().numpy(), minlength=cfg.vocab)
+    n = counts.sum()
+    keep = p * n >= 5
+    chi2 = (((counts - p * n) ** 2) / (p * n))[keep].sum() + ((counts[~keep].sum() - p[~keep].sum() * n) ** 2) / max(p[~keep].sum() * n, 1e-9)
+    dof = keep.sum()
+    assert chi2 < dof + 5 * np.sqrt(2 * dof), (chi2, dof)
+
+
+def test_sampler_steer_and_ilql_perturbation(dev):
+    """logits = pi + beta * min(q1, q2)  (value_rl_base/gpt2/generation.py:112-117), greedy."""
+    from lmrl_gym_amd.gpt2 import SampleParams
+    B, d = 130, 128
+    cfg, eng, ses, hid, logits = _engine_and_hidden(dev, B, vocab=2000, d=d)
+    g = torch.Generator().manual_seed(8)
+    qh = [_bf(torch.relu(torch.randn(B, d, generator=g))) for _ in range(2)]
+    qw = [_bf(torch.randn(cfg.vocab_padded, d, generator=g) * 0.3) for _ in range(2)]
+    qb = [torch.randn(cfg.vocab_padded, generator=g) for _ in range(2)]
+    q = [qh[i].double() @ qw[i].double().t() + qb[i].double() for i in range(2)]
+    beta = 4.0
+    full = logits + beta * torch.minimum(q[0], q[1])[:, : cfg.vocab]
+    lo = torch.zeros(B, cfg.vocab_padded, device=dev)
+    ops = [tuple(x.to(dev) for x in (qh[i], qw[i], qb[i])) for i in range(2)]
+    tok, lp = ses.sample(SampleParams(0.0, 0, 1, 0, 0.0, beta, 0), hidden=hid, logits_out=lo, q1=ops[0], q2=ops[1])
+    torch.testing.assert_close(lo.cpu()[:, : cfg.vocab].double(), full, rtol=2e-3, atol=2e-2)
+    top2 = full.topk(2).values
+    safe = (top2[:, 0] - top2[:, 1]) > 5e-2
+    assert safe.float().mean() > 0.8 and torch.equal(tok.cpu()[safe].long(), full.argmax(1)[safe])
+    # steering adds `strength` to one logit per row
+    steer = torch.randint(0, cfg.vocab, (B,), generator=g).to(torch.int32)
+    tok, _ = ses.sample(SampleParams(1.0, 0, 5, 1, 1000.0, 0.0, 0), hidden=hid, steer_tok=steer.to(dev))
+    assert torch.equal(tok.cpu(), steer)
