@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py — headline metric of BASELINE.json: env-steps/sec, GPT-2-small Wordle rollouts, 1024 envs per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one lock-step EPISODE of the hot path over one batch: 1024 envs x up to 6 turns, each turn =
+GPT-2-small policy samples an action token by token (persistent KV cache, fused LM-head sampler), the batched
+Wordle kernel steps the envs, the observation is injected as tokens.  `value` = env.step calls completed by all
+ranks / wall time of the K timed steps (barrier + synchronize on both sides, max over ranks).
+
+Synthetic workload (BASELINE.md M2'): random-init GPT-2-small (HF init, seed 0), bf16 weights/activations with
+fp32 accumulation and fp32 residual stream, temperature 1, full-vocabulary Gumbel-max sampling.  A random-init
+policy never spells a word, so each env's sampler is STEERED towards a scripted guess (uniform over the 431-word
+vocabulary, 10 % non-words; +30 on that token's logit): every logit is still computed and sampled from, but the
+episode then has the token mix of a trained policy (valid guesses, 6-token observations, early wins).
+
+Multi-GPU: rollouts shard by env with no data-path collective -> weak scaling, one process per GPU.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# kernel class whose HIP-event time is reported as the roofline line (the dominant one in profiles/r01_*.txt)
+ROOFLINE_TAG = "gemm_bf16_128x128"
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md (dense, no sparsity)
+
+
+def scripted_guesses(vocab_words, n_eps, n_turns, batch, seed=12345):
+    """[n_eps][n_turns][batch] packed guesses: uniform over the vocabulary from MT19937(seed), 10 % non-words."""
+    from lmrl_gym_amd.envs import wordle as W
+    rng = np.random.RandomState(seed)
+    packed = np.array([W.pack_guess(w) for w in vocab_words], dtype=np.uint32)
+    g = packed[rng.randint(0, len(packed), size=(n_eps, n_turns, batch))]
+    bad = rng.rand(n_eps, n_turns, batch) < 0.10
+    junk = rng.randint(0, 26, size=(n_eps, n_turns, batch, 5)).astype(np.uint32)
+    junk_packed = sum(junk[..., i] << np.uint32(5 * i) for i in range(5)).astype(np.uint32)
+    g[bad] = junk_packed[bad]
+    return g
+
+
+def cpu_baseline(vocab_words, budget_s=25.0):
+    """The reference's per-turn structure on the host cores: re-prefill the whole history, then decode with a KV
+    cache (HF PyTorch GPT2LMHeadModel as the port of the JAX model), env = the C oracle.  Bounded sample."""
+    import torch
+    import transformers
+    from oracle.wordle import OracleWordleEnv
+    from lmrl_gym_amd.rollout import WordleTokenTable
+    transformers.logging.set_verbosity_error()
+    torch.manual_seed(0)
+    model = transformers.GPT2LMHeadModel(transformers.GPT2Config()).eval()
+    tab = WordleTokenTable.default_gpt2()
+    Bc, turns = 32, 6
+    rng = np.random.RandomState(1)
+    envs = [OracleWordleEnv(vocab_words, True, -10.0) for _ in range(Bc)]
+    hist = [e.reset(i) for i, e in enumerate(envs)]
+    n_steps = 0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for turn in range(turns):
+            words = [vocab_words[k] for k in rng.randint(0, len(vocab_words), size=Bc)]
+            ids = torch.tensor([tab.encode_text("".join(t for t, _ in h)) for h in hist])
+            out = model(ids, use_cache=True)
+            past, logits = out.past_key_values, out.logits[:, -1]
+            for k in range(6):
+                steer = torch.tensor([(tab.encode_text(" ".join(w) + "\n"))[k] for w in words])
+                logits[torch.arange(Bc), steer] += 30.0
+                tok = torch.multinomial(torch.softmax(logits.float(), -1), 1)
+                if k < 5:
+                    out = model(tok, past_key_values=past, use_cache=True)
+                    past, logits = out.past_key_values, out.logits[:, -1]
+            for i, e in enumerate(envs):
+                hist[i], r, d = e.step(hist[i] + ((" ".join(words[i]) + "\n", True),))
+                n_steps += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+    dt = time.perf_counter() - t0
+    return dict(value=n_steps / dt, unit="env-steps/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{Bc} envs x {turn + 1} turns (valid scripted guesses), GPT-2-small fp32 on torch-CPU re-prefilling the "
+                       f"history every turn as the reference does + C oracle env; {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="envs per GPU")
+    ap.add_argument("--vocab-file", default="wordle_official_400.txt")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="after the timed region, print a per-kernel-class event breakdown to stderr")
+    args = ap.parse_args()
+
+    import torch
+    import lmrl_gym_amd  # noqa: F401
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.envs import wordle as W
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine
+    from lmrl_gym_amd.rollout import WordleRolloutEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    L = _lib.lib()
+    vocab = W.Vocabulary.builtin(args.vocab_file)
+    cfg = GPT2Config.gpt2_small()
+    eng = GPT2Engine.random_init(cfg, seed=0, device=dev)
+    B, n_turns = args.batch, W.N_TRIES
+    ro = WordleRolloutEngine(eng, vocab, B, max_new_tokens=6, bad_word_reward=-10.0)
+    n_eps = args.steps + args.warmup + (1 if args.breakdown else 0)
+    guesses = torch.from_numpy(scripted_guesses(vocab.all_vocab, n_eps, n_turns, B, seed=12345 + rank).view(np.int32)).to(dev)
+    total_steps = torch.zeros((), dtype=torch.int64, device=dev)
+    tag_ids = {L.lmrl_prof_tag_name(t).decode(): t for t in range(L.lmrl_prof_n_tags())}
+
+    def episode(i, count):
+        seeds = np.arange(B, dtype=np.uint64) + np.uint64((i * world + rank) * B)
+        ro.run_episode(seeds, temperature=1.0, sample_seed=1000 + rank, scripted_guesses=guesses[i], steer_strength=30.0)
+        if count:
+            total_steps.add_(ro.traj["n_steps"].sum())
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        episode(i, False)
+    L.lmrl_prof_reset()
+    L.lmrl_prof_enable(1 << tag_ids[ROOFLINE_TAG])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        episode(args.warmup + i, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    L.lmrl_prof_enable(0)
+
+    ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+    _lib.check(L.lmrl_prof_read(tag_ids[ROOFLINE_TAG], ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n)))
+    tflops = (work.value / (ms.value * 1e-3)) / 1e12 if ms.value > 0 else 0.0
+    roofline = dict(bound="mfma", kernel=ROOFLINE_TAG, achieved=round(tflops, 1), peak=MFMA_BF16_DENSE_PEAK_TFLOPS,
+                    unit="TFLOP/s", frac=round(tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), traffic=None,
+                    launches=int(n.value), avg_launch_us=round(ms.value * 1e3 / max(n.value, 1), 2),
+                    share_of_step_time=round(ms.value * 1e-3 / dt, 3))
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    steps_all = total_steps.clone()
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(steps_all, op=torch.distributed.ReduceOp.SUM)
+    dt_max, n_env_steps = float(t.item()), int(steps_all.item())
+
+    if args.breakdown and rank == 0:
+        L.lmrl_prof_reset(); L.lmrl_prof_enable(0xFFFFFFFF)
+        torch.cuda.synchronize(); tb = time.perf_counter()
+        episode(n_eps - 1, False)
+        torch.cuda.synchronize(); te = time.perf_counter() - tb
+        L.lmrl_prof_enable(0)
+        print(f"[breakdown] one episode with every tag bracketed: {te * 1e3:.2f} ms", file=sys.stderr)
+        for name, tid in tag_ids.items():
+            _lib.check(L.lmrl_prof_read(tid, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n)))
+            if n.value:
+                rate = f"{work.value / (ms.value * 1e-3) / 1e12:8.1f} T(FLOP|B)/s" if work.value > 0 else ""
+                print(f"[breakdown] {name:22s} {n.value:6d} launches {ms.value:9.3f} ms  avg {ms.value * 1e3 / n.value:8.2f} us {rate}", file=sys.stderr)
+
+    if rank == 0:
+        out = {
+            "metric": "env-steps/sec (GPT-2-small Wordle, batch 1024)", "value": round(n_env_steps / dt_max, 1),
+            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_max * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: Wordle env, GPT-2-small policy (random-init, steered sampling), "
+                                   f"{B} lock-step envs per GPU, {n_turns} turns x <=6 generated tokens, vocab {args.vocab_file}",
+                       "envs_per_gpu": B, "max_new_tokens": 6, "parallelism": f"env-sharded x{world}, no data-path collective",
+                       "env_steps_timed": n_env_steps},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(vocab.all_vocab)
+        print(json.dumps(out), flush=True)
+    ro.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

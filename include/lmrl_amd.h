@@ -224,6 +224,74 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
 int lmrl_sample_logits(const float *logits_d, int ld, int m, int vocab, const lmrl_sample_params *p,
                        const uint8_t *active_d, int32_t *token_d, float *logprob_d, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * On-device token <-> game bookkeeping for lock-step Wordle rollouts (csrc/wordle_tokens.hip).
+ * Replaces the per-turn host work of interact_environment + GPT2PPOPolicy.act
+ * (LLM_RL/environment.py:180-206, LLM_RL/algorithms/ppo/gpt2/interface.py:519-546) and the text
+ * (de)formatting of llm_rl_scripts/wordle/env/env.py:7-26.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t newline;          /* id of '\n' (= eos of an action, train_ilql_gpt2.py:393) */
+    int32_t pad;
+    int32_t letter_first[26]; /* 'a'..'z' as the first symbol of a line (no leading space) */
+    int32_t letter_sp[26];    /* ' a'..' z' */
+    int32_t sym_first[3];     /* 'g','y','b' */
+    int32_t sym_sp[3];        /* ' g',' y',' b' */
+    int32_t header[8];        /* ids of "Wordle:\n" (env.py:8) */
+    int32_t n_header;
+} lmrl_wordle_tokens;
+
+/* Per-env rollout record, all device pointers owned by the caller; N envs, cap = traj_cap, G = max_new_tokens.
+ * tokens/is_action/reward are exactly the fields of TokenTrajectory (LLM_RL/environment.py:329-380). */
+typedef struct {
+    int32_t *tokens;      /* [N][cap] */
+    uint8_t *is_action;   /* [N][cap] */
+    float *reward;        /* [N][cap]  reward on the last token of each action Text */
+    int32_t *n_tok;       /* [N] */
+    int32_t *gen;         /* [N][G] ids sampled for the current action */
+    int32_t *gen_len;     /* [N] */
+    uint8_t *gen_active;  /* [N] still generating the current action */
+    uint8_t *env_done;    /* [N] episode finished */
+    uint8_t *pend_newline;/* [N] action ended without eos: '\n' forced (interface.py:541) */
+    int32_t *n_steps;     /* [N] env steps taken */
+    float *ep_reward;     /* [N] sum of rewards */
+} lmrl_wordle_traj;
+
+typedef struct lmrl_wordle_tok_ctx lmrl_wordle_tok_ctx;
+/* token_class (host, [vocab]): bits 0-24 up to five 5-bit letters, bits 25-27 their count (7 = any char other than
+ * a-z / whitespace, or more than 5 letters, or whitespace between letters), bit 28 non-' ' whitespace before the first
+ * letter (anywhere when the token has no letters), bit 29 non-' ' whitespace after the last letter. */
+lmrl_wordle_tok_ctx *lmrl_wordle_tok_create(const lmrl_wordle_tokens *tokens, const uint32_t *token_class, int vocab,
+                                            int max_new_tokens, int traj_cap);
+void lmrl_wordle_tok_destroy(lmrl_wordle_tok_ctx *c);
+/* episode start: trajectory := header tokens; first model chunk (chunk_tok_d [N][8], chunk_cnt_d [N]) := header */
+int lmrl_wordle_tok_begin(lmrl_wordle_tok_ctx *c, const lmrl_wordle_traj *tr, int32_t *chunk_tok_d, int32_t *chunk_cnt_d,
+                          int n, void *stream);
+/* k-th sampled token of the current action: record it; envs that hit eos / max_new_tokens stop generating;
+ * next_tok_d/next_cnt_d (and active_d) describe the next single-token decode step. */
+int lmrl_wordle_tok_accept(lmrl_wordle_tok_ctx *c, const lmrl_wordle_traj *tr, const int32_t *sampled_d, int k,
+                           int32_t *next_tok_d, int32_t *next_cnt_d, uint8_t *active_d, int n, void *stream);
+/* action tokens -> packed guess for lmrl_wordle_step (+ active mask = episode not done); appends the action to the record */
+int lmrl_wordle_tok_guess(lmrl_wordle_tok_ctx *c, const lmrl_wordle_traj *tr, uint32_t *guess_d, uint8_t *active_d, int n,
+                          void *stream);
+/* env outputs -> reward placement, observation tokens, done flags, and the next model chunk
+ * ([last unforwarded action token][forced '\n'] + observation tokens; count 0 for finished envs) */
+int lmrl_wordle_tok_observe(lmrl_wordle_tok_ctx *c, const lmrl_wordle_traj *tr, const uint32_t *obs_d, const float *reward_d,
+                            const uint8_t *flags_d, int32_t *chunk_tok_d, int32_t *chunk_cnt_d, int n, void *stream);
+/* synthetic workloads: token spelling letter k (k = 5: '\n') of a scripted packed guess, for lmrl_sample_params.steer */
+int lmrl_wordle_tok_steer(lmrl_wordle_tok_ctx *c, const uint32_t *scripted_guess_d, int k, int32_t *steer_d, int n,
+                          void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel-class timing with HIP events on the launch stream (used by bench.py for the live roofline figure).
+ * mask bit t enables tag t; `work` accumulates the algorithmic flops (GEMM-class tags) or bytes (others) per launch.
+ * ------------------------------------------------------------------------------------------ */
+void lmrl_prof_enable(unsigned mask);
+void lmrl_prof_reset(void);
+int lmrl_prof_n_tags(void);
+const char *lmrl_prof_tag_name(int tag);
+int lmrl_prof_read(int tag, double *total_ms, double *total_work, long long *launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,18 @@ _SIGS = {
     "lmrl_gemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_sample_ws_bytes": (c_size_t, [c_int, c_int]),
     "lmrl_lm_head_sample": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int] + [c_void_p] * 8),
+    "lmrl_wordle_tok_create": (c_void_p, [c_void_p, c_void_p, c_int, c_int, c_int]),
+    "lmrl_wordle_tok_destroy": (None, [c_void_p]),
+    "lmrl_wordle_tok_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_wordle_tok_accept": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_wordle_tok_guess": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_wordle_tok_observe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_wordle_tok_steer": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "lmrl_prof_enable": (None, [ctypes.c_uint]),
+    "lmrl_prof_reset": (None, []),
+    "lmrl_prof_n_tags": (c_int, []),
+    "lmrl_prof_tag_name": (c_char_p, [c_int]),
+    "lmrl_prof_read": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
     "lmrl_sample_logits": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

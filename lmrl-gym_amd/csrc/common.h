@@ -32,6 +32,21 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+// ---- optional per-kernel-class HIP-event timing (bench.py's live roofline numbers). Off by default: a scope costs
+// two hipEventRecord calls on the launch stream only when its tag is enabled through lmrl_prof_enable().
+enum ProfTag {
+    PROF_GEMM_128x128 = 0, PROF_GEMM_64x128, PROF_GEMM_64x64, PROF_ATTN_DECODE, PROF_ATTN_CHUNK, PROF_LM_HEAD_SAMPLE,
+    PROF_LAYERNORM, PROF_EMBED, PROF_WORDLE_STEP, PROF_WORDLE_RESET, PROF_TOKENS, PROF_SAMPLE_REDUCE, PROF_N_TAGS
+};
+extern unsigned g_prof_mask;
+void prof_begin(int tag, hipStream_t s, double work);
+void prof_end(int tag, hipStream_t s);
+struct ProfScope {
+    int tag; hipStream_t s; bool on;
+    ProfScope(int t, hipStream_t st, double work) : tag(t), s(st), on((g_prof_mask >> t) & 1u) { if (on) prof_begin(tag, s, work); }
+    ~ProfScope() { if (on) prof_end(tag, s); }
+};
+
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace lmrl

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "common.h"
+
 namespace lmrl {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -185,7 +187,11 @@ inline hipError_t gemm_launch_cfg(const GemmArgs &g, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI>), dim3(tiles), dim3(256), shmem, s, g);
+    {
+        ProfScope ps(BM == 128 ? PROF_GEMM_128x128 : (BN == 128 ? PROF_GEMM_64x128 : PROF_GEMM_64x64), s,
+                     2.0 * (double)g.M * (double)g.N * (double)g.K);
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI>), dim3(tiles), dim3(256), shmem, s, g);
+    }
     return hipGetLastError();
 }
 

@@ -345,8 +345,12 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
         LMRL_CHECK_LAUNCH();
         GemmArgs g{w.h, L.w_qkv, L.b_qkv, w.qkv, M, 3 * d, d, d, 3 * d, 3 * d};
         LMRL_CHECK_HIP(gemm_launch<EPI_BF16>(g, s));
+        {
+        // algorithmic bytes: K+V rows read once (2 * 128 B per cached position per head) + q/k/v/out rows of the chunk
+        ProfScope ps(c == 1 ? PROF_ATTN_DECODE : PROF_ATTN_CHUNK, s, -1.0);
         if (c == 1) hipLaunchKernelGGL(attention_kernel<1>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
         else hipLaunchKernelGGL(attention_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
+        }
         LMRL_CHECK_LAUNCH();
         GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d};
         LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(gp, s));

@@ -370,6 +370,8 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     const uint16_t *A0 = (const uint16_t *)hidden_d, *W0 = (const uint16_t *)wte_d;
     const uint16_t *A1 = (const uint16_t *)q_hidden1_d, *W1 = (const uint16_t *)q_w1_d;
     const uint16_t *A2 = (const uint16_t *)q_hidden2_d, *W2 = (const uint16_t *)q_w2_d;
+    {
+    ProfScope ps(PROF_LM_HEAD_SAMPLE, s, 2.0 * (double)m * (double)vocab_padded * (double)d_model * nops);
     if (nops == 1)
         hipLaunchKernelGGL(lm_head_sample_kernel<1>, dim3(tiles), dim3(256), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
                            steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp);
@@ -379,6 +381,7 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     else
         hipLaunchKernelGGL(lm_head_sample_kernel<3>, dim3(tiles), dim3(256), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
                            steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp);
+    }
     LMRL_CHECK_LAUNCH();
     if (p->top_k > 0 && p->top_k < vocab) {
         LMRL_REQUIRE(logits_out_d, "lmrl_lm_head_sample: top_k sampling needs logits_out_d (materialised logits)");

@@ -243,6 +243,7 @@ int lmrl_wordle_step(lmrl_wordle_ctx *ctx, void *state_d, void *mt_d, const uint
     LMRL_REQUIRE(ctx && state_d && mt_d && guess_d && obs_d && reward_d && flags_d && n >= 0,
                  "lmrl_wordle_step: null pointer or negative n");
     if (n == 0) return LMRL_OK;
+    ProfScope ps(PROF_WORDLE_STEP, as_stream(stream), 96.0 * n);   // ~96 algorithmic bytes per env-step
     hipLaunchKernelGGL(wordle_step_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, as_stream(stream), ctx->words_d,
                        ctx->wmask_d, ctx->V, ctx->require, ctx->bad_reward, (uint32_t *)state_d, mt_d, guess_d, active_d,
                        obs_d, reward_d, flags_d, n);

@@ -1,0 +1,220 @@
+"""Lock-step Wordle rollouts entirely on the device: GPT-2 policy + sampler + env + token bookkeeping.
+
+This is the MI355X counterpart of `interact_environment(env, GPT2PPOPolicy(...), bsize=B)`
+(LLM_RL/environment.py:154-207 with LLM_RL/algorithms/ppo/gpt2/interface.py:507-546): the same per-turn
+sequence — policy generates an action until '\\n' / max_new_tokens, env.step, observation appended — but
+for B envs at once with no host round trip, a persistent KV cache (only a turn's new tokens are forwarded)
+and the observation injected as token ids.  The resulting per-env records are TokenTrajectory fields.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .envs import wordle as W
+from .gpt2 import GPT2Engine, SampleParams
+
+# GPT-2 BPE ids quoted from memory of the public vocabulary; NOT verifiable in the build container (no tokenizer
+# files offline).  Use `WordleTokenTable.from_tokenizer` whenever a tokenizer is available; for
+# random-init synthetic benchmarks only injectivity matters.
+_GPT2_SP_LETTERS = [257, 275, 269, 288, 304, 277, 308, 289, 1312, 474, 479, 300, 285, 299, 267, 279, 10662, 374, 264, 256,
+                    334, 410, 266, 2124, 331, 1976]
+
+
+class _CTokens(ctypes.Structure):
+    _fields_ = [("newline", ctypes.c_int32), ("pad", ctypes.c_int32), ("letter_first", ctypes.c_int32 * 26),
+                ("letter_sp", ctypes.c_int32 * 26), ("sym_first", ctypes.c_int32 * 3), ("sym_sp", ctypes.c_int32 * 3),
+                ("header", ctypes.c_int32 * 8), ("n_header", ctypes.c_int32)]
+
+
+class _CTraj(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("tokens", "is_action", "reward", "n_tok", "gen", "gen_len", "gen_active",
+                                               "env_done", "pend_newline", "n_steps", "ep_reward")]
+
+
+def classify_token_string(s: str) -> int:
+    """Token class word of csrc/wordle_tokens.hip for the decoded string of one token."""
+    letters = [c for c in s if "a" <= c <= "z"]
+    other = [c for c in s if not ("a" <= c <= "z") and not c.isspace()]
+    if other or len(letters) > 5:
+        return 7 << 25
+    idx = [i for i, c in enumerate(s) if "a" <= c <= "z"]
+    is_w = [c.isspace() and c != " " for c in s]
+    if not idx:
+        return (1 << 28) if any(is_w) else 0
+    first, last = idx[0], idx[-1]
+    if any(is_w[first:last + 1]):
+        return 7 << 25
+    word = 0
+    for k, c in enumerate(letters):
+        word |= (ord(c) - 97) << (5 * k)
+    return word | (len(letters) << 25) | ((1 << 28) if any(is_w[:first]) else 0) | ((1 << 29) if any(is_w[last + 1:]) else 0)
+
+
+@dataclass
+class WordleTokenTable:
+    newline: int
+    pad: int
+    letter_first: List[int]
+    letter_sp: List[int]
+    sym_first: List[int]   # g, y, b
+    sym_sp: List[int]
+    header: List[int]
+    strings: dict = field(default_factory=dict)   # id -> decoded string (for the class table)
+
+    @classmethod
+    def default_gpt2(cls, pad: int = 50256) -> "WordleTokenTable":
+        lf = list(range(64, 90))                      # 'a'..'z'
+        ls = list(_GPT2_SP_LETTERS)
+        t = cls(newline=198, pad=pad, letter_first=lf, letter_sp=ls,
+                sym_first=[lf[6], lf[24], lf[1]], sym_sp=[ls[6], ls[24], ls[1]], header=[26449, 293, 25, 198])
+        t.strings = {198: "\n", 26449: "Word", 293: "le", 25: ":"}
+        for i in range(26):
+            t.strings[lf[i]] = chr(97 + i)
+            t.strings[ls[i]] = " " + chr(97 + i)
+        return t
+
+    @classmethod
+    def from_tokenizer(cls, tokenizer, pad: Optional[int] = None) -> "WordleTokenTable":
+        one = lambda s: (lambda ids: ids[0] if len(ids) == 1 else (_ for _ in ()).throw(
+            ValueError(f"{s!r} is not a single token: {ids}")))(tokenizer.encode(s))
+        lf = [one(chr(97 + i)) for i in range(26)]
+        ls = [one(" " + chr(97 + i)) for i in range(26)]
+        header = list(tokenizer.encode("Wordle:\n"))
+        if len(header) > 8:
+            raise ValueError("header longer than 8 tokens")
+        t = cls(newline=one("\n"), pad=tokenizer.pad_token_id if pad is None else pad, letter_first=lf, letter_sp=ls,
+                sym_first=[lf[6], lf[24], lf[1]], sym_sp=[ls[6], ls[24], ls[1]], header=header)
+        vocab = len(tokenizer)
+        t.strings = {i: tokenizer.decode([i]) for i in range(vocab)}
+        return t
+
+    def token_class(self, vocab: int) -> np.ndarray:
+        """uint32 [vocab]; ids without a known string are 'invalid-making' (7 << 25) — a full tokenizer fills all."""
+        out = np.full(vocab, 7 << 25, dtype=np.uint32)
+        for i, s in self.strings.items():
+            if 0 <= i < vocab:
+                out[i] = classify_token_string(s)
+        return out
+
+    def c_struct(self) -> _CTokens:
+        c = _CTokens()
+        c.newline, c.pad = self.newline, self.pad
+        for i in range(26):
+            c.letter_first[i] = self.letter_first[i]
+            c.letter_sp[i] = self.letter_sp[i]
+        for i in range(3):
+            c.sym_first[i] = self.sym_first[i]
+            c.sym_sp[i] = self.sym_sp[i]
+        for i, h in enumerate(self.header):
+            c.header[i] = h
+        c.n_header = len(self.header)
+        return c
+
+    def encode_text(self, s: str) -> List[int]:
+        """Canonical ids of Wordle-alphabet text ('Wordle:\\n', 's t a r e\\n', 'g y b b y\\n', '\\n')."""
+        out: List[int] = []
+        for line in s.splitlines(keepends=True):
+            body = line[:-1] if line.endswith("\n") else line
+            if body == "Wordle:":
+                out += self.header[:-1]
+            elif body:
+                parts = body.split(" ")
+                for k, p in enumerate(parts):
+                    assert len(p) == 1 and "a" <= p <= "z", f"not Wordle-alphabet text: {line!r}"
+                    out.append(self.letter_first[ord(p) - 97] if k == 0 else self.letter_sp[ord(p) - 97])
+            if line.endswith("\n"):
+                out.append(self.newline)
+        return out
+
+
+class WordleRolloutEngine:
+    """B lock-step Wordle episodes driven by a GPT-2 policy on one GPU."""
+
+    def __init__(self, engine: GPT2Engine, vocab: W.Vocabulary, batch: int, tokens: Optional[WordleTokenTable] = None,
+                 max_new_tokens: int = 6, require_words_in_vocab: bool = True, bad_word_reward: float = -10.0,
+                 traj_cap: int = 128):
+        import torch
+        t = torch
+        self.eng, self.vocab, self.B = engine, vocab, batch
+        self.tokens = tokens or WordleTokenTable.default_gpt2(pad=engine.cfg.vocab - 1)
+        self.max_new, self.cap = max_new_tokens, traj_cap
+        self.dev = engine.device
+        self._L = _lib.lib()
+        self.env = W.VectorWordleEnv(vocab, require_words_in_vocab, bad_word_reward)
+        self.env._alloc(batch)
+        self.ses = engine.session(batch, traj_cap)
+        ct = self.tokens.c_struct()
+        cls = np.ascontiguousarray(self.tokens.token_class(engine.cfg.vocab))
+        self._tok = self._L.lmrl_wordle_tok_create(ctypes.byref(ct), cls.ctypes.data, engine.cfg.vocab, max_new_tokens, traj_cap)
+        if not self._tok:
+            raise _lib.LmrlError(self._L.lmrl_last_error().decode())
+        B, G, cap = batch, max_new_tokens, traj_cap
+        z = lambda *shape, dt: t.zeros(*shape, dtype=dt, device=self.dev)
+        self.traj = dict(tokens=z(B, cap, dt=t.int32), is_action=z(B, cap, dt=t.uint8), reward=z(B, cap, dt=t.float32),
+                         n_tok=z(B, dt=t.int32), gen=z(B, G, dt=t.int32), gen_len=z(B, dt=t.int32), gen_active=z(B, dt=t.uint8),
+                         env_done=z(B, dt=t.uint8), pend_newline=z(B, dt=t.uint8), n_steps=z(B, dt=t.int32),
+                         ep_reward=z(B, dt=t.float32))
+        self._ctraj = _CTraj(*[self.traj[n].data_ptr() for n, _ in _CTraj._fields_])
+        self.chunk_tok, self.chunk_cnt = z(B * 8, dt=t.int32), z(B, dt=t.int32)
+        self.next_tok, self.next_cnt = z(B, dt=t.int32), z(B, dt=t.int32)
+        self.guess, self.active = z(B, dt=t.int32), z(B, dt=t.uint8)
+        self.steer = z(B, dt=t.int32)
+        self.sample_step = 0
+
+    def close(self):
+        if getattr(self, "_tok", None):
+            self._L.lmrl_wordle_tok_destroy(self._tok)
+            self._tok = None
+        self.env.close()
+
+    def _ck(self, rc, what):
+        _lib.check(rc, what)
+
+    def run_episode(self, seeds: np.ndarray, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0,
+                    scripted_guesses=None, steer_strength: float = 0.0, n_turns: int = W.N_TRIES):
+        """One full episode for all B envs (asynchronous: returns after enqueueing; read results after a sync).
+
+        scripted_guesses: optional int32 device tensor [n_turns][B] of packed guesses; with steer_strength > 0 the
+        sampler is steered towards spelling them (synthetic-workload hook; every logit is still computed and sampled).
+        """
+        L, sp, tr, B = self._L, _lib.stream_ptr(), ctypes.byref(self._ctraj), self.B
+        self.env.reset_device(np.asarray(seeds, dtype=np.uint64))
+        self.ses.reset()
+        self._ck(L.lmrl_wordle_tok_begin(self._tok, tr, _lib.ptr(self.chunk_tok), _lib.ptr(self.chunk_cnt), B, sp), "tok_begin")
+        self.ses.forward(self.chunk_tok, self.chunk_cnt, 8)
+        logits_out = None
+        if top_k > 0:
+            import torch
+            logits_out = torch.empty(B, self.eng.cfg.vocab_padded, dtype=torch.float32, device=self.dev)
+        for turn in range(n_turns):
+            for k in range(self.max_new):
+                steer = None
+                if scripted_guesses is not None and steer_strength != 0.0:
+                    self._ck(L.lmrl_wordle_tok_steer(self._tok, _lib.ptr(scripted_guesses[turn]), k, _lib.ptr(self.steer), B, sp), "tok_steer")
+                    steer = self.steer
+                p = SampleParams(temperature, top_k, sample_seed, self.sample_step, steer_strength, 0.0, self.tokens.pad)
+                self.sample_step += 1
+                self.ses.sample(p, steer_tok=steer, active=self.traj["gen_active"], logits_out=logits_out)
+                self._ck(L.lmrl_wordle_tok_accept(self._tok, tr, _lib.ptr(self.ses.token), k, _lib.ptr(self.next_tok),
+                                                  _lib.ptr(self.next_cnt), None, B, sp), "tok_accept")
+                if k < self.max_new - 1:
+                    self.ses.forward(self.next_tok, self.next_cnt, 1)
+            self._ck(L.lmrl_wordle_tok_guess(self._tok, tr, _lib.ptr(self.guess), _lib.ptr(self.active), B, sp), "tok_guess")
+            self.env.step_device(self.guess, self.active)
+            self._ck(L.lmrl_wordle_tok_observe(self._tok, tr, _lib.ptr(self.env.obs), _lib.ptr(self.env.reward), _lib.ptr(self.env.flags),
+                                               _lib.ptr(self.chunk_tok), _lib.ptr(self.chunk_cnt), B, sp), "tok_observe")
+            if turn < n_turns - 1:
+                self.ses.forward(self.chunk_tok, self.chunk_cnt, 8)
+        return self.traj
+
+    def token_trajectories(self):
+        """Host copies as (tokens int32[t], is_action bool[t], reward float32[t], done bool) per env —
+        the fields of LLM_RL.environment.TokenTrajectory."""
+        tok = self.traj["tokens"].cpu().numpy(); ia = self.traj["is_action"].cpu().numpy().astype(bool)
+        rw = self.traj["reward"].cpu().numpy(); n = self.traj["n_tok"].cpu().numpy(); dn = self.traj["env_done"].cpu().numpy().astype(bool)
+        return [(tok[b, :n[b]].copy(), ia[b, :n[b]].copy(), rw[b, :n[b]].copy(), bool(dn[b])) for b in range(self.B)]

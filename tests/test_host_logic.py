@@ -242,3 +242,25 @@ def test_maze_host_tables_and_text():
                 assert f(mazes[ep["maze"]], st["position"], ep["goal"]) == last
                 n += 1
     assert n > 500
+
+
+# ------------------------------------------------------------------ rollout token tables
+def test_token_class_table():
+    from lmrl_gym_amd.rollout import classify_token_string as c
+    assert c("a") == (0 | 1 << 25) and c(" b") == (1 | 1 << 25)
+    assert c("st") == ((18 | 19 << 5) | 2 << 25)
+    assert c("\n") == 1 << 28 and c("  ") == 0 and c("") == 0
+    assert c("a\n") == (0 | 1 << 25 | 1 << 29) and c("\ta") == (0 | 1 << 25 | 1 << 28)
+    assert c("a\tb") == 7 << 25 and c("A") == 7 << 25 and c("abcdef") == 7 << 25 and c("a-") == 7 << 25
+
+
+def test_wordle_token_table_roundtrip():
+    from lmrl_gym_amd.rollout import WordleTokenTable
+    t = WordleTokenTable.default_gpt2()
+    ids = t.encode_text("Wordle:\ns t a r e\ng y b b y\n\n")
+    assert ids[:4] == t.header and ids[4] == t.letter_first[18] and ids[5] == t.letter_sp[19] and ids[-1] == t.newline
+    assert len(ids) == 4 + 6 + 6 + 1
+    allids = t.letter_first + t.letter_sp + [t.newline] + t.header[:3]
+    assert len(set(allids)) == len(allids)
+    cls = t.token_class(50257)
+    assert cls[t.letter_sp[4]] == (4 | 1 << 25) and cls[12345] == 7 << 25
