@@ -35,9 +35,11 @@ __host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1,
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// u in (0,1): (x >> 8 + 0.5) * 2^-24 ; Gumbel(0,1) = -log(-log u)
+// u in (0,1): ((x >> 9) + 0.5) * 2^-23 — 23 random bits so that "+ 0.5" is exact in fp32 (with 24 bits the top value
+// rounds to u == 1.0 and the Gumbel becomes +inf once per ~16.7 M draws, i.e. several times per 1024 x 50257 sampling
+// step).  Gumbel(0,1) = -log(-log u), range [-2.8, 16.6].
 __device__ __forceinline__ float gumbel_from_bits(uint32_t x) {
-    const float u = ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-08f;
+    const float u = ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-07f;
     return -__logf(-__logf(u));
 }
 

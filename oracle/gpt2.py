@@ -94,5 +94,5 @@ def gumbel_noise(rows: int, vocab: int, seed: int, step: int):
     c = np.tile(np.arange(ncol4, dtype=np.uint64), rows)
     o = philox4x32_10(r, c, np.full_like(r, step), np.zeros_like(r), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     bits = np.stack(o, axis=1).reshape(rows, ncol4 * 4)[:, :vocab]
-    u = ((bits >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(5.9604644775390625e-08)
+    u = ((bits >> np.uint64(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.1920928955078125e-07)
     return -np.log(-np.log(u))

@@ -83,22 +83,32 @@ def test_greedy_rollout_is_consistent_with_oracle_model(setup):
     torch.cuda.synchronize()
     trajs = ro.token_trajectories()
     checked = agree = 0
+    nl = ro.tokens.newline
     for b in range(0, B, 4):
         tok, ia, rw, dn = trajs[b]
         logits = O.forward(sd, torch.from_numpy(tok.astype(np.int64))[None], cfg.n_head, dtype=torch.float64)[0]
-        # a random model never spells a word: every action is max_new tokens + forced '\n', every observation is '\n'
-        assert len(tok) == 4 + 3 * (4 + 1 + 1) and not dn
-        assert rw[ia].sum() == -30.0
-        pos = 4
-        for turn in range(3):
-            for k in range(4):
-                top2 = logits[pos - 1].topk(2)
+        assert tok[:4].tolist() == ro.tokens.header and not ia[:4].any() and not dn
+        pos, turns = 4, 0
+        while pos < len(tok):
+            # action run: sampled tokens up to eos, or max_new tokens followed by the forced '\n'
+            start = pos
+            while pos < len(tok) and ia[pos]:
+                pos += 1
+            run = tok[start:pos]
+            assert 1 <= len(run) <= 5 and run[-1] == nl
+            n_sampled = len(run) if len(run) <= 4 and nl not in run[:-1].tolist() and len(run) < 5 else 4
+            if len(run) == 5:
+                assert nl not in run[:4].tolist()          # no eos among the 4 sampled tokens -> '\n' was forced
+            for k in range(n_sampled):
+                top2 = logits[start + k - 1].topk(2)
                 if top2.values[0] - top2.values[1] > 0.05:
                     checked += 1
-                    agree += int(top2.indices[0] == tok[pos])
-                pos += 1
-            assert tok[pos] == ro.tokens.newline and ia[pos] and rw[pos] == -10.0   # forced newline carries the reward
-            assert tok[pos + 1] == ro.tokens.newline and not ia[pos + 1]
-            pos += 2
-    assert checked > 50 and agree == checked, (agree, checked)
+                    agree += int(top2.indices[0] == tok[start + k])
+            # a random model never spells a word: reward -10 on the action's last token, observation "\n"
+            assert rw[pos - 1] == -10.0 and float(np.abs(rw[start:pos - 1]).sum()) == 0.0
+            assert tok[pos] == nl and not ia[pos]
+            pos += 1
+            turns += 1
+        assert turns == 3
+    assert checked > 30 and agree == checked, (agree, checked)
     ro.close()

@@ -39,3 +39,12 @@ def test_philox_known_answer():
     assert [int(x[0]) for x in o] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
     o = philox4x32_10([0xffffffff], [0xffffffff], [0xffffffff], [0xffffffff], 0xffffffff, 0xffffffff)
     assert [int(x[0]) for x in o] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+
+
+def test_gumbel_noise_is_finite_for_extreme_bits():
+    # u must stay strictly inside (0, 1) for every 32-bit draw (fp32 rounding of the +0.5 offset)
+    import numpy as np
+    for bits in (0, 1, 0xFFFFFFFF, 0xFFFFFE00, 0x80000000):
+        u = (np.float32(bits >> 9) + np.float32(0.5)) * np.float32(1.1920928955078125e-07)
+        assert 0.0 < float(u) < 1.0
+        assert np.isfinite(-np.log(-np.log(u)))
