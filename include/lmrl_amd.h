@@ -195,6 +195,9 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
 int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda,
                    int ldc, int n_store, int epilogue, void *stream);
 
+/* bench/test hook: 0 = default GEMM kernels (global_load_lds ring), 1 = round-1 register-staged kernels */
+void lmrl_gemm_set_variant(int v);
+
 /* ------------------------------------------------------------------------------------------
  * Fused LM-head + sampling (csrc/sampler.hip).  Replaces logits[:, -1] -> warpers -> jax.random.categorical in
  * the reference's generation loop and the ILQL perturbation logits = pi_beta + beta*min(q1,q2)

@@ -23,6 +23,15 @@ const char *kTagNames[PROF_N_TAGS] = {"gemm_bf16_128x128", "gemm_bf16_64x128", "
                                       "attention_chunk", "lm_head_sample", "layernorm", "embed", "wordle_step", "wordle_reset",
                                       "wordle_tokens", "sample_reduce"};
 }  // namespace
+static unsigned long long *g_counters_d = nullptr;   // [PROF_N_TAGS]
+unsigned long long *prof_byte_counter(int tag) {
+    if (!((g_prof_mask >> tag) & 1u)) return nullptr;
+    if (!g_counters_d) {
+        if (hipMalloc(&g_counters_d, sizeof(unsigned long long) * PROF_N_TAGS) != hipSuccess) return nullptr;
+        (void)hipMemset(g_counters_d, 0, sizeof(unsigned long long) * PROF_N_TAGS);
+    }
+    return g_counters_d + tag;
+}
 void prof_begin(int tag, hipStream_t s, double work) {
     ProfRec r;
     r.tag = tag; r.work = work;
@@ -47,6 +56,7 @@ void lmrl_prof_reset(void) {
     for (auto &r : lmrl::g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     lmrl::g_recs.clear();
     for (auto &o : lmrl::g_open) o.clear();
+    if (lmrl::g_counters_d) (void)hipMemset(lmrl::g_counters_d, 0, sizeof(unsigned long long) * lmrl::PROF_N_TAGS);
 }
 
 int lmrl_prof_n_tags(void) { return lmrl::PROF_N_TAGS; }
@@ -63,6 +73,10 @@ int lmrl_prof_read(int tag, double *total_ms, double *total_work, long long *lau
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
         ms += t; w += r.work; n++;
+    }
+    if (lmrl::g_counters_d) {   // data-dependent byte counts accumulated on the device
+        unsigned long long c = 0;
+        if (hipMemcpy(&c, lmrl::g_counters_d + tag, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess && c > 0) w = (double)c;
     }
     *total_ms = ms; *total_work = w; *launches = n;
     return LMRL_OK;

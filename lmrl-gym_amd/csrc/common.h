@@ -41,6 +41,8 @@ enum ProfTag {
 extern unsigned g_prof_mask;
 void prof_begin(int tag, hipStream_t s, double work);
 void prof_end(int tag, hipStream_t s);
+// device counter (bytes) for kernels whose algorithmic traffic is data dependent; null unless the tag is enabled
+unsigned long long *prof_byte_counter(int tag);
 struct ProfScope {
     int tag; hipStream_t s; bool on;
     ProfScope(int t, hipStream_t st, double work) : tag(t), s(st), on((g_prof_mask >> t) & 1u) { if (on) prof_begin(tag, s, work); }

@@ -41,9 +41,10 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rn(float f) {
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 __device__ __forceinline__ float gelu_new(float x) {
-    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  — GPT-2 "gelu_new"
+    // GPT-2 "gelu_new": 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3)  ==  x * sigmoid(2u) = x / (1 + e^(-2u)).
+    // One v_exp + one v_rcp instead of libm tanhf (~40 instructions): the fc-GEMM epilogue applies it 25 M times per launch.
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return 0.5f * x * (1.f + tanhf(u));
+    return x * __frcp_rn(1.f + __expf(-2.f * u));
 }
 
 struct GemmArgs {
@@ -176,6 +177,206 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2 main loop: HBM -> LDS directly with global_load_lds (16 B per lane, no staging VGPRs, no ds_write pass), an
+// S-stage LDS ring and COUNTED vmcnt waits so that S-2 whole K-tiles stay in flight across the (raw) barrier.
+// LDS image per stage is lane-linear per wave instruction (1 KiB = 8 rows x 128 B), so the XOR swizzle is applied
+// to the per-lane SOURCE address: LDS slot s of row r holds global chunk s ^ (r & 7); fragment reads use the same
+// involution (guide §5.4 rule 21).  All LDS lives in the single dynamic array (guide §5 "three .s-level traps").
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// XCD-aware workgroup -> tile mapping.  MI355X dispatches workgroup id to XCD (id % 8) and each XCD has a private 4 MiB
+// L2, so with a naive id -> (tile_m, tile_n) map every XCD pulls ALL of A and W through its own L2 (8x fabric traffic,
+// which dominates the ~10 us decode GEMMs).  Here the 8 XCDs form a gm x gn grid: XCD (i, j) owns the i-th group of
+// m-tiles and the j-th group of n-tiles, walking its tiles n-panel by n-panel.  Fabric traffic becomes A*gn + W*gm;
+// the launcher picks gm to minimise it.  Placement is observed behaviour, not a contract: a different placement only
+// changes speed.  Workgroups whose tile falls outside the problem exit immediately.
+struct XcdMap { int tiles_m, tiles_n, gm, tmg, tng; };
+
+inline XcdMap make_xcd_map(int tiles_m, int tiles_n, double a_bytes, double w_bytes) {
+    XcdMap x; x.tiles_m = tiles_m; x.tiles_n = tiles_n;
+    int best = 1; double best_cost = 1e300;
+    for (int gm = 1; gm <= 8; gm *= 2) {
+        if (gm > tiles_m && gm > 1) break;
+        const double cost = a_bytes * (8 / gm) + w_bytes * gm;
+        if (cost < best_cost) { best_cost = cost; best = gm; }
+    }
+    x.gm = best;
+    x.tmg = (tiles_m + best - 1) / best;
+    x.tng = (tiles_n + (8 / best) - 1) / (8 / best);
+    return x;
+}
+inline int xcd_grid(const XcdMap &x) { return 8 * x.tmg * x.tng; }
+
+__device__ __forceinline__ bool xcd_tile(const XcdMap &x, int id, int &tile_m, int &tile_n) {
+    const int xcd = id & 7, q = id >> 3;
+    const int gn = 8 / x.gm;
+    const int gi = xcd / gn, gj = xcd - gi * gn;
+    tile_m = gi * x.tmg + (q % x.tmg);
+    tile_n = gj * x.tng + (q / x.tmg);
+    return tile_m < x.tiles_m && tile_n < x.tiles_n;
+}
+
+// Shared main loop: acc[i][j] += W-fragment i (rows n0 + wn*BN/2 + 16 i ..) x A-fragment j (rows m0 + wm*BM/2 + 16 j ..).
+// Starts with a barrier so that it can be called repeatedly on the same LDS ring (fused multi-operand kernels).
+template <int BM, int BN, int STAGES>
+__device__ __forceinline__ void glds_mainloop(const uint16_t *__restrict__ A, int lda, const uint16_t *__restrict__ W, int K, int M,
+                                              int m0, int n0, char *smem, f32x4 (&acc)[BN / 32][BM / 32]) {
+    constexpr int BK = 64;
+    constexpr int FM = BM / 32, FN = BN / 32;
+    constexpr int LA = BM / 32, LW = BN / 32;          // glds instructions per wave per stage (1 KiB segments / 4 waves)
+    constexpr int L = LA + LW;
+    constexpr int STAGE = (BM + BN) * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nk = K / BK;
+    const int lrow = lane >> 3;                 // row within the 8-row segment == (row & 7)
+    const int src_c = (lane & 7) ^ lrow;        // source chunk for LDS slot (lane & 7)
+
+    const uint16_t *ap[LA];
+    const uint16_t *wp[LW];
+#pragma unroll
+    for (int i = 0; i < LA; i++) {
+        int m = m0 + (wave + 4 * i) * 8 + lrow;
+        m = m < M ? m : M - 1;
+        ap[i] = A + (size_t)m * lda + src_c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < LW; i++) wp[i] = W + (size_t)(n0 + (wave + 4 * i) * 8 + lrow) * K + src_c * 8;
+
+#define LMRL_GLDS_ISSUE(KT, SLOT)                                                                                     \
+    do {                                                                                                              \
+        char *sb_ = smem + (SLOT) * STAGE;                                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < LA; i_++)                                                             \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ap[i_] + (size_t)(KT) * BK), \
+                                             (__attribute__((address_space(3))) void *)(sb_ + (wave + 4 * i_) * 1024), 16, 0, 0); \
+        _Pragma("unroll") for (int i_ = 0; i_ < LW; i_++)                                                             \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wp[i_] + (size_t)(KT) * BK), \
+                                             (__attribute__((address_space(3))) void *)(sb_ + BM * 128 + (wave + 4 * i_) * 1024), 16, 0, 0); \
+    } while (0)
+
+    __builtin_amdgcn_s_barrier();   // every wave is done reading the ring from a previous call
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; s++)
+        if (s < nk) LMRL_GLDS_ISSUE(s, s);
+
+    const int lr = lane & 15, lq = lane >> 4;
+    int slot = 0;
+    for (int kt = 0; kt < nk; kt++) {
+        // stage kt must have landed; up to STAGES-2 later stages may stay in flight
+        const int ahead = nk - 1 - kt;
+        if (STAGES >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
+        else if (STAGES >= 3 && ahead >= 1) wait_vmcnt<(STAGES >= 3 ? L : 0)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < nk) {
+            int nslot = slot + STAGES - 1;
+            nslot = nslot >= STAGES ? nslot - STAGES : nslot;
+            LMRL_GLDS_ISSUE(kt + STAGES - 1, nslot);
+        }
+        const char *sA = smem + slot * STAGE;
+        const char *sW = sA + BM * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            bf16x8 fw[FN], fa[FM];
+            const int c = kk * 4 + lq;
+#pragma unroll
+            for (int i = 0; i < FN; i++) {
+                const int row = wn * (BN / 2) + i * 16 + lr;
+                fw[i] = *reinterpret_cast<const bf16x8 *>(sW + row * 128 + ((c ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < FM; j++) {
+                const int row = wm * (BM / 2) + j * 16 + lr;
+                fa[j] = *reinterpret_cast<const bf16x8 *>(sA + row * 128 + ((c ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < FN; i++)
+#pragma unroll
+                for (int j = 0; j < FM; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+#undef LMRL_GLDS_ISSUE
+}
+
+template <int BM, int BN, int STAGES, int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap xm) {
+    constexpr int FM = BM / 32, FN = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n;
+    if (!xcd_tile(xm, blockIdx.x, tile_m, tile_n)) return;   // workgroup-uniform
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int lr = lane & 15, lq = lane >> 4;
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; i++)
+#pragma unroll
+        for (int j = 0; j < FM; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    glds_mainloop<BM, BN, STAGES>(g.A, g.lda, g.W, g.K, g.M, m0, n0, smem, acc);
+
+#pragma unroll
+    for (int i = 0; i < FN; i++) {
+        const int n = n0 + wn * (BN / 2) + i * 16 + lq * 4;
+        if (n >= g.n_store) continue;
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (g.bias) b4 = *reinterpret_cast<const f32x4 *>(g.bias + n);
+#pragma unroll
+        for (int j = 0; j < FM; j++) {
+            const int m = m0 + wm * (BM / 2) + j * 16 + lr;
+            if (m >= g.M) continue;
+            f32x4 v = acc[i][j] + b4;
+            if (EPI == EPI_GELU_BF16) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = gelu_new(v[r]);
+            }
+            if (EPI == EPI_RELU_BF16) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) {
+                uint2 o;
+                o.x = (uint32_t)f32_to_bf16_rn(v[0]) | ((uint32_t)f32_to_bf16_rn(v[1]) << 16);
+                o.y = (uint32_t)f32_to_bf16_rn(v[2]) | ((uint32_t)f32_to_bf16_rn(v[3]) << 16);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc + n) = o;
+            } else if (EPI == EPI_RESID_F32) {
+                f32x4 *p = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n);
+                *p = *p + v;
+            } else {
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n) = v;
+            }
+        }
+    }
+}
+
+extern int g_gemm_variant;   // test/bench hook: 0 = auto (v2), 1 = v1 register-staged kernels
+
+template <int BM, int BN, int STAGES, int EPI>
+inline hipError_t gemm_launch_glds(const GemmArgs &g, hipStream_t s) {
+    const size_t shmem = (size_t)STAGES * (BM + BN) * 128;
+    const XcdMap xm = make_xcd_map((g.M + BM - 1) / BM, g.N / BN, 2.0 * g.M * g.K, 2.0 * g.N * g.K);
+    const int tiles = xcd_grid(xm);
+    static bool attr_set = false;
+    if (!attr_set && shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_glds_kernel<BM, BN, STAGES, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    {
+        ProfScope ps(BM == 128 && BN == 128 ? PROF_GEMM_128x128 : (BM * BN == 128 * 64 ? PROF_GEMM_64x128 : PROF_GEMM_64x64), s,
+                     2.0 * (double)g.M * (double)g.N * (double)g.K);
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, STAGES, EPI>), dim3(tiles), dim3(256), shmem, s, g, xm);
+    }
+    return hipGetLastError();
+}
+
 template <int BM, int BN, int EPI>
 inline hipError_t gemm_launch_cfg(const GemmArgs &g, hipStream_t s) {
     const size_t shmem = 2 * (BM + BN) * 128;
@@ -199,9 +400,28 @@ inline hipError_t gemm_launch_cfg(const GemmArgs &g, hipStream_t s) {
 template <int EPI>
 inline hipError_t gemm_launch(const GemmArgs &g, hipStream_t s) {
     const long t128 = (long)((g.M + 127) / 128) * (g.N / 128);
-    if (g.N % 128 == 0 && t128 >= 192) return gemm_launch_cfg<128, 128, EPI>(g, s);
-    if (g.N % 128 == 0 && (long)((g.M + 63) / 64) * (g.N / 128) >= 192) return gemm_launch_cfg<64, 128, EPI>(g, s);
-    return gemm_launch_cfg<64, 64, EPI>(g, s);
+    if (g_gemm_variant == 1) {
+        if (g.N % 128 == 0 && t128 >= 192) return gemm_launch_cfg<128, 128, EPI>(g, s);
+        if (g.N % 128 == 0 && (long)((g.M + 63) / 64) * (g.N / 128) >= 192) return gemm_launch_cfg<64, 128, EPI>(g, s);
+        return gemm_launch_cfg<64, 64, EPI>(g, s);
+    }
+    switch (g_gemm_variant) {   // forced configurations for tools/bench_gemm.py
+        case 10: return gemm_launch_glds<128, 128, 2, EPI>(g, s);
+        case 11: return gemm_launch_glds<128, 128, 3, EPI>(g, s);
+        case 12: return gemm_launch_glds<128, 128, 4, EPI>(g, s);
+        case 20: return gemm_launch_glds<128, 64, 2, EPI>(g, s);
+        case 21: return gemm_launch_glds<128, 64, 3, EPI>(g, s);
+        case 22: return gemm_launch_glds<128, 64, 4, EPI>(g, s);
+        case 30: return gemm_launch_glds<64, 64, 2, EPI>(g, s);
+        case 31: return gemm_launch_glds<64, 64, 3, EPI>(g, s);
+        case 32: return gemm_launch_glds<64, 64, 4, EPI>(g, s);
+        default: break;
+    }
+    // measured on MI355X (profiles/r01_gemm_config_sweep.txt): occupancy beats ring depth — 2-stage rings (2+ workgroups
+    // per CU) win everywhere except the long-K skinny GEMM, which wants 4 stages in flight.
+    if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI>(g, s);
+    if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI>(g, s);
+    return gemm_launch_glds<64, 64, 2, EPI>(g, s);
 }
 
 }  // namespace lmrl

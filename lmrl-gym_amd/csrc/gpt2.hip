@@ -127,6 +127,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------ attention
+// DPP lane move on a float (VALU, no LDS round trip): CTRL as in the ISA (quad_perm 0x00-0xFF, row_half_mirror 0x141 ...)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+
 // One wave per (env b, head h).  Keys/values stream from the KV cache (positions < len[b]) and from this
 // chunk's own qkv rows (positions >= len[b]); the new K/V rows are appended to the cache on the way.
 // Lane (rr = lane>>3, cc = lane&7) holds 8 head-dims (16 B) of row t0+rr: a load instruction covers
@@ -175,6 +181,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
             q[j][2 * k + 1] = bf16_to_f32((uint16_t)(w[k] >> 16)) * 0.125f;
         }
     }
+    // Online softmax state is kept PER ROW-GROUP (the 8 lanes sharing rr): a lane only ever accumulates the keys of its own
+    // rows, so its (m, l, o) can be rescaled independently; the 8 groups are merged once at the end with log-sum-exp
+    // weights.  Per key block and query this leaves only the 8-lane dot-product reduction, done with DPP moves
+    // (quad_perm xor1, xor2, row_half_mirror) instead of ds_bpermute shuffles.
     float m[C], l[C], o[C][8];
 #pragma unroll
     for (int j = 0; j < C; j++) {
@@ -207,12 +217,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; e++) s = fmaf(q[j][e], kf[e], s);
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            s += dpp_f32<0xB1>(s);      // quad_perm [1,0,3,2]  (lane ^ 1)
+            s += dpp_f32<0x4E>(s);      // quad_perm [2,3,0,1]  (lane ^ 2)
+            s += dpp_f32<0x141>(s);     // row_half_mirror: the other quad of this 8-lane group
             const bool ok = in_range && t <= L0 + j;   // causal: query j sits at position L0 + j
-            s = ok ? s : -1e30f;
-            float bm = s;
-            bm = fmaxf(bm, __shfl_xor(bm, 8)); bm = fmaxf(bm, __shfl_xor(bm, 16)); bm = fmaxf(bm, __shfl_xor(bm, 32));
-            const float m_new = fmaxf(m[j], bm);
+            const float m_new = ok ? fmaxf(m[j], s) : m[j];
             const float alpha = __expf(m[j] - m_new);
             const float p = ok ? __expf(s - m_new) : 0.f;
             l[j] = l[j] * alpha + p;
@@ -224,13 +233,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
 #pragma unroll
     for (int j = 0; j < C; j++) {
         if (j >= n_new) continue;
-        float lt = l[j];
+        // merge the 8 row-groups: M = max m_g ; weight w_g = exp(m_g - M)
+        float mm = m[j];
+        mm = fmaxf(mm, __shfl_xor(mm, 8)); mm = fmaxf(mm, __shfl_xor(mm, 16)); mm = fmaxf(mm, __shfl_xor(mm, 32));
+        const float w = __expf(m[j] - mm);
+        float lt = l[j] * w;
         lt += __shfl_xor(lt, 8); lt += __shfl_xor(lt, 16); lt += __shfl_xor(lt, 32);
         const float inv = 1.f / lt;
         float r8[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            float a = o[j][e];
+            float a = o[j][e] * w;
             a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
             r8[e] = a * inv;
         }
@@ -245,6 +258,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
     }
 }
 
+// profiling only (one launch per forward): algorithmic HBM bytes of the attention launches of this forward =
+// per (env, head, layer): K and V rows of every attended position (2 x 128 B) + the chunk's q rows and output rows.
+__global__ void attn_bytes_kernel(const int32_t *cnt, const int32_t *len, int B, int C, int heads_x_layers,
+                                  unsigned long long *counter) {
+    unsigned long long s = 0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const int n = min(cnt[b], C);
+        if (n > 0) s += (unsigned long long)(len[b] + n) * 256ull + (unsigned long long)n * 256ull;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    __shared__ unsigned long long red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(counter, (red[0] + red[1] + red[2] + red[3]) * (unsigned long long)heads_x_layers);
+}
+
 // rows_idx[b] = row of env b's last new token (or -1), then len[b] += cnt[b]
 __global__ void advance_kernel(const int32_t *cnt, int32_t *len, int32_t *rows_idx, int B, int C) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -253,6 +283,8 @@ __global__ void advance_kernel(const int32_t *cnt, int32_t *len, int32_t *rows_i
     rows_idx[b] = n > 0 ? b * C + n - 1 : -1;
     if (n > 0) len[b] += n;
 }
+
+int g_gemm_variant = 0;
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -331,6 +363,8 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
     Gpt2Ws w; w.carve(ws_d, cf, M, b);
     const size_t kv_layer = (size_t)b * cf.n_head * tmax * 64;
 
+    if (unsigned long long *ctr = prof_byte_counter(c == 1 ? PROF_ATTN_DECODE : PROF_ATTN_CHUNK))
+        hipLaunchKernelGGL(attn_bytes_kernel, dim3(1), dim3(256), 0, s, cnt_d, len_d, b, c, cf.n_head * cf.n_layer, ctr);
     hipLaunchKernelGGL(embed_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, s, m->wte, m->wpe, tokens_d, cnt_d, len_d, w.x, b, c, d,
                        cf.vocab, cf.n_pos);
     LMRL_CHECK_LAUNCH();
@@ -373,6 +407,8 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
     }
     return LMRL_OK;
 }
+
+void lmrl_gemm_set_variant(int v) { lmrl::g_gemm_variant = v; }
 
 // Plain bf16 GEMM entry (heads, LM-head logits): C = A.W^T + bias with a selectable epilogue.
 int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda,

@@ -54,9 +54,22 @@ struct SampleParams {
 
 constexpr int kPartialFloats = 6;   // {max, sumexp, best_score, best_col, best_z, pad}
 
-// LM head:   z[m][n] = (h[m] . wte[n]) * invT   (+ ILQL perturbation, + steer)
-// One 128 x 128 tile per workgroup, same staging/MFMA structure as gemm_bf16_kernel, up to three GEMM passes
-// over the same output tile (pi, q1, q2) combined in registers before the sampling epilogue.
+// LM head:   z[m][n] = (h[m] . wte[n])   (+ ILQL perturbation, + steer), then the sampling epilogue on z / T.
+// One 128 x 64 tile per workgroup on the shared global_load_lds main loop (gemm_bf16.h), up to three GEMM passes over
+// the same output tile (pi, q1, q2) combined in registers.  The two column-half waves of a row merge their partials
+// through LDS so exactly one partial per (row, 64-column tile) reaches HBM.
+constexpr int kLmBM = 128, kLmBN = 64, kLmStages = 2;
+
+struct RowPartial { float pmax, psum, best, best_z; int best_col; };
+
+__device__ __forceinline__ void merge_partial(RowPartial &a, float om, float os, float ob, float oz, int oc) {
+    const float nm = fmaxf(a.pmax, om);
+    const float e1 = (a.pmax == -INFINITY) ? 0.f : __expf(a.pmax - nm), e2 = (om == -INFINITY) ? 0.f : __expf(om - nm);
+    a.psum = a.psum * e1 + os * e2;
+    a.pmax = nm;
+    if (ob > a.best || (ob == a.best && oc < a.best_col)) { a.best = ob; a.best_col = oc; a.best_z = oz; }
+}
+
 template <int NOPS>
 __global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__restrict__ A0, const uint16_t *__restrict__ W0,
                                                              const uint16_t *__restrict__ A1, const uint16_t *__restrict__ W1,
@@ -64,21 +77,18 @@ __global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__r
                                                              const uint16_t *__restrict__ A2, const uint16_t *__restrict__ W2,
                                                              const float *__restrict__ bias2,
                                                              const int32_t *__restrict__ steer_tok,
-                                                             float *__restrict__ partials,   // [M][2*tiles_n][kPartialFloats]
+                                                             float *__restrict__ partials,   // [M][tiles_n][kPartialFloats]
                                                              float *__restrict__ logits_out, // optional [M][ldo] f32
-                                                             int M, int N, int K, int ldo, SampleParams sp) {
-    constexpr int BM = 128, BN = 128, BK = 64, FM = 4, FN = 4, CH = 4;
+                                                             int M, int N, int K, int ldo, SampleParams sp, XcdMap xm) {
+    constexpr int BM = kLmBM, BN = kLmBN, FM = BM / 32, FN = BN / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *sA = smem;
-    char *sW = smem + 2 * BM * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_m = (M + BM - 1) / BM;
     const int tiles_n = N / BN;
-    const int tile_m = blockIdx.x % tiles_m, tile_n = blockIdx.x / tiles_m;
+    int tile_m, tile_n;
+    if (!xcd_tile(xm, blockIdx.x, tile_m, tile_n)) return;   // workgroup-uniform
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int lr = lane & 15, lq = lane >> 4;
-    const int nk = K / BK;
 
     f32x4 z[FN][FM];     // combined logits
     f32x4 qmin[FN][FM];  // running min(q1, q2) for the ILQL form
@@ -92,59 +102,10 @@ __global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__r
         for (int i = 0; i < FN; i++)
 #pragma unroll
             for (int j = 0; j < FM; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x4 ra[CH], rw[CH];
-#define LMRL_LM_LOAD_TILES(KT)                                                                               \
-    do {                                                                                                     \
-        _Pragma("unroll") for (int i_ = 0; i_ < CH; i_++) {                                                  \
-            const int id_ = tid + i_ * 256, row_ = id_ >> 3, c_ = id_ & 7;                                   \
-            int m_ = m0 + row_;                                                                              \
-            m_ = m_ < M ? m_ : M - 1;                                                                        \
-            ra[i_] = *reinterpret_cast<const u32x4 *>(A + (size_t)m_ * K + (size_t)(KT) * BK + c_ * 8);      \
-            rw[i_] = *reinterpret_cast<const u32x4 *>(W + (size_t)(n0 + row_) * K + (size_t)(KT) * BK + c_ * 8); \
-        }                                                                                                    \
-    } while (0)
-#define LMRL_LM_STORE_TILES(BUF)                                                                             \
-    do {                                                                                                     \
-        _Pragma("unroll") for (int i_ = 0; i_ < CH; i_++) {                                                  \
-            const int id_ = tid + i_ * 256, row_ = id_ >> 3, c_ = id_ & 7;                                   \
-            *reinterpret_cast<u32x4 *>(sA + (BUF) * BM * 128 + row_ * 128 + ((c_ ^ (row_ & 7)) << 4)) = ra[i_]; \
-            *reinterpret_cast<u32x4 *>(sW + (BUF) * BN * 128 + row_ * 128 + ((c_ ^ (row_ & 7)) << 4)) = rw[i_]; \
-        }                                                                                                    \
-    } while (0)
-        __syncthreads();   // previous operand's last reads are done before buffer 0 is overwritten
-        LMRL_LM_LOAD_TILES(0);
-        LMRL_LM_STORE_TILES(0);
-        __syncthreads();
-        for (int kt = 0; kt < nk; kt++) {
-            const int buf = kt & 1;
-            if (kt + 1 < nk) LMRL_LM_LOAD_TILES(kt + 1);
-#pragma unroll
-            for (int kk = 0; kk < 2; kk++) {
-                bf16x8 fw[FN], fa[FM];
-                const int c = kk * 4 + lq;
-#pragma unroll
-                for (int i = 0; i < FN; i++) {
-                    const int row = wn * 64 + i * 16 + lr;
-                    fw[i] = *reinterpret_cast<const bf16x8 *>(sW + buf * BN * 128 + row * 128 + ((c ^ (row & 7)) << 4));
-                }
-#pragma unroll
-                for (int j = 0; j < FM; j++) {
-                    const int row = wm * 64 + j * 16 + lr;
-                    fa[j] = *reinterpret_cast<const bf16x8 *>(sA + buf * BM * 128 + row * 128 + ((c ^ (row & 7)) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < FN; i++)
-#pragma unroll
-                    for (int j = 0; j < FM; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
-            }
-            if (kt + 1 < nk) LMRL_LM_STORE_TILES(buf ^ 1);
-            __syncthreads();
-        }
-        // fold this operand in
+        glds_mainloop<BM, BN, kLmStages>(A, K, W, K, M, m0, n0, smem, acc);
 #pragma unroll
         for (int i = 0; i < FN; i++) {
-            const int n = n0 + wn * 64 + i * 16 + lq * 4;
+            const int n = n0 + wn * (BN / 2) + i * 16 + lq * 4;
             f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
             if (op == 1 && bias1) b4 = *reinterpret_cast<const f32x4 *>(bias1 + n);
             if (op == 2 && bias2) b4 = *reinterpret_cast<const f32x4 *>(bias2 + n);
@@ -162,15 +123,16 @@ __global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__r
     }
 
     // ---- sampling epilogue
+    __syncthreads();                                   // the LDS ring is free: reuse it for the wn=1 -> wn=0 hand-off
+    float *xch = reinterpret_cast<float *>(smem);      // [2 (wm)][64 rows][5]
 #pragma unroll
     for (int j = 0; j < FM; j++) {
-        const int m = m0 + wm * 64 + j * 16 + lr;
+        const int m = m0 + wm * (BM / 2) + j * 16 + lr;
         const int st = (steer_tok && m < M) ? steer_tok[m] : -1;
-        float pmax = -INFINITY, psum = 0.f, best = -INFINITY, best_z = 0.f;
-        int best_col = 0;
+        RowPartial rp{-INFINITY, 0.f, -INFINITY, 0.f, 0x7fffffff};
 #pragma unroll
         for (int i = 0; i < FN; i++) {
-            const int n = n0 + wn * 64 + i * 16 + lq * 4;
+            const int n = n0 + wn * (BN / 2) + i * 16 + lq * 4;
             uint32_t rnd[4] = {0, 0, 0, 0};
             if (!sp.greedy) philox4x32_10((uint32_t)m, (uint32_t)(n >> 2), sp.step, 0u, sp.seed_lo, sp.seed_hi, rnd);
             float zz[4];
@@ -187,30 +149,33 @@ __global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__r
                 const bool colok = (n + r) < sp.vocab;
                 const float v = colok ? zz[r] * sp.inv_temperature : -INFINITY;
                 const float sc = sp.greedy ? v : v + gumbel_from_bits(rnd[r]);
-                if (colok && sc > best) { best = sc; best_col = n + r; best_z = v; }
+                if (colok && sc > rp.best) { rp.best = sc; rp.best_col = n + r; rp.best_z = v; }
                 if (colok) {
-                    const float nm = fmaxf(pmax, v);
-                    psum = psum * __expf(pmax - nm) + __expf(v - nm);
-                    pmax = nm;
+                    const float nm = fmaxf(rp.pmax, v);
+                    rp.psum = rp.psum * __expf(rp.pmax - nm) + __expf(v - nm);
+                    rp.pmax = nm;
                 }
             }
         }
         // merge the 4 lane groups (lq) that hold the same row: xor 16, 32
 #pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-            const float om = __shfl_xor(pmax, o), os = __shfl_xor(psum, o);
-            const float ob = __shfl_xor(best, o), oz = __shfl_xor(best_z, o);
-            const int oc = __shfl_xor(best_col, o);
-            const float nm = fmaxf(pmax, om);
-            const float e1 = (pmax == -INFINITY) ? 0.f : __expf(pmax - nm), e2 = (om == -INFINITY) ? 0.f : __expf(om - nm);
-            psum = psum * e1 + os * e2;
-            pmax = nm;
-            if (ob > best || (ob == best && oc < best_col)) { best = ob; best_col = oc; best_z = oz; }
+        for (int o = 16; o <= 32; o <<= 1)
+            merge_partial(rp, __shfl_xor(rp.pmax, o), __shfl_xor(rp.psum, o), __shfl_xor(rp.best, o), __shfl_xor(rp.best_z, o),
+                          __shfl_xor(rp.best_col, o));
+        const int rl = j * 16 + lr;                     // row within this wave's 64-row half
+        float *slot = xch + ((size_t)wm * 64 + rl) * 5;
+        if (wn == 1 && lq == 0) {
+            slot[0] = rp.pmax; slot[1] = rp.psum; slot[2] = rp.best; slot[3] = rp.best_z; slot[4] = __int_as_float(rp.best_col);
         }
-        if (lq == 0 && m < M) {
-            float *p = partials + ((size_t)m * (2 * tiles_n) + (size_t)tile_n * 2 + wn) * kPartialFloats;
-            p[0] = pmax; p[1] = psum; p[2] = best; p[3] = __int_as_float(best_col); p[4] = best_z; p[5] = 0.f;
+        __syncthreads();
+        if (wn == 0 && lq == 0) {
+            merge_partial(rp, slot[0], slot[1], slot[2], slot[3], __float_as_int(slot[4]));
+            if (m < M) {
+                float *p = partials + ((size_t)m * tiles_n + tile_n) * kPartialFloats;
+                p[0] = rp.pmax; p[1] = rp.psum; p[2] = rp.best; p[3] = __int_as_float(rp.best_col); p[4] = rp.best_z; p[5] = 0.f;
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -349,7 +314,7 @@ using namespace lmrl;
 extern "C" {
 
 size_t lmrl_sample_ws_bytes(int m, int vocab_padded) {
-    return (size_t)m * (size_t)(2 * (vocab_padded / 128)) * kPartialFloats * sizeof(float);
+    return (size_t)m * (size_t)(vocab_padded / kLmBN) * kPartialFloats * sizeof(float);
 }
 
 int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_hidden1_d, const void *q_w1_d,
@@ -365,8 +330,9 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     sp.seed_lo = (uint32_t)p->seed; sp.seed_hi = (uint32_t)(p->seed >> 32); sp.step = p->step;
     sp.steer_strength = p->steer_strength; sp.beta = p->beta; sp.vocab = vocab;
     hipStream_t s = as_stream(stream);
-    const int tiles = ((m + 127) / 128) * (vocab_padded / 128);
-    const size_t shmem = 2 * 256 * 128;
+    const XcdMap xm = make_xcd_map((m + kLmBM - 1) / kLmBM, vocab_padded / kLmBN, 2.0 * m * d_model, 2.0 * (double)vocab_padded * d_model);
+    const int tiles = xcd_grid(xm);
+    const size_t shmem = (size_t)kLmStages * (kLmBM + kLmBN) * 128;
     const int nops = (q_hidden1_d && q_w1_d) ? ((q_hidden2_d && q_w2_d) ? 3 : 2) : 1;
     float *partials = (float *)ws_d;
     const uint16_t *A0 = (const uint16_t *)hidden_d, *W0 = (const uint16_t *)wte_d;
@@ -376,13 +342,13 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     ProfScope ps(PROF_LM_HEAD_SAMPLE, s, 2.0 * (double)m * (double)vocab_padded * (double)d_model * nops);
     if (nops == 1)
         hipLaunchKernelGGL(lm_head_sample_kernel<1>, dim3(tiles), dim3(256), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
-                           steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp);
+                           steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm);
     else if (nops == 2)
         hipLaunchKernelGGL(lm_head_sample_kernel<2>, dim3(tiles), dim3(256), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
-                           steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp);
+                           steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm);
     else
         hipLaunchKernelGGL(lm_head_sample_kernel<3>, dim3(tiles), dim3(256), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
-                           steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp);
+                           steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm);
     }
     LMRL_CHECK_LAUNCH();
     if (p->top_k > 0 && p->top_k < vocab) {
@@ -391,7 +357,7 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
                            token_d, logprob_d, sp, p->pad_token);
     } else {
         hipLaunchKernelGGL(sample_reduce_kernel, dim3(ceil_div(m, 4)), dim3(256), 0, s, partials, active_d, token_d, logprob_d, m,
-                           2 * (vocab_padded / 128), p->pad_token);
+                           vocab_padded / kLmBN, p->pad_token);
     }
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;

@@ -182,11 +182,20 @@ class WordleRolloutEngine:
         scripted_guesses: optional int32 device tensor [n_turns][B] of packed guesses; with steer_strength > 0 the
         sampler is steered towards spelling them (synthetic-workload hook; every logit is still computed and sampled).
         """
+        for _ in self.episode_phases(seeds, temperature, top_k, sample_seed, scripted_guesses, steer_strength, n_turns):
+            pass
+        return self.traj
+
+    def episode_phases(self, seeds: np.ndarray, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0,
+                       scripted_guesses=None, steer_strength: float = 0.0, n_turns: int = W.N_TRIES):
+        """Generator form of `run_episode`: enqueues one phase (a model forward + its sampling / env bookkeeping) per
+        `next()`, so a host loop can interleave several engines on different HIP streams."""
         L, sp, tr, B = self._L, _lib.stream_ptr(), ctypes.byref(self._ctraj), self.B
         self.env.reset_device(np.asarray(seeds, dtype=np.uint64))
         self.ses.reset()
         self._ck(L.lmrl_wordle_tok_begin(self._tok, tr, _lib.ptr(self.chunk_tok), _lib.ptr(self.chunk_cnt), B, sp), "tok_begin")
         self.ses.forward(self.chunk_tok, self.chunk_cnt, 8)
+        yield
         logits_out = None
         if top_k > 0:
             import torch
@@ -204,13 +213,14 @@ class WordleRolloutEngine:
                                                   _lib.ptr(self.next_cnt), None, B, sp), "tok_accept")
                 if k < self.max_new - 1:
                     self.ses.forward(self.next_tok, self.next_cnt, 1)
+                    yield
             self._ck(L.lmrl_wordle_tok_guess(self._tok, tr, _lib.ptr(self.guess), _lib.ptr(self.active), B, sp), "tok_guess")
             self.env.step_device(self.guess, self.active)
             self._ck(L.lmrl_wordle_tok_observe(self._tok, tr, _lib.ptr(self.env.obs), _lib.ptr(self.env.reward), _lib.ptr(self.env.flags),
                                                _lib.ptr(self.chunk_tok), _lib.ptr(self.chunk_cnt), B, sp), "tok_observe")
             if turn < n_turns - 1:
                 self.ses.forward(self.chunk_tok, self.chunk_cnt, 8)
-        return self.traj
+            yield
 
     def token_trajectories(self):
         """Host copies as (tokens int32[t], is_action bool[t], reward float32[t], done bool) per env —
