@@ -295,6 +295,67 @@ int lmrl_prof_n_tags(void);
 const char *lmrl_prof_tag_name(int tag);
 int lmrl_prof_read(int tag, double *total_ms, double *total_work, long long *launches);
 
+/* ------------------------------------------------------------------------------------------
+ * fp32 train-step building blocks (csrc/sgemm_f32.hip, csrc/train_ops.hip, csrc/losses.hip).
+ * Together they restate GPT2PPOTrain._step / GPT2ILQLTrain._step (LLM_RL/algorithms/ppo/gpt2/interface.py:72-211,
+ * LLM_RL/algorithms/ilql/gpt2/interface.py:88-367) in float32, the reference's default parameter/activation dtype.
+ * ------------------------------------------------------------------------------------------ */
+/* C[b] = alpha*op(A[b]).op(B[b]) + beta*C[b] (+bias[n]); row-major; op(A) MxK (trans_a: stored KxM), op(B) KxN
+ * (trans_b: stored NxK); batch index = outer*nb_inner + inner with separate element strides. Exact fp32 (MFMA f32). */
+int lmrl_sgemm(int trans_a, int trans_b, int m, int n, int k, float alpha, const float *a_d, int lda, long sa_outer,
+               long sa_inner, const float *b_d, int ldb, long sb_outer, long sb_inner, float beta, float *c_d, int ldc,
+               long sc_outer, long sc_inner, int nb_outer, int nb_inner, const float *bias_d, void *stream);
+int lmrl_embed_fwd(const float *wte_d, const float *wpe_d, const int32_t *ids_d, const int32_t *pos_d, float *x_d, int rows, int d, void *stream);
+int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d, float *dwte_d, float *dwpe_d, int rows, int d, void *stream);
+int lmrl_layernorm_fwd(const float *x_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, int rows, int d,
+                       float eps, void *stream);
+/* dx (=|+=) LN backward; dy_xhat_d (optional [rows][d]) receives dy*xhat whose column sum is d gamma */
+int lmrl_layernorm_bwd(const float *dy_d, const float *x_d, const float *g_d, const float *mean_d, const float *rstd_d, float *dx_d,
+                       float *dy_xhat_d, int rows, int d, int accumulate_dx, void *stream);
+size_t lmrl_colsum_ws_bytes(int cols);
+int lmrl_colsum(const float *x_d, int rows, int cols, int ld, float *out_d, int accumulate, float *ws_d, void *stream);
+int lmrl_gelu_fwd(const float *x_d, float *y_d, size_t n, void *stream);
+int lmrl_gelu_bwd(const float *dy_d, const float *x_d, float *dx_d, size_t n, void *stream);
+int lmrl_relu_fwd(const float *x_d, float *y_d, size_t n, void *stream);
+int lmrl_relu_bwd(const float *dy_d, const float *x_d, float *dx_d, size_t n, void *stream);
+/* out = a*x + b*y (y may be NULL).  Polyak: optax.incremental_update(new, old, s) = axpby(s, new, 1-s, old). */
+int lmrl_axpby(float a, const float *x_d, float b, const float *y_d, float *out_d, size_t n, void *stream);
+/* optax.adamw(b1, b2, eps, weight_decay) with bias correction at `step` (1-based) */
+int lmrl_adamw(float *p_d, const float *g_d, float *m_d, float *v_d, size_t n, float lr, float b1, float b2, float eps, float weight_decay,
+               int step, void *stream);
+/* P = causal (+ key padding mask [batch][t] uint8) softmax of S [batch*heads][t][t]; in place allowed */
+int lmrl_softmax_causal_fwd(const float *s_d, const uint8_t *key_mask_d, float *p_d, int batch, int heads, int t, void *stream);
+int lmrl_softmax_bwd(const float *p_d, float *dp_d, long rows, int t, void *stream);
+/* per row: lse = logsumexp(logits[:vocab]), target logit, logprob = target - lse
+ * (= -optax.softmax_cross_entropy_with_integer_labels; PPOInference.token_logprobs_from_logits, ppo/base_interface.py:396-403) */
+int lmrl_lse_gather(const float *logits_d, int ld, int vocab, const int32_t *targets_d, float *logprob_d, float *lse_d,
+                    float *target_logit_d, int rows, void *stream);
+/* logits := coef_ce[r]*(softmax - onehot(t)) + coef_gather[r]*onehot(t)  (CE backward + take_along_axis backward) */
+int lmrl_ce_bwd(float *logits_d, int ld, int vocab, const float *lse_d, const int32_t *targets_d, const float *coef_ce_d,
+                const float *coef_gather_d, int rows, void *stream);
+/* n = sum(should_take_action * attention_mask) as a device double */
+int lmrl_mask_sum(const uint8_t *sta_d, const float *attn_d, size_t n, double *out_d, void *stream);
+/* ppo_loss_fn forward+backward (ppo/base_interface.py:72-142). partials_d: [lmrl_ppo_loss_blocks(n)][lmrl_ppo_loss_nstats()]
+ * doubles (layout in csrc/losses.hip), d_logprobs_d / d_values_d: gradient of the scalar loss. */
+int lmrl_ppo_loss_blocks(size_t n);
+int lmrl_ppo_loss_nstats(void);
+int lmrl_ppo_loss(const float *attn_d, const float *logprobs_d, const float *values_d, const uint8_t *sta_d, const float *old_logprobs_d,
+                  const float *old_values_d, const float *old_adv_d, const float *old_ret_d, size_t n, float cliprange_value,
+                  float cliprange, float value_loss_coef, const double *n_mask_d, double *partials_d, float *d_logprobs_d,
+                  float *d_values_d, void *stream);
+/* ilql_loss forward+backward (ilql/base_interface.py:29-119) on gathered q1/q2/v/target-q [b][t1], v_final [b], per-token
+ * CQL cross-entropies ce1/ce2 [b][t1]. partials_d: [b][lmrl_ilql_loss_nstats()] doubles. Outputs dq1,dq2,dv,coef_ce [b][t1]. */
+int lmrl_ilql_loss_nstats(void);
+int lmrl_ilql_loss(const float *q1_d, const float *q2_d, const float *v_d, const float *v_final_d, const float *tq1_d, const float *tq2_d,
+                   const float *ce1_d, const float *ce2_d, const float *attn_d, const uint8_t *sta_d, const float *rewards_d, int b, int t1,
+                   float gamma, float tau, float cql_weight, const double *n_mask_d, double *partials_d, float *dq1_d, float *dq2_d,
+                   float *dv_d, float *coef_ce_d, void *stream);
+/* mc_loss forward+backward (mc_returns/base_interface.py:19-60) */
+int lmrl_mc_loss_blocks(size_t n);
+int lmrl_mc_loss_nstats(void);
+int lmrl_mc_loss(const float *q_d, const float *ce_d, const float *attn_d, const uint8_t *sta_d, const float *returns_d, size_t n,
+                 float cql_weight, const double *n_mask_d, double *partials_d, float *dq_d, float *coef_ce_d, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

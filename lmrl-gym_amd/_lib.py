@@ -61,6 +61,33 @@ _SIGS = {
     "lmrl_prof_n_tags": (c_int, []),
     "lmrl_prof_tag_name": (c_char_p, [c_int]),
     "lmrl_prof_read": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
+    "lmrl_sgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, ctypes.c_long, ctypes.c_long, c_void_p, c_int,
+                           ctypes.c_long, ctypes.c_long, c_float, c_void_p, c_int, ctypes.c_long, ctypes.c_long, c_int, c_int, c_void_p, c_void_p]),
+    "lmrl_embed_fwd": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "lmrl_embed_bwd": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "lmrl_layernorm_fwd": (c_int, [c_void_p] * 6 + [c_int, c_int, c_float, c_void_p]),
+    "lmrl_layernorm_bwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
+    "lmrl_colsum_ws_bytes": (c_size_t, [c_int]),
+    "lmrl_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "lmrl_gelu_fwd": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lmrl_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lmrl_relu_fwd": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lmrl_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lmrl_axpby": (c_int, [c_float, c_void_p, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lmrl_adamw": (c_int, [c_void_p] * 4 + [c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
+    "lmrl_softmax_causal_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "lmrl_softmax_bwd": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_int, c_void_p]),
+    "lmrl_lse_gather": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_ce_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_mask_sum": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "lmrl_ppo_loss_blocks": (c_int, [c_size_t]),
+    "lmrl_ppo_loss_nstats": (c_int, []),
+    "lmrl_ppo_loss": (c_int, [c_void_p] * 8 + [c_size_t, c_float, c_float, c_float] + [c_void_p] * 5),
+    "lmrl_ilql_loss_nstats": (c_int, []),
+    "lmrl_ilql_loss": (c_int, [c_void_p] * 11 + [c_int, c_int, c_float, c_float, c_float] + [c_void_p] * 7),
+    "lmrl_mc_loss_blocks": (c_int, [c_size_t]),
+    "lmrl_mc_loss_nstats": (c_int, []),
+    "lmrl_mc_loss": (c_int, [c_void_p] * 5 + [c_size_t, c_float] + [c_void_p] * 5),
     "lmrl_sample_logits": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -1,0 +1,255 @@
+"""ILQL on the MI355X engine — counterpart of LLM_RL/algorithms/ilql/{base_interface,data,gpt2/interface}.py.
+
+`ilql_loss` (numpy face, reference signature), `ILQLData` / `ILQLDataset`, and `GPT2ILQLTrain.step(...)` which restates
+`GPT2ILQLTrain._step` (ilql/gpt2/interface.py:88-367): base forward (+ frozen target base), q1/q2/v MLP heads, target q
+heads, Q(s,a) gathers, `v_final`, the loss, gradients w.r.t. (base, q1, q2, v), four AdamW updates and the Polyak / hard
+target updates — all arithmetic in HIP kernels (sgemm_f32, train_ops, `lmrl_ilql_loss`).
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, List, NamedTuple, Optional
+
+import numpy as np
+
+from .. import _lib
+from ..train import ops
+from ..train.gpt2_f32 import AdamW, GPT2F32, MLPHeadF32
+from .common import BlockingStrategy, block_sequences, initialize_attn_mask_pos_ids, stats_from_sums
+from .ppo import _t
+
+
+# ----------------------------------------------------------------------------- data (ilql/data.py:10-132)
+class ILQLData(NamedTuple):
+    input_ids: np.ndarray            # [t]
+    should_take_action: np.ndarray   # [t-1]
+    rewards: np.ndarray              # [t-1]
+    done: np.ndarray                 # []
+    next_token_ids: Optional[np.ndarray]
+    next_done: Optional[np.ndarray]
+
+    @staticmethod
+    def block(data: List["ILQLData"], blocking_strategy: BlockingStrategy, tokenizer) -> Dict[str, np.ndarray]:
+        has_next = any(x.next_token_ids is not None for x in data)
+        assert all(x.next_token_ids is None for x in data) or has_next
+        sm = blocking_strategy._replace(max_length=blocking_strategy.max_length - 1)
+        col = lambda name: [getattr(x, name) for x in data]
+        return dict(
+            input_ids=block_sequences(col("input_ids"), tokenizer.pad_token_id, np.int32, blocking_strategy),
+            should_take_action=block_sequences(col("should_take_action"), False, np.bool_, sm),
+            rewards=block_sequences(col("rewards"), 0.0, np.float32, sm),
+            dones=np.asarray(col("done"), dtype=np.bool_),
+            next_token_ids=block_sequences(col("next_token_ids"), tokenizer.pad_token_id, np.int32, blocking_strategy) if has_next else None,
+            next_dones=np.asarray(col("next_done"), dtype=np.bool_) if has_next else None,
+        )
+
+    @classmethod
+    def from_token_trajectory_chain(cls, chain) -> "ILQLData":
+        """ilql/data.py:58-79: next chunk's tokens up to (excluding) its first action, for bootstrapping."""
+        nxt = chain.next
+        if nxt is not None:
+            ia = nxt.token_trajectory.is_action
+            if ia[1:].sum() > 0:
+                first = int(np.argmax(ia[1:], axis=0)) + 1
+                next_token_ids, next_done = nxt.token_trajectory.tokens[:first], False
+            else:
+                next_token_ids, next_done = nxt.token_trajectory.tokens, nxt.token_trajectory.done
+        else:
+            next_token_ids, next_done = None, None
+        tt = chain.token_trajectory
+        return cls(input_ids=tt.tokens, should_take_action=tt.is_action[1:], rewards=tt.reward[1:], done=tt.done,
+                   next_token_ids=next_token_ids, next_done=next_done)
+
+
+class ILQLDataset:
+    def __init__(self, input_ids, should_take_action, rewards, dones, next_token_ids, next_dones):
+        assert input_ids.shape[1] == should_take_action.shape[1] + 1 == rewards.shape[1] + 1
+        assert input_ids.shape[0] == should_take_action.shape[0] == rewards.shape[0] == dones.shape[0]
+        self.input_ids, self.should_take_action, self.rewards, self.dones = input_ids, should_take_action, rewards, dones
+        self.next_token_ids, self.next_dones = next_token_ids, next_dones
+
+    def __getitem__(self, index):
+        return dict(input_ids=np.asarray(self.input_ids[index], dtype=np.int32),
+                    should_take_action=np.asarray(self.should_take_action[index], dtype=np.bool_),
+                    rewards=np.asarray(self.rewards[index], dtype=np.float32),
+                    dones=np.asarray(self.dones[index], dtype=np.float32),
+                    next_token_ids=None if self.next_token_ids is None else np.asarray(self.next_token_ids[index], dtype=np.int32),
+                    next_dones=None if self.next_dones is None else np.asarray(self.next_dones[index], dtype=np.float32))
+
+    def __len__(self):
+        return self.input_ids.shape[0]
+
+    @classmethod
+    def from_ilql_data_list(cls, ilql_data_list, tokenizer, blocking_strategy) -> "ILQLDataset":
+        return cls(**ILQLData.block(ilql_data_list, blocking_strategy, tokenizer))
+
+
+# ----------------------------------------------------------------------------- loss (ilql/base_interface.py:29-119)
+def _finalize_ilql_logs(P: np.ndarray, n: float, v_final: np.ndarray, cql_weight: float):
+    f = np.float32
+    s = P.sum(axis=0)
+    for t in range(7):
+        s[9 + 4 * t] = P[:, 9 + 4 * t].min(); s[10 + 4 * t] = P[:, 10 + 4 * t].max()
+    s[38], s[39] = P[:, 38].min(), P[:, 39].max()
+    q1_loss, q2_loss, v_loss, c1, c2 = (s[k] / n for k in range(5))
+    loss = q1_loss + q2_loss + v_loss + cql_weight * (c1 + c2)
+    st = lambda o, cnt: stats_from_sums(s[o], s[o], s[o + 1], s[o + 2], s[o + 3], cnt, n)
+    vf = np.asarray(v_final, dtype=np.float64)
+    logs = dict(
+        losses=dict(total_loss=f(loss), q1_loss=f(q1_loss), q2_loss=f(q2_loss), v_loss=f(v_loss), q1_cql_loss=f(c1), q2_cql_loss=f(c2)),
+        q1=st(7, s[5]), q2=st(11, s[5]), v=st(15, s[5]), target_q=st(19, s[5]), target_q1=st(23, s[5]), target_q2=st(27, s[5]),
+        vns=st(31, s[6]),
+        v_final=dict(mean=f(vf.sum() / len(vf)), min=f(vf.min()), max=f(vf.max()), std=f(vf.std())),
+        rewards=stats_from_sums(s[35], s[36], s[37], s[38], s[39], s[40], n),
+    )
+    return float(loss), logs
+
+
+def ilql_loss_device(q1, q2, v, v_final, tq1, tq2, ce1, ce2, attn, sta, rewards, *, gamma, tau, cql_weight):
+    """Device tensors [B, T-1] (v_final [B]); ce1/ce2 = per-token CQL cross-entropies of the two Q heads.
+    Returns (loss, logs, dq1, dq2, dv, coef_ce)."""
+    import torch
+    L = _lib.lib()
+    B, T1 = q1.shape
+    dev = q1.device
+    n_d = torch.zeros(1, dtype=torch.float64, device=dev)
+    ops.mask_sum(sta, attn, B * T1, n_d)
+    ns = L.lmrl_ilql_loss_nstats()
+    part = torch.empty((B, ns), dtype=torch.float64, device=dev)
+    dq1, dq2, dv, coef = (torch.empty_like(q1) for _ in range(4))
+    _lib.check(L.lmrl_ilql_loss(q1.data_ptr(), q2.data_ptr(), v.data_ptr(), v_final.data_ptr(), tq1.data_ptr(), tq2.data_ptr(),
+                                ce1.data_ptr(), ce2.data_ptr(), attn.data_ptr(), sta.data_ptr(), rewards.data_ptr(), B, T1, float(gamma),
+                                float(tau), float(cql_weight), n_d.data_ptr(), part.data_ptr(), dq1.data_ptr(), dq2.data_ptr(),
+                                dv.data_ptr(), coef.data_ptr(), _lib.stream_ptr()), "lmrl_ilql_loss")
+    loss, logs = _finalize_ilql_logs(part.cpu().numpy(), float(n_d.item()), v_final.cpu().numpy(), cql_weight)
+    return loss, logs, dq1, dq2, dv, coef
+
+
+def ilql_loss(q1, q2, v, v_final, target_q1, target_q2, q1_logits, q2_logits, token_ids, attention_mask, should_take_action, rewards, *,
+              gamma, tau, cql_weight):
+    """numpy face with the reference signature (q*_logits [B, T-1, V]); returns (loss, logs)."""
+    import torch
+    f32 = lambda x: _t(x, np.float32)
+    B, T1, V = np.asarray(q1_logits).shape
+    tok = _t(np.asarray(token_ids).reshape(-1), np.int32)
+    ces = []
+    for lg in (q1_logits, q2_logits):
+        lgd = f32(np.asarray(lg).reshape(B * T1, V))
+        lp = torch.empty(B * T1, dtype=torch.float32, device=lgd.device)
+        ops.lse_gather(lgd, V, V, tok, B * T1, logprob=lp)
+        ce = torch.empty_like(lp)
+        ops.axpby(-1.0, lp, 0.0, None, ce)
+        ces.append(ce.view(B, T1))
+    loss, logs, *_ = ilql_loss_device(f32(q1), f32(q2), f32(v), f32(v_final), f32(target_q1), f32(target_q2), ces[0], ces[1],
+                                      f32(attention_mask), _t(should_take_action, np.uint8), f32(rewards), gamma=gamma, tau=tau,
+                                      cql_weight=cql_weight)
+    return loss, logs
+
+
+# ----------------------------------------------------------------------------- train step (ilql/gpt2/interface.py:88-367)
+class GPT2ILQLTrain:
+    def __init__(self, base: GPT2F32, q1_head: MLPHeadF32, q2_head: MLPHeadF32, v_head: MLPHeadF32, pad_token_id: int,
+                 loss_kwargs: Dict[str, float], target_base: Optional[GPT2F32] = None, lr: float = 3e-5, weight_decay: float = 0.0,
+                 grad_accum_steps: int = 1, polyak_alpha: float = 0.005, hard_update_every: Optional[int] = None):
+        import torch
+        self.base, self.q1, self.q2, self.v = base, q1_head, q2_head, v_head
+        self.target_base = target_base
+        dev = base.dev
+        clone = lambda head: MLPHeadF32({k: t.clone() for k, t in head.p.items()}, dev)
+        self.q1_target, self.q2_target = clone(q1_head), clone(q2_head)
+        self.pad, self.loss_kwargs = pad_token_id, dict(loss_kwargs)
+        self.alpha, self.hard_every = polyak_alpha, hard_update_every
+        hd = lambda n: n.endswith("bias")
+        self.base_opt = AdamW(base.p, lr, weight_decay=weight_decay, every_k=grad_accum_steps)
+        self.q1_opt = AdamW(q1_head.p, lr, weight_decay=weight_decay, every_k=grad_accum_steps, no_decay=hd)
+        self.q2_opt = AdamW(q2_head.p, lr, weight_decay=weight_decay, every_k=grad_accum_steps, no_decay=hd)
+        self.v_opt = AdamW(v_head.p, lr, weight_decay=weight_decay, every_k=grad_accum_steps, no_decay=hd)
+        self.last_grads = None
+
+    def _update_targets(self, online: Dict[str, Any], target: Dict[str, Any], step: int):
+        """optax.incremental_update + optional optax.periodic_update (interface.py:327-365)."""
+        hard = self.hard_every is not None and step % self.hard_every == 0
+        for k, tp in target.items():
+            if hard:
+                ops.axpby(1.0, online[k], 0.0, None, tp)
+            else:
+                ops.axpby(self.alpha, online[k], 1.0 - self.alpha, tp, tp)
+
+    def step(self, input_ids, should_take_action, rewards, dones, next_token_ids=None, next_dones=None, prng_key=None,
+             attention_mask=None, position_ids=None, next_tokens_attention_mask=None, next_tokens_position_ids=None, train: bool = True):
+        import torch
+        ids = np.asarray(input_ids, dtype=np.int32)
+        am, pos = initialize_attn_mask_pos_ids(ids, self.pad, attention_mask, position_ids)
+        B, T = ids.shape
+        R, T1 = B * T, T - 1
+        base = self.base
+        dev = base.dev
+        V = self.q1.dout
+        ids_d, pos_d, am_d = _t(ids, np.int32), _t(pos, np.int32), _t(am, np.uint8)
+        hid, cache = base.forward(ids_d, am_d, pos_d)
+        thid = self.target_base.forward(ids_d, am_d, pos_d)[0] if self.target_base is not None else hid
+        q1o, q1c = self.q1.forward(hid, R)
+        q2o, q2c = self.q2.forward(hid, R)
+        vo, vc = self.v.forward(hid, R)
+        tq1o, _ = self.q1_target.forward(thid, R)
+        tq2o, _ = self.q2_target.forward(thid, R)
+        tgt = torch.zeros(R, dtype=torch.int32, device=dev)
+        tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
+        new = lambda: torch.empty(R, dtype=torch.float32, device=dev)
+        sl = lambda x: x.view(B, T)[:, :-1].contiguous()
+        q1sa, lse1, lp1 = new(), new(), new()
+        q2sa, lse2, lp2 = new(), new(), new()
+        tq1sa, tq2sa = new(), new()
+        ops.lse_gather(q1o, V, V, tgt, R, logprob=lp1, lse=lse1, target_logit=q1sa)
+        ops.lse_gather(q2o, V, V, tgt, R, logprob=lp2, lse=lse2, target_logit=q2sa)
+        ops.lse_gather(tq1o, V, V, tgt, R, target_logit=tq1sa)
+        ops.lse_gather(tq2o, V, V, tgt, R, target_logit=tq2sa)
+        ce1, ce2 = new(), new()
+        ops.axpby(-1.0, lp1, 0.0, None, ce1)
+        ops.axpby(-1.0, lp2, 0.0, None, ce2)
+        v_full = vo.view(B, T)
+        # v_final (interface.py:253-273)
+        sta = np.asarray(should_take_action, dtype=bool)
+        d = np.asarray(dones, dtype=np.float32)
+        if next_token_ids is not None:
+            nids = np.asarray(next_token_ids, dtype=np.int32)
+            nam, npos = initialize_attn_mask_pos_ids(nids, self.pad, next_tokens_attention_mask, next_tokens_position_ids)
+            nhid, ncache = base.forward(_t(nids, np.int32), _t(nam, np.uint8), _t(npos, np.int32))
+            last_idx = (nam.shape[1] - 1) - np.argmax(np.flip(nam, axis=1).astype(np.int32), axis=1)
+            rows = torch.from_numpy((np.arange(B) * nids.shape[1] + last_idx).astype(np.int64)).to(dev)
+            final_h = nhid.index_select(0, rows).contiguous()
+            nv, _ = self.v.forward(final_h, B)
+            v_final = torch.empty(B, dtype=torch.float32, device=dev)
+            ops.axpby(1.0, nv.view(B), 0.0, None, v_final)
+            v_final = v_final * _t(1.0 - np.asarray(next_dones, dtype=np.float32), np.float32)   # (1 - next_dones): host-known 0/1 mask
+        else:
+            last_action = (T1 - 1) - np.argmax(np.flip(sta, axis=1).astype(np.int32), axis=1) + 1
+            last_token = (T - 1) - np.argmax(np.flip(am, axis=1).astype(np.int32), axis=1)
+            final_idx = ((1 - d) * last_action + d * last_token).astype(np.int64)
+            rows = torch.from_numpy(np.arange(B) * T + final_idx).to(dev)
+            v_final = vo.view(R).index_select(0, rows) * _t(1.0 - d, np.float32)
+        f32 = lambda x: _t(x, np.float32)
+        loss, logs, dq1, dq2, dv, coef = ilql_loss_device(sl(q1sa), sl(q2sa), sl(v_full.reshape(R)), v_final.contiguous(), sl(tq1sa), sl(tq2sa),
+                                                          sl(ce1), sl(ce2), f32(am[:, 1:]), _t(sta, np.uint8), f32(rewards), **self.loss_kwargs)
+        if not train:
+            return self, loss, logs
+        # ---- backward
+        full = lambda g: (lambda z: (z.view(B, T)[:, :-1].copy_(g), z)[1])(torch.zeros(R, dtype=torch.float32, device=dev))
+        coef_r, dq1_r, dq2_r, dv_r = full(coef), full(dq1), full(dq2), full(dv)
+        ops.ce_bwd(q1o, V, V, lse1, tgt, coef_r, dq1_r, R)       # q1o := d loss / d q1 logits
+        ops.ce_bwd(q2o, V, V, lse2, tgt, coef_r, dq2_r, R)
+        bgrads, g1, g2, gv = base.zero_grads(), self.q1.zero_grads(), self.q2.zero_grads(), self.v.zero_grads()
+        d_hidden = torch.empty(R, base.d, dtype=torch.float32, device=dev)
+        self.q1.backward(q1c, q1o, g1, dx=d_hidden, accumulate_dx=False)
+        self.q2.backward(q2c, q2o, g2, dx=d_hidden, accumulate_dx=True)
+        self.v.backward(vc, dv_r.view(R, 1), gv, dx=d_hidden, accumulate_dx=True)
+        base.backward(cache, d_hidden, bgrads)
+        self.last_grads = (bgrads, g1, g2, gv)
+        upd = self.base_opt.apply(bgrads)
+        self.q1_opt.apply(g1); self.q2_opt.apply(g2); self.v_opt.apply(gv)
+        if upd:   # targets move only when MultiSteps.mini_step == 0 (interface.py:343-347)
+            if self.target_base is not None:
+                self._update_targets(base.p, self.target_base.p, self.base_opt.step_count)
+            self._update_targets(self.q1.p, self.q1_target.p, self.q1_opt.step_count)
+            self._update_targets(self.q2.p, self.q2_target.p, self.q2_opt.step_count)
+        return self, loss, logs

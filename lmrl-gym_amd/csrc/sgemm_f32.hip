@@ -1,0 +1,138 @@
+// sgemm_f32.hip — exact-fp32 batched GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32) for the TRAIN path.
+//
+// The reference trains in float32 (`jnp.float32` params / activations in LLM_RL/algorithms/{ppo,ilql}/gpt2/interface.py
+// and the heads), and BASELINE.json asks for ILQL train-step outputs within 1e-4 relative: the forward/backward GEMMs of
+// the train step therefore run on the f32-input MFMA (bit-for-bit an fmaf chain, 157 TFLOP/s peak) instead of bf16.
+//
+//   C[b] = alpha * op(A[b]) . op(B[b]) + beta * C[b] (+ bias[n])      row-major, arbitrary M, N, K, two-level batches
+//   op(A) is M x K:  transA = 0 -> A[m*lda + k]   transA = 1 -> A[k*lda + m]
+//   op(B) is K x N:  transB = 0 -> B[k*ldb + n]   transB = 1 -> B[n*ldb + k]
+//
+// The f32 MFMA takes ONE float per lane per operand (A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]), so both
+// LDS tiles are stored k-major and every transpose combination is just a different global->LDS copy; fragment reads are
+// conflict-free ds_read_b32.  64 x 64 output tile, 4 waves (one 32x32 MFMA tile each), BK = 16, register prefetch of the
+// next K-step.  At 64 cycles per MFMA the matrix pipe, not LDS, is the limiter.
+#include "../../include/lmrl_amd.h"
+#include "common.h"
+
+namespace lmrl {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+
+struct SgemmArgs {
+    const float *A, *B;
+    float *C;
+    const float *bias;
+    int M, N, K, lda, ldb, ldc;
+    long sAo, sAi, sBo, sBi, sCo, sCi;   // batch strides (outer, inner) in elements
+    int nb_inner;
+    float alpha, beta;
+};
+
+constexpr int SG_BM = 64, SG_BN = 64, SG_BK = 16, SG_LD = 68;   // LDS row stride (floats): 68 % 32 = 4 -> spread banks
+
+// Load a [BK x 64] k-major tile of op(X) for K-step k0 into registers (4 floats per thread per operand)
+// thread t handles 4 consecutive elements along the CONTIGUOUS global dimension.
+template <bool TRANS_K_CONTIG>   // true: memory is [row64][k] (k contiguous) ; false: memory is [k][row64] (row contiguous)
+__device__ __forceinline__ void sg_load(const float *__restrict__ X, int ld, int row0, int nrows, int k0, int K, int t, float (&r)[4]) {
+    if (TRANS_K_CONTIG) {
+        const int row = row0 + (t >> 2), k = k0 + (t & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = (row < nrows && k + i < K) ? X[(size_t)row * ld + k + i] : 0.f;
+    } else {
+        const int k = k0 + (t >> 4), row = row0 + (t & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = (k < K && row + i < nrows) ? X[(size_t)k * ld + row + i] : 0.f;
+    }
+}
+template <bool TRANS_K_CONTIG>
+__device__ __forceinline__ void sg_store(float *__restrict__ S, int t, const float (&r)[4]) {
+    if (TRANS_K_CONTIG) {
+        const int row = t >> 2, k = (t & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) S[(k + i) * SG_LD + row] = r[i];
+    } else {
+        const int k = t >> 4, row = (t & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) S[k * SG_LD + row + i] = r[i];
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void sgemm_f32_kernel(SgemmArgs g) {
+    __shared__ float sA[2][SG_BK * SG_LD];
+    __shared__ float sB[2][SG_BK * SG_LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bo = blockIdx.z / g.nb_inner, bi = blockIdx.z - bo * g.nb_inner;
+    const float *A = g.A + bo * g.sAo + bi * g.sAi;
+    const float *B = g.B + bo * g.sBo + bi * g.sBi;
+    float *C = g.C + bo * g.sCo + bi * g.sCi;
+    const int m0 = blockIdx.y * SG_BM, n0 = blockIdx.x * SG_BN;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    float ra[4], rb[4];
+    // op(A): rows = m. transA=0 -> memory [m][k] (k contiguous) ; transA=1 -> memory [k][m]
+    sg_load<!TA>(A, g.lda, m0, g.M, 0, g.K, t, ra);
+    // op(B): "rows" = n. transB=1 -> memory [n][k] (k contiguous) ; transB=0 -> memory [k][n]
+    sg_load<TB>(B, g.ldb, n0, g.N, 0, g.K, t, rb);
+    sg_store<!TA>(sA[0], t, ra);
+    sg_store<TB>(sB[0], t, rb);
+    __syncthreads();
+    const int nk = (g.K + SG_BK - 1) / SG_BK;
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            sg_load<!TA>(A, g.lda, m0, g.M, (kt + 1) * SG_BK, g.K, t, ra);
+            sg_load<TB>(B, g.ldb, n0, g.N, (kt + 1) * SG_BK, g.K, t, rb);
+        }
+        const float *pa = sA[buf] + (lane >> 5) * SG_LD + wm * 32 + (lane & 31);
+        const float *pb = sB[buf] + (lane >> 5) * SG_LD + wn * 32 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < SG_BK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk * SG_LD], pb[kk * SG_LD], acc, 0, 0, 0);
+        if (kt + 1 < nk) {
+            sg_store<!TA>(sA[buf ^ 1], t, ra);
+            sg_store<TB>(sB[buf ^ 1], t, rb);
+        }
+        __syncthreads();
+    }
+    // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col < g.N) {
+        const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < g.M) {
+                float *p = C + (size_t)row * g.ldc + col;
+                float v = g.alpha * acc[r] + bv;
+                if (g.beta != 0.f) v += g.beta * *p;
+                *p = v;
+            }
+        }
+    }
+}
+
+}  // namespace lmrl
+
+using namespace lmrl;
+
+extern "C" int lmrl_sgemm(int trans_a, int trans_b, int m, int n, int k, float alpha, const float *a_d, int lda, long sa_outer,
+                          long sa_inner, const float *b_d, int ldb, long sb_outer, long sb_inner, float beta, float *c_d, int ldc,
+                          long sc_outer, long sc_inner, int nb_outer, int nb_inner, const float *bias_d, void *stream) {
+    LMRL_REQUIRE(a_d && b_d && c_d && m > 0 && n > 0 && k > 0 && nb_outer > 0 && nb_inner > 0, "lmrl_sgemm: bad argument");
+    SgemmArgs g{a_d, b_d, c_d, bias_d, m, n, k, lda, ldb, ldc, sa_outer, sa_inner, sb_outer, sb_inner, sc_outer, sc_inner,
+                nb_inner, alpha, beta};
+    dim3 grid(ceil_div(n, SG_BN), ceil_div(m, SG_BM), nb_outer * nb_inner);
+    hipStream_t s = as_stream(stream);
+    if (!trans_a && !trans_b) hipLaunchKernelGGL((sgemm_f32_kernel<false, false>), grid, dim3(256), 0, s, g);
+    else if (!trans_a && trans_b) hipLaunchKernelGGL((sgemm_f32_kernel<false, true>), grid, dim3(256), 0, s, g);
+    else if (trans_a && !trans_b) hipLaunchKernelGGL((sgemm_f32_kernel<true, false>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((sgemm_f32_kernel<true, true>), grid, dim3(256), 0, s, g);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}

@@ -1,0 +1,353 @@
+// train_ops.hip — fp32 building blocks of the PPO / ILQL / BC train step on gfx950 (everything except the GEMMs, which
+// are sgemm_f32.hip): embeddings, LayerNorm, gelu_new, causal softmax, log-softmax/cross-entropy over the vocabulary,
+// column reductions for bias/LN gradients, AdamW, Polyak averaging.  All are HBM-bound streaming kernels: one wave per
+// row (16-byte accesses, shuffle reductions) or grid-stride elementwise.
+//
+// They restate, op for op, what jax/flax/optax execute for the reference's `_step` functions
+// (LLM_RL/algorithms/ppo/gpt2/interface.py:72-211, LLM_RL/algorithms/ilql/gpt2/interface.py:88-367): HF-Flax GPT-2
+// block (pre-LN, gelu_new, causal attention in fp32), optax.softmax_cross_entropy_with_integer_labels,
+// optax.adamw(b1, b2, eps, weight_decay) and optax.incremental_update.
+#include "../../include/lmrl_amd.h"
+#include "common.h"
+
+namespace lmrl {
+
+typedef __attribute__((ext_vector_type(4))) float v4f;
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------ embeddings
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const float *__restrict__ wte, const float *__restrict__ wpe,
+                                                        const int32_t *__restrict__ ids, const int32_t *__restrict__ pos,
+                                                        float *__restrict__ x, int R, int d) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const float *te = wte + (size_t)ids[r] * d, *pe = wpe + (size_t)pos[r] * d;
+    for (int c = lane * 4; c < d; c += 256) *reinterpret_cast<v4f *>(x + (size_t)r * d + c) = *reinterpret_cast<const v4f *>(te + c) + *reinterpret_cast<const v4f *>(pe + c);
+}
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float *__restrict__ dx, const int32_t *__restrict__ ids,
+                                                        const int32_t *__restrict__ pos, float *__restrict__ dwte,
+                                                        float *__restrict__ dwpe, int R, int d) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    for (int c = lane; c < d; c += 64) {
+        const float g = dx[(size_t)r * d + c];
+        atomicAdd(dwte + (size_t)ids[r] * d + c, g);
+        atomicAdd(dwpe + (size_t)pos[r] * d + c, g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm (fp32, d <= 4096)
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                     const float *__restrict__ b, float *__restrict__ y, float *__restrict__ mean,
+                                                     float *__restrict__ rstd, int R, int d, float eps) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const float *xr = x + (size_t)r * d;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += xr[c];
+    const float mu = wave_sum(s) / (float)d;
+    float q = 0.f;
+    for (int c = lane; c < d; c += 64) { const float t = xr[c] - mu; q += t * t; }
+    const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
+    for (int c = lane; c < d; c += 64) y[(size_t)r * d + c] = (xr[c] - mu) * rs * g[c] + b[c];
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+}
+// dx = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)),  dyg = dy * g ; also emits xhat*dy for the gamma gradient
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                     const float *__restrict__ g, const float *__restrict__ mean,
+                                                     const float *__restrict__ rstd, float *__restrict__ dx,
+                                                     float *__restrict__ dy_xhat, int R, int d, int accumulate) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const float mu = mean[r], rs = rstd[r];
+    const float *xr = x + (size_t)r * d, *dyr = dy + (size_t)r * d;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float xh = (xr[c] - mu) * rs, dg = dyr[c] * g[c];
+        s1 += dg; s2 += dg * xh;
+    }
+    s1 = wave_sum(s1) / (float)d; s2 = wave_sum(s2) / (float)d;
+    for (int c = lane; c < d; c += 64) {
+        const float xh = (xr[c] - mu) * rs, dg = dyr[c] * g[c];
+        const float v = rs * (dg - s1 - xh * s2);
+        float *p = dx + (size_t)r * d + c;
+        *p = accumulate ? *p + v : v;
+        if (dy_xhat) dy_xhat[(size_t)r * d + c] = dyr[c] * xh;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ column sums (bias / LN grads)
+// out[c] (+)= sum_r x[r][c] ; deterministic two-stage: stage 1 = SPLIT row slabs -> partial[SPLIT][C], stage 2 sums them.
+__global__ __launch_bounds__(256) void colsum_stage1(const float *__restrict__ x, float *__restrict__ partial, int R, int C, int ld,
+                                                     int rows_per_slab) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rows_per_slab, r1 = min(R, r0 + rows_per_slab);
+    float s = 0.f;
+    for (int r = r0; r < r1; r++) s += x[(size_t)r * ld + c];
+    partial[(size_t)blockIdx.y * C + c] = s;
+}
+__global__ __launch_bounds__(256) void colsum_stage2(const float *__restrict__ partial, float *__restrict__ out, int C, int nslab,
+                                                     int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < nslab; k++) s += partial[(size_t)k * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------ elementwise
+__device__ __forceinline__ float gelu_new_exact(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.f + tanhf(u));
+}
+__global__ void gelu_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = gelu_new_exact(x[i]);
+}
+__global__ void gelu_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ dx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+        const float th = tanhf(u);
+        const float du = 0.7978845608028654f * (1.f + 3.f * 0.044715f * v * v);
+        dx[i] = dy[i] * (0.5f * (1.f + th) + 0.5f * v * (1.f - th * th) * du);
+    }
+}
+__global__ void relu_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = fmaxf(x[i], 0.f);
+}
+__global__ void relu_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ dx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dx[i] = x[i] > 0.f ? dy[i] : 0.f;
+}
+// out = a*x + b*y   (residual adds, grad accumulation, Polyak: optax.incremental_update(new, old, s) = s*new + (1-s)*old)
+__global__ void axpby_kernel(float a, const float *__restrict__ x, float b, const float *__restrict__ y, float *__restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+// optax.adamw: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; mhat = m/(1-b1^t) ; vhat = v/(1-b2^t)
+//              p -= lr * (mhat / (sqrt(vhat) + eps) + wd * p)
+__global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, size_t n,
+                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float upd = (mi / bc1) / (sqrtf(vi / bc2) + eps) + wd * p[i];
+        p[i] = p[i] - lr * upd;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ causal softmax (attention)
+// S: [nb][T][T] scores (already scaled). P[r][c] = softmax over c <= r with key_mask[b][c] != 0 ; 0 elsewhere.  In place ok.
+__global__ __launch_bounds__(256) void softmax_causal_fwd_kernel(const float *__restrict__ S, const uint8_t *__restrict__ key_mask,
+                                                                 float *__restrict__ P, int T, int heads, long rows_total) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows_total) return;
+    const int r = (int)(row % T);
+    const long bh = row / T;
+    const int b = (int)(bh / heads);
+    const float *s = S + row * T;
+    float *p = P + row * T;
+    const uint8_t *km = key_mask ? key_mask + (size_t)b * T : nullptr;
+    float mx = -INFINITY;
+    for (int c = lane; c <= r; c += 64) if (!km || km[c]) mx = fmaxf(mx, s[c]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c <= r; c += 64) if (!km || km[c]) sum += __expf(s[c] - mx);
+    sum = wave_sum(sum);
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+    for (int c = lane; c < T; c += 64) {
+        const bool ok = c <= r && (!km || km[c]);
+        p[c] = ok ? __expf(s[c] - mx) * inv : 0.f;
+    }
+}
+// dS = P * (dP - sum_c dP*P), written over dP
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float *__restrict__ P, float *__restrict__ dP, int T, long rows_total) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows_total) return;
+    const float *p = P + row * T;
+    float *dp = dP + row * T;
+    float s = 0.f;
+    for (int c = lane; c < T; c += 64) s += dp[c] * p[c];
+    s = wave_sum(s);
+    for (int c = lane; c < T; c += 64) dp[c] = p[c] * (dp[c] - s);
+}
+
+// ------------------------------------------------------------------------------------------ log-softmax / CE over the vocabulary
+// One workgroup per row: lse = logsumexp(logits[r][:V]); target logit; logprob = target - lse.
+__global__ __launch_bounds__(256) void lse_gather_kernel(const float *__restrict__ logits, int ld, int V, const int32_t *__restrict__ targets,
+                                                         float *__restrict__ logprob, float *__restrict__ lse, float *__restrict__ target_logit) {
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float *row = logits + (size_t)r * ld;
+    float mx = -INFINITY;
+    for (int c = tid; c < V; c += 256) mx = fmaxf(mx, row[c]);
+    __shared__ float red[4];
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = tid; c < V; c += 256) s += expf(row[c] - mx);
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const float l = mx + logf(red[0] + red[1] + red[2] + red[3]);
+        int t = targets[r];
+        t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+        const float tl = row[t];
+        if (lse) lse[r] = l;
+        if (target_logit) target_logit[r] = tl;
+        if (logprob) logprob[r] = tl - l;
+    }
+}
+// dlogits[r][c] = coef_ce[r] * (softmax[r][c] - [c == t]) + coef_gather[r] * [c == t]     (written over the logits)
+// coef_ce = d loss / d CE_r ; coef_gather = d loss / d logits[r][t] from a direct gather (Q(s,a)).
+__global__ __launch_bounds__(256) void ce_bwd_kernel(float *__restrict__ logits, int ld, int V, const float *__restrict__ lse,
+                                                     const int32_t *__restrict__ targets, const float *__restrict__ coef_ce,
+                                                     const float *__restrict__ coef_gather) {
+    const int r = blockIdx.x;
+    float *row = logits + (size_t)r * ld;
+    const float l = lse[r], cc = coef_ce ? coef_ce[r] : 0.f, cg = coef_gather ? coef_gather[r] : 0.f;
+    int t = targets[r];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    for (int c = threadIdx.x; c < ld; c += 256) {
+        float v = 0.f;
+        if (c < V) {
+            v = cc == 0.f ? 0.f : cc * expf(row[c] - l);
+            if (c == t) v += cg - cc;
+        }
+        row[c] = v;
+    }
+}
+
+static int ew_grid(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g == 0 ? 1 : g));
+}
+
+}  // namespace lmrl
+
+using namespace lmrl;
+#define ST as_stream(stream)
+
+extern "C" {
+
+int lmrl_embed_fwd(const float *wte_d, const float *wpe_d, const int32_t *ids_d, const int32_t *pos_d, float *x_d, int rows, int d, void *stream) {
+    LMRL_REQUIRE(wte_d && wpe_d && ids_d && pos_d && x_d && rows > 0 && d % 4 == 0, "lmrl_embed_fwd: bad argument");
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, wte_d, wpe_d, ids_d, pos_d, x_d, rows, d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d, float *dwte_d, float *dwpe_d, int rows, int d, void *stream) {
+    LMRL_REQUIRE(dx_d && ids_d && pos_d && dwte_d && dwpe_d && rows > 0, "lmrl_embed_bwd: bad argument");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, dx_d, ids_d, pos_d, dwte_d, dwpe_d, rows, d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_layernorm_fwd(const float *x_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, int rows, int d,
+                       float eps, void *stream) {
+    LMRL_REQUIRE(x_d && g_d && b_d && y_d && mean_d && rstd_d && rows > 0 && d > 0, "lmrl_layernorm_fwd: bad argument");
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, x_d, g_d, b_d, y_d, mean_d, rstd_d, rows, d, eps);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_layernorm_bwd(const float *dy_d, const float *x_d, const float *g_d, const float *mean_d, const float *rstd_d, float *dx_d,
+                       float *dy_xhat_d, int rows, int d, int accumulate_dx, void *stream) {
+    LMRL_REQUIRE(dy_d && x_d && g_d && mean_d && rstd_d && dx_d && rows > 0, "lmrl_layernorm_bwd: bad argument");
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, dy_d, x_d, g_d, mean_d, rstd_d, dx_d, dy_xhat_d, rows, d,
+                       accumulate_dx);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+size_t lmrl_colsum_ws_bytes(int cols) { return (size_t)64 * cols * sizeof(float); }
+int lmrl_colsum(const float *x_d, int rows, int cols, int ld, float *out_d, int accumulate, float *ws_d, void *stream) {
+    LMRL_REQUIRE(x_d && out_d && ws_d && rows > 0 && cols > 0, "lmrl_colsum: bad argument");
+    const int nslab = rows < 64 ? rows : 64;
+    const int per = (rows + nslab - 1) / nslab;
+    const int slabs = (rows + per - 1) / per;
+    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(cols, 256), slabs), dim3(256), 0, ST, x_d, ws_d, rows, cols, ld, per);
+    hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(cols, 256)), dim3(256), 0, ST, ws_d, out_d, cols, slabs, accumulate);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_gelu_fwd(const float *x_d, float *y_d, size_t n, void *stream) {
+    LMRL_REQUIRE(x_d && y_d, "lmrl_gelu_fwd: null pointer");
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, x_d, y_d, n);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_gelu_bwd(const float *dy_d, const float *x_d, float *dx_d, size_t n, void *stream) {
+    LMRL_REQUIRE(dy_d && x_d && dx_d, "lmrl_gelu_bwd: null pointer");
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, dy_d, x_d, dx_d, n);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_relu_fwd(const float *x_d, float *y_d, size_t n, void *stream) {
+    LMRL_REQUIRE(x_d && y_d, "lmrl_relu_fwd: null pointer");
+    hipLaunchKernelGGL(relu_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, x_d, y_d, n);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_relu_bwd(const float *dy_d, const float *x_d, float *dx_d, size_t n, void *stream) {
+    LMRL_REQUIRE(dy_d && x_d && dx_d, "lmrl_relu_bwd: null pointer");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, dy_d, x_d, dx_d, n);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_axpby(float a, const float *x_d, float b, const float *y_d, float *out_d, size_t n, void *stream) {
+    LMRL_REQUIRE(x_d && out_d, "lmrl_axpby: null pointer");
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, a, x_d, b, y_d, out_d, n);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_adamw(float *p_d, const float *g_d, float *m_d, float *v_d, size_t n, float lr, float b1, float b2, float eps, float weight_decay,
+               int step, void *stream) {
+    LMRL_REQUIRE(p_d && g_d && m_d && v_d && step >= 1, "lmrl_adamw: bad argument");
+    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, p_d, g_d, m_d, v_d, n, lr, b1, b2, eps, weight_decay, bc1, bc2);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_softmax_causal_fwd(const float *s_d, const uint8_t *key_mask_d, float *p_d, int batch, int heads, int t, void *stream) {
+    LMRL_REQUIRE(s_d && p_d && batch > 0 && heads > 0 && t > 0, "lmrl_softmax_causal_fwd: bad argument");
+    const long rows = (long)batch * heads * t;
+    hipLaunchKernelGGL(softmax_causal_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, s_d, key_mask_d, p_d, t, heads, rows);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_softmax_bwd(const float *p_d, float *dp_d, long rows, int t, void *stream) {
+    LMRL_REQUIRE(p_d && dp_d && rows > 0 && t > 0, "lmrl_softmax_bwd: bad argument");
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, p_d, dp_d, t, rows);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_lse_gather(const float *logits_d, int ld, int vocab, const int32_t *targets_d, float *logprob_d, float *lse_d,
+                    float *target_logit_d, int rows, void *stream) {
+    LMRL_REQUIRE(logits_d && targets_d && rows > 0 && vocab > 0 && ld >= vocab, "lmrl_lse_gather: bad argument");
+    hipLaunchKernelGGL(lse_gather_kernel, dim3(rows), dim3(256), 0, ST, logits_d, ld, vocab, targets_d, logprob_d, lse_d, target_logit_d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_ce_bwd(float *logits_d, int ld, int vocab, const float *lse_d, const int32_t *targets_d, const float *coef_ce_d,
+                const float *coef_gather_d, int rows, void *stream) {
+    LMRL_REQUIRE(logits_d && lse_d && targets_d && rows > 0, "lmrl_ce_bwd: bad argument");
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(rows), dim3(256), 0, ST, logits_d, ld, vocab, lse_d, targets_d, coef_ce_d, coef_gather_d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+}

@@ -1,0 +1,264 @@
+"""GPT-2 forward + backward in float32 on the HIP train-step kernels.
+
+Mirrors what `policy_model(input_ids, attention_mask, position_ids, params, output_hidden_states=True)` +
+`jax.value_and_grad` do in the reference `_step` functions (LLM_RL/algorithms/ppo/gpt2/interface.py:111-133,
+LLM_RL/algorithms/ilql/gpt2/interface.py:139-177): HF GPT-2 blocks (pre-LN, gelu_new, causal attention masked by
+attention_mask, learned positions, tied LM head), float32 parameters and activations.
+
+Parameters are a dict of fp32 tensors with HF names/layouts (`h.0.attn.c_attn.weight` is [in, out]); gradients
+accumulate into a dict with the same keys.  torch only allocates; the arithmetic is sgemm_f32 / train_ops kernels.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+from . import ops
+
+
+class Workspace:
+    """Caches scratch tensors by (name, shape)."""
+
+    def __init__(self, device):
+        import torch
+        self.t, self.dev, self.buf = torch, device, {}
+
+    def get(self, name, shape, dtype=None, zero=False):
+        dtype = dtype or self.t.float32
+        key = (name, tuple(shape), dtype)
+        if key not in self.buf:
+            self.buf[key] = self.t.empty(shape, dtype=dtype, device=self.dev)
+        x = self.buf[key]
+        if zero:
+            x.zero_()
+        return x
+
+
+class GPT2F32:
+    def __init__(self, params: Dict[str, "torch.Tensor"], n_head: int, ln_eps: float = 1e-5, device=None):
+        import torch
+        self.t = torch
+        self.dev = device or next(iter(params.values())).device
+        self.p = {k: v.to(self.dev, torch.float32).contiguous() for k, v in params.items()}
+        self.n_head = n_head
+        self.eps = ln_eps
+        self.d = self.p["wte.weight"].shape[1]
+        self.vocab = self.p["wte.weight"].shape[0]
+        self.d_ff = self.p["h.0.mlp.c_fc.weight"].shape[1]
+        self.n_layer = 1 + max(int(k.split(".")[1]) for k in self.p if k.startswith("h."))
+        self.ws = Workspace(self.dev)
+        self._colsum_ws = torch.empty(64 * max(self.d_ff, 3 * self.d, self.vocab), dtype=torch.float32, device=self.dev)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_ids, attention_mask, position_ids, tag: str = "fwd"):
+        """input_ids / position_ids int32 [B,T], attention_mask uint8 [B,T] -> (final hidden [B*T, d], cache)."""
+        t = self.t
+        B, T = input_ids.shape
+        R, d, H, p = B * T, self.d, self.n_head, self.p
+        hd = d // H
+        ids = input_ids.reshape(-1).contiguous()
+        pos = position_ids.reshape(-1).contiguous()
+        km = attention_mask.to(t.uint8).contiguous()
+        new = lambda *shape: t.empty(shape, dtype=t.float32, device=self.dev)
+        x = new(R, d)
+        ops.embed_fwd(p["wte.weight"], p["wpe.weight"], ids, pos, x, R, d)
+        cache = dict(B=B, T=T, ids=ids, pos=pos, km=km, layers=[])
+        for l in range(self.n_layer):
+            q = f"h.{l}."
+            c = dict(x_in=x)
+            h1, c["m1"], c["r1"] = new(R, d), new(R), new(R)
+            ops.layernorm_fwd(x, p[q + "ln_1.weight"], p[q + "ln_1.bias"], h1, c["m1"], c["r1"], R, d, self.eps)
+            qkv = new(R, 3 * d)
+            ops.linear_fwd(h1, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], qkv, R, d, 3 * d)
+            P = new(B * H, T, T)
+            # S = scale * Q K^T per (b, h); Q/K/V are column slices of qkv (row stride 3d)
+            ops.sgemm(qkv, qkv, P, T, T, hd, trans_b=True, alpha=1.0 / math.sqrt(hd), lda=3 * d, ldb=3 * d, ldc=T, b_off=d,
+                      batch=(B, H), sa=(T * 3 * d, hd), sb=(T * 3 * d, hd), sc=(H * T * T, T * T))
+            ops.softmax_causal_fwd(P, km, P, B, H, T)
+            att = new(R, d)
+            ops.sgemm(P, qkv, att, T, hd, T, lda=T, ldb=3 * d, ldc=d, b_off=2 * d, batch=(B, H), sa=(H * T * T, T * T),
+                      sb=(T * 3 * d, hd), sc=(T * d, hd))
+            x_mid = new(R, d)
+            ops.linear_fwd(att, p[q + "attn.c_proj.weight"], p[q + "attn.c_proj.bias"], x_mid, R, d, d)
+            ops.axpby(1.0, x_mid, 1.0, x, x_mid)
+            h2, c["m2"], c["r2"] = new(R, d), new(R), new(R)
+            ops.layernorm_fwd(x_mid, p[q + "ln_2.weight"], p[q + "ln_2.bias"], h2, c["m2"], c["r2"], R, d, self.eps)
+            f = new(R, self.d_ff)
+            ops.linear_fwd(h2, p[q + "mlp.c_fc.weight"], p[q + "mlp.c_fc.bias"], f, R, d, self.d_ff)
+            g = new(R, self.d_ff)
+            ops.gelu_fwd(f, g)
+            x_out = new(R, d)
+            ops.linear_fwd(g, p[q + "mlp.c_proj.weight"], p[q + "mlp.c_proj.bias"], x_out, R, self.d_ff, d)
+            ops.axpby(1.0, x_out, 1.0, x_mid, x_out)
+            c.update(h1=h1, qkv=qkv, P=P, att=att, x_mid=x_mid, h2=h2, f=f, g=g)
+            cache["layers"].append(c)
+            x = x_out
+        hid, cache["mf"], cache["rf"] = new(R, d), new(R), new(R)
+        ops.layernorm_fwd(x, p["ln_f.weight"], p["ln_f.bias"], hid, cache["mf"], cache["rf"], R, d, self.eps)
+        cache["x_final"] = x
+        cache["hidden"] = hid
+        return hid, cache
+
+    def lm_logits(self, hidden, rows: int):
+        """logits [rows, V] = hidden @ wte^T (tied head), fp32 — PPOInference.token_logprobs_from_logits casts to f32 too."""
+        logits = self.t.empty(rows, self.vocab, dtype=self.t.float32, device=self.dev)
+        ops.sgemm(hidden, self.p["wte.weight"], logits, rows, self.vocab, self.d, trans_b=True, lda=self.d, ldb=self.d, ldc=self.vocab)
+        return logits
+
+    # ------------------------------------------------------------------ backward
+    def zero_grads(self) -> Dict[str, "torch.Tensor"]:
+        return {k: self.t.zeros_like(v) for k, v in self.p.items()}
+
+    def lm_head_backward(self, hidden, dlogits, rows: int, d_hidden, grads, accumulate_dh: bool):
+        """d_hidden (+)= dlogits @ wte ; grads[wte] += dlogits^T @ hidden"""
+        ops.sgemm(dlogits, self.p["wte.weight"], d_hidden, rows, self.d, self.vocab, lda=self.vocab, ldb=self.d, ldc=self.d,
+                  beta=1.0 if accumulate_dh else 0.0)
+        ops.sgemm(dlogits, hidden, grads["wte.weight"], self.vocab, self.d, rows, trans_a=True, lda=self.vocab, ldb=self.d, ldc=self.d, beta=1.0)
+
+    def backward(self, cache, d_hidden, grads: Dict[str, "torch.Tensor"]):
+        """d_hidden: gradient w.r.t. the final (post ln_f) hidden states [B*T, d]; accumulates into `grads`."""
+        t = self.t
+        B, T = cache["B"], cache["T"]
+        R, d, H, p, ws = B * T, self.d, self.n_head, self.p, self._colsum_ws
+        hd = d // H
+        scale = 1.0 / math.sqrt(hd)
+        new = lambda *shape: t.empty(shape, dtype=t.float32, device=self.dev)
+        tmp = new(R, d)
+        dx = new(R, d)
+        ops.layernorm_bwd(d_hidden, cache["x_final"], p["ln_f.weight"], cache["mf"], cache["rf"], dx, tmp, R, d, False)
+        ops.colsum(tmp, R, d, d, grads["ln_f.weight"], True, ws)
+        ops.colsum(d_hidden, R, d, d, grads["ln_f.bias"], True, ws)
+        for l in reversed(range(self.n_layer)):
+            q = f"h.{l}."
+            c = cache["layers"][l]
+            # MLP: x_out = x_mid + gelu(h2 W_fc + b) W_proj + b
+            dg = new(R, self.d_ff)
+            ops.linear_bwd(c["g"], p[q + "mlp.c_proj.weight"], dx, dg, grads[q + "mlp.c_proj.weight"], grads[q + "mlp.c_proj.bias"], R, self.d_ff, d, ws)
+            df = dg
+            ops.gelu_bwd(dg, c["f"], df)
+            dh2 = new(R, d)
+            ops.linear_bwd(c["h2"], p[q + "mlp.c_fc.weight"], df, dh2, grads[q + "mlp.c_fc.weight"], grads[q + "mlp.c_fc.bias"], R, d, self.d_ff, ws)
+            ops.layernorm_bwd(dh2, c["x_mid"], p[q + "ln_2.weight"], c["m2"], c["r2"], dx, tmp, R, d, True)   # dx := dx_mid
+            ops.colsum(tmp, R, d, d, grads[q + "ln_2.weight"], True, ws)
+            ops.colsum(dh2, R, d, d, grads[q + "ln_2.bias"], True, ws)
+            # attention projection
+            datt = new(R, d)
+            ops.linear_bwd(c["att"], p[q + "attn.c_proj.weight"], dx, datt, grads[q + "attn.c_proj.weight"], grads[q + "attn.c_proj.bias"], R, d, d, ws)
+            qkv, P = c["qkv"], c["P"]
+            dqkv = new(R, 3 * d)
+            # dV = P^T dA
+            ops.sgemm(P, datt, dqkv, T, hd, T, trans_a=True, lda=T, ldb=d, ldc=3 * d, c_off=2 * d, batch=(B, H), sa=(H * T * T, T * T),
+                      sb=(T * d, hd), sc=(T * 3 * d, hd))
+            # dP = dA V^T ; dS = softmax_bwd
+            dP = new(B * H, T, T)
+            ops.sgemm(datt, qkv, dP, T, T, hd, trans_b=True, lda=d, ldb=3 * d, ldc=T, b_off=2 * d, batch=(B, H), sa=(T * d, hd),
+                      sb=(T * 3 * d, hd), sc=(H * T * T, T * T))
+            ops.softmax_bwd(P, dP, B * H * T, T)
+            # dQ = scale * dS K ; dK = scale * dS^T Q
+            ops.sgemm(dP, qkv, dqkv, T, hd, T, alpha=scale, lda=T, ldb=3 * d, ldc=3 * d, b_off=d, batch=(B, H), sa=(H * T * T, T * T),
+                      sb=(T * 3 * d, hd), sc=(T * 3 * d, hd))
+            ops.sgemm(dP, qkv, dqkv, T, hd, T, trans_a=True, alpha=scale, lda=T, ldb=3 * d, ldc=3 * d, c_off=d, batch=(B, H),
+                      sa=(H * T * T, T * T), sb=(T * 3 * d, hd), sc=(T * 3 * d, hd))
+            dh1 = new(R, d)
+            ops.linear_bwd(c["h1"], p[q + "attn.c_attn.weight"], dqkv, dh1, grads[q + "attn.c_attn.weight"], grads[q + "attn.c_attn.bias"], R, d, 3 * d, ws)
+            ops.layernorm_bwd(dh1, c["x_in"], p[q + "ln_1.weight"], c["m1"], c["r1"], dx, tmp, R, d, True)    # dx := dx_in
+            ops.colsum(tmp, R, d, d, grads[q + "ln_1.weight"], True, ws)
+            ops.colsum(dh1, R, d, d, grads[q + "ln_1.bias"], True, ws)
+        ops.embed_bwd(dx, cache["ids"], cache["pos"], grads["wte.weight"], grads["wpe.weight"], R, d)
+        return grads
+
+
+# ---------------------------------------------------------------------- value heads (LLM_RL/heads/{linear_head,mlp_head}.py)
+class LinearHeadF32:
+    """`LinearHead`: x @ kernel + bias (heads/linear_head.py:112-119)."""
+
+    def __init__(self, params, device):
+        import torch
+        self.t, self.dev = torch, device
+        self.p = {k: v.to(device, torch.float32).contiguous() for k, v in params.items()}   # kernel [in,out], bias [out]
+        self.din, self.dout = self.p["kernel"].shape
+        self._ws = torch.empty(64 * max(self.dout, 1), dtype=torch.float32, device=device)
+
+    def forward(self, x, rows):
+        y = self.t.empty(rows, self.dout, dtype=self.t.float32, device=self.dev)
+        ops.linear_fwd(x, self.p["kernel"], self.p["bias"], y, rows, self.din, self.dout)
+        return y, dict(x=x, rows=rows)
+
+    def backward(self, cache, dy, grads, dx=None, accumulate_dx=False):
+        ops.linear_bwd(cache["x"], self.p["kernel"], dy, dx, grads["kernel"], grads["bias"], cache["rows"], self.din, self.dout, self._ws,
+                       dx_beta=1.0 if accumulate_dx else 0.0)
+
+    def zero_grads(self):
+        return {k: self.t.zeros_like(v) for k, v in self.p.items()}
+
+
+class MLPHeadF32:
+    """`MLPHead`: relu(x @ W1 + b1) @ W2 + b2 (heads/mlp_head.py:139-148). params: dense1.kernel/bias, dense2.kernel/bias."""
+
+    def __init__(self, params, device):
+        import torch
+        self.t, self.dev = torch, device
+        self.p = {k: v.to(device, torch.float32).contiguous() for k, v in params.items()}
+        self.din, self.dh = self.p["dense1.kernel"].shape
+        self.dout = self.p["dense2.kernel"].shape[1]
+        self._ws = torch.empty(64 * max(self.dout, self.dh), dtype=torch.float32, device=device)
+
+    def forward(self, x, rows):
+        t = self.t
+        z = t.empty(rows, self.dh, dtype=t.float32, device=self.dev)
+        ops.linear_fwd(x, self.p["dense1.kernel"], self.p["dense1.bias"], z, rows, self.din, self.dh)
+        a = t.empty_like(z)
+        ops.relu_fwd(z, a)
+        y = t.empty(rows, self.dout, dtype=t.float32, device=self.dev)
+        ops.linear_fwd(a, self.p["dense2.kernel"], self.p["dense2.bias"], y, rows, self.dh, self.dout)
+        return y, dict(x=x, z=z, a=a, rows=rows)
+
+    def backward(self, cache, dy, grads, dx=None, accumulate_dx=False):
+        t, rows = self.t, cache["rows"]
+        da = t.empty(rows, self.dh, dtype=t.float32, device=self.dev)
+        ops.linear_bwd(cache["a"], self.p["dense2.kernel"], dy, da, grads["dense2.kernel"], grads["dense2.bias"], rows, self.dh, self.dout, self._ws)
+        ops.relu_bwd(da, cache["z"], da)
+        ops.linear_bwd(cache["x"], self.p["dense1.kernel"], da, dx, grads["dense1.kernel"], grads["dense1.bias"], rows, self.din, self.dh, self._ws,
+                       dx_beta=1.0 if accumulate_dx else 0.0)
+
+    def zero_grads(self):
+        return {k: self.t.zeros_like(v) for k, v in self.p.items()}
+
+
+# ---------------------------------------------------------------------- optimizer
+class AdamW:
+    """optax.MultiSteps(optax.adamw(lr, b1, b2, eps, weight_decay, mask), every_k_schedule=k)
+    (llm_rl_scripts/wordle/ilql/train_ilql_gpt2.py:155-186): gradients are averaged over k micro-steps, then one AdamW
+    update; weight decay skips biases and LayerNorm parameters (the mask)."""
+
+    def __init__(self, params: Dict[str, "torch.Tensor"], lr, b1=0.9, b2=0.95, eps=1e-8, weight_decay=0.0, every_k: int = 1,
+                 no_decay=lambda name: name.endswith("bias") or ".ln_" in name or name.startswith("ln_f")):
+        import torch
+        self.t = torch
+        self.params = params
+        self.lr, self.b1, self.b2, self.eps, self.wd, self.k = lr, b1, b2, eps, weight_decay, every_k
+        self.no_decay = no_decay
+        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.acc = {k: torch.zeros_like(v) for k, v in params.items()} if every_k > 1 else None
+        self.step_count = 0     # number of applied updates
+        self.mini_step = 0
+
+    def apply(self, grads: Dict[str, "torch.Tensor"]) -> bool:
+        """Returns True when parameters were updated on this call (MultiSteps.mini_step wrapped to 0)."""
+        if self.k > 1:
+            for k, g in grads.items():
+                ops.axpby(1.0, self.acc[k], 1.0 / self.k, g, self.acc[k])
+            self.mini_step += 1
+            if self.mini_step < self.k:
+                return False
+            self.mini_step = 0
+            grads = self.acc
+        self.step_count += 1
+        for k, p in self.params.items():
+            wd = 0.0 if self.no_decay(k) else self.wd
+            ops.adamw(p, grads[k], self.m[k], self.v[k], self.lr, self.b1, self.b2, self.eps, wd, self.step_count)
+        if self.k > 1:
+            for a in self.acc.values():
+                a.zero_()
+        return True

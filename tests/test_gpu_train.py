@@ -1,0 +1,309 @@
+"""GPU tier: fp32 train path (sgemm on MFMA f32, train ops, loss kernels, GPT-2 fwd/bwd, PPO / ILQL steps) against
+float64 torch-CPU autograd of the oracle restatements (oracle/gpt2.py, oracle/rl.py)."""
+import numpy as np
+import pytest
+
+import lmrl_gym_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+F64 = torch.float64
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from lmrl_gym_amd import _lib
+    return _lib.require_gpu()
+
+
+def _close(got, exp, rtol=1e-4, atol=None, name=""):
+    got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
+    atol = atol if atol is not None else rtol * max(float(np.abs(exp).max()), 1e-12)
+    np.testing.assert_allclose(got, exp, rtol=rtol, atol=atol, err_msg=name)
+
+
+# ------------------------------------------------------------------ sgemm
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_sgemm_all_layouts(dev, ta, tb):
+    from lmrl_gym_amd.train import ops
+    g = torch.Generator().manual_seed(ta * 2 + tb)
+    for (M, N, K) in [(70, 33, 19), (128, 64, 64), (1, 5, 300), (257, 130, 65)]:
+        A = torch.randn((K, M) if ta else (M, K), generator=g); B = torch.randn((N, K) if tb else (K, N), generator=g)
+        C0 = torch.randn(M, N, generator=g); bias = torch.randn(N, generator=g)
+        ref = 0.7 * ((A.t() if ta else A).double() @ (B.t() if tb else B).double()) + 0.3 * C0.double() + bias.double()
+        Ad, Bd, Cd, bd = A.to(dev), B.to(dev), C0.to(dev).clone(), bias.to(dev)
+        ops.sgemm(Ad, Bd, Cd, M, N, K, trans_a=bool(ta), trans_b=bool(tb), alpha=0.7, beta=0.3, lda=A.shape[1], ldb=B.shape[1], ldc=N, bias=bd)
+        _close(Cd.cpu(), ref, rtol=2e-6, atol=2e-5, name=f"{M}x{N}x{K}")
+
+
+def test_sgemm_batched_strided_like_attention(dev):
+    from lmrl_gym_amd.train import ops
+    B, H, T, hd = 3, 4, 37, 16
+    d = H * hd
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B * T, 3 * d, generator=g)
+    S = torch.zeros(B * H, T, T)
+    qd, Sd = qkv.to(dev), S.to(dev)
+    ops.sgemm(qd, qd, Sd, T, T, hd, trans_b=True, alpha=0.25, lda=3 * d, ldb=3 * d, ldc=T, b_off=d, batch=(B, H),
+              sa=(T * 3 * d, hd), sb=(T * 3 * d, hd), sc=(H * T * T, T * T))
+    x = qkv.double().view(B, T, 3, H, hd)
+    ref = 0.25 * torch.einsum("bthe,bshe->bhts", x[:, :, 0], x[:, :, 1]).reshape(B * H, T, T)
+    _close(Sd.cpu(), ref, rtol=2e-6, atol=1e-5)
+
+
+# ------------------------------------------------------------------ elementwise / reduction ops vs autograd
+def test_train_ops_vs_autograd(dev):
+    from lmrl_gym_amd.train import ops
+    from oracle import gpt2 as O
+    g = torch.Generator().manual_seed(1)
+    R, d = 37, 96
+    x = torch.randn(R, d, generator=g); gam = torch.randn(d, generator=g); bet = torch.randn(d, generator=g); dy = torch.randn(R, d, generator=g)
+    xr = x.double().requires_grad_(True); gr = gam.double().requires_grad_(True); br = bet.double().requires_grad_(True)
+    y = O.layer_norm(xr, gr, br, 1e-5); y.backward(dy.double())
+    xd, gd, bd, dyd = x.to(dev), gam.to(dev), bet.to(dev), dy.to(dev)
+    yd, mean, rstd = torch.empty_like(xd), torch.empty(R, device=dev), torch.empty(R, device=dev)
+    ops.layernorm_fwd(xd, gd, bd, yd, mean, rstd, R, d, 1e-5)
+    _close(yd.cpu(), y.detach(), rtol=1e-5)
+    dxd, tmp = torch.zeros_like(xd), torch.empty_like(xd)
+    ops.layernorm_bwd(dyd, xd, gd, mean, rstd, dxd, tmp, R, d, False)
+    _close(dxd.cpu(), xr.grad, rtol=1e-5)
+    ws = torch.empty(64 * d, device=dev); dg = torch.zeros(d, device=dev); db = torch.ones(d, device=dev)
+    ops.colsum(tmp, R, d, d, dg, False, ws); ops.colsum(dyd, R, d, d, db, True, ws)
+    _close(dg.cpu(), gr.grad, rtol=1e-5); _close(db.cpu() - 1.0, br.grad, rtol=1e-5)
+    # gelu / relu
+    xr = x.double().requires_grad_(True); O.gelu_new(xr).backward(dy.double())
+    out, dxd = torch.empty_like(xd), torch.empty_like(xd)
+    ops.gelu_fwd(xd, out); ops.gelu_bwd(dyd, xd, dxd)
+    _close(out.cpu(), O.gelu_new(x.double()), rtol=1e-5); _close(dxd.cpu(), xr.grad, rtol=1e-5)
+    # causal softmax with key padding mask
+    B, H, T = 2, 3, 19
+    S = torch.randn(B * H, T, T, generator=g); km = torch.ones(B, T, dtype=torch.uint8); km[1, 13:] = 0
+    Sr = S.double().requires_grad_(True)
+    mask = torch.tril(torch.ones(T, T, dtype=torch.bool))[None] & km.bool().repeat_interleave(H, 0)[:, None, :]
+    P = Sr.masked_fill(~mask, float("-inf")).softmax(-1)
+    dP = torch.randn(B * H, T, T, generator=g)
+    (P * dP.double()).sum().backward()
+    Sd, dPd = S.to(dev), dP.to(dev)
+    Pd = torch.empty_like(Sd)
+    ops.softmax_causal_fwd(Sd, km.to(dev), Pd, B, H, T)
+    _close(Pd.cpu(), P.detach(), rtol=1e-5)
+    ops.softmax_bwd(Pd, dPd, B * H * T, T)
+    _close(dPd.cpu(), Sr.grad, rtol=1e-5)
+    # log-softmax gather + CE backward with an extra gather gradient
+    R, V, ld = 21, 1003, 1008
+    lg = torch.randn(R, ld, generator=g) * 3; tgt = torch.randint(0, V, (R,), generator=g).to(torch.int32)
+    cce = torch.randn(R, generator=g); cga = torch.randn(R, generator=g)
+    lr = lg[:, :V].double().requires_grad_(True)
+    lp = torch.log_softmax(lr, -1).gather(1, tgt.long()[:, None])[:, 0]
+    tl = lr.gather(1, tgt.long()[:, None])[:, 0]
+    ((-lp) * cce.double()).sum().add((tl * cga.double()).sum()).backward()
+    lgd = lg.to(dev); lpd, lsed, tld = (torch.empty(R, device=dev) for _ in range(3))
+    ops.lse_gather(lgd, ld, V, tgt.to(dev), R, logprob=lpd, lse=lsed, target_logit=tld)
+    _close(lpd.cpu(), lp.detach(), rtol=1e-5); _close(tld.cpu(), tl.detach(), rtol=1e-6)
+    ops.ce_bwd(lgd, ld, V, lsed, tgt.to(dev), cce.to(dev), cga.to(dev), R)
+    _close(lgd.cpu()[:, :V], lr.grad, rtol=1e-5)
+    assert float(lgd.cpu()[:, V:].abs().max()) == 0.0
+    # AdamW vs torch.optim.AdamW (decoupled weight decay == optax.adamw)
+    p = torch.randn(1000, generator=g); p_ref = p.clone().double().requires_grad_(True)
+    opt = torch.optim.AdamW([p_ref], lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01)
+    pd, m, v = p.to(dev), torch.zeros(1000, device=dev), torch.zeros(1000, device=dev)
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g)
+        p_ref.grad = gr.double(); opt.step()
+        ops.adamw(pd, gr.to(dev), m, v, 3e-3, 0.9, 0.95, 1e-8, 0.01, step)
+    _close(pd.cpu(), p_ref.detach(), rtol=1e-5)
+
+
+# ------------------------------------------------------------------ loss kernels
+def _grid(rng, B, T1):
+    sta = rng.rand(B, T1) < 0.4
+    sta[1] = False
+    attn = np.ones((B, T1), np.float32); attn[2, T1 // 2:] = 0; sta[2, T1 // 2:] = False
+    return sta, attn
+
+
+def _flat_logs(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(_flat_logs(v, prefix + k + "."))
+        else:
+            out[prefix + k] = float(v)
+    return out
+
+
+def test_ppo_loss_kernel_vs_oracle(dev):
+    from lmrl_gym_amd.algorithms import ppo
+    from oracle import rl
+    rng = np.random.RandomState(0)
+    B, T1 = 6, 41
+    sta, attn = _grid(rng, B, T1)
+    lp, v, olp, ov, oa, orr = (rng.randn(B, T1).astype(np.float32) * s for s in (0.3, 1, 0.3, 1, 1, 1))
+    olp = lp + rng.randn(B, T1).astype(np.float32) * 0.3     # ratios on both sides of the clip range
+    kw = dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=0.7)
+    td = lambda x: torch.from_numpy(x).double()
+    lpr, vr = td(lp).requires_grad_(True), td(v).requires_grad_(True)
+    loss_ref, logs_ref = rl.ppo_loss(td(attn), lpr, vr, torch.from_numpy(sta), td(olp), td(ov), td(oa), td(orr), **kw)
+    loss_ref.backward()
+    f = lambda x: torch.from_numpy(x).to(dev)
+    loss, logs, dlp, dv = ppo.ppo_loss_device(f(attn), f(lp), f(v), f(sta.astype(np.uint8)), f(olp), f(ov), f(oa), f(orr), **kw)
+    assert abs(loss - float(loss_ref)) < 1e-5 * max(1, abs(float(loss_ref)))
+    ref_flat, got_flat = _flat_logs(logs_ref), _flat_logs(logs)
+    assert set(ref_flat) == set(got_flat)
+    for k in ref_flat:
+        assert abs(got_flat[k] - ref_flat[k]) <= 2e-5 * max(1.0, abs(ref_flat[k])), (k, got_flat[k], ref_flat[k])
+    _close(dlp.cpu(), lpr.grad, rtol=1e-5); _close(dv.cpu(), vr.grad, rtol=1e-5)
+    loss2, logs2 = ppo.ppo_loss_fn(attn, lp, v, sta, olp, ov, oa, orr, **kw)
+    assert loss2 == loss
+
+
+def test_ilql_loss_kernel_vs_oracle(dev):
+    from lmrl_gym_amd.algorithms import ilql
+    from oracle import rl
+    rng = np.random.RandomState(1)
+    B, T1, V = 5, 23, 57
+    sta, attn = _grid(rng, B, T1)
+    q1, q2, v, tq1, tq2, r = (rng.randn(B, T1).astype(np.float32) for _ in range(6))
+    vf = rng.randn(B).astype(np.float32)
+    ql1, ql2 = rng.randn(B, T1, V).astype(np.float32), rng.randn(B, T1, V).astype(np.float32)
+    ids = rng.randint(0, V, size=(B, T1)).astype(np.int32)
+    kw = dict(gamma=0.99, tau=0.7, cql_weight=0.01)
+    td = lambda x: torch.from_numpy(x).double()
+    loss_ref, logs_ref = rl.ilql_loss(td(q1), td(q2), td(v), td(vf), td(tq1), td(tq2), td(ql1), td(ql2), torch.from_numpy(ids), td(attn),
+                                      torch.from_numpy(sta), td(r), **kw)
+    loss, logs = ilql.ilql_loss(q1, q2, v, vf, tq1, tq2, ql1, ql2, ids, attn, sta, r, **kw)
+    assert abs(loss - float(loss_ref)) < 2e-5 * max(1, abs(float(loss_ref)))
+    ref_flat, got_flat = _flat_logs(logs_ref), _flat_logs(logs)
+    assert set(ref_flat) == set(got_flat)
+    for k in ref_flat:
+        assert abs(got_flat[k] - ref_flat[k]) <= 3e-5 * max(1.0, abs(ref_flat[k])), (k, got_flat[k], ref_flat[k])
+
+
+# ------------------------------------------------------------------ full train steps
+def _tiny_model(seed, vocab=211):
+    from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
+    cfg = GPT2Config(2, 2, 64, 128, vocab, 32)
+    sd = init_hf_style_state_dict(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    for k in sd:
+        sd[k] = sd[k] * 4 + (0.1 * torch.randn(sd[k].shape, generator=g) if sd[k].dim() == 1 else 0)
+    return cfg, sd
+
+
+def _batch(rng, B, T, vocab, pad):
+    ids = rng.randint(1, vocab - 1, size=(B, T)).astype(np.int32)
+    lens = rng.randint(T // 2, T + 1, size=B); lens[0] = T
+    for b in range(B):
+        ids[b, lens[b]:] = pad
+    sta = np.zeros((B, T - 1), dtype=bool)
+    for b in range(B):
+        for t in range(3, lens[b] - 1):
+            sta[b, t] = (t // 3) % 2 == 0
+    return ids, sta, lens
+
+
+def test_ppo_train_step_vs_oracle(dev):
+    from lmrl_gym_amd.algorithms import ppo
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
+    from oracle import gpt2 as O, rl
+    cfg, sd = _tiny_model(3)
+    pad = cfg.vocab - 1
+    rng = np.random.RandomState(4)
+    B, T = 4, 17
+    ids, sta, lens = _batch(rng, B, T, cfg.vocab, pad)
+    hk, hb = torch.randn(cfg.d_model, 1, generator=torch.Generator().manual_seed(1)) * 0.1, torch.tensor([-4.1])
+    olp, ov, oa, orr = (rng.randn(B, T - 1).astype(np.float32) * s for s in (0.2, 1, 1, 1))
+    kw = dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0)
+    # ---- oracle: float64 autograd through the same graph
+    psd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    hkr, hbr = hk.double().requires_grad_(True), hb.double().requires_grad_(True)
+    am = torch.from_numpy((ids != pad).astype(np.int64)); pos = (am.cumsum(-1) - 1).clamp(min=0)
+    logits, hid = O.forward(psd, torch.from_numpy(ids).long(), cfg.n_head, attention_mask=am, position_ids=pos, return_hidden=True)
+    values = rl.linear_head(hid, hkr, hbr)[:, :-1, 0]
+    logprobs = rl.token_logprobs_from_logits(logits, torch.from_numpy(ids))
+    # old_logprobs near the new ones so that both clip branches occur
+    olp = logprobs.detach().numpy().astype(np.float32) + olp
+    td = lambda x: torch.from_numpy(np.asarray(x)).double()
+    loss_ref, logs_ref = rl.ppo_loss(am[:, 1:].double(), logprobs, values, torch.from_numpy(sta), td(olp), td(ov), td(oa), td(orr), **kw)
+    loss_ref.backward()
+    # ---- engine
+    pol = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
+    head = LinearHeadF32(dict(kernel=hk.clone(), bias=hb.clone()), dev)
+    tr = ppo.GPT2PPOTrain(pol, head, pad, kw, lr=1e-3, weight_decay=0.01)
+    p_before = {k: v.clone() for k, v in pol.p.items()}
+    _, loss, logs = tr.step(ids, sta, olp, ov, oa, orr)
+    assert abs(loss - float(loss_ref)) <= 1e-4 * abs(float(loss_ref)), (loss, float(loss_ref))
+    rf, gf = _flat_logs(logs_ref), _flat_logs(logs)
+    for k in rf:
+        assert abs(gf[k] - rf[k]) <= 1e-4 * max(1.0, abs(rf[k])), (k, gf[k], rf[k])
+    pg, hg = tr.last_grads
+    for k in psd:
+        _close(pg[k].cpu(), psd[k].grad, rtol=2e-4, name=k)
+    _close(hg["kernel"].cpu(), hkr.grad, rtol=2e-4); _close(hg["bias"].cpu(), hbr.grad, rtol=2e-4)
+    # one AdamW step: p' = p - lr*(mhat/(sqrt(vhat)+eps) + wd*p) with step-1 bias correction -> sign-like update
+    for k in ("h.0.attn.c_attn.weight", "ln_f.weight", "wte.weight"):
+        gref = psd[k].grad
+        wd = 0.0 if (k.endswith("bias") or ".ln_" in k or k.startswith("ln_f")) else 0.01
+        exp = p_before[k].cpu().double() - 1e-3 * (gref / (gref.abs() + 1e-8) + wd * p_before[k].cpu().double())
+        got = pol.p[k].cpu().double()
+        big = gref.abs() > 1e-6 * gref.abs().max()          # tiny gradients: the fp32 sign is not meaningful
+        assert float((got - exp)[big].abs().max()) < 2e-5
+
+
+def test_ilql_train_step_vs_oracle(dev):
+    from lmrl_gym_amd.algorithms import ilql
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    from oracle import gpt2 as O, rl
+    cfg, sd = _tiny_model(7, vocab=97)
+    _, tsd = _tiny_model(8, vocab=97)
+    pad = cfg.vocab - 1
+    rng = np.random.RandomState(9)
+    B, T, V, d = 4, 15, cfg.vocab, cfg.d_model
+    ids, sta, lens = _batch(rng, B, T, cfg.vocab, pad)
+    rewards = (rng.randn(B, T - 1) * sta).astype(np.float32)
+    dones = np.array([1, 0, 1, 0], dtype=np.float32)
+    g = torch.Generator().manual_seed(11)
+    mk = lambda out, b2: {"dense1.kernel": torch.randn(d, d, generator=g) * 0.2, "dense1.bias": torch.randn(d, generator=g) * 0.1,
+                          "dense2.kernel": torch.randn(d, out, generator=g) * 0.2, "dense2.bias": torch.full((out,), b2)}
+    hq1, hq2, hv = mk(V, -0.4), mk(V, -0.4), mk(1, -0.4)
+    kw = dict(gamma=0.99, tau=0.7, cql_weight=0.01)
+    # ---- oracle
+    psd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    req = lambda h: {k: v.double().requires_grad_(True) for k, v in h.items()}
+    rq1, rq2, rv = req(hq1), req(hq2), req(hv)
+    am = torch.from_numpy((ids != pad).astype(np.int64)); pos = (am.cumsum(-1) - 1).clamp(min=0)
+    idt = torch.from_numpy(ids).long()
+    _, hid = O.forward(psd, idt, cfg.n_head, attention_mask=am, position_ids=pos, return_hidden=True)
+    with torch.no_grad():
+        _, thid = O.forward({k: v.double() for k, v in tsd.items()}, idt, cfg.n_head, attention_mask=am, position_ids=pos, return_hidden=True)
+    mh = lambda x, h: rl.mlp_head(x, h["dense1.kernel"], h["dense1.bias"], h["dense2.kernel"], h["dense2.bias"])
+    q1o, q2o, vo = mh(hid, rq1), mh(hid, rq2), mh(hid, rv)
+    tq1o, tq2o = mh(thid, {k: v.detach() for k, v in rq1.items()}), mh(thid, {k: v.detach() for k, v in rq2.items()})
+    q1, q2, v, v_final, tq1, tq2 = rl.ilql_gather_qv(q1o, q2o, vo, tq1o, tq2o, idt, am, torch.from_numpy(sta), torch.from_numpy(dones))
+    loss_ref, logs_ref = rl.ilql_loss(q1, q2, v, v_final, tq1, tq2, q1o[:, :-1], q2o[:, :-1], idt[:, 1:], am[:, 1:].double(),
+                                      torch.from_numpy(sta), torch.from_numpy(rewards).double(), **kw)
+    loss_ref.backward()
+    # ---- engine
+    base = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
+    tbase = GPT2F32({k: v.clone() for k, v in tsd.items()}, cfg.n_head, device=dev)
+    cp = lambda h: {k: v.clone() for k, v in h.items()}
+    tr = ilql.GPT2ILQLTrain(base, MLPHeadF32(cp(hq1), dev), MLPHeadF32(cp(hq2), dev), MLPHeadF32(cp(hv), dev), pad, kw,
+                            target_base=tbase, lr=1e-3, polyak_alpha=0.1)
+    t_before = {k: v.clone() for k, v in tbase.p.items()}
+    _, loss, logs = tr.step(ids, sta, rewards, dones)
+    assert abs(loss - float(loss_ref)) <= 1e-4 * abs(float(loss_ref)), (loss, float(loss_ref))
+    rf, gf = _flat_logs(logs_ref), _flat_logs(logs)
+    assert set(rf) == set(gf)
+    for k in rf:
+        assert abs(gf[k] - rf[k]) <= 1e-4 * max(1.0, abs(rf[k])), (k, gf[k], rf[k])
+    bg, g1, g2, gv = tr.last_grads
+    for k in psd:
+        _close(bg[k].cpu(), psd[k].grad, rtol=3e-4, name=k)
+    for got, ref in ((g1, rq1), (g2, rq2), (gv, rv)):
+        for k in ref:
+            _close(got[k].cpu(), ref[k].grad, rtol=3e-4, name=k)
+    # Polyak: target = alpha * new_online + (1 - alpha) * old_target   (optax.incremental_update)
+    for k in ("h.1.mlp.c_fc.weight", "wte.weight"):
+        exp = 0.1 * base.p[k].cpu().double() + 0.9 * t_before[k].cpu().double()
+        _close(tbase.p[k].cpu(), exp, rtol=1e-6)
+    _close(tr.q1_target.p["dense2.bias"].cpu(), 0.1 * tr.q1.p["dense2.bias"].cpu().double() + 0.9 * hq1["dense2.bias"].double(), rtol=1e-6)
