@@ -1,0 +1,103 @@
+"""MC-returns baseline pieces — counterpart of LLM_RL/algorithms/mc_returns/{data,base_interface}.py:
+`get_rtg` (reward-to-go over action tokens, `lmrl_rtg`), `MCData`, `mc_loss` (`lmrl_mc_loss`)."""
+from __future__ import annotations
+
+from typing import Dict, List, NamedTuple
+
+import numpy as np
+
+from .. import _lib
+from ..train import ops
+from .common import BlockingStrategy, block_sequences, stats_from_sums
+from .ppo import _t
+
+
+def get_rtg(rewards: np.ndarray, gamma: float) -> np.ndarray:
+    """mc_returns/data.py:10-14 for a 1-d array of action rewards: rtg_i = sum_{j>=i} gamma^(j-i) r_j."""
+    import torch
+    r = np.asarray(rewards, dtype=np.float32).reshape(1, -1)
+    n = r.shape[1]
+    if n == 0:
+        return np.zeros((0,), dtype=np.float32)
+    rd = _t(r, np.float32)
+    sta = torch.ones((1, n), dtype=torch.uint8, device=rd.device)
+    out = torch.empty((1, n), dtype=torch.float32, device=rd.device)
+    _lib.check(_lib.lib().lmrl_rtg(rd.data_ptr(), sta.data_ptr(), None, out.data_ptr(), 1, n, float(gamma), _lib.stream_ptr()))
+    return out.cpu().numpy()[0]
+
+
+def rtg_from_chains(rewards: np.ndarray, should_take_action: np.ndarray, lens: np.ndarray, gamma: float) -> np.ndarray:
+    """Batched form: rewards / should_take_action [B, L] (whole chains concatenated per row) -> rtg scattered to positions."""
+    import torch
+    B, L = rewards.shape
+    rd, sd, ld = _t(rewards, np.float32), _t(should_take_action, np.uint8), _t(lens, np.int32)
+    out = torch.empty((B, L), dtype=torch.float32, device=rd.device)
+    _lib.check(_lib.lib().lmrl_rtg(rd.data_ptr(), sd.data_ptr(), ld.data_ptr(), out.data_ptr(), B, L, float(gamma), _lib.stream_ptr()))
+    return out.cpu().numpy()
+
+
+class MCData(NamedTuple):
+    input_ids: np.ndarray           # [t]
+    should_take_action: np.ndarray  # [t-1]
+    returns: np.ndarray             # [t-1]
+
+    @staticmethod
+    def block(data: List["MCData"], blocking_strategy: BlockingStrategy, tokenizer) -> Dict[str, np.ndarray]:
+        sm = blocking_strategy._replace(max_length=blocking_strategy.max_length - 1)
+        col = lambda name: [getattr(x, name) for x in data]
+        return dict(input_ids=block_sequences(col("input_ids"), tokenizer.pad_token_id, np.int32, blocking_strategy),
+                    should_take_action=block_sequences(col("should_take_action"), False, np.bool_, sm),
+                    returns=block_sequences(col("returns"), 0.0, np.float32, sm))
+
+    @classmethod
+    def from_token_trajectory_chain(cls, token_trajectory_chain, gamma: float) -> "MCData":
+        """mc_returns/data.py:49-74: reward-to-go over the action tokens of the WHOLE chain, written onto the first chunk."""
+        filt = []
+        for tt in token_trajectory_chain.to_list():
+            sta = tt.is_action[1:]
+            filt.append(tt.reward[1:][sta])
+        rtgs = get_rtg(np.concatenate(filt, axis=0), gamma)
+        sta0 = token_trajectory_chain.token_trajectory.is_action[1:]
+        returns = np.zeros(sta0.shape, dtype=np.float32)
+        returns[sta0] = rtgs[: sta0.sum()]
+        return cls(input_ids=token_trajectory_chain.token_trajectory.tokens, should_take_action=sta0, returns=returns)
+
+
+def mc_loss_device(q, ce, attn, sta, returns, *, cql_weight):
+    """Device tensors [B, T-1]; returns (loss, logs, dq, coef_ce)."""
+    import torch
+    L = _lib.lib()
+    n_el, dev = q.numel(), q.device
+    n_d = torch.zeros(1, dtype=torch.float64, device=dev)
+    ops.mask_sum(sta, attn, n_el, n_d)
+    nb, ns = L.lmrl_mc_loss_blocks(n_el), L.lmrl_mc_loss_nstats()
+    part = torch.empty((nb, ns), dtype=torch.float64, device=dev)
+    dq, coef = torch.empty_like(q), torch.empty_like(q)
+    _lib.check(L.lmrl_mc_loss(q.data_ptr(), ce.data_ptr(), attn.data_ptr(), sta.data_ptr(), returns.data_ptr(), n_el, float(cql_weight),
+                              n_d.data_ptr(), part.data_ptr(), dq.data_ptr(), coef.data_ptr(), _lib.stream_ptr()), "lmrl_mc_loss")
+    P = part.cpu().numpy()
+    s = P.sum(axis=0)
+    s[5], s[6], s[9], s[10] = P[:, 5].min(), P[:, 6].max(), P[:, 9].min(), P[:, 10].max()
+    n = float(n_d.item())
+    f = np.float32
+    q_loss, cql = s[0] / n, s[1] / n
+    loss = q_loss + cql_weight * cql
+    logs = dict(losses=dict(total_loss=f(loss), q_loss=f(q_loss), q_cql_loss=f(cql)),
+                q=stats_from_sums(s[3], s[3], s[4], s[5], s[6], s[2], n), returns=stats_from_sums(s[7], s[7], s[8], s[9], s[10], s[2], n))
+    return float(loss), logs, dq, coef
+
+
+def mc_loss(q, q_logits, token_ids, attention_mask, should_take_action, returns, *, cql_weight):
+    """numpy face with the reference signature (mc_returns/base_interface.py:19-60); returns (loss, logs)."""
+    import torch
+    B, T1, V = np.asarray(q_logits).shape
+    lg = _t(np.asarray(q_logits).reshape(B * T1, V), np.float32)
+    tok = _t(np.asarray(token_ids).reshape(-1), np.int32)
+    lp = torch.empty(B * T1, dtype=torch.float32, device=lg.device)
+    ops.lse_gather(lg, V, V, tok, B * T1, logprob=lp)
+    ce = torch.empty_like(lp)
+    ops.axpby(-1.0, lp, 0.0, None, ce)
+    f32 = lambda x: _t(x, np.float32)
+    loss, logs, _, _ = mc_loss_device(f32(q), ce.view(B, T1), f32(attention_mask), _t(should_take_action, np.uint8), f32(returns),
+                                      cql_weight=cql_weight)
+    return loss, logs

@@ -307,3 +307,98 @@ def test_ilql_train_step_vs_oracle(dev):
         exp = 0.1 * base.p[k].cpu().double() + 0.9 * t_before[k].cpu().double()
         _close(tbase.p[k].cpu(), exp, rtol=1e-6)
     _close(tr.q1_target.p["dense2.bias"].cpu(), 0.1 * tr.q1.p["dense2.bias"].cpu().double() + 0.9 * hq1["dense2.bias"].double(), rtol=1e-6)
+
+
+# ------------------------------------------------------------------ MC returns, BC, rerankers
+def test_mc_returns_and_loss(dev):
+    from lmrl_gym_amd.algorithms import mc_returns as mc
+    from lmrl_gym_amd import environment as E
+    from oracle import rl
+    rng = np.random.RandomState(2)
+    r = rng.randn(29).astype(np.float32)
+    for g in (1.0, 0.99, 0.7):
+        np.testing.assert_allclose(mc.get_rtg(r, g), rl.get_rtg(r, g), rtol=3e-5, atol=3e-5)
+    # chain -> MCData vs the oracle's restatement of mc_returns/data.py:49-74
+    golden = __import__("conftest").load_golden("rl_helpers.json")
+    for ch in golden["chains"]:
+        node = None
+        for tt in reversed(ch["token_chain"]):
+            node = E.TokenTrajectoryChain(E.TokenTrajectory(np.array(tt["tokens"], np.int32), np.array(tt["is_action"], bool),
+                                                            np.array(tt["reward"], np.float32), np.array(tt["done"])), node)
+        d = mc.MCData.from_token_trajectory_chain(node, gamma=0.9)
+        ref = rl.mc_data_from_chain(ch["token_chain"], 0.9)
+        assert d.input_ids.tolist() == ref["input_ids"] and d.should_take_action.astype(int).tolist() == ref["should_take_action"]
+        np.testing.assert_allclose(d.returns, ref["returns"], rtol=3e-5, atol=3e-5)
+    B, T1, V = 4, 17, 33
+    sta, attn = _grid(rng, B, T1)
+    q, ret = rng.randn(B, T1).astype(np.float32), rng.randn(B, T1).astype(np.float32)
+    ql = rng.randn(B, T1, V).astype(np.float32); ids = rng.randint(0, V, size=(B, T1)).astype(np.int32)
+    td = lambda x: torch.from_numpy(x).double()
+    lref, logs_ref = rl.mc_loss(td(q), td(ql), torch.from_numpy(ids), td(attn), torch.from_numpy(sta), td(ret), cql_weight=0.05)
+    loss, logs = mc.mc_loss(q, ql, ids, attn, sta, ret, cql_weight=0.05)
+    rf, gf = _flat_logs(logs_ref), _flat_logs(logs)
+    assert set(rf) == set(gf) and abs(loss - float(lref)) < 2e-5 * max(1, abs(float(lref)))
+    for k in rf:
+        assert abs(gf[k] - rf[k]) <= 3e-5 * max(1.0, abs(rf[k])), (k, gf[k], rf[k])
+
+
+def test_bc_train_step_and_score_fns(dev):
+    from lmrl_gym_amd import environment as E
+    from lmrl_gym_amd.algorithms import bc, reranker
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    from oracle import gpt2 as O, rl
+    cfg, sd = _tiny_model(12)
+    pad = cfg.vocab - 1
+    rng = np.random.RandomState(5)
+    B, T = 3, 14
+    ids, sta, lens = _batch(rng, B, T, cfg.vocab, pad)
+    is_action = np.concatenate([np.zeros((B, 1), bool), sta], axis=1)
+    psd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    am = torch.from_numpy((ids != pad).astype(np.int64)); pos = (am.cumsum(-1) - 1).clamp(min=0)
+    logits = O.forward(psd, torch.from_numpy(ids).long(), cfg.n_head, attention_mask=am, position_ids=pos)
+    lref = rl.bc_loss(logits, torch.from_numpy(ids), am, torch.from_numpy(is_action), non_action_weight=0.3)
+    lref.backward()
+    m = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
+    tr = bc.GPT2BCTrain(m, pad, non_action_weight=0.3, lr=1e-3)
+    _, loss, _ = tr.step(ids, is_action)
+    assert abs(loss - float(lref)) <= 1e-4 * abs(float(lref))
+    for k in psd:
+        _close(tr.last_grads[k].cpu(), psd[k].grad, rtol=3e-4, name=k)
+    assert bc.filter_items(lambda x: x, [1, 5, 3, 9], take_top=50) == [5, 9]
+
+    # score functions + reranker on a char-level tokenizer
+    class Tok:
+        pad_token_id = pad
+
+        def encode(self, s):
+            return [1 + (ord(c) % (cfg.vocab - 3)) for c in s]
+
+    m2 = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
+    hist = (E.Text("obs one\n", False), E.Text("go\n", True), E.Text("obs two\n", False))
+    props = [hist + (E.Text(a, True),) for a in ("left\n", "right\n", "up\n", "down\n")]
+    fn = reranker.build_logprob_score_fn(m2, Tok(), max_length=40, bsize=3)
+    scores = fn(props)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    for p, sc in zip(props, scores):
+        toks = sum((Tok().encode(t.text) for t in p), [])
+        n_act = len(Tok().encode(p[-1].text))
+        lg = O.forward(sd64, torch.tensor([toks]), cfg.n_head)
+        lp = rl.token_logprobs_from_logits(lg, torch.tensor([toks]))[0]
+        assert abs(sc - float(lp[-n_act:].sum())) < 2e-3
+    chosen = reranker.ReRankerPolicy(lambda h: props, fn).act(hist)
+    assert chosen == props[int(np.argmax(scores))]
+    g = torch.Generator().manual_seed(3)
+    d = cfg.d_model
+    mk = lambda out: MLPHeadF32({"dense1.kernel": torch.randn(d, d, generator=g) * 0.2, "dense1.bias": torch.zeros(d),
+                                 "dense2.kernel": torch.randn(d, out, generator=g) * 0.2, "dense2.bias": torch.zeros(out)}, dev)
+    q1, q2, vh = mk(cfg.vocab), mk(cfg.vocab), mk(1)
+    adv = reranker.build_ilql_score_fn(m2, q1, q2, vh, Tok(), max_length=40, bsize=4)(props)
+    for p, sc in zip(props, adv):
+        toks = sum((Tok().encode(t.text) for t in p), [])
+        n_act = len(Tok().encode(p[-1].text))
+        _, hid = O.forward(sd64, torch.tensor([toks]), cfg.n_head, return_hidden=True)
+        hd = lambda h: rl.mlp_head(hid, *(h.p[k].cpu() for k in ("dense1.kernel", "dense1.bias", "dense2.kernel", "dense2.bias")))
+        qo1, qo2, vo = hd(q1), hd(q2), hd(vh)
+        t = torch.tensor(toks)
+        qa = torch.minimum(qo1[0, :-1].gather(1, t[1:, None])[:, 0], qo2[0, :-1].gather(1, t[1:, None])[:, 0]) - vo[0, :-1, 0]
+        assert abs(sc - float(qa[-n_act:].sum())) < 2e-3
