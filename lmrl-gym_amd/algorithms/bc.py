@@ -6,6 +6,7 @@ from typing import Any, Callable, Dict, List, Optional, Tuple
 
 import numpy as np
 
+from .. import dist as D
 from ..train import ops
 from ..train.gpt2_f32 import AdamW, GPT2F32
 from .common import BlockingStrategy, Padding, Truncation, block_sequences, initialize_attn_mask_pos_ids
@@ -61,12 +62,16 @@ class GPT2BCTrain:
         lp, lse = torch.empty(R, dtype=torch.float32, device=dev), torch.empty(R, dtype=torch.float32, device=dev)
         ops.lse_gather(logits, m.vocab, m.vocab, tgt, R, logprob=lp, lse=lse)
         w, denom = bc_weights(am, is_action, self.w)
+        if D.is_distributed():
+            denom = float(D.allreduce_sum_(torch.tensor([denom], dtype=torch.float64, device=dev)).item())
         wfull = np.zeros((B, T), dtype=np.float32)
         wfull[:, :-1] = w / denom
         coef = _t(wfull.reshape(-1), np.float32)
         # loss = sum(coef * CE) = -sum(coef * logprob): a dot product done as a 1 x 1 x R GEMM on the matrix core
         out = torch.zeros(1, dtype=torch.float32, device=dev)
         ops.sgemm(coef, lp, out, 1, 1, R, alpha=-1.0, lda=R, ldb=1, ldc=1)
+        if D.is_distributed():
+            D.allreduce_sum_(out)
         loss = float(out.item())
         if not train:
             return self, loss, {"loss": np.float32(loss)}
@@ -76,5 +81,6 @@ class GPT2BCTrain:
         m.lm_head_backward(hid, logits, R, d_hidden, grads, accumulate_dh=False)
         m.backward(cache, d_hidden, grads)
         self.last_grads = grads
+        D.allreduce_grads([grads])
         self.opt.apply(grads)
         return self, loss, {"loss": np.float32(loss)}

@@ -13,6 +13,7 @@ from typing import Any, Dict, List, NamedTuple, Optional
 import numpy as np
 
 from .. import _lib
+from .. import dist as D
 from ..train import ops
 from ..train.gpt2_f32 import AdamW, GPT2F32, MLPHeadF32
 from .common import BlockingStrategy, block_sequences, initialize_attn_mask_pos_ids, stats_from_sums
@@ -91,6 +92,12 @@ def _finalize_ilql_logs(P: np.ndarray, n: float, v_final: np.ndarray, cql_weight
     for t in range(7):
         s[9 + 4 * t] = P[:, 9 + 4 * t].min(); s[10 + 4 * t] = P[:, 10 + 4 * t].max()
     s[38], s[39] = P[:, 38].min(), P[:, 39].max()
+    if D.is_distributed():
+        mn_i = [9 + 4 * t for t in range(7)] + [38]
+        mx_i = [10 + 4 * t for t in range(7)] + [39]
+        add_i = [k for k in range(len(s)) if k not in mn_i + mx_i]
+        a, mn, mx = D.reduce_stat_partials(s[add_i], s[mn_i], s[mx_i])
+        s[add_i], s[mn_i], s[mx_i] = a, mn, mx
     q1_loss, q2_loss, v_loss, c1, c2 = (s[k] / n for k in range(5))
     loss = q1_loss + q2_loss + v_loss + cql_weight * (c1 + c2)
     st = lambda o, cnt: stats_from_sums(s[o], s[o], s[o + 1], s[o + 2], s[o + 3], cnt, n)
@@ -114,6 +121,7 @@ def ilql_loss_device(q1, q2, v, v_final, tq1, tq2, ce1, ce2, attn, sta, rewards,
     dev = q1.device
     n_d = torch.zeros(1, dtype=torch.float64, device=dev)
     ops.mask_sum(sta, attn, B * T1, n_d)
+    D.allreduce_sum_(n_d)     # data parallel: global token count
     ns = L.lmrl_ilql_loss_nstats()
     part = torch.empty((B, ns), dtype=torch.float64, device=dev)
     dq1, dq2, dv, coef = (torch.empty_like(q1) for _ in range(4))
@@ -245,6 +253,7 @@ class GPT2ILQLTrain:
         self.v.backward(vc, dv_r.view(R, 1), gv, dx=d_hidden, accumulate_dx=True)
         base.backward(cache, d_hidden, bgrads)
         self.last_grads = (bgrads, g1, g2, gv)
+        D.allreduce_grads([bgrads, g1, g2, gv])  # the one data-path collective of an ILQL step (~815 MB fp32 for GPT-2-small)
         upd = self.base_opt.apply(bgrads)
         self.q1_opt.apply(g1); self.q2_opt.apply(g2); self.v_opt.apply(gv)
         if upd:   # targets move only when MultiSteps.mini_step == 0 (interface.py:343-347)

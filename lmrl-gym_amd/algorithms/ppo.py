@@ -13,6 +13,7 @@ from typing import Any, Dict, List, NamedTuple, Optional, Tuple
 import numpy as np
 
 from .. import _lib
+from .. import dist as D
 from ..train import ops
 from ..train.gpt2_f32 import AdamW, GPT2F32, LinearHeadF32
 from .common import BlockingStrategy, block_sequences, initialize_attn_mask_pos_ids, stats_from_sums
@@ -119,6 +120,7 @@ def ppo_loss_device(attn, logprobs, values, sta, old_logprobs, old_values, old_a
     dev = logprobs.device
     n_d = torch.zeros(1, dtype=torch.float64, device=dev)
     ops.mask_sum(sta, attn, n_el, n_d)
+    D.allreduce_sum_(n_d)     # data parallel: divide by the GLOBAL token count (ppo/base_interface.py:92 under a dp-sharded batch)
     nb, ns = L.lmrl_ppo_loss_blocks(n_el), L.lmrl_ppo_loss_nstats()
     part = torch.empty((nb, ns), dtype=torch.float64, device=dev)
     dlp, dv = torch.empty_like(logprobs), torch.empty_like(values)
@@ -132,6 +134,12 @@ def ppo_loss_device(attn, logprobs, values, sta, old_logprobs, old_values, old_a
         s[k] = P[:, k].min()
     for k in (13, 18, 23):
         s[k] = P[:, k].max()
+    if D.is_distributed():
+        mn_i, mx_i = [12, 17, 22], [13, 18, 23]
+        add_i = [k for k in range(len(s)) if k not in mn_i + mx_i]
+        a, mn, mx = D.reduce_stat_partials(s[add_i], s[mn_i], s[mx_i])
+        s[add_i], s[mn_i], s[mx_i] = a, mn, mx
+        n_el = n_el * D.world()[1]
     n = s[0]
     f = np.float32
     vf_loss, pg_loss = 0.5 * s[1] / n, s[4] / n
@@ -262,6 +270,7 @@ class GPT2PPOTrain:
         head.backward(hcache, dvals, hgrads, dx=d_hidden, accumulate_dx=True)
         pol.backward(cache, d_hidden, pgrads)
         self.last_grads = (pgrads, hgrads)
+        D.allreduce_grads([pgrads, hgrads])      # the one data-path collective of a PPO step (RCCL over xGMI)
         self.policy_opt.apply(pgrads)
         self.head_opt.apply(hgrads)
         return self, loss, logs

@@ -1,0 +1,175 @@
+"""Text-in / text-out policies on the HIP rollout engine — counterparts of `GPT2PPOPolicy`
+(LLM_RL/algorithms/ppo/gpt2/interface.py:468-549, also the BC policy of the task scripts) and `GPT2ValuePolicy`
+(LLM_RL/algorithms/value_rl_base/gpt2/interface.py:239-330).
+
+`act(text_history, done)` keeps the reference contract: done slots get the eos string as prompt and `None` back, prompts
+are LEFT-truncated to `max_input_length` tokens, generation stops at `eos_token_id` or `max_new_tokens`,
+`out_str_process` post-processes the completion, and the result is `history + (Text(completion, True),)`.
+This is the general (any tokenizer, any env) path with one host sync per generated token; the all-device Wordle loop is
+`lmrl_gym_amd.rollout.WordleRolloutEngine`.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .environment import BatchedTextPolicy, Text, TextHistory, text_history_to_str
+from .gpt2 import GPT2Engine, SampleParams
+
+
+class _Generator:
+    """Prefill (8-token chunks) + token-by-token decode for a fixed batch on one or two KV sessions."""
+
+    def __init__(self, engines: Sequence[GPT2Engine], batch: int, tmax: int):
+        import torch
+        self.t = torch
+        self.engines, self.B, self.tmax = list(engines), batch, tmax
+        self.sessions = [e.session(batch, tmax) for e in self.engines]
+        self.dev = self.engines[0].device
+
+    def prefill(self, prompts: List[List[int]]):
+        t, B = self.t, self.B
+        for s in self.sessions:
+            s.reset()
+        maxlen = max(len(p) for p in prompts)
+        for c0 in range(0, maxlen, 8):
+            toks = np.zeros((B, 8), dtype=np.int32)
+            cnt = np.zeros(B, dtype=np.int32)
+            for b, p in enumerate(prompts):
+                seg = p[c0:c0 + 8]
+                toks[b, : len(seg)] = seg
+                cnt[b] = len(seg)
+            td, cd = t.from_numpy(toks.reshape(-1)).to(self.dev), t.from_numpy(cnt).to(self.dev)
+            for s in self.sessions:
+                s.forward(td, cd, 8)
+
+    def decode_step(self, tokens: np.ndarray, active: np.ndarray):
+        t = self.t
+        td = t.from_numpy(tokens.astype(np.int32)).to(self.dev)
+        cd = t.from_numpy(active.astype(np.int32)).to(self.dev)
+        for s in self.sessions:
+            s.forward(td, cd, 1)
+
+
+class GPT2PPOPolicy(BatchedTextPolicy):
+    def __init__(self, engine: GPT2Engine, tokenizer, max_input_length: int = 256, max_new_tokens: int = 256, do_sample: bool = True,
+                 temperature: Optional[float] = None, top_k: Optional[int] = None, eos_token_id: Optional[int] = None,
+                 pad_token_id: Optional[int] = None, seed: int = 0, in_str_process: Optional[Callable[[str], str]] = None,
+                 out_str_process: Optional[Callable[[str], str]] = None):
+        self.engine, self.tokenizer = engine, tokenizer
+        self.max_input_length, self.max_new_tokens = max_input_length, max_new_tokens
+        self.temperature = (temperature if temperature is not None else 1.0) if do_sample else 0.0
+        self.top_k = top_k or 0
+        self.eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
+        self.pad = pad_token_id if pad_token_id is not None else getattr(tokenizer, "pad_token_id", 0)
+        self.seed, self.calls = seed, 0
+        self.in_str_process = in_str_process or (lambda x: x)
+        self.out_str_process = out_str_process or (lambda x: x)
+        self._gen: Optional[_Generator] = None
+
+    # hooks the ILQL policy overrides
+    def _engines(self) -> List[GPT2Engine]:
+        return [self.engine]
+
+    def _sample(self, gen: _Generator, params: SampleParams, active_d, logits_out):
+        return gen.sessions[0].sample(params, active=active_d, logits_out=logits_out)
+
+    def act(self, text_history: List[Optional[TextHistory]], done: Optional[List[bool]] = None) -> List[Optional[TextHistory]]:
+        import torch
+        B = len(text_history)
+        if done is None:
+            done = [False] * B
+        eos_str = self.tokenizer.decode([self.eos]) if self.eos is not None else ""
+        raw = [eos_str if d else self.in_str_process(text_history_to_str(h)) for h, d in zip(text_history, done)]
+        prompts = []
+        for s in raw:
+            ids = list(self.tokenizer.encode(s))
+            if len(ids) > self.max_input_length:           # Truncation.LEFT
+                ids = ids[len(ids) - self.max_input_length:]
+            prompts.append(ids if ids else [self.pad])
+        tmax = -(-(self.max_input_length + self.max_new_tokens + 8) // 8) * 8
+        if self._gen is None or self._gen.B != B or self._gen.tmax != tmax:
+            self._gen = _Generator(self._engines(), B, tmax)
+        gen = self._gen
+        gen.prefill(prompts)
+        self.calls += 1                                     # one random stream per act() call, like the per-call key split
+        active = np.array([not d for d in done], dtype=bool)
+        out_ids: List[List[int]] = [[] for _ in range(B)]
+        logits_out = None
+        if self.top_k > 0:
+            logits_out = torch.empty(B, self.engine.cfg.vocab_padded, dtype=torch.float32, device=gen.dev)
+        for k in range(self.max_new_tokens):
+            if not active.any():
+                break
+            p = SampleParams(self.temperature, self.top_k, self.seed + (self.calls << 20), k, 0.0, 0.0, self.pad)
+            active_d = torch.from_numpy(active.astype(np.uint8)).to(gen.dev)
+            tok, _ = self._sample(gen, p, active_d, logits_out)
+            tok = tok.cpu().numpy()
+            step_active = active.copy()
+            for b in range(B):
+                if active[b]:
+                    out_ids[b].append(int(tok[b]))
+                    if self.eos is not None and tok[b] == self.eos:
+                        active[b] = False
+            nxt = active & step_active
+            if k + 1 < self.max_new_tokens and nxt.any():
+                gen.decode_step(np.where(nxt, tok, 0), nxt)
+        results: List[Optional[TextHistory]] = []
+        for h, d, ids in zip(text_history, done, out_ids):
+            if d:
+                results.append(None)
+            else:
+                results.append(tuple(h) + (Text(self.out_str_process(self.tokenizer.decode(ids)), True),))
+        return results
+
+    def set_params(self, engine: GPT2Engine) -> None:
+        """PPOPolicy.set_params (ppo/base_interface.py:821-823): swap in freshly trained weights."""
+        self.engine = engine
+        self._gen = None
+
+
+class GPT2ValuePolicy(GPT2PPOPolicy):
+    """ILQL policy: logits = pi_beta_logits + beta * min(Q1, Q2)(h_value)   (value_rl_base/gpt2/generation.py:97-119).
+
+    q heads: dicts with bf16 device tensors `w1` [d][d] ([out][in]), `w2` [vocab_padded][d] and f32 `b1` [d], `b2` [vocab_padded]
+    (build them with `heads_to_engine_layout`)."""
+
+    def __init__(self, pi_beta: GPT2Engine, value_base: GPT2Engine, q1_head: dict, q2_head: Optional[dict], beta: float, tokenizer, **kw):
+        super().__init__(pi_beta, tokenizer, **kw)
+        self.value_base, self.q1, self.q2, self.beta = value_base, q1_head, q2_head, beta
+
+    def _engines(self):
+        return [self.engine, self.value_base]
+
+    def _sample(self, gen, params, active_d, logits_out):
+        import torch
+        L = _lib.lib()
+        pi_ses, v_ses = gen.sessions
+        d, B = self.value_base.cfg.d_model, gen.B
+        ops = []
+        for head in (self.q1, self.q2):
+            if head is None:
+                ops.append(None)
+                continue
+            qh = torch.empty(B, d, dtype=torch.bfloat16, device=gen.dev)
+            _lib.check(L.lmrl_gemm_bf16(_lib.ptr(v_ses.last_hidden), _lib.ptr(head["w1"]), _lib.ptr(head["b1"]), _lib.ptr(qh), B, d, d, d, d, d,
+                                        4, _lib.stream_ptr()), "lmrl_gemm_bf16(q head dense1 + relu)")
+            ops.append((qh, head["w2"], head["b2"]))
+        params.beta = self.beta
+        return pi_ses.sample(params, active=active_d, logits_out=logits_out, q1=ops[0], q2=ops[1])
+
+
+def heads_to_engine_layout(head_params: dict, vocab_padded: int, device) -> dict:
+    """MLPHead params (`dense1.kernel` [d,d], `dense1.bias`, `dense2.kernel` [d,V], `dense2.bias`) -> bf16 [out][in] tensors
+    padded to `vocab_padded` rows for the fused sampler."""
+    import torch
+    w1 = head_params["dense1.kernel"].t().contiguous().to(device, torch.bfloat16)
+    V, d = head_params["dense2.kernel"].shape[1], head_params["dense2.kernel"].shape[0]
+    w2 = torch.zeros(vocab_padded, d, dtype=torch.bfloat16, device=device)
+    w2[:V] = head_params["dense2.kernel"].t().to(device, torch.bfloat16)
+    b2 = torch.zeros(vocab_padded, dtype=torch.float32, device=device)
+    b2[:V] = head_params["dense2.bias"].to(device, torch.float32)
+    return dict(w1=w1, b1=head_params["dense1.bias"].to(device, torch.float32).contiguous(), w2=w2, b2=b2)

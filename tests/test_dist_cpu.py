@@ -1,0 +1,84 @@
+"""CPU tier, world_size 2 over gloo: the N > 1 plumbing (env sharding, bucketed gradient all-reduce, stat / moment
+reductions, the bench's max-time / sum-steps reduction)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import lmrl_gym_amd  # noqa: F401
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lmrl_gym_amd import dist as D
+    try:
+        assert D.is_distributed() and D.world() == (rank, world)
+        # 1. shards tile the env range exactly
+        lo, hi = D.shard_range(1027, rank, world)
+        spans = [None] * world
+        dist.all_gather_object(spans, (lo, hi))
+        assert spans[0][0] == 0 and spans[-1][1] == 1027 and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        # 2. bucketed gradient all-reduce == sum over ranks, several buckets, ragged shapes
+        g = torch.Generator().manual_seed(123)
+        shapes = dict(a=(7, 5), b=(3,), c=(11, 2, 2), d=(1,))
+        full = [{k: torch.randn(*s, generator=g) for k, s in shapes.items()} for _ in range(world * 2)]
+        mine = [{k: v.clone() for k, v in full[rank * 2 + i].items()} for i in range(2)]
+        n_coll = D.allreduce_grads(mine, bucket_bytes=100)
+        assert n_coll >= 3
+        for i in range(2):
+            for k in shapes:
+                exp = sum(full[r * 2 + i][k] for r in range(world))
+                torch.testing.assert_close(mine[i][k], exp)
+        avg = [{k: v.clone() for k, v in full[rank * 2].items()}]
+        D.allreduce_grads(avg, average=True)
+        torch.testing.assert_close(avg[0]["a"], sum(full[r * 2]["a"] for r in range(world)) / world)
+        # 3. n-before-loss scheme: local grads of sum(x)/n_global summed over ranks == global-mean gradient
+        x = torch.arange(10, dtype=torch.float64)[rank::world]
+        n_glob = D.allreduce_sum_(torch.tensor([float(x.numel())], dtype=torch.float64))
+        local_grad = {"w": (x / n_glob).sum().reshape(1)}
+        D.allreduce_grads([local_grad])
+        assert abs(float(local_grad["w"]) - 4.5) < 1e-12
+        # 4. stats and whitening moments
+        data = np.random.RandomState(0).randn(1000)
+        sh = data[lo * 1000 // 1027: hi * 1000 // 1027] if False else data[rank::world]
+        s, mn, mx = D.reduce_stat_partials([sh.sum(), (sh ** 2).sum(), len(sh)], [sh.min()], [sh.max()])
+        assert abs(s[0] - data.sum()) < 1e-9 and s[2] == 1000 and mn[0] == data.min() and mx[0] == data.max()
+        var = s[1] / s[2] - (s[0] / s[2]) ** 2
+        assert abs(var - data.var()) < 1e-9
+        # 5. bench reduction: max time, summed steps
+        t = torch.tensor([0.5 + rank], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n = torch.tensor([100 + rank]); dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        assert float(t) == 0.5 + world - 1 and int(n) == sum(100 + r for r in range(world))
+        ret[rank] = "ok"
+    except Exception as e:   # surface the failure in the parent
+        ret[rank] = repr(e)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+
+
+def test_single_process_is_a_no_op():
+    from lmrl_gym_amd import dist as D
+    assert not D.is_distributed() and D.world() == (0, 1)
+    g = [{"w": torch.ones(3)}]
+    assert D.allreduce_grads(g) == 0 and torch.equal(g[0]["w"], torch.ones(3))
+    assert D.shard_range(10, 0, 1) == (0, 10)

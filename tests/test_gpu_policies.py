@@ -1,0 +1,177 @@
+"""GPU tier: text policies (generic generate path), the ILQL value policy, and the rollout -> PPOData pipeline."""
+import numpy as np
+import pytest
+
+import lmrl_gym_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class CharTok:
+    """Deterministic stand-in tokenizer: one token per character."""
+    def __init__(self, vocab):
+        self.vocab, self.pad_token_id, self.eos_token_id = vocab, vocab - 1, 10   # '\n'
+
+    def encode(self, s):
+        return [ord(c) % (self.vocab - 1) for c in s]
+
+    def decode(self, ids):
+        return "".join(chr(i) for i in ids)
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
+    from oracle import gpt2 as O
+    dev = _lib.require_gpu()
+    cfg = GPT2Config(2, 2, 128, 256, 130, 96)
+    mk = lambda seed: O.round_weights_to_bf16({k: (v * 6 if v.dim() == 2 else v) for k, v in init_hf_style_state_dict(cfg, seed=seed).items()})
+    sd, sd_v = mk(21), mk(22)
+    return dev, cfg, sd, sd_v, GPT2Engine(cfg, sd, dev), GPT2Engine(cfg, sd_v, dev)
+
+
+def _oracle_greedy(sd, cfg, prompt_ids, max_new, eos, extra_logits=None):
+    """Greedy continuation under the float64 oracle; returns the tokens up to (excluding) the first step whose top-2
+    margin is too small to survive bf16 rounding."""
+    from oracle import gpt2 as O
+    ids, out = list(prompt_ids), []
+    for _ in range(max_new):
+        lg = O.forward(sd, torch.tensor([ids]), cfg.n_head)[0, -1, : cfg.vocab]
+        if extra_logits is not None:
+            lg = lg + extra_logits(ids)
+        top2 = lg.topk(2)
+        if top2.values[0] - top2.values[1] <= 0.05:
+            return out, False
+        t = int(top2.indices[0]); ids.append(t); out.append(t)
+        if t == eos:
+            break
+    return out, True
+
+
+def test_ppo_policy_greedy_matches_oracle_generation(setup):
+    from lmrl_gym_amd import environment as E
+    from lmrl_gym_amd.policies import GPT2PPOPolicy
+    dev, cfg, sd, sd_v, eng, eng_v = setup
+    tok = CharTok(cfg.vocab)
+    pol = GPT2PPOPolicy(eng, tok, max_input_length=24, max_new_tokens=7, do_sample=False, eos_token_id=tok.eos_token_id,
+                        out_str_process=lambda x: x.removesuffix("\n") + "\n")
+    hists = [(E.Text("The goal is at 8, 6.\n", False),), (E.Text("a much longer observation that must be left-truncated to fit!\n", False), E.Text("move up\n", True), E.Text("ok\n", False)),
+             (E.Text("x\n", False),), None]
+    done = [False, False, False, True]
+    res = pol.act([h if h is not None else (E.Text("", False),) for h in hists], done)
+    assert res[3] is None
+    checked = 0
+    for h, r in zip(hists[:3], res[:3]):
+        ids = tok.encode(E.text_history_to_str(h))[-24:]
+        exp, ok = _oracle_greedy(sd, cfg, ids, 7, tok.eos_token_id)
+        assert r[:-1] == h and r[-1].is_action and r[-1].text.endswith("\n")
+        got = r[-1].text
+        if ok:
+            assert got == tok.decode(exp).removesuffix("\n") + "\n"
+        else:   # compare up to the first step whose top-2 margin is below bf16 resolution
+            assert got.startswith(tok.decode(exp))
+        checked += len(exp)
+    assert checked >= 6
+    # sampling: reproducible for a fixed seed, and wired through interact_environment with a device env
+    from lmrl_gym_amd.envs import maze as M
+    env = M.setup_maze_env("double_t_maze", "describe_observation_give_position", "standard_reward", last_k=1, max_steps=3)
+    runs = []
+    for _ in range(2):
+        sp = GPT2PPOPolicy(eng, tok, max_input_length=64, max_new_tokens=4, do_sample=True, temperature=0.8, top_k=20, seed=5,
+                           eos_token_id=tok.eos_token_id, out_str_process=lambda x: x.removesuffix("\n") + "\n")
+        inter = E.interact_environment(env, sp, env_seed=[1, 2, 3], bsize=3, npad=1)
+        runs.append([[tr.post_action_history[-1].text for tr in ep] for ep in inter])
+        assert all(len(ep) == 4 and ep[-1].done for ep in inter)      # max_steps=3 -> 'Failure' on the 4th step
+    assert runs[0] == runs[1]
+
+
+def test_value_policy_logit_perturbation(setup):
+    from lmrl_gym_amd import environment as E
+    from lmrl_gym_amd.policies import GPT2ValuePolicy, heads_to_engine_layout
+    from oracle import gpt2 as O, rl
+    dev, cfg, sd, sd_v, eng, eng_v = setup
+    tok = CharTok(cfg.vocab)
+    g = torch.Generator().manual_seed(2)
+    d, V = cfg.d_model, cfg.vocab
+    bf = lambda x: x.to(torch.bfloat16).float()
+    mk = lambda: {"dense1.kernel": bf(torch.randn(d, d, generator=g) * 0.2), "dense1.bias": torch.randn(d, generator=g) * 0.1,
+                  "dense2.kernel": bf(torch.randn(d, V, generator=g) * 0.2), "dense2.bias": torch.randn(V, generator=g) * 0.1}
+    h1, h2 = mk(), mk()
+    beta = 3.0
+    pol = GPT2ValuePolicy(eng, eng_v, heads_to_engine_layout(h1, cfg.vocab_padded, dev), heads_to_engine_layout(h2, cfg.vocab_padded, dev),
+                          beta, tok, max_input_length=32, max_new_tokens=5, do_sample=False, eos_token_id=tok.eos_token_id)
+
+    def extra(ids):
+        _, hid = O.forward(sd_v, torch.tensor([ids]), cfg.n_head, return_hidden=True)
+        h = hid[0, -1].to(torch.bfloat16).double()              # the engine hands bf16 hidden states to the heads
+        q = [rl.mlp_head(h, p["dense1.kernel"], p["dense1.bias"], p["dense2.kernel"], p["dense2.bias"]) for p in (h1, h2)]
+        return beta * torch.minimum(q[0], q[1])
+
+    hists = [(E.Text("Wordle:\n", False),), (E.Text("abc def\n", False), E.Text("go\n", True), E.Text("hm\n", False))]
+    res = pol.act(hists, [False, False])
+    n_ok = 0
+    for h, r in zip(hists, res):
+        exp, ok = _oracle_greedy(sd, cfg, tok.encode(E.text_history_to_str(h)), 5, tok.eos_token_id, extra_logits=extra)
+        assert r[-1].text == tok.decode(exp) if ok else r[-1].text.startswith(tok.decode(exp))
+        n_ok += len(exp)
+    assert n_ok >= 4
+
+
+def test_ppo_data_pipeline_vs_oracle(setup):
+    from lmrl_gym_amd import environment as E
+    from lmrl_gym_amd.algorithms.ppo_inference import GPT2PPOInference
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
+    from oracle import gpt2 as O, rl
+    dev, cfg, sd, sd_v, eng, eng_v = setup
+    tok = CharTok(cfg.vocab)
+    pad = tok.pad_token_id
+    T = E.Text
+    # chains whose later chunks start with a state (the reference asserts this, ppo/base_interface.py:319-327)
+    specs = [
+        [([T("Wordle:\n", False), T("s t a r e\n", True), T("b y b b g\n", False), T("c r a n e\n", True), T("g g g g g\n", False)], (0.0, -1.0, 0.0, 0.0, 0.0), True)],
+        [([T("obs A\n", False), T("move up\n", True), T("obs B\n", False), T("move left\n", True)], (0.0, -1.0, 0.0, -4.0), False),
+         ([T("obs C\n", False), T("move down\n", True), T("Success\n", False)], (0.0, 0.0, 0.0), True)],
+        [([T("q\n", False), T("a\n", True)], (0.0, -2.0), False), ([T("r\n", False), T("b\n", True), T("s\n", False)], (0.0, 1.5, 0.0), False)],
+    ]
+    chains, chain_dicts = [], []
+    for spec in specs:
+        node = None
+        for hist, rew, dn in reversed(spec):
+            node = E.TextTrajectoryChain(E.TextTrajectory(tuple(hist), rew, dn), node)
+        tch = E.TokenTrajectoryChain.from_text_trajectory_chain(node, tok)
+        chains.append(tch)
+        chain_dicts.append([dict(tokens=t.tokens.tolist(), is_action=t.is_action.tolist(), reward=t.reward.tolist(), done=bool(t.done)) for t in tch.to_list()])
+    hk, hb = torch.randn(cfg.d_model, 1, generator=torch.Generator().manual_seed(3)) * 0.2, torch.tensor([-0.5])
+    inf = GPT2PPOInference(GPT2F32(sd, cfg.n_head, device=dev), LinearHeadF32(dict(kernel=hk, bias=hb), dev), pad,
+                           initial_policy=GPT2F32(sd_v, cfg.n_head, device=dev))
+    kw = dict(gamma=0.97, lam=0.9, kl_weight=0.05)
+    datas, kls = inf.get_ppo_data_from_token_trajectory_chain(chains, bsize=2, max_length=None, **kw)
+    # oracle: float64 forward of both models per chunk, then the post-forward half of the reference pipeline
+    lp_c, ilp_c, v_c = [], [], []
+    for cd in chain_dicts:
+        lps, ilps, vs = [], [], []
+        for j, tt in enumerate(cd):
+            ids = torch.tensor([tt["tokens"]])
+            lg, hid = O.forward(sd, ids, cfg.n_head, return_hidden=True)
+            ilg = O.forward(sd_v, ids, cfg.n_head)
+            lps.append(rl.token_logprobs_from_logits(lg, ids)[0].numpy()); ilps.append(rl.token_logprobs_from_logits(ilg, ids)[0].numpy())
+            v = rl.linear_head(hid, hk, hb)[0, :, 0].numpy()
+            vs.append(v[:-1]); last = v[-1]
+        lp_c.append(np.concatenate(lps)); ilp_c.append(np.concatenate(ilps))
+        v_c.append(np.concatenate(vs + [np.array([last * (1.0 - float(cd[-1]["done"]))])]))
+    ref, ref_kls = rl.ppo_data_from_chains(chain_dicts, lp_c, ilp_c, v_c, **kw)
+    np.testing.assert_allclose(kls, ref_kls, rtol=2e-3, atol=2e-5)
+    k = 0
+    for cd, r in zip(chain_dicts, ref):
+        offs = np.cumsum([0] + r["chunk_lens"])
+        for j, tt in enumerate(cd):
+            d = datas[k]; k += 1
+            sl = slice(offs[j], offs[j + 1])
+            assert d.input_ids.tolist() == tt["tokens"] and d.should_take_action.astype(int).tolist() == list(r["should_take_action"][sl])
+            np.testing.assert_allclose(d.old_logprobs, r["old_logprobs"][sl], rtol=1e-4, atol=1e-4)
+            np.testing.assert_allclose(d.old_values, r["old_values"][sl], rtol=1e-4, atol=1e-4)
+            np.testing.assert_allclose(d.old_returns, r["old_returns"][sl], rtol=2e-4, atol=2e-4)
+            np.testing.assert_allclose(d.old_advantages, r["old_advantages"][sl], rtol=2e-3, atol=2e-3)
+    assert k == len(datas)
