@@ -197,6 +197,8 @@ int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *
 
 /* bench/test hook: 0 = default GEMM kernels (global_load_lds ring), 1 = round-1 register-staged kernels */
 void lmrl_gemm_set_variant(int v);
+/* bench/test hook: 0 = MFMA chunk attention (default), 1 = VALU chunk attention */
+void lmrl_attn_set_variant(int v);
 
 /* ------------------------------------------------------------------------------------------
  * Fused LM-head + sampling (csrc/sampler.hip).  Replaces logits[:, -1] -> warpers -> jax.random.categorical in

@@ -258,6 +258,150 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------ chunk attention on MFMA
+// C = 8 chunk rows per env: the VALU kernel above spends ~40 instructions per (query, 8 keys); here one wave still owns an
+// (env, head) but does S^T = K.Q^T and O^T = V^T.P^T with v_mfma_f32_16x16x32_bf16 over 32-key blocks:
+//   step A  A-operand = K rows straight from HBM (16 B/lane, row = key, k = head dims), B-operand = the 8 queries padded to 16
+//           columns.  MFMA row i of sub-block sb is mapped to key t0 + (i/4)*8 + sb*4 + (i%4) so that after both sub-blocks
+//           lane (query j = lane&15, group g = lane>>4) holds the scores of the 8 CONTIGUOUS keys t0 + 8g .. t0 + 8g + 7 —
+//   step B  online softmax per query; the max is shared by the 4 lane groups of a query (xor 16/32) because the O^T
+//           accumulators of a query live in all 4 groups;
+//   step C  — exactly the k-slot order the P^T B-operand needs, so P never moves between lanes; the V^T A-operand (8 keys of
+//           one head-dim per lane) is gathered from a per-wave LDS copy of the 32 x 64 V block (row stride 136 B).
+// Rows t >= len[b] come from this chunk's own qkv rows, as in the VALU kernel; new K/V rows are appended to the cache.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+__global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ kcache,
+                                                                    uint16_t *__restrict__ vcache, const int32_t *__restrict__ cnt,
+                                                                    const int32_t *__restrict__ len, uint16_t *__restrict__ out, int B,
+                                                                    int H, int Tmax, int d) {
+    constexpr int C = 8, VROW = 136;
+    __shared__ __attribute__((aligned(16))) unsigned char vlds_all[4][32 * VROW];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave_id = blockIdx.x * 4 + wave;
+    if (wave_id >= B * H) return;
+    const int b = wave_id / H, h = wave_id - b * H;
+    const int n_new = min(cnt[b], C);
+    if (n_new <= 0) return;
+    const int L0 = len[b];
+    const int T = L0 + n_new;
+    const size_t ld = (size_t)3 * d;
+    uint16_t *kc = kcache + ((size_t)b * H + h) * Tmax * 64;
+    uint16_t *vc = vcache + ((size_t)b * H + h) * Tmax * 64;
+    const uint16_t *qbase = qkv + (size_t)b * C * ld + (size_t)h * 64;
+    unsigned char *vlds = vlds_all[wave];
+    const int j = lane & 15, g = lane >> 4;
+
+    {   // append this chunk's K/V rows to the cache
+        const int rr = lane >> 3, cc = lane & 7;
+        if (rr < n_new && L0 + rr < Tmax) {
+            *reinterpret_cast<uint4 *>(kc + (size_t)(L0 + rr) * 64 + cc * 8) = *reinterpret_cast<const uint4 *>(qbase + (size_t)rr * ld + d + cc * 8);
+            *reinterpret_cast<uint4 *>(vc + (size_t)(L0 + rr) * 64 + cc * 8) = *reinterpret_cast<const uint4 *>(qbase + (size_t)rr * ld + 2 * d + cc * 8);
+        }
+    }
+    // B operand of step A: query j (zero beyond n_new), dims kk*32 + g*8 ..
+    bf16x8_t qf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+        u32x4 raw = u32x4{0u, 0u, 0u, 0u};
+        if (j < n_new) raw = *reinterpret_cast<const u32x4 *>(qbase + (size_t)j * ld + kk * 32 + g * 8);
+        qf[kk] = __builtin_bit_cast(bf16x8_t, raw);
+    }
+    f32x4 oacc[4];
+#pragma unroll
+    for (int f = 0; f < 4; f++) oacc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -1e30f, l = 0.f;
+    const int qpos = L0 + j;   // position of this lane's query
+
+    for (int t0 = 0; t0 < T; t0 += 32) {
+        // ---- stage the V block [32 keys][64 dims] into LDS (row stride 136 B)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int id = lane + 64 * i, kl = id >> 3, c = id & 7;
+            int t = t0 + kl; t = t < T ? t : T - 1;
+            const uint16_t *vp = t < L0 ? vc + (size_t)t * 64 + c * 8 : qbase + (size_t)(t - L0) * ld + 2 * d + c * 8;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(vp);
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(vlds + kl * VROW + c * 16);
+            dst[0] = ((unsigned long long)v[1] << 32) | v[0];
+            dst[1] = ((unsigned long long)v[3] << 32) | v[2];
+        }
+        // The LDS tile is written as 64-bit words and read back as 16-bit elements by OTHER lanes of this wave: type-based
+        // alias analysis would let the compiler move those reads above the writes, so pin the order (LDS itself is in-order
+        // per wave; no s_barrier needed because the tile is private to the wave).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- step A: scores of keys t0 + 8g + (sb*4 + r) for query j
+        f32x4 sacc[2];
+#pragma unroll
+        for (int sb = 0; sb < 2; sb++) {
+            sacc[sb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int t = t0 + (j >> 2) * 8 + sb * 4 + (j & 3);
+            t = t < T ? t : T - 1;
+            const uint16_t *kp = t < L0 ? kc + (size_t)t * 64 : qbase + (size_t)(t - L0) * ld + d;
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4 *>(kp + kk * 32 + g * 8));
+                sacc[sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], sacc[sb], 0, 0, 0);
+            }
+        }
+        // ---- step B: online softmax for query j over its 8 keys, max shared across the 4 lane groups
+        float sv[8];
+        float bm = -1e30f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int t = t0 + g * 8 + e;
+            const bool ok = t < T && t <= qpos && j < n_new;
+            sv[e] = ok ? sacc[e >> 2][e & 3] * 0.125f : -1e30f;
+            bm = fmaxf(bm, sv[e]);
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 16));
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        const float m_new = fmaxf(m, bm);
+        const float alpha = __expf(m - m_new);
+        float psum = 0.f;
+        uint32_t pk[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const float p0 = sv[e] > -1e29f ? __expf(sv[e] - m_new) : 0.f;
+            const float p1 = sv[e + 1] > -1e29f ? __expf(sv[e + 1] - m_new) : 0.f;
+            const uint16_t h0 = f32_to_bf16_rn(p0), h1 = f32_to_bf16_rn(p1);
+            psum += bf16_to_f32(h0) + bf16_to_f32(h1);   // sum what the PV product actually uses
+            pk[e >> 1] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        }
+        l = l * alpha + psum;
+        m = m_new;
+        const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, u32x4{pk[0], pk[1], pk[2], pk[3]});
+        // ---- step C: O^T[dim][query] = alpha * O^T + V^T . P^T ; V^T fragment gathered from LDS
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            uint32_t vw[4];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const uint16_t a0 = *reinterpret_cast<const uint16_t *>(vlds + (g * 8 + e) * VROW + (f * 16 + j) * 2);
+                const uint16_t a1 = *reinterpret_cast<const uint16_t *>(vlds + (g * 8 + e + 1) * VROW + (f * 16 + j) * 2);
+                vw[e >> 1] = (uint32_t)a0 | ((uint32_t)a1 << 16);
+            }
+            const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, u32x4{vw[0], vw[1], vw[2], vw[3]});
+#pragma unroll
+            for (int r = 0; r < 4; r++) oacc[f][r] *= alpha;
+            oacc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[f], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all V^T gathers done before the next block overwrites the tile
+    }
+    // ---- finish: l over the 4 lane groups, write query j's 16 dims per lane (4 per fragment)
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (j < n_new) {
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            uint2 o;
+            o.x = (uint32_t)f32_to_bf16_rn(oacc[f][0] * inv) | ((uint32_t)f32_to_bf16_rn(oacc[f][1] * inv) << 16);
+            o.y = (uint32_t)f32_to_bf16_rn(oacc[f][2] * inv) | ((uint32_t)f32_to_bf16_rn(oacc[f][3] * inv) << 16);
+            *reinterpret_cast<uint2 *>(out + ((size_t)b * C + j) * d + (size_t)h * 64 + f * 16 + g * 4) = o;
+        }
+    }
+}
+
 // profiling only (one launch per forward): algorithmic HBM bytes of the attention launches of this forward =
 // per (env, head, layer): K and V rows of every attended position (2 x 128 B) + the chunk's q rows and output rows.
 __global__ void attn_bytes_kernel(const int32_t *cnt, const int32_t *len, int B, int C, int heads_x_layers,
@@ -285,6 +429,7 @@ __global__ void advance_kernel(const int32_t *cnt, int32_t *len, int32_t *rows_i
 }
 
 int g_gemm_variant = 0;
+int g_attn_variant = 0;   // test/bench hook: 1 = VALU chunk attention
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -383,7 +528,8 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
         // algorithmic bytes: K+V rows read once (2 * 128 B per cached position per head) + q/k/v/out rows of the chunk
         ProfScope ps(c == 1 ? PROF_ATTN_DECODE : PROF_ATTN_CHUNK, s, -1.0);
         if (c == 1) hipLaunchKernelGGL(attention_kernel<1>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
-        else hipLaunchKernelGGL(attention_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
+        else if (g_attn_variant == 1) hipLaunchKernelGGL(attention_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
+        else hipLaunchKernelGGL(attention_chunk_mfma_kernel, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
         }
         LMRL_CHECK_LAUNCH();
         GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d};
@@ -409,6 +555,7 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
 }
 
 void lmrl_gemm_set_variant(int v) { lmrl::g_gemm_variant = v; }
+void lmrl_attn_set_variant(int v) { lmrl::g_attn_variant = v; }
 
 // Plain bf16 GEMM entry (heads, LM-head logits): C = A.W^T + bias with a selectable epilogue.
 int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda,
