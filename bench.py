@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="envs per GPU")
     ap.add_argument("--vocab-file", default="wordle_official_400.txt")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-variant", type=int, default=0, help="tuning hook: forwarded to lmrl_gemm_set_variant")
     ap.add_argument("--streams", type=int, default=1, help="split the batch into this many sub-batches on separate HIP streams")
     ap.add_argument("--breakdown", action="store_true", help="after the timed region, print a per-kernel-class event breakdown to stderr")
     args = ap.parse_args()
@@ -123,6 +124,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     L = _lib.lib()
+    L.lmrl_gemm_set_variant(args.gemm_variant)
     vocab = W.Vocabulary.builtin(args.vocab_file)
     cfg = GPT2Config.gpt2_small()
     eng = GPT2Engine.random_init(cfg, seed=0, device=dev)
@@ -139,16 +141,17 @@ def main():
     n_eps = args.steps + args.warmup + (1 if args.breakdown else 0)
     guesses = torch.from_numpy(scripted_guesses(vocab.all_vocab, n_eps, n_turns, B, seed=12345 + rank).view(np.int32)).to(dev)
     guesses_s = [guesses[:, :, k * Bs:(k + 1) * Bs].contiguous() for k in range(S)]
+    # env seeds of every episode resident in HBM up front: no host->device copy (= host sync) between episodes
+    seeds_all = torch.from_numpy((np.arange(n_eps * world * B, dtype=np.int64)).reshape(n_eps, world, B)[:, rank].copy()).to(dev)
     total_steps = torch.zeros((), dtype=torch.int64, device=dev)
     tag_ids = {L.lmrl_prof_tag_name(t).decode(): t for t in range(L.lmrl_prof_n_tags())}
     torch.cuda.synchronize()
 
     def episode(i, count):
-        base = np.uint64((i * world + rank) * B)
         gens = []
         for k, (r, st) in enumerate(zip(ros, streams)):
             with torch.cuda.stream(st):
-                seeds = np.arange(Bs, dtype=np.uint64) + base + np.uint64(k * Bs)
+                seeds = seeds_all[i, k * Bs:(k + 1) * Bs]
                 gens.append(r.episode_phases(seeds, temperature=1.0, sample_seed=1000 + rank * 16 + k,
                                              scripted_guesses=guesses_s[k][i], steer_strength=30.0))
         live = list(range(S))
@@ -195,6 +198,17 @@ def main():
                     avg_launch_us=round(ms.value * 1e3 / max(n.value, 1), 2), share_of_step_time=round(ms.value * 1e-3 / dt, 3))
 
     roofline = read_tag(ROOFLINE_TAG)
+    # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of this same
+    # command; gfx950 FETCH_SIZE counts 64 B per 128 B request for wide coalesced loads -> doubled, per the microarch
+    # guide).  Not measurable from inside the process, so the committed summary is reported, with its source.
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write.json")))
+        key = next(k for k in pmc if "attention_kernel<1>" in k)
+        roofline["traffic"] = round((2.0 * pmc[key]["fetch_kb_avg"] + pmc[key]["write_kb_avg"]) * 1024)
+        roofline["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_fetch_write.json)"
+        roofline["algorithmic_bytes_per_launch"] = round(work.value / max(n.value, 1))
+    except Exception:
+        roofline["traffic"] = None
     # other kernel classes: one extra, untimed episode with their brackets on (brackets cost ~2 us per launch)
     L.lmrl_prof_reset()
     mask = 0

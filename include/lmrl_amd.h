@@ -167,7 +167,7 @@ int lmrl_whiten_apply(const float *x_d, const uint8_t *mask_d, const double *mom
  *     ln1_g f32[d], ln1_b f32[d], w_qkv bf16[3d][d], b_qkv f32[3d], w_proj bf16[d][d], b_proj f32[d],
  *     ln2_g f32[d], ln2_b f32[d], w_fc bf16[dff][d], b_fc f32[dff], w_fc2 bf16[d][dff], b_fc2 f32[d]
  *   i.e. every matrix is stored [out][in] (HF Conv1D weights transposed once at load time).
- * KV cache: bf16 [n_layer][2][B][n_head][tmax][64].
+ * KV cache: bf16 [n_layer][2 (K,V)][B][tmax][n_head*64] (token-major: one env's keys for all heads are one contiguous stream).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int32_t n_layer, n_head, d_model, d_ff, vocab, vocab_padded, n_pos;

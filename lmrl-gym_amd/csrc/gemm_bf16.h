@@ -415,6 +415,11 @@ inline hipError_t gemm_launch(const GemmArgs &g, hipStream_t s) {
         case 30: return gemm_launch_glds<64, 64, 2, EPI>(g, s);
         case 31: return gemm_launch_glds<64, 64, 3, EPI>(g, s);
         case 32: return gemm_launch_glds<64, 64, 4, EPI>(g, s);
+        case 100: if (g.M < 2048) return gemm_launch_glds<128, 64, 2, EPI>(g, s); break;
+        case 101: if (g.M < 2048) return gemm_launch_glds<64, 64, 2, EPI>(g, s); break;
+        case 102: if (g.M < 2048) return g.K >= 2048 ? gemm_launch_glds<128, 64, 3, EPI>(g, s) : gemm_launch_glds<64, 64, 2, EPI>(g, s); break;
+        case 103: if (g.M < 2048) return g.K >= 2048 ? gemm_launch_glds<64, 64, 3, EPI>(g, s) : gemm_launch_glds<64, 64, 2, EPI>(g, s); break;
+        case 104: if (g.M >= 2048) return gemm_launch_glds<128, 128, 2, EPI>(g, s); break;
         default: break;
     }
     // measured on MI355X (profiles/r01_gemm_config_sweep.txt): occupancy beats ring depth — 2-stage rings (2+ workgroups

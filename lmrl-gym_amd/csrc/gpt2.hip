@@ -15,8 +15,8 @@
 // Data layout in HBM
 //   residual stream x   f32  [B*C][d]
 //   GEMM activations    bf16 [B*C][d | 3d | d_ff]
-//   KV cache            bf16 [layer][2 (K,V)][B][H][Tmax][64]   (one (b,h) stream is contiguous:
-//                       a wave reads 8 rows = 1 KiB per load instruction, 16 B per lane)
+//   KV cache            bf16 [layer][2 (K,V)][B][Tmax][H*64]  (token-major: one env's K (or V) for all heads is ONE
+//                       contiguous T x 1.5 KiB stream; appends are whole 1.5 KiB rows; a wave reads 8 rows x 128 B per load)
 //   weights             bf16 [N][K] ("out x in", K contiguous) so activation and weight fragments are
 //                       both K-major for the MFMA operand loads (gemm_bf16.h)
 #include "../../include/lmrl_amd.h"
@@ -86,14 +86,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
         if (src < 0) return;   // env contributed no token
     }
     const float *xr = x + (size_t)src * d;
-    f32x4 v[MAXV];
+    f32x4 v[MAXV], g4[MAXV], b4[MAXV];
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXV; k++) {
+    for (int k = 0; k < MAXV; k++) {   // issue every load up front: x row, gamma and beta are independent
         const int c = (k * 64 + lane) * 4;
-        v[k] = c < d ? *reinterpret_cast<const f32x4 *>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+        const bool in = c < d;
+        v[k] = in ? *reinterpret_cast<const f32x4 *>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        g4[k] = in ? *reinterpret_cast<const f32x4 *>(gam + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        b4[k] = in ? *reinterpret_cast<const f32x4 *>(bet + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int k = 0; k < MAXV; k++) s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mean = s / (float)d;
@@ -114,10 +118,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     for (int k = 0; k < MAXV; k++) {
         const int c = (k * 64 + lane) * 4;
         if (c < d) {
-            const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gam + c), b4 = *reinterpret_cast<const f32x4 *>(bet + c);
             uint16_t o[4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) o[e] = f32_to_bf16_rn((v[k][e] - mean) * rstd * g4[e] + b4[e]);
+            for (int e = 0; e < 4; e++) o[e] = f32_to_bf16_rn((v[k][e] - mean) * rstd * g4[k][e] + b4[k][e]);
             uint2 pk;
             pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
             pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
@@ -154,8 +157,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
     const int T = L0 + n_new;
     const int rr = lane >> 3, cc = lane & 7;
     const size_t ld = (size_t)3 * d;
-    uint16_t *kc = kcache + ((size_t)b * H + h) * Tmax * 64;
-    uint16_t *vc = vcache + ((size_t)b * H + h) * Tmax * 64;
+    uint16_t *kc = kcache + (size_t)b * Tmax * d + (size_t)h * 64;   // token-major cache: row t of head h at kc + t*d
+    uint16_t *vc = vcache + (size_t)b * Tmax * d + (size_t)h * 64;
     const uint16_t *qbase = qkv + (size_t)b * C * ld + (size_t)h * 64;
 
     // append this chunk's K/V rows to the cache (row j -> position L0 + j)
@@ -163,8 +166,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
         if (L0 + j < Tmax) {
             const uint4 kv = *reinterpret_cast<const uint4 *>(qbase + (size_t)j * ld + d + cc * 8);
             const uint4 vv = *reinterpret_cast<const uint4 *>(qbase + (size_t)j * ld + 2 * d + cc * 8);
-            *reinterpret_cast<uint4 *>(kc + (size_t)(L0 + j) * 64 + cc * 8) = kv;
-            *reinterpret_cast<uint4 *>(vc + (size_t)(L0 + j) * 64 + cc * 8) = vv;
+            *reinterpret_cast<uint4 *>(kc + (size_t)(L0 + j) * d + cc * 8) = kv;
+            *reinterpret_cast<uint4 *>(vc + (size_t)(L0 + j) * d + cc * 8) = vv;
         }
     }
 
@@ -193,41 +196,52 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
         for (int e = 0; e < 8; e++) o[j][e] = 0.f;
     }
 
-    for (int t0 = 0; t0 < T; t0 += 8) {
-        const int t = t0 + rr;
-        const bool in_range = t < T;
-        const int tc = in_range ? t : T - 1;
-        // position < L0: cache ; otherwise this chunk's own row
-        const uint16_t *kp = tc < L0 ? kc + (size_t)tc * 64 + cc * 8 : qbase + (size_t)(tc - L0) * ld + d + cc * 8;
-        const uint16_t *vp = tc < L0 ? vc + (size_t)tc * 64 + cc * 8 : qbase + (size_t)(tc - L0) * ld + 2 * d + cc * 8;
-        const uint4 kraw = *reinterpret_cast<const uint4 *>(kp);
-        const uint4 vraw = *reinterpret_cast<const uint4 *>(vp);
-        float kf[8], vf[8];
-        {
-            const uint32_t kw[4] = {kraw.x, kraw.y, kraw.z, kraw.w}, vw[4] = {vraw.x, vraw.y, vraw.z, vraw.w};
+    // U key blocks (8 rows each) per iteration: all 2U loads of a lane are issued before the first use so that a decode
+    // wave keeps several 16-byte requests in flight (the kernel is HBM-latency/bandwidth bound, not ALU bound).
+    constexpr int U = (C == 1) ? 4 : 1;
+    for (int t0 = 0; t0 < T; t0 += 8 * U) {
+        uint4 kraw[U], vraw[U];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                kf[2 * k] = bf16_to_f32((uint16_t)(kw[k] & 0xffff)); kf[2 * k + 1] = bf16_to_f32((uint16_t)(kw[k] >> 16));
-                vf[2 * k] = bf16_to_f32((uint16_t)(vw[k] & 0xffff)); vf[2 * k + 1] = bf16_to_f32((uint16_t)(vw[k] >> 16));
-            }
+        for (int u = 0; u < U; u++) {
+            const int t = t0 + u * 8 + rr;
+            const int tc = t < T ? t : T - 1;
+            // position < L0: cache ; otherwise this chunk's own row
+            const uint16_t *kp = tc < L0 ? kc + (size_t)tc * d + cc * 8 : qbase + (size_t)(tc - L0) * ld + d + cc * 8;
+            const uint16_t *vp = tc < L0 ? vc + (size_t)tc * d + cc * 8 : qbase + (size_t)(tc - L0) * ld + 2 * d + cc * 8;
+            kraw[u] = *reinterpret_cast<const uint4 *>(kp);
+            vraw[u] = *reinterpret_cast<const uint4 *>(vp);
         }
 #pragma unroll
-        for (int j = 0; j < C; j++) {
-            if (j >= n_new) continue;   // wave-uniform
-            float s = 0.f;
+        for (int u = 0; u < U; u++) {
+            const int t = t0 + u * 8 + rr;
+            const bool in_range = t < T;
+            float kf[8], vf[8];
+            {
+                const uint32_t kw[4] = {kraw[u].x, kraw[u].y, kraw[u].z, kraw[u].w}, vw[4] = {vraw[u].x, vraw[u].y, vraw[u].z, vraw[u].w};
 #pragma unroll
-            for (int e = 0; e < 8; e++) s = fmaf(q[j][e], kf[e], s);
-            s += dpp_f32<0xB1>(s);      // quad_perm [1,0,3,2]  (lane ^ 1)
-            s += dpp_f32<0x4E>(s);      // quad_perm [2,3,0,1]  (lane ^ 2)
-            s += dpp_f32<0x141>(s);     // row_half_mirror: the other quad of this 8-lane group
-            const bool ok = in_range && t <= L0 + j;   // causal: query j sits at position L0 + j
-            const float m_new = ok ? fmaxf(m[j], s) : m[j];
-            const float alpha = __expf(m[j] - m_new);
-            const float p = ok ? __expf(s - m_new) : 0.f;
-            l[j] = l[j] * alpha + p;
+                for (int k = 0; k < 4; k++) {
+                    kf[2 * k] = bf16_to_f32((uint16_t)(kw[k] & 0xffff)); kf[2 * k + 1] = bf16_to_f32((uint16_t)(kw[k] >> 16));
+                    vf[2 * k] = bf16_to_f32((uint16_t)(vw[k] & 0xffff)); vf[2 * k + 1] = bf16_to_f32((uint16_t)(vw[k] >> 16));
+                }
+            }
 #pragma unroll
-            for (int e = 0; e < 8; e++) o[j][e] = fmaf(p, vf[e], o[j][e] * alpha);
-            m[j] = m_new;
+            for (int j = 0; j < C; j++) {
+                if (j >= n_new) continue;   // wave-uniform
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) s = fmaf(q[j][e], kf[e], s);
+                s += dpp_f32<0xB1>(s);      // quad_perm [1,0,3,2]  (lane ^ 1)
+                s += dpp_f32<0x4E>(s);      // quad_perm [2,3,0,1]  (lane ^ 2)
+                s += dpp_f32<0x141>(s);     // row_half_mirror: the other quad of this 8-lane group
+                const bool ok = in_range && t <= L0 + j;   // causal: query j sits at position L0 + j
+                const float m_new = ok ? fmaxf(m[j], s) : m[j];
+                const float alpha = __expf(m[j] - m_new);
+                const float p = ok ? __expf(s - m_new) : 0.f;
+                l[j] = l[j] * alpha + p;
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[j][e] = fmaf(p, vf[e], o[j][e] * alpha);
+                m[j] = m_new;
+            }
         }
     }
 #pragma unroll
@@ -286,8 +300,8 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
     const int L0 = len[b];
     const int T = L0 + n_new;
     const size_t ld = (size_t)3 * d;
-    uint16_t *kc = kcache + ((size_t)b * H + h) * Tmax * 64;
-    uint16_t *vc = vcache + ((size_t)b * H + h) * Tmax * 64;
+    uint16_t *kc = kcache + (size_t)b * Tmax * d + (size_t)h * 64;   // token-major cache: row t of head h at kc + t*d
+    uint16_t *vc = vcache + (size_t)b * Tmax * d + (size_t)h * 64;
     const uint16_t *qbase = qkv + (size_t)b * C * ld + (size_t)h * 64;
     unsigned char *vlds = vlds_all[wave];
     const int j = lane & 15, g = lane >> 4;
@@ -295,8 +309,8 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
     {   // append this chunk's K/V rows to the cache
         const int rr = lane >> 3, cc = lane & 7;
         if (rr < n_new && L0 + rr < Tmax) {
-            *reinterpret_cast<uint4 *>(kc + (size_t)(L0 + rr) * 64 + cc * 8) = *reinterpret_cast<const uint4 *>(qbase + (size_t)rr * ld + d + cc * 8);
-            *reinterpret_cast<uint4 *>(vc + (size_t)(L0 + rr) * 64 + cc * 8) = *reinterpret_cast<const uint4 *>(qbase + (size_t)rr * ld + 2 * d + cc * 8);
+            *reinterpret_cast<uint4 *>(kc + (size_t)(L0 + rr) * d + cc * 8) = *reinterpret_cast<const uint4 *>(qbase + (size_t)rr * ld + d + cc * 8);
+            *reinterpret_cast<uint4 *>(vc + (size_t)(L0 + rr) * d + cc * 8) = *reinterpret_cast<const uint4 *>(qbase + (size_t)rr * ld + 2 * d + cc * 8);
         }
     }
     // B operand of step A: query j (zero beyond n_new), dims kk*32 + g*8 ..
@@ -319,7 +333,7 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
         for (int i = 0; i < 4; i++) {
             const int id = lane + 64 * i, kl = id >> 3, c = id & 7;
             int t = t0 + kl; t = t < T ? t : T - 1;
-            const uint16_t *vp = t < L0 ? vc + (size_t)t * 64 + c * 8 : qbase + (size_t)(t - L0) * ld + 2 * d + c * 8;
+            const uint16_t *vp = t < L0 ? vc + (size_t)t * d + c * 8 : qbase + (size_t)(t - L0) * ld + 2 * d + c * 8;
             const u32x4 v = *reinterpret_cast<const u32x4 *>(vp);
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(vlds + kl * VROW + c * 16);
             dst[0] = ((unsigned long long)v[1] << 32) | v[0];
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
             sacc[sb] = f32x4{0.f, 0.f, 0.f, 0.f};
             int t = t0 + (j >> 2) * 8 + sb * 4 + (j & 3);
             t = t < T ? t : T - 1;
-            const uint16_t *kp = t < L0 ? kc + (size_t)t * 64 : qbase + (size_t)(t - L0) * ld + d;
+            const uint16_t *kp = t < L0 ? kc + (size_t)t * d : qbase + (size_t)(t - L0) * ld + d;
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
                 const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4 *>(kp + kk * 32 + g * 8));

@@ -148,13 +148,21 @@ class VectorWordleEnv(BatchedTextEnv):
         self.reward = t.zeros(n, dtype=t.float32, device=self.device)
         self.flags = t.zeros(n, dtype=t.uint8, device=self.device)
 
-    def reset_device(self, seeds: np.ndarray, mask: Optional["np.ndarray"] = None) -> None:
+    def reset_device(self, seeds, mask=None) -> None:
+        """seeds: numpy uint64 array OR an int64 device tensor (no host sync: lets consecutive episodes pipeline);
+        mask: optional numpy / device uint8 array selecting the envs to reset."""
         t = self._torch
         n = len(seeds)
         if n != self.n:
             self._alloc(n)
-        seeds_d = t.from_numpy(np.asarray(seeds, dtype=np.uint64).view(np.int64).copy()).to(self.device)
-        mask_d = None if mask is None else t.from_numpy(np.asarray(mask, dtype=np.uint8)).to(self.device)
+        if isinstance(seeds, t.Tensor):
+            seeds_d = seeds
+        else:
+            seeds_d = t.from_numpy(np.asarray(seeds, dtype=np.uint64).view(np.int64).copy()).to(self.device)
+        if mask is None or isinstance(mask, t.Tensor):
+            mask_d = mask
+        else:
+            mask_d = t.from_numpy(np.asarray(mask, dtype=np.uint8)).to(self.device)
         _lib.check(self._L.lmrl_wordle_reset(self._ctx, _lib.ptr(self.state), _lib.ptr(self.mt), _lib.ptr(seeds_d),
                                              _lib.ptr(mask_d), n, _lib.stream_ptr()), "lmrl_wordle_reset")
 

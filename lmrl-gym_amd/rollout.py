@@ -191,7 +191,7 @@ class WordleRolloutEngine:
         """Generator form of `run_episode`: enqueues one phase (a model forward + its sampling / env bookkeeping) per
         `next()`, so a host loop can interleave several engines on different HIP streams."""
         L, sp, tr, B = self._L, _lib.stream_ptr(), ctypes.byref(self._ctraj), self.B
-        self.env.reset_device(np.asarray(seeds, dtype=np.uint64))
+        self.env.reset_device(seeds if not isinstance(seeds, np.ndarray) else np.asarray(seeds, dtype=np.uint64))
         self.ses.reset()
         self._ck(L.lmrl_wordle_tok_begin(self._tok, tr, _lib.ptr(self.chunk_tok), _lib.ptr(self.chunk_cnt), B, sp), "tok_begin")
         self.ses.forward(self.chunk_tok, self.chunk_cnt, 8)

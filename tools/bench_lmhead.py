@@ -1,0 +1,23 @@
+"""LM-head sampler micro-benchmark: greedy (no RNG) vs Gumbel sampling at M=1024, GPT-2-small vocabulary."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import lmrl_gym_amd  # noqa
+from lmrl_gym_amd import _lib
+from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, SampleParams
+dev = _lib.require_gpu()
+cfg = GPT2Config(1, 12, 768, 3072, 50257, 64)
+eng = GPT2Engine.random_init(cfg, seed=0, device=dev)
+B = 1024
+ses = eng.session(B, 8)
+hid = torch.randn(B, 768, device=dev).to(torch.bfloat16)
+for name, temp in [("greedy", 0.0), ("gumbel", 1.0)]:
+    for _ in range(3):
+        ses.sample(SampleParams(temp, 0, 1, 0, 0.0, 0.0, 0), hidden=hid)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(20):
+        ses.sample(SampleParams(temp, 0, 1, k, 0.0, 0.0, 0), hidden=hid)
+    e1.record(); torch.cuda.synchronize()
+    print(name, "%.1f us per call (lm_head + reduce)" % (e0.elapsed_time(e1) * 1e3 / 20))
