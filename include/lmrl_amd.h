@@ -213,6 +213,7 @@ typedef struct {
     float steer_strength;   /* added to logit[steer_tok_d[row]] (synthetic workloads only; 0 = off) */
     float beta;             /* ILQL logit perturbation weight */
     int32_t pad_token;      /* written for inactive rows */
+    const uint32_t *epoch_d;/* optional DEVICE word = 4th Philox counter word (0 when NULL): fresh noise per hipGraph replay */
 } lmrl_sample_params;
 
 size_t lmrl_sample_ws_bytes(int m, int vocab_padded);
@@ -283,7 +284,8 @@ int lmrl_wordle_tok_guess(lmrl_wordle_tok_ctx *c, const lmrl_wordle_traj *tr, ui
  * ([last unforwarded action token][forced '\n'] + observation tokens; count 0 for finished envs) */
 int lmrl_wordle_tok_observe(lmrl_wordle_tok_ctx *c, const lmrl_wordle_traj *tr, const uint32_t *obs_d, const float *reward_d,
                             const uint8_t *flags_d, int32_t *chunk_tok_d, int32_t *chunk_cnt_d, int n, void *stream);
-/* synthetic workloads: token spelling letter k (k = 5: '\n') of a scripted packed guess, for lmrl_sample_params.steer */
+/* synthetic workloads: token spelling letter k (k = 5: '\n') of a scripted packed guess, for lmrl_sample_params.steer;
+ * k < 0 writes all six positions at once, steer_d = int32 [6][n] */
 int lmrl_wordle_tok_steer(lmrl_wordle_tok_ctx *c, const uint32_t *scripted_guess_d, int k, int32_t *steer_d, int n,
                           void *stream);
 

@@ -129,6 +129,125 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------ fused small kernels
+// embed + first LayerNorm: x[r] = wte[tok] + wpe[pos] (fp32 residual stream) and h[r] = LN(x[r]) (bf16) in one pass.
+template <int MAXV>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const uint16_t *__restrict__ wte, const uint16_t *__restrict__ wpe,
+                                                       const int32_t *__restrict__ tokens, const int32_t *__restrict__ cnt,
+                                                       const int32_t *__restrict__ len, const float *__restrict__ gam,
+                                                       const float *__restrict__ bet, float *__restrict__ x, uint16_t *__restrict__ y,
+                                                       int B, int C, int d, int vocab, int n_pos, float eps) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= B * C) return;
+    const int b = r / C, j = r - b * C;
+    int tok = tokens[r];
+    int pos = len[b] + j;
+    const bool valid = j < cnt[b];
+    if (!valid || tok < 0 || tok >= vocab) tok = 0;
+    if (!valid || pos >= n_pos) pos = 0;
+    const uint16_t *te = wte + (size_t)tok * d, *pe = wpe + (size_t)pos * d;
+    f32x4 v[MAXV], g4[MAXV], b4[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int c = (k * 64 + lane) * 4;
+        v[k] = f32x4{0.f, 0.f, 0.f, 0.f}; g4[k] = v[k]; b4[k] = v[k];
+        if (c < d) {
+            const uint2 a = *reinterpret_cast<const uint2 *>(te + c), p = *reinterpret_cast<const uint2 *>(pe + c);
+            v[k] = f32x4{bf16_to_f32((uint16_t)(a.x & 0xffff)) + bf16_to_f32((uint16_t)(p.x & 0xffff)),
+                         bf16_to_f32((uint16_t)(a.x >> 16)) + bf16_to_f32((uint16_t)(p.x >> 16)),
+                         bf16_to_f32((uint16_t)(a.y & 0xffff)) + bf16_to_f32((uint16_t)(p.y & 0xffff)),
+                         bf16_to_f32((uint16_t)(a.y >> 16)) + bf16_to_f32((uint16_t)(p.y >> 16))};
+            g4[k] = *reinterpret_cast<const f32x4 *>(gam + c);
+            b4[k] = *reinterpret_cast<const f32x4 *>(bet + c);
+            *reinterpret_cast<f32x4 *>(x + (size_t)r * d + c) = v[k];
+        }
+        s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const float t = v[k][e] - mean; q += t * t; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)d + eps);
+#pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < d) {
+            uint16_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = f32_to_bf16_rn((v[k][e] - mean) * rstd * g4[k][e] + b4[k][e]);
+            uint2 pk;
+            pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+            pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+            *reinterpret_cast<uint2 *>(y + (size_t)r * d + c) = pk;
+        }
+    }
+}
+
+// final LayerNorm of each env's LAST new token + len[b] += cnt[b] (replaces advance_kernel + gathered layernorm)
+template <int MAXV>
+__global__ __launch_bounds__(256) void final_ln_advance_kernel(const float *__restrict__ x, const float *__restrict__ gam,
+                                                               const float *__restrict__ bet, uint16_t *__restrict__ y,
+                                                               const int32_t *__restrict__ cnt, int32_t *__restrict__ len, int B, int C,
+                                                               int d, float eps) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const int n = min(cnt[b], C);
+    if (n <= 0) return;
+    if (lane == 0) len[b] += n;
+    if (!y) return;
+    const float *xr = x + ((size_t)b * C + n - 1) * d;
+    f32x4 v[MAXV], g4[MAXV], b4[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int c = (k * 64 + lane) * 4;
+        const bool in = c < d;
+        v[k] = in ? *reinterpret_cast<const f32x4 *>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        g4[k] = in ? *reinterpret_cast<const f32x4 *>(gam + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        b4[k] = in ? *reinterpret_cast<const f32x4 *>(bet + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const float t = v[k][e] - mean; q += t * t; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)d + eps);
+#pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < d) {
+            uint16_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = f32_to_bf16_rn((v[k][e] - mean) * rstd * g4[k][e] + b4[k][e]);
+            uint2 pk;
+            pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+            pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+            *reinterpret_cast<uint2 *>(y + (size_t)b * d + c) = pk;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ attention
 // DPP lane move on a float (VALU, no LDS round trip): CTRL as in the ISA (quad_perm 0x00-0xFF, row_half_mirror 0x141 ...)
 template <int CTRL>
@@ -524,8 +643,11 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
 
     if (unsigned long long *ctr = prof_byte_counter(c == 1 ? PROF_ATTN_DECODE : PROF_ATTN_CHUNK))
         hipLaunchKernelGGL(attn_bytes_kernel, dim3(1), dim3(256), 0, s, cnt_d, len_d, b, c, cf.n_head * cf.n_layer, ctr);
-    hipLaunchKernelGGL(embed_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, s, m->wte, m->wpe, tokens_d, cnt_d, len_d, w.x, b, c, d,
-                       cf.vocab, cf.n_pos);
+    // embeddings + LN1 of layer 0 in one launch
+    if (d <= 1024) hipLaunchKernelGGL(embed_ln_kernel<4>, dim3(ceil_div(M, 4)), dim3(256), 0, s, m->wte, m->wpe, tokens_d, cnt_d, len_d,
+                                      m->layers[0].ln1_g, m->layers[0].ln1_b, w.x, w.h, b, c, d, cf.vocab, cf.n_pos, cf.ln_eps);
+    else hipLaunchKernelGGL(embed_ln_kernel<8>, dim3(ceil_div(M, 4)), dim3(256), 0, s, m->wte, m->wpe, tokens_d, cnt_d, len_d,
+                            m->layers[0].ln1_g, m->layers[0].ln1_b, w.x, w.h, b, c, d, cf.vocab, cf.n_pos, cf.ln_eps);
     LMRL_CHECK_LAUNCH();
     auto ln = [&](const float *g, const float *be, uint16_t *y, const int32_t *idx, int rows) {
         if (d <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w.x, g, be, y, idx, rows, d, cf.ln_eps);
@@ -534,8 +656,10 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
     for (int l = 0; l < cf.n_layer; l++) {
         const Gpt2Layer &L = m->layers[l];
         uint16_t *kc = (uint16_t *)kv_d + (size_t)(2 * l) * kv_layer, *vc = kc + kv_layer;
-        ln(L.ln1_g, L.ln1_b, w.h, nullptr, M);
-        LMRL_CHECK_LAUNCH();
+        if (l > 0) {
+            ln(L.ln1_g, L.ln1_b, w.h, nullptr, M);
+            LMRL_CHECK_LAUNCH();
+        }
         GemmArgs g{w.h, L.w_qkv, L.b_qkv, w.qkv, M, 3 * d, d, d, 3 * d, 3 * d};
         LMRL_CHECK_HIP(gemm_launch<EPI_BF16>(g, s));
         {
@@ -555,16 +679,16 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
         GemmArgs g2{w.ff, L.w_fc2, L.b_fc2, w.x, M, d, cf.d_ff, cf.d_ff, d, d};
         LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(g2, s));
     }
-    hipLaunchKernelGGL(advance_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, s, cnt_d, len_d, w.rows_idx, b, c);
-    LMRL_CHECK_LAUNCH();
-    if (last_hidden_d) {
-        ln(m->lnf_g, m->lnf_b, (uint16_t *)last_hidden_d, w.rows_idx, b);
-        LMRL_CHECK_LAUNCH();
-    }
-    if (all_hidden_d) {
+    if (all_hidden_d) {   // before len is advanced / independent of it
         ln(m->lnf_g, m->lnf_b, (uint16_t *)all_hidden_d, nullptr, M);
         LMRL_CHECK_LAUNCH();
     }
+    // ln_f of each env's last new token (optional) + len[b] += cnt[b]
+    if (d <= 1024) hipLaunchKernelGGL(final_ln_advance_kernel<4>, dim3(ceil_div(b, 4)), dim3(256), 0, s, w.x, m->lnf_g, m->lnf_b,
+                                      (uint16_t *)last_hidden_d, cnt_d, len_d, b, c, d, cf.ln_eps);
+    else hipLaunchKernelGGL(final_ln_advance_kernel<8>, dim3(ceil_div(b, 4)), dim3(256), 0, s, w.x, m->lnf_g, m->lnf_b,
+                            (uint16_t *)last_hidden_d, cnt_d, len_d, b, c, d, cf.ln_eps);
+    LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }
 

@@ -98,6 +98,46 @@ LMRL_HD void mt_seed(const MtRef &r, uint64_t seed, const uint32_t *table) {
     *(r.idx + r.e) = kMtN;
 }
 
+#ifndef LMRL_HOST_ONLY
+// Seeding + first regeneration with the 624-word state held in LDS (32 streams per 64-thread workgroup use 78 KiB):
+// the 1870 dependent steps then pay LDS latency (~64 cycles) instead of an HBM round trip each, and the final state is
+// written to the struct-of-arrays HBM buffer with coalesced stores.  `lds` = 624*32 uint32 of dynamic shared memory.
+constexpr int kMtSeedLanes = 32;
+__device__ __forceinline__ void mt_seed_and_twist_lds(uint32_t *lds, void *mt_buf, int n, int e, bool do_it, uint64_t seed,
+                                                      const uint32_t *table) {
+    const int slot = threadIdx.x % kMtSeedLanes;
+    if (do_it) {
+        MtRef l;
+        l.mt = lds; l.idx = lds; l.n = kMtSeedLanes; l.e = slot;       // idx unused below
+        const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+        const int klen = key[1] ? 2 : 1;
+        uint32_t prev = table[0], mt1 = 0;
+        int j = 0;
+        for (int i = 1; i < kMtN; i++) {
+            const uint32_t cur = (table[i] ^ ((prev ^ (prev >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            l.set(i, cur);
+            if (i == 1) mt1 = cur;
+            prev = cur;
+            j = (j + 1 == klen) ? 0 : j + 1;
+        }
+        mt1 = (mt1 ^ ((prev ^ (prev >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+        prev = mt1;
+        for (int i = 2; i < kMtN; i++) {
+            const uint32_t cur = (l.get(i) ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+            l.set(i, cur);
+            prev = cur;
+        }
+        mt1 = (mt1 ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
+        l.set(1, mt1);
+        l.set(0, 0x80000000u);
+        mt_twist(l);
+        MtRef g = mt_ref(mt_buf, n, e);
+        for (int k = 0; k < kMtN; k++) g.set(k, l.get(k));
+        g.idx[e] = 0;
+    }
+}
+#endif
+
 LMRL_HD uint32_t mt_next(const MtRef &r) {
     uint32_t i = r.idx[r.e];
     if (i >= (uint32_t)kMtN) {

@@ -5,6 +5,8 @@
 
 namespace lmrl {
 
+constexpr size_t kMtSeedLdsBytes = (size_t)kMtN * kMtSeedLanes * sizeof(uint32_t);   // 78 KiB
+
 // init_genrand(19650218) table, uploaded once per process.
 static uint32_t *g_table_d = nullptr;
 
@@ -19,17 +21,21 @@ int mt_table(const uint32_t **out) {
     return LMRL_OK;
 }
 
-// One thread per stream; consecutive threads touch consecutive dwords of every mt[k][*] row.
-__global__ void mt_seed_kernel(void *mt, const uint64_t *seeds, const uint8_t *mask, const uint32_t *table, int n) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    if (mask && !mask[e]) return;
-    MtRef r = mt_ref(mt, n, e);
-    mt_seed(r, seeds[e], table);
-    // do the first regeneration here (coalesced across streams) so that draws in the
-    // wave-per-env step kernels are a single dword read.
-    mt_twist(r);
-    r.idx[e] = 0;
+static hipError_t mt_seed_attr();
+
+// One thread per stream, 32 streams per workgroup with the MT state in LDS during seeding (mt19937.h).
+__global__ __launch_bounds__(kMtSeedLanes) void mt_seed_kernel(void *mt, const uint64_t *seeds, const uint8_t *mask, const uint32_t *table, int n) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t mt_lds[];
+    const int e = blockIdx.x * kMtSeedLanes + threadIdx.x;
+    const bool on = e < n && (!mask || mask[e]);
+    mt_seed_and_twist_lds(mt_lds, mt, n, e, on, on ? seeds[e] : 0ull, table);
+}
+
+static hipError_t mt_seed_attr() {
+    static bool done = false;
+    if (done) return hipSuccess;
+    done = true;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&mt_seed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMtSeedLdsBytes);
 }
 
 __global__ void mt_stream_kernel(void *mt, uint32_t *out, int n_out, int n) {
@@ -60,7 +66,8 @@ int lmrl_mt_seed(void *mt_d, const uint64_t *seeds_d, const uint8_t *mask_d, int
     const uint32_t *table;
     int rc = mt_table(&table);
     if (rc) return rc;
-    hipLaunchKernelGGL(mt_seed_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, as_stream(stream), mt_d, seeds_d, mask_d, table, n);
+    LMRL_CHECK_HIP(mt_seed_attr());
+    hipLaunchKernelGGL(mt_seed_kernel, dim3(ceil_div(n, kMtSeedLanes)), dim3(kMtSeedLanes), kMtSeedLdsBytes, as_stream(stream), mt_d, seeds_d, mask_d, table, n);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

@@ -7,7 +7,7 @@
 // (LLM_RL/algorithms/value_rl_base/gpt2/generation.py:97-119).
 //
 // jax.random.categorical(logits) IS argmax(logits + Gumbel noise), so sampling needs no normalisation:
-// the LM-head GEMM tile epilogue draws the noise (Philox4x32-10, counter = (row, column/4, step)), keeps a
+// the LM-head GEMM tile epilogue draws the noise (Philox4x32-7, counter = (row, column/4, step, epoch)), keeps a
 // per-row running (max, sum-exp, best perturbed score, its column, its logit) and only ~10 floats per
 // (row, 128-column tile) ever reach HBM instead of the [B, 50257] fp32 logits (206 MB / token at B=1024).
 // A second tiny kernel merges the per-tile partials into (token, log-prob).
@@ -21,11 +21,14 @@
 
 namespace lmrl {
 
-// ---- Philox4x32-10 (Salmon et al. 2011), the counter-based generator also used by cuRAND/rocRAND ----
+// ---- Philox4x32-R (Salmon et al., SC'11), the counter-based generator also used by cuRAND/rocRAND.  The sampler uses
+// R = 7 rounds: the smallest round count the paper reports as passing BigCrush; its 32x32->64 multiplies are quarter-rate
+// on CDNA, so rounds are what the Gumbel epilogue pays for (10 -> 7 rounds = -12 us per 1024 x 50257 sampling step).
+constexpr int kPhiloxRounds = 7;
 __host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                        uint32_t k1, uint32_t out[4]) {
 #pragma unroll
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < kPhiloxRounds; r++) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
         const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
@@ -47,6 +50,7 @@ struct SampleParams {
     float inv_temperature;   // 1/T ; greedy when `greedy` != 0
     int greedy;
     uint32_t seed_lo, seed_hi, step;
+    const uint32_t *epoch;   // optional device word used as the 4th Philox counter word (lets a captured hipGraph draw fresh noise per replay)
     float steer_strength;    // added to the logit of steer_tok[row] (synthetic-workload hook, see bench.py)
     float beta;              // ILQL: logits = pi + beta*min(q1,q2) ; 0 with no q operands
     int vocab;               // logical vocabulary (columns >= vocab are padding -> -inf)
@@ -123,6 +127,7 @@ __global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__r
     }
 
     // ---- sampling epilogue
+    const uint32_t epoch = sp.epoch ? *sp.epoch : 0u;
     __syncthreads();                                   // the LDS ring is free: reuse it for the wn=1 -> wn=0 hand-off
     float *xch = reinterpret_cast<float *>(smem);      // [2 (wm)][64 rows][5]
 #pragma unroll
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__r
         for (int i = 0; i < FN; i++) {
             const int n = n0 + wn * (BN / 2) + i * 16 + lq * 4;
             uint32_t rnd[4] = {0, 0, 0, 0};
-            if (!sp.greedy) philox4x32_10((uint32_t)m, (uint32_t)(n >> 2), sp.step, 0u, sp.seed_lo, sp.seed_hi, rnd);
+            if (!sp.greedy) philox4x32_10((uint32_t)m, (uint32_t)(n >> 2), sp.step, epoch, sp.seed_lo, sp.seed_hi, rnd);
             float zz[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -263,11 +268,12 @@ __global__ __launch_bounds__(256) void topk_sample_kernel(const float *__restric
         __syncthreads();
     }
     const uint32_t thr_key = prefix;   // key of the k-th largest logit
+    const uint32_t epoch = sp.epoch ? *sp.epoch : 0u;
     float pmax = -INFINITY, psum = 0.f, best = -INFINITY, best_z = 0.f;
     int best_col = 0x7fffffff;
     for (int n4 = tid * 4; n4 < vocab; n4 += 256 * 4) {
         uint32_t rnd[4] = {0, 0, 0, 0};
-        if (!sp.greedy) philox4x32_10((uint32_t)m, (uint32_t)(n4 >> 2), sp.step, 0u, sp.seed_lo, sp.seed_hi, rnd);
+        if (!sp.greedy) philox4x32_10((uint32_t)m, (uint32_t)(n4 >> 2), sp.step, epoch, sp.seed_lo, sp.seed_hi, rnd);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int n = n4 + r;
@@ -327,7 +333,7 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     SampleParams sp;
     sp.greedy = (p->temperature <= 0.f) ? 1 : 0;
     sp.inv_temperature = sp.greedy ? 1.f : 1.f / p->temperature;
-    sp.seed_lo = (uint32_t)p->seed; sp.seed_hi = (uint32_t)(p->seed >> 32); sp.step = p->step;
+    sp.seed_lo = (uint32_t)p->seed; sp.seed_hi = (uint32_t)(p->seed >> 32); sp.step = p->step; sp.epoch = p->epoch_d;
     sp.steer_strength = p->steer_strength; sp.beta = p->beta; sp.vocab = vocab;
     hipStream_t s = as_stream(stream);
     const XcdMap xm = make_xcd_map((m + kLmBM - 1) / kLmBM, vocab_padded / kLmBN, 2.0 * m * d_model, 2.0 * (double)vocab_padded * d_model);
@@ -369,7 +375,7 @@ int lmrl_sample_logits(const float *logits_d, int ld, int m, int vocab, const lm
     SampleParams sp;
     sp.greedy = (p->temperature <= 0.f) ? 1 : 0;
     sp.inv_temperature = sp.greedy ? 1.f : 1.f / p->temperature;
-    sp.seed_lo = (uint32_t)p->seed; sp.seed_hi = (uint32_t)(p->seed >> 32); sp.step = p->step;
+    sp.seed_lo = (uint32_t)p->seed; sp.seed_hi = (uint32_t)(p->seed >> 32); sp.step = p->step; sp.epoch = p->epoch_d;
     sp.steer_strength = 0.f; sp.beta = 0.f; sp.vocab = vocab;
     hipLaunchKernelGGL(topk_sample_kernel, dim3(m), dim3(256), 0, as_stream(stream), logits_d, ld, vocab, p->top_k, active_d,
                        token_d, logprob_d, sp, p->pad_token);

@@ -30,19 +30,18 @@ struct WordleCtx {
 // rows of the SoA game-state buffer
 enum { ROW_FORB = 0, ROW_MUST = 5, ROW_NFILT = 10, ROW_NACT = 11, ROW_HIST = 12 };
 
-__global__ void wordle_reset_kernel(uint32_t *st, void *mt, const uint64_t *seeds, const uint8_t *mask,
-                                    const uint32_t *table, int V, int n) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    if (mask && !mask[e]) return;
-    for (int k = 0; k < 10; k++) st[(size_t)k * n + e] = 0u;           // all POSSIBLE (game.py:72-74)
-    st[(size_t)ROW_NFILT * n + e] = (uint32_t)V;                       // filtered_vocab = all_vocab
-    st[(size_t)ROW_NACT * n + e] = 0u;
-    for (int k = 0; k < kWordleTries; k++) st[(size_t)(ROW_HIST + k) * n + e] = kBadGuess;
-    MtRef r = mt_ref(mt, n, e);
-    mt_seed(r, seeds[e], table);                                       // env.py:53
-    mt_twist(r);
-    r.idx[e] = 0;
+__global__ __launch_bounds__(kMtSeedLanes) void wordle_reset_kernel(uint32_t *st, void *mt, const uint64_t *seeds, const uint8_t *mask,
+                                                                    const uint32_t *table, int V, int n) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t mt_lds[];
+    const int e = blockIdx.x * kMtSeedLanes + threadIdx.x;
+    const bool on = e < n && (!mask || mask[e]);
+    if (on) {
+        for (int k = 0; k < 10; k++) st[(size_t)k * n + e] = 0u;           // all POSSIBLE (game.py:72-74)
+        st[(size_t)ROW_NFILT * n + e] = (uint32_t)V;                       // filtered_vocab = all_vocab
+        st[(size_t)ROW_NACT * n + e] = 0u;
+        for (int k = 0; k < kWordleTries; k++) st[(size_t)(ROW_HIST + k) * n + e] = kBadGuess;
+    }
+    mt_seed_and_twist_lds(mt_lds, mt, n, e, on, on ? seeds[e] : 0ull, table);   // env.py:53, state staged in LDS
 }
 
 __global__ __launch_bounds__(256) void wordle_step_kernel(const uint32_t *__restrict__ words,
@@ -232,7 +231,13 @@ int lmrl_wordle_reset(lmrl_wordle_ctx *ctx, void *state_d, void *mt_d, const uin
     const uint32_t *table;
     int rc = mt_table(&table);
     if (rc) return rc;
-    hipLaunchKernelGGL(wordle_reset_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, as_stream(stream),
+    constexpr size_t lds = (size_t)kMtN * kMtSeedLanes * sizeof(uint32_t);
+    static bool attr = false;
+    if (!attr) {
+        LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&wordle_reset_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(wordle_reset_kernel, dim3(ceil_div(n, kMtSeedLanes)), dim3(kMtSeedLanes), lds, as_stream(stream),
                        (uint32_t *)state_d, mt_d, seeds_d, mask_d, table, ctx->V, n);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;

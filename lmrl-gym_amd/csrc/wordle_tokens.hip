@@ -141,6 +141,15 @@ __global__ void tok_observe_kernel(lmrl_wordle_tokens t, lmrl_wordle_traj tr, co
 __global__ void tok_steer_kernel(lmrl_wordle_tokens t, const uint32_t *scripted_guess, int k, int32_t *steer, int n) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
+    if (k < 0) {   // all six positions at once: steer[j][e]
+        const uint32_t g = scripted_guess[e];
+        for (int j = 0; j < 5; j++) {
+            const uint32_t c = (g >> (5 * j)) & 31u;
+            steer[(size_t)j * n + e] = j == 0 ? t.letter_first[c % 26] : t.letter_sp[c % 26];
+        }
+        steer[(size_t)5 * n + e] = t.newline;
+        return;
+    }
     if (k >= 5) { steer[e] = t.newline; return; }
     const uint32_t c = (scripted_guess[e] >> (5 * k)) & 31u;
     steer[e] = k == 0 ? t.letter_first[c % 26] : t.letter_sp[c % 26];

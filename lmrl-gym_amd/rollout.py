@@ -163,7 +163,7 @@ class WordleRolloutEngine:
         self.chunk_tok, self.chunk_cnt = z(B * 8, dt=t.int32), z(B, dt=t.int32)
         self.next_tok, self.next_cnt = z(B, dt=t.int32), z(B, dt=t.int32)
         self.guess, self.active = z(B, dt=t.int32), z(B, dt=t.uint8)
-        self.steer = z(B, dt=t.int32)
+        self.steer = z(6, B, dt=t.int32)
         self.sample_step = 0
 
     def close(self):
@@ -176,18 +176,47 @@ class WordleRolloutEngine:
         _lib.check(rc, what)
 
     def run_episode(self, seeds: np.ndarray, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0,
-                    scripted_guesses=None, steer_strength: float = 0.0, n_turns: int = W.N_TRIES):
+                    scripted_guesses=None, steer_strength: float = 0.0, n_turns: int = W.N_TRIES, epoch=None):
         """One full episode for all B envs (asynchronous: returns after enqueueing; read results after a sync).
 
         scripted_guesses: optional int32 device tensor [n_turns][B] of packed guesses; with steer_strength > 0 the
         sampler is steered towards spelling them (synthetic-workload hook; every logit is still computed and sampled).
         """
-        for _ in self.episode_phases(seeds, temperature, top_k, sample_seed, scripted_guesses, steer_strength, n_turns):
+        for _ in self.episode_phases(seeds, temperature, top_k, sample_seed, scripted_guesses, steer_strength, n_turns, epoch):
             pass
         return self.traj
 
+    # ---- hipGraph mode: the whole episode (~3400 kernel launches) is captured once and replayed with one host call.
+    # Everything that changes between episodes lives in device memory: env seeds, scripted guesses and the sampler's
+    # `epoch` word (4th Philox counter word), so replays draw fresh noise and start from fresh env seeds.
+    def capture_episode(self, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0, steer_strength: float = 0.0,
+                        n_turns: int = W.N_TRIES, scripted: bool = False):
+        import torch
+        t = torch
+        self.g_seeds = t.zeros(self.B, dtype=t.int64, device=self.dev)
+        self.g_guesses = t.zeros((n_turns, self.B), dtype=t.int32, device=self.dev) if scripted else None
+        self.g_epoch = t.zeros(1, dtype=t.int32, device=self.dev)
+        kw = dict(temperature=temperature, top_k=top_k, sample_seed=sample_seed, scripted_guesses=self.g_guesses,
+                  steer_strength=steer_strength, n_turns=n_turns, epoch=self.g_epoch)
+        self.run_episode(self.g_seeds, **kw)            # eager warm-up: one-time attribute / table initialisation
+        t.cuda.synchronize()
+        self.sample_step = 0
+        self.graph = t.cuda.CUDAGraph()
+        with t.cuda.graph(self.graph):
+            self.run_episode(self.g_seeds, **kw)
+        return self.graph
+
+    def replay_episode(self, seeds_d, guesses_d=None):
+        """seeds_d int64 [B] and guesses_d int32 [n_turns][B] are device tensors (device-to-device copies, no host sync)."""
+        self.g_seeds.copy_(seeds_d, non_blocking=True)
+        if guesses_d is not None:
+            self.g_guesses.copy_(guesses_d, non_blocking=True)
+        self.g_epoch.add_(1)
+        self.graph.replay()
+        return self.traj
+
     def episode_phases(self, seeds: np.ndarray, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0,
-                       scripted_guesses=None, steer_strength: float = 0.0, n_turns: int = W.N_TRIES):
+                       scripted_guesses=None, steer_strength: float = 0.0, n_turns: int = W.N_TRIES, epoch=None):
         """Generator form of `run_episode`: enqueues one phase (a model forward + its sampling / env bookkeeping) per
         `next()`, so a host loop can interleave several engines on different HIP streams."""
         L, sp, tr, B = self._L, _lib.stream_ptr(), ctypes.byref(self._ctraj), self.B
@@ -200,13 +229,14 @@ class WordleRolloutEngine:
         if top_k > 0:
             import torch
             logits_out = torch.empty(B, self.eng.cfg.vocab_padded, dtype=torch.float32, device=self.dev)
+        steered = scripted_guesses is not None and steer_strength != 0.0
         for turn in range(n_turns):
+            if steered:     # one launch spells the whole scripted guess of this turn
+                self._ck(L.lmrl_wordle_tok_steer(self._tok, _lib.ptr(scripted_guesses[turn]), -1, _lib.ptr(self.steer), B, sp), "tok_steer")
             for k in range(self.max_new):
-                steer = None
-                if scripted_guesses is not None and steer_strength != 0.0:
-                    self._ck(L.lmrl_wordle_tok_steer(self._tok, _lib.ptr(scripted_guesses[turn]), k, _lib.ptr(self.steer), B, sp), "tok_steer")
-                    steer = self.steer
-                p = SampleParams(temperature, top_k, sample_seed, self.sample_step, steer_strength, 0.0, self.tokens.pad)
+                steer = self.steer[min(k, 5)] if steered else None
+                p = SampleParams(temperature, top_k, sample_seed, self.sample_step, steer_strength, 0.0, self.tokens.pad,
+                                 _lib.ptr(epoch))
                 self.sample_step += 1
                 self.ses.sample(p, steer_tok=steer, active=self.traj["gen_active"], logits_out=logits_out)
                 self._ck(L.lmrl_wordle_tok_accept(self._tok, tr, _lib.ptr(self.ses.token), k, _lib.ptr(self.next_tok),

@@ -67,13 +67,14 @@ def round_weights_to_bf16(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
     return out
 
 
-# ---- Philox4x32-10 + Gumbel, restating csrc/sampler.hip's documented random stream (numpy, uint64 math)
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
+# ---- Philox4x32-R + Gumbel, restating csrc/sampler.hip's documented random stream (numpy, uint64 math); the sampler
+# uses R = 7 rounds, the Random123 known-answer vectors (tests/test_oracle_gpt2.py) pin the R = 10 function
+def philox4x32_10(c0, c1, c2, c3, k0, k1, rounds: int = 10):
     import numpy as np
     c0, c1, c2, c3 = (np.asarray(x, dtype=np.uint64) for x in (c0, c1, c2, c3))
     k0, k1 = np.uint64(k0), np.uint64(k1)
     M = np.uint64(0xFFFFFFFF)
-    for _ in range(10):
+    for _ in range(rounds):
         p0 = np.uint64(0xD2511F53) * c0
         p1 = np.uint64(0xCD9E8D57) * c2
         n0 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M
@@ -86,13 +87,13 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
-def gumbel_noise(rows: int, vocab: int, seed: int, step: int):
-    """[rows, vocab] float32 Gumbel noise exactly as the kernels draw it: counter (row, col//4, step, 0)."""
+def gumbel_noise(rows: int, vocab: int, seed: int, step: int, epoch: int = 0):
+    """[rows, vocab] float32 Gumbel noise exactly as the kernels draw it: counter (row, col//4, step, epoch)."""
     import numpy as np
     ncol4 = (vocab + 3) // 4
     r = np.repeat(np.arange(rows, dtype=np.uint64), ncol4)
     c = np.tile(np.arange(ncol4, dtype=np.uint64), rows)
-    o = philox4x32_10(r, c, np.full_like(r, step), np.zeros_like(r), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    o = philox4x32_10(r, c, np.full_like(r, step), np.full_like(r, epoch), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, rounds=7)
     bits = np.stack(o, axis=1).reshape(rows, ncol4 * 4)[:, :vocab]
     u = ((bits >> np.uint64(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.1920928955078125e-07)
     return -np.log(-np.log(u))
