@@ -105,6 +105,9 @@ def lib() -> ctypes.CDLL:
             raise LmrlError(
                 f"{SO_PATH} not found: build it with `python lmrl-gym_amd/build.py` "
                 "(or `__graft_entry__.build()`); there is no CPU fallback for the HIP path.")
+        # torch first: it brings its own libamdhip64 and the library must bind to that same HIP runtime — loading ours
+        # first leaves two runtimes in the process and every device call of this library then fails.
+        import torch  # noqa: F401
         L = ctypes.CDLL(SO_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)

@@ -38,6 +38,41 @@ def bc_weights(attention_mask: np.ndarray, is_action: np.ndarray, non_action_wei
     return am * (ia + (1.0 - ia) * np.float32(non_action_weight)), float(am.sum())
 
 
+def masked_ce_forward_backward(m: GPT2F32, ids: np.ndarray, am: np.ndarray, pos: np.ndarray, w: np.ndarray, denom: float,
+                               grads=None, grad_scale: float = 1.0) -> float:
+    """loss = sum(w * CE(logits[:, :-1], ids[:, 1:])) / denom with the masked sums all-reduced across ranks; when `grads`
+    is given, grad_scale * d loss / d params is ACCUMULATED into it (shared by the BC trainer and the PPO BC term)."""
+    import torch
+    B, T = ids.shape
+    R, dev = B * T, m.dev
+    ids_d = _t(ids, np.int32)
+    hid, cache = m.forward(ids_d, _t(am, np.uint8), _t(pos, np.int32))
+    logits = m.lm_logits(hid, R)
+    tgt = torch.zeros(R, dtype=torch.int32, device=dev)
+    tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
+    lp, lse = torch.empty(R, dtype=torch.float32, device=dev), torch.empty(R, dtype=torch.float32, device=dev)
+    ops.lse_gather(logits, m.vocab, m.vocab, tgt, R, logprob=lp, lse=lse)
+    if D.is_distributed():
+        denom = float(D.allreduce_sum_(torch.tensor([denom], dtype=torch.float64, device=dev)).item())
+    wfull = np.zeros((B, T), dtype=np.float32)
+    wfull[:, :-1] = np.asarray(w, dtype=np.float32) / np.float32(denom)
+    coef = _t(wfull.reshape(-1), np.float32)
+    # loss = sum(coef * CE) = -sum(coef * logprob): a dot product done as a 1 x 1 x R GEMM on the matrix core
+    out = torch.zeros(1, dtype=torch.float32, device=dev)
+    ops.sgemm(coef, lp, out, 1, 1, R, alpha=-1.0, lda=R, ldb=1, ldc=1)
+    if D.is_distributed():
+        D.allreduce_sum_(out)
+    loss = float(out.item())
+    if grads is not None:
+        if grad_scale != 1.0:
+            ops.axpby(grad_scale, coef, 0.0, None, coef)
+        ops.ce_bwd(logits, m.vocab, m.vocab, lse, tgt, coef, None, R)
+        d_hidden = torch.empty(R, m.d, dtype=torch.float32, device=dev)
+        m.lm_head_backward(hid, logits, R, d_hidden, grads, accumulate_dh=False)
+        m.backward(cache, d_hidden, grads)
+    return loss
+
+
 class GPT2BCTrain:
     """fp32 BC trainer: loss = sum(w * CE) / sum(attn[:, 1:])  (bc/interface.py:28-43)."""
 
@@ -48,38 +83,13 @@ class GPT2BCTrain:
         self.last_grads = None
 
     def step(self, input_ids, is_action, attention_mask=None, position_ids=None, train: bool = True):
-        import torch
         ids = np.asarray(input_ids, dtype=np.int32)
         am, pos = initialize_attn_mask_pos_ids(ids, self.pad, attention_mask, position_ids)
-        B, T = ids.shape
-        R, m = B * T, self.model
-        dev = m.dev
-        ids_d = _t(ids, np.int32)
-        hid, cache = m.forward(ids_d, _t(am, np.uint8), _t(pos, np.int32))
-        logits = m.lm_logits(hid, R)
-        tgt = torch.zeros(R, dtype=torch.int32, device=dev)
-        tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
-        lp, lse = torch.empty(R, dtype=torch.float32, device=dev), torch.empty(R, dtype=torch.float32, device=dev)
-        ops.lse_gather(logits, m.vocab, m.vocab, tgt, R, logprob=lp, lse=lse)
         w, denom = bc_weights(am, is_action, self.w)
-        if D.is_distributed():
-            denom = float(D.allreduce_sum_(torch.tensor([denom], dtype=torch.float64, device=dev)).item())
-        wfull = np.zeros((B, T), dtype=np.float32)
-        wfull[:, :-1] = w / denom
-        coef = _t(wfull.reshape(-1), np.float32)
-        # loss = sum(coef * CE) = -sum(coef * logprob): a dot product done as a 1 x 1 x R GEMM on the matrix core
-        out = torch.zeros(1, dtype=torch.float32, device=dev)
-        ops.sgemm(coef, lp, out, 1, 1, R, alpha=-1.0, lda=R, ldb=1, ldc=1)
-        if D.is_distributed():
-            D.allreduce_sum_(out)
-        loss = float(out.item())
+        grads = self.model.zero_grads() if train else None
+        loss = masked_ce_forward_backward(self.model, ids, am, pos, w, denom, grads)
         if not train:
             return self, loss, {"loss": np.float32(loss)}
-        ops.ce_bwd(logits, m.vocab, m.vocab, lse, tgt, coef, None, R)
-        grads = m.zero_grads()
-        d_hidden = torch.empty(R, m.d, dtype=torch.float32, device=dev)
-        m.lm_head_backward(hid, logits, R, d_hidden, grads, accumulate_dh=False)
-        m.backward(cache, d_hidden, grads)
         self.last_grads = grads
         D.allreduce_grads([grads])
         self.opt.apply(grads)

@@ -101,3 +101,53 @@ def mc_loss(q, q_logits, token_ids, attention_mask, should_take_action, returns,
     loss, logs, _, _ = mc_loss_device(f32(q), ce.view(B, T1), f32(attention_mask), _t(should_take_action, np.uint8), f32(returns),
                                       cql_weight=cql_weight)
     return loss, logs
+
+
+class GPT2MCTrain:
+    """fp32 MC-returns trainer: GPT-2 base + Q `MLPHead` (d -> d -> V), loss = `mc_loss`
+    (LLM_RL/algorithms/mc_returns/gpt2/interface.py:57-170; step signature of mc_returns/base_interface.py:89-137).
+    `step` returns `(self, loss, logs)` and updates the trainer in place."""
+
+    def __init__(self, base, q_head, pad_token_id: int, loss_kwargs, lr: float = 3e-5, weight_decay: float = 0.0,
+                 grad_accum_steps: int = 1, detach_q: bool = False):
+        from ..train.gpt2_f32 import AdamW
+        self.base, self.q_head, self.pad, self.loss_kwargs, self.detach_q = base, q_head, pad_token_id, dict(loss_kwargs), detach_q
+        self.base_opt = AdamW(base.p, lr, weight_decay=weight_decay, every_k=grad_accum_steps)
+        self.q_opt = AdamW(q_head.p, lr, weight_decay=weight_decay, every_k=grad_accum_steps, no_decay=lambda n: n.endswith("bias"))
+        self.last_grads = None
+
+    def step(self, input_ids, should_take_action, returns, prng_key=None, attention_mask=None, position_ids=None, train: bool = True):
+        import torch
+        from .. import dist as D
+        from .common import initialize_attn_mask_pos_ids
+        ids = np.asarray(input_ids, dtype=np.int32)
+        am, pos = initialize_attn_mask_pos_ids(ids, self.pad, attention_mask, position_ids)
+        B, T = ids.shape
+        R, base, dev, V = B * T, self.base, self.base.dev, self.q_head.dout
+        ids_d = _t(ids, np.int32)
+        hid, cache = base.forward(ids_d, _t(am, np.uint8), _t(pos, np.int32))
+        qo, qc = self.q_head.forward(hid, R)
+        tgt = torch.zeros(R, dtype=torch.int32, device=dev)
+        tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
+        new = lambda: torch.empty(R, dtype=torch.float32, device=dev)
+        qsa, lse, lp, ce = new(), new(), new(), new()
+        ops.lse_gather(qo, V, V, tgt, R, logprob=lp, lse=lse, target_logit=qsa)
+        ops.axpby(-1.0, lp, 0.0, None, ce)
+        sl = lambda x: x.view(B, T)[:, :-1].contiguous()
+        f32 = lambda x: _t(x, np.float32)
+        loss, logs, dq, coef = mc_loss_device(sl(qsa), sl(ce), f32(am[:, 1:]), _t(should_take_action, np.uint8), f32(returns), **self.loss_kwargs)
+        if not train:
+            return self, loss, logs
+        full = lambda g: (lambda z: (z.view(B, T)[:, :-1].copy_(g), z)[1])(torch.zeros(R, dtype=torch.float32, device=dev))
+        ops.ce_bwd(qo, V, V, lse, tgt, full(coef), full(dq), R)          # qo := d loss / d q logits
+        bgrads, qgrads = base.zero_grads(), self.q_head.zero_grads()
+        d_hidden = torch.empty(R, base.d, dtype=torch.float32, device=dev)
+        self.q_head.backward(qc, qo, qgrads, dx=d_hidden, accumulate_dx=False)
+        if self.detach_q:
+            d_hidden.zero_()
+        base.backward(cache, d_hidden, bgrads)
+        self.last_grads = (bgrads, qgrads)
+        D.allreduce_grads([bgrads, qgrads])
+        self.base_opt.apply(bgrads)
+        self.q_opt.apply(qgrads)
+        return self, loss, logs

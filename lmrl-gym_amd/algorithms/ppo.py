@@ -166,6 +166,16 @@ def ppo_loss_fn(attention_mask, logprobs, values, should_take_action, old_logpro
 
 
 # ----------------------------------------------------------------------------- data (ppo/data.py:9-114)
+def _masked_lm_term(policy, pad, input_ids, attention_mask, position_ids, training_mask, grads, grad_scale):
+    """The BC auxiliary of PPO: JaxSeq `loss_fn_mask` as wired in llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py —
+    sum(CE * training_mask[:, 1:]) / sum(training_mask[:, 1:]) on a second batch (third-party arithmetic: parity unpinned)."""
+    from .bc import masked_ce_forward_backward
+    ids = np.asarray(input_ids, dtype=np.int32)
+    am, pos = initialize_attn_mask_pos_ids(ids, pad, attention_mask, position_ids)
+    tm = np.asarray(training_mask if training_mask is not None else am, dtype=np.float32)[:, 1:]
+    return masked_ce_forward_backward(policy, ids, am, pos, tm, float(tm.sum()), grads, grad_scale)
+
+
 class PPOData(NamedTuple):
     input_ids: np.ndarray           # [t]
     should_take_action: np.ndarray  # [t-1]
@@ -229,6 +239,9 @@ class GPT2PPOTrain:
         self.bc_loss_weight = bc_loss_weight
         self.last_grads = None
 
+    def _bc_term(self, ids, am, pos, tmask, grads):
+        return _masked_lm_term(self.policy, self.pad, ids, am, pos, tmask, grads, self.bc_loss_weight)
+
     def step(self, input_ids, should_take_action, old_logprobs, old_values, old_advantages, old_returns, prng_key=None,
              attention_mask=None, position_ids=None, bc_data_input_ids=None, bc_data_input_attention_mask=None,
              bc_data_input_position_ids=None, bc_data_input_training_mask=None, train: bool = True):
@@ -254,6 +267,11 @@ class GPT2PPOTrain:
         attn_s = f32(am[:, 1:])
         loss, logs, dlp, dv = ppo_loss_device(attn_s, sl(logprob_all), sl(values_full.view(R)), _t(should_take_action, np.uint8),
                                               f32(old_logprobs), f32(old_values), f32(old_advantages), f32(old_returns), **self.loss_kwargs)
+        use_bc = bc_data_input_ids is not None
+        if use_bc and not train:
+            bc_loss = self._bc_term(bc_data_input_ids, bc_data_input_attention_mask, bc_data_input_position_ids, bc_data_input_training_mask, None)
+            total = loss + bc_loss * self.bc_loss_weight
+            return self, total, {"ppo": logs, "bc": {"loss": np.float32(bc_loss)}, "total_loss": np.float32(total)}
         if not train:
             return self, loss, logs
         # ---- backward: d loss / d logprob[r] -> logits via CE backward (logprob = -CE -> coef_ce = -dlp) ; values -> head
@@ -269,6 +287,11 @@ class GPT2PPOTrain:
         dvals.view(B, T)[:, :-1] = dv
         head.backward(hcache, dvals, hgrads, dx=d_hidden, accumulate_dx=True)
         pol.backward(cache, d_hidden, pgrads)
+        if use_bc:   # policy_grads += bc_loss_weight * bc_grads ; loss += bc_loss_weight * bc_loss  (gpt2/interface.py:180-203)
+            del cache, logits, d_hidden
+            bc_loss = self._bc_term(bc_data_input_ids, bc_data_input_attention_mask, bc_data_input_position_ids, bc_data_input_training_mask, pgrads)
+            total = loss + bc_loss * self.bc_loss_weight
+            loss, logs = total, {"ppo": logs, "bc": {"loss": np.float32(bc_loss)}, "total_loss": np.float32(total)}
         self.last_grads = (pgrads, hgrads)
         D.allreduce_grads([pgrads, hgrads])      # the one data-path collective of a PPO step (RCCL over xGMI)
         self.policy_opt.apply(pgrads)

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__r
         const int m = m0 + wm * (BM / 2) + j * 16 + lr;
         const int st = (steer_tok && m < M) ? steer_tok[m] : -1;
         RowPartial rp{-INFINITY, 0.f, -INFINITY, 0.f, 0x7fffffff};
+        float vv[FN][4];
 #pragma unroll
         for (int i = 0; i < FN; i++) {
             const int n = n0 + wn * (BN / 2) + i * 16 + lq * 4;
@@ -155,12 +156,16 @@ __global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__r
                 const float v = colok ? zz[r] * sp.inv_temperature : -INFINITY;
                 const float sc = sp.greedy ? v : v + gumbel_from_bits(rnd[r]);
                 if (colok && sc > rp.best) { rp.best = sc; rp.best_col = n + r; rp.best_z = v; }
-                if (colok) {
-                    const float nm = fmaxf(rp.pmax, v);
-                    rp.psum = rp.psum * __expf(rp.pmax - nm) + __expf(v - nm);
-                    rp.pmax = nm;
-                }
+                vv[i][r] = v;
+                rp.pmax = fmaxf(rp.pmax, v);
             }
+        }
+        // this lane's 4*FN logits: one exp each against the lane maximum (padding columns are -inf -> exp = 0)
+        if (rp.pmax > -INFINITY) {
+#pragma unroll
+            for (int i = 0; i < FN; i++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) rp.psum += __expf(vv[i][r] - rp.pmax);
         }
         // merge the 4 lane groups (lq) that hold the same row: xor 16, 32
 #pragma unroll

@@ -191,8 +191,9 @@ def ilql_loss(q1, q2, v, v_final, target_q1, target_q2, q1_logits, q2_logits, to
 
 
 def ilql_gather_qv(q1_head_out, q2_head_out, v_head_out, tq1_head_out, tq2_head_out, input_ids, attention_mask,
-                   should_take_action, dones):
-    """ilql/gpt2/interface.py:241-273 (no next_token_ids branch): Q(s,a) gathers, v, v_full, v_final."""
+                   should_take_action, dones, next_v_head_out=None, next_attention_mask=None, next_dones=None):
+    """ilql/gpt2/interface.py:241-273: Q(s,a) gathers, v, v_full, v_final.  With `next_v_head_out` (the V head applied to
+    the hidden states of `next_token_ids`, [B, T', 1]) v_final follows the next-token branch (:252-264)."""
     ids = input_ids[:, 1:].long().unsqueeze(-1)
     take = lambda h: h[:, :-1].gather(2, ids).squeeze(2)
     q1, q2 = take(q1_head_out), take(q2_head_out)
@@ -205,6 +206,10 @@ def ilql_gather_qv(q1_head_out, q2_head_out, v_head_out, tq1_head_out, tq2_head_
     d = dones.to(F64)
     final_idx = ((1 - d) * last_action + d * last_token).to(torch.int64)
     v_final = v_full[torch.arange(v_full.shape[0]), final_idx] * (1 - d)
+    if next_v_head_out is not None:
+        nam = next_attention_mask
+        last_next = (nam.shape[1] - 1) - torch.argmax(torch.flip(nam.to(torch.int32), dims=[1]), dim=1)
+        v_final = next_v_head_out.squeeze(2)[torch.arange(nam.shape[0]), last_next] * (1 - next_dones.to(F64))
     return q1, q2, v, v_final.detach(), tq1, tq2
 
 

@@ -309,6 +309,97 @@ def test_ilql_train_step_vs_oracle(dev):
     _close(tr.q1_target.p["dense2.bias"].cpu(), 0.1 * tr.q1.p["dense2.bias"].cpu().double() + 0.9 * hq1["dense2.bias"].double(), rtol=1e-6)
 
 
+def test_ilql_next_token_branch_and_ppo_bc_term(dev):
+    """(1) ILQL step with next_token_ids/next_dones: v_final comes from the V head on the last next-chunk token
+    (ilql/gpt2/interface.py:252-264).  (2) PPO step with the BC auxiliary batch: loss + w*bc_loss, grads summed (:180-203)."""
+    from lmrl_gym_amd.algorithms import ilql, ppo
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32, MLPHeadF32
+    from oracle import gpt2 as O, rl
+    cfg, sd = _tiny_model(17, vocab=61)
+    pad = cfg.vocab - 1
+    rng = np.random.RandomState(21)
+    B, T, V, d = 3, 13, cfg.vocab, cfg.d_model
+    ids, sta, lens = _batch(rng, B, T, cfg.vocab, pad)
+    nids = np.full((B, 6), pad, dtype=np.int32)
+    for b, n in enumerate((6, 2, 4)):
+        nids[b, :n] = rng.randint(0, pad, size=n)
+    ndones = np.array([0, 1, 0], dtype=np.float32)
+    rewards = (rng.randn(B, T - 1) * sta).astype(np.float32)
+    dones = np.array([0, 0, 1], dtype=np.float32)
+    g = torch.Generator().manual_seed(4)
+    mk = lambda out: {"dense1.kernel": torch.randn(d, d, generator=g) * 0.2, "dense1.bias": torch.randn(d, generator=g) * 0.1,
+                      "dense2.kernel": torch.randn(d, out, generator=g) * 0.2, "dense2.bias": torch.full((out,), -0.3)}
+    hq1, hq2, hv = mk(V), mk(V), mk(1)
+    kw = dict(gamma=0.9, tau=0.6, cql_weight=0.1)
+    psd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    req = lambda h: {k: v.double().requires_grad_(True) for k, v in h.items()}
+    rq1, rq2, rv = req(hq1), req(hq2), req(hv)
+    am = torch.from_numpy((ids != pad).astype(np.int64)); pos = (am.cumsum(-1) - 1).clamp(min=0)
+    nam = torch.from_numpy((nids != pad).astype(np.int64)); npos = (nam.cumsum(-1) - 1).clamp(min=0)
+    idt = torch.from_numpy(ids).long()
+    mh = lambda x, h: rl.mlp_head(x, h["dense1.kernel"], h["dense1.bias"], h["dense2.kernel"], h["dense2.bias"])
+    _, hid = O.forward(psd, idt, cfg.n_head, attention_mask=am, position_ids=pos, return_hidden=True)
+    _, nhid = O.forward(psd, torch.from_numpy(nids).long(), cfg.n_head, attention_mask=nam, position_ids=npos, return_hidden=True)
+    q1o, q2o, vo = mh(hid, rq1), mh(hid, rq2), mh(hid, rv)
+    det = lambda h: {k: v.detach() for k, v in h.items()}
+    tq1o, tq2o = mh(hid.detach(), det(rq1)), mh(hid.detach(), det(rq2))      # no separate target base: targets share the trunk
+    q1, q2, v, v_final, tq1, tq2 = rl.ilql_gather_qv(q1o, q2o, vo, tq1o, tq2o, idt, am, torch.from_numpy(sta), torch.from_numpy(dones),
+                                                     next_v_head_out=mh(nhid, rv), next_attention_mask=nam, next_dones=torch.from_numpy(ndones))
+    loss_ref, logs_ref = rl.ilql_loss(q1, q2, v, v_final, tq1, tq2, q1o[:, :-1], q2o[:, :-1], idt[:, 1:], am[:, 1:].double(),
+                                      torch.from_numpy(sta), torch.from_numpy(rewards).double(), **kw)
+    loss_ref.backward()
+    base = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
+    cp = lambda h: {k: v.clone() for k, v in h.items()}
+    tr = ilql.GPT2ILQLTrain(base, MLPHeadF32(cp(hq1), dev), MLPHeadF32(cp(hq2), dev), MLPHeadF32(cp(hv), dev), pad, kw, lr=1e-3)
+    _, loss, logs = tr.step(ids, sta, rewards, dones, next_token_ids=nids, next_dones=ndones)
+    assert abs(loss - float(loss_ref)) <= 1e-4 * abs(float(loss_ref)), (loss, float(loss_ref))
+    rf, gf = _flat_logs(logs_ref), _flat_logs(logs)
+    for k in rf:
+        assert abs(gf[k] - rf[k]) <= 1e-4 * max(1.0, abs(rf[k])), (k, gf[k], rf[k])
+    for k in psd:
+        _close(tr.last_grads[0][k].cpu(), psd[k].grad, rtol=3e-4, name=k)
+
+    # ---- PPO + BC auxiliary
+    cfg, sd = _tiny_model(19)
+    pad = cfg.vocab - 1
+    B, T = 3, 12
+    ids, sta, lens = _batch(rng, B, T, cfg.vocab, pad)
+    bc_ids, bc_sta, _ = _batch(rng, 2, 10, cfg.vocab, pad)
+    bc_mask = np.concatenate([np.zeros((2, 1), np.float32), bc_sta.astype(np.float32)], axis=1) * (bc_ids != pad)
+    hk, hb = torch.randn(cfg.d_model, 1, generator=g) * 0.1, torch.tensor([-1.0])
+    olp, ov, oa, orr = (rng.randn(B, T - 1).astype(np.float32) * s for s in (0.2, 1, 1, 1))
+    kw = dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=0.5)
+    bcw = 0.7
+    psd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    hkr, hbr = hk.double().requires_grad_(True), hb.double().requires_grad_(True)
+    am = torch.from_numpy((ids != pad).astype(np.int64)); pos = (am.cumsum(-1) - 1).clamp(min=0)
+    logits, hid = O.forward(psd, torch.from_numpy(ids).long(), cfg.n_head, attention_mask=am, position_ids=pos, return_hidden=True)
+    values = rl.linear_head(hid, hkr, hbr)[:, :-1, 0]
+    logprobs = rl.token_logprobs_from_logits(logits, torch.from_numpy(ids))
+    olp = logprobs.detach().numpy().astype(np.float32) + olp
+    td = lambda x: torch.from_numpy(np.asarray(x)).double()
+    ppo_ref, _ = rl.ppo_loss(am[:, 1:].double(), logprobs, values, torch.from_numpy(sta), td(olp), td(ov), td(oa), td(orr), **kw)
+    bam = torch.from_numpy((bc_ids != pad).astype(np.int64)); bpos = (bam.cumsum(-1) - 1).clamp(min=0)
+    bl = O.forward(psd, torch.from_numpy(bc_ids).long(), cfg.n_head, attention_mask=bam, position_ids=bpos)
+    bce = -rl.token_logprobs_from_logits(bl, torch.from_numpy(bc_ids))
+    bm = td(bc_mask)[:, 1:]
+    bc_ref = (bce * bm).sum() / bm.sum()
+    total_ref = ppo_ref + bcw * bc_ref
+    total_ref.backward()
+    pol = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
+    head = LinearHeadF32(dict(kernel=hk.clone(), bias=hb.clone()), dev)
+    tr = ppo.GPT2PPOTrain(pol, head, pad, kw, lr=1e-3, bc_loss_weight=bcw)
+    _, ev_loss, ev_logs = tr.step(ids, sta, olp, ov, oa, orr, bc_data_input_ids=bc_ids, bc_data_input_training_mask=bc_mask, train=False)
+    _, loss, logs = tr.step(ids, sta, olp, ov, oa, orr, bc_data_input_ids=bc_ids, bc_data_input_training_mask=bc_mask)
+    assert set(logs) == {"ppo", "bc", "total_loss"} and abs(ev_loss - loss) < 1e-6
+    assert abs(loss - float(total_ref)) <= 1e-4 * abs(float(total_ref)), (loss, float(total_ref))
+    assert abs(float(logs["bc"]["loss"]) - float(bc_ref)) <= 1e-4 * abs(float(bc_ref))
+    pg, hg = tr.last_grads
+    for k in psd:
+        _close(pg[k].cpu(), psd[k].grad, rtol=3e-4, name=k)
+    _close(hg["kernel"].cpu(), hkr.grad, rtol=3e-4)
+
+
 # ------------------------------------------------------------------ MC returns, BC, rerankers
 def test_mc_returns_and_loss(dev):
     from lmrl_gym_amd.algorithms import mc_returns as mc
@@ -340,6 +431,41 @@ def test_mc_returns_and_loss(dev):
     assert set(rf) == set(gf) and abs(loss - float(lref)) < 2e-5 * max(1, abs(float(lref)))
     for k in rf:
         assert abs(gf[k] - rf[k]) <= 3e-5 * max(1.0, abs(rf[k])), (k, gf[k], rf[k])
+
+
+def test_mc_train_step_vs_oracle(dev):
+    from lmrl_gym_amd.algorithms import mc_returns as mc
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    from oracle import gpt2 as O, rl
+    cfg, sd = _tiny_model(23, vocab=53)
+    pad = cfg.vocab - 1
+    rng = np.random.RandomState(6)
+    B, T, V, d = 3, 12, cfg.vocab, cfg.d_model
+    ids, sta, lens = _batch(rng, B, T, cfg.vocab, pad)
+    ret = (rng.randn(B, T - 1) * sta).astype(np.float32)
+    g = torch.Generator().manual_seed(8)
+    hq = {"dense1.kernel": torch.randn(d, d, generator=g) * 0.2, "dense1.bias": torch.randn(d, generator=g) * 0.1,
+          "dense2.kernel": torch.randn(d, V, generator=g) * 0.2, "dense2.bias": torch.full((V,), -0.2)}
+    psd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    rq = {k: v.double().requires_grad_(True) for k, v in hq.items()}
+    am = torch.from_numpy((ids != pad).astype(np.int64)); pos = (am.cumsum(-1) - 1).clamp(min=0)
+    idt = torch.from_numpy(ids).long()
+    _, hid = O.forward(psd, idt, cfg.n_head, attention_mask=am, position_ids=pos, return_hidden=True)
+    qo = rl.mlp_head(hid, rq["dense1.kernel"], rq["dense1.bias"], rq["dense2.kernel"], rq["dense2.bias"])
+    q = qo[:, :-1].gather(2, idt[:, 1:].unsqueeze(-1)).squeeze(2)
+    lref, logs_ref = rl.mc_loss(q, qo[:, :-1], idt[:, 1:], am[:, 1:].double(), torch.from_numpy(sta), torch.from_numpy(ret).double(), cql_weight=0.05)
+    lref.backward()
+    base = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
+    tr = mc.GPT2MCTrain(base, MLPHeadF32({k: v.clone() for k, v in hq.items()}, dev), pad, dict(cql_weight=0.05), lr=1e-3)
+    _, loss, logs = tr.step(ids, sta, ret)
+    assert abs(loss - float(lref)) <= 1e-4 * abs(float(lref))
+    rf, gf = _flat_logs(logs_ref), _flat_logs(logs)
+    for k in rf:
+        assert abs(gf[k] - rf[k]) <= 1e-4 * max(1.0, abs(rf[k])), (k, gf[k], rf[k])
+    for k in psd:
+        _close(tr.last_grads[0][k].cpu(), psd[k].grad, rtol=3e-4, name=k)
+    for k in rq:
+        _close(tr.last_grads[1][k].cpu(), rq[k].grad, rtol=3e-4, name=k)
 
 
 def test_bc_train_step_and_score_fns(dev):
