@@ -199,6 +199,9 @@ int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *
 void lmrl_gemm_set_variant(int v);
 /* bench/test hook: 0 = MFMA chunk attention (default), 1 = VALU chunk attention */
 void lmrl_attn_set_variant(int v);
+/* A/B hook: 1 (default) folds every LayerNorm but ln_f into the neighbouring GEMMs (no stand-alone LN launches);
+ * 0 runs the stand-alone LayerNorm kernels. */
+void lmrl_gpt2_set_ln_fusion(int on);
 
 /* ------------------------------------------------------------------------------------------
  * Fused LM-head + sampling (csrc/sampler.hip).  Replaces logits[:, -1] -> warpers -> jax.random.categorical in

@@ -30,6 +30,14 @@ enum GemmEpi {
     EPI_RESID_F32 = 2,   // C f32 += acc + bias   (residual stream, in place)
     EPI_F32 = 3,         // C f32 = acc + bias
     EPI_RELU_BF16 = 4,   // C bf16 = relu(acc + bias)
+    // ---- LayerNorm folded into the neighbouring GEMMs (no stand-alone LN launch between them):
+    // producer: the residual GEMM also writes a bf16 copy of the updated row and per-(row, 32-column group) partial
+    //           sums (sum x, sum x^2) into fixed slots (deterministic: one writer per slot, fixed read order);
+    // consumer: runs on the RAW bf16 residual copy with gamma pre-multiplied into W (W' = W . diag(gamma)) and applies
+    //           LN(x) W^T = rstd * (x W'^T - mu * colsum(W')) + (bias + W beta) in the epilogue.
+    EPI_RESID_F32_STATS = 5,
+    EPI_BF16_LN = 6,
+    EPI_GELU_BF16_LN = 7,
 };
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rn(float f) {
@@ -54,6 +62,12 @@ struct GemmArgs {
     void *C;             // [M][ldc] bf16 or f32 by epilogue
     int M, N, K, lda, ldc;
     int n_store;         // columns >= n_store are not stored (logical N, <= N)
+    // LayerNorm fusion operands (EPI_RESID_F32_STATS / EPI_*_LN only)
+    float2 *stats;        // [M][nslots] (sum x, sum x^2) partials of the residual row
+    uint16_t *xb;         // producer: bf16 copy of the updated residual stream, [M][ldc]
+    const float *colsum;  // consumer: c[n] = sum_k W'[n][k]
+    int nslots;           // consumer: slots to add per row ; producer: row pitch of `stats`
+    float inv_d, eps;     // consumer: 1/d_model, LN epsilon
 };
 
 template <int BM, int BN, int EPI>
@@ -222,9 +236,14 @@ __device__ __forceinline__ bool xcd_tile(const XcdMap &x, int id, int &tile_m, i
 
 // Shared main loop: acc[i][j] += W-fragment i (rows n0 + wn*BN/2 + 16 i ..) x A-fragment j (rows m0 + wm*BM/2 + 16 j ..).
 // Starts with a barrier so that it can be called repeatedly on the same LDS ring (fused multi-operand kernels).
-template <int BM, int BN, int STAGES>
+struct NoExtraLoads { __device__ __forceinline__ void operator()() const {} };
+
+// EXTRA / extra(): `EXTRA` additional per-lane global loads that the caller issues through `extra()` right AFTER the ring
+// prologue; vmcnt retires loads in order, so the wait for the first K-tile allows them to stay in flight and their
+// latency hides behind the K loop (they are complete by the second wait).
+template <int BM, int BN, int STAGES, int EXTRA = 0, class Extra = NoExtraLoads>
 __device__ __forceinline__ void glds_mainloop(const uint16_t *__restrict__ A, int lda, const uint16_t *__restrict__ W, int K, int M,
-                                              int m0, int n0, char *smem, f32x4 (&acc)[BN / 32][BM / 32]) {
+                                              int m0, int n0, char *smem, f32x4 (&acc)[BN / 32][BM / 32], Extra extra = Extra()) {
     constexpr int BK = 64;
     constexpr int FM = BM / 32, FN = BN / 32;
     constexpr int LA = BM / 32, LW = BN / 32;          // glds instructions per wave per stage (1 KiB segments / 4 waves)
@@ -262,13 +281,24 @@ __device__ __forceinline__ void glds_mainloop(const uint16_t *__restrict__ A, in
 #pragma unroll
     for (int s = 0; s < STAGES - 1; s++)
         if (s < nk) LMRL_GLDS_ISSUE(s, s);
+    if (EXTRA > 0) {
+        // compiler barriers: the extra loads must be issued after the prologue and before the first counted wait — the
+        // wait for K-tile 0 is vmcnt(... + EXTRA), which is only correct for exactly this issue order
+        asm volatile("" ::: "memory");
+        extra();
+        asm volatile("" ::: "memory");
+    }
 
     const int lr = lane & 15, lq = lane >> 4;
     int slot = 0;
     for (int kt = 0; kt < nk; kt++) {
         // stage kt must have landed; up to STAGES-2 later stages may stay in flight
         const int ahead = nk - 1 - kt;
-        if (STAGES >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
+        if (EXTRA > 0 && kt == 0) {      // the caller's EXTRA loads were issued after every prologue stage
+            if (STAGES >= 4 && ahead >= 2) wait_vmcnt<2 * L + EXTRA>();
+            else if (STAGES >= 3 && ahead >= 1) wait_vmcnt<(STAGES >= 3 ? L : 0) + EXTRA>();
+            else wait_vmcnt<EXTRA>();
+        } else if (STAGES >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
         else if (STAGES >= 3 && ahead >= 1) wait_vmcnt<(STAGES >= 3 ? L : 0)>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -304,9 +334,10 @@ __device__ __forceinline__ void glds_mainloop(const uint16_t *__restrict__ A, in
 #undef LMRL_GLDS_ISSUE
 }
 
-template <int BM, int BN, int STAGES, int EPI>
+template <int BM, int BN, int STAGES, int EPI, int NQ = 0>
 __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap xm) {
     constexpr int FM = BM / 32, FN = BN / 32;
+    constexpr bool LN_IN = (EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -314,25 +345,105 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
     if (!xcd_tile(xm, blockIdx.x, tile_m, tile_n)) return;   // workgroup-uniform
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int lr = lane & 15, lq = lane >> 4;
+    // LN_IN: the tile's BM x nslots (sum, sum^2) slots are one contiguous region of `stats`; the 256 threads fetch it
+    // coalesced (NL float4 each) right after the ring prologue, so the latency hides behind the K loop.  After the loop
+    // the per-float4 partial sums go through the (now free) LDS ring and one thread per row adds them in a fixed order
+    // -> (mu, rstd) per row, bit-reproducible.
+    constexpr int NL = LN_IN ? (NQ * BM) / 64 : 0;           // float4 loads per thread: BM*nslots*8 B / (256*16 B)
+    f32x4 st[NL > 0 ? NL : 1];
     f32x4 acc[FN][FM];
 #pragma unroll
     for (int i = 0; i < FN; i++)
 #pragma unroll
         for (int j = 0; j < FM; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    glds_mainloop<BM, BN, STAGES>(g.A, g.lda, g.W, g.K, g.M, m0, n0, smem, acc);
+    if (LN_IN) {
+        const int h4 = g.nslots / 2;                         // float4 per row
+        const f32x4 *sp = reinterpret_cast<const f32x4 *>(g.stats + (size_t)m0 * g.nslots);
+        const int lim = (g.M - m0 < BM ? g.M - m0 : BM) * h4;
+        auto issue = [&]() {   // unconditional (clamped) loads: exactly NL VMEM instructions per wave, as the wait assumes
+#pragma unroll
+            for (int k = 0; k < NL; k++) {
+                const int idx = (int)threadIdx.x + 256 * k;
+                st[k] = sp[idx < lim ? idx : lim - 1];
+            }
+        };
+        glds_mainloop<BM, BN, STAGES, NL>(g.A, g.lda, g.W, g.K, g.M, m0, n0, smem, acc, issue);
+        __syncthreads();                                     // every wave is done with the LDS ring
+        float2 *part = reinterpret_cast<float2 *>(smem);     // [BM * h4] partial (sum, sum^2)
+        float2 *murs = part + BM * 4 * NQ;                   // [BM] (mu, rstd)
+#pragma unroll
+        for (int k = 0; k < NL; k++) part[threadIdx.x + 256 * k] = make_float2(st[k][0] + st[k][2], st[k][1] + st[k][3]);   // rows >= M: unused
+        __syncthreads();
+        if (threadIdx.x < BM) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int q = 0; q < h4; q++) { const float2 p = part[threadIdx.x * h4 + q]; s1 += p.x; s2 += p.y; }
+            const float mu = s1 * g.inv_d;
+            murs[threadIdx.x] = make_float2(mu, rsqrtf(fmaxf(s2 * g.inv_d - mu * mu, 0.f) + g.eps));
+        }
+        __syncthreads();
+    } else {
+        glds_mainloop<BM, BN, STAGES>(g.A, g.lda, g.W, g.K, g.M, m0, n0, smem, acc);
+    }
 
+    if (EPI == EPI_RESID_F32_STATS) {
+        // x += acc + bias ; xb = bf16(x) ; slot (tile_n, wn) of the row gets (sum x, sum x^2) over this wave's BN/2 columns
+#pragma unroll
+        for (int j = 0; j < FM; j++) {
+            const int m = m0 + wm * (BM / 2) + j * 16 + lr;
+            const bool row_ok = m < g.M;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < FN; i++) {
+                const int n = n0 + wn * (BN / 2) + i * 16 + lq * 4;
+                if (n >= g.n_store || !row_ok) continue;
+                f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (g.bias) b4 = *reinterpret_cast<const f32x4 *>(g.bias + n);
+                f32x4 *p = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n);
+                const f32x4 v = *p + (acc[i][j] + b4);
+                *p = v;
+                uint2 o;
+                o.x = (uint32_t)f32_to_bf16_rn(v[0]) | ((uint32_t)f32_to_bf16_rn(v[1]) << 16);
+                o.y = (uint32_t)f32_to_bf16_rn(v[2]) | ((uint32_t)f32_to_bf16_rn(v[3]) << 16);
+                *reinterpret_cast<uint2 *>(g.xb + (size_t)m * g.ldc + n) = o;
+                s1 += (v[0] + v[1]) + (v[2] + v[3]);
+                s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (lq == 0 && row_ok) g.stats[(size_t)m * g.nslots + tile_n * 2 + wn] = make_float2(s1, s2);
+        }
+        return;
+    }
+
+    float ln_mu[FM], ln_rs[FM];
+    if (LN_IN) {
+        const float2 *murs = reinterpret_cast<const float2 *>(smem) + BM * 4 * NQ;
+#pragma unroll
+        for (int j = 0; j < FM; j++) {
+            const float2 p = murs[wm * (BM / 2) + j * 16 + lr];
+            ln_mu[j] = p.x; ln_rs[j] = p.y;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < FN; i++) {
         const int n = n0 + wn * (BN / 2) + i * 16 + lq * 4;
         if (n >= g.n_store) continue;
         f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (g.bias) b4 = *reinterpret_cast<const f32x4 *>(g.bias + n);
+        f32x4 c4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (LN_IN) c4 = *reinterpret_cast<const f32x4 *>(g.colsum + n);
 #pragma unroll
         for (int j = 0; j < FM; j++) {
-            const int m = m0 + wm * (BM / 2) + j * 16 + lr;
+            const int rl = wm * (BM / 2) + j * 16 + lr;
+            const int m = m0 + rl;
             if (m >= g.M) continue;
-            f32x4 v = acc[i][j] + b4;
-            if (EPI == EPI_GELU_BF16) {
+            f32x4 v;
+            if (LN_IN) {
+                v = (acc[i][j] - c4 * ln_mu[j]) * ln_rs[j] + b4;
+            } else {
+                v = acc[i][j] + b4;
+            }
+            if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_BF16_LN) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = gelu_new(v[r]);
             }
@@ -340,7 +451,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
             }
-            if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) {
+            if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || LN_IN) {
                 uint2 o;
                 o.x = (uint32_t)f32_to_bf16_rn(v[0]) | ((uint32_t)f32_to_bf16_rn(v[1]) << 16);
                 o.y = (uint32_t)f32_to_bf16_rn(v[2]) | ((uint32_t)f32_to_bf16_rn(v[3]) << 16);
@@ -357,14 +468,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
 
 extern int g_gemm_variant;   // test/bench hook: 0 = auto (v2), 1 = v1 register-staged kernels
 
-template <int BM, int BN, int STAGES, int EPI>
+template <int BM, int BN, int STAGES, int EPI, int NQ = 0>
 inline hipError_t gemm_launch_glds(const GemmArgs &g, hipStream_t s) {
     const size_t shmem = (size_t)STAGES * (BM + BN) * 128;
     const XcdMap xm = make_xcd_map((g.M + BM - 1) / BM, g.N / BN, 2.0 * g.M * g.K, 2.0 * g.N * g.K);
     const int tiles = xcd_grid(xm);
     static bool attr_set = false;
     if (!attr_set && shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_glds_kernel<BM, BN, STAGES, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_glds_kernel<BM, BN, STAGES, EPI, NQ>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -372,7 +483,7 @@ inline hipError_t gemm_launch_glds(const GemmArgs &g, hipStream_t s) {
     {
         ProfScope ps(BM == 128 && BN == 128 ? PROF_GEMM_128x128 : (BM * BN == 128 * 64 ? PROF_GEMM_64x128 : PROF_GEMM_64x64), s,
                      2.0 * (double)g.M * (double)g.N * (double)g.K);
-        hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, STAGES, EPI>), dim3(tiles), dim3(256), shmem, s, g, xm);
+        hipLaunchKernelGGL((gemm_bf16_glds_kernel<BM, BN, STAGES, EPI, NQ>), dim3(tiles), dim3(256), shmem, s, g, xm);
     }
     return hipGetLastError();
 }
@@ -394,6 +505,31 @@ inline hipError_t gemm_launch_cfg(const GemmArgs &g, hipStream_t s) {
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI>), dim3(tiles), dim3(256), shmem, s, g);
     }
     return hipGetLastError();
+}
+
+// LayerNorm-fused epilogues: the slot layout is 2 per 64-column tile, so BN is fixed to 64 and the forced sweep
+// configurations / v1 kernels do not apply; otherwise the same shape policy as gemm_launch below.
+template <int EPI, int NQ>
+inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
+    if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI, NQ>(g, s);
+    if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
+    return gemm_launch_glds<64, 64, 2, EPI, NQ>(g, s);
+}
+// Slots per row are padded to 8*NQ (zero filled): NQ = 1 (d_model <= 256), 3 (768), 4 (1024).
+inline int ln_fusion_nq(int d_model) {
+    const int need = d_model / 64 * 2;
+    return need <= 8 ? 1 : (need == 24 ? 3 : (need == 32 ? 4 : 0));   // 0: no folded configuration -> stand-alone LayerNorm
+}
+template <int EPI>
+inline hipError_t gemm_launch_ln(const GemmArgs &g, hipStream_t s) {
+    static_assert(EPI == EPI_RESID_F32_STATS || EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN, "LN-fused epilogues only");
+    if (EPI == EPI_RESID_F32_STATS) return gemm_launch_ln_nq<EPI, 0>(g, s);
+    switch (g.nslots / 8) {
+        case 1: return gemm_launch_ln_nq<EPI, 1>(g, s);
+        case 3: return gemm_launch_ln_nq<EPI, 3>(g, s);
+        case 4: return gemm_launch_ln_nq<EPI, 4>(g, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 // Tile choice: keep >= ~1 workgroup per CU (256 CUs) when the problem allows it.

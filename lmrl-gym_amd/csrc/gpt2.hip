@@ -32,6 +32,10 @@ struct Gpt2Layer {
     const float *ln2_g, *ln2_b;
     const uint16_t *w_fc; const float *b_fc;
     const uint16_t *w_fc2; const float *b_fc2;
+    // LayerNorm folded into the consuming GEMM (owned by the model, built at create):
+    //   W' = bf16(W . diag(gamma)), colsum[n] = sum_k W'[n][k], bias' = bias + W beta
+    uint16_t *wf_qkv; float *cs_qkv, *bf_qkv;
+    uint16_t *wf_fc; float *cs_fc, *bf_fc;
 };
 
 struct Gpt2Model {
@@ -127,6 +131,66 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
             *reinterpret_cast<uint2 *>(yr + c) = pk;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm folding
+// One wave per output row n:  W'[n][k] = bf16(W[n][k] * gamma[k]) ; colsum[n] = sum_k W'[n][k] ; bias'[n] = bias[n] + sum_k W[n][k] beta[k]
+__global__ __launch_bounds__(256) void fold_ln_kernel(const uint16_t *__restrict__ W, const float *__restrict__ gam,
+                                                      const float *__restrict__ bet, const float *__restrict__ bias,
+                                                      uint16_t *__restrict__ Wf, float *__restrict__ colsum, float *__restrict__ biasf,
+                                                      int N, int K) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float cs = 0.f, bs = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = bf16_to_f32(W[(size_t)n * K + k]);
+        const uint16_t wf = f32_to_bf16_rn(w * gam[k]);
+        Wf[(size_t)n * K + k] = wf;
+        cs += bf16_to_f32(wf);
+        bs += w * bet[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cs += __shfl_xor(cs, o); bs += __shfl_xor(bs, o); }
+    if (lane == 0) { colsum[n] = cs; biasf[n] = bias[n] + bs; }
+}
+
+// embed for the LN-folded path: x = wte[tok] + wpe[pos] (fp32), xb = bf16(x), stats slot 0 = (sum x, sum x^2), other slots 0
+template <int MAXV>
+__global__ __launch_bounds__(256) void embed_stats_kernel(const uint16_t *__restrict__ wte, const uint16_t *__restrict__ wpe,
+                                                          const int32_t *__restrict__ tokens, const int32_t *__restrict__ cnt,
+                                                          const int32_t *__restrict__ len, float *__restrict__ x, uint16_t *__restrict__ xb,
+                                                          float2 *__restrict__ stats, int nslots, int B, int C, int d, int vocab, int n_pos) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= B * C) return;
+    const int b = r / C, j = r - b * C;
+    int tok = tokens[r];
+    int pos = len[b] + j;
+    const bool valid = j < cnt[b];
+    if (!valid || tok < 0 || tok >= vocab) tok = 0;
+    if (!valid || pos >= n_pos) pos = 0;
+    const uint16_t *te = wte + (size_t)tok * d, *pe = wpe + (size_t)pos * d;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; k++) {
+        const int c = (k * 64 + lane) * 4;
+        if (c < d) {
+            const uint2 a = *reinterpret_cast<const uint2 *>(te + c), p = *reinterpret_cast<const uint2 *>(pe + c);
+            const f32x4 v = f32x4{bf16_to_f32((uint16_t)(a.x & 0xffff)) + bf16_to_f32((uint16_t)(p.x & 0xffff)),
+                                  bf16_to_f32((uint16_t)(a.x >> 16)) + bf16_to_f32((uint16_t)(p.x >> 16)),
+                                  bf16_to_f32((uint16_t)(a.y & 0xffff)) + bf16_to_f32((uint16_t)(p.y & 0xffff)),
+                                  bf16_to_f32((uint16_t)(a.y >> 16)) + bf16_to_f32((uint16_t)(p.y >> 16))};
+            *reinterpret_cast<f32x4 *>(x + (size_t)r * d + c) = v;
+            uint2 o;
+            o.x = (uint32_t)f32_to_bf16_rn(v[0]) | ((uint32_t)f32_to_bf16_rn(v[1]) << 16);
+            o.y = (uint32_t)f32_to_bf16_rn(v[2]) | ((uint32_t)f32_to_bf16_rn(v[3]) << 16);
+            *reinterpret_cast<uint2 *>(xb + (size_t)r * d + c) = o;
+            s1 += (v[0] + v[1]) + (v[2] + v[3]);
+            s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    for (int sl = lane; sl < nslots; sl += 64) stats[(size_t)r * nslots + sl] = sl == 0 ? make_float2(s1, s2) : make_float2(0.f, 0.f);
 }
 
 // ------------------------------------------------------------------------------------------ fused small kernels
@@ -563,14 +627,16 @@ __global__ void advance_kernel(const int32_t *cnt, int32_t *len, int32_t *rows_i
 
 int g_gemm_variant = 0;
 int g_attn_variant = 0;   // test/bench hook: 1 = VALU chunk attention
+int g_ln_fusion = 1;      // 0 = stand-alone LayerNorm launches (A/B hook), 1 = LN folded into the neighbouring GEMMs
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Gpt2Ws {
-    float *x; uint16_t *h, *qkv, *att, *ff; int32_t *rows_idx;
+    float *x; uint16_t *h, *qkv, *att, *ff; int32_t *rows_idx; float2 *stats;
+    static int nslots(const lmrl_gpt2_config &c) { const int nq = ln_fusion_nq(c.d_model); return nq ? 8 * nq : 8; }   // padded slot pitch
     static size_t bytes(const lmrl_gpt2_config &c, size_t M, size_t B) {
         return align256(M * c.d_model * 4) + align256(M * c.d_model * 2) + align256(M * 3 * c.d_model * 2) +
-               align256(M * c.d_model * 2) + align256(M * c.d_ff * 2) + align256(B * 4);
+               align256(M * c.d_model * 2) + align256(M * c.d_ff * 2) + align256(B * 4) + align256(M * nslots(c) * 8);
     }
     void carve(void *ws, const lmrl_gpt2_config &c, size_t M, size_t B) {
         char *p = (char *)ws;
@@ -579,8 +645,8 @@ struct Gpt2Ws {
         qkv = (uint16_t *)p; p += align256(M * 3 * c.d_model * 2);
         att = (uint16_t *)p; p += align256(M * c.d_model * 2);
         ff = (uint16_t *)p; p += align256(M * c.d_ff * 2);
-        rows_idx = (int32_t *)p;
-        (void)B;
+        rows_idx = (int32_t *)p; p += align256(B * 4);
+        stats = (float2 *)p;
     }
 };
 
@@ -615,12 +681,38 @@ lmrl_gpt2 *lmrl_gpt2_create(const lmrl_gpt2_config *cfg, const void *wte, const 
         L.ln2_g = (const float *)p[6]; L.ln2_b = (const float *)p[7];
         L.w_fc = (const uint16_t *)p[8]; L.b_fc = (const float *)p[9];
         L.w_fc2 = (const uint16_t *)p[10]; L.b_fc2 = (const float *)p[11];
+        L.wf_qkv = L.wf_fc = nullptr; L.cs_qkv = L.bf_qkv = L.cs_fc = L.bf_fc = nullptr;
+    }
+    // LayerNorm folding (ln_1 -> c_attn, ln_2 -> c_fc): model-owned copies, built once
+    const int d = cfg->d_model, dff = cfg->d_ff;
+    bool ok = hipDeviceSynchronize() == hipSuccess;
+    for (int l = 0; l < cfg->n_layer && ok; l++) {
+        Gpt2Layer &L = m->layers[l];
+        ok = ok && hipMalloc(&L.wf_qkv, (size_t)3 * d * d * 2) == hipSuccess && hipMalloc(&L.cs_qkv, (size_t)3 * d * 4) == hipSuccess &&
+             hipMalloc(&L.bf_qkv, (size_t)3 * d * 4) == hipSuccess && hipMalloc(&L.wf_fc, (size_t)dff * d * 2) == hipSuccess &&
+             hipMalloc(&L.cs_fc, (size_t)dff * 4) == hipSuccess && hipMalloc(&L.bf_fc, (size_t)dff * 4) == hipSuccess;
+        if (!ok) break;
+        hipLaunchKernelGGL(fold_ln_kernel, dim3(ceil_div(3 * d, 4)), dim3(256), 0, 0, L.w_qkv, L.ln1_g, L.ln1_b, L.b_qkv, L.wf_qkv, L.cs_qkv,
+                           L.bf_qkv, 3 * d, d);
+        hipLaunchKernelGGL(fold_ln_kernel, dim3(ceil_div(dff, 4)), dim3(256), 0, 0, L.w_fc, L.ln2_g, L.ln2_b, L.b_fc, L.wf_fc, L.cs_fc,
+                           L.bf_fc, dff, d);
+    }
+    ok = ok && hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    if (!ok) {
+        set_error("lmrl_gpt2_create: device allocation / LayerNorm folding failed (is a GPU visible?)");
+        lmrl_gpt2_destroy(m);
+        return nullptr;
     }
     return m;
 }
 
 void lmrl_gpt2_destroy(lmrl_gpt2 *m) {
     if (!m) return;
+    for (int l = 0; m->layers && l < m->cfg.n_layer; l++) {
+        Gpt2Layer &L = m->layers[l];
+        (void)hipFree(L.wf_qkv); (void)hipFree(L.cs_qkv); (void)hipFree(L.bf_qkv);
+        (void)hipFree(L.wf_fc); (void)hipFree(L.cs_fc); (void)hipFree(L.bf_fc);
+    }
     delete[] m->layers;
     delete m;
 }
@@ -643,25 +735,40 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
 
     if (unsigned long long *ctr = prof_byte_counter(c == 1 ? PROF_ATTN_DECODE : PROF_ATTN_CHUNK))
         hipLaunchKernelGGL(attn_bytes_kernel, dim3(1), dim3(256), 0, s, cnt_d, len_d, b, c, cf.n_head * cf.n_layer, ctr);
-    // embeddings + LN1 of layer 0 in one launch
-    if (d <= 1024) hipLaunchKernelGGL(embed_ln_kernel<4>, dim3(ceil_div(M, 4)), dim3(256), 0, s, m->wte, m->wpe, tokens_d, cnt_d, len_d,
-                                      m->layers[0].ln1_g, m->layers[0].ln1_b, w.x, w.h, b, c, d, cf.vocab, cf.n_pos, cf.ln_eps);
-    else hipLaunchKernelGGL(embed_ln_kernel<8>, dim3(ceil_div(M, 4)), dim3(256), 0, s, m->wte, m->wpe, tokens_d, cnt_d, len_d,
-                            m->layers[0].ln1_g, m->layers[0].ln1_b, w.x, w.h, b, c, d, cf.vocab, cf.n_pos, cf.ln_eps);
-    LMRL_CHECK_LAUNCH();
+    const bool fused = g_ln_fusion && g_gemm_variant != 1 && ln_fusion_nq(d) != 0;
+    const int nsl = Gpt2Ws::nslots(cf);
     auto ln = [&](const float *g, const float *be, uint16_t *y, const int32_t *idx, int rows) {
         if (d <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w.x, g, be, y, idx, rows, d, cf.ln_eps);
         else hipLaunchKernelGGL(layernorm_kernel<8>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w.x, g, be, y, idx, rows, d, cf.ln_eps);
     };
+    if (fused) {
+        // LN-folded path: w.h holds the bf16 copy of the residual stream, w.stats its per-row (sum, sum^2) slots
+        if (d <= 1024) hipLaunchKernelGGL(embed_stats_kernel<4>, dim3(ceil_div(M, 4)), dim3(256), 0, s, m->wte, m->wpe, tokens_d, cnt_d, len_d,
+                                          w.x, w.h, w.stats, nsl, b, c, d, cf.vocab, cf.n_pos);
+        else hipLaunchKernelGGL(embed_stats_kernel<8>, dim3(ceil_div(M, 4)), dim3(256), 0, s, m->wte, m->wpe, tokens_d, cnt_d, len_d,
+                                w.x, w.h, w.stats, nsl, b, c, d, cf.vocab, cf.n_pos);
+    } else {
+        // embeddings + LN1 of layer 0 in one launch
+        if (d <= 1024) hipLaunchKernelGGL(embed_ln_kernel<4>, dim3(ceil_div(M, 4)), dim3(256), 0, s, m->wte, m->wpe, tokens_d, cnt_d, len_d,
+                                          m->layers[0].ln1_g, m->layers[0].ln1_b, w.x, w.h, b, c, d, cf.vocab, cf.n_pos, cf.ln_eps);
+        else hipLaunchKernelGGL(embed_ln_kernel<8>, dim3(ceil_div(M, 4)), dim3(256), 0, s, m->wte, m->wpe, tokens_d, cnt_d, len_d,
+                                m->layers[0].ln1_g, m->layers[0].ln1_b, w.x, w.h, b, c, d, cf.vocab, cf.n_pos, cf.ln_eps);
+    }
+    LMRL_CHECK_LAUNCH();
     for (int l = 0; l < cf.n_layer; l++) {
         const Gpt2Layer &L = m->layers[l];
         uint16_t *kc = (uint16_t *)kv_d + (size_t)(2 * l) * kv_layer, *vc = kc + kv_layer;
-        if (l > 0) {
-            ln(L.ln1_g, L.ln1_b, w.h, nullptr, M);
-            LMRL_CHECK_LAUNCH();
+        if (fused) {
+            GemmArgs g{w.h, L.wf_qkv, L.bf_qkv, w.qkv, M, 3 * d, d, d, 3 * d, 3 * d, w.stats, nullptr, L.cs_qkv, nsl, 1.f / (float)d, cf.ln_eps};
+            LMRL_CHECK_HIP(gemm_launch_ln<EPI_BF16_LN>(g, s));
+        } else {
+            if (l > 0) {
+                ln(L.ln1_g, L.ln1_b, w.h, nullptr, M);
+                LMRL_CHECK_LAUNCH();
+            }
+            GemmArgs g{w.h, L.w_qkv, L.b_qkv, w.qkv, M, 3 * d, d, d, 3 * d, 3 * d};
+            LMRL_CHECK_HIP(gemm_launch<EPI_BF16>(g, s));
         }
-        GemmArgs g{w.h, L.w_qkv, L.b_qkv, w.qkv, M, 3 * d, d, d, 3 * d, 3 * d};
-        LMRL_CHECK_HIP(gemm_launch<EPI_BF16>(g, s));
         {
         // algorithmic bytes: K+V rows read once (2 * 128 B per cached position per head) + q/k/v/out rows of the chunk
         ProfScope ps(c == 1 ? PROF_ATTN_DECODE : PROF_ATTN_CHUNK, s, -1.0);
@@ -670,14 +777,24 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
         else hipLaunchKernelGGL(attention_chunk_mfma_kernel, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
         }
         LMRL_CHECK_LAUNCH();
-        GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d};
-        LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(gp, s));
-        ln(L.ln2_g, L.ln2_b, w.h, nullptr, M);
-        LMRL_CHECK_LAUNCH();
-        GemmArgs gf{w.h, L.w_fc, L.b_fc, w.ff, M, cf.d_ff, d, d, cf.d_ff, cf.d_ff};
-        LMRL_CHECK_HIP(gemm_launch<EPI_GELU_BF16>(gf, s));
-        GemmArgs g2{w.ff, L.w_fc2, L.b_fc2, w.x, M, d, cf.d_ff, cf.d_ff, d, d};
-        LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(g2, s));
+        if (fused) {
+            GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f};
+            LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, s));
+            GemmArgs gf{w.h, L.wf_fc, L.bf_fc, w.ff, M, cf.d_ff, d, d, cf.d_ff, cf.d_ff, w.stats, nullptr, L.cs_fc, nsl, 1.f / (float)d, cf.ln_eps};
+            LMRL_CHECK_HIP(gemm_launch_ln<EPI_GELU_BF16_LN>(gf, s));
+            GemmArgs g2{w.ff, L.w_fc2, L.b_fc2, w.x, M, d, cf.d_ff, cf.d_ff, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f};
+            if (l + 1 < cf.n_layer) LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(g2, s));
+            else LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(g2, s));      // ln_f reads the fp32 stream directly
+        } else {
+            GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d};
+            LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(gp, s));
+            ln(L.ln2_g, L.ln2_b, w.h, nullptr, M);
+            LMRL_CHECK_LAUNCH();
+            GemmArgs gf{w.h, L.w_fc, L.b_fc, w.ff, M, cf.d_ff, d, d, cf.d_ff, cf.d_ff};
+            LMRL_CHECK_HIP(gemm_launch<EPI_GELU_BF16>(gf, s));
+            GemmArgs g2{w.ff, L.w_fc2, L.b_fc2, w.x, M, d, cf.d_ff, cf.d_ff, d, d};
+            LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(g2, s));
+        }
     }
     if (all_hidden_d) {   // before len is advanced / independent of it
         ln(m->lnf_g, m->lnf_b, (uint16_t *)all_hidden_d, nullptr, M);
@@ -694,6 +811,7 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
 
 void lmrl_gemm_set_variant(int v) { lmrl::g_gemm_variant = v; }
 void lmrl_attn_set_variant(int v) { lmrl::g_attn_variant = v; }
+void lmrl_gpt2_set_ln_fusion(int on) { lmrl::g_ln_fusion = on; }
 
 // Plain bf16 GEMM entry (heads, LM-head logits): C = A.W^T + bias with a selectable epilogue.
 int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda,

@@ -47,8 +47,18 @@ def test_gemm_bf16_epilogues(dev, M, N, K):
 
 
 # ------------------------------------------------------------------ forward: chunked prefill + decode vs full-sequence oracle
+@pytest.fixture
+def ln_fusion(request):
+    """LayerNorm folded into the neighbouring GEMMs (1, the default) or stand-alone LN launches (0)."""
+    from lmrl_gym_amd import _lib
+    _lib.lib().lmrl_gpt2_set_ln_fusion(request.param)
+    yield request.param
+    _lib.lib().lmrl_gpt2_set_ln_fusion(1)
+
+
+@pytest.mark.parametrize("ln_fusion", [1, 0], indirect=True)
 @pytest.mark.parametrize("cfgname", ["tiny", "small2"])
-def test_gpt2_forward_kv_cache(dev, cfgname):
+def test_gpt2_forward_kv_cache(dev, cfgname, ln_fusion):
     from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
     from oracle import gpt2 as O
     cfg = dict(tiny=GPT2Config(2, 2, 128, 512, 1000, 64), small2=GPT2Config(2, 12, 768, 3072, 50257, 128))[cfgname]
@@ -56,7 +66,8 @@ def test_gpt2_forward_kv_cache(dev, cfgname):
     g = torch.Generator().manual_seed(2)
     for k in sd:   # non-trivial LN / bias values
         if sd[k].dim() == 1:
-            sd[k] = sd[k] + 0.1 * torch.randn(sd[k].shape, generator=g)
+            sd[k] = sd[k] + 0.3 * torch.randn(sd[k].shape, generator=g)
+    sd["wpe.weight"] = sd["wpe.weight"] + 0.05          # a non-zero row mean in the residual stream (exercises mu * colsum)
     sd = O.round_weights_to_bf16(sd)
     eng = GPT2Engine(cfg, sd, dev)
     B, T = 5, 40
