@@ -118,11 +118,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank %= max(torch.cuda.device_count(), 1)      # (lets a 1-GPU box exercise the N > 1 launch path with gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("LMRL_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" only for launch-path tests
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     L = _lib.lib()
     L.lmrl_gemm_set_variant(args.gemm_variant)
@@ -149,10 +154,19 @@ def main():
     torch.cuda.synchronize()
 
     if args.graph:
-        for r, st in zip(ros, streams):
-            with torch.cuda.stream(st):
-                r.capture_episode(temperature=1.0, sample_seed=1000 + rank * 16 + ros.index(r), steer_strength=30.0, scripted=True)
-        torch.cuda.synchronize()
+        try:
+            for r, st in zip(ros, streams):
+                with torch.cuda.stream(st):
+                    r.capture_episode(temperature=1.0, sample_seed=1000 + rank * 16 + ros.index(r), steer_strength=30.0, scripted=True)
+            torch.cuda.synchronize()
+        except Exception as e:   # never lose the measurement to a capture problem: same launches, issued eagerly
+            print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
+            args.graph = 0
+            torch.cuda.synchronize()
+        if world > 1:            # every rank must time the same mode
+            flag = torch.tensor([args.graph], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            args.graph = int(flag.item())
 
     def episode(i, count, eager=False):
         if args.graph and not eager:
@@ -253,6 +267,8 @@ def main():
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     steps_all = torch.stack(total_steps_parts).sum() if total_steps_parts else total_steps.clone()
     if world > 1:
+        if backend != "nccl":
+            t, steps_all = t.cpu(), steps_all.cpu()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(steps_all, op=torch.distributed.ReduceOp.SUM)
     dt_max, n_env_steps = float(t.item()), int(steps_all.item())

@@ -202,7 +202,9 @@ class WordleRolloutEngine:
         t.cuda.synchronize()
         self.sample_step = 0
         self.graph = t.cuda.CUDAGraph()
-        with t.cuda.graph(self.graph):
+        # thread-local capture mode: other threads of the process (e.g. the RCCL watchdog of torch.distributed) may keep
+        # calling HIP APIs while this thread captures
+        with t.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.run_episode(self.g_seeds, **kw)
         return self.graph
 
