@@ -292,14 +292,20 @@ __device__ __forceinline__ void glds_mainloop(const uint16_t *__restrict__ A, in
     const int lr = lane & 15, lq = lane >> 4;
     int slot = 0;
     for (int kt = 0; kt < nk; kt++) {
-        // stage kt must have landed; up to STAGES-2 later stages may stay in flight
+        // stage kt must have landed; up to STAGES-2 later stages may stay in flight (plus, before the first K-tile, the
+        // caller's EXTRA loads, which were issued after every prologue stage)
         const int ahead = nk - 1 - kt;
-        if (EXTRA > 0 && kt == 0) {      // the caller's EXTRA loads were issued after every prologue stage
-            if (STAGES >= 4 && ahead >= 2) wait_vmcnt<2 * L + EXTRA>();
-            else if (STAGES >= 3 && ahead >= 1) wait_vmcnt<(STAGES >= 3 ? L : 0) + EXTRA>();
+        const int inflight = ahead < STAGES - 2 ? ahead : STAGES - 2;
+        if (EXTRA > 0 && kt == 0) {
+            if (inflight >= 4 && STAGES >= 6) wait_vmcnt<4 * L + EXTRA>();
+            else if (inflight == 3 && STAGES >= 5) wait_vmcnt<3 * L + EXTRA>();
+            else if (inflight == 2 && STAGES >= 4) wait_vmcnt<2 * L + EXTRA>();
+            else if (inflight == 1 && STAGES >= 3) wait_vmcnt<L + EXTRA>();
             else wait_vmcnt<EXTRA>();
-        } else if (STAGES >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
-        else if (STAGES >= 3 && ahead >= 1) wait_vmcnt<(STAGES >= 3 ? L : 0)>();
+        } else if (inflight >= 4 && STAGES >= 6) wait_vmcnt<4 * L>();
+        else if (inflight == 3 && STAGES >= 5) wait_vmcnt<3 * L>();
+        else if (inflight == 2 && STAGES >= 4) wait_vmcnt<2 * L>();
+        else if (inflight == 1 && STAGES >= 3) wait_vmcnt<L>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (kt + STAGES - 1 < nk) {
@@ -509,11 +515,16 @@ inline hipError_t gemm_launch_cfg(const GemmArgs &g, hipStream_t s) {
 
 // LayerNorm-fused epilogues: the slot layout is 2 per 64-column tile, so BN is fixed to 64 and the forced sweep
 // configurations / v1 kernels do not apply; otherwise the same shape policy as gemm_launch below.
+extern int g_gemm_variant;
 template <int EPI, int NQ>
 inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
+    // same measured shape policy as gemm_launch below; variant 101 = the former all-2-stage decode policy (A/B hook)
     if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI, NQ>(g, s);
     if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
-    return gemm_launch_glds<64, 64, 2, EPI, NQ>(g, s);
+    if (g_gemm_variant == 101) return gemm_launch_glds<64, 64, 2, EPI, NQ>(g, s);
+    if (g.N <= 1024) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
+    if (g_gemm_variant == 109) return gemm_launch_glds<128, 64, 3, EPI, NQ>(g, s);
+    return gemm_launch_glds<64, 64, 3, EPI, NQ>(g, s);
 }
 // Slots per row are padded to 8*NQ (zero filled): NQ = 1 (d_model <= 256), 3 (768), 4 (1024).
 inline int ln_fusion_nq(int d_model) {
@@ -558,11 +569,14 @@ inline hipError_t gemm_launch(const GemmArgs &g, hipStream_t s) {
         case 104: if (g.M >= 2048) return gemm_launch_glds<128, 128, 2, EPI>(g, s); break;
         default: break;
     }
-    // measured on MI355X (profiles/r01_gemm_config_sweep.txt): occupancy beats ring depth — 2-stage rings (2+ workgroups
-    // per CU) win everywhere except the long-K skinny GEMM, which wants 4 stages in flight.
+    // measured on MI355X (profiles/r01_gemm_config_sweep.txt + in-situ sweeps): the prefill GEMMs (M >= 2048, thousands of
+    // tiles) want occupancy: 2-stage rings, 3 workgroups per CU.  The decode GEMMs (M = 1024) have only 192-768 tiles, i.e.
+    // 1-3 per CU, and are bound by the latency chain of their K loop: as many stages as still leave every tile resident
+    // at once (768 tiles: 3 stages = 48 KiB -> 3 WG/CU; 192 tiles: 4 stages = 64 KiB -> 2 WG/CU).
     if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI>(g, s);
     if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI>(g, s);
-    return gemm_launch_glds<64, 64, 2, EPI>(g, s);
+    if (g.N <= 1024) return gemm_launch_glds<64, 64, 4, EPI>(g, s);
+    return gemm_launch_glds<64, 64, 3, EPI>(g, s);
 }
 
 }  // namespace lmrl
