@@ -523,7 +523,6 @@ inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
     if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
     if (g_gemm_variant == 101) return gemm_launch_glds<64, 64, 2, EPI, NQ>(g, s);
     if (g.N <= 1024) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
-    if (g_gemm_variant == 109) return gemm_launch_glds<128, 64, 3, EPI, NQ>(g, s);
     return gemm_launch_glds<64, 64, 3, EPI, NQ>(g, s);
 }
 // Slots per row are padded to 8*NQ (zero filled): NQ = 1 (d_model <= 256), 3 (768), 4 (1024).
