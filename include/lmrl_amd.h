@@ -312,6 +312,8 @@ int lmrl_prof_read(int tag, double *total_ms, double *total_work, long long *lau
 int lmrl_sgemm(int trans_a, int trans_b, int m, int n, int k, float alpha, const float *a_d, int lda, long sa_outer,
                long sa_inner, const float *b_d, int ldb, long sb_outer, long sb_inner, float beta, float *c_d, int ldc,
                long sc_outer, long sc_inner, int nb_outer, int nb_inner, const float *bias_d, void *stream);
+/* A/B hook: 0 = auto (128x128 tiles when m, n >= 128), 1 = always the 64x64-tile kernel */
+void lmrl_sgemm_set_variant(int v);
 int lmrl_embed_fwd(const float *wte_d, const float *wpe_d, const int32_t *ids_d, const int32_t *pos_d, float *x_d, int rows, int d, void *stream);
 int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d, float *dwte_d, float *dwpe_d, int rows, int d, void *stream);
 int lmrl_layernorm_fwd(const float *x_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, int rows, int d,

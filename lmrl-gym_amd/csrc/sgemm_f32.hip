@@ -117,9 +117,123 @@ __global__ __launch_bounds__(256) void sgemm_f32_kernel(SgemmArgs g) {
     }
 }
 
+// ---- 128 x 128 tile variant for the large GEMMs (Dense / LM head / Q heads and their gradients).
+// With 64 x 64 tiles every K-step pulls 8 KiB through L2 for 131 kFLOP (16 FLOP/B): at the f32 MFMA rate that is ~10 TB/s
+// of L2 -> LDS traffic chip-wide, so the small tile is L2-bound.  Here each wave owns 2 x 2 MFMA tiles (64 x 64 outputs,
+// 64 accumulator registers): 32 FLOP/B, every A/B fragment read from LDS feeds two MFMAs.  Same k-major LDS image and the
+// same four transpose forms; global loads are lane-consecutive along the contiguous dimension (arbitrary ld / alignment:
+// the head matrices have ld = 50258).
+constexpr int SG2_BM = 128, SG2_BN = 128, SG2_BK = 16, SG2_LD = 132;
+
+template <bool K_CONTIG>   // true: memory [row][k] ; false: memory [k][row]
+__device__ __forceinline__ void sg2_load(const float *__restrict__ X, int ld, int row0, int nrows, int k0, int K, int t, float (&r)[8]) {
+    if (K_CONTIG) {
+        const int k = k0 + (t & 15);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int row = row0 + (t >> 4) + 16 * i;
+            r[i] = (row < nrows && k < K) ? X[(size_t)row * ld + k] : 0.f;
+        }
+    } else {
+        const int k = k0 + (t >> 4);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int row = row0 + (t & 15) + 16 * i;
+            r[i] = (k < K && row < nrows) ? X[(size_t)k * ld + row] : 0.f;
+        }
+    }
+}
+template <bool K_CONTIG>
+__device__ __forceinline__ void sg2_store(float *__restrict__ S, int t, const float (&r)[8]) {
+    if (K_CONTIG) {
+        const int k = t & 15;
+#pragma unroll
+        for (int i = 0; i < 8; i++) S[k * SG2_LD + (t >> 4) + 16 * i] = r[i];
+    } else {
+        const int k = t >> 4;
+#pragma unroll
+        for (int i = 0; i < 8; i++) S[k * SG2_LD + (t & 15) + 16 * i] = r[i];
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void sgemm_f32_128_kernel(SgemmArgs g) {
+    __shared__ float sA[2][SG2_BK * SG2_LD];
+    __shared__ float sB[2][SG2_BK * SG2_LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bo = blockIdx.z / g.nb_inner, bi = blockIdx.z - bo * g.nb_inner;
+    const float *A = g.A + bo * g.sAo + bi * g.sAi;
+    const float *B = g.B + bo * g.sBo + bi * g.sBi;
+    float *C = g.C + bo * g.sCo + bi * g.sCi;
+    const int m0 = blockIdx.y * SG2_BM, n0 = blockIdx.x * SG2_BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
+    float ra[8], rb[8];
+    sg2_load<!TA>(A, g.lda, m0, g.M, 0, g.K, t, ra);
+    sg2_load<TB>(B, g.ldb, n0, g.N, 0, g.K, t, rb);
+    sg2_store<!TA>(sA[0], t, ra);
+    sg2_store<TB>(sB[0], t, rb);
+    __syncthreads();
+    const int nk = (g.K + SG2_BK - 1) / SG2_BK;
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            sg2_load<!TA>(A, g.lda, m0, g.M, (kt + 1) * SG2_BK, g.K, t, ra);
+            sg2_load<TB>(B, g.ldb, n0, g.N, (kt + 1) * SG2_BK, g.K, t, rb);
+        }
+        const float *pa = sA[buf] + (lane >> 5) * SG2_LD + wm * 64 + (lane & 31);
+        const float *pb = sB[buf] + (lane >> 5) * SG2_LD + wn * 64 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < SG2_BK; kk += 2) {
+            const float a0 = pa[kk * SG2_LD], a1 = pa[kk * SG2_LD + 32];
+            const float b0 = pb[kk * SG2_LD], b1 = pb[kk * SG2_LD + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            sg2_store<!TA>(sA[buf ^ 1], t, ra);
+            sg2_store<TB>(sB[buf ^ 1], t, rb);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const int col = n0 + wn * 64 + b * 32 + (lane & 31);
+        if (col >= g.N) continue;
+        const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.M) {
+                    float *p = C + (size_t)row * g.ldc + col;
+                    float v = g.alpha * acc[a][b][r] + bv;
+                    if (g.beta != 0.f) v += g.beta * *p;
+                    *p = v;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace lmrl
 
 using namespace lmrl;
+
+extern "C" void lmrl_sgemm_set_variant(int v);
+static int g_sgemm_variant = 0;   // 0: auto, 1: always the 64 x 64 tile kernel (A/B hook)
+void lmrl_sgemm_set_variant(int v) { g_sgemm_variant = v; }
+
 
 extern "C" int lmrl_sgemm(int trans_a, int trans_b, int m, int n, int k, float alpha, const float *a_d, int lda, long sa_outer,
                           long sa_inner, const float *b_d, int ldb, long sb_outer, long sb_inner, float beta, float *c_d, int ldc,
@@ -127,8 +241,17 @@ extern "C" int lmrl_sgemm(int trans_a, int trans_b, int m, int n, int k, float a
     LMRL_REQUIRE(a_d && b_d && c_d && m > 0 && n > 0 && k > 0 && nb_outer > 0 && nb_inner > 0, "lmrl_sgemm: bad argument");
     SgemmArgs g{a_d, b_d, c_d, bias_d, m, n, k, lda, ldb, ldc, sa_outer, sa_inner, sb_outer, sb_inner, sc_outer, sc_inner,
                 nb_inner, alpha, beta};
-    dim3 grid(ceil_div(n, SG_BN), ceil_div(m, SG_BM), nb_outer * nb_inner);
     hipStream_t s = as_stream(stream);
+    if (g_sgemm_variant != 1 && m >= 128 && n >= 128) {   // large GEMMs: 128 x 128 tiles (2 x 2 MFMA tiles per wave)
+        dim3 grid2(ceil_div(n, SG2_BN), ceil_div(m, SG2_BM), nb_outer * nb_inner);
+        if (!trans_a && !trans_b) hipLaunchKernelGGL((sgemm_f32_128_kernel<false, false>), grid2, dim3(256), 0, s, g);
+        else if (!trans_a && trans_b) hipLaunchKernelGGL((sgemm_f32_128_kernel<false, true>), grid2, dim3(256), 0, s, g);
+        else if (trans_a && !trans_b) hipLaunchKernelGGL((sgemm_f32_128_kernel<true, false>), grid2, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((sgemm_f32_128_kernel<true, true>), grid2, dim3(256), 0, s, g);
+        LMRL_CHECK_LAUNCH();
+        return LMRL_OK;
+    }
+    dim3 grid(ceil_div(n, SG_BN), ceil_div(m, SG_BM), nb_outer * nb_inner);
     if (!trans_a && !trans_b) hipLaunchKernelGGL((sgemm_f32_kernel<false, false>), grid, dim3(256), 0, s, g);
     else if (!trans_a && trans_b) hipLaunchKernelGGL((sgemm_f32_kernel<false, true>), grid, dim3(256), 0, s, g);
     else if (trans_a && !trans_b) hipLaunchKernelGGL((sgemm_f32_kernel<true, false>), grid, dim3(256), 0, s, g);

@@ -27,7 +27,7 @@ def _close(got, exp, rtol=1e-4, atol=None, name=""):
 def test_sgemm_all_layouts(dev, ta, tb):
     from lmrl_gym_amd.train import ops
     g = torch.Generator().manual_seed(ta * 2 + tb)
-    for (M, N, K) in [(70, 33, 19), (128, 64, 64), (1, 5, 300), (257, 130, 65)]:
+    for (M, N, K) in [(70, 33, 19), (128, 64, 64), (1, 5, 300), (257, 130, 65), (300, 517, 100), (128, 128, 16)]:
         A = torch.randn((K, M) if ta else (M, K), generator=g); B = torch.randn((N, K) if tb else (K, N), generator=g)
         C0 = torch.randn(M, N, generator=g); bias = torch.randn(N, generator=g)
         ref = 0.7 * ((A.t() if ta else A).double() @ (B.t() if tb else B).double()) + 0.3 * C0.double() + bias.double()
