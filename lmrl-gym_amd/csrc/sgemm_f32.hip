@@ -226,9 +226,28 @@ __global__ __launch_bounds__(256) void sgemm_f32_128_kernel(SgemmArgs g) {
     }
 }
 
+// split-K second pass: C = alpha * sum_s ws[s] + beta * C + bias, partials added in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int S, int M, int N, float *__restrict__ C, int ldc,
+                                                            float alpha, float beta, const float *__restrict__ bias) {
+    const size_t MN = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < MN; i += (size_t)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int sidx = 0; sidx < S; sidx++) a += ws[(size_t)sidx * MN + i];
+        const int r = (int)(i / N), c = (int)(i - (size_t)r * N);
+        float v = alpha * a + (bias ? bias[c] : 0.f);
+        float *p = C + (size_t)r * ldc + c;
+        if (beta != 0.f) v += beta * *p;
+        *p = v;
+    }
+}
+
 }  // namespace lmrl
 
 using namespace lmrl;
+
+// process-wide split-K workspace (train path only; grown on demand, never inside a graph capture)
+static float *g_splitk_ws = nullptr;
+static size_t g_splitk_ws_floats = 0;
 
 extern "C" void lmrl_sgemm_set_variant(int v);
 static int g_sgemm_variant = 0;   // 0: auto, 1: always the 64 x 64 tile kernel (A/B hook)
@@ -242,6 +261,39 @@ extern "C" int lmrl_sgemm(int trans_a, int trans_b, int m, int n, int k, float a
     SgemmArgs g{a_d, b_d, c_d, bias_d, m, n, k, lda, ldb, ldc, sa_outer, sa_inner, sb_outer, sb_inner, sc_outer, sc_inner,
                 nb_inner, alpha, beta};
     hipStream_t s = as_stream(stream);
+    // Weight-gradient shapes (dW = X^T dY: small M x N, K = all tokens of the batch) have fewer 128 x 128 tiles than CUs:
+    // split K across workgroups into a workspace and add the partials in a fixed order (no atomics -> deterministic).
+    if (g_sgemm_variant == 0 && m >= 128 && n >= 128 && nb_outer * nb_inner == 1 && k >= 4096) {
+        const long tiles = (long)ceil_div(n, SG2_BN) * ceil_div(m, SG2_BM);
+        int S = 1;
+        if (tiles < 256) {
+            S = (int)((512 + tiles - 1) / tiles);
+            if (S > 16) S = 16;
+            while (S > 1 && (k % (S * SG2_BK) != 0 || k / S < 1024)) S--;
+        }
+        if (S > 1) {
+            const size_t need = (size_t)S * m * n;
+            if (need > g_splitk_ws_floats) {
+                if (g_splitk_ws) { LMRL_CHECK_HIP(hipStreamSynchronize(s)); LMRL_CHECK_HIP(hipFree(g_splitk_ws)); g_splitk_ws = nullptr; g_splitk_ws_floats = 0; }
+                LMRL_CHECK_HIP(hipMalloc(&g_splitk_ws, need * sizeof(float)));
+                g_splitk_ws_floats = need;
+            }
+            const int kc = k / S;
+            SgemmArgs gs{a_d, b_d, g_splitk_ws, nullptr, m, n, kc, lda, ldb, n,
+                         trans_a ? (long)kc * lda : (long)kc, 0, trans_b ? (long)kc : (long)kc * ldb, 0, (long)m * n, 0, 1, 1.f, 0.f};
+            dim3 grid2(ceil_div(n, SG2_BN), ceil_div(m, SG2_BM), S);
+            if (!trans_a && !trans_b) hipLaunchKernelGGL((sgemm_f32_128_kernel<false, false>), grid2, dim3(256), 0, s, gs);
+            else if (!trans_a && trans_b) hipLaunchKernelGGL((sgemm_f32_128_kernel<false, true>), grid2, dim3(256), 0, s, gs);
+            else if (trans_a && !trans_b) hipLaunchKernelGGL((sgemm_f32_128_kernel<true, false>), grid2, dim3(256), 0, s, gs);
+            else hipLaunchKernelGGL((sgemm_f32_128_kernel<true, true>), grid2, dim3(256), 0, s, gs);
+            LMRL_CHECK_LAUNCH();
+            const size_t mn = (size_t)m * n;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((mn + 1023) / 1024 < 2048 ? (mn + 1023) / 1024 : 2048)), dim3(256), 0, s,
+                               g_splitk_ws, S, m, n, c_d, ldc, alpha, beta, bias_d);
+            LMRL_CHECK_LAUNCH();
+            return LMRL_OK;
+        }
+    }
     if (g_sgemm_variant != 1 && m >= 128 && n >= 128) {   // large GEMMs: 128 x 128 tiles (2 x 2 MFMA tiles per wave)
         dim3 grid2(ceil_div(n, SG2_BN), ceil_div(m, SG2_BM), nb_outer * nb_inner);
         if (!trans_a && !trans_b) hipLaunchKernelGGL((sgemm_f32_128_kernel<false, false>), grid2, dim3(256), 0, s, g);

@@ -36,6 +36,24 @@ def test_sgemm_all_layouts(dev, ta, tb):
         _close(Cd.cpu(), ref, rtol=2e-6, atol=2e-5, name=f"{M}x{N}x{K}")
 
 
+def test_sgemm_split_k_weight_gradient_shapes(dev):
+    """dW = X^T dY shapes (small M x N, K = all tokens): the split-K path must equal a float64 matmul and be bit-reproducible."""
+    from lmrl_gym_amd.train import ops
+    g = torch.Generator().manual_seed(11)
+    for (ta, tb, M, N, K) in [(1, 0, 256, 384, 8192), (0, 1, 128, 256, 4096), (0, 0, 200, 130, 16384)]:
+        A = torch.randn((K, M) if ta else (M, K), generator=g); B = torch.randn((N, K) if tb else (K, N), generator=g)
+        C0 = torch.randn(M, N, generator=g); bias = torch.randn(N, generator=g)
+        ref = 0.5 * ((A.t() if ta else A).double() @ (B.t() if tb else B).double()) + 1.0 * C0.double() + bias.double()
+        outs = []
+        for _ in range(2):
+            Cd = C0.to(dev).clone()
+            ops.sgemm(A.to(dev), B.to(dev), Cd, M, N, K, trans_a=bool(ta), trans_b=bool(tb), alpha=0.5, beta=1.0, lda=A.shape[1],
+                      ldb=B.shape[1], ldc=N, bias=bias.to(dev))
+            outs.append(Cd.cpu())
+        assert torch.equal(outs[0], outs[1])
+        _close(outs[0], ref, rtol=3e-6, name=f"splitk {M}x{N}x{K}")
+
+
 def test_sgemm_batched_strided_like_attention(dev):
     from lmrl_gym_amd.train import ops
     B, H, T, hd = 3, 4, 37, 16
