@@ -125,13 +125,23 @@ __global__ __launch_bounds__(256) void whiten_moments_kernel(const float *__rest
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; red[2][wave] = cnt; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {   // per-workgroup partial; whiten_finish_kernel adds them in workgroup order (deterministic)
         double a = 0, b2 = 0, c2 = 0;
         for (int w = 0; w < 4; w++) { a += red[0][w]; b2 += red[1][w]; c2 += red[2][w]; }
-        atomicAdd(&moments[0], a);
-        atomicAdd(&moments[1], b2);
-        atomicAdd(&moments[2], c2);
+        moments[3 * blockIdx.x + 0] = a;
+        moments[3 * blockIdx.x + 1] = b2;
+        moments[3 * blockIdx.x + 2] = c2;
     }
+}
+
+__global__ __launch_bounds__(64) void whiten_finish_kernel(const double *__restrict__ partials, int nblocks, double *__restrict__ moments) {
+    double s = 0.0, ss = 0.0, cnt = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) { s += partials[3 * b]; ss += partials[3 * b + 1]; cnt += partials[3 * b + 2]; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        s += __shfl_down(s, d); ss += __shfl_down(ss, d); cnt += __shfl_down(cnt, d);
+    }
+    if (threadIdx.x == 0) { moments[0] = s; moments[1] = ss; moments[2] = cnt; }
 }
 
 __global__ __launch_bounds__(256) void whiten_apply_kernel(const float *__restrict__ x, const uint8_t *__restrict__ mask,
@@ -200,11 +210,20 @@ int lmrl_rtg(const float *rewards_d, const uint8_t *sta_d, const int32_t *len_d,
 
 int lmrl_whiten_moments(const float *x_d, const uint8_t *mask_d, double *moments_d, size_t n, void *stream) {
     LMRL_REQUIRE(x_d && moments_d, "lmrl_whiten_moments: null pointer");
-    LMRL_CHECK_HIP(hipMemsetAsync(moments_d, 0, 3 * sizeof(double), as_stream(stream)));
-    if (n == 0) return LMRL_OK;
-    int grid = ceil_div((long)n, 256);
-    if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(whiten_moments_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x_d, mask_d, moments_d, n);
+    if (n == 0) {
+        LMRL_CHECK_HIP(hipMemsetAsync(moments_d, 0, 3 * sizeof(double), as_stream(stream)));
+        return LMRL_OK;
+    }
+    // per-workgroup partials in a process-wide scratch buffer (calls on different streams must not overlap), then a
+    // fixed-order final sum: bit-reproducible, no fp64 atomics
+    constexpr int kMaxBlocks = 1024;
+    static double *partials = nullptr;
+    if (!partials) LMRL_CHECK_HIP(hipMalloc(&partials, (size_t)kMaxBlocks * 3 * sizeof(double)));
+    int grid = ceil_div((long)n, 256 * 8);
+    if (grid > kMaxBlocks) grid = kMaxBlocks;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(whiten_moments_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x_d, mask_d, partials, n);
+    hipLaunchKernelGGL(whiten_finish_kernel, dim3(1), dim3(64), 0, as_stream(stream), partials, grid, moments_d);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }
