@@ -1,0 +1,82 @@
+"""GPU tier: the pieces compose the way the reference's task scripts use them at toy scale:
+device data generation -> jsonl -> ILQL / MC / BC datasets -> train steps -> value policy on the HIP engine -> text_env_eval."""
+import numpy as np
+import pytest
+
+import lmrl_gym_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_generated_dataset_replays_on_the_oracle_env(tmp_path):
+    from lmrl_gym_amd import datasets as DS
+    from lmrl_gym_amd.envs import wordle as W
+    from oracle.wordle import OracleWordleEnv
+    vocab = W.Vocabulary.builtin("wordle_official_400.txt")
+    items, seeds = DS.generate_wordle_dataset(vocab, 150, prob_smart=0.7, seed=4, bsize=64, return_seeds=True)
+    assert len(items) == 150 and len(seeds) == 150
+    wins = 0
+    for it, sd in zip(items, seeds):
+        o = OracleWordleEnv(vocab.all_vocab, True, -1.0)
+        hist = o.reset(sd)
+        seq, rew = it["sequence"], it["reward"]
+        assert seq[0] == ("Wordle:\n", 0.0) and len(rew) == len(seq) - 1 and it["done"]
+        done, k = False, 1
+        while not done:
+            hist, r, done = o.step(hist + ((seq[k][0], True),))
+            assert seq[k][1] == 1.0 and seq[k + 1] == (hist[-1][0], 0.0)
+            assert rew[k - 1] == float(r) and rew[k] == 0.0
+            k += 2
+        assert k == len(seq)
+        wins += rew[-2] == 0.0
+    assert wins > 0          # the "smart" branch does solve some games
+    p = tmp_path / "wordle.jsonl"
+    DS.write_jsonl(str(p), items)
+    tok = DS.WordleTokenizer()
+    mc = DS.mc_data_from_jsonl(str(p), tok, gamma=1.0)
+    for d, it in zip(mc[:20], items[:20]):
+        total = sum(it["reward"])
+        first_action = int(np.argmax(d.should_take_action))
+        assert abs(float(d.returns[first_action]) - total) < 1e-5      # undiscounted return-to-go of the first action token
+
+
+def test_toy_ilql_pipeline_end_to_end(tmp_path):
+    from lmrl_gym_amd import datasets as DS, environment as E
+    from lmrl_gym_amd.algorithms import ilql
+    from lmrl_gym_amd.algorithms.common import BlockingStrategy, Padding, Truncation
+    from lmrl_gym_amd.envs import wordle as W
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
+    from lmrl_gym_amd.policies import GPT2ValuePolicy, heads_to_engine_layout
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    from lmrl_gym_amd import _lib
+    dev = _lib.require_gpu()
+    vocab = W.Vocabulary.builtin("wordle_official_400.txt")
+    tok = DS.WordleTokenizer()
+    p = tmp_path / "train.jsonl"
+    DS.write_jsonl(str(p), DS.generate_wordle_dataset(vocab, 64, prob_smart=0.5, seed=1))
+    ds = DS.ilql_dataset_from_jsonl(str(p), tok, BlockingStrategy(Padding.RIGHT, Truncation.RIGHT, 80))
+    cfg = GPT2Config(2, 2, 128, 256, 50257, 128)
+    sd = init_hf_style_state_dict(cfg, seed=0)
+    base = GPT2F32(sd, cfg.n_head, device=dev)
+    d, V = cfg.d_model, cfg.vocab
+    g = torch.Generator().manual_seed(0)
+    mk = lambda out, b2: MLPHeadF32({"dense1.kernel": torch.randn(d, d, generator=g) * 0.05, "dense1.bias": torch.zeros(d),
+                                     "dense2.kernel": torch.zeros(d, out), "dense2.bias": torch.full((out,), b2)}, dev)
+    tr = ilql.GPT2ILQLTrain(base, mk(V, -4.4), mk(V, -4.4), mk(1, -4.4), tok.pad_token_id, dict(gamma=0.99, tau=0.7, cql_weight=0.01), lr=1e-3)
+    losses = []
+    for epoch in range(2):
+        for batch in DS.dataloader(np.random.default_rng(epoch), ds, 16):
+            _, loss, logs = tr.step(batch["input_ids"], batch["should_take_action"], batch["rewards"], batch["dones"])
+            assert np.isfinite(loss)
+            losses.append(loss)
+    assert len(losses) == 8 and losses[-1] < losses[0]
+    # trained weights -> bf16 rollout engine -> ILQL value policy -> evaluation on the (reformatted) Wordle env
+    eng = GPT2Engine(cfg, {k: v.detach().cpu() for k, v in base.p.items()}, dev)
+    hl = lambda h: heads_to_engine_layout({k: v.detach().cpu() for k, v in h.p.items()}, cfg.vocab_padded, dev)
+    pol = GPT2ValuePolicy(eng, eng, hl(tr.q1), hl(tr.q2), 4.0, tok, max_input_length=96, max_new_tokens=8, do_sample=True, seed=3,
+                          eos_token_id=tok.eos_token_id, out_str_process=lambda x: x.removesuffix("\n") + "\n")
+    env = W.ReformatWordleEnvironment(vocab, require_words_in_vocab=True, bad_word_reward=-10.0)
+    inter, summary = E.text_env_eval(env, pol, n_rollouts=6, bsize=3, seed_generator=iter(range(100)), verbose=False)
+    assert len(inter) == 6 and all(ep[-1].done for ep in inter)
+    assert set(summary["reward"]) >= {"mean", "std", "min", "max"} and np.isfinite(summary["reward"]["mean"])
