@@ -80,3 +80,20 @@ def test_toy_ilql_pipeline_end_to_end(tmp_path):
     inter, summary = E.text_env_eval(env, pol, n_rollouts=6, bsize=3, seed_generator=iter(range(100)), verbose=False)
     assert len(inter) == 6 and all(ep[-1].done for ep in inter)
     assert set(summary["reward"]) >= {"mean", "std", "min", "max"} and np.isfinite(summary["reward"]["mean"])
+
+
+def test_checkpoint_roundtrip_drives_the_engine(tmp_path):
+    """weights -> reference checkpoint layout (flax msgpack + config.json) -> loaded back -> rollout engine: identical
+    hidden states to the engine built from the original state dict."""
+    from lmrl_gym_amd import _lib, checkpoints as C
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
+    dev = _lib.require_gpu()
+    cfg = GPT2Config(2, 2, 128, 256, 500, 64)
+    sd = init_hf_style_state_dict(cfg, seed=9)
+    C.save_gpt2_checkpoint(str(tmp_path / "policy"), cfg, sd)
+    cfg2, sd2 = C.load_gpt2_checkpoint(str(tmp_path / "policy"))
+    e1, e2 = GPT2Engine(cfg, sd, dev), GPT2Engine(cfg2, {k: torch.from_numpy(v) for k, v in sd2.items()}, dev)
+    toks = torch.randint(0, 500, (4 * 8,), generator=torch.Generator().manual_seed(0)).to(torch.int32).to(dev)
+    cnt = torch.tensor([8, 3, 8, 5], dtype=torch.int32, device=dev)
+    h = [e.session(4, 16).forward(toks, cnt, 8).clone() for e in (e1, e2)]
+    assert torch.equal(h[0], h[1])
