@@ -20,6 +20,28 @@ from .common import BlockingStrategy, Padding, Truncation, block_sequences, init
 from .ppo import PPOData, _t, gae_from_chains
 
 
+def text_trajectory_chains_from_interactions(raw_results, tokenizer, max_length: int, gamma: float):
+    """The rollout -> chain step of the task scripts' `ppo_dataset_loader` (llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py:
+    310-342): per episode one TextTrajectory with reward [0, r1, 0, r2, 0, ...]; while its tokenisation reaches `max_length`
+    the last (action, observation) pair is cut, its discounted reward folded into the previous action and `done` cleared;
+    episodes shorter than 3 texts or still too long are skipped."""
+    from ..environment import TextTrajectory, TextTrajectoryChain, TokenTrajectory
+    chains = []
+    for raw in raw_results:
+        hist = tuple(raw[-1].post_transition_history)
+        reward = sum([[it.reward, 0.0] for it in raw], [0.0])
+        done = raw[-1].done
+        n_tok = lambda h, r, d: TokenTrajectory.from_text_trajectory(TextTrajectory(h, tuple(r), d), tokenizer).tokens.shape[0]
+        while len(hist) > 3 and n_tok(hist, reward, done) >= max_length:
+            new_reward = list(reward[:-2])
+            new_reward[-2] += sum(reward[-2:]) * gamma
+            hist, reward, done = hist[:-2], new_reward, False
+        if len(hist) < 3 or n_tok(hist, reward, done) >= max_length:
+            continue
+        chains.append(TextTrajectoryChain(TextTrajectory(hist, tuple(reward), done), None))
+    return chains
+
+
 class PPOForwardOutput(NamedTuple):
     initial_policy_logprobs: Optional[np.ndarray]   # [B, T-1] log p_init(ids[t+1] | ids[:t+1])
     policy_logprobs: np.ndarray                     # [B, T-1]
@@ -65,8 +87,37 @@ class CombinedTokenTrajectoryChain(NamedTuple):
 
 
 class GPT2PPOInference:
-    def __init__(self, policy: GPT2F32, value_head: LinearHeadF32, pad_token_id: int, initial_policy: Optional[GPT2F32] = None):
+    def __init__(self, policy: GPT2F32, value_head: LinearHeadF32, pad_token_id: int, initial_policy: Optional[GPT2F32] = None,
+                 tokenizer=None, loss_kwargs: Optional[dict] = None, bc_loss_weight: float = 0.0):
         self.policy, self.value_head, self.initial_policy, self.pad = policy, value_head, initial_policy, pad_token_id
+        self.tokenizer, self.loss_kwargs, self.bc_loss_weight = tokenizer, dict(loss_kwargs or {}), bc_loss_weight
+
+    def forward_from_str(self, input_strs: List[str], blocking_strategy: BlockingStrategy = BlockingStrategy(Padding.RIGHT, Truncation.RIGHT, None),
+                         token_process=None) -> PPOForwardOutput:
+        """base_interface.py:437-462."""
+        tp = token_process or (lambda x: x)
+        tokens = block_sequences([tp(list(self.tokenizer.encode(s))) for s in input_strs], self.pad, np.int32, blocking_strategy)
+        return self.forward(tokens)
+
+    def get_ppo_data_from_text_trajectory_chain(self, text_trajectory_chains, bsize: int, max_length: Optional[int] = None, token_process=None,
+                                                **kw) -> Tuple[List[PPOData], np.ndarray]:
+        """base_interface.py:671-708: tokenise the chains, then the token-level pipeline."""
+        from ..environment import TokenTrajectoryChain
+        chains = [TokenTrajectoryChain.from_text_trajectory_chain(c, self.tokenizer, token_process=token_process) for c in text_trajectory_chains]
+        return self.get_ppo_data_from_token_trajectory_chain(chains, bsize=bsize, max_length=max_length, **kw)
+
+    def eval_loss(self, input_ids, should_take_action, old_logprobs, old_values, old_advantages, old_returns, attention_mask=None,
+                  position_ids=None, prng_key=None, bc_data_input_ids=None, bc_data_input_attention_mask=None, bc_data_input_position_ids=None,
+                  bc_data_input_training_mask=None, train: bool = False):
+        """base_interface.py:747-799: the train step's loss / log dict without the update (returns (loss, logs))."""
+        from .ppo import GPT2PPOTrain
+        ev = GPT2PPOTrain.__new__(GPT2PPOTrain)            # loss-only view on the same weights: no optimizer state is created
+        ev.policy, ev.value_head, ev.pad, ev.loss_kwargs, ev.bc_loss_weight = self.policy, self.value_head, self.pad, self.loss_kwargs, self.bc_loss_weight
+        _, loss, logs = ev.step(input_ids, should_take_action, old_logprobs, old_values, old_advantages, old_returns, attention_mask=attention_mask,
+                                position_ids=position_ids, bc_data_input_ids=bc_data_input_ids,
+                                bc_data_input_attention_mask=bc_data_input_attention_mask, bc_data_input_position_ids=bc_data_input_position_ids,
+                                bc_data_input_training_mask=bc_data_input_training_mask, train=False)
+        return loss, logs
 
     def _logprobs(self, model: GPT2F32, ids_d, am_d, pos_d, B, T):
         import torch

@@ -97,3 +97,64 @@ def test_checkpoint_roundtrip_drives_the_engine(tmp_path):
     cnt = torch.tensor([8, 3, 8, 5], dtype=torch.int32, device=dev)
     h = [e.session(4, 16).forward(toks, cnt, 8).clone() for e in (e1, e2)]
     assert torch.equal(h[0], h[1])
+
+
+def test_toy_online_ppo_round(tmp_path):
+    """One round of the online PPO loop of llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py at toy scale: rollouts with the policy
+    on the HIP engine -> text chains -> PPOData (both policies' log-probs, values, KL-penalised GAE, whitening) -> PPODataset
+    -> train steps with the BC auxiliary batch -> new weights pushed back into the rollout policy."""
+    from lmrl_gym_amd import _lib, datasets as DS, environment as E
+    from lmrl_gym_amd.algorithms import ppo
+    from lmrl_gym_amd.algorithms.common import BlockingStrategy, Padding, Truncation
+    from lmrl_gym_amd.algorithms.ppo_inference import GPT2PPOInference, text_trajectory_chains_from_interactions
+    from lmrl_gym_amd.envs import wordle as W
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
+    from lmrl_gym_amd.policies import GPT2PPOPolicy
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
+    dev = _lib.require_gpu()
+    vocab = W.Vocabulary.builtin("wordle_official_400.txt")
+    tok = DS.WordleTokenizer()
+    cfg = GPT2Config(2, 2, 128, 256, 50257, 128)
+    sd = init_hf_style_state_dict(cfg, seed=2)
+    # bias the LM head towards the Wordle alphabet so that sampled actions decode to letters (a BC-initialised policy's role)
+    letters = tok.table.letter_sp + tok.table.letter_first + [tok.table.newline]
+    sd["wte.weight"][letters] += 1.0
+    sd["ln_f.bias"] = sd["wte.weight"][letters].mean(0) * 0.5
+    pol_f32, init_f32 = GPT2F32(sd, cfg.n_head, device=dev), GPT2F32(sd, cfg.n_head, device=dev)
+    head = LinearHeadF32(dict(kernel=torch.zeros(cfg.d_model, 1), bias=torch.tensor([-4.1])), dev)
+    max_len = 96
+    policy = GPT2PPOPolicy(GPT2Engine(cfg, sd, dev), tok, max_input_length=72, max_new_tokens=12, do_sample=True, seed=1,
+                           eos_token_id=tok.eos_token_id, out_str_process=lambda x: x.removesuffix("\n") + "\n")
+    env = W.ReformatWordleEnvironment(vocab, require_words_in_vocab=True, bad_word_reward=-10.0)
+    raw, summary = E.text_env_eval(env, policy, n_rollouts=8, bsize=4, seed_generator=iter(range(1000)), verbose=False)
+    assert len(raw) == 8 and np.isfinite(summary["reward"]["mean"])
+
+    class AnyTok:                 # sampled text is arbitrary GPT-2 text only in a real run; here: Wordle alphabet or unknown -> pad id
+        pad_token_id, eos_token_id = tok.pad_token_id, tok.eos_token_id
+
+        def encode(self, s):
+            try:
+                return tok.encode(s)
+            except AssertionError:
+                return [tok.table.newline]
+    chains = text_trajectory_chains_from_interactions(raw, AnyTok(), max_len, gamma=1.0)
+    assert 1 <= len(chains) <= 8
+    kw = dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0)
+    inf = GPT2PPOInference(pol_f32, head, tok.pad_token_id, initial_policy=init_f32, tokenizer=AnyTok(), loss_kwargs=kw, bc_loss_weight=1.0)
+    ctl = ppo.AdaptiveKLController(init_kl_coef=0.001, target=0.1, horizon=10000)
+    datas, kls = inf.get_ppo_data_from_text_trajectory_chain(chains, bsize=4, max_length=max_len, gamma=1.0, lam=0.95, kl_weight=ctl.value)
+    assert np.allclose(kls, 0.0, atol=1e-5)               # policy == initial policy in round 0
+    ctl.update(float(kls.mean()), 4)
+    ds = ppo.PPODataset.from_ppo_data_list(datas, tok, BlockingStrategy(Padding.RIGHT, Truncation.RIGHT, max_len))
+    bc = DS.MaskDataset.blocked_from_str_segments([[("Wordle:\n", 0.0), ("s t a r e\n", 1.0), ("b b y b b\n", 0.0)]] * 4, tok,
+                                                  BlockingStrategy(Padding.RIGHT, Truncation.RIGHT, 32))
+    tr = ppo.GPT2PPOTrain(pol_f32, head, tok.pad_token_id, kw, lr=1e-4, bc_loss_weight=1.0)
+    before = pol_f32.p["h.0.mlp.c_fc.weight"].clone()
+    for batch in DS.dataloader(np.random.default_rng(0), ds, min(4, len(ds)), truncate=True):
+        ev_loss, _ = inf.eval_loss(**batch, bc_data_input_ids=bc.input_ids, bc_data_input_training_mask=bc.input_training_mask)
+        _, loss, logs = tr.step(**batch, bc_data_input_ids=bc.input_ids, bc_data_input_training_mask=bc.input_training_mask)
+        assert np.isfinite(loss) and abs(ev_loss - loss) < 1e-5 * max(1.0, abs(loss)) and set(logs) == {"ppo", "bc", "total_loss"}
+    assert not torch.equal(before, pol_f32.p["h.0.mlp.c_fc.weight"])
+    policy.set_params(GPT2Engine(cfg, {k: v.detach().cpu() for k, v in pol_f32.p.items()}, dev))
+    raw2, _ = E.text_env_eval(env, policy, n_rollouts=4, bsize=4, seed_generator=iter(range(4)), verbose=False)
+    assert len(raw2) == 4
