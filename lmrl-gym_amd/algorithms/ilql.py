@@ -16,7 +16,7 @@ from .. import _lib
 from .. import dist as D
 from ..train import ops
 from ..train.gpt2_f32 import AdamW, GPT2F32, MLPHeadF32
-from .common import BlockingStrategy, block_sequences, initialize_attn_mask_pos_ids, stats_from_sums
+from .common import BlockingStrategy, Padding, Truncation, block_sequences, initialize_attn_mask_pos_ids, stats_from_sums
 from .ppo import _t
 
 
@@ -262,3 +262,61 @@ class GPT2ILQLTrain:
             self._update_targets(self.q1.p, self.q1_target.p, self.q1_opt.step_count)
             self._update_targets(self.q2.p, self.q2_target.p, self.q2_opt.step_count)
         return self, loss, logs
+
+
+# ----------------------------------------------------------------------------- inference face
+class ValueRLForwardOutput(NamedTuple):
+    """value_rl_base/base_interface.py:20-24 (base_raw_output reduced to the LM logits)."""
+    base_logits: np.ndarray            # [B, T, V]
+    q1: np.ndarray                     # [B, T, V]
+    q2: Optional[np.ndarray]
+    v: Optional[np.ndarray]            # [B, T]
+
+
+class GPT2ILQLInference:
+    """Counterpart of `ILQLInference` / `ValueRLInference` (ilql/base_interface.py:235-439, value_rl_base/base_interface.py:26-181)
+    on the fp32 train kernels: `forward`, `forward_from_str`, `eval_loss`; generation is `policies.GPT2ValuePolicy`
+    (`generate_from_str` below wraps it)."""
+
+    def __init__(self, base: GPT2F32, q1_head: MLPHeadF32, q2_head: Optional[MLPHeadF32], v_head: Optional[MLPHeadF32], pad_token_id: int,
+                 tokenizer=None, loss_kwargs: Optional[Dict[str, float]] = None, target_base: Optional[GPT2F32] = None,
+                 q1_target_head: Optional[MLPHeadF32] = None, q2_target_head: Optional[MLPHeadF32] = None, policy=None):
+        self.base, self.q1, self.q2, self.v, self.pad, self.tokenizer = base, q1_head, q2_head, v_head, pad_token_id, tokenizer
+        self.loss_kwargs, self.target_base = dict(loss_kwargs or {}), target_base
+        self.q1_target, self.q2_target, self.policy = q1_target_head, q2_target_head, policy
+
+    def forward(self, input_ids, attention_mask=None, position_ids=None) -> ValueRLForwardOutput:
+        ids = np.asarray(input_ids, dtype=np.int32)
+        am, pos = initialize_attn_mask_pos_ids(ids, self.pad, attention_mask, position_ids)
+        B, T = ids.shape
+        R = B * T
+        hid, _ = self.base.forward(_t(ids, np.int32), _t(am, np.uint8), _t(pos, np.int32))
+        logits = self.base.lm_logits(hid, R).view(B, T, -1).cpu().numpy()
+        q1 = self.q1.forward(hid, R)[0].view(B, T, -1).cpu().numpy()
+        q2 = self.q2.forward(hid, R)[0].view(B, T, -1).cpu().numpy() if self.q2 is not None else None
+        v = self.v.forward(hid, R)[0].view(B, T).cpu().numpy() if self.v is not None else None
+        return ValueRLForwardOutput(logits, q1, q2, v)
+
+    def forward_from_str(self, input_strs: List[str], blocking_strategy: BlockingStrategy = BlockingStrategy(Padding.RIGHT, Truncation.RIGHT, None),
+                         token_process=None) -> ValueRLForwardOutput:
+        tp = token_process or (lambda x: x)
+        return self.forward(block_sequences([tp(list(self.tokenizer.encode(s))) for s in input_strs], self.pad, np.int32, blocking_strategy))
+
+    def eval_loss(self, input_ids, should_take_action, rewards, dones, next_token_ids=None, next_dones=None, attention_mask=None,
+                  position_ids=None, next_tokens_attention_mask=None, next_tokens_position_ids=None, prng_key=None, train: bool = False):
+        """ilql/base_interface.py:383-439: loss and log dict of the train step without an update."""
+        ev = GPT2ILQLTrain.__new__(GPT2ILQLTrain)          # loss-only view on the same weights: no optimizer state is created
+        ev.base, ev.q1, ev.q2, ev.v, ev.pad, ev.loss_kwargs = self.base, self.q1, self.q2, self.v, self.pad, self.loss_kwargs
+        ev.target_base = self.target_base
+        ev.q1_target, ev.q2_target = self.q1_target or self.q1, self.q2_target or self.q2
+        _, loss, logs = ev.step(input_ids, should_take_action, rewards, dones, next_token_ids=next_token_ids, next_dones=next_dones,
+                                attention_mask=attention_mask, position_ids=position_ids, next_tokens_attention_mask=next_tokens_attention_mask,
+                                next_tokens_position_ids=next_tokens_position_ids, train=False)
+        return loss, logs
+
+    def generate_from_str(self, input_strs: List[str]) -> List[str]:
+        """Completions of `input_strs` under the ILQL-perturbed policy given at construction (a `policies.GPT2ValuePolicy`)."""
+        from ..environment import Text
+        assert self.policy is not None, "pass policy=GPT2ValuePolicy(...) to generate"
+        out = self.policy.act([(Text(s, False),) for s in input_strs], [False] * len(input_strs))
+        return [h[-1].text for h in out]

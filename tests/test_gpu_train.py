@@ -418,6 +418,43 @@ def test_ilql_next_token_branch_and_ppo_bc_term(dev):
     _close(hg["kernel"].cpu(), hkr.grad, rtol=3e-4)
 
 
+def test_ilql_inference_forward_and_eval_loss(dev):
+    from lmrl_gym_amd.algorithms import ilql
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    from oracle import gpt2 as O, rl
+    cfg, sd = _tiny_model(31, vocab=71)
+    pad = cfg.vocab - 1
+    rng = np.random.RandomState(3)
+    B, T, V, d = 3, 11, cfg.vocab, cfg.d_model
+    ids, sta, lens = _batch(rng, B, T, cfg.vocab, pad)
+    g = torch.Generator().manual_seed(2)
+    mk = lambda out: {"dense1.kernel": torch.randn(d, d, generator=g) * 0.2, "dense1.bias": torch.randn(d, generator=g) * 0.1,
+                      "dense2.kernel": torch.randn(d, out, generator=g) * 0.2, "dense2.bias": torch.full((out,), -0.3)}
+    hq1, hq2, hv = mk(V), mk(V), mk(1)
+    base = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
+    heads = [MLPHeadF32({k: v.clone() for k, v in h.items()}, dev) for h in (hq1, hq2, hv)]
+    kw = dict(gamma=0.95, tau=0.8, cql_weight=0.05)
+    inf = ilql.GPT2ILQLInference(base, heads[0], heads[1], heads[2], pad, loss_kwargs=kw)
+    out = inf.forward(ids)
+    am = torch.from_numpy((ids != pad).astype(np.int64)); pos = (am.cumsum(-1) - 1).clamp(min=0)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    lg, hid = O.forward(sd64, torch.from_numpy(ids).long(), cfg.n_head, attention_mask=am, position_ids=pos, return_hidden=True)
+    mh = lambda h: rl.mlp_head(hid, *(h[k].double() for k in ("dense1.kernel", "dense1.bias", "dense2.kernel", "dense2.bias")))
+    real = am.bool().numpy()
+    _close(out.base_logits[real], lg.numpy()[real], rtol=2e-5)
+    _close(out.q1[real], mh(hq1).numpy()[real], rtol=2e-5); _close(out.q2[real], mh(hq2).numpy()[real], rtol=2e-5)
+    _close(out.v[real], mh(hv)[..., 0].numpy()[real], rtol=2e-5)
+    # eval_loss == the train step's loss on the same weights, and leaves the weights untouched
+    rewards = (rng.randn(B, T - 1) * sta).astype(np.float32)
+    dones = np.array([1, 0, 1], dtype=np.float32)
+    w0 = base.p["h.0.attn.c_attn.weight"].clone()
+    ev_loss, ev_logs = inf.eval_loss(ids, sta, rewards, dones)
+    assert torch.equal(w0, base.p["h.0.attn.c_attn.weight"])
+    tr = ilql.GPT2ILQLTrain(base, heads[0], heads[1], heads[2], pad, kw, lr=1e-3)
+    _, loss, logs = tr.step(ids, sta, rewards, dones)
+    assert abs(ev_loss - loss) <= 1e-6 * max(1.0, abs(loss)) and _flat_logs(ev_logs).keys() == _flat_logs(logs).keys()
+
+
 # ------------------------------------------------------------------ MC returns, BC, rerankers
 def test_mc_returns_and_loss(dev):
     from lmrl_gym_amd.algorithms import mc_returns as mc
