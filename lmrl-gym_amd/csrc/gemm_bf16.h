@@ -522,8 +522,10 @@ inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
     if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI, NQ>(g, s);
     if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
     if (g_gemm_variant == 101) return gemm_launch_glds<64, 64, 2, EPI, NQ>(g, s);
-    if (g.N <= 1024) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
-    return gemm_launch_glds<64, 64, 3, EPI, NQ>(g, s);
+    const long tiles = (long)((g.M + 63) / 64) * (g.N / 64);
+    if (tiles <= 512) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
+    if (tiles <= 768) return gemm_launch_glds<64, 64, 3, EPI, NQ>(g, s);
+    return gemm_launch_glds<64, 64, 2, EPI, NQ>(g, s);
 }
 // Slots per row are padded to 8*NQ (zero filled): NQ = 1 (d_model <= 256), 3 (768), 4 (1024).
 inline int ln_fusion_nq(int d_model) {
@@ -574,8 +576,10 @@ inline hipError_t gemm_launch(const GemmArgs &g, hipStream_t s) {
     // at once (768 tiles: 3 stages = 48 KiB -> 3 WG/CU; 192 tiles: 4 stages = 64 KiB -> 2 WG/CU).
     if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI>(g, s);
     if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI>(g, s);
-    if (g.N <= 1024) return gemm_launch_glds<64, 64, 4, EPI>(g, s);
-    return gemm_launch_glds<64, 64, 3, EPI>(g, s);
+    const long tiles = (long)((g.M + 63) / 64) * (g.N / 64);
+    if (tiles <= 512) return gemm_launch_glds<64, 64, 4, EPI>(g, s);      // 64 KiB ring -> 2 WG/CU -> 512 resident tiles
+    if (tiles <= 768) return gemm_launch_glds<64, 64, 3, EPI>(g, s);      // 48 KiB ring -> 3 WG/CU -> 768 resident tiles
+    return gemm_launch_glds<64, 64, 2, EPI>(g, s);
 }
 
 }  // namespace lmrl
