@@ -122,7 +122,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = os.environ.get("LMRL_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" only for launch-path tests
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("LMRL_BENCH_FORCE_DIST") == "1"   # FORCE_DIST: 1-rank RCCL group, launch-path test
+    if use_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -163,7 +164,7 @@ def main():
             print(f"[bench] rank {rank}: hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
             args.graph = 0
             torch.cuda.synchronize()
-        if world > 1:            # every rank must time the same mode
+        if use_dist:             # every rank must time the same mode
             flag = torch.tensor([args.graph], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
             args.graph = int(flag.item())
@@ -198,7 +199,7 @@ def main():
     total_steps_parts = []
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -266,7 +267,7 @@ def main():
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     steps_all = torch.stack(total_steps_parts).sum() if total_steps_parts else total_steps.clone()
-    if world > 1:
+    if use_dist:
         if backend != "nccl":
             t, steps_all = t.cpu(), steps_all.cpu()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -303,7 +304,7 @@ def main():
         print(json.dumps(out), flush=True)
     for r in ros:
         r.close()
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 
