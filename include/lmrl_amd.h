@@ -217,6 +217,8 @@ typedef struct {
     float beta;             /* ILQL logit perturbation weight */
     int32_t pad_token;      /* written for inactive rows */
     const uint32_t *epoch_d;/* optional DEVICE word = 4th Philox counter word (0 when NULL): fresh noise per hipGraph replay */
+    float top_p;            /* nucleus mass in (0, 1); <= 0 or >= 1 = off.  Applied after temperature and top_k (HF warper order):
+                             * the smallest prefix of the descending-sorted tokens whose cumulative probability reaches top_p */
 } lmrl_sample_params;
 
 size_t lmrl_sample_ws_bytes(int m, int vocab_padded);
@@ -229,7 +231,7 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
                         int d_model, int vocab, int vocab_padded, const lmrl_sample_params *p, const int32_t *steer_tok_d,
                         const uint8_t *active_d, int32_t *token_d, float *logprob_d, float *logits_out_d, void *ws_d,
                         void *stream);
-/* Sample from materialised logits (temperature, top-k) with the same random stream. */
+/* Sample from materialised logits (temperature, top-k, top-p) with the same random stream. */
 int lmrl_sample_logits(const float *logits_d, int ld, int m, int vocab, const lmrl_sample_params *p,
                        const uint8_t *active_d, int32_t *token_d, float *logprob_d, void *stream);
 

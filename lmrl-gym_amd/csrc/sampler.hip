@@ -234,7 +234,7 @@ __device__ __forceinline__ uint32_t f32_order_key(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__global__ __launch_bounds__(256) void topk_sample_kernel(const float *__restrict__ logits, int ld, int vocab, int top_k,
+__global__ __launch_bounds__(256) void topk_sample_kernel(const float *__restrict__ logits, int ld, int vocab, int top_k, float top_p,
                                                           const uint8_t *__restrict__ active, int32_t *__restrict__ token,
                                                           float *__restrict__ logprob, SampleParams sp, int pad_token) {
     const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -272,7 +272,68 @@ __global__ __launch_bounds__(256) void topk_sample_kernel(const float *__restric
         prefix = sel_prefix; remaining = sel_remaining;
         __syncthreads();
     }
-    const uint32_t thr_key = prefix;   // key of the k-th largest logit
+    uint32_t thr_key = prefix;   // key of the k-th largest logit (0 = keep everything when top_k is off)
+    if (top_k <= 0 || top_k >= vocab) thr_key = 0;
+
+    // ---- top-p (nucleus) over what top-k kept, HF TopPLogitsWarper: keep the descending-sorted prefix whose cumulative
+    // probability reaches top_p, i.e. token K is kept iff mass(keys > K) < top_p * Z.  A second radix select, this time on
+    // probability MASS per bucket; masses are 32.32 fixed-point integers so that the LDS atomics add in any order to the
+    // same sums (bit-reproducible).  Tokens tied with the crossing token are all kept.
+    if (top_p > 0.f && top_p < 1.f && !sp.greedy) {
+        __shared__ unsigned long long mhist[256];
+        __shared__ unsigned long long sel_above, sel_total;
+        __shared__ float s_rowmax[4];
+        float rmax = -INFINITY;
+        for (int n = tid; n < vocab; n += 256) {
+            const float raw = row[n];
+            if (f32_order_key(raw) >= thr_key) rmax = fmaxf(rmax, raw);
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o));
+        if (lane == 0) s_rowmax[wave] = rmax;
+        __syncthreads();
+        rmax = fmaxf(fmaxf(s_rowmax[0], s_rowmax[1]), fmaxf(s_rowmax[2], s_rowmax[3]));
+        uint32_t pprefix = 0;
+        unsigned long long above = 0, target = 0;
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 24 - 8 * pass;
+            mhist[tid] = 0ull;
+            __syncthreads();
+            for (int n = tid; n < vocab; n += 256) {
+                const float raw = row[n];
+                const uint32_t key = f32_order_key(raw);
+                if (key < thr_key) continue;
+                const bool match = pass == 0 || (key >> (shift + 8)) == (pprefix >> (shift + 8));
+                if (match) {
+                    const float e = __expf((raw - rmax) * sp.inv_temperature);          // in (0, 1]
+                    atomicAdd(&mhist[(key >> shift) & 255u], (unsigned long long)((double)e * 4294967296.0));
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                if (pass == 0) {
+                    unsigned long long tot = 0;
+                    for (int b = 0; b < 256; b++) tot += mhist[b];
+                    sel_total = (unsigned long long)((double)top_p * (double)tot);
+                    if (sel_total == 0) sel_total = 1;
+                }
+                const unsigned long long tgt = sel_total;
+                unsigned long long ab = pass == 0 ? 0ull : sel_above;
+                uint32_t b = 255;
+                for (;; b--) {
+                    if (ab + mhist[b] >= tgt || b == 0) break;      // the crossing token lives in bucket b
+                    ab += mhist[b];
+                }
+                sel_above = ab;
+                sel_prefix = pprefix | (b << shift);
+            }
+            __syncthreads();
+            pprefix = sel_prefix; above = sel_above; target = sel_total;
+            __syncthreads();
+        }
+        (void)above; (void)target;
+        if (pprefix > thr_key) thr_key = pprefix;
+    }
     const uint32_t epoch = sp.epoch ? *sp.epoch : 0u;
     float pmax = -INFINITY, psum = 0.f, best = -INFINITY, best_z = 0.f;
     int best_col = 0x7fffffff;
@@ -362,9 +423,10 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
                            steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm);
     }
     LMRL_CHECK_LAUNCH();
-    if (p->top_k > 0 && p->top_k < vocab) {
-        LMRL_REQUIRE(logits_out_d, "lmrl_lm_head_sample: top_k sampling needs logits_out_d (materialised logits)");
-        hipLaunchKernelGGL(topk_sample_kernel, dim3(m), dim3(256), 0, s, logits_out_d, vocab_padded, vocab, p->top_k, active_d,
+    const bool nucleus = p->top_p > 0.f && p->top_p < 1.f && !sp.greedy;
+    if ((p->top_k > 0 && p->top_k < vocab) || nucleus) {
+        LMRL_REQUIRE(logits_out_d, "lmrl_lm_head_sample: top_k / top_p sampling needs logits_out_d (materialised logits)");
+        hipLaunchKernelGGL(topk_sample_kernel, dim3(m), dim3(256), 0, s, logits_out_d, vocab_padded, vocab, p->top_k, p->top_p, active_d,
                            token_d, logprob_d, sp, p->pad_token);
     } else {
         hipLaunchKernelGGL(sample_reduce_kernel, dim3(ceil_div(m, 4)), dim3(256), 0, s, partials, active_d, token_d, logprob_d, m,
@@ -382,7 +444,7 @@ int lmrl_sample_logits(const float *logits_d, int ld, int m, int vocab, const lm
     sp.inv_temperature = sp.greedy ? 1.f : 1.f / p->temperature;
     sp.seed_lo = (uint32_t)p->seed; sp.seed_hi = (uint32_t)(p->seed >> 32); sp.step = p->step; sp.epoch = p->epoch_d;
     sp.steer_strength = 0.f; sp.beta = 0.f; sp.vocab = vocab;
-    hipLaunchKernelGGL(topk_sample_kernel, dim3(m), dim3(256), 0, as_stream(stream), logits_d, ld, vocab, p->top_k, active_d,
+    hipLaunchKernelGGL(topk_sample_kernel, dim3(m), dim3(256), 0, as_stream(stream), logits_d, ld, vocab, p->top_k, p->top_p, active_d,
                        token_d, logprob_d, sp, p->pad_token);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;

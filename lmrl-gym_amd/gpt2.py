@@ -50,7 +50,7 @@ class _CConfig(ctypes.Structure):
 class SampleParams(ctypes.Structure):
     _fields_ = [("temperature", ctypes.c_float), ("top_k", ctypes.c_int32), ("seed", ctypes.c_uint64),
                 ("step", ctypes.c_uint32), ("steer_strength", ctypes.c_float), ("beta", ctypes.c_float),
-                ("pad_token", ctypes.c_int32), ("epoch_d", ctypes.c_void_p)]
+                ("pad_token", ctypes.c_int32), ("epoch_d", ctypes.c_void_p), ("top_p", ctypes.c_float)]
 
 
 def init_hf_style_state_dict(cfg: GPT2Config, seed: int = 0) -> Dict[str, "torch.Tensor"]:

@@ -56,13 +56,15 @@ class _Generator:
 
 class GPT2PPOPolicy(BatchedTextPolicy):
     def __init__(self, engine: GPT2Engine, tokenizer, max_input_length: int = 256, max_new_tokens: int = 256, do_sample: bool = True,
-                 temperature: Optional[float] = None, top_k: Optional[int] = None, eos_token_id: Optional[int] = None,
+                 temperature: Optional[float] = None, top_k: Optional[int] = None, top_p: Optional[float] = None,
+                 eos_token_id: Optional[int] = None,
                  pad_token_id: Optional[int] = None, seed: int = 0, in_str_process: Optional[Callable[[str], str]] = None,
                  out_str_process: Optional[Callable[[str], str]] = None):
         self.engine, self.tokenizer = engine, tokenizer
         self.max_input_length, self.max_new_tokens = max_input_length, max_new_tokens
         self.temperature = (temperature if temperature is not None else 1.0) if do_sample else 0.0
         self.top_k = top_k or 0
+        self.top_p = float(top_p) if top_p is not None and 0.0 < top_p < 1.0 and do_sample else 0.0
         self.eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
         self.pad = pad_token_id if pad_token_id is not None else getattr(tokenizer, "pad_token_id", 0)
         self.seed, self.calls = seed, 0
@@ -99,12 +101,12 @@ class GPT2PPOPolicy(BatchedTextPolicy):
         active = np.array([not d for d in done], dtype=bool)
         out_ids: List[List[int]] = [[] for _ in range(B)]
         logits_out = None
-        if self.top_k > 0:
+        if self.top_k > 0 or self.top_p > 0.0:
             logits_out = torch.empty(B, self.engine.cfg.vocab_padded, dtype=torch.float32, device=gen.dev)
         for k in range(self.max_new_tokens):
             if not active.any():
                 break
-            p = SampleParams(self.temperature, self.top_k, self.seed + (self.calls << 20), k, 0.0, 0.0, self.pad)
+            p = SampleParams(self.temperature, self.top_k, self.seed + (self.calls << 20), k, 0.0, 0.0, self.pad, None, self.top_p)
             active_d = torch.from_numpy(active.astype(np.uint8)).to(gen.dev)
             tok, _ = self._sample(gen, p, active_d, logits_out)
             tok = tok.cpu().numpy()

@@ -189,6 +189,47 @@ def test_sampler_distribution_chi_square(dev):
     assert chi2 < dof + 5 * np.sqrt(2 * dof), (chi2, dof)
 
 
+def test_sampler_top_p_and_top_k_warpers(dev):
+    """Nucleus sampling with the HF warper semantics (temperature -> top_k -> top_p; the descending-sorted prefix whose
+    cumulative probability reaches top_p is kept): support, renormalised log-probs and empirical frequencies."""
+    import ctypes
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.gpt2 import SampleParams
+    V, B = 257, 4096
+    g = torch.Generator().manual_seed(7)
+    base = torch.randn(V, generator=g) * 2.0
+    logits = base[None].repeat(B, 1).contiguous().to(dev)
+    L = _lib.lib()
+    for temp, top_k, top_p in [(1.0, 0, 0.8), (0.7, 0, 0.5), (1.2, 20, 0.9), (1.0, 5, 0.999)]:
+        # reference kept set
+        z = base.double() / temp
+        order = torch.argsort(z, descending=True, stable=True)
+        keep = torch.ones(V, dtype=torch.bool)
+        if top_k > 0:
+            kth = z[order[top_k - 1]]
+            keep &= z >= kth
+        zk = torch.where(keep, z, torch.tensor(float("-inf"), dtype=torch.float64))
+        probs = torch.softmax(zk, -1)
+        cum = torch.cumsum(probs[order], 0)
+        mask_sorted = torch.roll(cum < top_p, 1); mask_sorted[0] = True
+        keep2 = torch.zeros(V, dtype=torch.bool); keep2[order[mask_sorted]] = True
+        final = torch.softmax(torch.where(keep2, z, torch.tensor(float("-inf"), dtype=torch.float64)), -1).numpy()
+        counts = np.zeros(V)
+        for step in range(3):
+            sp = SampleParams(temp, top_k, 11, step, 0.0, 0.0, 0, None, top_p)
+            tok = torch.zeros(B, dtype=torch.int32, device=dev); lp = torch.zeros(B, dtype=torch.float32, device=dev)
+            _lib.check(L.lmrl_sample_logits(_lib.ptr(logits), V, B, V, ctypes.byref(sp), None, _lib.ptr(tok), _lib.ptr(lp), _lib.stream_ptr()))
+            t = tok.cpu().numpy()
+            assert keep2.numpy()[t].all(), (temp, top_k, top_p)                       # never outside the nucleus
+            np.testing.assert_allclose(lp.cpu().numpy(), np.log(final[t]), rtol=1e-4, atol=1e-4)
+            counts += np.bincount(t, minlength=V)
+        n = counts.sum()
+        big = final * n >= 5
+        chi2 = (((counts - final * n) ** 2) / np.maximum(final * n, 1e-12))[big].sum()
+        dof = max(int(big.sum()) - 1, 1)
+        assert chi2 < dof + 6 * np.sqrt(2 * dof) + 10, (chi2, dof, temp, top_k, top_p)
+
+
 def test_sampler_steer_and_ilql_perturbation(dev):
     """logits = pi + beta * min(q1, q2)  (value_rl_base/gpt2/generation.py:112-117), greedy."""
     from lmrl_gym_amd.gpt2 import SampleParams
