@@ -231,6 +231,11 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
                         int d_model, int vocab, int vocab_padded, const lmrl_sample_params *p, const int32_t *steer_tok_d,
                         const uint8_t *active_d, int32_t *token_d, float *logprob_d, float *logits_out_d, void *ws_d,
                         void *stream);
+/* Generation bookkeeping for any tokenizer (the per-token host loop of HF `generate` / GPT2PPOPolicy.act, ppo/gpt2/interface.py:
+ * 527-535): for every live row append sampled_d[row] to out_tokens_d[row][out_len_d[row]++]; a row stops (active_d[row] = 0) at
+ * eos_token (< 0: none) or at `cap` tokens; next_tok_d / next_cnt_d are the inputs of the next single-token forward. */
+int lmrl_gen_accept(const int32_t *sampled_d, uint8_t *active_d, int32_t *out_tokens_d /* [n][cap] */, int32_t *out_len_d,
+                    int32_t *next_tok_d, int32_t *next_cnt_d, int eos_token, int cap, int n, void *stream);
 /* Sample from materialised logits (temperature, top-k, top-p) with the same random stream. */
 int lmrl_sample_logits(const float *logits_d, int ld, int m, int vocab, const lmrl_sample_params *p,
                        const uint8_t *active_d, int32_t *token_d, float *logprob_d, void *stream);

@@ -91,6 +91,7 @@ _SIGS = {
     "lmrl_mc_loss_blocks": (c_int, [c_size_t]),
     "lmrl_mc_loss_nstats": (c_int, []),
     "lmrl_mc_loss": (c_int, [c_void_p] * 5 + [c_size_t, c_float] + [c_void_p] * 5),
+    "lmrl_gen_accept": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lmrl_sample_logits": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

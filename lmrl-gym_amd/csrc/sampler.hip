@@ -379,11 +379,39 @@ __global__ __launch_bounds__(256) void topk_sample_kernel(const float *__restric
     }
 }
 
+// ---- generic generation bookkeeping (any tokenizer / env): append the sampled token of every live sequence, stop a sequence
+// at eos or at `cap` tokens, and emit the next decode step's inputs — so a whole `generate` runs without a host sync.
+__global__ void gen_accept_kernel(const int32_t *__restrict__ sampled, uint8_t *__restrict__ active, int32_t *__restrict__ out_tokens,
+                                  int32_t *__restrict__ out_len, int32_t *__restrict__ next_tok, int32_t *__restrict__ next_cnt, int eos,
+                                  int cap, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    int cnt = 0;
+    if (active[e]) {
+        const int tok = sampled[e];
+        const int l = out_len[e];
+        out_tokens[(size_t)e * cap + l] = tok;
+        out_len[e] = l + 1;
+        if ((eos >= 0 && tok == eos) || l + 1 >= cap) active[e] = 0;
+        else { cnt = 1; next_tok[e] = tok; }
+    }
+    next_cnt[e] = cnt;
+}
+
 }  // namespace lmrl
 
 using namespace lmrl;
 
 extern "C" {
+
+int lmrl_gen_accept(const int32_t *sampled_d, uint8_t *active_d, int32_t *out_tokens_d, int32_t *out_len_d, int32_t *next_tok_d,
+                    int32_t *next_cnt_d, int eos_token, int cap, int n, void *stream) {
+    LMRL_REQUIRE(sampled_d && active_d && out_tokens_d && out_len_d && next_tok_d && next_cnt_d && cap > 0 && n > 0, "lmrl_gen_accept: bad argument");
+    hipLaunchKernelGGL(gen_accept_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), sampled_d, active_d, out_tokens_d, out_len_d,
+                       next_tok_d, next_cnt_d, eos_token, cap, n);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
 
 size_t lmrl_sample_ws_bytes(int m, int vocab_padded) {
     return (size_t)m * (size_t)(vocab_padded / kLmBN) * kPartialFloats * sizeof(float);

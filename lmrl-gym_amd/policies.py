@@ -98,27 +98,31 @@ class GPT2PPOPolicy(BatchedTextPolicy):
         gen = self._gen
         gen.prefill(prompts)
         self.calls += 1                                     # one random stream per act() call, like the per-call key split
-        active = np.array([not d for d in done], dtype=bool)
-        out_ids: List[List[int]] = [[] for _ in range(B)]
+        # Generation loop without a host sync per token: live flags, the generated ids and the next decode inputs stay on the
+        # device (`lmrl_gen_accept`); the host only peeks at the live flags every `sync_every` tokens to stop early.
+        L = _lib.lib()
+        cap = self.max_new_tokens
+        active_d = torch.from_numpy(np.array([not d for d in done], dtype=np.uint8)).to(gen.dev)
+        out_tok = torch.zeros((B, cap), dtype=torch.int32, device=gen.dev)
+        out_len = torch.zeros(B, dtype=torch.int32, device=gen.dev)
+        next_tok = torch.zeros(B, dtype=torch.int32, device=gen.dev)
+        next_cnt = torch.zeros(B, dtype=torch.int32, device=gen.dev)
         logits_out = None
         if self.top_k > 0 or self.top_p > 0.0:
             logits_out = torch.empty(B, self.engine.cfg.vocab_padded, dtype=torch.float32, device=gen.dev)
-        for k in range(self.max_new_tokens):
-            if not active.any():
+        sync_every = 16
+        for k in range(cap):
+            if k % sync_every == 0 and k > 0 and not bool(active_d.any().item()):
                 break
             p = SampleParams(self.temperature, self.top_k, self.seed + (self.calls << 20), k, 0.0, 0.0, self.pad, None, self.top_p)
-            active_d = torch.from_numpy(active.astype(np.uint8)).to(gen.dev)
             tok, _ = self._sample(gen, p, active_d, logits_out)
-            tok = tok.cpu().numpy()
-            step_active = active.copy()
-            for b in range(B):
-                if active[b]:
-                    out_ids[b].append(int(tok[b]))
-                    if self.eos is not None and tok[b] == self.eos:
-                        active[b] = False
-            nxt = active & step_active
-            if k + 1 < self.max_new_tokens and nxt.any():
-                gen.decode_step(np.where(nxt, tok, 0), nxt)
+            _lib.check(L.lmrl_gen_accept(_lib.ptr(tok), _lib.ptr(active_d), _lib.ptr(out_tok), _lib.ptr(out_len), _lib.ptr(next_tok),
+                                         _lib.ptr(next_cnt), -1 if self.eos is None else int(self.eos), cap, B, _lib.stream_ptr()), "lmrl_gen_accept")
+            if k + 1 < cap:
+                for s_ in gen.sessions:
+                    s_.forward(next_tok, next_cnt, 1)
+        ot, ol = out_tok.cpu().numpy(), out_len.cpu().numpy()
+        out_ids: List[List[int]] = [ot[b, : ol[b]].tolist() for b in range(B)]
         results: List[Optional[TextHistory]] = []
         for h, d, ids in zip(text_history, done, out_ids):
             if d:
