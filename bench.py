@@ -252,6 +252,17 @@ def main():
         roofline["algorithmic_bytes_per_launch"] = round(work.value / max(n.value, 1))
     except Exception:
         roofline["traffic"] = None
+    # the committed rocprofv3 --kernel-trace --stats summary of this same command, for cross-checking the live event figure
+    # (events bracket the launch on the stream and therefore include the dispatch gap, ~3 us, that rocprof's kernel
+    # begin/end timestamps do not)
+    try:
+        import csv
+        prof = os.path.join(ROOT, "profiles", "r01h_bench_kernel_stats.csv")
+        row = next(r for r in csv.DictReader(open(prof)) if "attention_kernel<1>" in r["Name"])
+        roofline["rocprofv3_avg_launch_us"] = round(float(row["AverageNs"]) / 1e3, 2)
+        roofline["rocprofv3_summary"] = "profiles/r01h_bench_kernel_stats.csv"
+    except Exception:
+        pass
     # other kernel classes: one extra, untimed episode with their brackets on (brackets cost ~2 us per launch)
     L.lmrl_prof_reset()
     mask = 0
