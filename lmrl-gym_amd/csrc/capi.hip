@@ -40,6 +40,15 @@ void prof_begin(int tag, hipStream_t s, double work) {
     g_recs.push_back(r);
     g_open[tag].push_back(g_recs.size() - 1);
 }
+bool prof_kernel_events(int tag, double work, hipEvent_t *start, hipEvent_t *stop) {
+    if (!((g_prof_mask >> tag) & 1u)) return false;
+    ProfRec r;
+    r.tag = tag; r.work = work;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return false;
+    g_recs.push_back(r);
+    *start = r.a; *stop = r.b;
+    return true;
+}
 void prof_end(int tag, hipStream_t s) {
     if (g_open[tag].empty()) return;
     const size_t i = g_open[tag].back();

@@ -41,6 +41,9 @@ enum ProfTag {
 extern unsigned g_prof_mask;
 void prof_begin(int tag, hipStream_t s, double work);
 void prof_end(int tag, hipStream_t s);
+// a start/stop event pair for hipExtLaunchKernelGGL (timestamps the kernel itself, like rocprofv3's kernel trace, instead of
+// bracketing the launch on the stream); false when the tag is disabled
+bool prof_kernel_events(int tag, double work, hipEvent_t *start, hipEvent_t *stop);
 // device counter (bytes) for kernels whose algorithmic traffic is data dependent; null unless the tag is enabled
 unsigned long long *prof_byte_counter(int tag);
 struct ProfScope {

@@ -21,6 +21,7 @@
 //                       both K-major for the MFMA operand loads (gemm_bf16.h)
 #include "../../include/lmrl_amd.h"
 #include "common.h"
+#include <hip/hip_ext.h>
 #include "gemm_bf16.h"
 
 namespace lmrl {
@@ -769,8 +770,13 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
             GemmArgs g{w.h, L.w_qkv, L.b_qkv, w.qkv, M, 3 * d, d, d, 3 * d, 3 * d};
             LMRL_CHECK_HIP(gemm_launch<EPI_BF16>(g, s));
         }
-        {
         // algorithmic bytes: K+V rows read once (2 * 128 B per cached position per head) + q/k/v/out rows of the chunk
+        hipEvent_t ev_a, ev_b;
+        if (c == 1 && prof_kernel_events(PROF_ATTN_DECODE, -1.0, &ev_a, &ev_b)) {
+            // the roofline kernel: start/stop events attached to the dispatch itself (kernel begin -> end, as rocprofv3 reports it)
+            hipExtLaunchKernelGGL(attention_kernel<1>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, ev_a, ev_b, 0, (const uint16_t *)w.qkv, kc, vc,
+                                  cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d);
+        } else {
         ProfScope ps(c == 1 ? PROF_ATTN_DECODE : PROF_ATTN_CHUNK, s, -1.0);
         if (c == 1) hipLaunchKernelGGL(attention_kernel<1>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
         else if (g_attn_variant == 1) hipLaunchKernelGGL(attention_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
