@@ -353,6 +353,45 @@ def setup_maze_env(maze_name, describe_function, reward_function=None, last_k=1,
                    reward_function=reward_function, last_k=last_k)
 
 
+def update_position(maze: np.ndarray, position: Tuple[int, int], action: str, actions: Dict[str, Tuple[int, int]] = manhatten_actions
+                    ) -> Tuple[int, int]:
+    """maze/env/env.py:104-107 (host face of the move the device kernel applies)."""
+    if action in actions and maze[position[0] + actions[action][0], position[1] + actions[action][1]] == 0:
+        return (position[0] + actions[action][0], position[1] + actions[action][1])
+    return tuple(position)
+
+
+def double_t_maze_optimal_directions() -> Dict[Tuple[int, int], str]:
+    """The cell -> optimal move table of maze/env/mazes.py:20-48, derived with `maze_solver` (tests pin it to the
+    reference's table through tests/golden/maze_traces.json)."""
+    sol = maze_solver(1 - double_t_maze(), [(8, 6)])
+    return {k: v for k, v in sol.items() if k != (8, 6)}
+
+
+def compute_move_accuracy(policy, reranker: bool = False, verbose: bool = False) -> float:
+    """maze/env/maze_utils.py:63-89: percentage of free cells of the double-T maze (goal (8, 6)) where the policy's action
+    for `describe_observation_give_position` is the optimal move.  Batched policies get all cells in ONE `act` call
+    instead of the reference's per-cell loop (same observations, same answers)."""
+    maze, goal = double_t_maze(), (8, 6)
+    answers = double_t_maze_optimal_directions()
+    positions = [tuple(p) for p in np.argwhere(maze == 0).tolist()]
+    hists = [(Text(describe_observation_give_position(maze, pos, goal), False),) for pos in positions]
+    if reranker:
+        preds = [policy.act(h)[-1].text for h in hists]
+    else:
+        outs = policy.act(list(hists), done=[False] * len(hists))
+        preds = [o[-1].text for o in outs]
+    n_ok = 0
+    for pos, pred in zip(positions, preds):
+        if pos == goal:
+            continue
+        ok = pred == answers[pos]
+        n_ok += int(ok)
+        if verbose:
+            print("correct!" if ok else "incorrect!", pos, repr(pred), repr(answers[pos]))
+    return n_ok / (len(positions) - 1) * 100
+
+
 def pick_start_position(maze_name):
     if maze_name == "umaze":
         return (3, 1)

@@ -264,3 +264,33 @@ def test_wordle_token_table_roundtrip():
     assert len(set(allids)) == len(allids)
     cls = t.token_class(50257)
     assert cls[t.letter_sp[4]] == (4 | 1 << 25) and cls[12345] == 7 << 25
+
+
+def test_maze_move_accuracy_and_optimal_table():
+    """compute_move_accuracy (maze_utils.py:63-89) and the optimal-direction table vs the reference's own known answers."""
+    import re
+    from conftest import load_golden
+    from lmrl_gym_amd.envs import maze as M
+    from lmrl_gym_amd.environment import Text
+    ref = {tuple(k): v for k, v in load_golden("maze_traces.json")["double_t_maze_optimal_directions"]}
+    tab = M.double_t_maze_optimal_directions()
+    assert tab == ref
+    assert M.update_position(M.double_t_maze(), (1, 1), "move right\n") == (1, 2)
+    assert M.update_position(M.double_t_maze(), (1, 1), "move up\n") == (1, 1) and M.update_position(M.double_t_maze(), (1, 1), "jump\n") == (1, 1)
+
+    class Perfect:                      # BatchedTextPolicy face
+        def __init__(self, wrong_rows=()):
+            self.wrong_rows = wrong_rows
+
+        def act(self, hs, done=None):
+            out = []
+            for h in hs:
+                m = re.findall(r"(\d+), (\d+)", h[0].text)
+                pos = (int(m[-1][0]), int(m[-1][1]))
+                a = "move up\n" if pos[0] in self.wrong_rows else tab.get(pos, "move up\n")
+                out.append(h + (Text(a, True),))
+            return out
+
+    assert M.compute_move_accuracy(Perfect()) == 100.0
+    n_row1 = sum(1 for p in tab if p[0] == 1)
+    assert abs(M.compute_move_accuracy(Perfect(wrong_rows=(1,))) - (len(tab) - n_row1) / len(tab) * 100) < 1e-9
