@@ -284,9 +284,10 @@ def test_maze_move_accuracy_and_optimal_table():
 
         def act(self, hs, done=None):
             out = []
+            maze = M.double_t_maze()
+            by_obs = {M.describe_observation_give_position(maze, tuple(p), (8, 6)): tuple(p) for p in np.argwhere(maze == 0).tolist()}
             for h in hs:
-                m = re.findall(r"(\d+), (\d+)", h[0].text)
-                pos = (int(m[-1][0]), int(m[-1][1]))
+                pos = by_obs[h[0].text]
                 a = "move up\n" if pos[0] in self.wrong_rows else tab.get(pos, "move up\n")
                 out.append(h + (Text(a, True),))
             return out
