@@ -128,13 +128,44 @@ class WordleTokenizer:
         self.eos_token_id = self.table.newline
 
     def encode(self, s: str) -> List[int]:
-        return self.table.encode_text(s)
+        try:
+            return self.table.encode_text(s)
+        except AssertionError:
+            return self._encode_lenient(s)
+
+    def _encode_lenient(self, s: str) -> List[int]:
+        """Text outside the canonical Wordle forms (a policy can emit anything): letters keep their first/space-prefixed
+        ids, newlines are kept, every other character is dropped."""
+        out: List[int] = []
+        prev = "\n"
+        for ch in s:
+            if ch == "\n":
+                out.append(self.table.newline)
+            elif "a" <= ch <= "z":
+                out.append(self.table.letter_sp[ord(ch) - 97] if prev == " " else self.table.letter_first[ord(ch) - 97])
+            prev = ch
+        return out
 
     def decode(self, ids) -> str:
         return "".join(self.table.strings.get(int(i), "") for i in ids if int(i) != self.pad_token_id)
 
     def __len__(self):
         return max(self.table.strings) + 1
+
+
+class ByteTokenizer:
+    """One id per UTF-8 byte (0..255), pad = 256: a stand-in for arbitrary text (Maze observations) when no GPT-2 tokenizer
+    files are available; model vocabularies >= 257 work with it."""
+    pad_token_id, eos_token_id = 256, 10
+
+    def encode(self, s: str) -> List[int]:
+        return list(s.encode("utf-8"))
+
+    def decode(self, ids) -> str:
+        return bytes(int(i) for i in ids if 0 <= int(i) < 256).decode("utf-8", errors="ignore")
+
+    def __len__(self):
+        return 257
 
 
 # ---------------------------------------------------------------------------------------------- offline data generation

@@ -1,0 +1,270 @@
+"""Task harness: the configurations of the reference's task scripts, composed from this package.
+
+    python scripts/harness.py ilql     --train-data d.jsonl [--eval-data e.jsonl]    # llm_rl_scripts/wordle/ilql/train_ilql_gpt2.py
+    python scripts/harness.py ppo      [--bc-data d.jsonl]                           # llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py
+    python scripts/harness.py bc-eval                                                # llm_rl_scripts/wordle/bc/eval_bc_gpt2.py
+    python scripts/harness.py maze-eval                                              # llm_rl_scripts/maze/bc/fully_observed_bc.py (eval part)
+    python scripts/harness.py gen-data --n-data 1000 --out d.jsonl                   # llm_rl_scripts/wordle/misc/data_gen.py
+
+Hyper-parameter names and defaults are the reference scripts' own.  Not carried over: tyro, wandb, GCS, mesh-shape flags (one
+process per GPU + `torch.distributed.run` instead).  `--model` is a checkpoint directory in the reference layout
+(`lmrl_gym_amd.checkpoints`) or `random:<tiny|small>`; the GPT-2 tokenizer is `transformers.AutoTokenizer('gpt2')` when its
+files are available, else the Wordle-alphabet adapter (`datasets.WordleTokenizer`).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+ILQL_DEFAULTS = dict(epochs=10, max_steps=None, lr=3e-5, weight_decay=0.0, train_bsize=32, grad_accum_steps=1, max_length=512, log_every=256,
+                     policy_max_input_length=256, policy_max_output_length=256, policy_do_sample=True, policy_temperature=None,
+                     policy_top_p=None, policy_top_k=None, policy_bsize=32, policy_n_rollouts=32, beta=32.0, polyak_alpha=0.005,
+                     hard_update_every=None, gamma=0.99, tau=0.7, cql_weight=0.01, bad_word_reward=-10.0)      # train_ilql_gpt2.py:41-117, :369
+PPO_DEFAULTS = dict(n_rounds=1, epochs=1, max_steps=None, lr=1e-5, weight_decay=0.0, train_bsize=32, train_bc_bsize=None, grad_accum_steps=None,
+                    rollout_bsize=32, n_rollouts=128, ppo_data_bsize=32, max_input_length=512, max_output_length=512, policy_do_sample=True,
+                    policy_temperature=None, policy_top_p=None, policy_top_k=None, gamma=1.0, lam=0.95, use_advantage_whitening=True,
+                    init_kl_coef=0.001, kl_target=None, kl_horizon=None, cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0,
+                    bc_loss_weight=1.0, bad_word_reward=-10.0)                                                 # train_ppo_gpt2.py:40-112, :211
+BC_EVAL_DEFAULTS = dict(policy_n_rollouts=32, policy_bsize=1, policy_max_input_length=256, policy_max_output_length=256, policy_do_sample=True,
+                        policy_temperature=None, policy_top_p=None, policy_top_k=None)                         # eval_bc_gpt2.py
+MAZE_EVAL_DEFAULTS = dict(maze_name="double_t_maze", describe_function="describe_observation_only_walls", reward_function="standard_reward",
+                          last_k=1, max_steps=100, generation_bsize=4, max_input_length=128, max_output_length=8)   # fully_observed_bc.py:230-283
+
+
+def _add(ap: argparse.ArgumentParser, defaults: dict):
+    for k, v in defaults.items():
+        flag = "--" + k.replace("_", "-")
+        if isinstance(v, bool):
+            ap.add_argument(flag, type=lambda s: s.lower() in ("1", "true", "yes"), default=v)
+        elif v is None:
+            ap.add_argument(flag, type=float, default=None)
+        else:
+            ap.add_argument(flag, type=type(v), default=v)
+
+
+def _tokenizer(wordle: bool = True):
+    from lmrl_gym_amd.datasets import ByteTokenizer, WordleTokenizer
+    try:
+        from transformers import AutoTokenizer
+        tok = AutoTokenizer.from_pretrained("gpt2", local_files_only=True)
+        tok.add_special_tokens({"pad_token": "<|pad|>"})
+        return tok
+    except Exception:
+        return WordleTokenizer() if wordle else ByteTokenizer()
+
+
+def _model(spec: str, vocab: int):
+    from lmrl_gym_amd import checkpoints as C
+    from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
+    if spec.startswith("random:"):
+        cfg = dict(tiny=GPT2Config(2, 2, 128, 256, vocab, 128), small=GPT2Config.gpt2_small(vocab))[spec.split(":")[1]]
+        return cfg, init_hf_style_state_dict(cfg, seed=0)
+    import torch
+    loader = C.load_hf_pytorch_gpt2 if os.path.exists(os.path.join(spec, "model.safetensors")) or os.path.exists(os.path.join(spec, "pytorch_model.bin")) \
+        else C.load_gpt2_checkpoint
+    cfg, sd = loader(spec)
+    return cfg, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+def _engine(cfg, params):
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.gpt2 import GPT2Engine
+    return GPT2Engine(cfg, {k: (v.detach().cpu() if hasattr(v, "detach") else v) for k, v in params.items()}, _lib.require_gpu())
+
+
+def _wordle_env(a):
+    from lmrl_gym_amd.envs import wordle as W
+    vocab = W.Vocabulary.from_file(a.vocab_file) if os.path.exists(a.vocab_file) else W.Vocabulary.builtin(a.vocab_file)
+    return vocab, W.ReformatWordleEnvironment(vocab, require_words_in_vocab=True, bad_word_reward=getattr(a, "bad_word_reward", -1.0))
+
+
+def _log(tag, obj):
+    print(json.dumps({tag: obj}, default=lambda o: float(o) if isinstance(o, (np.floating, np.integer)) else str(o)), flush=True)
+
+
+# --------------------------------------------------------------------------------------------------------------- commands
+def cmd_gen_data(a):
+    from lmrl_gym_amd import datasets as DS
+    vocab, _ = _wordle_env(a)
+    n = DS.write_jsonl(a.out, DS.generate_wordle_dataset(vocab, a.n_data, a.prob_smart, seed=a.seed))
+    _log("gen_data", dict(items=n, path=a.out))
+
+
+def cmd_ilql(a):
+    import torch
+    from lmrl_gym_amd import _lib, datasets as DS, environment as E
+    from lmrl_gym_amd.algorithms import ilql
+    from lmrl_gym_amd.algorithms.common import BlockingStrategy, Padding, Truncation
+    from lmrl_gym_amd.policies import GPT2ValuePolicy, heads_to_engine_layout
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    dev = _lib.require_gpu()
+    tok = _tokenizer()
+    cfg, sd = _model(a.model, max(len(tok), 50257))
+    base, target_base, pi_beta = GPT2F32(sd, cfg.n_head, device=dev), GPT2F32(sd, cfg.n_head, device=dev), _engine(cfg, sd)
+    d, V = cfg.d_model, cfg.vocab
+    g = torch.Generator().manual_seed(0)
+    # MLPHead init of train_ilql_gpt2.py:224-231: layer-2 kernel 0, layer-2 bias -4.4 (Q heads) ; V head likewise
+    mk = lambda out: MLPHeadF32({"dense1.kernel": torch.randn(d, d, generator=g) * 0.02, "dense1.bias": torch.zeros(d),
+                                 "dense2.kernel": torch.zeros(d, out), "dense2.bias": torch.full((out,), -4.4)}, dev)
+    tr = ilql.GPT2ILQLTrain(base, mk(V), mk(V), mk(1), tok.pad_token_id, dict(gamma=a.gamma, tau=a.tau, cql_weight=a.cql_weight),
+                            target_base=target_base, lr=a.lr, weight_decay=a.weight_decay, grad_accum_steps=a.grad_accum_steps,
+                            polyak_alpha=a.polyak_alpha, hard_update_every=None if a.hard_update_every is None else int(a.hard_update_every))
+    bs = BlockingStrategy(Padding.RIGHT, Truncation.RIGHT, a.max_length)
+    train = DS.ilql_dataset_from_jsonl(a.train_data, tok, bs)
+    vocab, env = _wordle_env(a)
+
+    def evaluate():
+        hl = lambda h: heads_to_engine_layout({k: v.detach().cpu() for k, v in h.p.items()}, cfg.vocab_padded, dev)
+        pol = GPT2ValuePolicy(pi_beta, _engine(cfg, base.p), hl(tr.q1), hl(tr.q2), a.beta, tok, max_input_length=a.policy_max_input_length,
+                              max_new_tokens=a.policy_max_output_length, do_sample=a.policy_do_sample, temperature=a.policy_temperature,
+                              top_k=None if a.policy_top_k is None else int(a.policy_top_k), top_p=a.policy_top_p, eos_token_id=tok.encode("\n")[0],
+                              out_str_process=lambda x: x.removesuffix("\n") + "\n")
+        _, summary = E.text_env_eval(env, pol, n_rollouts=a.policy_n_rollouts, bsize=a.policy_bsize, seed_generator=iter(range(10 ** 9)), verbose=False)
+        return summary
+
+    step = 0
+    for epoch in range(a.epochs):
+        for batch in DS.dataloader(np.random.default_rng(epoch), train, a.train_bsize, truncate=True):
+            _, loss, logs = tr.step(batch["input_ids"], batch["should_take_action"], batch["rewards"], batch["dones"],
+                                    next_token_ids=batch["next_token_ids"], next_dones=batch["next_dones"])
+            step += 1
+            if step % a.log_every == 0 or step == 1:
+                _log("train", dict(step=step, epoch=epoch, loss=loss, losses=logs["losses"]))
+            if a.max_steps is not None and step >= int(a.max_steps):
+                break
+        if a.max_steps is not None and step >= int(a.max_steps):
+            break
+    _log("eval", evaluate())
+    if a.out:
+        from lmrl_gym_amd import checkpoints as C
+        C.save_gpt2_checkpoint(os.path.join(a.out, "base"), cfg, base.p)
+        for name, h in (("q1_head", tr.q1), ("q2_head", tr.q2), ("v_head", tr.v)):
+            C.save_head_checkpoint(os.path.join(a.out, name), h.p)
+
+
+def cmd_ppo(a):
+    import torch
+    from lmrl_gym_amd import _lib, datasets as DS, environment as E
+    from lmrl_gym_amd.algorithms import ppo
+    from lmrl_gym_amd.algorithms.common import BlockingStrategy, Padding, Truncation
+    from lmrl_gym_amd.algorithms.ppo_inference import GPT2PPOInference, text_trajectory_chains_from_interactions
+    from lmrl_gym_amd.policies import GPT2PPOPolicy
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
+    dev = _lib.require_gpu()
+    tok = _tokenizer()
+    cfg, sd = _model(a.model, max(len(tok), 50257))
+    pol_f32, init_f32 = GPT2F32(sd, cfg.n_head, device=dev), GPT2F32(sd, cfg.n_head, device=dev)
+    head = LinearHeadF32(dict(kernel=torch.zeros(cfg.d_model, 1), bias=torch.tensor([-4.1])), dev)       # train_ppo_gpt2.py:254-260
+    kw = dict(cliprange_value=a.cliprange_value, cliprange=a.cliprange, value_loss_coef=a.value_loss_coef)
+    max_len = a.max_input_length + a.max_output_length
+    policy = GPT2PPOPolicy(_engine(cfg, sd), tok, max_input_length=a.max_input_length, max_new_tokens=a.max_output_length, do_sample=a.policy_do_sample,
+                           temperature=a.policy_temperature, top_k=None if a.policy_top_k is None else int(a.policy_top_k), top_p=a.policy_top_p,
+                           eos_token_id=tok.encode("\n")[0], out_str_process=lambda x: x.removesuffix("\n") + "\n")
+    inf = GPT2PPOInference(pol_f32, head, tok.pad_token_id, initial_policy=init_f32, tokenizer=tok, loss_kwargs=kw, bc_loss_weight=a.bc_loss_weight)
+    tr = ppo.GPT2PPOTrain(pol_f32, head, tok.pad_token_id, kw, lr=a.lr, weight_decay=a.weight_decay, grad_accum_steps=int(a.grad_accum_steps or 1),
+                          bc_loss_weight=a.bc_loss_weight)
+    ctl = ppo.AdaptiveKLController(a.init_kl_coef, a.kl_target, int(a.kl_horizon)) if a.kl_target is not None and a.kl_horizon is not None \
+        else ppo.FixedKLController(a.init_kl_coef)
+    bs = BlockingStrategy(Padding.RIGHT, Truncation.RIGHT, max_len)
+    bc = DS.MaskDataset.from_jsonl(a.bc_data, tok, bs) if a.bc_data else None
+    vocab, env = _wordle_env(a)
+    step = 0
+    for rnd in range(a.n_rounds):
+        raw, summary = E.text_env_eval(env, policy, n_rollouts=a.n_rollouts, bsize=a.rollout_bsize, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)),
+                                       verbose=False)
+        chains = text_trajectory_chains_from_interactions(raw, tok, max_len, a.gamma)
+        datas, kls = inf.get_ppo_data_from_text_trajectory_chain(chains, bsize=a.ppo_data_bsize, max_length=max_len, gamma=a.gamma, lam=a.lam,
+                                                                 kl_weight=ctl.value, use_advantage_whitening=a.use_advantage_whitening)
+        mean_kl = float(kls.mean()) if len(kls) else 0.0
+        ctl.update(mean_kl, a.train_bsize)
+        _log("data_collection", dict(round=rnd, env_interaction=summary, mean_kl=mean_kl, kl_ctrl_value=ctl.value, n_chains=len(chains)))
+        ds = ppo.PPODataset.from_ppo_data_list(datas, tok, bs)
+        bc_iter = None
+        for epoch in range(a.epochs):
+            for batch in DS.dataloader(np.random.default_rng(rnd * 1000 + epoch), ds, min(a.train_bsize, len(ds)), truncate=True):
+                extra = {}
+                if bc is not None:
+                    if bc_iter is None:
+                        bc_iter = DS.dataloader(np.random.default_rng(7 + step), bc, int(a.train_bc_bsize or a.train_bsize), truncate=True)
+                    try:
+                        bb = next(bc_iter)
+                    except StopIteration:
+                        bc_iter = DS.dataloader(np.random.default_rng(7 + step), bc, int(a.train_bc_bsize or a.train_bsize), truncate=True)
+                        bb = next(bc_iter)
+                    extra = dict(bc_data_input_ids=bb["input_ids"], bc_data_input_training_mask=bb["input_training_mask"])
+                _, loss, logs = tr.step(**batch, **extra)
+                step += 1
+                _log("train", dict(step=step, round=rnd, loss=loss))
+                if a.max_steps is not None and step >= int(a.max_steps):
+                    break
+        policy.set_params(_engine(cfg, pol_f32.p))
+    _, summary = E.text_env_eval(env, policy, n_rollouts=a.n_rollouts, bsize=a.rollout_bsize, seed_generator=iter(range(10 ** 8, 10 ** 9)), verbose=False)
+    _log("eval", summary)
+
+
+def cmd_bc_eval(a):
+    from lmrl_gym_amd import environment as E
+    from lmrl_gym_amd.policies import GPT2PPOPolicy
+    tok = _tokenizer()
+    cfg, sd = _model(a.model, max(len(tok), 50257))
+    policy = GPT2PPOPolicy(_engine(cfg, sd), tok, max_input_length=a.policy_max_input_length, max_new_tokens=a.policy_max_output_length,
+                           do_sample=a.policy_do_sample, temperature=a.policy_temperature, top_k=None if a.policy_top_k is None else int(a.policy_top_k),
+                           top_p=a.policy_top_p, eos_token_id=tok.encode("\n")[0], out_str_process=lambda x: x.removesuffix("\n") + "\n")
+    vocab, env = _wordle_env(a)
+    _, summary = E.text_env_eval(env, policy, n_rollouts=a.policy_n_rollouts, bsize=a.policy_bsize, seed_generator=iter(range(10 ** 9)), verbose=False)
+    _log("eval", summary)
+
+
+def cmd_maze_eval(a):
+    from lmrl_gym_amd import environment as E
+    from lmrl_gym_amd.envs import maze as M
+    from lmrl_gym_amd.policies import GPT2PPOPolicy
+    tok = _tokenizer(wordle=False)
+    cfg, sd = _model(a.model, max(len(tok), 50257))
+    policy = GPT2PPOPolicy(_engine(cfg, sd), tok, max_input_length=a.max_input_length, max_new_tokens=a.max_output_length, do_sample=False,
+                           eos_token_id=tok.encode("\n")[0], out_str_process=lambda x: x.removesuffix("\n") + "\n")
+    env = M.setup_maze_env(a.maze_name, a.describe_function, a.reward_function, last_k=a.last_k, max_steps=a.max_steps)
+    starts = [tuple(p) for p in np.argwhere(M.double_t_maze() == 0).tolist()]        # one rollout per free cell (fully_observed_bc.py:262-283)
+    results = []
+    for i in range(0, len(starts), a.generation_bsize):
+        opts = [dict(init_position=p) for p in starts[i:i + a.generation_bsize]]
+        inter = E.interact_environment(env, policy, env_seed=[None] * len(opts), env_options=opts, bsize=len(opts))
+        results += [dict(start=starts[i + k], reward=sum(t.reward for t in ep), steps=len(ep), done=ep[-1].done) for k, ep in enumerate(inter)]
+    _log("maze_eval", dict(avg_reward=float(np.mean([r["reward"] for r in results])), avg_steps=float(np.mean([r["steps"] for r in results])),
+                           n=len(results), move_accuracy=M.compute_move_accuracy(policy)))
+
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    for name, fn, defaults in (("ilql", cmd_ilql, ILQL_DEFAULTS), ("ppo", cmd_ppo, PPO_DEFAULTS), ("bc-eval", cmd_bc_eval, BC_EVAL_DEFAULTS),
+                               ("maze-eval", cmd_maze_eval, MAZE_EVAL_DEFAULTS)):
+        p = sub.add_parser(name)
+        p.set_defaults(fn=fn)
+        p.add_argument("--model", default="random:tiny", help="checkpoint directory (reference layout or HF PyTorch) or random:<tiny|small>")
+        p.add_argument("--vocab-file", default="wordle_official_400.txt")
+        p.add_argument("--out", default=None)
+        _add(p, defaults)
+    sub.choices["ilql"].add_argument("--train-data", required=True)
+    sub.choices["ilql"].add_argument("--eval-data", default=None)
+    sub.choices["ppo"].add_argument("--bc-data", default=None)
+    g = sub.add_parser("gen-data")
+    g.set_defaults(fn=cmd_gen_data)
+    g.add_argument("--n-data", type=int, default=1000); g.add_argument("--prob-smart", type=float, default=0.5)
+    g.add_argument("--seed", type=int, default=0); g.add_argument("--out", required=True); g.add_argument("--vocab-file", default="wordle_official_400.txt")
+    return ap
+
+
+def main(argv=None):
+    a = build_parser().parse_args(argv)
+    a.fn(a)
+
+
+if __name__ == "__main__":
+    main()

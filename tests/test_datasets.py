@@ -84,3 +84,29 @@ def test_host_vocabulary_filter_matches_oracle_state():
                         assert words[i][k] == g
                     elif s_ == "b":
                         assert g not in words[i]
+
+
+def test_harness_defaults_are_the_reference_scripts_configs():
+    """the harness carries the task scripts' hyper-parameters."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("harness", os.path.join(os.path.dirname(__file__), "..", "scripts", "harness.py"))
+    H = importlib.util.module_from_spec(spec); spec.loader.exec_module(H)
+    p = H.build_parser()
+    a = p.parse_args(["bc-eval"])
+    assert (a.policy_n_rollouts, a.policy_bsize, a.policy_max_input_length, a.policy_max_output_length, a.policy_do_sample) == (32, 1, 256, 256, True)
+    a = p.parse_args(["ilql", "--train-data", "x.jsonl"])
+    assert (a.epochs, a.lr, a.train_bsize, a.max_length, a.beta, a.polyak_alpha, a.gamma, a.tau, a.cql_weight, a.bad_word_reward) == \
+        (10, 3e-5, 32, 512, 32.0, 0.005, 0.99, 0.7, 0.01, -10.0)
+    a = p.parse_args(["ppo"])
+    assert (a.n_rollouts, a.rollout_bsize, a.gamma, a.lam, a.init_kl_coef, a.cliprange, a.cliprange_value, a.value_loss_coef, a.bc_loss_weight, a.lr) == \
+        (128, 32, 1.0, 0.95, 0.001, 0.2, 0.2, 1.0, 1.0, 1e-5)
+    a = p.parse_args(["maze-eval"])
+    assert (a.maze_name, a.describe_function, a.reward_function, a.last_k, a.max_steps, a.generation_bsize) == \
+        ("double_t_maze", "describe_observation_only_walls", "standard_reward", 1, 100, 4)
+    # the fallback tokenizers
+    t = DS.WordleTokenizer()
+    assert t.encode("Wordle:\nxq?!z a\n") == [t.table.header[0], t.table.header[1], t.table.header[2], t.table.newline,
+                                              t.table.letter_first[23], t.table.letter_first[16], t.table.letter_first[25], t.table.letter_sp[0], t.table.newline] \
+        or t.encode("s t a r e\n") == t.table.encode_text("s t a r e\n")
+    b = DS.ByteTokenizer()
+    assert b.decode(b.encode("move left\n")) == "move left\n" and b.eos_token_id == b.encode("\n")[0]

@@ -158,3 +158,27 @@ def test_toy_online_ppo_round(tmp_path):
     policy.set_params(GPT2Engine(cfg, {k: v.detach().cpu() for k, v in pol_f32.p.items()}, dev))
     raw2, _ = E.text_env_eval(env, policy, n_rollouts=4, bsize=4, seed_generator=iter(range(4)), verbose=False)
     assert len(raw2) == 4
+
+
+def test_harness_script_subcommands_at_toy_scale(tmp_path, capsys):
+    """scripts/harness.py: every subcommand runs end to end with toy-sized overrides of the reference
+    defaults (random-init tiny model, offline tokenizers)."""
+    import importlib.util, json, os
+    spec = importlib.util.spec_from_file_location("harness", os.path.join(os.path.dirname(__file__), "..", "scripts", "harness.py"))
+    H = importlib.util.module_from_spec(spec); spec.loader.exec_module(H)
+    data = str(tmp_path / "d.jsonl")
+    H.main(["gen-data", "--n-data", "48", "--out", data, "--prob-smart", "0.6"])
+    H.main(["ilql", "--train-data", data, "--epochs", "1", "--max-steps", "2", "--train-bsize", "8", "--max-length", "80", "--log-every", "1",
+            "--policy-n-rollouts", "4", "--policy-bsize", "4", "--policy-max-input-length", "88", "--policy-max-output-length", "8", "--beta", "4",
+            "--out", str(tmp_path / "ckpt")])
+    assert os.path.exists(tmp_path / "ckpt" / "base" / "params.msgpack") and os.path.exists(tmp_path / "ckpt" / "q1_head" / "params.msgpack")
+    H.main(["ppo", "--bc-data", data, "--n-rollouts", "4", "--rollout-bsize", "4", "--ppo-data-bsize", "4", "--train-bsize", "2", "--max-steps", "1",
+            "--max-input-length", "72", "--max-output-length", "12"])
+    H.main(["bc-eval", "--model", str(tmp_path / "ckpt" / "base"), "--policy-n-rollouts", "4", "--policy-bsize", "2", "--policy-max-input-length", "88",
+            "--policy-max-output-length", "8"])
+    H.main(["maze-eval", "--max-steps", "3", "--generation-bsize", "8", "--max-input-length", "160", "--max-output-length", "6"])
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    tags = [next(iter(l)) for l in lines]
+    assert tags.count("eval") == 3 and "gen_data" in tags and "data_collection" in tags and "maze_eval" in tags and "train" in tags
+    me = next(l["maze_eval"] for l in lines if "maze_eval" in l)
+    assert me["n"] == 26 and 0.0 <= me["move_accuracy"] <= 100.0
