@@ -46,36 +46,6 @@ struct Gpt2Model {
     Gpt2Layer *layers;
 };
 
-// ------------------------------------------------------------------------------------------ embedding
-// x[r][:] = wte[token][:] + wpe[pos][:]   (one wave per row, 16 B loads)
-__global__ __launch_bounds__(256) void embed_kernel(const uint16_t *__restrict__ wte, const uint16_t *__restrict__ wpe,
-                                                    const int32_t *__restrict__ tokens, const int32_t *__restrict__ cnt,
-                                                    const int32_t *__restrict__ len, float *__restrict__ x, int B, int C, int d,
-                                                    int vocab, int n_pos) {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (r >= B * C) return;
-    const int b = r / C, j = r - b * C;
-    int tok = tokens[r];
-    int pos = len[b] + j;
-    const bool valid = j < cnt[b];
-    if (!valid || tok < 0 || tok >= vocab) tok = 0;
-    if (!valid || pos >= n_pos) pos = 0;
-    const uint16_t *te = wte + (size_t)tok * d, *pe = wpe + (size_t)pos * d;
-    float *xr = x + (size_t)r * d;
-    for (int c = lane * 8; c < d; c += 64 * 8) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(te + c), p = *reinterpret_cast<const uint4 *>(pe + c);
-        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, pw[4] = {p.x, p.y, p.z, p.w};
-        float o[8];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            o[2 * k] = bf16_to_f32((uint16_t)(aw[k] & 0xffff)) + bf16_to_f32((uint16_t)(pw[k] & 0xffff));
-            o[2 * k + 1] = bf16_to_f32((uint16_t)(aw[k] >> 16)) + bf16_to_f32((uint16_t)(pw[k] >> 16));
-        }
-        *reinterpret_cast<f32x4 *>(xr + c) = f32x4{o[0], o[1], o[2], o[3]};
-        *reinterpret_cast<f32x4 *>(xr + c + 4) = f32x4{o[4], o[5], o[6], o[7]};
-    }
-}
-
 // ------------------------------------------------------------------------------------------ layernorm
 // y[r][:] (bf16) = (x[r][:] - mean) * rsqrt(var + eps) * g + b ; one wave per row; d <= 64*4*MAXV.
 // `rows_idx` (optional) gathers source rows (used for the final LN over each env's last token only).
@@ -259,7 +229,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const uint16_t *__restric
     }
 }
 
-// final LayerNorm of each env's LAST new token + len[b] += cnt[b] (replaces advance_kernel + gathered layernorm)
+// final LayerNorm of each env's LAST new token + len[b] += cnt[b] (one launch: the gather, the LayerNorm and the cache-length advance)
 template <int MAXV>
 __global__ __launch_bounds__(256) void final_ln_advance_kernel(const float *__restrict__ x, const float *__restrict__ gam,
                                                                const float *__restrict__ bet, uint16_t *__restrict__ y,
@@ -615,15 +585,6 @@ __global__ void attn_bytes_kernel(const int32_t *cnt, const int32_t *len, int B,
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(counter, (red[0] + red[1] + red[2] + red[3]) * (unsigned long long)heads_x_layers);
-}
-
-// rows_idx[b] = row of env b's last new token (or -1), then len[b] += cnt[b]
-__global__ void advance_kernel(const int32_t *cnt, int32_t *len, int32_t *rows_idx, int B, int C) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const int n = min(cnt[b], C);
-    rows_idx[b] = n > 0 ? b * C + n - 1 : -1;
-    if (n > 0) len[b] += n;
 }
 
 int g_gemm_variant = 0;

@@ -46,13 +46,6 @@ class _Generator:
             for s in self.sessions:
                 s.forward(td, cd, 8)
 
-    def decode_step(self, tokens: np.ndarray, active: np.ndarray):
-        t = self.t
-        td = t.from_numpy(tokens.astype(np.int32)).to(self.dev)
-        cd = t.from_numpy(active.astype(np.int32)).to(self.dev)
-        for s in self.sessions:
-            s.forward(td, cd, 1)
-
 
 class GPT2PPOPolicy(BatchedTextPolicy):
     def __init__(self, engine: GPT2Engine, tokenizer, max_input_length: int = 256, max_new_tokens: int = 256, do_sample: bool = True,
