@@ -98,6 +98,37 @@ def test_gpt2_forward_kv_cache(dev, cfgname, ln_fusion):
     assert err < 1.5e-2, float(err)
 
 
+def test_gpt2_small_full_depth_vs_oracle(dev):
+    """The BASELINE configuration's model (GPT-2-small: 12 layers, d = 768, V = 50257): final hidden states and greedy tokens of
+    the bf16 engine against the float64 oracle on the same bf16-rounded weights, through chunked prefill + decode steps."""
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, SampleParams, init_hf_style_state_dict
+    from oracle import gpt2 as O
+    cfg = GPT2Config.gpt2_small()
+    sd = O.round_weights_to_bf16(init_hf_style_state_dict(cfg, seed=0))
+    sd["wte.weight"] = (sd["wte.weight"] * 4).to(torch.bfloat16).float()        # wider logit margins for the argmax comparison
+    eng = GPT2Engine(cfg, sd, dev)
+    B, T = 3, 21
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, cfg.vocab, (B, T), generator=g)
+    ref_logits, ref_hid = O.forward(sd, ids, cfg.n_head, dtype=torch.float64, return_hidden=True)
+    ses = eng.session(B, 32)
+    pos = 0
+    for C, n in [(8, 8), (8, 8), (1, 1), (1, 1), (1, 1), (1, 1), (1, 1)]:
+        toks = torch.zeros(B, C, dtype=torch.int32)
+        toks[:, :n] = ids[:, pos:pos + n]
+        last = ses.forward(toks.reshape(-1).to(dev), torch.full((B,), n, dtype=torch.int32, device=dev), C).float().cpu()
+        pos += n
+        ref = ref_hid[:, pos - 1]
+        err = (last.double() - ref).norm() / ref.norm()
+        assert err < 2e-2, (pos, float(err))
+        tok, _ = ses.sample(SampleParams(0.0, 0, 0, 0, 0.0, 0.0, 0))
+        top2 = ref_logits[:, pos - 1, : cfg.vocab].topk(2, dim=-1)
+        for b in range(B):
+            if float(top2.values[b, 0] - top2.values[b, 1]) > 0.25:
+                assert int(tok[b]) == int(top2.indices[b, 0]), (pos, b)
+    assert pos == T
+
+
 # ------------------------------------------------------------------ fused LM head + sampler
 def _engine_and_hidden(dev, B, vocab=5003, d=128):
     from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
