@@ -182,3 +182,39 @@ def test_harness_script_subcommands_at_toy_scale(tmp_path, capsys):
     assert tags.count("eval") == 3 and "gen_data" in tags and "data_collection" in tags and "maze_eval" in tags and "train" in tags
     me = next(l["maze_eval"] for l in lines if "maze_eval" in l)
     assert me["n"] == 26 and 0.0 <= me["move_accuracy"] <= 100.0
+
+
+def test_reference_style_code_through_compat_imports():
+    """Code written against the reference's import paths (compat/) runs on the HIP env and reproduces the oracle env."""
+    import os, sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "compat"))
+    sys.path.insert(0, root)
+    try:
+        from LLM_RL.environment import Text, TextPolicy, text_env_eval
+        from llm_rl_scripts.wordle.env.env import ReformatWordleEnvironment, WordleEnvironment
+        from llm_rl_scripts.wordle.env.game import Vocabulary
+        from lmrl_gym_amd.envs.wordle import Vocabulary as V2
+        from oracle.wordle import OracleWordleEnv
+        vocab = V2.builtin("wordle_official_400.txt")
+        assert Vocabulary is V2
+        env = ReformatWordleEnvironment(WordleEnvironment(vocab, require_words_in_vocab=True, bad_word_reward=-10.0))
+
+        class Scripted(TextPolicy):
+            def __init__(self):
+                self.rng = np.random.RandomState(0)
+
+            def act(self, text_history):
+                return text_history + (Text(" ".join(vocab.all_vocab[self.rng.randint(len(vocab.all_vocab))]) + "\n", True),)
+
+        inter, summary = text_env_eval(env, Scripted(), n_rollouts=5, seed_generator=iter([11, 12, 13, 14, 15]), bsize=1, verbose=False)
+        assert len(inter) == 5
+        for ep, seed in zip(inter, [11, 12, 13, 14, 15]):
+            o = OracleWordleEnv(vocab.all_vocab, True, -10.0)
+            hist = o.reset(seed)
+            for tr in ep:
+                hist, r, d = o.step(hist + ((tr.post_action_history[-1].text, True),))
+                assert tr.post_transition_history[-1].text == hist[-1][0] and float(tr.reward) == float(r) and tr.done == d
+    finally:
+        sys.path.remove(root)
+        for k in [k for k in sys.modules if k == "LLM_RL" or k.startswith("LLM_RL.") or k == "llm_rl_scripts" or k.startswith("llm_rl_scripts.")]:
+            del sys.modules[k]

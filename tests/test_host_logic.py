@@ -295,3 +295,34 @@ def test_maze_move_accuracy_and_optimal_table():
     assert M.compute_move_accuracy(Perfect()) == 100.0
     n_row1 = sum(1 for p in tab if p[0] == 1)
     assert abs(M.compute_move_accuracy(Perfect(wrong_rows=(1,))) - (len(tab) - n_row1) / len(tab) * 100) < 1e-9
+
+
+def test_compat_import_paths_resolve_to_the_package():
+    """compat/: the reference's module paths are thin re-exports of lmrl_gym_amd (no second implementation)."""
+    import importlib
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..", "compat")
+    sys.path.insert(0, os.path.abspath(root))
+    try:
+        mods = []
+        for d, _, fs in os.walk(root):
+            for f in fs:
+                if f.endswith(".py"):
+                    rel = os.path.relpath(os.path.join(d, f), root)[:-3].replace(os.sep, ".")
+                    mods.append(rel[:-9] if rel.endswith(".__init__") else rel)
+        assert len(mods) >= 30
+        for m in mods:
+            importlib.import_module(m)
+        import lmrl_gym_amd.environment as E
+        import lmrl_gym_amd.envs.wordle as W
+        from LLM_RL.environment import Text, interact_environment, text_env_eval
+        from LLM_RL.algorithms.ppo.base_interface import get_advantages_and_returns, ppo_loss_fn
+        from llm_rl_scripts.wordle.env.env import ReformatWordleEnvironment
+        from llm_rl_scripts.maze.env.maze_utils import setup_maze_env
+        assert Text is E.Text and text_env_eval is E.text_env_eval and interact_environment is E.interact_environment
+        assert ReformatWordleEnvironment is W.ReformatWordleEnvironment and callable(setup_maze_env) and callable(ppo_loss_fn)
+        assert callable(get_advantages_and_returns)
+    finally:
+        sys.path.remove(os.path.abspath(root))
+        for k in [k for k in sys.modules if k == "LLM_RL" or k.startswith("LLM_RL.") or k == "llm_rl_scripts" or k.startswith("llm_rl_scripts.")]:
+            del sys.modules[k]
