@@ -147,10 +147,17 @@ class KVSession:
 
     def reset(self):
         self.len.zero_()
+        self._len_bound = 0
+
+    _len_bound = 0   # host-side upper bound of max(self.len): forwards are enqueued without reading the device lengths back
 
     def forward(self, tokens, cnt, chunk: int, all_hidden=None):
         """tokens int32 [B*chunk], cnt int32 [B]; updates the cache, self.len and self.last_hidden."""
         e = self.eng
+        self._len_bound += chunk
+        if self._len_bound > self.tmax:
+            raise _lib.LmrlError(f"KV cache overflow: up to {self._len_bound} positions would be written into a cache of tmax = {self.tmax} "
+                                 "(size the session for prompt + generated tokens, or reset() it)")
         _lib.check(e._L.lmrl_gpt2_forward(e._h, _lib.ptr(self.kv), self.tmax, _lib.ptr(self.ws[chunk]), _lib.ptr(tokens),
                                           _lib.ptr(cnt), _lib.ptr(self.len), self.B, chunk, _lib.ptr(self.last_hidden),
                                           _lib.ptr(all_hidden), _lib.stream_ptr()), "lmrl_gpt2_forward")
