@@ -182,7 +182,7 @@ void lmrl_gpt2_destroy(lmrl_gpt2 *m);
 size_t lmrl_gpt2_kv_bytes(const lmrl_gpt2 *m, int b, int tmax);
 size_t lmrl_gpt2_ws_bytes(const lmrl_gpt2 *m, int b, int c);
 /*
- * Forward B envs x C token slots (C = 1 decode, C = 8 chunked prefill).  Env b contributes cnt_d[b] <= C new
+ * Forward B envs x C token slots (C = 1 decode, C = 8 or 16 chunked prefill).  Env b contributes cnt_d[b] <= C new
  * tokens tokens_d[b*C + j] at positions len_d[b] + j; their K/V rows are appended to the cache and len_d[b] is
  * advanced by cnt_d[b].  last_hidden_d (bf16 [B][d], optional): ln_f of each env's LAST new token (row untouched
  * when cnt_d[b] == 0).  all_hidden_d (bf16 [B*C][d], optional): ln_f of every row.

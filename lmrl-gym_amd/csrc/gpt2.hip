@@ -439,11 +439,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
 // Rows t >= len[b] come from this chunk's own qkv rows, as in the VALU kernel; new K/V rows are appended to the cache.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
+template <int C>   // chunk rows per env: 8 (the per-turn Wordle chunk; half of the 16 MFMA query columns) or 16 (all of them)
 __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ kcache,
                                                                     uint16_t *__restrict__ vcache, const int32_t *__restrict__ cnt,
                                                                     const int32_t *__restrict__ len, uint16_t *__restrict__ out, int B,
                                                                     int H, int Tmax, int d) {
-    constexpr int C = 8, VROW = 136;
+    static_assert(C == 8 || C == 16, "the query block is one 16-column MFMA tile");
+    constexpr int VROW = 136;
     __shared__ __attribute__((aligned(16))) unsigned char vlds_all[4][32 * VROW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wave_id = blockIdx.x * 4 + wave;
@@ -461,10 +463,13 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
     const int j = lane & 15, g = lane >> 4;
 
     {   // append this chunk's K/V rows to the cache
-        const int rr = lane >> 3, cc = lane & 7;
-        if (rr < n_new && L0 + rr < Tmax) {
-            *reinterpret_cast<uint4 *>(kc + (size_t)(L0 + rr) * d + cc * 8) = *reinterpret_cast<const uint4 *>(qbase + (size_t)rr * ld + d + cc * 8);
-            *reinterpret_cast<uint4 *>(vc + (size_t)(L0 + rr) * d + cc * 8) = *reinterpret_cast<const uint4 *>(qbase + (size_t)rr * ld + 2 * d + cc * 8);
+        const int cc = lane & 7;
+#pragma unroll
+        for (int rr = lane >> 3; rr < C; rr += 8) {
+            if (rr < n_new && L0 + rr < Tmax) {
+                *reinterpret_cast<uint4 *>(kc + (size_t)(L0 + rr) * d + cc * 8) = *reinterpret_cast<const uint4 *>(qbase + (size_t)rr * ld + d + cc * 8);
+                *reinterpret_cast<uint4 *>(vc + (size_t)(L0 + rr) * d + cc * 8) = *reinterpret_cast<const uint4 *>(qbase + (size_t)rr * ld + 2 * d + cc * 8);
+            }
         }
     }
     // B operand of step A: query j (zero beyond n_new), dims kk*32 + g*8 ..
@@ -688,7 +693,7 @@ size_t lmrl_gpt2_ws_bytes(const lmrl_gpt2 *m, int b, int c) { return Gpt2Ws::byt
 int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int32_t *tokens_d, const int32_t *cnt_d,
                       int32_t *len_d, int b, int c, void *last_hidden_d, void *all_hidden_d, void *stream) {
     LMRL_REQUIRE(m && kv_d && ws_d && tokens_d && cnt_d && len_d && b > 0, "lmrl_gpt2_forward: bad argument");
-    LMRL_REQUIRE(c == 1 || c == 8, "lmrl_gpt2_forward: chunk width must be 1 or 8");
+    LMRL_REQUIRE(c == 1 || c == 8 || c == 16, "lmrl_gpt2_forward: chunk width must be 1, 8 or 16");
     const lmrl_gpt2_config &cf = m->cfg;
     hipStream_t s = as_stream(stream);
     const int M = b * c, d = cf.d_model;
@@ -740,8 +745,9 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
         } else {
         ProfScope ps(c == 1 ? PROF_ATTN_DECODE : PROF_ATTN_CHUNK, s, -1.0);
         if (c == 1) hipLaunchKernelGGL(attention_kernel<1>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
-        else if (g_attn_variant == 1) hipLaunchKernelGGL(attention_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
-        else hipLaunchKernelGGL(attention_chunk_mfma_kernel, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
+        else if (g_attn_variant == 1 && c == 8) hipLaunchKernelGGL(attention_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
+        else if (c == 16) hipLaunchKernelGGL(attention_chunk_mfma_kernel<16>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
+        else hipLaunchKernelGGL(attention_chunk_mfma_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
         }
         LMRL_CHECK_LAUNCH();
         if (fused) {

@@ -138,7 +138,7 @@ class KVSession:
         self.eng, self.B, self.tmax = eng, batch, tmax
         L, dev = eng._L, eng.device
         self.kv = torch.zeros(L.lmrl_gpt2_kv_bytes(eng._h, batch, tmax), dtype=torch.uint8, device=dev)
-        self.ws = {c: torch.zeros(L.lmrl_gpt2_ws_bytes(eng._h, batch, c), dtype=torch.uint8, device=dev) for c in (1, 8)}
+        self.ws = {c: torch.zeros(L.lmrl_gpt2_ws_bytes(eng._h, batch, c), dtype=torch.uint8, device=dev) for c in (1, 8, 16)}
         self.len = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.last_hidden = torch.zeros(batch, eng.cfg.d_model, dtype=torch.bfloat16, device=dev)
         self.sample_ws = torch.zeros(L.lmrl_sample_ws_bytes(batch, eng.cfg.vocab_padded), dtype=torch.uint8, device=dev)

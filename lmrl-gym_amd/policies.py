@@ -31,20 +31,21 @@ class _Generator:
         self.dev = self.engines[0].device
 
     def prefill(self, prompts: List[List[int]]):
-        t, B = self.t, self.B
+        """Chunked prefill, 16 tokens per env per forward (one full MFMA query tile of the chunk-attention kernel)."""
+        t, B, C = self.t, self.B, 16
         for s in self.sessions:
             s.reset()
         maxlen = max(len(p) for p in prompts)
-        for c0 in range(0, maxlen, 8):
-            toks = np.zeros((B, 8), dtype=np.int32)
+        for c0 in range(0, maxlen, C):
+            toks = np.zeros((B, C), dtype=np.int32)
             cnt = np.zeros(B, dtype=np.int32)
             for b, p in enumerate(prompts):
-                seg = p[c0:c0 + 8]
+                seg = p[c0:c0 + C]
                 toks[b, : len(seg)] = seg
                 cnt[b] = len(seg)
             td, cd = t.from_numpy(toks.reshape(-1)).to(self.dev), t.from_numpy(cnt).to(self.dev)
             for s in self.sessions:
-                s.forward(td, cd, 8)
+                s.forward(td, cd, C)
 
 
 class GPT2PPOPolicy(BatchedTextPolicy):
@@ -85,7 +86,7 @@ class GPT2PPOPolicy(BatchedTextPolicy):
             if len(ids) > self.max_input_length:           # Truncation.LEFT
                 ids = ids[len(ids) - self.max_input_length:]
             prompts.append(ids if ids else [self.pad])
-        tmax = -(-(self.max_input_length + self.max_new_tokens + 8) // 8) * 8
+        tmax = -(-(self.max_input_length + self.max_new_tokens + 16) // 16) * 16
         if self._gen is None or self._gen.B != B or self._gen.tmax != tmax:
             self._gen = _Generator(self._engines(), B, tmax)
         gen = self._gen

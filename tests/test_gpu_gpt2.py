@@ -77,7 +77,7 @@ def test_gpt2_forward_kv_cache(dev, cfgname, ln_fusion):
     ses = eng.session(B, 48)
     # schedule: chunk of 8 with ragged counts, then single-token decode steps with some envs idle, then another chunk
     consumed = np.zeros(B, dtype=int)
-    plan = [(8, [8, 5, 1, 0, 7]), (1, [1, 1, 1, 1, 0]), (1, [1, 0, 1, 1, 1]), (8, [8, 8, 3, 8, 2]), (1, [1, 1, 1, 1, 1]), (8, [4, 0, 8, 6, 8])]
+    plan = [(8, [8, 5, 1, 0, 7]), (1, [1, 1, 1, 1, 0]), (1, [1, 0, 1, 1, 1]), (16, [16, 9, 3, 8, 12]), (1, [1, 1, 1, 1, 1]), (8, [4, 0, 8, 6, 8])]
     for C, cnts in plan:
         toks = torch.zeros(B, C, dtype=torch.int32)
         for b, c in enumerate(cnts):
