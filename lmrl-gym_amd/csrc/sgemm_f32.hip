@@ -156,6 +156,29 @@ __device__ __forceinline__ void sg2_store(float *__restrict__ S, int t, const fl
     }
 }
 
+// 16-byte fast path for a full, aligned tile (workgroup-uniform choice per operand): the same k-major LDS image, fetched as
+// two float4 per thread instead of eight guarded scalar loads.
+template <bool K_CONTIG>
+__device__ __forceinline__ void sg2_load_vec(const float *__restrict__ X, int ld, int row0, int k0, int t, float (&r)[8]) {
+    const float *p = K_CONTIG ? X + (size_t)(row0 + (t >> 1)) * ld + k0 + (t & 1) * 8      // [row][k]: row t>>1, k (t&1)*8 .. +7
+                              : X + (size_t)(k0 + (t >> 4)) * ld + row0 + (t & 15) * 8;     // [k][row]: k t>>4, rows (t&15)*8 .. +7
+    const f32x4v v0 = *reinterpret_cast<const f32x4v *>(p), v1 = *reinterpret_cast<const f32x4v *>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { r[i] = v0[i]; r[4 + i] = v1[i]; }
+}
+template <bool K_CONTIG>
+__device__ __forceinline__ void sg2_store_vec(float *__restrict__ S, int t, const float (&r)[8]) {
+    if (K_CONTIG) {
+        const int row = t >> 1, k = (t & 1) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) S[(k + i) * SG2_LD + row] = r[i];
+    } else {
+        float *p = S + (t >> 4) * SG2_LD + (t & 15) * 8;
+        *reinterpret_cast<f32x4v *>(p) = f32x4v{r[0], r[1], r[2], r[3]};
+        *reinterpret_cast<f32x4v *>(p + 4) = f32x4v{r[4], r[5], r[6], r[7]};
+    }
+}
+
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void sgemm_f32_128_kernel(SgemmArgs g) {
     __shared__ float sA[2][SG2_BK * SG2_LD];
@@ -176,17 +199,21 @@ __global__ __launch_bounds__(256) void sgemm_f32_128_kernel(SgemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
     float ra[8], rb[8];
-    sg2_load<!TA>(A, g.lda, m0, g.M, 0, g.K, t, ra);
-    sg2_load<TB>(B, g.ldb, n0, g.N, 0, g.K, t, rb);
-    sg2_store<!TA>(sA[0], t, ra);
-    sg2_store<TB>(sB[0], t, rb);
+    // full, 16-byte-aligned tiles take the float4 path (workgroup-uniform per operand)
+    const bool kfull = (g.K % SG2_BK) == 0;
+    const bool va = kfull && m0 + SG2_BM <= g.M && (g.lda & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const bool vb = kfull && n0 + SG2_BN <= g.N && (g.ldb & 3) == 0 && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    if (va) sg2_load_vec<!TA>(A, g.lda, m0, 0, t, ra); else sg2_load<!TA>(A, g.lda, m0, g.M, 0, g.K, t, ra);
+    if (vb) sg2_load_vec<TB>(B, g.ldb, n0, 0, t, rb); else sg2_load<TB>(B, g.ldb, n0, g.N, 0, g.K, t, rb);
+    if (va) sg2_store_vec<!TA>(sA[0], t, ra); else sg2_store<!TA>(sA[0], t, ra);
+    if (vb) sg2_store_vec<TB>(sB[0], t, rb); else sg2_store<TB>(sB[0], t, rb);
     __syncthreads();
     const int nk = (g.K + SG2_BK - 1) / SG2_BK;
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
         if (kt + 1 < nk) {
-            sg2_load<!TA>(A, g.lda, m0, g.M, (kt + 1) * SG2_BK, g.K, t, ra);
-            sg2_load<TB>(B, g.ldb, n0, g.N, (kt + 1) * SG2_BK, g.K, t, rb);
+            if (va) sg2_load_vec<!TA>(A, g.lda, m0, (kt + 1) * SG2_BK, t, ra); else sg2_load<!TA>(A, g.lda, m0, g.M, (kt + 1) * SG2_BK, g.K, t, ra);
+            if (vb) sg2_load_vec<TB>(B, g.ldb, n0, (kt + 1) * SG2_BK, t, rb); else sg2_load<TB>(B, g.ldb, n0, g.N, (kt + 1) * SG2_BK, g.K, t, rb);
         }
         const float *pa = sA[buf] + (lane >> 5) * SG2_LD + wm * 64 + (lane & 31);
         const float *pb = sB[buf] + (lane >> 5) * SG2_LD + wn * 64 + (lane & 31);
@@ -200,8 +227,8 @@ __global__ __launch_bounds__(256) void sgemm_f32_128_kernel(SgemmArgs g) {
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
         if (kt + 1 < nk) {
-            sg2_store<!TA>(sA[buf ^ 1], t, ra);
-            sg2_store<TB>(sB[buf ^ 1], t, rb);
+            if (va) sg2_store_vec<!TA>(sA[buf ^ 1], t, ra); else sg2_store<!TA>(sA[buf ^ 1], t, ra);
+            if (vb) sg2_store_vec<TB>(sB[buf ^ 1], t, rb); else sg2_store<TB>(sB[buf ^ 1], t, rb);
         }
         __syncthreads();
     }
