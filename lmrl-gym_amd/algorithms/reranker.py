@@ -68,6 +68,16 @@ def build_logprob_score_fn(model, tokenizer, max_length: int, bsize: int):
     return score_fn
 
 
+def build_ppo_score_fn(inference, tokenizer, max_length: int, bsize: int):
+    """ppo/score_fn.py:10-66 signature: `inference` is a `GPT2PPOInference` (its policy is scored) or a bare `GPT2F32`."""
+    return build_logprob_score_fn(getattr(inference, "policy", inference), tokenizer, max_length, bsize)
+
+
+def build_bc_score_fn(inference, tokenizer, max_length: int, bsize: int):
+    """ppo/score_fn.py:69-126 signature: `inference` is a `GPT2F32` (or any object with a `.model` / `.policy` GPT2F32)."""
+    return build_logprob_score_fn(getattr(inference, "model", getattr(inference, "policy", inference)), tokenizer, max_length, bsize)
+
+
 def build_ilql_score_fn(base, q1_head, q2_head, v_head, tokenizer, max_length: int, bsize: int, value_weight: float = 1.0,
                         pi_beta=None, logit_weight: Optional[float] = None):
     """ilql/gpt2/score_fn.py:22-66: sum over the last action's tokens of value_weight * (min(Q1,Q2)(s,a) - V(s))
