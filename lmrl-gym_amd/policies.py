@@ -144,6 +144,13 @@ class GPT2ValuePolicy(GPT2PPOPolicy):
     def _engines(self):
         return [self.engine, self.value_base]
 
+    def set_params(self, policy_params) -> None:
+        """ValueRLPolicy.set_params (value_rl_base/gpt2/interface.py:322-330): `(pi_beta, base, q1_head, q2_head)` — engines for
+        the two transformers, `heads_to_engine_layout` dicts for the heads."""
+        pi_beta, base, q1, q2 = policy_params
+        self.engine, self.value_base, self.q1, self.q2 = pi_beta, base, q1, q2
+        self._gen = None
+
     def _sample(self, gen, params, active_d, logits_out):
         import torch
         L = _lib.lib()
