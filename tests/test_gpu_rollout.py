@@ -112,3 +112,60 @@ def test_greedy_rollout_is_consistent_with_oracle_model(setup):
         assert turns == 3
     assert checked > 30 and agree == checked, (agree, checked)
     ro.close()
+
+
+def test_action_decoding_fuzz_against_text_semantics(setup):
+    """lmrl_wordle_tok_guess decodes generated ids into a guess WITHOUT building text: fuzz it against the reference's text
+    path — decode, `removesuffix('\\n') + '\\n'` (out_str_process), `strip().replace(' ', '')` (deformat_history, env.py:22-23),
+    then 5 chars a-z (game.py:214-217) — on a token table with multi-letter, whitespace-carrying, empty and junk tokens."""
+    import ctypes
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.envs import wordle as W
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
+    from lmrl_gym_amd.rollout import WordleRolloutEngine, WordleTokenTable
+    from oracle.wordle import deformat_action
+    dev, _, _, _, vocab = setup
+    letters = [chr(97 + i) for i in range(26)]
+    strings = letters + [" " + c for c in letters] + ["ab", " st", "are", "xyz ", " q ", " ", "  ", "\t", " \t", "\t a", "a\tb", "x ", "\n\n", " \n",
+                                                      "!", "A", "é", "", "abcde", " crane", "abcdef", "a b", "Wordle", ":"]
+    NL = len(strings)                      # eos id
+    strings = strings + ["\n"]
+    tab = WordleTokenTable(newline=NL, pad=NL + 1, letter_first=list(range(26)), letter_sp=list(range(26, 52)), sym_first=[6, 24, 1],
+                           sym_sp=[32, 50, 27], header=[strings.index("Wordle"), strings.index(":"), NL])
+    tab.strings = {i: s for i, s in enumerate(strings)}
+    cfg = GPT2Config(1, 2, 128, 128, 128, 32)
+    eng = GPT2Engine(cfg, init_hf_style_state_dict(cfg, seed=0), dev)
+    B, G = 4096, 6
+    ro = WordleRolloutEngine(eng, vocab, B, tokens=tab, max_new_tokens=G)
+    rng = np.random.RandomState(0)
+    # biased towards letters so that valid words occur; ~25 % of the rows end with eos before G tokens
+    pool = np.concatenate([np.arange(52)] * 6 + [np.arange(52, NL)] * 2 + [np.full(12, NL)])
+    gen = pool[rng.randint(0, len(pool), size=(B, G))].astype(np.int32)
+    words = vocab.all_vocab
+    for b in range(0, B, 7):               # plant canonical spellings of real words (with / without eos in the window)
+        w = words[rng.randint(len(words))]
+        gen[b, :5] = [ord(w[0]) - 97] + [26 + ord(c) - 97 for c in w[1:]]
+        gen[b, 5] = NL if b % 2 == 0 else strings.index(" ")
+    glen = np.full(B, G, dtype=np.int32)
+    for b in range(B):                     # generation stops at the first eos (tok_accept semantics)
+        hit = np.nonzero(gen[b] == NL)[0]
+        if len(hit):
+            glen[b] = hit[0] + 1
+    ro.traj["gen"].copy_(torch.from_numpy(gen)); ro.traj["gen_len"].copy_(torch.from_numpy(glen))
+    ro.traj["env_done"].zero_(); ro.traj["n_tok"].zero_()
+    _lib.check(_lib.lib().lmrl_wordle_tok_guess(ro._tok, ctypes.byref(ro._ctraj), _lib.ptr(ro.guess), _lib.ptr(ro.active), B, _lib.stream_ptr()))
+    got = ro.guess.cpu().numpy().view(np.uint32)
+    pend = ro.traj["pend_newline"].cpu().numpy()
+    n_valid = 0
+    for b in range(B):
+        toks = gen[b, : glen[b]]
+        text = "".join(strings[t] for t in toks)
+        saw_eos = toks[-1] == NL
+        action = deformat_action(text.removesuffix("\n") + "\n")
+        ok = len(action) == 5 and all("a" <= c <= "z" for c in action)
+        exp = W.pack_guess(action) if ok else 0xFFFFFFFF
+        assert int(got[b]) == exp, (b, [strings[t] for t in toks], action, hex(int(got[b])), hex(exp))
+        assert int(pend[b]) == (0 if saw_eos else 1)
+        n_valid += ok
+    assert n_valid > B // 10
+    ro.close()
