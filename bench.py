@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="1: capture the episode into a hipGraph and replay it (default); 0: eager launches")
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning hook: forwarded to lmrl_gemm_set_variant")
+    ap.add_argument("--share-header", type=int, default=1, help="1 (default): the K/V rows of the header text every env starts from are computed "
+                    "once per episode and broadcast to all envs (bit-identical to per-env prefill); 0: prefill the header per env")
     ap.add_argument("--streams", type=int, default=1, help="split the batch into this many sub-batches on separate HIP streams")
     ap.add_argument("--breakdown", action="store_true", help="after the timed region, print a per-kernel-class event breakdown to stderr")
     args = ap.parse_args()
@@ -143,7 +145,7 @@ def main():
     ros = []
     for st in streams:
         with torch.cuda.stream(st):
-            ros.append(WordleRolloutEngine(eng, vocab, Bs, max_new_tokens=6, bad_word_reward=-10.0))
+            ros.append(WordleRolloutEngine(eng, vocab, Bs, max_new_tokens=6, bad_word_reward=-10.0, share_header=bool(args.share_header)))
     ro = ros[0]
     n_eps = args.steps + args.warmup + (1 if args.breakdown else 0)
     guesses = torch.from_numpy(scripted_guesses(vocab.all_vocab, n_eps, n_turns, B, seed=12345 + rank).view(np.int32)).to(dev)
@@ -306,7 +308,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: Wordle env, GPT-2-small policy (random-init, steered sampling), "
                                    f"{B} lock-step envs per GPU, {n_turns} turns x <=6 generated tokens, vocab {args.vocab_file}",
-                       "envs_per_gpu": B, "hip_streams": S, "hip_graph": bool(args.graph), "max_new_tokens": 6, "parallelism": f"env-sharded x{world}, no data-path collective",
+                       "envs_per_gpu": B, "hip_streams": S, "hip_graph": bool(args.graph), "shared_header_prefill": bool(args.share_header), "max_new_tokens": 6, "parallelism": f"env-sharded x{world}, no data-path collective",
                        "env_steps_timed": n_env_steps},
             "roofline": roofline, "roofline_secondary": roofline_secondary,
         }

@@ -190,6 +190,15 @@ size_t lmrl_gpt2_ws_bytes(const lmrl_gpt2 *m, int b, int c);
 int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int32_t *tokens_d, const int32_t *cnt_d,
                       int32_t *len_d, int b, int c, void *last_hidden_d, void *all_hidden_d, void *stream);
 
+/*
+ * Shared prompt prefix: copy positions [0, n_pos) of the single env of a 1-env KV session (src) into all `b` envs of dst,
+ * set dst_len_d[i] = n_pos and (optionally) broadcast the prefix's last hidden state.  All envs of a lock-step Wordle batch
+ * start from the same header text ('Wordle:\n', wordle/env/env.py:8), so its K/V are computed once per episode instead of
+ * once per env; the copied rows are bit-identical to what a per-env forward writes.
+ */
+int lmrl_gpt2_kv_broadcast(const lmrl_gpt2 *m, const void *src_kv_d, int src_tmax, void *dst_kv_d, int dst_tmax, int b, int n_pos,
+                           const void *src_hidden_d, void *dst_hidden_d, int32_t *dst_len_d, void *stream);
+
 /* C[m][n] = A[m][k] . W[n][k]^T + bias[n]; A, W bf16.  epilogue: 0 bf16, 1 gelu_new->bf16, 2 f32 += (residual),
  * 3 f32, 4 relu->bf16.  Used for the value heads (heads/linear_head.py:112-119, heads/mlp_head.py:139-148). */
 int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda,

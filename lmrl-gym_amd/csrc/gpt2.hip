@@ -575,6 +575,25 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
     }
 }
 
+// Shared-prefix broadcast: every env of a batch starts from the same prompt prefix (the Wordle header), so its K/V rows are
+// computed ONCE (a 1-env forward on a small session) and copied into all B caches; len and the last hidden state follow.
+// One workgroup row per (layer, K|V, env): n_pos rows of d bf16, 16 B per lane.
+__global__ __launch_bounds__(256) void kv_broadcast_kernel(const uint16_t *__restrict__ src, int src_tmax, uint16_t *__restrict__ dst,
+                                                           int dst_tmax, int B, int n_pos, int d, const uint16_t *__restrict__ src_hidden,
+                                                           uint16_t *__restrict__ dst_hidden, int32_t *__restrict__ dst_len) {
+    const int b = blockIdx.x, lk = blockIdx.y;        // lk = layer * 2 + (0 K | 1 V)
+    const uint16_t *sp = src + (size_t)lk * src_tmax * d;                       // source session has a single env
+    uint16_t *dp = dst + ((size_t)lk * B + b) * dst_tmax * d;
+    const int chunks = n_pos * d / 8;
+    for (int i = threadIdx.x; i < chunks; i += blockDim.x)
+        reinterpret_cast<u32x4 *>(dp)[i] = reinterpret_cast<const u32x4 *>(sp)[i];
+    if (lk == 0) {
+        if (dst_hidden) for (int i = threadIdx.x; i < d / 8; i += blockDim.x)
+            reinterpret_cast<u32x4 *>(dst_hidden + (size_t)b * d)[i] = reinterpret_cast<const u32x4 *>(src_hidden)[i];
+        if (threadIdx.x == 0) dst_len[b] = n_pos;
+    }
+}
+
 // profiling only (one launch per forward): algorithmic HBM bytes of the attention launches of this forward =
 // per (env, head, layer): K and V rows of every attended position (2 x 128 B) + the chunk's q rows and output rows.
 __global__ void attn_bytes_kernel(const int32_t *cnt, const int32_t *len, int B, int C, int heads_x_layers,
@@ -778,6 +797,17 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
                                       (uint16_t *)last_hidden_d, cnt_d, len_d, b, c, d, cf.ln_eps);
     else hipLaunchKernelGGL(final_ln_advance_kernel<8>, dim3(ceil_div(b, 4)), dim3(256), 0, s, w.x, m->lnf_g, m->lnf_b,
                             (uint16_t *)last_hidden_d, cnt_d, len_d, b, c, d, cf.ln_eps);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_gpt2_kv_broadcast(const lmrl_gpt2 *m, const void *src_kv_d, int src_tmax, void *dst_kv_d, int dst_tmax, int b, int n_pos,
+                           const void *src_hidden_d, void *dst_hidden_d, int32_t *dst_len_d, void *stream) {
+    LMRL_REQUIRE(m && src_kv_d && dst_kv_d && dst_len_d && b > 0 && n_pos > 0 && n_pos <= src_tmax && n_pos <= dst_tmax,
+                 "lmrl_gpt2_kv_broadcast: bad argument");
+    LMRL_REQUIRE(!dst_hidden_d || src_hidden_d, "lmrl_gpt2_kv_broadcast: dst_hidden_d needs src_hidden_d");
+    hipLaunchKernelGGL(kv_broadcast_kernel, dim3(b, 2 * m->cfg.n_layer), dim3(256), 0, as_stream(stream), (const uint16_t *)src_kv_d, src_tmax,
+                       (uint16_t *)dst_kv_d, dst_tmax, b, n_pos, m->cfg.d_model, (const uint16_t *)src_hidden_d, (uint16_t *)dst_hidden_d, dst_len_d);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

@@ -163,6 +163,16 @@ class KVSession:
                                           _lib.ptr(all_hidden), _lib.stream_ptr()), "lmrl_gpt2_forward")
         return self.last_hidden
 
+    def broadcast_prefix_from(self, src: "KVSession", n_pos: int):
+        """Every env of this session starts with the `n_pos`-token prefix held by the 1-env session `src`
+        (`lmrl_gpt2_kv_broadcast`): K/V rows, cache lengths and the last hidden state."""
+        assert src.B == 1 and src.eng is self.eng
+        e = self.eng
+        _lib.check(e._L.lmrl_gpt2_kv_broadcast(e._h, _lib.ptr(src.kv), src.tmax, _lib.ptr(self.kv), self.tmax, self.B, n_pos,
+                                               _lib.ptr(src.last_hidden), _lib.ptr(self.last_hidden), _lib.ptr(self.len), _lib.stream_ptr()),
+                   "lmrl_gpt2_kv_broadcast")
+        self._len_bound = max(self._len_bound, n_pos)
+
     def sample(self, params: SampleParams, steer_tok=None, active=None, hidden=None, logits_out=None,
                q1=None, q2=None):
         """Fused LM head + sampling of one token per env from `hidden` (default: last_hidden).

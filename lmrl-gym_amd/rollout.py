@@ -137,7 +137,7 @@ class WordleRolloutEngine:
 
     def __init__(self, engine: GPT2Engine, vocab: W.Vocabulary, batch: int, tokens: Optional[WordleTokenTable] = None,
                  max_new_tokens: int = 6, require_words_in_vocab: bool = True, bad_word_reward: float = -10.0,
-                 traj_cap: int = 128):
+                 traj_cap: int = 128, share_header: bool = True):
         import torch
         t = torch
         self.eng, self.vocab, self.B = engine, vocab, batch
@@ -148,6 +148,9 @@ class WordleRolloutEngine:
         self.env = W.VectorWordleEnv(vocab, require_words_in_vocab, bad_word_reward)
         self.env._alloc(batch)
         self.ses = engine.session(batch, traj_cap)
+        # every env starts from the same header text: its K/V are computed once per episode on a 1-env session and broadcast
+        self.share_header = share_header
+        self.ses1 = engine.session(1, 16) if share_header else None
         ct = self.tokens.c_struct()
         cls = np.ascontiguousarray(self.tokens.token_class(engine.cfg.vocab))
         self._tok = self._L.lmrl_wordle_tok_create(ctypes.byref(ct), cls.ctypes.data, engine.cfg.vocab, max_new_tokens, traj_cap)
@@ -225,7 +228,12 @@ class WordleRolloutEngine:
         self.env.reset_device(seeds if not isinstance(seeds, np.ndarray) else np.asarray(seeds, dtype=np.uint64))
         self.ses.reset()
         self._ck(L.lmrl_wordle_tok_begin(self._tok, tr, _lib.ptr(self.chunk_tok), _lib.ptr(self.chunk_cnt), B, sp), "tok_begin")
-        self.ses.forward(self.chunk_tok, self.chunk_cnt, 8)
+        if self.share_header:
+            self.ses1.reset()
+            self.ses1.forward(self.chunk_tok[:8], self.chunk_cnt[:1], 8)      # env 0's header chunk = everybody's header chunk
+            self.ses.broadcast_prefix_from(self.ses1, len(self.tokens.header))
+        else:
+            self.ses.forward(self.chunk_tok, self.chunk_cnt, 8)
         yield
         logits_out = None
         if top_k > 0:

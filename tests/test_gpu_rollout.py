@@ -169,3 +169,22 @@ def test_action_decoding_fuzz_against_text_semantics(setup):
         n_valid += ok
     assert n_valid > B // 10
     ro.close()
+
+
+def test_shared_header_prefix_is_bit_identical_to_per_env_prefill(setup):
+    """The header's K/V computed once and broadcast (`lmrl_gpt2_kv_broadcast`) vs prefilled per env: same sampled tokens,
+    same records, same KV rows — the optimisation changes how often identical rows are computed, not what they are."""
+    from lmrl_gym_amd.rollout import WordleRolloutEngine
+    dev, cfg, sd, eng, vocab = setup
+    B = 96
+    seeds = np.arange(B, dtype=np.uint64) + 300
+    out = []
+    for share in (True, False):
+        ro = WordleRolloutEngine(eng, vocab, B, max_new_tokens=6, share_header=share)
+        ro.run_episode(seeds, temperature=0.9, sample_seed=17)
+        torch.cuda.synchronize()
+        out.append((ro.traj["tokens"].cpu().clone(), ro.traj["n_tok"].cpu().clone(), ro.traj["reward"].cpu().clone(),
+                    ro.ses.kv.clone(), ro.ses.len.cpu().clone()))
+        ro.close()
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
