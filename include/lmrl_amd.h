@@ -211,6 +211,9 @@ void lmrl_attn_set_variant(int v);
 /* A/B hook: 1 (default) folds every LayerNorm but ln_f into the neighbouring GEMMs (no stand-alone LN launches);
  * 0 runs the stand-alone LayerNorm kernels. */
 void lmrl_gpt2_set_ln_fusion(int on);
+/* Ragged prefill: chunk (c > 1) forwards with b*c >= min_slots (default 2048; 0 = never) run on the compacted rows (sum of
+ * cnt_d) instead of all b*c slots; results are bit-identical (every output row depends on its own input row only). */
+void lmrl_gpt2_set_ragged_prefill(int min_slots);
 
 /* ------------------------------------------------------------------------------------------
  * Fused LM-head + sampling (csrc/sampler.hip).  Replaces logits[:, -1] -> warpers -> jax.random.categorical in

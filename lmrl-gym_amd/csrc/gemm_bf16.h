@@ -68,6 +68,7 @@ struct GemmArgs {
     const float *colsum;  // consumer: c[n] = sum_k W'[n][k]
     int nslots;           // consumer: slots to add per row ; producer: row pitch of `stats`
     float inv_d, eps;     // consumer: 1/d_model, LN epsilon
+    const int *m_dev;     // optional DEVICE row count (<= M): ragged batches — tiles beyond it exit, `M` then only sizes the grid
 };
 
 template <int BM, int BN, int EPI>
@@ -229,7 +230,7 @@ __device__ __forceinline__ bool xcd_tile(const XcdMap &x, int id, int &tile_m, i
     const int xcd = id & 7, q = id >> 3;
     const int gn = 8 / x.gm;
     const int gi = xcd / gn, gj = xcd - gi * gn;
-    tile_m = gi * x.tmg + (q % x.tmg);
+    tile_m = (q % x.tmg) * x.gm + gi;      // m-tiles dealt round-robin to the gm groups: a ragged (short) M thins every group equally
     tile_n = gj * x.tng + (q / x.tmg);
     return tile_m < x.tiles_m && tile_n < x.tiles_n;
 }
@@ -351,6 +352,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
     if (!xcd_tile(xm, blockIdx.x, tile_m, tile_n)) return;   // workgroup-uniform
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int lr = lane & 15, lq = lane >> 4;
+    const int Mr = g.m_dev ? *g.m_dev : g.M;          // rows actually present (workgroup-uniform scalar load)
+    if (m0 >= Mr) return;
     // LN_IN: the tile's BM x nslots (sum, sum^2) slots are one contiguous region of `stats`; the 256 threads fetch it
     // coalesced (NL float4 each) right after the ring prologue, so the latency hides behind the K loop.  After the loop
     // the per-float4 partial sums go through the (now free) LDS ring and one thread per row adds them in a fixed order
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
     if (LN_IN) {
         const int h4 = g.nslots / 2;                         // float4 per row
         const f32x4 *sp = reinterpret_cast<const f32x4 *>(g.stats + (size_t)m0 * g.nslots);
-        const int lim = (g.M - m0 < BM ? g.M - m0 : BM) * h4;
+        const int lim = (Mr - m0 < BM ? Mr - m0 : BM) * h4;
         auto issue = [&]() {   // unconditional (clamped) loads: exactly NL VMEM instructions per wave, as the wait assumes
 #pragma unroll
             for (int k = 0; k < NL; k++) {
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
                 st[k] = sp[idx < lim ? idx : lim - 1];
             }
         };
-        glds_mainloop<BM, BN, STAGES, NL>(g.A, g.lda, g.W, g.K, g.M, m0, n0, smem, acc, issue);
+        glds_mainloop<BM, BN, STAGES, NL>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc, issue);
         __syncthreads();                                     // every wave is done with the LDS ring
         float2 *part = reinterpret_cast<float2 *>(smem);     // [BM * h4] partial (sum, sum^2)
         float2 *murs = part + BM * 4 * NQ;                   // [BM] (mu, rstd)
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
         }
         __syncthreads();
     } else {
-        glds_mainloop<BM, BN, STAGES>(g.A, g.lda, g.W, g.K, g.M, m0, n0, smem, acc);
+        glds_mainloop<BM, BN, STAGES>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc);
     }
 
     if (EPI == EPI_RESID_F32_STATS) {
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
 #pragma unroll
         for (int j = 0; j < FM; j++) {
             const int m = m0 + wm * (BM / 2) + j * 16 + lr;
-            const bool row_ok = m < g.M;
+            const bool row_ok = m < Mr;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < FN; i++) {
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
         for (int j = 0; j < FM; j++) {
             const int rl = wm * (BM / 2) + j * 16 + lr;
             const int m = m0 + rl;
-            if (m >= g.M) continue;
+            if (m >= Mr) continue;
             f32x4 v;
             if (LN_IN) {
                 v = (acc[i][j] - c4 * ln_mu[j]) * ln_rs[j] + b4;

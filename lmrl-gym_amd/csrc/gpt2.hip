@@ -130,11 +130,16 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void embed_stats_kernel(const uint16_t *__restrict__ wte, const uint16_t *__restrict__ wpe,
                                                           const int32_t *__restrict__ tokens, const int32_t *__restrict__ cnt,
                                                           const int32_t *__restrict__ len, float *__restrict__ x, uint16_t *__restrict__ xb,
-                                                          float2 *__restrict__ stats, int nslots, int B, int C, int d, int vocab, int n_pos) {
+                                                          float2 *__restrict__ stats, int nslots, int B, int C, int d, int vocab, int n_pos,
+                                                          const int32_t *__restrict__ row_map, const int32_t *__restrict__ m_dev) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= B * C) return;
-    const int b = r / C, j = r - b * C;
-    int tok = tokens[r];
+    int b = r / C, j = r - b * C;
+    if (row_map) {                          // ragged prefill: row r of the compacted batch belongs to (env, slot) = row_map[r]
+        if (r >= *m_dev) return;
+        b = row_map[r] >> 5; j = row_map[r] & 31;
+    }
+    int tok = tokens[b * C + j];
     int pos = len[b] + j;
     const bool valid = j < cnt[b];
     if (!valid || tok < 0 || tok >= vocab) tok = 0;
@@ -234,14 +239,14 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void final_ln_advance_kernel(const float *__restrict__ x, const float *__restrict__ gam,
                                                                const float *__restrict__ bet, uint16_t *__restrict__ y,
                                                                const int32_t *__restrict__ cnt, int32_t *__restrict__ len, int B, int C,
-                                                               int d, float eps) {
+                                                               int d, float eps, const int32_t *__restrict__ off) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
     const int n = min(cnt[b], C);
     if (n <= 0) return;
     if (lane == 0) len[b] += n;
     if (!y) return;
-    const float *xr = x + ((size_t)b * C + n - 1) * d;
+    const float *xr = x + ((size_t)(off ? off[b] : b * C) + n - 1) * d;
     f32x4 v[MAXV], g4[MAXV], b4[MAXV];
     float s = 0.f;
 #pragma unroll
@@ -443,7 +448,7 @@ template <int C>   // chunk rows per env: 8 (the per-turn Wordle chunk; half of 
 __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ kcache,
                                                                     uint16_t *__restrict__ vcache, const int32_t *__restrict__ cnt,
                                                                     const int32_t *__restrict__ len, uint16_t *__restrict__ out, int B,
-                                                                    int H, int Tmax, int d) {
+                                                                    int H, int Tmax, int d, const int32_t *__restrict__ off) {
     static_assert(C == 8 || C == 16, "the query block is one 16-column MFMA tile");
     constexpr int VROW = 136;
     __shared__ __attribute__((aligned(16))) unsigned char vlds_all[4][32 * VROW];
@@ -458,7 +463,8 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
     const size_t ld = (size_t)3 * d;
     uint16_t *kc = kcache + (size_t)b * Tmax * d + (size_t)h * 64;   // token-major cache: row t of head h at kc + t*d
     uint16_t *vc = vcache + (size_t)b * Tmax * d + (size_t)h * 64;
-    const uint16_t *qbase = qkv + (size_t)b * C * ld + (size_t)h * 64;
+    const size_t row0 = off ? (size_t)off[b] : (size_t)b * C;      // first row of this env in the (possibly compacted) chunk batch
+    const uint16_t *qbase = qkv + row0 * ld + (size_t)h * 64;
     unsigned char *vlds = vlds_all[wave];
     const int j = lane & 15, g = lane >> 4;
 
@@ -570,9 +576,37 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
             uint2 o;
             o.x = (uint32_t)f32_to_bf16_rn(oacc[f][0] * inv) | ((uint32_t)f32_to_bf16_rn(oacc[f][1] * inv) << 16);
             o.y = (uint32_t)f32_to_bf16_rn(oacc[f][2] * inv) | ((uint32_t)f32_to_bf16_rn(oacc[f][3] * inv) << 16);
-            *reinterpret_cast<uint2 *>(out + ((size_t)b * C + j) * d + (size_t)h * 64 + f * 16 + g * 4) = o;
+            *reinterpret_cast<uint2 *>(out + (row0 + j) * d + (size_t)h * 64 + f * 16 + g * 4) = o;
         }
     }
+}
+
+// Ragged prefill: a chunk forward only has cnt[b] <= C valid rows per env (7 of 8 in a Wordle turn, fewer for short
+// observations, 0 for finished envs).  The rows are compacted env-major so that the GEMMs see M = sum(cnt) rows: off[b] =
+// first row of env b, off[B] = M (the GEMMs read it from device memory: tiles beyond it exit), row_map[r] = (env << 5) | slot.
+__global__ __launch_bounds__(1024) void ragged_scan_kernel(const int32_t *__restrict__ cnt, int B, int C, int32_t *__restrict__ off,
+                                                           int32_t *__restrict__ row_map) {
+    __shared__ int32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (B + 1023) / 1024, lo = t * per, hi = min(lo + per, B);
+    int sum = 0;
+    for (int b = lo; b < hi; b++) sum += max(0, min(cnt[b], C));
+    part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {          // inclusive Hillis-Steele scan of the 1024 segment sums
+        const int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - sum;                       // exclusive prefix of this thread's segment
+    for (int b = lo; b < hi; b++) {
+        const int n = max(0, min(cnt[b], C));
+        off[b] = run;
+        for (int j = 0; j < n; j++) row_map[run + j] = (b << 5) | j;
+        run += n;
+    }
+    if (t == 1023) off[B] = part[1023];
 }
 
 // Shared-prefix broadcast: every env of a batch starts from the same prompt prefix (the Wordle header), so its K/V rows are
@@ -613,18 +647,19 @@ __global__ void attn_bytes_kernel(const int32_t *cnt, const int32_t *len, int B,
 
 int g_gemm_variant = 0;
 int g_attn_variant = 0;   // test/bench hook: 1 = VALU chunk attention
+int g_ragged_prefill = 2048; // chunk forwards with >= this many slots run on the compacted (sum of cnt) rows; 0 = never (A/B hook)
 int g_ln_fusion = 1;      // 0 = stand-alone LayerNorm launches (A/B hook), 1 = LN folded into the neighbouring GEMMs
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Gpt2Ws {
-    float *x; uint16_t *h, *qkv, *att, *ff; int32_t *rows_idx; float2 *stats;
+    float *x; uint16_t *h, *qkv, *att, *ff; int32_t *rows_idx; float2 *stats; int32_t *off, *row_map;
     static int nslots(const lmrl_gpt2_config &c) { const int nq = ln_fusion_nq(c.d_model); return nq ? 8 * nq : 8; }   // padded slot pitch
     static size_t bytes(const lmrl_gpt2_config &c, size_t M, size_t B) {
         return align256(M * c.d_model * 4) + align256(M * c.d_model * 2) + align256(M * 3 * c.d_model * 2) +
-               align256(M * c.d_model * 2) + align256(M * c.d_ff * 2) + align256(B * 4) + align256(M * nslots(c) * 8);
+               align256(M * c.d_model * 2) + align256(M * c.d_ff * 2) + align256(B * 4) + align256(M * nslots(c) * 8) + align256((B + 1) * 4) + align256(M * 4);
     }
-    void carve(void *ws, const lmrl_gpt2_config &c, size_t M, size_t B) {
+    void carve(void *ws, const lmrl_gpt2_config &c, size_t M, size_t B) {   // same order as bytes()
         char *p = (char *)ws;
         x = (float *)p; p += align256(M * c.d_model * 4);
         h = (uint16_t *)p; p += align256(M * c.d_model * 2);
@@ -632,7 +667,9 @@ struct Gpt2Ws {
         att = (uint16_t *)p; p += align256(M * c.d_model * 2);
         ff = (uint16_t *)p; p += align256(M * c.d_ff * 2);
         rows_idx = (int32_t *)p; p += align256(B * 4);
-        stats = (float2 *)p;
+        stats = (float2 *)p; p += align256(M * nslots(c) * 8);
+        off = (int32_t *)p; p += align256((B + 1) * 4);
+        row_map = (int32_t *)p;
     }
 };
 
@@ -723,6 +760,10 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
         hipLaunchKernelGGL(attn_bytes_kernel, dim3(1), dim3(256), 0, s, cnt_d, len_d, b, c, cf.n_head * cf.n_layer, ctr);
     const bool fused = g_ln_fusion && g_gemm_variant != 1 && ln_fusion_nq(d) != 0;
     const int nsl = Gpt2Ws::nslots(cf);
+    // ragged prefill (chunk forwards on the LN-folded path, unless the caller wants every row's hidden state back)
+    const bool ragged = fused && g_ragged_prefill > 0 && c > 1 && !all_hidden_d && M >= g_ragged_prefill;
+    const int32_t *off = ragged ? w.off : nullptr, *row_map = ragged ? w.row_map : nullptr, *m_dev = ragged ? w.off + b : nullptr;
+    if (ragged) hipLaunchKernelGGL(ragged_scan_kernel, dim3(1), dim3(1024), 0, s, cnt_d, b, c, w.off, w.row_map);
     auto ln = [&](const float *g, const float *be, uint16_t *y, const int32_t *idx, int rows) {
         if (d <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w.x, g, be, y, idx, rows, d, cf.ln_eps);
         else hipLaunchKernelGGL(layernorm_kernel<8>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w.x, g, be, y, idx, rows, d, cf.ln_eps);
@@ -730,9 +771,9 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
     if (fused) {
         // LN-folded path: w.h holds the bf16 copy of the residual stream, w.stats its per-row (sum, sum^2) slots
         if (d <= 1024) hipLaunchKernelGGL(embed_stats_kernel<4>, dim3(ceil_div(M, 4)), dim3(256), 0, s, m->wte, m->wpe, tokens_d, cnt_d, len_d,
-                                          w.x, w.h, w.stats, nsl, b, c, d, cf.vocab, cf.n_pos);
+                                          w.x, w.h, w.stats, nsl, b, c, d, cf.vocab, cf.n_pos, row_map, m_dev);
         else hipLaunchKernelGGL(embed_stats_kernel<8>, dim3(ceil_div(M, 4)), dim3(256), 0, s, m->wte, m->wpe, tokens_d, cnt_d, len_d,
-                                w.x, w.h, w.stats, nsl, b, c, d, cf.vocab, cf.n_pos);
+                                w.x, w.h, w.stats, nsl, b, c, d, cf.vocab, cf.n_pos, row_map, m_dev);
     } else {
         // embeddings + LN1 of layer 0 in one launch
         if (d <= 1024) hipLaunchKernelGGL(embed_ln_kernel<4>, dim3(ceil_div(M, 4)), dim3(256), 0, s, m->wte, m->wpe, tokens_d, cnt_d, len_d,
@@ -745,7 +786,7 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
         const Gpt2Layer &L = m->layers[l];
         uint16_t *kc = (uint16_t *)kv_d + (size_t)(2 * l) * kv_layer, *vc = kc + kv_layer;
         if (fused) {
-            GemmArgs g{w.h, L.wf_qkv, L.bf_qkv, w.qkv, M, 3 * d, d, d, 3 * d, 3 * d, w.stats, nullptr, L.cs_qkv, nsl, 1.f / (float)d, cf.ln_eps};
+            GemmArgs g{w.h, L.wf_qkv, L.bf_qkv, w.qkv, M, 3 * d, d, d, 3 * d, 3 * d, w.stats, nullptr, L.cs_qkv, nsl, 1.f / (float)d, cf.ln_eps, m_dev};
             LMRL_CHECK_HIP(gemm_launch_ln<EPI_BF16_LN>(g, s));
         } else {
             if (l > 0) {
@@ -764,17 +805,17 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
         } else {
         ProfScope ps(c == 1 ? PROF_ATTN_DECODE : PROF_ATTN_CHUNK, s, -1.0);
         if (c == 1) hipLaunchKernelGGL(attention_kernel<1>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
-        else if (g_attn_variant == 1 && c == 8) hipLaunchKernelGGL(attention_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
-        else if (c == 16) hipLaunchKernelGGL(attention_chunk_mfma_kernel<16>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
-        else hipLaunchKernelGGL(attention_chunk_mfma_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
+        else if (g_attn_variant == 1 && c == 8 && !ragged) hipLaunchKernelGGL(attention_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
+        else if (c == 16) hipLaunchKernelGGL(attention_chunk_mfma_kernel<16>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d, off);
+        else hipLaunchKernelGGL(attention_chunk_mfma_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d, off);
         }
         LMRL_CHECK_LAUNCH();
         if (fused) {
-            GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f};
+            GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
             LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, s));
-            GemmArgs gf{w.h, L.wf_fc, L.bf_fc, w.ff, M, cf.d_ff, d, d, cf.d_ff, cf.d_ff, w.stats, nullptr, L.cs_fc, nsl, 1.f / (float)d, cf.ln_eps};
+            GemmArgs gf{w.h, L.wf_fc, L.bf_fc, w.ff, M, cf.d_ff, d, d, cf.d_ff, cf.d_ff, w.stats, nullptr, L.cs_fc, nsl, 1.f / (float)d, cf.ln_eps, m_dev};
             LMRL_CHECK_HIP(gemm_launch_ln<EPI_GELU_BF16_LN>(gf, s));
-            GemmArgs g2{w.ff, L.w_fc2, L.b_fc2, w.x, M, d, cf.d_ff, cf.d_ff, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f};
+            GemmArgs g2{w.ff, L.w_fc2, L.b_fc2, w.x, M, d, cf.d_ff, cf.d_ff, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
             if (l + 1 < cf.n_layer) LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(g2, s));
             else LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(g2, s));      // ln_f reads the fp32 stream directly
         } else {
@@ -794,9 +835,9 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
     }
     // ln_f of each env's last new token (optional) + len[b] += cnt[b]
     if (d <= 1024) hipLaunchKernelGGL(final_ln_advance_kernel<4>, dim3(ceil_div(b, 4)), dim3(256), 0, s, w.x, m->lnf_g, m->lnf_b,
-                                      (uint16_t *)last_hidden_d, cnt_d, len_d, b, c, d, cf.ln_eps);
+                                      (uint16_t *)last_hidden_d, cnt_d, len_d, b, c, d, cf.ln_eps, off);
     else hipLaunchKernelGGL(final_ln_advance_kernel<8>, dim3(ceil_div(b, 4)), dim3(256), 0, s, w.x, m->lnf_g, m->lnf_b,
-                            (uint16_t *)last_hidden_d, cnt_d, len_d, b, c, d, cf.ln_eps);
+                            (uint16_t *)last_hidden_d, cnt_d, len_d, b, c, d, cf.ln_eps, off);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }
@@ -815,6 +856,7 @@ int lmrl_gpt2_kv_broadcast(const lmrl_gpt2 *m, const void *src_kv_d, int src_tma
 void lmrl_gemm_set_variant(int v) { lmrl::g_gemm_variant = v; }
 void lmrl_attn_set_variant(int v) { lmrl::g_attn_variant = v; }
 void lmrl_gpt2_set_ln_fusion(int on) { lmrl::g_ln_fusion = on; }
+void lmrl_gpt2_set_ragged_prefill(int min_slots) { lmrl::g_ragged_prefill = min_slots; }
 
 // Plain bf16 GEMM entry (heads, LM-head logits): C = A.W^T + bias with a selectable epilogue.
 int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda,

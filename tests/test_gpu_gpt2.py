@@ -284,3 +284,32 @@ def test_sampler_steer_and_ilql_perturbation(dev):
     steer = torch.randint(0, cfg.vocab, (B,), generator=g).to(torch.int32)
     tok, _ = ses.sample(SampleParams(1.0, 0, 5, 1, 1000.0, 0.0, 0), hidden=hid, steer_tok=steer.to(dev))
     assert torch.equal(tok.cpu(), steer)
+
+
+def test_ragged_prefill_is_bit_identical(dev):
+    """Chunk forwards on the compacted rows (sum of cnt) vs on all B*C slots: same last hidden states, same KV cache, same
+    cache lengths, bit for bit, for ragged counts including empty envs; decode steps afterwards agree too."""
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
+    cfg = GPT2Config(2, 12, 768, 3072, 1000, 64)
+    eng = GPT2Engine(cfg, init_hf_style_state_dict(cfg, seed=2), dev)
+    B = 37
+    g = torch.Generator().manual_seed(1)
+    plan = [(8, torch.randint(0, 9, (B,), generator=g)), (16, torch.randint(0, 17, (B,), generator=g)), (1, torch.ones(B, dtype=torch.int64)),
+            (8, torch.randint(3, 9, (B,), generator=g))]
+    plan[0][1][0] = 0; plan[0][1][B - 1] = 8
+    outs = []
+    for min_slots in (1, 0):
+        _lib.lib().lmrl_gpt2_set_ragged_prefill(min_slots)
+        try:
+            ses = eng.session(B, 48)
+            hs = []
+            for C, cnt in plan:
+                toks = torch.randint(0, cfg.vocab, (B * C,), generator=torch.Generator().manual_seed(C)).to(torch.int32).to(dev)
+                hs.append(ses.forward(toks, cnt.to(torch.int32).to(dev), C).clone())
+            outs.append((hs, ses.kv.clone(), ses.len.clone()))
+        finally:
+            _lib.lib().lmrl_gpt2_set_ragged_prefill(2048)
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
