@@ -306,19 +306,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
                                                         uint16_t *__restrict__ kcache, uint16_t *__restrict__ vcache,
                                                         const int32_t *__restrict__ cnt, const int32_t *__restrict__ len,
                                                         uint16_t *__restrict__ out,          // [B*C][d]
-                                                        int B, int H, int Tmax, int d) {
+                                                        int B, int H, int Tmax, int d, const int32_t *__restrict__ off = nullptr) {
     const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (wave_id >= B * H) return;
     const int b = wave_id / H, h = wave_id - b * H;
     const int n_new = min(cnt[b], C);
     if (n_new <= 0) return;
+    const size_t row0 = off ? (size_t)off[b] : (size_t)b * C;       // first row of this env in the (possibly compacted) batch
     const int L0 = len[b];
     const int T = L0 + n_new;
     const int rr = lane >> 3, cc = lane & 7;
     const size_t ld = (size_t)3 * d;
     uint16_t *kc = kcache + (size_t)b * Tmax * d + (size_t)h * 64;   // token-major cache: row t of head h at kc + t*d
     uint16_t *vc = vcache + (size_t)b * Tmax * d + (size_t)h * 64;
-    const uint16_t *qbase = qkv + (size_t)b * C * ld + (size_t)h * 64;
+    const uint16_t *qbase = qkv + row0 * ld + (size_t)h * 64;
 
     // append this chunk's K/V rows to the cache (row j -> position L0 + j)
     for (int j = rr; j < n_new; j += 8) {
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
             pk.y = (uint32_t)f32_to_bf16_rn(r8[2]) | ((uint32_t)f32_to_bf16_rn(r8[3]) << 16);
             pk.z = (uint32_t)f32_to_bf16_rn(r8[4]) | ((uint32_t)f32_to_bf16_rn(r8[5]) << 16);
             pk.w = (uint32_t)f32_to_bf16_rn(r8[6]) | ((uint32_t)f32_to_bf16_rn(r8[7]) << 16);
-            *reinterpret_cast<uint4 *>(out + ((size_t)b * C + j) * d + (size_t)h * 64 + cc * 8) = pk;
+            *reinterpret_cast<uint4 *>(out + (row0 + j) * d + (size_t)h * 64 + cc * 8) = pk;
         }
     }
 }
@@ -760,8 +761,9 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
         hipLaunchKernelGGL(attn_bytes_kernel, dim3(1), dim3(256), 0, s, cnt_d, len_d, b, c, cf.n_head * cf.n_layer, ctr);
     const bool fused = g_ln_fusion && g_gemm_variant != 1 && ln_fusion_nq(d) != 0;
     const int nsl = Gpt2Ws::nslots(cf);
-    // ragged prefill (chunk forwards on the LN-folded path, unless the caller wants every row's hidden state back)
-    const bool ragged = fused && g_ragged_prefill > 0 && c > 1 && !all_hidden_d && M >= g_ragged_prefill;
+    // ragged batches (LN-folded path, unless the caller wants every row's hidden state back): by default only the chunk
+    // forwards of large batches qualify (b*c >= 2048); a decode forward with finished rows qualifies when the threshold is lowered
+    const bool ragged = fused && g_ragged_prefill > 0 && !all_hidden_d && M >= g_ragged_prefill;
     const int32_t *off = ragged ? w.off : nullptr, *row_map = ragged ? w.row_map : nullptr, *m_dev = ragged ? w.off + b : nullptr;
     if (ragged) hipLaunchKernelGGL(ragged_scan_kernel, dim3(1), dim3(1024), 0, s, cnt_d, b, c, w.off, w.row_map);
     auto ln = [&](const float *g, const float *be, uint16_t *y, const int32_t *idx, int rows) {
@@ -801,10 +803,10 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
         if (c == 1 && prof_kernel_events(PROF_ATTN_DECODE, -1.0, &ev_a, &ev_b)) {
             // the roofline kernel: start/stop events attached to the dispatch itself (kernel begin -> end, as rocprofv3 reports it)
             hipExtLaunchKernelGGL(attention_kernel<1>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, ev_a, ev_b, 0, (const uint16_t *)w.qkv, kc, vc,
-                                  cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d);
+                                  cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off);
         } else {
         ProfScope ps(c == 1 ? PROF_ATTN_DECODE : PROF_ATTN_CHUNK, s, -1.0);
-        if (c == 1) hipLaunchKernelGGL(attention_kernel<1>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
+        if (c == 1) hipLaunchKernelGGL(attention_kernel<1>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d, off);
         else if (g_attn_variant == 1 && c == 8 && !ragged) hipLaunchKernelGGL(attention_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
         else if (c == 16) hipLaunchKernelGGL(attention_chunk_mfma_kernel<16>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d, off);
         else hipLaunchKernelGGL(attention_chunk_mfma_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d, off);

@@ -90,6 +90,15 @@ class GPT2PPOPolicy(BatchedTextPolicy):
         if self._gen is None or self._gen.B != B or self._gen.tmax != tmax:
             self._gen = _Generator(self._engines(), B, tmax)
         gen = self._gen
+        # sequences of a batch end at different steps: run every forward on the compacted live rows (results are bit-identical)
+        _lib.lib().lmrl_gpt2_set_ragged_prefill(1)
+        try:
+            return self._generate(gen, prompts, text_history, done, B)
+        finally:
+            _lib.lib().lmrl_gpt2_set_ragged_prefill(2048)
+
+    def _generate(self, gen, prompts, text_history, done, B):
+        import torch
         gen.prefill(prompts)
         self.calls += 1                                     # one random stream per act() call, like the per-call key split
         # Generation loop without a host sync per token: live flags, the generated ids and the next decode inputs stay on the

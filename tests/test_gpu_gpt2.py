@@ -295,8 +295,8 @@ def test_ragged_prefill_is_bit_identical(dev):
     eng = GPT2Engine(cfg, init_hf_style_state_dict(cfg, seed=2), dev)
     B = 37
     g = torch.Generator().manual_seed(1)
-    plan = [(8, torch.randint(0, 9, (B,), generator=g)), (16, torch.randint(0, 17, (B,), generator=g)), (1, torch.ones(B, dtype=torch.int64)),
-            (8, torch.randint(3, 9, (B,), generator=g))]
+    plan = [(8, torch.randint(0, 9, (B,), generator=g)), (16, torch.randint(0, 17, (B,), generator=g)), (1, torch.randint(0, 2, (B,), generator=g)),
+            (1, torch.ones(B, dtype=torch.int64)), (8, torch.randint(3, 9, (B,), generator=g))]
     plan[0][1][0] = 0; plan[0][1][B - 1] = 8
     outs = []
     for min_slots in (1, 0):
