@@ -259,10 +259,10 @@ def main():
     # begin/end timestamps do not)
     try:
         import csv
-        prof = os.path.join(ROOT, "profiles", "r01i_bench_kernel_stats.csv")
+        prof = os.path.join(ROOT, "profiles", "r01j_bench_kernel_stats.csv")
         row = next(r for r in csv.DictReader(open(prof)) if "attention_kernel<1>" in r["Name"])
         roofline["rocprofv3_avg_launch_us"] = round(float(row["AverageNs"]) / 1e3, 2)
-        roofline["rocprofv3_summary"] = "profiles/r01i_bench_kernel_stats.csv"
+        roofline["rocprofv3_summary"] = "profiles/r01j_bench_kernel_stats.csv"
     except Exception:
         pass
     # other kernel classes: one extra, untimed episode with their brackets on (brackets cost ~2 us per launch)
