@@ -268,3 +268,52 @@ class WordleRolloutEngine:
         tok = self.traj["tokens"].cpu().numpy(); ia = self.traj["is_action"].cpu().numpy().astype(bool)
         rw = self.traj["reward"].cpu().numpy(); n = self.traj["n_tok"].cpu().numpy(); dn = self.traj["env_done"].cpu().numpy().astype(bool)
         return [(tok[b, :n[b]].copy(), ia[b, :n[b]].copy(), rw[b, :n[b]].copy(), bool(dn[b])) for b in range(self.B)]
+
+    # ---- the script-level call on the device engine -----------------------------------------------------------------
+    def interactions(self, decode=None):
+        """The finished episode as `List[List[InteractionTransition]]` — what `interact_environment` returns for the same
+        rollout (LLM_RL/environment.py:154-207): one transition per env step with the pre-action, post-action and
+        post-transition histories, the step reward and the done flag.  `decode(ids) -> str` defaults to the token table."""
+        from .environment import InteractionTransition, Text
+        dec = decode or (lambda ids: "".join(self.tokens.strings.get(int(i), "") for i in ids))
+        out = []
+        for tok, ia, rw, dn in self.token_trajectories():
+            hist, trans, i, n = [], [], 0, len(tok)
+            while i < n:                                   # split the record into runs of equal is_action = the Text items
+                j = i
+                while j < n and ia[j] == ia[i]:
+                    j += 1
+                # runs alternate: header, action, observation, action, ... (an action is always followed by its observation)
+                hist.append((Text(dec(tok[i:j]), bool(ia[i])), float(rw[j - 1]) if ia[i] else 0.0))
+                i = j
+            texts = [h for h, _ in hist]
+            for k, (t, r) in enumerate(hist):
+                if t.is_action:
+                    has_obs = k + 1 < len(texts)
+                    post = tuple(texts[: k + 2]) if has_obs else tuple(texts[: k + 1])
+                    last = not any(x.is_action for x in texts[k + 1:])
+                    trans.append(InteractionTransition(tuple(texts[:k]), tuple(texts[: k + 1]), post, r, bool(dn) and last))
+            out.append(trans)
+        return out
+
+    def text_env_eval(self, n_rollouts: int, seed_generator=None, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0,
+                      interaction_callback=None, decode=None):
+        """`text_env_eval(env, policy, n_rollouts, bsize=B)` (LLM_RL/environment.py:211-267) with env, policy and the whole
+        lock-step loop on the device: ceil(n / B) episodes batches, the same (interactions, summary) return value."""
+        inter, rewards, dones, lengths = [], [], [], []
+        batch_id = 0
+        while len(inter) < n_rollouts:
+            actual = min(n_rollouts - len(inter), self.B)
+            seeds = np.zeros(self.B, dtype=np.uint64)
+            seeds[:actual] = [next(seed_generator) for _ in range(actual)] if seed_generator is not None else \
+                np.random.randint(0, 2 ** 31 - 1, size=actual)
+            self.run_episode(seeds, temperature=temperature, top_k=top_k, sample_seed=sample_seed + (batch_id << 20))
+            batch_id += 1
+            for ep in self.interactions(decode)[:actual]:
+                inter.append(ep)
+                rewards.append(sum(t.reward for t in ep)); dones.append(ep[-1].done); lengths.append(len(ep))
+                if interaction_callback is not None:
+                    interaction_callback(ep)
+        summ = lambda x: dict(mean=np.mean(x), std=np.std(x), min=np.min(x), max=np.max(x))
+        return inter, dict(reward=summ(np.asarray(rewards, dtype=np.float32)), done=summ(np.asarray(dones, dtype=np.float32)), length=summ(lengths))
+

@@ -188,3 +188,43 @@ def test_shared_header_prefix_is_bit_identical_to_per_env_prefill(setup):
         ro.close()
     for a, b in zip(out[0], out[1]):
         assert torch.equal(a, b)
+
+
+def test_device_text_env_eval_matches_reference_protocol(setup):
+    """`WordleRolloutEngine.text_env_eval`: the (interactions, summary) of `text_env_eval` with env + policy + loop on the
+    device.  With scripted (steered) actions every transition must equal what the reference protocol yields on the oracle env."""
+    from lmrl_gym_amd import environment as E
+    from lmrl_gym_amd.envs import wordle as W
+    from lmrl_gym_amd.rollout import WordleRolloutEngine
+    from oracle.wordle import OracleWordleEnv
+    dev, cfg, sd, eng, vocab = setup
+    B = 64
+    ro = WordleRolloutEngine(eng, vocab, B, max_new_tokens=6)
+    rng = np.random.RandomState(3)
+    words = vocab.all_vocab
+    gi = rng.randint(0, len(words), size=(6, B))
+    packed = np.array([[W.pack_guess(words[k]) for k in row] for row in gi], dtype=np.uint32)
+    seeds = np.arange(B, dtype=np.uint64) + 700
+    ro.run_episode(seeds, temperature=1.0, sample_seed=9, scripted_guesses=torch.from_numpy(packed.view(np.int32)).to(dev), steer_strength=200.0)
+    torch.cuda.synchronize()
+    inter = ro.interactions()
+    assert len(inter) == B
+    for b, ep in enumerate(inter):
+        o = OracleWordleEnv(words, True, -10.0)
+        hist = tuple(E.Text(t, a) for t, a in o.reset(int(seeds[b])))
+        raw = o.reset(int(seeds[b]))
+        done, t = False, 0
+        while not done:
+            a = " ".join(words[gi[t][b]]) + "\n"
+            raw2, r, done = o.step(raw + ((a, True),))
+            tr = ep[t]
+            pre = tuple(E.Text(x, y) for x, y in raw); post_a = pre + (E.Text(a, True),); post_t = tuple(E.Text(x, y) for x, y in raw2)
+            assert tr.pre_action_history == pre and tr.post_action_history == post_a and tr.post_transition_history == post_t
+            assert tr.reward == float(r) and tr.done == done
+            raw, t = raw2, t + 1
+        assert len(ep) == t
+    # unsteered: the summary has the reference's shape and the episode count is honoured across batches
+    inter2, summary = ro.text_env_eval(70, seed_generator=iter(range(1000)), temperature=1.0, sample_seed=4)
+    assert len(inter2) == 70 and set(summary) == {"reward", "done", "length"} and set(summary["reward"]) == {"mean", "std", "min", "max"}
+    assert all(ep[-1].done for ep in inter2) and summary["length"]["max"] <= 6
+    ro.close()
