@@ -84,6 +84,14 @@ def _wordle_env(a):
     return vocab, W.ReformatWordleEnvironment(vocab, require_words_in_vocab=True, bad_word_reward=getattr(a, "bad_word_reward", -1.0))
 
 
+def _device_rollouts(engine, vocab, tok, bsize, bad_word_reward, max_new_tokens):
+    """Wordle rollouts with env + policy + loop on the device (`WordleRolloutEngine`); needs single-token letters/symbols, i.e. the
+    GPT-2 tokenizer or the Wordle adapter."""
+    from lmrl_gym_amd.rollout import WordleRolloutEngine, WordleTokenTable
+    table = getattr(tok, "table", None) or WordleTokenTable.from_tokenizer(tok)
+    return WordleRolloutEngine(engine, vocab, bsize, tokens=table, max_new_tokens=max_new_tokens, bad_word_reward=bad_word_reward)
+
+
 def _log(tag, obj):
     print(json.dumps({tag: obj}, default=lambda o: float(o) if isinstance(o, (np.floating, np.integer)) else str(o)), flush=True)
 
@@ -217,7 +225,13 @@ def cmd_bc_eval(a):
                            do_sample=a.policy_do_sample, temperature=a.policy_temperature, top_k=None if a.policy_top_k is None else int(a.policy_top_k),
                            top_p=a.policy_top_p, eos_token_id=tok.encode("\n")[0], out_str_process=lambda x: x.removesuffix("\n") + "\n")
     vocab, env = _wordle_env(a)
-    _, summary = E.text_env_eval(env, policy, n_rollouts=a.policy_n_rollouts, bsize=a.policy_bsize, seed_generator=iter(range(10 ** 9)), verbose=False)
+    if a.device_rollouts:       # same call, env + policy + loop on the GPU
+        ro = _device_rollouts(policy.engine, vocab, tok, a.policy_bsize, -1.0, min(a.policy_max_output_length, 12))
+        _, summary = ro.text_env_eval(a.policy_n_rollouts, seed_generator=iter(range(10 ** 9)), temperature=a.policy_temperature or 1.0,
+                                      top_k=int(a.policy_top_k or 0))
+        ro.close()
+    else:
+        _, summary = E.text_env_eval(env, policy, n_rollouts=a.policy_n_rollouts, bsize=a.policy_bsize, seed_generator=iter(range(10 ** 9)), verbose=False)
     _log("eval", summary)
 
 
@@ -250,6 +264,7 @@ def build_parser() -> argparse.ArgumentParser:
         p.add_argument("--model", default="random:tiny", help="checkpoint directory (reference layout or HF PyTorch) or random:<tiny|small>")
         p.add_argument("--vocab-file", default="wordle_official_400.txt")
         p.add_argument("--out", default=None)
+        p.add_argument("--device-rollouts", type=int, default=0, help="bc-eval: 1 = run the rollouts on the device-resident Wordle engine")
         _add(p, defaults)
     sub.choices["ilql"].add_argument("--train-data", required=True)
     sub.choices["ilql"].add_argument("--eval-data", default=None)
