@@ -137,7 +137,11 @@ class WordleRolloutEngine:
 
     def __init__(self, engine: GPT2Engine, vocab: W.Vocabulary, batch: int, tokens: Optional[WordleTokenTable] = None,
                  max_new_tokens: int = 6, require_words_in_vocab: bool = True, bad_word_reward: float = -10.0,
-                 traj_cap: int = 128, share_header: bool = True):
+                 traj_cap: int = 128, share_header: bool = True, value_engine: Optional[GPT2Engine] = None, q1_head: Optional[dict] = None,
+                 q2_head: Optional[dict] = None, beta: float = 0.0):
+        """`value_engine` + `q1_head` (+ `q2_head`) + `beta` turn the policy into the ILQL value policy
+        (`GPT2ValueRLGeneration`, value_rl_base/gpt2/generation.py:97-119): `engine` is pi_beta, `value_engine` the value base
+        whose last hidden state feeds the Q heads (`policies.heads_to_engine_layout` dicts); logits = pi_beta + beta * min(Q1, Q2)."""
         import torch
         t = torch
         self.eng, self.vocab, self.B = engine, vocab, batch
@@ -151,6 +155,11 @@ class WordleRolloutEngine:
         # every env starts from the same header text: its K/V are computed once per episode on a 1-env session and broadcast
         self.share_header = share_header
         self.ses1 = engine.session(1, 16) if share_header else None
+        self.veng, self.q1, self.q2, self.beta = value_engine, q1_head, q2_head, float(beta)
+        assert (value_engine is None) == (q1_head is None), "value_engine and q1_head come together"
+        self.vses = value_engine.session(batch, traj_cap) if value_engine is not None else None
+        self.vses1 = value_engine.session(1, 16) if value_engine is not None and share_header else None
+        self.qh = [t.zeros(batch, value_engine.cfg.d_model, dtype=t.bfloat16, device=self.dev) for _ in range(2)] if value_engine is not None else None
         ct = self.tokens.c_struct()
         cls = np.ascontiguousarray(self.tokens.token_class(engine.cfg.vocab))
         self._tok = self._L.lmrl_wordle_tok_create(ctypes.byref(ct), cls.ctypes.data, engine.cfg.vocab, max_new_tokens, traj_cap)
@@ -226,14 +235,17 @@ class WordleRolloutEngine:
         `next()`, so a host loop can interleave several engines on different HIP streams."""
         L, sp, tr, B = self._L, _lib.stream_ptr(), ctypes.byref(self._ctraj), self.B
         self.env.reset_device(seeds if not isinstance(seeds, np.ndarray) else np.asarray(seeds, dtype=np.uint64))
-        self.ses.reset()
+        pairs = [(self.ses, self.ses1)] + ([(self.vses, self.vses1)] if self.vses is not None else [])     # (pi_beta), (value base)
+        for ses, _ in pairs:
+            ses.reset()
         self._ck(L.lmrl_wordle_tok_begin(self._tok, tr, _lib.ptr(self.chunk_tok), _lib.ptr(self.chunk_cnt), B, sp), "tok_begin")
-        if self.share_header:
-            self.ses1.reset()
-            self.ses1.forward(self.chunk_tok[:8], self.chunk_cnt[:1], 8)      # env 0's header chunk = everybody's header chunk
-            self.ses.broadcast_prefix_from(self.ses1, len(self.tokens.header))
-        else:
-            self.ses.forward(self.chunk_tok, self.chunk_cnt, 8)
+        for ses, ses1 in pairs:
+            if self.share_header:
+                ses1.reset()
+                ses1.forward(self.chunk_tok[:8], self.chunk_cnt[:1], 8)      # env 0's header chunk = everybody's header chunk
+                ses.broadcast_prefix_from(ses1, len(self.tokens.header))
+            else:
+                ses.forward(self.chunk_tok, self.chunk_cnt, 8)
         yield
         logits_out = None
         if top_k > 0:
@@ -245,21 +257,31 @@ class WordleRolloutEngine:
                 self._ck(L.lmrl_wordle_tok_steer(self._tok, _lib.ptr(scripted_guesses[turn]), -1, _lib.ptr(self.steer), B, sp), "tok_steer")
             for k in range(self.max_new):
                 steer = self.steer[min(k, 5)] if steered else None
-                p = SampleParams(temperature, top_k, sample_seed, self.sample_step, steer_strength, 0.0, self.tokens.pad,
+                p = SampleParams(temperature, top_k, sample_seed, self.sample_step, steer_strength, self.beta, self.tokens.pad,
                                  _lib.ptr(epoch))
                 self.sample_step += 1
-                self.ses.sample(p, steer_tok=steer, active=self.traj["gen_active"], logits_out=logits_out)
+                qops = [None, None]
+                if self.vses is not None:     # Q heads on the value base's last hidden state: relu(dense1) here, dense2 inside the sampler
+                    dv = self.veng.cfg.d_model
+                    for i, head in enumerate((self.q1, self.q2)):
+                        if head is not None:
+                            self._ck(L.lmrl_gemm_bf16(_lib.ptr(self.vses.last_hidden), _lib.ptr(head["w1"]), _lib.ptr(head["b1"]), _lib.ptr(self.qh[i]),
+                                                      B, dv, dv, dv, dv, dv, 4, sp), "q head dense1 + relu")
+                            qops[i] = (self.qh[i], head["w2"], head["b2"])
+                self.ses.sample(p, steer_tok=steer, active=self.traj["gen_active"], logits_out=logits_out, q1=qops[0], q2=qops[1])
                 self._ck(L.lmrl_wordle_tok_accept(self._tok, tr, _lib.ptr(self.ses.token), k, _lib.ptr(self.next_tok),
                                                   _lib.ptr(self.next_cnt), None, B, sp), "tok_accept")
                 if k < self.max_new - 1:
-                    self.ses.forward(self.next_tok, self.next_cnt, 1)
+                    for ses, _ in pairs:
+                        ses.forward(self.next_tok, self.next_cnt, 1)
                     yield
             self._ck(L.lmrl_wordle_tok_guess(self._tok, tr, _lib.ptr(self.guess), _lib.ptr(self.active), B, sp), "tok_guess")
             self.env.step_device(self.guess, self.active)
             self._ck(L.lmrl_wordle_tok_observe(self._tok, tr, _lib.ptr(self.env.obs), _lib.ptr(self.env.reward), _lib.ptr(self.env.flags),
                                                _lib.ptr(self.chunk_tok), _lib.ptr(self.chunk_cnt), B, sp), "tok_observe")
             if turn < n_turns - 1:
-                self.ses.forward(self.chunk_tok, self.chunk_cnt, 8)
+                for ses, _ in pairs:
+                    ses.forward(self.chunk_tok, self.chunk_cnt, 8)
             yield
 
     def token_trajectories(self):

@@ -129,6 +129,16 @@ def cmd_ilql(a):
 
     def evaluate():
         hl = lambda h: heads_to_engine_layout({k: v.detach().cpu() for k, v in h.p.items()}, cfg.vocab_padded, dev)
+        if a.device_rollouts:       # ILQL value policy, env and loop on the GPU
+            from lmrl_gym_amd.rollout import WordleRolloutEngine, WordleTokenTable
+            table = getattr(tok, "table", None) or WordleTokenTable.from_tokenizer(tok)
+            ro = WordleRolloutEngine(pi_beta, vocab, a.policy_bsize, tokens=table, max_new_tokens=min(a.policy_max_output_length, 12),
+                                     bad_word_reward=a.bad_word_reward, value_engine=_engine(cfg, base.p), q1_head=hl(tr.q1), q2_head=hl(tr.q2),
+                                     beta=a.beta)
+            _, summary = ro.text_env_eval(a.policy_n_rollouts, seed_generator=iter(range(10 ** 9)), temperature=a.policy_temperature or 1.0,
+                                          top_k=int(a.policy_top_k or 0))
+            ro.close()
+            return summary
         pol = GPT2ValuePolicy(pi_beta, _engine(cfg, base.p), hl(tr.q1), hl(tr.q2), a.beta, tok, max_input_length=a.policy_max_input_length,
                               max_new_tokens=a.policy_max_output_length, do_sample=a.policy_do_sample, temperature=a.policy_temperature,
                               top_k=None if a.policy_top_k is None else int(a.policy_top_k), top_p=a.policy_top_p, eos_token_id=tok.encode("\n")[0],
@@ -264,7 +274,7 @@ def build_parser() -> argparse.ArgumentParser:
         p.add_argument("--model", default="random:tiny", help="checkpoint directory (reference layout or HF PyTorch) or random:<tiny|small>")
         p.add_argument("--vocab-file", default="wordle_official_400.txt")
         p.add_argument("--out", default=None)
-        p.add_argument("--device-rollouts", type=int, default=0, help="bc-eval: 1 = run the rollouts on the device-resident Wordle engine")
+        p.add_argument("--device-rollouts", type=int, default=0, help="bc-eval / ilql evaluation: 1 = run the rollouts on the device-resident Wordle engine")
         _add(p, defaults)
     sub.choices["ilql"].add_argument("--train-data", required=True)
     sub.choices["ilql"].add_argument("--eval-data", default=None)

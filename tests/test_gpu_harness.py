@@ -171,6 +171,8 @@ def test_harness_script_subcommands_at_toy_scale(tmp_path, capsys):
     H.main(["ilql", "--train-data", data, "--epochs", "1", "--max-steps", "2", "--train-bsize", "8", "--max-length", "80", "--log-every", "1",
             "--policy-n-rollouts", "4", "--policy-bsize", "4", "--policy-max-input-length", "88", "--policy-max-output-length", "8", "--beta", "4",
             "--out", str(tmp_path / "ckpt")])
+    H.main(["ilql", "--train-data", data, "--epochs", "1", "--max-steps", "1", "--train-bsize", "8", "--max-length", "80", "--policy-n-rollouts", "5",
+            "--policy-bsize", "4", "--beta", "4", "--device-rollouts", "1"])
     assert os.path.exists(tmp_path / "ckpt" / "base" / "params.msgpack") and os.path.exists(tmp_path / "ckpt" / "q1_head" / "params.msgpack")
     H.main(["ppo", "--bc-data", data, "--n-rollouts", "4", "--rollout-bsize", "4", "--ppo-data-bsize", "4", "--train-bsize", "2", "--max-steps", "1",
             "--max-input-length", "72", "--max-output-length", "12"])
@@ -180,7 +182,7 @@ def test_harness_script_subcommands_at_toy_scale(tmp_path, capsys):
     H.main(["maze-eval", "--max-steps", "3", "--generation-bsize", "8", "--max-input-length", "160", "--max-output-length", "6"])
     lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
     tags = [next(iter(l)) for l in lines]
-    assert tags.count("eval") == 4 and "gen_data" in tags and "data_collection" in tags and "maze_eval" in tags and "train" in tags
+    assert tags.count("eval") == 5 and "gen_data" in tags and "data_collection" in tags and "maze_eval" in tags and "train" in tags
     me = next(l["maze_eval"] for l in lines if "maze_eval" in l)
     assert me["n"] == 26 and 0.0 <= me["move_accuracy"] <= 100.0
 

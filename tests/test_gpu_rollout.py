@@ -228,3 +228,48 @@ def test_device_text_env_eval_matches_reference_protocol(setup):
     assert len(inter2) == 70 and set(summary) == {"reward", "done", "length"} and set(summary["reward"]) == {"mean", "std", "min", "max"}
     assert all(ep[-1].done for ep in inter2) and summary["length"]["max"] <= 6
     ro.close()
+
+
+def test_ilql_value_policy_on_the_device_engine(setup):
+    """pi_beta + beta * min(Q1, Q2) inside the device-resident loop (value_rl_base/gpt2/generation.py:97-119): every greedy
+    token must be the argmax of the oracle's perturbed logits on the recorded prefix (two KV sessions, heads fused in the sampler)."""
+    from lmrl_gym_amd.gpt2 import GPT2Engine, init_hf_style_state_dict
+    from lmrl_gym_amd.policies import heads_to_engine_layout
+    from lmrl_gym_amd.rollout import WordleRolloutEngine
+    from oracle import gpt2 as O, rl
+    dev, cfg, sd, eng, vocab = setup
+    sd_v = O.round_weights_to_bf16(init_hf_style_state_dict(cfg, seed=6))
+    sd_v["wte.weight"] = (sd_v["wte.weight"] * 8).to(torch.bfloat16).float()
+    eng_v = GPT2Engine(cfg, sd_v, dev)
+    g = torch.Generator().manual_seed(5)
+    d, V = cfg.d_model, cfg.vocab
+    bf = lambda x: x.to(torch.bfloat16).float()
+    mk = lambda: {"dense1.kernel": bf(torch.randn(d, d, generator=g) * 0.2), "dense1.bias": torch.randn(d, generator=g) * 0.1,
+                  "dense2.kernel": bf(torch.randn(d, V, generator=g) * 0.3), "dense2.bias": torch.randn(V, generator=g) * 0.1}
+    h1, h2 = mk(), mk()
+    beta = 2.0
+    B = 24
+    ro = WordleRolloutEngine(eng, vocab, B, max_new_tokens=4, value_engine=eng_v, q1_head=heads_to_engine_layout(h1, cfg.vocab_padded, dev),
+                             q2_head=heads_to_engine_layout(h2, cfg.vocab_padded, dev), beta=beta)
+    ro.run_episode(np.arange(B, dtype=np.uint64), temperature=0.0, n_turns=2)
+    torch.cuda.synchronize()
+    checked = 0
+    nl = ro.tokens.newline
+    for tok, ia, rw, dn in ro.token_trajectories()[:6]:
+        ids = torch.from_numpy(tok.astype(np.int64))[None]
+        lg = O.forward(sd, ids, cfg.n_head, dtype=torch.float64)[0, :, :V]
+        _, hid = O.forward(sd_v, ids, cfg.n_head, dtype=torch.float64, return_hidden=True)
+        hb = hid[0].to(torch.bfloat16).double()
+        q = [rl.mlp_head(hb, p["dense1.kernel"], p["dense1.bias"], p["dense2.kernel"], p["dense2.bias"]) for p in (h1, h2)]
+        pert = lg + beta * torch.minimum(q[0], q[1])
+        run = 0
+        for i in range(1, len(tok)):
+            run = run + 1 if ia[i] else 0
+            if not ia[i] or run > 4:              # a 5th action token is the forced newline
+                continue
+            top2 = pert[i - 1].topk(2)
+            if float(top2.values[0] - top2.values[1]) > 0.1:
+                assert int(top2.indices[0]) == int(tok[i]), (i, int(top2.indices[0]), int(tok[i]))
+                checked += 1
+    assert checked >= 20, checked
+    ro.close()
