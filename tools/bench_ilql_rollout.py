@@ -1,0 +1,36 @@
+"""configs[2] rollouts: ILQL value policy (pi_beta + beta*min(Q1,Q2); two GPT-2-small transformers + two MLP Q heads 768->768->V)
+on the device-resident Wordle loop, 1024 envs, steered synthetic workload as in bench.py.  Prints env-steps/s."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import lmrl_gym_amd  # noqa
+from lmrl_gym_amd import _lib
+from lmrl_gym_amd.envs import wordle as W
+from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine
+from lmrl_gym_amd.policies import heads_to_engine_layout
+from lmrl_gym_amd.rollout import WordleRolloutEngine
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import scripted_guesses
+
+dev = _lib.require_gpu()
+cfg = GPT2Config.gpt2_small()
+pi_beta, base = GPT2Engine.random_init(cfg, seed=0, device=dev), GPT2Engine.random_init(cfg, seed=1, device=dev)
+g = torch.Generator().manual_seed(0)
+d, V = cfg.d_model, cfg.vocab
+mk = lambda: heads_to_engine_layout({"dense1.kernel": torch.randn(d, d, generator=g) * 0.02, "dense1.bias": torch.zeros(d),
+                                     "dense2.kernel": torch.randn(d, V, generator=g) * 0.002, "dense2.bias": torch.full((V,), -4.4)}, cfg.vocab_padded, dev)
+vocab = W.Vocabulary.builtin("wordle_official_400.txt")
+B, steps, warm = 1024, 4, 1
+ro = WordleRolloutEngine(pi_beta, vocab, B, max_new_tokens=6, bad_word_reward=-10.0, value_engine=base, q1_head=mk(), q2_head=mk(), beta=32.0)
+guesses = torch.from_numpy(scripted_guesses(vocab.all_vocab, steps + warm, W.N_TRIES, B, seed=1).view(np.int32)).to(dev)
+seeds = torch.arange((steps + warm) * B, dtype=torch.int64, device=dev).view(steps + warm, B)
+ro.capture_episode(temperature=1.0, sample_seed=5, steer_strength=30.0 + 32.0 * 5, scripted=True)
+torch.cuda.synchronize()
+n = torch.zeros((), dtype=torch.int64, device=dev)
+for i in range(warm):
+    ro.replay_episode(seeds[i], guesses[i])
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(warm, warm + steps):
+    ro.replay_episode(seeds[i], guesses[i]); n += ro.traj["n_steps"].sum()
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print("ILQL value-policy rollouts: %.1f env-steps/s  (%.2f ms per 1024-env episode, %d env steps)" % (int(n) / dt, dt * 1e3 / steps, int(n)))
