@@ -194,8 +194,14 @@ def cmd_ppo(a):
     vocab, env = _wordle_env(a)
     step = 0
     for rnd in range(a.n_rounds):
-        raw, summary = E.text_env_eval(env, policy, n_rollouts=a.n_rollouts, bsize=a.rollout_bsize, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)),
-                                       verbose=False)
+        if a.device_rollouts:       # env + policy + lock-step loop on the GPU; same (interactions, summary) as text_env_eval
+            ro = _device_rollouts(policy.engine, vocab, tok, a.rollout_bsize, a.bad_word_reward, min(a.max_output_length, 12))
+            raw, summary = ro.text_env_eval(a.n_rollouts, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)), temperature=a.policy_temperature or 1.0,
+                                            top_k=int(a.policy_top_k or 0), sample_seed=rnd)
+            ro.close()
+        else:
+            raw, summary = E.text_env_eval(env, policy, n_rollouts=a.n_rollouts, bsize=a.rollout_bsize, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)),
+                                           verbose=False)
         chains = text_trajectory_chains_from_interactions(raw, tok, max_len, a.gamma)
         datas, kls = inf.get_ppo_data_from_text_trajectory_chain(chains, bsize=a.ppo_data_bsize, max_length=max_len, gamma=a.gamma, lam=a.lam,
                                                                  kl_weight=ctl.value, use_advantage_whitening=a.use_advantage_whitening)
@@ -274,7 +280,7 @@ def build_parser() -> argparse.ArgumentParser:
         p.add_argument("--model", default="random:tiny", help="checkpoint directory (reference layout or HF PyTorch) or random:<tiny|small>")
         p.add_argument("--vocab-file", default="wordle_official_400.txt")
         p.add_argument("--out", default=None)
-        p.add_argument("--device-rollouts", type=int, default=0, help="bc-eval / ilql evaluation: 1 = run the rollouts on the device-resident Wordle engine")
+        p.add_argument("--device-rollouts", type=int, default=0, help="1 = run the Wordle rollouts (bc-eval, ilql evaluation, ppo data collection) on the device-resident engine")
         _add(p, defaults)
     sub.choices["ilql"].add_argument("--train-data", required=True)
     sub.choices["ilql"].add_argument("--eval-data", default=None)
