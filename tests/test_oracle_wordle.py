@@ -42,6 +42,18 @@ def test_mt19937_vs_stdlib_random_seeds():
         assert _stream(seed, 700) == [r.getrandbits(32) for _ in range(700)]
 
 
+def test_mt19937_survey_sanity_value():
+    """Random(123): getrandbits(9) x3 = 26, 137, 44, then choice(range(431)) = 393."""
+    r = random.Random(123)
+    assert [r.getrandbits(9) for _ in range(3)] == [26, 137, 44] and r.choice(range(431)) == 393
+    s = _stream(123, 8)
+    assert [w >> 23 for w in s[:3]] == [26, 137, 44]
+    k, i = (431).bit_length(), 3                     # _randbelow(431): 9-bit draws until r < 431
+    while (s[i] >> (32 - k)) >= 431:
+        i += 1
+    assert s[i] >> (32 - k) == 393
+
+
 @pytest.mark.parametrize("tag,fname", [("v431", "wordle_official_400.txt"), ("v2315", "wordle_official.txt")])
 def test_wordle_traces(tag, fname):
     g = load_golden(f"wordle_traces_{tag}.json")
