@@ -247,10 +247,10 @@ def main():
     # command; gfx950 FETCH_SIZE counts 64 B per 128 B request for wide coalesced loads -> doubled, per the microarch
     # guide).  Not measurable from inside the process, so the committed summary is reported, with its source.
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01j_pmc_fetch_write.json")))
         key = next(k for k in pmc if "attention_kernel<1>" in k)
         roofline["traffic"] = round((2.0 * pmc[key]["fetch_kb_avg"] + pmc[key]["write_kb_avg"]) * 1024)
-        roofline["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_fetch_write.json)"
+        roofline["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01j_pmc_fetch_write.json)"
         roofline["algorithmic_bytes_per_launch"] = round(work.value / max(n.value, 1))
     except Exception:
         roofline["traffic"] = None

@@ -1,0 +1,27 @@
+# HBM traffic per kernel (source of bench.py's roofline.traffic): FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes
+# (they do not fit one pass: microarch guide §PMC), kernel-trace only, each pass under its own timeout.
+# Output: gpurun_out/pmc_fetch_write.json  {kernel: {launches, fetch_kb_avg, write_kb_avg}}  (units: KB as reported; the
+# gfx950 FETCH_SIZE x2 correction is applied by the reader, not here).
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python /root/repo/bench.py --graph 0 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || echo "pass $c failed/timeout"
+done
+python - <<'PY'
+import csv, glob, json, collections
+out = collections.defaultdict(dict)
+for c, key in (("FETCH_SIZE", "fetch_kb_avg"), ("WRITE_SIZE", "write_kb_avg")):
+    fs = glob.glob(f"/tmp/pmc_{c}/**/*counter_collection.csv", recursive=True)
+    if not fs:
+        continue
+    agg = collections.defaultdict(float); n = collections.Counter()
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] != c:
+            continue
+        k = r["Kernel_Name"][:60]
+        agg[k] += float(r["Counter_Value"]); n[k] += 1
+    for k in agg:
+        out[k]["launches"] = n[k]; out[k][key] = agg[k] / n[k]
+json.dump(out, open("/root/repo/gpurun_out/pmc_fetch_write.json", "w"), indent=1)
+for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("fetch_kb_avg", 0) * kv[1].get("launches", 0))[:10]:
+    print("%-60s n=%5d fetch %10.1f KB  write %10.1f KB" % (k, v.get("launches", 0), v.get("fetch_kb_avg", -1), v.get("write_kb_avg", -1)))
+PY
