@@ -7,6 +7,7 @@ from typing import Dict, List, NamedTuple
 import numpy as np
 
 from .. import _lib
+from .. import dist as D
 from ..train import ops
 from .common import BlockingStrategy, block_sequences, stats_from_sums
 from .ppo import _t
@@ -70,6 +71,7 @@ def mc_loss_device(q, ce, attn, sta, returns, *, cql_weight):
     n_el, dev = q.numel(), q.device
     n_d = torch.zeros(1, dtype=torch.float64, device=dev)
     ops.mask_sum(sta, attn, n_el, n_d)
+    D.allreduce_sum_(n_d)     # data parallel: divide by the GLOBAL token count, as PPO / ILQL do (dist.py convention)
     nb, ns = L.lmrl_mc_loss_blocks(n_el), L.lmrl_mc_loss_nstats()
     part = torch.empty((nb, ns), dtype=torch.float64, device=dev)
     dq, coef = torch.empty_like(q), torch.empty_like(q)
@@ -78,6 +80,11 @@ def mc_loss_device(q, ce, attn, sta, returns, *, cql_weight):
     P = part.cpu().numpy()
     s = P.sum(axis=0)
     s[5], s[6], s[9], s[10] = P[:, 5].min(), P[:, 6].max(), P[:, 9].min(), P[:, 10].max()
+    if D.is_distributed():    # logged sums / mins / maxes of all ranks -> the log dict equals the single-process one
+        mn_i, mx_i = [5, 9], [6, 10]
+        add_i = [k for k in range(len(s)) if k not in mn_i + mx_i]
+        a, mn, mx = D.reduce_stat_partials(s[add_i], s[mn_i], s[mx_i])
+        s[add_i], s[mn_i], s[mx_i] = a, mn, mx
     n = float(n_d.item())
     f = np.float32
     q_loss, cql = s[0] / n, s[1] / n

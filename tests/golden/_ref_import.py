@@ -83,6 +83,12 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         return None
 
     def create_module(self, spec):
+        if spec.name in _SHIM_MODULES:      # numpy-backed jax.numpy / jax.nn / jax.lax / optax (tests/golden/_jnp_shim.py)
+            real = _SHIM_MODULES[spec.name]
+            m = _StubModule(spec.name)
+            m.__path__ = []
+            m.__dict__.update({k: v for k, v in real.__dict__.items() if not k.startswith("__")})
+            return m
         m = _StubModule(spec.name)
         m.__path__ = []
         return m
@@ -92,9 +98,24 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
             module.colored = lambda s, *a, **k: s
         if module.__name__ == "IPython":
             module.embed = lambda *a, **k: None
+        if module.__name__ == "jax" and _SHIM_MODULES:      # `jax.nn.one_hot` / `jax.lax.stop_gradient` are reached by attribute
+            import importlib
+            for sub in ("numpy", "nn", "lax"):
+                setattr(module, sub, importlib.import_module("jax." + sub))
 
 
-def install():
+_SHIM_MODULES = {}
+
+
+def install(jnp_shim: bool = False):
+    """jnp_shim=True additionally backs `jax.numpy`, `jax.nn`, `jax.lax` and `optax` with the numpy restatements of
+    tests/golden/_jnp_shim.py so that the reference's loss functions execute (every other jax/flax name stays a placeholder)."""
+    if jnp_shim and not _SHIM_MODULES:
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import _jnp_shim
+        _SHIM_MODULES.update(_jnp_shim.make_modules())
+        assert not any(k in sys.modules for k in _SHIM_MODULES), "install(jnp_shim=True) must run before the reference is imported"
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     if not any(isinstance(f, _StubFinder) for f in sys.meta_path):
