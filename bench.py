@@ -103,7 +103,6 @@ def main():
     ap.add_argument("--vocab-file", default="wordle_official_400.txt")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="1: capture the episode into a hipGraph and replay it (default); 0: eager launches")
-    ap.add_argument("--gemm-variant", type=int, default=0, help="tuning hook: forwarded to lmrl_gemm_set_variant")
     ap.add_argument("--share-header", type=int, default=1, help="1 (default): the K/V rows of the header text every env starts from are computed "
                     "once per episode and broadcast to all envs (bit-identical to per-env prefill); 0: prefill the header per env")
     ap.add_argument("--streams", type=int, default=1, help="split the batch into this many sub-batches on separate HIP streams")
@@ -133,7 +132,6 @@ def main():
             dist.init_process_group(backend)
 
     L = _lib.lib()
-    L.lmrl_gemm_set_variant(args.gemm_variant)
     vocab = W.Vocabulary.builtin(args.vocab_file)
     cfg = GPT2Config.gpt2_small()
     eng = GPT2Engine.random_init(cfg, seed=0, device=dev)

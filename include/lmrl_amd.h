@@ -186,9 +186,16 @@ size_t lmrl_gpt2_ws_bytes(const lmrl_gpt2 *m, int b, int c);
  * tokens tokens_d[b*C + j] at positions len_d[b] + j; their K/V rows are appended to the cache and len_d[b] is
  * advanced by cnt_d[b].  last_hidden_d (bf16 [B][d], optional): ln_f of each env's LAST new token (row untouched
  * when cnt_d[b] == 0).  all_hidden_d (bf16 [B*C][d], optional): ln_f of every row.
+ * `flags` (LMRL_FWD_*, 0 = defaults) select per-CALL variants; there is no process-wide forward state, so sessions with
+ * different settings may be interleaved on any streams.  Every variant computes the same function (the LN-folded and
+ * stand-alone paths within bf16 rounding of each other, ragged vs padded bit-identically).
  */
+#define LMRL_FWD_LN_STANDALONE 1u  /* stand-alone LayerNorm launches instead of LN folded into the neighbouring GEMMs (A/B, cross-check) */
+#define LMRL_FWD_RAGGED_ALWAYS 2u  /* run on the compacted rows (sum of cnt_d) whatever the batch size; default: only when b*c >= 2048 */
+#define LMRL_FWD_RAGGED_NEVER  4u  /* always run all b*c slots */
+#define LMRL_FWD_ATTN_VALU     8u  /* c == 8 only: VALU chunk attention instead of the MFMA kernel (cross-check) */
 int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int32_t *tokens_d, const int32_t *cnt_d,
-                      int32_t *len_d, int b, int c, void *last_hidden_d, void *all_hidden_d, void *stream);
+                      int32_t *len_d, int b, int c, void *last_hidden_d, void *all_hidden_d, unsigned flags, void *stream);
 
 /*
  * Shared prompt prefix: copy positions [0, n_pos) of the single env of a 1-env KV session (src) into all `b` envs of dst,
@@ -204,16 +211,9 @@ int lmrl_gpt2_kv_broadcast(const lmrl_gpt2 *m, const void *src_kv_d, int src_tma
 int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda,
                    int ldc, int n_store, int epilogue, void *stream);
 
-/* bench/test hook: 0 = default GEMM kernels (global_load_lds ring), 1 = round-1 register-staged kernels */
+/* TOOLS ONLY (tools/bench_gemm.py tile-configuration sweeps; never called by the package): forces a GEMM tile configuration,
+ * 0 = the shape policy, 1 = the round-1 register-staged kernels, 10.. = fixed tiles. */
 void lmrl_gemm_set_variant(int v);
-/* bench/test hook: 0 = MFMA chunk attention (default), 1 = VALU chunk attention */
-void lmrl_attn_set_variant(int v);
-/* A/B hook: 1 (default) folds every LayerNorm but ln_f into the neighbouring GEMMs (no stand-alone LN launches);
- * 0 runs the stand-alone LayerNorm kernels. */
-void lmrl_gpt2_set_ln_fusion(int on);
-/* Ragged prefill: chunk (c > 1) forwards with b*c >= min_slots (default 2048; 0 = never) run on the compacted rows (sum of
- * cnt_d) instead of all b*c slots; results are bit-identical (every output row depends on its own input row only). */
-void lmrl_gpt2_set_ragged_prefill(int min_slots);
 
 /* ------------------------------------------------------------------------------------------
  * Fused LM-head + sampling (csrc/sampler.hip).  Replaces logits[:, -1] -> warpers -> jax.random.categorical in

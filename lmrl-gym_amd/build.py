@@ -2,13 +2,17 @@
 
     python lmrl-gym_amd/build.py [--force] [--verbose]
 
-Every csrc/*.hip is compiled to csrc/_obj/*.o (only when stale) and linked into
-lmrl-gym_amd/liblmrl_amd.so.  The .so is git-ignored but travels to the GPU box with the tree.
+Every csrc/*.hip is compiled to csrc/_obj/*.o and linked into lmrl-gym_amd/liblmrl_amd.so.  Staleness is decided by
+CONTENT, not mtime: csrc/_obj/manifest.json records, per object, the sha256 of its source + every header under csrc/ and
+include/ + the compiler flags + `hipcc --version`; an object (and the .so) is reused only when that digest matches, so a
+shipped `_obj/` can never be linked against changed sources.  The .so is git-ignored but travels to the GPU box with the tree.
 """
 from __future__ import annotations
 
 import concurrent.futures as cf
 import glob
+import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -30,24 +34,36 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (ROCm toolchain required to build liblmrl_amd.so)")
 
 
-def _stale(target: str, deps) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _sha(paths, extra: str = "") -> str:
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())
+    return h.hexdigest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "lmrl_amd.h"), __file__]
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "lmrl_amd.h")]
+    ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    common = _sha(headers, extra=" ".join(FLAGS) + ver)
+    man_path = os.path.join(OBJ, "manifest.json")
+    try:
+        with open(man_path) as f:
+            manifest = json.load(f)
+    except Exception:
+        manifest = {}
     jobs = []
     objs = []
+    digests = {}
     for s in srcs:
-        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        name = os.path.basename(s)[:-4]
+        o = os.path.join(OBJ, name + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + headers):
+        digests[name] = _sha([s], extra=common)
+        if force or not os.path.exists(o) or manifest.get(name) != digests[name]:
             jobs.append((s, o))
 
     def compile_one(job):
@@ -65,13 +81,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
-    if jobs or force or _stale(SO, objs):
+    link_digest = hashlib.sha256("".join(digests[k] for k in sorted(digests)).encode()).hexdigest()
+    if jobs or force or not os.path.exists(SO) or manifest.get("__so__") != link_digest:
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", SO] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    digests["__so__"] = link_digest
+    with open(man_path, "w") as f:
+        json.dump(digests, f, indent=1, sort_keys=True)
     return SO
 
 

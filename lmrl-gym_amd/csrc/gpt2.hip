@@ -646,10 +646,8 @@ __global__ void attn_bytes_kernel(const int32_t *cnt, const int32_t *len, int B,
     if (threadIdx.x == 0) atomicAdd(counter, (red[0] + red[1] + red[2] + red[3]) * (unsigned long long)heads_x_layers);
 }
 
-int g_gemm_variant = 0;
-int g_attn_variant = 0;   // test/bench hook: 1 = VALU chunk attention
-int g_ragged_prefill = 2048; // chunk forwards with >= this many slots run on the compacted (sum of cnt) rows; 0 = never (A/B hook)
-int g_ln_fusion = 1;      // 0 = stand-alone LayerNorm launches (A/B hook), 1 = LN folded into the neighbouring GEMMs
+int g_gemm_variant = 0;   // tools/ only (tools/bench_gemm.py tile-configuration sweeps): never touched by the product path
+constexpr int kRaggedAutoMinSlots = 2048;   // default policy: forwards with >= this many slots run on the compacted (sum of cnt) rows
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -748,7 +746,7 @@ size_t lmrl_gpt2_kv_bytes(const lmrl_gpt2 *m, int b, int tmax) {
 size_t lmrl_gpt2_ws_bytes(const lmrl_gpt2 *m, int b, int c) { return Gpt2Ws::bytes(m->cfg, (size_t)b * c, b); }
 
 int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int32_t *tokens_d, const int32_t *cnt_d,
-                      int32_t *len_d, int b, int c, void *last_hidden_d, void *all_hidden_d, void *stream) {
+                      int32_t *len_d, int b, int c, void *last_hidden_d, void *all_hidden_d, unsigned flags, void *stream) {
     LMRL_REQUIRE(m && kv_d && ws_d && tokens_d && cnt_d && len_d && b > 0, "lmrl_gpt2_forward: bad argument");
     LMRL_REQUIRE(c == 1 || c == 8 || c == 16, "lmrl_gpt2_forward: chunk width must be 1, 8 or 16");
     const lmrl_gpt2_config &cf = m->cfg;
@@ -759,11 +757,14 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
 
     if (unsigned long long *ctr = prof_byte_counter(c == 1 ? PROF_ATTN_DECODE : PROF_ATTN_CHUNK))
         hipLaunchKernelGGL(attn_bytes_kernel, dim3(1), dim3(256), 0, s, cnt_d, len_d, b, c, cf.n_head * cf.n_layer, ctr);
-    const bool fused = g_ln_fusion && g_gemm_variant != 1 && ln_fusion_nq(d) != 0;
+    LMRL_REQUIRE(!((flags & LMRL_FWD_RAGGED_ALWAYS) && (flags & LMRL_FWD_RAGGED_NEVER)), "lmrl_gpt2_forward: contradictory ragged flags");
+    const bool fused = !(flags & LMRL_FWD_LN_STANDALONE) && g_gemm_variant != 1 && ln_fusion_nq(d) != 0;
     const int nsl = Gpt2Ws::nslots(cf);
-    // ragged batches (LN-folded path, unless the caller wants every row's hidden state back): by default only the chunk
-    // forwards of large batches qualify (b*c >= 2048); a decode forward with finished rows qualifies when the threshold is lowered
-    const bool ragged = fused && g_ragged_prefill > 0 && !all_hidden_d && M >= g_ragged_prefill;
+    // ragged batches (LN-folded path, unless the caller wants every row's hidden state back): by default only the forwards of
+    // large batches qualify (b*c >= 2048); LMRL_FWD_RAGGED_ALWAYS compacts every forward (generation loops whose rows finish at
+    // different steps), LMRL_FWD_RAGGED_NEVER none.  A per-call property: nothing here is process state.
+    const bool ragged = fused && !all_hidden_d && !(flags & LMRL_FWD_RAGGED_NEVER) &&
+                        ((flags & LMRL_FWD_RAGGED_ALWAYS) || M >= kRaggedAutoMinSlots);
     const int32_t *off = ragged ? w.off : nullptr, *row_map = ragged ? w.row_map : nullptr, *m_dev = ragged ? w.off + b : nullptr;
     if (ragged) hipLaunchKernelGGL(ragged_scan_kernel, dim3(1), dim3(1024), 0, s, cnt_d, b, c, w.off, w.row_map);
     auto ln = [&](const float *g, const float *be, uint16_t *y, const int32_t *idx, int rows) {
@@ -807,7 +808,7 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
         } else {
         ProfScope ps(c == 1 ? PROF_ATTN_DECODE : PROF_ATTN_CHUNK, s, -1.0);
         if (c == 1) hipLaunchKernelGGL(attention_kernel<1>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d, off);
-        else if (g_attn_variant == 1 && c == 8 && !ragged) hipLaunchKernelGGL(attention_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
+        else if ((flags & LMRL_FWD_ATTN_VALU) && c == 8 && !ragged) hipLaunchKernelGGL(attention_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d);
         else if (c == 16) hipLaunchKernelGGL(attention_chunk_mfma_kernel<16>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d, off);
         else hipLaunchKernelGGL(attention_chunk_mfma_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d, off);
         }
@@ -856,9 +857,6 @@ int lmrl_gpt2_kv_broadcast(const lmrl_gpt2 *m, const void *src_kv_d, int src_tma
 }
 
 void lmrl_gemm_set_variant(int v) { lmrl::g_gemm_variant = v; }
-void lmrl_attn_set_variant(int v) { lmrl::g_attn_variant = v; }
-void lmrl_gpt2_set_ln_fusion(int on) { lmrl::g_ln_fusion = on; }
-void lmrl_gpt2_set_ragged_prefill(int min_slots) { lmrl::g_ragged_prefill = min_slots; }
 
 // Plain bf16 GEMM entry (heads, LM-head logits): C = A.W^T + bias with a selectable epilogue.
 int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda,

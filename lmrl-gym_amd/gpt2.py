@@ -118,8 +118,8 @@ class GPT2Engine:
             4 * c.d_model + 3 * c.d_model * c.d_model + 3 * c.d_model + c.d_model * c.d_model + c.d_model +
             2 * c.d_model * c.d_ff + c.d_ff + c.d_model)
 
-    def session(self, batch: int, tmax: int) -> "KVSession":
-        return KVSession(self, batch, tmax)
+    def session(self, batch: int, tmax: int, flags: int = 0) -> "KVSession":
+        return KVSession(self, batch, tmax, flags)
 
     def __del__(self):
         try:
@@ -130,12 +130,17 @@ class GPT2Engine:
             pass
 
 
-class KVSession:
-    """Persistent per-env KV cache + workspace for `batch` lock-step sequences of at most `tmax` tokens."""
+# lmrl_gpt2_forward flags (include/lmrl_amd.h): per-call variants, held per SESSION — never process state
+FWD_LN_STANDALONE, FWD_RAGGED_ALWAYS, FWD_RAGGED_NEVER, FWD_ATTN_VALU = 1, 2, 4, 8
 
-    def __init__(self, eng: GPT2Engine, batch: int, tmax: int):
+
+class KVSession:
+    """Persistent per-env KV cache + workspace for `batch` lock-step sequences of at most `tmax` tokens.
+    `flags` (FWD_*) are this session's forward variants; two sessions with different flags can be interleaved freely."""
+
+    def __init__(self, eng: GPT2Engine, batch: int, tmax: int, flags: int = 0):
         import torch
-        self.eng, self.B, self.tmax = eng, batch, tmax
+        self.eng, self.B, self.tmax, self.flags = eng, batch, tmax, int(flags)
         L, dev = eng._L, eng.device
         self.kv = torch.zeros(L.lmrl_gpt2_kv_bytes(eng._h, batch, tmax), dtype=torch.uint8, device=dev)
         self.ws = {c: torch.zeros(L.lmrl_gpt2_ws_bytes(eng._h, batch, c), dtype=torch.uint8, device=dev) for c in (1, 8, 16)}
@@ -160,7 +165,7 @@ class KVSession:
                                  "(size the session for prompt + generated tokens, or reset() it)")
         _lib.check(e._L.lmrl_gpt2_forward(e._h, _lib.ptr(self.kv), self.tmax, _lib.ptr(self.ws[chunk]), _lib.ptr(tokens),
                                           _lib.ptr(cnt), _lib.ptr(self.len), self.B, chunk, _lib.ptr(self.last_hidden),
-                                          _lib.ptr(all_hidden), _lib.stream_ptr()), "lmrl_gpt2_forward")
+                                          _lib.ptr(all_hidden), self.flags, _lib.stream_ptr()), "lmrl_gpt2_forward")
         return self.last_hidden
 
     def broadcast_prefix_from(self, src: "KVSession", n_pos: int):

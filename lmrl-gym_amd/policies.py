@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _lib
 from .environment import BatchedTextPolicy, Text, TextHistory, text_history_to_str
-from .gpt2 import GPT2Engine, SampleParams
+from .gpt2 import FWD_RAGGED_ALWAYS, GPT2Engine, SampleParams
 
 
 class _Generator:
@@ -27,7 +27,9 @@ class _Generator:
         import torch
         self.t = torch
         self.engines, self.B, self.tmax = list(engines), batch, tmax
-        self.sessions = [e.session(batch, tmax) for e in self.engines]
+        # sequences of a batch end at different steps: every forward of these sessions runs on the compacted live rows
+        # (bit-identical results); a per-session flag, not process state
+        self.sessions = [e.session(batch, tmax, flags=FWD_RAGGED_ALWAYS) for e in self.engines]
         self.dev = self.engines[0].device
 
     def prefill(self, prompts: List[List[int]]):
@@ -90,12 +92,7 @@ class GPT2PPOPolicy(BatchedTextPolicy):
         if self._gen is None or self._gen.B != B or self._gen.tmax != tmax:
             self._gen = _Generator(self._engines(), B, tmax)
         gen = self._gen
-        # sequences of a batch end at different steps: run every forward on the compacted live rows (results are bit-identical)
-        _lib.lib().lmrl_gpt2_set_ragged_prefill(1)
-        try:
-            return self._generate(gen, prompts, text_history, done, B)
-        finally:
-            _lib.lib().lmrl_gpt2_set_ragged_prefill(2048)
+        return self._generate(gen, prompts, text_history, done, B)
 
     def _generate(self, gen, prompts, text_history, done, B):
         import torch
@@ -131,8 +128,23 @@ class GPT2PPOPolicy(BatchedTextPolicy):
             if d:
                 results.append(None)
             else:
-                results.append(tuple(h) + (Text(self.out_str_process(self.tokenizer.decode(ids)), True),))
+                results.append(tuple(h) + (Text(self.out_str_process(self._decode_generation(ids)), True),))
         return results
+
+    def _decode_generation(self, ids: List[int]) -> str:
+        """The reference decodes generations with `batch_decode(..., skip_special_tokens=True)`
+        (value_rl_base/base_interface.py:126, bc/core.py:102): special tokens (eos / pad) never reach the action Text.  An eos that
+        is ordinary text (Wordle: eos = the '\n' token, train_ilql_gpt2.py:393) is not special and stays."""
+        try:
+            return self.tokenizer.decode(ids, skip_special_tokens=True)
+        except TypeError:
+            # minimal tokenizers without the keyword: drop what THEY declare special (`all_special_ids`; default: only the pad id —
+            # an eos id is ordinary text unless the tokenizer says otherwise, exactly as '\n' is for the GPT-2 tokenizer)
+            special = getattr(self.tokenizer, "all_special_ids", None)
+            if special is None:
+                special = [t for t in (getattr(self.tokenizer, "pad_token_id", None),) if t is not None]
+            special = set(special)
+            return self.tokenizer.decode([t for t in ids if t not in special])
 
     def set_params(self, engine: GPT2Engine) -> None:
         """PPOPolicy.set_params (ppo/base_interface.py:821-823): swap in freshly trained weights."""

@@ -7,11 +7,15 @@ the reference lines it follows (paths relative to /root/reference/LLM_RL).
 Pinning status
   * get_action_state_next_state_idxs, gae, AdaptiveKLController, chain/data shaping:
     PINNED against tests/golden/rl_helpers.json (outputs of the reference's own numpy code).
-  * ppo_loss, ilql_loss, mc_loss, bc_loss, whiten, get_rtg, heads, token_logprobs,
-    tensor_stats: the reference versions are JAX-only and cannot execute in the build
-    container (no jax) and the reference holds no tests or golden vectors for them ->
-    "parity unpinned": these are line-by-line float64 restatements; the HIP kernels are
-    compared with them within the tolerances written in the tests.
+  * ppo_loss, ilql_loss, get_query_indicators, mc_loss, bc_loss, whiten, get_rtg, token_logprobs_from_logits,
+    tensor_stats: PINNED against tests/golden/rl_losses.json — outputs of the reference's own, unmodified JAX
+    functions executed under a numpy-backed `jax.numpy` / `optax` shim (tests/golden/_jnp_shim.py,
+    make_loss_fixtures.py): loss, the complete log dict, and directional derivatives taken by complex-step
+    differentiation THROUGH the reference code (so its stop_gradient placement is pinned too);
+    tests/test_oracle_losses_pinned.py.
+  * still "parity unpinned": the flax head modules (linear_head / mlp_head: flax is not installable; they are a
+    Dense / Dense-relu-Dense restatement), ilql_gather_qv (lives inside a pjit closure of the reference), the
+    GPT-2 forward vs the JAX model and the sampling stream (oracle/gpt2.py).
 """
 from __future__ import annotations
 

@@ -47,19 +47,10 @@ def test_gemm_bf16_epilogues(dev, M, N, K):
 
 
 # ------------------------------------------------------------------ forward: chunked prefill + decode vs full-sequence oracle
-@pytest.fixture
-def ln_fusion(request):
-    """LayerNorm folded into the neighbouring GEMMs (1, the default) or stand-alone LN launches (0)."""
-    from lmrl_gym_amd import _lib
-    _lib.lib().lmrl_gpt2_set_ln_fusion(request.param)
-    yield request.param
-    _lib.lib().lmrl_gpt2_set_ln_fusion(1)
-
-
-@pytest.mark.parametrize("ln_fusion", [1, 0], indirect=True)
+@pytest.mark.parametrize("ln_fusion", [1, 0])    # LayerNorm folded into the neighbouring GEMMs (default) / stand-alone LN launches (per-session flag)
 @pytest.mark.parametrize("cfgname", ["tiny", "small2", "medium2"])
 def test_gpt2_forward_kv_cache(dev, cfgname, ln_fusion):
-    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
+    from lmrl_gym_amd.gpt2 import FWD_LN_STANDALONE, GPT2Config, GPT2Engine, init_hf_style_state_dict
     from oracle import gpt2 as O
     cfg = dict(tiny=GPT2Config(2, 2, 128, 512, 1000, 64), small2=GPT2Config(2, 12, 768, 3072, 50257, 128),
                medium2=GPT2Config(2, 16, 1024, 4096, 5000, 64))[cfgname]      # GPT-2-medium width: the NQ = 4 LayerNorm-fold configuration
@@ -74,7 +65,7 @@ def test_gpt2_forward_kv_cache(dev, cfgname, ln_fusion):
     B, T = 5, 40
     ids = torch.randint(0, cfg.vocab, (B, T), generator=g)
     ref_logits, ref_hid = O.forward(sd, ids, cfg.n_head, dtype=torch.float64, return_hidden=True)
-    ses = eng.session(B, 48)
+    ses = eng.session(B, 48, flags=0 if ln_fusion else FWD_LN_STANDALONE)
     # schedule: chunk of 8 with ragged counts, then single-token decode steps with some envs idle, then another chunk
     consumed = np.zeros(B, dtype=int)
     plan = [(8, [8, 5, 1, 0, 7]), (1, [1, 1, 1, 1, 0]), (1, [1, 0, 1, 1, 1]), (16, [16, 9, 3, 8, 12]), (1, [1, 1, 1, 1, 1]), (8, [4, 0, 8, 6, 8])]
@@ -289,7 +280,6 @@ def test_sampler_steer_and_ilql_perturbation(dev):
 def test_ragged_prefill_is_bit_identical(dev):
     """Chunk forwards on the compacted rows (sum of cnt) vs on all B*C slots: same last hidden states, same KV cache, same
     cache lengths, bit for bit, for ragged counts including empty envs; decode steps afterwards agree too."""
-    from lmrl_gym_amd import _lib
     from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
     cfg = GPT2Config(2, 12, 768, 3072, 1000, 64)
     eng = GPT2Engine(cfg, init_hf_style_state_dict(cfg, seed=2), dev)
@@ -299,17 +289,15 @@ def test_ragged_prefill_is_bit_identical(dev):
             (1, torch.ones(B, dtype=torch.int64)), (8, torch.randint(3, 9, (B,), generator=g))]
     plan[0][1][0] = 0; plan[0][1][B - 1] = 8
     outs = []
-    for min_slots in (1, 0):
-        _lib.lib().lmrl_gpt2_set_ragged_prefill(min_slots)
-        try:
-            ses = eng.session(B, 48)
-            hs = []
-            for C, cnt in plan:
-                toks = torch.randint(0, cfg.vocab, (B * C,), generator=torch.Generator().manual_seed(C)).to(torch.int32).to(dev)
-                hs.append(ses.forward(toks, cnt.to(torch.int32).to(dev), C).clone())
-            outs.append((hs, ses.kv.clone(), ses.len.clone()))
-        finally:
-            _lib.lib().lmrl_gpt2_set_ragged_prefill(2048)
+    from lmrl_gym_amd.gpt2 import FWD_RAGGED_ALWAYS, FWD_RAGGED_NEVER
+    # the two sessions are INTERLEAVED forward by forward: the variant is a property of the call, not of the process
+    sess = [eng.session(B, 48, flags=FWD_RAGGED_ALWAYS), eng.session(B, 48, flags=FWD_RAGGED_NEVER)]
+    hs = [[], []]
+    for C, cnt in plan:
+        toks = torch.randint(0, cfg.vocab, (B * C,), generator=torch.Generator().manual_seed(C)).to(torch.int32).to(dev)
+        for i, ses in enumerate(sess):
+            hs[i].append(ses.forward(toks, cnt.to(torch.int32).to(dev), C).clone())
+    outs = [(hs[i], sess[i].kv.clone(), sess[i].len.clone()) for i in range(2)]
     for a, b in zip(outs[0][0], outs[1][0]):
         assert torch.equal(a, b)
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])

@@ -175,3 +175,66 @@ def test_ppo_data_pipeline_vs_oracle(setup):
             np.testing.assert_allclose(d.old_returns, r["old_returns"][sl], rtol=2e-4, atol=2e-4)
             np.testing.assert_allclose(d.old_advantages, r["old_advantages"][sl], rtol=2e-3, atol=2e-3)
     assert k == len(datas)
+
+
+def test_special_token_eos_never_reaches_the_action_text_and_sessions_do_not_share_state(setup):
+    """(1) ADVICE r01: the reference decodes generations with skip_special_tokens=True (value_rl_base/base_interface.py:126), so a
+    SPECIAL eos ('<|endoftext|>') never appears in the action Text, while an ordinary-text eos ('\\n', Wordle) stays.
+    (2) VERDICT r01 #7: forward variants are per-session flags — two policies with different settings, called alternately, give
+    exactly what each gives alone (no process-wide knob flips between them)."""
+    from lmrl_gym_amd import environment as E
+    from lmrl_gym_amd.gpt2 import FWD_LN_STANDALONE, FWD_RAGGED_ALWAYS, FWD_RAGGED_NEVER
+    from lmrl_gym_amd.policies import GPT2PPOPolicy
+    dev, cfg, sd, sd_v, eng, eng_v = setup
+
+    class SpecialTok(CharTok):
+        """'<|endoftext|>' = id 127 is a SPECIAL token (HF semantics: skipped by decode(skip_special_tokens=True))."""
+        def __init__(self, vocab):
+            super().__init__(vocab)
+            self.eos_token_id, self.all_special_ids = 127, [127, vocab - 1]
+
+        def decode(self, ids, skip_special_tokens=False):
+            return "".join("<|endoftext|>" if i == 127 else chr(i) for i in ids if not (skip_special_tokens and i in self.all_special_ids))
+
+    hists = [(E.Text("state one\n", False),), (E.Text("another, longer state text\n", False),), (E.Text("x\n", False),)]
+    # steer-free greedy generation: find what the model emits, then declare its FIRST generated token to be the special eos
+    probe = GPT2PPOPolicy(eng, CharTok(cfg.vocab), max_input_length=32, max_new_tokens=5, do_sample=False, eos_token_id=None)
+    first = [r[-1].text[0] for r in probe.act(hists)]
+    tok = SpecialTok(cfg.vocab)
+    tok.eos_token_id = ord(first[0]); tok.all_special_ids = [ord(first[0]), cfg.vocab - 1]
+    tok.decode = lambda ids, skip_special_tokens=False: "".join(chr(i) for i in ids if not (skip_special_tokens and i in tok.all_special_ids))
+    pol = GPT2PPOPolicy(eng, tok, max_input_length=32, max_new_tokens=5, do_sample=False)      # eos defaults to tokenizer.eos_token_id
+    out = pol.act(hists)
+    assert out[0][-1].text == "" and out[0][-1].is_action            # generation stopped at the special eos and it was not rendered
+    assert all(first[0] not in r[-1].text for r in out)
+    # an ordinary-text eos stays in the text (the Wordle setup: eos = '\n')
+    plain = GPT2PPOPolicy(eng, CharTok(cfg.vocab), max_input_length=32, max_new_tokens=5, do_sample=False, eos_token_id=ord(first[0]))
+    assert plain.act(hists)[0][-1].text == first[0]
+
+    # ---- interleaved policies with different per-session flags
+    def run(flags_a, flags_b, interleave):
+        pa = GPT2PPOPolicy(eng, CharTok(cfg.vocab), max_input_length=32, max_new_tokens=6, do_sample=True, temperature=0.8, seed=3, eos_token_id=10)
+        pb = GPT2PPOPolicy(eng_v, CharTok(cfg.vocab), max_input_length=32, max_new_tokens=6, do_sample=True, temperature=0.8, seed=4, eos_token_id=10)
+        res = ([], [])
+        for rnd in range(2):
+            for i, (p, fl) in enumerate(((pa, flags_a), (pb, flags_b))):
+                if not interleave and i == 1:
+                    continue
+                if p._gen is None:
+                    p.act(hists)                               # builds the sessions
+                    p.calls = 0
+                for s_ in p._gen.sessions:
+                    s_.flags = fl
+                res[i].append(p.act(hists))
+        if not interleave:
+            for rnd in range(2):
+                if pb._gen is None:
+                    pb.act(hists); pb.calls = 0
+                for s_ in pb._gen.sessions:
+                    s_.flags = flags_b
+                res[1].append(pb.act(hists))
+        return res
+
+    fa, fb = FWD_RAGGED_ALWAYS, FWD_RAGGED_NEVER | FWD_LN_STANDALONE
+    inter, solo = run(fa, fb, True), run(fa, fb, False)
+    assert inter[0] == solo[0] and inter[1] == solo[1]

@@ -10,8 +10,7 @@ B = 5
 g = torch.Generator().manual_seed(0)
 outs = {}
 for variant in (1, 0):
-    L.lmrl_attn_set_variant(variant)
-    ses = eng.session(B, 48)
+    ses = eng.session(B, 48, flags=8 if variant else 0)      # FWD_ATTN_VALU: VALU chunk attention as the cross-check
     res = []
     for C, cnts in [(8, [8, 5, 1, 0, 7]), (8, [8, 8, 3, 8, 2])]:
         toks = torch.randint(0, 1000, (B * C,), generator=torch.Generator().manual_seed(C + sum(cnts))).to(torch.int32).to(dev)
