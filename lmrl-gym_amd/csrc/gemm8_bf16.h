@@ -1,0 +1,361 @@
+// gemm8_bf16.h — large-tile bf16 MFMA GEMM for gfx950 (prefill GEMMs, LM head): 8 waves per workgroup, register-double-buffered
+// fragments, one barrier per K-step placed MID-step.
+//
+//   C[M,N] = A[M,K] . W[N,K]^T (+ the fused epilogues of gemm_bf16.h)
+//
+// Why a second kernel: the 4-wave 64x64 / 128x64 tiles of gemm_bf16.h move (BM+BN)*128 B through L2 -> LDS -> VGPR per K-step for
+// BM*BN*128 flop; at ~135 GB/s of L2 bandwidth per CU and 256 B/clk of LDS bandwidth that caps them well below the MFMA rate
+// (128x64 ~1.5 PF L2 ceiling, and the LDS array is busier than the MFMA pipe).  A 256x256 (or 256x128 / 128x128) tile
+// with 8 waves owning 128x64 (64x64) each quadruples the flop per staged byte.
+//
+// Pipeline (per workgroup; S LDS slots of (BM+BN)*128 B, filled by global_load_lds, XOR swizzle on the source address exactly as in
+// gemm_bf16.h):
+//   prologue   issue stages 0..S-1 ; wait stage 0 (counted vmcnt) ; barrier ; read fragments F0 = (stage 0, k-half 0)
+//   step t     read F1 = (t, k-half 1)                      <- LDS reads of the second half fly under ...
+//              MFMA(F0)                                     <- ... the MFMAs of the first half
+//              wait stage t+1 (counted) ; lgkmcnt(0) ; barrier     [mid-step: every wave now holds stage t entirely in registers]
+//              issue stage t+S into slot t % S              <- the slot just vacated; S-1 stages stay in flight
+//              read F0' = (t+1, k-half 0)                   <- fly under ...
+//              MFMA(F1)                                     <- ... the MFMAs of the second half
+// so the matrix pipe always has a block of independent MFMAs to issue while the next fragments and the next stages are in flight,
+// with ONE barrier per K-step.  Hazards: a slot is re-filled only after a barrier that every wave reached with lgkmcnt(0) (all its
+// reads of that slot retired); a stage is read only after the issuing waves' counted vmcnt AND the barrier behind it.
+#pragma once
+#include "gemm_bf16.h"
+
+namespace lmrl {
+
+#ifdef LMRL_G8_PROBE   // tools/gemm8_bench.hip only: per-workgroup s_memtime stamps (entry, stage 0 landed, K loop done, epilogue done)
+__device__ unsigned long long *g8_probe = nullptr;
+#define LMRL_G8_STAMP(I) do { if (g8_probe && threadIdx.x == 0) g8_probe[(size_t)blockIdx.x * 4 + (I)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LMRL_G8_STAMP(I) do { } while (0)
+#endif
+
+struct G8NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// acc[i][j] += W-fragment i (rows n0 + wn*TN + 16 i ..) x A-fragment j (rows m0 + wm*TM + 16 j ..) over K.  Starts with a barrier so that it
+// can be called repeatedly on the same LDS ring (fused multi-operand kernels).  `head()` runs right after the ring prologue has been
+// issued: either plain global loads whose results are first used after the loop (they fly under it), or a block that ends with
+// vmcnt(0) (the LayerNorm moments, which need LDS scratch OUTSIDE the ring: every slot is being filled).
+template <int BM, int BN, int WM, int WN, int STAGES, class Head = G8NoHook>
+__device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int lda, const uint16_t *__restrict__ W, int K, int Mr, int m0, int n0,
+                                            char *smem, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], Head head = Head()) {
+    constexpr int NW = WM * WN, BK = 64;
+    constexpr int TM = BM / WM, TN = BN / WN;            // per-wave output tile
+    constexpr int FM = TM / 16, FN = TN / 16;            // 16-row activation / weight fragments per wave
+    constexpr int LA = BM / 8 / NW, LW = BN / 8 / NW;    // global_load_lds instructions per wave per stage (1 KiB = 8 rows each)
+    constexpr int L = LA + LW;
+    constexpr int STAGE = (BM + BN) * 128;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && TM % 16 == 0 && TN % 16 == 0, "tile / wave layout");
+    static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS slots");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int nk = K / BK;
+    const int lrow = lane >> 3, src_c = (lane & 7) ^ lrow;
+
+    const uint16_t *ap[LA];
+    const uint16_t *wp[LW];
+#pragma unroll
+    for (int i = 0; i < LA; i++) {
+        int m = m0 + (wave + NW * i) * 8 + lrow;
+        m = m < Mr ? m : Mr - 1;
+        ap[i] = A + (size_t)m * lda + src_c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < LW; i++) wp[i] = W + (size_t)(n0 + (wave + NW * i) * 8 + lrow) * K + src_c * 8;
+
+#define LMRL_G8_ISSUE(KT, SLOT)                                                                                       \
+    do {                                                                                                              \
+        char *sb_ = smem + (SLOT) * STAGE;                                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < LA; i_++)                                                             \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ap[i_] + (size_t)(KT) * BK), \
+                                             (__attribute__((address_space(3))) void *)(sb_ + (wave + NW * i_) * 1024), 16, 0, 0); \
+        _Pragma("unroll") for (int i_ = 0; i_ < LW; i_++)                                                             \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wp[i_] + (size_t)(KT) * BK), \
+                                             (__attribute__((address_space(3))) void *)(sb_ + BM * 128 + (wave + NW * i_) * 1024), 16, 0, 0); \
+    } while (0)
+#define LMRL_G8_READ(FW, FA, SLOT, KK)                                                                                \
+    do {                                                                                                              \
+        const char *sA_ = smem + (SLOT) * STAGE;                                                                      \
+        const char *sW_ = sA_ + BM * 128;                                                                             \
+        const int c_ = (KK) * 4 + lq;                                                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < FN; i_++) {                                                           \
+            const int row_ = wn * TN + i_ * 16 + lr;                                                                  \
+            FW[i_] = *reinterpret_cast<const bf16x8 *>(sW_ + row_ * 128 + ((c_ ^ (row_ & 7)) << 4));                  \
+        }                                                                                                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < FM; j_++) {                                                           \
+            const int row_ = wm * TM + j_ * 16 + lr;                                                                  \
+            FA[j_] = *reinterpret_cast<const bf16x8 *>(sA_ + row_ * 128 + ((c_ ^ (row_ & 7)) << 4));                  \
+        }                                                                                                             \
+    } while (0)
+#define LMRL_G8_MFMA(FW, FA)                                                                                          \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < FN; i_++)                                                             \
+            _Pragma("unroll") for (int j_ = 0; j_ < FM; j_++)                                                         \
+                acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FW[i_], FA[j_], acc[i_][j_], 0, 0, 0);          \
+    } while (0)
+
+    // ---- prologue
+    __builtin_amdgcn_s_barrier();   // every wave is done reading the ring from a previous call
+#pragma unroll
+    for (int s = 0; s < STAGES; s++)
+        if (s < nk) LMRL_G8_ISSUE(s, s);
+    asm volatile("" ::: "memory");
+    head();
+    asm volatile("" ::: "memory");
+    {
+        const int inflight = (nk - 1 < STAGES - 1) ? nk - 1 : STAGES - 1;     // stages that may stay in flight behind stage 0
+        if (inflight >= 2) wait_vmcnt<2 * L>();
+        else if (inflight == 1) wait_vmcnt<L>();
+        else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    LMRL_G8_STAMP(1);
+    bf16x8 fw0[FN], fa0[FM], fw1[FN], fa1[FM];
+    LMRL_G8_READ(fw0, fa0, 0, 0);
+    int slot = 0;
+    for (int t = 0; t < nk; t++) {
+        LMRL_G8_READ(fw1, fa1, slot, 1);
+        LMRL_G8_MFMA(fw0, fa0);
+        const int nslot = slot + 1 == STAGES ? 0 : slot + 1;
+        if (t + 1 < nk) {
+            const int behind = nk - 2 - t;                                    // stages issued after stage t+1
+            const int inflight = behind < STAGES - 2 ? behind : STAGES - 2;
+            if (inflight >= 1) wait_vmcnt<L>();
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + STAGES < nk) LMRL_G8_ISSUE(t + STAGES, slot);
+            LMRL_G8_READ(fw0, fa0, nslot, 0);
+        }
+        LMRL_G8_MFMA(fw1, fa1);
+        slot = nslot;
+    }
+#undef LMRL_G8_ISSUE
+#undef LMRL_G8_READ
+#undef LMRL_G8_MFMA
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0>
+__global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap xm) {
+    constexpr int NW = WM * WN, NT = NW * 64;
+    constexpr int TM = BM / WM, TN = BN / WN;            // per-wave output tile
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr bool LN_IN = (EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    int tile_m, tile_n;
+    if (!xcd_tile(xm, blockIdx.x, tile_m, tile_n)) return;   // workgroup-uniform
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int Mr = g.m_dev ? *g.m_dev : g.M;
+    if (m0 >= Mr) return;
+    LMRL_G8_STAMP(0);
+    const int lr = lane & 15, lq = lane >> 4;
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; i++)
+#pragma unroll
+        for (int j = 0; j < FM; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr bool RESID = (EPI == EPI_RESID_F32_STATS || EPI == EPI_RESID_F32);
+    constexpr int STAGE = (BM + BN) * 128;
+    float ln_mu[FM], ln_rs[FM];          // LN_IN: this lane's rows' (mu, rstd)
+    f32x4 xres[FN][FM];                  // RESID: this lane's slice of the residual stream, prefetched under the K loop
+    if (LN_IN) {
+        // as in gemm_bf16_glds_kernel: fetch the tile's BM x nslots moment slots behind the ring prologue, wait for everything, reduce to
+        // (mu, rstd) per row in LDS scratch behind the ring (same association order: ln_row_moments) and keep this lane's rows in registers
+        constexpr int NLQ = NQ > 0 ? (NQ * BM * 4 + NT - 1) / NT : 1;      // float4 loads per thread: BM * nslots * 8 B / (NT * 16 B)
+        constexpr int TPR = NT / BM >= 4 ? 4 : (NT / BM >= 2 ? 2 : 1);
+        auto head = [&]() {
+            const int h4 = g.nslots / 2;
+            const f32x4 *sp = reinterpret_cast<const f32x4 *>(g.stats + (size_t)m0 * g.nslots);
+            const int lim = (Mr - m0 < BM ? Mr - m0 : BM) * h4;
+            f32x4 st[NLQ];
+#pragma unroll
+            for (int k = 0; k < NLQ; k++) {
+                const int idx = tid + NT * k;
+                st[k] = sp[idx < lim ? idx : lim - 1];
+            }
+            wait_vmcnt<0>();
+            float2 *part = reinterpret_cast<float2 *>(smem + STAGES * STAGE);    // [BM * h4] partial (sum, sum^2), behind the ring
+            float2 *murs = part + BM * 4 * NQ;                                   // [BM] (mu, rstd)
+#pragma unroll
+            for (int k = 0; k < NLQ; k++)
+                if (tid + NT * k < BM * h4) part[tid + NT * k] = make_float2(st[k][0] + st[k][2], st[k][1] + st[k][3]);   // rows >= M: unused
+            __syncthreads();
+            {
+                const int row = tid / TPR, q = tid % TPR;
+                if (row < BM) {
+                    const float2 mr = ln_row_moments<TPR>(part + row * h4, h4, q, g.inv_d, g.eps);
+                    if (q == 0) murs[row] = mr;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < FM; j++) {
+                const float2 p2 = murs[wm * TM + j * 16 + lr];
+                ln_mu[j] = p2.x; ln_rs[j] = p2.y;
+            }
+        };
+        g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc, head);
+    } else if (RESID) {
+        auto prefetch = [&]() {
+#pragma unroll
+            for (int i = 0; i < FN; i++)
+#pragma unroll
+                for (int j = 0; j < FM; j++) {
+                    int m = m0 + wm * TM + j * 16 + lr;
+                    m = m < Mr ? m : Mr - 1;
+                    int n = n0 + wn * TN + i * 16 + lq * 4;
+                    n = n < g.n_store ? n : 0;
+                    xres[i][j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(g.C) + (size_t)m * g.ldc + n);
+                }
+        };
+        g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc, prefetch);
+    } else {
+        g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc);
+    }
+    LMRL_G8_STAMP(2);
+
+    // ---- epilogues (same arithmetic as gemm_bf16_glds_kernel; a lane holds C[m][n..n+3], n = n0 + wn*TN + 16 i + 4 lq, m = m0 + wm*TM + 16 j + lr)
+    if (EPI == EPI_RESID_F32_STATS) {
+        // x += acc + bias ; xb = bf16(x) ; the wave's TN columns are TN/32 stat slots of the row: slot s holds (sum x, sum x^2) of columns
+        // [32 s, 32 s + 32).  A fragment i covers 16 columns: slot = (n0 + wn*TN + 16 i) / 32, two fragments per slot.
+        static_assert(TN % 32 == 0, "stat slots are 32 columns wide");
+#pragma unroll
+        for (int j = 0; j < FM; j++) {
+            const int m = m0 + wm * TM + j * 16 + lr;
+            const bool row_ok = m < Mr;
+#pragma unroll
+            for (int i2 = 0; i2 < FN; i2 += 2) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = i2; i < i2 + 2; i++) {
+                    const int n = n0 + wn * TN + i * 16 + lq * 4;
+                    if (n >= g.n_store || !row_ok) continue;
+                    f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (g.bias) b4 = *reinterpret_cast<const f32x4 *>(g.bias + n);
+                    const f32x4 v = xres[i][j] + (acc[i][j] + b4);
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n) = v;
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2 *>(g.xb + (size_t)m * g.ldc + n) = o;
+                    s1 += (v[0] + v[1]) + (v[2] + v[3]);
+                    s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                }
+                s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                const int sl = (n0 + wn * TN + i2 * 16) >> 5;
+                if (lq == 0 && row_ok && sl < g.nslots) g.stats[(size_t)m * g.nslots + sl] = make_float2(s1, s2);
+            }
+        }
+        LMRL_G8_STAMP(3);
+        return;
+    }
+
+    constexpr bool BF16_OUT = (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || LN_IN);
+    if (BF16_OUT && (FN % 2 == 0)) {
+        // bf16 outputs, fragment pairs (i, i+1): a lane holds columns [16i + 4lq, +4) of both; v_permlane16_swap (odd 16-lane rows of the
+        // first operand <-> even rows of the second) regroups them so that every lane owns 8 CONSECUTIVE columns (16 B) of one fragment:
+        // lanes with lq even keep fragment i (columns 8(lq/2) ..), lanes with lq odd take fragment i+1 -> one dwordx4 store per pair and
+        // 64 contiguous bytes per row per instruction instead of two dwordx2 stores of 32 contiguous bytes.
+#pragma unroll
+        for (int i = 0; i < FN; i += 2) {
+            const int nA = n0 + wn * TN + i * 16 + lq * 4, nB = nA + 16;
+            f32x4 bA = f32x4{0.f, 0.f, 0.f, 0.f}, bB = bA, cA = bA, cB = bA;
+            if (g.bias) { bA = *reinterpret_cast<const f32x4 *>(g.bias + nA); bB = *reinterpret_cast<const f32x4 *>(g.bias + nB); }
+            if (LN_IN) { cA = *reinterpret_cast<const f32x4 *>(g.colsum + nA); cB = *reinterpret_cast<const f32x4 *>(g.colsum + nB); }
+            const int n_st = n0 + wn * TN + (i + (lq & 1)) * 16 + (lq >> 1) * 8;      // first of this lane's 8 columns after the regrouping
+#pragma unroll
+            for (int j = 0; j < FM; j++) {
+                const int m = m0 + wm * TM + j * 16 + lr;
+                f32x4 vA, vB;
+                if (LN_IN) { vA = (acc[i][j] - cA * ln_mu[j]) * ln_rs[j] + bA; vB = (acc[i + 1][j] - cB * ln_mu[j]) * ln_rs[j] + bB; }
+                else { vA = acc[i][j] + bA; vB = acc[i + 1][j] + bB; }
+                if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_BF16_LN) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { vA[r] = gelu_new(vA[r]); vB[r] = gelu_new(vB[r]); }
+                }
+                if (EPI == EPI_RELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { vA[r] = fmaxf(vA[r], 0.f); vB[r] = fmaxf(vB[r], 0.f); }
+                }
+                uint32_t a0 = pack_bf16x2(vA[0], vA[1]), a1 = pack_bf16x2(vA[2], vA[3]);
+                uint32_t b0 = pack_bf16x2(vB[0], vB[1]), b1 = pack_bf16x2(vB[2], vB[3]);
+                // after the swaps: lq = 0: (A.r0, A.r1) ; lq = 1: (B.r0, B.r1) ; lq = 2: (A.r2, A.r3) ; lq = 3: (B.r2, B.r3)   (r = source lane row)
+                auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                if (m < Mr && n_st < g.n_store)
+                    *reinterpret_cast<u32x4 *>(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc + n_st) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LMRL_G8_STAMP(3);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < FN; i++) {
+        const int n = n0 + wn * TN + i * 16 + lq * 4;
+        if (n >= g.n_store) continue;
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (g.bias) b4 = *reinterpret_cast<const f32x4 *>(g.bias + n);
+        f32x4 c4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (LN_IN) c4 = *reinterpret_cast<const f32x4 *>(g.colsum + n);
+#pragma unroll
+        for (int j = 0; j < FM; j++) {
+            const int m = m0 + wm * TM + j * 16 + lr;
+            if (m >= Mr) continue;
+            f32x4 v;
+            if (LN_IN) v = (acc[i][j] - c4 * ln_mu[j]) * ln_rs[j] + b4;
+            else v = acc[i][j] + b4;
+            if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_BF16_LN) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = gelu_new(v[r]);
+            }
+            if (EPI == EPI_RELU_BF16) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || LN_IN) {
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc + n) = o;
+            } else if (EPI == EPI_RESID_F32) {
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n) = xres[i][j] + v;
+            } else {
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n) = v;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LMRL_G8_STAMP(3);
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0>
+inline hipError_t gemm8_launch(const GemmArgs &g, hipStream_t s) {
+    constexpr bool LN_IN = (EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN);
+    constexpr size_t shmem = (size_t)STAGES * (BM + BN) * 128 + (LN_IN ? (size_t)BM * 4 * NQ * 8 + BM * 8 : 0);   // ring (+ LayerNorm-moment scratch)
+    static_assert(shmem <= 160 * 1024, "LDS ring exceeds 160 KiB");
+    const XcdMap xm = make_xcd_map((g.M + BM - 1) / BM, g.N / BN, 2.0 * g.M * g.K, 2.0 * g.N * g.K);
+    const int tiles = xcd_grid(xm);
+    static bool attr_set = false;
+    if (!attr_set && shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8_kernel<BM, BN, WM, WN, STAGES, EPI, NQ>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    {
+        ProfScope ps(PROF_GEMM_128x128, s, 2.0 * (double)g.M * (double)g.N * (double)g.K);
+        hipLaunchKernelGGL((gemm8_kernel<BM, BN, WM, WN, STAGES, EPI, NQ>), dim3(tiles), dim3(WM * WN * 64), shmem, s, g, xm);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace lmrl

@@ -40,19 +40,50 @@ enum GemmEpi {
     EPI_GELU_BF16_LN = 7,
 };
 
-__device__ __forceinline__ uint16_t f32_to_bf16_rn(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32); the integer bit trick it replaces
+// cost ~6 VALU per value, which made the bf16 epilogues VALU-bound (profiles/r02_gemm8_bench.txt)
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hw_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const hw_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2));
 }
+__device__ __forceinline__ uint16_t f32_to_bf16_rn(float f) { return (uint16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 __device__ __forceinline__ float gelu_new(float x) {
     // GPT-2 "gelu_new": 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3)  ==  x * sigmoid(2u) = x / (1 + e^(-2u)).
-    // One v_exp + one v_rcp instead of libm tanhf (~40 instructions): the fc-GEMM epilogue applies it 25 M times per launch.
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return x * __frcp_rn(1.f + __expf(-2.f * u));
+    // 4 plain VALU + v_exp_f32 + v_rcp_f32: the fc-GEMM epilogue applies it 25 M times per prefill launch.
+    const float t = x * fmaf(0.044715f * x, x, 1.0f);                                  // x + 0.044715 x^3
+    const float e = __builtin_amdgcn_exp2f(t * (-2.0f * 0.7978845608028654f * 1.4426950408889634f));   // e^(-2u)
+    return x * __builtin_amdgcn_rcpf(1.f + e);
+}
+
+// Per-row LayerNorm moments from the producer's (sum x, sum x^2) slots: ONE association order everywhere — four partial sums of nslots/8
+// consecutive float4 (= 2 slots each), combined as (p0 + p1) + (p2 + p3) — so every kernel / tile shape derives bit-identical (mu, rstd).
+// TPR threads cooperate on a row (1, 2 or 4 consecutive lanes); `part` holds the row's nslots/2 (sum, sum^2) float2 partials.
+template <int TPR>
+__device__ __forceinline__ float2 ln_row_moments(const float2 *part_row, int h4, int q, float inv_d, float eps) {
+    const int per = h4 / 4;                     // float2 entries per quarter
+    float s1 = 0.f, s2 = 0.f;
+    if (TPR == 4) {
+        for (int k = 0; k < per; k++) { const float2 p = part_row[q * per + k]; s1 += p.x; s2 += p.y; }
+        s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
+        s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2);
+    } else if (TPR == 2) {
+        float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+        for (int k = 0; k < per; k++) { const float2 p = part_row[(2 * q) * per + k]; a1 += p.x; a2 += p.y; }
+        for (int k = 0; k < per; k++) { const float2 p = part_row[(2 * q + 1) * per + k]; b1 += p.x; b2 += p.y; }
+        s1 = a1 + b1; s2 = a2 + b2;
+        s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
+    } else {
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int qq = 0; qq < 4; qq++)
+            for (int k = 0; k < per; k++) { const float2 p = part_row[qq * per + k]; a[qq] += p.x; b[qq] += p.y; }
+        s1 = (a[0] + a[1]) + (a[2] + a[3]); s2 = (b[0] + b[1]) + (b[2] + b[3]);
+    }
+    const float mu = s1 * inv_d;
+    return make_float2(mu, rsqrtf(fmaxf(s2 * inv_d - mu * mu, 0.f) + eps));
 }
 
 struct GemmArgs {
@@ -179,8 +210,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
             }
             if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16) {
                 uint2 o;
-                o.x = (uint32_t)f32_to_bf16_rn(v[0]) | ((uint32_t)f32_to_bf16_rn(v[1]) << 16);
-                o.y = (uint32_t)f32_to_bf16_rn(v[2]) | ((uint32_t)f32_to_bf16_rn(v[3]) << 16);
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc + n) = o;
             } else if (EPI == EPI_RESID_F32) {
                 f32x4 *p = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n);
@@ -241,7 +272,7 @@ struct NoExtraLoads { __device__ __forceinline__ void operator()() const {} };
 
 // EXTRA / extra(): `EXTRA` additional per-lane global loads that the caller issues through `extra()` right AFTER the ring
 // prologue; vmcnt retires loads in order, so the wait for the first K-tile allows them to stay in flight and their
-// latency hides behind the K loop (they are complete by the second wait).
+// latency hides behind the K loop (they are complete by the second wait; with nk == 1 the caller's own use waits).
 template <int BM, int BN, int STAGES, int EXTRA = 0, class Extra = NoExtraLoads>
 __device__ __forceinline__ void glds_mainloop(const uint16_t *__restrict__ A, int lda, const uint16_t *__restrict__ W, int K, int M,
                                               int m0, int n0, char *smem, f32x4 (&acc)[BN / 32][BM / 32], Extra extra = Extra()) {
@@ -282,9 +313,11 @@ __device__ __forceinline__ void glds_mainloop(const uint16_t *__restrict__ A, in
 #pragma unroll
     for (int s = 0; s < STAGES - 1; s++)
         if (s < nk) LMRL_GLDS_ISSUE(s, s);
-    if (EXTRA > 0) {
-        // compiler barriers: the extra loads must be issued after the prologue and before the first counted wait — the
-        // wait for K-tile 0 is vmcnt(... + EXTRA), which is only correct for exactly this issue order
+    {
+        // compiler barriers: the hook's loads must be issued after the prologue and before the first counted wait — the
+        // wait for K-tile 0 is vmcnt(... + EXTRA), which is only correct for exactly this issue order.  A hook that drains
+        // everything itself (EXTRA == 0, ends with vmcnt(0): the LayerNorm moments) may use the ring slot STAGES-1, which
+        // the prologue leaves free until the loop's first barrier.
         asm volatile("" ::: "memory");
         extra();
         asm volatile("" ::: "memory");
@@ -345,6 +378,8 @@ template <int BM, int BN, int STAGES, int EPI, int NQ = 0>
 __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap xm) {
     constexpr int FM = BM / 32, FN = BN / 32;
     constexpr bool LN_IN = (EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN);
+    constexpr bool RESID = (EPI == EPI_RESID_F32_STATS || EPI == EPI_RESID_F32);
+    constexpr int STAGE = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -354,42 +389,70 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
     const int lr = lane & 15, lq = lane >> 4;
     const int Mr = g.m_dev ? *g.m_dev : g.M;          // rows actually present (workgroup-uniform scalar load)
     if (m0 >= Mr) return;
-    // LN_IN: the tile's BM x nslots (sum, sum^2) slots are one contiguous region of `stats`; the 256 threads fetch it
-    // coalesced (NL float4 each) right after the ring prologue, so the latency hides behind the K loop.  After the loop
-    // the per-float4 partial sums go through the (now free) LDS ring and one thread per row adds them in a fixed order
-    // -> (mu, rstd) per row, bit-reproducible.
-    constexpr int NL = LN_IN ? (NQ * BM) / 64 : 0;           // float4 loads per thread: BM*nslots*8 B / (256*16 B)
-    f32x4 st[NL > 0 ? NL : 1];
     f32x4 acc[FN][FM];
 #pragma unroll
     for (int i = 0; i < FN; i++)
 #pragma unroll
         for (int j = 0; j < FM; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float ln_mu[FM], ln_rs[FM];          // LN_IN: this lane's rows' (mu, rstd)
+    f32x4 xres[FN][FM];                  // RESID: this lane's slice of the residual stream, prefetched under the K loop
     if (LN_IN) {
-        const int h4 = g.nslots / 2;                         // float4 per row
-        const f32x4 *sp = reinterpret_cast<const f32x4 *>(g.stats + (size_t)m0 * g.nslots);
-        const int lim = (Mr - m0 < BM ? Mr - m0 : BM) * h4;
-        auto issue = [&]() {   // unconditional (clamped) loads: exactly NL VMEM instructions per wave, as the wait assumes
+        // The tile's BM x nslots (sum, sum^2) slots are one contiguous region of `stats`.  Right after the ring prologue is in flight the
+        // 256 threads fetch it coalesced, wait for everything, reduce it through the ring slot the prologue left free ((mu, rstd) per row,
+        // fixed association order: ln_row_moments) and keep their own rows' moments in registers: the K loop itself then carries no
+        // extra registers or waits, and nothing is left to do between the loop and the epilogue.
+        constexpr int NL = (NQ * BM) / 64;           // float4 loads per thread: BM*nslots*8 B / (256*16 B)
+        constexpr int TPR = 256 / BM >= 4 ? 4 : (256 / BM >= 2 ? 2 : 1);
+        static_assert(BM * 4 * NQ * 8 + BM * 8 <= STAGE, "LN scratch must fit one ring slot");
+        auto head = [&]() {
+            const int h4 = g.nslots / 2;                         // float4 per row
+            const f32x4 *sp = reinterpret_cast<const f32x4 *>(g.stats + (size_t)m0 * g.nslots);
+            const int lim = (Mr - m0 < BM ? Mr - m0 : BM) * h4;
+            f32x4 st[NL > 0 ? NL : 1];
 #pragma unroll
             for (int k = 0; k < NL; k++) {
                 const int idx = (int)threadIdx.x + 256 * k;
                 st[k] = sp[idx < lim ? idx : lim - 1];
             }
-        };
-        glds_mainloop<BM, BN, STAGES, NL>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc, issue);
-        __syncthreads();                                     // every wave is done with the LDS ring
-        float2 *part = reinterpret_cast<float2 *>(smem);     // [BM * h4] partial (sum, sum^2)
-        float2 *murs = part + BM * 4 * NQ;                   // [BM] (mu, rstd)
+            wait_vmcnt<0>();
+            float2 *part = reinterpret_cast<float2 *>(smem + (STAGES - 1) * STAGE);     // [BM * h4] partial (sum, sum^2)
+            float2 *murs = part + BM * 4 * NQ;                                          // [BM] (mu, rstd)
 #pragma unroll
-        for (int k = 0; k < NL; k++) part[threadIdx.x + 256 * k] = make_float2(st[k][0] + st[k][2], st[k][1] + st[k][3]);   // rows >= M: unused
-        __syncthreads();
-        if (threadIdx.x < BM) {
-            float s1 = 0.f, s2 = 0.f;
-            for (int q = 0; q < h4; q++) { const float2 p = part[threadIdx.x * h4 + q]; s1 += p.x; s2 += p.y; }
-            const float mu = s1 * g.inv_d;
-            murs[threadIdx.x] = make_float2(mu, rsqrtf(fmaxf(s2 * g.inv_d - mu * mu, 0.f) + g.eps));
-        }
-        __syncthreads();
+            for (int k = 0; k < NL; k++) part[threadIdx.x + 256 * k] = make_float2(st[k][0] + st[k][2], st[k][1] + st[k][3]);   // rows >= M: unused
+            __syncthreads();
+            {
+                const int row = (int)threadIdx.x / TPR, q = (int)threadIdx.x % TPR;
+                if (row < BM) {
+                    const float2 mr = ln_row_moments<TPR>(part + row * h4, h4, q, g.inv_d, g.eps);
+                    if (q == 0) murs[row] = mr;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < FM; j++) {
+                const float2 p2 = murs[wm * (BM / 2) + j * 16 + lr];
+                ln_mu[j] = p2.x; ln_rs[j] = p2.y;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is handed to the ring at the loop's first barrier
+        };
+        glds_mainloop<BM, BN, STAGES, 0>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc, head);
+    } else if (RESID) {
+        // read-modify-write epilogue: fetch this lane's residual values NOW (FN*FM float4 loads behind the ring prologue, in-order
+        // vmcnt: the counted waits of the loop leave them in flight) so that the epilogue does not start with a dependent HBM round trip
+        auto prefetch = [&]() {
+#pragma unroll
+            for (int i = 0; i < FN; i++)
+#pragma unroll
+                for (int j = 0; j < FM; j++) {
+                    int m = m0 + wm * (BM / 2) + j * 16 + lr;
+                    m = m < Mr ? m : Mr - 1;
+                    int n = n0 + wn * (BN / 2) + i * 16 + lq * 4;
+                    n = n < g.n_store ? n : 0;
+                    xres[i][j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(g.C) + (size_t)m * g.ldc + n);
+                }
+        };
+        glds_mainloop<BM, BN, STAGES, FN * FM>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc, prefetch);
     } else {
         glds_mainloop<BM, BN, STAGES>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc);
     }
@@ -407,12 +470,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
                 if (n >= g.n_store || !row_ok) continue;
                 f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (g.bias) b4 = *reinterpret_cast<const f32x4 *>(g.bias + n);
-                f32x4 *p = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n);
-                const f32x4 v = *p + (acc[i][j] + b4);
-                *p = v;
+                const f32x4 v = xres[i][j] + (acc[i][j] + b4);
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n) = v;
                 uint2 o;
-                o.x = (uint32_t)f32_to_bf16_rn(v[0]) | ((uint32_t)f32_to_bf16_rn(v[1]) << 16);
-                o.y = (uint32_t)f32_to_bf16_rn(v[2]) | ((uint32_t)f32_to_bf16_rn(v[3]) << 16);
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2 *>(g.xb + (size_t)m * g.ldc + n) = o;
                 s1 += (v[0] + v[1]) + (v[2] + v[3]);
                 s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
@@ -424,15 +486,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
         return;
     }
 
-    float ln_mu[FM], ln_rs[FM];
-    if (LN_IN) {
-        const float2 *murs = reinterpret_cast<const float2 *>(smem) + BM * 4 * NQ;
-#pragma unroll
-        for (int j = 0; j < FM; j++) {
-            const float2 p = murs[wm * (BM / 2) + j * 16 + lr];
-            ln_mu[j] = p.x; ln_rs[j] = p.y;
-        }
-    }
 #pragma unroll
     for (int i = 0; i < FN; i++) {
         const int n = n0 + wn * (BN / 2) + i * 16 + lq * 4;
@@ -462,12 +515,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
             }
             if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || LN_IN) {
                 uint2 o;
-                o.x = (uint32_t)f32_to_bf16_rn(v[0]) | ((uint32_t)f32_to_bf16_rn(v[1]) << 16);
-                o.y = (uint32_t)f32_to_bf16_rn(v[2]) | ((uint32_t)f32_to_bf16_rn(v[3]) << 16);
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc + n) = o;
             } else if (EPI == EPI_RESID_F32) {
-                f32x4 *p = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n);
-                *p = *p + v;
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n) = xres[i][j] + v;
             } else {
                 *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n) = v;
             }
@@ -514,75 +566,6 @@ inline hipError_t gemm_launch_cfg(const GemmArgs &g, hipStream_t s) {
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, EPI>), dim3(tiles), dim3(256), shmem, s, g);
     }
     return hipGetLastError();
-}
-
-// LayerNorm-fused epilogues: the slot layout is 2 per 64-column tile, so BN is fixed to 64 and the forced sweep
-// configurations / v1 kernels do not apply; otherwise the same shape policy as gemm_launch below.
-extern int g_gemm_variant;
-template <int EPI, int NQ>
-inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
-    // same measured shape policy as gemm_launch below; variant 101 = the former all-2-stage decode policy (A/B hook)
-    if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI, NQ>(g, s);
-    if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
-    if (g_gemm_variant == 101) return gemm_launch_glds<64, 64, 2, EPI, NQ>(g, s);
-    const long tiles = (long)((g.M + 63) / 64) * (g.N / 64);
-    if (tiles <= 512) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
-    if (tiles <= 768) return gemm_launch_glds<64, 64, 3, EPI, NQ>(g, s);
-    return gemm_launch_glds<64, 64, 2, EPI, NQ>(g, s);
-}
-// Slots per row are padded to 8*NQ (zero filled): NQ = 1 (d_model <= 256), 3 (768), 4 (1024).
-inline int ln_fusion_nq(int d_model) {
-    const int need = d_model / 64 * 2;
-    return need <= 8 ? 1 : (need == 24 ? 3 : (need == 32 ? 4 : 0));   // 0: no folded configuration -> stand-alone LayerNorm
-}
-template <int EPI>
-inline hipError_t gemm_launch_ln(const GemmArgs &g, hipStream_t s) {
-    static_assert(EPI == EPI_RESID_F32_STATS || EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN, "LN-fused epilogues only");
-    if (EPI == EPI_RESID_F32_STATS) return gemm_launch_ln_nq<EPI, 0>(g, s);
-    switch (g.nslots / 8) {
-        case 1: return gemm_launch_ln_nq<EPI, 1>(g, s);
-        case 3: return gemm_launch_ln_nq<EPI, 3>(g, s);
-        case 4: return gemm_launch_ln_nq<EPI, 4>(g, s);
-        default: return hipErrorInvalidValue;
-    }
-}
-
-// Tile choice: keep >= ~1 workgroup per CU (256 CUs) when the problem allows it.
-template <int EPI>
-inline hipError_t gemm_launch(const GemmArgs &g, hipStream_t s) {
-    const long t128 = (long)((g.M + 127) / 128) * (g.N / 128);
-    if (g_gemm_variant == 1) {
-        if (g.N % 128 == 0 && t128 >= 192) return gemm_launch_cfg<128, 128, EPI>(g, s);
-        if (g.N % 128 == 0 && (long)((g.M + 63) / 64) * (g.N / 128) >= 192) return gemm_launch_cfg<64, 128, EPI>(g, s);
-        return gemm_launch_cfg<64, 64, EPI>(g, s);
-    }
-    switch (g_gemm_variant) {   // forced configurations for tools/bench_gemm.py
-        case 10: return gemm_launch_glds<128, 128, 2, EPI>(g, s);
-        case 11: return gemm_launch_glds<128, 128, 3, EPI>(g, s);
-        case 12: return gemm_launch_glds<128, 128, 4, EPI>(g, s);
-        case 20: return gemm_launch_glds<128, 64, 2, EPI>(g, s);
-        case 21: return gemm_launch_glds<128, 64, 3, EPI>(g, s);
-        case 22: return gemm_launch_glds<128, 64, 4, EPI>(g, s);
-        case 30: return gemm_launch_glds<64, 64, 2, EPI>(g, s);
-        case 31: return gemm_launch_glds<64, 64, 3, EPI>(g, s);
-        case 32: return gemm_launch_glds<64, 64, 4, EPI>(g, s);
-        case 100: if (g.M < 2048) return gemm_launch_glds<128, 64, 2, EPI>(g, s); break;
-        case 101: if (g.M < 2048) return gemm_launch_glds<64, 64, 2, EPI>(g, s); break;
-        case 102: if (g.M < 2048) return g.K >= 2048 ? gemm_launch_glds<128, 64, 3, EPI>(g, s) : gemm_launch_glds<64, 64, 2, EPI>(g, s); break;
-        case 103: if (g.M < 2048) return g.K >= 2048 ? gemm_launch_glds<64, 64, 3, EPI>(g, s) : gemm_launch_glds<64, 64, 2, EPI>(g, s); break;
-        case 104: if (g.M >= 2048) return gemm_launch_glds<128, 128, 2, EPI>(g, s); break;
-        default: break;
-    }
-    // measured on MI355X (profiles/r01_gemm_config_sweep.txt + in-situ sweeps): the prefill GEMMs (M >= 2048, thousands of
-    // tiles) want occupancy: 2-stage rings, 3 workgroups per CU.  The decode GEMMs (M = 1024) have only 192-768 tiles, i.e.
-    // 1-3 per CU, and are bound by the latency chain of their K loop: as many stages as still leave every tile resident
-    // at once (768 tiles: 3 stages = 48 KiB -> 3 WG/CU; 192 tiles: 4 stages = 64 KiB -> 2 WG/CU).
-    if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI>(g, s);
-    if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI>(g, s);
-    const long tiles = (long)((g.M + 63) / 64) * (g.N / 64);
-    if (tiles <= 512) return gemm_launch_glds<64, 64, 4, EPI>(g, s);      // 64 KiB ring -> 2 WG/CU -> 512 resident tiles
-    if (tiles <= 768) return gemm_launch_glds<64, 64, 3, EPI>(g, s);      // 48 KiB ring -> 3 WG/CU -> 768 resident tiles
-    return gemm_launch_glds<64, 64, 2, EPI>(g, s);
 }
 
 }  // namespace lmrl

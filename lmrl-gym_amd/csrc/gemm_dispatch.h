@@ -1,0 +1,85 @@
+// gemm_dispatch.h — shape policy: which bf16 GEMM kernel (gemm_bf16.h 4-wave rings, gemm8_bf16.h 8-wave large tiles) runs a given
+// (M, N, K, epilogue).  Every choice below is a measurement (profiles/r01_gemm_config_sweep.txt, profiles/r02_gemm8_bench.txt).
+#pragma once
+#include "gemm8_bf16.h"
+
+namespace lmrl {
+
+// LayerNorm-fused epilogues: the slot layout is 2 per 64-column tile, so BN is fixed to 64 and the forced sweep
+// configurations / v1 kernels do not apply; otherwise the same shape policy as gemm_launch below.
+extern int g_gemm_variant;
+template <int EPI, int NQ>
+inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
+    // same measured shape policy as gemm_launch below; variant 101 = the former all-2-stage decode policy (A/B hook)
+    // M >= 2048 (prefill): the LN consumers (qkv, fc: wide N) run on the 8-wave 128x128 tile of gemm8_bf16.h, two workgroups per CU
+    // (measured +15..19 % over the 4-wave 128x64 ring, profiles/r02_gemm8_bench.txt); the residual producers (N = d_model) stay on the ring
+    if constexpr (EPI != EPI_RESID_F32_STATS && NQ > 0) {
+        if (g.M >= 2048 && g.N % 128 == 0 && g_gemm_variant != 105) return gemm8_launch<128, 128, 2, 4, 2, EPI, NQ>(g, s);
+    }
+    if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI, NQ>(g, s);
+    if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
+    if (g_gemm_variant == 101) return gemm_launch_glds<64, 64, 2, EPI, NQ>(g, s);
+    const long tiles = (long)((g.M + 63) / 64) * (g.N / 64);
+    if (tiles <= 512) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
+    if (tiles <= 768) return gemm_launch_glds<64, 64, 3, EPI, NQ>(g, s);
+    return gemm_launch_glds<64, 64, 2, EPI, NQ>(g, s);
+}
+// Slots per row are padded to 8*NQ (zero filled): NQ = 1 (d_model <= 256), 3 (768), 4 (1024).
+inline int ln_fusion_nq(int d_model) {
+    const int need = d_model / 64 * 2;
+    return need <= 8 ? 1 : (need == 24 ? 3 : (need == 32 ? 4 : 0));   // 0: no folded configuration -> stand-alone LayerNorm
+}
+template <int EPI>
+inline hipError_t gemm_launch_ln(const GemmArgs &g, hipStream_t s) {
+    static_assert(EPI == EPI_RESID_F32_STATS || EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN, "LN-fused epilogues only");
+    if (EPI == EPI_RESID_F32_STATS) return gemm_launch_ln_nq<EPI, 0>(g, s);
+    switch (g.nslots / 8) {
+        case 1: return gemm_launch_ln_nq<EPI, 1>(g, s);
+        case 3: return gemm_launch_ln_nq<EPI, 3>(g, s);
+        case 4: return gemm_launch_ln_nq<EPI, 4>(g, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// Tile choice: keep >= ~1 workgroup per CU (256 CUs) when the problem allows it.
+template <int EPI>
+inline hipError_t gemm_launch(const GemmArgs &g, hipStream_t s) {
+    const long t128 = (long)((g.M + 127) / 128) * (g.N / 128);
+    if (g_gemm_variant == 1) {
+        if (g.N % 128 == 0 && t128 >= 192) return gemm_launch_cfg<128, 128, EPI>(g, s);
+        if (g.N % 128 == 0 && (long)((g.M + 63) / 64) * (g.N / 128) >= 192) return gemm_launch_cfg<64, 128, EPI>(g, s);
+        return gemm_launch_cfg<64, 64, EPI>(g, s);
+    }
+    switch (g_gemm_variant) {   // forced configurations for tools/bench_gemm.py
+        case 10: return gemm_launch_glds<128, 128, 2, EPI>(g, s);
+        case 11: return gemm_launch_glds<128, 128, 3, EPI>(g, s);
+        case 12: return gemm_launch_glds<128, 128, 4, EPI>(g, s);
+        case 20: return gemm_launch_glds<128, 64, 2, EPI>(g, s);
+        case 21: return gemm_launch_glds<128, 64, 3, EPI>(g, s);
+        case 22: return gemm_launch_glds<128, 64, 4, EPI>(g, s);
+        case 30: return gemm_launch_glds<64, 64, 2, EPI>(g, s);
+        case 31: return gemm_launch_glds<64, 64, 3, EPI>(g, s);
+        case 32: return gemm_launch_glds<64, 64, 4, EPI>(g, s);
+        case 100: if (g.M < 2048) return gemm_launch_glds<128, 64, 2, EPI>(g, s); break;
+        case 101: if (g.M < 2048) return gemm_launch_glds<64, 64, 2, EPI>(g, s); break;
+        case 102: if (g.M < 2048) return g.K >= 2048 ? gemm_launch_glds<128, 64, 3, EPI>(g, s) : gemm_launch_glds<64, 64, 2, EPI>(g, s); break;
+        case 103: if (g.M < 2048) return g.K >= 2048 ? gemm_launch_glds<64, 64, 3, EPI>(g, s) : gemm_launch_glds<64, 64, 2, EPI>(g, s); break;
+        case 104: if (g.M >= 2048) return gemm_launch_glds<128, 128, 2, EPI>(g, s); break;
+        default: break;
+    }
+    // measured on MI355X (profiles/r01_gemm_config_sweep.txt + in-situ sweeps): the prefill GEMMs (M >= 2048, thousands of
+    // tiles) want occupancy: 2-stage rings, 3 workgroups per CU.  The decode GEMMs (M = 1024) have only 192-768 tiles, i.e.
+    // 1-3 per CU, and are bound by the latency chain of their K loop: as many stages as still leave every tile resident
+    // at once (768 tiles: 3 stages = 48 KiB -> 3 WG/CU; 192 tiles: 4 stages = 64 KiB -> 2 WG/CU).
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || EPI == EPI_F32) {
+        if (g.M >= 2048 && g.N % 128 == 0 && g.K < 2048) return gemm8_launch<128, 128, 2, 4, 2, EPI>(g, s);   // wide prefill GEMMs: 8-wave 128x128 tiles
+    }
+    if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI>(g, s);
+    if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI>(g, s);
+    const long tiles = (long)((g.M + 63) / 64) * (g.N / 64);
+    if (tiles <= 512) return gemm_launch_glds<64, 64, 4, EPI>(g, s);      // 64 KiB ring -> 2 WG/CU -> 512 resident tiles
+    if (tiles <= 768) return gemm_launch_glds<64, 64, 3, EPI>(g, s);      // 48 KiB ring -> 3 WG/CU -> 768 resident tiles
+    return gemm_launch_glds<64, 64, 2, EPI>(g, s);
+}
+
+}  // namespace lmrl

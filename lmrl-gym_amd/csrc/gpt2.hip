@@ -22,7 +22,7 @@
 #include "../../include/lmrl_amd.h"
 #include "common.h"
 #include <hip/hip_ext.h>
-#include "gemm_bf16.h"
+#include "gemm_dispatch.h"
 
 namespace lmrl {
 
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void embed_stats_kernel(const uint16_t *__rest
                                   bf16_to_f32((uint16_t)(a.y >> 16)) + bf16_to_f32((uint16_t)(p.y >> 16))};
             *reinterpret_cast<f32x4 *>(x + (size_t)r * d + c) = v;
             uint2 o;
-            o.x = (uint32_t)f32_to_bf16_rn(v[0]) | ((uint32_t)f32_to_bf16_rn(v[1]) << 16);
-            o.y = (uint32_t)f32_to_bf16_rn(v[2]) | ((uint32_t)f32_to_bf16_rn(v[3]) << 16);
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
             *reinterpret_cast<uint2 *>(xb + (size_t)r * d + c) = o;
             s1 += (v[0] + v[1]) + (v[2] + v[3]);
             s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
@@ -423,10 +423,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
         }
         if (rr == 0) {
             uint4 pk;
-            pk.x = (uint32_t)f32_to_bf16_rn(r8[0]) | ((uint32_t)f32_to_bf16_rn(r8[1]) << 16);
-            pk.y = (uint32_t)f32_to_bf16_rn(r8[2]) | ((uint32_t)f32_to_bf16_rn(r8[3]) << 16);
-            pk.z = (uint32_t)f32_to_bf16_rn(r8[4]) | ((uint32_t)f32_to_bf16_rn(r8[5]) << 16);
-            pk.w = (uint32_t)f32_to_bf16_rn(r8[6]) | ((uint32_t)f32_to_bf16_rn(r8[7]) << 16);
+            pk.x = pack_bf16x2(r8[0], r8[1]);
+            pk.y = pack_bf16x2(r8[2], r8[3]);
+            pk.z = pack_bf16x2(r8[4], r8[5]);
+            pk.w = pack_bf16x2(r8[6], r8[7]);
             *reinterpret_cast<uint4 *>(out + (row0 + j) * d + (size_t)h * 64 + cc * 8) = pk;
         }
     }
@@ -575,8 +575,8 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
 #pragma unroll
         for (int f = 0; f < 4; f++) {
             uint2 o;
-            o.x = (uint32_t)f32_to_bf16_rn(oacc[f][0] * inv) | ((uint32_t)f32_to_bf16_rn(oacc[f][1] * inv) << 16);
-            o.y = (uint32_t)f32_to_bf16_rn(oacc[f][2] * inv) | ((uint32_t)f32_to_bf16_rn(oacc[f][3] * inv) << 16);
+            o.x = pack_bf16x2(oacc[f][0] * inv, oacc[f][1] * inv);
+            o.y = pack_bf16x2(oacc[f][2] * inv, oacc[f][3] * inv);
             *reinterpret_cast<uint2 *>(out + (row0 + j) * d + (size_t)h * 64 + f * 16 + g * 4) = o;
         }
     }

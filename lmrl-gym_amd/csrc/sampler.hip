@@ -17,7 +17,7 @@
 // greedy decoding (temperature == 0) is deterministic and is what parity tests pin.
 #include "../../include/lmrl_amd.h"
 #include "common.h"
-#include "gemm_bf16.h"
+#include "gemm_dispatch.h"
 
 namespace lmrl {
 
