@@ -25,12 +25,6 @@
 
 namespace lmrl {
 
-#ifdef LMRL_G8_PROBE   // tools/gemm8_bench.hip only: per-workgroup s_memtime stamps (entry, stage 0 landed, K loop done, epilogue done)
-__device__ unsigned long long *g8_probe = nullptr;
-#define LMRL_G8_STAMP(I) do { if (g8_probe && threadIdx.x == 0) g8_probe[(size_t)blockIdx.x * 4 + (I)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define LMRL_G8_STAMP(I) do { } while (0)
-#endif
 
 struct G8NoHook { __device__ __forceinline__ void operator()() const {} };
 

@@ -20,6 +20,13 @@
 
 namespace lmrl {
 
+#ifdef LMRL_G8_PROBE   // tools/gemm8_bench.hip only: per-workgroup s_memtime stamps (entry, stage 0 landed, K loop done, epilogue done)
+__device__ unsigned long long *g8_probe = nullptr;
+#define LMRL_G8_STAMP(I) do { if (g8_probe && threadIdx.x == 0) g8_probe[(size_t)blockIdx.x * 4 + (I)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LMRL_G8_STAMP(I) do { } while (0)
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -342,6 +349,7 @@ __device__ __forceinline__ void glds_mainloop(const uint16_t *__restrict__ A, in
         else if (inflight == 1 && STAGES >= 3) wait_vmcnt<L>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+        if (kt == 0) LMRL_G8_STAMP(1);
         if (kt + STAGES - 1 < nk) {
             int nslot = slot + STAGES - 1;
             nslot = nslot >= STAGES ? nslot - STAGES : nslot;
@@ -389,6 +397,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
     const int lr = lane & 15, lq = lane >> 4;
     const int Mr = g.m_dev ? *g.m_dev : g.M;          // rows actually present (workgroup-uniform scalar load)
     if (m0 >= Mr) return;
+    LMRL_G8_STAMP(0);
     f32x4 acc[FN][FM];
 #pragma unroll
     for (int i = 0; i < FN; i++)
@@ -456,6 +465,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
     } else {
         glds_mainloop<BM, BN, STAGES>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc);
     }
+    LMRL_G8_STAMP(2);
 
     if (EPI == EPI_RESID_F32_STATS) {
         // x += acc + bias ; xb = bf16(x) ; slot (tile_n, wn) of the row gets (sum x, sum x^2) over this wave's BN/2 columns
@@ -483,6 +493,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
             s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
             if (lq == 0 && row_ok) g.stats[(size_t)m * g.nslots + tile_n * 2 + wn] = make_float2(s1, s2);
         }
+        LMRL_G8_STAMP(3);
         return;
     }
 
@@ -525,6 +536,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
             }
         }
     }
+#ifdef LMRL_G8_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LMRL_G8_STAMP(3);
+#endif
 }
 
 extern int g_gemm_variant;   // test/bench hook: 0 = auto (v2), 1 = v1 register-staged kernels

@@ -15,6 +15,10 @@ inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
     // (measured +15..19 % over the 4-wave 128x64 ring, profiles/r02_gemm8_bench.txt); the residual producers (N = d_model) stay on the ring
     if constexpr (EPI != EPI_RESID_F32_STATS && NQ > 0) {
         if (g.M >= 2048 && g.N % 128 == 0 && g_gemm_variant != 105) return gemm8_launch<128, 128, 2, 4, 2, EPI, NQ>(g, s);
+        // decode (M ~ 1024) LN consumers with a wide N (qkv 144 tiles, fc 192 tiles of 128x128): one 8-wave workgroup per CU moves half the
+        // bytes per flop of the 64x64 ring and measured 12.5 vs 15.0 us (profiles/r02_gemm8_bench.txt); 3 slots: nothing else shares the LDS
+        if (g.M >= 512 && g.N % 128 == 0 && g.K < 2048 && (long)((g.M + 127) / 128) * (g.N / 128) >= 128 && g_gemm_variant != 105)
+            return gemm8_launch<128, 128, 2, 4, 3, EPI, NQ>(g, s);
     }
     if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI, NQ>(g, s);
     if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);

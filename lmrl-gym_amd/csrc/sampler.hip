@@ -43,7 +43,10 @@ __host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1,
 // step).  Gumbel(0,1) = -log(-log u), range [-2.8, 16.6].
 __device__ __forceinline__ float gumbel_from_bits(uint32_t x) {
     const float u = ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-07f;
-    return -__logf(-__logf(u));
+    // raw v_log_f32 (log2): u in [2^-24, 1) and -ln u in [6e-8, 16.7] are normal numbers, so the denormal pre-scaling that __logf
+    // wraps around the instruction (compare + select + ldexp per call) is dead weight here
+    const float e = -0.6931471805599453f * __builtin_amdgcn_logf(u);          // -ln u  ~ Exp(1)
+    return -0.6931471805599453f * __builtin_amdgcn_logf(e);                   // -ln(-ln u)
 }
 
 struct SampleParams {
@@ -59,23 +62,26 @@ struct SampleParams {
 constexpr int kPartialFloats = 6;   // {max, sumexp, best_score, best_col, best_z, pad}
 
 // LM head:   z[m][n] = (h[m] . wte[n])   (+ ILQL perturbation, + steer), then the sampling epilogue on z / T.
-// One 128 x 64 tile per workgroup on the shared global_load_lds main loop (gemm_bf16.h), up to three GEMM passes over
-// the same output tile (pi, q1, q2) combined in registers.  The two column-half waves of a row merge their partials
-// through LDS so exactly one partial per (row, 64-column tile) reaches HBM.
-constexpr int kLmBM = 128, kLmBN = 64, kLmStages = 2;
+// One 128 x 128 tile per 8-wave workgroup (2 x 4 waves, 64 x 32 outputs each) on the large-tile main loop of gemm8_bf16.h, two
+// workgroups per CU; up to three GEMM passes over the same output tile (pi, q1, q2) combined in registers.  The four column-quarter
+// waves of a row merge their partials through LDS so exactly one partial per (row, 128-column tile) reaches HBM.
+constexpr int kLmBM = 128, kLmBN = 128, kLmWM = 2, kLmWN = 4, kLmStages = 2;
 
 struct RowPartial { float pmax, psum, best, best_z; int best_col; };
 
+template <bool WANT_LP = true>
 __device__ __forceinline__ void merge_partial(RowPartial &a, float om, float os, float ob, float oz, int oc) {
-    const float nm = fmaxf(a.pmax, om);
-    const float e1 = (a.pmax == -INFINITY) ? 0.f : __expf(a.pmax - nm), e2 = (om == -INFINITY) ? 0.f : __expf(om - nm);
-    a.psum = a.psum * e1 + os * e2;
-    a.pmax = nm;
+    if (WANT_LP) {      // log-sum-exp pieces only when the caller asked for the sampled token's log-probability
+        const float nm = fmaxf(a.pmax, om);
+        const float e1 = (a.pmax == -INFINITY) ? 0.f : __expf(a.pmax - nm), e2 = (om == -INFINITY) ? 0.f : __expf(om - nm);
+        a.psum = a.psum * e1 + os * e2;
+        a.pmax = nm;
+    }
     if (ob > a.best || (ob == a.best && oc < a.best_col)) { a.best = ob; a.best_col = oc; a.best_z = oz; }
 }
 
-template <int NOPS>
-__global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__restrict__ A0, const uint16_t *__restrict__ W0,
+template <int NOPS, bool WANT_LP>
+__global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const uint16_t *__restrict__ A0, const uint16_t *__restrict__ W0,
                                                              const uint16_t *__restrict__ A1, const uint16_t *__restrict__ W1,
                                                              const float *__restrict__ bias1,
                                                              const uint16_t *__restrict__ A2, const uint16_t *__restrict__ W2,
@@ -84,10 +90,10 @@ __global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__r
                                                              float *__restrict__ partials,   // [M][tiles_n][kPartialFloats]
                                                              float *__restrict__ logits_out, // optional [M][ldo] f32
                                                              int M, int N, int K, int ldo, SampleParams sp, XcdMap xm) {
-    constexpr int BM = kLmBM, BN = kLmBN, FM = BM / 32, FN = BN / 32;
+    constexpr int BM = kLmBM, BN = kLmBN, WM = kLmWM, WN = kLmWN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = N / BN;
     int tile_m, tile_n;
     if (!xcd_tile(xm, blockIdx.x, tile_m, tile_n)) return;   // workgroup-uniform
@@ -106,10 +112,10 @@ __global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__r
         for (int i = 0; i < FN; i++)
 #pragma unroll
             for (int j = 0; j < FM; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        glds_mainloop<BM, BN, kLmStages>(A, K, W, K, M, m0, n0, smem, acc);
+        g8_mainloop<BM, BN, WM, WN, kLmStages>(A, K, W, K, M, m0, n0, smem, acc);
 #pragma unroll
         for (int i = 0; i < FN; i++) {
-            const int n = n0 + wn * (BN / 2) + i * 16 + lq * 4;
+            const int n = n0 + wn * TN + i * 16 + lq * 4;
             f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
             if (op == 1 && bias1) b4 = *reinterpret_cast<const f32x4 *>(bias1 + n);
             if (op == 2 && bias2) b4 = *reinterpret_cast<const f32x4 *>(bias2 + n);
@@ -126,19 +132,19 @@ __global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__r
         }
     }
 
-    // ---- sampling epilogue
+    // ---- sampling epilogue: every wave first reduces ALL its rows (FM partials per lane, lane groups merged by shuffles), then ONE
+    // exchange through LDS merges the WN column quarters — two barriers per tile instead of two per 16-row fragment
     const uint32_t epoch = sp.epoch ? *sp.epoch : 0u;
-    __syncthreads();                                   // the LDS ring is free: reuse it for the wn=1 -> wn=0 hand-off
-    float *xch = reinterpret_cast<float *>(smem);      // [2 (wm)][64 rows][5]
+    RowPartial rps[FM];
 #pragma unroll
     for (int j = 0; j < FM; j++) {
-        const int m = m0 + wm * (BM / 2) + j * 16 + lr;
+        const int m = m0 + wm * TM + j * 16 + lr;
         const int st = (steer_tok && m < M) ? steer_tok[m] : -1;
         RowPartial rp{-INFINITY, 0.f, -INFINITY, 0.f, 0x7fffffff};
         float vv[FN][4];
 #pragma unroll
         for (int i = 0; i < FN; i++) {
-            const int n = n0 + wn * (BN / 2) + i * 16 + lq * 4;
+            const int n = n0 + wn * TN + i * 16 + lq * 4;
             uint32_t rnd[4] = {0, 0, 0, 0};
             if (!sp.greedy) philox4x32_10((uint32_t)m, (uint32_t)(n >> 2), sp.step, epoch, sp.seed_lo, sp.seed_hi, rnd);
             float zz[4];
@@ -155,13 +161,14 @@ __global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__r
                 const bool colok = (n + r) < sp.vocab;
                 const float v = colok ? zz[r] * sp.inv_temperature : -INFINITY;
                 const float sc = sp.greedy ? v : v + gumbel_from_bits(rnd[r]);
-                if (colok && sc > rp.best) { rp.best = sc; rp.best_col = n + r; rp.best_z = v; }
+                const bool take = sc > rp.best;                 // a padding column scores -inf and never wins; selects, not branches
+                rp.best = take ? sc : rp.best; rp.best_col = take ? n + r : rp.best_col; rp.best_z = take ? v : rp.best_z;
                 vv[i][r] = v;
-                rp.pmax = fmaxf(rp.pmax, v);
+                if (WANT_LP) rp.pmax = fmaxf(rp.pmax, v);
             }
         }
         // this lane's 4*FN logits: one exp each against the lane maximum (padding columns are -inf -> exp = 0)
-        if (rp.pmax > -INFINITY) {
+        if (WANT_LP && rp.pmax > -INFINITY) {
 #pragma unroll
             for (int i = 0; i < FN; i++)
 #pragma unroll
@@ -170,22 +177,34 @@ __global__ __launch_bounds__(256) void lm_head_sample_kernel(const uint16_t *__r
         // merge the 4 lane groups (lq) that hold the same row: xor 16, 32
 #pragma unroll
         for (int o = 16; o <= 32; o <<= 1)
-            merge_partial(rp, __shfl_xor(rp.pmax, o), __shfl_xor(rp.psum, o), __shfl_xor(rp.best, o), __shfl_xor(rp.best_z, o),
-                          __shfl_xor(rp.best_col, o));
-        const int rl = j * 16 + lr;                     // row within this wave's 64-row half
-        float *slot = xch + ((size_t)wm * 64 + rl) * 5;
-        if (wn == 1 && lq == 0) {
-            slot[0] = rp.pmax; slot[1] = rp.psum; slot[2] = rp.best; slot[3] = rp.best_z; slot[4] = __int_as_float(rp.best_col);
+            merge_partial<WANT_LP>(rp, __shfl_xor(rp.pmax, o), __shfl_xor(rp.psum, o), __shfl_xor(rp.best, o), __shfl_xor(rp.best_z, o),
+                                   __shfl_xor(rp.best_col, o));
+        rps[j] = rp;
+    }
+    __syncthreads();                                   // the LDS ring is free: reuse it for the column-quarter hand-off
+    float *xch = reinterpret_cast<float *>(smem);      // [WM][TM rows][WN - 1][5]
+    if (wn > 0 && lq == 0) {
+#pragma unroll
+        for (int j = 0; j < FM; j++) {
+            float *sl = xch + ((((size_t)wm * TM + j * 16 + lr) * (WN - 1)) + (wn - 1)) * 5;
+            sl[0] = rps[j].pmax; sl[1] = rps[j].psum; sl[2] = rps[j].best; sl[3] = rps[j].best_z; sl[4] = __int_as_float(rps[j].best_col);
         }
-        __syncthreads();
-        if (wn == 0 && lq == 0) {
-            merge_partial(rp, slot[0], slot[1], slot[2], slot[3], __float_as_int(slot[4]));
+    }
+    __syncthreads();
+    if (wn == 0 && lq == 0) {
+#pragma unroll
+        for (int j = 0; j < FM; j++) {
+            const int m = m0 + wm * TM + j * 16 + lr;
+            const float *slot = xch + (((size_t)wm * TM + j * 16 + lr) * (WN - 1)) * 5;
+            RowPartial rp = rps[j];
+#pragma unroll
+            for (int w = 0; w < WN - 1; w++)            // fixed order: column quarters 1, 2, 3
+                merge_partial<WANT_LP>(rp, slot[w * 5 + 0], slot[w * 5 + 1], slot[w * 5 + 2], slot[w * 5 + 3], __float_as_int(slot[w * 5 + 4]));
             if (m < M) {
                 float *p = partials + ((size_t)m * tiles_n + tile_n) * kPartialFloats;
                 p[0] = rp.pmax; p[1] = rp.psum; p[2] = rp.best; p[3] = __int_as_float(rp.best_col); p[4] = rp.best_z; p[5] = 0.f;
             }
         }
-        __syncthreads();
     }
 }
 
@@ -440,15 +459,14 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     const uint16_t *A2 = (const uint16_t *)q_hidden2_d, *W2 = (const uint16_t *)q_w2_d;
     {
     ProfScope ps(PROF_LM_HEAD_SAMPLE, s, 2.0 * (double)m * (double)vocab_padded * (double)d_model * nops);
-    if (nops == 1)
-        hipLaunchKernelGGL(lm_head_sample_kernel<1>, dim3(tiles), dim3(256), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
-                           steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm);
-    else if (nops == 2)
-        hipLaunchKernelGGL(lm_head_sample_kernel<2>, dim3(tiles), dim3(256), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
-                           steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm);
-    else
-        hipLaunchKernelGGL(lm_head_sample_kernel<3>, dim3(tiles), dim3(256), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
-                           steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm);
+#define LMRL_LM_LAUNCH(NOPS_, LP_)                                                                                                    \
+    hipLaunchKernelGGL((lm_head_sample_kernel<NOPS_, LP_>), dim3(tiles), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, \
+                       q_b2_d, steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm)
+    const bool lp = logprob_d != nullptr;      // the log-sum-exp (one exp per logit) is computed only when the log-prob is wanted
+    if (nops == 1) { if (lp) LMRL_LM_LAUNCH(1, true); else LMRL_LM_LAUNCH(1, false); }
+    else if (nops == 2) { if (lp) LMRL_LM_LAUNCH(2, true); else LMRL_LM_LAUNCH(2, false); }
+    else { if (lp) LMRL_LM_LAUNCH(3, true); else LMRL_LM_LAUNCH(3, false); }
+#undef LMRL_LM_LAUNCH
     }
     LMRL_CHECK_LAUNCH();
     const bool nucleus = p->top_p > 0.f && p->top_p < 1.f && !sp.greedy;

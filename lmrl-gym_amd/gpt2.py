@@ -179,9 +179,11 @@ class KVSession:
         self._len_bound = max(self._len_bound, n_pos)
 
     def sample(self, params: SampleParams, steer_tok=None, active=None, hidden=None, logits_out=None,
-               q1=None, q2=None):
+               q1=None, q2=None, want_logprob: bool = True):
         """Fused LM head + sampling of one token per env from `hidden` (default: last_hidden).
-        q1/q2: optional (q_hidden bf16 [B][d], w bf16 [Vp][d], bias f32 [Vp]) ILQL operands."""
+        q1/q2: optional (q_hidden bf16 [B][d], w bf16 [Vp][d], bias f32 [Vp]) ILQL operands.
+        want_logprob=False skips the log-sum-exp over the vocabulary (the reference's sampling step returns only the token;
+        rollouts do not use the sampled token's log-probability) and returns (token, None)."""
         e = self.eng
         h = self.last_hidden if hidden is None else hidden
         qa = [None] * 6
@@ -191,7 +193,8 @@ class KVSession:
             qa[3:6] = [_lib.ptr(x) for x in q2]
         _lib.check(e._L.lmrl_lm_head_sample(_lib.ptr(h), _lib.ptr(e.wte), qa[0], qa[1], qa[2], qa[3], qa[4], qa[5], self.B,
                                             e.cfg.d_model, e.cfg.vocab, e.cfg.vocab_padded, ctypes.byref(params),
-                                            _lib.ptr(steer_tok), _lib.ptr(active), _lib.ptr(self.token), _lib.ptr(self.logprob),
+                                            _lib.ptr(steer_tok), _lib.ptr(active), _lib.ptr(self.token),
+                                            _lib.ptr(self.logprob) if want_logprob else None,
                                             _lib.ptr(logits_out), _lib.ptr(self.sample_ws), _lib.stream_ptr()),
                    "lmrl_lm_head_sample")
-        return self.token, self.logprob
+        return self.token, (self.logprob if want_logprob else None)

@@ -73,7 +73,7 @@ class GPT2PPOPolicy(BatchedTextPolicy):
         return [self.engine]
 
     def _sample(self, gen: _Generator, params: SampleParams, active_d, logits_out):
-        return gen.sessions[0].sample(params, active=active_d, logits_out=logits_out)
+        return gen.sessions[0].sample(params, active=active_d, logits_out=logits_out, want_logprob=False)
 
     def act(self, text_history: List[Optional[TextHistory]], done: Optional[List[bool]] = None) -> List[Optional[TextHistory]]:
         import torch
@@ -187,7 +187,7 @@ class GPT2ValuePolicy(GPT2PPOPolicy):
                                         4, _lib.stream_ptr()), "lmrl_gemm_bf16(q head dense1 + relu)")
             ops.append((qh, head["w2"], head["b2"]))
         params.beta = self.beta
-        return pi_ses.sample(params, active=active_d, logits_out=logits_out, q1=ops[0], q2=ops[1])
+        return pi_ses.sample(params, active=active_d, logits_out=logits_out, q1=ops[0], q2=ops[1], want_logprob=False)
 
 
 def heads_to_engine_layout(head_params: dict, vocab_padded: int, device) -> dict:

@@ -268,7 +268,8 @@ class WordleRolloutEngine:
                             self._ck(L.lmrl_gemm_bf16(_lib.ptr(self.vses.last_hidden), _lib.ptr(head["w1"]), _lib.ptr(head["b1"]), _lib.ptr(self.qh[i]),
                                                       B, dv, dv, dv, dv, dv, 4, sp), "q head dense1 + relu")
                             qops[i] = (self.qh[i], head["w2"], head["b2"])
-                self.ses.sample(p, steer_tok=steer, active=self.traj["gen_active"], logits_out=logits_out, q1=qops[0], q2=qops[1])
+                self.ses.sample(p, steer_tok=steer, active=self.traj["gen_active"], logits_out=logits_out, q1=qops[0], q2=qops[1],
+                                want_logprob=False)
                 self._ck(L.lmrl_wordle_tok_accept(self._tok, tr, _lib.ptr(self.ses.token), k, _lib.ptr(self.next_tok),
                                                   _lib.ptr(self.next_cnt), None, B, sp), "tok_accept")
                 if k < self.max_new - 1:

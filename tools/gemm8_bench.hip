@@ -61,6 +61,7 @@ int main(int argc, char **argv) {
                                  {7168, 768, 3072, "prefill fc2"}, {1024, 50432, 768, "lm head"}, {1024, 2304, 768, "decode qkv"},
                                  {1024, 3072, 768, "decode fc"}, {1024, 768, 3072, "decode fc2"}, {4096, 4096, 4096, "4096^3"}};
     if (quick) { shapes = {shapes[0], shapes[2], shapes[4]}; }
+    if (argc > 1 && std::string(argv[1]) == "decode") { shapes = {{1024, 2304, 768, "decode qkv"}, {1024, 768, 768, "decode proj"}, {1024, 3072, 768, "decode fc"}, {1024, 768, 3072, "decode fc2"}}; }
     std::vector<Cfg> cfgs = {
         {"ring 128x64 s2 (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<128, 64, 2, EPI_BF16>(g, s); }, 128, 64},
         {"ring 64x64 s3 (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<64, 64, 3, EPI_BF16>(g, s); }, 64, 64},
@@ -79,6 +80,10 @@ int main(int argc, char **argv) {
         {"g8 128x128 2x4 s2 GELU_LN", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 4, 2, EPI_GELU_BF16_LN, 3>(g, s); }, 128, 128, false, true},
         {"ring 128x64 s2 BF16_LN", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<128, 64, 2, EPI_BF16_LN, 3>(g, s); }, 128, 64, false, true},
         {"g8 128x128 2x4 s2 BF16_LN", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 4, 2, EPI_BF16_LN, 3>(g, s); }, 128, 128, false, true},
+        {"ring 64x64 s4 (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<64, 64, 4, EPI_BF16>(g, s); }, 64, 64},
+        {"ring 64x64 s6 (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<64, 64, 6, EPI_BF16>(g, s); }, 64, 64},
+        {"ring 64x64 s4 RESID_STATS", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<64, 64, 4, EPI_RESID_F32_STATS>(g, s); }, 64, 64, false, true},
+        {"ring 64x64 s3 GELU_LN", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<64, 64, 3, EPI_GELU_BF16_LN, 3>(g, s); }, 64, 64, false, true},
         {"ring 128x64 s2 GELU", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<128, 64, 2, EPI_GELU_BF16>(g, s); }, 128, 64, false, true},
         {"g8 128x128 2x4 s2 GELU", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 4, 2, EPI_GELU_BF16>(g, s); }, 128, 128, false, true},
     };
@@ -105,7 +110,8 @@ int main(int argc, char **argv) {
                 if (N % cfgs[c].bn) continue;
                 GemmArgs g{A, W, bias, C, M, N, K, K, N, N};
                 if (cfgs[c].ln) {
-                    if (K != 768) continue;
+                    if (K != 768 && cfgs[c].name.find("RESID") == std::string::npos) continue;
+                    if (cfgs[c].name.find("RESID") != std::string::npos) { if (N != 768) continue; g.xb = reinterpret_cast<uint16_t *>(R); }
                     g.stats = reinterpret_cast<float2 *>(stats); g.colsum = colsum; g.nslots = 24; g.inv_d = 1.f / 768.f; g.eps = 1e-5f;
                 }
                 if (rnd == 0 && cfgs[c].ln) errs[c] = 0.f;
@@ -127,12 +133,12 @@ int main(int argc, char **argv) {
         }
         // per-workgroup timeline of the g8 configurations (one extra launch each): cycles from the first workgroup's entry
         for (size_t c = 0; c < cfgs.size(); c++) {
-            if (us[c].empty() || cfgs[c].name.substr(0, 2) != "g8") continue;
+            if (us[c].empty()) continue;
             const size_t nwg = 8 * 4096;
             unsigned long long *pb; CK(hipMalloc(&pb, nwg * 4 * 8)); CK(hipMemsetAsync(pb, 0, nwg * 4 * 8, st));
             CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g8_probe), &pb, sizeof(pb), 0, hipMemcpyHostToDevice, st));
             GemmArgs g{A, W + (size_t)(NWC - 1) * N * K, bias, C, M, N, K, K, N, N};
-            if (cfgs[c].ln) { g.stats = reinterpret_cast<float2 *>(stats); g.colsum = colsum; g.nslots = 24; g.inv_d = 1.f / 768.f; g.eps = 1e-5f; }
+            if (cfgs[c].ln) { g.stats = reinterpret_cast<float2 *>(stats); g.colsum = colsum; g.nslots = 24; g.inv_d = 1.f / 768.f; g.eps = 1e-5f; g.xb = reinterpret_cast<uint16_t *>(R); }
             CK(cfgs[c].run(g, st));
             std::vector<unsigned long long> h(nwg * 4);
             CK(hipMemcpyAsync(h.data(), pb, nwg * 4 * 8, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
