@@ -432,6 +432,116 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------ decode attention, single-sweep form
+// Single-token decode (C = 1), one wave per (env, head) as attention_kernel<1>, restructured so that a strand costs TWO dependent memory
+// latencies instead of three or four: the scalar length load, then ONE batch of vector loads covering the whole context — ceil(L0 / 8)
+// key blocks, a wave-uniform count, so up to 8 U cached positions are requested at once and no row beyond the context is touched
+// (speculating past the length was measured: the over-read costs more bandwidth than the saved latency is worth).  The query and the
+// new token's own K/V row (taken from the qkv buffer, attended last, appended to the cache) are requested before the length arrives.
+// Softmax state per 8-lane row group, groups merged at the end (as above); the QK dot product is v_dot2_f32_bf16 on packed operands.
+template <int U>
+__global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *__restrict__ qkv,   // [rows][3d]
+                                                               uint16_t *__restrict__ kcache, uint16_t *__restrict__ vcache,
+                                                               const int32_t *__restrict__ cnt, const int32_t *__restrict__ len,
+                                                               uint16_t *__restrict__ out,          // [rows][d]
+                                                               int B, int H, int Tmax, int d, const int32_t *__restrict__ off, int n_shared) {
+    typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+    const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wave_id >= B * H) return;
+    const int b = wave_id / H, h = wave_id - b * H;
+    const int rr = lane >> 3, cc = lane & 7;
+    // wave-uniform bases (SGPR): env 0's rows of this head, and this env's element offset from them.  Positions < n_shared hold the same
+    // values in every env (a prompt prefix broadcast by lmrl_gpt2_kv_broadcast): they are read from env 0, i.e. from L2, not once per env
+    const char *kc = reinterpret_cast<const char *>(kcache + (size_t)h * 64);
+    const char *vc = reinterpret_cast<const char *>(vcache + (size_t)h * 64);
+    const uint32_t env_row = (uint32_t)b * (uint32_t)Tmax;
+    const size_t row0 = off ? (size_t)off[b] : (size_t)b;           // first (only) row of this env in the possibly compacted batch
+    const uint16_t *qbase = qkv + row0 * ((size_t)3 * d) + (size_t)h * 64 + cc * 8;
+    const uint4 qv = *reinterpret_cast<const uint4 *>(qbase);
+    const uint4 knew = *reinterpret_cast<const uint4 *>(qbase + d), vnew = *reinterpret_cast<const uint4 *>(qbase + 2 * d);
+    if (cnt[b] <= 0) return;                                         // wave-uniform: finished env (its rows are not in the batch)
+    const int L0 = len[b];
+    uint4 kr[U], vr[U];
+#define LMRL_DEC_LOAD(TBASE)                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < U; u++)                                                             \
+        if ((TBASE) + u * 8 < L0) {                                  /* wave-uniform: block u holds cached positions */ \
+            const int tt_ = (TBASE) + u * 8 + rr;                                                             \
+            const uint32_t tc_ = (uint32_t)(tt_ < L0 ? tt_ : L0 - 1);                                         \
+            const uint32_t bo_ = (((tc_ < (uint32_t)n_shared ? 0u : env_row) + tc_) * (uint32_t)d + (uint32_t)cc * 8u) * 2u; \
+            kr[u] = *reinterpret_cast<const uint4 *>(kc + bo_);                                               \
+            vr[u] = *reinterpret_cast<const uint4 *>(vc + bo_);                                               \
+        }
+    LMRL_DEC_LOAD(0);
+    if (rr == 0 && L0 < Tmax) {                                      // append the new token's K/V row to the cache
+        *reinterpret_cast<uint4 *>(const_cast<char *>(kc) + (((size_t)env_row + L0) * d + cc * 8) * 2) = knew;
+        *reinterpret_cast<uint4 *>(const_cast<char *>(vc) + (((size_t)env_row + L0) * d + cc * 8) * 2) = vnew;
+    }
+    uint32_t qp[4];                                                  // query slice as packed bf16 pairs, pre-scaled by 1/sqrt(64) (exact)
+    {
+        const uint32_t w[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) qp[k] = pack_bf16x2(bf16_to_f32((uint16_t)(w[k] & 0xffff)) * 0.125f, bf16_to_f32((uint16_t)(w[k] >> 16)) * 0.125f);
+    }
+    float m = -1e30f, l = 0.f, o[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = 0.f;
+#define LMRL_DEC_ROW(KW, VW, OK)                                                                               \
+    do {                                                                                                       \
+        const uint32_t kw_[4] = {(KW).x, (KW).y, (KW).z, (KW).w};                                              \
+        const uint32_t vw_[4] = {(VW).x, (VW).y, (VW).z, (VW).w};                                              \
+        float s_ = 0.f;                                                                                        \
+        _Pragma("unroll") for (int k = 0; k < 4; k++)                                                          \
+            s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_v, qp[k]), __builtin_bit_cast(bf16x2_v, kw_[k]), s_, false); \
+        s_ += dpp_f32<0xB1>(s_);      /* quad_perm [1,0,3,2]  (lane ^ 1) */                                    \
+        s_ += dpp_f32<0x4E>(s_);      /* quad_perm [2,3,0,1]  (lane ^ 2) */                                    \
+        s_ += dpp_f32<0x141>(s_);     /* row_half_mirror: the other quad of this 8-lane group */               \
+        const float m_new_ = (OK) ? fmaxf(m, s_) : m;                                                          \
+        const float alpha_ = __expf(m - m_new_);                                                               \
+        const float pr_ = (OK) ? __expf(s_ - m_new_) : 0.f;                                                    \
+        l = l * alpha_ + pr_;                                                                                  \
+        _Pragma("unroll") for (int k = 0; k < 4; k++) {                                                        \
+            o[2 * k] = fmaf(pr_, __uint_as_float(vw_[k] << 16), o[2 * k] * alpha_);                            \
+            o[2 * k + 1] = fmaf(pr_, __uint_as_float(vw_[k] & 0xffff0000u), o[2 * k + 1] * alpha_);            \
+        }                                                                                                      \
+        m = m_new_;                                                                                            \
+    } while (0)
+    for (int t0 = 0; t0 < L0; t0 += 8 * U) {
+        if (t0 > 0) LMRL_DEC_LOAD(t0);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (t0 + u * 8 < L0) {                                   // wave-uniform
+                const bool ok = t0 + u * 8 + rr < L0;
+                LMRL_DEC_ROW(kr[u], vr[u], ok);
+            }
+    }
+    {   // position L0 (this step's own token): row group 0 attends it last
+        const bool ok = rr == 0;
+        LMRL_DEC_ROW(knew, vnew, ok);
+    }
+#undef LMRL_DEC_LOAD
+#undef LMRL_DEC_ROW
+    // merge the 8 row-groups: M = max m_g ; weight w_g = exp(m_g - M)
+    float mm = m;
+    mm = fmaxf(mm, __shfl_xor(mm, 8)); mm = fmaxf(mm, __shfl_xor(mm, 16)); mm = fmaxf(mm, __shfl_xor(mm, 32));
+    const float w = __expf(m - mm);
+    float lt = l * w;
+    lt += __shfl_xor(lt, 8); lt += __shfl_xor(lt, 16); lt += __shfl_xor(lt, 32);
+    const float inv = 1.f / lt;
+    float r8[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        float a = o[e] * w;
+        a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+        r8[e] = a * inv;
+    }
+    if (rr == 0) {
+        uint4 pk;
+        pk.x = pack_bf16x2(r8[0], r8[1]); pk.y = pack_bf16x2(r8[2], r8[3]);
+        pk.z = pack_bf16x2(r8[4], r8[5]); pk.w = pack_bf16x2(r8[6], r8[7]);
+        *reinterpret_cast<uint4 *>(out + row0 * d + (size_t)h * 64 + cc * 8) = pk;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ chunk attention on MFMA
 // C = 8 chunk rows per env: the VALU kernel above spends ~40 instructions per (query, 8 keys); here one wave still owns an
 // (env, head) but does S^T = K.Q^T and O^T = V^T.P^T with v_mfma_f32_16x16x32_bf16 over 32-key blocks:
@@ -632,11 +742,16 @@ __global__ __launch_bounds__(256) void kv_broadcast_kernel(const uint16_t *__res
 // profiling only (one launch per forward): algorithmic HBM bytes of the attention launches of this forward =
 // per (env, head, layer): K and V rows of every attended position (2 x 128 B) + the chunk's q rows and output rows.
 __global__ void attn_bytes_kernel(const int32_t *cnt, const int32_t *len, int B, int C, int heads_x_layers,
-                                  unsigned long long *counter) {
+                                  unsigned long long *counter, int n_shared) {
     unsigned long long s = 0;
+    bool first = true;      // a shared prefix is read from ONE env's rows: its bytes count once per launch, not once per env
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const int n = min(cnt[b], C);
-        if (n > 0) s += (unsigned long long)(len[b] + n) * 256ull + (unsigned long long)n * 256ull;
+        if (n > 0) {
+            const int shared = (n_shared > 0 && !(first && threadIdx.x == 0)) ? min(n_shared, len[b]) : 0;
+            s += (unsigned long long)(len[b] - shared + n) * 256ull + (unsigned long long)n * 256ull;
+            first = false;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
@@ -755,8 +870,11 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
     Gpt2Ws w; w.carve(ws_d, cf, M, b);
     const size_t kv_layer = (size_t)b * cf.n_head * tmax * 64;
 
+    // positions [0, n_shared) of every env's cache equal env 0's (lmrl_gpt2_kv_broadcast): the decode attention reads them from env 0
+    const int n_shared = (int)((flags >> 8) & 0xffu);
+    LMRL_REQUIRE(n_shared <= tmax, "lmrl_gpt2_forward: shared prefix longer than the cache");
     if (unsigned long long *ctr = prof_byte_counter(c == 1 ? PROF_ATTN_DECODE : PROF_ATTN_CHUNK))
-        hipLaunchKernelGGL(attn_bytes_kernel, dim3(1), dim3(256), 0, s, cnt_d, len_d, b, c, cf.n_head * cf.n_layer, ctr);
+        hipLaunchKernelGGL(attn_bytes_kernel, dim3(1), dim3(256), 0, s, cnt_d, len_d, b, c, cf.n_head * cf.n_layer, ctr, c == 1 ? n_shared : 0);
     LMRL_REQUIRE(!((flags & LMRL_FWD_RAGGED_ALWAYS) && (flags & LMRL_FWD_RAGGED_NEVER)), "lmrl_gpt2_forward: contradictory ragged flags");
     const bool fused = !(flags & LMRL_FWD_LN_STANDALONE) && g_gemm_variant != 1 && ln_fusion_nq(d) != 0;
     const int nsl = Gpt2Ws::nslots(cf);
@@ -801,7 +919,21 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
         }
         // algorithmic bytes: K+V rows read once (2 * 128 B per cached position per head) + q/k/v/out rows of the chunk
         hipEvent_t ev_a, ev_b;
-        if (c == 1 && prof_kernel_events(PROF_ATTN_DECODE, -1.0, &ev_a, &ev_b)) {
+        // decode: the single-shot kernel; LMRL_FWD_ATTN_VALU keeps the multi-round-trip per-head kernel as the cross-check
+        const bool shot = c == 1 && !(flags & LMRL_FWD_ATTN_VALU);
+        if (shot) {
+            const bool ev = prof_kernel_events(PROF_ATTN_DECODE, -1.0, &ev_a, &ev_b);   // start/stop events attached to the dispatch itself
+#define LMRL_DEC_LAUNCH(U_)                                                                                                                          \
+            do {                                                                                                                                     \
+                if (ev) hipExtLaunchKernelGGL((attention_decode_kernel<U_>), dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, ev_a, ev_b, 0,         \
+                                              (const uint16_t *)w.qkv, kc, vc, cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off,     \
+                                              n_shared);                                                                                             \
+                else hipLaunchKernelGGL((attention_decode_kernel<U_>), dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, (const uint16_t *)w.qkv, kc,   \
+                                        vc, cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off, n_shared);                              \
+            } while (0)
+            LMRL_DEC_LAUNCH(4);      // 32 cached positions per batch of loads, 72 VGPRs -> 7 waves per SIMD (measured best of U = 4 / 6 / 8 / 10)
+#undef LMRL_DEC_LAUNCH
+        } else if (c == 1 && prof_kernel_events(PROF_ATTN_DECODE, -1.0, &ev_a, &ev_b)) {
             // the roofline kernel: start/stop events attached to the dispatch itself (kernel begin -> end, as rocprofv3 reports it)
             hipExtLaunchKernelGGL(attention_kernel<1>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, ev_a, ev_b, 0, (const uint16_t *)w.qkv, kc, vc,
                                   cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off);

@@ -153,6 +153,9 @@ class KVSession:
     def reset(self):
         self.len.zero_()
         self._len_bound = 0
+        self.shared_prefix = 0
+
+    shared_prefix = 0   # positions [0, shared_prefix) of every env's cache equal env 0's (set by broadcast_prefix_from, cleared by reset)
 
     _len_bound = 0   # host-side upper bound of max(self.len): forwards are enqueued without reading the device lengths back
 
@@ -165,7 +168,7 @@ class KVSession:
                                  "(size the session for prompt + generated tokens, or reset() it)")
         _lib.check(e._L.lmrl_gpt2_forward(e._h, _lib.ptr(self.kv), self.tmax, _lib.ptr(self.ws[chunk]), _lib.ptr(tokens),
                                           _lib.ptr(cnt), _lib.ptr(self.len), self.B, chunk, _lib.ptr(self.last_hidden),
-                                          _lib.ptr(all_hidden), self.flags, _lib.stream_ptr()), "lmrl_gpt2_forward")
+                                          _lib.ptr(all_hidden), self.flags | ((self.shared_prefix & 0xFF) << 8), _lib.stream_ptr()), "lmrl_gpt2_forward")
         return self.last_hidden
 
     def broadcast_prefix_from(self, src: "KVSession", n_pos: int):
@@ -177,6 +180,7 @@ class KVSession:
                                                _lib.ptr(src.last_hidden), _lib.ptr(self.last_hidden), _lib.ptr(self.len), _lib.stream_ptr()),
                    "lmrl_gpt2_kv_broadcast")
         self._len_bound = max(self._len_bound, n_pos)
+        self.shared_prefix = min(n_pos, 255)
 
     def sample(self, params: SampleParams, steer_tok=None, active=None, hidden=None, logits_out=None,
                q1=None, q2=None, want_logprob: bool = True):
