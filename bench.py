@@ -32,10 +32,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# Kernel whose HIP-event time is reported as the roofline line: the top entry of `rocprofv3 --kernel-trace --stats`
-# (profiles/r01_bench_kernel_stats.csv) is attention_kernel<1>, the single-token decode attention that streams the KV cache.
+# Kernel whose HIP-event time is reported as the roofline line: the decode attention (attention_decode_kernel, the single-token attention
+# that streams the KV cache) — the largest HBM-bound kernel of the step and the one the north star's ">= 60 % of HBM roofline" refers to.
 ROOFLINE_TAG = "attention_decode"
-SECONDARY_TAGS = ["gemm_bf16_64x64", "gemm_bf16_64x128", "lm_head_sample", "attention_chunk"]
+ROOFLINE_KERNEL = "attention_decode_kernel"                 # its name in the rocprofv3 / PMC summaries
+PROFILE_STATS = "profiles/r02_bench_kernel_stats.csv"       # committed `rocprofv3 --kernel-trace --stats` summary of this command
+PROFILE_PMC = "profiles/r02_pmc_fetch_write.json"           # committed FETCH_SIZE / WRITE_SIZE passes (tools/pmc_fetch_write.sh)
+SECONDARY_TAGS = ["gemm_bf16_64x64", "gemm_bf16_64x128", "gemm_bf16_128x128", "lm_head_sample", "attention_chunk"]
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md (dense, no sparsity)
 HBM_PEAK_GBS = 8000.0                  # same guide: 8 TB/s spec (6.3 TB/s measured achievable)
 
@@ -53,9 +56,9 @@ def scripted_guesses(vocab_words, n_eps, n_turns, batch, seed=12345):
     return g
 
 
-def cpu_baseline(vocab_words, budget_s=25.0):
-    """The reference's per-turn structure on the host cores: re-prefill the whole history, then decode with a KV
-    cache (HF PyTorch GPT2LMHeadModel as the port of the JAX model), env = the C oracle.  Bounded sample."""
+def _cpu_rollout(vocab_words, n_envs, max_turns, budget_s):
+    """The reference's per-turn structure on the host cores: re-prefill the whole history, then decode with a KV cache (HF PyTorch
+    GPT2LMHeadModel as the port of the JAX model), env = the C oracle.  Returns (env steps, seconds, turns run)."""
     import torch
     import transformers
     from oracle.wordle import OracleWordleEnv
@@ -64,21 +67,20 @@ def cpu_baseline(vocab_words, budget_s=25.0):
     torch.manual_seed(0)
     model = transformers.GPT2LMHeadModel(transformers.GPT2Config()).eval()
     tab = WordleTokenTable.default_gpt2()
-    Bc, turns = 32, 6
     rng = np.random.RandomState(1)
-    envs = [OracleWordleEnv(vocab_words, True, -10.0) for _ in range(Bc)]
+    envs = [OracleWordleEnv(vocab_words, True, -10.0) for _ in range(n_envs)]
     hist = [e.reset(i) for i, e in enumerate(envs)]
     n_steps = 0
     t0 = time.perf_counter()
     with torch.no_grad():
-        for turn in range(turns):
-            words = [vocab_words[k] for k in rng.randint(0, len(vocab_words), size=Bc)]
+        for turn in range(max_turns):
+            words = [vocab_words[k] for k in rng.randint(0, len(vocab_words), size=n_envs)]
             ids = torch.tensor([tab.encode_text("".join(t for t, _ in h)) for h in hist])
             out = model(ids, use_cache=True)
             past, logits = out.past_key_values, out.logits[:, -1]
             for k in range(6):
                 steer = torch.tensor([(tab.encode_text(" ".join(w) + "\n"))[k] for w in words])
-                logits[torch.arange(Bc), steer] += 30.0
+                logits[torch.arange(n_envs), steer] += 30.0
                 tok = torch.multinomial(torch.softmax(logits.float(), -1), 1)
                 if k < 5:
                     out = model(tok, past_key_values=past, use_cache=True)
@@ -88,10 +90,32 @@ def cpu_baseline(vocab_words, budget_s=25.0):
                 n_steps += 1
             if time.perf_counter() - t0 > budget_s:
                 break
-    dt = time.perf_counter() - t0
-    return dict(value=n_steps / dt, unit="env-steps/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{Bc} envs x {turn + 1} turns (valid scripted guesses), GPT-2-small fp32 on torch-CPU re-prefilling the "
-                       f"history every turn as the reference does + C oracle env; {dt:.1f} s")
+    return n_steps, time.perf_counter() - t0, turn + 1
+
+
+def cpu_baseline(vocab_words, budget_s=14.0):
+    """the CPU path timed beside the GPU number — (1) the rollout port on ALL host threads and (2) on ONE thread
+    (`value` is the all-threads figure), (3) the env alone (C oracle, one thread, no LM).  Bounded samples, ~25 s in total."""
+    import torch
+    from oracle.wordle import run_scripted
+    n_all = torch.get_num_threads()
+    s_all, t_all, turns_all = _cpu_rollout(vocab_words, 32, 6, budget_s)
+    torch.set_num_threads(1)
+    try:
+        s_one, t_one, turns_one = _cpu_rollout(vocab_words, 16, 3, budget_s * 0.6)
+    finally:
+        torch.set_num_threads(n_all)
+    rng = np.random.RandomState(2)
+    gi = rng.randint(0, len(vocab_words), size=(6, 2048))
+    te = time.perf_counter()
+    env_steps = run_scripted(vocab_words, 2048, gi)
+    te = time.perf_counter() - te
+    return dict(value=s_all / t_all, unit="env-steps/s", cores=n_all, kind="port",
+                sample=f"32 envs x {turns_all} turns (valid scripted guesses), GPT-2-small fp32 on torch-CPU re-prefilling the history every "
+                       f"turn as the reference does + C oracle env; {t_all:.1f} s",
+                one_thread=dict(value=s_one / t_one, cores=1, sample=f"16 envs x {turns_one} turns, same path; {t_one:.1f} s"),
+                env_only=dict(value=env_steps / te, unit="env-steps/s", cores=1,
+                              sample=f"C oracle env alone (no LM), 2048 envs x 6 scripted steps, one thread; {te:.2f} s"))
 
 
 def main():
@@ -245,10 +269,10 @@ def main():
     # command; gfx950 FETCH_SIZE counts 64 B per 128 B request for wide coalesced loads -> doubled, per the microarch
     # guide).  Not measurable from inside the process, so the committed summary is reported, with its source.
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01j_pmc_fetch_write.json")))
-        key = next(k for k in pmc if "attention_kernel<1>" in k)
+        pmc = json.load(open(os.path.join(ROOT, PROFILE_PMC)))
+        key = next(k for k in pmc if ROOFLINE_KERNEL in k)
         roofline["traffic"] = round((2.0 * pmc[key]["fetch_kb_avg"] + pmc[key]["write_kb_avg"]) * 1024)
-        roofline["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01j_pmc_fetch_write.json)"
+        roofline["traffic_unit"] = f"bytes per launch (2*FETCH_SIZE + WRITE_SIZE, {PROFILE_PMC})"
         roofline["algorithmic_bytes_per_launch"] = round(work.value / max(n.value, 1))
     except Exception:
         roofline["traffic"] = None
@@ -257,16 +281,18 @@ def main():
     # begin/end timestamps do not)
     try:
         import csv
-        prof = os.path.join(ROOT, "profiles", "r01j_bench_kernel_stats.csv")
-        row = next(r for r in csv.DictReader(open(prof)) if "attention_kernel<1>" in r["Name"])
+        prof = os.path.join(ROOT, PROFILE_STATS)
+        row = next(r for r in csv.DictReader(open(prof)) if ROOFLINE_KERNEL in r["Name"])
         roofline["rocprofv3_avg_launch_us"] = round(float(row["AverageNs"]) / 1e3, 2)
-        roofline["rocprofv3_summary"] = "profiles/r01j_bench_kernel_stats.csv"
+        roofline["rocprofv3_summary"] = PROFILE_STATS
     except Exception:
         pass
-    # other kernel classes: one extra, untimed episode with their brackets on (brackets cost ~2 us per launch)
+    # other kernel classes: one extra, untimed episode with their brackets on (brackets cost ~2 us per launch); the same episode yields
+    # the whole-step algorithmic flop / byte totals of `roofline_step`
     L.lmrl_prof_reset()
+    step_tags = SECONDARY_TAGS + [ROOFLINE_TAG]
     mask = 0
-    for tg in SECONDARY_TAGS:
+    for tg in step_tags:
         mask |= 1 << tag_ids[tg]
     L.lmrl_prof_enable(mask)
     torch.cuda.synchronize(); tb = time.perf_counter()
@@ -275,6 +301,23 @@ def main():
     L.lmrl_prof_enable(0)
     roofline_secondary = [read_tag(tg) for tg in SECONDARY_TAGS]
     dt = dt_keep
+    # whole step: algorithmic flops = every GEMM / LM-head flop of the episode; algorithmic bytes = K/V rows the attention reads (device-
+    # counted, shared prefix once) + the weights each forward has to stream once (bf16 layers per forward, the tied LM head per sampled token)
+    flops = bytes_kv = 0.0
+    for tg in step_tags:
+        _lib.check(L.lmrl_prof_read(tag_ids[tg], ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n)))
+        if tg.startswith("attention"):
+            bytes_kv += work.value
+        else:
+            flops += work.value
+    n_fwd = n_turns * 6 + (0 if args.share_header else 1)                 # forwards over all envs: 5 decode + 1 chunk per turn (+ header chunk)
+    layer_w = cfg.n_layer * (3 * cfg.d_model * cfg.d_model + cfg.d_model * cfg.d_model + 2 * cfg.d_model * cfg.d_ff) * 2
+    bytes_w = n_fwd * layer_w + n_turns * 6 * cfg.vocab_padded * cfg.d_model * 2
+    step_s = dt_keep / args.steps
+    roofline_step = dict(flops=flops, bytes=bytes_kv + bytes_w, tflops=round(flops / step_s / 1e12, 1), tb_per_s=round((bytes_kv + bytes_w) / step_s / 1e12, 3),
+                         frac_mfma_peak=round(flops / step_s / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                         frac_hbm_peak=round((bytes_kv + bytes_w) / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                         note="algorithmic work of one episode (counted in one eager episode of the same workload) / graph-timed ms_per_step")
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     steps_all = torch.stack(total_steps_parts).sum() if total_steps_parts else total_steps.clone()
@@ -304,11 +347,13 @@ def main():
             "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "dtype_note": "the reference's OPTIONAL bf16 mode (bf16 weights / activations, fp32 accumulation, residual stream and logits; "
+                          "BASELINE.md M2); the reference's default arithmetic is fp32",
             "config": {"workload": "configs[1]: Wordle env, GPT-2-small policy (random-init, steered sampling), "
                                    f"{B} lock-step envs per GPU, {n_turns} turns x <=6 generated tokens, vocab {args.vocab_file}",
                        "envs_per_gpu": B, "hip_streams": S, "hip_graph": bool(args.graph), "shared_header_prefill": bool(args.share_header), "max_new_tokens": 6, "parallelism": f"env-sharded x{world}, no data-path collective",
                        "env_steps_timed": n_env_steps},
-            "roofline": roofline, "roofline_secondary": roofline_secondary,
+            "roofline": roofline, "roofline_secondary": roofline_secondary, "roofline_step": roofline_step,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vocab.all_vocab)

@@ -42,7 +42,7 @@ __device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int 
     constexpr int L = LA + LW;
     constexpr int STAGE = (BM + BN) * 128;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && TM % 16 == 0 && TN % 16 == 0, "tile / wave layout");
-    static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS slots");
+    static_assert(STAGES >= 2 && STAGES <= 6, "2 to 6 LDS slots");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int lr = lane & 15, lq = lane >> 4;
@@ -101,7 +101,10 @@ __device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int 
     asm volatile("" ::: "memory");
     {
         const int inflight = (nk - 1 < STAGES - 1) ? nk - 1 : STAGES - 1;     // stages that may stay in flight behind stage 0
-        if (inflight >= 2) wait_vmcnt<2 * L>();
+        if (inflight >= 5 && STAGES >= 6) wait_vmcnt<5 * L>();
+        else if (inflight == 4 && STAGES >= 5) wait_vmcnt<4 * L>();
+        else if (inflight == 3 && STAGES >= 4) wait_vmcnt<3 * L>();
+        else if (inflight == 2 && STAGES >= 3) wait_vmcnt<2 * L>();
         else if (inflight == 1) wait_vmcnt<L>();
         else wait_vmcnt<0>();
     }
@@ -117,7 +120,10 @@ __device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int 
         if (t + 1 < nk) {
             const int behind = nk - 2 - t;                                    // stages issued after stage t+1
             const int inflight = behind < STAGES - 2 ? behind : STAGES - 2;
-            if (inflight >= 1) wait_vmcnt<L>();
+            if (inflight >= 4 && STAGES >= 6) wait_vmcnt<4 * L>();
+            else if (inflight == 3 && STAGES >= 5) wait_vmcnt<3 * L>();
+            else if (inflight == 2 && STAGES >= 4) wait_vmcnt<2 * L>();
+            else if (inflight == 1 && STAGES >= 3) wait_vmcnt<L>();
             else wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();

@@ -62,6 +62,7 @@ int main(int argc, char **argv) {
                                  {1024, 3072, 768, "decode fc"}, {1024, 768, 3072, "decode fc2"}, {4096, 4096, 4096, "4096^3"}};
     if (quick) { shapes = {shapes[0], shapes[2], shapes[4]}; }
     if (argc > 1 && std::string(argv[1]) == "decode") { shapes = {{1024, 2304, 768, "decode qkv"}, {1024, 768, 768, "decode proj"}, {1024, 3072, 768, "decode fc"}, {1024, 768, 3072, "decode fc2"}}; }
+    if (argc > 1 && std::string(argv[1]) == "resid") { shapes = {{1024, 768, 768, "decode proj"}, {1024, 768, 3072, "decode fc2"}, {7168, 768, 768, "prefill proj"}, {7168, 768, 3072, "prefill fc2"}}; }
     std::vector<Cfg> cfgs = {
         {"ring 128x64 s2 (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<128, 64, 2, EPI_BF16>(g, s); }, 128, 64},
         {"ring 64x64 s3 (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<64, 64, 3, EPI_BF16>(g, s); }, 64, 64},
@@ -84,6 +85,12 @@ int main(int argc, char **argv) {
         {"ring 64x64 s6 (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<64, 64, 6, EPI_BF16>(g, s); }, 64, 64},
         {"ring 64x64 s4 RESID_STATS", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<64, 64, 4, EPI_RESID_F32_STATS>(g, s); }, 64, 64, false, true},
         {"ring 64x64 s3 GELU_LN", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<64, 64, 3, EPI_GELU_BF16_LN, 3>(g, s); }, 64, 64, false, true},
+        {"g8 64x64 4x2 s3 RESID_STATS", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<64, 64, 4, 2, 3, EPI_RESID_F32_STATS>(g, s); }, 64, 64, false, true},
+        {"g8 64x64 4x2 s4 RESID_STATS", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<64, 64, 4, 2, 4, EPI_RESID_F32_STATS>(g, s); }, 64, 64, false, true},
+        {"g8 64x64 4x2 s6 RESID_STATS", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<64, 64, 4, 2, 6, EPI_RESID_F32_STATS>(g, s); }, 64, 64, false, true},
+        {"g8 64x128 2x4 s4 RESID_STATS", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<64, 128, 2, 4, 4, EPI_RESID_F32_STATS>(g, s); }, 64, 128, false, true},
+        {"g8 128x64 4x2 s4 RESID_STATS", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 64, 4, 2, 4, EPI_RESID_F32_STATS>(g, s); }, 128, 64, false, true},
+        {"ring 64x64 s6 RESID_STATS", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<64, 64, 6, EPI_RESID_F32_STATS>(g, s); }, 64, 64, false, true},
         {"ring 128x64 s2 GELU", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<128, 64, 2, EPI_GELU_BF16>(g, s); }, 128, 64, false, true},
         {"g8 128x128 2x4 s2 GELU", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 4, 2, EPI_GELU_BF16>(g, s); }, 128, 128, false, true},
     };
