@@ -102,11 +102,16 @@ def _finalize_ilql_logs(P: np.ndarray, n: float, v_final: np.ndarray, cql_weight
     loss = q1_loss + q2_loss + v_loss + cql_weight * (c1 + c2)
     st = lambda o, cnt: stats_from_sums(s[o], s[o], s[o + 1], s[o + 2], s[o + 3], cnt, n)
     vf = np.asarray(v_final, dtype=np.float64)
+    vf_sum, vf_sq, vf_n, vf_min, vf_max = vf.sum(), (vf * vf).sum(), float(len(vf)), vf.min(), vf.max()
+    if D.is_distributed():   # v_final statistics are over the GLOBAL batch (get_tensor_stats with an all-ones mask, base_interface.py:117)
+        (vf_sum, vf_sq, vf_n), (vf_min,), (vf_max,) = D.reduce_stat_partials([vf_sum, vf_sq, vf_n], [vf_min], [vf_max])
+    vf_mean = vf_sum / vf_n
+    vf_std = np.sqrt(max(vf_sq / vf_n - vf_mean * vf_mean, 0.0))
     logs = dict(
         losses=dict(total_loss=f(loss), q1_loss=f(q1_loss), q2_loss=f(q2_loss), v_loss=f(v_loss), q1_cql_loss=f(c1), q2_cql_loss=f(c2)),
         q1=st(7, s[5]), q2=st(11, s[5]), v=st(15, s[5]), target_q=st(19, s[5]), target_q1=st(23, s[5]), target_q2=st(27, s[5]),
         vns=st(31, s[6]),
-        v_final=dict(mean=f(vf.sum() / len(vf)), min=f(vf.min()), max=f(vf.max()), std=f(vf.std())),
+        v_final=dict(mean=f(vf_mean), min=f(vf_min), max=f(vf_max), std=f(vf_std)),
         rewards=stats_from_sums(s[35], s[36], s[37], s[38], s[39], s[40], n),
     )
     return float(loss), logs
@@ -251,9 +256,12 @@ class GPT2ILQLTrain:
         self.q1.backward(q1c, q1o, g1, dx=d_hidden, accumulate_dx=False)
         self.q2.backward(q2c, q2o, g2, dx=d_hidden, accumulate_dx=True)
         self.v.backward(vc, dv_r.view(R, 1), gv, dx=d_hidden, accumulate_dx=True)
-        base.backward(cache, d_hidden, bgrads)
+        # data parallel: the head gradients (final already) and the base gradients are all-reduced while the base backward runs — arena
+        # slices go to RCCL as blocks finish (dist.GradReducer); the one data-path collective of an ILQL step (~815 MB fp32, GPT-2-small)
+        red = D.GradReducer()
+        base.backward(cache, d_hidden, bgrads, on_final=red.ready(bgrads))
         self.last_grads = (bgrads, g1, g2, gv)
-        D.allreduce_grads([bgrads, g1, g2, gv])  # the one data-path collective of an ILQL step (~815 MB fp32 for GPT-2-small)
+        red.finish([g1, g2, gv])
         upd = self.base_opt.apply(bgrads)
         self.q1_opt.apply(g1); self.q2_opt.apply(g2); self.v_opt.apply(gv)
         if upd:   # targets move only when MultiSteps.mini_step == 0 (interface.py:343-347)

@@ -152,9 +152,10 @@ class GPT2MCTrain:
         self.q_head.backward(qc, qo, qgrads, dx=d_hidden, accumulate_dx=False)
         if self.detach_q:
             d_hidden.zero_()
-        base.backward(cache, d_hidden, bgrads)
+        red = D.GradReducer()                        # gradient all-reduce overlapped with the base backward (data parallel)
+        base.backward(cache, d_hidden, bgrads, on_final=red.ready(bgrads))
         self.last_grads = (bgrads, qgrads)
-        D.allreduce_grads([bgrads, qgrads])
+        red.finish([qgrads])
         self.base_opt.apply(bgrads)
         self.q_opt.apply(qgrads)
         return self, loss, logs

@@ -286,14 +286,17 @@ class GPT2PPOTrain:
         dvals = torch.zeros(R, 1, dtype=torch.float32, device=dev)
         dvals.view(B, T)[:, :-1] = dv
         head.backward(hcache, dvals, hgrads, dx=d_hidden, accumulate_dx=True)
-        pol.backward(cache, d_hidden, pgrads)
+        # data parallel: the policy gradient all-reduce overlaps this backward (arena slices are handed to RCCL as blocks finish) unless a
+        # BC auxiliary batch still has to accumulate into the same gradients afterwards
+        red = D.GradReducer()
+        pol.backward(cache, d_hidden, pgrads, on_final=None if use_bc else red.ready(pgrads))
         if use_bc:   # policy_grads += bc_loss_weight * bc_grads ; loss += bc_loss_weight * bc_loss  (gpt2/interface.py:180-203)
             del cache, logits, d_hidden
             bc_loss = self._bc_term(bc_data_input_ids, bc_data_input_attention_mask, bc_data_input_position_ids, bc_data_input_training_mask, pgrads)
             total = loss + bc_loss * self.bc_loss_weight
             loss, logs = total, {"ppo": logs, "bc": {"loss": np.float32(bc_loss)}, "total_loss": np.float32(total)}
         self.last_grads = (pgrads, hgrads)
-        D.allreduce_grads([pgrads, hgrads])      # the one data-path collective of a PPO step (RCCL over xGMI)
+        red.finish([pgrads, hgrads] if use_bc else [hgrads])      # the one data-path collective of a PPO step (RCCL over xGMI)
         self.policy_opt.apply(pgrads)
         self.head_opt.apply(hgrads)
         return self, loss, logs

@@ -32,41 +32,99 @@ def shard_range(n_total: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_sum_(t, group=None):
+def _all_reduce_inplace(t, group=None, async_op: bool = False):
+    """SUM all-reduce of a device tensor in place.  RCCL ("nccl") reduces device memory directly; the gloo backend of the CPU / single-GPU
+    test tier stages a device tensor through the host (gloo has no ROCm device path)."""
     import torch.distributed as dist
+    if dist.get_backend(group) != "gloo" or not t.is_cuda:
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    h = t.cpu()
+    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+    t.copy_(h)
+    return None
+
+
+def allreduce_sum_(t, group=None):
     if is_distributed():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce_inplace(t, group)
     return t
 
 
+def _flat_chunks(grad_dicts, bucket_bytes):
+    """Yield flat fp32 views to reduce: a GradArena (train/gpt2_f32.py) is ONE flat buffer and is reduced in place in `bucket_bytes`
+    slices; a plain dict of tensors falls back to per-tensor reduction (tensors are not assumed adjacent in memory)."""
+    for d in grad_dicts:
+        flat = getattr(d, "flat", None)
+        if flat is not None:
+            step = max(1, bucket_bytes // flat.element_size())
+            for lo in range(0, flat.numel(), step):
+                yield flat[lo:lo + step]
+        else:
+            for _, g in sorted(d.items()):
+                yield g.reshape(-1) if g.is_contiguous() else g
+
+
 def allreduce_grads(grad_dicts: Sequence[Dict[str, "torch.Tensor"]], bucket_bytes: int = 256 << 20, average: bool = False, group=None) -> int:
-    """In-place SUM (or mean) all-reduce of every tensor in the given gradient dicts, packed into flat buckets.
-    Returns the number of collectives issued."""
-    import torch
+    """In-place SUM (or mean) all-reduce of every gradient in the given dicts.  Gradient arenas are reduced in place on slices of their
+    flat buffer (no torch.cat / copy-back: xGMI links are point-to-point, so few large messages); returns the number of collectives."""
     import torch.distributed as dist
     if not is_distributed():
         return 0
     ws = dist.get_world_size(group)
-    tensors: List["torch.Tensor"] = [g for d in grad_dicts for _, g in sorted(d.items())]
     n_coll = 0
-    i = 0
-    while i < len(tensors):
-        j, size = i, 0
-        while j < len(tensors) and (j == i or size + tensors[j].numel() * tensors[j].element_size() <= bucket_bytes):
-            size += tensors[j].numel() * tensors[j].element_size()
-            j += 1
-        chunk = tensors[i:j]
-        flat = torch.cat([t.reshape(-1) for t in chunk])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    for chunk in _flat_chunks(grad_dicts, bucket_bytes):
+        _all_reduce_inplace(chunk, group)
         if average:
-            flat.div_(ws)
-        off = 0
-        for t in chunk:
-            t.copy_(flat[off:off + t.numel()].view_as(t))
-            off += t.numel()
+            chunk.div_(ws)
         n_coll += 1
-        i = j
     return n_coll
+
+
+class GradReducer:
+    """Overlaps the data-parallel gradient all-reduce with the backward pass.  `GPT2F32.backward(..., on_final=reducer.ready(arena))`
+    reports parameter groups whose gradients are final (ln_f, then block after block, then the embeddings — the arena is laid out in that
+    order); whenever `bucket_bytes` of finished gradients have piled up, an asynchronous all-reduce of that arena slice is enqueued — RCCL
+    runs it on its own stream behind the kernels already launched, concurrently with the rest of the backward.  `finish()` reduces what is
+    left (plus any further dicts, e.g. the heads) and waits.  Without a process group every call is a no-op."""
+
+    def __init__(self, bucket_bytes: int = 64 << 20, group=None):
+        self.bucket_bytes, self.group = bucket_bytes, group
+        self.works, self.n_coll = [], 0
+        self._arena, self._lo, self._hi = None, 0, 0
+
+    def _flush(self):
+        if self._arena is not None and self._hi > self._lo:
+            w = _all_reduce_inplace(self._arena.flat[self._lo:self._hi], self.group, async_op=True)
+            if w is not None:
+                self.works.append(w)
+            self.n_coll += 1
+            self._lo = self._hi
+
+    def ready(self, arena):
+        """The `on_final` callback for one arena."""
+        if not is_distributed():
+            return None
+        self._arena, self._lo, self._hi = arena, 0, 0
+
+        def on_final(names):
+            lo, hi = arena.span(names)
+            assert lo == self._hi, "gradients must become final in arena order"
+            self._hi = hi
+            if (self._hi - self._lo) * arena.flat.element_size() >= self.bucket_bytes:
+                self._flush()
+        return on_final
+
+    def finish(self, more: Sequence[Dict[str, "torch.Tensor"]] = ()):
+        if not is_distributed():
+            return 0
+        if self._arena is not None:
+            self._hi = self._arena.flat.numel()              # whatever has not been handed over yet (normally the last partial bucket)
+            self._flush()
+        self.n_coll += allreduce_grads(more, group=self.group)
+        for w in self.works:
+            w.wait()
+        self.works = []
+        return self.n_coll
 
 
 def reduce_stat_partials(sums, mins, maxs, group=None):

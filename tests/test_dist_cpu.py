@@ -56,6 +56,35 @@ def _worker(rank, world, port, ret):
         assert abs(s[0] - data.sum()) < 1e-9 and s[2] == 1000 and mn[0] == data.min() and mx[0] == data.max()
         var = s[1] / s[2] - (s[0] / s[2]) ** 2
         assert abs(var - data.var()) < 1e-9
+        # 4b. gradient arena: in-place bucketed all-reduce on slices of the flat buffer + the overlapped reducer fed in finalisation order
+        from lmrl_gym_amd.train.gpt2_f32 import GradArena
+        gp = torch.Generator().manual_seed(7)
+        params = {"ln_f.weight": torch.zeros(5), "h.1.w": torch.zeros(4, 3), "h.1.b": torch.zeros(3), "h.0.w": torch.zeros(4, 3), "h.0.b": torch.zeros(3), "wte": torch.zeros(6, 2)}
+        order = ["ln_f.weight", "h.1.w", "h.1.b", "h.0.w", "h.0.b", "wte"]
+        per_rank = [{k: torch.randn(v.shape, generator=gp) for k, v in params.items()} for _ in range(world)]
+        expect = {k: sum(per_rank[r][k] for r in range(world)) for k in params}
+        ar = GradArena(params, order)
+        assert ar.flat.numel() == sum(v.numel() for v in params.values()) and ar["h.0.w"].data_ptr() == ar.flat[ar.order["h.0.w"][0]:].data_ptr()
+        for k in params:
+            ar[k].copy_(per_rank[rank][k])
+        assert D.allreduce_grads([ar], bucket_bytes=40) == -(-ar.flat.numel() * 4 // 40)          # 10 floats per collective, in place
+        for k in params:
+            torch.testing.assert_close(ar[k], expect[k])
+        for k in params:
+            ar[k].copy_(per_rank[rank][k])
+        red = D.GradReducer(bucket_bytes=60)
+        cb = red.ready(ar)
+        cb(["ln_f.weight"]); cb(["h.1.w", "h.1.b"]); cb(["h.0.w", "h.0.b"]); cb(["wte"])
+        extra = {"kernel": per_rank[rank]["wte"].clone()}
+        assert red.finish([extra]) >= 3
+        for k in params:
+            torch.testing.assert_close(ar[k], expect[k])
+        torch.testing.assert_close(extra["kernel"], expect["wte"])
+        try:                                                     # out-of-order hand-over is a bug in the caller: refused
+            red2 = D.GradReducer(); cb2 = red2.ready(ar); cb2(["h.0.w"])
+            raise RuntimeError("expected an assertion")
+        except AssertionError:
+            pass
         # 5. bench reduction: max time, summed steps
         t = torch.tensor([0.5 + rank], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
         n = torch.tensor([100 + rank]); dist.all_reduce(n, op=dist.ReduceOp.SUM)
