@@ -118,9 +118,97 @@ def cpu_baseline(vocab_words, budget_s=14.0):
                               sample=f"C oracle env alone (no LM), 2048 envs x 6 scripted steps, one thread; {te:.2f} s"))
 
 
+def main_train_step(args):
+    """`--mode ilql-step` / `--mode ppo-step`: the train step of configs[2] at the sizes SURVEY.md §8d names (M3: GPT-2-small, B = 32 x T = 512
+    per GPU; M4: B = 32 x T = 1024), fp32 (the reference's default train arithmetic) on the f32-input MFMA, synthetic ids ~ U[0, 50257) with the
+    6-on / 6-off action pattern after a 4-token header.  N > 1: pure data parallelism, every rank its own B sequences (weak scaling), ONE
+    gradient all-reduce per step overlapped with the backward pass (lmrl_gym_amd.dist.GradReducer).  `value` = sequences / s over all ranks."""
+    import torch
+    import lmrl_gym_amd  # noqa: F401
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.algorithms import ilql, ppo
+    from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32, MLPHeadF32
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("LMRL_BENCH_BACKEND", "nccl")
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+        dist.init_process_group(backend, device_id=dev) if backend == "nccl" else dist.init_process_group(backend)
+    cfg = GPT2Config.gpt2_small(50258)            # +1 added <|pad|> token (train_ilql_gpt2.py:115-116)
+    pad, n_params = 50257, 124.4e6
+    B = args.train_batch
+    T = 512 if args.mode == "ilql-step" else 1024
+    rng = np.random.RandomState(1000 + rank)
+    ids = rng.randint(0, 50257, size=(B, T)).astype(np.int32)
+    t = np.arange(T - 1)
+    sta = np.broadcast_to(((t >= 4) & (((t - 4) // 6) % 2 == 0))[None, :], (B, T - 1)).copy()
+    sd = init_hf_style_state_dict(cfg, seed=0)
+    d, V = cfg.d_model, cfg.vocab
+    tok = B * T
+    if args.mode == "ilql-step":
+        base, tbase = GPT2F32(sd, cfg.n_head, device=dev), GPT2F32(sd, cfg.n_head, device=dev)
+        g = torch.Generator().manual_seed(1)
+        mk = lambda out, b2: MLPHeadF32({"dense1.kernel": torch.randn(d, d, generator=g) * 0.02, "dense1.bias": torch.zeros(d),
+                                         "dense2.kernel": torch.zeros(d, out), "dense2.bias": torch.full((out,), b2)}, dev)
+        tr = ilql.GPT2ILQLTrain(base, mk(V, -4.4), mk(V, -4.4), mk(1, -4.4), pad, dict(gamma=0.99, tau=0.7, cql_weight=0.01), target_base=tbase, lr=3e-5)
+        rewards = np.where(sta & ~np.roll(sta, -1, axis=1), -1.0, 0.0).astype(np.float32)
+        dones = (rng.rand(B) < 0.5).astype(np.float32)
+        step = lambda: tr.step(ids, sta, rewards, dones)
+        head_flops = 2 * (d * d + d * V) * tok * (3 * 2 + 2)             # q1, q2 forward + backward (3x) and the two target-head forwards
+        flops = (6 + 2) * n_params * tok + head_flops + 12 * 6 * 2 * T * d * tok
+        workload = f"configs[2] / M3: ILQL train step, GPT-2-small fp32, B={B} x T={T} per GPU (train_ilql_gpt2.py:55-110), target base + 2 Q heads + V head"
+    else:
+        pol = GPT2F32(sd, cfg.n_head, device=dev)
+        head = LinearHeadF32(dict(kernel=torch.randn(d, 1) * 0.01, bias=torch.tensor([-4.1])), dev)
+        tr = ppo.GPT2PPOTrain(pol, head, pad, dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0), lr=1e-5)
+        f = lambda s_: (rng.randn(B, T - 1) * s_).astype(np.float32)
+        olp, ov, oa, orr = f(0.1) - 10.8, f(1), f(1), f(1)
+        step = lambda: tr.step(ids, sta, olp, ov, oa, orr)
+        flops = 6 * n_params * tok + 12 * 6 * 2 * T * d * tok
+        workload = f"M4: PPO train step, GPT-2-small fp32, B={B} x T={T} per GPU (train_ppo_gpt2.py:60-112), LinearHead value function"
+
+    def barrier():
+        if use_dist:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    for _ in range(max(args.warmup, 1)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, loss, _ = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if use_dist:
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank == 0:
+        ach = flops / (dt / args.steps) / 1e12
+        print(json.dumps({
+            "metric": f"{args.mode} sequences/sec (GPT-2-small fp32, B={B}, T={T})", "value": round(world * B * args.steps / dt, 2), "unit": "sequences/s",
+            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(dt * 1e3 / args.steps, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "per_gpu_batch": B, "seq_len": T, "parallelism": f"dp{world}, one overlapped gradient all-reduce per step",
+                       "last_loss": float(loss)},
+            "roofline": {"bound": "mfma", "kernel": "sgemm_f32_kernel (every matmul of the step: v_mfma_f32_32x32x2_f32)", "achieved": round(ach, 1),
+                         "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
+                         "note": "model flops of one step / wall time of the whole step (lower bound for the GEMM kernel itself: 91 % of kernel time, "
+                                 "profiles/r01_train_kernel_stats_final.csv)"}}), flush=True)
+    if use_dist:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--mode", default="rollout", choices=["rollout", "ilql-step", "ppo-step"],
+                    help="rollout (default): the headline env-steps/s line; ilql-step / ppo-step: the train step of configs[2] (M3 / M4 sizes)")
+    ap.add_argument("--train-batch", type=int, default=32, help="sequences per GPU in the train-step modes")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="envs per GPU")
@@ -132,6 +220,8 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="split the batch into this many sub-batches on separate HIP streams")
     ap.add_argument("--breakdown", action="store_true", help="after the timed region, print a per-kernel-class event breakdown to stderr")
     args = ap.parse_args()
+    if args.mode != "rollout":
+        return main_train_step(args)
 
     import torch
     import lmrl_gym_amd  # noqa: F401
