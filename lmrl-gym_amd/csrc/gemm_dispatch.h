@@ -30,10 +30,10 @@ inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
     if (tiles <= 768) return gemm_launch_glds<64, 64, 3, EPI, NQ>(g, s);
     return gemm_launch_glds<64, 64, 2, EPI, NQ>(g, s);
 }
-// Slots per row are padded to 8*NQ (zero filled): NQ = 1 (d_model <= 256), 3 (768), 4 (1024).
+// Slots per row are padded to 8*NQ (zero filled): NQ = 1 (d_model <= 256), 3 (768: GPT-2-small), 4 (1024: medium), 5 (1280: large).
 inline int ln_fusion_nq(int d_model) {
     const int need = d_model / 64 * 2;
-    return need <= 8 ? 1 : (need == 24 ? 3 : (need == 32 ? 4 : 0));   // 0: no folded configuration -> stand-alone LayerNorm
+    return need <= 8 ? 1 : (need == 24 ? 3 : (need == 32 ? 4 : (need == 40 ? 5 : 0)));   // 0: no folded configuration -> stand-alone LayerNorm
 }
 template <int EPI>
 inline hipError_t gemm_launch_ln(const GemmArgs &g, hipStream_t s) {
@@ -43,6 +43,7 @@ inline hipError_t gemm_launch_ln(const GemmArgs &g, hipStream_t s) {
         case 1: return gemm_launch_ln_nq<EPI, 1>(g, s);
         case 3: return gemm_launch_ln_nq<EPI, 3>(g, s);
         case 4: return gemm_launch_ln_nq<EPI, 4>(g, s);
+        case 5: return gemm_launch_ln_nq<EPI, 5>(g, s);
         default: return hipErrorInvalidValue;
     }
 }

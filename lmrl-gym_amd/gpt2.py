@@ -40,6 +40,10 @@ class GPT2Config:
     def gpt2_medium(cls, vocab: int = 50257) -> "GPT2Config":
         return cls(24, 16, 1024, 4096, vocab, 1024)
 
+    @classmethod
+    def gpt2_large(cls, vocab: int = 50257) -> "GPT2Config":
+        return cls(36, 20, 1280, 5120, vocab, 1024)
+
 
 class _CConfig(ctypes.Structure):
     _fields_ = [("n_layer", ctypes.c_int32), ("n_head", ctypes.c_int32), ("d_model", ctypes.c_int32),

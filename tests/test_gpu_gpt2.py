@@ -48,12 +48,13 @@ def test_gemm_bf16_epilogues(dev, M, N, K):
 
 # ------------------------------------------------------------------ forward: chunked prefill + decode vs full-sequence oracle
 @pytest.mark.parametrize("ln_fusion", [1, 0])    # LayerNorm folded into the neighbouring GEMMs (default) / stand-alone LN launches (per-session flag)
-@pytest.mark.parametrize("cfgname", ["tiny", "small2", "medium2"])
+@pytest.mark.parametrize("cfgname", ["tiny", "small2", "medium2", "large2"])
 def test_gpt2_forward_kv_cache(dev, cfgname, ln_fusion):
     from lmrl_gym_amd.gpt2 import FWD_LN_STANDALONE, GPT2Config, GPT2Engine, init_hf_style_state_dict
     from oracle import gpt2 as O
     cfg = dict(tiny=GPT2Config(2, 2, 128, 512, 1000, 64), small2=GPT2Config(2, 12, 768, 3072, 50257, 128),
-               medium2=GPT2Config(2, 16, 1024, 4096, 5000, 64))[cfgname]      # GPT-2-medium width: the NQ = 4 LayerNorm-fold configuration
+               medium2=GPT2Config(2, 16, 1024, 4096, 5000, 64),                # GPT-2-medium width: the NQ = 4 LayerNorm-fold configuration
+               large2=GPT2Config(2, 20, 1280, 5120, 3000, 64))[cfgname]        # GPT-2-large width (20 heads): NQ = 5
     sd = init_hf_style_state_dict(cfg, seed=1)
     g = torch.Generator().manual_seed(2)
     for k in sd:   # non-trivial LN / bias values

@@ -238,3 +238,45 @@ def test_special_token_eos_never_reaches_the_action_text_and_sessions_do_not_sha
     fa, fb = FWD_RAGGED_ALWAYS, FWD_RAGGED_NEVER | FWD_LN_STANDALONE
     inter, solo = run(fa, fb, True), run(fa, fb, False)
     assert inter[0] == solo[0] and inter[1] == solo[1]
+
+
+def test_twenty_questions_dual_model_rollout(setup):
+    """N4: the policy model asks, a SECOND resident model (the oracle) answers inside the rollout loop — both on the HIP engine, through the
+    reference protocol (`interact_environment` over `BatchedTwentyQuestionsPolicyEnvironment`).  Random-init models: what is checked is the
+    plumbing — every oracle answer equals the reference post-processing of the oracle engine's own greedy completion of the reference
+    prompt (re-generated here), rewards / done follow create_trajectory_from_history, both engines keep their own KV sessions."""
+    from lmrl_gym_amd import environment as E
+    from lmrl_gym_amd.envs import twenty_questions as Q
+    from lmrl_gym_amd.policies import GPT2PPOPolicy
+    dev, cfg, sd, sd_v, eng, eng_v = setup
+    tok = CharTok(cfg.vocab)
+    Q.set_pos_tagger(Q.rule_pos_tag)
+    try:
+        wl = Q.get_default_word_list()
+        seen = []
+
+        class Spy(Q.GPT2EngineOracle):
+            def generate_answers(self, words, questions, return_full=False):
+                ans = super().generate_answers(words, questions, return_full)
+                seen.append((list(words), list(questions), list(ans)))
+                return ans
+        oracle = Spy(eng_v, tok, max_input_length=96, max_new_tokens=4, eos_token_id=10)
+        asker = GPT2PPOPolicy(eng, tok, max_input_length=64, max_new_tokens=12, do_sample=True, temperature=0.9, seed=5, eos_token_id=10,
+                              out_str_process=Q.asker_postproc_simple)
+        env = Q.BatchedTwentyQuestionsPolicyEnvironment(oracle, wl, max_conversation_length=3, bsize=4)
+        inter = E.interact_environment(env, asker, initial_text_history=None, env_seed=[1, 2, 3, 4], env_options=[{"deterministic": True}] * 4,
+                                       bsize=4, npad=0)
+        assert len(inter) == 4 and all(len(ep) == 3 and ep[-1].done for ep in inter)      # a random oracle never confirms the word: 3 questions each
+        for ep in inter:
+            for t in ep:
+                assert t.reward == -1.0 and t.post_action_history[-1].is_action and t.post_action_history[-1].text.endswith("?\n")
+                assert t.post_transition_history[-1].text in ("Yes.\n", "No.\n") and not t.post_transition_history[-1].is_action
+        assert len(seen) == 3 and all(len(w) == 4 for w, _, _ in seen)
+        # the oracle engine really produced the answers: regenerate one batch greedily and post-process as the reference does
+        words, questions, answers = seen[1]
+        regen = GPT2PPOPolicy(eng_v, tok, max_input_length=96, max_new_tokens=4, do_sample=False, eos_token_id=10)
+        outs = [h[-1].text for h in regen.act([(E.Text(Q.get_oracle_prompt(w, q), False),) for w, q in zip(words, questions)])]
+        assert Q.answers_from_outputs(questions, outs)[0] == answers
+        assert [w.words for w in words] == [wl[s % len(wl)].words for s in (1, 2, 3, 4)]
+    finally:
+        Q.set_pos_tagger(None)
