@@ -210,6 +210,17 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
 int lmrl_gpt2_kv_broadcast(const lmrl_gpt2 *m, const void *src_kv_d, int src_tmax, void *dst_kv_d, int dst_tmax, int b, int n_pos,
                            const void *src_hidden_d, void *dst_hidden_d, int32_t *dst_len_d, void *stream);
 
+/*
+ * Prompt-prefix cache (indexed form of lmrl_gpt2_kv_broadcast): env i of dst starts from the prompt held by row idx_d[i] of the session
+ * `src` (src_b envs, same model): K/V rows [0, src_len_d[row]), dst_len_d[i] = that length and (optionally) the row's last hidden state.
+ * idx_d[i] < 0 leaves env i with an empty cache.  Text envs whose observations form a finite set (Maze with last_k = 1: one prompt per
+ * (goal, cell), llm_rl_scripts/maze/env/env.py:8-81,182-184) prefill each distinct prompt once per set of weights instead of once per
+ * env per turn (the reference re-encodes and re-runs the whole prompt on every act(), ppo/gpt2/interface.py:519-546); the copied rows are
+ * the rows a per-env prefill of the same tokens writes.
+ */
+int lmrl_gpt2_kv_gather(const lmrl_gpt2 *m, const void *src_kv_d, int src_b, int src_tmax, const int32_t *src_len_d, const void *src_hidden_d,
+                        const int32_t *idx_d, void *dst_kv_d, int dst_tmax, int b, void *dst_hidden_d, int32_t *dst_len_d, void *stream);
+
 /* C[m][n] = A[m][k] . W[n][k]^T + bias[n]; A, W bf16.  epilogue: 0 bf16, 1 gelu_new->bf16, 2 f32 += (residual),
  * 3 f32, 4 relu->bf16.  Used for the value heads (heads/linear_head.py:112-119, heads/mlp_head.py:139-148). */
 int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda,
@@ -314,6 +325,55 @@ int lmrl_wordle_tok_observe(lmrl_wordle_tok_ctx *c, const lmrl_wordle_traj *tr, 
  * k < 0 writes all six positions at once, steer_d = int32 [6][n] */
 int lmrl_wordle_tok_steer(lmrl_wordle_tok_ctx *c, const uint32_t *scripted_guess_d, int k, int32_t *steer_d, int n,
                           void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * On-device token <-> game bookkeeping for lock-step Maze rollouts (csrc/maze_tokens.hip), for histories of one item
+ * (last_k = 1, the reference's Maze harness: maze/bc/fully_observed_bc.py:230-237): a turn's prompt is the observation of the current
+ * cell, a pure function of (goal, cell) (maze/env/env.py:8-81), so prompts come from a token table instead of the host tokenizer, and the
+ * generated ids are decoded through a per-token byte table and matched against the four action strings (env.py:94-99) on the device.
+ * Replaces the per-turn host work of interact_environment + GPT2PPOPolicy.act (LLM_RL/environment.py:180-206,
+ * ppo/gpt2/interface.py:519-546).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t *pos;         /* [N][T]  (row << 16 | col) the turn's observation was rendered from */
+    int32_t *gen;         /* [N][T][G] generated ids of the turn's action (before decoding) */
+    int32_t *gen_len;     /* [N][T] */
+    uint8_t *action;      /* [N][T]  LMRL_MAZE_LEFT..LMRL_MAZE_OTHER the decoded text maps to */
+    float *reward;        /* [N][T] */
+    uint8_t *kind;        /* [N][T]  LMRL_MAZE_KIND_* of the step's result */
+    int32_t *n_turns;     /* [N] env steps taken */
+    uint8_t *live;        /* [N] episode still running */
+    float *ep_reward;     /* [N] */
+    int32_t *obs_idx;     /* [N] row of the observation table for the current turn (-1: finished) */
+    int32_t *out_tok;     /* [N][G] generation buffer of the current turn (lmrl_gen_accept) */
+    int32_t *out_len;     /* [N] */
+    uint8_t *gen_active;  /* [N] */
+    uint8_t *act;         /* [N] action code of the current turn (input of lmrl_maze_step) */
+    uint8_t *stepping;    /* [N] env takes part in the current turn (active mask of lmrl_maze_step) */
+} lmrl_maze_traj;
+
+typedef struct lmrl_maze_tok_ctx lmrl_maze_tok_ctx;
+/* obs_tok [n_obs][obs_cap] / obs_len [n_obs]: token ids of every observation text, row = goal_slot * rows * cols + r * cols + c;
+ * goal_slot [rows * cols]: slot of a goal cell (-1: not a goal of this table).  tok_bytes [vocab][16] / tok_blen [vocab]: the decoded
+ * bytes of each token id; blen 0 = skipped (special tokens under skip_special_tokens=True, value_rl_base/base_interface.py:126),
+ * 255 = not representable (non-ASCII or longer than 16 bytes: such a token cannot be part of an action string).  T = max_turns. */
+lmrl_maze_tok_ctx *lmrl_maze_tok_create(const int32_t *obs_tok, const int32_t *obs_len, int n_obs, int obs_cap, const int32_t *goal_slot,
+                                        int rows, int cols, const uint8_t *tok_bytes, const uint8_t *tok_blen, int vocab,
+                                        int max_new_tokens, int max_turns);
+void lmrl_maze_tok_destroy(lmrl_maze_tok_ctx *c);
+/* episode start (after lmrl_maze_reset): every env live, counters cleared */
+int lmrl_maze_tok_begin(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, int n, void *stream);
+/* turn start: obs_idx from the env state (pos, goal), position recorded, generation buffers cleared, gen_active = live */
+int lmrl_maze_tok_turn(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, void *stream);
+/* chunk j (chunk tokens per env) of the current prompts for a prefill forward: chunk_tok_d [N][chunk], chunk_cnt_d [N] */
+int lmrl_maze_tok_prompt(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, int j, int chunk, int32_t *chunk_tok_d, int32_t *chunk_cnt_d,
+                         int n, void *stream);
+/* generated ids -> action code: text = concat(token bytes, special tokens skipped); `text.removesuffix('\n') + '\n'`
+ * (the Maze scripts' out_str_process) compared with the four action strings; records ids and code */
+int lmrl_maze_tok_action(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, int n, void *stream);
+/* outputs of lmrl_maze_step -> record (reward, kind), counters, live &= !done */
+int lmrl_maze_tok_result(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const float *reward_d, const uint8_t *done_d,
+                         const uint8_t *kind_d, int n, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-kernel-class timing with HIP events on the launch stream (used by bench.py for the live roofline figure).

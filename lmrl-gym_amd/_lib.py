@@ -51,6 +51,14 @@ _SIGS = {
     "lmrl_sgemm_set_variant": (None, [c_int]),
     "lmrl_sample_ws_bytes": (c_size_t, [c_int, c_int]),
     "lmrl_lm_head_sample": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int] + [c_void_p] * 8),
+    "lmrl_maze_tok_create": (c_void_p, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "lmrl_maze_tok_destroy": (None, [c_void_p]),
+    "lmrl_maze_tok_begin": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_maze_tok_turn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_maze_tok_prompt": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_maze_tok_action": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_maze_tok_result": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_gpt2_kv_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "lmrl_wordle_tok_create": (c_void_p, [c_void_p, c_void_p, c_int, c_int, c_int]),
     "lmrl_wordle_tok_destroy": (None, [c_void_p]),
     "lmrl_wordle_tok_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

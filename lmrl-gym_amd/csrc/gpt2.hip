@@ -739,6 +739,31 @@ __global__ __launch_bounds__(256) void kv_broadcast_kernel(const uint16_t *__res
     }
 }
 
+// Prompt-prefix cache: env b starts from the prompt held by row idx[b] of another session of the same model (K/V rows, cache length and
+// last hidden state) — the indexed form of kv_broadcast_kernel.  A text env whose observations form a finite set (Maze: one text per
+// (goal, cell)) prefills every distinct prompt ONCE per set of weights; a turn then starts with this copy instead of a prefill.
+// idx[b] < 0: the env gets an empty cache (finished episode).  One workgroup per (env, layer x K|V), 16 B per lane.
+__global__ __launch_bounds__(256) void kv_gather_kernel(const uint16_t *__restrict__ src, int src_b, int src_tmax, const int32_t *__restrict__ src_len,
+                                                        const int32_t *__restrict__ idx, uint16_t *__restrict__ dst, int dst_tmax, int B, int d,
+                                                        const uint16_t *__restrict__ src_hidden, uint16_t *__restrict__ dst_hidden,
+                                                        int32_t *__restrict__ dst_len) {
+    const int b = blockIdx.x, lk = blockIdx.y;
+    const int r = idx[b];
+    const int n_pos = (r >= 0 && r < src_b) ? min(min(src_len[r], dst_tmax), src_tmax) : 0;
+    if (n_pos > 0) {
+        const uint16_t *sp = src + ((size_t)lk * src_b + r) * src_tmax * d;
+        uint16_t *dp = dst + ((size_t)lk * B + b) * dst_tmax * d;
+        const int chunks = n_pos * d / 8;
+        for (int i = threadIdx.x; i < chunks; i += blockDim.x)
+            reinterpret_cast<u32x4 *>(dp)[i] = reinterpret_cast<const u32x4 *>(sp)[i];
+    }
+    if (lk == 0) {
+        if (dst_hidden && n_pos > 0) for (int i = threadIdx.x; i < d / 8; i += blockDim.x)
+            reinterpret_cast<u32x4 *>(dst_hidden + (size_t)b * d)[i] = reinterpret_cast<const u32x4 *>(src_hidden + (size_t)r * d)[i];
+        if (threadIdx.x == 0) dst_len[b] = n_pos;
+    }
+}
+
 // profiling only (one launch per forward): algorithmic HBM bytes of the attention launches of this forward =
 // per (env, head, layer): K and V rows of every attended position (2 x 128 B) + the chunk's q rows and output rows.
 __global__ void attn_bytes_kernel(const int32_t *cnt, const int32_t *len, int B, int C, int heads_x_layers,
@@ -984,6 +1009,18 @@ int lmrl_gpt2_kv_broadcast(const lmrl_gpt2 *m, const void *src_kv_d, int src_tma
     LMRL_REQUIRE(!dst_hidden_d || src_hidden_d, "lmrl_gpt2_kv_broadcast: dst_hidden_d needs src_hidden_d");
     hipLaunchKernelGGL(kv_broadcast_kernel, dim3(b, 2 * m->cfg.n_layer), dim3(256), 0, as_stream(stream), (const uint16_t *)src_kv_d, src_tmax,
                        (uint16_t *)dst_kv_d, dst_tmax, b, n_pos, m->cfg.d_model, (const uint16_t *)src_hidden_d, (uint16_t *)dst_hidden_d, dst_len_d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_gpt2_kv_gather(const lmrl_gpt2 *m, const void *src_kv_d, int src_b, int src_tmax, const int32_t *src_len_d, const void *src_hidden_d,
+                        const int32_t *idx_d, void *dst_kv_d, int dst_tmax, int b, void *dst_hidden_d, int32_t *dst_len_d, void *stream) {
+    LMRL_REQUIRE(m && src_kv_d && src_len_d && idx_d && dst_kv_d && dst_len_d && b > 0 && src_b > 0 && src_tmax > 0 && dst_tmax > 0,
+                 "lmrl_gpt2_kv_gather: bad argument");
+    LMRL_REQUIRE(!dst_hidden_d || src_hidden_d, "lmrl_gpt2_kv_gather: dst_hidden_d needs src_hidden_d");
+    hipLaunchKernelGGL(kv_gather_kernel, dim3(b, 2 * m->cfg.n_layer), dim3(256), 0, as_stream(stream), (const uint16_t *)src_kv_d, src_b, src_tmax,
+                       src_len_d, idx_d, (uint16_t *)dst_kv_d, dst_tmax, b, m->cfg.d_model, (const uint16_t *)src_hidden_d, (uint16_t *)dst_hidden_d,
+                       dst_len_d);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

@@ -191,13 +191,10 @@ class VectorMazeEnv(BatchedTextEnv):
         return self.describe_function(self.maze, [int(st_row[0]), int(st_row[1])], [int(st_row[2]), int(st_row[3])],
                                       self.initial_positions[i], self.move_history[i])
 
-    def reset(self, seed=None, options=None) -> List[TextHistory]:
+    def reset_device(self, seed, options=None) -> None:
+        """MazeEnv.reset for len(seed) envs without leaving the device: state only, no observation text (device rollout loops)."""
         t = self._torch
-        if seed is None and options is None:
-            seed, options = [None], [None]
-        elif seed is None:
-            seed = [None] * len(options)
-        elif options is None:
+        if options is None:
             options = [None] * len(seed)
         assert len(seed) == len(options)
         n = len(seed)
@@ -205,11 +202,12 @@ class VectorMazeEnv(BatchedTextEnv):
             self._alloc(n)
         goal = np.full((n, 2), -1, dtype=np.int32)
         init = np.full((n, 2), -1, dtype=np.int32)
-        free = np.argwhere(self.maze == 0).tolist()
+        free = None
         for i, o in enumerate(options):
             if o is not None and "goal" in o:
                 goal[i] = o["goal"]
             if o is not None and "init_position" in o:
+                free = np.argwhere(self.maze == 0).tolist() if free is None else free
                 g = list(o["goal"]) if "goal" in o else None
                 assert list(o["init_position"]) in free and list(o["init_position"]) != g
                 init[i] = o["init_position"]
@@ -217,6 +215,16 @@ class VectorMazeEnv(BatchedTextEnv):
         seeds_d, goal_d, init_d = (t.from_numpy(x.copy()).to(self.device) for x in (seeds, goal, init))
         _lib.check(self._L.lmrl_maze_reset(self._ctx, _lib.ptr(self.state), _lib.ptr(self.mt), _lib.ptr(seeds_d),
                                            _lib.ptr(goal_d), _lib.ptr(init_d), None, n, _lib.stream_ptr()), "lmrl_maze_reset")
+
+    def reset(self, seed=None, options=None) -> List[TextHistory]:
+        if seed is None and options is None:
+            seed, options = [None], [None]
+        elif seed is None:
+            seed = [None] * len(options)
+        elif options is None:
+            options = [None] * len(seed)
+        self.reset_device(seed, options)
+        n = self.n
         st = self.positions()
         out = []
         for i in range(n):

@@ -186,6 +186,19 @@ class KVSession:
         self._len_bound = max(self._len_bound, n_pos)
         self.shared_prefix = min(n_pos, 255)
 
+    def gather_prefix_from(self, src: "KVSession", idx, max_pos: int):
+        """Env b starts from the prompt held by row idx[b] (int32 device tensor; < 0: empty cache) of the session `src` of the same
+        engine (`lmrl_gpt2_kv_gather`): K/V rows, cache length and last hidden state.  `max_pos` bounds the copied prompt lengths."""
+        assert src.eng is self.eng
+        e = self.eng
+        if max_pos > self.tmax:
+            raise _lib.LmrlError(f"KV cache overflow: prompts of up to {max_pos} positions into a cache of tmax = {self.tmax}")
+        _lib.check(e._L.lmrl_gpt2_kv_gather(e._h, _lib.ptr(src.kv), src.B, src.tmax, _lib.ptr(src.len), _lib.ptr(src.last_hidden), _lib.ptr(idx),
+                                            _lib.ptr(self.kv), self.tmax, self.B, _lib.ptr(self.last_hidden), _lib.ptr(self.len), _lib.stream_ptr()),
+                   "lmrl_gpt2_kv_gather")
+        self._len_bound = max_pos
+        self.shared_prefix = 0
+
     def sample(self, params: SampleParams, steer_tok=None, active=None, hidden=None, logits_out=None,
                q1=None, q2=None, want_logprob: bool = True):
         """Fused LM head + sampling of one token per env from `hidden` (default: last_hidden).

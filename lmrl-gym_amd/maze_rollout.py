@@ -1,0 +1,332 @@
+"""Lock-step Maze rollouts entirely on the device, for one-item histories (last_k = 1).
+
+The MI355X counterpart of `interact_environment(maze_env, GPT2PPOPolicy(...), bsize=B)` (LLM_RL/environment.py:154-207 with
+ppo/gpt2/interface.py:507-546) on the reference's Maze harness (maze/bc/fully_observed_bc.py:230-283: `last_k=1`, `max_steps=100`).
+With last_k = 1 the policy's prompt is the observation of the current cell — a pure function of (goal, cell)
+(maze/env/env.py:8-81) — so the host renders and tokenises every distinct observation ONCE per (maze, tokenizer), and prefills each of
+them ONCE per set of weights into a prompt-prefix cache (one KV row per observation, `lmrl_gpt2_kv_gather`).  A turn is then
+
+    obs row <- env state | K/V + last hidden <- prefix cache | generate <= max_new ids | ids -> action code | lmrl_maze_step | record
+
+with no host round trip; one turn is one hipGraph replay.  The reference re-encodes the text and re-runs the whole prompt through the
+model for every env on every turn.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from . import _lib
+from .envs import maze as M
+from .gpt2 import FWD_RAGGED_ALWAYS, GPT2Engine, SampleParams
+
+_TOK_BYTES = 16
+
+
+class _CTraj(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("pos", "gen", "gen_len", "action", "reward", "kind", "n_turns", "live", "ep_reward", "obs_idx",
+                                               "out_tok", "out_len", "gen_active", "act", "stepping")]
+
+
+def maze_out_str_process(x: str) -> str:
+    """The Maze scripts' `out_str_process` (e.g. maze/bc/fully_observed_bc.py:265): exactly one trailing newline."""
+    return x.removesuffix("\n") + "\n"
+
+
+def _decode_one(tokenizer, i: int) -> str:
+    try:
+        return tokenizer.decode([i], skip_special_tokens=True)
+    except TypeError:
+        special = getattr(tokenizer, "all_special_ids", None)
+        if special is None:
+            special = [t for t in (getattr(tokenizer, "pad_token_id", None),) if t is not None]
+        return "" if i in special else tokenizer.decode([i])
+
+
+def token_byte_table(tokenizer, vocab: int):
+    """(bytes uint8 [vocab][16], blen uint8 [vocab]) for `lmrl_maze_tok_create`: the decoded string of every id.  blen 0: the id adds
+    nothing to the text (special tokens under skip_special_tokens=True; ids the tokenizer decodes to ''), 255: non-ASCII or longer than
+    16 bytes — such a token cannot occur in an action string, and for byte-level BPE (decode = concatenation of token bytes, invalid
+    UTF-8 -> U+FFFD) any text containing it is not an action.  Ids beyond len(tokenizer) (padded model vocabularies) are 255."""
+    tb = np.zeros((vocab, _TOK_BYTES), dtype=np.uint8)
+    bl = np.full(vocab, 255, dtype=np.uint8)
+    for i in range(min(vocab, len(tokenizer))):
+        s = _decode_one(tokenizer, i)
+        if s == "":
+            bl[i] = 0
+        elif s.isascii() and len(s) <= _TOK_BYTES:
+            b = s.encode("ascii")
+            tb[i, : len(b)] = np.frombuffer(b, dtype=np.uint8)
+            bl[i] = len(b)
+    return tb, bl
+
+
+class MazeRolloutEngine:
+    """B lock-step Maze episodes (last_k = 1) driven by a GPT-2 policy on one GPU.
+
+    `value_engine` + `q1_head` (+ `q2_head`) + `beta` make it the ILQL value policy (value_rl_base/gpt2/generation.py:97-119), as in
+    `WordleRolloutEngine`.  `prefix_cache=False` prefills the observation tokens per env per turn instead (16-token chunks): the
+    cross-check of the cache, and the fallback for tables too large to prefill."""
+
+    def __init__(self, engine: GPT2Engine, tokenizer, env: M.MazeEnv, batch: int, max_new_tokens: int = 8, eos_token_id: Optional[int] = None,
+                 max_input_length: int = 256, in_str_process: Optional[Callable[[str], str]] = None, prefix_cache: bool = True,
+                 max_turns: Optional[int] = None, value_engine: Optional[GPT2Engine] = None, q1_head: Optional[dict] = None,
+                 q2_head: Optional[dict] = None, beta: float = 0.0, session_flags: int = FWD_RAGGED_ALWAYS):
+        import torch
+        t = torch
+        venv = env.as_batched() if isinstance(env, M.MazeEnv) else env
+        if venv.last_k != 1:
+            raise ValueError("MazeRolloutEngine: the device loop covers one-item histories (last_k = 1); use interact_environment with "
+                             "GPT2PPOPolicy for longer histories")
+        if max_turns is None:
+            if venv.max_steps is None:
+                raise ValueError("MazeRolloutEngine: env without max_steps needs max_turns")
+            max_turns = venv.max_steps + 1            # the step after max_steps steps returns Failure (env.py:164-165)
+        self.eng, self.tok, self.env, self.B = engine, tokenizer, venv, batch
+        self.max_new, self.T = max_new_tokens, int(max_turns)
+        self.eos = eos_token_id if eos_token_id is not None else getattr(tokenizer, "eos_token_id", None)
+        self.pad = getattr(tokenizer, "pad_token_id", 0) or 0
+        self.dev, self._L = engine.device, _lib.lib()
+        self.in_str_process = in_str_process or (lambda x: x)
+        self.prefix_cache = prefix_cache
+        # ---- observation table: one row per (goal slot, cell)
+        maze, goals = venv.maze, venv.valid_goals
+        R, C = maze.shape
+        goal_slot = np.full(R * C, -1, dtype=np.int32)
+        rows: List[List[int]] = []
+        self._obs_text = {}
+        for gi, g in enumerate(goals.tolist()):
+            goal_slot[g[0] * C + g[1]] = gi
+            for r in range(R):
+                for c in range(C):
+                    ids: List[int] = []
+                    if maze[r, c] == 0:
+                        text = venv.describe_function(maze, [r, c], [int(g[0]), int(g[1])], None, [])
+                        self._obs_text[(gi, r, c)] = text
+                        ids = list(tokenizer.encode(self.in_str_process(text)))
+                        if len(ids) > max_input_length:               # Truncation.LEFT (interface.py:519-524)
+                            ids = ids[len(ids) - max_input_length:]
+                        ids = ids or [self.pad]
+                    rows.append(ids)
+        self.obs_cap = -(-max(len(x) for x in rows) // 16) * 16
+        self.max_obs_len = max(len(x) for x in rows)
+        obs_tok = np.zeros((len(rows), self.obs_cap), dtype=np.int32)
+        obs_len = np.array([len(x) for x in rows], dtype=np.int32)
+        for i, x in enumerate(rows):
+            obs_tok[i, : len(x)] = x
+        self.obs_tok_h, self.obs_len_h, self.goal_slot = obs_tok, obs_len, goal_slot
+        tb, bl = token_byte_table(tokenizer, engine.cfg.vocab)
+        self._tok = self._L.lmrl_maze_tok_create(obs_tok.ctypes.data, obs_len.ctypes.data, len(rows), self.obs_cap, goal_slot.ctypes.data, R, C,
+                                                 tb.ctypes.data, bl.ctypes.data, engine.cfg.vocab, max_new_tokens, self.T)
+        if not self._tok:
+            raise _lib.LmrlError(self._L.lmrl_last_error().decode())
+        # ---- sessions
+        tmax = self.obs_cap + -(-max_new_tokens // 16) * 16        # whole 16-token prompt chunks (per-turn prefill mode) + the generated ids
+        self.veng, self.q1, self.q2, self.beta = value_engine, q1_head, q2_head, float(beta)
+        assert (value_engine is None) == (q1_head is None), "value_engine and q1_head come together"
+        self.engines = [engine] + ([value_engine] if value_engine is not None else [])
+        self.sessions = [e.session(batch, tmax, flags=session_flags) for e in self.engines]
+        self.ses = self.sessions[0]
+        self.vses = self.sessions[1] if value_engine is not None else None
+        self.qh = [t.zeros(batch, value_engine.cfg.d_model, dtype=t.bfloat16, device=self.dev) for _ in range(2)] if value_engine is not None else None
+        self.caches = None
+        B, G, T = batch, max_new_tokens, self.T
+        z = lambda *shape, dt: t.zeros(*shape, dtype=dt, device=self.dev)
+        self.traj = dict(pos=z(B, T, dt=t.int32), gen=z(B, T, G, dt=t.int32), gen_len=z(B, T, dt=t.int32), action=z(B, T, dt=t.uint8),
+                         reward=z(B, T, dt=t.float32), kind=z(B, T, dt=t.uint8), n_turns=z(B, dt=t.int32), live=z(B, dt=t.uint8),
+                         ep_reward=z(B, dt=t.float32), obs_idx=z(B, dt=t.int32), out_tok=z(B, G, dt=t.int32), out_len=z(B, dt=t.int32),
+                         gen_active=z(B, dt=t.uint8), act=z(B, dt=t.uint8), stepping=z(B, dt=t.uint8))
+        self._ctraj = _CTraj(*[self.traj[n].data_ptr() for n, _ in _CTraj._fields_])
+        self.chunk_tok, self.chunk_cnt = z(B * 16, dt=t.int32), z(B, dt=t.int32)
+        self.next_tok, self.next_cnt = z(B, dt=t.int32), z(B, dt=t.int32)
+        self.epoch = z(1, dt=t.int32)                  # 4th Philox counter word: episode base + turn (device side: graph replays advance it)
+        self.env._alloc(batch)
+        self.turn_graph = None
+        if prefix_cache:
+            self.refresh_prefix_cache()
+
+    def close(self):
+        if getattr(self, "_tok", None):
+            self._L.lmrl_maze_tok_destroy(self._tok)
+            self._tok = None
+        self.env.close()
+
+    # ---- prompt-prefix cache ------------------------------------------------------------------------------------------------------
+    def refresh_prefix_cache(self):
+        """Prefill every distinct observation once (per engine); call again after the weights change (`set_params`)."""
+        import torch
+        t = torch
+        n, cap = self.obs_tok_h.shape
+        self.caches = []
+        lens = t.from_numpy(self.obs_len_h).to(self.dev)
+        for e in self.engines:
+            ses = e.session(n, cap)
+            ses.reset()
+            for c0 in range(0, self.max_obs_len, 16):
+                toks = t.from_numpy(np.ascontiguousarray(self.obs_tok_h[:, c0:c0 + 16]).reshape(-1)).to(self.dev)
+                cnt = t.clamp(lens - c0, 0, 16).to(t.int32)
+                ses.forward(toks, cnt, 16)
+            self.caches.append(ses)
+
+    def set_params(self, engine: GPT2Engine) -> None:
+        """Swap in freshly trained policy weights (PPOPolicy.set_params, ppo/base_interface.py:821-823)."""
+        self.eng = self.engines[0] = engine
+        self.sessions[0] = self.ses = engine.session(self.B, self.ses.tmax, flags=self.ses.flags)
+        self.turn_graph = None
+        if self.prefix_cache:
+            self.refresh_prefix_cache()
+
+    # ---- one lock-step turn ----------------------------------------------------------------------------------------------------------
+    def _turn(self, temperature: float, top_k: int, sample_seed: int, logits_out=None):
+        L, sp, tr, B = self._L, _lib.stream_ptr(), ctypes.byref(self._ctraj), self.B
+        ck = _lib.check
+        ck(L.lmrl_maze_tok_turn(self._tok, tr, _lib.ptr(self.env.state), B, sp), "maze_tok_turn")
+        if self.prefix_cache:
+            for ses, cache in zip(self.sessions, self.caches):
+                ses.gather_prefix_from(cache, self.traj["obs_idx"], self.max_obs_len)
+        else:
+            for ses in self.sessions:
+                ses.reset()
+            for j in range(-(-self.max_obs_len // 16)):
+                ck(L.lmrl_maze_tok_prompt(self._tok, tr, j, 16, _lib.ptr(self.chunk_tok), _lib.ptr(self.chunk_cnt), B, sp), "maze_tok_prompt")
+                for ses in self.sessions:
+                    ses.forward(self.chunk_tok, self.chunk_cnt, 16)
+        for k in range(self.max_new):
+            p = SampleParams(temperature, top_k, sample_seed, k, 0.0, self.beta, self.pad, _lib.ptr(self.epoch))
+            qops = [None, None]
+            if self.vses is not None:
+                dv = self.veng.cfg.d_model
+                for i, head in enumerate((self.q1, self.q2)):
+                    if head is not None:
+                        ck(L.lmrl_gemm_bf16(_lib.ptr(self.vses.last_hidden), _lib.ptr(head["w1"]), _lib.ptr(head["b1"]), _lib.ptr(self.qh[i]),
+                                            B, dv, dv, dv, dv, dv, 4, sp), "q head dense1 + relu")
+                        qops[i] = (self.qh[i], head["w2"], head["b2"])
+            self.ses.sample(p, active=self.traj["gen_active"], logits_out=logits_out, q1=qops[0], q2=qops[1], want_logprob=False)
+            ck(L.lmrl_gen_accept(_lib.ptr(self.ses.token), _lib.ptr(self.traj["gen_active"]), _lib.ptr(self.traj["out_tok"]),
+                                 _lib.ptr(self.traj["out_len"]), _lib.ptr(self.next_tok), _lib.ptr(self.next_cnt),
+                                 -1 if self.eos is None else int(self.eos), self.max_new, B, sp), "lmrl_gen_accept")
+            if k < self.max_new - 1:
+                for ses in self.sessions:
+                    ses.forward(self.next_tok, self.next_cnt, 1)
+        ck(L.lmrl_maze_tok_action(self._tok, tr, B, sp), "maze_tok_action")
+        e = self.env
+        ck(L.lmrl_maze_step(e._ctx, _lib.ptr(e.state), _lib.ptr(self.traj["act"]), _lib.ptr(self.traj["stepping"]), _lib.ptr(e.reward),
+                            _lib.ptr(e.done), _lib.ptr(e.kind), _lib.ptr(e.walls), B, sp), "lmrl_maze_step")
+        ck(L.lmrl_maze_tok_result(self._tok, tr, _lib.ptr(e.reward), _lib.ptr(e.done), _lib.ptr(e.kind), B, sp), "maze_tok_result")
+        self.epoch.add_(1)
+
+    def capture_turn(self, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0):
+        """One turn (~ max_new x n_layer x 7 launches) as a hipGraph; `run_episode(..., use_graph=True)` replays it per turn."""
+        import torch
+        t = torch
+        self._graph_args = (temperature, top_k, sample_seed)
+        self._logits = t.empty(self.B, self.eng.cfg.vocab_padded, dtype=t.float32, device=self.dev) if top_k > 0 else None
+        self.env.reset_device([0] * self.B)
+        _lib.check(self._L.lmrl_maze_tok_begin(self._tok, ctypes.byref(self._ctraj), self.B, _lib.stream_ptr()), "maze_tok_begin")
+        self._turn(temperature, top_k, sample_seed, self._logits)           # eager warm-up
+        t.cuda.synchronize()
+        g = t.cuda.CUDAGraph()
+        with t.cuda.graph(g, capture_error_mode="thread_local"):
+            self._turn(temperature, top_k, sample_seed, self._logits)
+        self.turn_graph = g
+        return g
+
+    def run_episode(self, seeds, options=None, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0, episode: int = 0,
+                    use_graph: bool = False, sync_every: int = 8, max_turns: Optional[int] = None):
+        """One full episode for all B envs; returns the device record dict (read after a sync).  The host peeks at the live flags every
+        `sync_every` turns to stop early (0: never — fixed T turns, fully asynchronous)."""
+        import torch
+        t = torch
+        if use_graph:
+            if self.turn_graph is None or self._graph_args != (temperature, top_k, sample_seed):
+                self.capture_turn(temperature, top_k, sample_seed)
+            logits = self._logits
+        else:
+            logits = t.empty(self.B, self.eng.cfg.vocab_padded, dtype=t.float32, device=self.dev) if top_k > 0 else None
+        assert len(seeds) == self.B
+        self.env.reset_device(list(seeds), options)
+        _lib.check(self._L.lmrl_maze_tok_begin(self._tok, ctypes.byref(self._ctraj), self.B, _lib.stream_ptr()), "maze_tok_begin")
+        self.epoch.fill_(int(episode) << 12)
+        n = self.T if max_turns is None else min(self.T, max_turns)
+        for turn in range(n):
+            if sync_every and turn and turn % sync_every == 0 and not bool(self.traj["live"].any().item()):
+                break
+            if use_graph:
+                self.turn_graph.replay()
+            else:
+                self._turn(temperature, top_k, sample_seed, logits)
+        return self.traj
+
+    # ---- host views ----------------------------------------------------------------------------------------------------------------
+    def records(self):
+        """Host copies per env: dict(pos [n][2], gen list of id lists, action uint8 [n], reward f32 [n], kind uint8 [n], goal (r, c))."""
+        h = {k: v.cpu().numpy() for k, v in self.traj.items()}
+        st = self.env.positions()
+        out = []
+        for b in range(self.B):
+            n = int(h["n_turns"][b])
+            pos = np.stack([h["pos"][b, :n] >> 16, h["pos"][b, :n] & 0xFFFF], axis=1) if n else np.zeros((0, 2), dtype=np.int32)
+            gen = [h["gen"][b, i, : h["gen_len"][b, i]].tolist() for i in range(n)]
+            out.append(dict(pos=pos, gen=gen, action=h["action"][b, :n].copy(), reward=h["reward"][b, :n].copy(), kind=h["kind"][b, :n].copy(),
+                            goal=(int(st[b, 2]), int(st[b, 3])), final_pos=(int(st[b, 0]), int(st[b, 1])), live=bool(h["live"][b])))
+        return out
+
+    def _decode(self, ids: List[int]) -> str:
+        try:
+            return self.tok.decode(ids, skip_special_tokens=True)
+        except TypeError:
+            special = getattr(self.tok, "all_special_ids", None)
+            if special is None:
+                special = [t for t in (getattr(self.tok, "pad_token_id", None),) if t is not None]
+            special = set(special)
+            return self.tok.decode([i for i in ids if i not in special])
+
+    def interactions(self):
+        """The finished episodes as `List[List[InteractionTransition]]` — what `interact_environment` returns for the same rollouts
+        (LLM_RL/environment.py:154-207; histories per maze/env/env.py:161-184 with last_k = 1)."""
+        from .environment import InteractionTransition, Text
+        maze = self.env.maze
+        out = []
+        for rec in self.records():
+            g = [rec["goal"][0], rec["goal"][1]]
+            desc = lambda p: Text(self.env.describe_function(maze, [int(p[0]), int(p[1])], g, None, []), False)
+            n = len(rec["gen"])
+            trans = []
+            for i in range(n):
+                pre = (desc(rec["pos"][i]),)
+                post_action = pre + (Text(maze_out_str_process(self._decode(rec["gen"][i])), True),)
+                kind = int(rec["kind"][i])
+                if kind == M.KIND_FAILURE:
+                    post, done = (Text("Failure\n", False),), True
+                elif kind == M.KIND_SUCCESS:
+                    post, done = (Text("Success\n", False),), True
+                else:
+                    nxt = rec["pos"][i + 1] if i + 1 < n else rec["final_pos"]
+                    post, done = (desc(nxt),), False
+                trans.append(InteractionTransition(pre, post_action, post, float(rec["reward"][i]), done))
+            out.append(trans)
+        return out
+
+    def text_env_eval(self, n_rollouts: int, seed_generator=None, env_options=None, temperature: float = 1.0, top_k: int = 0,
+                      sample_seed: int = 0, interaction_callback=None, use_graph: bool = True):
+        """`text_env_eval(env, policy, n_rollouts, bsize=B, env_options=...)` (LLM_RL/environment.py:211-267) with the whole lock-step
+        loop on the device: ceil(n / B) episode batches, the same (interactions, summary) return value."""
+        inter, rewards, dones, lengths = [], [], [], []
+        batch_id = 0
+        while len(inter) < n_rollouts:
+            actual = min(n_rollouts - len(inter), self.B)
+            seeds = [0] * self.B
+            seeds[:actual] = [next(seed_generator) for _ in range(actual)] if seed_generator is not None else \
+                np.random.randint(0, 2 ** 31 - 1, size=actual).tolist()
+            options = [env_options] * self.B if env_options is not None else None
+            self.run_episode(seeds, options, temperature=temperature, top_k=top_k, sample_seed=sample_seed, episode=batch_id, use_graph=use_graph)
+            batch_id += 1
+            for ep in self.interactions()[:actual]:
+                inter.append(ep)
+                rewards.append(sum(t.reward for t in ep)); dones.append(ep[-1].done); lengths.append(len(ep))
+                if interaction_callback is not None:
+                    interaction_callback(ep)
+        summ = lambda x: dict(mean=np.mean(x), std=np.std(x), min=np.min(x), max=np.max(x))
+        return inter, dict(reward=summ(np.asarray(rewards, dtype=np.float32)), done=summ(np.asarray(dones, dtype=np.float32)), length=summ(lengths))

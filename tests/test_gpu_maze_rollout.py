@@ -1,0 +1,170 @@
+"""GPU tier: the device-resident Maze rollout loop (lmrl_gym_amd.maze_rollout.MazeRolloutEngine, csrc/maze_tokens.hip,
+lmrl_gpt2_kv_gather) against (a) the CPU oracle env replaying the recorded actions, (b) the host text path for the action decoding,
+(c) per-turn prefill instead of the prompt-prefix cache, (d) eager launches instead of the per-turn hipGraph, and (e) the generic
+host-tokenising path `interact_environment(env, GPT2ValuePolicy)` on greedy decoding — transition by transition."""
+import numpy as np
+import pytest
+
+import lmrl_gym_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+_MERGED = ["move left", "move right", "move up", "move down", "move", " left", " right", " up", " down", "\n\n", "mo", "ve left"]
+
+
+class MergedByteTokenizer:
+    """Bytes 0..255 as ids 0..255, a few multi-byte tokens above (so that an action can be spelled in several ways), pad = special."""
+    eos_token_id = 10                      # '\n'
+
+    def __init__(self):
+        self.extra = list(_MERGED)
+        self.pad_token_id = 256 + len(self.extra)
+        self.all_special_ids = [self.pad_token_id]
+
+    def __len__(self):
+        return self.pad_token_id + 1
+
+    def encode(self, s):
+        return list(s.encode("utf-8"))
+
+    def decode(self, ids):
+        out = b""
+        for i in ids:
+            i = int(i)
+            if i < 256:
+                out += bytes([i])
+            elif i < self.pad_token_id:
+                out += self.extra[i - 256].encode()
+        return out.decode("utf-8", errors="replace")
+
+
+def _setup(dev, B, max_new, max_steps, describe="describe_observation_give_position", prefix_cache=True, seed=0, boost=12.0):
+    from lmrl_gym_amd.envs import maze as M
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine
+    from lmrl_gym_amd.maze_rollout import MazeRolloutEngine
+    from lmrl_gym_amd.policies import heads_to_engine_layout
+    tok = MergedByteTokenizer()
+    cfg = GPT2Config(2, 2, 128, 256, len(tok) + 3, 256)          # model vocabulary a little larger than the tokenizer's
+    pi = GPT2Engine.random_init(cfg, seed=seed, device=dev)
+    vb = GPT2Engine.random_init(cfg, seed=seed + 1, device=dev)
+    d, V = cfg.d_model, cfg.vocab
+    g = torch.Generator().manual_seed(seed + 2)
+    bias = torch.full((V,), -boost)
+    for i in (256, 257, 258, 259, 260, 261, 262, 263, 264, 10, 266, 267):     # action pieces and the eos
+        bias[i] = 0.0
+    head = heads_to_engine_layout({"dense1.kernel": torch.randn(d, d, generator=g) * 0.05, "dense1.bias": torch.zeros(d),
+                                   "dense2.kernel": torch.randn(d, V, generator=g) * 0.3, "dense2.bias": bias}, cfg.vocab_padded, dev)
+    env = M.setup_maze_env("double_t_maze", describe, "standard_reward", last_k=1, max_steps=max_steps)
+    eng = MazeRolloutEngine(pi, tok, env, B, max_new_tokens=max_new, eos_token_id=tok.eos_token_id, prefix_cache=prefix_cache,
+                            value_engine=vb, q1_head=head, q2_head=None, beta=1.0)
+    return eng, tok, pi, vb, head, env
+
+
+def _snapshot(eng):
+    """Host copy of the record with everything beyond the valid extents (n_turns, gen_len) zeroed — those cells keep older contents."""
+    torch.cuda.synchronize()
+    h = {k: v.cpu().numpy().copy() for k, v in eng.traj.items() if k in ("pos", "gen", "gen_len", "action", "reward", "kind", "n_turns", "live",
+                                                                         "ep_reward")}
+    T, G = h["gen"].shape[1:]
+    turn_ok = np.arange(T)[None, :] < h["n_turns"][:, None]
+    for k in ("pos", "gen_len", "action", "reward", "kind"):
+        h[k] = np.where(turn_ok, h[k], 0)
+    h["gen"] = np.where(turn_ok[:, :, None] & (np.arange(G)[None, None, :] < h["gen_len"][:, :, None]), h["gen"], 0)
+    return h, eng.env.positions()
+
+
+@pytest.mark.parametrize("max_new,describe", [(1, "describe_observation_give_position"), (3, "describe_observation_only_walls")])
+def test_device_loop_matches_oracle_env_and_host_decoding(max_new, describe):
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.maze_rollout import maze_out_str_process
+    from oracle.maze import ACTIONS, OracleMazeEnv
+    dev = _lib.require_gpu()
+    B, max_steps = 96, 12
+    eng, tok, *_ = _setup(dev, B, max_new, max_steps, describe)
+    seeds = [1000 + 7 * i for i in range(B)]
+    options = [None if i % 3 else {"init_position": [1, 1 + (i % 5)]} for i in range(B)]
+    eng.run_episode(seeds, options, temperature=1.0, sample_seed=5, use_graph=False, sync_every=0)
+    torch.cuda.synchronize()
+    recs = eng.records()
+    names = list(ACTIONS)
+    n_moves = n_actions = 0
+    for b, rec in enumerate(recs):
+        o = OracleMazeEnv("double_t_maze", describe, "standard_reward", last_k=1, max_steps=max_steps)
+        hist = o.reset(seeds[b], options[b])
+        assert not rec["live"]
+        done = False
+        for i in range(len(rec["gen"])):
+            assert not done
+            assert tuple(rec["pos"][i]) == tuple(o.position), (b, i)
+            text = maze_out_str_process(tok.decode([t for t in rec["gen"][i] if t not in tok.all_special_ids]))     # the host text path
+            code = {"move left\n": 0, "move right\n": 1, "move up\n": 2, "move down\n": 3}.get(text, 4)
+            assert code == rec["action"][i], (b, i, rec["gen"][i], text)
+            n_actions += code != 4
+            before = tuple(o.position)
+            hist, r, done = o.step(tuple(hist) + ((text, True),))
+            n_moves += tuple(o.position) != before
+            assert r == rec["reward"][i]
+            kind = rec["kind"][i]
+            assert (hist[0][0] == "Failure\n") == (kind == 1) and (hist[0][0] == "Success\n") == (kind == 2)
+            if kind in (0, 3):
+                assert (kind == 0) == (text in names)
+        assert done                                              # every episode ended (goal, or Failure after max_steps steps)
+        assert rec["final_pos"] == tuple(o.position) and rec["goal"] == tuple(o.goal)
+    # the steered policy does walk (max_new = 3 spells an action only now and then: most texts there exercise the OTHER paths)
+    assert (n_actions > B and n_moves > B // 2) if max_new == 1 else (n_actions >= 8 and n_moves >= 3), (n_actions, n_moves)
+    # interactions(): the InteractionTransition view, texts re-rendered on the host
+    inter = eng.interactions()
+    assert all(len(ep) == len(rec["gen"]) and ep[-1].done for ep, rec in zip(inter, recs))
+    assert all(t.post_action_history[-1].is_action and t.post_action_history[-1].text.endswith("\n") for ep in inter for t in ep)
+
+
+def test_prefix_cache_graph_and_per_turn_prefill_agree():
+    from lmrl_gym_amd import _lib
+    dev = _lib.require_gpu()
+    B, max_new, max_steps = 64, 3, 6
+    seeds = [31 * i + 3 for i in range(B)]
+    snaps = []
+    for prefix_cache, use_graph in ((True, False), (True, True), (False, False)):
+        eng, *_ = _setup(dev, B, max_new, max_steps, prefix_cache=prefix_cache)
+        eng.run_episode(seeds, None, temperature=0.9, sample_seed=11, episode=2, use_graph=use_graph, sync_every=0 if use_graph else 4)
+        snaps.append(_snapshot(eng))
+        if use_graph:                                  # a second episode on the same captured graph: fresh seeds, fresh noise
+            eng.run_episode([s + 1 for s in seeds], None, temperature=0.9, sample_seed=11, episode=3, use_graph=True)
+            again = _snapshot(eng)
+            assert not np.array_equal(again[0]["gen"], snaps[-1][0]["gen"])
+        eng.close()
+    (a, pa), (g, pg), (p, pp) = snaps
+    for k in a:
+        assert np.array_equal(a[k], g[k]), f"graph replay differs from eager launches in {k}"
+        assert np.array_equal(a[k], p[k]), f"prompt-prefix cache differs from per-turn prefill in {k}"
+    assert np.array_equal(pa, pg) and np.array_equal(pa, pp)
+    assert int(a["n_turns"].max()) == max_steps + 1
+
+
+def test_greedy_device_loop_equals_generic_text_path():
+    """Same weights, greedy decoding: the device loop's transitions == interact_environment(VectorMazeEnv, GPT2ValuePolicy) — the host
+    path that renders, tokenises, prefills and decodes every turn (LLM_RL/environment.py:154-207)."""
+    from lmrl_gym_amd import _lib, environment as E
+    from lmrl_gym_amd.maze_rollout import maze_out_str_process
+    from lmrl_gym_amd.policies import GPT2ValuePolicy
+    dev = _lib.require_gpu()
+    B, max_new, max_steps = 48, 3, 10
+    eng, tok, pi, vb, head, env = _setup(dev, B, max_new, max_steps, boost=6.0)
+    seeds = [5 + 13 * i for i in range(B)]
+    eng.run_episode(seeds, None, temperature=0.0, use_graph=True)
+    torch.cuda.synchronize()
+    mine = eng.interactions()
+    pol = GPT2ValuePolicy(pi, vb, head, None, 1.0, tok, max_input_length=256, max_new_tokens=max_new, do_sample=False,
+                          eos_token_id=tok.eos_token_id, out_str_process=maze_out_str_process)
+    ref = E.interact_environment(env, pol, env_seed=seeds, bsize=B)
+    assert len(mine) == len(ref) == B
+    n_steps = 0
+    for b, (x, y) in enumerate(zip(mine, ref)):
+        assert len(x) == len(y), (b, len(x), len(y))
+        for i, (tx, ty) in enumerate(zip(x, y)):
+            assert tx == ty, (b, i, tx, ty)
+            n_steps += 1
+    assert n_steps >= B * 3
+    kinds = {t.post_action_history[-1].text for ep in mine for t in ep}
+    assert len(kinds) >= 3, kinds                                # several distinct actions were taken

@@ -1,0 +1,27 @@
+"""Maze rollouts on the device-resident loop (MazeRolloutEngine: prompt-prefix cache + per-turn hipGraph) — same workload as
+tools/bench_maze_generic.py: GPT-2-small random init, byte-level stand-in tokenizer, `describe_observation_give_position`,
+B envs, max_steps 20, max_new_tokens 12."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import lmrl_gym_amd
+from lmrl_gym_amd import _lib, datasets as DS
+from lmrl_gym_amd.envs import maze as M
+from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine
+from lmrl_gym_amd.maze_rollout import MazeRolloutEngine
+dev = _lib.require_gpu()
+tok = DS.ByteTokenizer()
+eng = GPT2Engine.random_init(GPT2Config.gpt2_small(), seed=0, device=dev)
+for B, cache in ((256, True), (1024, True), (1024, False), (4096, True)):
+    env = M.setup_maze_env("double_t_maze", "describe_observation_give_position", "standard_reward", last_k=1, max_steps=20)
+    r = MazeRolloutEngine(eng, tok, env, B, max_new_tokens=12, eos_token_id=tok.eos_token_id, max_input_length=160, prefix_cache=cache)
+    r.run_episode(list(range(B)), sample_seed=1, use_graph=True, sync_every=0)           # capture + warm-up
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    reps = 3
+    for e in range(reps):
+        r.run_episode(list(range(100 + e * B, 100 + (e + 1) * B)), sample_seed=1, episode=e + 1, use_graph=True, sync_every=0)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+    steps = int(r.traj["n_turns"].sum().item())
+    print("B=%5d prefix_cache=%-5s prompt<=%d tok: %6d env steps in %.3f s -> %.0f env-steps/s (%.2f ms per lock-step turn)"
+          % (B, cache, r.max_obs_len, steps, dt, steps / dt, dt / r.T * 1e3), flush=True)
+    r.close()
