@@ -150,19 +150,22 @@ def main_train_step(args):
     d, V = cfg.d_model, cfg.vocab
     tok = B * T
     if args.mode == "ilql-step":
-        base, tbase = GPT2F32(sd, cfg.n_head, device=dev), GPT2F32(sd, cfg.n_head, device=dev)
+        mmode = args.train_matmul
+        base, tbase = GPT2F32(sd, cfg.n_head, device=dev, matmul=mmode), GPT2F32(sd, cfg.n_head, device=dev, matmul=mmode)
         g = torch.Generator().manual_seed(1)
         mk = lambda out, b2: MLPHeadF32({"dense1.kernel": torch.randn(d, d, generator=g) * 0.02, "dense1.bias": torch.zeros(d),
-                                         "dense2.kernel": torch.zeros(d, out), "dense2.bias": torch.full((out,), b2)}, dev)
+                                         "dense2.kernel": torch.zeros(d, out), "dense2.bias": torch.full((out,), b2)}, dev, matmul=mmode)
         tr = ilql.GPT2ILQLTrain(base, mk(V, -4.4), mk(V, -4.4), mk(1, -4.4), pad, dict(gamma=0.99, tau=0.7, cql_weight=0.01), target_base=tbase, lr=3e-5)
         rewards = np.where(sta & ~np.roll(sta, -1, axis=1), -1.0, 0.0).astype(np.float32)
         dones = (rng.rand(B) < 0.5).astype(np.float32)
         step = lambda: tr.step(ids, sta, rewards, dones)
-        head_flops = 2 * (d * d + d * V) * tok * (3 * 2 + 2)             # q1, q2 forward + backward (3x) and the two target-head forwards
+        # q1, q2 forward + backward (3x each); the two target heads: dense1 forward + ONE column of dense2 per token (Q_target(s, a) only)
+        head_flops = 2 * (d * d + d * V) * tok * (3 * 2) + 2 * (d * d + d) * tok * 2
         flops = (6 + 2) * n_params * tok + head_flops + 12 * 6 * 2 * T * d * tok
         workload = f"configs[2] / M3: ILQL train step, GPT-2-small fp32, B={B} x T={T} per GPU (train_ilql_gpt2.py:55-110), target base + 2 Q heads + V head"
     else:
-        pol = GPT2F32(sd, cfg.n_head, device=dev)
+        mmode = args.train_matmul
+        pol = GPT2F32(sd, cfg.n_head, device=dev, matmul=mmode)
         head = LinearHeadF32(dict(kernel=torch.randn(d, 1) * 0.01, bias=torch.tensor([-4.1])), dev)
         tr = ppo.GPT2PPOTrain(pol, head, pad, dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0), lr=1e-5)
         f = lambda s_: (rng.randn(B, T - 1) * s_).astype(np.float32)
@@ -189,16 +192,24 @@ def main_train_step(args):
     dt = float(tt.item())
     if rank == 0:
         ach = flops / (dt / args.steps) / 1e12
+        bf = args.train_matmul == "bf16"
+        prec = "bf16 matmul operands, fp32 accumulation / parameters / optimizer" if bf else "fp32"
+        roof = ({"bound": "mfma", "kernel": "gemm8_kernel / gemm_bf16_glds_kernel (Dense / Conv1D / head products: v_mfma_f32_16x16x32_bf16) + "
+                                            "sgemm_f32_kernel (attention products, fp32)", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                 "frac": round(ach / 2500.0, 4), "traffic": None,
+                 "note": "model flops of one step / wall time of the whole step, priced against the dense bf16 MFMA peak although the attention "
+                         "products and every elementwise / reduction kernel of the step stay fp32"} if bf else
+                {"bound": "mfma", "kernel": "sgemm_f32_kernel (every matmul of the step: v_mfma_f32_32x32x2_f32)", "achieved": round(ach, 1),
+                 "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
+                 "note": "model flops of one step / wall time of the whole step (lower bound for the GEMM kernel itself: 91 % of kernel time, "
+                         "profiles/r01_train_kernel_stats_final.csv)"})
         print(json.dumps({
-            "metric": f"{args.mode} sequences/sec (GPT-2-small fp32, B={B}, T={T})", "value": round(world * B * args.steps / dt, 2), "unit": "sequences/s",
-            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(dt * 1e3 / args.steps, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "per_gpu_batch": B, "seq_len": T, "parallelism": f"dp{world}, one overlapped gradient all-reduce per step",
-                       "last_loss": float(loss)},
-            "roofline": {"bound": "mfma", "kernel": "sgemm_f32_kernel (every matmul of the step: v_mfma_f32_32x32x2_f32)", "achieved": round(ach, 1),
-                         "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
-                         "note": "model flops of one step / wall time of the whole step (lower bound for the GEMM kernel itself: 91 % of kernel time, "
-                                 "profiles/r01_train_kernel_stats_final.csv)"}}), flush=True)
+            "metric": f"{args.mode} sequences/sec (GPT-2-small {'bf16-matmul' if bf else 'fp32'}, B={B}, T={T})", "value": round(world * B * args.steps / dt, 2),
+            "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(dt * 1e3 / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf else "f32", "data": "synthetic",
+            "config": {"workload": workload.replace("fp32", prec), "per_gpu_batch": B, "seq_len": T,
+                       "parallelism": f"dp{world}, one overlapped gradient all-reduce per step", "train_matmul": args.train_matmul, "last_loss": float(loss)},
+            "roofline": roof}), flush=True)
     if use_dist:
         torch.distributed.destroy_process_group()
 
@@ -209,6 +220,9 @@ def main():
     ap.add_argument("--mode", default="rollout", choices=["rollout", "ilql-step", "ppo-step"],
                     help="rollout (default): the headline env-steps/s line; ilql-step / ppo-step: the train step of configs[2] (M3 / M4 sizes)")
     ap.add_argument("--train-batch", type=int, default=32, help="sequences per GPU in the train-step modes")
+    ap.add_argument("--train-matmul", default="f32", choices=["f32", "bf16"],
+                    help="train-step modes: f32 = the reference's default arithmetic; bf16 = its optional bf16_activations mode (bf16 MFMA operands, "
+                         "fp32 accumulation / parameters / gradients / optimizer)")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="envs per GPU")

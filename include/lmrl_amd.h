@@ -415,6 +415,17 @@ int lmrl_axpby(float a, const float *x_d, float b, const float *y_d, float *out_
 /* optax.adamw(b1, b2, eps, weight_decay) with bias correction at `step` (1-based) */
 int lmrl_adamw(float *p_d, const float *g_d, float *m_d, float *v_d, size_t n, float lr, float b1, float b2, float eps, float weight_decay,
                int step, void *stream);
+/* ---- bf16-MFMA matmul mode of the train step (csrc/train_bf16.hip): the reference's optional `bf16_activations`
+ * (train_ilql_gpt2.py:193; model dtype bf16, fp32 parameters).  Operands are staged as K-major bf16 matrices for lmrl_gemm_bf16.
+ * lmrl_cast_bf16: dst [rows_dst][ld_dst] bf16 := round-to-nearest-even of src [rows][cols] fp32 (transpose = 0) or of its transpose
+ * (transpose = 1: dst[c][r] = src[r][c]); everything outside the source extent is zero-filled (K padding to multiples of 64). */
+int lmrl_cast_bf16(const float *src_d, long ld_src, int rows, int cols, void *dst_d, long ld_dst, int rows_dst, int transpose, void *stream);
+/* dst[j][i] = beta*dst[j][i] + src[i][j]   (src [n][k] -> dst [k][n]): gradients produced in transposed form */
+int lmrl_transpose_add_f32(const float *src_d, long ld_src, float *dst_d, long ld_dst, int n, int k, float beta, void *stream);
+/* out[r] = sum_j a[r][j]*w[j][idx[r]] + bias[idx[r]]: the one column of a Dense layer that `take_along_axis(logits, token)` reads —
+ * the ILQL target Q heads are only ever evaluated at the taken token (ilql/base_interface.py:57-66), exact fp32 */
+int lmrl_gather_dot_f32(const float *a_d, long lda, const float *w_d, long ldw, const float *bias_d, const int32_t *idx_d, float *out_d, int rows,
+                        int k, int n, void *stream);
 /* P = causal (+ key padding mask [batch][t] uint8) softmax of S [batch*heads][t][t]; in place allowed */
 int lmrl_softmax_causal_fwd(const float *s_d, const uint8_t *key_mask_d, float *p_d, int batch, int heads, int t, void *stream);
 int lmrl_softmax_bwd(const float *p_d, float *dp_d, long rows, int t, void *stream);

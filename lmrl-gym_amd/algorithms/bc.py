@@ -51,7 +51,7 @@ def masked_ce_forward_backward(m: GPT2F32, ids: np.ndarray, am: np.ndarray, pos:
     tgt = torch.zeros(R, dtype=torch.int32, device=dev)
     tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
     lp, lse = torch.empty(R, dtype=torch.float32, device=dev), torch.empty(R, dtype=torch.float32, device=dev)
-    ops.lse_gather(logits, m.vocab, m.vocab, tgt, R, logprob=lp, lse=lse)
+    ops.lse_gather(logits, m.ld_vocab, m.vocab, tgt, R, logprob=lp, lse=lse)
     if D.is_distributed():
         denom = float(D.allreduce_sum_(torch.tensor([denom], dtype=torch.float64, device=dev)).item())
     wfull = np.zeros((B, T), dtype=np.float32)
@@ -66,7 +66,7 @@ def masked_ce_forward_backward(m: GPT2F32, ids: np.ndarray, am: np.ndarray, pos:
     if grads is not None:
         if grad_scale != 1.0:
             ops.axpby(grad_scale, coef, 0.0, None, coef)
-        ops.ce_bwd(logits, m.vocab, m.vocab, lse, tgt, coef, None, R)
+        ops.ce_bwd(logits, m.ld_vocab, m.vocab, lse, tgt, coef, None, R)
         d_hidden = torch.empty(R, m.d, dtype=torch.float32, device=dev)
         m.lm_head_backward(hid, logits, R, d_hidden, grads, accumulate_dh=False)
         m.backward(cache, d_hidden, grads)

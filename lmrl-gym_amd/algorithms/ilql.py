@@ -204,19 +204,18 @@ class GPT2ILQLTrain:
         q1o, q1c = self.q1.forward(hid, R)
         q2o, q2c = self.q2.forward(hid, R)
         vo, vc = self.v.forward(hid, R)
-        tq1o, _ = self.q1_target.forward(thid, R)
-        tq2o, _ = self.q2_target.forward(thid, R)
         tgt = torch.zeros(R, dtype=torch.int32, device=dev)
         tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
+        # the target heads are only read at the taken token (take_along_axis, base_interface.py:57-66): one column per row, not [R, V]
+        tq1sa = self.q1_target.forward_at(thid, R, tgt)
+        tq2sa = self.q2_target.forward_at(thid, R, tgt)
         new = lambda: torch.empty(R, dtype=torch.float32, device=dev)
         sl = lambda x: x.view(B, T)[:, :-1].contiguous()
         q1sa, lse1, lp1 = new(), new(), new()
         q2sa, lse2, lp2 = new(), new(), new()
-        tq1sa, tq2sa = new(), new()
-        ops.lse_gather(q1o, V, V, tgt, R, logprob=lp1, lse=lse1, target_logit=q1sa)
-        ops.lse_gather(q2o, V, V, tgt, R, logprob=lp2, lse=lse2, target_logit=q2sa)
-        ops.lse_gather(tq1o, V, V, tgt, R, target_logit=tq1sa)
-        ops.lse_gather(tq2o, V, V, tgt, R, target_logit=tq2sa)
+        ld = self.q1.ld_out
+        ops.lse_gather(q1o, ld, V, tgt, R, logprob=lp1, lse=lse1, target_logit=q1sa)
+        ops.lse_gather(q2o, ld, V, tgt, R, logprob=lp2, lse=lse2, target_logit=q2sa)
         ce1, ce2 = new(), new()
         ops.axpby(-1.0, lp1, 0.0, None, ce1)
         ops.axpby(-1.0, lp2, 0.0, None, ce2)
@@ -249,8 +248,8 @@ class GPT2ILQLTrain:
         # ---- backward
         full = lambda g: (lambda z: (z.view(B, T)[:, :-1].copy_(g), z)[1])(torch.zeros(R, dtype=torch.float32, device=dev))
         coef_r, dq1_r, dq2_r, dv_r = full(coef), full(dq1), full(dq2), full(dv)
-        ops.ce_bwd(q1o, V, V, lse1, tgt, coef_r, dq1_r, R)       # q1o := d loss / d q1 logits
-        ops.ce_bwd(q2o, V, V, lse2, tgt, coef_r, dq2_r, R)
+        ops.ce_bwd(q1o, ld, V, lse1, tgt, coef_r, dq1_r, R)       # q1o := d loss / d q1 logits
+        ops.ce_bwd(q2o, ld, V, lse2, tgt, coef_r, dq2_r, R)
         bgrads, g1, g2, gv = base.zero_grads(), self.q1.zero_grads(), self.q2.zero_grads(), self.v.zero_grads()
         d_hidden = torch.empty(R, base.d, dtype=torch.float32, device=dev)
         self.q1.backward(q1c, q1o, g1, dx=d_hidden, accumulate_dx=False)
@@ -299,9 +298,9 @@ class GPT2ILQLInference:
         B, T = ids.shape
         R = B * T
         hid, _ = self.base.forward(_t(ids, np.int32), _t(am, np.uint8), _t(pos, np.int32))
-        logits = self.base.lm_logits(hid, R).view(B, T, -1).cpu().numpy()
-        q1 = self.q1.forward(hid, R)[0].view(B, T, -1).cpu().numpy()
-        q2 = self.q2.forward(hid, R)[0].view(B, T, -1).cpu().numpy() if self.q2 is not None else None
+        logits = self.base.lm_logits(hid, R).view(B, T, -1)[:, :, :self.base.vocab].cpu().numpy()
+        q1 = self.q1.forward(hid, R)[0].view(B, T, -1)[:, :, :self.q1.dout].cpu().numpy()
+        q2 = self.q2.forward(hid, R)[0].view(B, T, -1)[:, :, :self.q2.dout].cpu().numpy() if self.q2 is not None else None
         v = self.v.forward(hid, R)[0].view(B, T).cpu().numpy() if self.v is not None else None
         return ValueRLForwardOutput(logits, q1, q2, v)
 

@@ -138,7 +138,8 @@ class GPT2MCTrain:
         tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
         new = lambda: torch.empty(R, dtype=torch.float32, device=dev)
         qsa, lse, lp, ce = new(), new(), new(), new()
-        ops.lse_gather(qo, V, V, tgt, R, logprob=lp, lse=lse, target_logit=qsa)
+        ld = self.q_head.ld_out
+        ops.lse_gather(qo, ld, V, tgt, R, logprob=lp, lse=lse, target_logit=qsa)
         ops.axpby(-1.0, lp, 0.0, None, ce)
         sl = lambda x: x.view(B, T)[:, :-1].contiguous()
         f32 = lambda x: _t(x, np.float32)
@@ -146,7 +147,7 @@ class GPT2MCTrain:
         if not train:
             return self, loss, logs
         full = lambda g: (lambda z: (z.view(B, T)[:, :-1].copy_(g), z)[1])(torch.zeros(R, dtype=torch.float32, device=dev))
-        ops.ce_bwd(qo, V, V, lse, tgt, full(coef), full(dq), R)          # qo := d loss / d q logits
+        ops.ce_bwd(qo, ld, V, lse, tgt, full(coef), full(dq), R)          # qo := d loss / d q logits
         bgrads, qgrads = base.zero_grads(), self.q_head.zero_grads()
         d_hidden = torch.empty(R, base.d, dtype=torch.float32, device=dev)
         self.q_head.backward(qc, qo, qgrads, dx=d_hidden, accumulate_dx=False)

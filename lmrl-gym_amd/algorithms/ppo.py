@@ -261,7 +261,7 @@ class GPT2PPOTrain:
         tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
         logprob_all = torch.empty(R, dtype=torch.float32, device=dev)
         lse = torch.empty(R, dtype=torch.float32, device=dev)
-        ops.lse_gather(logits, pol.vocab, pol.vocab, tgt, R, logprob=logprob_all, lse=lse)
+        ops.lse_gather(logits, pol.ld_vocab, pol.vocab, tgt, R, logprob=logprob_all, lse=lse)
         sl = lambda x: x.view(B, T)[:, :-1].contiguous()
         f32 = lambda x: _t(x, np.float32)
         attn_s = f32(am[:, 1:])
@@ -279,7 +279,7 @@ class GPT2PPOTrain:
         neg = torch.empty_like(dlp)
         ops.axpby(-1.0, dlp, 0.0, None, neg)
         coef.view(B, T)[:, :-1] = neg
-        ops.ce_bwd(logits, pol.vocab, pol.vocab, lse, tgt, coef, None, R)        # logits := dlogits
+        ops.ce_bwd(logits, pol.ld_vocab, pol.vocab, lse, tgt, coef, None, R)        # logits := dlogits
         pgrads, hgrads = pol.zero_grads(), head.zero_grads()
         d_hidden = torch.empty(R, pol.d, dtype=torch.float32, device=dev)
         pol.lm_head_backward(hid, logits, R, d_hidden, pgrads, accumulate_dh=False)

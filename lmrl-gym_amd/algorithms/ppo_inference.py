@@ -126,7 +126,7 @@ class GPT2PPOInference:
         tgt = torch.zeros(B * T, dtype=torch.int32, device=model.dev)
         tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
         lp = torch.empty(B * T, dtype=torch.float32, device=model.dev)
-        ops.lse_gather(logits, model.vocab, model.vocab, tgt, B * T, logprob=lp)   # token_logprobs_from_logits, :396-403
+        ops.lse_gather(logits, model.ld_vocab, model.vocab, tgt, B * T, logprob=lp)   # token_logprobs_from_logits, :396-403
         return hid, lp.view(B, T)[:, :-1].cpu().numpy()
 
     def forward(self, input_ids, attention_mask=None, position_ids=None) -> PPOForwardOutput:

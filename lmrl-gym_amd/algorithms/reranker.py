@@ -59,7 +59,7 @@ def build_logprob_score_fn(model, tokenizer, max_length: int, bsize: int):
             tgt = torch.zeros(B * T, dtype=torch.int32, device=model.dev)
             tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
             lp = torch.empty(B * T, dtype=torch.float32, device=model.dev)
-            ops.lse_gather(logits, model.vocab, model.vocab, tgt, B * T, logprob=lp)
+            ops.lse_gather(logits, model.ld_vocab, model.vocab, tgt, B * T, logprob=lp)
             lpn = lp.view(B, T)[:, :-1].cpu().numpy() * am[:, 1:]
             for x in range(B):
                 out.append(float(lpn[x][(prefix_len[i + x] - 1):].sum()))
@@ -101,7 +101,7 @@ def build_ilql_score_fn(base, q1_head, q2_head, v_head, tokenizer, max_length: i
             for head in (q1_head, q2_head):
                 qo, _ = head.forward(hid, R)
                 qsa = torch.empty(R, dtype=torch.float32, device=base.dev)
-                ops.lse_gather(qo, head.dout, head.dout, tgt, R, target_logit=qsa)
+                ops.lse_gather(qo, head.ld_out, head.dout, tgt, R, target_logit=qsa)
                 qs.append(qsa.view(B, T)[:, :-1].cpu().numpy())
             vo, _ = v_head.forward(hid, R)
             v = vo.view(B, T)[:, :-1].cpu().numpy()
@@ -109,7 +109,7 @@ def build_ilql_score_fn(base, q1_head, q2_head, v_head, tokenizer, max_length: i
             if pi_beta is not None and logit_weight is not None:
                 phid, _ = pi_beta.forward(ids_d, _t(am, np.uint8), _t(pos, np.int32))
                 lp = torch.empty(R, dtype=torch.float32, device=base.dev)
-                ops.lse_gather(pi_beta.lm_logits(phid, R), pi_beta.vocab, pi_beta.vocab, tgt, R, logprob=lp)
+                ops.lse_gather(pi_beta.lm_logits(phid, R), pi_beta.ld_vocab, pi_beta.vocab, tgt, R, logprob=lp)
                 adv = adv + logit_weight * lp.view(B, T)[:, :-1].cpu().numpy()
             adv = adv * am[:, 1:]
             for x in range(B):

@@ -84,12 +84,20 @@ __device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int 
             FA[j_] = *reinterpret_cast<const bf16x8 *>(sA_ + row_ * 128 + ((c_ ^ (row_ & 7)) << 4));                  \
         }                                                                                                             \
     } while (0)
+#if defined(LMRL_G8_ABLATE) && (LMRL_G8_ABLATE & 1)   /* tools/gemm8_bench.hip only: K loop without the MFMAs (fragments kept alive) */
+#define LMRL_G8_MFMA(FW, FA)                                                                                          \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < FN; i_++) asm volatile("" ::"v"(FW[i_]));                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < FM; j_++) asm volatile("" ::"v"(FA[j_]));                             \
+    } while (0)
+#else
 #define LMRL_G8_MFMA(FW, FA)                                                                                          \
     do {                                                                                                              \
         _Pragma("unroll") for (int i_ = 0; i_ < FN; i_++)                                                             \
             _Pragma("unroll") for (int j_ = 0; j_ < FM; j_++)                                                         \
                 acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FW[i_], FA[j_], acc[i_][j_], 0, 0, 0);          \
     } while (0)
+#endif
 
     // ---- prologue
     __builtin_amdgcn_s_barrier();   // every wave is done reading the ring from a previous call
@@ -127,7 +135,10 @@ __device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int 
             else wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+#if defined(LMRL_G8_ABLATE) && (LMRL_G8_ABLATE & 2)   /* K loop without the in-loop fetches */
+#else
             if (t + STAGES < nk) LMRL_G8_ISSUE(t + STAGES, slot);
+#endif
             LMRL_G8_READ(fw0, fa0, nslot, 0);
         }
         LMRL_G8_MFMA(fw1, fa1);

@@ -1,0 +1,148 @@
+// train_bf16.hip — operand staging for the train step's bf16-MFMA matmul mode (the reference's optional `bf16_activations`,
+// train_ilql_gpt2.py:193 / train_ppo_gpt2.py: model dtype bf16 with fp32 parameters): every Dense / Conv1D product of the forward AND
+// backward pass runs on `v_mfma_f32_16x16x32_bf16` (the rollout engine's GEMM kernels, C = A . W^T with both operands K-major), with
+// fp32 accumulation, fp32 outputs, fp32 master weights / gradients / optimizer state.  The three products of a linear layer
+//     y  = x . w          A = bf16(x)   [R][k]     W = bf16(w)^T  [n][k]
+//     dx = dy . w^T       A = bf16(dy)  [R][n]     W = bf16(w)    [k][n]
+//     dw = x^T . dy       A = bf16(x)^T [k][R]     W = bf16(dy)^T [n][R]
+// need each operand as a K-major bf16 matrix whose K extent is a multiple of 64: the kernels here cast (round-to-nearest-even, the MFMA
+// input rounding of the rollout engine) and, where needed, transpose, zero-filling the padding.  All are HBM streaming kernels.
+// Also: the gathered column product used for the ILQL target Q heads (only Q_target(s, a) of the taken token is ever read,
+// ilql/base_interface.py: take_along_axis of the target logits), and a transposing accumulate for gradients produced in [n][k] form.
+#include "../../include/lmrl_amd.h"
+#include "gemm_bf16.h"
+
+namespace lmrl {
+
+// dst[r][c] = bf16(src[r][c]) for r < rows, c < cols; zero elsewhere in [rows_dst][ld_dst].  8 columns (16 B out) per lane.
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict__ src, long ld_src, int rows, int cols, uint16_t *__restrict__ dst,
+                                                        long ld_dst, int rows_dst) {
+    const long chunks_per_row = ld_dst / 8;
+    const long total = (long)rows_dst * chunks_per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / chunks_per_row;
+        const int c0 = (int)(i - r * chunks_per_row) * 8;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = 0.f;
+        if (r < rows) {
+            const float *p = src + r * ld_src + c0;
+            if (c0 + 8 <= cols && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (c0 + k < cols) v[k] = p[k];
+            }
+        }
+        uint4 o;
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<uint4 *>(dst + r * ld_dst + c0) = o;
+    }
+}
+
+// dst[c][r] = bf16(src[r][c]) for r < rows, c < cols; zero elsewhere in [rows_dst][ld_dst].  64 x 64 tiles through LDS: coalesced 256-B
+// reads along c, 128-B writes along r.
+__global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float *__restrict__ src, long ld_src, int rows, int cols, uint16_t *__restrict__ dst,
+                                                          long ld_dst, int rows_dst) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int r = r0 + ty + k * 4, c = c0 + tx;
+        tile[ty + k * 4][tx] = (r < rows && c < cols) ? src[(long)r * ld_src + c] : 0.f;
+    }
+    __syncthreads();
+    // out row = c0 + cc, 64 r-values = 128 B: 8 lanes x 16 B per row, 32 rows per pass
+    const int rr8 = (threadIdx.x & 7) * 8, cc = threadIdx.x >> 3;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int c = c0 + cc + k * 32;
+        if (c < rows_dst && r0 + rr8 < ld_dst) {
+            uint4 o;
+            const int q = cc + k * 32;
+            o.x = pack_bf16x2(tile[rr8 + 0][q], tile[rr8 + 1][q]); o.y = pack_bf16x2(tile[rr8 + 2][q], tile[rr8 + 3][q]);
+            o.z = pack_bf16x2(tile[rr8 + 4][q], tile[rr8 + 5][q]); o.w = pack_bf16x2(tile[rr8 + 6][q], tile[rr8 + 7][q]);
+            *reinterpret_cast<uint4 *>(dst + (long)c * ld_dst + r0 + rr8) = o;
+        }
+    }
+}
+
+// dst[j][i] = beta * dst[j][i] + src[i][j]   (src [n][k], dst [k][n]): 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_add_kernel(const float *__restrict__ src, long ld_src, float *__restrict__ dst, long ld_dst, int n,
+                                                            int k, float beta) {
+    __shared__ float tile[32][33];
+    const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = i0 + ty + q * 8, j = j0 + tx;
+        tile[ty + q * 8][tx] = (i < n && j < k) ? src[(long)i * ld_src + j] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int j = j0 + ty + q * 8, i = i0 + tx;
+        if (i < n && j < k) {
+            float *p = dst + (long)j * ld_dst + i;
+            *p = (beta != 0.f ? beta * *p : 0.f) + tile[tx][ty + q * 8];
+        }
+    }
+}
+
+// out[r] = sum_j a[r][j] * w[j][idx[r]] + bias[idx[r]]: one wave per row
+__global__ __launch_bounds__(256) void gather_dot_kernel(const float *__restrict__ a, long lda, const float *__restrict__ w, long ldw,
+                                                         const float *__restrict__ bias, const int32_t *__restrict__ idx, float *__restrict__ out,
+                                                         int rows, int k, int n) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    int c = idx[r];
+    c = c < 0 ? 0 : (c >= n ? n - 1 : c);
+    float s = 0.f;
+    for (int j = lane; j < k; j += 64) s = fmaf(a[(long)r * lda + j], w[(long)j * ldw + c], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[r] = s + (bias ? bias[c] : 0.f);
+}
+
+}  // namespace lmrl
+
+using namespace lmrl;
+
+extern "C" {
+
+int lmrl_cast_bf16(const float *src_d, long ld_src, int rows, int cols, void *dst_d, long ld_dst, int rows_dst, int transpose, void *stream) {
+    LMRL_REQUIRE(src_d && dst_d && rows > 0 && cols > 0 && rows_dst > 0 && ld_dst > 0 && ld_dst % 8 == 0, "lmrl_cast_bf16: bad argument");
+    hipStream_t s = as_stream(stream);
+    if (!transpose) {
+        LMRL_REQUIRE(rows_dst >= rows && ld_dst >= cols, "lmrl_cast_bf16: destination smaller than the source");
+        const long total = (long)rows_dst * (ld_dst / 8);
+        const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+        hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, src_d, ld_src, rows, cols, (uint16_t *)dst_d, ld_dst, rows_dst);
+    } else {
+        LMRL_REQUIRE(rows_dst >= cols && ld_dst >= rows, "lmrl_cast_bf16: destination smaller than the transposed source");
+        hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((int)((ld_dst + 63) / 64), (rows_dst + 63) / 64), dim3(256), 0, s, src_d, ld_src, rows, cols,
+                           (uint16_t *)dst_d, ld_dst, rows_dst);
+    }
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_transpose_add_f32(const float *src_d, long ld_src, float *dst_d, long ld_dst, int n, int k, float beta, void *stream) {
+    LMRL_REQUIRE(src_d && dst_d && n > 0 && k > 0, "lmrl_transpose_add_f32: bad argument");
+    hipLaunchKernelGGL(transpose_add_kernel, dim3((n + 31) / 32, (k + 31) / 32), dim3(256), 0, as_stream(stream), src_d, ld_src, dst_d, ld_dst, n, k,
+                       beta);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_gather_dot_f32(const float *a_d, long lda, const float *w_d, long ldw, const float *bias_d, const int32_t *idx_d, float *out_d, int rows,
+                        int k, int n, void *stream) {
+    LMRL_REQUIRE(a_d && w_d && idx_d && out_d && rows > 0 && k > 0 && n > 0, "lmrl_gather_dot_f32: bad argument");
+    hipLaunchKernelGGL(gather_dot_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), a_d, lda, w_d, ldw, bias_d, idx_d, out_d, rows, k, n);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+}  // extern "C"

@@ -67,8 +67,13 @@ class Workspace:
 
 
 class GPT2F32:
-    def __init__(self, params: Dict[str, "torch.Tensor"], n_head: int, ln_eps: float = 1e-5, device=None):
+    """GPT-2 forward / backward for the train step on fp32 parameters.  `matmul="bf16"` runs every Dense / Conv1D product (and the tied LM
+    head) on the bf16 MFMA with fp32 accumulation — the reference's optional `bf16_activations` mode (train_ilql_gpt2.py:193) — see
+    `ops.MatmulBF16`; the default "f32" is the reference's default arithmetic."""
+
+    def __init__(self, params: Dict[str, "torch.Tensor"], n_head: int, ln_eps: float = 1e-5, device=None, matmul: str = "f32"):
         import torch
+        assert matmul in ("f32", "bf16")
         self.t = torch
         self.dev = device or next(iter(params.values())).device
         self.p = {k: v.to(self.dev, torch.float32).contiguous() for k, v in params.items()}
@@ -80,11 +85,15 @@ class GPT2F32:
         self.n_layer = 1 + max(int(k.split(".")[1]) for k in self.p if k.startswith("h."))
         self.ws = Workspace(self.dev)
         self._colsum_ws = torch.empty(64 * max(self.d_ff, 3 * self.d, self.vocab), dtype=torch.float32, device=self.dev)
+        self.mm = ops.MatmulBF16(self.dev) if matmul == "bf16" else None
+        self.ld_vocab = ops._pad(self.vocab) if self.mm is not None else self.vocab     # row stride of [rows, V] logits
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids, attention_mask, position_ids, tag: str = "fwd"):
         """input_ids / position_ids int32 [B,T], attention_mask uint8 [B,T] -> (final hidden [B*T, d], cache)."""
         t = self.t
+        if self.mm is not None:
+            self.mm.begin_step()          # the optimizer may have moved the fp32 masters since the last forward: re-stage the bf16 copies
         B, T = input_ids.shape
         R, d, H, p = B * T, self.d, self.n_head, self.p
         hd = d // H
@@ -101,7 +110,7 @@ class GPT2F32:
             h1, c["m1"], c["r1"] = new(R, d), new(R), new(R)
             ops.layernorm_fwd(x, p[q + "ln_1.weight"], p[q + "ln_1.bias"], h1, c["m1"], c["r1"], R, d, self.eps)
             qkv = new(R, 3 * d)
-            ops.linear_fwd(h1, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], qkv, R, d, 3 * d)
+            ops.linear_fwd(h1, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], qkv, R, d, 3 * d, mm=self.mm)
             P = new(B * H, T, T)
             # S = scale * Q K^T per (b, h); Q/K/V are column slices of qkv (row stride 3d)
             ops.sgemm(qkv, qkv, P, T, T, hd, trans_b=True, alpha=1.0 / math.sqrt(hd), lda=3 * d, ldb=3 * d, ldc=T, b_off=d,
@@ -111,16 +120,16 @@ class GPT2F32:
             ops.sgemm(P, qkv, att, T, hd, T, lda=T, ldb=3 * d, ldc=d, b_off=2 * d, batch=(B, H), sa=(H * T * T, T * T),
                       sb=(T * 3 * d, hd), sc=(T * d, hd))
             x_mid = new(R, d)
-            ops.linear_fwd(att, p[q + "attn.c_proj.weight"], p[q + "attn.c_proj.bias"], x_mid, R, d, d)
+            ops.linear_fwd(att, p[q + "attn.c_proj.weight"], p[q + "attn.c_proj.bias"], x_mid, R, d, d, mm=self.mm)
             ops.axpby(1.0, x_mid, 1.0, x, x_mid)
             h2, c["m2"], c["r2"] = new(R, d), new(R), new(R)
             ops.layernorm_fwd(x_mid, p[q + "ln_2.weight"], p[q + "ln_2.bias"], h2, c["m2"], c["r2"], R, d, self.eps)
             f = new(R, self.d_ff)
-            ops.linear_fwd(h2, p[q + "mlp.c_fc.weight"], p[q + "mlp.c_fc.bias"], f, R, d, self.d_ff)
+            ops.linear_fwd(h2, p[q + "mlp.c_fc.weight"], p[q + "mlp.c_fc.bias"], f, R, d, self.d_ff, mm=self.mm)
             g = new(R, self.d_ff)
             ops.gelu_fwd(f, g)
             x_out = new(R, d)
-            ops.linear_fwd(g, p[q + "mlp.c_proj.weight"], p[q + "mlp.c_proj.bias"], x_out, R, self.d_ff, d)
+            ops.linear_fwd(g, p[q + "mlp.c_proj.weight"], p[q + "mlp.c_proj.bias"], x_out, R, self.d_ff, d, mm=self.mm)
             ops.axpby(1.0, x_out, 1.0, x_mid, x_out)
             c.update(h1=h1, qkv=qkv, P=P, att=att, x_mid=x_mid, h2=h2, f=f, g=g)
             cache["layers"].append(c)
@@ -132,9 +141,16 @@ class GPT2F32:
         return hid, cache
 
     def lm_logits(self, hidden, rows: int):
-        """logits [rows, V] = hidden @ wte^T (tied head), fp32 — PPOInference.token_logprobs_from_logits casts to f32 too."""
-        logits = self.t.empty(rows, self.vocab, dtype=self.t.float32, device=self.dev)
-        ops.sgemm(hidden, self.p["wte.weight"], logits, rows, self.vocab, self.d, trans_b=True, lda=self.d, ldb=self.d, ldc=self.vocab)
+        """logits [rows, ld_vocab] (columns [0, V) valid) = hidden @ wte^T (tied head), fp32 — PPOInference.token_logprobs_from_logits casts
+        to f32 too.  ld_vocab = V in fp32 mode, V padded to a multiple of 64 in bf16-matmul mode."""
+        V, d, ld, mm = self.vocab, self.d, self.ld_vocab, self.mm
+        logits = self.t.empty(rows, ld, dtype=self.t.float32, device=self.dev)
+        if mm is None:
+            ops.sgemm(hidden, self.p["wte.weight"], logits, rows, V, d, trans_b=True, lda=d, ldb=d, ldc=ld)
+        else:
+            hb = mm.cast("x", hidden, rows, d, d)
+            wb = mm.cast(("w", self.p["wte.weight"].data_ptr()), self.p["wte.weight"], V, d, d, keep=True)           # [pad(V)][d]
+            mm.gemm(hb, wb, None, logits, rows, ops._pad(V), ops._pad(d), ops._pad(d), ld, V)
         return logits
 
     # ------------------------------------------------------------------ backward
@@ -156,10 +172,18 @@ class GPT2F32:
         return self._arena.zero_()
 
     def lm_head_backward(self, hidden, dlogits, rows: int, d_hidden, grads, accumulate_dh: bool):
-        """d_hidden (+)= dlogits @ wte ; grads[wte] += dlogits^T @ hidden"""
-        ops.sgemm(dlogits, self.p["wte.weight"], d_hidden, rows, self.d, self.vocab, lda=self.vocab, ldb=self.d, ldc=self.d,
-                  beta=1.0 if accumulate_dh else 0.0)
-        ops.sgemm(dlogits, hidden, grads["wte.weight"], self.vocab, self.d, rows, trans_a=True, lda=self.vocab, ldb=self.d, ldc=self.d, beta=1.0)
+        """d_hidden (+)= dlogits @ wte ; grads[wte] += dlogits^T @ hidden   (dlogits [rows, ld_vocab])"""
+        V, d, ld, mm = self.vocab, self.d, self.ld_vocab, self.mm
+        if mm is None:
+            ops.sgemm(dlogits, self.p["wte.weight"], d_hidden, rows, d, V, lda=ld, ldb=d, ldc=d, beta=1.0 if accumulate_dh else 0.0)
+            ops.sgemm(dlogits, hidden, grads["wte.weight"], V, d, rows, trans_a=True, lda=ld, ldb=d, ldc=d, beta=1.0)
+            return
+        dlb = mm.cast("dy", dlogits, rows, V, ld)                                                                      # [rows][pad(V)]
+        wt = mm.cast(("wT", self.p["wte.weight"].data_ptr()), self.p["wte.weight"], V, d, d, transpose=True, keep=True)  # [d][pad(V)]
+        mm.gemm(dlb, wt, None, d_hidden, rows, ops._pad(d), ops._pad(V), ops._pad(V), d, d, accumulate=accumulate_dh)
+        dlt = mm.cast("dyT", dlogits, rows, V, ld, transpose=True)                                                     # [pad(V)][pad(rows)]
+        ht = mm.cast("xT", hidden, rows, d, d, transpose=True)                                                         # [d][pad(rows)]
+        mm.gemm(dlt, ht, None, grads["wte.weight"], V, ops._pad(d), ops._pad(rows), ops._pad(rows), d, d, accumulate=True)
 
     def backward(self, cache, d_hidden, grads: Dict[str, "torch.Tensor"], on_final=None):
         """d_hidden: gradient w.r.t. the final (post ln_f) hidden states [B*T, d]; accumulates into `grads`.
@@ -183,17 +207,17 @@ class GPT2F32:
             c = cache["layers"][l]
             # MLP: x_out = x_mid + gelu(h2 W_fc + b) W_proj + b
             dg = new(R, self.d_ff)
-            ops.linear_bwd(c["g"], p[q + "mlp.c_proj.weight"], dx, dg, grads[q + "mlp.c_proj.weight"], grads[q + "mlp.c_proj.bias"], R, self.d_ff, d, ws)
+            ops.linear_bwd(c["g"], p[q + "mlp.c_proj.weight"], dx, dg, grads[q + "mlp.c_proj.weight"], grads[q + "mlp.c_proj.bias"], R, self.d_ff, d, ws, mm=self.mm)
             df = dg
             ops.gelu_bwd(dg, c["f"], df)
             dh2 = new(R, d)
-            ops.linear_bwd(c["h2"], p[q + "mlp.c_fc.weight"], df, dh2, grads[q + "mlp.c_fc.weight"], grads[q + "mlp.c_fc.bias"], R, d, self.d_ff, ws)
+            ops.linear_bwd(c["h2"], p[q + "mlp.c_fc.weight"], df, dh2, grads[q + "mlp.c_fc.weight"], grads[q + "mlp.c_fc.bias"], R, d, self.d_ff, ws, mm=self.mm)
             ops.layernorm_bwd(dh2, c["x_mid"], p[q + "ln_2.weight"], c["m2"], c["r2"], dx, tmp, R, d, True)   # dx := dx_mid
             ops.colsum(tmp, R, d, d, grads[q + "ln_2.weight"], True, ws)
             ops.colsum(dh2, R, d, d, grads[q + "ln_2.bias"], True, ws)
             # attention projection
             datt = new(R, d)
-            ops.linear_bwd(c["att"], p[q + "attn.c_proj.weight"], dx, datt, grads[q + "attn.c_proj.weight"], grads[q + "attn.c_proj.bias"], R, d, d, ws)
+            ops.linear_bwd(c["att"], p[q + "attn.c_proj.weight"], dx, datt, grads[q + "attn.c_proj.weight"], grads[q + "attn.c_proj.bias"], R, d, d, ws, mm=self.mm)
             qkv, P = c["qkv"], c["P"]
             dqkv = new(R, 3 * d)
             # dV = P^T dA
@@ -210,7 +234,7 @@ class GPT2F32:
             ops.sgemm(dP, qkv, dqkv, T, hd, T, trans_a=True, alpha=scale, lda=T, ldb=3 * d, ldc=3 * d, c_off=d, batch=(B, H),
                       sa=(H * T * T, T * T), sb=(T * 3 * d, hd), sc=(T * 3 * d, hd))
             dh1 = new(R, d)
-            ops.linear_bwd(c["h1"], p[q + "attn.c_attn.weight"], dqkv, dh1, grads[q + "attn.c_attn.weight"], grads[q + "attn.c_attn.bias"], R, d, 3 * d, ws)
+            ops.linear_bwd(c["h1"], p[q + "attn.c_attn.weight"], dqkv, dh1, grads[q + "attn.c_attn.weight"], grads[q + "attn.c_attn.bias"], R, d, 3 * d, ws, mm=self.mm)
             ops.layernorm_bwd(dh1, c["x_in"], p[q + "ln_1.weight"], c["m1"], c["r1"], dx, tmp, R, d, True)    # dx := dx_in
             ops.colsum(tmp, R, d, d, grads[q + "ln_1.weight"], True, ws)
             ops.colsum(dh1, R, d, d, grads[q + "ln_1.bias"], True, ws)
@@ -225,23 +249,29 @@ class GPT2F32:
 
 # ---------------------------------------------------------------------- value heads (LLM_RL/heads/{linear_head,mlp_head}.py)
 class LinearHeadF32:
-    """`LinearHead`: x @ kernel + bias (heads/linear_head.py:112-119)."""
+    """`LinearHead`: x @ kernel + bias (heads/linear_head.py:112-119).  matmul="bf16": see GPT2F32 (outputs narrower than 64 columns,
+    e.g. the scalar value head, stay on the fp32 kernel: nothing to gain on the matrix core)."""
 
-    def __init__(self, params, device):
+    def __init__(self, params, device, matmul: str = "f32"):
         import torch
         self.t, self.dev = torch, device
         self.p = {k: v.to(device, torch.float32).contiguous() for k, v in params.items()}   # kernel [in,out], bias [out]
         self.din, self.dout = self.p["kernel"].shape
         self._ws = torch.empty(64 * max(self.dout, 1), dtype=torch.float32, device=device)
+        self.mm = ops.MatmulBF16(device) if matmul == "bf16" and self.dout >= 64 else None
+        self.ld_out = ops._pad(self.dout) if self.mm is not None else self.dout
 
     def forward(self, x, rows):
-        y = self.t.empty(rows, self.dout, dtype=self.t.float32, device=self.dev)
-        ops.linear_fwd(x, self.p["kernel"], self.p["bias"], y, rows, self.din, self.dout)
+        """-> (y [rows, ld_out] with columns [0, dout) valid, cache)"""
+        y = self.t.empty(rows, self.ld_out, dtype=self.t.float32, device=self.dev)
+        if self.mm is not None:
+            self.mm.begin_step()
+        ops.linear_fwd(x, self.p["kernel"], self.p["bias"], y, rows, self.din, self.dout, mm=self.mm, ldy=self.ld_out)
         return y, dict(x=x, rows=rows)
 
     def backward(self, cache, dy, grads, dx=None, accumulate_dx=False):
         ops.linear_bwd(cache["x"], self.p["kernel"], dy, dx, grads["kernel"], grads["bias"], cache["rows"], self.din, self.dout, self._ws,
-                       dx_beta=1.0 if accumulate_dx else 0.0)
+                       dx_beta=1.0 if accumulate_dx else 0.0, mm=self.mm, lddy=self.ld_out)
 
     def zero_grads(self):
         if getattr(self, "_arena", None) is None:
@@ -252,31 +282,52 @@ class LinearHeadF32:
 class MLPHeadF32:
     """`MLPHead`: relu(x @ W1 + b1) @ W2 + b2 (heads/mlp_head.py:139-148). params: dense1.kernel/bias, dense2.kernel/bias."""
 
-    def __init__(self, params, device):
+    def __init__(self, params, device, matmul: str = "f32"):
         import torch
         self.t, self.dev = torch, device
         self.p = {k: v.to(device, torch.float32).contiguous() for k, v in params.items()}
         self.din, self.dh = self.p["dense1.kernel"].shape
         self.dout = self.p["dense2.kernel"].shape[1]
         self._ws = torch.empty(64 * max(self.dout, self.dh), dtype=torch.float32, device=device)
+        self.mm = ops.MatmulBF16(device) if matmul == "bf16" else None
+        self.mm2 = self.mm if self.dout >= 64 else None           # a scalar output (V head) stays on the fp32 kernel
+        self.ld_out = ops._pad(self.dout) if self.mm2 is not None else self.dout
 
-    def forward(self, x, rows):
+    def hidden(self, x, rows):
+        """relu(x @ W1 + b1) -> (a, z)"""
         t = self.t
+        if self.mm is not None:
+            self.mm.begin_step()          # a forward starts here: re-stage the bf16 weight copies (see GPT2F32.forward)
         z = t.empty(rows, self.dh, dtype=t.float32, device=self.dev)
-        ops.linear_fwd(x, self.p["dense1.kernel"], self.p["dense1.bias"], z, rows, self.din, self.dh)
+        ops.linear_fwd(x, self.p["dense1.kernel"], self.p["dense1.bias"], z, rows, self.din, self.dh, mm=self.mm)
         a = t.empty_like(z)
         ops.relu_fwd(z, a)
-        y = t.empty(rows, self.dout, dtype=t.float32, device=self.dev)
-        ops.linear_fwd(a, self.p["dense2.kernel"], self.p["dense2.bias"], y, rows, self.dh, self.dout)
+        return a, z
+
+    def forward(self, x, rows):
+        """-> (y [rows, ld_out] with columns [0, dout) valid, cache)"""
+        t = self.t
+        a, z = self.hidden(x, rows)
+        y = t.empty(rows, self.ld_out, dtype=t.float32, device=self.dev)
+        ops.linear_fwd(a, self.p["dense2.kernel"], self.p["dense2.bias"], y, rows, self.dh, self.dout, mm=self.mm2, ldy=self.ld_out)
         return y, dict(x=x, z=z, a=a, rows=rows)
+
+    def forward_at(self, x, rows, idx):
+        """y[r, idx[r]] for every row without forming y: `take_along_axis(head(x), idx)` — how the ILQL loss reads the TARGET Q heads
+        (ilql/base_interface.py:57-66).  dense2 shrinks from a [rows, dh] x [dh, V] product to one dh-long dot product per row (fp32)."""
+        a, _ = self.hidden(x, rows)
+        out = self.t.empty(rows, dtype=self.t.float32, device=self.dev)
+        ops.gather_dot(a, self.p["dense2.kernel"], self.p["dense2.bias"], idx, out, rows, self.dh, self.dout)
+        return out
 
     def backward(self, cache, dy, grads, dx=None, accumulate_dx=False):
         t, rows = self.t, cache["rows"]
         da = t.empty(rows, self.dh, dtype=t.float32, device=self.dev)
-        ops.linear_bwd(cache["a"], self.p["dense2.kernel"], dy, da, grads["dense2.kernel"], grads["dense2.bias"], rows, self.dh, self.dout, self._ws)
+        ops.linear_bwd(cache["a"], self.p["dense2.kernel"], dy, da, grads["dense2.kernel"], grads["dense2.bias"], rows, self.dh, self.dout, self._ws,
+                       mm=self.mm2, lddy=self.ld_out)
         ops.relu_bwd(da, cache["z"], da)
         ops.linear_bwd(cache["x"], self.p["dense1.kernel"], da, dx, grads["dense1.kernel"], grads["dense1.bias"], rows, self.din, self.dh, self._ws,
-                       dx_beta=1.0 if accumulate_dx else 0.0)
+                       dx_beta=1.0 if accumulate_dx else 0.0, mm=self.mm)
 
     def zero_grads(self):
         if getattr(self, "_arena", None) is None:

@@ -26,18 +26,101 @@ def sgemm(a, b, c, m, n, k, *, trans_a=False, trans_b=False, alpha=1.0, beta=0.0
                                batch[0], batch[1], _lib.ptr(bias), _sp()), "lmrl_sgemm")
 
 
-def linear_fwd(x, w, b, y, rows, k, n):
-    """y[rows][n] = x[rows][k] @ w[k][n] + b   (flax Dense / HF Conv1D kernel layout [in, out])"""
-    sgemm(x, w, y, rows, n, k, lda=k, ldb=n, ldc=n, bias=b)
+def _pad(n: int, m: int = 64) -> int:
+    return -(-n // m) * m
 
 
-def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_beta=0.0):
+class MatmulBF16:
+    """The train step's bf16-MFMA matmul mode (the reference's optional `bf16_activations`, train_ilql_gpt2.py:193): every Dense / Conv1D
+    product of forward and backward runs on the rollout engine's bf16 GEMM kernels (`lmrl_gemm_bf16`: fp32 accumulation, fp32 outputs);
+    parameters, gradients, optimizer state, LayerNorm / softmax / losses and the attention products stay fp32.  This object owns the
+    staged bf16 operands: weight copies (and their transposes) are cast once per step (`begin_step()` drops them: the optimizer has moved
+    the fp32 masters), activation / gradient operands go through reusable scratch buffers (csrc/train_bf16.hip)."""
+
+    def __init__(self, device):
+        import torch
+        self.t, self.dev = torch, device
+        self.w, self.scratch = {}, {}
+
+    def begin_step(self):
+        self.w.clear()
+
+    def _buf(self, name, numel):
+        b = self.scratch.get(name)
+        if b is None or b.numel() < numel:
+            b = self.scratch[name] = self.t.empty(numel, dtype=self.t.bfloat16, device=self.dev)
+        return b
+
+    def cast(self, name, x, rows, cols, ld_src, transpose=False, keep=False):
+        """K-major bf16 operand of `lmrl_gemm_bf16` from fp32 x [rows][cols] (row stride ld_src): [rows][pad64(cols)], or for
+        transpose=True [pad64(cols)][pad64(rows)] = x^T; padding zero-filled.  keep=True: a per-step weight copy keyed by `name`."""
+        if keep and name in self.w:
+            return self.w[name]
+        rd, ld = (_pad(rows), _pad(cols)) if not transpose else (_pad(cols), _pad(rows))
+        dst = self.t.empty(rd * ld, dtype=self.t.bfloat16, device=self.dev) if keep else self._buf(name, rd * ld)
+        _lib.check(_L().lmrl_cast_bf16(x.data_ptr(), ld_src, rows, cols, dst.data_ptr(), ld, rd, int(transpose), _sp()), "lmrl_cast_bf16")
+        if keep:
+            self.w[name] = dst
+        return dst
+
+    def bias(self, b, n):
+        """fp32 bias padded to a multiple of 64 entries (the GEMM epilogue reads whole 4-column groups)."""
+        key = ("bias", b.data_ptr())
+        if key not in self.w:
+            bp = self.t.zeros(_pad(n), dtype=self.t.float32, device=self.dev)
+            bp[:n].copy_(b)
+            self.w[key] = bp
+        return self.w[key]
+
+    def gemm(self, a, w, bias, c, m, n, k, lda, ldc, n_store, accumulate=False):
+        """c[m][n_store] (=|+=) a[m][k] . w[n][k]^T + bias, fp32 out (lmrl_gemm_bf16 epilogues 3 / 2)."""
+        _lib.check(_L().lmrl_gemm_bf16(a.data_ptr(), w.data_ptr(), _lib.ptr(bias), c.data_ptr(), m, n, k, lda, ldc, n_store, 2 if accumulate else 3,
+                                       _sp()), "lmrl_gemm_bf16")
+
+
+def linear_fwd(x, w, b, y, rows, k, n, mm: Optional[MatmulBF16] = None, ldy=None):
+    """y[rows][n] = x[rows][k] @ w[k][n] + b   (flax Dense / HF Conv1D kernel layout [in, out]); row stride of y = ldy (default n)"""
+    ldy = ldy or n
+    if mm is None:
+        sgemm(x, w, y, rows, n, k, lda=k, ldb=n, ldc=ldy, bias=b)
+        return
+    assert ldy % 4 == 0 and ldy >= _pad(n, 4), "bf16 matmul mode: the output row stride must cover whole 4-column groups"
+    xb = mm.cast("x", x, rows, k, k)
+    wt = mm.cast(("wT", w.data_ptr()), w, k, n, n, transpose=True, keep=True)          # [pad(n)][pad(k)]
+    mm.gemm(xb, wt, mm.bias(b, n) if b is not None else None, y, rows, _pad(n), _pad(k), _pad(k), ldy, n)
+
+
+def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_beta=0.0, mm: Optional[MatmulBF16] = None, lddy=None):
     """dx = dy @ w^T ; dw (+)= x^T @ dy ; db (+)= colsum(dy)"""
-    if dx is not None:
-        sgemm(dy, w, dx, rows, k, n, trans_b=True, lda=n, ldb=n, ldc=k, beta=dx_beta)
-    sgemm(x, dy, dw, k, n, rows, trans_a=True, lda=k, ldb=n, ldc=n, beta=1.0 if accumulate_dw else 0.0)
+    lddy = lddy or n
+    if mm is None:
+        if dx is not None:
+            sgemm(dy, w, dx, rows, k, n, trans_b=True, lda=lddy, ldb=n, ldc=k, beta=dx_beta)
+        sgemm(x, dy, dw, k, n, rows, trans_a=True, lda=k, ldb=lddy, ldc=n, beta=1.0 if accumulate_dw else 0.0)
+    else:
+        assert dx_beta in (0.0, 1.0)
+        if dx is not None:
+            dyb = mm.cast("dy", dy, rows, n, lddy)                                      # [rows][pad(n)]
+            assert k % 64 == 0, "bf16 matmul mode: layer widths must be multiples of 64"
+            wb = mm.cast(("w", w.data_ptr()), w, k, n, n, keep=True)                     # [k][pad(n)]
+            mm.gemm(dyb, wb, None, dx, rows, k, _pad(n), _pad(n), k, k, accumulate=dx_beta == 1.0)
+        xt = mm.cast("xT", x, rows, k, k, transpose=True)                               # [pad(k)][pad(rows)]
+        dyt = mm.cast("dyT", dy, rows, n, lddy, transpose=True)                         # [pad(n)][pad(rows)]
+        if n % 4 == 0:
+            mm.gemm(xt, dyt, None, dw, k, _pad(n), _pad(rows), _pad(rows), n, n, accumulate=accumulate_dw)
+        else:   # rows of dw are not 16-byte aligned: produce dw^T [n][k] and add its transpose
+            tmp = mm.t.empty(n, k, dtype=mm.t.float32, device=mm.dev)
+            mm.gemm(dyt, xt, None, tmp, n, _pad(k), _pad(rows), _pad(rows), k, k)
+            _lib.check(_L().lmrl_transpose_add_f32(tmp.data_ptr(), k, dw.data_ptr(), n, n, k, 1.0 if accumulate_dw else 0.0, _sp()),
+                       "lmrl_transpose_add_f32")
     if db is not None:
-        colsum(dy, rows, n, n, db, accumulate_dw, ws)
+        colsum(dy, rows, n, lddy, db, accumulate_dw, ws)
+
+
+def gather_dot(a, w, bias, idx, out, rows, k, n):
+    """out[r] = a[r] . w[:, idx[r]] + bias[idx[r]]  (w [k][n] flax Dense kernel)"""
+    _lib.check(_L().lmrl_gather_dot_f32(a.data_ptr(), k, w.data_ptr(), n, _lib.ptr(bias), idx.data_ptr(), out.data_ptr(), rows, k, n, _sp()),
+               "lmrl_gather_dot_f32")
 
 
 def colsum(x, rows, cols, ld, out, accumulate, ws):

@@ -1,0 +1,159 @@
+"""GPU tier: the train step's bf16-MFMA matmul mode (`GPT2F32(matmul="bf16")`, `MLPHeadF32(matmul="bf16")`; csrc/train_bf16.hip +
+lmrl_gemm_bf16) — the reference's optional `bf16_activations` (train_ilql_gpt2.py:193).  The reference's exact bf16 numerics live in
+JAX/XLA and cannot be pinned here; the mode is pinned to OUR exact fp32 step (itself checked against float64 autograd and the reference's
+loss functions) with the tolerances written below:
+    loss: 2e-2 relative (of max(|loss|, 0.05)); log entries (means / extrema of per-token quantities): 5e-2 of max(|value|, 0.5)
+    every gradient tensor: relative L2 error <= 0.10 and cosine similarity >= 0.995
+(bf16 operands carry 8 mantissa bits: 2^-9 relative rounding per operand, fp32 accumulation; the test models use 2-3x inflated weights and
+Q-value losses with strong cancellation (q - target), the worst case for operand rounding: measured 1.5-9 % / cosine >= 0.996, losses within
+0.3 %.  The products themselves are exact for the rounded operands: test_linear_bf16_against_bf16_rounded_operands).
+Also: the operand-staging kernels bit-exactly against torch's round-to-nearest-even cast, the gathered target-head column product, and
+the transposing accumulate."""
+import numpy as np
+import pytest
+
+import lmrl_gym_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from lmrl_gym_amd import _lib
+    return _lib.require_gpu()
+
+
+def test_staging_kernels_bit_exact(dev):
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.train import ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(0)
+    for rows, cols, ld in ((37, 211, 211), (128, 64, 64), (70, 50, 56), (5, 7, 12)):
+        x = (torch.randn(rows, ld, generator=g) * 3).to(dev)
+        x[0, 0] = 1.0 + 2.0 ** -8            # an exact tie: round-to-nearest-EVEN
+        x[1, 1] = 1.0 + 3 * 2.0 ** -8
+        ref = x[:, :cols].to(torch.bfloat16)
+        rp, cp = ops._pad(rows), ops._pad(cols)
+        a = torch.full((rp, cp), 7.0, dtype=torch.bfloat16, device=dev)
+        _lib.check(L.lmrl_cast_bf16(x.data_ptr(), ld, rows, cols, a.data_ptr(), cp, rp, 0, _lib.stream_ptr()))
+        assert torch.equal(a[:rows, :cols], ref) and float(a[rows:].abs().sum()) == 0 and float(a[:, cols:].abs().sum()) == 0
+        b = torch.full((cp, rp), 7.0, dtype=torch.bfloat16, device=dev)
+        _lib.check(L.lmrl_cast_bf16(x.data_ptr(), ld, rows, cols, b.data_ptr(), rp, cp, 1, _lib.stream_ptr()))
+        assert torch.equal(b[:cols, :rows], ref.t()) and float(b[cols:].abs().sum()) == 0 and float(b[:, rows:].abs().sum()) == 0
+    # gathered column product == take_along_axis of the full product
+    rows, k, n = 300, 192, 1001
+    a = torch.randn(rows, k, generator=g).to(dev); w = torch.randn(k, n, generator=g).to(dev); bias = torch.randn(n, generator=g).to(dev)
+    idx = torch.randint(0, n, (rows,), generator=g).to(torch.int32).to(dev)
+    out = torch.empty(rows, device=dev)
+    ops.gather_dot(a, w, bias, idx, out, rows, k, n)
+    ref = (a.double() @ w.double() + bias.double()).gather(1, idx.long()[:, None])[:, 0]
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-4)
+    # transposing accumulate
+    src = torch.randn(45, 70, generator=g).to(dev); dst = torch.randn(70, 45, generator=g).to(dev); d0 = dst.clone()
+    _lib.check(L.lmrl_transpose_add_f32(src.data_ptr(), 70, dst.data_ptr(), 45, 45, 70, 1.0, _lib.stream_ptr()))
+    assert torch.equal(dst, d0 + src.t())
+    _lib.check(L.lmrl_transpose_add_f32(src.data_ptr(), 70, dst.data_ptr(), 45, 45, 70, 0.0, _lib.stream_ptr()))
+    assert torch.equal(dst, src.t().contiguous())
+
+
+def test_linear_bf16_against_bf16_rounded_operands(dev):
+    """y, dx, dw of one linear layer in bf16 mode == float64 products of the bf16-ROUNDED operands (the only error left is the fp32
+    accumulation order): covers the padded-vocabulary output stride and the transposed-dw path for n % 4 != 0."""
+    from lmrl_gym_amd.train import ops
+    g = torch.Generator().manual_seed(1)
+    for rows, k, n in ((56, 64, 211), (200, 128, 192), (130, 192, 64)):
+        mm = ops.MatmulBF16(dev)
+        x = torch.randn(rows, k, generator=g).to(dev); w = (torch.randn(k, n, generator=g) * 0.1).to(dev); b = torch.randn(n, generator=g).to(dev)
+        ld = ops._pad(n)
+        y = torch.zeros(rows, ld, device=dev)
+        ops.linear_fwd(x, w, b, y, rows, k, n, mm=mm, ldy=ld)
+        r = lambda t: t.to(torch.bfloat16).double()
+        torch.testing.assert_close(y[:, :n].double(), r(x) @ r(w) + b.double(), rtol=1e-5, atol=1e-4)
+        dy = torch.randn(rows, ld, generator=g).to(dev)
+        dx = torch.randn(rows, k, generator=g).to(dev); dx0 = dx.clone()
+        dw = torch.randn(k, n, generator=g).to(dev); dw0 = dw.clone()
+        db = torch.zeros(n, device=dev)
+        ws = torch.empty(64 * max(n, k), device=dev)
+        ops.linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, accumulate_dw=True, dx_beta=1.0, mm=mm, lddy=ld)
+        torch.testing.assert_close(dx.double(), dx0.double() + r(dy[:, :n]) @ r(w).t(), rtol=1e-5, atol=2e-4)
+        torch.testing.assert_close(dw.double(), dw0.double() + r(x).t() @ r(dy[:, :n]), rtol=1e-5, atol=2e-4)
+        torch.testing.assert_close(db.double(), dy[:, :n].double().sum(0), rtol=1e-5, atol=1e-4)
+
+
+def _flat_logs(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(_flat_logs(v, prefix + k + "."))
+        else:
+            out[prefix + k] = float(v)
+    return out
+
+
+def _run(algo, dev, matmul, cfgname):
+    from lmrl_gym_amd.algorithms import ilql, mc_returns as mc, ppo
+    from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32, MLPHeadF32
+    if cfgname == "toy":
+        cfg, B, T = GPT2Config(2, 2, 64, 128, 211, 32), 6, 15
+    else:
+        cfg, B, T = GPT2Config(2, 12, 768, 3072, 50257, 128), 2, 96
+    sd = init_hf_style_state_dict(cfg, seed=7)
+    g = torch.Generator().manual_seed(107)
+    for k in sd:
+        sd[k] = sd[k] * (3 if cfgname == "toy" else 2) + (0.1 * torch.randn(sd[k].shape, generator=g) if sd[k].dim() == 1 else 0)
+    rng = np.random.RandomState(11)
+    V, d, pad = cfg.vocab, cfg.d_model, cfg.vocab - 1
+    ids = rng.randint(1, V - 1, size=(B, T)).astype(np.int32)
+    ids[1, T - 4:] = pad
+    sta = np.zeros((B, T - 1), dtype=bool)
+    sta[:, 3:T - 5] = (np.arange(3, T - 5) // 3 % 2 == 0)[None, :]
+    f = lambda s: (rng.randn(B, T - 1) * s).astype(np.float32)
+    mk = lambda out: {"dense1.kernel": torch.randn(d, d, generator=g) * 0.1, "dense1.bias": torch.randn(d, generator=g) * 0.1,
+                      "dense2.kernel": torch.randn(d, out, generator=g) * 0.1, "dense2.bias": torch.full((out,), -0.4)}
+    base = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev, matmul=matmul)
+    if algo == "ppo":
+        head = LinearHeadF32(dict(kernel=torch.randn(d, 1, generator=g) * 0.1, bias=torch.tensor([-1.0])), dev, matmul=matmul)
+        tr = ppo.GPT2PPOTrain(base, head, pad, dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0), lr=1e-3)
+        _, loss, logs = tr.step(ids, sta, f(0.2) - 5.0, f(1), f(1), f(1))
+        grads = dict(tr.last_grads[0]); grads.update({"head." + k: v for k, v in tr.last_grads[1].items()})
+    elif algo == "ilql":
+        tbase = GPT2F32({k: v.clone() * 1.01 for k, v in sd.items()}, cfg.n_head, device=dev, matmul=matmul)
+        h = lambda out: MLPHeadF32(mk(out), dev, matmul=matmul)
+        tr = ilql.GPT2ILQLTrain(base, h(V), h(V), h(1), pad, dict(gamma=0.99, tau=0.7, cql_weight=0.01), target_base=tbase, lr=1e-3)
+        _, loss, logs = tr.step(ids, sta, f(1) * sta, (rng.rand(B) < 0.5).astype(np.float32))
+        grads = dict(tr.last_grads[0])
+        for i, hg in enumerate(tr.last_grads[1:]):
+            grads.update({f"h{i}." + k: v for k, v in hg.items()})
+    else:
+        tr = mc.GPT2MCTrain(base, MLPHeadF32(mk(V), dev, matmul=matmul), pad, dict(cql_weight=0.05), lr=1e-3)
+        _, loss, logs = tr.step(ids, sta, f(1) * sta)
+        grads = dict(tr.last_grads[0]); grads.update({"q." + k: v for k, v in tr.last_grads[1].items()})
+    return float(loss), _flat_logs(logs), {k: v.detach().double().cpu() for k, v in grads.items()}
+
+
+@pytest.mark.parametrize("cfgname", ["toy", "width"])
+@pytest.mark.parametrize("algo", ["ppo", "ilql", "mc"])
+def test_bf16_matmul_step_tracks_the_fp32_step(dev, algo, cfgname):
+    l0, logs0, g0 = _run(algo, dev, "f32", cfgname)
+    l1, logs1, g1 = _run(algo, dev, "bf16", cfgname)
+    assert abs(l1 - l0) <= 2e-2 * max(abs(l0), 0.05), (l0, l1)
+    assert set(logs0) == set(logs1)
+    for k in logs0:
+        if np.isnan(logs0[k]) and np.isnan(logs1[k]):
+            continue
+        # extrema (min / max entries) and clip fractions may sit on a different token: compare with a looser absolute floor
+        assert abs(logs1[k] - logs0[k]) <= 5e-2 * max(abs(logs0[k]), 0.5), (k, logs0[k], logs1[k])
+    worst = (0.0, None)
+    for k in g0:
+        a, b = g0[k].reshape(-1), g1[k].reshape(-1)
+        na = float(a.norm())
+        if na < 1e-12:
+            assert float(b.norm()) < 1e-9, k
+            continue
+        rel = float((a - b).norm()) / na
+        cos = float((a * b).sum()) / (na * float(b.norm()))
+        worst = max(worst, (rel, k))
+        assert rel <= 0.10 and cos >= 0.995, (k, rel, cos)
+    print(f"{algo}/{cfgname}: loss {l0:.6f} vs {l1:.6f}; worst gradient relative L2 error {worst[0]:.4f} ({worst[1]})")

@@ -96,7 +96,7 @@ int main(int argc, char **argv) {
     };
     hipStream_t st; CK(hipStreamCreate(&st));
     for (const Shape &sh : shapes) {
-        const int M = sh.M, N = sh.N, K = sh.K, NWC = N > 10000 ? 2 : 12;
+        const int M = sh.M, N = sh.N, K = sh.K, NWC = getenv("LMRL_NWC") ? atoi(getenv("LMRL_NWC")) : (N > 10000 ? 2 : 12);   // LMRL_NWC=1: hot L2
         uint16_t *A, *W, *C; float *bias, *R, *err;
         CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)NWC * N * K * 2)); CK(hipMalloc(&C, (size_t)M * N * 4));
         CK(hipMalloc(&bias, (size_t)N * 4)); CK(hipMalloc(&R, (size_t)M * N * 4)); CK(hipMalloc(&err, 4));
