@@ -415,6 +415,18 @@ int lmrl_axpby(float a, const float *x_d, float b, const float *y_d, float *out_
 /* optax.adamw(b1, b2, eps, weight_decay) with bias correction at `step` (1-based) */
 int lmrl_adamw(float *p_d, const float *g_d, float *m_d, float *v_d, size_t n, float lr, float b1, float b2, float eps, float weight_decay,
                int step, void *stream);
+/* ---- causal self-attention of the train step without the [B*H][T][T] tensors (csrc/flash_attn_train.hip): online-softmax tile sweeps on the
+ * matrix cores, head dim 64.  qkv_d [B*T][3*H*64] fp32 (HF GPT-2 c_attn output: q | k | v), key_mask_d [B][T] uint8 or NULL, att_d / datt_d
+ * [B*T][H*64]; lse_d [lmrl_flash_attn_lse_bytes] is written by fwd and read by bwd; ws_d [lmrl_flash_attn_ws_bytes] is scratch (re-staged by
+ * each call).  bf16 = 0: exact fp32 operands (v_mfma_f32_16x16x4_f32); 1: bf16 operands, fp32 accumulation / softmax / outputs.
+ * Same masking as lmrl_softmax_causal_fwd: keys c <= r with key_mask != 0; a query with no valid key gets a zero output row.
+ * Restates the attention of FlaxGPT2 as differentiated by the reference's train steps (ppo/gpt2/interface.py:72-211). */
+size_t lmrl_flash_attn_ws_bytes(int batch, int heads, int t, int bf16);
+size_t lmrl_flash_attn_lse_bytes(int batch, int heads, int t);
+int lmrl_flash_attn_fwd(const float *qkv_d, const uint8_t *key_mask_d, float *att_d, float *lse_d, void *ws_d, int batch, int heads, int t, int bf16,
+                        void *stream);
+int lmrl_flash_attn_bwd(const float *qkv_d, const uint8_t *key_mask_d, const float *att_d, const float *datt_d, const float *lse_d, float *dqkv_d,
+                        void *ws_d, int batch, int heads, int t, int bf16, void *stream);
 /* ---- bf16-MFMA matmul mode of the train step (csrc/train_bf16.hip): the reference's optional `bf16_activations`
  * (train_ilql_gpt2.py:193; model dtype bf16, fp32 parameters).  Operands are staged as K-major bf16 matrices for lmrl_gemm_bf16.
  * lmrl_cast_bf16: dst [rows_dst][ld_dst] bf16 := round-to-nearest-even of src [rows][cols] fp32 (transpose = 0) or of its transpose

@@ -1,0 +1,459 @@
+// flash_attn_train.hip — causal self-attention of the TRAIN step (forward and backward) without the [B*H][T][T] score / probability
+// tensors: the HF-Flax GPT-2 attention the reference's `_step` functions differentiate (ppo/gpt2/interface.py:72-211,
+// ilql/gpt2/interface.py:88-367) — softmax(Q K^T / sqrt(64) + causal + key-padding mask) V, head dim 64 — as an online-softmax tile
+// sweep on the matrix cores.  One source for both arithmetic modes of the train step:
+//     E = F32  : exact fp32 operands on v_mfma_f32_16x16x4_f32 (the reference's default arithmetic)
+//     E = BF16 : bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulation / softmax / outputs (`bf16_activations`)
+// A lane's MFMA operand is always "8 consecutive k-elements of row (lane & 15), starting at 8*(lane >> 4)" of a 32-wide k slab: the bf16
+// instruction consumes it directly; the fp32 path issues 8 16x16x4 MFMAs whose k index is paired (lane >> 4, s) <-> 8*(lane >> 4) + s on
+// both operands (a permutation of the summation index).  Operands are staged once per call by a streaming pre-pass into per-head
+// K-major matrices (natural [T][64] and transposed [64][T]), so every tile load is a run of 16-byte row chunks.
+//
+// Forward, one workgroup per (64 queries, head): 4 waves x 16 queries; per 64-key block S = K.Q^T lands as lane (query = lane & 15) x
+// 8 CONSECUTIVE keys (the K rows fed to the two 16-row MFMAs of a 32-key slab are interleaved 4 by 4), i.e. exactly the next MFMA's
+// operand layout: P goes from registers straight into O += V^T.P with no LDS round trip.  Saves lse = m + log(l) per query.
+// Backward, two kernels (no atomics, deterministic): dQ per query block (recompute S, P; dP = V.dO^T; dS = P (dP - D); dQ = K^T.dS)
+// and dK/dV per key block (lane owns a key: S^T, dP^T; dV += dO^T.P^T, dK += Q^T.dS^T), D = rowsum(dO o O) from the pre-pass.
+// Masking matches softmax_causal_fwd_kernel (train_ops.hip): keys c <= r with key_mask[b][c] != 0; a row with no valid key gives 0.
+#include "../../include/lmrl_amd.h"
+#include "gemm_bf16.h"
+
+namespace lmrl {
+
+struct ElemF32 {
+    typedef float T;
+    static constexpr int SZ = 4, CPR = 16, ROWB = 256, TILE = 64 * 256;
+    struct Frag { f32x4 a, b; };
+};
+struct ElemBF16 {
+    typedef uint16_t T;
+    static constexpr int SZ = 2, CPR = 8, ROWB = 128, TILE = 64 * 128;
+    struct Frag { bf16x8 v; };
+};
+
+// 64 x 64 tile in LDS: 16-byte chunks, chunk index XOR-swizzled with the row so that the 16-lane groups of ds_read_b128 hit 16 distinct
+// chunk columns (the GEMM kernels' scheme; fp32 rows are 16 chunks wide, so the swizzle uses 4 row bits)
+template <class E>
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row * E::ROWB + ((chunk ^ (row & (E::CPR - 1))) << 4); }
+
+template <class E>
+__device__ __forceinline__ void load_tile(char *tile, const typename E::T *src, long ld) {
+#pragma unroll
+    for (int c = threadIdx.x; c < 64 * E::CPR; c += 256) {
+        const int row = c / E::CPR, ch = c % E::CPR;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(src + (long)row * ld) + ch * 16);
+        *reinterpret_cast<u32x4 *>(tile + tile_off<E>(row, ch)) = v;
+    }
+}
+
+__device__ __forceinline__ ElemBF16::Frag ld_frag_lds(ElemBF16, const char *tile, int row, int e0) {
+    ElemBF16::Frag f;
+    f.v = *reinterpret_cast<const bf16x8 *>(tile + tile_off<ElemBF16>(row, e0 >> 3));
+    return f;
+}
+__device__ __forceinline__ ElemF32::Frag ld_frag_lds(ElemF32, const char *tile, int row, int e0) {
+    ElemF32::Frag f;
+    f.a = *reinterpret_cast<const f32x4 *>(tile + tile_off<ElemF32>(row, e0 >> 2));
+    f.b = *reinterpret_cast<const f32x4 *>(tile + tile_off<ElemF32>(row, (e0 >> 2) + 1));
+    return f;
+}
+__device__ __forceinline__ ElemBF16::Frag ld_frag_glb(ElemBF16, const uint16_t *p) {
+    ElemBF16::Frag f;
+    f.v = *reinterpret_cast<const bf16x8 *>(p);
+    return f;
+}
+__device__ __forceinline__ ElemF32::Frag ld_frag_glb(ElemF32, const float *p) {
+    ElemF32::Frag f;
+    f.a = *reinterpret_cast<const f32x4 *>(p);
+    f.b = *reinterpret_cast<const f32x4 *>(p + 4);
+    return f;
+}
+__device__ __forceinline__ ElemBF16::Frag make_frag(ElemBF16, const float (&v)[8]) {
+    u32x4 w = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    ElemBF16::Frag f;
+    f.v = __builtin_bit_cast(bf16x8, w);
+    return f;
+}
+__device__ __forceinline__ ElemF32::Frag make_frag(ElemF32, const float (&v)[8]) {
+    ElemF32::Frag f;
+    f.a = f32x4{v[0], v[1], v[2], v[3]};
+    f.b = f32x4{v[4], v[5], v[6], v[7]};
+    return f;
+}
+// acc[i = 4*(lane>>4) + e][j = lane & 15] += sum_k A[i][k] B[j][k] over a 32-wide k slab
+__device__ __forceinline__ f32x4 mma(ElemBF16, f32x4 acc, const ElemBF16::Frag &a, const ElemBF16::Frag &b) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma(ElemF32, f32x4 acc, const ElemF32::Frag &a, const ElemF32::Frag &b) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.a[s], b.a[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.b[s], b.b[s], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ void st_elem(uint16_t *p, float v) { *p = f32_to_bf16_rn(v); }
+__device__ __forceinline__ void st_elem(float *p, float v) { *p = v; }
+
+// key-validity bytes of one 64-key block -> LDS (1 = key index < T and key_mask set).  Branch-free on purpose: the per-element
+// `ok ? score : -inf` selects below must stay selects (a divergent short-circuit load around AGPR moves was miscompiled by hipcc 7.2).
+__device__ __forceinline__ void load_key_valid(uint8_t *sM, const uint8_t *kmb, int k0, int T) {
+    if (threadIdx.x < 64) {
+        const int kk = k0 + threadIdx.x;
+        const int kc = kk < T ? kk : T - 1;
+        const uint8_t mv = kmb ? kmb[kc] : (uint8_t)1;
+        sM[threadIdx.x] = (kk < T && mv != 0) ? 1 : 0;
+    }
+}
+
+// rows of a 32-row slab fed to the two 16-row MFMAs so that the lane holding output rows 4*lq + e gets slab rows 8*lq + e (first MFMA)
+// and 8*lq + 4 + e (second): 8 consecutive rows per lane
+__device__ __forceinline__ int slab_row(int lr) { return (lr >> 2) * 8 + (lr & 3); }
+
+// ------------------------------------------------------------------------------------------ operand staging
+// src [B*T][ld] fp32, columns col0 + h*64 + c  ->  natural Xn [BH][Tp][64] and transposed XT [BH][64][Tp] (zero rows / columns for t >= T)
+template <class E>
+__global__ __launch_bounds__(256) void flash_stage_kernel(const float *__restrict__ src, long ld, int col0, float scale, typename E::T *__restrict__ Xn,
+                                                          typename E::T *__restrict__ XT, const float *__restrict__ other, float *__restrict__ rowdot,
+                                                          int H, int T, int Tp) {
+    __shared__ float tile[64][65];
+    __shared__ float prod[64][65];
+    const int t0 = blockIdx.x * 64, bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int r = ty + 4 * k, t = t0 + r;
+        float v = 0.f, o = 0.f;
+        if (t < T) {
+            const long at = ((long)b * T + t) * ld + col0 + h * 64 + tx;
+            v = src[at] * scale;
+            if (other) o = other[at];
+        }
+        tile[r][tx] = v;
+        if (other) prod[r][tx] = v * o;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int r = ty + 4 * k;
+        st_elem(Xn + ((long)bh * Tp + t0 + r) * 64 + tx, tile[r][tx]);
+        st_elem(XT + ((long)bh * 64 + r) * Tp + t0 + tx, tile[tx][r]);
+    }
+    if (other && threadIdx.x < 64) {
+        float s = 0.f;
+        for (int c = 0; c < 64; c++) s += prod[threadIdx.x][c];
+        rowdot[(long)bh * Tp + t0 + threadIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <class E>
+__global__ __launch_bounds__(256) void flash_fwd_kernel(const typename E::T *__restrict__ Qn, const typename E::T *__restrict__ Kn,
+                                                        const typename E::T *__restrict__ VT, const uint8_t *__restrict__ km, float *__restrict__ att,
+                                                        float *__restrict__ lse, int H, int T, int Tp, int d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *sK = smem, *sV = smem + E::TILE;
+    uint8_t *sM = reinterpret_cast<uint8_t *>(smem + 2 * E::TILE);
+    const int qb = gridDim.x - 1 - blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh - b * H;      // longest sweeps first
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
+    const int qi = qb * 64 + wave * 16 + lr;
+    typename E::Frag qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) qf[s] = ld_frag_glb(E(), Qn + ((long)bh * Tp + qi) * 64 + s * 32 + lq * 8);
+    const uint8_t *kmb = km ? km + (long)b * T : nullptr;
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ra = slab_row(lr);
+    for (int kb = 0; kb <= qb; kb++) {
+        __syncthreads();
+        load_tile<E>(sK, Kn + ((long)bh * Tp + kb * 64) * 64, 64);
+        load_tile<E>(sV, VT + (long)bh * 64 * Tp + kb * 64, Tp);
+        load_key_valid(sM, kmb, kb * 64, T);
+        __syncthreads();
+        float s[2][8];
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = sa;
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                sa = mma(E(), sa, ld_frag_lds(E(), sK, p * 32 + ra, sl * 32 + lq * 8), qf[sl]);
+                sb = mma(E(), sb, ld_frag_lds(E(), sK, p * 32 + ra + 4, sl * 32 + lq * 8), qf[sl]);
+            }
+            const unsigned long long mb = *reinterpret_cast<const unsigned long long *>(sM + p * 32 + lq * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int kk = kb * 64 + p * 32 + lq * 8 + e;
+                const bool ok = (kk <= qi) & (((mb >> (8 * e)) & 0xffull) != 0);
+                const float v = ok ? (e < 4 ? sa[e] : sb[e - 4]) : -INFINITY;
+                s[p][e] = v;
+                mloc = fmaxf(mloc, v);
+            }
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m, mloc);
+        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __expf(m - m_safe);
+        float rs = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) { s[p][e] = __expf(s[p][e] - m_safe); rs += s[p][e]; }
+        l = l * alpha + rs;
+        m = m_new;
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] *= alpha;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const typename E::Frag pf = make_frag(E(), s[p]);
+#pragma unroll
+            for (int db = 0; db < 4; db++) o[db] = mma(E(), o[db], ld_frag_lds(E(), sV, db * 16 + lr, p * 32 + lq * 8), pf);
+        }
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    if (qi < T) {
+#pragma unroll
+        for (int db = 0; db < 4; db++)
+            *reinterpret_cast<f32x4 *>(att + ((long)b * T + qi) * d + h * 64 + db * 16 + lq * 4) = o[db] * inv;
+    }
+    if (lq == 0) lse[(long)bh * Tp + qi] = (qi < T && l > 0.f) ? m + __logf(l) : INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------ backward: dQ
+template <class E>
+__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const typename E::T *__restrict__ Qn, const typename E::T *__restrict__ Kn,
+                                                           const typename E::T *__restrict__ Vn, const typename E::T *__restrict__ KT,
+                                                           const typename E::T *__restrict__ dOn, const float *__restrict__ Dsum,
+                                                           const float *__restrict__ lse, const uint8_t *__restrict__ km, float *__restrict__ dqkv,
+                                                           int H, int T, int Tp, int d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *sK = smem, *sV = smem + E::TILE, *sKT = smem + 2 * E::TILE;
+    uint8_t *sM = reinterpret_cast<uint8_t *>(smem + 3 * E::TILE);
+    const int qb = gridDim.x - 1 - blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
+    const int qi = qb * 64 + wave * 16 + lr;
+    typename E::Frag qf[2], dof[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        qf[s] = ld_frag_glb(E(), Qn + ((long)bh * Tp + qi) * 64 + s * 32 + lq * 8);
+        dof[s] = ld_frag_glb(E(), dOn + ((long)bh * Tp + qi) * 64 + s * 32 + lq * 8);
+    }
+    const float Lq = lse[(long)bh * Tp + qi], Dq = Dsum[(long)bh * Tp + qi];
+    const uint8_t *kmb = km ? km + (long)b * T : nullptr;
+    f32x4 dq[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ra = slab_row(lr);
+    for (int kb = 0; kb <= qb; kb++) {
+        __syncthreads();
+        load_tile<E>(sK, Kn + ((long)bh * Tp + kb * 64) * 64, 64);
+        load_tile<E>(sV, Vn + ((long)bh * Tp + kb * 64) * 64, 64);
+        load_tile<E>(sKT, KT + (long)bh * 64 * Tp + kb * 64, Tp);
+        load_key_valid(sM, kmb, kb * 64, T);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = sa, pa = sa, pb = sa;
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                sa = mma(E(), sa, ld_frag_lds(E(), sK, p * 32 + ra, sl * 32 + lq * 8), qf[sl]);
+                sb = mma(E(), sb, ld_frag_lds(E(), sK, p * 32 + ra + 4, sl * 32 + lq * 8), qf[sl]);
+                pa = mma(E(), pa, ld_frag_lds(E(), sV, p * 32 + ra, sl * 32 + lq * 8), dof[sl]);
+                pb = mma(E(), pb, ld_frag_lds(E(), sV, p * 32 + ra + 4, sl * 32 + lq * 8), dof[sl]);
+            }
+            float ds[8];
+            const unsigned long long mb = *reinterpret_cast<const unsigned long long *>(sM + p * 32 + lq * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int kk = kb * 64 + p * 32 + lq * 8 + e;
+                const bool ok = (kk <= qi) & (qi < T) & (((mb >> (8 * e)) & 0xffull) != 0);
+                const float sv = e < 4 ? sa[e] : sb[e - 4], dp = e < 4 ? pa[e] : pb[e - 4];
+                const float pr = ok ? __expf(sv - Lq) : 0.f;
+                ds[e] = pr * (dp - Dq);
+            }
+            const typename E::Frag dsf = make_frag(E(), ds);
+#pragma unroll
+            for (int db = 0; db < 4; db++) dq[db] = mma(E(), dq[db], ld_frag_lds(E(), sKT, db * 16 + lr, p * 32 + lq * 8), dsf);
+        }
+    }
+    if (qi < T) {
+#pragma unroll
+        for (int db = 0; db < 4; db++)
+            *reinterpret_cast<f32x4 *>(dqkv + ((long)b * T + qi) * 3 * d + h * 64 + db * 16 + lq * 4) = dq[db] * 0.125f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dK, dV
+template <class E>
+__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const typename E::T *__restrict__ Qn, const typename E::T *__restrict__ Kn,
+                                                            const typename E::T *__restrict__ Vn, const typename E::T *__restrict__ QT,
+                                                            const typename E::T *__restrict__ dOn, const typename E::T *__restrict__ dOT,
+                                                            const float *__restrict__ Dsum, const float *__restrict__ lse,
+                                                            const uint8_t *__restrict__ km, float *__restrict__ dqkv, int H, int T, int Tp, int d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *sQ = smem, *sdO = smem + E::TILE, *sQT = smem + 2 * E::TILE, *sdOT = smem + 3 * E::TILE;
+    float *sL = reinterpret_cast<float *>(smem + 4 * E::TILE), *sD = sL + 64;
+    const int kb = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh - b * H;                         // key block 0 has the longest sweep: first
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
+    const int kj = kb * 64 + wave * 16 + lr;
+    typename E::Frag kf[2], vf[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        kf[s] = ld_frag_glb(E(), Kn + ((long)bh * Tp + kj) * 64 + s * 32 + lq * 8);
+        vf[s] = ld_frag_glb(E(), Vn + ((long)bh * Tp + kj) * 64 + s * 32 + lq * 8);
+    }
+    const uint8_t kmv = km ? km[(long)b * T + (kj < T ? kj : T - 1)] : (uint8_t)1;
+    const bool key_ok = (kj < T) & (kmv != 0);
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = dk[i]; }
+    const int ra = slab_row(lr);
+    const int nqb = Tp / 64;
+    for (int qb = kb; qb < nqb; qb++) {
+        __syncthreads();
+        load_tile<E>(sQ, Qn + ((long)bh * Tp + qb * 64) * 64, 64);
+        load_tile<E>(sdO, dOn + ((long)bh * Tp + qb * 64) * 64, 64);
+        load_tile<E>(sQT, QT + (long)bh * 64 * Tp + qb * 64, Tp);
+        load_tile<E>(sdOT, dOT + (long)bh * 64 * Tp + qb * 64, Tp);
+        if (threadIdx.x < 64) {
+            sL[threadIdx.x] = lse[(long)bh * Tp + qb * 64 + threadIdx.x];
+            sD[threadIdx.x] = Dsum[(long)bh * Tp + qb * 64 + threadIdx.x];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = sa, pa = sa, pb = sa;
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                sa = mma(E(), sa, ld_frag_lds(E(), sQ, p * 32 + ra, sl * 32 + lq * 8), kf[sl]);
+                sb = mma(E(), sb, ld_frag_lds(E(), sQ, p * 32 + ra + 4, sl * 32 + lq * 8), kf[sl]);
+                pa = mma(E(), pa, ld_frag_lds(E(), sdO, p * 32 + ra, sl * 32 + lq * 8), vf[sl]);
+                pb = mma(E(), pb, ld_frag_lds(E(), sdO, p * 32 + ra + 4, sl * 32 + lq * 8), vf[sl]);
+            }
+            float pr[8], ds[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int ql = p * 32 + lq * 8 + e, qq = qb * 64 + ql;
+                const bool ok = key_ok & (qq >= kj) & (qq < T);
+                const float sv = e < 4 ? sa[e] : sb[e - 4], dp = e < 4 ? pa[e] : pb[e - 4];
+                pr[e] = ok ? __expf(sv - sL[ql]) : 0.f;
+                ds[e] = pr[e] * (dp - sD[ql]);
+            }
+            const typename E::Frag pf = make_frag(E(), pr), dsf = make_frag(E(), ds);
+#pragma unroll
+            for (int db = 0; db < 4; db++) {
+                dv[db] = mma(E(), dv[db], ld_frag_lds(E(), sdOT, db * 16 + lr, p * 32 + lq * 8), pf);
+                dk[db] = mma(E(), dk[db], ld_frag_lds(E(), sQT, db * 16 + lr, p * 32 + lq * 8), dsf);
+            }
+        }
+    }
+    if (kj < T) {
+#pragma unroll
+        for (int db = 0; db < 4; db++) {
+            float *row = dqkv + ((long)b * T + kj) * 3 * d + h * 64 + db * 16 + lq * 4;
+            *reinterpret_cast<f32x4 *>(row + d) = dk[db];
+            *reinterpret_cast<f32x4 *>(row + 2 * d) = dv[db];
+        }
+    }
+}
+
+struct FlashWs {
+    char *Qn, *Kn, *Vn, *QT, *KT, *VT, *dOn, *dOT;
+    float *D;
+    static size_t mat_bytes(int bh, int tp, int esz) { return ((size_t)bh * tp * 64 * esz + 255) & ~(size_t)255; }
+    static size_t bytes(int bh, int tp, int esz) { return 8 * mat_bytes(bh, tp, esz) + (size_t)bh * tp * sizeof(float); }
+    void carve(void *ws, int bh, int tp, int esz) {
+        char *p = static_cast<char *>(ws);
+        const size_t m = mat_bytes(bh, tp, esz);
+        Qn = p; Kn = p + m; Vn = p + 2 * m; QT = p + 3 * m; KT = p + 4 * m; VT = p + 5 * m; dOn = p + 6 * m; dOT = p + 7 * m;
+        D = reinterpret_cast<float *>(p + 8 * m);
+    }
+};
+
+template <class K>
+static hipError_t allow_lds(K kernel, size_t bytes) {
+    return bytes > 64 * 1024 ? hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
+                             : hipSuccess;
+}
+
+template <class E>
+static int flash_stage_qkv(const float *qkv, const FlashWs &w, int batch, int heads, int t, int tp, hipStream_t s) {
+    typedef typename E::T T;
+    const int d = heads * 64;
+    const dim3 grid(tp / 64, batch * heads);
+    hipLaunchKernelGGL(flash_stage_kernel<E>, grid, dim3(256), 0, s, qkv, (long)3 * d, 0, 0.125f, (T *)w.Qn, (T *)w.QT, (const float *)nullptr,
+                       (float *)nullptr, heads, t, tp);
+    hipLaunchKernelGGL(flash_stage_kernel<E>, grid, dim3(256), 0, s, qkv, (long)3 * d, d, 1.f, (T *)w.Kn, (T *)w.KT, (const float *)nullptr,
+                       (float *)nullptr, heads, t, tp);
+    hipLaunchKernelGGL(flash_stage_kernel<E>, grid, dim3(256), 0, s, qkv, (long)3 * d, 2 * d, 1.f, (T *)w.Vn, (T *)w.VT, (const float *)nullptr,
+                       (float *)nullptr, heads, t, tp);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+template <class E>
+static int flash_fwd(const float *qkv, const uint8_t *km, float *att, float *lse, void *ws, int batch, int heads, int t, hipStream_t s) {
+    typedef typename E::T T;
+    const int tp = (t + 63) / 64 * 64, bh = batch * heads, d = heads * 64;
+    FlashWs w; w.carve(ws, bh, tp, E::SZ);
+    int rc = flash_stage_qkv<E>(qkv, w, batch, heads, t, tp, s);
+    if (rc) return rc;
+    const size_t lds = 2 * E::TILE + 64;
+    LMRL_CHECK_HIP(allow_lds(flash_fwd_kernel<E>, lds));
+    hipLaunchKernelGGL(flash_fwd_kernel<E>, dim3(tp / 64, bh), dim3(256), lds, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.VT, km, att, lse, heads,
+                       t, tp, d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+template <class E>
+static int flash_bwd(const float *qkv, const uint8_t *km, const float *att, const float *datt, const float *lse, float *dqkv, void *ws, int batch,
+                     int heads, int t, hipStream_t s) {
+    typedef typename E::T T;
+    const int tp = (t + 63) / 64 * 64, bh = batch * heads, d = heads * 64;
+    FlashWs w; w.carve(ws, bh, tp, E::SZ);
+    int rc = flash_stage_qkv<E>(qkv, w, batch, heads, t, tp, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(flash_stage_kernel<E>, dim3(tp / 64, bh), dim3(256), 0, s, datt, (long)d, 0, 1.f, (T *)w.dOn, (T *)w.dOT, att, w.D, heads, t, tp);
+    LMRL_CHECK_LAUNCH();
+    const size_t lds_q = 3 * E::TILE + 64, lds_kv = 4 * E::TILE + 512;
+    LMRL_CHECK_HIP(allow_lds(flash_bwd_dq_kernel<E>, lds_q));
+    LMRL_CHECK_HIP(allow_lds(flash_bwd_dkv_kernel<E>, lds_kv));
+    hipLaunchKernelGGL(flash_bwd_dq_kernel<E>, dim3(tp / 64, bh), dim3(256), lds_q, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.Vn, (const T *)w.KT,
+                       (const T *)w.dOn, (const float *)w.D, lse, km, dqkv, heads, t, tp, d);
+    hipLaunchKernelGGL(flash_bwd_dkv_kernel<E>, dim3(tp / 64, bh), dim3(256), lds_kv, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.Vn,
+                       (const T *)w.QT, (const T *)w.dOn, (const T *)w.dOT, (const float *)w.D, lse, km, dqkv, heads, t, tp, d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+}  // namespace lmrl
+
+using namespace lmrl;
+
+extern "C" {
+
+size_t lmrl_flash_attn_ws_bytes(int batch, int heads, int t, int bf16) {
+    return FlashWs::bytes(batch * heads, (t + 63) / 64 * 64, bf16 ? 2 : 4);
+}
+size_t lmrl_flash_attn_lse_bytes(int batch, int heads, int t) { return (size_t)batch * heads * ((t + 63) / 64 * 64) * sizeof(float); }
+
+int lmrl_flash_attn_fwd(const float *qkv_d, const uint8_t *key_mask_d, float *att_d, float *lse_d, void *ws_d, int batch, int heads, int t, int bf16,
+                        void *stream) {
+    LMRL_REQUIRE(qkv_d && att_d && lse_d && ws_d && batch > 0 && heads > 0 && t > 0, "lmrl_flash_attn_fwd: bad argument");
+    return bf16 ? flash_fwd<ElemBF16>(qkv_d, key_mask_d, att_d, lse_d, ws_d, batch, heads, t, as_stream(stream))
+                : flash_fwd<ElemF32>(qkv_d, key_mask_d, att_d, lse_d, ws_d, batch, heads, t, as_stream(stream));
+}
+
+int lmrl_flash_attn_bwd(const float *qkv_d, const uint8_t *key_mask_d, const float *att_d, const float *datt_d, const float *lse_d, float *dqkv_d,
+                        void *ws_d, int batch, int heads, int t, int bf16, void *stream) {
+    LMRL_REQUIRE(qkv_d && att_d && datt_d && lse_d && dqkv_d && ws_d && batch > 0 && heads > 0 && t > 0, "lmrl_flash_attn_bwd: bad argument");
+    return bf16 ? flash_bwd<ElemBF16>(qkv_d, key_mask_d, att_d, datt_d, lse_d, dqkv_d, ws_d, batch, heads, t, as_stream(stream))
+                : flash_bwd<ElemF32>(qkv_d, key_mask_d, att_d, datt_d, lse_d, dqkv_d, ws_d, batch, heads, t, as_stream(stream));
+}
+
+}  // extern "C"

@@ -71,9 +71,13 @@ class GPT2F32:
     head) on the bf16 MFMA with fp32 accumulation — the reference's optional `bf16_activations` mode (train_ilql_gpt2.py:193) — see
     `ops.MatmulBF16`; the default "f32" is the reference's default arithmetic."""
 
-    def __init__(self, params: Dict[str, "torch.Tensor"], n_head: int, ln_eps: float = 1e-5, device=None, matmul: str = "f32"):
+    def __init__(self, params: Dict[str, "torch.Tensor"], n_head: int, ln_eps: float = 1e-5, device=None, matmul: str = "f32",
+                 attention: str = "flash"):
+        """attention="flash": online-softmax tile sweeps (csrc/flash_attn_train.hip; operands fp32 or bf16 following `matmul`), no
+        [B*H, T, T] tensors; "materialized": the batched-sgemm + softmax formulation (fp32; the cross-check of the flash kernels)."""
         import torch
-        assert matmul in ("f32", "bf16")
+        assert matmul in ("f32", "bf16") and attention in ("flash", "materialized")
+        self.attention = attention
         self.t = torch
         self.dev = device or next(iter(params.values())).device
         self.p = {k: v.to(self.dev, torch.float32).contiguous() for k, v in params.items()}
@@ -104,6 +108,14 @@ class GPT2F32:
         x = new(R, d)
         ops.embed_fwd(p["wte.weight"], p["wpe.weight"], ids, pos, x, R, d)
         cache = dict(B=B, T=T, ids=ids, pos=pos, km=km, layers=[])
+        flash = self.attention == "flash" and hd == 64
+        lse_n = 0
+        if flash:
+            key = (B, H, T)
+            if getattr(self, "_flash_key", None) != key:
+                self._flash_ws, self._flash_key = ops.flash_attn_ws(B, H, T, self.mm is not None, self.dev), key
+            lse_n = self._flash_ws[1]
+        cache["flash"] = flash
         for l in range(self.n_layer):
             q = f"h.{l}."
             c = dict(x_in=x)
@@ -111,14 +123,19 @@ class GPT2F32:
             ops.layernorm_fwd(x, p[q + "ln_1.weight"], p[q + "ln_1.bias"], h1, c["m1"], c["r1"], R, d, self.eps)
             qkv = new(R, 3 * d)
             ops.linear_fwd(h1, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], qkv, R, d, 3 * d, mm=self.mm)
-            P = new(B * H, T, T)
-            # S = scale * Q K^T per (b, h); Q/K/V are column slices of qkv (row stride 3d)
-            ops.sgemm(qkv, qkv, P, T, T, hd, trans_b=True, alpha=1.0 / math.sqrt(hd), lda=3 * d, ldb=3 * d, ldc=T, b_off=d,
-                      batch=(B, H), sa=(T * 3 * d, hd), sb=(T * 3 * d, hd), sc=(H * T * T, T * T))
-            ops.softmax_causal_fwd(P, km, P, B, H, T)
             att = new(R, d)
-            ops.sgemm(P, qkv, att, T, hd, T, lda=T, ldb=3 * d, ldc=d, b_off=2 * d, batch=(B, H), sa=(H * T * T, T * T),
-                      sb=(T * 3 * d, hd), sc=(T * d, hd))
+            if flash:
+                P = None
+                c["lse"] = new(lse_n)
+                ops.flash_attn_fwd(qkv, km, att, c["lse"], self._flash_ws[0], B, H, T, self.mm is not None)
+            else:
+                P = new(B * H, T, T)
+                # S = scale * Q K^T per (b, h); Q/K/V are column slices of qkv (row stride 3d)
+                ops.sgemm(qkv, qkv, P, T, T, hd, trans_b=True, alpha=1.0 / math.sqrt(hd), lda=3 * d, ldb=3 * d, ldc=T, b_off=d,
+                          batch=(B, H), sa=(T * 3 * d, hd), sb=(T * 3 * d, hd), sc=(H * T * T, T * T))
+                ops.softmax_causal_fwd(P, km, P, B, H, T)
+                ops.sgemm(P, qkv, att, T, hd, T, lda=T, ldb=3 * d, ldc=d, b_off=2 * d, batch=(B, H), sa=(H * T * T, T * T),
+                          sb=(T * 3 * d, hd), sc=(T * d, hd))
             x_mid = new(R, d)
             ops.linear_fwd(att, p[q + "attn.c_proj.weight"], p[q + "attn.c_proj.bias"], x_mid, R, d, d, mm=self.mm)
             ops.axpby(1.0, x_mid, 1.0, x, x_mid)
@@ -220,19 +237,10 @@ class GPT2F32:
             ops.linear_bwd(c["att"], p[q + "attn.c_proj.weight"], dx, datt, grads[q + "attn.c_proj.weight"], grads[q + "attn.c_proj.bias"], R, d, d, ws, mm=self.mm)
             qkv, P = c["qkv"], c["P"]
             dqkv = new(R, 3 * d)
-            # dV = P^T dA
-            ops.sgemm(P, datt, dqkv, T, hd, T, trans_a=True, lda=T, ldb=d, ldc=3 * d, c_off=2 * d, batch=(B, H), sa=(H * T * T, T * T),
-                      sb=(T * d, hd), sc=(T * 3 * d, hd))
-            # dP = dA V^T ; dS = softmax_bwd
-            dP = new(B * H, T, T)
-            ops.sgemm(datt, qkv, dP, T, T, hd, trans_b=True, lda=d, ldb=3 * d, ldc=T, b_off=2 * d, batch=(B, H), sa=(T * d, hd),
-                      sb=(T * 3 * d, hd), sc=(H * T * T, T * T))
-            ops.softmax_bwd(P, dP, B * H * T, T)
-            # dQ = scale * dS K ; dK = scale * dS^T Q
-            ops.sgemm(dP, qkv, dqkv, T, hd, T, alpha=scale, lda=T, ldb=3 * d, ldc=3 * d, b_off=d, batch=(B, H), sa=(H * T * T, T * T),
-                      sb=(T * 3 * d, hd), sc=(T * 3 * d, hd))
-            ops.sgemm(dP, qkv, dqkv, T, hd, T, trans_a=True, alpha=scale, lda=T, ldb=3 * d, ldc=3 * d, c_off=d, batch=(B, H),
-                      sa=(H * T * T, T * T), sb=(T * 3 * d, hd), sc=(T * 3 * d, hd))
+            if cache["flash"]:
+                ops.flash_attn_bwd(qkv, cache["km"], c["att"], datt, c["lse"], dqkv, self._flash_ws[0], B, H, T, self.mm is not None)
+            else:
+                self._attention_bwd_materialized(qkv, P, datt, dqkv, B, T, H, hd, d, scale, new)
             dh1 = new(R, d)
             ops.linear_bwd(c["h1"], p[q + "attn.c_attn.weight"], dqkv, dh1, grads[q + "attn.c_attn.weight"], grads[q + "attn.c_attn.bias"], R, d, 3 * d, ws, mm=self.mm)
             ops.layernorm_bwd(dh1, c["x_in"], p[q + "ln_1.weight"], c["m1"], c["r1"], dx, tmp, R, d, True)    # dx := dx_in
@@ -245,6 +253,22 @@ class GPT2F32:
         if on_final is not None:
             on_final(["wpe.weight", "wte.weight"])
         return grads
+
+    def _attention_bwd_materialized(self, qkv, P, datt, dqkv, B, T, H, hd, d, scale, new):
+        """dqkv from the stored probabilities P [B*H, T, T] (batched sgemm + softmax backward)."""
+        # dV = P^T dA
+        ops.sgemm(P, datt, dqkv, T, hd, T, trans_a=True, lda=T, ldb=d, ldc=3 * d, c_off=2 * d, batch=(B, H), sa=(H * T * T, T * T),
+                  sb=(T * d, hd), sc=(T * 3 * d, hd))
+        # dP = dA V^T ; dS = softmax_bwd
+        dP = new(B * H, T, T)
+        ops.sgemm(datt, qkv, dP, T, T, hd, trans_b=True, lda=d, ldb=3 * d, ldc=T, b_off=2 * d, batch=(B, H), sa=(T * d, hd),
+                  sb=(T * 3 * d, hd), sc=(H * T * T, T * T))
+        ops.softmax_bwd(P, dP, B * H * T, T)
+        # dQ = scale * dS K ; dK = scale * dS^T Q
+        ops.sgemm(dP, qkv, dqkv, T, hd, T, alpha=scale, lda=T, ldb=3 * d, ldc=3 * d, b_off=d, batch=(B, H), sa=(H * T * T, T * T),
+                  sb=(T * 3 * d, hd), sc=(T * 3 * d, hd))
+        ops.sgemm(dP, qkv, dqkv, T, hd, T, trans_a=True, alpha=scale, lda=T, ldb=3 * d, ldc=3 * d, c_off=d, batch=(B, H),
+                  sa=(H * T * T, T * T), sb=(T * 3 * d, hd), sc=(T * 3 * d, hd))
 
 
 # ---------------------------------------------------------------------- value heads (LLM_RL/heads/{linear_head,mlp_head}.py)

@@ -190,3 +190,20 @@ def ce_bwd(logits, ld, vocab, lse, targets, coef_ce, coef_gather, rows):
 
 def mask_sum(sta, attn, n, out):
     _lib.check(_L().lmrl_mask_sum(_lib.ptr(sta), _lib.ptr(attn), n, out.data_ptr(), _sp()), "lmrl_mask_sum")
+
+
+def flash_attn_ws(batch, heads, t, bf16, device):
+    import torch
+    L = _L()
+    return (torch.empty(L.lmrl_flash_attn_ws_bytes(batch, heads, t, int(bf16)), dtype=torch.uint8, device=device),
+            L.lmrl_flash_attn_lse_bytes(batch, heads, t) // 4)
+
+
+def flash_attn_fwd(qkv, key_mask, att, lse, ws, batch, heads, t, bf16):
+    _lib.check(_L().lmrl_flash_attn_fwd(qkv.data_ptr(), _lib.ptr(key_mask), att.data_ptr(), lse.data_ptr(), ws.data_ptr(), batch, heads, t, int(bf16),
+                                        _sp()), "lmrl_flash_attn_fwd")
+
+
+def flash_attn_bwd(qkv, key_mask, att, datt, lse, dqkv, ws, batch, heads, t, bf16):
+    _lib.check(_L().lmrl_flash_attn_bwd(qkv.data_ptr(), _lib.ptr(key_mask), att.data_ptr(), datt.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
+                                        ws.data_ptr(), batch, heads, t, int(bf16), _sp()), "lmrl_flash_attn_bwd")
