@@ -225,6 +225,10 @@ int lmrl_gpt2_kv_gather(const lmrl_gpt2 *m, const void *src_kv_d, int src_b, int
  * 3 f32, 4 relu->bf16.  Used for the value heads (heads/linear_head.py:112-119, heads/mlp_head.py:139-148). */
 int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda,
                    int ldc, int n_store, int epilogue, void *stream);
+/* same with an explicit row pitch of W (ldw elements, >= k; 0 = dense): operands whose natural pitch is a large power of two (the
+ * transposed operands of the train step's dW products, k = B*T) are padded so that the rows of a tile do not all start in one HBM channel */
+int lmrl_gemm_bf16_ld(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc, int n_store,
+                      int epilogue, void *stream);
 
 /* TOOLS ONLY (tools/bench_gemm.py tile-configuration sweeps; never called by the package): forces a GEMM tile configuration,
  * 0 = the shape policy, 1 = the round-1 register-staged kernels, 10.. = fixed tiles. */

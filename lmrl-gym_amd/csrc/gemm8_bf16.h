@@ -33,7 +33,8 @@ struct G8NoHook { __device__ __forceinline__ void operator()() const {} };
 // issued: either plain global loads whose results are first used after the loop (they fly under it), or a block that ends with
 // vmcnt(0) (the LayerNorm moments, which need LDS scratch OUTSIDE the ring: every slot is being filled).
 template <int BM, int BN, int WM, int WN, int STAGES, class Head = G8NoHook>
-__device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int lda, const uint16_t *__restrict__ W, int K, int Mr, int m0, int n0,
+__device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int lda, const uint16_t *__restrict__ W, int ldw, int K, int Mr, int m0,
+                                            int n0,
                                             char *smem, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], Head head = Head()) {
     constexpr int NW = WM * WN, BK = 64;
     constexpr int TM = BM / WM, TN = BN / WN;            // per-wave output tile
@@ -58,7 +59,7 @@ __device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int 
         ap[i] = A + (size_t)m * lda + src_c * 8;
     }
 #pragma unroll
-    for (int i = 0; i < LW; i++) wp[i] = W + (size_t)(n0 + (wave + NW * i) * 8 + lrow) * K + src_c * 8;
+    for (int i = 0; i < LW; i++) wp[i] = W + (size_t)(n0 + (wave + NW * i) * 8 + lrow) * ldw + src_c * 8;
 
 #define LMRL_G8_ISSUE(KT, SLOT)                                                                                       \
     do {                                                                                                              \
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
                 ln_mu[j] = p2.x; ln_rs[j] = p2.y;
             }
         };
-        g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc, head);
+        g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, head);
     } else if (RESID) {
         auto prefetch = [&]() {
 #pragma unroll
@@ -226,9 +227,9 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
                     xres[i][j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(g.C) + (size_t)m * g.ldc + n);
                 }
         };
-        g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc, prefetch);
+        g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, prefetch);
     } else {
-        g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc);
+        g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc);
     }
     LMRL_G8_STAMP(2);
 

@@ -107,6 +107,9 @@ struct GemmArgs {
     int nslots;           // consumer: slots to add per row ; producer: row pitch of `stats`
     float inv_d, eps;     // consumer: 1/d_model, LN epsilon
     const int *m_dev;     // optional DEVICE row count (<= M): ragged batches — tiles beyond it exit, `M` then only sizes the grid
+    int ldw;              // row pitch of W in elements (0: dense, = K).  Operands whose natural pitch is a large power of two (the
+                          // transposed train-step operands, K = B*T) are padded by the caller: every row of a tile would otherwise
+                          // start in the same HBM channel
 };
 
 template <int BM, int BN, int EPI>
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
         }                                                                                                          \
         _Pragma("unroll") for (int i_ = 0; i_ < W_CH; i_++) {                                                      \
             const int id_ = tid + i_ * 256, row_ = id_ >> 3, c_ = id_ & 7;                                         \
-            rw[i_] = *reinterpret_cast<const u32x4 *>(g.W + (size_t)(n0 + row_) * g.K + (size_t)(KT) * BK + c_ * 8); \
+            rw[i_] = *reinterpret_cast<const u32x4 *>(g.W + (size_t)(n0 + row_) * (g.ldw > 0 ? g.ldw : g.K) + (size_t)(KT) * BK + c_ * 8); \
         }                                                                                                          \
     } while (0)
 #define LMRL_GEMM_STORE_TILES(BUF)                                                                                 \
@@ -281,7 +284,7 @@ struct NoExtraLoads { __device__ __forceinline__ void operator()() const {} };
 // prologue; vmcnt retires loads in order, so the wait for the first K-tile allows them to stay in flight and their
 // latency hides behind the K loop (they are complete by the second wait; with nk == 1 the caller's own use waits).
 template <int BM, int BN, int STAGES, int EXTRA = 0, class Extra = NoExtraLoads>
-__device__ __forceinline__ void glds_mainloop(const uint16_t *__restrict__ A, int lda, const uint16_t *__restrict__ W, int K, int M,
+__device__ __forceinline__ void glds_mainloop(const uint16_t *__restrict__ A, int lda, const uint16_t *__restrict__ W, int ldw, int K, int M,
                                               int m0, int n0, char *smem, f32x4 (&acc)[BN / 32][BM / 32], Extra extra = Extra()) {
     constexpr int BK = 64;
     constexpr int FM = BM / 32, FN = BN / 32;
@@ -303,7 +306,7 @@ __device__ __forceinline__ void glds_mainloop(const uint16_t *__restrict__ A, in
         ap[i] = A + (size_t)m * lda + src_c * 8;
     }
 #pragma unroll
-    for (int i = 0; i < LW; i++) wp[i] = W + (size_t)(n0 + (wave + 4 * i) * 8 + lrow) * K + src_c * 8;
+    for (int i = 0; i < LW; i++) wp[i] = W + (size_t)(n0 + (wave + 4 * i) * 8 + lrow) * ldw + src_c * 8;
 
 #define LMRL_GLDS_ISSUE(KT, SLOT)                                                                                     \
     do {                                                                                                              \
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is handed to the ring at the loop's first barrier
         };
-        glds_mainloop<BM, BN, STAGES, 0>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc, head);
+        glds_mainloop<BM, BN, STAGES, 0>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, head);
     } else if (RESID) {
         // read-modify-write epilogue: fetch this lane's residual values NOW (FN*FM float4 loads behind the ring prologue, in-order
         // vmcnt: the counted waits of the loop leave them in flight) so that the epilogue does not start with a dependent HBM round trip
@@ -461,9 +464,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
                     xres[i][j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(g.C) + (size_t)m * g.ldc + n);
                 }
         };
-        glds_mainloop<BM, BN, STAGES, FN * FM>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc, prefetch);
+        glds_mainloop<BM, BN, STAGES, FN * FM>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, prefetch);
     } else {
-        glds_mainloop<BM, BN, STAGES>(g.A, g.lda, g.W, g.K, Mr, m0, n0, smem, acc);
+        glds_mainloop<BM, BN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc);
     }
     LMRL_G8_STAMP(2);
 

@@ -72,17 +72,34 @@ inline hipError_t gemm_launch(const GemmArgs &g, hipStream_t s) {
         case 102: if (g.M < 2048) return g.K >= 2048 ? gemm_launch_glds<128, 64, 3, EPI>(g, s) : gemm_launch_glds<64, 64, 2, EPI>(g, s); break;
         case 103: if (g.M < 2048) return g.K >= 2048 ? gemm_launch_glds<64, 64, 3, EPI>(g, s) : gemm_launch_glds<64, 64, 2, EPI>(g, s); break;
         case 104: if (g.M >= 2048) return gemm_launch_glds<128, 128, 2, EPI>(g, s); break;
+        case 40: if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32) return gemm8_launch<128, 128, 2, 4, 2, EPI>(g, s); break;
+        case 41: if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32) return gemm8_launch<256, 128, 4, 2, 3, EPI>(g, s); break;
+        case 42: if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32) return gemm8_launch<128, 256, 2, 4, 3, EPI>(g, s); break;
+        case 43: if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32) return gemm8_launch<256, 128, 4, 2, 2, EPI>(g, s); break;
+        case 44: if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32) return gemm8_launch<256, 256, 2, 4, 2, EPI>(g, s); break;
         default: break;
     }
     // measured on MI355X (profiles/r01_gemm_config_sweep.txt + in-situ sweeps): the prefill GEMMs (M >= 2048, thousands of
     // tiles) want occupancy: 2-stage rings, 3 workgroups per CU.  The decode GEMMs (M = 1024) have only 192-768 tiles, i.e.
     // 1-3 per CU, and are bound by the latency chain of their K loop: as many stages as still leave every tile resident
     // at once (768 tiles: 3 stages = 48 KiB -> 3 WG/CU; 192 tiles: 4 stages = 64 KiB -> 2 WG/CU).
+    if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32) {
+        // fp32-output products of the train step's bf16-matmul mode (M = B*T = 16 k rows, or the vocabulary): 256x256 tiles halve the LDS
+        // and L2 traffic per flop; taken when the tile count fills whole rounds of the 256 CUs (tools/bench_train_gemm.py, profiles/r02_train_gemm_sweep.txt:
+        // fc / fc2 / dX / head products 95-1450 us vs 117-3690 us; the 576-tile qkv product stays on 128x128)
+        const long t256 = (long)((g.M + 255) / 256) * (g.N / 256);
+        if (g.M >= 4096 && g.N % 256 == 0 && (g.K >= 2048 || t256 <= 256 || t256 % 256 == 0 || t256 >= 1024))
+            return gemm8_launch<256, 256, 2, 4, 2, EPI>(g, s);
+    }
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || EPI == EPI_F32) {
         if (g.M >= 2048 && g.N % 128 == 0 && g.K < 2048) return gemm8_launch<128, 128, 2, 4, 2, EPI>(g, s);   // wide prefill GEMMs: 8-wave 128x128 tiles
     }
     if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI>(g, s);
-    if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI>(g, s);
+    if (g.K >= 2048) {
+        // dW products (K = B*T): more 64x64 tiles than can be co-resident (512) -> 128x128 tiles in one round (dw fc: 165 vs 228 us)
+        if (g.N % 128 == 0 && (long)((g.M + 63) / 64) * (g.N / 64) > 512) return gemm_launch_glds<128, 128, 2, EPI>(g, s);
+        return gemm_launch_glds<64, 64, 4, EPI>(g, s);
+    }
     const long tiles = (long)((g.M + 63) / 64) * (g.N / 64);
     if (tiles <= 512) return gemm_launch_glds<64, 64, 4, EPI>(g, s);      // 64 KiB ring -> 2 WG/CU -> 512 resident tiles
     if (tiles <= 768) return gemm_launch_glds<64, 64, 3, EPI>(g, s);      // 48 KiB ring -> 3 WG/CU -> 768 resident tiles

@@ -1028,11 +1028,13 @@ int lmrl_gpt2_kv_gather(const lmrl_gpt2 *m, const void *src_kv_d, int src_b, int
 void lmrl_gemm_set_variant(int v) { lmrl::g_gemm_variant = v; }
 
 // Plain bf16 GEMM entry (heads, LM-head logits): C = A.W^T + bias with a selectable epilogue.
-int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda,
-                   int ldc, int n_store, int epilogue, void *stream) {
+int lmrl_gemm_bf16_ld(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc, int n_store,
+                      int epilogue, void *stream) {
     LMRL_REQUIRE(a_d && w_d && c_d && m > 0 && n > 0 && k > 0, "lmrl_gemm_bf16: bad argument");
-    LMRL_REQUIRE(n % 64 == 0 && k % 64 == 0 && lda % 8 == 0 && ldc % 4 == 0, "lmrl_gemm_bf16: n, k must be multiples of 64");
+    LMRL_REQUIRE(n % 64 == 0 && k % 64 == 0 && lda % 8 == 0 && ldc % 4 == 0 && lda >= k && (ldw == 0 || (ldw >= k && ldw % 8 == 0)),
+                 "lmrl_gemm_bf16: n, k must be multiples of 64 and the operand pitches multiples of 8 elements covering k");
     GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, bias_d, c_d, m, n, k, lda, ldc, n_store > 0 ? n_store : n};
+    g.ldw = ldw;
     hipStream_t s = as_stream(stream);
     switch (epilogue) {
         case EPI_BF16: LMRL_CHECK_HIP(gemm_launch<EPI_BF16>(g, s)); break;
@@ -1043,5 +1045,10 @@ int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *
         default: LMRL_REQUIRE(false, "lmrl_gemm_bf16: unknown epilogue");
     }
     return LMRL_OK;
+}
+
+int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda, int ldc, int n_store, int epilogue,
+                   void *stream) {
+    return lmrl_gemm_bf16_ld(a_d, w_d, bias_d, c_d, m, n, k, lda, 0, ldc, n_store, epilogue, stream);
 }
 }

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const
         for (int i = 0; i < FN; i++)
 #pragma unroll
             for (int j = 0; j < FM; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        g8_mainloop<BM, BN, WM, WN, kLmStages>(A, K, W, K, M, m0, n0, smem, acc);
+        g8_mainloop<BM, BN, WM, WN, kLmStages>(A, K, W, K, K, M, m0, n0, smem, acc);
 #pragma unroll
         for (int i = 0; i < FN; i++) {
             const int n = n0 + wn * TN + i * 16 + lq * 4;

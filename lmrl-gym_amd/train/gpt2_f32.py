@@ -167,7 +167,7 @@ class GPT2F32:
         else:
             hb = mm.cast("x", hidden, rows, d, d)
             wb = mm.cast(("w", self.p["wte.weight"].data_ptr()), self.p["wte.weight"], V, d, d, keep=True)           # [pad(V)][d]
-            mm.gemm(hb, wb, None, logits, rows, ops._pad(V), ops._pad(d), ops._pad(d), ld, V)
+            mm.gemm(hb, wb, None, logits, rows, ops._padn(V), d, ld, V)
         return logits
 
     # ------------------------------------------------------------------ backward
@@ -197,10 +197,10 @@ class GPT2F32:
             return
         dlb = mm.cast("dy", dlogits, rows, V, ld)                                                                      # [rows][pad(V)]
         wt = mm.cast(("wT", self.p["wte.weight"].data_ptr()), self.p["wte.weight"], V, d, d, transpose=True, keep=True)  # [d][pad(V)]
-        mm.gemm(dlb, wt, None, d_hidden, rows, ops._pad(d), ops._pad(V), ops._pad(V), d, d, accumulate=accumulate_dh)
+        mm.gemm(dlb, wt, None, d_hidden, rows, ops._pad(d), V, d, d, accumulate=accumulate_dh)
         dlt = mm.cast("dyT", dlogits, rows, V, ld, transpose=True)                                                     # [pad(V)][pad(rows)]
         ht = mm.cast("xT", hidden, rows, d, d, transpose=True)                                                         # [d][pad(rows)]
-        mm.gemm(dlt, ht, None, grads["wte.weight"], V, ops._pad(d), ops._pad(rows), ops._pad(rows), d, d, accumulate=True)
+        mm.gemm(dlt, ht, None, grads["wte.weight"], V, ops._pad(d), rows, d, d, accumulate=True)
 
     def backward(self, cache, d_hidden, grads: Dict[str, "torch.Tensor"], on_final=None):
         """d_hidden: gradient w.r.t. the final (post ln_f) hidden states [B*T, d]; accumulates into `grads`.

@@ -30,6 +30,19 @@ def _pad(n: int, m: int = 64) -> int:
     return -(-n // m) * m
 
 
+def _padn(n: int) -> int:
+    """Padded N extent (rows of a staged W operand): vocabulary-sized extents go to multiples of 256 so that the 256x256-tile kernel
+    applies; everything else to multiples of 64."""
+    return _pad(n, 256) if n >= 8192 else _pad(n)
+
+
+def _pitch(k: int) -> int:
+    """Row pitch (elements) of a staged bf16 operand with K extent k: pad64(k), plus 64 elements when that is a multiple of 512 elements
+    (1 KiB): with a power-of-two pitch every row of a GEMM tile starts in the same HBM channel (measured 3x on the dW products, K = B*T)."""
+    kp = _pad(k)
+    return kp + 64 if kp % 512 == 0 else kp
+
+
 class MatmulBF16:
     """The train step's bf16-MFMA matmul mode (the reference's optional `bf16_activations`, train_ilql_gpt2.py:193): every Dense / Conv1D
     product of forward and backward runs on the rollout engine's bf16 GEMM kernels (`lmrl_gemm_bf16`: fp32 accumulation, fp32 outputs);
@@ -56,7 +69,7 @@ class MatmulBF16:
         transpose=True [pad64(cols)][pad64(rows)] = x^T; padding zero-filled.  keep=True: a per-step weight copy keyed by `name`."""
         if keep and name in self.w:
             return self.w[name]
-        rd, ld = (_pad(rows), _pad(cols)) if not transpose else (_pad(cols), _pad(rows))
+        rd, ld = (_padn(rows), _pitch(cols)) if not transpose else (_padn(cols), _pitch(rows))
         dst = self.t.empty(rd * ld, dtype=self.t.bfloat16, device=self.dev) if keep else self._buf(name, rd * ld)
         _lib.check(_L().lmrl_cast_bf16(x.data_ptr(), ld_src, rows, cols, dst.data_ptr(), ld, rd, int(transpose), _sp()), "lmrl_cast_bf16")
         if keep:
@@ -67,15 +80,17 @@ class MatmulBF16:
         """fp32 bias padded to a multiple of 64 entries (the GEMM epilogue reads whole 4-column groups)."""
         key = ("bias", b.data_ptr())
         if key not in self.w:
-            bp = self.t.zeros(_pad(n), dtype=self.t.float32, device=self.dev)
+            bp = self.t.zeros(_padn(n), dtype=self.t.float32, device=self.dev)
             bp[:n].copy_(b)
             self.w[key] = bp
         return self.w[key]
 
-    def gemm(self, a, w, bias, c, m, n, k, lda, ldc, n_store, accumulate=False):
-        """c[m][n_store] (=|+=) a[m][k] . w[n][k]^T + bias, fp32 out (lmrl_gemm_bf16 epilogues 3 / 2)."""
-        _lib.check(_L().lmrl_gemm_bf16(a.data_ptr(), w.data_ptr(), _lib.ptr(bias), c.data_ptr(), m, n, k, lda, ldc, n_store, 2 if accumulate else 3,
-                                       _sp()), "lmrl_gemm_bf16")
+    def gemm(self, a, w, bias, c, m, n, k, ldc, n_store, accumulate=False):
+        """c[m][n_store] (=|+=) a[m][k] . w[n][k]^T + bias, fp32 out (lmrl_gemm_bf16 epilogues 3 / 2); a, w staged by `cast`
+        (row pitch _pitch(k))."""
+        ld = _pitch(k)
+        _lib.check(_L().lmrl_gemm_bf16_ld(a.data_ptr(), w.data_ptr(), _lib.ptr(bias), c.data_ptr(), m, n, _pad(k), ld, ld, ldc, n_store,
+                                          2 if accumulate else 3, _sp()), "lmrl_gemm_bf16")
 
 
 def linear_fwd(x, w, b, y, rows, k, n, mm: Optional[MatmulBF16] = None, ldy=None):
@@ -87,7 +102,7 @@ def linear_fwd(x, w, b, y, rows, k, n, mm: Optional[MatmulBF16] = None, ldy=None
     assert ldy % 4 == 0 and ldy >= _pad(n, 4), "bf16 matmul mode: the output row stride must cover whole 4-column groups"
     xb = mm.cast("x", x, rows, k, k)
     wt = mm.cast(("wT", w.data_ptr()), w, k, n, n, transpose=True, keep=True)          # [pad(n)][pad(k)]
-    mm.gemm(xb, wt, mm.bias(b, n) if b is not None else None, y, rows, _pad(n), _pad(k), _pad(k), ldy, n)
+    mm.gemm(xb, wt, mm.bias(b, n) if b is not None else None, y, rows, _padn(n), k, ldy, n)
 
 
 def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_beta=0.0, mm: Optional[MatmulBF16] = None, lddy=None):
@@ -103,14 +118,14 @@ def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_b
             dyb = mm.cast("dy", dy, rows, n, lddy)                                      # [rows][pad(n)]
             assert k % 64 == 0, "bf16 matmul mode: layer widths must be multiples of 64"
             wb = mm.cast(("w", w.data_ptr()), w, k, n, n, keep=True)                     # [k][pad(n)]
-            mm.gemm(dyb, wb, None, dx, rows, k, _pad(n), _pad(n), k, k, accumulate=dx_beta == 1.0)
+            mm.gemm(dyb, wb, None, dx, rows, k, n, k, k, accumulate=dx_beta == 1.0)
         xt = mm.cast("xT", x, rows, k, k, transpose=True)                               # [pad(k)][pad(rows)]
         dyt = mm.cast("dyT", dy, rows, n, lddy, transpose=True)                         # [pad(n)][pad(rows)]
         if n % 4 == 0:
-            mm.gemm(xt, dyt, None, dw, k, _pad(n), _pad(rows), _pad(rows), n, n, accumulate=accumulate_dw)
+            mm.gemm(xt, dyt, None, dw, k, _padn(n), rows, n, n, accumulate=accumulate_dw)
         else:   # rows of dw are not 16-byte aligned: produce dw^T [n][k] and add its transpose
             tmp = mm.t.empty(n, k, dtype=mm.t.float32, device=mm.dev)
-            mm.gemm(dyt, xt, None, tmp, n, _pad(k), _pad(rows), _pad(rows), k, k)
+            mm.gemm(dyt, xt, None, tmp, n, _pad(k), rows, k, k)
             _lib.check(_L().lmrl_transpose_add_f32(tmp.data_ptr(), k, dw.data_ptr(), n, n, k, 1.0 if accumulate_dw else 0.0, _sp()),
                        "lmrl_transpose_add_f32")
     if db is not None:
