@@ -436,6 +436,11 @@ int lmrl_flash_attn_bwd(const float *qkv_d, const uint8_t *key_mask_d, const flo
  * lmrl_cast_bf16: dst [rows_dst][ld_dst] bf16 := round-to-nearest-even of src [rows][cols] fp32 (transpose = 0) or of its transpose
  * (transpose = 1: dst[c][r] = src[r][c]); everything outside the source extent is zero-filled (K padding to multiples of 64). */
 int lmrl_cast_bf16(const float *src_d, long ld_src, int rows, int cols, void *dst_d, long ld_dst, int rows_dst, int transpose, void *stream);
+/* transposed cast (as lmrl_cast_bf16 with transpose = 1) that also produces colsum_d[c] (=|+=) sum_r src[r][c] — the bias gradient of a
+ * Dense layer falls out of staging dy^T for the dW product instead of a second pass over dy.  ws_d: lmrl_cast_bf16_t_colsum_ws_bytes. */
+size_t lmrl_cast_bf16_t_colsum_ws_bytes(int rows, int rows_dst);
+int lmrl_cast_bf16_t_colsum(const float *src_d, long ld_src, int rows, int cols, void *dst_d, long ld_dst, int rows_dst, float *colsum_d,
+                            int accumulate, float *ws_d, void *stream);
 /* dst[j][i] = beta*dst[j][i] + src[i][j]   (src [n][k] -> dst [k][n]): gradients produced in transposed form */
 int lmrl_transpose_add_f32(const float *src_d, long ld_src, float *dst_d, long ld_dst, int n, int k, float beta, void *stream);
 /* out[r] = sum_j a[r][j]*w[j][idx[r]] + bias[idx[r]]: the one column of a Dense layer that `take_along_axis(logits, token)` reads —

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict_
 // dst[c][r] = bf16(src[r][c]) for r < rows, c < cols; zero elsewhere in [rows_dst][ld_dst].  64 x 64 tiles through LDS: coalesced 256-B
 // reads along c, 128-B writes along r.
 __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float *__restrict__ src, long ld_src, int rows, int cols, uint16_t *__restrict__ dst,
-                                                          long ld_dst, int rows_dst) {
+                                                          long ld_dst, int rows_dst, float *__restrict__ colpart) {
     __shared__ float tile[64][65];
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -54,6 +54,11 @@ __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float *__restric
         tile[ty + k * 4][tx] = (r < rows && c < cols) ? src[(long)r * ld_src + c] : 0.f;
     }
     __syncthreads();
+    if (colpart && threadIdx.x < 64 && r0 < rows) {      // this 64-row block's share of the column sums (the bias gradient of the layer): fixed order
+        float sum = 0.f;
+        for (int r = 0; r < 64; r++) sum += tile[r][threadIdx.x];
+        if (c0 + (int)threadIdx.x < rows_dst) colpart[(long)blockIdx.x * rows_dst + c0 + threadIdx.x] = sum;
+    }
     // out row = c0 + cc, 64 r-values = 128 B: 8 lanes x 16 B per row, 32 rows per pass
     const int rr8 = (threadIdx.x & 7) * 8, cc = threadIdx.x >> 3;
 #pragma unroll
@@ -67,6 +72,22 @@ __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float *__restric
             *reinterpret_cast<uint4 *>(dst + (long)c * ld_dst + r0 + rr8) = o;
         }
     }
+}
+
+// out[c] (+)= sum over row blocks of colpart[rb][c], in row-block order (deterministic)
+__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float *__restrict__ colpart, int nrb, int ldp, int cols, float *__restrict__ out,
+                                                             int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int rb = 0;
+    for (; rb + 3 < nrb; rb += 4) {
+        s0 += colpart[(long)rb * ldp + c]; s1 += colpart[(long)(rb + 1) * ldp + c];
+        s2 += colpart[(long)(rb + 2) * ldp + c]; s3 += colpart[(long)(rb + 3) * ldp + c];
+    }
+    for (; rb < nrb; rb++) s0 += colpart[(long)rb * ldp + c];
+    const float s = (s0 + s1) + (s2 + s3);
+    out[c] = accumulate ? out[c] + s : s;
 }
 
 // dst[j][i] = beta * dst[j][i] + src[i][j]   (src [n][k], dst [k][n]): 32 x 32 tiles through LDS
@@ -123,8 +144,23 @@ int lmrl_cast_bf16(const float *src_d, long ld_src, int rows, int cols, void *ds
     } else {
         LMRL_REQUIRE(rows_dst >= cols && ld_dst >= rows, "lmrl_cast_bf16: destination smaller than the transposed source");
         hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((int)((ld_dst + 63) / 64), (rows_dst + 63) / 64), dim3(256), 0, s, src_d, ld_src, rows, cols,
-                           (uint16_t *)dst_d, ld_dst, rows_dst);
+                           (uint16_t *)dst_d, ld_dst, rows_dst, (float *)nullptr);
     }
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+size_t lmrl_cast_bf16_t_colsum_ws_bytes(int rows, int rows_dst) { return (size_t)((rows + 63) / 64) * (size_t)rows_dst * sizeof(float); }
+
+int lmrl_cast_bf16_t_colsum(const float *src_d, long ld_src, int rows, int cols, void *dst_d, long ld_dst, int rows_dst, float *colsum_d,
+                            int accumulate, float *ws_d, void *stream) {
+    LMRL_REQUIRE(src_d && dst_d && colsum_d && ws_d && rows > 0 && cols > 0 && ld_dst % 8 == 0 && rows_dst >= cols && ld_dst >= rows,
+                 "lmrl_cast_bf16_t_colsum: bad argument");
+    hipStream_t s = as_stream(stream);
+    const int nrb = (rows + 63) / 64;       // row blocks that hold source rows (blocks beyond only zero-fill the padding)
+    hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((int)((ld_dst + 63) / 64), (rows_dst + 63) / 64), dim3(256), 0, s, src_d, ld_src, rows, cols,
+                       (uint16_t *)dst_d, ld_dst, rows_dst, ws_d);
+    hipLaunchKernelGGL(colpart_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, (const float *)ws_d, nrb, rows_dst, cols, colsum_d, accumulate);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

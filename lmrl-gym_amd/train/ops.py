@@ -64,13 +64,21 @@ class MatmulBF16:
             b = self.scratch[name] = self.t.empty(numel, dtype=self.t.bfloat16, device=self.dev)
         return b
 
-    def cast(self, name, x, rows, cols, ld_src, transpose=False, keep=False):
+    def cast(self, name, x, rows, cols, ld_src, transpose=False, keep=False, colsum=None):
         """K-major bf16 operand of `lmrl_gemm_bf16` from fp32 x [rows][cols] (row stride ld_src): [rows][pad64(cols)], or for
-        transpose=True [pad64(cols)][pad64(rows)] = x^T; padding zero-filled.  keep=True: a per-step weight copy keyed by `name`."""
+        transpose=True [pad64(cols)][pad64(rows)] = x^T; padding zero-filled.  keep=True: a per-step weight copy keyed by `name`.
+        colsum=(out, accumulate) (transpose only): also out[c] (=|+=) sum_r x[r][c]."""
         if keep and name in self.w:
             return self.w[name]
         rd, ld = (_padn(rows), _pitch(cols)) if not transpose else (_padn(cols), _pitch(rows))
         dst = self.t.empty(rd * ld, dtype=self.t.bfloat16, device=self.dev) if keep else self._buf(name, rd * ld)
+        if colsum is not None:
+            assert transpose
+            nws = _L().lmrl_cast_bf16_t_colsum_ws_bytes(rows, rd) // 2
+            ws = self._buf("colsum_ws", nws)
+            _lib.check(_L().lmrl_cast_bf16_t_colsum(x.data_ptr(), ld_src, rows, cols, dst.data_ptr(), ld, rd, colsum[0].data_ptr(), int(colsum[1]),
+                                                    ws.data_ptr(), _sp()), "lmrl_cast_bf16_t_colsum")
+            return dst
         _lib.check(_L().lmrl_cast_bf16(x.data_ptr(), ld_src, rows, cols, dst.data_ptr(), ld, rd, int(transpose), _sp()), "lmrl_cast_bf16")
         if keep:
             self.w[name] = dst
@@ -120,7 +128,8 @@ def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_b
             wb = mm.cast(("w", w.data_ptr()), w, k, n, n, keep=True)                     # [k][pad(n)]
             mm.gemm(dyb, wb, None, dx, rows, k, n, k, k, accumulate=dx_beta == 1.0)
         xt = mm.cast("xT", x, rows, k, k, transpose=True)                               # [pad(k)][pad(rows)]
-        dyt = mm.cast("dyT", dy, rows, n, lddy, transpose=True)                         # [pad(n)][pad(rows)]
+        dyt = mm.cast("dyT", dy, rows, n, lddy, transpose=True, colsum=(db, accumulate_dw) if db is not None else None)   # [pad(n)][pad(rows)]
+        db = None                                                                       # the bias gradient came out of the staging pass
         if n % 4 == 0:
             mm.gemm(xt, dyt, None, dw, k, _padn(n), rows, n, n, accumulate=accumulate_dw)
         else:   # rows of dw are not 16-byte aligned: produce dw^T [n][k] and add its transpose
