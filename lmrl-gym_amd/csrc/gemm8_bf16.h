@@ -61,6 +61,9 @@ __device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int 
 #pragma unroll
     for (int i = 0; i < LW; i++) wp[i] = W + (size_t)(n0 + (wave + NW * i) * 8 + lrow) * ldw + src_c * 8;
 
+#ifndef LMRL_G8_W_AUX
+#define LMRL_G8_W_AUX 0   /* cache policy bits of the weight-stream loads (tools: -DLMRL_G8_W_AUX=2 = nt) */
+#endif
 #define LMRL_G8_ISSUE(KT, SLOT)                                                                                       \
     do {                                                                                                              \
         char *sb_ = smem + (SLOT) * STAGE;                                                                            \
@@ -69,7 +72,7 @@ __device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int 
                                              (__attribute__((address_space(3))) void *)(sb_ + (wave + NW * i_) * 1024), 16, 0, 0); \
         _Pragma("unroll") for (int i_ = 0; i_ < LW; i_++)                                                             \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wp[i_] + (size_t)(KT) * BK), \
-                                             (__attribute__((address_space(3))) void *)(sb_ + BM * 128 + (wave + NW * i_) * 1024), 16, 0, 0); \
+                                             (__attribute__((address_space(3))) void *)(sb_ + BM * 128 + (wave + NW * i_) * 1024), 16, 0, LMRL_G8_W_AUX); \
     } while (0)
 #define LMRL_G8_READ(FW, FA, SLOT, KK)                                                                                \
     do {                                                                                                              \
@@ -145,13 +148,77 @@ __device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int 
         LMRL_G8_MFMA(fw1, fa1);
         slot = nslot;
     }
+}
+
+// Two K-steps per barrier on a 4-slot ring (slots {0,1} and {2,3} alternate): for GEMMs with ONE resident workgroup per CU (decode, M ~ 1024:
+// 144-192 tiles of 128x128) the K loop is a dependent chain — fragment reads -> lgkmcnt(0) -> barrier -> next reads — that costs ~0.33 us per
+// K-step before any MFMA or fetch (DESIGN.md 6b ablation); pairing the steps halves the number of barriers and drains, and keeps two whole
+// stages (64 KB) in flight across each pair.  128 KB of LDS: affordable exactly because nothing else shares the CU.  K / 64 must be even.
+template <int BM, int BN, int WM, int WN, class Head = G8NoHook>
+__device__ __forceinline__ void g8_mainloop_pair(const uint16_t *__restrict__ A, int lda, const uint16_t *__restrict__ W, int ldw, int K, int Mr,
+                                                 int m0, int n0, char *smem, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], Head head = Head()) {
+    constexpr int NW = WM * WN, BK = 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int LA = BM / 8 / NW, LW = BN / 8 / NW;
+    constexpr int L = LA + LW;
+    constexpr int STAGE = (BM + BN) * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int np = K / BK / 2;                              // pairs of K-steps
+    const int lrow = lane >> 3, src_c = (lane & 7) ^ lrow;
+    const uint16_t *ap[LA];
+    const uint16_t *wp[LW];
+#pragma unroll
+    for (int i = 0; i < LA; i++) {
+        int m = m0 + (wave + NW * i) * 8 + lrow;
+        m = m < Mr ? m : Mr - 1;
+        ap[i] = A + (size_t)m * lda + src_c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < LW; i++) wp[i] = W + (size_t)(n0 + (wave + NW * i) * 8 + lrow) * ldw + src_c * 8;
+
+    __builtin_amdgcn_s_barrier();
+    LMRL_G8_ISSUE(0, 0);
+    LMRL_G8_ISSUE(1, 1);
+    if (np > 1) { LMRL_G8_ISSUE(2, 2); LMRL_G8_ISSUE(3, 3); }
+    asm volatile("" ::: "memory");
+    head();
+    asm volatile("" ::: "memory");
+    if (np > 1) wait_vmcnt<2 * L>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    LMRL_G8_STAMP(1);
+    bf16x8 fw0[FN], fa0[FM], fw1[FN], fa1[FM];
+    LMRL_G8_READ(fw0, fa0, 0, 0);
+    int a = 0;
+    for (int u = 0; u < np; u++) {
+        const int b = a + 1, an = a ^ 2;
+        LMRL_G8_READ(fw1, fa1, a, 1);
+        LMRL_G8_MFMA(fw0, fa0);
+        LMRL_G8_READ(fw0, fa0, b, 0);
+        LMRL_G8_MFMA(fw1, fa1);
+        LMRL_G8_READ(fw1, fa1, b, 1);
+        LMRL_G8_MFMA(fw0, fa0);
+        if (u + 1 < np) {
+            wait_vmcnt<0>();                                // the next pair (issued one pair ago) has landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // ... for every wave, and every wave holds this pair in registers
+            if (u + 2 < np) { LMRL_G8_ISSUE(2 * u + 4, a); LMRL_G8_ISSUE(2 * u + 5, b); }
+            LMRL_G8_READ(fw0, fa0, an, 0);
+        }
+        LMRL_G8_MFMA(fw1, fa1);
+        a = an;
+    }
+}
 #undef LMRL_G8_ISSUE
 #undef LMRL_G8_READ
 #undef LMRL_G8_MFMA
-}
 
-template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0>
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0, bool PAIR = false>
 __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap xm) {
+    static_assert(!PAIR || STAGES == 4, "the paired K loop runs on a 4-slot ring");
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int TM = BM / WM, TN = BN / WN;            // per-wave output tile
     constexpr int FM = TM / 16, FN = TN / 16;
@@ -213,7 +280,8 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
                 ln_mu[j] = p2.x; ln_rs[j] = p2.y;
             }
         };
-        g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, head);
+        if constexpr (PAIR) g8_mainloop_pair<BM, BN, WM, WN>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, head);
+        else g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, head);
     } else if (RESID) {
         auto prefetch = [&]() {
 #pragma unroll
@@ -229,7 +297,8 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
         };
         g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, prefetch);
     } else {
-        g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc);
+        if constexpr (PAIR) g8_mainloop_pair<BM, BN, WM, WN>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc);
+        else g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc);
     }
     LMRL_G8_STAMP(2);
 
@@ -349,7 +418,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
     LMRL_G8_STAMP(3);
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0>
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0, bool PAIR = false>
 inline hipError_t gemm8_launch(const GemmArgs &g, hipStream_t s) {
     constexpr bool LN_IN = (EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN);
     constexpr size_t shmem = (size_t)STAGES * (BM + BN) * 128 + (LN_IN ? (size_t)BM * 4 * NQ * 8 + BM * 8 : 0);   // ring (+ LayerNorm-moment scratch)
@@ -358,14 +427,14 @@ inline hipError_t gemm8_launch(const GemmArgs &g, hipStream_t s) {
     const int tiles = xcd_grid(xm);
     static bool attr_set = false;
     if (!attr_set && shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8_kernel<BM, BN, WM, WN, STAGES, EPI, NQ>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8_kernel<BM, BN, WM, WN, STAGES, EPI, NQ, PAIR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     {
         ProfScope ps(PROF_GEMM_128x128, s, 2.0 * (double)g.M * (double)g.N * (double)g.K);
-        hipLaunchKernelGGL((gemm8_kernel<BM, BN, WM, WN, STAGES, EPI, NQ>), dim3(tiles), dim3(WM * WN * 64), shmem, s, g, xm);
+        hipLaunchKernelGGL((gemm8_kernel<BM, BN, WM, WN, STAGES, EPI, NQ, PAIR>), dim3(tiles), dim3(WM * WN * 64), shmem, s, g, xm);
     }
     return hipGetLastError();
 }

@@ -17,8 +17,12 @@ inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
         if (g.M >= 2048 && g.N % 128 == 0 && g_gemm_variant != 105) return gemm8_launch<128, 128, 2, 4, 2, EPI, NQ>(g, s);
         // decode (M ~ 1024) LN consumers with a wide N (qkv 144 tiles, fc 192 tiles of 128x128): one 8-wave workgroup per CU moves half the
         // bytes per flop of the 64x64 ring and measured 12.5 vs 15.0 us (profiles/r02_gemm8_bench.txt); 3 slots: nothing else shares the LDS
-        if (g.M >= 512 && g.N % 128 == 0 && g.K < 2048 && (long)((g.M + 127) / 128) * (g.N / 128) >= 128 && g_gemm_variant != 105)
+        if (g.M >= 512 && g.N % 128 == 0 && g.K < 2048 && (long)((g.M + 127) / 128) * (g.N / 128) >= 128 && g_gemm_variant != 105) {
+            // (paired K-steps — one barrier per two K-steps on a 4-slot ring, g8_mainloop_pair — are 5 % faster in isolation, 12.6 -> 11.9 us,
+            //  and measured SLOWER inside the episode, 49.72 vs 49.22 ms on the same box: variant 107 keeps the A/B)
+            if (g.K % 128 == 0 && g_gemm_variant == 107) return gemm8_launch<128, 128, 2, 4, 4, EPI, NQ, true>(g, s);
             return gemm8_launch<128, 128, 2, 4, 3, EPI, NQ>(g, s);
+        }
     }
     if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI, NQ>(g, s);
     // (decode residual producers, N = d_model, 192 tiles: the 8-wave 64x64 form of gemm8_bf16.h is ~10 % faster in isolation but measured
