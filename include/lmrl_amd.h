@@ -410,6 +410,7 @@ int lmrl_layernorm_bwd(const float *dy_d, const float *x_d, const float *g_d, co
                        float *dy_xhat_d, int rows, int d, int accumulate_dx, void *stream);
 size_t lmrl_colsum_ws_bytes(int cols);
 int lmrl_colsum(const float *x_d, int rows, int cols, int ld, float *out_d, int accumulate, float *ws_d, void *stream);
+/* elementwise ops: in-place calls are supported (y_d == x_d, dx_d == dy_d, out_d == x_d or y_d) */
 int lmrl_gelu_fwd(const float *x_d, float *y_d, size_t n, void *stream);
 int lmrl_gelu_bwd(const float *dy_d, const float *x_d, float *dx_d, size_t n, void *stream);
 int lmrl_relu_fwd(const float *x_d, float *y_d, size_t n, void *stream);

@@ -163,7 +163,8 @@ def ilql_loss(q1, q2, v, v_final, target_q1, target_q2, q1_logits, q2_logits, to
 class GPT2ILQLTrain:
     def __init__(self, base: GPT2F32, q1_head: MLPHeadF32, q2_head: MLPHeadF32, v_head: MLPHeadF32, pad_token_id: int,
                  loss_kwargs: Dict[str, float], target_base: Optional[GPT2F32] = None, lr: float = 3e-5, weight_decay: float = 0.0,
-                 grad_accum_steps: int = 1, polyak_alpha: float = 0.005, hard_update_every: Optional[int] = None):
+                 grad_accum_steps: int = 1, polyak_alpha: float = 0.005, hard_update_every: Optional[int] = None,
+                 detach_q1: bool = False, detach_q2: bool = False, detach_v: bool = False):
         import torch
         self.base, self.q1, self.q2, self.v = base, q1_head, q2_head, v_head
         self.target_base = target_base
@@ -172,15 +173,18 @@ class GPT2ILQLTrain:
         self.q1_target, self.q2_target = clone(q1_head), clone(q2_head)
         self.pad, self.loss_kwargs = pad_token_id, dict(loss_kwargs)
         self.alpha, self.hard_every = polyak_alpha, hard_update_every
+        self.detach_q1, self.detach_q2, self.detach_v = detach_q1, detach_q2, detach_v
         hd = lambda n: n.endswith("bias")
         self.base_opt = AdamW(base.p, lr, weight_decay=weight_decay, every_k=grad_accum_steps)
         self.q1_opt = AdamW(q1_head.p, lr, weight_decay=weight_decay, every_k=grad_accum_steps, no_decay=hd)
         self.q2_opt = AdamW(q2_head.p, lr, weight_decay=weight_decay, every_k=grad_accum_steps, no_decay=hd)
         self.v_opt = AdamW(v_head.p, lr, weight_decay=weight_decay, every_k=grad_accum_steps, no_decay=hd)
         self.last_grads = None
+        self.calls = 0
 
     def _update_targets(self, online: Dict[str, Any], target: Dict[str, Any], step: int):
-        """optax.incremental_update + optional optax.periodic_update (interface.py:327-365)."""
+        """optax.incremental_update + optional optax.periodic_update (interface.py:327-365).  `step` is the reference's TrainState.step:
+        it counts every apply_gradients call, MultiSteps micro-steps included (`self.calls`), not the applied optimizer updates."""
         hard = self.hard_every is not None and step % self.hard_every == 0
         for k, tp in target.items():
             if hard:
@@ -252,22 +256,27 @@ class GPT2ILQLTrain:
         ops.ce_bwd(q2o, ld, V, lse2, tgt, coef_r, dq2_r, R)
         bgrads, g1, g2, gv = base.zero_grads(), self.q1.zero_grads(), self.q2.zero_grads(), self.v.zero_grads()
         d_hidden = torch.empty(R, base.d, dtype=torch.float32, device=dev)
-        self.q1.backward(q1c, q1o, g1, dx=d_hidden, accumulate_dx=False)
-        self.q2.backward(q2c, q2o, g2, dx=d_hidden, accumulate_dx=True)
-        self.v.backward(vc, dv_r.view(R, 1), gv, dx=d_hidden, accumulate_dx=True)
+        # detach_q1 / detach_q2 / detach_v (interface.py:120-139: stop_gradient on the hidden states fed to that head): the head still trains,
+        # its gradient does not reach the transformer
+        scratch = torch.empty_like(d_hidden) if (self.detach_q1 or self.detach_q2 or self.detach_v) else None
+        d_hidden.zero_()
+        self.q1.backward(q1c, q1o, g1, dx=scratch if self.detach_q1 else d_hidden, accumulate_dx=not self.detach_q1)
+        self.q2.backward(q2c, q2o, g2, dx=scratch if self.detach_q2 else d_hidden, accumulate_dx=not self.detach_q2)
+        self.v.backward(vc, dv_r.view(R, 1), gv, dx=scratch if self.detach_v else d_hidden, accumulate_dx=not self.detach_v)
         # data parallel: the head gradients (final already) and the base gradients are all-reduced while the base backward runs — arena
         # slices go to RCCL as blocks finish (dist.GradReducer); the one data-path collective of an ILQL step (~815 MB fp32, GPT-2-small)
         red = D.GradReducer()
         base.backward(cache, d_hidden, bgrads, on_final=red.ready(bgrads))
         self.last_grads = (bgrads, g1, g2, gv)
         red.finish([g1, g2, gv])
+        self.calls += 1                                 # TrainState.step of the reference: one per apply_gradients call
         upd = self.base_opt.apply(bgrads)
         self.q1_opt.apply(g1); self.q2_opt.apply(g2); self.v_opt.apply(gv)
         if upd:   # targets move only when MultiSteps.mini_step == 0 (interface.py:343-347)
             if self.target_base is not None:
-                self._update_targets(base.p, self.target_base.p, self.base_opt.step_count)
-            self._update_targets(self.q1.p, self.q1_target.p, self.q1_opt.step_count)
-            self._update_targets(self.q2.p, self.q2_target.p, self.q2_opt.step_count)
+                self._update_targets(base.p, self.target_base.p, self.calls)
+            self._update_targets(self.q1.p, self.q1_target.p, self.calls)
+            self._update_targets(self.q2.p, self.q2_target.p, self.calls)
         return self, loss, logs
 
 

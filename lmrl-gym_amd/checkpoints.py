@@ -171,8 +171,11 @@ def load_gpt2_checkpoint(path: str):
     cfg_json, tree = _load_params_dir(path)
     sd = flax_gpt2_params_to_state_dict(tree)
     d = sd["wte.weight"].shape[1]
+    if "n_head" not in cfg_json:
+        # the head count is not recoverable from the tensors (c_attn is [d, 3d] for any head count): refuse instead of guessing
+        raise ValueError(f"{path}/config.json has no 'n_head': cannot reconstruct the GPT-2 configuration")
     cfg = GPT2Config(n_layer=1 + max(int(k.split(".")[1]) for k in sd if k.startswith("h.")),
-                     n_head=int(cfg_json.get("n_head", d // 64)), d_model=d, d_ff=sd["h.0.mlp.c_fc.weight"].shape[1],
+                     n_head=int(cfg_json["n_head"]), d_model=d, d_ff=sd["h.0.mlp.c_fc.weight"].shape[1],
                      vocab=sd["wte.weight"].shape[0], n_pos=sd["wpe.weight"].shape[0],
                      ln_eps=float(cfg_json.get("layer_norm_epsilon", 1e-5)))
     return cfg, sd

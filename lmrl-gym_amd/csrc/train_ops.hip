@@ -111,10 +111,11 @@ __device__ __forceinline__ float gelu_new_exact(float x) {
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
     return 0.5f * x * (1.f + tanhf(u));
 }
-__global__ void gelu_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n) {
+// (the elementwise kernels below may be called in place — out == x or out == y: no __restrict__ on the pairs that may alias)
+__global__ void gelu_fwd_kernel(const float *x, float *y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = gelu_new_exact(x[i]);
 }
-__global__ void gelu_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ dx, size_t n) {
+__global__ void gelu_bwd_kernel(const float *dy, const float *__restrict__ x, float *dx, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = x[i];
         const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
@@ -123,14 +124,14 @@ __global__ void gelu_bwd_kernel(const float *__restrict__ dy, const float *__res
         dx[i] = dy[i] * (0.5f * (1.f + th) + 0.5f * v * (1.f - th * th) * du);
     }
 }
-__global__ void relu_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n) {
+__global__ void relu_fwd_kernel(const float *x, float *y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = fmaxf(x[i], 0.f);
 }
-__global__ void relu_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ dx, size_t n) {
+__global__ void relu_bwd_kernel(const float *dy, const float *__restrict__ x, float *dx, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dx[i] = x[i] > 0.f ? dy[i] : 0.f;
 }
 // out = a*x + b*y   (residual adds, grad accumulation, Polyak: optax.incremental_update(new, old, s) = s*new + (1-s)*old)
-__global__ void axpby_kernel(float a, const float *__restrict__ x, float b, const float *__restrict__ y, float *__restrict__ out, size_t n) {
+__global__ void axpby_kernel(float a, const float *x, float b, const float *y, float *out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = a * x[i] + (y ? b * y[i] : 0.f);
 }
@@ -150,8 +151,8 @@ __global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g,
 
 // ------------------------------------------------------------------------------------------ causal softmax (attention)
 // S: [nb][T][T] scores (already scaled). P[r][c] = softmax over c <= r with key_mask[b][c] != 0 ; 0 elsewhere.  In place ok.
-__global__ __launch_bounds__(256) void softmax_causal_fwd_kernel(const float *__restrict__ S, const uint8_t *__restrict__ key_mask,
-                                                                 float *__restrict__ P, int T, int heads, long rows_total) {
+__global__ __launch_bounds__(256) void softmax_causal_fwd_kernel(const float *S, const uint8_t *__restrict__ key_mask, float *P, int T, int heads,
+                                                                 long rows_total) {   // S == P allowed: the reductions finish before the write loop, and each lane reads element c before it writes it
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows_total) return;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void softmax_causal_fwd_kernel(const float *__
     }
 }
 // dS = P * (dP - sum_c dP*P), written over dP
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float *__restrict__ P, float *__restrict__ dP, int T, long rows_total) {
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float *__restrict__ P, float *dP, int T, long rows_total) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows_total) return;

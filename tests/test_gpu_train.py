@@ -583,3 +583,51 @@ def test_bc_train_step_and_score_fns(dev):
         t = torch.tensor(toks)
         qa = torch.minimum(qo1[0, :-1].gather(1, t[1:, None])[:, 0], qo2[0, :-1].gather(1, t[1:, None])[:, 0]) - vo[0, :-1, 0]
         assert abs(sc - float(qa[-n_act:].sum())) < 2e-3
+
+
+def test_ilql_detach_flags_and_hard_update_counter(dev):
+    """detach_q1 / detach_q2 / detach_v (ilql/gpt2/interface.py:120-139: stop_gradient on the hidden states fed to a head): with all three set
+    no gradient reaches the transformer while the head gradients are unchanged; with one set, the transformer gradient is the sum of the other
+    two heads' contributions.  The hard target sync counts every apply_gradients call (TrainState.step), MultiSteps micro-steps included."""
+    from lmrl_gym_amd.algorithms import ilql
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    cfg, sd = _tiny_model(21)
+    rng = np.random.RandomState(5)
+    B, T, pad = 3, 12, cfg.vocab - 1
+    ids, sta, _ = _batch(rng, B, T, cfg.vocab, pad)
+    rewards = (rng.randn(B, T - 1) * sta).astype(np.float32)
+    dones = np.array([1, 0, 1], dtype=np.float32)
+    g = torch.Generator().manual_seed(9)
+    d, V = cfg.d_model, cfg.vocab
+    mk = lambda out: {"dense1.kernel": torch.randn(d, d, generator=g) * 0.2, "dense1.bias": torch.randn(d, generator=g) * 0.1,
+                      "dense2.kernel": torch.randn(d, out, generator=g) * 0.2, "dense2.bias": torch.full((out,), -0.3)}
+    hq1, hq2, hv = mk(V), mk(V), mk(1)
+    kw = dict(gamma=0.99, tau=0.7, cql_weight=0.01)
+    cp = lambda h: {k: v.clone() for k, v in h.items()}
+
+    def run(**flags):
+        base = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
+        tr = ilql.GPT2ILQLTrain(base, MLPHeadF32(cp(hq1), dev), MLPHeadF32(cp(hq2), dev), MLPHeadF32(cp(hv), dev), pad, kw, lr=1e-3, **flags)
+        tr.step(ids, sta, rewards, dones)
+        return [{k: v.clone() for k, v in gd.items()} for gd in tr.last_grads]
+
+    full = run()
+    none = run(detach_q1=True, detach_q2=True, detach_v=True)
+    assert all(float(v.abs().max()) == 0.0 for v in none[0].values())
+    for a, b in zip(full[1:], none[1:]):                     # the heads themselves train as before
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    only = [run(detach_q2=True, detach_v=True), run(detach_q1=True, detach_v=True), run(detach_q1=True, detach_q2=True)]
+    for k in full[0]:                                        # linearity of the backward pass in d_hidden
+        s = only[0][0][k] + only[1][0][k] + only[2][0][k]
+        assert float((s - full[0][k]).abs().max()) <= 2e-5 * max(float(full[0][k].abs().max()), 1e-6), k
+    # hard target updates: every 2nd apply_gradients CALL with grad_accum_steps = 2 -> on every applied update
+    base = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
+    tr = ilql.GPT2ILQLTrain(base, MLPHeadF32(cp(hq1), dev), MLPHeadF32(cp(hq2), dev), MLPHeadF32(cp(hv), dev), pad, kw, lr=1e-2,
+                            grad_accum_steps=2, hard_update_every=2, polyak_alpha=0.005)
+    for i in range(4):
+        tr.step(ids, sta, rewards, dones)
+        if i % 2 == 1:                                       # micro-step boundary: parameters moved and the targets were hard-synced
+            assert tr.calls == i + 1
+            for k in tr.q1.p:
+                assert torch.equal(tr.q1.p[k], tr.q1_target.p[k]), (i, k)
