@@ -222,7 +222,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int TM = BM / WM, TN = BN / WN;            // per-wave output tile
     constexpr int FM = TM / 16, FN = TN / 16;
-    constexpr bool LN_IN = (EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN);
+    constexpr bool LN_IN = (EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN || EPI == EPI_BF16_LN_KV);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -244,12 +244,19 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
     constexpr int STAGE = (BM + BN) * 128;
     float ln_mu[FM], ln_rs[FM];          // LN_IN: this lane's rows' (mu, rstd)
     f32x4 xres[FN][FM];                  // RESID: this lane's slice of the residual stream, prefetched under the K loop
+    long kvrow[FM];                      // EPI_BF16_LN_KV: cache rows this lane's K / V columns are appended to (looked up in the prologue)
     if (LN_IN) {
         // as in gemm_bf16_glds_kernel: fetch the tile's BM x nslots moment slots behind the ring prologue, wait for everything, reduce to
         // (mu, rstd) per row in LDS scratch behind the ring (same association order: ln_row_moments) and keep this lane's rows in registers
         constexpr int NLQ = NQ > 0 ? (NQ * BM * 4 + NT - 1) / NT : 1;      // float4 loads per thread: BM * nslots * 8 B / (NT * 16 B)
         constexpr int TPR = NT / BM >= 4 ? 4 : (NT / BM >= 2 ? 2 : 1);
         auto head = [&]() {
+            if constexpr (EPI == EPI_BF16_LN_KV) {
+                if (g.kv_k) {
+#pragma unroll
+                    for (int j = 0; j < FM; j++) kvrow[j] = kv_append_row(g, m0 + wm * TM + j * 16 + lr, Mr);
+                }
+            }
             const int h4 = g.nslots / 2;
             const f32x4 *sp = reinterpret_cast<const f32x4 *>(g.stats + (size_t)m0 * g.nslots);
             const int lim = (Mr - m0 < BM ? Mr - m0 : BM) * h4;
@@ -373,6 +380,13 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
                 auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
                 if (m < Mr && n_st < g.n_store)
                     *reinterpret_cast<u32x4 *>(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc + n_st) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                if constexpr (EPI == EPI_BF16_LN_KV) {
+                    if (g.kv_k && n_st >= g.kv_d && n_st < g.n_store && kvrow[j] >= 0) {
+                        const bool isv = n_st >= 2 * g.kv_d;
+                        uint16_t *dst = (isv ? g.kv_v : g.kv_k) + kvrow[j] * g.kv_d + (n_st - (isv ? 2 : 1) * g.kv_d);
+                        *reinterpret_cast<u32x4 *>(dst) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    }
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -407,6 +421,12 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
                 o.x = pack_bf16x2(v[0], v[1]);
                 o.y = pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc + n) = o;
+                if constexpr (EPI == EPI_BF16_LN_KV) {
+                    if (g.kv_k && n >= g.kv_d && kvrow[j] >= 0) {
+                        const bool isv = n >= 2 * g.kv_d;
+                        *reinterpret_cast<uint2 *>((isv ? g.kv_v : g.kv_k) + kvrow[j] * g.kv_d + (n - (isv ? 2 : 1) * g.kv_d)) = o;
+                    }
+                }
             } else if (EPI == EPI_RESID_F32) {
                 *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n) = xres[i][j] + v;
             } else {
@@ -420,7 +440,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
 
 template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0, bool PAIR = false>
 inline hipError_t gemm8_launch(const GemmArgs &g, hipStream_t s) {
-    constexpr bool LN_IN = (EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN);
+    constexpr bool LN_IN = (EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN || EPI == EPI_BF16_LN_KV);
     constexpr size_t shmem = (size_t)STAGES * (BM + BN) * 128 + (LN_IN ? (size_t)BM * 4 * NQ * 8 + BM * 8 : 0);   // ring (+ LayerNorm-moment scratch)
     static_assert(shmem <= 160 * 1024, "LDS ring exceeds 160 KiB");
     const XcdMap xm = make_xcd_map((g.M + BM - 1) / BM, g.N / BN, 2.0 * g.M * g.K, 2.0 * g.N * g.K);

@@ -45,6 +45,7 @@ enum GemmEpi {
     EPI_RESID_F32_STATS = 5,
     EPI_BF16_LN = 6,
     EPI_GELU_BF16_LN = 7,
+    EPI_BF16_LN_KV = 8,  // EPI_BF16_LN + the K / V columns of every row also appended to the KV cache (GemmArgs::kv_*)
 };
 
 // fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32); the integer bit trick it replaces
@@ -110,7 +111,24 @@ struct GemmArgs {
     int ldw;              // row pitch of W in elements (0: dense, = K).  Operands whose natural pitch is a large power of two (the
                           // transposed train-step operands, K = B*T) are padded by the caller: every row of a tile would otherwise
                           // start in the same HBM channel
+    // EPI_BF16_LN_KV only (the decode qkv GEMM under LMRL_FWD_KV_FROM_GEMM): also append the new token's K / V row to the KV cache — row m belongs to env b = kv_rowmap ?
+    // kv_rowmap[m] >> 5 : m; columns [kv_d, 2 kv_d) go to kv_k + (b * kv_tmax + kv_len[b]) * kv_d, columns [2 kv_d, 3 kv_d) to kv_v + the same
+    // offset (envs with kv_cnt[b] <= 0 or a full cache are skipped) — so that the decode attention kernel does no stores into the stream it reads
+    uint16_t *kv_k, *kv_v;
+    const int *kv_len, *kv_cnt, *kv_rowmap;
+    int kv_tmax, kv_d;
 };
+
+// cache row (b * tmax + len[b]) the K/V columns of GEMM row m are appended to, or -1.  Loads are unconditional on clamped indices (selects, no
+// divergent branches around them).
+__device__ __forceinline__ long kv_append_row(const GemmArgs &g, int m, int Mr) {
+    const int mc = m < Mr ? m : Mr - 1;
+    const int b = g.kv_rowmap ? (g.kv_rowmap[mc] >> 5) : mc;
+    const int len = g.kv_len[b];
+    const int cnt = g.kv_cnt ? g.kv_cnt[b] : 1;
+    const bool ok = (m < Mr) & (cnt > 0) & (len < g.kv_tmax);
+    return ok ? (long)b * g.kv_tmax + len : -1l;
+}
 
 template <int BM, int BN, int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
@@ -388,7 +406,7 @@ __device__ __forceinline__ void glds_mainloop(const uint16_t *__restrict__ A, in
 template <int BM, int BN, int STAGES, int EPI, int NQ = 0>
 __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap xm) {
     constexpr int FM = BM / 32, FN = BN / 32;
-    constexpr bool LN_IN = (EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN);
+    constexpr bool LN_IN = (EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN || EPI == EPI_BF16_LN_KV);
     constexpr bool RESID = (EPI == EPI_RESID_F32_STATS || EPI == EPI_RESID_F32);
     constexpr int STAGE = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -408,6 +426,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
         for (int j = 0; j < FM; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     float ln_mu[FM], ln_rs[FM];          // LN_IN: this lane's rows' (mu, rstd)
+    long kvrow[FM];                      // EPI_BF16_LN_KV: cache rows this lane's K / V columns are appended to (looked up in the prologue)
     f32x4 xres[FN][FM];                  // RESID: this lane's slice of the residual stream, prefetched under the K loop
     if (LN_IN) {
         // The tile's BM x nslots (sum, sum^2) slots are one contiguous region of `stats`.  Right after the ring prologue is in flight the
@@ -418,6 +437,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
         constexpr int TPR = 256 / BM >= 4 ? 4 : (256 / BM >= 2 ? 2 : 1);
         static_assert(BM * 4 * NQ * 8 + BM * 8 <= STAGE, "LN scratch must fit one ring slot");
         auto head = [&]() {
+            if constexpr (EPI == EPI_BF16_LN_KV) {
+                if (g.kv_k) {
+#pragma unroll
+                    for (int j = 0; j < FM; j++) kvrow[j] = kv_append_row(g, m0 + wm * (BM / 2) + j * 16 + lr, Mr);
+                }
+            }
             const int h4 = g.nslots / 2;                         // float4 per row
             const f32x4 *sp = reinterpret_cast<const f32x4 *>(g.stats + (size_t)m0 * g.nslots);
             const int lim = (Mr - m0 < BM ? Mr - m0 : BM) * h4;
@@ -532,6 +557,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
                 o.x = pack_bf16x2(v[0], v[1]);
                 o.y = pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc + n) = o;
+                if constexpr (EPI == EPI_BF16_LN_KV) {
+                    if (g.kv_k && n >= g.kv_d && kvrow[j] >= 0) {
+                        const bool isv = n >= 2 * g.kv_d;
+                        uint16_t *dst = (isv ? g.kv_v : g.kv_k) + kvrow[j] * g.kv_d + (n - (isv ? 2 : 1) * g.kv_d);
+                        *reinterpret_cast<uint2 *>(dst) = o;
+                    }
+                }
             } else if (EPI == EPI_RESID_F32) {
                 *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n) = xres[i][j] + v;
             } else {

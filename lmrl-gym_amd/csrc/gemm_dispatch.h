@@ -41,7 +41,7 @@ inline int ln_fusion_nq(int d_model) {
 }
 template <int EPI>
 inline hipError_t gemm_launch_ln(const GemmArgs &g, hipStream_t s) {
-    static_assert(EPI == EPI_RESID_F32_STATS || EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN, "LN-fused epilogues only");
+    static_assert(EPI == EPI_RESID_F32_STATS || EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN || EPI == EPI_BF16_LN_KV, "LN-fused epilogues only");
     if (EPI == EPI_RESID_F32_STATS) return gemm_launch_ln_nq<EPI, 0>(g, s);
     switch (g.nslots / 8) {
         case 1: return gemm_launch_ln_nq<EPI, 1>(g, s);
@@ -92,7 +92,7 @@ inline hipError_t gemm_launch(const GemmArgs &g, hipStream_t s) {
         // and L2 traffic per flop; taken when the tile count fills whole rounds of the 256 CUs (tools/bench_train_gemm.py, profiles/r02_train_gemm_sweep.txt:
         // fc / fc2 / dX / head products 95-1450 us vs 117-3690 us; the 576-tile qkv product stays on 128x128)
         const long t256 = (long)((g.M + 255) / 256) * (g.N / 256);
-        if (g.M >= 4096 && g.N % 256 == 0 && (g.K >= 2048 || t256 <= 256 || t256 % 256 == 0 || t256 >= 1024))
+        if (g.M >= 4096 && g.N % 256 == 0 && t256 >= 160 && (g.K >= 2048 || t256 <= 256 || t256 % 256 == 0 || t256 >= 1024))
             return gemm8_launch<256, 256, 2, 4, 2, EPI>(g, s);
     }
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || EPI == EPI_F32) {

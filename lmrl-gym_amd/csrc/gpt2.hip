@@ -444,7 +444,8 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *_
                                                                uint16_t *__restrict__ kcache, uint16_t *__restrict__ vcache,
                                                                const int32_t *__restrict__ cnt, const int32_t *__restrict__ len,
                                                                uint16_t *__restrict__ out,          // [rows][d]
-                                                               int B, int H, int Tmax, int d, const int32_t *__restrict__ off, int n_shared) {
+                                                               int B, int H, int Tmax, int d, const int32_t *__restrict__ off, int n_shared,
+                                                               int append) {
     typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
     const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (wave_id >= B * H) return;
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *_
             vr[u] = *reinterpret_cast<const uint4 *>(vc + bo_);                                               \
         }
     LMRL_DEC_LOAD(0);
-    if (rr == 0 && L0 < Tmax) {                                      // append the new token's K/V row to the cache
+    if (append && rr == 0 && L0 < Tmax) {                            // append the new token's K/V row to the cache (unless the qkv GEMM did)
         *reinterpret_cast<uint4 *>(const_cast<char *>(kc) + (((size_t)env_row + L0) * d + cc * 8) * 2) = knew;
         *reinterpret_cast<uint4 *>(const_cast<char *>(vc) + (((size_t)env_row + L0) * d + cc * 8) * 2) = vnew;
     }
@@ -928,12 +929,22 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
                                 m->layers[0].ln1_g, m->layers[0].ln1_b, w.x, w.h, b, c, d, cf.vocab, cf.n_pos, cf.ln_eps);
     }
     LMRL_CHECK_LAUNCH();
+    // LMRL_FWD_KV_FROM_GEMM (single-token decode, LN-folded path): the qkv GEMM's epilogue appends the new K / V rows and the attention kernel
+    // only reads.  Measured: attention 25.3 -> 23.8 us (0.53 of the HBM roofline) but the qkv GEMM 12.7 -> 15.3 us (its tile scatters 16-byte
+    // stores over 128 envs' cache pages), a net loss of 1.2 us per layer — so it is off by default and kept as a per-call variant.
+    const bool kv_from_gemm = fused && c == 1 && (flags & LMRL_FWD_KV_FROM_GEMM) && !(flags & LMRL_FWD_ATTN_VALU);
+    const int append_in_attn = kv_from_gemm ? 0 : 1;
     for (int l = 0; l < cf.n_layer; l++) {
         const Gpt2Layer &L = m->layers[l];
         uint16_t *kc = (uint16_t *)kv_d + (size_t)(2 * l) * kv_layer, *vc = kc + kv_layer;
         if (fused) {
             GemmArgs g{w.h, L.wf_qkv, L.bf_qkv, w.qkv, M, 3 * d, d, d, 3 * d, 3 * d, w.stats, nullptr, L.cs_qkv, nsl, 1.f / (float)d, cf.ln_eps, m_dev};
-            LMRL_CHECK_HIP(gemm_launch_ln<EPI_BF16_LN>(g, s));
+            if (kv_from_gemm) {   // decode: the new K / V rows go to the cache from this GEMM's epilogue, the attention kernel only reads
+                g.kv_k = kc; g.kv_v = vc; g.kv_len = len_d; g.kv_cnt = cnt_d; g.kv_rowmap = row_map; g.kv_tmax = tmax; g.kv_d = d;
+                LMRL_CHECK_HIP(gemm_launch_ln<EPI_BF16_LN_KV>(g, s));
+            } else {
+                LMRL_CHECK_HIP(gemm_launch_ln<EPI_BF16_LN>(g, s));
+            }
         } else {
             if (l > 0) {
                 ln(L.ln1_g, L.ln1_b, w.h, nullptr, M);
@@ -952,9 +963,9 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
             do {                                                                                                                                     \
                 if (ev) hipExtLaunchKernelGGL((attention_decode_kernel<U_>), dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, ev_a, ev_b, 0,         \
                                               (const uint16_t *)w.qkv, kc, vc, cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off,     \
-                                              n_shared);                                                                                             \
+                                              n_shared, append_in_attn);                                                                             \
                 else hipLaunchKernelGGL((attention_decode_kernel<U_>), dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, (const uint16_t *)w.qkv, kc,   \
-                                        vc, cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off, n_shared);                              \
+                                        vc, cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off, n_shared, append_in_attn);              \
             } while (0)
             LMRL_DEC_LAUNCH(4);      // 32 cached positions per batch of loads, 72 VGPRs -> 7 waves per SIMD (measured best of U = 4 / 6 / 8 / 10)
 #undef LMRL_DEC_LAUNCH

@@ -290,15 +290,18 @@ def test_ragged_prefill_is_bit_identical(dev):
             (1, torch.ones(B, dtype=torch.int64)), (8, torch.randint(3, 9, (B,), generator=g))]
     plan[0][1][0] = 0; plan[0][1][B - 1] = 8
     outs = []
-    from lmrl_gym_amd.gpt2 import FWD_RAGGED_ALWAYS, FWD_RAGGED_NEVER
-    # the two sessions are INTERLEAVED forward by forward: the variant is a property of the call, not of the process
-    sess = [eng.session(B, 48, flags=FWD_RAGGED_ALWAYS), eng.session(B, 48, flags=FWD_RAGGED_NEVER)]
-    hs = [[], []]
+    from lmrl_gym_amd.gpt2 import FWD_KV_FROM_GEMM, FWD_RAGGED_ALWAYS, FWD_RAGGED_NEVER
+    # the sessions are INTERLEAVED forward by forward: the variant is a property of the call, not of the process.  FWD_KV_FROM_GEMM: the
+    # decode qkv GEMM's epilogue appends the new K / V rows instead of the attention kernel — same cache bytes, same outputs
+    sess = [eng.session(B, 48, flags=FWD_RAGGED_ALWAYS), eng.session(B, 48, flags=FWD_RAGGED_NEVER),
+            eng.session(B, 48, flags=FWD_RAGGED_ALWAYS | FWD_KV_FROM_GEMM), eng.session(B, 48, flags=FWD_RAGGED_NEVER | FWD_KV_FROM_GEMM)]
+    hs = [[] for _ in sess]
     for C, cnt in plan:
         toks = torch.randint(0, cfg.vocab, (B * C,), generator=torch.Generator().manual_seed(C)).to(torch.int32).to(dev)
         for i, ses in enumerate(sess):
             hs[i].append(ses.forward(toks, cnt.to(torch.int32).to(dev), C).clone())
-    outs = [(hs[i], sess[i].kv.clone(), sess[i].len.clone()) for i in range(2)]
-    for a, b in zip(outs[0][0], outs[1][0]):
-        assert torch.equal(a, b)
-    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    outs = [(hs[i], sess[i].kv.clone(), sess[i].len.clone()) for i in range(len(sess))]
+    for o in outs[1:]:
+        for a, b in zip(outs[0][0], o[0]):
+            assert torch.equal(a, b)
+        assert torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2])
