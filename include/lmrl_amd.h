@@ -449,6 +449,10 @@ int lmrl_transpose_add_f32(const float *src_d, long ld_src, float *dst_d, long l
  * the ILQL target Q heads are only ever evaluated at the taken token (ilql/base_interface.py:57-66), exact fp32 */
 int lmrl_gather_dot_f32(const float *a_d, long lda, const float *w_d, long ldw, const float *bias_d, const int32_t *idx_d, float *out_d, int rows,
                         int k, int n, void *stream);
+/* lmrl_adamw over a whole parameter arena in one launch: seg_end_d[nseg] (exclusive element ends, ascending, last = n) and seg_wd_d[nseg] give
+ * the weight-decay coefficient of each tensor (the optax mask: 0 for biases / LayerNorm).  Element for element the arithmetic of lmrl_adamw. */
+int lmrl_adamw_segments(float *p_d, const float *g_d, float *m_d, float *v_d, long n, const long *seg_end_d, const float *seg_wd_d, int nseg, float lr,
+                        float b1, float b2, float eps, int step, void *stream);
 /* P = causal (+ key padding mask [batch][t] uint8) softmax of S [batch*heads][t][t]; in place allowed */
 int lmrl_softmax_causal_fwd(const float *s_d, const uint8_t *key_mask_d, float *p_d, int batch, int heads, int t, void *stream);
 int lmrl_softmax_bwd(const float *p_d, float *dp_d, long rows, int t, void *stream);

@@ -186,6 +186,12 @@ class GPT2ILQLTrain:
         """optax.incremental_update + optional optax.periodic_update (interface.py:327-365).  `step` is the reference's TrainState.step:
         it counts every apply_gradients call, MultiSteps micro-steps included (`self.calls`), not the applied optimizer updates."""
         hard = self.hard_every is not None and step % self.hard_every == 0
+        if getattr(online, "flat", None) is not None and getattr(target, "flat", None) is not None and online.order == target.order:
+            if hard:                                     # parameter arenas: the whole model in one launch
+                ops.axpby(1.0, online.flat, 0.0, None, target.flat)
+            else:
+                ops.axpby(self.alpha, online.flat, 1.0 - self.alpha, target.flat, target.flat)
+            return
         for k, tp in target.items():
             if hard:
                 ops.axpby(1.0, online[k], 0.0, None, tp)

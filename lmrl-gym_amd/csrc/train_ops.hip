@@ -149,6 +149,32 @@ __global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g,
     }
 }
 
+// The same update over a whole parameter ARENA in one launch: the weight-decay coefficient is a per-tensor property (biases and LayerNorm
+// parameters are masked out, train_ilql_gpt2.py:155-186), so the arena comes with a table of segment ends and coefficients.  One workgroup
+// per 4096-element chunk; its first lane's segment is found by bisection, lanes then walk forward (a chunk rarely crosses a boundary).
+__global__ __launch_bounds__(256) void adamw_segments_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                             float *__restrict__ v, long n, const long *__restrict__ seg_end,
+                                                             const float *__restrict__ seg_wd, int nseg, float lr, float b1, float b2, float eps,
+                                                             float bc1, float bc2) {
+    const long base = (long)blockIdx.x * 4096;
+    int lo = 0, hi = nseg - 1;                       // first segment with seg_end > base
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (seg_end[mid] > base) hi = mid; else lo = mid + 1; }
+    int s = lo;
+#pragma unroll 4
+    for (int k = 0; k < 16; k++) {
+        const long i = base + k * 256 + threadIdx.x;
+        if (i >= n) break;
+        while (s < nseg - 1 && i >= seg_end[s]) s++;
+        const float wd = seg_wd[s];
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float upd = (mi / bc1) / (sqrtf(vi / bc2) + eps) + wd * p[i];
+        p[i] = p[i] - lr * upd;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ causal softmax (attention)
 // S: [nb][T][T] scores (already scaled). P[r][c] = softmax over c <= r with key_mask[b][c] != 0 ; 0 elsewhere.  In place ok.
 __global__ __launch_bounds__(256) void softmax_causal_fwd_kernel(const float *S, const uint8_t *__restrict__ key_mask, float *P, int T, int heads,
@@ -321,6 +347,15 @@ int lmrl_adamw(float *p_d, const float *g_d, float *m_d, float *v_d, size_t n, f
     LMRL_REQUIRE(p_d && g_d && m_d && v_d && step >= 1, "lmrl_adamw: bad argument");
     const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
     hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, p_d, g_d, m_d, v_d, n, lr, b1, b2, eps, weight_decay, bc1, bc2);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_adamw_segments(float *p_d, const float *g_d, float *m_d, float *v_d, long n, const long *seg_end_d, const float *seg_wd_d, int nseg, float lr,
+                        float b1, float b2, float eps, int step, void *stream) {
+    LMRL_REQUIRE(p_d && g_d && m_d && v_d && seg_end_d && seg_wd_d && nseg > 0 && n > 0 && step >= 1, "lmrl_adamw_segments: bad argument");
+    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    hipLaunchKernelGGL(adamw_segments_kernel, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, ST, p_d, g_d, m_d, v_d, n, seg_end_d, seg_wd_d, nseg, lr, b1,
+                       b2, eps, bc1, bc2);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

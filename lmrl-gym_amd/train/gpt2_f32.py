@@ -37,6 +37,18 @@ class GradArena(dict):
             self.order[k] = (off, n)
             off += n
 
+    @classmethod
+    def of_values(cls, params: Dict[str, "torch.Tensor"], order=None) -> "GradArena":
+        """An arena holding COPIES of `params` (fp32): the model's parameter store — AdamW and the Polyak target update then run as one
+        launch over `.flat` instead of one per tensor."""
+        a = cls(params, order)
+        for k, v in params.items():
+            a[k].copy_(v)
+        return a
+
+    def same_layout(self, other) -> bool:
+        return isinstance(other, GradArena) and self.order == other.order
+
     def zero_(self):
         self.flat.zero_()
         return self
@@ -80,13 +92,14 @@ class GPT2F32:
         self.attention = attention
         self.t = torch
         self.dev = device or next(iter(params.values())).device
-        self.p = {k: v.to(self.dev, torch.float32).contiguous() for k, v in params.items()}
+        p32 = {k: v.to(self.dev, torch.float32) for k, v in params.items()}
+        self.n_layer = 1 + max(int(k.split(".")[1]) for k in p32 if k.startswith("h."))
+        self.p = GradArena.of_values(p32, self.grad_order())     # one flat buffer, in the order the backward pass finalises the gradients
         self.n_head = n_head
         self.eps = ln_eps
         self.d = self.p["wte.weight"].shape[1]
         self.vocab = self.p["wte.weight"].shape[0]
         self.d_ff = self.p["h.0.mlp.c_fc.weight"].shape[1]
-        self.n_layer = 1 + max(int(k.split(".")[1]) for k in self.p if k.startswith("h."))
         self.ws = Workspace(self.dev)
         self._colsum_ws = torch.empty(64 * max(self.d_ff, 3 * self.d, self.vocab), dtype=torch.float32, device=self.dev)
         self.mm = ops.MatmulBF16(self.dev) if matmul == "bf16" else None
@@ -372,27 +385,50 @@ class AdamW:
         self.params = params
         self.lr, self.b1, self.b2, self.eps, self.wd, self.k = lr, b1, b2, eps, weight_decay, every_k
         self.no_decay = no_decay
-        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
-        self.v = {k: torch.zeros_like(v) for k, v in params.items()}
-        self.acc = {k: torch.zeros_like(v) for k, v in params.items()} if every_k > 1 else None
+        self.arena = isinstance(params, GradArena)      # parameters in one flat buffer: one launch per update instead of one per tensor
+        if self.arena:
+            self.m, self.v = GradArena(params, list(params.order)), GradArena(params, list(params.order))
+            self.acc = GradArena(params, list(params.order)) if every_k > 1 else None
+            ends, wds = [], []
+            for k, (off, n) in params.order.items():
+                ends.append(off + n)
+                wds.append(0.0 if no_decay(k) else weight_decay)
+            dev = params.flat.device
+            self._seg_end = torch.tensor(ends, dtype=torch.int64, device=dev)
+            self._seg_wd = torch.tensor(wds, dtype=torch.float32, device=dev)
+        else:
+            self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+            self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+            self.acc = {k: torch.zeros_like(v) for k, v in params.items()} if every_k > 1 else None
         self.step_count = 0     # number of applied updates
         self.mini_step = 0
 
     def apply(self, grads: Dict[str, "torch.Tensor"]) -> bool:
         """Returns True when parameters were updated on this call (MultiSteps.mini_step wrapped to 0)."""
+        fast = self.arena and self.params.same_layout(grads)
         if self.k > 1:
-            for k, g in grads.items():
-                ops.axpby(1.0, self.acc[k], 1.0 / self.k, g, self.acc[k])
+            if fast:
+                ops.axpby(1.0, self.acc.flat, 1.0 / self.k, grads.flat, self.acc.flat)
+            else:
+                for k, g in grads.items():
+                    ops.axpby(1.0, self.acc[k], 1.0 / self.k, g, self.acc[k])
             self.mini_step += 1
             if self.mini_step < self.k:
                 return False
             self.mini_step = 0
             grads = self.acc
         self.step_count += 1
-        for k, p in self.params.items():
-            wd = 0.0 if self.no_decay(k) else self.wd
-            ops.adamw(p, grads[k], self.m[k], self.v[k], self.lr, self.b1, self.b2, self.eps, wd, self.step_count)
+        if fast:
+            ops.adamw_segments(self.params.flat, grads.flat, self.m.flat, self.v.flat, self._seg_end, self._seg_wd, self.lr, self.b1, self.b2,
+                               self.eps, self.step_count)
+        else:
+            for k, p in self.params.items():
+                wd = 0.0 if self.no_decay(k) else self.wd
+                ops.adamw(p, grads[k], self.m[k], self.v[k], self.lr, self.b1, self.b2, self.eps, wd, self.step_count)
         if self.k > 1:
-            for a in self.acc.values():
-                a.zero_()
+            if self.arena:
+                self.acc.flat.zero_()
+            else:
+                for a in self.acc.values():
+                    a.zero_()
         return True

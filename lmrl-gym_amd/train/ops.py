@@ -186,6 +186,11 @@ def adamw(p, g, m, v, lr, b1, b2, eps, wd, step):
                                float(eps), float(wd), int(step), _sp()), "lmrl_adamw")
 
 
+def adamw_segments(p, g, m, v, seg_end, seg_wd, lr, b1, b2, eps, step):
+    _lib.check(_L().lmrl_adamw_segments(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), seg_end.data_ptr(), seg_wd.data_ptr(),
+                                        seg_end.numel(), float(lr), float(b1), float(b2), float(eps), int(step), _sp()), "lmrl_adamw_segments")
+
+
 def embed_fwd(wte, wpe, ids, pos, x, rows, d):
     _lib.check(_L().lmrl_embed_fwd(wte.data_ptr(), wpe.data_ptr(), ids.data_ptr(), pos.data_ptr(), x.data_ptr(), rows, d, _sp()), "lmrl_embed_fwd")
 
