@@ -14,30 +14,26 @@
 
 namespace lmrl {
 
-// dst[r][c] = bf16(src[r][c]) for r < rows, c < cols; zero elsewhere in [rows_dst][ld_dst].  8 columns (16 B out) per lane.
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict__ src, long ld_src, int rows, int cols, uint16_t *__restrict__ dst,
+// dst[r][c] = bf16(src[r][c]) for r < rows, c < cols; zero elsewhere in [rows_dst][ld_dst].  One workgroup (128 lanes) per destination row,
+// 8 columns (32 B in, 16 B out) per lane and iteration: no index arithmetic beyond one multiply per row.
+__global__ __launch_bounds__(128) void cast_bf16_kernel(const float *__restrict__ src, long ld_src, int rows, int cols, uint16_t *__restrict__ dst,
                                                         long ld_dst, int rows_dst) {
-    const long chunks_per_row = ld_dst / 8;
-    const long total = (long)rows_dst * chunks_per_row;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / chunks_per_row;
-        const int c0 = (int)(i - r * chunks_per_row) * 8;
+    const int r = blockIdx.x;
+    const float *p = src + (long)r * ld_src;
+    uint16_t *q = dst + (long)r * ld_dst;
+    const bool vec = r < rows && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+    for (int c0 = threadIdx.x * 8; c0 < ld_dst; c0 += 128 * 8) {
         float v[8];
+        if (vec && c0 + 8 <= cols) {
+            const float4 a = *reinterpret_cast<const float4 *>(p + c0), b = *reinterpret_cast<const float4 *>(p + c0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = 0.f;
-        if (r < rows) {
-            const float *p = src + r * ld_src + c0;
-            if (c0 + 8 <= cols && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-                const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
-                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; k++) if (c0 + k < cols) v[k] = p[k];
-            }
+            for (int k = 0; k < 8; k++) v[k] = (r < rows && c0 + k < cols) ? p[c0 + k] : 0.f;
         }
         uint4 o;
         o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-        *reinterpret_cast<uint4 *>(dst + r * ld_dst + c0) = o;
+        *reinterpret_cast<uint4 *>(q + c0) = o;
     }
 }
 
@@ -48,10 +44,20 @@ __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float *__restric
     __shared__ float tile[64][65];
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if ((ld_src & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && c0 + 64 <= cols) {      // workgroup-uniform: 16-byte loads
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int r = r0 + ty + k * 4, c = c0 + tx;
-        tile[ty + k * 4][tx] = (r < rows && c < cols) ? src[(long)r * ld_src + c] : 0.f;
+        for (int k = 0; k < 4; k++) {
+            const int idx = threadIdx.x + 256 * k, rl = idx >> 4, c4 = (idx & 15) * 4;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r0 + rl < rows) x = *reinterpret_cast<const float4 *>(src + (long)(r0 + rl) * ld_src + c0 + c4);
+            tile[rl][c4] = x.x; tile[rl][c4 + 1] = x.y; tile[rl][c4 + 2] = x.z; tile[rl][c4 + 3] = x.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int r = r0 + ty + k * 4, c = c0 + tx;
+            tile[ty + k * 4][tx] = (r < rows && c < cols) ? src[(long)r * ld_src + c] : 0.f;
+        }
     }
     __syncthreads();
     if (colpart && threadIdx.x < 64 && r0 < rows) {      // this 64-row block's share of the column sums (the bias gradient of the layer): fixed order
@@ -138,9 +144,7 @@ int lmrl_cast_bf16(const float *src_d, long ld_src, int rows, int cols, void *ds
     hipStream_t s = as_stream(stream);
     if (!transpose) {
         LMRL_REQUIRE(rows_dst >= rows && ld_dst >= cols, "lmrl_cast_bf16: destination smaller than the source");
-        const long total = (long)rows_dst * (ld_dst / 8);
-        const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-        hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, s, src_d, ld_src, rows, cols, (uint16_t *)dst_d, ld_dst, rows_dst);
+        hipLaunchKernelGGL(cast_bf16_kernel, dim3(rows_dst), dim3(128), 0, s, src_d, ld_src, rows, cols, (uint16_t *)dst_d, ld_dst, rows_dst);
     } else {
         LMRL_REQUIRE(rows_dst >= cols && ld_dst >= rows, "lmrl_cast_bf16: destination smaller than the transposed source");
         hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((int)((ld_dst + 63) / 64), (rows_dst + 63) / 64), dim3(256), 0, s, src_d, ld_src, rows, cols,

@@ -217,23 +217,42 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float *__restric
 // One workgroup per row: lse = logsumexp(logits[r][:V]); target logit; logprob = target - lse.
 __global__ __launch_bounds__(256) void lse_gather_kernel(const float *__restrict__ logits, int ld, int V, const int32_t *__restrict__ targets,
                                                          float *__restrict__ logprob, float *__restrict__ lse, float *__restrict__ target_logit) {
+    // ONE pass over the row (200 KB at V = 50 257: a second pass would come from HBM again): per-thread running (max, sum of exp) over float4
+    // groups — one rescale per group — merged across the workgroup at the end.
     const int r = blockIdx.x, tid = threadIdx.x;
     const float *row = logits + (size_t)r * ld;
-    float mx = -INFINITY;
-    for (int c = tid; c < V; c += 256) mx = fmaxf(mx, row[c]);
-    __shared__ float red[4];
-    mx = wave_max(mx);
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float s = 0.f;
-    for (int c = tid; c < V; c += 256) s += expf(row[c] - mx);
-    s = wave_sum(s);
-    if ((tid & 63) == 0) red[tid >> 6] = s;
+    float mx = -INFINITY, s = 0.f;
+    const int head = (int)((16 - (reinterpret_cast<uintptr_t>(row) & 15)) & 15) >> 2;        // scalars before the first 16-byte boundary
+    const int nvec = (V - (head < V ? head : V)) >> 2;
+    auto add = [&](float x) {
+        if (x > mx) { s = s * __expf(mx - x) + 1.f; mx = x; }
+        else s += __expf(x - mx);
+    };
+    for (int c = tid; c < head && c < V; c += 256) add(row[c]);
+    const float4 *rv = reinterpret_cast<const float4 *>(row + head);
+    for (int q = tid; q < nvec; q += 256) {
+        const float4 x = rv[q];
+        const float gm = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+        if (gm > mx) { s *= __expf(mx - gm); mx = gm; }
+        s += (__expf(x.x - mx) + __expf(x.y - mx)) + (__expf(x.z - mx) + __expf(x.w - mx));
+    }
+    for (int c = head + 4 * nvec + tid; c < V; c += 256) add(row[c]);
+    // merge (max, sum) pairs: wave shuffle, then the four waves through LDS
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o), os = __shfl_xor(s, o);
+        const float nm = fmaxf(mx, om);
+        s = (mx == -INFINITY ? 0.f : s * __expf(mx - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
+        mx = nm;
+    }
+    __shared__ float rm[4], rs[4];
+    if ((tid & 63) == 0) { rm[tid >> 6] = mx; rs[tid >> 6] = s; }
     __syncthreads();
     if (tid == 0) {
-        const float l = mx + logf(red[0] + red[1] + red[2] + red[3]);
+        const float m4 = fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
+        float tot = 0.f;
+        for (int w = 0; w < 4; w++) tot += rm[w] == -INFINITY ? 0.f : rs[w] * __expf(rm[w] - m4);
+        const float l = m4 + logf(tot);
         int t = targets[r];
         t = t < 0 ? 0 : (t >= V ? V - 1 : t);
         const float tl = row[t];
