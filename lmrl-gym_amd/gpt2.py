@@ -159,14 +159,25 @@ class KVSession:
         self._len_bound = 0
         self.shared_prefix = 0
 
+    def set_len(self, lens):
+        """Truncate / set every env's cache length from the host (int array [B]): positions >= lens[b] are treated as free and will be
+        overwritten by the next forwards — how a policy keeps the K/V rows of the longest common prefix of consecutive prompts."""
+        import torch
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        assert lens.shape == (self.B,) and int(lens.max(initial=0)) <= self.tmax
+        self.len.copy_(torch.from_numpy(lens))
+        self._len_bound = int(lens.max(initial=0))
+        self.shared_prefix = 0
+
     shared_prefix = 0   # positions [0, shared_prefix) of every env's cache equal env 0's (set by broadcast_prefix_from, cleared by reset)
 
     _len_bound = 0   # host-side upper bound of max(self.len): forwards are enqueued without reading the device lengths back
 
-    def forward(self, tokens, cnt, chunk: int, all_hidden=None):
-        """tokens int32 [B*chunk], cnt int32 [B]; updates the cache, self.len and self.last_hidden."""
+    def forward(self, tokens, cnt, chunk: int, all_hidden=None, len_bound_after: Optional[int] = None):
+        """tokens int32 [B*chunk], cnt int32 [B]; updates the cache, self.len and self.last_hidden.  `len_bound_after`: the caller's exact
+        knowledge of max(len) after this forward (ragged prefills); default: the previous bound + chunk."""
         e = self.eng
-        self._len_bound += chunk
+        self._len_bound = self._len_bound + chunk if len_bound_after is None else int(len_bound_after)
         if self._len_bound > self.tmax:
             raise _lib.LmrlError(f"KV cache overflow: up to {self._len_bound} positions would be written into a cache of tmax = {self.tmax} "
                                  "(size the session for prompt + generated tokens, or reset() it)")

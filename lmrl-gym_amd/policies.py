@@ -31,23 +31,40 @@ class _Generator:
         # (bit-identical results); a per-session flag, not process state
         self.sessions = [e.session(batch, tmax, flags=FWD_RAGGED_ALWAYS) for e in self.engines]
         self.dev = self.engines[0].device
+        self.cached: List[List[int]] = [[] for _ in range(batch)]     # token ids whose K/V rows sit at positions [0, n) of every session
+        self.prefilled_tokens = 0                                      # tokens actually forwarded by prefill() (diagnostic)
 
-    def prefill(self, prompts: List[List[int]]):
-        """Chunked prefill, 16 tokens per env per forward (one full MFMA query tile of the chunk-attention kernel)."""
+    def prefill(self, prompts: List[List[int]], reuse: bool = True):
+        """Chunked prefill, 16 tokens per env per forward (one full MFMA query tile of the chunk-attention kernel).
+
+        reuse=True keeps, per env, the K/V rows of the longest common prefix of this prompt and the previous call's prompt and forwards only
+        the rest: a text env's history grows by an action and an observation per turn, so a turn costs its NEW tokens instead of the whole
+        history (the reference re-encodes and re-runs the full prompt in every `act`, ppo/gpt2/interface.py:519-546).  A prompt that was
+        left-truncated, re-tokenised differently or belongs to a new episode simply has a short common prefix."""
         t, B, C = self.t, self.B, 16
+        keep = np.zeros(B, dtype=np.int32)
+        if reuse:
+            for b, p in enumerate(prompts):
+                old, n, lim = self.cached[b], 0, min(len(self.cached[b]), len(p) - 1)      # at least one token is forwarded: its hidden
+                while n < lim and old[n] == p[n]:                                       # state feeds the first sample
+                    n += 1
+                keep[b] = n
         for s in self.sessions:
-            s.reset()
-        maxlen = max(len(p) for p in prompts)
+            s.set_len(keep) if reuse else s.reset()
+        maxlen = max(len(p) - int(k) for p, k in zip(prompts, keep))
         for c0 in range(0, maxlen, C):
             toks = np.zeros((B, C), dtype=np.int32)
             cnt = np.zeros(B, dtype=np.int32)
             for b, p in enumerate(prompts):
-                seg = p[c0:c0 + C]
+                seg = p[keep[b] + c0: keep[b] + c0 + C]
                 toks[b, : len(seg)] = seg
                 cnt[b] = len(seg)
+            self.prefilled_tokens += int(cnt.sum())
             td, cd = t.from_numpy(toks.reshape(-1)).to(self.dev), t.from_numpy(cnt).to(self.dev)
+            bound = max(min(int(k) + c0 + C, len(p)) for p, k in zip(prompts, keep))      # exact: the kept prefixes differ per env
             for s in self.sessions:
-                s.forward(td, cd, C)
+                s.forward(td, cd, C, len_bound_after=bound)
+        self.cached = [list(p) for p in prompts]      # generation writes behind the prompt: those rows are re-derived from the next prompt
 
 
 class GPT2PPOPolicy(BatchedTextPolicy):
@@ -55,8 +72,9 @@ class GPT2PPOPolicy(BatchedTextPolicy):
                  temperature: Optional[float] = None, top_k: Optional[int] = None, top_p: Optional[float] = None,
                  eos_token_id: Optional[int] = None,
                  pad_token_id: Optional[int] = None, seed: int = 0, in_str_process: Optional[Callable[[str], str]] = None,
-                 out_str_process: Optional[Callable[[str], str]] = None):
+                 out_str_process: Optional[Callable[[str], str]] = None, reuse_kv: bool = True):
         self.engine, self.tokenizer = engine, tokenizer
+        self.reuse_kv = reuse_kv
         self.max_input_length, self.max_new_tokens = max_input_length, max_new_tokens
         self.temperature = (temperature if temperature is not None else 1.0) if do_sample else 0.0
         self.top_k = top_k or 0
@@ -96,7 +114,7 @@ class GPT2PPOPolicy(BatchedTextPolicy):
 
     def _generate(self, gen, prompts, text_history, done, B):
         import torch
-        gen.prefill(prompts)
+        gen.prefill(prompts, reuse=self.reuse_kv)
         self.calls += 1                                     # one random stream per act() call, like the per-call key split
         # Generation loop without a host sync per token: live flags, the generated ids and the next decode inputs stay on the
         # device (`lmrl_gen_accept`); the host only peeks at the live flags every `sync_every` tokens to stop early.

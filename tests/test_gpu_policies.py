@@ -280,3 +280,39 @@ def test_twenty_questions_dual_model_rollout(setup):
         assert [w.words for w in words] == [wl[s % len(wl)].words for s in (1, 2, 3, 4)]
     finally:
         Q.set_pos_tagger(None)
+
+
+def test_kv_reuse_across_act_calls_forwards_only_new_tokens(setup):
+    """`GPT2PPOPolicy(reuse_kv=True)` keeps the K/V rows of the longest common prefix of consecutive prompts (the reference re-runs the whole
+    history in every act, ppo/gpt2/interface.py:519-546).  Over a multi-turn episode with growing histories: identical bookkeeping (cache
+    lengths), hidden states within the engine's bf16 tolerance of the from-scratch prefill, the same greedy actions except where the top-2
+    margin is at rounding level, and far fewer prefilled tokens."""
+    from lmrl_gym_amd import environment as E
+    from lmrl_gym_amd.policies import GPT2PPOPolicy
+    dev, cfg, sd, sd_v, eng, eng_v = setup
+    tok = CharTok(cfg.vocab)
+    mk = lambda reuse: GPT2PPOPolicy(eng, tok, max_input_length=80, max_new_tokens=5, do_sample=False, eos_token_id=tok.eos_token_id,
+                                     out_str_process=lambda x: x.removesuffix("\n") + "\n", reuse_kv=reuse)
+    pa, pb = mk(True), mk(False)
+    B = 7
+    hist = [(E.Text("s%d: fox\n" % i, False),) for i in range(B)]
+    same = total = 0
+    for turn in range(5):
+        ha = pa.act(hist, [False] * B)
+        hb = pb.act(hist, [False] * B)
+        la, lb = pa._gen.sessions[0].len.cpu().numpy(), pb._gen.sessions[0].len.cpu().numpy()
+        assert (la == lb).all()
+        xa, xb = pa._gen.sessions[0].last_hidden.float().cpu(), pb._gen.sessions[0].last_hidden.float().cpu()
+        for x, y in zip(ha, hb):
+            total += 1
+            same += x[-1].text == y[-1].text
+        # both policies continue from policy B's (from-scratch) actions so that the histories stay identical
+        hist = [tuple(h) + (E.Text("o%d%d.\n" % (turn, i), False),) for i, h in enumerate(hb)]
+        if turn == 3:                      # one env starts a new episode: its common prefix collapses, the others keep theirs
+            hist[2] = (E.Text("new ep\n", False),)
+    assert same >= int(0.9 * total), (same, total)
+    assert pa._gen.prefilled_tokens * 2 < pb._gen.prefilled_tokens, (pa._gen.prefilled_tokens, pb._gen.prefilled_tokens)
+    # a prompt longer than max_input_length is LEFT-truncated: the prefix no longer matches and the prompt is prefilled from scratch
+    long = [(E.Text("x" * 200 + "\n", False),)] * B
+    ha, hb = pa.act(long, [False] * B), pb.act(long, [False] * B)
+    assert [h[-1].text for h in ha] == [h[-1].text for h in hb]
