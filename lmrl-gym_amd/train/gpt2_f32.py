@@ -84,12 +84,13 @@ class GPT2F32:
     `ops.MatmulBF16`; the default "f32" is the reference's default arithmetic."""
 
     def __init__(self, params: Dict[str, "torch.Tensor"], n_head: int, ln_eps: float = 1e-5, device=None, matmul: str = "f32",
-                 attention: str = "flash"):
+                 attention: str = "flash", gradient_checkpointing: bool = False):
         """attention="flash": online-softmax tile sweeps (csrc/flash_attn_train.hip; operands fp32 or bf16 following `matmul`), no
         [B*H, T, T] tensors; "materialized": the batched-sgemm + softmax formulation (fp32; the cross-check of the flash kernels)."""
         import torch
         assert matmul in ("f32", "bf16") and attention in ("flash", "materialized")
         self.attention = attention
+        self.gradient_checkpointing = gradient_checkpointing      # the scripts' flag (train_ilql_gpt2.py:201-202): recompute blocks in backward
         self.t = torch
         self.dev = device or next(iter(params.values())).device
         p32 = {k: v.to(self.dev, torch.float32) for k, v in params.items()}
@@ -104,6 +105,46 @@ class GPT2F32:
         self._colsum_ws = torch.empty(64 * max(self.d_ff, 3 * self.d, self.vocab), dtype=torch.float32, device=self.dev)
         self.mm = ops.MatmulBF16(self.dev) if matmul == "bf16" else None
         self.ld_vocab = ops._pad(self.vocab) if self.mm is not None else self.vocab     # row stride of [rows, V] logits
+
+    def _layer_forward(self, l: int, x, B: int, T: int, km, flash: bool, lse_n: int):
+        """One transformer block: x [B*T, d] -> (x_out, cache of every intermediate the backward pass reads)."""
+        t = self.t
+        R, d, H, p = B * T, self.d, self.n_head, self.p
+        hd = d // H
+        new = lambda *shape: t.empty(shape, dtype=t.float32, device=self.dev)
+        q = f"h.{l}."
+        c = dict(x_in=x)
+        h1, c["m1"], c["r1"] = new(R, d), new(R), new(R)
+        ops.layernorm_fwd(x, p[q + "ln_1.weight"], p[q + "ln_1.bias"], h1, c["m1"], c["r1"], R, d, self.eps)
+        qkv = new(R, 3 * d)
+        ops.linear_fwd(h1, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], qkv, R, d, 3 * d, mm=self.mm)
+        att = new(R, d)
+        if flash:
+            P = None
+            c["lse"] = new(lse_n)
+            ops.flash_attn_fwd(qkv, km, att, c["lse"], self._flash_ws[0], B, H, T, self.mm is not None)
+        else:
+            P = new(B * H, T, T)
+            # S = scale * Q K^T per (b, h); Q/K/V are column slices of qkv (row stride 3d)
+            ops.sgemm(qkv, qkv, P, T, T, hd, trans_b=True, alpha=1.0 / math.sqrt(hd), lda=3 * d, ldb=3 * d, ldc=T, b_off=d,
+                      batch=(B, H), sa=(T * 3 * d, hd), sb=(T * 3 * d, hd), sc=(H * T * T, T * T))
+            ops.softmax_causal_fwd(P, km, P, B, H, T)
+            ops.sgemm(P, qkv, att, T, hd, T, lda=T, ldb=3 * d, ldc=d, b_off=2 * d, batch=(B, H), sa=(H * T * T, T * T),
+                      sb=(T * 3 * d, hd), sc=(T * d, hd))
+        x_mid = new(R, d)
+        ops.linear_fwd(att, p[q + "attn.c_proj.weight"], p[q + "attn.c_proj.bias"], x_mid, R, d, d, mm=self.mm)
+        ops.axpby(1.0, x_mid, 1.0, x, x_mid)
+        h2, c["m2"], c["r2"] = new(R, d), new(R), new(R)
+        ops.layernorm_fwd(x_mid, p[q + "ln_2.weight"], p[q + "ln_2.bias"], h2, c["m2"], c["r2"], R, d, self.eps)
+        f = new(R, self.d_ff)
+        ops.linear_fwd(h2, p[q + "mlp.c_fc.weight"], p[q + "mlp.c_fc.bias"], f, R, d, self.d_ff, mm=self.mm)
+        g = new(R, self.d_ff)
+        ops.gelu_fwd(f, g)
+        x_out = new(R, d)
+        ops.linear_fwd(g, p[q + "mlp.c_proj.weight"], p[q + "mlp.c_proj.bias"], x_out, R, self.d_ff, d, mm=self.mm)
+        ops.axpby(1.0, x_out, 1.0, x_mid, x_out)
+        c.update(h1=h1, qkv=qkv, P=P, att=att, x_mid=x_mid, h2=h2, f=f, g=g)
+        return x_out, c
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids, attention_mask, position_ids, tag: str = "fwd"):
@@ -129,40 +170,12 @@ class GPT2F32:
                 self._flash_ws, self._flash_key = ops.flash_attn_ws(B, H, T, self.mm is not None, self.dev), key
             lse_n = self._flash_ws[1]
         cache["flash"] = flash
+        cache["lse_n"] = lse_n
         for l in range(self.n_layer):
-            q = f"h.{l}."
-            c = dict(x_in=x)
-            h1, c["m1"], c["r1"] = new(R, d), new(R), new(R)
-            ops.layernorm_fwd(x, p[q + "ln_1.weight"], p[q + "ln_1.bias"], h1, c["m1"], c["r1"], R, d, self.eps)
-            qkv = new(R, 3 * d)
-            ops.linear_fwd(h1, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], qkv, R, d, 3 * d, mm=self.mm)
-            att = new(R, d)
-            if flash:
-                P = None
-                c["lse"] = new(lse_n)
-                ops.flash_attn_fwd(qkv, km, att, c["lse"], self._flash_ws[0], B, H, T, self.mm is not None)
-            else:
-                P = new(B * H, T, T)
-                # S = scale * Q K^T per (b, h); Q/K/V are column slices of qkv (row stride 3d)
-                ops.sgemm(qkv, qkv, P, T, T, hd, trans_b=True, alpha=1.0 / math.sqrt(hd), lda=3 * d, ldb=3 * d, ldc=T, b_off=d,
-                          batch=(B, H), sa=(T * 3 * d, hd), sb=(T * 3 * d, hd), sc=(H * T * T, T * T))
-                ops.softmax_causal_fwd(P, km, P, B, H, T)
-                ops.sgemm(P, qkv, att, T, hd, T, lda=T, ldb=3 * d, ldc=d, b_off=2 * d, batch=(B, H), sa=(H * T * T, T * T),
-                          sb=(T * 3 * d, hd), sc=(T * d, hd))
-            x_mid = new(R, d)
-            ops.linear_fwd(att, p[q + "attn.c_proj.weight"], p[q + "attn.c_proj.bias"], x_mid, R, d, d, mm=self.mm)
-            ops.axpby(1.0, x_mid, 1.0, x, x_mid)
-            h2, c["m2"], c["r2"] = new(R, d), new(R), new(R)
-            ops.layernorm_fwd(x_mid, p[q + "ln_2.weight"], p[q + "ln_2.bias"], h2, c["m2"], c["r2"], R, d, self.eps)
-            f = new(R, self.d_ff)
-            ops.linear_fwd(h2, p[q + "mlp.c_fc.weight"], p[q + "mlp.c_fc.bias"], f, R, d, self.d_ff, mm=self.mm)
-            g = new(R, self.d_ff)
-            ops.gelu_fwd(f, g)
-            x_out = new(R, d)
-            ops.linear_fwd(g, p[q + "mlp.c_proj.weight"], p[q + "mlp.c_proj.bias"], x_out, R, self.d_ff, d, mm=self.mm)
-            ops.axpby(1.0, x_out, 1.0, x_mid, x_out)
-            c.update(h1=h1, qkv=qkv, P=P, att=att, x_mid=x_mid, h2=h2, f=f, g=g)
-            cache["layers"].append(c)
+            x_out, c = self._layer_forward(l, x, B, T, km, flash, lse_n)
+            # gradient_checkpointing (train_ilql_gpt2.py:201-202): keep only the block input; backward() recomputes the block — the same
+            # launches on the same inputs, i.e. bit-identical intermediates — right before it differentiates it
+            cache["layers"].append(dict(x_in=x) if self.gradient_checkpointing else c)
             x = x_out
         hid, cache["mf"], cache["rf"] = new(R, d), new(R), new(R)
         ops.layernorm_fwd(x, p["ln_f.weight"], p["ln_f.bias"], hid, cache["mf"], cache["rf"], R, d, self.eps)
@@ -235,6 +248,8 @@ class GPT2F32:
         for l in reversed(range(self.n_layer)):
             q = f"h.{l}."
             c = cache["layers"][l]
+            if "h1" not in c:              # checkpointed block: recompute its intermediates from the stored input
+                _, c = self._layer_forward(l, c["x_in"], B, T, cache["km"], cache["flash"], cache["lse_n"])
             # MLP: x_out = x_mid + gelu(h2 W_fc + b) W_proj + b
             dg = new(R, self.d_ff)
             ops.linear_bwd(c["g"], p[q + "mlp.c_proj.weight"], dx, dg, grads[q + "mlp.c_proj.weight"], grads[q + "mlp.c_proj.bias"], R, self.d_ff, d, ws, mm=self.mm)

@@ -25,12 +25,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ILQL_DEFAULTS = dict(epochs=10, max_steps=None, lr=3e-5, weight_decay=0.0, train_bsize=32, grad_accum_steps=1, max_length=512, log_every=256,
                      policy_max_input_length=256, policy_max_output_length=256, policy_do_sample=True, policy_temperature=None,
                      policy_top_p=None, policy_top_k=None, policy_bsize=32, policy_n_rollouts=32, beta=32.0, polyak_alpha=0.005,
-                     hard_update_every=None, gamma=0.99, tau=0.7, cql_weight=0.01, bad_word_reward=-10.0)      # train_ilql_gpt2.py:41-117, :369
+                     hard_update_every=None, gamma=0.99, tau=0.7, cql_weight=0.01, bad_word_reward=-10.0,
+                     bf16_activations=False, gradient_checkpointing=False)                                   # train_ilql_gpt2.py:41-117, :369
 PPO_DEFAULTS = dict(n_rounds=1, epochs=1, max_steps=None, lr=1e-5, weight_decay=0.0, train_bsize=32, train_bc_bsize=None, grad_accum_steps=None,
                     rollout_bsize=32, n_rollouts=128, ppo_data_bsize=32, max_input_length=512, max_output_length=512, policy_do_sample=True,
                     policy_temperature=None, policy_top_p=None, policy_top_k=None, gamma=1.0, lam=0.95, use_advantage_whitening=True,
                     init_kl_coef=0.001, kl_target=None, kl_horizon=None, cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0,
-                    bc_loss_weight=1.0, bad_word_reward=-10.0)                                                 # train_ppo_gpt2.py:40-112, :211
+                    bc_loss_weight=1.0, bad_word_reward=-10.0, bf16_activations=False, gradient_checkpointing=False)   # train_ppo_gpt2.py:40-112, :211
 BC_EVAL_DEFAULTS = dict(policy_n_rollouts=32, policy_bsize=1, policy_max_input_length=256, policy_max_output_length=256, policy_do_sample=True,
                         policy_temperature=None, policy_top_p=None, policy_top_k=None)                         # eval_bc_gpt2.py
 MAZE_EVAL_DEFAULTS = dict(maze_name="double_t_maze", describe_function="describe_observation_only_walls", reward_function="standard_reward",
@@ -114,12 +115,14 @@ def cmd_ilql(a):
     dev = _lib.require_gpu()
     tok = _tokenizer()
     cfg, sd = _model(a.model, max(len(tok), 50257))
-    base, target_base, pi_beta = GPT2F32(sd, cfg.n_head, device=dev), GPT2F32(sd, cfg.n_head, device=dev), _engine(cfg, sd)
+    mm = dict(matmul="bf16" if a.bf16_activations else "f32")                 # the scripts' bf16_activations / gradient_checkpointing flags
+    base = GPT2F32(sd, cfg.n_head, device=dev, gradient_checkpointing=a.gradient_checkpointing, **mm)
+    target_base, pi_beta = GPT2F32(sd, cfg.n_head, device=dev, **mm), _engine(cfg, sd)
     d, V = cfg.d_model, cfg.vocab
     g = torch.Generator().manual_seed(0)
     # MLPHead init of train_ilql_gpt2.py:224-231: layer-2 kernel 0, layer-2 bias -4.4 (Q heads) ; V head likewise
     mk = lambda out: MLPHeadF32({"dense1.kernel": torch.randn(d, d, generator=g) * 0.02, "dense1.bias": torch.zeros(d),
-                                 "dense2.kernel": torch.zeros(d, out), "dense2.bias": torch.full((out,), -4.4)}, dev)
+                                 "dense2.kernel": torch.zeros(d, out), "dense2.bias": torch.full((out,), -4.4)}, dev, **mm)
     tr = ilql.GPT2ILQLTrain(base, mk(V), mk(V), mk(1), tok.pad_token_id, dict(gamma=a.gamma, tau=a.tau, cql_weight=a.cql_weight),
                             target_base=target_base, lr=a.lr, weight_decay=a.weight_decay, grad_accum_steps=a.grad_accum_steps,
                             polyak_alpha=a.polyak_alpha, hard_update_every=None if a.hard_update_every is None else int(a.hard_update_every))
@@ -177,7 +180,9 @@ def cmd_ppo(a):
     dev = _lib.require_gpu()
     tok = _tokenizer()
     cfg, sd = _model(a.model, max(len(tok), 50257))
-    pol_f32, init_f32 = GPT2F32(sd, cfg.n_head, device=dev), GPT2F32(sd, cfg.n_head, device=dev)
+    mm = dict(matmul="bf16" if a.bf16_activations else "f32")
+    pol_f32 = GPT2F32(sd, cfg.n_head, device=dev, gradient_checkpointing=a.gradient_checkpointing, **mm)
+    init_f32 = GPT2F32(sd, cfg.n_head, device=dev, **mm)
     head = LinearHeadF32(dict(kernel=torch.zeros(cfg.d_model, 1), bias=torch.tensor([-4.1])), dev)       # train_ppo_gpt2.py:254-260
     kw = dict(cliprange_value=a.cliprange_value, cliprange=a.cliprange, value_loss_coef=a.value_loss_coef)
     max_len = a.max_input_length + a.max_output_length

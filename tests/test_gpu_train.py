@@ -631,3 +631,29 @@ def test_ilql_detach_flags_and_hard_update_counter(dev):
             assert tr.calls == i + 1
             for k in tr.q1.p:
                 assert torch.equal(tr.q1.p[k], tr.q1_target.p[k]), (i, k)
+
+
+def test_gradient_checkpointing_is_bit_identical(dev):
+    """`GPT2F32(gradient_checkpointing=True)` (the scripts' flag, train_ilql_gpt2.py:201-202) keeps only each block's input and recomputes
+    the block in backward: same launches on the same inputs — loss, every gradient and the post-AdamW parameters are bit-identical, in the
+    fp32 mode, with the tiled attention at head dim 64, and in the bf16-matmul mode."""
+    from lmrl_gym_amd.algorithms import ppo
+    from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
+    for cfg, matmul in ((GPT2Config(2, 2, 64, 128, 211, 32), "f32"), (GPT2Config(3, 2, 128, 256, 300, 160), "f32"),
+                        (GPT2Config(2, 2, 128, 256, 300, 160), "bf16")):
+        sd = init_hf_style_state_dict(cfg, seed=5)
+        rng = np.random.RandomState(2)
+        B, T, pad = 3, 20, cfg.vocab - 1
+        ids, sta, _ = _batch(rng, B, T, cfg.vocab, pad)
+        f = lambda s: (rng.randn(B, T - 1) * s).astype(np.float32)
+        olp, ov, oa, orr = f(0.1) - 5.0, f(1), f(1), f(1)
+        outs = []
+        for ck in (False, True):
+            pol = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev, matmul=matmul, gradient_checkpointing=ck)
+            head = LinearHeadF32(dict(kernel=torch.full((cfg.d_model, 1), 0.01), bias=torch.tensor([-1.0])), dev)
+            tr = ppo.GPT2PPOTrain(pol, head, pad, dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0), lr=1e-3)
+            _, loss, _ = tr.step(ids, sta, olp, ov, oa, orr)
+            outs.append((loss, tr.last_grads[0].flat.clone(), pol.p.flat.clone()))
+        assert outs[0][0] == outs[1][0]
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
