@@ -130,6 +130,39 @@ int lmrl_maze_step(lmrl_maze_ctx *ctx, void *state_d, const uint8_t *action_d, c
                    float *reward_d, uint8_t *done_d, uint8_t *kind_d, uint8_t *walls_d, int n, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Chess env stepping (csrc/chess.hip, csrc/chess_rules.h): python-chess as the reference's chess env uses it
+ * (llm_rl_scripts/chess/env/env.py:28-185 — Board(fen), push_san, san, fen, is_checkmate, is_game_over), one game per lane.
+ * The opponent (Stockfish over UCI, env.py:157-170) is a host process pool and hands its moves back in UCI form.
+ * Position buffer: lmrl_chess_pos_bytes() per game.  Strings are fixed-pitch, NUL-terminated: FEN LMRL_CHESS_FEN_BYTES, SAN action
+ * LMRL_CHESS_ACTION_BYTES, UCI move 8 bytes.
+ * ------------------------------------------------------------------------------------------ */
+#define LMRL_CHESS_FEN_BYTES 96
+#define LMRL_CHESS_ACTION_BYTES 16
+#define LMRL_CHESS_ILLEGAL 0   /* unparsable / illegal / ambiguous SAN: reward -1, not done, board unchanged   env.py:109-118 */
+#define LMRL_CHESS_MOVED 1     /* legal move, game goes on: the opponent is to move */
+#define LMRL_CHESS_GAME_OVER 2 /* legal move ended the game: reward 1 if checkmate else 0, done                env.py:121-125 */
+#define LMRL_CHESS_NULL_MOVE 3 /* '--' / 'Z0': reward -1, done                                                env.py:111-113 */
+size_t lmrl_chess_pos_bytes(void);
+/* chess.Board(fen) for n games; ok_d[i] = 0 for a malformed FEN */
+int lmrl_chess_reset(void *pos_d, const char *fens_d, uint8_t *ok_d, int n, void *stream);
+/* the agent's half of ChessEnv.step: actions_d [n][LMRL_CHESS_ACTION_BYTES] SAN (blanks already removed); result_d = LMRL_CHESS_*,
+ * fen_out_d [n][LMRL_CHESS_FEN_BYTES] = board.fen() after the half-step; inactive games: result 255, nothing written */
+int lmrl_chess_agent_step(void *pos_d, const char *actions_d, const uint8_t *active_d, float *reward_d, uint8_t *done_d, uint8_t *result_d,
+                          char *fen_out_d, int n, void *stream);
+/* the opponent's half: uci_d [n][8] a legal engine move; san_out_d = board.san(move) BEFORE it is played (env.py:163), reward -1 if the agent
+ * is mated, done = is_game_over(); ok_d = 0 if the move is not legal in the position */
+int lmrl_chess_opponent_step(void *pos_d, const char *uci_d, const uint8_t *active_d, float *reward_d, uint8_t *done_d, uint8_t *ok_d, char *san_out_d,
+                             char *fen_out_d, int n, void *stream);
+/* the same rules on ONE position in host memory (CPU-tier tests, oracle comparisons; no GPU needed).  Negative return = bad argument. */
+int lmrl_chess_host_from_fen(const char *fen, void *pos);
+int lmrl_chess_host_fen(const void *pos, char *out);                                  /* -> length */
+int lmrl_chess_host_legal_moves(const void *pos, char *out_uci /* [256][8] */, char *out_san /* [256][16] or NULL */);   /* -> count */
+int lmrl_chess_host_agent_step(void *pos, const char *san, float *reward, int *done);  /* -> LMRL_CHESS_* */
+int lmrl_chess_host_opponent_step(void *pos, const char *uci, char *san_out, float *reward, int *done);   /* -> 1 if the move was legal */
+/* bit0 check, bit1 checkmate, bit2 is_game_over, bit3 insufficient material, bit4 stalemate, bit5 fivefold repetition, bit6 75-move rule */
+int lmrl_chess_host_status(const void *pos);
+
+/* ------------------------------------------------------------------------------------------
  * Per-token RL reductions (wavefront-shuffle kernels).
  * ------------------------------------------------------------------------------------------ */
 /*

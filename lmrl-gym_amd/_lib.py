@@ -60,6 +60,16 @@ _SIGS = {
     "lmrl_maze_tok_action": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "lmrl_maze_tok_result": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lmrl_gpt2_kv_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "lmrl_chess_pos_bytes": (c_size_t, []),
+    "lmrl_chess_reset": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_chess_agent_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_chess_opponent_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_chess_host_from_fen": (c_int, [ctypes.c_char_p, c_void_p]),
+    "lmrl_chess_host_fen": (c_int, [c_void_p, c_void_p]),
+    "lmrl_chess_host_legal_moves": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "lmrl_chess_host_agent_step": (c_int, [c_void_p, ctypes.c_char_p, c_void_p, c_void_p]),
+    "lmrl_chess_host_opponent_step": (c_int, [c_void_p, ctypes.c_char_p, c_void_p, c_void_p, c_void_p]),
+    "lmrl_chess_host_status": (c_int, [c_void_p]),
     "lmrl_wordle_tok_create": (c_void_p, [c_void_p, c_void_p, c_int, c_int, c_int]),
     "lmrl_wordle_tok_destroy": (None, [c_void_p]),
     "lmrl_wordle_tok_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
