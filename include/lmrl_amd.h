@@ -146,9 +146,10 @@ size_t lmrl_chess_pos_bytes(void);
 /* chess.Board(fen) for n games; ok_d[i] = 0 for a malformed FEN */
 int lmrl_chess_reset(void *pos_d, const char *fens_d, uint8_t *ok_d, int n, void *stream);
 /* the agent's half of ChessEnv.step: actions_d [n][LMRL_CHESS_ACTION_BYTES] SAN (blanks already removed); result_d = LMRL_CHESS_*,
- * fen_out_d [n][LMRL_CHESS_FEN_BYTES] = board.fen() after the half-step; inactive games: result 255, nothing written */
+ * fen_out_d [n][LMRL_CHESS_FEN_BYTES] = board.fen() after the half-step; uci_out_d [n][8] (optional) = the played move in UCI form (what the
+ * engine is told, env.py:121), empty for an illegal action; inactive games: result 255, nothing written */
 int lmrl_chess_agent_step(void *pos_d, const char *actions_d, const uint8_t *active_d, float *reward_d, uint8_t *done_d, uint8_t *result_d,
-                          char *fen_out_d, int n, void *stream);
+                          char *fen_out_d, char *uci_out_d, int n, void *stream);
 /* the opponent's half: uci_d [n][8] a legal engine move; san_out_d = board.san(move) BEFORE it is played (env.py:163), reward -1 if the agent
  * is mated, done = is_game_over(); ok_d = 0 if the move is not legal in the position */
 int lmrl_chess_opponent_step(void *pos_d, const char *uci_d, const uint8_t *active_d, float *reward_d, uint8_t *done_d, uint8_t *ok_d, char *san_out_d,

@@ -62,7 +62,7 @@ _SIGS = {
     "lmrl_gpt2_kv_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "lmrl_chess_pos_bytes": (c_size_t, []),
     "lmrl_chess_reset": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "lmrl_chess_agent_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_chess_agent_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lmrl_chess_opponent_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lmrl_chess_host_from_fen": (c_int, [ctypes.c_char_p, c_void_p]),
     "lmrl_chess_host_fen": (c_int, [c_void_p, c_void_p]),

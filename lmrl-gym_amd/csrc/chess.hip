@@ -29,13 +29,13 @@ __global__ void chess_reset_kernel(Pos *pos, const char *fens, uint8_t *ok, int 
 }
 
 __global__ void chess_agent_step_kernel(Pos *pos, const char *actions, const uint8_t *active, float *reward, uint8_t *done, uint8_t *result,
-                                        char *fen_out, int n) {
+                                        char *fen_out, char *uci_out, int n) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     if (active && !active[e]) { result[e] = 255; return; }
     const char *a = actions + (size_t)e * kAct;
     float r; int d;
-    const int res = agent_half_step(pos[e], a, cstr_len(a, kAct), &r, &d);
+    const int res = agent_half_step(pos[e], a, cstr_len(a, kAct), &r, &d, uci_out ? uci_out + (size_t)e * 8 : nullptr);
     reward[e] = r; done[e] = (uint8_t)d; result[e] = (uint8_t)res;
     fen(pos[e], fen_out + (size_t)e * kFen);
 }
@@ -68,10 +68,10 @@ int lmrl_chess_reset(void *pos_d, const char *fens_d, uint8_t *ok_d, int n, void
 }
 
 int lmrl_chess_agent_step(void *pos_d, const char *actions_d, const uint8_t *active_d, float *reward_d, uint8_t *done_d, uint8_t *result_d,
-                          char *fen_out_d, int n, void *stream) {
+                          char *fen_out_d, char *uci_out_d, int n, void *stream) {
     LMRL_REQUIRE(pos_d && actions_d && reward_d && done_d && result_d && fen_out_d && n > 0, "lmrl_chess_agent_step: bad argument");
     hipLaunchKernelGGL(chess_agent_step_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, as_stream(stream), (Pos *)pos_d, actions_d, active_d, reward_d, done_d,
-                       result_d, fen_out_d, n);
+                       result_d, fen_out_d, uci_out_d, n);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

@@ -517,9 +517,10 @@ LMRL_HD inline int parse_san(const Pos &p, const char *s, int len, Move *out) {
 // ChessEnv.step for the agent's half: the action (already stripped of blanks) is a SAN string.  result: 0 illegal / unparsable (reward -1, not done,
 // board unchanged), 1 legal and the game goes on (the opponent is to move), 2 legal and the game is over (reward 1 if checkmate else 0),
 // 3 null move (reward -1, done).
-LMRL_HD inline int agent_half_step(Pos &p, const char *san_str, int len, float *reward, int *done) {
+LMRL_HD inline int agent_half_step(Pos &p, const char *san_str, int len, float *reward, int *done, char *uci_out = nullptr) {
     Move m;
     const int st = parse_san(p, san_str, len, &m);
+    if (uci_out) { if (st == SAN_OK) uci(m, uci_out); else uci_out[0] = 0; }
     if (st == SAN_NULL) { *reward = -1.f; *done = 1; return 3; }
     if (st != SAN_OK) { *reward = -1.f; *done = 0; return 0; }
     make(p, m);
