@@ -42,6 +42,21 @@ def text_trajectory_chains_from_interactions(raw_results, tokenizer, max_length:
     return chains
 
 
+def text_trajectory_chains_from_transitions(raw_results):
+    """The rollout -> chain step for envs whose observation is only the CURRENT state (chess: llm_rl_scripts/chess/ppo/train_ppo_gpt2_online.py:
+    293-314): one TextTrajectory per transition — `post_action_history` with reward [0, r] — linked through `next` in episode order."""
+    from ..environment import TextTrajectory, TextTrajectoryChain
+    chains = []
+    for raw in raw_results:
+        chain = None
+        for tr in reversed(list(raw)):
+            hist = tuple(tr.post_action_history)
+            chain = TextTrajectoryChain(TextTrajectory(hist, (0.0,) * (len(hist) - 1) + (float(tr.reward),), bool(tr.done)), chain)
+        if chain is not None:
+            chains.append(chain)
+    return chains
+
+
 class PPOForwardOutput(NamedTuple):
     initial_policy_logprobs: Optional[np.ndarray]   # [B, T-1] log p_init(ids[t+1] | ids[:t+1])
     policy_logprobs: np.ndarray                     # [B, T-1]

@@ -174,7 +174,8 @@ def cmd_ppo(a):
     from lmrl_gym_amd import _lib, datasets as DS, environment as E
     from lmrl_gym_amd.algorithms import ppo
     from lmrl_gym_amd.algorithms.common import BlockingStrategy, Padding, Truncation
-    from lmrl_gym_amd.algorithms.ppo_inference import GPT2PPOInference, text_trajectory_chains_from_interactions
+    from lmrl_gym_amd.algorithms.ppo_inference import (GPT2PPOInference, text_trajectory_chains_from_interactions,
+                                                       text_trajectory_chains_from_transitions)
     from lmrl_gym_amd.policies import GPT2PPOPolicy
     from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
     dev = _lib.require_gpu()
@@ -196,7 +197,17 @@ def cmd_ppo(a):
         else ppo.FixedKLController(a.init_kl_coef)
     bs = BlockingStrategy(Padding.RIGHT, Truncation.RIGHT, max_len)
     bc = DS.MaskDataset.from_jsonl(a.bc_data, tok, bs) if a.bc_data else None
-    vocab, env = _wordle_env(a)
+    if a.env == "chess":        # configs[3]: online PPO against the chess env (chess/ppo/train_ppo_gpt2_online.py:201-222)
+        from lmrl_gym_amd.envs import chess as C
+        if a.device_rollouts:
+            raise SystemExit("--device-rollouts is the Wordle token loop; the chess env steps its boards on the device through the text protocol")
+        start = C.large_piece_random_endgame(a.chess_pieces) if a.chess_pieces else None
+        env = C.FenChessHistoryEnv(max_moves=a.chess_max_moves, from_position=start, random_opponent=bool(a.chess_random_opponent),
+                                   **({} if a.chess_random_opponent else dict(engine_path=a.chess_engine, engine_options={"Use NNUE": a.chess_use_nnue},
+                                                                              movetime_ms=a.chess_movetime_ms)))
+        vocab = None
+    else:
+        vocab, env = _wordle_env(a)
     step = 0
     for rnd in range(a.n_rounds):
         if a.device_rollouts:       # env + policy + lock-step loop on the GPU; same (interactions, summary) as text_env_eval
@@ -207,7 +218,7 @@ def cmd_ppo(a):
         else:
             raw, summary = E.text_env_eval(env, policy, n_rollouts=a.n_rollouts, bsize=a.rollout_bsize, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)),
                                            verbose=False)
-        chains = text_trajectory_chains_from_interactions(raw, tok, max_len, a.gamma)
+        chains = text_trajectory_chains_from_transitions(raw) if a.env == "chess" else text_trajectory_chains_from_interactions(raw, tok, max_len, a.gamma)
         datas, kls = inf.get_ppo_data_from_text_trajectory_chain(chains, bsize=a.ppo_data_bsize, max_length=max_len, gamma=a.gamma, lam=a.lam,
                                                                  kl_weight=ctl.value, use_advantage_whitening=a.use_advantage_whitening)
         mean_kl = float(kls.mean()) if len(kls) else 0.0
@@ -290,6 +301,14 @@ def build_parser() -> argparse.ArgumentParser:
     sub.choices["ilql"].add_argument("--train-data", required=True)
     sub.choices["ilql"].add_argument("--eval-data", default=None)
     sub.choices["ppo"].add_argument("--bc-data", default=None)
+    pp = sub.choices["ppo"]
+    pp.add_argument("--env", default="wordle", choices=["wordle", "chess"])
+    pp.add_argument("--chess-engine", default=os.environ.get("CHESS_ENGINE_PATH"), help="UCI engine binary (the reference: stockfish/stockfish-ubuntu-20.04-x86-64-avx2)")
+    pp.add_argument("--chess-use-nnue", default="true", help="'false' for a binary built without the net file")
+    pp.add_argument("--chess-random-opponent", type=int, default=0)
+    pp.add_argument("--chess-pieces", default=None, help="e.g. kQK: start every round from a random endgame of this material (large_piece_random_endgame)")
+    pp.add_argument("--chess-max-moves", type=int, default=400)
+    pp.add_argument("--chess-movetime-ms", type=int, default=100)
     g = sub.add_parser("gen-data")
     g.set_defaults(fn=cmd_gen_data)
     g.add_argument("--n-data", type=int, default=1000); g.add_argument("--prob-smart", type=float, default=0.5)
