@@ -94,12 +94,19 @@ def _cpu_rollout(vocab_words, n_envs, max_turns, budget_s):
 
 
 def cpu_baseline(vocab_words, budget_s=14.0):
-    """the CPU path timed beside the GPU number — (1) the rollout port on ALL host threads and (2) on ONE thread
-    (`value` is the all-threads figure), (3) the env alone (C oracle, one thread, no LM).  Bounded samples, ~25 s in total."""
+    """the CPU path timed beside the GPU number — (1) the rollout port on many host threads (the faster of all / 16 threads:
+    `value`, `cores`), (2) on ONE thread, (3) the env alone (C oracle, one thread, no LM).  Bounded samples, ~30 s in total."""
     import torch
     from oracle.wordle import run_scripted
     n_all = torch.get_num_threads()
-    s_all, t_all, turns_all = _cpu_rollout(vocab_words, 32, 6, budget_s)
+    # all host threads is not always the fastest configuration for 32 short sequences (oversubscription on 128-thread hosts): the multi-thread
+    # point is the best of {all threads, 16 threads}; `cores` reports the count it was measured with
+    runs = {}
+    for n_thr in sorted({n_all, min(16, n_all)}, reverse=True):
+        torch.set_num_threads(n_thr)
+        runs[n_thr] = _cpu_rollout(vocab_words, 32, 6, budget_s * 0.6)
+    n_best = max(runs, key=lambda k: runs[k][0] / runs[k][1])
+    s_all, t_all, turns_all = runs[n_best]
     torch.set_num_threads(1)
     try:
         s_one, t_one, turns_one = _cpu_rollout(vocab_words, 16, 3, budget_s * 0.6)
@@ -110,7 +117,8 @@ def cpu_baseline(vocab_words, budget_s=14.0):
     te = time.perf_counter()
     env_steps = run_scripted(vocab_words, 2048, gi)
     te = time.perf_counter() - te
-    return dict(value=s_all / t_all, unit="env-steps/s", cores=n_all, kind="port",
+    return dict(value=s_all / t_all, unit="env-steps/s", cores=n_best, kind="port",
+                by_threads={str(k): round(v[0] / v[1], 2) for k, v in runs.items()},
                 sample=f"32 envs x {turns_all} turns (valid scripted guesses), GPT-2-small fp32 on torch-CPU re-prefilling the history every "
                        f"turn as the reference does + C oracle env; {t_all:.1f} s",
                 one_thread=dict(value=s_one / t_one, cores=1, sample=f"16 envs x {turns_one} turns, same path; {t_one:.1f} s"),
