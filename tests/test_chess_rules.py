@@ -214,3 +214,32 @@ def test_termination_rules():
             break
     assert over_at == 16, over_at              # the start position (after ply 0, 4, 8, 12, 16) occurs for the 5th time after ply 16
     assert b.status() & 4
+
+
+def test_parse_san_never_misbehaves_on_arbitrary_text():
+    """A policy may emit anything: every string is either one of the position's SAN moves (possibly spelled differently) or rejected with
+    reward -1 / not done / board untouched (chess/env/env.py:109-118)."""
+    rng = random.Random(99)
+    alphabet = "abcdefgh12345678NBRQKOx=+#-0 Z"
+    fens = [START, "r3k2r/p1ppqpb1/bn2pnp1/3PN3/1p2P3/2N2Q1p/PPPBBPPP/R3K2R w KQkq - 0 1", "4k3/P6P/8/8/8/8/p6p/4K3 w - - 0 1"]
+    n_ok = n_bad = 0
+    for fen in fens:
+        sans = {s for _, s in Board(fen).legal()}
+        for _ in range(3000):
+            text = "".join(rng.choice(alphabet) for _ in range(rng.randint(0, 9)))
+            b = Board(fen)
+            res, rew, done = b.agent(text)
+            if res in (1, 2):
+                n_ok += 1
+                assert text.strip() and b.fen() != fen
+                reach = set()
+                for u, _ in Board(fen).legal():                 # an accepted string resolves to one of the legal moves
+                    c = Board(fen); c.push_uci(u); reach.add(c.fen())
+                assert b.fen() in reach
+            elif res == 3:
+                assert text in ("--", "Z0") and rew == -1.0 and done == 1
+            else:
+                n_bad += 1
+                assert (rew, done) == (-1.0, 0) and b.fen() == fen
+                assert text not in sans
+    assert n_ok >= 1 and n_bad > 8000
