@@ -77,6 +77,11 @@ int main(int argc, char **argv) {
         {"g8 128x128 2x4 PAIR BF16_LN", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 4, 4, EPI_BF16_LN, 3, true>(g, s); }, 128, 128, false, true},
         {"g8 128x128 2x4 PAIR GELU_LN", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 4, 4, EPI_GELU_BF16_LN, 3, true>(g, s); }, 128, 128, false, true},
         {"g8 64x128 2x4 PAIR", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<64, 128, 2, 4, 4, EPI_BF16, 0, true>(g, s); }, 64, 128},
+        {"g8 128x128 4x4 s2 (16w)", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 4, 4, 2, EPI_BF16>(g, s); }, 128, 128},
+        {"g8 128x128 4x4 s3 (16w)", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 4, 4, 3, EPI_BF16>(g, s); }, 128, 128},
+        {"g8 128x128 4x4 s4 (16w)", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 4, 4, 4, EPI_BF16>(g, s); }, 128, 128},
+        {"g8 128x128 4x4 s3 BF16_LN", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 4, 4, 3, EPI_BF16_LN, 3>(g, s); }, 128, 128, false, true},
+        {"g8 64x128 2x4 s4", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<64, 128, 2, 4, 4, EPI_BF16>(g, s); }, 64, 128},
         {"g8 128x128 2x2 s3 (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 2, 3, EPI_BF16>(g, s); }, 128, 128},
         {"g8 128x128 2x4 s2 f32out", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 4, 2, EPI_F32>(g, s); }, 128, 128, true},
         {"g8 256x256 2x4 s2 f32out", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<256, 256, 2, 4, 2, EPI_F32>(g, s); }, 256, 256, true},
