@@ -473,10 +473,6 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *_
             vr[u] = *reinterpret_cast<const uint4 *>(vc + bo_);                                               \
         }
     LMRL_DEC_LOAD(0);
-    if (append && rr == 0 && L0 < Tmax) {                            // append the new token's K/V row to the cache (unless the qkv GEMM did)
-        *reinterpret_cast<uint4 *>(const_cast<char *>(kc) + (((size_t)env_row + L0) * d + cc * 8) * 2) = knew;
-        *reinterpret_cast<uint4 *>(const_cast<char *>(vc) + (((size_t)env_row + L0) * d + cc * 8) * 2) = vnew;
-    }
     uint32_t qp[4];                                                  // query slice as packed bf16 pairs, pre-scaled by 1/sqrt(64) (exact)
     {
         const uint32_t w[4] = {qv.x, qv.y, qv.z, qv.w};
@@ -540,6 +536,11 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *_
         pk.x = pack_bf16x2(r8[0], r8[1]); pk.y = pack_bf16x2(r8[2], r8[3]);
         pk.z = pack_bf16x2(r8[4], r8[5]); pk.w = pack_bf16x2(r8[6], r8[7]);
         *reinterpret_cast<uint4 *>(out + row0 * d + (size_t)h * 64 + cc * 8) = pk;
+        if (append && L0 < Tmax) {     // append the new token's K/V row to the cache (unless the qkv GEMM did) — at the very end: the wave's
+                                       // stores then follow its load stream instead of sitting inside it
+            *reinterpret_cast<uint4 *>(const_cast<char *>(kc) + (((size_t)env_row + L0) * d + cc * 8) * 2) = knew;
+            *reinterpret_cast<uint4 *>(const_cast<char *>(vc) + (((size_t)env_row + L0) * d + cc * 8) * 2) = vnew;
+        }
     }
 }
 
