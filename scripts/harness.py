@@ -32,6 +32,10 @@ PPO_DEFAULTS = dict(n_rounds=1, epochs=1, max_steps=None, lr=1e-5, weight_decay=
                     policy_temperature=None, policy_top_p=None, policy_top_k=None, gamma=1.0, lam=0.95, use_advantage_whitening=True,
                     init_kl_coef=0.001, kl_target=None, kl_horizon=None, cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0,
                     bc_loss_weight=1.0, bad_word_reward=-10.0, bf16_activations=False, gradient_checkpointing=False)   # train_ppo_gpt2.py:40-112, :211
+FILTERED_BC_DEFAULTS = dict(n_rounds=1, epochs=1, max_steps=None, lr=1e-5, weight_decay=0.0, train_bsize=32, grad_accum_steps=None, rollout_bsize=32,
+                            n_rollouts=128, filter_percengage=0.3, bf16_activations=False, gradient_checkpointing=False, max_input_length=512,
+                            max_output_length=512, policy_do_sample=True, policy_temperature=None, policy_top_p=None, policy_top_k=None,
+                            bad_word_reward=-10.0)                                    # wordle/online_filtered_bc/train_online_filtered_bc_gpt2.py:40-87
 BC_EVAL_DEFAULTS = dict(policy_n_rollouts=32, policy_bsize=1, policy_max_input_length=256, policy_max_output_length=256, policy_do_sample=True,
                         policy_temperature=None, policy_top_p=None, policy_top_k=None)                         # eval_bc_gpt2.py
 MAZE_EVAL_DEFAULTS = dict(maze_name="double_t_maze", describe_function="describe_observation_only_walls", reward_function="standard_reward",
@@ -248,6 +252,54 @@ def cmd_ppo(a):
     _log("eval", summary)
 
 
+def cmd_filtered_bc(a):
+    """Online filtered BC (LLM_RL/algorithms/online_filtered_bc/train.py + wordle/online_filtered_bc/train_online_filtered_bc_gpt2.py:198-278):
+    every round: rollouts with the current policy, keep the top `filter_percengage` episodes by total reward, BC on their action tokens."""
+    import torch
+    from lmrl_gym_amd import _lib, datasets as DS, environment as E
+    from lmrl_gym_amd.algorithms import bc
+    from lmrl_gym_amd.algorithms.common import BlockingStrategy, Padding, Truncation
+    from lmrl_gym_amd.policies import GPT2PPOPolicy
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32
+    dev = _lib.require_gpu()
+    tok = _tokenizer()
+    cfg, sd = _model(a.model, max(len(tok), 50257))
+    model = GPT2F32(sd, cfg.n_head, device=dev, matmul="bf16" if a.bf16_activations else "f32", gradient_checkpointing=a.gradient_checkpointing)
+    tr = bc.GPT2BCTrain(model, tok.pad_token_id, lr=a.lr, weight_decay=a.weight_decay, grad_accum_steps=int(a.grad_accum_steps or 1))
+    policy = GPT2PPOPolicy(_engine(cfg, sd), tok, max_input_length=a.max_input_length, max_new_tokens=a.max_output_length, do_sample=a.policy_do_sample,
+                           temperature=a.policy_temperature, top_k=None if a.policy_top_k is None else int(a.policy_top_k), top_p=a.policy_top_p,
+                           eos_token_id=tok.encode("\n")[0], out_str_process=lambda x: x.removesuffix("\n") + "\n")
+    vocab, env = _wordle_env(a)
+    bs = BlockingStrategy(Padding.RIGHT, Truncation.LEFT, a.max_input_length + a.max_output_length)
+    step = 0
+    for rnd in range(a.n_rounds):
+        if a.device_rollouts:
+            ro = _device_rollouts(policy.engine, vocab, tok, a.rollout_bsize, a.bad_word_reward, min(a.max_output_length, 12))
+            raw, summary = ro.text_env_eval(a.n_rollouts, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)), temperature=a.policy_temperature or 1.0,
+                                            top_k=int(a.policy_top_k or 0), sample_seed=rnd)
+            ro.close()
+        else:
+            raw, summary = E.text_env_eval(env, policy, n_rollouts=a.n_rollouts, bsize=a.rollout_bsize, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)),
+                                           verbose=False)
+        segs = [[(t.text, float(t.is_action)) for t in ep[-1].post_transition_history] for ep in raw]
+        rewards = [sum(t.reward for t in ep) for ep in raw]
+        top = sorted(range(len(segs)), key=lambda i: rewards[i], reverse=True)[: int(len(segs) * a.filter_percengage)]
+        _log("data_collection", dict(round=rnd, env_interaction=summary, kept=len(top), reward_cutoff=min((rewards[i] for i in top), default=None)))
+        if not top:
+            continue
+        ds = DS.MaskDataset.blocked_from_str_segments([segs[i] for i in top], tok, bs)
+        for epoch in range(a.epochs):
+            for batch in DS.dataloader(np.random.default_rng(rnd * 1000 + epoch), ds, min(a.train_bsize, len(ds)), truncate=True):
+                _, loss, _ = tr.step(batch["input_ids"], batch["input_training_mask"] > 0)
+                step += 1
+                _log("train", dict(step=step, round=rnd, loss=loss))
+                if a.max_steps is not None and step >= int(a.max_steps):
+                    break
+        policy.set_params(_engine(cfg, model.p))
+    _, summary = E.text_env_eval(env, policy, n_rollouts=a.n_rollouts, bsize=a.rollout_bsize, seed_generator=iter(range(10 ** 8, 10 ** 9)), verbose=False)
+    _log("eval", summary)
+
+
 def cmd_bc_eval(a):
     from lmrl_gym_amd import environment as E
     from lmrl_gym_amd.policies import GPT2PPOPolicy
@@ -289,7 +341,8 @@ def cmd_maze_eval(a):
 def build_parser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     sub = ap.add_subparsers(dest="cmd", required=True)
-    for name, fn, defaults in (("ilql", cmd_ilql, ILQL_DEFAULTS), ("ppo", cmd_ppo, PPO_DEFAULTS), ("bc-eval", cmd_bc_eval, BC_EVAL_DEFAULTS),
+    for name, fn, defaults in (("ilql", cmd_ilql, ILQL_DEFAULTS), ("ppo", cmd_ppo, PPO_DEFAULTS), ("filtered-bc", cmd_filtered_bc, FILTERED_BC_DEFAULTS),
+                               ("bc-eval", cmd_bc_eval, BC_EVAL_DEFAULTS),
                                ("maze-eval", cmd_maze_eval, MAZE_EVAL_DEFAULTS)):
         p = sub.add_parser(name)
         p.set_defaults(fn=fn)

@@ -178,6 +178,11 @@ def test_harness_script_subcommands_at_toy_scale(tmp_path, capsys):
             "--max-input-length", "72", "--max-output-length", "12"])
     H.main(["ppo", "--n-rollouts", "6", "--rollout-bsize", "4", "--ppo-data-bsize", "4", "--train-bsize", "2", "--max-steps", "1",
             "--max-input-length", "96", "--max-output-length", "6", "--device-rollouts", "1"])
+    # online filtered BC (wordle/online_filtered_bc): rollouts -> top 50 % by reward -> BC on the action tokens, text path and device loop
+    H.main(["filtered-bc", "--n-rollouts", "6", "--rollout-bsize", "3", "--filter-percengage", "0.5", "--train-bsize", "2", "--max-steps", "1",
+            "--max-input-length", "96", "--max-output-length", "8"])
+    H.main(["filtered-bc", "--n-rollouts", "6", "--rollout-bsize", "4", "--filter-percengage", "0.5", "--train-bsize", "2", "--max-steps", "1",
+            "--max-input-length", "96", "--max-output-length", "6", "--device-rollouts", "1", "--bf16-activations", "1"])
     # configs[3] at toy scale: online PPO against the chess env (random opponent; and the reference-built engine when present)
     H.main(["ppo", "--env", "chess", "--chess-random-opponent", "1", "--chess-pieces", "kQK", "--chess-max-moves", "3", "--n-rollouts", "4", "--rollout-bsize", "4",
             "--ppo-data-bsize", "4", "--train-bsize", "2", "--max-steps", "1", "--max-input-length", "160", "--max-output-length", "8"])
@@ -191,7 +196,7 @@ def test_harness_script_subcommands_at_toy_scale(tmp_path, capsys):
     H.main(["maze-eval", "--max-steps", "3", "--generation-bsize", "8", "--max-input-length", "160", "--max-output-length", "6"])
     lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
     tags = [next(iter(l)) for l in lines]
-    assert tags.count("eval") >= 7 and tags.count("data_collection") >= 3 and "gen_data" in tags and "data_collection" in tags and "maze_eval" in tags and "train" in tags
+    assert tags.count("eval") >= 9 and tags.count("data_collection") >= 5 and "gen_data" in tags and "data_collection" in tags and "maze_eval" in tags and "train" in tags
     me = next(l["maze_eval"] for l in lines if "maze_eval" in l)
     assert me["n"] == 26 and 0.0 <= me["move_accuracy"] <= 100.0
 
