@@ -440,6 +440,11 @@ int lmrl_embed_fwd(const float *wte_d, const float *wpe_d, const int32_t *ids_d,
 int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d, float *dwte_d, float *dwpe_d, int rows, int d, void *stream);
 int lmrl_layernorm_fwd(const float *x_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, int rows, int d,
                        float eps, void *stream);
+/* LayerNorm / gelu forward that ALSO write the bf16 copy of their output (row pitch ldb elements) — the operand of the GEMM that consumes it in
+ * the bf16-matmul train mode (saves the separate lmrl_cast_bf16 pass) */
+int lmrl_layernorm_fwd_staged(const float *x_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, void *yb_d, long ldb,
+                              int rows, int d, float eps, void *stream);
+int lmrl_gelu_fwd_staged(const float *x_d, float *y_d, void *yb_d, long ldb, int rows, int cols, void *stream);
 /* dx (=|+=) LN backward; dy_xhat_d (optional [rows][d]) receives dy*xhat whose column sum is d gamma */
 int lmrl_layernorm_bwd(const float *dy_d, const float *x_d, const float *g_d, const float *mean_d, const float *rstd_d, float *dx_d,
                        float *dy_xhat_d, int rows, int d, int accumulate_dx, void *stream);
@@ -465,6 +470,9 @@ size_t lmrl_flash_attn_ws_bytes(int batch, int heads, int t, int bf16);
 size_t lmrl_flash_attn_lse_bytes(int batch, int heads, int t);
 int lmrl_flash_attn_fwd(const float *qkv_d, const uint8_t *key_mask_d, float *att_d, float *lse_d, void *ws_d, int batch, int heads, int t, int bf16,
                         void *stream);
+/* forward that also writes the bf16 copy of att (row pitch ldb elements): the operand of the output projection in the bf16-matmul train mode */
+int lmrl_flash_attn_fwd_staged(const float *qkv_d, const uint8_t *key_mask_d, float *att_d, float *lse_d, void *ws_d, void *att_bf16_d, long ldb, int batch,
+                               int heads, int t, int bf16, void *stream);
 int lmrl_flash_attn_bwd(const float *qkv_d, const uint8_t *key_mask_d, const float *att_d, const float *datt_d, const float *lse_d, float *dqkv_d,
                         void *ws_d, int batch, int heads, int t, int bf16, void *stream);
 /* ---- bf16-MFMA matmul mode of the train step (csrc/train_bf16.hip): the reference's optional `bf16_activations`

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void flash_stage_kernel(const float *__restric
 template <class E>
 __global__ __launch_bounds__(256) void flash_fwd_kernel(const typename E::T *__restrict__ Qn, const typename E::T *__restrict__ Kn,
                                                         const typename E::T *__restrict__ VT, const uint8_t *__restrict__ km, float *__restrict__ att,
-                                                        float *__restrict__ lse, int H, int T, int Tp, int d) {
+                                                        float *__restrict__ lse, int H, int T, int Tp, int d, uint16_t *__restrict__ att_b, long ldb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *sK = smem, *sV = smem + E::TILE;
     uint8_t *sM = reinterpret_cast<uint8_t *>(smem + 2 * E::TILE);
@@ -219,6 +219,15 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const typename E::T *__r
 #pragma unroll
         for (int db = 0; db < 4; db++)
             *reinterpret_cast<f32x4 *>(att + ((long)b * T + qi) * d + h * 64 + db * 16 + lq * 4) = o[db] * inv;
+        if (att_b) {     // bf16 copy: the operand of the output projection in the bf16-matmul train mode
+#pragma unroll
+            for (int db = 0; db < 4; db++) {
+                const f32x4 v = o[db] * inv;
+                uint2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2 *>(att_b + ((long)b * T + qi) * ldb + h * 64 + db * 16 + lq * 4) = pk;
+            }
+        }
     }
     if (lq == 0) lse[(long)bh * Tp + qi] = (qi < T && l > 0.f) ? m + __logf(l) : INFINITY;
 }
@@ -396,7 +405,8 @@ static int flash_stage_qkv(const float *qkv, const FlashWs &w, int batch, int he
 }
 
 template <class E>
-static int flash_fwd(const float *qkv, const uint8_t *km, float *att, float *lse, void *ws, int batch, int heads, int t, hipStream_t s) {
+static int flash_fwd(const float *qkv, const uint8_t *km, float *att, float *lse, void *ws, int batch, int heads, int t, hipStream_t s,
+                     void *att_b = nullptr, long ldb = 0) {
     typedef typename E::T T;
     const int tp = (t + 63) / 64 * 64, bh = batch * heads, d = heads * 64;
     FlashWs w; w.carve(ws, bh, tp, E::SZ);
@@ -405,7 +415,7 @@ static int flash_fwd(const float *qkv, const uint8_t *km, float *att, float *lse
     const size_t lds = 2 * E::TILE + 64;
     LMRL_CHECK_HIP(allow_lds(flash_fwd_kernel<E>, lds));
     hipLaunchKernelGGL(flash_fwd_kernel<E>, dim3(tp / 64, bh), dim3(256), lds, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.VT, km, att, lse, heads,
-                       t, tp, d);
+                       t, tp, d, (uint16_t *)att_b, ldb);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }
@@ -447,6 +457,14 @@ int lmrl_flash_attn_fwd(const float *qkv_d, const uint8_t *key_mask_d, float *at
     LMRL_REQUIRE(qkv_d && att_d && lse_d && ws_d && batch > 0 && heads > 0 && t > 0, "lmrl_flash_attn_fwd: bad argument");
     return bf16 ? flash_fwd<ElemBF16>(qkv_d, key_mask_d, att_d, lse_d, ws_d, batch, heads, t, as_stream(stream))
                 : flash_fwd<ElemF32>(qkv_d, key_mask_d, att_d, lse_d, ws_d, batch, heads, t, as_stream(stream));
+}
+
+int lmrl_flash_attn_fwd_staged(const float *qkv_d, const uint8_t *key_mask_d, float *att_d, float *lse_d, void *ws_d, void *att_bf16_d, long ldb, int batch,
+                               int heads, int t, int bf16, void *stream) {
+    LMRL_REQUIRE(qkv_d && att_d && lse_d && ws_d && att_bf16_d && ldb >= heads * 64 && ldb % 4 == 0 && batch > 0 && heads > 0 && t > 0,
+                 "lmrl_flash_attn_fwd_staged: bad argument");
+    return bf16 ? flash_fwd<ElemBF16>(qkv_d, key_mask_d, att_d, lse_d, ws_d, batch, heads, t, as_stream(stream), att_bf16_d, ldb)
+                : flash_fwd<ElemF32>(qkv_d, key_mask_d, att_d, lse_d, ws_d, batch, heads, t, as_stream(stream), att_bf16_d, ldb);
 }
 
 int lmrl_flash_attn_bwd(const float *qkv_d, const uint8_t *key_mask_d, const float *att_d, const float *datt_d, const float *lse_d, float *dqkv_d,

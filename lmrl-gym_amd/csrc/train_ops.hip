@@ -14,6 +14,13 @@ namespace lmrl {
 
 typedef __attribute__((ext_vector_type(4))) float v4f;
 
+// fp32 -> bf16, round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {f, 0.f};
+    return (uint16_t)(__builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2)) & 0xffffu);
+}
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float *__restrict_
 // ------------------------------------------------------------------------------------------ LayerNorm (fp32, d <= 4096)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ g,
                                                      const float *__restrict__ b, float *__restrict__ y, float *__restrict__ mean,
-                                                     float *__restrict__ rstd, int R, int d, float eps) {
+                                                     float *__restrict__ rstd, int R, int d, float eps, uint16_t *__restrict__ yb, long ldb) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= R) return;
     const float *xr = x + (size_t)r * d;
@@ -81,7 +88,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
     float q = 0.f;
     for (int c = lane; c < d; c += 64) { const float t = xr[c] - mu; q += t * t; }
     const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
-    for (int c = lane; c < d; c += 64) y[(size_t)r * d + c] = (xr[c] - mu) * rs * g[c] + b[c];
+    for (int c = lane; c < d; c += 64) {
+        const float v = (xr[c] - mu) * rs * g[c] + b[c];
+        y[(size_t)r * d + c] = v;
+        if (yb) yb[(size_t)r * ldb + c] = f32_to_bf16_rne(v);      // the bf16 operand of the consuming GEMM (bf16-matmul train mode)
+    }
     if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
 }
 // dx = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)),  dyg = dy * g ; also emits xhat*dy for the gamma gradient
@@ -136,6 +147,16 @@ __device__ __forceinline__ float gelu_new_exact(float x) {
 // (the elementwise kernels below may be called in place — out == x or out == y: no __restrict__ on the pairs that may alias)
 __global__ void gelu_fwd_kernel(const float *x, float *y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = gelu_new_exact(x[i]);
+}
+// the same on a [rows][cols] matrix, also writing the bf16 copy (row pitch ldb) the consuming GEMM reads
+__global__ void gelu_fwd_staged_kernel(const float *x, float *y, uint16_t *__restrict__ yb, long ldb, int rows, int cols) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = gelu_new_exact(x[i]);
+        y[i] = v;
+        const size_t r = i / cols;
+        yb[r * ldb + (i - r * cols)] = f32_to_bf16_rne(v);
+    }
 }
 __global__ void gelu_bwd_kernel(const float *dy, const float *__restrict__ x, float *dx, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -334,7 +355,20 @@ int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d
 int lmrl_layernorm_fwd(const float *x_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, int rows, int d,
                        float eps, void *stream) {
     LMRL_REQUIRE(x_d && g_d && b_d && y_d && mean_d && rstd_d && rows > 0 && d > 0, "lmrl_layernorm_fwd: bad argument");
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, x_d, g_d, b_d, y_d, mean_d, rstd_d, rows, d, eps);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, x_d, g_d, b_d, y_d, mean_d, rstd_d, rows, d, eps, (uint16_t *)nullptr, 0l);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_layernorm_fwd_staged(const float *x_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, void *yb_d, long ldb,
+                              int rows, int d, float eps, void *stream) {
+    LMRL_REQUIRE(x_d && g_d && b_d && y_d && mean_d && rstd_d && yb_d && ldb >= d && rows > 0 && d > 0, "lmrl_layernorm_fwd_staged: bad argument");
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, x_d, g_d, b_d, y_d, mean_d, rstd_d, rows, d, eps, (uint16_t *)yb_d, ldb);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_gelu_fwd_staged(const float *x_d, float *y_d, void *yb_d, long ldb, int rows, int cols, void *stream) {
+    LMRL_REQUIRE(x_d && y_d && yb_d && rows > 0 && cols > 0 && ldb >= cols, "lmrl_gelu_fwd_staged: bad argument");
+    hipLaunchKernelGGL(gelu_fwd_staged_kernel, dim3(ew_grid((size_t)rows * cols)), dim3(256), 0, ST, x_d, y_d, (uint16_t *)yb_d, ldb, rows, cols);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

@@ -114,15 +114,27 @@ class GPT2F32:
         new = lambda *shape: t.empty(shape, dtype=t.float32, device=self.dev)
         q = f"h.{l}."
         c = dict(x_in=x)
+        mm = self.mm
+        stage = mm is not None and d % 64 == 0 and self.d_ff % 64 == 0     # producers write the bf16 GEMM operands themselves (no cast pass)
         h1, c["m1"], c["r1"] = new(R, d), new(R), new(R)
-        ops.layernorm_fwd(x, p[q + "ln_1.weight"], p[q + "ln_1.bias"], h1, c["m1"], c["r1"], R, d, self.eps)
+        xb = None
+        if stage:
+            xb, ldb = mm.stage(R, d)
+            ops.layernorm_fwd_staged(x, p[q + "ln_1.weight"], p[q + "ln_1.bias"], h1, c["m1"], c["r1"], xb, ldb, R, d, self.eps)
+        else:
+            ops.layernorm_fwd(x, p[q + "ln_1.weight"], p[q + "ln_1.bias"], h1, c["m1"], c["r1"], R, d, self.eps)
         qkv = new(R, 3 * d)
-        ops.linear_fwd(h1, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], qkv, R, d, 3 * d, mm=self.mm)
+        ops.linear_fwd(h1, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], qkv, R, d, 3 * d, mm=self.mm, xb=xb)
         att = new(R, d)
+        xb = None
         if flash:
             P = None
             c["lse"] = new(lse_n)
-            ops.flash_attn_fwd(qkv, km, att, c["lse"], self._flash_ws[0], B, H, T, self.mm is not None)
+            if stage:
+                xb, ldb = mm.stage(R, d)
+                ops.flash_attn_fwd_staged(qkv, km, att, c["lse"], self._flash_ws[0], xb, ldb, B, H, T, True)
+            else:
+                ops.flash_attn_fwd(qkv, km, att, c["lse"], self._flash_ws[0], B, H, T, self.mm is not None)
         else:
             P = new(B * H, T, T)
             # S = scale * Q K^T per (b, h); Q/K/V are column slices of qkv (row stride 3d)
@@ -132,16 +144,26 @@ class GPT2F32:
             ops.sgemm(P, qkv, att, T, hd, T, lda=T, ldb=3 * d, ldc=d, b_off=2 * d, batch=(B, H), sa=(H * T * T, T * T),
                       sb=(T * 3 * d, hd), sc=(T * d, hd))
         x_mid = new(R, d)
-        ops.linear_fwd(att, p[q + "attn.c_proj.weight"], p[q + "attn.c_proj.bias"], x_mid, R, d, d, mm=self.mm)
+        ops.linear_fwd(att, p[q + "attn.c_proj.weight"], p[q + "attn.c_proj.bias"], x_mid, R, d, d, mm=self.mm, xb=xb)
         ops.axpby(1.0, x_mid, 1.0, x, x_mid)
         h2, c["m2"], c["r2"] = new(R, d), new(R), new(R)
-        ops.layernorm_fwd(x_mid, p[q + "ln_2.weight"], p[q + "ln_2.bias"], h2, c["m2"], c["r2"], R, d, self.eps)
+        xb = None
+        if stage:
+            xb, ldb = mm.stage(R, d)
+            ops.layernorm_fwd_staged(x_mid, p[q + "ln_2.weight"], p[q + "ln_2.bias"], h2, c["m2"], c["r2"], xb, ldb, R, d, self.eps)
+        else:
+            ops.layernorm_fwd(x_mid, p[q + "ln_2.weight"], p[q + "ln_2.bias"], h2, c["m2"], c["r2"], R, d, self.eps)
         f = new(R, self.d_ff)
-        ops.linear_fwd(h2, p[q + "mlp.c_fc.weight"], p[q + "mlp.c_fc.bias"], f, R, d, self.d_ff, mm=self.mm)
+        ops.linear_fwd(h2, p[q + "mlp.c_fc.weight"], p[q + "mlp.c_fc.bias"], f, R, d, self.d_ff, mm=self.mm, xb=xb)
         g = new(R, self.d_ff)
-        ops.gelu_fwd(f, g)
+        xb = None
+        if stage:
+            xb, ldb = mm.stage(R, self.d_ff)
+            ops.gelu_fwd_staged(f, g, xb, ldb, R, self.d_ff)
+        else:
+            ops.gelu_fwd(f, g)
         x_out = new(R, d)
-        ops.linear_fwd(g, p[q + "mlp.c_proj.weight"], p[q + "mlp.c_proj.bias"], x_out, R, self.d_ff, d, mm=self.mm)
+        ops.linear_fwd(g, p[q + "mlp.c_proj.weight"], p[q + "mlp.c_proj.bias"], x_out, R, self.d_ff, d, mm=self.mm, xb=xb)
         ops.axpby(1.0, x_out, 1.0, x_mid, x_out)
         c.update(h1=h1, qkv=qkv, P=P, att=att, x_mid=x_mid, h2=h2, f=f, g=g)
         return x_out, c

@@ -84,6 +84,11 @@ class MatmulBF16:
             self.w[name] = dst
         return dst
 
+    def stage(self, rows, k):
+        """(buffer, row pitch) for a producer that writes the bf16 operand [rows][k] of the NEXT `linear_fwd` itself (k a multiple of 64)."""
+        assert k % 64 == 0
+        return self._buf("x", _padn(rows) * _pitch(k)), _pitch(k)
+
     def bias(self, b, n):
         """fp32 bias padded to a multiple of 64 entries (the GEMM epilogue reads whole 4-column groups)."""
         key = ("bias", b.data_ptr())
@@ -101,14 +106,16 @@ class MatmulBF16:
                                           2 if accumulate else 3, _sp()), "lmrl_gemm_bf16")
 
 
-def linear_fwd(x, w, b, y, rows, k, n, mm: Optional[MatmulBF16] = None, ldy=None):
-    """y[rows][n] = x[rows][k] @ w[k][n] + b   (flax Dense / HF Conv1D kernel layout [in, out]); row stride of y = ldy (default n)"""
+def linear_fwd(x, w, b, y, rows, k, n, mm: Optional[MatmulBF16] = None, ldy=None, xb=None):
+    """y[rows][n] = x[rows][k] @ w[k][n] + b   (flax Dense / HF Conv1D kernel layout [in, out]); row stride of y = ldy (default n).
+    xb: the bf16 operand of x if its producer already staged it (`MatmulBF16.stage`, LayerNorm / gelu / attention `_staged` forms)."""
     ldy = ldy or n
     if mm is None:
         sgemm(x, w, y, rows, n, k, lda=k, ldb=n, ldc=ldy, bias=b)
         return
     assert ldy % 4 == 0 and ldy >= _pad(n, 4), "bf16 matmul mode: the output row stride must cover whole 4-column groups"
-    xb = mm.cast("x", x, rows, k, k)
+    if xb is None:
+        xb = mm.cast("x", x, rows, k, k)
     wt = mm.cast(("wT", w.data_ptr()), w, k, n, n, transpose=True, keep=True)          # [pad(n)][pad(k)]
     mm.gemm(xb, wt, mm.bias(b, n) if b is not None else None, y, rows, _padn(n), k, ldy, n)
 
@@ -154,6 +161,15 @@ def colsum(x, rows, cols, ld, out, accumulate, ws):
 def layernorm_fwd(x, g, b, y, mean, rstd, rows, d, eps):
     _lib.check(_L().lmrl_layernorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, d,
                                        float(eps), _sp()), "lmrl_layernorm_fwd")
+
+
+def layernorm_fwd_staged(x, g, b, y, mean, rstd, yb, ldb, rows, d, eps):
+    _lib.check(_L().lmrl_layernorm_fwd_staged(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), yb.data_ptr(), ldb,
+                                              rows, d, float(eps), _sp()), "lmrl_layernorm_fwd_staged")
+
+
+def gelu_fwd_staged(x, y, yb, ldb, rows, cols):
+    _lib.check(_L().lmrl_gelu_fwd_staged(x.data_ptr(), y.data_ptr(), yb.data_ptr(), ldb, rows, cols, _sp()), "lmrl_gelu_fwd_staged")
 
 
 def layernorm_bwd(dy, x, g, mean, rstd, dx, dy_xhat, rows, d, accumulate_dx):
@@ -231,6 +247,11 @@ def flash_attn_ws(batch, heads, t, bf16, device):
 def flash_attn_fwd(qkv, key_mask, att, lse, ws, batch, heads, t, bf16):
     _lib.check(_L().lmrl_flash_attn_fwd(qkv.data_ptr(), _lib.ptr(key_mask), att.data_ptr(), lse.data_ptr(), ws.data_ptr(), batch, heads, t, int(bf16),
                                         _sp()), "lmrl_flash_attn_fwd")
+
+
+def flash_attn_fwd_staged(qkv, key_mask, att, lse, ws, att_b, ldb, batch, heads, t, bf16):
+    _lib.check(_L().lmrl_flash_attn_fwd_staged(qkv.data_ptr(), _lib.ptr(key_mask), att.data_ptr(), lse.data_ptr(), ws.data_ptr(), att_b.data_ptr(), ldb,
+                                               batch, heads, t, int(bf16), _sp()), "lmrl_flash_attn_fwd_staged")
 
 
 def flash_attn_bwd(qkv, key_mask, att, datt, lse, dqkv, ws, batch, heads, t, bf16):
