@@ -256,6 +256,27 @@ int lmrl_gpt2_kv_broadcast(const lmrl_gpt2 *m, const void *src_kv_d, int src_tma
 int lmrl_gpt2_kv_gather(const lmrl_gpt2 *m, const void *src_kv_d, int src_b, int src_tmax, const int32_t *src_len_d, const void *src_hidden_d,
                         const int32_t *idx_d, void *dst_kv_d, int dst_tmax, int b, void *dst_hidden_d, int32_t *dst_len_d, void *stream);
 
+/*
+ * Indexed prompt prefix: the copy-free form of lmrl_gpt2_kv_gather.  lmrl_gpt2_kv_attach sets dst_len_d[i] = pfx_n_d[i] = the prompt length
+ * of prefix row idx_d[i] (0 for idx < 0), copies that row's last hidden state and (order_d, optional, [b]) lists the envs grouped by prefix
+ * row.  Single-token decode forwards then go through lmrl_gpt2_forward_prefixed: positions [0, n_d[i]) of env i are READ from row row_d[i]
+ * of the prefix session's cache — the bytes of a prompt exist once however many envs stand on it, and with order_d each XCD walks envs that
+ * share prompts, so those rows are served by its L2 — while the generated tokens' rows go to / come from env i's own cache at their
+ * absolute positions.  Results are bit-identical to the copying form (same rows, same order of arithmetic).
+ * The reference re-runs the whole prompt per env per act() (ppo/gpt2/interface.py:519-546).
+ */
+typedef struct {
+    const void *kv_d;           /* the prefix session's cache: lmrl_gpt2_kv_bytes(m, n_rows, tmax) */
+    int32_t n_rows, tmax;
+    const int32_t *row_d;       /* [b] prefix row behind env i (< 0: none) — the idx_d given to lmrl_gpt2_kv_attach */
+    const int32_t *n_d;         /* [b] prefix length of env i — pfx_n_d of lmrl_gpt2_kv_attach */
+    const int32_t *order_d;     /* [b] launch order (a permutation of the envs) or NULL */
+} lmrl_kv_prefix;
+int lmrl_gpt2_kv_attach(const lmrl_gpt2 *m, int src_b, const int32_t *src_len_d, const void *src_hidden_d, const int32_t *idx_d, int b,
+                        int dst_tmax, void *dst_hidden_d, int32_t *dst_len_d, int32_t *pfx_n_d, int32_t *order_d, void *stream);
+int lmrl_gpt2_forward_prefixed(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int32_t *tokens_d, const int32_t *cnt_d,
+                               int32_t *len_d, int b, void *last_hidden_d, const lmrl_kv_prefix *pfx, unsigned flags, void *stream);
+
 /* C[m][n] = A[m][k] . W[n][k]^T + bias[n]; A, W bf16.  epilogue: 0 bf16, 1 gelu_new->bf16, 2 f32 += (residual),
  * 3 f32, 4 relu->bf16.  Used for the value heads (heads/linear_head.py:112-119, heads/mlp_head.py:139-148). */
 int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda,

@@ -60,6 +60,9 @@ _SIGS = {
     "lmrl_maze_tok_action": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "lmrl_maze_tok_result": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lmrl_gpt2_kv_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "lmrl_gpt2_kv_attach": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lmrl_gpt2_forward_prefixed": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                           ctypes.c_uint, c_void_p]),
     "lmrl_chess_pos_bytes": (c_size_t, []),
     "lmrl_chess_reset": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lmrl_chess_agent_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

@@ -439,17 +439,34 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t *__restri
 // (speculating past the length was measured: the over-read costs more bandwidth than the saved latency is worth).  The query and the
 // new token's own K/V row (taken from the qkv buffer, attended last, appended to the cache) are requested before the length arrives.
 // Softmax state per 8-lane row group, groups merged at the end (as above); the QK dot product is v_dot2_f32_bf16 on packed operands.
-template <int U>
+//
+// PFX (indexed prompt prefix, lmrl_gpt2_forward_prefixed): positions [0, pfx.n[b]) of env b are the rows of row pfx.row[b] of ANOTHER
+// session's cache (a prompt-prefix cache: one prefill per distinct prompt) and are read from there — nothing is copied per env, and envs
+// that share a prompt read the same bytes.  pfx.order (optional) lists the envs grouped by prefix row; workgroup ids are then spread so
+// that each XCD walks a CONTIGUOUS stretch of that list: the waves resident on an XCD at any moment share a handful of prompts, whose
+// rows stay in that XCD's L2.  Positions >= pfx.n[b] live in the env's own cache at their absolute position, as without a prefix.
+struct DecodePrefix {
+    const uint16_t *k, *v;       // this layer's K / V block of the prefix session
+    const int32_t *row, *n, *order;
+    int tmax;
+};
+
+template <int U, bool PFX>
 __global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *__restrict__ qkv,   // [rows][3d]
                                                                uint16_t *__restrict__ kcache, uint16_t *__restrict__ vcache,
                                                                const int32_t *__restrict__ cnt, const int32_t *__restrict__ len,
                                                                uint16_t *__restrict__ out,          // [rows][d]
                                                                int B, int H, int Tmax, int d, const int32_t *__restrict__ off, int n_shared,
-                                                               int append) {
+                                                               int append, DecodePrefix pfx) {
     typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
-    const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
+    int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (PFX && pfx.order && (gridDim.x & 7) == 0)            // workgroup ids round-robin over the 8 XCDs: XCD x gets ids [x, x + 8, ..]
+        wave_id = ((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * 4 + (threadIdx.x >> 6);
     if (wave_id >= B * H) return;
-    const int b = wave_id / H, h = wave_id - b * H;
+    int b = wave_id / H;
+    const int h = wave_id - b * H;
+    if (PFX && pfx.order) b = pfx.order[b];
     const int rr = lane >> 3, cc = lane & 7;
     // wave-uniform bases (SGPR): env 0's rows of this head, and this env's element offset from them.  Positions < n_shared hold the same
     // values in every env (a prompt prefix broadcast by lmrl_gpt2_kv_broadcast): they are read from env 0, i.e. from L2, not once per env
@@ -462,15 +479,32 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *_
     const uint4 knew = *reinterpret_cast<const uint4 *>(qbase + d), vnew = *reinterpret_cast<const uint4 *>(qbase + 2 * d);
     if (cnt[b] <= 0) return;                                         // wave-uniform: finished env (its rows are not in the batch)
     const int L0 = len[b];
+    // PFX: positions < pn come from row prow of the prefix session (wave-uniform scalars; the per-lane choice is two selects)
+    uint32_t pn = 0u, prow = 0u;
+    const char *pkc = kc, *pvc = vc;
+    if (PFX) {
+        const int r = pfx.row[b];
+        pn = r >= 0 ? (uint32_t)pfx.n[b] : 0u;
+        prow = (uint32_t)max(r, 0) * (uint32_t)pfx.tmax;
+        pkc = reinterpret_cast<const char *>(pfx.k + (size_t)h * 64);
+        pvc = reinterpret_cast<const char *>(pfx.v + (size_t)h * 64);
+    }
     uint4 kr[U], vr[U];
 #define LMRL_DEC_LOAD(TBASE)                                                                                   \
     _Pragma("unroll") for (int u = 0; u < U; u++)                                                             \
         if ((TBASE) + u * 8 < L0) {                                  /* wave-uniform: block u holds cached positions */ \
             const int tt_ = (TBASE) + u * 8 + rr;                                                             \
             const uint32_t tc_ = (uint32_t)(tt_ < L0 ? tt_ : L0 - 1);                                         \
-            const uint32_t bo_ = (((tc_ < (uint32_t)n_shared ? 0u : env_row) + tc_) * (uint32_t)d + (uint32_t)cc * 8u) * 2u; \
-            kr[u] = *reinterpret_cast<const uint4 *>(kc + bo_);                                               \
-            vr[u] = *reinterpret_cast<const uint4 *>(vc + bo_);                                               \
+            if (PFX) {                                                                                        \
+                const bool in_p_ = tc_ < pn;                                                                  \
+                const uint32_t bo_ = (((in_p_ ? prow : env_row) + tc_) * (uint32_t)d + (uint32_t)cc * 8u) * 2u; \
+                kr[u] = *reinterpret_cast<const uint4 *>((in_p_ ? pkc : kc) + bo_);                           \
+                vr[u] = *reinterpret_cast<const uint4 *>((in_p_ ? pvc : vc) + bo_);                           \
+            } else {                                                                                          \
+                const uint32_t bo_ = (((tc_ < (uint32_t)n_shared ? 0u : env_row) + tc_) * (uint32_t)d + (uint32_t)cc * 8u) * 2u; \
+                kr[u] = *reinterpret_cast<const uint4 *>(kc + bo_);                                           \
+                vr[u] = *reinterpret_cast<const uint4 *>(vc + bo_);                                           \
+            }                                                                                                 \
         }
     LMRL_DEC_LOAD(0);
     uint32_t qp[4];                                                  // query slice as packed bf16 pairs, pre-scaled by 1/sqrt(64) (exact)
@@ -766,6 +800,58 @@ __global__ __launch_bounds__(256) void kv_gather_kernel(const uint16_t *__restri
     }
 }
 
+// Indexed prompt prefix (lmrl_gpt2_kv_attach): nothing is copied but the last hidden state — env b's cache length becomes the prompt length
+// of prefix row idx[b], and the decode attention reads positions below it from that row (attention_decode_kernel<.., true>).
+// Blocks [0, B): per-env bookkeeping; block B: the launch order — envs grouped by prefix row (counting sort over the rows; the order inside a
+// group does not matter: it only decides which waves run side by side).  idx < 0 / out of range: empty cache, sorted last.
+constexpr int kAttachMaxRows = 12288;        // prefix rows the LDS histogram holds (48 KB); more rows: identity order
+__global__ __launch_bounds__(1024) void kv_attach_kernel(int src_b, const int32_t *__restrict__ src_len, const int32_t *__restrict__ idx, int B, int d,
+                                                         int dst_tmax, const uint16_t *__restrict__ src_hidden, uint16_t *__restrict__ dst_hidden,
+                                                         int32_t *__restrict__ dst_len, int32_t *__restrict__ pfx_n, int32_t *__restrict__ order) {
+    const int b = blockIdx.x;
+    if (b < B) {
+        const int r = idx[b];
+        const int n = (r >= 0 && r < src_b) ? min(src_len[r], dst_tmax) : 0;
+        if (dst_hidden && n > 0) for (int i = threadIdx.x; i < d / 8; i += blockDim.x)
+            reinterpret_cast<u32x4 *>(dst_hidden + (size_t)b * d)[i] = reinterpret_cast<const u32x4 *>(src_hidden + (size_t)r * d)[i];
+        if (threadIdx.x == 0) { dst_len[b] = n; pfx_n[b] = n; }
+        return;
+    }
+    if (!order) return;
+    if (src_b > kAttachMaxRows) {
+        for (int i = threadIdx.x; i < B; i += blockDim.x) order[i] = i;
+        return;
+    }
+    __shared__ int32_t hist[kAttachMaxRows + 1];
+    __shared__ int32_t part[1024];
+    const int nb = src_b + 1;                                // bucket src_b: envs without a prefix
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const int r = idx[i];
+        atomicAdd(&hist[(r >= 0 && r < src_b) ? r : src_b], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the histogram: each thread owns a contiguous stretch of buckets
+    const int per = (nb + blockDim.x - 1) / blockDim.x, lo = min((int)threadIdx.x * per, nb), hi = min(lo + per, nb);
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += hist[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < (int)blockDim.x; i++) { const int v = part[i]; part[i] = run; run += v; }
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = lo; i < hi; i++) { const int v = hist[i]; hist[i] = run; run += v; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const int r = idx[i];
+        order[atomicAdd(&hist[(r >= 0 && r < src_b) ? r : src_b], 1)] = i;
+    }
+}
+
 // profiling only (one launch per forward): algorithmic HBM bytes of the attention launches of this forward =
 // per (env, head, layer): K and V rows of every attended position (2 x 128 B) + the chunk's q rows and output rows.
 __global__ void attn_bytes_kernel(const int32_t *cnt, const int32_t *len, int B, int C, int heads_x_layers,
@@ -887,8 +973,9 @@ size_t lmrl_gpt2_kv_bytes(const lmrl_gpt2 *m, int b, int tmax) {
 
 size_t lmrl_gpt2_ws_bytes(const lmrl_gpt2 *m, int b, int c) { return Gpt2Ws::bytes(m->cfg, (size_t)b * c, b); }
 
-int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int32_t *tokens_d, const int32_t *cnt_d,
-                      int32_t *len_d, int b, int c, void *last_hidden_d, void *all_hidden_d, unsigned flags, void *stream) {
+static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int32_t *tokens_d, const int32_t *cnt_d,
+                             int32_t *len_d, int b, int c, void *last_hidden_d, void *all_hidden_d, const lmrl_kv_prefix *pfx, unsigned flags,
+                             void *stream) {
     LMRL_REQUIRE(m && kv_d && ws_d && tokens_d && cnt_d && len_d && b > 0, "lmrl_gpt2_forward: bad argument");
     LMRL_REQUIRE(c == 1 || c == 8 || c == 16, "lmrl_gpt2_forward: chunk width must be 1, 8 or 16");
     const lmrl_gpt2_config &cf = m->cfg;
@@ -900,6 +987,13 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
     // positions [0, n_shared) of every env's cache equal env 0's (lmrl_gpt2_kv_broadcast): the decode attention reads them from env 0
     const int n_shared = (int)((flags >> 8) & 0xffu);
     LMRL_REQUIRE(n_shared <= tmax, "lmrl_gpt2_forward: shared prefix longer than the cache");
+    if (pfx) {
+        LMRL_REQUIRE(c == 1 && !(flags & LMRL_FWD_ATTN_VALU), "lmrl_gpt2_forward_prefixed: single-token decode on the default attention kernel only");
+        LMRL_REQUIRE(pfx->kv_d && pfx->row_d && pfx->n_d && pfx->n_rows > 0 && pfx->tmax > 0 && n_shared == 0, "lmrl_gpt2_forward_prefixed: bad prefix");
+        LMRL_REQUIRE((size_t)pfx->n_rows * pfx->tmax * d * 2 < ((size_t)1 << 32) && (size_t)b * tmax * d * 2 < ((size_t)1 << 32),
+                     "lmrl_gpt2_forward_prefixed: a layer's K block must stay below 4 GiB (32-bit row offsets)");
+    }
+    const size_t pfx_layer = pfx ? (size_t)pfx->n_rows * cf.n_head * pfx->tmax * 64 : 0;
     if (unsigned long long *ctr = prof_byte_counter(c == 1 ? PROF_ATTN_DECODE : PROF_ATTN_CHUNK))
         hipLaunchKernelGGL(attn_bytes_kernel, dim3(1), dim3(256), 0, s, cnt_d, len_d, b, c, cf.n_head * cf.n_layer, ctr, c == 1 ? n_shared : 0);
     LMRL_REQUIRE(!((flags & LMRL_FWD_RAGGED_ALWAYS) && (flags & LMRL_FWD_RAGGED_NEVER)), "lmrl_gpt2_forward: contradictory ragged flags");
@@ -960,15 +1054,22 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
         const bool shot = c == 1 && !(flags & LMRL_FWD_ATTN_VALU);
         if (shot) {
             const bool ev = prof_kernel_events(PROF_ATTN_DECODE, -1.0, &ev_a, &ev_b);   // start/stop events attached to the dispatch itself
-#define LMRL_DEC_LAUNCH(U_)                                                                                                                          \
+            DecodePrefix dp{};
+            if (pfx) {
+                dp.k = (const uint16_t *)pfx->kv_d + (size_t)(2 * l) * pfx_layer; dp.v = dp.k + pfx_layer;
+                dp.row = pfx->row_d; dp.n = pfx->n_d; dp.order = pfx->order_d; dp.tmax = pfx->tmax;
+            }
+#define LMRL_DEC_LAUNCH(U_, PFX_)                                                                                                                    \
             do {                                                                                                                                     \
-                if (ev) hipExtLaunchKernelGGL((attention_decode_kernel<U_>), dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, ev_a, ev_b, 0,         \
+                if (ev) hipExtLaunchKernelGGL((attention_decode_kernel<U_, PFX_>), dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, ev_a, ev_b, 0,   \
                                               (const uint16_t *)w.qkv, kc, vc, cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off,     \
-                                              n_shared, append_in_attn);                                                                             \
-                else hipLaunchKernelGGL((attention_decode_kernel<U_>), dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, (const uint16_t *)w.qkv, kc,   \
-                                        vc, cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off, n_shared, append_in_attn);              \
+                                              n_shared, append_in_attn, dp);                                                                         \
+                else hipLaunchKernelGGL((attention_decode_kernel<U_, PFX_>), dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, (const uint16_t *)w.qkv,  \
+                                        kc, vc, cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off, n_shared, append_in_attn, dp);      \
             } while (0)
-            LMRL_DEC_LAUNCH(4);      // 32 cached positions per batch of loads, 72 VGPRs -> 7 waves per SIMD (measured best of U = 4 / 6 / 8 / 10)
+            // 32 cached positions per batch of loads, 72 VGPRs -> 7 waves per SIMD (measured best of U = 4 / 6 / 8 / 10)
+            if (pfx) LMRL_DEC_LAUNCH(4, true);
+            else LMRL_DEC_LAUNCH(4, false);
 #undef LMRL_DEC_LAUNCH
         } else if (c == 1 && prof_kernel_events(PROF_ATTN_DECODE, -1.0, &ev_a, &ev_b)) {
             // the roofline kernel: start/stop events attached to the dispatch itself (kernel begin -> end, as rocprofv3 reports it)
@@ -1010,6 +1111,27 @@ int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int3
                                       (uint16_t *)last_hidden_d, cnt_d, len_d, b, c, d, cf.ln_eps, off);
     else hipLaunchKernelGGL(final_ln_advance_kernel<8>, dim3(ceil_div(b, 4)), dim3(256), 0, s, w.x, m->lnf_g, m->lnf_b,
                             (uint16_t *)last_hidden_d, cnt_d, len_d, b, c, d, cf.ln_eps, off);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_gpt2_forward(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int32_t *tokens_d, const int32_t *cnt_d,
+                      int32_t *len_d, int b, int c, void *last_hidden_d, void *all_hidden_d, unsigned flags, void *stream) {
+    return gpt2_forward_impl(m, kv_d, tmax, ws_d, tokens_d, cnt_d, len_d, b, c, last_hidden_d, all_hidden_d, nullptr, flags, stream);
+}
+
+int lmrl_gpt2_forward_prefixed(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, const int32_t *tokens_d, const int32_t *cnt_d,
+                               int32_t *len_d, int b, void *last_hidden_d, const lmrl_kv_prefix *pfx, unsigned flags, void *stream) {
+    LMRL_REQUIRE(pfx, "lmrl_gpt2_forward_prefixed: no prefix");
+    return gpt2_forward_impl(m, kv_d, tmax, ws_d, tokens_d, cnt_d, len_d, b, 1, last_hidden_d, nullptr, pfx, flags, stream);
+}
+
+int lmrl_gpt2_kv_attach(const lmrl_gpt2 *m, int src_b, const int32_t *src_len_d, const void *src_hidden_d, const int32_t *idx_d, int b,
+                        int dst_tmax, void *dst_hidden_d, int32_t *dst_len_d, int32_t *pfx_n_d, int32_t *order_d, void *stream) {
+    LMRL_REQUIRE(m && src_b > 0 && src_len_d && idx_d && b > 0 && dst_tmax > 0 && dst_len_d && pfx_n_d, "lmrl_gpt2_kv_attach: bad argument");
+    LMRL_REQUIRE(!dst_hidden_d || src_hidden_d, "lmrl_gpt2_kv_attach: dst_hidden_d needs src_hidden_d");
+    hipLaunchKernelGGL(kv_attach_kernel, dim3(b + 1), dim3(1024), 0, as_stream(stream), src_b, src_len_d, idx_d, b, m->cfg.d_model, dst_tmax,
+                       (const uint16_t *)src_hidden_d, (uint16_t *)dst_hidden_d, dst_len_d, pfx_n_d, order_d);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

@@ -57,6 +57,11 @@ class SampleParams(ctypes.Structure):
                 ("pad_token", ctypes.c_int32), ("epoch_d", ctypes.c_void_p), ("top_p", ctypes.c_float)]
 
 
+class _CKVPrefix(ctypes.Structure):      # lmrl_kv_prefix (include/lmrl_amd.h)
+    _fields_ = [("kv_d", ctypes.c_void_p), ("n_rows", ctypes.c_int32), ("tmax", ctypes.c_int32), ("row_d", ctypes.c_void_p),
+                ("n_d", ctypes.c_void_p), ("order_d", ctypes.c_void_p)]
+
+
 def init_hf_style_state_dict(cfg: GPT2Config, seed: int = 0) -> Dict[str, "torch.Tensor"]:
     """Random-init weights with HF GPT-2 names/shapes/statistics (Conv1D kernels are [in, out];
     normal(0, initializer_range); residual projections scaled by 1/sqrt(2*n_layer); LN = 1/0)."""
@@ -158,6 +163,7 @@ class KVSession:
         self.len.zero_()
         self._len_bound = 0
         self.shared_prefix = 0
+        self._prefix = None
 
     def set_len(self, lens):
         """Truncate / set every env's cache length from the host (int array [B]): positions >= lens[b] are treated as free and will be
@@ -168,10 +174,13 @@ class KVSession:
         self.len.copy_(torch.from_numpy(lens))
         self._len_bound = int(lens.max(initial=0))
         self.shared_prefix = 0
+        self._prefix = None
 
     shared_prefix = 0   # positions [0, shared_prefix) of every env's cache equal env 0's (set by broadcast_prefix_from, cleared by reset)
 
     _len_bound = 0   # host-side upper bound of max(self.len): forwards are enqueued without reading the device lengths back
+
+    _prefix = None   # (_CKVPrefix, keep-alive refs) while the envs stand on rows of a prompt-prefix session (attach_prefix_from)
 
     def forward(self, tokens, cnt, chunk: int, all_hidden=None, len_bound_after: Optional[int] = None):
         """tokens int32 [B*chunk], cnt int32 [B]; updates the cache, self.len and self.last_hidden.  `len_bound_after`: the caller's exact
@@ -181,6 +190,13 @@ class KVSession:
         if self._len_bound > self.tmax:
             raise _lib.LmrlError(f"KV cache overflow: up to {self._len_bound} positions would be written into a cache of tmax = {self.tmax} "
                                  "(size the session for prompt + generated tokens, or reset() it)")
+        if self._prefix is not None:
+            if chunk != 1 or all_hidden is not None:
+                raise _lib.LmrlError("a session attached to a prompt-prefix cache takes single-token decode forwards only (reset() it first)")
+            _lib.check(e._L.lmrl_gpt2_forward_prefixed(e._h, _lib.ptr(self.kv), self.tmax, _lib.ptr(self.ws[1]), _lib.ptr(tokens), _lib.ptr(cnt),
+                                                       _lib.ptr(self.len), self.B, _lib.ptr(self.last_hidden), ctypes.byref(self._prefix[0]),
+                                                       self.flags, _lib.stream_ptr()), "lmrl_gpt2_forward_prefixed")
+            return self.last_hidden
         _lib.check(e._L.lmrl_gpt2_forward(e._h, _lib.ptr(self.kv), self.tmax, _lib.ptr(self.ws[chunk]), _lib.ptr(tokens),
                                           _lib.ptr(cnt), _lib.ptr(self.len), self.B, chunk, _lib.ptr(self.last_hidden),
                                           _lib.ptr(all_hidden), self.flags | ((self.shared_prefix & 0xFF) << 8), _lib.stream_ptr()), "lmrl_gpt2_forward")
@@ -207,6 +223,28 @@ class KVSession:
         _lib.check(e._L.lmrl_gpt2_kv_gather(e._h, _lib.ptr(src.kv), src.B, src.tmax, _lib.ptr(src.len), _lib.ptr(src.last_hidden), _lib.ptr(idx),
                                             _lib.ptr(self.kv), self.tmax, self.B, _lib.ptr(self.last_hidden), _lib.ptr(self.len), _lib.stream_ptr()),
                    "lmrl_gpt2_kv_gather")
+        self._len_bound = max_pos
+        self.shared_prefix = 0
+        self._prefix = None
+
+    def attach_prefix_from(self, src: "KVSession", idx, max_pos: int, group: bool = True):
+        """The copy-free form of `gather_prefix_from` (`lmrl_gpt2_kv_attach` + `lmrl_gpt2_forward_prefixed`): env b's positions below the
+        prompt length of row idx[b] are READ from `src`'s cache by the decode attention; only the generated tokens' rows are written to
+        this session.  `idx` must stay alive and unchanged until the next attach / reset (it is the kernel's row table); `group`: launch
+        the envs grouped by prefix row (rows shared by several envs are then served from L2).  Decode forwards only."""
+        import torch
+        assert src.eng is self.eng
+        e = self.eng
+        if max_pos > self.tmax:
+            raise _lib.LmrlError(f"KV cache overflow: prompts of up to {max_pos} positions into a cache of tmax = {self.tmax}")
+        if getattr(self, "_pfx_n", None) is None:
+            self._pfx_n = torch.zeros(self.B, dtype=torch.int32, device=e.device)
+            self._pfx_order = torch.zeros(self.B, dtype=torch.int32, device=e.device)
+        _lib.check(e._L.lmrl_gpt2_kv_attach(e._h, src.B, _lib.ptr(src.len), _lib.ptr(src.last_hidden), _lib.ptr(idx), self.B, self.tmax,
+                                            _lib.ptr(self.last_hidden), _lib.ptr(self.len), _lib.ptr(self._pfx_n),
+                                            _lib.ptr(self._pfx_order) if group else None, _lib.stream_ptr()), "lmrl_gpt2_kv_attach")
+        self._prefix = (_CKVPrefix(_lib.ptr(src.kv), src.B, src.tmax, _lib.ptr(idx), _lib.ptr(self._pfx_n),
+                                   _lib.ptr(self._pfx_order) if group else None), src, idx)
         self._len_bound = max_pos
         self.shared_prefix = 0
 

@@ -4,7 +4,10 @@ The MI355X counterpart of `interact_environment(maze_env, GPT2PPOPolicy(...), bs
 ppo/gpt2/interface.py:507-546) on the reference's Maze harness (maze/bc/fully_observed_bc.py:230-283: `last_k=1`, `max_steps=100`).
 With last_k = 1 the policy's prompt is the observation of the current cell — a pure function of (goal, cell)
 (maze/env/env.py:8-81) — so the host renders and tokenises every distinct observation ONCE per (maze, tokenizer), and prefills each of
-them ONCE per set of weights into a prompt-prefix cache (one KV row per observation, `lmrl_gpt2_kv_gather`).  A turn is then
+them ONCE per set of weights into a prompt-prefix cache (one KV row per observation).  By default the envs then only POINT at their row
+(`lmrl_gpt2_kv_attach`): the decode attention reads the prompt positions from the cache row itself (`lmrl_gpt2_forward_prefixed`), envs
+standing on the same cell share those bytes through L2, and only the generated tokens' rows are written per env;
+`prefix_indexed=False` copies the rows per env per turn instead (`lmrl_gpt2_kv_gather`, bit-identical).  A turn is then
 
     obs row <- env state | K/V + last hidden <- prefix cache | generate <= max_new ids | ids -> action code | lmrl_maze_step | record
 
@@ -68,10 +71,12 @@ class MazeRolloutEngine:
 
     `value_engine` + `q1_head` (+ `q2_head`) + `beta` make it the ILQL value policy (value_rl_base/gpt2/generation.py:97-119), as in
     `WordleRolloutEngine`.  `prefix_cache=False` prefills the observation tokens per env per turn instead (16-token chunks): the
-    cross-check of the cache, and the fallback for tables too large to prefill."""
+    cross-check of the cache, and the fallback for tables too large to prefill; `prefix_indexed=False` keeps the cache but copies its rows
+    into every env's own cache each turn (the cross-check of the indexed attention)."""
 
     def __init__(self, engine: GPT2Engine, tokenizer, env: M.MazeEnv, batch: int, max_new_tokens: int = 8, eos_token_id: Optional[int] = None,
                  max_input_length: int = 256, in_str_process: Optional[Callable[[str], str]] = None, prefix_cache: bool = True,
+                 prefix_indexed: bool = True,
                  max_turns: Optional[int] = None, value_engine: Optional[GPT2Engine] = None, q1_head: Optional[dict] = None,
                  q2_head: Optional[dict] = None, beta: float = 0.0, session_flags: int = FWD_RAGGED_ALWAYS):
         import torch
@@ -91,6 +96,7 @@ class MazeRolloutEngine:
         self.dev, self._L = engine.device, _lib.lib()
         self.in_str_process = in_str_process or (lambda x: x)
         self.prefix_cache = prefix_cache
+        self.prefix_indexed = prefix_indexed        # read the prompt rows from the prefix cache (no per-turn copy) vs copy them per env
         # ---- observation table: one row per (goal slot, cell)
         maze, goals = venv.maze, venv.valid_goals
         R, C = maze.shape
@@ -185,7 +191,10 @@ class MazeRolloutEngine:
         ck(L.lmrl_maze_tok_turn(self._tok, tr, _lib.ptr(self.env.state), B, sp), "maze_tok_turn")
         if self.prefix_cache:
             for ses, cache in zip(self.sessions, self.caches):
-                ses.gather_prefix_from(cache, self.traj["obs_idx"], self.max_obs_len)
+                if self.prefix_indexed:
+                    ses.attach_prefix_from(cache, self.traj["obs_idx"], self.max_obs_len)
+                else:
+                    ses.gather_prefix_from(cache, self.traj["obs_idx"], self.max_obs_len)
         else:
             for ses in self.sessions:
                 ses.reset()

@@ -305,3 +305,54 @@ def test_ragged_prefill_is_bit_identical(dev):
         for a, b in zip(outs[0][0], o[0]):
             assert torch.equal(a, b)
         assert torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2])
+
+
+@pytest.mark.parametrize("B,group", [(37, True), (37, False), (256, True)])
+def test_indexed_prefix_attention_equals_copied_prefix(dev, B, group):
+    """`attach_prefix_from` (prompt rows READ from the prefix session by the decode attention, lmrl_gpt2_forward_prefixed) vs
+    `gather_prefix_from` (rows copied per env): same hidden states after every decode step and the same generated-token rows in the
+    env caches, bit for bit — ragged prompt lengths, envs without a prompt (idx < 0), finished envs (cnt = 0), both launch orders
+    (B = 256 with 12 heads: a grid the XCD-grouped order applies to)."""
+    from lmrl_gym_amd.gpt2 import FWD_KV_FROM_GEMM, GPT2Config, GPT2Engine, init_hf_style_state_dict
+    cfg = GPT2Config(2, 12, 768, 3072, 1000, 64)
+    eng = GPT2Engine(cfg, init_hf_style_state_dict(cfg, seed=4), dev)
+    R, cap, tmax = 9, 32, 40
+    g = torch.Generator().manual_seed(7)
+    src = eng.session(R, cap)
+    src.reset()
+    plens = torch.randint(1, cap + 1, (R,), generator=g)
+    plens[0], plens[1] = cap, 1
+    for c0 in range(0, cap, 16):
+        toks = torch.randint(0, cfg.vocab, (R * 16,), generator=g).to(torch.int32).to(dev)
+        src.forward(toks, torch.clamp(plens - c0, 0, 16).to(torch.int32).to(dev), 16)
+    idx = torch.randint(0, R, (B,), generator=g).to(torch.int32)
+    idx[3] = -1
+    idx = idx.to(dev)
+    for flags in (0, FWD_KV_FROM_GEMM):
+        a, b = eng.session(B, tmax, flags=flags), eng.session(B, tmax, flags=flags)
+        a.reset(); b.reset()
+        a.gather_prefix_from(src, idx, cap)
+        b.attach_prefix_from(src, idx, cap, group=group)
+        assert torch.equal(a.len, b.len) and torch.equal(a.last_hidden, b.last_hidden)
+        if group:
+            order = b._pfx_order.cpu().numpy()
+            assert sorted(order.tolist()) == list(range(B))
+            keys = np.where(idx.cpu().numpy() >= 0, idx.cpu().numpy(), R)[order]
+            assert (np.diff(keys) >= 0).all()                     # grouped by prefix row, envs without one last
+        for step in range(tmax - cap):
+            toks = torch.randint(0, cfg.vocab, (B,), generator=g).to(torch.int32).to(dev)
+            cnt = (torch.rand(B, generator=g) < 0.9).to(torch.int32).to(dev)
+            ha = a.forward(toks, cnt, 1).clone()
+            hb = b.forward(toks, cnt, 1).clone()
+            assert torch.equal(ha, hb), step
+            assert torch.equal(a.len, b.len)
+        # generated rows: position t >= prompt length of env i, layer l, K|V — equal in both caches (the prompt rows exist only in `a`)
+        kva = a.kv.view(torch.int16).view(2 * cfg.n_layer, B, tmax, cfg.d_model)
+        kvb = b.kv.view(torch.int16).view(2 * cfg.n_layer, B, tmax, cfg.d_model)
+        n0 = torch.where(idx >= 0, src.len[idx.clamp(min=0).long()], torch.zeros_like(idx))
+        t_idx = torch.arange(tmax, device=dev)[None, :]
+        own = (t_idx >= n0[:, None]) & (t_idx < a.len[:, None])
+        assert own.any()
+        assert torch.equal(kva[:, own], kvb[:, own])
+        with pytest.raises(Exception):
+            b.forward(torch.zeros(B * 8, dtype=torch.int32, device=dev), torch.ones(B, dtype=torch.int32, device=dev), 8)

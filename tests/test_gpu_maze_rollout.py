@@ -39,7 +39,8 @@ class MergedByteTokenizer:
         return out.decode("utf-8", errors="replace")
 
 
-def _setup(dev, B, max_new, max_steps, describe="describe_observation_give_position", prefix_cache=True, seed=0, boost=12.0):
+def _setup(dev, B, max_new, max_steps, describe="describe_observation_give_position", prefix_cache=True, seed=0, boost=12.0,
+           prefix_indexed=True):
     from lmrl_gym_amd.envs import maze as M
     from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine
     from lmrl_gym_amd.maze_rollout import MazeRolloutEngine
@@ -57,7 +58,7 @@ def _setup(dev, B, max_new, max_steps, describe="describe_observation_give_posit
                                    "dense2.kernel": torch.randn(d, V, generator=g) * 0.3, "dense2.bias": bias}, cfg.vocab_padded, dev)
     env = M.setup_maze_env("double_t_maze", describe, "standard_reward", last_k=1, max_steps=max_steps)
     eng = MazeRolloutEngine(pi, tok, env, B, max_new_tokens=max_new, eos_token_id=tok.eos_token_id, prefix_cache=prefix_cache,
-                            value_engine=vb, q1_head=head, q2_head=None, beta=1.0)
+                            prefix_indexed=prefix_indexed, value_engine=vb, q1_head=head, q2_head=None, beta=1.0)
     return eng, tok, pi, vb, head, env
 
 
@@ -125,8 +126,9 @@ def test_prefix_cache_graph_and_per_turn_prefill_agree():
     B, max_new, max_steps = 64, 3, 6
     seeds = [31 * i + 3 for i in range(B)]
     snaps = []
-    for prefix_cache, use_graph in ((True, False), (True, True), (False, False)):
-        eng, *_ = _setup(dev, B, max_new, max_steps, prefix_cache=prefix_cache)
+    # indexed prefix (rows read from the prefix cache) eager / graph, per-turn prefill, and the copying form of the cache
+    for prefix_cache, use_graph, indexed in ((True, False, True), (True, True, True), (False, False, True), (True, True, False)):
+        eng, *_ = _setup(dev, B, max_new, max_steps, prefix_cache=prefix_cache, prefix_indexed=indexed)
         eng.run_episode(seeds, None, temperature=0.9, sample_seed=11, episode=2, use_graph=use_graph, sync_every=0 if use_graph else 4)
         snaps.append(_snapshot(eng))
         if use_graph:                                  # a second episode on the same captured graph: fresh seeds, fresh noise
@@ -134,11 +136,12 @@ def test_prefix_cache_graph_and_per_turn_prefill_agree():
             again = _snapshot(eng)
             assert not np.array_equal(again[0]["gen"], snaps[-1][0]["gen"])
         eng.close()
-    (a, pa), (g, pg), (p, pp) = snaps
+    (a, pa), (g, pg), (p, pp), (c, pc) = snaps
     for k in a:
         assert np.array_equal(a[k], g[k]), f"graph replay differs from eager launches in {k}"
         assert np.array_equal(a[k], p[k]), f"prompt-prefix cache differs from per-turn prefill in {k}"
-    assert np.array_equal(pa, pg) and np.array_equal(pa, pp)
+        assert np.array_equal(a[k], c[k]), f"indexed prefix rows differ from copied prefix rows in {k}"
+    assert np.array_equal(pa, pg) and np.array_equal(pa, pp) and np.array_equal(pa, pc)
     assert int(a["n_turns"].max()) == max_steps + 1
 
 

@@ -12,9 +12,10 @@ from lmrl_gym_amd.maze_rollout import MazeRolloutEngine
 dev = _lib.require_gpu()
 tok = DS.ByteTokenizer()
 eng = GPT2Engine.random_init(GPT2Config.gpt2_small(), seed=0, device=dev)
-for B, cache in ((256, True), (1024, True), (1024, False), (4096, True)):
+for B, cache, indexed in ((256, True, True), (1024, True, True), (1024, True, False), (1024, False, True), (4096, True, True), (4096, True, False)):
     env = M.setup_maze_env("double_t_maze", "describe_observation_give_position", "standard_reward", last_k=1, max_steps=20)
-    r = MazeRolloutEngine(eng, tok, env, B, max_new_tokens=12, eos_token_id=tok.eos_token_id, max_input_length=160, prefix_cache=cache)
+    r = MazeRolloutEngine(eng, tok, env, B, max_new_tokens=12, eos_token_id=tok.eos_token_id, max_input_length=160, prefix_cache=cache,
+                          prefix_indexed=indexed)
     r.run_episode(list(range(B)), sample_seed=1, use_graph=True, sync_every=0)           # capture + warm-up
     torch.cuda.synchronize(); t0 = time.perf_counter()
     reps = 3
@@ -22,6 +23,6 @@ for B, cache in ((256, True), (1024, True), (1024, False), (4096, True)):
         r.run_episode(list(range(100 + e * B, 100 + (e + 1) * B)), sample_seed=1, episode=e + 1, use_graph=True, sync_every=0)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
     steps = int(r.traj["n_turns"].sum().item())
-    print("B=%5d prefix_cache=%-5s prompt<=%d tok: %6d env steps in %.3f s -> %.0f env-steps/s (%.2f ms per lock-step turn)"
-          % (B, cache, r.max_obs_len, steps, dt, steps / dt, dt / r.T * 1e3), flush=True)
+    print("B=%5d prefix_cache=%-5s indexed=%-5s rows=%d prompt<=%d tok: %6d env steps in %.3f s -> %.0f env-steps/s (%.2f ms per lock-step turn)"
+          % (B, cache, indexed and cache, r.obs_tok_h.shape[0], r.max_obs_len, steps, dt, steps / dt, dt / r.T * 1e3), flush=True)
     r.close()
