@@ -469,6 +469,13 @@ int lmrl_gelu_fwd_staged(const float *x_d, float *y_d, void *yb_d, long ldb, int
 /* dx (=|+=) LN backward; dy_xhat_d (optional [rows][d]) receives dy*xhat whose column sum is d gamma */
 int lmrl_layernorm_bwd(const float *dy_d, const float *x_d, const float *g_d, const float *mean_d, const float *rstd_d, float *dx_d,
                        float *dy_xhat_d, int rows, int d, int accumulate_dx, void *stream);
+/* LayerNorm backward with the gamma / beta gradients reduced in the same pass (row slabs -> per-slab partial rows -> fixed-order sum):
+ * dx (+)= ..., dgamma (+)= sum_r dy*xhat, dbeta (+)= sum_r dy.  d_model in {128, 256, 768, 1024, 1280, 1600} (the per-lane column
+ * registers are compile-time); other widths use lmrl_layernorm_bwd + lmrl_colsum. */
+int lmrl_layernorm_bwd_fused_supported(int d);
+size_t lmrl_layernorm_bwd_fused_ws_bytes(int rows, int d);
+int lmrl_layernorm_bwd_fused(const float *dy_d, const float *x_d, const float *g_d, const float *mean_d, const float *rstd_d, float *dx_d,
+                             float *dgamma_d, float *dbeta_d, int rows, int d, int accumulate_dx, int accumulate_dg, float *ws_d, void *stream);
 size_t lmrl_colsum_ws_bytes(int cols);
 int lmrl_colsum(const float *x_d, int rows, int cols, int ld, float *out_d, int accumulate, float *ws_d, void *stream);
 /* elementwise ops: in-place calls are supported (y_d == x_d, dx_d == dy_d, out_d == x_d or y_d) */

@@ -104,6 +104,10 @@ _SIGS = {
     "lmrl_embed_bwd": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "lmrl_layernorm_fwd": (c_int, [c_void_p] * 6 + [c_int, c_int, c_float, c_void_p]),
     "lmrl_layernorm_bwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
+    "lmrl_layernorm_bwd_fused_supported": (c_int, [c_int]),
+    "lmrl_layernorm_bwd_fused_ws_bytes": (c_size_t, [c_int, c_int]),
+    "lmrl_layernorm_bwd_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                         c_int, c_void_p, c_void_p]),
     "lmrl_colsum_ws_bytes": (c_size_t, [c_int]),
     "lmrl_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "lmrl_gelu_fwd": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -119,6 +119,69 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
     }
 }
 
+// The same with the gamma / beta gradients reduced in the same pass: a workgroup owns a slab of rows, every lane keeps the running column
+// sums of dy*xhat and dy for its NC columns in registers across the slab's rows, the four waves are merged through LDS in a fixed order and
+// the slab's partial row goes to partial[slab][2][d]; ln_bwd_reduce_kernel then sums the slabs (fixed order: deterministic).  Replaces
+// ln_bwd_kernel + a [R][d] dy*xhat scratch matrix + two column-sum passes over R x d (3 launches, 4 extra sweeps of the activations).
+template <int NC>
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ g,
+                                                           const float *__restrict__ mean, const float *__restrict__ rstd, float *dx,
+                                                           float *__restrict__ partial, int R, int rows_per_wg, int accumulate) {
+    constexpr int d = NC * 64;
+    __shared__ float sm[4][2][d];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float gv[NC], ag[NC], ab[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) { gv[k] = g[lane + 64 * k]; ag[k] = 0.f; ab[k] = 0.f; }
+    const int r_end = min(R, (int)(blockIdx.x + 1) * rows_per_wg);
+    for (int r = blockIdx.x * rows_per_wg + wave; r < r_end; r += 4) {
+        const float mu = mean[r], rs = rstd[r];
+        const float *xr = x + (size_t)r * d, *dyr = dy + (size_t)r * d;
+        float xh[NC], dv[NC], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; k++) { xh[k] = xr[lane + 64 * k]; dv[k] = dyr[lane + 64 * k]; }
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            xh[k] = (xh[k] - mu) * rs;
+            const float dg = dv[k] * gv[k];
+            s1 += dg; s2 += dg * xh[k];
+        }
+        s1 = wave_sum(s1) / (float)d; s2 = wave_sum(s2) / (float)d;
+        float *dxr = dx + (size_t)r * d;
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            const float v = rs * (dv[k] * gv[k] - s1 - xh[k] * s2);
+            dxr[lane + 64 * k] = accumulate ? dxr[lane + 64 * k] + v : v;
+            ag[k] += dv[k] * xh[k];
+            ab[k] += dv[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; k++) { sm[wave][0][lane + 64 * k] = ag[k]; sm[wave][1][lane + 64 * k] = ab[k]; }
+    __syncthreads();
+    float *out = partial + (size_t)blockIdx.x * 2 * d;
+    for (int i = threadIdx.x; i < 2 * d; i += 256) {
+        const int which = i >= d, c = i - which * d;
+        out[i] = (sm[0][which][c] + sm[1][which][c]) + (sm[2][which][c] + sm[3][which][c]);
+    }
+}
+// dgamma[c] (+)= sum_slab partial[slab][0][c], dbeta likewise: 64 columns per workgroup, 4 slab phases per column merged through LDS
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restrict__ partial, int nslab, int d, float *dgamma, float *dbeta,
+                                                            int accumulate) {
+    __shared__ float sm[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;      // col over [0, 2d)
+    float s = 0.f;
+    if (col < 2 * d)
+        for (int k = ph; k < nslab; k += 4) s += partial[(size_t)k * 2 * d + col];
+    sm[ph][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ph == 0 && col < 2 * d) {
+        const float v = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+        float *o = col < d ? dgamma + col : dbeta + (col - d);
+        *o = accumulate ? *o + v : v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ column sums (bias / LN grads)
 // out[c] (+)= sum_r x[r][c] ; deterministic two-stage: stage 1 = SPLIT row slabs -> partial[SPLIT][C], stage 2 sums them.
 __global__ __launch_bounds__(256) void colsum_stage1(const float *__restrict__ x, float *__restrict__ partial, int R, int C, int ld,
@@ -126,9 +189,18 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float *__restrict__ x
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const int r0 = blockIdx.y * rows_per_slab, r1 = min(R, r0 + rows_per_slab);
-    float s = 0.f;
-    for (int r = r0; r < r1; r++) s += x[(size_t)r * ld + c];
-    partial[(size_t)blockIdx.y * C + c] = s;
+    // 8 independent loads in flight per thread (a serial "s += x[r]" loop waits a full memory latency per row); fixed association order
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = x[(size_t)(r + u) * ld + c];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] += v[u];
+    }
+    for (; r < r1; r++) a[0] += x[(size_t)r * ld + c];
+    partial[(size_t)blockIdx.y * C + c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 __global__ __launch_bounds__(256) void colsum_stage2(const float *__restrict__ partial, float *__restrict__ out, int C, int nslab,
                                                      int accumulate) {
@@ -377,6 +449,31 @@ int lmrl_layernorm_bwd(const float *dy_d, const float *x_d, const float *g_d, co
     LMRL_REQUIRE(dy_d && x_d && g_d && mean_d && rstd_d && dx_d && rows > 0, "lmrl_layernorm_bwd: bad argument");
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, dy_d, x_d, g_d, mean_d, rstd_d, dx_d, dy_xhat_d, rows, d,
                        accumulate_dx);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+static int ln_bwd_rows_per_wg(int rows) { return ((std::max(4, ceil_div(rows, 512)) + 3) / 4) * 4; }   // <= 512 slabs, whole 4-row rounds
+int lmrl_layernorm_bwd_fused_supported(int d) { return d == 128 || d == 256 || d == 768 || d == 1024 || d == 1280 || d == 1600; }
+size_t lmrl_layernorm_bwd_fused_ws_bytes(int rows, int d) {
+    return (size_t)ceil_div(rows, ln_bwd_rows_per_wg(rows)) * 2 * d * sizeof(float);
+}
+int lmrl_layernorm_bwd_fused(const float *dy_d, const float *x_d, const float *g_d, const float *mean_d, const float *rstd_d, float *dx_d,
+                             float *dgamma_d, float *dbeta_d, int rows, int d, int accumulate_dx, int accumulate_dg, float *ws_d, void *stream) {
+    LMRL_REQUIRE(dy_d && x_d && g_d && mean_d && rstd_d && dx_d && dgamma_d && dbeta_d && ws_d && rows > 0, "lmrl_layernorm_bwd_fused: bad argument");
+    LMRL_REQUIRE(lmrl_layernorm_bwd_fused_supported(d), "lmrl_layernorm_bwd_fused: d_model must be one of 128, 256, 768, 1024, 1280, 1600");
+    const int rpw = ln_bwd_rows_per_wg(rows), nslab = ceil_div(rows, rpw);
+#define LMRL_LNB(NC_)                                                                                                                        \
+    hipLaunchKernelGGL(ln_bwd_fused_kernel<NC_>, dim3(nslab), dim3(256), 0, ST, dy_d, x_d, g_d, mean_d, rstd_d, dx_d, ws_d, rows, rpw, accumulate_dx)
+    switch (d / 64) {
+        case 2: LMRL_LNB(2); break;
+        case 4: LMRL_LNB(4); break;
+        case 12: LMRL_LNB(12); break;
+        case 16: LMRL_LNB(16); break;
+        case 20: LMRL_LNB(20); break;
+        default: LMRL_LNB(25); break;
+    }
+#undef LMRL_LNB
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(2 * d, 64)), dim3(256), 0, ST, ws_d, nslab, d, dgamma_d, dbeta_d, accumulate_dg);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

@@ -260,11 +260,21 @@ class GPT2F32:
         hd = d // H
         scale = 1.0 / math.sqrt(hd)
         new = lambda *shape: t.empty(shape, dtype=t.float32, device=self.dev)
-        tmp = new(R, d)
         dx = new(R, d)
-        ops.layernorm_bwd(d_hidden, cache["x_final"], p["ln_f.weight"], cache["mf"], cache["rf"], dx, tmp, R, d, False)
-        ops.colsum(tmp, R, d, d, grads["ln_f.weight"], True, ws)
-        ops.colsum(d_hidden, R, d, d, grads["ln_f.bias"], True, ws)
+        if ops.layernorm_bwd_fused_supported(d):
+            lws = new(ops.layernorm_bwd_fused_ws_floats(R, d))
+
+            def ln_bwd(dy, x, name, mean, rstd, accumulate_dx):   # dx (+)=, gamma / beta gradients accumulated, one pass
+                ops.layernorm_bwd_fused(dy, x, p[name + ".weight"], mean, rstd, dx, grads[name + ".weight"], grads[name + ".bias"], R, d,
+                                        accumulate_dx, True, lws)
+        else:
+            tmp = new(R, d)
+
+            def ln_bwd(dy, x, name, mean, rstd, accumulate_dx):
+                ops.layernorm_bwd(dy, x, p[name + ".weight"], mean, rstd, dx, tmp, R, d, accumulate_dx)
+                ops.colsum(tmp, R, d, d, grads[name + ".weight"], True, ws)
+                ops.colsum(dy, R, d, d, grads[name + ".bias"], True, ws)
+        ln_bwd(d_hidden, cache["x_final"], "ln_f", cache["mf"], cache["rf"], False)
         if on_final is not None:
             on_final(["ln_f.weight", "ln_f.bias"])
         for l in reversed(range(self.n_layer)):
@@ -279,9 +289,7 @@ class GPT2F32:
             ops.gelu_bwd(dg, c["f"], df)
             dh2 = new(R, d)
             ops.linear_bwd(c["h2"], p[q + "mlp.c_fc.weight"], df, dh2, grads[q + "mlp.c_fc.weight"], grads[q + "mlp.c_fc.bias"], R, d, self.d_ff, ws, mm=self.mm)
-            ops.layernorm_bwd(dh2, c["x_mid"], p[q + "ln_2.weight"], c["m2"], c["r2"], dx, tmp, R, d, True)   # dx := dx_mid
-            ops.colsum(tmp, R, d, d, grads[q + "ln_2.weight"], True, ws)
-            ops.colsum(dh2, R, d, d, grads[q + "ln_2.bias"], True, ws)
+            ln_bwd(dh2, c["x_mid"], q + "ln_2", c["m2"], c["r2"], True)    # dx := dx_mid
             # attention projection
             datt = new(R, d)
             ops.linear_bwd(c["att"], p[q + "attn.c_proj.weight"], dx, datt, grads[q + "attn.c_proj.weight"], grads[q + "attn.c_proj.bias"], R, d, d, ws, mm=self.mm)
@@ -293,9 +301,7 @@ class GPT2F32:
                 self._attention_bwd_materialized(qkv, P, datt, dqkv, B, T, H, hd, d, scale, new)
             dh1 = new(R, d)
             ops.linear_bwd(c["h1"], p[q + "attn.c_attn.weight"], dqkv, dh1, grads[q + "attn.c_attn.weight"], grads[q + "attn.c_attn.bias"], R, d, 3 * d, ws, mm=self.mm)
-            ops.layernorm_bwd(dh1, c["x_in"], p[q + "ln_1.weight"], c["m1"], c["r1"], dx, tmp, R, d, True)    # dx := dx_in
-            ops.colsum(tmp, R, d, d, grads[q + "ln_1.weight"], True, ws)
-            ops.colsum(dh1, R, d, d, grads[q + "ln_1.bias"], True, ws)
+            ln_bwd(dh1, c["x_in"], q + "ln_1", c["m1"], c["r1"], True)     # dx := dx_in
             if on_final is not None:
                 on_final([q + n for n in ("mlp.c_proj.weight", "mlp.c_proj.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "ln_2.weight", "ln_2.bias",
                                           "attn.c_proj.weight", "attn.c_proj.bias", "attn.c_attn.weight", "attn.c_attn.bias", "ln_1.weight", "ln_1.bias")])

@@ -177,6 +177,21 @@ def layernorm_bwd(dy, x, g, mean, rstd, dx, dy_xhat, rows, d, accumulate_dx):
                                        _lib.ptr(dy_xhat), rows, d, int(accumulate_dx), _sp()), "lmrl_layernorm_bwd")
 
 
+def layernorm_bwd_fused_supported(d) -> bool:
+    return bool(_L().lmrl_layernorm_bwd_fused_supported(int(d)))
+
+
+def layernorm_bwd_fused_ws_floats(rows, d) -> int:
+    return _L().lmrl_layernorm_bwd_fused_ws_bytes(int(rows), int(d)) // 4
+
+
+def layernorm_bwd_fused(dy, x, g, mean, rstd, dx, dgamma, dbeta, rows, d, accumulate_dx, accumulate_dg, ws):
+    """dx (+)= LN backward ; dgamma (+)= colsum(dy * xhat) ; dbeta (+)= colsum(dy) — one pass over the activations + a small reduce"""
+    _lib.check(_L().lmrl_layernorm_bwd_fused(dy.data_ptr(), x.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                             dgamma.data_ptr(), dbeta.data_ptr(), rows, d, int(accumulate_dx), int(accumulate_dg),
+                                             ws.data_ptr(), _sp()), "lmrl_layernorm_bwd_fused")
+
+
 def gelu_fwd(x, y):
     _lib.check(_L().lmrl_gelu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _sp()), "lmrl_gelu_fwd")
 

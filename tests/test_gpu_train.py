@@ -1,5 +1,7 @@
 """GPU tier: fp32 train path (sgemm on MFMA f32, train ops, loss kernels, GPT-2 fwd/bwd, PPO / ILQL steps) against
 float64 torch-CPU autograd of the oracle restatements (oracle/gpt2.py, oracle/rl.py)."""
+import math
+
 import numpy as np
 import pytest
 
@@ -67,6 +69,38 @@ def test_sgemm_batched_strided_like_attention(dev):
     x = qkv.double().view(B, T, 3, H, hd)
     ref = 0.25 * torch.einsum("bthe,bshe->bhts", x[:, :, 0], x[:, :, 1]).reshape(B * H, T, T)
     _close(Sd.cpu(), ref, rtol=2e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("R,d", [(37, 128), (515, 768), (4099, 1024), (130, 1600)])
+def test_layernorm_bwd_fused_vs_autograd(dev, R, d):
+    """LN backward with the gamma / beta gradients reduced in the same pass: dx, dgamma, dbeta vs float64 autograd, the accumulate flags,
+    ragged last slab (R not a multiple of the rows per workgroup), and run-to-run bit-identity (no atomics)."""
+    from lmrl_gym_amd.train import ops
+    from oracle import gpt2 as O
+    g = torch.Generator().manual_seed(R + d)
+    x = torch.randn(R, d, generator=g) * 2 + 0.5; gam = torch.randn(d, generator=g); bet = torch.randn(d, generator=g)
+    dy = torch.randn(R, d, generator=g)
+    xr = x.double().requires_grad_(True); gr = gam.double().requires_grad_(True); br = bet.double().requires_grad_(True)
+    O.layer_norm(xr, gr, br, 1e-5).backward(dy.double())
+    xd, gd, bd, dyd = x.to(dev), gam.to(dev), bet.to(dev), dy.to(dev)
+    yd, mean, rstd = torch.empty_like(xd), torch.empty(R, device=dev), torch.empty(R, device=dev)
+    ops.layernorm_fwd(xd, gd, bd, yd, mean, rstd, R, d, 1e-5)
+    assert ops.layernorm_bwd_fused_supported(d) and not ops.layernorm_bwd_fused_supported(96)
+    ws = torch.empty(ops.layernorm_bwd_fused_ws_floats(R, d), device=dev)
+    outs = []
+    for rep in range(2):
+        dxd = torch.full_like(xd, 3.0); dg = torch.full((d,), 2.0, device=dev); db = torch.full((d,), -1.0, device=dev)
+        ops.layernorm_bwd_fused(dyd, xd, gd, mean, rstd, dxd, dg, db, R, d, True, True, ws)          # everything accumulates
+        outs.append((dxd.clone(), dg.clone(), db.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    dxd, dg, db = outs[0]
+    _close(dxd.cpu() - 3.0, xr.grad, rtol=2e-5, atol=2e-5)
+    _close(dg.cpu() - 2.0, gr.grad, rtol=2e-5, atol=1e-4 * math.sqrt(R))
+    _close(db.cpu() + 1.0, br.grad, rtol=2e-5, atol=1e-4 * math.sqrt(R))
+    dxd = torch.full_like(xd, 7.0); dg = torch.full((d,), 7.0, device=dev); db = torch.full((d,), 7.0, device=dev)
+    ops.layernorm_bwd_fused(dyd, xd, gd, mean, rstd, dxd, dg, db, R, d, False, False, ws)            # overwrite
+    _close(dxd.cpu(), xr.grad, rtol=2e-5, atol=2e-5)
+    _close(dg.cpu(), gr.grad, rtol=2e-5, atol=1e-4 * math.sqrt(R)); _close(db.cpu(), br.grad, rtol=2e-5, atol=1e-4 * math.sqrt(R))
 
 
 # ------------------------------------------------------------------ elementwise / reduction ops vs autograd
