@@ -513,6 +513,13 @@ int lmrl_cast_bf16(const float *src_d, long ld_src, int rows, int cols, void *ds
 size_t lmrl_cast_bf16_t_colsum_ws_bytes(int rows, int rows_dst);
 int lmrl_cast_bf16_t_colsum(const float *src_d, long ld_src, int rows, int cols, void *dst_d, long ld_dst, int rows_dst, float *colsum_d,
                             int accumulate, float *ws_d, void *stream);
+/* bf16-matmul train mode, operands staged by their producer: dlogits of the CE / gather losses (lmrl_ce_bwd's formula) written directly as
+ * the bf16 A operand [rows_dst][ld_dst] of the head's backward products (no fp32 dlogits, no cast pass), and the K-major transposed copy
+ * (+ optional column sums = the bias gradient, from the bf16 values) made from such a bf16 operand. */
+int lmrl_ce_bwd_bf16(const float *logits_d, int ld, int vocab, const float *lse_d, const int32_t *targets_d, const float *coef_ce_d,
+                     const float *coef_gather_d, int rows, void *dst_d, long ld_dst, int rows_dst, void *stream);
+int lmrl_transpose_bf16_colsum(const void *src_d, long ld_src, int rows, int cols, void *dst_d, long ld_dst, int rows_dst, float *colsum_d,
+                               int accumulate, float *ws_d, void *stream);
 /* dst[j][i] = beta*dst[j][i] + src[i][j]   (src [n][k] -> dst [k][n]): gradients produced in transposed form */
 int lmrl_transpose_add_f32(const float *src_d, long ld_src, float *dst_d, long ld_dst, int n, int k, float beta, void *stream);
 /* out[r] = sum_j a[r][j]*w[j][idx[r]] + bias[idx[r]]: the one column of a Dense layer that `take_along_axis(logits, token)` reads —

@@ -91,6 +91,9 @@ _SIGS = {
     "lmrl_cast_bf16": (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]),
     "lmrl_cast_bf16_t_colsum_ws_bytes": (c_size_t, [c_int, c_int]),
     "lmrl_cast_bf16_t_colsum": (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, ctypes.c_long, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "lmrl_ce_bwd_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_long, c_int, c_void_p]),
+    "lmrl_transpose_bf16_colsum": (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, ctypes.c_long, c_int, c_void_p, c_int, c_void_p,
+                                           c_void_p]),
     "lmrl_transpose_add_f32": (c_int, [c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_int, c_int, c_float, c_void_p]),
     "lmrl_gather_dot_f32": (c_int, [c_void_p, ctypes.c_long, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lmrl_flash_attn_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -66,9 +66,9 @@ def masked_ce_forward_backward(m: GPT2F32, ids: np.ndarray, am: np.ndarray, pos:
     if grads is not None:
         if grad_scale != 1.0:
             ops.axpby(grad_scale, coef, 0.0, None, coef)
-        ops.ce_bwd(logits, m.ld_vocab, m.vocab, lse, tgt, coef, None, R)
+        dlogits, dlb = m.ce_bwd(logits, lse, tgt, coef, None, R)
         d_hidden = torch.empty(R, m.d, dtype=torch.float32, device=dev)
-        m.lm_head_backward(hid, logits, R, d_hidden, grads, accumulate_dh=False)
+        m.lm_head_backward(hid, dlogits, R, d_hidden, grads, accumulate_dh=False, dlb=dlb)
         m.backward(cache, d_hidden, grads)
     return loss
 

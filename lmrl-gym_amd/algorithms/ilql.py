@@ -258,16 +258,17 @@ class GPT2ILQLTrain:
         # ---- backward
         full = lambda g: (lambda z: (z.view(B, T)[:, :-1].copy_(g), z)[1])(torch.zeros(R, dtype=torch.float32, device=dev))
         coef_r, dq1_r, dq2_r, dv_r = full(coef), full(dq1), full(dq2), full(dv)
-        ops.ce_bwd(q1o, ld, V, lse1, tgt, coef_r, dq1_r, R)       # q1o := d loss / d q1 logits
-        ops.ce_bwd(q2o, ld, V, lse2, tgt, coef_r, dq2_r, R)
+        # d loss / d q logits: in place (fp32) or straight into the bf16 operand of the head's backward products (bf16-matmul mode)
+        dq1o, dq1b = self.q1.ce_bwd(q1o, lse1, tgt, coef_r, dq1_r, R)
+        dq2o, dq2b = self.q2.ce_bwd(q2o, lse2, tgt, coef_r, dq2_r, R)
         bgrads, g1, g2, gv = base.zero_grads(), self.q1.zero_grads(), self.q2.zero_grads(), self.v.zero_grads()
         d_hidden = torch.empty(R, base.d, dtype=torch.float32, device=dev)
         # detach_q1 / detach_q2 / detach_v (interface.py:120-139: stop_gradient on the hidden states fed to that head): the head still trains,
         # its gradient does not reach the transformer
         scratch = torch.empty_like(d_hidden) if (self.detach_q1 or self.detach_q2 or self.detach_v) else None
         d_hidden.zero_()
-        self.q1.backward(q1c, q1o, g1, dx=scratch if self.detach_q1 else d_hidden, accumulate_dx=not self.detach_q1)
-        self.q2.backward(q2c, q2o, g2, dx=scratch if self.detach_q2 else d_hidden, accumulate_dx=not self.detach_q2)
+        self.q1.backward(q1c, dq1o, g1, dx=scratch if self.detach_q1 else d_hidden, accumulate_dx=not self.detach_q1, dyb=dq1b)
+        self.q2.backward(q2c, dq2o, g2, dx=scratch if self.detach_q2 else d_hidden, accumulate_dx=not self.detach_q2, dyb=dq2b)
         self.v.backward(vc, dv_r.view(R, 1), gv, dx=scratch if self.detach_v else d_hidden, accumulate_dx=not self.detach_v)
         # data parallel: the head gradients (final already) and the base gradients are all-reduced while the base backward runs — arena
         # slices go to RCCL as blocks finish (dist.GradReducer); the one data-path collective of an ILQL step (~815 MB fp32, GPT-2-small)

@@ -147,10 +147,10 @@ class GPT2MCTrain:
         if not train:
             return self, loss, logs
         full = lambda g: (lambda z: (z.view(B, T)[:, :-1].copy_(g), z)[1])(torch.zeros(R, dtype=torch.float32, device=dev))
-        ops.ce_bwd(qo, ld, V, lse, tgt, full(coef), full(dq), R)          # qo := d loss / d q logits
+        dqo, dqb = self.q_head.ce_bwd(qo, lse, tgt, full(coef), full(dq), R)          # d loss / d q logits
         bgrads, qgrads = base.zero_grads(), self.q_head.zero_grads()
         d_hidden = torch.empty(R, base.d, dtype=torch.float32, device=dev)
-        self.q_head.backward(qc, qo, qgrads, dx=d_hidden, accumulate_dx=False)
+        self.q_head.backward(qc, dqo, qgrads, dx=d_hidden, accumulate_dx=False, dyb=dqb)
         if self.detach_q:
             d_hidden.zero_()
         red = D.GradReducer()                        # gradient all-reduce overlapped with the base backward (data parallel)

@@ -279,10 +279,10 @@ class GPT2PPOTrain:
         neg = torch.empty_like(dlp)
         ops.axpby(-1.0, dlp, 0.0, None, neg)
         coef.view(B, T)[:, :-1] = neg
-        ops.ce_bwd(logits, pol.ld_vocab, pol.vocab, lse, tgt, coef, None, R)        # logits := dlogits
+        dlogits, dlb = pol.ce_bwd(logits, lse, tgt, coef, None, R)        # in place (fp32) / the staged bf16 operand (bf16-matmul mode)
         pgrads, hgrads = pol.zero_grads(), head.zero_grads()
         d_hidden = torch.empty(R, pol.d, dtype=torch.float32, device=dev)
-        pol.lm_head_backward(hid, logits, R, d_hidden, pgrads, accumulate_dh=False)
+        pol.lm_head_backward(hid, dlogits, R, d_hidden, pgrads, accumulate_dh=False, dlb=dlb)
         dvals = torch.zeros(R, 1, dtype=torch.float32, device=dev)
         dvals.view(B, T)[:, :-1] = dv
         head.backward(hcache, dvals, hgrads, dx=d_hidden, accumulate_dx=True)

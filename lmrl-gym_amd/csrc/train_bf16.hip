@@ -80,6 +80,80 @@ __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float *__restric
     }
 }
 
+// The same from a bf16 source (an operand a producer already staged, e.g. dlogits written by ce_bwd_bf16_kernel): dst[c][r] = src[r][c].
+// Half the read traffic of the fp32 form and no second rounding; colpart sums the bf16 values (what the dW product multiplies).
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t *__restrict__ src, long ld_src, int rows, int cols,
+                                                             uint16_t *__restrict__ dst, long ld_dst, int rows_dst, float *__restrict__ colpart) {
+    __shared__ uint16_t tile[64][72];            // row pitch 144 B: 16-byte aligned rows, column reads spread over the banks
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int idx = threadIdx.x + 256 * k, rl = idx >> 3, c8 = (idx & 7) * 8;
+        uint4 x = make_uint4(0u, 0u, 0u, 0u);
+        if (r0 + rl < rows && c0 + c8 < cols) x = *reinterpret_cast<const uint4 *>(src + (long)(r0 + rl) * ld_src + c0 + c8);   // src padding is zero
+        *reinterpret_cast<uint4 *>(&tile[rl][c8]) = x;
+    }
+    __syncthreads();
+    if (colpart && threadIdx.x < 64 && r0 < rows) {
+        float sum = 0.f;
+        for (int r = 0; r < 64; r++) sum += bf16_to_f32(tile[r][threadIdx.x]);
+        if (c0 + (int)threadIdx.x < rows_dst) colpart[(long)blockIdx.x * rows_dst + c0 + threadIdx.x] = sum;
+    }
+    const int rr8 = (threadIdx.x & 7) * 8, cc = threadIdx.x >> 3;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int c = c0 + cc + k * 32;
+        if (c < rows_dst && r0 + rr8 < ld_dst) {
+            const int q = cc + k * 32;
+            uint4 o;
+            o.x = (uint32_t)tile[rr8 + 0][q] | ((uint32_t)tile[rr8 + 1][q] << 16); o.y = (uint32_t)tile[rr8 + 2][q] | ((uint32_t)tile[rr8 + 3][q] << 16);
+            o.z = (uint32_t)tile[rr8 + 4][q] | ((uint32_t)tile[rr8 + 5][q] << 16); o.w = (uint32_t)tile[rr8 + 6][q] | ((uint32_t)tile[rr8 + 7][q] << 16);
+            *reinterpret_cast<uint4 *>(dst + (long)c * ld_dst + r0 + rr8) = o;
+        }
+    }
+}
+
+// dlogits of the CE / gather losses (ce_bwd_kernel's formula) written as the bf16 A operand [rows_dst][ld_dst] of the head's backward
+// products — no fp32 dlogits matrix, no cast pass over it.  One workgroup per destination row; padding rows / columns are zero-filled.
+__global__ __launch_bounds__(256) void ce_bwd_bf16_kernel(const float *__restrict__ logits, int ld, int V, const float *__restrict__ lse,
+                                                          const int32_t *__restrict__ targets, const float *__restrict__ coef_ce,
+                                                          const float *__restrict__ coef_gather, int rows, uint16_t *__restrict__ dst, long ld_dst) {
+    const int r = blockIdx.x;
+    uint16_t *q = dst + (long)r * ld_dst;
+    if (r >= rows) {
+        for (int c0 = threadIdx.x * 8; c0 < ld_dst; c0 += 256 * 8) *reinterpret_cast<uint4 *>(q + c0) = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    const float *row = logits + (size_t)r * ld;
+    const float l = lse[r], cc = coef_ce ? coef_ce[r] : 0.f, cg = coef_gather ? coef_gather[r] : 0.f;
+    int t = targets[r];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    const bool vec = (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+    for (int c0 = threadIdx.x * 8; c0 < ld_dst; c0 += 256 * 8) {
+        float x[8], v[8];
+        if (vec && c0 + 8 <= V) {
+            const float4 a = *reinterpret_cast<const float4 *>(row + c0), b = *reinterpret_cast<const float4 *>(row + c0 + 4);
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = c0 + k < V ? row[c0 + k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int c = c0 + k;
+            float g = 0.f;
+            if (c < V) {
+                g = cc == 0.f ? 0.f : cc * expf(x[k] - l);
+                if (c == t) g += cg - cc;
+            }
+            v[k] = g;
+        }
+        uint4 o;
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<uint4 *>(q + c0) = o;
+    }
+}
+
 // out[c] (+)= sum over row blocks of colpart[rb][c], in row-block order (deterministic)
 __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float *__restrict__ colpart, int nrb, int ldp, int cols, float *__restrict__ out,
                                                              int accumulate) {
@@ -165,6 +239,31 @@ int lmrl_cast_bf16_t_colsum(const float *src_d, long ld_src, int rows, int cols,
     hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((int)((ld_dst + 63) / 64), (rows_dst + 63) / 64), dim3(256), 0, s, src_d, ld_src, rows, cols,
                        (uint16_t *)dst_d, ld_dst, rows_dst, ws_d);
     hipLaunchKernelGGL(colpart_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, (const float *)ws_d, nrb, rows_dst, cols, colsum_d, accumulate);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_transpose_bf16_colsum(const void *src_d, long ld_src, int rows, int cols, void *dst_d, long ld_dst, int rows_dst, float *colsum_d,
+                               int accumulate, float *ws_d, void *stream) {
+    LMRL_REQUIRE(src_d && dst_d && rows > 0 && cols > 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && rows_dst >= cols && ld_dst >= rows &&
+                 (!colsum_d || ws_d), "lmrl_transpose_bf16_colsum: bad argument");
+    hipStream_t s = as_stream(stream);
+    const int nrb = (rows + 63) / 64;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((int)((ld_dst + 63) / 64), (rows_dst + 63) / 64), dim3(256), 0, s, (const uint16_t *)src_d, ld_src,
+                       rows, cols, (uint16_t *)dst_d, ld_dst, rows_dst, colsum_d ? ws_d : (float *)nullptr);
+    if (colsum_d)
+        hipLaunchKernelGGL(colpart_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, (const float *)ws_d, nrb, rows_dst, cols, colsum_d,
+                           accumulate);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_ce_bwd_bf16(const float *logits_d, int ld, int vocab, const float *lse_d, const int32_t *targets_d, const float *coef_ce_d,
+                     const float *coef_gather_d, int rows, void *dst_d, long ld_dst, int rows_dst, void *stream) {
+    LMRL_REQUIRE(logits_d && lse_d && targets_d && dst_d && rows > 0 && vocab > 0 && ld >= vocab && ld_dst >= vocab && ld_dst % 8 == 0 &&
+                 rows_dst >= rows, "lmrl_ce_bwd_bf16: bad argument");
+    hipLaunchKernelGGL(ce_bwd_bf16_kernel, dim3(rows_dst), dim3(256), 0, as_stream(stream), logits_d, ld, vocab, lse_d, targets_d, coef_ce_d,
+                       coef_gather_d, rows, (uint16_t *)dst_d, ld_dst);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

@@ -236,17 +236,30 @@ class GPT2F32:
             self._arena = GradArena(self.p, self.grad_order())
         return self._arena.zero_()
 
-    def lm_head_backward(self, hidden, dlogits, rows: int, d_hidden, grads, accumulate_dh: bool):
-        """d_hidden (+)= dlogits @ wte ; grads[wte] += dlogits^T @ hidden   (dlogits [rows, ld_vocab])"""
+    def ce_bwd(self, logits, lse, targets, coef_ce, coef_gather, rows: int):
+        """d loss / d logits of the CE (+ gather) terms for `lm_head_backward` -> (dlogits, dlb): fp32 mode overwrites `logits` in place
+        (dlb None); bf16-matmul mode writes the bf16 operand of the backward products directly (dlogits None: no fp32 copy exists)."""
+        if self.mm is None:
+            ops.ce_bwd(logits, self.ld_vocab, self.vocab, lse, targets, coef_ce, coef_gather, rows)
+            return logits, None
+        return None, ops.ce_bwd_staged(self.mm, logits, self.ld_vocab, self.vocab, lse, targets, coef_ce, coef_gather, rows)
+
+    def lm_head_backward(self, hidden, dlogits, rows: int, d_hidden, grads, accumulate_dh: bool, dlb=None):
+        """d_hidden (+)= dlogits @ wte ; grads[wte] += dlogits^T @ hidden   (dlogits [rows, ld_vocab], or its staged bf16 operand dlb)"""
         V, d, ld, mm = self.vocab, self.d, self.ld_vocab, self.mm
         if mm is None:
             ops.sgemm(dlogits, self.p["wte.weight"], d_hidden, rows, d, V, lda=ld, ldb=d, ldc=d, beta=1.0 if accumulate_dh else 0.0)
             ops.sgemm(dlogits, hidden, grads["wte.weight"], V, d, rows, trans_a=True, lda=ld, ldb=d, ldc=d, beta=1.0)
             return
-        dlb = mm.cast("dy", dlogits, rows, V, ld)                                                                      # [rows][pad(V)]
+        staged = dlb is not None
+        if not staged:
+            dlb = mm.cast("dy", dlogits, rows, V, ld)                                                                  # [rows][pad(V)]
         wt = mm.cast(("wT", self.p["wte.weight"].data_ptr()), self.p["wte.weight"], V, d, d, transpose=True, keep=True)  # [d][pad(V)]
         mm.gemm(dlb, wt, None, d_hidden, rows, ops._pad(d), V, d, d, accumulate=accumulate_dh)
-        dlt = mm.cast("dyT", dlogits, rows, V, ld, transpose=True)                                                     # [pad(V)][pad(rows)]
+        if staged:
+            dlt = mm.transpose_staged("dyT", dlb, ops._pitch(V), rows, V)                                              # [pad(V)][pad(rows)]
+        else:
+            dlt = mm.cast("dyT", dlogits, rows, V, ld, transpose=True)
         ht = mm.cast("xT", hidden, rows, d, d, transpose=True)                                                         # [d][pad(rows)]
         mm.gemm(dlt, ht, None, grads["wte.weight"], V, ops._pad(d), rows, d, d, accumulate=True)
 
@@ -349,9 +362,16 @@ class LinearHeadF32:
         ops.linear_fwd(x, self.p["kernel"], self.p["bias"], y, rows, self.din, self.dout, mm=self.mm, ldy=self.ld_out)
         return y, dict(x=x, rows=rows)
 
-    def backward(self, cache, dy, grads, dx=None, accumulate_dx=False):
+    def ce_bwd(self, y, lse, targets, coef_ce, coef_gather, rows):
+        """d loss / d y of the CE (+ gather) terms -> (dy, dyb) for `backward` (see GPT2F32.ce_bwd)"""
+        if self.mm is None:
+            ops.ce_bwd(y, self.ld_out, self.dout, lse, targets, coef_ce, coef_gather, rows)
+            return y, None
+        return None, ops.ce_bwd_staged(self.mm, y, self.ld_out, self.dout, lse, targets, coef_ce, coef_gather, rows)
+
+    def backward(self, cache, dy, grads, dx=None, accumulate_dx=False, dyb=None):
         ops.linear_bwd(cache["x"], self.p["kernel"], dy, dx, grads["kernel"], grads["bias"], cache["rows"], self.din, self.dout, self._ws,
-                       dx_beta=1.0 if accumulate_dx else 0.0, mm=self.mm, lddy=self.ld_out)
+                       dx_beta=1.0 if accumulate_dx else 0.0, mm=self.mm, lddy=self.ld_out, dyb=dyb)
 
     def zero_grads(self):
         if getattr(self, "_arena", None) is None:
@@ -400,11 +420,18 @@ class MLPHeadF32:
         ops.gather_dot(a, self.p["dense2.kernel"], self.p["dense2.bias"], idx, out, rows, self.dh, self.dout)
         return out
 
-    def backward(self, cache, dy, grads, dx=None, accumulate_dx=False):
+    def ce_bwd(self, y, lse, targets, coef_ce, coef_gather, rows):
+        """d loss / d y of the CE (+ gather) terms -> (dy, dyb) for `backward` (see GPT2F32.ce_bwd)"""
+        if self.mm2 is None:
+            ops.ce_bwd(y, self.ld_out, self.dout, lse, targets, coef_ce, coef_gather, rows)
+            return y, None
+        return None, ops.ce_bwd_staged(self.mm2, y, self.ld_out, self.dout, lse, targets, coef_ce, coef_gather, rows)
+
+    def backward(self, cache, dy, grads, dx=None, accumulate_dx=False, dyb=None):
         t, rows = self.t, cache["rows"]
         da = t.empty(rows, self.dh, dtype=t.float32, device=self.dev)
         ops.linear_bwd(cache["a"], self.p["dense2.kernel"], dy, da, grads["dense2.kernel"], grads["dense2.bias"], rows, self.dh, self.dout, self._ws,
-                       mm=self.mm2, lddy=self.ld_out)
+                       mm=self.mm2, lddy=self.ld_out, dyb=dyb)
         ops.relu_bwd(da, cache["z"], da)
         ops.linear_bwd(cache["x"], self.p["dense1.kernel"], da, dx, grads["dense1.kernel"], grads["dense1.bias"], rows, self.din, self.dh, self._ws,
                        dx_beta=1.0 if accumulate_dx else 0.0, mm=self.mm)

@@ -84,6 +84,22 @@ class MatmulBF16:
             self.w[name] = dst
         return dst
 
+    def transpose_staged(self, name, xb, ld_src, rows, cols, colsum=None):
+        """[pad(cols)][pad(rows)] = xb^T from a bf16 operand xb [rows..][ld_src] a producer already staged; colsum as in `cast`."""
+        rd, ld = _padn(cols), _pitch(rows)
+        dst = self._buf(name, rd * ld)
+        ws = None
+        if colsum is not None:
+            ws = self._buf("colsum_ws", _L().lmrl_cast_bf16_t_colsum_ws_bytes(rows, rd) // 2)
+        _lib.check(_L().lmrl_transpose_bf16_colsum(xb.data_ptr(), ld_src, rows, cols, dst.data_ptr(), ld, rd,
+                                                   colsum[0].data_ptr() if colsum is not None else None, int(colsum[1]) if colsum is not None else 0,
+                                                   _lib.ptr(ws), _sp()), "lmrl_transpose_bf16_colsum")
+        return dst
+
+    def stage_dy(self, rows, n):
+        """(buffer, row pitch) for a producer that writes the bf16 dy operand [pad(rows)][pitch(n)] of the next `linear_bwd` itself."""
+        return self._buf("dy", _padn(rows) * _pitch(n)), _pitch(n)
+
     def stage(self, rows, k):
         """(buffer, row pitch) for a producer that writes the bf16 operand [rows][k] of the NEXT `linear_fwd` itself (k a multiple of 64)."""
         assert k % 64 == 0
@@ -120,8 +136,9 @@ def linear_fwd(x, w, b, y, rows, k, n, mm: Optional[MatmulBF16] = None, ldy=None
     mm.gemm(xb, wt, mm.bias(b, n) if b is not None else None, y, rows, _padn(n), k, ldy, n)
 
 
-def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_beta=0.0, mm: Optional[MatmulBF16] = None, lddy=None):
-    """dx = dy @ w^T ; dw (+)= x^T @ dy ; db (+)= colsum(dy)"""
+def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_beta=0.0, mm: Optional[MatmulBF16] = None, lddy=None, dyb=None):
+    """dx = dy @ w^T ; dw (+)= x^T @ dy ; db (+)= colsum(dy).  dyb (bf16 mode): dy already staged by its producer as the bf16 operand
+    `mm.stage_dy(rows, n)` — then `dy` is not read (may be None) and the bias gradient sums the bf16 values."""
     lddy = lddy or n
     if mm is None:
         if dx is not None:
@@ -130,12 +147,19 @@ def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_b
     else:
         assert dx_beta in (0.0, 1.0)
         if dx is not None:
-            dyb = mm.cast("dy", dy, rows, n, lddy)                                      # [rows][pad(n)]
+            if dyb is None:
+                dyb_ = mm.cast("dy", dy, rows, n, lddy)                                 # [rows][pad(n)]
+            else:
+                dyb_ = dyb
             assert k % 64 == 0, "bf16 matmul mode: layer widths must be multiples of 64"
             wb = mm.cast(("w", w.data_ptr()), w, k, n, n, keep=True)                     # [k][pad(n)]
-            mm.gemm(dyb, wb, None, dx, rows, k, n, k, k, accumulate=dx_beta == 1.0)
+            mm.gemm(dyb_, wb, None, dx, rows, k, n, k, k, accumulate=dx_beta == 1.0)
         xt = mm.cast("xT", x, rows, k, k, transpose=True)                               # [pad(k)][pad(rows)]
-        dyt = mm.cast("dyT", dy, rows, n, lddy, transpose=True, colsum=(db, accumulate_dw) if db is not None else None)   # [pad(n)][pad(rows)]
+        cs = (db, accumulate_dw) if db is not None else None
+        if dyb is None:
+            dyt = mm.cast("dyT", dy, rows, n, lddy, transpose=True, colsum=cs)          # [pad(n)][pad(rows)]
+        else:
+            dyt = mm.transpose_staged("dyT", dyb, _pitch(n), rows, n, colsum=cs)
         db = None                                                                       # the bias gradient came out of the staging pass
         if n % 4 == 0:
             mm.gemm(xt, dyt, None, dw, k, _padn(n), rows, n, n, accumulate=accumulate_dw)
@@ -246,6 +270,15 @@ def lse_gather(logits, ld, vocab, targets, rows, logprob=None, lse=None, target_
 def ce_bwd(logits, ld, vocab, lse, targets, coef_ce, coef_gather, rows):
     _lib.check(_L().lmrl_ce_bwd(logits.data_ptr(), ld, vocab, lse.data_ptr(), targets.data_ptr(), _lib.ptr(coef_ce), _lib.ptr(coef_gather),
                                 rows, _sp()), "lmrl_ce_bwd")
+
+
+def ce_bwd_staged(mm: MatmulBF16, logits, ld, vocab, lse, targets, coef_ce, coef_gather, rows):
+    """bf16-matmul mode: d loss / d logits written straight into the bf16 dy operand of the head's backward products (no fp32 dlogits
+    matrix, no cast pass over [rows][vocab]); returns the operand for `linear_bwd(dyb=...)` / `lm_head_backward(dlb=...)`."""
+    dst, ldd = mm.stage_dy(rows, vocab)
+    _lib.check(_L().lmrl_ce_bwd_bf16(logits.data_ptr(), ld, vocab, lse.data_ptr(), targets.data_ptr(), _lib.ptr(coef_ce), _lib.ptr(coef_gather),
+                                     rows, dst.data_ptr(), ldd, _padn(rows), _sp()), "lmrl_ce_bwd_bf16")
+    return dst
 
 
 def mask_sum(sta, attn, n, out):

@@ -57,6 +57,36 @@ def test_staging_kernels_bit_exact(dev):
     assert torch.equal(dst, src.t().contiguous())
 
 
+@pytest.mark.parametrize("rows,V,ld", [(37, 211, 256), (130, 1000, 1024), (64, 50257, 50304)])
+def test_producer_staged_dlogits(dev, rows, V, ld):
+    """`ce_bwd_staged` (dlogits written directly as the bf16 operand) == `ce_bwd` in place followed by the cast pass, bit for bit (padding
+    zero); `transpose_staged` of that operand == its transpose, with the column sums of the bf16 values; and a head backward fed the staged
+    operand gives the gradients of the cast path (same products; the bias gradient sums bf16 instead of fp32 values)."""
+    from lmrl_gym_amd.train import ops
+    g = torch.Generator().manual_seed(rows + V)
+    logits = (torch.randn(rows, ld, generator=g) * 2).to(dev)
+    tgt = torch.randint(0, V, (rows,), generator=g).to(torch.int32).to(dev)
+    coef = torch.randn(rows, generator=g).to(dev); coef[1] = 0.0
+    cg = torch.randn(rows, generator=g).to(dev)
+    lse = torch.empty(rows, device=dev); lp = torch.empty(rows, device=dev)
+    ops.lse_gather(logits, ld, V, tgt, rows, logprob=lp, lse=lse)
+    mm = ops.MatmulBF16(dev)
+    dyb = ops.ce_bwd_staged(mm, logits, ld, V, lse, tgt, coef, cg, rows)
+    rp, pitch = ops._padn(rows), ops._pitch(V)
+    got = dyb[: rp * pitch].view(rp, pitch).clone()
+    ref32 = logits.clone()
+    ops.ce_bwd(ref32, ld, V, lse, tgt, coef, cg, rows)
+    assert torch.equal(got[:rows, :V], ref32[:, :V].to(torch.bfloat16))
+    assert float(got[rows:].float().abs().sum()) == 0 and float(got[:, V:].float().abs().sum()) == 0
+    db = torch.full((V,), 0.5, device=dev)
+    dyt = mm.transpose_staged("dyT", dyb, pitch, rows, V, colsum=(db, True))
+    rd, ldt = ops._padn(V), ops._pitch(rows)
+    gt = dyt[: rd * ldt].view(rd, ldt)
+    assert torch.equal(gt[:V, :rows], got[:rows, :V].t())
+    assert float(gt[V:].float().abs().sum()) == 0 and float(gt[:, rows:].float().abs().sum()) == 0
+    np.testing.assert_allclose((db - 0.5).cpu().numpy(), got[:rows, :V].float().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 def test_linear_bf16_against_bf16_rounded_operands(dev):
     """y, dx, dw of one linear layer in bf16 mode == float64 products of the bf16-ROUNDED operands (the only error left is the fp32
     accumulation order): covers the padded-vocabulary output stride and the transposed-dw path for n % 4 != 0."""
