@@ -475,12 +475,16 @@ int lmrl_layernorm_bwd(const float *dy_d, const float *x_d, const float *g_d, co
 int lmrl_layernorm_bwd_fused_supported(int d);
 size_t lmrl_layernorm_bwd_fused_ws_bytes(int rows, int d);
 int lmrl_layernorm_bwd_fused(const float *dy_d, const float *x_d, const float *g_d, const float *mean_d, const float *rstd_d, float *dx_d,
-                             float *dgamma_d, float *dbeta_d, int rows, int d, int accumulate_dx, int accumulate_dg, float *ws_d, void *stream);
+                             float *dgamma_d, float *dbeta_d, int rows, int d, int accumulate_dx, int accumulate_dg, float *ws_d,
+                             void *dxb_d /* optional: bf16 copy of the final dx, row pitch ldb — the dy operand of the next linear backward */,
+                             long ldb, void *stream);
 size_t lmrl_colsum_ws_bytes(int cols);
 int lmrl_colsum(const float *x_d, int rows, int cols, int ld, float *out_d, int accumulate, float *ws_d, void *stream);
 /* elementwise ops: in-place calls are supported (y_d == x_d, dx_d == dy_d, out_d == x_d or y_d) */
 int lmrl_gelu_fwd(const float *x_d, float *y_d, size_t n, void *stream);
 int lmrl_gelu_bwd(const float *dy_d, const float *x_d, float *dx_d, size_t n, void *stream);
+/* bf16-matmul mode: dx written only as the bf16 dy operand [rows_dst][ldb] of the next linear backward (padding zero-filled) */
+int lmrl_gelu_bwd_bf16(const float *dy_d, const float *x_d, int rows, int cols, void *dst_d, long ldb, int rows_dst, void *stream);
 int lmrl_relu_fwd(const float *x_d, float *y_d, size_t n, void *stream);
 int lmrl_relu_bwd(const float *dy_d, const float *x_d, float *dx_d, size_t n, void *stream);
 /* out = a*x + b*y (y may be NULL).  Polyak: optax.incremental_update(new, old, s) = axpby(s, new, 1-s, old). */

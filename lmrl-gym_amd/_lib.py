@@ -110,7 +110,8 @@ _SIGS = {
     "lmrl_layernorm_bwd_fused_supported": (c_int, [c_int]),
     "lmrl_layernorm_bwd_fused_ws_bytes": (c_size_t, [c_int, c_int]),
     "lmrl_layernorm_bwd_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                         c_int, c_void_p, c_void_p]),
+                                         c_int, c_void_p, c_void_p, ctypes.c_long, c_void_p]),
+    "lmrl_gelu_bwd_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.c_long, c_int, c_void_p]),
     "lmrl_colsum_ws_bytes": (c_size_t, [c_int]),
     "lmrl_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "lmrl_gelu_fwd": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
 template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ g,
                                                            const float *__restrict__ mean, const float *__restrict__ rstd, float *dx,
-                                                           float *__restrict__ partial, int R, int rows_per_wg, int accumulate) {
+                                                           float *__restrict__ partial, int R, int rows_per_wg, int accumulate,
+                                                           uint16_t *__restrict__ dxb, long ldb) {
     constexpr int d = NC * 64;
     __shared__ float sm[4][2][d];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -150,8 +151,10 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float *__restri
         float *dxr = dx + (size_t)r * d;
 #pragma unroll
         for (int k = 0; k < NC; k++) {
-            const float v = rs * (dv[k] * gv[k] - s1 - xh[k] * s2);
-            dxr[lane + 64 * k] = accumulate ? dxr[lane + 64 * k] + v : v;
+            float v = rs * (dv[k] * gv[k] - s1 - xh[k] * s2);
+            if (accumulate) v += dxr[lane + 64 * k];
+            dxr[lane + 64 * k] = v;
+            if (dxb) dxb[(size_t)r * ldb + lane + 64 * k] = f32_to_bf16_rne(v);    // the bf16 dy operand of the next linear backward (bf16-matmul mode)
             ag[k] += dv[k] * xh[k];
             ab[k] += dv[k];
         }
@@ -237,6 +240,44 @@ __global__ void gelu_bwd_kernel(const float *dy, const float *__restrict__ x, fl
         const float th = tanhf(u);
         const float du = 0.7978845608028654f * (1.f + 3.f * 0.044715f * v * v);
         dx[i] = dy[i] * (0.5f * (1.f + th) + 0.5f * v * (1.f - th * th) * du);
+    }
+}
+// the same written as the bf16 dy operand [rows_dst][ldb] of the next linear backward (bf16-matmul mode: nothing else reads dx); one
+// workgroup per destination row, 8 columns per lane and iteration, padding zero-filled
+__global__ __launch_bounds__(256) void gelu_bwd_bf16_kernel(const float *__restrict__ dy, const float *__restrict__ x, int rows, int cols,
+                                                            uint16_t *__restrict__ dst, long ldb) {
+    const int r = blockIdx.x;
+    uint16_t *q = dst + (size_t)r * ldb;
+    const float *dyr = dy + (size_t)r * cols, *xr = x + (size_t)r * cols;
+    const bool vec = r < rows && (cols & 3) == 0;
+    for (int c0 = threadIdx.x * 8; c0 < ldb; c0 += 256 * 8) {
+        float a[8], b[8], o[8];
+        if (vec && c0 + 8 <= cols) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(dyr + c0), a1 = *reinterpret_cast<const float4 *>(dyr + c0 + 4);
+            const float4 b0 = *reinterpret_cast<const float4 *>(xr + c0), b1 = *reinterpret_cast<const float4 *>(xr + c0 + 4);
+            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+            b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool ok = r < rows && c0 + k < cols;
+                a[k] = ok ? dyr[c0 + k] : 0.f; b[k] = ok ? xr[c0 + k] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float v = b[k];
+            const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+            const float th = tanhf(u);
+            const float du = 0.7978845608028654f * (1.f + 3.f * 0.044715f * v * v);
+            o[k] = a[k] * (0.5f * (1.f + th) + 0.5f * v * (1.f - th * th) * du);
+        }
+        uint4 pk;
+        pk.x = (uint32_t)f32_to_bf16_rne(o[0]) | ((uint32_t)f32_to_bf16_rne(o[1]) << 16);
+        pk.y = (uint32_t)f32_to_bf16_rne(o[2]) | ((uint32_t)f32_to_bf16_rne(o[3]) << 16);
+        pk.z = (uint32_t)f32_to_bf16_rne(o[4]) | ((uint32_t)f32_to_bf16_rne(o[5]) << 16);
+        pk.w = (uint32_t)f32_to_bf16_rne(o[6]) | ((uint32_t)f32_to_bf16_rne(o[7]) << 16);
+        *reinterpret_cast<uint4 *>(q + c0) = pk;
     }
 }
 __global__ void relu_fwd_kernel(const float *x, float *y, size_t n) {
@@ -458,12 +499,16 @@ size_t lmrl_layernorm_bwd_fused_ws_bytes(int rows, int d) {
     return (size_t)ceil_div(rows, ln_bwd_rows_per_wg(rows)) * 2 * d * sizeof(float);
 }
 int lmrl_layernorm_bwd_fused(const float *dy_d, const float *x_d, const float *g_d, const float *mean_d, const float *rstd_d, float *dx_d,
-                             float *dgamma_d, float *dbeta_d, int rows, int d, int accumulate_dx, int accumulate_dg, float *ws_d, void *stream) {
+                             float *dgamma_d, float *dbeta_d, int rows, int d, int accumulate_dx, int accumulate_dg, float *ws_d, void *dxb_d,
+                             long ldb, void *stream) {
     LMRL_REQUIRE(dy_d && x_d && g_d && mean_d && rstd_d && dx_d && dgamma_d && dbeta_d && ws_d && rows > 0, "lmrl_layernorm_bwd_fused: bad argument");
     LMRL_REQUIRE(lmrl_layernorm_bwd_fused_supported(d), "lmrl_layernorm_bwd_fused: d_model must be one of 128, 256, 768, 1024, 1280, 1600");
+    LMRL_REQUIRE(!dxb_d || ldb >= d, "lmrl_layernorm_bwd_fused: bf16 copy pitch smaller than d_model");
     const int rpw = ln_bwd_rows_per_wg(rows), nslab = ceil_div(rows, rpw);
 #define LMRL_LNB(NC_)                                                                                                                        \
-    hipLaunchKernelGGL(ln_bwd_fused_kernel<NC_>, dim3(nslab), dim3(256), 0, ST, dy_d, x_d, g_d, mean_d, rstd_d, dx_d, ws_d, rows, rpw, accumulate_dx)
+    hipLaunchKernelGGL(ln_bwd_fused_kernel<NC_>, dim3(nslab), dim3(256), 0, ST,                                                               \
+                       dy_d, x_d, g_d, mean_d, rstd_d, dx_d, ws_d, rows, rpw, accumulate_dx, \
+                       (uint16_t *)dxb_d, ldb)
     switch (d / 64) {
         case 2: LMRL_LNB(2); break;
         case 4: LMRL_LNB(4); break;
@@ -497,6 +542,12 @@ int lmrl_gelu_fwd(const float *x_d, float *y_d, size_t n, void *stream) {
 int lmrl_gelu_bwd(const float *dy_d, const float *x_d, float *dx_d, size_t n, void *stream) {
     LMRL_REQUIRE(dy_d && x_d && dx_d, "lmrl_gelu_bwd: null pointer");
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, dy_d, x_d, dx_d, n);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_gelu_bwd_bf16(const float *dy_d, const float *x_d, int rows, int cols, void *dst_d, long ldb, int rows_dst, void *stream) {
+    LMRL_REQUIRE(dy_d && x_d && dst_d && rows > 0 && cols > 0 && ldb >= cols && ldb % 8 == 0 && rows_dst >= rows, "lmrl_gelu_bwd_bf16: bad argument");
+    hipLaunchKernelGGL(gelu_bwd_bf16_kernel, dim3(rows_dst), dim3(256), 0, ST, dy_d, x_d, rows, cols, (uint16_t *)dst_d, ldb);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

@@ -274,12 +274,16 @@ class GPT2F32:
         scale = 1.0 / math.sqrt(hd)
         new = lambda *shape: t.empty(shape, dtype=t.float32, device=self.dev)
         dx = new(R, d)
+        mm = self.mm
+        dxb = [None]       # bf16-matmul mode: the bf16 copy of dx the LayerNorm backward leaves behind = the dy operand of the next c_proj backward
         if ops.layernorm_bwd_fused_supported(d):
             lws = new(ops.layernorm_bwd_fused_ws_floats(R, d))
 
             def ln_bwd(dy, x, name, mean, rstd, accumulate_dx):   # dx (+)=, gamma / beta gradients accumulated, one pass
+                buf, ldb = mm.stage_dy(R, d) if mm is not None else (None, 0)
                 ops.layernorm_bwd_fused(dy, x, p[name + ".weight"], mean, rstd, dx, grads[name + ".weight"], grads[name + ".bias"], R, d,
-                                        accumulate_dx, True, lws)
+                                        accumulate_dx, True, lws, buf, ldb)
+                dxb[0] = buf
         else:
             tmp = new(R, d)
 
@@ -297,15 +301,22 @@ class GPT2F32:
                 _, c = self._layer_forward(l, c["x_in"], B, T, cache["km"], cache["flash"], cache["lse_n"])
             # MLP: x_out = x_mid + gelu(h2 W_fc + b) W_proj + b
             dg = new(R, self.d_ff)
-            ops.linear_bwd(c["g"], p[q + "mlp.c_proj.weight"], dx, dg, grads[q + "mlp.c_proj.weight"], grads[q + "mlp.c_proj.bias"], R, self.d_ff, d, ws, mm=self.mm)
-            df = dg
-            ops.gelu_bwd(dg, c["f"], df)
+            ops.linear_bwd(c["g"], p[q + "mlp.c_proj.weight"], dx, dg, grads[q + "mlp.c_proj.weight"], grads[q + "mlp.c_proj.bias"], R, self.d_ff, d, ws, mm=mm,
+                           dyb=dxb[0])
+            dfb = None
+            if mm is not None:             # df only feeds the c_fc backward products: written as their bf16 operand, no fp32 copy
+                df, dfb = None, ops.gelu_bwd_staged(mm, dg, c["f"], R, self.d_ff)
+            else:
+                df = dg
+                ops.gelu_bwd(dg, c["f"], df)
             dh2 = new(R, d)
-            ops.linear_bwd(c["h2"], p[q + "mlp.c_fc.weight"], df, dh2, grads[q + "mlp.c_fc.weight"], grads[q + "mlp.c_fc.bias"], R, d, self.d_ff, ws, mm=self.mm)
+            ops.linear_bwd(c["h2"], p[q + "mlp.c_fc.weight"], df, dh2, grads[q + "mlp.c_fc.weight"], grads[q + "mlp.c_fc.bias"], R, d, self.d_ff, ws, mm=mm,
+                           dyb=dfb)
             ln_bwd(dh2, c["x_mid"], q + "ln_2", c["m2"], c["r2"], True)    # dx := dx_mid
             # attention projection
             datt = new(R, d)
-            ops.linear_bwd(c["att"], p[q + "attn.c_proj.weight"], dx, datt, grads[q + "attn.c_proj.weight"], grads[q + "attn.c_proj.bias"], R, d, d, ws, mm=self.mm)
+            ops.linear_bwd(c["att"], p[q + "attn.c_proj.weight"], dx, datt, grads[q + "attn.c_proj.weight"], grads[q + "attn.c_proj.bias"], R, d, d, ws, mm=mm,
+                           dyb=dxb[0])
             qkv, P = c["qkv"], c["P"]
             dqkv = new(R, 3 * d)
             if cache["flash"]:

@@ -209,11 +209,19 @@ def layernorm_bwd_fused_ws_floats(rows, d) -> int:
     return _L().lmrl_layernorm_bwd_fused_ws_bytes(int(rows), int(d)) // 4
 
 
-def layernorm_bwd_fused(dy, x, g, mean, rstd, dx, dgamma, dbeta, rows, d, accumulate_dx, accumulate_dg, ws):
-    """dx (+)= LN backward ; dgamma (+)= colsum(dy * xhat) ; dbeta (+)= colsum(dy) — one pass over the activations + a small reduce"""
+def layernorm_bwd_fused(dy, x, g, mean, rstd, dx, dgamma, dbeta, rows, d, accumulate_dx, accumulate_dg, ws, dxb=None, ldb=0):
+    """dx (+)= LN backward ; dgamma (+)= colsum(dy * xhat) ; dbeta (+)= colsum(dy) — one pass over the activations + a small reduce.
+    dxb (bf16 mode): also the bf16 copy of the final dx (row pitch ldb), the dy operand of the next `linear_bwd(dyb=...)`."""
     _lib.check(_L().lmrl_layernorm_bwd_fused(dy.data_ptr(), x.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
                                              dgamma.data_ptr(), dbeta.data_ptr(), rows, d, int(accumulate_dx), int(accumulate_dg),
-                                             ws.data_ptr(), _sp()), "lmrl_layernorm_bwd_fused")
+                                             ws.data_ptr(), _lib.ptr(dxb), ldb, _sp()), "lmrl_layernorm_bwd_fused")
+
+
+def gelu_bwd_staged(mm, dy, x, rows, cols):
+    """bf16-matmul mode: gelu backward written only as the bf16 dy operand of the next `linear_bwd(dyb=...)`"""
+    dst, ldb = mm.stage_dy(rows, cols)
+    _lib.check(_L().lmrl_gelu_bwd_bf16(dy.data_ptr(), x.data_ptr(), rows, cols, dst.data_ptr(), ldb, _padn(rows), _sp()), "lmrl_gelu_bwd_bf16")
+    return dst
 
 
 def gelu_fwd(x, y):

@@ -90,7 +90,9 @@ def test_layernorm_bwd_fused_vs_autograd(dev, R, d):
     outs = []
     for rep in range(2):
         dxd = torch.full_like(xd, 3.0); dg = torch.full((d,), 2.0, device=dev); db = torch.full((d,), -1.0, device=dev)
-        ops.layernorm_bwd_fused(dyd, xd, gd, mean, rstd, dxd, dg, db, R, d, True, True, ws)          # everything accumulates
+        dxb = torch.zeros(R, d + 64, dtype=torch.bfloat16, device=dev)
+        ops.layernorm_bwd_fused(dyd, xd, gd, mean, rstd, dxd, dg, db, R, d, True, True, ws, dxb, d + 64)   # everything accumulates
+        assert torch.equal(dxb[:, :d], dxd.to(torch.bfloat16)) and float(dxb[:, d:].float().abs().sum()) == 0   # bf16 copy of the final dx
         outs.append((dxd.clone(), dg.clone(), db.clone()))
     assert all(torch.equal(a, b) for a, b in zip(*outs))
     dxd, dg, db = outs[0]
