@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const typename E::T *
                                                            const typename E::T *__restrict__ Vn, const typename E::T *__restrict__ KT,
                                                            const typename E::T *__restrict__ dOn, const float *__restrict__ Dsum,
                                                            const float *__restrict__ lse, const uint8_t *__restrict__ km, float *__restrict__ dqkv,
+                                                           uint16_t *__restrict__ dqb, long ldb,
                                                            int H, int T, int Tp, int d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *sK = smem, *sV = smem + E::TILE, *sKT = smem + 2 * E::TILE;
@@ -291,8 +292,13 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const typename E::T *
     }
     if (qi < T) {
 #pragma unroll
-        for (int db = 0; db < 4; db++)
-            *reinterpret_cast<f32x4 *>(dqkv + ((long)b * T + qi) * 3 * d + h * 64 + db * 16 + lq * 4) = dq[db] * 0.125f;
+        for (int db = 0; db < 4; db++) {
+            const f32x4 v = dq[db] * 0.125f;
+            if (dqb)       // bf16-matmul train mode: dqkv is only the dy operand of the c_attn backward products — written as that operand
+                *reinterpret_cast<uint2 *>(dqb + ((long)b * T + qi) * ldb + h * 64 + db * 16 + lq * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            else
+                *reinterpret_cast<f32x4 *>(dqkv + ((long)b * T + qi) * 3 * d + h * 64 + db * 16 + lq * 4) = v;
+        }
     }
 }
 
@@ -302,7 +308,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const typename E::T 
                                                             const typename E::T *__restrict__ Vn, const typename E::T *__restrict__ QT,
                                                             const typename E::T *__restrict__ dOn, const typename E::T *__restrict__ dOT,
                                                             const float *__restrict__ Dsum, const float *__restrict__ lse,
-                                                            const uint8_t *__restrict__ km, float *__restrict__ dqkv, int H, int T, int Tp, int d) {
+                                                            const uint8_t *__restrict__ km, float *__restrict__ dqkv, uint16_t *__restrict__ dqb,
+                                                            long ldb, int H, int T, int Tp, int d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *sQ = smem, *sdO = smem + E::TILE, *sQT = smem + 2 * E::TILE, *sdOT = smem + 3 * E::TILE;
     float *sL = reinterpret_cast<float *>(smem + 4 * E::TILE), *sD = sL + 64;
@@ -363,9 +370,15 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const typename E::T 
     if (kj < T) {
 #pragma unroll
         for (int db = 0; db < 4; db++) {
-            float *row = dqkv + ((long)b * T + kj) * 3 * d + h * 64 + db * 16 + lq * 4;
-            *reinterpret_cast<f32x4 *>(row + d) = dk[db];
-            *reinterpret_cast<f32x4 *>(row + 2 * d) = dv[db];
+            if (dqb) {
+                uint16_t *row = dqb + ((long)b * T + kj) * ldb + h * 64 + db * 16 + lq * 4;
+                *reinterpret_cast<uint2 *>(row + d) = make_uint2(pack_bf16x2(dk[db][0], dk[db][1]), pack_bf16x2(dk[db][2], dk[db][3]));
+                *reinterpret_cast<uint2 *>(row + 2 * d) = make_uint2(pack_bf16x2(dv[db][0], dv[db][1]), pack_bf16x2(dv[db][2], dv[db][3]));
+            } else {
+                float *row = dqkv + ((long)b * T + kj) * 3 * d + h * 64 + db * 16 + lq * 4;
+                *reinterpret_cast<f32x4 *>(row + d) = dk[db];
+                *reinterpret_cast<f32x4 *>(row + 2 * d) = dv[db];
+            }
         }
     }
 }
@@ -421,8 +434,8 @@ static int flash_fwd(const float *qkv, const uint8_t *km, float *att, float *lse
 }
 
 template <class E>
-static int flash_bwd(const float *qkv, const uint8_t *km, const float *att, const float *datt, const float *lse, float *dqkv, void *ws, int batch,
-                     int heads, int t, hipStream_t s) {
+static int flash_bwd(const float *qkv, const uint8_t *km, const float *att, const float *datt, const float *lse, float *dqkv, uint16_t *dqb,
+                     long ldb, void *ws, int batch, int heads, int t, hipStream_t s) {
     typedef typename E::T T;
     const int tp = (t + 63) / 64 * 64, bh = batch * heads, d = heads * 64;
     FlashWs w; w.carve(ws, bh, tp, E::SZ);
@@ -434,9 +447,9 @@ static int flash_bwd(const float *qkv, const uint8_t *km, const float *att, cons
     LMRL_CHECK_HIP(allow_lds(flash_bwd_dq_kernel<E>, lds_q));
     LMRL_CHECK_HIP(allow_lds(flash_bwd_dkv_kernel<E>, lds_kv));
     hipLaunchKernelGGL(flash_bwd_dq_kernel<E>, dim3(tp / 64, bh), dim3(256), lds_q, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.Vn, (const T *)w.KT,
-                       (const T *)w.dOn, (const float *)w.D, lse, km, dqkv, heads, t, tp, d);
+                       (const T *)w.dOn, (const float *)w.D, lse, km, dqkv, dqb, ldb, heads, t, tp, d);
     hipLaunchKernelGGL(flash_bwd_dkv_kernel<E>, dim3(tp / 64, bh), dim3(256), lds_kv, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.Vn,
-                       (const T *)w.QT, (const T *)w.dOn, (const T *)w.dOT, (const float *)w.D, lse, km, dqkv, heads, t, tp, d);
+                       (const T *)w.QT, (const T *)w.dOn, (const T *)w.dOT, (const float *)w.D, lse, km, dqkv, dqb, ldb, heads, t, tp, d);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }
@@ -470,8 +483,15 @@ int lmrl_flash_attn_fwd_staged(const float *qkv_d, const uint8_t *key_mask_d, fl
 int lmrl_flash_attn_bwd(const float *qkv_d, const uint8_t *key_mask_d, const float *att_d, const float *datt_d, const float *lse_d, float *dqkv_d,
                         void *ws_d, int batch, int heads, int t, int bf16, void *stream) {
     LMRL_REQUIRE(qkv_d && att_d && datt_d && lse_d && dqkv_d && ws_d && batch > 0 && heads > 0 && t > 0, "lmrl_flash_attn_bwd: bad argument");
-    return bf16 ? flash_bwd<ElemBF16>(qkv_d, key_mask_d, att_d, datt_d, lse_d, dqkv_d, ws_d, batch, heads, t, as_stream(stream))
-                : flash_bwd<ElemF32>(qkv_d, key_mask_d, att_d, datt_d, lse_d, dqkv_d, ws_d, batch, heads, t, as_stream(stream));
+    return bf16 ? flash_bwd<ElemBF16>(qkv_d, key_mask_d, att_d, datt_d, lse_d, dqkv_d, nullptr, 0, ws_d, batch, heads, t, as_stream(stream))
+                : flash_bwd<ElemF32>(qkv_d, key_mask_d, att_d, datt_d, lse_d, dqkv_d, nullptr, 0, ws_d, batch, heads, t, as_stream(stream));
+}
+
+int lmrl_flash_attn_bwd_staged(const float *qkv_d, const uint8_t *key_mask_d, const float *att_d, const float *datt_d, const float *lse_d,
+                               void *dqkv_bf16_d, long ldb, void *ws_d, int batch, int heads, int t, void *stream) {
+    LMRL_REQUIRE(qkv_d && att_d && datt_d && lse_d && dqkv_bf16_d && ws_d && ldb >= 3 * heads * 64 && ldb % 4 == 0 && batch > 0 && heads > 0 && t > 0,
+                 "lmrl_flash_attn_bwd_staged: bad argument");
+    return flash_bwd<ElemBF16>(qkv_d, key_mask_d, att_d, datt_d, lse_d, nullptr, (uint16_t *)dqkv_bf16_d, ldb, ws_d, batch, heads, t, as_stream(stream));
 }
 
 }  // extern "C"

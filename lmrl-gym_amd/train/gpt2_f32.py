@@ -318,13 +318,18 @@ class GPT2F32:
             ops.linear_bwd(c["att"], p[q + "attn.c_proj.weight"], dx, datt, grads[q + "attn.c_proj.weight"], grads[q + "attn.c_proj.bias"], R, d, d, ws, mm=mm,
                            dyb=dxb[0])
             qkv, P = c["qkv"], c["P"]
-            dqkv = new(R, 3 * d)
-            if cache["flash"]:
-                ops.flash_attn_bwd(qkv, cache["km"], c["att"], datt, c["lse"], dqkv, self._flash_ws[0], B, H, T, self.mm is not None)
+            dqkv, dqkvb = None, None
+            if cache["flash"] and mm is not None:
+                dqkvb = ops.flash_attn_bwd_staged(mm, qkv, cache["km"], c["att"], datt, c["lse"], self._flash_ws[0], B, H, T)
+            elif cache["flash"]:
+                dqkv = new(R, 3 * d)
+                ops.flash_attn_bwd(qkv, cache["km"], c["att"], datt, c["lse"], dqkv, self._flash_ws[0], B, H, T, False)
             else:
+                dqkv = new(R, 3 * d)
                 self._attention_bwd_materialized(qkv, P, datt, dqkv, B, T, H, hd, d, scale, new)
             dh1 = new(R, d)
-            ops.linear_bwd(c["h1"], p[q + "attn.c_attn.weight"], dqkv, dh1, grads[q + "attn.c_attn.weight"], grads[q + "attn.c_attn.bias"], R, d, 3 * d, ws, mm=self.mm)
+            ops.linear_bwd(c["h1"], p[q + "attn.c_attn.weight"], dqkv, dh1, grads[q + "attn.c_attn.weight"], grads[q + "attn.c_attn.bias"], R, d, 3 * d, ws, mm=mm,
+                           dyb=dqkvb)
             ln_bwd(dh1, c["x_in"], q + "ln_1", c["m1"], c["r1"], True)     # dx := dx_in
             if on_final is not None:
                 on_final([q + n for n in ("mlp.c_proj.weight", "mlp.c_proj.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "ln_2.weight", "ln_2.bias",

@@ -61,6 +61,11 @@ def test_flash_attention_fwd_bwd(B, T, H, pad, bf16):
         assert err <= tol, (name, err)
     if pad == "left":                                  # queries before the first valid key: exact zero rows
         assert float(att.view(B, T, d)[0, :23].abs().max()) == 0.0
+    if bf16:     # the staged form: d(qkv) written as the bf16 operand of the c_attn backward products == the rounded fp32 output
+        mm = ops.MatmulBF16(dev)
+        dst = ops.flash_attn_bwd_staged(mm, qkv, km, att, datt, lse, ws, B, H, T)
+        ldb = ops._pitch(3 * d)
+        assert torch.equal(dst[: B * T * ldb].view(B * T, ldb)[:, : 3 * d], dqkv.to(torch.bfloat16))
 
 
 def test_flash_and_materialized_train_paths_agree():
