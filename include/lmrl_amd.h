@@ -462,7 +462,8 @@ int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d
 int lmrl_layernorm_fwd(const float *x_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, int rows, int d,
                        float eps, void *stream);
 /* LayerNorm / gelu forward that ALSO write the bf16 copy of their output (row pitch ldb elements) — the operand of the GEMM that consumes it in
- * the bf16-matmul train mode (saves the separate lmrl_cast_bf16 pass) */
+ * the bf16-matmul train mode (saves the separate lmrl_cast_bf16 pass).  y_d may be NULL: only the bf16 copy is kept (it also serves, transposed,
+ * as the operand of the layer's dW product). */
 int lmrl_layernorm_fwd_staged(const float *x_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, void *yb_d, long ldb,
                               int rows, int d, float eps, void *stream);
 int lmrl_gelu_fwd_staged(const float *x_d, float *y_d, void *yb_d, long ldb, int rows, int cols, void *stream);

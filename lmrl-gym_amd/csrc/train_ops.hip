@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
     const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
     for (int c = lane; c < d; c += 64) {
         const float v = (xr[c] - mu) * rs * g[c] + b[c];
-        y[(size_t)r * d + c] = v;
+        if (y) y[(size_t)r * d + c] = v;
         if (yb) yb[(size_t)r * ldb + c] = f32_to_bf16_rne(v);      // the bf16 operand of the consuming GEMM (bf16-matmul train mode)
     }
     if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
@@ -168,18 +168,22 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float *__restri
         out[i] = (sm[0][which][c] + sm[1][which][c]) + (sm[2][which][c] + sm[3][which][c]);
     }
 }
-// dgamma[c] (+)= sum_slab partial[slab][0][c], dbeta likewise: 64 columns per workgroup, 4 slab phases per column merged through LDS
+// dgamma[c] (+)= sum_slab partial[slab][0][c], dbeta likewise: 16 columns per workgroup, 16 slab phases per column merged through LDS in a
+// fixed order (2d / 16 workgroups: enough of them to pull the 2 x nslab x d partial matrix at HBM rate)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restrict__ partial, int nslab, int d, float *dgamma, float *dbeta,
                                                             int accumulate) {
-    __shared__ float sm[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;      // col over [0, 2d)
+    __shared__ float sm[16][17];
+    const int cl = threadIdx.x & 15, ph = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;                      // over [0, 2d)
     float s = 0.f;
     if (col < 2 * d)
-        for (int k = ph; k < nslab; k += 4) s += partial[(size_t)k * 2 * d + col];
-    sm[ph][threadIdx.x & 63] = s;
+        for (int k = ph; k < nslab; k += 16) s += partial[(size_t)k * 2 * d + col];
+    sm[ph][cl] = s;
     __syncthreads();
     if (ph == 0 && col < 2 * d) {
-        const float v = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) v += sm[k][cl];
         float *o = col < d ? dgamma + col : dbeta + (col - d);
         *o = accumulate ? *o + v : v;
     }
@@ -223,14 +227,45 @@ __device__ __forceinline__ float gelu_new_exact(float x) {
 __global__ void gelu_fwd_kernel(const float *x, float *y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = gelu_new_exact(x[i]);
 }
-// the same on a [rows][cols] matrix, also writing the bf16 copy (row pitch ldb) the consuming GEMM reads
-__global__ void gelu_fwd_staged_kernel(const float *x, float *y, uint16_t *__restrict__ yb, long ldb, int rows, int cols) {
-    const size_t n = (size_t)rows * cols;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float v = gelu_new_exact(x[i]);
-        y[i] = v;
-        const size_t r = i / cols;
-        yb[r * ldb + (i - r * cols)] = f32_to_bf16_rne(v);
+// the same on a [rows][cols] matrix, writing the bf16 copy (row pitch ldb) the consuming GEMM reads and, optionally, the fp32 result
+// (bf16-matmul train mode keeps only the bf16 copy: it is both the c_proj operand and, transposed, the operand of its dW product).
+// One workgroup per row, 8 columns per lane and iteration.
+__global__ __launch_bounds__(256) void gelu_fwd_staged_kernel(const float *__restrict__ x, float *y, uint16_t *__restrict__ yb, long ldb, int rows,
+                                                              int cols) {
+    const int r = blockIdx.x;
+    const float *xr = x + (size_t)r * cols;
+    const bool vec = (cols & 3) == 0;
+    for (int c0 = threadIdx.x * 8; c0 < cols; c0 += 256 * 8) {
+        float a[8], o[8];
+        const bool full = vec && c0 + 8 <= cols;
+        if (full) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(xr + c0), a1 = *reinterpret_cast<const float4 *>(xr + c0 + 4);
+            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) a[k] = c0 + k < cols ? xr[c0 + k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[k] = gelu_new_exact(a[k]);
+        if (full && (ldb & 7) == 0) {
+            uint4 pk;
+            pk.x = (uint32_t)f32_to_bf16_rne(o[0]) | ((uint32_t)f32_to_bf16_rne(o[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16_rne(o[2]) | ((uint32_t)f32_to_bf16_rne(o[3]) << 16);
+            pk.z = (uint32_t)f32_to_bf16_rne(o[4]) | ((uint32_t)f32_to_bf16_rne(o[5]) << 16);
+            pk.w = (uint32_t)f32_to_bf16_rne(o[6]) | ((uint32_t)f32_to_bf16_rne(o[7]) << 16);
+            *reinterpret_cast<uint4 *>(yb + (size_t)r * ldb + c0) = pk;
+            if (y) {
+                *reinterpret_cast<float4 *>(y + (size_t)r * cols + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4 *>(y + (size_t)r * cols + c0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (c0 + k < cols) {
+                    yb[(size_t)r * ldb + c0 + k] = f32_to_bf16_rne(o[k]);
+                    if (y) y[(size_t)r * cols + c0 + k] = o[k];
+                }
+        }
     }
 }
 __global__ void gelu_bwd_kernel(const float *dy, const float *__restrict__ x, float *dx, size_t n) {
@@ -474,14 +509,14 @@ int lmrl_layernorm_fwd(const float *x_d, const float *g_d, const float *b_d, flo
 }
 int lmrl_layernorm_fwd_staged(const float *x_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, void *yb_d, long ldb,
                               int rows, int d, float eps, void *stream) {
-    LMRL_REQUIRE(x_d && g_d && b_d && y_d && mean_d && rstd_d && yb_d && ldb >= d && rows > 0 && d > 0, "lmrl_layernorm_fwd_staged: bad argument");
+    LMRL_REQUIRE(x_d && g_d && b_d && mean_d && rstd_d && yb_d && ldb >= d && rows > 0 && d > 0, "lmrl_layernorm_fwd_staged: bad argument");
     hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, x_d, g_d, b_d, y_d, mean_d, rstd_d, rows, d, eps, (uint16_t *)yb_d, ldb);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }
 int lmrl_gelu_fwd_staged(const float *x_d, float *y_d, void *yb_d, long ldb, int rows, int cols, void *stream) {
-    LMRL_REQUIRE(x_d && y_d && yb_d && rows > 0 && cols > 0 && ldb >= cols, "lmrl_gelu_fwd_staged: bad argument");
-    hipLaunchKernelGGL(gelu_fwd_staged_kernel, dim3(ew_grid((size_t)rows * cols)), dim3(256), 0, ST, x_d, y_d, (uint16_t *)yb_d, ldb, rows, cols);
+    LMRL_REQUIRE(x_d && yb_d && rows > 0 && cols > 0 && ldb >= cols, "lmrl_gelu_fwd_staged: bad argument");
+    hipLaunchKernelGGL(gelu_fwd_staged_kernel, dim3(rows), dim3(256), 0, ST, x_d, y_d, (uint16_t *)yb_d, ldb, rows, cols);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }
@@ -518,7 +553,7 @@ int lmrl_layernorm_bwd_fused(const float *dy_d, const float *x_d, const float *g
         default: LMRL_LNB(25); break;
     }
 #undef LMRL_LNB
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(2 * d, 64)), dim3(256), 0, ST, ws_d, nslab, d, dgamma_d, dbeta_d, accumulate_dg);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(2 * d, 16)), dim3(256), 0, ST, ws_d, nslab, d, dgamma_d, dbeta_d, accumulate_dg);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

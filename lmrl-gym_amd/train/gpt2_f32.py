@@ -116,23 +116,26 @@ class GPT2F32:
         c = dict(x_in=x)
         mm = self.mm
         stage = mm is not None and d % 64 == 0 and self.d_ff % 64 == 0     # producers write the bf16 GEMM operands themselves (no cast pass)
-        h1, c["m1"], c["r1"] = new(R, d), new(R), new(R)
-        xb = None
+        # stage: LayerNorm / gelu / attention write the bf16 operand of the consuming GEMM themselves, into per-layer buffers the backward
+        # transposes for the dW products — no fp32 copies of h1 / h2 / g exist in this mode (att keeps one: the flash backward reads it)
+        c["m1"], c["r1"] = new(R), new(R)
+        h1 = h1b = None
         if stage:
-            xb, ldb = mm.stage(R, d)
-            ops.layernorm_fwd_staged(x, p[q + "ln_1.weight"], p[q + "ln_1.bias"], h1, c["m1"], c["r1"], xb, ldb, R, d, self.eps)
+            h1b, ldb = mm.stash(R, d)
+            ops.layernorm_fwd_staged(x, p[q + "ln_1.weight"], p[q + "ln_1.bias"], None, c["m1"], c["r1"], h1b, ldb, R, d, self.eps)
         else:
+            h1 = new(R, d)
             ops.layernorm_fwd(x, p[q + "ln_1.weight"], p[q + "ln_1.bias"], h1, c["m1"], c["r1"], R, d, self.eps)
         qkv = new(R, 3 * d)
-        ops.linear_fwd(h1, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], qkv, R, d, 3 * d, mm=self.mm, xb=xb)
+        ops.linear_fwd(h1, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], qkv, R, d, 3 * d, mm=self.mm, xb=h1b)
         att = new(R, d)
-        xb = None
+        attb = None
         if flash:
             P = None
             c["lse"] = new(lse_n)
             if stage:
-                xb, ldb = mm.stage(R, d)
-                ops.flash_attn_fwd_staged(qkv, km, att, c["lse"], self._flash_ws[0], xb, ldb, B, H, T, True)
+                attb, ldb = mm.stash(R, d)
+                ops.flash_attn_fwd_staged(qkv, km, att, c["lse"], self._flash_ws[0], attb, ldb, B, H, T, True)
             else:
                 ops.flash_attn_fwd(qkv, km, att, c["lse"], self._flash_ws[0], B, H, T, self.mm is not None)
         else:
@@ -144,27 +147,29 @@ class GPT2F32:
             ops.sgemm(P, qkv, att, T, hd, T, lda=T, ldb=3 * d, ldc=d, b_off=2 * d, batch=(B, H), sa=(H * T * T, T * T),
                       sb=(T * 3 * d, hd), sc=(T * d, hd))
         x_mid = new(R, d)
-        ops.linear_fwd(att, p[q + "attn.c_proj.weight"], p[q + "attn.c_proj.bias"], x_mid, R, d, d, mm=self.mm, xb=xb)
+        ops.linear_fwd(att, p[q + "attn.c_proj.weight"], p[q + "attn.c_proj.bias"], x_mid, R, d, d, mm=self.mm, xb=attb)
         ops.axpby(1.0, x_mid, 1.0, x, x_mid)
-        h2, c["m2"], c["r2"] = new(R, d), new(R), new(R)
-        xb = None
+        c["m2"], c["r2"] = new(R), new(R)
+        h2 = h2b = None
         if stage:
-            xb, ldb = mm.stage(R, d)
-            ops.layernorm_fwd_staged(x_mid, p[q + "ln_2.weight"], p[q + "ln_2.bias"], h2, c["m2"], c["r2"], xb, ldb, R, d, self.eps)
+            h2b, ldb = mm.stash(R, d)
+            ops.layernorm_fwd_staged(x_mid, p[q + "ln_2.weight"], p[q + "ln_2.bias"], None, c["m2"], c["r2"], h2b, ldb, R, d, self.eps)
         else:
+            h2 = new(R, d)
             ops.layernorm_fwd(x_mid, p[q + "ln_2.weight"], p[q + "ln_2.bias"], h2, c["m2"], c["r2"], R, d, self.eps)
         f = new(R, self.d_ff)
-        ops.linear_fwd(h2, p[q + "mlp.c_fc.weight"], p[q + "mlp.c_fc.bias"], f, R, d, self.d_ff, mm=self.mm, xb=xb)
-        g = new(R, self.d_ff)
-        xb = None
+        ops.linear_fwd(h2, p[q + "mlp.c_fc.weight"], p[q + "mlp.c_fc.bias"], f, R, d, self.d_ff, mm=self.mm, xb=h2b)
+        g = gb = None
         if stage:
-            xb, ldb = mm.stage(R, self.d_ff)
-            ops.gelu_fwd_staged(f, g, xb, ldb, R, self.d_ff)
+            gb, ldb = mm.stash(R, self.d_ff)
+            ops.gelu_fwd_staged(f, None, gb, ldb, R, self.d_ff)
         else:
+            g = new(R, self.d_ff)
             ops.gelu_fwd(f, g)
         x_out = new(R, d)
-        ops.linear_fwd(g, p[q + "mlp.c_proj.weight"], p[q + "mlp.c_proj.bias"], x_out, R, self.d_ff, d, mm=self.mm, xb=xb)
+        ops.linear_fwd(g, p[q + "mlp.c_proj.weight"], p[q + "mlp.c_proj.bias"], x_out, R, self.d_ff, d, mm=self.mm, xb=gb)
         ops.axpby(1.0, x_out, 1.0, x_mid, x_out)
+        c.update(h1b=h1b, attb=attb, h2b=h2b, gb=gb)
         c.update(h1=h1, qkv=qkv, P=P, att=att, x_mid=x_mid, h2=h2, f=f, g=g)
         return x_out, c
 
@@ -302,7 +307,7 @@ class GPT2F32:
             # MLP: x_out = x_mid + gelu(h2 W_fc + b) W_proj + b
             dg = new(R, self.d_ff)
             ops.linear_bwd(c["g"], p[q + "mlp.c_proj.weight"], dx, dg, grads[q + "mlp.c_proj.weight"], grads[q + "mlp.c_proj.bias"], R, self.d_ff, d, ws, mm=mm,
-                           dyb=dxb[0])
+                           dyb=dxb[0], xb=c.get("gb"))
             dfb = None
             if mm is not None:             # df only feeds the c_fc backward products: written as their bf16 operand, no fp32 copy
                 df, dfb = None, ops.gelu_bwd_staged(mm, dg, c["f"], R, self.d_ff)
@@ -311,12 +316,12 @@ class GPT2F32:
                 ops.gelu_bwd(dg, c["f"], df)
             dh2 = new(R, d)
             ops.linear_bwd(c["h2"], p[q + "mlp.c_fc.weight"], df, dh2, grads[q + "mlp.c_fc.weight"], grads[q + "mlp.c_fc.bias"], R, d, self.d_ff, ws, mm=mm,
-                           dyb=dfb)
+                           dyb=dfb, xb=c.get("h2b"))
             ln_bwd(dh2, c["x_mid"], q + "ln_2", c["m2"], c["r2"], True)    # dx := dx_mid
             # attention projection
             datt = new(R, d)
             ops.linear_bwd(c["att"], p[q + "attn.c_proj.weight"], dx, datt, grads[q + "attn.c_proj.weight"], grads[q + "attn.c_proj.bias"], R, d, d, ws, mm=mm,
-                           dyb=dxb[0])
+                           dyb=dxb[0], xb=c.get("attb"))
             qkv, P = c["qkv"], c["P"]
             dqkv, dqkvb = None, None
             if cache["flash"] and mm is not None:
@@ -329,7 +334,7 @@ class GPT2F32:
                 self._attention_bwd_materialized(qkv, P, datt, dqkv, B, T, H, hd, d, scale, new)
             dh1 = new(R, d)
             ops.linear_bwd(c["h1"], p[q + "attn.c_attn.weight"], dqkv, dh1, grads[q + "attn.c_attn.weight"], grads[q + "attn.c_attn.bias"], R, d, 3 * d, ws, mm=mm,
-                           dyb=dqkvb)
+                           dyb=dqkvb, xb=c.get("h1b"))
             ln_bwd(dh1, c["x_in"], q + "ln_1", c["m1"], c["r1"], True)     # dx := dx_in
             if on_final is not None:
                 on_final([q + n for n in ("mlp.c_proj.weight", "mlp.c_proj.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "ln_2.weight", "ln_2.bias",

@@ -100,6 +100,12 @@ class MatmulBF16:
         """(buffer, row pitch) for a producer that writes the bf16 dy operand [pad(rows)][pitch(n)] of the next `linear_bwd` itself."""
         return self._buf("dy", _padn(rows) * _pitch(n)), _pitch(n)
 
+    def stash(self, rows, k):
+        """(fresh buffer, row pitch) for a staged operand [rows][k] that must outlive the next `stage`: the forward keeps its bf16 operands
+        per layer, the backward transposes them for the dW products (`linear_bwd(xb=...)`) — no fp32 copy of those activations exists."""
+        assert k % 64 == 0
+        return self.t.empty(_padn(rows) * _pitch(k), dtype=self.t.bfloat16, device=self.dev), _pitch(k)
+
     def stage(self, rows, k):
         """(buffer, row pitch) for a producer that writes the bf16 operand [rows][k] of the NEXT `linear_fwd` itself (k a multiple of 64)."""
         assert k % 64 == 0
@@ -107,6 +113,8 @@ class MatmulBF16:
 
     def bias(self, b, n):
         """fp32 bias padded to a multiple of 64 entries (the GEMM epilogue reads whole 4-column groups)."""
+        if n == _padn(n) and b.is_contiguous() and b.data_ptr() % 16 == 0:
+            return b                        # already whole column groups: read in place (no per-step staging copy)
         key = ("bias", b.data_ptr())
         if key not in self.w:
             bp = self.t.zeros(_padn(n), dtype=self.t.float32, device=self.dev)
@@ -136,9 +144,11 @@ def linear_fwd(x, w, b, y, rows, k, n, mm: Optional[MatmulBF16] = None, ldy=None
     mm.gemm(xb, wt, mm.bias(b, n) if b is not None else None, y, rows, _padn(n), k, ldy, n)
 
 
-def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_beta=0.0, mm: Optional[MatmulBF16] = None, lddy=None, dyb=None):
+def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_beta=0.0, mm: Optional[MatmulBF16] = None, lddy=None, dyb=None,
+               xb=None):
     """dx = dy @ w^T ; dw (+)= x^T @ dy ; db (+)= colsum(dy).  dyb (bf16 mode): dy already staged by its producer as the bf16 operand
-    `mm.stage_dy(rows, n)` — then `dy` is not read (may be None) and the bias gradient sums the bf16 values."""
+    `mm.stage_dy(rows, n)` — then `dy` is not read (may be None) and the bias gradient sums the bf16 values.  xb (bf16 mode): the bf16
+    operand of x the forward kept (`mm.stash(rows, k)`) — then `x` is not read (may be None)."""
     lddy = lddy or n
     if mm is None:
         if dx is not None:
@@ -154,7 +164,10 @@ def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_b
             assert k % 64 == 0, "bf16 matmul mode: layer widths must be multiples of 64"
             wb = mm.cast(("w", w.data_ptr()), w, k, n, n, keep=True)                     # [k][pad(n)]
             mm.gemm(dyb_, wb, None, dx, rows, k, n, k, k, accumulate=dx_beta == 1.0)
-        xt = mm.cast("xT", x, rows, k, k, transpose=True)                               # [pad(k)][pad(rows)]
+        if xb is None:
+            xt = mm.cast("xT", x, rows, k, k, transpose=True)                           # [pad(k)][pad(rows)]
+        else:
+            xt = mm.transpose_staged("xT", xb, _pitch(k), rows, k)
         cs = (db, accumulate_dw) if db is not None else None
         if dyb is None:
             dyt = mm.cast("dyT", dy, rows, n, lddy, transpose=True, colsum=cs)          # [pad(n)][pad(rows)]
@@ -188,12 +201,12 @@ def layernorm_fwd(x, g, b, y, mean, rstd, rows, d, eps):
 
 
 def layernorm_fwd_staged(x, g, b, y, mean, rstd, yb, ldb, rows, d, eps):
-    _lib.check(_L().lmrl_layernorm_fwd_staged(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), yb.data_ptr(), ldb,
+    _lib.check(_L().lmrl_layernorm_fwd_staged(x.data_ptr(), g.data_ptr(), b.data_ptr(), _lib.ptr(y), mean.data_ptr(), rstd.data_ptr(), yb.data_ptr(), ldb,
                                               rows, d, float(eps), _sp()), "lmrl_layernorm_fwd_staged")
 
 
 def gelu_fwd_staged(x, y, yb, ldb, rows, cols):
-    _lib.check(_L().lmrl_gelu_fwd_staged(x.data_ptr(), y.data_ptr(), yb.data_ptr(), ldb, rows, cols, _sp()), "lmrl_gelu_fwd_staged")
+    _lib.check(_L().lmrl_gelu_fwd_staged(x.data_ptr(), _lib.ptr(y), yb.data_ptr(), ldb, rows, cols, _sp()), "lmrl_gelu_fwd_staged")
 
 
 def layernorm_bwd(dy, x, g, mean, rstd, dx, dy_xhat, rows, d, accumulate_dx):
