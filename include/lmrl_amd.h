@@ -507,10 +507,11 @@ int lmrl_flash_attn_fwd(const float *qkv_d, const uint8_t *key_mask_d, float *at
 int lmrl_flash_attn_fwd_staged(const float *qkv_d, const uint8_t *key_mask_d, float *att_d, float *lse_d, void *ws_d, void *att_bf16_d, long ldb, int batch,
                                int heads, int t, int bf16, void *stream);
 int lmrl_flash_attn_bwd(const float *qkv_d, const uint8_t *key_mask_d, const float *att_d, const float *datt_d, const float *lse_d, float *dqkv_d,
-                        void *ws_d, int batch, int heads, int t, int bf16, void *stream);
+                        void *ws_d, int batch, int heads, int t, int bf16,
+                        int qkv_staged /* ws_d still holds what lmrl_flash_attn_fwd staged from these qkv: skip the re-staging */, void *stream);
 /* bf16 kernels, d(qkv) written only as the bf16 dy operand [batch*t][ldb] of the c_attn backward products (bf16-matmul train mode) */
 int lmrl_flash_attn_bwd_staged(const float *qkv_d, const uint8_t *key_mask_d, const float *att_d, const float *datt_d, const float *lse_d,
-                               void *dqkv_bf16_d, long ldb, void *ws_d, int batch, int heads, int t, void *stream);
+                               void *dqkv_bf16_d, long ldb, void *ws_d, int batch, int heads, int t, int qkv_staged, void *stream);
 /* ---- bf16-MFMA matmul mode of the train step (csrc/train_bf16.hip): the reference's optional `bf16_activations`
  * (train_ilql_gpt2.py:193; model dtype bf16, fp32 parameters).  Operands are staged as K-major bf16 matrices for lmrl_gemm_bf16.
  * lmrl_cast_bf16: dst [rows_dst][ld_dst] bf16 := round-to-nearest-even of src [rows][cols] fp32 (transpose = 0) or of its transpose

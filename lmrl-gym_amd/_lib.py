@@ -100,8 +100,8 @@ _SIGS = {
     "lmrl_flash_attn_lse_bytes": (c_size_t, [c_int, c_int, c_int]),
     "lmrl_flash_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_flash_attn_fwd_staged": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p]),
-    "lmrl_flash_attn_bwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_void_p]),
-    "lmrl_flash_attn_bwd_staged": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "lmrl_flash_attn_bwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lmrl_flash_attn_bwd_staged": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_adamw_segments": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "lmrl_layernorm_fwd_staged": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_int, c_float, c_void_p]),
     "lmrl_gelu_fwd_staged": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]),

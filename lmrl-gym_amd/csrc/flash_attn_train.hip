@@ -435,12 +435,14 @@ static int flash_fwd(const float *qkv, const uint8_t *km, float *att, float *lse
 
 template <class E>
 static int flash_bwd(const float *qkv, const uint8_t *km, const float *att, const float *datt, const float *lse, float *dqkv, uint16_t *dqb,
-                     long ldb, void *ws, int batch, int heads, int t, hipStream_t s) {
+                     long ldb, void *ws, int batch, int heads, int t, hipStream_t s, int qkv_staged) {
     typedef typename E::T T;
     const int tp = (t + 63) / 64 * 64, bh = batch * heads, d = heads * 64;
     FlashWs w; w.carve(ws, bh, tp, E::SZ);
-    int rc = flash_stage_qkv<E>(qkv, w, batch, heads, t, tp, s);
-    if (rc) return rc;
+    if (!qkv_staged) {       // qkv_staged: ws still holds the six q / k / v matrices the forward of these same qkv staged
+        int rc = flash_stage_qkv<E>(qkv, w, batch, heads, t, tp, s);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(flash_stage_kernel<E>, dim3(tp / 64, bh), dim3(256), 0, s, datt, (long)d, 0, 1.f, (T *)w.dOn, (T *)w.dOT, att, w.D, heads, t, tp);
     LMRL_CHECK_LAUNCH();
     const size_t lds_q = 3 * E::TILE + 64, lds_kv = 4 * E::TILE + 512;
@@ -481,17 +483,18 @@ int lmrl_flash_attn_fwd_staged(const float *qkv_d, const uint8_t *key_mask_d, fl
 }
 
 int lmrl_flash_attn_bwd(const float *qkv_d, const uint8_t *key_mask_d, const float *att_d, const float *datt_d, const float *lse_d, float *dqkv_d,
-                        void *ws_d, int batch, int heads, int t, int bf16, void *stream) {
+                        void *ws_d, int batch, int heads, int t, int bf16, int qkv_staged, void *stream) {
     LMRL_REQUIRE(qkv_d && att_d && datt_d && lse_d && dqkv_d && ws_d && batch > 0 && heads > 0 && t > 0, "lmrl_flash_attn_bwd: bad argument");
-    return bf16 ? flash_bwd<ElemBF16>(qkv_d, key_mask_d, att_d, datt_d, lse_d, dqkv_d, nullptr, 0, ws_d, batch, heads, t, as_stream(stream))
-                : flash_bwd<ElemF32>(qkv_d, key_mask_d, att_d, datt_d, lse_d, dqkv_d, nullptr, 0, ws_d, batch, heads, t, as_stream(stream));
+    return bf16 ? flash_bwd<ElemBF16>(qkv_d, key_mask_d, att_d, datt_d, lse_d, dqkv_d, nullptr, 0, ws_d, batch, heads, t, as_stream(stream), qkv_staged)
+                : flash_bwd<ElemF32>(qkv_d, key_mask_d, att_d, datt_d, lse_d, dqkv_d, nullptr, 0, ws_d, batch, heads, t, as_stream(stream), qkv_staged);
 }
 
 int lmrl_flash_attn_bwd_staged(const float *qkv_d, const uint8_t *key_mask_d, const float *att_d, const float *datt_d, const float *lse_d,
-                               void *dqkv_bf16_d, long ldb, void *ws_d, int batch, int heads, int t, void *stream) {
+                               void *dqkv_bf16_d, long ldb, void *ws_d, int batch, int heads, int t, int qkv_staged, void *stream) {
     LMRL_REQUIRE(qkv_d && att_d && datt_d && lse_d && dqkv_bf16_d && ws_d && ldb >= 3 * heads * 64 && ldb % 4 == 0 && batch > 0 && heads > 0 && t > 0,
                  "lmrl_flash_attn_bwd_staged: bad argument");
-    return flash_bwd<ElemBF16>(qkv_d, key_mask_d, att_d, datt_d, lse_d, nullptr, (uint16_t *)dqkv_bf16_d, ldb, ws_d, batch, heads, t, as_stream(stream));
+    return flash_bwd<ElemBF16>(qkv_d, key_mask_d, att_d, datt_d, lse_d, nullptr, (uint16_t *)dqkv_bf16_d, ldb, ws_d, batch, heads, t, as_stream(stream),
+                               qkv_staged);
 }
 
 }  // extern "C"

@@ -133,11 +133,13 @@ class GPT2F32:
         if flash:
             P = None
             c["lse"] = new(lse_n)
+            # a workspace per block and per forward call: the q / k / v matrices staged here are the ones the block's backward sweeps
+            fws = c["flash_ws"] = t.empty_like(self._flash_ws[0])
             if stage:
                 attb, ldb = mm.stash(R, d)
-                ops.flash_attn_fwd_staged(qkv, km, att, c["lse"], self._flash_ws[0], attb, ldb, B, H, T, True)
+                ops.flash_attn_fwd_staged(qkv, km, att, c["lse"], fws, attb, ldb, B, H, T, True)
             else:
-                ops.flash_attn_fwd(qkv, km, att, c["lse"], self._flash_ws[0], B, H, T, self.mm is not None)
+                ops.flash_attn_fwd(qkv, km, att, c["lse"], fws, B, H, T, self.mm is not None)
         else:
             P = new(B * H, T, T)
             # S = scale * Q K^T per (b, h); Q/K/V are column slices of qkv (row stride 3d)
@@ -325,10 +327,10 @@ class GPT2F32:
             qkv, P = c["qkv"], c["P"]
             dqkv, dqkvb = None, None
             if cache["flash"] and mm is not None:
-                dqkvb = ops.flash_attn_bwd_staged(mm, qkv, cache["km"], c["att"], datt, c["lse"], self._flash_ws[0], B, H, T)
+                dqkvb = ops.flash_attn_bwd_staged(mm, qkv, cache["km"], c["att"], datt, c["lse"], c["flash_ws"], B, H, T, qkv_staged=True)
             elif cache["flash"]:
                 dqkv = new(R, 3 * d)
-                ops.flash_attn_bwd(qkv, cache["km"], c["att"], datt, c["lse"], dqkv, self._flash_ws[0], B, H, T, False)
+                ops.flash_attn_bwd(qkv, cache["km"], c["att"], datt, c["lse"], dqkv, c["flash_ws"], B, H, T, False, qkv_staged=True)
             else:
                 dqkv = new(R, 3 * d)
                 self._attention_bwd_materialized(qkv, P, datt, dqkv, B, T, H, hd, d, scale, new)

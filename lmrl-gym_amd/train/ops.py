@@ -323,14 +323,16 @@ def flash_attn_fwd_staged(qkv, key_mask, att, lse, ws, att_b, ldb, batch, heads,
                                                batch, heads, t, int(bf16), _sp()), "lmrl_flash_attn_fwd_staged")
 
 
-def flash_attn_bwd(qkv, key_mask, att, datt, lse, dqkv, ws, batch, heads, t, bf16):
+def flash_attn_bwd(qkv, key_mask, att, datt, lse, dqkv, ws, batch, heads, t, bf16, qkv_staged=False):
+    """qkv_staged: `ws` is the workspace the forward of these same qkv ran in and nothing has used it since — its staged q / k / v
+    matrices are reused instead of staged again."""
     _lib.check(_L().lmrl_flash_attn_bwd(qkv.data_ptr(), _lib.ptr(key_mask), att.data_ptr(), datt.data_ptr(), lse.data_ptr(), dqkv.data_ptr(),
-                                        ws.data_ptr(), batch, heads, t, int(bf16), _sp()), "lmrl_flash_attn_bwd")
+                                        ws.data_ptr(), batch, heads, t, int(bf16), int(qkv_staged), _sp()), "lmrl_flash_attn_bwd")
 
 
-def flash_attn_bwd_staged(mm, qkv, key_mask, att, datt, lse, ws, batch, heads, t):
+def flash_attn_bwd_staged(mm, qkv, key_mask, att, datt, lse, ws, batch, heads, t, qkv_staged=False):
     """bf16 kernels; d(qkv) written only as the bf16 dy operand of the c_attn `linear_bwd(dyb=...)`"""
     dst, ldb = mm.stage_dy(batch * t, 3 * heads * 64)
     _lib.check(_L().lmrl_flash_attn_bwd_staged(qkv.data_ptr(), _lib.ptr(key_mask), att.data_ptr(), datt.data_ptr(), lse.data_ptr(), dst.data_ptr(), ldb,
-                                               ws.data_ptr(), batch, heads, t, _sp()), "lmrl_flash_attn_bwd_staged")
+                                               ws.data_ptr(), batch, heads, t, int(qkv_staged), _sp()), "lmrl_flash_attn_bwd_staged")
     return dst

@@ -50,7 +50,10 @@ def test_flash_attention_fwd_bwd(B, T, H, pad, bf16):
     lse = torch.empty(lse_n, device=dev)
     ops.flash_attn_fwd(qkv, km, att, lse, ws, B, H, T, bf16)
     dqkv = torch.full((B * T, 3 * d), 7.0, device=dev)
-    ops.flash_attn_bwd(qkv, km, att, datt, lse, dqkv, ws, B, H, T, bf16)
+    ops.flash_attn_bwd(qkv, km, att, datt, lse, dqkv, ws, B, H, T, bf16, qkv_staged=True)     # the forward's staged q / k / v are still in ws
+    dqkv2 = torch.full((B * T, 3 * d), 7.0, device=dev)
+    ops.flash_attn_bwd(qkv, km, att, datt, lse, dqkv2, ws, B, H, T, bf16)                       # staged again: same bits
+    assert torch.equal(dqkv, dqkv2)
     o_ref, g_ref = _ref(qkv, km, datt, B, T, H)
     tol = 2.5e-2 if bf16 else 2e-5
     err_o = float((att.double().cpu() - o_ref).abs().max()) / float(o_ref.abs().max())
@@ -63,7 +66,7 @@ def test_flash_attention_fwd_bwd(B, T, H, pad, bf16):
         assert float(att.view(B, T, d)[0, :23].abs().max()) == 0.0
     if bf16:     # the staged form: d(qkv) written as the bf16 operand of the c_attn backward products == the rounded fp32 output
         mm = ops.MatmulBF16(dev)
-        dst = ops.flash_attn_bwd_staged(mm, qkv, km, att, datt, lse, ws, B, H, T)
+        dst = ops.flash_attn_bwd_staged(mm, qkv, km, att, datt, lse, ws, B, H, T, qkv_staged=True)
         ldb = ops._pitch(3 * d)
         assert torch.equal(dst[: B * T * ldb].view(B * T, ldb)[:, : 3 * d], dqkv.to(torch.bfloat16))
 
