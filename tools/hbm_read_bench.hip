@@ -61,6 +61,27 @@ int main() {
             printf("%-52s U=%d  %7.2f us  %6.0f GB/s\n", c.name, U, ms * 1e3 / iters, bytes / (ms * 1e-3 / iters) / 1e9);
         }
     }
+    // the same KV-shaped read when the bytes were touched just before (same buffer every launch: served by the 256 MB memory-side cache)
+    // and when 1 / 2 other layers' worth of bytes (402 / 804 MB) went through in between
+    for (int gap : {0, 1, 2}) {
+        auto launch = [&](int L) {
+            hipLaunchKernelGGL(read_kernel<4>, dim3(2048), dim3(256), 0, st, buf + layer_bytes * L, (size_t)128 * 1536, T * 1536, sink);
+        };
+        const int iters = 64;
+        float tot = 0.f;
+        for (int it = 0; it < iters + 4; it++) {
+            for (int g2 = 1; g2 <= gap; g2++)          // evict: stream other layers' bytes (whole 402 MB blocks)
+                hipLaunchKernelGGL(read_kernel<8>, dim3(4096), dim3(256), 0, st, buf + layer_bytes * g2, layer_bytes / 4096, (int)(layer_bytes / 4096), sink);
+            launch(0);                                  // "prefetch"
+            CK(hipEventRecord(e0, st));
+            launch(0);                                  // the read that would be the attention sweep
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (it >= 4) tot += ms;
+        }
+        printf("KV shape re-read right after a touch, %d x 402 MB streamed before      %7.2f us  %6.0f GB/s\n", gap, tot * 1e3 / iters,
+               (double)2048 * T * 1536 / (tot * 1e-3 / iters) / 1e9);
+    }
     // one large contiguous read for reference: 1.6 GB
     {
         const size_t big = layer_bytes * 4;
