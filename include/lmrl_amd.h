@@ -286,6 +286,13 @@ int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *
 int lmrl_gemm_bf16_ld(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc, int n_store,
                       int epilogue, void *stream);
 
+/* Split-K form for products with few output tiles and a long K (the train step's weight-gradient products dW = x^T . dy: K = B*T):
+ * S copies of the 128 x 128 tile grid each accumulate a slice of K into fp32 partials in ws_d, a fixed-order reduce then writes
+ * c (=|+=) their sum — deterministic.  lmrl_gemm_bf16_splitk_ws_bytes returns 0 when the shape is better served by lmrl_gemm_bf16_ld. */
+size_t lmrl_gemm_bf16_splitk_ws_bytes(int m, int n, int k);
+int lmrl_gemm_bf16_splitk(const void *a_d, const void *w_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc, int n_store, int accumulate,
+                          void *ws_d, void *stream);
+
 /* TOOLS ONLY (tools/bench_gemm.py tile-configuration sweeps; never called by the package): forces a GEMM tile configuration,
  * 0 = the shape policy, 1 = the round-1 register-staged kernels, 10.. = fixed tiles. */
 void lmrl_gemm_set_variant(int v);

@@ -216,7 +216,11 @@ __device__ __forceinline__ void g8_mainloop_pair(const uint16_t *__restrict__ A,
 #undef LMRL_G8_READ
 #undef LMRL_G8_MFMA
 
-template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0, bool PAIR = false>
+// SPLITK (fp32-output epilogue only; the weight-gradient products of the train step: K = B*T = 16 k .. 32 k against an output of a few dozen
+// tiles): the grid holds kv_tmax = S copies of the tile grid; copy z accumulates K-steps [z * kv_d, min(K, (z + 1) * kv_d)) and stores its
+// partial tile to C + z * M * ldc (splitk_reduce_kernel adds the copies in a fixed order).  The two ints alias the kv_* fields, which only
+// EPI_BF16_LN_KV reads: no other instantiation's argument block changes.
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0, bool PAIR = false, bool SPLITK = false>
 __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap xm) {
     static_assert(!PAIR || STAGES == 4, "the paired K loop runs on a 4-slot ring");
     constexpr int NW = WM * WN, NT = NW * 64;
@@ -227,7 +231,17 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
     int tile_m, tile_n;
-    if (!xcd_tile(xm, blockIdx.x, tile_m, tile_n)) return;   // workgroup-uniform
+    int wg_id = blockIdx.x;
+    if constexpr (SPLITK) {
+        static_assert(EPI == EPI_F32, "split-K partials are plain fp32 tiles");
+        const int per = gridDim.x / g.kv_tmax, z = wg_id / per;      // per is a multiple of 8: id % 8 (the XCD) is unchanged
+        wg_id -= z * per;
+        const int k0 = z * g.kv_d;
+        g.A += k0; g.W += k0;
+        g.K = min(g.kv_d, g.K - k0);
+        g.C = reinterpret_cast<float *>(g.C) + (size_t)z * g.M * g.ldc;
+    }
+    if (!xcd_tile(xm, wg_id, tile_m, tile_n)) return;   // workgroup-uniform
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int Mr = g.m_dev ? *g.m_dev : g.M;
     if (m0 >= Mr) return;
@@ -456,6 +470,25 @@ inline hipError_t gemm8_launch(const GemmArgs &g, hipStream_t s) {
         ProfScope ps(PROF_GEMM_128x128, s, 2.0 * (double)g.M * (double)g.N * (double)g.K);
         hipLaunchKernelGGL((gemm8_kernel<BM, BN, WM, WN, STAGES, EPI, NQ, PAIR>), dim3(tiles), dim3(WM * WN * 64), shmem, s, g, xm);
     }
+    return hipGetLastError();
+}
+
+// Split-K launch of the fp32-output kernel: S copies of the tile grid, partials to ws [S][M][ldc = N] (see gemm8_kernel<.., SPLITK>).
+template <int BM, int BN, int WM, int WN, int STAGES>
+inline hipError_t gemm8_launch_splitk(GemmArgs g, float *ws, int S, int kchunk, hipStream_t s) {
+    constexpr size_t shmem = (size_t)STAGES * (BM + BN) * 128;
+    const XcdMap xm = make_xcd_map((g.M + BM - 1) / BM, g.N / BN, 2.0 * g.M * g.K / S, 2.0 * g.N * g.K / S);
+    const int tiles = xcd_grid(xm);
+    g.C = ws; g.ldc = g.N; g.n_store = g.N; g.bias = nullptr; g.m_dev = nullptr;
+    g.kv_tmax = S; g.kv_d = kchunk;
+    static bool attr_set = false;
+    if (!attr_set && shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8_kernel<BM, BN, WM, WN, STAGES, EPI_F32, 0, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm8_kernel<BM, BN, WM, WN, STAGES, EPI_F32, 0, false, true>), dim3(tiles * S), dim3(WM * WN * 64), shmem, s, g, xm);
     return hipGetLastError();
 }
 

@@ -874,6 +874,41 @@ __global__ void attn_bytes_kernel(const int32_t *cnt, const int32_t *len, int B,
     if (threadIdx.x == 0) atomicAdd(counter, (red[0] + red[1] + red[2] + red[3]) * (unsigned long long)heads_x_layers);
 }
 
+// c[m][n] (=|+=) sum_z ws[z][m][n] for n < n_store, z in order (deterministic); ws rows have pitch ldw
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int S, long zstride, int ldw, float *c, int ldc, int M,
+                                                            int n_store, int accumulate) {
+    const int n4 = (n_store + 3) / 4;
+    const long total = (long)M * n4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+        const float *p = ws + (long)m * ldw + n;
+        f32x4 a = *reinterpret_cast<const f32x4 *>(p);
+        for (int z = 1; z < S; z++) a += *reinterpret_cast<const f32x4 *>(p + z * zstride);
+        float *o = c + (long)m * ldc + n;
+        if (n + 4 <= n_store && (ldc & 3) == 0) {
+            if (accumulate) a += *reinterpret_cast<const f32x4 *>(o);
+            *reinterpret_cast<f32x4 *>(o) = a;
+        } else {
+            for (int k = 0; k < 4 && n + k < n_store; k++) o[k] = accumulate ? o[k] + a[k] : a[k];
+        }
+    }
+}
+
+// Split-K plan for C[m][n] = A[m][k] . W[n][k]^T with few output tiles and a long K (the dW products): S copies of the 128 x 128 tile grid
+// so that ~2 workgroups per CU are busy; 0 = not worth splitting.
+static int splitk_plan(int m, int n, int k, int *kchunk) {
+    if (k < 4096 || n % 128 != 0 || k % 64 != 0) return 0;
+    const long tiles = (long)((m + 127) / 128) * (n / 128);
+    if (tiles > 200) return 0;
+    const int ksteps = k / 64;
+    int S = (int)(512 / tiles);
+    S = std::min(S, ksteps / 16);                 // >= 16 K-steps per copy: the ring prologue / epilogue stay a small part of a copy's life
+    if (S < 2) return 0;
+    const int per = (ksteps + S - 1) / S;
+    *kchunk = per * 64;
+    return (ksteps + per - 1) / per;
+}
+
 int g_gemm_variant = 0;   // tools/ only (tools/bench_gemm.py tile-configuration sweeps): never touched by the product path
 constexpr int kRaggedAutoMinSlots = 2048;   // default policy: forwards with >= this many slots run on the compacted (sum of cnt) rows
 
@@ -1155,6 +1190,29 @@ int lmrl_gpt2_kv_gather(const lmrl_gpt2 *m, const void *src_kv_d, int src_b, int
     hipLaunchKernelGGL(kv_gather_kernel, dim3(b, 2 * m->cfg.n_layer), dim3(256), 0, as_stream(stream), (const uint16_t *)src_kv_d, src_b, src_tmax,
                        src_len_d, idx_d, (uint16_t *)dst_kv_d, dst_tmax, b, m->cfg.d_model, (const uint16_t *)src_hidden_d, (uint16_t *)dst_hidden_d,
                        dst_len_d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+size_t lmrl_gemm_bf16_splitk_ws_bytes(int m, int n, int k) {
+    int kchunk = 0;
+    const int S = lmrl::splitk_plan(m, n, k, &kchunk);
+    return S ? (size_t)S * m * n * sizeof(float) : 0;
+}
+
+int lmrl_gemm_bf16_splitk(const void *a_d, const void *w_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc, int n_store, int accumulate,
+                          void *ws_d, void *stream) {
+    LMRL_REQUIRE(a_d && w_d && c_d && ws_d && m > 0 && n > 0 && k > 0 && n_store > 0 && n_store <= n, "lmrl_gemm_bf16_splitk: bad argument");
+    int kchunk = 0;
+    const int S = lmrl::splitk_plan(m, n, k, &kchunk);
+    LMRL_REQUIRE(S >= 2, "lmrl_gemm_bf16_splitk: no split-K plan for this shape (lmrl_gemm_bf16_splitk_ws_bytes returned 0)");
+    hipStream_t s = as_stream(stream);
+    GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, nullptr, ws_d, m, n, k, lda, n, n};
+    g.ldw = ldw;
+    LMRL_CHECK_HIP((gemm8_launch_splitk<128, 128, 2, 4, 2>(g, (float *)ws_d, S, kchunk, s)));
+    const long total = (long)m * ((n_store + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, (const float *)ws_d, S,
+                       (long)m * n, n, (float *)c_d, ldc, m, n_store, accumulate);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

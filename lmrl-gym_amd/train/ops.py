@@ -126,6 +126,13 @@ class MatmulBF16:
         """c[m][n_store] (=|+=) a[m][k] . w[n][k]^T + bias, fp32 out (lmrl_gemm_bf16 epilogues 3 / 2); a, w staged by `cast`
         (row pitch _pitch(k))."""
         ld = _pitch(k)
+        if bias is None:       # few output tiles, long K (the dW products): split-K over ~2 workgroups per CU + a fixed-order reduce
+            nws = _L().lmrl_gemm_bf16_splitk_ws_bytes(m, n, _pad(k))
+            if nws:
+                ws = self._buf("splitk_ws", nws // 2)
+                _lib.check(_L().lmrl_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, _pad(k), ld, ld, ldc, n_store, int(accumulate),
+                                                      ws.data_ptr(), _sp()), "lmrl_gemm_bf16_splitk")
+                return
         _lib.check(_L().lmrl_gemm_bf16_ld(a.data_ptr(), w.data_ptr(), _lib.ptr(bias), c.data_ptr(), m, n, _pad(k), ld, ld, ldc, n_store,
                                           2 if accumulate else 3, _sp()), "lmrl_gemm_bf16")
 

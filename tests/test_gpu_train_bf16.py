@@ -87,6 +87,33 @@ def test_producer_staged_dlogits(dev, rows, V, ld):
     np.testing.assert_allclose((db - 0.5).cpu().numpy(), got[:rows, :V].float().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("m,n,n_store,k", [(768, 768, 768, 16384), (768, 2304, 2304, 4096), (256, 256, 211, 8192), (3072, 768, 768, 16384)])
+def test_splitk_gemm_matches_single_pass(dev, m, n, n_store, k):
+    """The split-K form used for the weight-gradient products (few output tiles, K = B*T): == float64 of the bf16 operands to fp32
+    accumulation accuracy, the accumulate flag, a ragged n_store, run-to-run bit-identity (fixed-order reduce, no atomics); shapes with
+    enough tiles report no plan."""
+    from lmrl_gym_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(m + n + k)
+    a = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    w = (torch.randn(n, k, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    nws = L.lmrl_gemm_bf16_splitk_ws_bytes(m, n, k)
+    assert nws > 0 and L.lmrl_gemm_bf16_splitk_ws_bytes(16384, 768, 768) == 0 and L.lmrl_gemm_bf16_splitk_ws_bytes(1536, 50432, 16384) == 0
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    ref = a.double() @ w.double().t()
+    outs = []
+    for rep in range(2):
+        c = torch.full((m, n_store), 2.0, device=dev)
+        _lib.check(L.lmrl_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, k, k, n_store, n_store, 1, ws.data_ptr(), _lib.stream_ptr()))
+        outs.append(c.clone())
+    assert torch.equal(outs[0], outs[1])
+    err = (outs[0].double() - 2.0 - ref[:, :n_store]).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item() + 1e-4, err
+    c = torch.full((m, n_store), 9.0, device=dev)
+    _lib.check(L.lmrl_gemm_bf16_splitk(a.data_ptr(), w.data_ptr(), c.data_ptr(), m, n, k, k, k, n_store, n_store, 0, ws.data_ptr(), _lib.stream_ptr()))
+    assert (c.double() - ref[:, :n_store]).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-4
+
+
 def test_linear_bf16_against_bf16_rounded_operands(dev):
     """y, dx, dw of one linear layer in bf16 mode == float64 products of the bf16-ROUNDED operands (the only error left is the fp32
     accumulation order): covers the padded-vocabulary output stride and the transposed-dw path for n % 4 != 0."""
