@@ -167,10 +167,14 @@ def main_train_step(args):
         rewards = np.where(sta & ~np.roll(sta, -1, axis=1), -1.0, 0.0).astype(np.float32)
         dones = (rng.rand(B) < 0.5).astype(np.float32)
         step = lambda: tr.step(ids, sta, rewards, dones)
-        # q1, q2 forward + backward (3x each); the two target heads: dense1 forward + ONE column of dense2 per token (Q_target(s, a) only)
-        head_flops = 2 * (d * d + d * V) * tok * (3 * 2) + 2 * (d * d + d) * tok * 2
-        flops = (6 + 2) * n_params * tok + head_flops + 12 * 6 * 2 * T * d * tok
-        workload = f"configs[2] / M3: ILQL train step, GPT-2-small fp32, B={B} x T={T} per GPU (train_ilql_gpt2.py:55-110), target base + 2 Q heads + V head"
+        # q1, q2 forward + backward (3x each) on the rows the loss reads (should_take_action x attention mask: GPT2ILQLTrain.compact_q_rows — the
+        # flops actually executed, not the dense B*T count); the two target heads: dense1 forward + ONE column of dense2 per token
+        q_tok = int(sta.sum())          # no padding in the synthetic batch: attention_mask = 1
+        head_flops = 2 * (d * d + d * V) * q_tok * (3 * 2) + 2 * (d * d + d) * tok * 2
+        # matmul parameters of the transformer blocks only: the embedding tables do no flops and ILQL never forms LM logits
+        n_mm = n_params - V * d - cfg.n_pos * d
+        flops = (6 + 2) * n_mm * tok + head_flops + 12 * 6 * 2 * T * d * tok
+        workload = f"configs[2] / M3: ILQL train step, GPT-2-small fp32, B={B} x T={T} per GPU (train_ilql_gpt2.py:55-110), target base + 2 Q heads + V head; should_take_action on {100.0 * q_tok / tok:.0f} % of the tokens"
     else:
         mmode = args.train_matmul
         pol = GPT2F32(sd, cfg.n_head, device=dev, matmul=mmode)
@@ -179,8 +183,12 @@ def main_train_step(args):
         f = lambda s_: (rng.randn(B, T - 1) * s_).astype(np.float32)
         olp, ov, oa, orr = f(0.1) - 10.8, f(1), f(1), f(1)
         step = lambda: tr.step(ids, sta, olp, ov, oa, orr)
-        flops = 6 * n_params * tok + 12 * 6 * 2 * T * d * tok
-        workload = f"M4: PPO train step, GPT-2-small fp32, B={B} x T={T} per GPU (train_ppo_gpt2.py:60-112), LinearHead value function"
+        # the tied LM head (V x d of the 124.4 M parameters) runs on the rows the loss reads only (GPT2PPOTrain.compact_rows): executed flops
+        q_tok = int(sta.sum())
+        n_mm = n_params - V * d - cfg.n_pos * d          # transformer-block matmul parameters (embedding lookups do no flops)
+        flops = 6 * n_mm * tok + 6 * V * d * q_tok + 12 * 6 * 2 * T * d * tok
+        workload = (f"M4: PPO train step, GPT-2-small fp32, B={B} x T={T} per GPU (train_ppo_gpt2.py:60-112), LinearHead value function; "
+                    f"should_take_action on {100.0 * q_tok / tok:.0f} % of the tokens")
 
     def barrier():
         if use_dist:

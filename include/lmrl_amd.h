@@ -466,6 +466,11 @@ int lmrl_sgemm(int trans_a, int trans_b, int m, int n, int k, float alpha, const
 void lmrl_sgemm_set_variant(int v);
 int lmrl_embed_fwd(const float *wte_d, const float *wpe_d, const int32_t *ids_d, const int32_t *pos_d, float *x_d, int rows, int d, void *stream);
 int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d, float *dwte_d, float *dwpe_d, int rows, int d, void *stream);
+/* Row compaction for the vocabulary-wide heads of the train steps: the losses read the Q / policy logits only on rows whose mask is set
+ * (should_take_action x attention mask: ilql/base_interface.py:22-119, ppo/base_interface.py:72-142), so a head runs on the gathered rows
+ * dst[i] = src[idx[i]] and its input gradient goes back with dst[idx[i]] (=|+=) src[i].  idx_d holds DISTINCT rows (no atomics). */
+int lmrl_gather_rows_f32(const float *src_d, const int32_t *idx_d, float *dst_d, int n, int d, void *stream);
+int lmrl_scatter_rows_f32(const float *src_d, const int32_t *idx_d, float *dst_d, int n, int d, int accumulate, void *stream);
 int lmrl_layernorm_fwd(const float *x_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, int rows, int d,
                        float eps, void *stream);
 /* LayerNorm / gelu forward that ALSO write the bf16 copy of their output (row pitch ldb elements) — the operand of the GEMM that consumes it in

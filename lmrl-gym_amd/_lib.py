@@ -115,6 +115,8 @@ _SIGS = {
     "lmrl_layernorm_bwd_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                          c_int, c_void_p, c_void_p, ctypes.c_long, c_void_p]),
     "lmrl_gelu_bwd_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, ctypes.c_long, c_int, c_void_p]),
+    "lmrl_gather_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "lmrl_scatter_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lmrl_colsum_ws_bytes": (c_size_t, [c_int]),
     "lmrl_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "lmrl_gelu_fwd": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

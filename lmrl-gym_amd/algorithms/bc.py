@@ -9,7 +9,7 @@ import numpy as np
 from .. import dist as D
 from ..train import ops
 from ..train.gpt2_f32 import AdamW, GPT2F32
-from .common import BlockingStrategy, Padding, Truncation, block_sequences, initialize_attn_mask_pos_ids
+from .common import BlockingStrategy, Padding, Truncation, block_sequences, initialize_attn_mask_pos_ids, masked_rows
 from .ppo import _t
 
 
@@ -39,7 +39,7 @@ def bc_weights(attention_mask: np.ndarray, is_action: np.ndarray, non_action_wei
 
 
 def masked_ce_forward_backward(m: GPT2F32, ids: np.ndarray, am: np.ndarray, pos: np.ndarray, w: np.ndarray, denom: float,
-                               grads=None, grad_scale: float = 1.0) -> float:
+                               grads=None, grad_scale: float = 1.0, compact_rows: bool = True) -> float:
     """loss = sum(w * CE(logits[:, :-1], ids[:, 1:])) / denom with the masked sums all-reduced across ranks; when `grads`
     is given, grad_scale * d loss / d params is ACCUMULATED into it (shared by the BC trainer and the PPO BC term)."""
     import torch
@@ -47,28 +47,47 @@ def masked_ce_forward_backward(m: GPT2F32, ids: np.ndarray, am: np.ndarray, pos:
     R, dev = B * T, m.dev
     ids_d = _t(ids, np.int32)
     hid, cache = m.forward(ids_d, _t(am, np.uint8), _t(pos, np.int32))
-    logits = m.lm_logits(hid, R)
-    tgt = torch.zeros(R, dtype=torch.int32, device=dev)
-    tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
-    lp, lse = torch.empty(R, dtype=torch.float32, device=dev), torch.empty(R, dtype=torch.float32, device=dev)
-    ops.lse_gather(logits, m.ld_vocab, m.vocab, tgt, R, logprob=lp, lse=lse)
     if D.is_distributed():
         denom = float(D.allreduce_sum_(torch.tensor([denom], dtype=torch.float64, device=dev)).item())
-    wfull = np.zeros((B, T), dtype=np.float32)
-    wfull[:, :-1] = np.asarray(w, dtype=np.float32) / np.float32(denom)
-    coef = _t(wfull.reshape(-1), np.float32)
+    wn = np.asarray(w, dtype=np.float32) / np.float32(denom)                     # [B, T-1] CE weights
+    # the LM head runs on the rows with a non-zero weight only (with non_action_weight = 0: the action tokens) — rows of weight 0
+    # contribute exact zeros to the loss and to every gradient
+    rows_h = masked_rows(wn != 0, T)
+    Ra = int(rows_h.size)
+    compact = compact_rows and 0 < Ra < R
+    if compact:
+        idx = _t(rows_h, np.int32)
+        hq, Rq = ops.gather_rows(hid, idx, Ra, m.d), Ra
+        tgt = _t(ids[:, 1:][wn != 0].astype(np.int32), np.int32)
+        coef = _t(wn[wn != 0].astype(np.float32), np.float32)
+    else:
+        hq, Rq = hid, R
+        tgt = torch.zeros(R, dtype=torch.int32, device=dev)
+        tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
+        wfull = np.zeros((B, T), dtype=np.float32)
+        wfull[:, :-1] = wn
+        coef = _t(wfull.reshape(-1), np.float32)
+    logits = m.lm_logits(hq, Rq)
+    lp, lse = torch.empty(Rq, dtype=torch.float32, device=dev), torch.empty(Rq, dtype=torch.float32, device=dev)
+    ops.lse_gather(logits, m.ld_vocab, m.vocab, tgt, Rq, logprob=lp, lse=lse)
     # loss = sum(coef * CE) = -sum(coef * logprob): a dot product done as a 1 x 1 x R GEMM on the matrix core
     out = torch.zeros(1, dtype=torch.float32, device=dev)
-    ops.sgemm(coef, lp, out, 1, 1, R, alpha=-1.0, lda=R, ldb=1, ldc=1)
+    ops.sgemm(coef, lp, out, 1, 1, Rq, alpha=-1.0, lda=Rq, ldb=1, ldc=1)
     if D.is_distributed():
         D.allreduce_sum_(out)
     loss = float(out.item())
     if grads is not None:
         if grad_scale != 1.0:
             ops.axpby(grad_scale, coef, 0.0, None, coef)
-        dlogits, dlb = m.ce_bwd(logits, lse, tgt, coef, None, R)
-        d_hidden = torch.empty(R, m.d, dtype=torch.float32, device=dev)
-        m.lm_head_backward(hid, dlogits, R, d_hidden, grads, accumulate_dh=False, dlb=dlb)
+        dlogits, dlb = m.ce_bwd(logits, lse, tgt, coef, None, Rq)
+        if compact:
+            dhq = torch.empty(Ra, m.d, dtype=torch.float32, device=dev)
+            m.lm_head_backward(hq, dlogits, Ra, dhq, grads, accumulate_dh=False, dlb=dlb)
+            d_hidden = torch.zeros(R, m.d, dtype=torch.float32, device=dev)
+            ops.scatter_rows(dhq, idx, d_hidden, Ra, m.d, False)
+        else:
+            d_hidden = torch.empty(R, m.d, dtype=torch.float32, device=dev)
+            m.lm_head_backward(hid, dlogits, R, d_hidden, grads, accumulate_dh=False, dlb=dlb)
         m.backward(cache, d_hidden, grads)
     return loss
 

@@ -53,6 +53,16 @@ def initialize_attn_mask_pos_ids(input_ids: np.ndarray, pad_token_id: Optional[i
     return attention_mask, np.asarray(position_ids, dtype=np.int32)
 
 
+def masked_rows(mask_bt1: np.ndarray, T: int) -> np.ndarray:
+    """Flat row indices r = b*T + t (int32, increasing) of the set entries of a [B, T-1] mask on the shifted grid — the rows of the
+    [B*T, d] hidden-state matrix whose vocabulary-wide head outputs a masked loss actually reads (the train steps run those heads on the
+    gathered rows only: every term of ppo_loss_fn / ilql_loss / mc_loss / the BC loss carries such a mask)."""
+    m = np.asarray(mask_bt1, dtype=bool)
+    B, T1 = m.shape
+    assert T1 == T - 1
+    return (np.arange(B, dtype=np.int64)[:, None] * T + np.arange(T1, dtype=np.int64)[None, :])[m].astype(np.int32)
+
+
 def stats_from_sums(sum_w, sum_b, sumsq_b, mn, mx, count_b, n) -> Dict[str, np.float32]:
     """get_tensor_stats: mean = sum(x*mask)/n ; min/max/std over mask.astype(bool) (population std)."""
     f = np.float32

@@ -16,7 +16,7 @@ from .. import _lib
 from .. import dist as D
 from ..train import ops
 from ..train.gpt2_f32 import AdamW, GPT2F32, MLPHeadF32
-from .common import BlockingStrategy, Padding, Truncation, block_sequences, initialize_attn_mask_pos_ids, stats_from_sums
+from .common import BlockingStrategy, Padding, Truncation, block_sequences, initialize_attn_mask_pos_ids, stats_from_sums, masked_rows
 from .ppo import _t
 
 
@@ -161,11 +161,17 @@ def ilql_loss(q1, q2, v, v_final, target_q1, target_q2, q1_logits, q2_logits, to
 
 # ----------------------------------------------------------------------------- train step (ilql/gpt2/interface.py:88-367)
 class GPT2ILQLTrain:
+    compact_q_rows = True        # class default (GPT2ILQLInference.eval_loss builds a loss-only view without __init__)
+
     def __init__(self, base: GPT2F32, q1_head: MLPHeadF32, q2_head: MLPHeadF32, v_head: MLPHeadF32, pad_token_id: int,
                  loss_kwargs: Dict[str, float], target_base: Optional[GPT2F32] = None, lr: float = 3e-5, weight_decay: float = 0.0,
                  grad_accum_steps: int = 1, polyak_alpha: float = 0.005, hard_update_every: Optional[int] = None,
-                 detach_q1: bool = False, detach_q2: bool = False, detach_v: bool = False):
+                 detach_q1: bool = False, detach_q2: bool = False, detach_v: bool = False, compact_q_rows: bool = True):
+        """compact_q_rows: run the two Q heads (forward and backward: six [rows, d] x [d, V] products) only on the rows the loss reads —
+        `should_take_action x attention_mask[:, 1:]` masks every Q term of `ilql_loss` (ilql/base_interface.py:22-119) — instead of on all B*T
+        rows; same loss, logs and gradients (rows outside the mask contribute exact zeros), fewer flops in proportion to the mask density."""
         import torch
+        self.compact_q_rows = compact_q_rows
         self.base, self.q1, self.q2, self.v = base, q1_head, q2_head, v_head
         self.target_base = target_base
         dev = base.dev
@@ -211,8 +217,6 @@ class GPT2ILQLTrain:
         ids_d, pos_d, am_d = _t(ids, np.int32), _t(pos, np.int32), _t(am, np.uint8)
         hid, cache = base.forward(ids_d, am_d, pos_d)
         thid = self.target_base.forward(ids_d, am_d, pos_d)[0] if self.target_base is not None else hid
-        q1o, q1c = self.q1.forward(hid, R)
-        q2o, q2c = self.q2.forward(hid, R)
         vo, vc = self.v.forward(hid, R)
         tgt = torch.zeros(R, dtype=torch.int32, device=dev)
         tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
@@ -221,17 +225,41 @@ class GPT2ILQLTrain:
         tq2sa = self.q2_target.forward_at(thid, R, tgt)
         new = lambda: torch.empty(R, dtype=torch.float32, device=dev)
         sl = lambda x: x.view(B, T)[:, :-1].contiguous()
-        q1sa, lse1, lp1 = new(), new(), new()
-        q2sa, lse2, lp2 = new(), new(), new()
+        sta = np.asarray(should_take_action, dtype=bool)
+        # rows the Q terms of the loss read: should_take_action x attention_mask[:, 1:] (host-known).  The Q heads run on those rows only
+        # (gathered hidden states -> logits -> lse / gather; backward: dlogits -> head backward -> scatter-add into d_hidden)
+        q_mask = sta & (np.asarray(am)[:, 1:] != 0)
+        q_rows = masked_rows(q_mask, T)
+        Ra = int(q_rows.size)
+        compact = self.compact_q_rows and 0 < Ra < R
+        if compact:
+            idx = _t(q_rows, np.int32)
+            hq = ops.gather_rows(hid, idx, Ra, base.d)
+            tgt_q = _t(ids[:, 1:][q_mask].astype(np.int32), np.int32)
+            Rq = Ra
+        else:
+            idx, hq, tgt_q, Rq = None, hid, tgt, R
+        q1o, q1c = self.q1.forward(hq, Rq)
+        q2o, q2c = self.q2.forward(hq, Rq)
+        newq = lambda: torch.empty(Rq, dtype=torch.float32, device=dev)
+        q1sa_q, lse1, lp1 = newq(), newq(), newq()
+        q2sa_q, lse2, lp2 = newq(), newq(), newq()
         ld = self.q1.ld_out
-        ops.lse_gather(q1o, ld, V, tgt, R, logprob=lp1, lse=lse1, target_logit=q1sa)
-        ops.lse_gather(q2o, ld, V, tgt, R, logprob=lp2, lse=lse2, target_logit=q2sa)
-        ce1, ce2 = new(), new()
-        ops.axpby(-1.0, lp1, 0.0, None, ce1)
-        ops.axpby(-1.0, lp2, 0.0, None, ce2)
+        ops.lse_gather(q1o, ld, V, tgt_q, Rq, logprob=lp1, lse=lse1, target_logit=q1sa_q)
+        ops.lse_gather(q2o, ld, V, tgt_q, Rq, logprob=lp2, lse=lse2, target_logit=q2sa_q)
+        ce1_q, ce2_q = newq(), newq()
+        ops.axpby(-1.0, lp1, 0.0, None, ce1_q)
+        ops.axpby(-1.0, lp2, 0.0, None, ce2_q)
+        if compact:      # back to [R] vectors for the loss kernel (zeros off the mask: those entries are multiplied by a zero mask there)
+            def spread(vq):
+                full_v = torch.zeros(R, dtype=torch.float32, device=dev)
+                ops.scatter_rows(vq, idx, full_v, Ra, 1, False)
+                return full_v
+            q1sa, q2sa, ce1, ce2 = spread(q1sa_q), spread(q2sa_q), spread(ce1_q), spread(ce2_q)
+        else:
+            q1sa, q2sa, ce1, ce2 = q1sa_q, q2sa_q, ce1_q, ce2_q
         v_full = vo.view(B, T)
         # v_final (interface.py:253-273)
-        sta = np.asarray(should_take_action, dtype=bool)
         d = np.asarray(dones, dtype=np.float32)
         if next_token_ids is not None:
             nids = np.asarray(next_token_ids, dtype=np.int32)
@@ -259,16 +287,28 @@ class GPT2ILQLTrain:
         full = lambda g: (lambda z: (z.view(B, T)[:, :-1].copy_(g), z)[1])(torch.zeros(R, dtype=torch.float32, device=dev))
         coef_r, dq1_r, dq2_r, dv_r = full(coef), full(dq1), full(dq2), full(dv)
         # d loss / d q logits: in place (fp32) or straight into the bf16 operand of the head's backward products (bf16-matmul mode)
-        dq1o, dq1b = self.q1.ce_bwd(q1o, lse1, tgt, coef_r, dq1_r, R)
-        dq2o, dq2b = self.q2.ce_bwd(q2o, lse2, tgt, coef_r, dq2_r, R)
+        if compact:
+            coef_q, dq1_q, dq2_q = (ops.gather_rows(x.view(R, 1), idx, Ra, 1).view(Ra) for x in (coef_r, dq1_r, dq2_r))
+        else:
+            coef_q, dq1_q, dq2_q = coef_r, dq1_r, dq2_r
+        dq1o, dq1b = self.q1.ce_bwd(q1o, lse1, tgt_q, coef_q, dq1_q, Rq)
+        dq2o, dq2b = self.q2.ce_bwd(q2o, lse2, tgt_q, coef_q, dq2_q, Rq)
         bgrads, g1, g2, gv = base.zero_grads(), self.q1.zero_grads(), self.q2.zero_grads(), self.v.zero_grads()
         d_hidden = torch.empty(R, base.d, dtype=torch.float32, device=dev)
         # detach_q1 / detach_q2 / detach_v (interface.py:120-139: stop_gradient on the hidden states fed to that head): the head still trains,
         # its gradient does not reach the transformer
         scratch = torch.empty_like(d_hidden) if (self.detach_q1 or self.detach_q2 or self.detach_v) else None
         d_hidden.zero_()
-        self.q1.backward(q1c, dq1o, g1, dx=scratch if self.detach_q1 else d_hidden, accumulate_dx=not self.detach_q1, dyb=dq1b)
-        self.q2.backward(q2c, dq2o, g2, dx=scratch if self.detach_q2 else d_hidden, accumulate_dx=not self.detach_q2, dyb=dq2b)
+        if compact:
+            dhq = torch.zeros(Ra, base.d, dtype=torch.float32, device=dev)          # d loss / d (gathered hidden rows), both Q heads
+            scr_q = torch.empty_like(dhq) if (self.detach_q1 or self.detach_q2) else None
+            self.q1.backward(q1c, dq1o, g1, dx=scr_q if self.detach_q1 else dhq, accumulate_dx=not self.detach_q1, dyb=dq1b)
+            self.q2.backward(q2c, dq2o, g2, dx=scr_q if self.detach_q2 else dhq, accumulate_dx=not self.detach_q2, dyb=dq2b)
+            if not (self.detach_q1 and self.detach_q2):
+                ops.scatter_rows(dhq, idx, d_hidden, Ra, base.d, True)
+        else:
+            self.q1.backward(q1c, dq1o, g1, dx=scratch if self.detach_q1 else d_hidden, accumulate_dx=not self.detach_q1, dyb=dq1b)
+            self.q2.backward(q2c, dq2o, g2, dx=scratch if self.detach_q2 else d_hidden, accumulate_dx=not self.detach_q2, dyb=dq2b)
         self.v.backward(vc, dv_r.view(R, 1), gv, dx=scratch if self.detach_v else d_hidden, accumulate_dx=not self.detach_v)
         # data parallel: the head gradients (final already) and the base gradients are all-reduced while the base backward runs — arena
         # slices go to RCCL as blocks finish (dist.GradReducer); the one data-path collective of an ILQL step (~815 MB fp32, GPT-2-small)

@@ -123,6 +123,8 @@ class GPT2MCTrain:
         self.q_opt = AdamW(q_head.p, lr, weight_decay=weight_decay, every_k=grad_accum_steps, no_decay=lambda n: n.endswith("bias"))
         self.last_grads = None
 
+    compact_q_rows = True
+
     def step(self, input_ids, should_take_action, returns, prng_key=None, attention_mask=None, position_ids=None, train: bool = True):
         import torch
         from .. import dist as D
@@ -133,26 +135,54 @@ class GPT2MCTrain:
         R, base, dev, V = B * T, self.base, self.base.dev, self.q_head.dout
         ids_d = _t(ids, np.int32)
         hid, cache = base.forward(ids_d, _t(am, np.uint8), _t(pos, np.int32))
-        qo, qc = self.q_head.forward(hid, R)
-        tgt = torch.zeros(R, dtype=torch.int32, device=dev)
-        tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
-        new = lambda: torch.empty(R, dtype=torch.float32, device=dev)
-        qsa, lse, lp, ce = new(), new(), new(), new()
+        # the Q head runs on the rows the loss reads (should_take_action x attention_mask[:, 1:] masks every term of mc_loss) — see
+        # GPT2ILQLTrain.compact_q_rows
+        from .common import masked_rows
+        q_mask = np.asarray(should_take_action, dtype=bool) & (np.asarray(am)[:, 1:] != 0)
+        rows_h = masked_rows(q_mask, T)
+        Ra = int(rows_h.size)
+        compact = self.compact_q_rows and 0 < Ra < R
+        if compact:
+            idx = _t(rows_h, np.int32)
+            hq, Rq, tgt = ops.gather_rows(hid, idx, Ra, base.d), Ra, _t(ids[:, 1:][q_mask].astype(np.int32), np.int32)
+        else:
+            idx, hq, Rq = None, hid, R
+            tgt = torch.zeros(R, dtype=torch.int32, device=dev)
+            tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
+        qo, qc = self.q_head.forward(hq, Rq)
+        newq = lambda: torch.empty(Rq, dtype=torch.float32, device=dev)
+        qsa_q, lse, lp, ce_q = newq(), newq(), newq(), newq()
         ld = self.q_head.ld_out
-        ops.lse_gather(qo, ld, V, tgt, R, logprob=lp, lse=lse, target_logit=qsa)
-        ops.axpby(-1.0, lp, 0.0, None, ce)
+        ops.lse_gather(qo, ld, V, tgt, Rq, logprob=lp, lse=lse, target_logit=qsa_q)
+        ops.axpby(-1.0, lp, 0.0, None, ce_q)
+        if compact:
+            qsa, ce = torch.zeros(R, dtype=torch.float32, device=dev), torch.zeros(R, dtype=torch.float32, device=dev)
+            ops.scatter_rows(qsa_q, idx, qsa, Ra, 1, False)
+            ops.scatter_rows(ce_q, idx, ce, Ra, 1, False)
+        else:
+            qsa, ce = qsa_q, ce_q
         sl = lambda x: x.view(B, T)[:, :-1].contiguous()
         f32 = lambda x: _t(x, np.float32)
         loss, logs, dq, coef = mc_loss_device(sl(qsa), sl(ce), f32(am[:, 1:]), _t(should_take_action, np.uint8), f32(returns), **self.loss_kwargs)
         if not train:
             return self, loss, logs
         full = lambda g: (lambda z: (z.view(B, T)[:, :-1].copy_(g), z)[1])(torch.zeros(R, dtype=torch.float32, device=dev))
-        dqo, dqb = self.q_head.ce_bwd(qo, lse, tgt, full(coef), full(dq), R)          # d loss / d q logits
+        coef_r, dq_r = full(coef), full(dq)
+        if compact:
+            coef_r, dq_r = (ops.gather_rows(x.view(R, 1), idx, Ra, 1).view(Ra) for x in (coef_r, dq_r))
+        dqo, dqb = self.q_head.ce_bwd(qo, lse, tgt, coef_r, dq_r, Rq)          # d loss / d q logits
         bgrads, qgrads = base.zero_grads(), self.q_head.zero_grads()
-        d_hidden = torch.empty(R, base.d, dtype=torch.float32, device=dev)
-        self.q_head.backward(qc, dqo, qgrads, dx=d_hidden, accumulate_dx=False, dyb=dqb)
-        if self.detach_q:
-            d_hidden.zero_()
+        if compact:
+            dhq = torch.empty(Ra, base.d, dtype=torch.float32, device=dev)
+            self.q_head.backward(qc, dqo, qgrads, dx=dhq, accumulate_dx=False, dyb=dqb)
+            d_hidden = torch.zeros(R, base.d, dtype=torch.float32, device=dev)
+            if not self.detach_q:
+                ops.scatter_rows(dhq, idx, d_hidden, Ra, base.d, False)
+        else:
+            d_hidden = torch.empty(R, base.d, dtype=torch.float32, device=dev)
+            self.q_head.backward(qc, dqo, qgrads, dx=d_hidden, accumulate_dx=False, dyb=dqb)
+            if self.detach_q:
+                d_hidden.zero_()
         red = D.GradReducer()                        # gradient all-reduce overlapped with the base backward (data parallel)
         base.backward(cache, d_hidden, bgrads, on_final=red.ready(bgrads))
         self.last_grads = (bgrads, qgrads)

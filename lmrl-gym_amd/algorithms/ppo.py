@@ -16,7 +16,7 @@ from .. import _lib
 from .. import dist as D
 from ..train import ops
 from ..train.gpt2_f32 import AdamW, GPT2F32, LinearHeadF32
-from .common import BlockingStrategy, block_sequences, initialize_attn_mask_pos_ids, stats_from_sums
+from .common import BlockingStrategy, block_sequences, initialize_attn_mask_pos_ids, masked_rows, stats_from_sums
 
 
 # ----------------------------------------------------------------------------- KL controllers (base_interface.py:38-69)
@@ -226,6 +226,10 @@ class PPODataset:
 class GPT2PPOTrain:
     """fp32 PPO trainer: GPT-2 policy + LinearHead value head, two AdamW states.
 
+    `compact_rows` (default on): the tied LM head (forward and both backward products, [rows, d] x [d, V]) runs only on the rows whose
+    log-probability the loss reads — `should_take_action x attention_mask[:, 1:]` masks every policy term of `ppo_loss_fn`
+    (ppo/base_interface.py:72-142) — same loss / logs / gradients, head flops in proportion to the mask density.
+
     `step(...)` has the reference signature (base_interface.py:172-228) and returns `(self, loss, logs)`; the trainer is
     updated in place (the reference donates the old buffers)."""
 
@@ -238,6 +242,8 @@ class GPT2PPOTrain:
         self.head_opt = AdamW(value_head.p, lr, weight_decay=weight_decay, every_k=grad_accum_steps, no_decay=lambda n: n == "bias")
         self.bc_loss_weight = bc_loss_weight
         self.last_grads = None
+
+    compact_rows = True
 
     def _bc_term(self, ids, am, pos, tmask, grads):
         return _masked_lm_term(self.policy, self.pad, ids, am, pos, tmask, grads, self.bc_loss_weight)
@@ -255,13 +261,27 @@ class GPT2PPOTrain:
         ids_d, pos_d, am_d = _t(ids, np.int32), _t(pos, np.int32), _t(am, np.uint8)
         hid, cache = pol.forward(ids_d, am_d, pos_d)
         values_full, hcache = head.forward(hid, R)                               # [R, 1]
-        logits = pol.lm_logits(hid, R)                                           # fp32 [R, V]
-        # logprobs[b, t] = log p(ids[b, t+1] | ids[b, :t+1]) for t < T-1 : row r = b*T + t, target ids[b, t+1]
+        # logprobs[b, t] = log p(ids[b, t+1] | ids[b, :t+1]) for t < T-1 : row r = b*T + t, target ids[b, t+1] — needed on the masked rows only
+        p_mask = np.asarray(should_take_action, dtype=bool) & (np.asarray(am)[:, 1:] != 0)
+        rows_h = masked_rows(p_mask, T)
+        Ra = int(rows_h.size)
+        compact = self.compact_rows and 0 < Ra < R
         tgt = torch.zeros(R, dtype=torch.int32, device=dev)
         tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
-        logprob_all = torch.empty(R, dtype=torch.float32, device=dev)
-        lse = torch.empty(R, dtype=torch.float32, device=dev)
-        ops.lse_gather(logits, pol.ld_vocab, pol.vocab, tgt, R, logprob=logprob_all, lse=lse)
+        if compact:
+            idx = _t(rows_h, np.int32)
+            hq, tgt_q, Rq = ops.gather_rows(hid, idx, Ra, pol.d), _t(ids[:, 1:][p_mask].astype(np.int32), np.int32), Ra
+        else:
+            idx, hq, tgt_q, Rq = None, hid, tgt, R
+        logits = pol.lm_logits(hq, Rq)                                           # fp32 [Rq, V]
+        lp_q = torch.empty(Rq, dtype=torch.float32, device=dev)
+        lse = torch.empty(Rq, dtype=torch.float32, device=dev)
+        ops.lse_gather(logits, pol.ld_vocab, pol.vocab, tgt_q, Rq, logprob=lp_q, lse=lse)
+        if compact:
+            logprob_all = torch.zeros(R, dtype=torch.float32, device=dev)          # zeros off the mask (multiplied by the zero mask in the loss)
+            ops.scatter_rows(lp_q, idx, logprob_all, Ra, 1, False)
+        else:
+            logprob_all = lp_q
         sl = lambda x: x.view(B, T)[:, :-1].contiguous()
         f32 = lambda x: _t(x, np.float32)
         attn_s = f32(am[:, 1:])
@@ -279,10 +299,17 @@ class GPT2PPOTrain:
         neg = torch.empty_like(dlp)
         ops.axpby(-1.0, dlp, 0.0, None, neg)
         coef.view(B, T)[:, :-1] = neg
-        dlogits, dlb = pol.ce_bwd(logits, lse, tgt, coef, None, R)        # in place (fp32) / the staged bf16 operand (bf16-matmul mode)
+        coef_q = ops.gather_rows(coef.view(R, 1), idx, Ra, 1).view(Ra) if compact else coef
+        dlogits, dlb = pol.ce_bwd(logits, lse, tgt_q, coef_q, None, Rq)   # in place (fp32) / the staged bf16 operand (bf16-matmul mode)
         pgrads, hgrads = pol.zero_grads(), head.zero_grads()
-        d_hidden = torch.empty(R, pol.d, dtype=torch.float32, device=dev)
-        pol.lm_head_backward(hid, dlogits, R, d_hidden, pgrads, accumulate_dh=False, dlb=dlb)
+        if compact:
+            dhq = torch.empty(Ra, pol.d, dtype=torch.float32, device=dev)
+            pol.lm_head_backward(hq, dlogits, Ra, dhq, pgrads, accumulate_dh=False, dlb=dlb)
+            d_hidden = torch.zeros(R, pol.d, dtype=torch.float32, device=dev)
+            ops.scatter_rows(dhq, idx, d_hidden, Ra, pol.d, False)
+        else:
+            d_hidden = torch.empty(R, pol.d, dtype=torch.float32, device=dev)
+            pol.lm_head_backward(hid, dlogits, R, d_hidden, pgrads, accumulate_dh=False, dlb=dlb)
         dvals = torch.zeros(R, 1, dtype=torch.float32, device=dev)
         dvals.view(B, T)[:, :-1] = dv
         head.backward(hcache, dvals, hgrads, dx=d_hidden, accumulate_dx=True)

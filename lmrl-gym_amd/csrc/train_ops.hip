@@ -41,6 +41,32 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const float *__restrict_
     const float *te = wte + (size_t)ids[r] * d, *pe = wpe + (size_t)pos[r] * d;
     for (int c = lane * 4; c < d; c += 256) *reinterpret_cast<v4f *>(x + (size_t)r * d + c) = *reinterpret_cast<const v4f *>(te + c) + *reinterpret_cast<const v4f *>(pe + c);
 }
+// Row compaction for the vocabulary-wide heads: the RL losses read the Q / policy logits only on rows whose mask is set (should_take_action x
+// attention mask), so the heads run on the gathered rows and their input gradient is scattered back.  idx holds DISTINCT rows: no atomics.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx, float *__restrict__ dst,
+                                                          int n, int d) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const float *p = src + (size_t)idx[i] * d;
+    if ((d & 3) == 0) for (int c = lane * 4; c < d; c += 256) *reinterpret_cast<v4f *>(dst + (size_t)i * d + c) = *reinterpret_cast<const v4f *>(p + c);
+    else for (int c = lane; c < d; c += 64) dst[(size_t)i * d + c] = p[c];
+}
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx, float *dst, int n, int d,
+                                                           int accumulate) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    float *q = dst + (size_t)idx[i] * d;
+    const float *p = src + (size_t)i * d;
+    if ((d & 3) == 0) {
+        for (int c = lane * 4; c < d; c += 256) {
+            v4f v = *reinterpret_cast<const v4f *>(p + c);
+            if (accumulate) v += *reinterpret_cast<const v4f *>(q + c);
+            *reinterpret_cast<v4f *>(q + c) = v;
+        }
+    } else {
+        for (int c = lane; c < d; c += 64) q[c] = accumulate ? q[c] + p[c] : p[c];
+    }
+}
 // Embedding gradients WITHOUT atomics (bit-reproducible): one wave per row r of one table (blockIdx.y: 0 token ids -> dwte, 1 positions -> dwpe).
 // The wave owns index ids[r] iff r is its FIRST occurrence (a ballot scan over the earlier rows; the id array is 64 KB and lives in L2); the owner
 // then adds the rows that carry the same index in increasing row order and is the only writer of that table row.
@@ -497,6 +523,18 @@ int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d
     if (d <= 64 * 12) hipLaunchKernelGGL(embed_bwd_kernel<12>, grid, dim3(256), 0, ST, dx_d, ids_d, pos_d, dwte_d, dwpe_d, rows, d);
     else if (d <= 64 * 20) hipLaunchKernelGGL(embed_bwd_kernel<20>, grid, dim3(256), 0, ST, dx_d, ids_d, pos_d, dwte_d, dwpe_d, rows, d);
     else hipLaunchKernelGGL(embed_bwd_kernel<32>, grid, dim3(256), 0, ST, dx_d, ids_d, pos_d, dwte_d, dwpe_d, rows, d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_gather_rows_f32(const float *src_d, const int32_t *idx_d, float *dst_d, int n, int d, void *stream) {
+    LMRL_REQUIRE(src_d && idx_d && dst_d && n > 0 && d > 0, "lmrl_gather_rows_f32: bad argument");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, ST, src_d, idx_d, dst_d, n, d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_scatter_rows_f32(const float *src_d, const int32_t *idx_d, float *dst_d, int n, int d, int accumulate, void *stream) {
+    LMRL_REQUIRE(src_d && idx_d && dst_d && n > 0 && d > 0, "lmrl_scatter_rows_f32: bad argument");
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, ST, src_d, idx_d, dst_d, n, d, accumulate);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

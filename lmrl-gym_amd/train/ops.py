@@ -202,6 +202,18 @@ def colsum(x, rows, cols, ld, out, accumulate, ws):
     _lib.check(_L().lmrl_colsum(x.data_ptr(), rows, cols, ld, out.data_ptr(), int(accumulate), ws.data_ptr(), _sp()), "lmrl_colsum")
 
 
+def gather_rows(src, idx, n, d):
+    """dst[i] = src[idx[i]] (fp32 rows of d floats; idx int32 device tensor) -> new [n, d] tensor"""
+    dst = src.new_empty((n, d))
+    _lib.check(_L().lmrl_gather_rows_f32(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), n, d, _sp()), "lmrl_gather_rows_f32")
+    return dst
+
+
+def scatter_rows(src, idx, dst, n, d, accumulate):
+    """dst[idx[i]] (=|+=) src[i]; idx holds distinct rows"""
+    _lib.check(_L().lmrl_scatter_rows_f32(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), n, d, int(accumulate), _sp()), "lmrl_scatter_rows_f32")
+
+
 def layernorm_fwd(x, g, b, y, mean, rstd, rows, d, eps):
     _lib.check(_L().lmrl_layernorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, d,
                                        float(eps), _sp()), "lmrl_layernorm_fwd")

@@ -363,6 +363,43 @@ def test_ilql_train_step_vs_oracle(dev):
     _close(tr.q1_target.p["dense2.bias"].cpu(), 0.1 * tr.q1.p["dense2.bias"].cpu().double() + 0.9 * hq1["dense2.bias"].double(), rtol=1e-6)
 
 
+@pytest.mark.parametrize("detach", [(False, False), (True, False), (True, True)])
+def test_ilql_q_heads_on_masked_rows_only(dev, detach):
+    """`compact_q_rows` (default): the Q heads run on the rows `should_take_action x attention_mask[:, 1:]` selects — every Q term of the
+    loss carries that mask — vs on all B*T rows: same loss and logs (the same fp32 operations per selected row), gradients equal up to
+    the summation order of the products over rows; including the detach flags (scatter of the head's input gradient skipped)."""
+    from lmrl_gym_amd.algorithms import ilql
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    cfg, sd = _tiny_model(31, vocab=97)
+    pad = cfg.vocab - 1
+    rng = np.random.RandomState(5)
+    B, T, V, d = 5, 19, cfg.vocab, cfg.d_model
+    ids, sta, lens = _batch(rng, B, T, cfg.vocab, pad)
+    rewards = (rng.randn(B, T - 1) * sta).astype(np.float32)
+    dones = (rng.rand(B) < 0.5).astype(np.float32)
+    g = torch.Generator().manual_seed(3)
+    mk = lambda out: {"dense1.kernel": torch.randn(d, d, generator=g) * 0.2, "dense1.bias": torch.randn(d, generator=g) * 0.1,
+                      "dense2.kernel": torch.randn(d, out, generator=g) * 0.2, "dense2.bias": torch.full((out,), -0.3)}
+    hq1, hq2, hv = mk(V), mk(V), mk(1)
+    cp = lambda h: {k: v.clone() for k, v in h.items()}
+    res = []
+    for compact in (False, True):
+        base = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
+        tr = ilql.GPT2ILQLTrain(base, MLPHeadF32(cp(hq1), dev), MLPHeadF32(cp(hq2), dev), MLPHeadF32(cp(hv), dev), pad,
+                                dict(gamma=0.99, tau=0.7, cql_weight=0.05), lr=1e-3, detach_q1=detach[0], detach_q2=detach[1],
+                                compact_q_rows=compact)
+        _, loss, logs = tr.step(ids, sta, rewards, dones)
+        res.append((loss, _flat_logs(logs), [{k: v.clone() for k, v in gr.items()} for gr in tr.last_grads]))
+    (l0, g0, gr0), (l1, g1, gr1) = res
+    assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0))
+    assert set(g0) == set(g1)
+    for k in g0:
+        assert abs(g0[k] - g1[k]) <= 1e-6 * max(1.0, abs(g0[k])), (k, g0[k], g1[k])
+    for a, b in zip(gr0, gr1):
+        for k in a:
+            _close(b[k].cpu(), a[k].cpu(), rtol=2e-5, name=k)
+
+
 def test_ilql_next_token_branch_and_ppo_bc_term(dev):
     """(1) ILQL step with next_token_ids/next_dones: v_final comes from the V head on the last next-chunk token
     (ilql/gpt2/interface.py:252-264).  (2) PPO step with the BC auxiliary batch: loss + w*bc_loss, grads summed (:180-203)."""
