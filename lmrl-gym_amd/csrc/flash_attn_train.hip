@@ -111,6 +111,18 @@ __device__ __forceinline__ int slab_row(int lr) { return (lr >> 2) * 8 + (lr & 3
 
 // ------------------------------------------------------------------------------------------ operand staging
 // src [B*T][ld] fp32, columns col0 + h*64 + c  ->  natural Xn [BH][Tp][64] and transposed XT [BH][64][Tp] (zero rows / columns for t >= T)
+// 8 consecutive elements per lane: one 16-byte store (bf16) or two (fp32)
+__device__ __forceinline__ void st_vec8(uint16_t *p, const float (&v)[8]) {
+    uint4 o;
+    o.x = (uint32_t)f32_to_bf16_rn(v[0]) | ((uint32_t)f32_to_bf16_rn(v[1]) << 16); o.y = (uint32_t)f32_to_bf16_rn(v[2]) | ((uint32_t)f32_to_bf16_rn(v[3]) << 16);
+    o.z = (uint32_t)f32_to_bf16_rn(v[4]) | ((uint32_t)f32_to_bf16_rn(v[5]) << 16); o.w = (uint32_t)f32_to_bf16_rn(v[6]) | ((uint32_t)f32_to_bf16_rn(v[7]) << 16);
+    *reinterpret_cast<uint4 *>(p) = o;
+}
+__device__ __forceinline__ void st_vec8(float *p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4 *>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4 *>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+
 template <class E>
 __global__ __launch_bounds__(256) void flash_stage_kernel(const float *__restrict__ src, long ld, int col0, float scale, typename E::T *__restrict__ Xn,
                                                           typename E::T *__restrict__ XT, const float *__restrict__ other, float *__restrict__ rowdot,
@@ -118,25 +130,34 @@ __global__ __launch_bounds__(256) void flash_stage_kernel(const float *__restric
     __shared__ float tile[64][65];
     __shared__ float prod[64][65];
     const int t0 = blockIdx.x * 64, bh = blockIdx.y, b = bh / H, h = bh - b * H;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    // in: 16 lanes x 16 B per token row (the 64 floats of this head), 16 rows per pass
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int r = ty + 4 * k, t = t0 + r;
-        float v = 0.f, o = 0.f;
+    for (int k = 0; k < 4; k++) {
+        const int i = threadIdx.x + 256 * k, r = i >> 4, c4 = (i & 15) * 4, t = t0 + r;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f}, o = f32x4{0.f, 0.f, 0.f, 0.f};
         if (t < T) {
-            const long at = ((long)b * T + t) * ld + col0 + h * 64 + tx;
-            v = src[at] * scale;
-            if (other) o = other[at];
+            const long at = ((long)b * T + t) * ld + col0 + h * 64 + c4;
+            v = *reinterpret_cast<const f32x4 *>(src + at) * scale;
+            if (other) o = *reinterpret_cast<const f32x4 *>(other + at);
         }
-        tile[r][tx] = v;
-        if (other) prod[r][tx] = v * o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) tile[r][c4 + e] = v[e];
+        if (other) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) prod[r][c4 + e] = v[e] * o[e];
+        }
     }
     __syncthreads();
+    // out: 8 lanes x 8 elements per row, 32 rows per pass — natural rows (token, head dims) and transposed rows (head dim, tokens)
+    const int c8 = (threadIdx.x & 7) * 8, rr = threadIdx.x >> 3;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int r = ty + 4 * k;
-        st_elem(Xn + ((long)bh * Tp + t0 + r) * 64 + tx, tile[r][tx]);
-        st_elem(XT + ((long)bh * 64 + r) * Tp + t0 + tx, tile[tx][r]);
+    for (int k = 0; k < 2; k++) {
+        const int r = rr + 32 * k;
+        float a[8], bt[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) { a[e] = tile[r][c8 + e]; bt[e] = tile[c8 + e][r]; }
+        st_vec8(Xn + ((long)bh * Tp + t0 + r) * 64 + c8, a);
+        st_vec8(XT + ((long)bh * 64 + r) * Tp + t0 + c8, bt);
     }
     if (other && threadIdx.x < 64) {
         float s = 0.f;
