@@ -36,6 +36,27 @@ struct ElemBF16 {
 template <class E>
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * E::ROWB + ((chunk ^ (row & (E::CPR - 1))) << 4); }
 
+// the same in two halves — global -> registers now, registers -> LDS later — so that the loads of the NEXT tile are in flight while the
+// MFMAs of the current one run (the sweeps are latency-bound otherwise: a 64 x 64 tile is 16 MFMAs per wave between two barriers)
+template <class E>
+struct TileRegs { u32x4 v[64 * E::CPR / 256]; };
+template <class E>
+__device__ __forceinline__ void tile_fetch(TileRegs<E> &r, const typename E::T *src, long ld) {
+#pragma unroll
+    for (int i = 0; i < 64 * E::CPR / 256; i++) {
+        const int c = threadIdx.x + 256 * i, row = c / E::CPR, ch = c % E::CPR;
+        r.v[i] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(src + (long)row * ld) + ch * 16);
+    }
+}
+template <class E>
+__device__ __forceinline__ void tile_commit(char *tile, const TileRegs<E> &r) {
+#pragma unroll
+    for (int i = 0; i < 64 * E::CPR / 256; i++) {
+        const int c = threadIdx.x + 256 * i, row = c / E::CPR, ch = c % E::CPR;
+        *reinterpret_cast<u32x4 *>(tile + tile_off<E>(row, ch)) = r.v[i];
+    }
+}
+
 template <class E>
 __device__ __forceinline__ void load_tile(char *tile, const typename E::T *src, long ld) {
 #pragma unroll
@@ -96,6 +117,12 @@ __device__ __forceinline__ void st_elem(float *p, float v) { *p = v; }
 
 // key-validity bytes of one 64-key block -> LDS (1 = key index < T and key_mask set).  Branch-free on purpose: the per-element
 // `ok ? score : -inf` selects below must stay selects (a divergent short-circuit load around AGPR moves was miscompiled by hipcc 7.2).
+__device__ __forceinline__ uint8_t key_valid_fetch(const uint8_t *kmb, int k0, int T) {      // threads 0..63; branch-free as below
+    const int kk = k0 + (threadIdx.x & 63);
+    const int kc = kk < T ? kk : T - 1;
+    const uint8_t mv = kmb ? kmb[kc] : (uint8_t)1;
+    return (kk < T && mv != 0) ? 1 : 0;
+}
 __device__ __forceinline__ void load_key_valid(uint8_t *sM, const uint8_t *kmb, int k0, int T) {
     if (threadIdx.x < 64) {
         const int kk = k0 + threadIdx.x;
@@ -167,7 +194,7 @@ __global__ __launch_bounds__(256) void flash_stage_kernel(const float *__restric
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <class E>
+template <class E, bool PF>
 __global__ __launch_bounds__(256) void flash_fwd_kernel(const typename E::T *__restrict__ Qn, const typename E::T *__restrict__ Kn,
                                                         const typename E::T *__restrict__ VT, const uint8_t *__restrict__ km, float *__restrict__ att,
                                                         float *__restrict__ lse, int H, int T, int Tp, int d, uint16_t *__restrict__ att_b, long ldb) {
@@ -186,12 +213,30 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const typename E::T *__r
 #pragma unroll
     for (int i = 0; i < 4; i++) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ra = slab_row(lr);
+    TileRegs<E> rk, rv;
+    uint8_t rm = 0;
+    if (PF) {
+        tile_fetch<E>(rk, Kn + ((long)bh * Tp) * 64, 64);
+        tile_fetch<E>(rv, VT + (long)bh * 64 * Tp, Tp);
+        rm = key_valid_fetch(kmb, 0, T);
+    }
     for (int kb = 0; kb <= qb; kb++) {
         __syncthreads();
-        load_tile<E>(sK, Kn + ((long)bh * Tp + kb * 64) * 64, 64);
-        load_tile<E>(sV, VT + (long)bh * 64 * Tp + kb * 64, Tp);
-        load_key_valid(sM, kmb, kb * 64, T);
+        if (PF) {
+            tile_commit<E>(sK, rk);
+            tile_commit<E>(sV, rv);
+            if (threadIdx.x < 64) sM[threadIdx.x] = rm;
+        } else {
+            load_tile<E>(sK, Kn + ((long)bh * Tp + kb * 64) * 64, 64);
+            load_tile<E>(sV, VT + (long)bh * 64 * Tp + kb * 64, Tp);
+            load_key_valid(sM, kmb, kb * 64, T);
+        }
         __syncthreads();
+        if (PF && kb < qb) {        // next key block: requested now, committed to LDS after this block's MFMAs
+            tile_fetch<E>(rk, Kn + ((long)bh * Tp + (kb + 1) * 64) * 64, 64);
+            tile_fetch<E>(rv, VT + (long)bh * 64 * Tp + (kb + 1) * 64, Tp);
+            rm = key_valid_fetch(kmb, (kb + 1) * 64, T);
+        }
         float s[2][8];
         float mloc = -INFINITY;
 #pragma unroll
@@ -254,7 +299,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const typename E::T *__r
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ
-template <class E>
+template <class E, bool PF>
 __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const typename E::T *__restrict__ Qn, const typename E::T *__restrict__ Kn,
                                                            const typename E::T *__restrict__ Vn, const typename E::T *__restrict__ KT,
                                                            const typename E::T *__restrict__ dOn, const float *__restrict__ Dsum,
@@ -279,13 +324,34 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const typename E::T *
 #pragma unroll
     for (int i = 0; i < 4; i++) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ra = slab_row(lr);
+    TileRegs<E> rk, rv, rkt;
+    uint8_t rm = 0;
+    if (PF) {
+        tile_fetch<E>(rk, Kn + ((long)bh * Tp) * 64, 64);
+        tile_fetch<E>(rv, Vn + ((long)bh * Tp) * 64, 64);
+        tile_fetch<E>(rkt, KT + (long)bh * 64 * Tp, Tp);
+        rm = key_valid_fetch(kmb, 0, T);
+    }
     for (int kb = 0; kb <= qb; kb++) {
         __syncthreads();
-        load_tile<E>(sK, Kn + ((long)bh * Tp + kb * 64) * 64, 64);
-        load_tile<E>(sV, Vn + ((long)bh * Tp + kb * 64) * 64, 64);
-        load_tile<E>(sKT, KT + (long)bh * 64 * Tp + kb * 64, Tp);
-        load_key_valid(sM, kmb, kb * 64, T);
+        if (PF) {
+            tile_commit<E>(sK, rk);
+            tile_commit<E>(sV, rv);
+            tile_commit<E>(sKT, rkt);
+            if (threadIdx.x < 64) sM[threadIdx.x] = rm;
+        } else {
+            load_tile<E>(sK, Kn + ((long)bh * Tp + kb * 64) * 64, 64);
+            load_tile<E>(sV, Vn + ((long)bh * Tp + kb * 64) * 64, 64);
+            load_tile<E>(sKT, KT + (long)bh * 64 * Tp + kb * 64, Tp);
+            load_key_valid(sM, kmb, kb * 64, T);
+        }
         __syncthreads();
+        if (PF && kb < qb) {
+            tile_fetch<E>(rk, Kn + ((long)bh * Tp + (kb + 1) * 64) * 64, 64);
+            tile_fetch<E>(rv, Vn + ((long)bh * Tp + (kb + 1) * 64) * 64, 64);
+            tile_fetch<E>(rkt, KT + (long)bh * 64 * Tp + (kb + 1) * 64, Tp);
+            rm = key_valid_fetch(kmb, (kb + 1) * 64, T);
+        }
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = sa, pa = sa, pb = sa;
@@ -324,7 +390,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const typename E::T *
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
-template <class E>
+template <class E, bool PF>
 __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const typename E::T *__restrict__ Qn, const typename E::T *__restrict__ Kn,
                                                             const typename E::T *__restrict__ Vn, const typename E::T *__restrict__ QT,
                                                             const typename E::T *__restrict__ dOn, const typename E::T *__restrict__ dOT,
@@ -350,17 +416,37 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const typename E::T 
     for (int i = 0; i < 4; i++) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = dk[i]; }
     const int ra = slab_row(lr);
     const int nqb = Tp / 64;
+    TileRegs<E> rq, rdo, rqt, rdot;
+    float rl = 0.f, rd = 0.f;
+    auto fetch = [&](int qb_) {
+        tile_fetch<E>(rq, Qn + ((long)bh * Tp + qb_ * 64) * 64, 64);
+        tile_fetch<E>(rdo, dOn + ((long)bh * Tp + qb_ * 64) * 64, 64);
+        tile_fetch<E>(rqt, QT + (long)bh * 64 * Tp + qb_ * 64, Tp);
+        tile_fetch<E>(rdot, dOT + (long)bh * 64 * Tp + qb_ * 64, Tp);
+        rl = lse[(long)bh * Tp + qb_ * 64 + (threadIdx.x & 63)];
+        rd = Dsum[(long)bh * Tp + qb_ * 64 + (threadIdx.x & 63)];
+    };
+    if (PF) fetch(kb);
     for (int qb = kb; qb < nqb; qb++) {
         __syncthreads();
-        load_tile<E>(sQ, Qn + ((long)bh * Tp + qb * 64) * 64, 64);
-        load_tile<E>(sdO, dOn + ((long)bh * Tp + qb * 64) * 64, 64);
-        load_tile<E>(sQT, QT + (long)bh * 64 * Tp + qb * 64, Tp);
-        load_tile<E>(sdOT, dOT + (long)bh * 64 * Tp + qb * 64, Tp);
-        if (threadIdx.x < 64) {
-            sL[threadIdx.x] = lse[(long)bh * Tp + qb * 64 + threadIdx.x];
-            sD[threadIdx.x] = Dsum[(long)bh * Tp + qb * 64 + threadIdx.x];
+        if (PF) {
+            tile_commit<E>(sQ, rq);
+            tile_commit<E>(sdO, rdo);
+            tile_commit<E>(sQT, rqt);
+            tile_commit<E>(sdOT, rdot);
+            if (threadIdx.x < 64) { sL[threadIdx.x] = rl; sD[threadIdx.x] = rd; }
+        } else {
+            load_tile<E>(sQ, Qn + ((long)bh * Tp + qb * 64) * 64, 64);
+            load_tile<E>(sdO, dOn + ((long)bh * Tp + qb * 64) * 64, 64);
+            load_tile<E>(sQT, QT + (long)bh * 64 * Tp + qb * 64, Tp);
+            load_tile<E>(sdOT, dOT + (long)bh * 64 * Tp + qb * 64, Tp);
+            if (threadIdx.x < 64) {
+                sL[threadIdx.x] = lse[(long)bh * Tp + qb * 64 + threadIdx.x];
+                sD[threadIdx.x] = Dsum[(long)bh * Tp + qb * 64 + threadIdx.x];
+            }
         }
         __syncthreads();
+        if (PF && qb + 1 < nqb) fetch(qb + 1);
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = sa, pa = sa, pb = sa;
@@ -403,6 +489,21 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const typename E::T 
         }
     }
 }
+
+// which sweeps fetch the next tile through registers under the current tile's MFMAs — measured per kernel and arithmetic mode (B = 32, H = 12,
+// T = 512 / 1024): bf16 forward 88 -> 67 / 277 -> 235 us, bf16 dQ 108 -> 94 / 338 -> 292 us, fp32 dQ 1402 -> 1348 us; the dK/dV kernels and the
+// fp32 forward lose (the fetch registers cost them a wave of occupancy: +2..8 %) and keep the plain load.  -DLMRL_FLASH_PF=<mask> to A/B
+// (bit 0 fwd, 1 dq, 2 dkv; bits 3-5 the same for fp32).
+#ifndef LMRL_FLASH_PF
+#define LMRL_FLASH_PF 0x13
+#endif
+template <class E> struct FlashPrefetch;
+template <> struct FlashPrefetch<ElemBF16> {
+    static constexpr bool fwd = (LMRL_FLASH_PF & 1) != 0, dq = (LMRL_FLASH_PF & 2) != 0, dkv = (LMRL_FLASH_PF & 4) != 0;
+};
+template <> struct FlashPrefetch<ElemF32> {
+    static constexpr bool fwd = (LMRL_FLASH_PF & 8) != 0, dq = (LMRL_FLASH_PF & 16) != 0, dkv = (LMRL_FLASH_PF & 32) != 0;
+};
 
 struct FlashWs {
     char *Qn, *Kn, *Vn, *QT, *KT, *VT, *dOn, *dOT;
@@ -447,8 +548,9 @@ static int flash_fwd(const float *qkv, const uint8_t *km, float *att, float *lse
     int rc = flash_stage_qkv<E>(qkv, w, batch, heads, t, tp, s);
     if (rc) return rc;
     const size_t lds = 2 * E::TILE + 64;
-    LMRL_CHECK_HIP(allow_lds(flash_fwd_kernel<E>, lds));
-    hipLaunchKernelGGL(flash_fwd_kernel<E>, dim3(tp / 64, bh), dim3(256), lds, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.VT, km, att, lse, heads,
+    constexpr bool PF = FlashPrefetch<E>::fwd;
+    LMRL_CHECK_HIP(allow_lds(flash_fwd_kernel<E, PF>, lds));
+    hipLaunchKernelGGL((flash_fwd_kernel<E, PF>), dim3(tp / 64, bh), dim3(256), lds, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.VT, km, att, lse, heads,
                        t, tp, d, (uint16_t *)att_b, ldb);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
@@ -467,11 +569,12 @@ static int flash_bwd(const float *qkv, const uint8_t *km, const float *att, cons
     hipLaunchKernelGGL(flash_stage_kernel<E>, dim3(tp / 64, bh), dim3(256), 0, s, datt, (long)d, 0, 1.f, (T *)w.dOn, (T *)w.dOT, att, w.D, heads, t, tp);
     LMRL_CHECK_LAUNCH();
     const size_t lds_q = 3 * E::TILE + 64, lds_kv = 4 * E::TILE + 512;
-    LMRL_CHECK_HIP(allow_lds(flash_bwd_dq_kernel<E>, lds_q));
-    LMRL_CHECK_HIP(allow_lds(flash_bwd_dkv_kernel<E>, lds_kv));
-    hipLaunchKernelGGL(flash_bwd_dq_kernel<E>, dim3(tp / 64, bh), dim3(256), lds_q, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.Vn, (const T *)w.KT,
+    constexpr bool PFQ = FlashPrefetch<E>::dq, PFKV = FlashPrefetch<E>::dkv;
+    LMRL_CHECK_HIP(allow_lds(flash_bwd_dq_kernel<E, PFQ>, lds_q));
+    LMRL_CHECK_HIP(allow_lds(flash_bwd_dkv_kernel<E, PFKV>, lds_kv));
+    hipLaunchKernelGGL((flash_bwd_dq_kernel<E, PFQ>), dim3(tp / 64, bh), dim3(256), lds_q, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.Vn, (const T *)w.KT,
                        (const T *)w.dOn, (const float *)w.D, lse, km, dqkv, dqb, ldb, heads, t, tp, d);
-    hipLaunchKernelGGL(flash_bwd_dkv_kernel<E>, dim3(tp / 64, bh), dim3(256), lds_kv, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.Vn,
+    hipLaunchKernelGGL((flash_bwd_dkv_kernel<E, PFKV>), dim3(tp / 64, bh), dim3(256), lds_kv, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.Vn,
                        (const T *)w.QT, (const T *)w.dOn, (const T *)w.dOT, (const float *)w.D, lse, km, dqkv, dqb, ldb, heads, t, tp, d);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
