@@ -237,6 +237,16 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const typename E::T *__r
             tile_fetch<E>(rv, VT + (long)bh * 64 * Tp + (kb + 1) * 64, Tp);
             rm = key_valid_fetch(kmb, (kb + 1) * 64, T);
         }
+        // blocks strictly below the diagonal whose 64 keys are all valid need no masking at all (most blocks of a long sweep): the
+        // per-element compare / byte extract / select is a third of the VALU work of a block.  Workgroup-uniform (SGPR) condition.
+        bool plain = kb < qb;
+        {
+            const unsigned long long *m8 = reinterpret_cast<const unsigned long long *>(sM);
+            unsigned long long all = 0x0101010101010101ull;
+#pragma unroll
+            for (int i = 0; i < 8; i++) all &= m8[i];
+            plain = plain && __builtin_amdgcn_readfirstlane((int)(all == 0x0101010101010101ull)) != 0;
+        }
         float s[2][8];
         float mloc = -INFINITY;
 #pragma unroll
@@ -247,14 +257,23 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const typename E::T *__r
                 sa = mma(E(), sa, ld_frag_lds(E(), sK, p * 32 + ra, sl * 32 + lq * 8), qf[sl]);
                 sb = mma(E(), sb, ld_frag_lds(E(), sK, p * 32 + ra + 4, sl * 32 + lq * 8), qf[sl]);
             }
-            const unsigned long long mb = *reinterpret_cast<const unsigned long long *>(sM + p * 32 + lq * 8);
+            if (plain) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int kk = kb * 64 + p * 32 + lq * 8 + e;
-                const bool ok = (kk <= qi) & (((mb >> (8 * e)) & 0xffull) != 0);
-                const float v = ok ? (e < 4 ? sa[e] : sb[e - 4]) : -INFINITY;
-                s[p][e] = v;
-                mloc = fmaxf(mloc, v);
+                for (int e = 0; e < 8; e++) {
+                    const float v = e < 4 ? sa[e] : sb[e - 4];
+                    s[p][e] = v;
+                    mloc = fmaxf(mloc, v);
+                }
+            } else {
+                const unsigned long long mb = *reinterpret_cast<const unsigned long long *>(sM + p * 32 + lq * 8);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int kk = kb * 64 + p * 32 + lq * 8 + e;
+                    const bool ok = (kk <= qi) & (((mb >> (8 * e)) & 0xffull) != 0);
+                    const float v = ok ? (e < 4 ? sa[e] : sb[e - 4]) : -INFINITY;
+                    s[p][e] = v;
+                    mloc = fmaxf(mloc, v);
+                }
             }
         }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
@@ -352,6 +371,14 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const typename E::T *
             tile_fetch<E>(rkt, KT + (long)bh * 64 * Tp + (kb + 1) * 64, Tp);
             rm = key_valid_fetch(kmb, (kb + 1) * 64, T);
         }
+        bool plain = kb < qb && qb * 64 + 63 < T;
+        {
+            const unsigned long long *m8 = reinterpret_cast<const unsigned long long *>(sM);
+            unsigned long long all = 0x0101010101010101ull;
+#pragma unroll
+            for (int i = 0; i < 8; i++) all &= m8[i];
+            plain = plain && __builtin_amdgcn_readfirstlane((int)(all == 0x0101010101010101ull)) != 0;
+        }
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = sa, pa = sa, pb = sa;
@@ -363,14 +390,22 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const typename E::T *
                 pb = mma(E(), pb, ld_frag_lds(E(), sV, p * 32 + ra + 4, sl * 32 + lq * 8), dof[sl]);
             }
             float ds[8];
-            const unsigned long long mb = *reinterpret_cast<const unsigned long long *>(sM + p * 32 + lq * 8);
+            if (plain) {      // below the diagonal, all 64 keys valid, all 64 queries real: no masking (see flash_fwd_kernel)
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int kk = kb * 64 + p * 32 + lq * 8 + e;
-                const bool ok = (kk <= qi) & (qi < T) & (((mb >> (8 * e)) & 0xffull) != 0);
-                const float sv = e < 4 ? sa[e] : sb[e - 4], dp = e < 4 ? pa[e] : pb[e - 4];
-                const float pr = ok ? __expf(sv - Lq) : 0.f;
-                ds[e] = pr * (dp - Dq);
+                for (int e = 0; e < 8; e++) {
+                    const float sv = e < 4 ? sa[e] : sb[e - 4], dp = e < 4 ? pa[e] : pb[e - 4];
+                    ds[e] = __expf(sv - Lq) * (dp - Dq);
+                }
+            } else {
+                const unsigned long long mb = *reinterpret_cast<const unsigned long long *>(sM + p * 32 + lq * 8);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int kk = kb * 64 + p * 32 + lq * 8 + e;
+                    const bool ok = (kk <= qi) & (qi < T) & (((mb >> (8 * e)) & 0xffull) != 0);
+                    const float sv = e < 4 ? sa[e] : sb[e - 4], dp = e < 4 ? pa[e] : pb[e - 4];
+                    const float pr = ok ? __expf(sv - Lq) : 0.f;
+                    ds[e] = pr * (dp - Dq);
+                }
             }
             const typename E::Frag dsf = make_frag(E(), ds);
 #pragma unroll
@@ -411,6 +446,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const typename E::T 
     }
     const uint8_t kmv = km ? km[(long)b * T + (kj < T ? kj : T - 1)] : (uint8_t)1;
     const bool key_ok = (kj < T) & (kmv != 0);
+    const bool all_keys_ok = __syncthreads_and((int)key_ok) != 0;          // all 64 keys of this workgroup's block are valid
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = dk[i]; }
@@ -458,13 +494,23 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const typename E::T 
                 pb = mma(E(), pb, ld_frag_lds(E(), sdO, p * 32 + ra + 4, sl * 32 + lq * 8), vf[sl]);
             }
             float pr[8], ds[8];
+            if (all_keys_ok && qb > kb && qb * 64 + 63 < T) {      // workgroup-uniform: no masking on this block
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int ql = p * 32 + lq * 8 + e, qq = qb * 64 + ql;
-                const bool ok = key_ok & (qq >= kj) & (qq < T);
-                const float sv = e < 4 ? sa[e] : sb[e - 4], dp = e < 4 ? pa[e] : pb[e - 4];
-                pr[e] = ok ? __expf(sv - sL[ql]) : 0.f;
-                ds[e] = pr[e] * (dp - sD[ql]);
+                for (int e = 0; e < 8; e++) {
+                    const int ql = p * 32 + lq * 8 + e;
+                    const float sv = e < 4 ? sa[e] : sb[e - 4], dp = e < 4 ? pa[e] : pb[e - 4];
+                    pr[e] = __expf(sv - sL[ql]);
+                    ds[e] = pr[e] * (dp - sD[ql]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int ql = p * 32 + lq * 8 + e, qq = qb * 64 + ql;
+                    const bool ok = key_ok & (qq >= kj) & (qq < T);
+                    const float sv = e < 4 ? sa[e] : sb[e - 4], dp = e < 4 ? pa[e] : pb[e - 4];
+                    pr[e] = ok ? __expf(sv - sL[ql]) : 0.f;
+                    ds[e] = pr[e] * (dp - sD[ql]);
+                }
             }
             const typename E::Frag pf = make_frag(E(), pr), dsf = make_frag(E(), ds);
 #pragma unroll
@@ -490,12 +536,13 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const typename E::T 
     }
 }
 
-// which sweeps fetch the next tile through registers under the current tile's MFMAs — measured per kernel and arithmetic mode (B = 32, H = 12,
-// T = 512 / 1024): bf16 forward 88 -> 67 / 277 -> 235 us, bf16 dQ 108 -> 94 / 338 -> 292 us, fp32 dQ 1402 -> 1348 us; the dK/dV kernels and the
-// fp32 forward lose (the fetch registers cost them a wave of occupancy: +2..8 %) and keep the plain load.  -DLMRL_FLASH_PF=<mask> to A/B
-// (bit 0 fwd, 1 dq, 2 dkv; bits 3-5 the same for fp32).
+// which sweeps fetch the next tile through registers under the current tile's MFMAs — A/B per kernel and arithmetic mode on one box
+// (tools/_bin-style script, B = 32, H = 12, T = 512 / 1024; plain -> prefetch): bf16 forward 75 -> 68 / 245 -> 212 us, bf16 dQ 108 -> 94 /
+// 341 -> 292 us, fp32 forward 282 -> 255 / 965 -> 926 us, fp32 dQ 412 -> 373 / 1413 -> 1348 us; the dK/dV kernels (four tiles per step: the
+// fetch registers cost them a wave of occupancy) are neutral in bf16 (168 -> 153 / 562 -> 582 us) and lose in fp32 (632 -> 658 / 2263 -> 2409 us)
+// and keep the plain load.  -DLMRL_FLASH_PF=<mask> to A/B (bit 0 fwd, 1 dq, 2 dkv; bits 3-5 the same for fp32).
 #ifndef LMRL_FLASH_PF
-#define LMRL_FLASH_PF 0x13
+#define LMRL_FLASH_PF 0x1b
 #endif
 template <class E> struct FlashPrefetch;
 template <> struct FlashPrefetch<ElemBF16> {
