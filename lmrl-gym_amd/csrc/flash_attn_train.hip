@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const typename E::T 
 }
 
 // which sweeps fetch the next tile through registers under the current tile's MFMAs — A/B per kernel and arithmetic mode on one box
-// (tools/_bin-style script, B = 32, H = 12, T = 512 / 1024; plain -> prefetch): bf16 forward 75 -> 68 / 245 -> 212 us, bf16 dQ 108 -> 94 /
+// (tools/bench_flash_train.py under rocprofv3, B = 32, H = 12, T = 512 / 1024; plain -> prefetch): bf16 forward 75 -> 68 / 245 -> 212 us, bf16 dQ 108 -> 94 /
 // 341 -> 292 us, fp32 forward 282 -> 255 / 965 -> 926 us, fp32 dQ 412 -> 373 / 1413 -> 1348 us; the dK/dV kernels (four tiles per step: the
 // fetch registers cost them a wave of occupancy) are neutral in bf16 (168 -> 153 / 562 -> 582 us) and lose in fp32 (632 -> 658 / 2263 -> 2409 us)
 // and keep the plain load.  -DLMRL_FLASH_PF=<mask> to A/B (bit 0 fwd, 1 dq, 2 dkv; bits 3-5 the same for fp32).

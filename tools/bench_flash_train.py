@@ -1,0 +1,28 @@
+"""The train step's flash-attention kernels alone (forward, dQ, dK/dV; bf16 and fp32 operands) at the ILQL (T = 512) and PPO (T = 1024) bench
+shapes, B = 32, H = 12 — run under `rocprofv3 --kernel-trace` to read per-kernel durations (how the LMRL_FLASH_PF prefetch mask in
+csrc/flash_attn_train.hip was chosen: build once with -DLMRL_FLASH_PF=0 and once with 0x3f, same box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from lmrl_gym_amd import _lib
+from lmrl_gym_amd.train import ops
+dev = _lib.require_gpu()
+for T in (512, 1024):
+    for bf16 in (True, False):
+        B, H = 32, 12
+        d = H * 64
+        g = torch.Generator().manual_seed(0)
+        qkv = torch.randn(B * T, 3 * d, generator=g).to(dev)
+        datt = torch.randn(B * T, d, generator=g).to(dev)
+        ws, lse_n = ops.flash_attn_ws(B, H, T, bf16, dev)
+        att = torch.empty(B * T, d, device=dev); lse = torch.empty(lse_n, device=dev); dqkv = torch.empty(B * T, 3 * d, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        for it in range(4):
+            ev[0].record()
+            ops.flash_attn_fwd(qkv, None, att, lse, ws, B, H, T, bf16)
+            ev[1].record()
+            ops.flash_attn_bwd(qkv, None, att, datt, lse, dqkv, ws, B, H, T, bf16, qkv_staged=True)
+            ev[2].record()
+        torch.cuda.synchronize()
+        print("T=%4d %s  forward (3 stagings + sweep) %7.1f us   backward (dO staging + dQ + dK/dV) %7.1f us"
+              % (T, "bf16" if bf16 else "fp32", ev[0].elapsed_time(ev[1]) * 1e3, ev[1].elapsed_time(ev[2]) * 1e3))
