@@ -239,14 +239,15 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void final_ln_advance_kernel(const float *__restrict__ x, const float *__restrict__ gam,
                                                                const float *__restrict__ bet, uint16_t *__restrict__ y,
                                                                const int32_t *__restrict__ cnt, int32_t *__restrict__ len, int B, int C,
-                                                               int d, float eps, const int32_t *__restrict__ off) {
+                                                               int d, float eps, const int32_t *__restrict__ off, int compact) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
     const int n = min(cnt[b], C);
     if (n <= 0) return;
     if (lane == 0) len[b] += n;
     if (!y) return;
-    const float *xr = x + ((size_t)(off ? off[b] : b * C) + n - 1) * d;
+    // compact: x holds ONE row per env (the last new token's, gathered before the last layer's projection / MLP), row b
+    const float *xr = compact ? x + (size_t)b * d : x + ((size_t)(off ? off[b] : b * C) + n - 1) * d;
     f32x4 v[MAXV], g4[MAXV], b4[MAXV];
     float s = 0.f;
 #pragma unroll
@@ -285,6 +286,33 @@ __global__ __launch_bounds__(256) void final_ln_advance_kernel(const float *__re
             pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
             *reinterpret_cast<uint2 *>(y + (size_t)b * d + c) = pk;
         }
+    }
+}
+
+// Last layer of a chunk forward: only each env's LAST new token goes on through the output projection and the MLP (its hidden state is all
+// the caller reads; the other rows of the chunk only had to leave their K / V rows in the cache, which the attention launch has done).
+// One wave per env: att row (bf16) and residual row (fp32) of that token -> row b of the compact buffers; envs without new tokens get zeros.
+__global__ __launch_bounds__(256) void gather_last_rows_kernel(const uint16_t *__restrict__ att, const float *__restrict__ x,
+                                                               const int32_t *__restrict__ cnt, const int32_t *__restrict__ off, int B, int C, int d,
+                                                               uint16_t *__restrict__ att_c, float *__restrict__ x_c, float2 *__restrict__ stats_c,
+                                                               int nslots) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    // moment slots of the row: the projection's epilogue fills the real ones, the padding slots (slot pitch 8 * NQ) must read as zero
+    for (int k = lane; k < nslots; k += 64) stats_c[(size_t)b * nslots + k] = make_float2(0.f, 0.f);
+    const int n = min(cnt[b], C);
+    const size_t r = (size_t)(off ? off[b] : b * C) + (n > 0 ? n - 1 : 0);
+    for (int c8 = lane * 8; c8 < d; c8 += 512) {
+        u32x4 a = u32x4{0u, 0u, 0u, 0u};
+        f32x4 x0 = f32x4{0.f, 0.f, 0.f, 0.f}, x1 = x0;
+        if (n > 0) {
+            a = *reinterpret_cast<const u32x4 *>(att + r * d + c8);
+            x0 = *reinterpret_cast<const f32x4 *>(x + r * d + c8);
+            x1 = *reinterpret_cast<const f32x4 *>(x + r * d + c8 + 4);
+        }
+        *reinterpret_cast<u32x4 *>(att_c + (size_t)b * d + c8) = a;
+        *reinterpret_cast<f32x4 *>(x_c + (size_t)b * d + c8) = x0;
+        *reinterpret_cast<f32x4 *>(x_c + (size_t)b * d + c8 + 4) = x1;
     }
 }
 
@@ -1064,6 +1092,20 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
     // stores over 128 envs' cache pages), a net loss of 1.2 us per layer — so it is off by default and kept as a per-call variant.
     const bool kv_from_gemm = fused && c == 1 && (flags & LMRL_FWD_KV_FROM_GEMM) && !(flags & LMRL_FWD_ATTN_VALU);
     const int append_in_attn = kv_from_gemm ? 0 : 1;
+    // chunk forwards that return at most the last token's hidden state: the last layer's projection + MLP run on ONE row per env (the same
+    // per-row arithmetic as on the full chunk: bit-identical results), or not at all when no hidden state is asked for (a prompt's
+    // non-final chunks).  The compact operands live in the qkv scratch, which is dead after the attention launch.
+    const bool last_only = fused && c > 1 && !all_hidden_d && !(flags & LMRL_FWD_FULL_LAST_LAYER);
+    uint16_t *lc_att = nullptr, *lc_h = nullptr, *lc_ff = nullptr; float *lc_x = nullptr; float2 *lc_stats = nullptr;
+    if (last_only) {
+        char *p = (char *)w.qkv;
+        lc_x = (float *)p; p += align256((size_t)b * d * 4);
+        lc_att = (uint16_t *)p; p += align256((size_t)b * d * 2);
+        lc_h = (uint16_t *)p; p += align256((size_t)b * d * 2);
+        lc_ff = (uint16_t *)p; p += align256((size_t)b * cf.d_ff * 2);
+        lc_stats = (float2 *)p; p += align256((size_t)b * nsl * 8);
+        LMRL_REQUIRE((size_t)(p - (char *)w.qkv) <= (size_t)M * 3 * d * 2, "lmrl_gpt2_forward: qkv scratch too small for the compact last-layer rows");
+    }
     for (int l = 0; l < cf.n_layer; l++) {
         const Gpt2Layer &L = m->layers[l];
         uint16_t *kc = (uint16_t *)kv_d + (size_t)(2 * l) * kv_layer, *vc = kc + kv_layer;
@@ -1118,7 +1160,20 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
         else hipLaunchKernelGGL(attention_chunk_mfma_kernel<8>, dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, w.qkv, kc, vc, cnt_d, len_d, w.att, b, cf.n_head, tmax, d, off);
         }
         LMRL_CHECK_LAUNCH();
-        if (fused) {
+        if (fused && l + 1 == cf.n_layer && last_only) {
+            // last layer of a chunk forward: nothing after the attention for rows whose hidden state nobody reads
+            if (last_hidden_d) {
+                hipLaunchKernelGGL(gather_last_rows_kernel, dim3(ceil_div(b, 4)), dim3(256), 0, s, (const uint16_t *)w.att, (const float *)w.x, cnt_d, off,
+                                   b, c, d, lc_att, lc_x, lc_stats, nsl);
+                LMRL_CHECK_LAUNCH();
+                GemmArgs gp{lc_att, L.w_proj, L.b_proj, lc_x, b, d, d, d, d, d, lc_stats, lc_h, nullptr, nsl, 0.f, 0.f, nullptr};
+                LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, s));
+                GemmArgs gf{lc_h, L.wf_fc, L.bf_fc, lc_ff, b, cf.d_ff, d, d, cf.d_ff, cf.d_ff, lc_stats, nullptr, L.cs_fc, nsl, 1.f / (float)d, cf.ln_eps, nullptr};
+                LMRL_CHECK_HIP(gemm_launch_ln<EPI_GELU_BF16_LN>(gf, s));
+                GemmArgs g2{lc_ff, L.w_fc2, L.b_fc2, lc_x, b, d, cf.d_ff, cf.d_ff, d, d, lc_stats, lc_h, nullptr, nsl, 0.f, 0.f, nullptr};
+                LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(g2, s));
+            }
+        } else if (fused) {
             GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
             LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, s));
             GemmArgs gf{w.h, L.wf_fc, L.bf_fc, w.ff, M, cf.d_ff, d, d, cf.d_ff, cf.d_ff, w.stats, nullptr, L.cs_fc, nsl, 1.f / (float)d, cf.ln_eps, m_dev};
@@ -1142,10 +1197,11 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
         LMRL_CHECK_LAUNCH();
     }
     // ln_f of each env's last new token (optional) + len[b] += cnt[b]
-    if (d <= 1024) hipLaunchKernelGGL(final_ln_advance_kernel<4>, dim3(ceil_div(b, 4)), dim3(256), 0, s, w.x, m->lnf_g, m->lnf_b,
-                                      (uint16_t *)last_hidden_d, cnt_d, len_d, b, c, d, cf.ln_eps, off);
-    else hipLaunchKernelGGL(final_ln_advance_kernel<8>, dim3(ceil_div(b, 4)), dim3(256), 0, s, w.x, m->lnf_g, m->lnf_b,
-                            (uint16_t *)last_hidden_d, cnt_d, len_d, b, c, d, cf.ln_eps, off);
+    const float *xf = last_only ? lc_x : w.x;
+    if (d <= 1024) hipLaunchKernelGGL(final_ln_advance_kernel<4>, dim3(ceil_div(b, 4)), dim3(256), 0, s, xf, m->lnf_g, m->lnf_b,
+                                      (uint16_t *)last_hidden_d, cnt_d, len_d, b, c, d, cf.ln_eps, off, last_only ? 1 : 0);
+    else hipLaunchKernelGGL(final_ln_advance_kernel<8>, dim3(ceil_div(b, 4)), dim3(256), 0, s, xf, m->lnf_g, m->lnf_b,
+                            (uint16_t *)last_hidden_d, cnt_d, len_d, b, c, d, cf.ln_eps, off, last_only ? 1 : 0);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }
