@@ -43,6 +43,18 @@ MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md 
 HBM_PEAK_GBS = 8000.0                  # same guide: 8 TB/s spec (6.3 TB/s measured achievable)
 
 
+def csrc_digest():
+    """sha256 over every kernel source / header of the library (lmrl-gym_amd/csrc/*.hip, *.h): ties a committed PMC summary to the code it
+    was collected on (tools/pmc_fetch_write.sh records it as __meta__.csrc_digest)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "lmrl-gym_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h"))):
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()
+
+
 def scripted_guesses(vocab_words, n_eps, n_turns, batch, seed=12345):
     """[n_eps][n_turns][batch] packed guesses: uniform over the vocabulary from MT19937(seed), 10 % non-words."""
     from lmrl_gym_amd.envs import wordle as W
@@ -126,30 +138,38 @@ def cpu_baseline(vocab_words, budget_s=14.0):
                               sample=f"C oracle env alone (no LM), 2048 envs x 6 scripted steps, one thread; {te:.2f} s"))
 
 
-def main_train_step(args):
-    """`--mode ilql-step` / `--mode ppo-step`: the train step of configs[2] at the sizes SURVEY.md §8d names (M3: GPT-2-small, B = 32 x T = 512
-    per GPU; M4: B = 32 x T = 1024), fp32 (the reference's default train arithmetic) on the f32-input MFMA, synthetic ids ~ U[0, 50257) with the
-    6-on / 6-off action pattern after a 4-token header.  N > 1: pure data parallelism, every rank its own B sequences (weak scaling), ONE
-    gradient all-reduce per step overlapped with the backward pass (lmrl_gym_amd.dist.GradReducer).  `value` = sequences / s over all ranks."""
+def _dist_setup(torch):
+    """(world, rank, dev, backend, use_dist) from the launcher's environment; initialises the process group when world > 1.  RCCL ("nccl")
+    needs one GPU per rank: when a box has fewer GPUs than ranks (launch-path tests on a 1-GPU box) the ranks share GPUs and fall back to gloo."""
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    n_dev = max(torch.cuda.device_count(), 1)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % n_dev
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("LMRL_BENCH_BACKEND") or ("nccl" if n_dev >= world else "gloo")
+    use_dist = world > 1 or os.environ.get("LMRL_BENCH_FORCE_DIST") == "1"   # FORCE_DIST: 1-rank RCCL group, launch-path test
+    if use_dist:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=dev) if backend == "nccl" else dist.init_process_group(backend)
+    return world, rank, dev, backend, use_dist
+
+
+def run_train_step(mode, matmul, B, steps, warmup, dev, rank, world, use_dist, backend, measure_exposed=True):
+    """One train-step measurement (`mode` = "ilql-step" | "ppo-step") at the sizes SURVEY.md §8d names (M3: GPT-2-small, B = 32 x T = 512 per GPU;
+    M4: B = 32 x T = 1024), synthetic ids ~ U[0, 50257) with the 6-on / 6-off action pattern after a 4-token header.  N > 1: pure data
+    parallelism, every rank its own B sequences (weak scaling), ONE gradient all-reduce per step overlapped with the backward pass
+    (lmrl_gym_amd.dist.GradReducer) — ilql/gpt2/interface.py:292-324.  Returns a dict (ms_per_step, executed flops, all-reduce bytes and, for
+    N > 1, the EXPOSED all-reduce time = step with the collective - the same step without it)."""
     import torch
     import lmrl_gym_amd  # noqa: F401
-    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd import dist as D
     from lmrl_gym_amd.algorithms import ilql, ppo
     from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
     from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32, MLPHeadF32
-    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    backend = os.environ.get("LMRL_BENCH_BACKEND", "nccl")
-    use_dist = world > 1
-    if use_dist:
-        import torch.distributed as dist
-        dist.init_process_group(backend, device_id=dev) if backend == "nccl" else dist.init_process_group(backend)
     cfg = GPT2Config.gpt2_small(50258)            # +1 added <|pad|> token (train_ilql_gpt2.py:115-116)
     pad, n_params = 50257, 124.4e6
-    B = args.train_batch
-    T = 512 if args.mode == "ilql-step" else 1024
+    T = 512 if mode == "ilql-step" else 1024
     rng = np.random.RandomState(1000 + rank)
     ids = rng.randint(0, 50257, size=(B, T)).astype(np.int32)
     t = np.arange(T - 1)
@@ -157,8 +177,8 @@ def main_train_step(args):
     sd = init_hf_style_state_dict(cfg, seed=0)
     d, V = cfg.d_model, cfg.vocab
     tok = B * T
-    if args.mode == "ilql-step":
-        mmode = args.train_matmul
+    mmode = matmul
+    if mode == "ilql-step":
         base, tbase = GPT2F32(sd, cfg.n_head, device=dev, matmul=mmode), GPT2F32(sd, cfg.n_head, device=dev, matmul=mmode)
         g = torch.Generator().manual_seed(1)
         mk = lambda out, b2: MLPHeadF32({"dense1.kernel": torch.randn(d, d, generator=g) * 0.02, "dense1.bias": torch.zeros(d),
@@ -176,7 +196,6 @@ def main_train_step(args):
         flops = (6 + 2) * n_mm * tok + head_flops + 12 * 6 * 2 * T * d * tok
         workload = f"configs[2] / M3: ILQL train step, GPT-2-small fp32, B={B} x T={T} per GPU (train_ilql_gpt2.py:55-110), target base + 2 Q heads + V head; should_take_action on {100.0 * q_tok / tok:.0f} % of the tokens"
     else:
-        mmode = args.train_matmul
         pol = GPT2F32(sd, cfg.n_head, device=dev, matmul=mmode)
         head = LinearHeadF32(dict(kernel=torch.randn(d, 1) * 0.01, bias=torch.tensor([-4.1])), dev)
         tr = ppo.GPT2PPOTrain(pol, head, pad, dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0), lr=1e-5)
@@ -194,40 +213,96 @@ def main_train_step(args):
         if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
-    for _ in range(max(args.warmup, 1)):
+
+    def timed(n):
+        barrier()
+        t0 = time.perf_counter()
+        loss = None
+        for _ in range(n):
+            _, loss, _ = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if use_dist:
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        return float(tt.item()), float(loss)
+
+    for _ in range(max(warmup, 1)):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        _, loss, _ = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if use_dist:
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tt.item())
+    dt, loss = timed(steps)
+    out = dict(mode=mode, matmul=matmul, per_gpu_batch=B, seq_len=T, steps=steps, warmup=max(warmup, 1), ms_per_step=round(dt * 1e3 / steps, 2),
+               sequences_per_s=round(world * B * steps / dt, 2), executed_tflops_per_gpu=round(flops / (dt / steps) / 1e12, 1),
+               last_loss=loss, workload=workload, flops_per_step_per_gpu=flops)
+    bf = matmul == "bf16"
+    peak = MFMA_BF16_DENSE_PEAK_TFLOPS if bf else 157.3
+    out["mfma_peak_tflops"] = peak
+    out["frac"] = round(out["executed_tflops_per_gpu"] / peak, 4)
+    if world > 1:
+        out["allreduce_bytes_per_step_per_rank"] = int(D.LAST_REDUCE_BYTES)
+        out["allreduce"] = f"one in-place SUM all-reduce of the fp32 gradient arenas per step ({backend}), >=64 MB slices overlapped with the backward pass"
+        if measure_exposed:
+            D.set_grad_reduce(False)                 # timing only: same kernels, no data-path collective (ranks diverge — nothing reads the result)
+            try:
+                step()
+                dt_off, _ = timed(steps)
+            finally:
+                D.set_grad_reduce(True)
+            out["ms_per_step_without_allreduce"] = round(dt_off * 1e3 / steps, 2)
+            out["allreduce_exposed_ms"] = round((dt - dt_off) * 1e3 / steps, 2)
+    del tr, step
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def main_train_step(args):
+    """`--mode ilql-step` / `--mode ppo-step`: the train step of configs[2] as its own bench line (`value` = sequences / s over all ranks)."""
+    import torch
+    world, rank, dev, backend, use_dist = _dist_setup(torch)
+    r = run_train_step(args.mode, args.train_matmul, args.train_batch, args.steps, args.warmup, dev, rank, world, use_dist, backend)
     if rank == 0:
-        ach = flops / (dt / args.steps) / 1e12
         bf = args.train_matmul == "bf16"
+        B, T, ach = r["per_gpu_batch"], r["seq_len"], r["executed_tflops_per_gpu"]
         prec = "bf16 matmul operands, fp32 accumulation / parameters / optimizer" if bf else "fp32"
         roof = ({"bound": "mfma", "kernel": "gemm8_kernel / gemm_bf16_glds_kernel (Dense / Conv1D / head products: v_mfma_f32_16x16x32_bf16) + "
-                                            "sgemm_f32_kernel (attention products, fp32)", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                            "sgemm_f32_kernel (attention products, fp32)", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s",
                  "frac": round(ach / 2500.0, 4), "traffic": None,
                  "note": "model flops of one step / wall time of the whole step, priced against the dense bf16 MFMA peak although the attention "
                          "products and every elementwise / reduction kernel of the step stay fp32"} if bf else
-                {"bound": "mfma", "kernel": "sgemm_f32_kernel (every matmul of the step: v_mfma_f32_32x32x2_f32)", "achieved": round(ach, 1),
+                {"bound": "mfma", "kernel": "sgemm_f32_kernel (every matmul of the step: v_mfma_f32_32x32x2_f32)", "achieved": ach,
                  "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
                  "note": "model flops of one step / wall time of the whole step (lower bound for the GEMM kernel itself: 91 % of kernel time, "
                          "profiles/r01_train_kernel_stats_final.csv)"})
-        print(json.dumps({
-            "metric": f"{args.mode} sequences/sec (GPT-2-small {'bf16-matmul' if bf else 'fp32'}, B={B}, T={T})", "value": round(world * B * args.steps / dt, 2),
-            "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(dt * 1e3 / args.steps, 2),
+        line = {
+            "metric": f"{args.mode} sequences/sec (GPT-2-small {'bf16-matmul' if bf else 'fp32'}, B={B}, T={T})", "value": r["sequences_per_s"],
+            "unit": "sequences/s", "n_gpus": world, "steps": r["steps"], "warmup": r["warmup"], "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf else "f32", "data": "synthetic",
-            "config": {"workload": workload.replace("fp32", prec), "per_gpu_batch": B, "seq_len": T,
-                       "parallelism": f"dp{world}, one overlapped gradient all-reduce per step", "train_matmul": args.train_matmul, "last_loss": float(loss)},
-            "roofline": roof}), flush=True)
+            "config": {"workload": r["workload"].replace("fp32", prec), "per_gpu_batch": B, "seq_len": T,
+                       "parallelism": f"dp{world}, one overlapped gradient all-reduce per step", "train_matmul": args.train_matmul, "last_loss": r["last_loss"]},
+            "roofline": roof}
+        for k in ("allreduce_bytes_per_step_per_rank", "allreduce_exposed_ms", "ms_per_step_without_allreduce"):
+            if k in r:
+                line[k] = r[k]
+        print(json.dumps(line), flush=True)
     if use_dist:
         torch.distributed.destroy_process_group()
+
+
+def _spawn_ranks(argv, n):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: re-exec this command under torch.distributed.run, one rank per GPU
+    (RCCL), exactly as the driver's explicit launch line does.  Rank 0's JSON line passes through on stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver (RCCL / cross-process device memory)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -249,7 +324,12 @@ def main():
                     "once per episode and broadcast to all envs (bit-identical to per-env prefill); 0: prefill the header per env")
     ap.add_argument("--streams", type=int, default=1, help="split the batch into this many sub-batches on separate HIP streams")
     ap.add_argument("--breakdown", action="store_true", help="after the timed region, print a per-kernel-class event breakdown to stderr")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the `train_step` leg of the default line (ILQL M3 step, fp32 and bf16-matmul)")
+    ap.add_argument("--train-steps", type=int, default=3, help="timed steps per arithmetic mode in the `train_step` leg of the default line")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: spawn the N ranks ourselves (an external torch.distributed.run launch sets WORLD_SIZE and skips this)
+        sys.exit(_spawn_ranks(sys.argv[1:], args.gpus))
     if args.mode != "rollout":
         return main_train_step(args)
 
@@ -260,20 +340,7 @@ def main():
     from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine
     from lmrl_gym_amd.rollout import WordleRolloutEngine
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    local_rank %= max(torch.cuda.device_count(), 1)      # (lets a 1-GPU box exercise the N > 1 launch path with gloo)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    backend = os.environ.get("LMRL_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" only for launch-path tests
-    use_dist = world > 1 or os.environ.get("LMRL_BENCH_FORCE_DIST") == "1"   # FORCE_DIST: 1-rank RCCL group, launch-path test
-    if use_dist:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    world, rank, dev, backend, use_dist = _dist_setup(torch)
 
     L = _lib.lib()
     vocab = W.Vocabulary.builtin(args.vocab_file)
@@ -359,6 +426,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     L.lmrl_prof_enable(0)
+    # what a drop-in caller of `text_env_eval` pays on top of the device episode (LLM_RL/environment.py:211-267 returns HOST lists of
+    # InteractionTransition): device -> host copy of the records + building the Python objects for this rank's B envs.  Outside `value`.
+    th = time.perf_counter()
+    n_trans = sum(len(ep) for r in ros for ep in r.interactions())
+    host_materialise_ms = (time.perf_counter() - th) * 1e3
 
     ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
 
@@ -391,8 +463,15 @@ def main():
     try:
         pmc = json.load(open(os.path.join(ROOT, PROFILE_PMC)))
         key = next(k for k in pmc if ROOFLINE_KERNEL in k)
-        roofline["traffic"] = round((2.0 * pmc[key]["fetch_kb_avg"] + pmc[key]["write_kb_avg"]) * 1024)
-        roofline["traffic_unit"] = f"bytes per launch (2*FETCH_SIZE + WRITE_SIZE, {PROFILE_PMC})"
+        live = csrc_digest()
+        if pmc.get("__meta__", {}).get("csrc_digest") != live:
+            # the counters were collected on other kernel sources than the ones running now: refuse to report them as this run's traffic
+            roofline["traffic"] = None
+            roofline["traffic_note"] = (f"{PROFILE_PMC} was collected on kernel sources {str(pmc.get('__meta__', {}).get('csrc_digest'))[:12]}, "
+                                        f"live sources are {live[:12]}: stale, not reported (regenerate with tools/pmc_fetch_write.sh)")
+        else:
+            roofline["traffic"] = round((2.0 * pmc[key]["fetch_kb_avg"] + pmc[key]["write_kb_avg"]) * 1024)
+            roofline["traffic_unit"] = f"bytes per launch (2*FETCH_SIZE + WRITE_SIZE, {PROFILE_PMC}, kernel sources {live[:12]})"
         roofline["algorithmic_bytes_per_launch"] = round(work.value / max(n.value, 1))
     except Exception:
         roofline["traffic"] = None
@@ -474,12 +553,29 @@ def main():
                        "envs_per_gpu": B, "hip_streams": S, "hip_graph": bool(args.graph), "shared_header_prefill": bool(args.share_header), "max_new_tokens": 6, "parallelism": f"env-sharded x{world}, no data-path collective",
                        "env_steps_timed": n_env_steps},
             "roofline": roofline, "roofline_secondary": roofline_secondary, "roofline_step": roofline_step,
+            "host_materialise_ms": round(host_materialise_ms, 2),
+            "host_materialise_note": f"rank 0, one episode batch: device->host copy of the records + {n_trans} InteractionTransition objects built in "
+                                     "Python (what text_env_eval returns); not inside `value`, which ends on the device",
+            "value_incl_host_materialise": round(n_env_steps / (dt_max + args.steps * host_materialise_ms * 1e-3), 1),
         }
+    for r in ros:
+        r.close()
+    del ros, ro, eng
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    if not args.no_train_step:
+        # the gradient step of the path (configs[2]): ILQL M3 in the reference's default fp32 arithmetic and in its optional bf16-matmul mode;
+        # for N > 1 every rank takes part (data parallel, one gradient all-reduce per step over RCCL)
+        ts = {}
+        for mm in ("f32", "bf16"):
+            ts["ilql_" + mm] = run_train_step("ilql-step", mm, args.train_batch, args.train_steps, 1, dev, rank, world, use_dist, backend)
+        if rank == 0:
+            out["train_step"] = ts
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vocab.all_vocab)
         print(json.dumps(out), flush=True)
-    for r in ros:
-        r.close()
     if use_dist:
         torch.distributed.destroy_process_group()
 

@@ -85,7 +85,10 @@ int lmrl_wordle_reset(lmrl_wordle_ctx *ctx, void *state_d, void *mt_d, const uin
  *               bits [16,19): number of symbols (0 for an invalid action -> observation text "\n")
  *   reward_d[i] -1 / 0 (int in the reference) or bad_word_reward (game.py:290-293)
  *   flags_d[i]  bit0 done (game.py:295-296), bit1 a target was drawn (valid transition),
- *               bit2 reward is the float bad_word_reward
+ *               bit2 reward is the float bad_word_reward,
+ *               bit3 `rng.choice(filtered_vocab)` was reached with an EMPTY filtered vocabulary: the reference raises IndexError
+ *                    there (game.py:178-179, 219); the env is marked done and the Python face raises IndexError (unreachable from a
+ *                    state produced by reset/step: the sampled target always stays in its own filtered list)
  * Inactive envs: outputs untouched, state untouched.
  */
 int lmrl_wordle_step(lmrl_wordle_ctx *ctx, void *state_d, void *mt_d, const uint32_t *guess_d,
@@ -154,6 +157,12 @@ int lmrl_chess_agent_step(void *pos_d, const char *actions_d, const uint8_t *act
  * is mated, done = is_game_over(); ok_d = 0 if the move is not legal in the position */
 int lmrl_chess_opponent_step(void *pos_d, const char *uci_d, const uint8_t *active_d, float *reward_d, uint8_t *done_d, uint8_t *ok_d, char *san_out_d,
                              char *fen_out_d, int n, void *stream);
+/* board.legal_moves (+ board.san of each), board.fen(), is_check / is_checkmate / is_game_over ... of n games in one launch
+ * (env.py:157-170 random opponent `random.choice(list(board.legal_moves))`, :150-155 `is_game_over`; chess/eval move-accuracy loops):
+ * uci_out_d [n][lmrl_chess_max_moves()][8], san_out_d [n][lmrl_chess_max_moves()][LMRL_CHESS_ACTION_BYTES], count_d [n], status_d [n] with
+ * the bits of lmrl_chess_host_status, fen_out_d [n][LMRL_CHESS_FEN_BYTES]; every output is optional (NULL) */
+int lmrl_chess_max_moves(void);
+int lmrl_chess_describe(const void *pos_d, char *uci_out_d, char *san_out_d, int32_t *count_d, uint8_t *status_d, char *fen_out_d, int n, void *stream);
 /* the same rules on ONE position in host memory (CPU-tier tests, oracle comparisons; no GPU needed).  Negative return = bad argument. */
 int lmrl_chess_host_from_fen(const char *fen, void *pos);
 int lmrl_chess_host_fen(const void *pos, char *out);                                  /* -> length */

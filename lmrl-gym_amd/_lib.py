@@ -67,6 +67,8 @@ _SIGS = {
     "lmrl_chess_reset": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lmrl_chess_agent_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lmrl_chess_opponent_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_chess_max_moves": (c_int, []),
+    "lmrl_chess_describe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lmrl_chess_host_from_fen": (c_int, [ctypes.c_char_p, c_void_p]),
     "lmrl_chess_host_fen": (c_int, [c_void_p, c_void_p]),
     "lmrl_chess_host_legal_moves": (c_int, [c_void_p, c_void_p, c_void_p]),

@@ -168,8 +168,9 @@ class GPT2ILQLTrain:
                  grad_accum_steps: int = 1, polyak_alpha: float = 0.005, hard_update_every: Optional[int] = None,
                  detach_q1: bool = False, detach_q2: bool = False, detach_v: bool = False, compact_q_rows: bool = True):
         """compact_q_rows: run the two Q heads (forward and backward: six [rows, d] x [d, V] products) only on the rows the loss reads —
-        `should_take_action x attention_mask[:, 1:]` masks every Q term of `ilql_loss` (ilql/base_interface.py:22-119) — instead of on all B*T
-        rows; same loss, logs and gradients (rows outside the mask contribute exact zeros), fewer flops in proportion to the mask density."""
+        the `should_take_action` rows: the L2 terms of `ilql_loss` select by should_take_action alone, n and the CQL terms by
+        should_take_action x attention_mask (ilql/base_interface.py:22-119), so that row set covers every Q term — instead of on all B*T
+        rows; same loss, logs and gradients (rows outside the set contribute exact zeros), fewer flops in proportion to the mask density."""
         import torch
         self.compact_q_rows = compact_q_rows
         self.base, self.q1, self.q2, self.v = base, q1_head, q2_head, v_head
@@ -226,9 +227,12 @@ class GPT2ILQLTrain:
         new = lambda: torch.empty(R, dtype=torch.float32, device=dev)
         sl = lambda x: x.view(B, T)[:, :-1].contiguous()
         sta = np.asarray(should_take_action, dtype=bool)
-        # rows the Q terms of the loss read: should_take_action x attention_mask[:, 1:] (host-known).  The Q heads run on those rows only
-        # (gathered hidden states -> logits -> lse / gather; backward: dlogits -> head backward -> scatter-add into d_hidden)
-        q_mask = sta & (np.asarray(am)[:, 1:] != 0)
+        # rows the Q terms of the loss read: should_take_action (host-known).  The q1 / q2 / v L2 terms and target_q select by
+        # should_take_action ALONE (qv_query_indicators / sa_mask, base_interface.py:57-83); only n and the CQL terms also multiply by the
+        # attention mask (:48-49, :91-95) — the loss kernel applies that second mask itself, so the compacted row set must be the superset.
+        # The Q heads run on those rows only (gathered hidden states -> logits -> lse / gather; backward: dlogits -> head backward ->
+        # scatter-add into d_hidden)
+        q_mask = sta
         q_rows = masked_rows(q_mask, T)
         Ra = int(q_rows.size)
         compact = self.compact_q_rows and 0 < Ra < R

@@ -135,10 +135,11 @@ class GPT2MCTrain:
         R, base, dev, V = B * T, self.base, self.base.dev, self.q_head.dout
         ids_d = _t(ids, np.int32)
         hid, cache = base.forward(ids_d, _t(am, np.uint8), _t(pos, np.int32))
-        # the Q head runs on the rows the loss reads (should_take_action x attention_mask[:, 1:] masks every term of mc_loss) — see
+        # the Q head runs on the rows the loss reads: should_take_action (the L2 term selects by it alone — q_query_indicators / a_mask,
+        # mc_returns/base_interface.py:32-41; the CQL term and n also multiply by the attention mask, which the loss kernel applies) — see
         # GPT2ILQLTrain.compact_q_rows
         from .common import masked_rows
-        q_mask = np.asarray(should_take_action, dtype=bool) & (np.asarray(am)[:, 1:] != 0)
+        q_mask = np.asarray(should_take_action, dtype=bool)
         rows_h = masked_rows(q_mask, T)
         Ra = int(rows_h.size)
         compact = self.compact_q_rows and 0 < Ra < R

@@ -52,6 +52,27 @@ __global__ void chess_opponent_step_kernel(Pos *pos, const char *ucis, const uin
     fen(pos[e], fen_out + (size_t)e * kFen);
 }
 
+// board.legal_moves / board.san / board.fen / is_check ... for every game at once: what the env's random opponent, the move-accuracy
+// evaluators and the parity tests read.  One game per lane; the move list goes out as fixed-pitch strings.
+__global__ void chess_describe_kernel(const Pos *pos, char *uci_out, char *san_out, int32_t *count, uint8_t *status, char *fen_out, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const Pos &p = pos[e];
+    Move mv[kMaxMoves];
+    const int k = gen_legal(p, mv);
+    if (count) count[e] = k;
+    for (int i = 0; i < k; i++) {
+        if (uci_out) uci(mv[i], uci_out + ((size_t)e * kMaxMoves + i) * 8);
+        if (san_out) san(p, mv[i], san_out + ((size_t)e * kMaxMoves + i) * kAct);
+    }
+    if (status) {
+        const bool chk = in_check(p, p.stm);
+        status[e] = (uint8_t)((chk ? 1 : 0) | ((chk && !k) ? 2 : 0) | (is_game_over(p) ? 4 : 0) | (is_insufficient_material(p) ? 8 : 0) |
+                              ((!chk && !k) ? 16 : 0) | (is_repetition(p, 5) ? 32 : 0) | (p.halfmove >= 150 ? 64 : 0));
+    }
+    if (fen_out) fen(p, fen_out + (size_t)e * kFen);
+}
+
 }  // namespace lmrl
 
 using namespace lmrl;
@@ -81,6 +102,16 @@ int lmrl_chess_opponent_step(void *pos_d, const char *uci_d, const uint8_t *acti
     LMRL_REQUIRE(pos_d && uci_d && reward_d && done_d && ok_d && san_out_d && fen_out_d && n > 0, "lmrl_chess_opponent_step: bad argument");
     hipLaunchKernelGGL(chess_opponent_step_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, as_stream(stream), (Pos *)pos_d, uci_d, active_d, reward_d, done_d,
                        ok_d, san_out_d, fen_out_d, n);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_chess_max_moves(void) { return kMaxMoves; }
+
+int lmrl_chess_describe(const void *pos_d, char *uci_out_d, char *san_out_d, int32_t *count_d, uint8_t *status_d, char *fen_out_d, int n, void *stream) {
+    LMRL_REQUIRE(pos_d && n > 0 && (uci_out_d || san_out_d || count_d || status_d || fen_out_d), "lmrl_chess_describe: bad argument");
+    hipLaunchKernelGGL(chess_describe_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, as_stream(stream), (const Pos *)pos_d, uci_out_d, san_out_d, count_d,
+                       status_d, fen_out_d, n);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

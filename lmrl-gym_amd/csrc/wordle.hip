@@ -75,7 +75,14 @@ __global__ __launch_bounds__(256) void wordle_step_kernel(const uint32_t *__rest
             if (__any(w == g)) { member = true; break; }
         }
     }
-    const bool valid = shaped && (member || !require) && nfilt > 0;   // goes through transition_state
+    // game.py:214-219: a well-formed action (in the vocabulary when required) goes through `rng.choice(filtered_vocab)`.  On an EMPTY
+    // filtered vocabulary the reference raises IndexError there (random.choice([]), game.py:178-179).  The state can not get there: the
+    // sampled target always satisfies the state it produces (HERE only where it matches, NOT_HERE where it differs, all-NOT_HERE only for
+    // letters it lacks), so the target itself stays in the filtered list.  Should a corrupted state arrive here anyway, the step does not
+    // silently diverge: flag bit 8 is raised, the env is finished, and the host wrappers raise IndexError like the reference.
+    const bool would_choose = shaped && (member || !require);
+    const bool empty_choice = would_choose && nfilt == 0;
+    const bool valid = would_choose && nfilt > 0;                      // goes through transition_state
     const bool bad_word = !(shaped && member);                        // reward() first clause (game.py:291-292)
 
     uint32_t new_nfilt = nfilt;
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256) void wordle_step_kernel(const uint32_t *__rest
         st[(size_t)ROW_NACT * n + e] = new_nact;
         obs[e] = o;
         reward[e] = rew;
-        flags[e] = (uint8_t)((done ? 1 : 0) | (valid ? 2 : 0) | (bad_word ? 4 : 0));
+        flags[e] = (uint8_t)(((done || empty_choice) ? 1 : 0) | (valid ? 2 : 0) | (bad_word ? 4 : 0) | (empty_choice ? 8 : 0));
     }
 }
 

@@ -80,6 +80,17 @@ def allreduce_grads(grad_dicts: Sequence[Dict[str, "torch.Tensor"]], bucket_byte
     return n_coll
 
 
+# bench-only switch: with the gradient reduction off, a data-parallel step runs the same kernels without the data-path collective, so
+# `bench.py` can report the EXPOSED all-reduce time (step with - step without).  Never off in a real run: ranks would diverge.
+_GRAD_REDUCE_ENABLED = True
+LAST_REDUCE_BYTES = 0          # bytes handed to the gradient all-reduce by the most recent GradReducer.finish() (per rank)
+
+
+def set_grad_reduce(enabled: bool) -> None:
+    global _GRAD_REDUCE_ENABLED
+    _GRAD_REDUCE_ENABLED = bool(enabled)
+
+
 class GradReducer:
     """Overlaps the data-parallel gradient all-reduce with the backward pass.  `GPT2F32.backward(..., on_final=reducer.ready(arena))`
     reports parameter groups whose gradients are final (ln_f, then block after block, then the embeddings — the arena is laid out in that
@@ -89,7 +100,7 @@ class GradReducer:
 
     def __init__(self, bucket_bytes: int = 64 << 20, group=None):
         self.bucket_bytes, self.group = bucket_bytes, group
-        self.works, self.n_coll = [], 0
+        self.works, self.n_coll, self.n_bytes = [], 0, 0
         self._arena, self._lo, self._hi = None, 0, 0
 
     def _flush(self):
@@ -98,11 +109,12 @@ class GradReducer:
             if w is not None:
                 self.works.append(w)
             self.n_coll += 1
+            self.n_bytes += (self._hi - self._lo) * self._arena.flat.element_size()
             self._lo = self._hi
 
     def ready(self, arena):
         """The `on_final` callback for one arena."""
-        if not is_distributed():
+        if not is_distributed() or not _GRAD_REDUCE_ENABLED:
             return None
         self._arena, self._lo, self._hi = arena, 0, 0
 
@@ -115,15 +127,20 @@ class GradReducer:
         return on_final
 
     def finish(self, more: Sequence[Dict[str, "torch.Tensor"]] = ()):
-        if not is_distributed():
+        global LAST_REDUCE_BYTES
+        if not is_distributed() or not _GRAD_REDUCE_ENABLED:
             return 0
         if self._arena is not None:
             self._hi = self._arena.flat.numel()              # whatever has not been handed over yet (normally the last partial bucket)
             self._flush()
         self.n_coll += allreduce_grads(more, group=self.group)
+        for d in more:
+            flat = getattr(d, "flat", None)
+            self.n_bytes += flat.numel() * flat.element_size() if flat is not None else sum(g.numel() * g.element_size() for g in d.values())
         for w in self.works:
             w.wait()
         self.works = []
+        LAST_REDUCE_BYTES = self.n_bytes
         return self.n_coll
 
 

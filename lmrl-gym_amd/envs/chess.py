@@ -49,14 +49,30 @@ def postprocess_state(state: str) -> str:
 
 
 # ----------------------------------------------------------------------------- opponent engines
+def normalise_uci_options(options: Optional[Dict[str, Union[str, int]]]) -> Dict[str, Union[str, int]]:
+    """What the python `stockfish` package the reference goes through (env.py:55-57: `Stockfish(path, parameters={"Threads", "UCI_Elo"})`)
+    does in `update_engine_parameters`: when exactly one of {"Skill Level", "UCI_Elo"} is given without an explicit "UCI_LimitStrength", it
+    sets UCI_LimitStrength itself — "true" for UCI_Elo (Stockfish ignores UCI_Elo otherwise and would play at full strength), "false" for
+    Skill Level.  The switch is sent BEFORE the value it enables."""
+    opts = dict(options or {})
+    if (("Skill Level" in opts) != ("UCI_Elo" in opts)) and "UCI_LimitStrength" not in opts:
+        limit = "true" if "UCI_Elo" in opts else "false"
+        opts = {"UCI_LimitStrength": limit, **opts}
+    elif "UCI_LimitStrength" in opts:
+        opts = {"UCI_LimitStrength": opts.pop("UCI_LimitStrength"), **opts}
+    return opts
+
+
 class UCIEngine:
     """One UCI engine process (Stockfish).  Stateless between calls: every query sends `position fen <start> moves ...`."""
 
     def __init__(self, path: str, options: Optional[Dict[str, Union[str, int]]] = None):
         self.p = subprocess.Popen([path], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, bufsize=1)
         self._cmd("uci", "uciok")
-        for k, v in (options or {}).items():
-            self._send(f"setoption name {k} value {v}")
+        self.sent_options = []
+        for k, v in normalise_uci_options(options).items():
+            self.sent_options.append(f"setoption name {k} value {v}")
+            self._send(self.sent_options[-1])
         self._cmd("isready", "readyok")
 
     def _send(self, s: str):
@@ -178,6 +194,25 @@ class VectorChessBoards:
         return (self._unpack(self.san_out, ACTION_BYTES), self.reward.cpu().numpy().copy(), self.done.cpu().numpy().astype(bool),
                 self._unpack(self.fen_out, FEN_BYTES))
 
+    def describe(self, want_san: bool = True):
+        """Every game's legal moves (UCI [+ SAN]), status bits (bit0 check, bit1 checkmate, bit2 game over, bit3 insufficient material,
+        bit4 stalemate, bit5 fivefold, bit6 75-move) and FEN, generated on the device in one launch (`lmrl_chess_describe`).
+        -> (moves: List[List[(uci, san)]], status: np.uint8[n], fens: List[str])"""
+        t, n, L = self.t, self.n, self.L
+        mm = L.lmrl_chess_max_moves()
+        uci = t.zeros(n * mm * 8, dtype=t.uint8, device=self.dev)
+        san = t.zeros(n * mm * ACTION_BYTES, dtype=t.uint8, device=self.dev) if want_san else None
+        cnt = t.zeros(n, dtype=t.int32, device=self.dev)
+        status = t.zeros(n, dtype=t.uint8, device=self.dev)
+        _lib.check(L.lmrl_chess_describe(_lib.ptr(self.pos), _lib.ptr(uci), _lib.ptr(san), _lib.ptr(cnt), _lib.ptr(status), _lib.ptr(self.fen_out), n,
+                                         _lib.stream_ptr()), "lmrl_chess_describe")
+        cnt_h = cnt.cpu().numpy()
+        u = uci.cpu().numpy().reshape(n, mm, 8)
+        sn = san.cpu().numpy().reshape(n, mm, ACTION_BYTES) if want_san else None
+        cut = lambda row: row.tobytes().split(b"\0")[0].decode("ascii")
+        moves = [[(cut(u[i, j]), cut(sn[i, j]) if want_san else "") for j in range(int(cnt_h[i]))] for i in range(n)]
+        return moves, status.cpu().numpy().copy(), self._unpack(self.fen_out, FEN_BYTES)
+
     def host_position(self, i: int) -> ctypes.Array:
         """Host copy of game i's position (for the host faces of the rules: legal move lists for the random opponent)."""
         nb = self.L.lmrl_chess_pos_bytes()
@@ -237,9 +272,10 @@ class VectorChessEnv(BatchedTextEnv):
             for i in idx:
                 self.moves[i].append(played[i])                    # the engine follows the game as UCI moves (env.py:121)
             if self.random_opponent:
+                all_moves, _, _ = self.boards.describe(want_san=False)         # list(board.legal_moves) of every game, one device launch
                 replies = []
                 for i in idx:
-                    lm = self.boards.legal_moves(i)
+                    lm = all_moves[i]
                     replies.append(lm[int(np.random.choice(len(lm), 1)[0])][0])          # np.random.choice(legal_moves, 1)[0]   env.py:178
             else:
                 replies = self.engine.best_moves([(self.starts[i], self.moves[i]) for i in idx])

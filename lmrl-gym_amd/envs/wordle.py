@@ -215,6 +215,8 @@ class VectorWordleEnv(BatchedTextEnv):
         obs = self.obs.cpu().numpy().view(np.uint32)
         rew = self.reward.cpu().numpy()
         flg = self.flags.cpu().numpy()
+        if (flg[active > 0] & 8).any():     # random.choice([]) in the reference (game.py:178-179, 219): same exception type, same place
+            raise IndexError("Cannot choose from an empty sequence (filtered vocabulary is empty)")
         out = []
         for i in range(self.n):
             if not active[i]:

@@ -150,6 +150,7 @@ class MazeRolloutEngine:
         self.epoch = z(1, dt=t.int32)                  # 4th Philox counter word: episode base + turn (device side: graph replays advance it)
         self.env._alloc(batch)
         self.turn_graph = None
+        self.episodes = 0                              # episode batches run by text_env_eval so far: successive calls draw fresh sampler noise
         if prefix_cache:
             self.refresh_prefix_cache()
 
@@ -166,6 +167,7 @@ class MazeRolloutEngine:
         t = torch
         n, cap = self.obs_tok_h.shape
         self.caches = []
+        self.turn_graph = None      # a captured turn replays attach_prefix_from against the OLD cache sessions: never keep it across a refresh
         lens = t.from_numpy(self.obs_len_h).to(self.dev)
         for e in self.engines:
             ses = e.session(n, cap)
@@ -321,17 +323,18 @@ class MazeRolloutEngine:
     def text_env_eval(self, n_rollouts: int, seed_generator=None, env_options=None, temperature: float = 1.0, top_k: int = 0,
                       sample_seed: int = 0, interaction_callback=None, use_graph: bool = True):
         """`text_env_eval(env, policy, n_rollouts, bsize=B, env_options=...)` (LLM_RL/environment.py:211-267) with the whole lock-step
-        loop on the device: ceil(n / B) episode batches, the same (interactions, summary) return value."""
+        loop on the device: ceil(n / B) episode batches, the same (interactions, summary) return value.  The sampler's episode word keeps
+        counting across calls (`self.episodes`, as GPT2PPOPolicy splits its PRNG key on every act(), ppo/gpt2/interface.py:524-526): two PPO
+        rounds with the same `sample_seed` do not replay the same noise."""
         inter, rewards, dones, lengths = [], [], [], []
-        batch_id = 0
         while len(inter) < n_rollouts:
             actual = min(n_rollouts - len(inter), self.B)
             seeds = [0] * self.B
             seeds[:actual] = [next(seed_generator) for _ in range(actual)] if seed_generator is not None else \
                 np.random.randint(0, 2 ** 31 - 1, size=actual).tolist()
             options = [env_options] * self.B if env_options is not None else None
-            self.run_episode(seeds, options, temperature=temperature, top_k=top_k, sample_seed=sample_seed, episode=batch_id, use_graph=use_graph)
-            batch_id += 1
+            self.run_episode(seeds, options, temperature=temperature, top_k=top_k, sample_seed=sample_seed, episode=self.episodes, use_graph=use_graph)
+            self.episodes += 1
             for ep in self.interactions()[:actual]:
                 inter.append(ep)
                 rewards.append(sum(t.reward for t in ep)); dones.append(ep[-1].done); lengths.append(len(ep))

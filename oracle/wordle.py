@@ -68,6 +68,8 @@ class OracleWordleEnv:
         ol, ri, dn = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         rw = ctypes.c_double()
         self._L.orc_wordle_step(self._h, raw, n, obs, ctypes.byref(ol), ctypes.byref(rw), ctypes.byref(ri), ctypes.byref(dn))
+        if ol.value < 0:
+            raise IndexError("Cannot choose from an empty sequence")     # random.choice([]) (game.py:178-179)
         sym = obs.raw[: ol.value].decode("ascii")
         reward = int(rw.value) if ri.value else float(rw.value)
         return text_history + ((reformat_obs(sym), False),), reward, bool(dn.value)

@@ -215,7 +215,8 @@ void orc_wordle_step(orc_wordle *g, const char *action, int len, char *obs_out, 
         g->last_valid = 0;
         *obs_len = 0;
     } else {
-        /* game.py:219-221 */
+        /* game.py:219-221; random.choice([]) raises IndexError in the reference: reported as *obs_len = -1 (the Python face raises) */
+        if (g->n_filtered == 0) { *obs_len = -1; *reward = 0.0; *reward_is_int = 1; *done = 1; return; }
         uint32_t r = orc_mt_randbelow(&g->rng, (uint32_t)g->n_filtered);
         const char *target = g->words + (size_t)g->filtered[r] * NCH;
         /* WordleState.transition_state (game.py:82-92) */

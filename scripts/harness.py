@@ -272,7 +272,10 @@ def cmd_filtered_bc(a):
     vocab, env = _wordle_env(a)
     bs = BlockingStrategy(Padding.RIGHT, Truncation.LEFT, a.max_input_length + a.max_output_length)
     step = 0
+    limit = None if a.max_steps is None else int(a.max_steps)
     for rnd in range(a.n_rounds):
+        if limit is not None and step >= limit:      # the step budget ends the run: no further rollouts, epochs or rounds
+            break
         if a.device_rollouts:
             ro = _device_rollouts(policy.engine, vocab, tok, a.rollout_bsize, a.bad_word_reward, min(a.max_output_length, 12))
             raw, summary = ro.text_env_eval(a.n_rollouts, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)), temperature=a.policy_temperature or 1.0,
@@ -289,11 +292,13 @@ def cmd_filtered_bc(a):
             continue
         ds = DS.MaskDataset.blocked_from_str_segments([segs[i] for i in top], tok, bs)
         for epoch in range(a.epochs):
+            if limit is not None and step >= limit:
+                break
             for batch in DS.dataloader(np.random.default_rng(rnd * 1000 + epoch), ds, min(a.train_bsize, len(ds)), truncate=True):
                 _, loss, _ = tr.step(batch["input_ids"], batch["input_training_mask"] > 0)
                 step += 1
                 _log("train", dict(step=step, round=rnd, loss=loss))
-                if a.max_steps is not None and step >= int(a.max_steps):
+                if limit is not None and step >= limit:
                     break
         policy.set_params(_engine(cfg, model.p))
     _, summary = E.text_env_eval(env, policy, n_rollouts=a.n_rollouts, bsize=a.rollout_bsize, seed_generator=iter(range(10 ** 8, 10 ** 9)), verbose=False)

@@ -243,3 +243,21 @@ def test_parse_san_never_misbehaves_on_arbitrary_text():
                 assert (rew, done) == (-1.0, 0) and b.fen() == fen
                 assert text not in sans
     assert n_ok >= 1 and n_bad > 8000
+
+
+def test_engine_options_limit_strength_like_the_stockfish_package():
+    """the reference reaches Stockfish through the python `stockfish` package, whose update_engine_parameters turns
+    UCI_LimitStrength on when only UCI_Elo is given (env.py:55-57) — without it Stockfish ignores UCI_Elo and plays at full strength."""
+    from lmrl_gym_amd.envs import chess as C
+    o = C.normalise_uci_options({"Threads": 1, "UCI_Elo": 1200})
+    assert list(o.items()) == [("UCI_LimitStrength", "true"), ("Threads", 1), ("UCI_Elo", 1200)]        # the switch goes out first
+    assert C.normalise_uci_options({"Skill Level": 3})["UCI_LimitStrength"] == "false"
+    assert "UCI_LimitStrength" not in C.normalise_uci_options({"Threads": 2})
+    assert "UCI_LimitStrength" not in C.normalise_uci_options({"Skill Level": 3, "UCI_Elo": 1500})      # both given: the package leaves it alone
+    assert list(C.normalise_uci_options({"UCI_Elo": 1500, "UCI_LimitStrength": "false"}).items())[0] == ("UCI_LimitStrength", "false")
+    from oracle import stockfish_uci as S
+    if S.available():
+        eng = C.UCIEngine(S.BINARY, {"Threads": 1, "UCI_Elo": 1350, "Use NNUE": "false"})
+        assert eng.sent_options[0] == "setoption name UCI_LimitStrength value true" and "setoption name UCI_Elo value 1350" in eng.sent_options
+        assert len(eng.best_move_time(START, [], 10)) in (4, 5)
+        eng.close()

@@ -111,3 +111,25 @@ def test_single_process_is_a_no_op():
     g = [{"w": torch.ones(3)}]
     assert D.allreduce_grads(g) == 0 and torch.equal(g[0]["w"], torch.ones(3))
     assert D.shard_range(10, 0, 1) == (0, 10)
+
+
+def test_bench_spawn_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher environment re-execs itself under torch.distributed.run with N ranks on 127.0.0.1
+    (the driver's own N > 1 line); with WORLD_SIZE set (external launcher) it must not spawn again."""
+    import importlib
+    import subprocess
+    bench = importlib.import_module("bench")
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    assert bench._spawn_ranks(["--gpus", "4", "--steps", "3"], 4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # launcher environment present -> main() goes straight to the rank code (which needs a GPU): _spawn_ranks must not be called
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setattr(bench, "_spawn_ranks", lambda *a: (_ for _ in ()).throw(AssertionError("spawned twice")))
+    monkeypatch.setattr(bench, "main_train_step", lambda args: "rank code")
+    monkeypatch.setattr("sys.argv", ["bench.py", "--gpus", "4", "--mode", "ilql-step"])
+    assert bench.main() == "rank code"

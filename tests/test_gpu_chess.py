@@ -46,6 +46,95 @@ class ScriptedChessPolicy:
         return out
 
 
+def test_device_rules_equal_reference_stockfish_fixtures():
+    """The DEVICE kernels against the oracle directly: all positions of tests/golden/chess_perft.json — legal move sets
+    (`go perft 1`), positions (`d`) and check flags produced by the Stockfish 15.1 built from the reference's own sources — are walked on the
+    device, every game of the fixture in lock step: `lmrl_chess_describe` (legal moves, FEN, status) and `lmrl_chess_opponent_step` (the
+    fixture's move, SAN + FEN out).  Then the SAN layer on the device: every legal move's SAN, fed to `lmrl_chess_agent_step` on a fresh
+    copy of its position, must play exactly that move (SAN -> move is python-chess behaviour and has no oracle here: round trip only)."""
+    import json
+    from test_chess_rules import _same_position
+    from lmrl_gym_amd.envs import chess as C
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chess_perft.json")))
+    games = fx["games"]
+    G = len(games)
+    boards = C.VectorChessBoards()
+    boards.reset([g["fen"] for g in games])
+    n_pos = n_check = n_mate = 0
+    san_cases = []                      # (fen of the position as the DEVICE prints it, san, uci)
+    t = 0
+    while True:
+        live = [len(g["steps"]) > t for g in games]
+        if not any(live):
+            break
+        moves, status, fens = boards.describe()
+        ucis = [""] * G
+        for i, g in enumerate(games):
+            if not live[i]:
+                continue
+            step = g["steps"][t]
+            assert sorted(u for u, _ in moves[i]) == step["legal"], (g["fen"], t, step["fen"])
+            _same_position(fens[i], step["fen"], step["legal"])
+            assert bool(status[i] & 1) == step["check"], (step["fen"], status[i])
+            assert bool(status[i] & 2) == (step["check"] and not step["legal"])
+            assert bool(status[i] & 16) == ((not step["check"]) and not step["legal"])
+            n_pos += 1; n_check += step["check"]; n_mate += bool(status[i] & 2)
+            san_cases += [(fens[i], sn, u) for u, sn in moves[i]]
+            if step["move"] is None:
+                assert not moves[i] or (status[i] & 4)
+                live[i] = False
+            else:
+                ucis[i] = step["move"]
+        if not any(live):
+            break
+        sans, _, dones, _ = boards.opponent_step(ucis, live)            # raises if the device rejects a fixture move
+        for i, g in enumerate(games):
+            if live[i]:
+                nxt = g["steps"][t + 1] if t + 1 < len(g["steps"]) else None
+                expect = dict(moves[i])[ucis[i]]
+                assert sans[i] == expect                              # board.san(move) of the step == the SAN listed for that move
+                if nxt is not None:                                   # '+' / '#' suffix == the oracle's check flag of the next position
+                    assert sans[i].endswith(("+", "#")) == nxt["check"], (sans[i], nxt["fen"])
+                    assert sans[i].endswith("#") == (nxt["check"] and not nxt["legal"])
+        t += 1
+    assert n_pos == sum(len(g["steps"]) for g in games) >= 2500 and n_check > 50
+    # illegal candidates are rejected: for a sample of positions, every from-to pair that is NOT in the oracle's list
+    rng = random.Random(5)
+    sample = rng.sample([(g["fen"], st) for g in games for st in g["steps"]], 40)
+    sq = [f + r for f in "abcdefgh" for r in "12345678"]
+    cand, expect = [], []
+    for _, st in sample:
+        legal = set(st["legal"])
+        for a in sq:
+            for b in sq:
+                if a != b:
+                    for promo in ("", "q", "n"):
+                        u = a + b + promo
+                        if promo and not (a[1] in "27" and b[1] in "18"):
+                            continue
+                        cand.append((st["fen"], u)); expect.append(u in legal)
+    vb = C.VectorChessBoards()
+    vb.reset([f for f, _ in cand])
+    n = len(cand)
+    act = torch.ones(n, dtype=torch.uint8, device=vb.dev)
+    from lmrl_gym_amd import _lib
+    _lib.check(vb.L.lmrl_chess_opponent_step(_lib.ptr(vb.pos), _lib.ptr(vb._strings([u for _, u in cand], 8)), _lib.ptr(act), _lib.ptr(vb.reward),
+                                             _lib.ptr(vb.done), _lib.ptr(vb.ok), _lib.ptr(vb.san_out), _lib.ptr(vb.fen_out), n, _lib.stream_ptr()))
+    ok = vb.ok.cpu().numpy().astype(bool)
+    bad = [cand[i] for i in range(n) if ok[i] != expect[i]]
+    assert not bad, bad[:5]
+    assert sum(expect) > 800 and n > 150000
+    # SAN round trip on the device, every legal move of every fixture position
+    vb = C.VectorChessBoards()
+    vb.reset([f for f, _, _ in san_cases])
+    res, rew, dn, _, played = vb.agent_step([sn for _, sn, _ in san_cases], [True] * len(san_cases))
+    assert len(san_cases) > 50000
+    wrong = [san_cases[i] + (played[i],) for i in range(len(san_cases)) if played[i] != san_cases[i][2] or res[i] not in (C.MOVED, C.GAME_OVER)]
+    assert not wrong, wrong[:5]
+    mates = [i for i in range(len(san_cases)) if san_cases[i][1].endswith("#")]
+    assert all(res[i] == C.GAME_OVER and rew[i] == 1.0 and dn[i] for i in mates)
+
+
 def test_batched_env_equals_host_rules_random_opponent():
     from test_chess_rules import Board
     from lmrl_gym_amd import environment as E

@@ -190,3 +190,29 @@ def test_two_ranks_half_batch_equal_one_rank_full_batch(tmp_path):
     ret = mgr.dict()
     mp.spawn(_dp_worker, args=(2, port, path, ret), nprocs=2, join=True)
     assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+
+
+def test_bench_gpus_2_spawns_two_ranks_and_reports_the_train_step():
+    """the plain driver command `python bench.py --gpus 2 ...` must itself launch 2 ranks (torch.distributed.run, one
+    process per GPU; on this 1-GPU tier the ranks share the GPU and the group falls back to gloo) and rank 0 must print ONE JSON line with
+    n_gpus = 2 whose `train_step` object carries the ILQL step with its gradient all-reduce (bytes, exposed time)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "64",
+                        "--train-batch", "2", "--train-steps", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["envs_per_gpu"] == 64
+    assert out["config"]["env_steps_timed"] >= 2 * 64            # both ranks' env steps are summed
+    ts = out["train_step"]
+    for k in ("ilql_f32", "ilql_bf16"):
+        assert ts[k]["ms_per_step"] > 0 and np.isfinite(ts[k]["last_loss"])
+        # base transformer + two Q heads + V head, fp32: the ONE data-path collective of the step
+        assert ts[k]["allreduce_bytes_per_step_per_rank"] > 4 * 124e6
+        assert "allreduce_exposed_ms" in ts[k]

@@ -4,7 +4,7 @@
 # gfx950 FETCH_SIZE x2 correction is applied by the reader, not here).
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python /root/repo/bench.py --graph 0 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || echo "pass $c failed/timeout"
+  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python /root/repo/bench.py --graph 0 --steps 1 --warmup 1 --no-cpu-baseline --no-train-step > /dev/null 2>&1 || echo "pass $c failed/timeout"
 done
 python - <<'PY'
 import csv, glob, json, collections
@@ -21,7 +21,12 @@ for c, key in (("FETCH_SIZE", "fetch_kb_avg"), ("WRITE_SIZE", "write_kb_avg")):
         agg[k] += float(r["Counter_Value"]); n[k] += 1
     for k in agg:
         out[k]["launches"] = n[k]; out[k][key] = agg[k] / n[k]
+import sys
+sys.path.insert(0, "/root/repo")
+import bench
+out["__meta__"] = {"csrc_digest": bench.csrc_digest(), "command": "bench.py --graph 0 --steps 1 --warmup 1 --no-cpu-baseline --no-train-step"}
 json.dump(out, open("/root/repo/gpurun_out/pmc_fetch_write.json", "w"), indent=1)
+out.pop("__meta__")
 for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("fetch_kb_avg", 0) * kv[1].get("launches", 0))[:10]:
     print("%-60s n=%5d fetch %10.1f KB  write %10.1f KB" % (k, v.get("launches", 0), v.get("fetch_kb_avg", -1), v.get("write_kb_avg", -1)))
 PY
