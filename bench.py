@@ -356,7 +356,7 @@ def main():
         with torch.cuda.stream(st):
             ros.append(WordleRolloutEngine(eng, vocab, Bs, max_new_tokens=6, bad_word_reward=-10.0, share_header=bool(args.share_header)))
     ro = ros[0]
-    n_eps = args.steps + args.warmup + (1 if args.breakdown else 0)
+    n_eps = max(args.steps, 2) + args.warmup + (1 if args.breakdown else 0)      # (the roofline leg replays episodes warmup .. warmup + 1 eagerly)
     guesses = torch.from_numpy(scripted_guesses(vocab.all_vocab, n_eps, n_turns, B, seed=12345 + rank).view(np.int32)).to(dev)
     guesses_s = [guesses[:, :, k * Bs:(k + 1) * Bs].contiguous() for k in range(S)]
     # env seeds of every episode resident in HBM up front: no host->device copy (= host sync) between episodes

@@ -323,7 +323,19 @@ typedef struct {
     const uint32_t *epoch_d;/* optional DEVICE word = 4th Philox counter word (0 when NULL): fresh noise per hipGraph replay */
     float top_p;            /* nucleus mass in (0, 1); <= 0 or >= 1 = off.  Applied after temperature and top_k (HF warper order):
                              * the smallest prefix of the descending-sorted tokens whose cumulative probability reaches top_p */
+    int32_t rng;            /* LMRL_RNG_PHILOX (0, default): the package's own counter stream above.
+                             * LMRL_RNG_JAX: the stream of `jax.random.categorical(key, logits[m, vocab])` as HF-Flax `_sample` calls it for the
+                             * reference (ppo/gpt2/interface.py:524-535): `seed` = the call's PRNG key, (key[0] << 32) | key[1]; Gumbel word of
+                             * (row, column) = element row * vocab + column of jax.random.gumbel(key, (m * vocab,)) — threefry2x32-20 over the
+                             * iota split in halves (csrc/threefry.h); logits / temperature by division; `step` and `epoch_d` are unused (the
+                             * caller walks the key schedule: lmrl_gym_amd/jax_prng.py).  All m rows of the call form ONE noise array. */
 } lmrl_sample_params;
+#define LMRL_RNG_PHILOX 0
+#define LMRL_RNG_JAX 1
+/* host faces of the LMRL_RNG_JAX stream: the Threefry-2x32 (20 rounds) block function and words [i0, i0 + count) of
+ * jax.random.bits(key, (n,), uint32) — for known-answer tests without a GPU */
+void lmrl_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]);
+int lmrl_jax_random_bits_host(const uint32_t key[2], uint32_t n, uint32_t i0, uint32_t count, uint32_t *out);
 
 size_t lmrl_sample_ws_bytes(int m, int vocab_padded);
 /* hidden_d bf16 [m][d] . wte_d bf16 [vocab_padded][d]^T -> token_d[m] (+ logprob_d[m] under the sampling

@@ -18,6 +18,7 @@
 #include "../../include/lmrl_amd.h"
 #include "common.h"
 #include "gemm_dispatch.h"
+#include "threefry.h"
 
 namespace lmrl {
 
@@ -49,8 +50,17 @@ __device__ __forceinline__ float gumbel_from_bits(uint32_t x) {
     return -0.6931471805599453f * __builtin_amdgcn_logf(e);                   // -ln(-ln u)
 }
 
+// Gumbel(0,1) word of the LMRL_RNG_JAX stream: element i of jax.random.gumbel(key, (n,)) — accurate logf (the fast log of the Philox
+// path is a 1-ulp-class approximation; this mode exists to match another implementation's draws, not to be fast)
+__device__ __forceinline__ float gumbel_jax(uint32_t k0, uint32_t k1, uint32_t i, uint32_t n) {
+    return -logf(-logf(jax_uniform_open(jax_random_word(k0, k1, i, n))));
+}
+
 struct SampleParams {
     float inv_temperature;   // 1/T ; greedy when `greedy` != 0
+    float temperature;       // T (LMRL_RNG_JAX divides, as the TemperatureLogitsWarper does)
+    int rng;                 // LMRL_RNG_PHILOX / LMRL_RNG_JAX
+    uint32_t jax_n;          // LMRL_RNG_JAX: total words of the noise array = rows * vocab (the shape of the logits handed to categorical)
     int greedy;
     uint32_t seed_lo, seed_hi, step;
     const uint32_t *epoch;   // optional device word used as the 4th Philox counter word (lets a captured hipGraph draw fresh noise per replay)
@@ -80,7 +90,7 @@ __device__ __forceinline__ void merge_partial(RowPartial &a, float om, float os,
     if (ob > a.best || (ob == a.best && oc < a.best_col)) { a.best = ob; a.best_col = oc; a.best_z = oz; }
 }
 
-template <int NOPS, bool WANT_LP>
+template <int NOPS, bool WANT_LP, bool JAX = false>
 __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const uint16_t *__restrict__ A0, const uint16_t *__restrict__ W0,
                                                              const uint16_t *__restrict__ A1, const uint16_t *__restrict__ W1,
                                                              const float *__restrict__ bias1,
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const
         for (int i = 0; i < FN; i++) {
             const int n = n0 + wn * TN + i * 16 + lq * 4;
             uint32_t rnd[4] = {0, 0, 0, 0};
-            if (!sp.greedy) philox4x32_10((uint32_t)m, (uint32_t)(n >> 2), sp.step, epoch, sp.seed_lo, sp.seed_hi, rnd);
+            if (!JAX && !sp.greedy) philox4x32_10((uint32_t)m, (uint32_t)(n >> 2), sp.step, epoch, sp.seed_lo, sp.seed_hi, rnd);
             float zz[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -159,8 +169,14 @@ __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const bool colok = (n + r) < sp.vocab;
-                const float v = colok ? zz[r] * sp.inv_temperature : -INFINITY;
-                const float sc = sp.greedy ? v : v + gumbel_from_bits(rnd[r]);
+                float v, sc;
+                if (JAX) {      // jax.random.categorical(key, logits / T): key = (seed_hi, seed_lo), word index = row * V + column
+                    v = colok ? zz[r] / sp.temperature : -INFINITY;
+                    sc = (sp.greedy || !colok || m >= M) ? v : v + gumbel_jax(sp.seed_hi, sp.seed_lo, (uint32_t)m * (uint32_t)sp.vocab + (uint32_t)(n + r), sp.jax_n);
+                } else {
+                    v = colok ? zz[r] * sp.inv_temperature : -INFINITY;
+                    sc = sp.greedy ? v : v + gumbel_from_bits(rnd[r]);
+                }
                 const bool take = sc > rp.best;                 // a padding column scores -inf and never wins; selects, not branches
                 rp.best = take ? sc : rp.best; rp.best_col = take ? n + r : rp.best_col; rp.best_z = take ? v : rp.best_z;
                 vv[i][r] = v;
@@ -358,15 +374,17 @@ __global__ __launch_bounds__(256) void topk_sample_kernel(const float *__restric
     int best_col = 0x7fffffff;
     for (int n4 = tid * 4; n4 < vocab; n4 += 256 * 4) {
         uint32_t rnd[4] = {0, 0, 0, 0};
-        if (!sp.greedy) philox4x32_10((uint32_t)m, (uint32_t)(n4 >> 2), sp.step, epoch, sp.seed_lo, sp.seed_hi, rnd);
+        const bool jax = sp.rng == LMRL_RNG_JAX;
+        if (!sp.greedy && !jax) philox4x32_10((uint32_t)m, (uint32_t)(n4 >> 2), sp.step, epoch, sp.seed_lo, sp.seed_hi, rnd);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int n = n4 + r;
             if (n >= vocab) continue;
             const float raw = row[n];
             if (f32_order_key(raw) < thr_key) continue;
-            const float v = raw * sp.inv_temperature;
-            const float sc = sp.greedy ? v : v + gumbel_from_bits(rnd[r]);
+            const float v = jax ? raw / sp.temperature : raw * sp.inv_temperature;
+            const float sc = sp.greedy ? v : v + (jax ? gumbel_jax(sp.seed_hi, sp.seed_lo, (uint32_t)m * (uint32_t)vocab + (uint32_t)n, sp.jax_n)
+                                                      : gumbel_from_bits(rnd[r]));
             if (sc > best || (sc == best && n < best_col)) { best = sc; best_col = n; best_z = v; }
             const float nm = fmaxf(pmax, v);
             psum = psum * ((pmax == -INFINITY) ? 0.f : __expf(pmax - nm)) + __expf(v - nm);
@@ -448,6 +466,10 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     sp.inv_temperature = sp.greedy ? 1.f : 1.f / p->temperature;
     sp.seed_lo = (uint32_t)p->seed; sp.seed_hi = (uint32_t)(p->seed >> 32); sp.step = p->step; sp.epoch = p->epoch_d;
     sp.steer_strength = p->steer_strength; sp.beta = p->beta; sp.vocab = vocab;
+    sp.temperature = sp.greedy ? 1.f : p->temperature; sp.rng = p->rng;
+    LMRL_REQUIRE(p->rng == LMRL_RNG_PHILOX || p->rng == LMRL_RNG_JAX, "lmrl_lm_head_sample: unknown rng mode");
+    LMRL_REQUIRE(p->rng != LMRL_RNG_JAX || (double)m * vocab < 4294967296.0, "lmrl_lm_head_sample: LMRL_RNG_JAX needs rows * vocab < 2^32 (uint32 iota)");
+    sp.jax_n = (uint32_t)m * (uint32_t)vocab;
     hipStream_t s = as_stream(stream);
     const XcdMap xm = make_xcd_map((m + kLmBM - 1) / kLmBM, vocab_padded / kLmBN, 2.0 * m * d_model, 2.0 * (double)vocab_padded * d_model);
     const int tiles = xcd_grid(xm);
@@ -459,13 +481,16 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     const uint16_t *A2 = (const uint16_t *)q_hidden2_d, *W2 = (const uint16_t *)q_w2_d;
     {
     ProfScope ps(PROF_LM_HEAD_SAMPLE, s, 2.0 * (double)m * (double)vocab_padded * (double)d_model * nops);
-#define LMRL_LM_LAUNCH(NOPS_, LP_)                                                                                                    \
-    hipLaunchKernelGGL((lm_head_sample_kernel<NOPS_, LP_>), dim3(tiles), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, \
+#define LMRL_LM_LAUNCH(NOPS_, LP_, JAX_)                                                                                                    \
+    hipLaunchKernelGGL((lm_head_sample_kernel<NOPS_, LP_, JAX_>), dim3(tiles), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, \
                        q_b2_d, steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm)
     const bool lp = logprob_d != nullptr;      // the log-sum-exp (one exp per logit) is computed only when the log-prob is wanted
-    if (nops == 1) { if (lp) LMRL_LM_LAUNCH(1, true); else LMRL_LM_LAUNCH(1, false); }
-    else if (nops == 2) { if (lp) LMRL_LM_LAUNCH(2, true); else LMRL_LM_LAUNCH(2, false); }
-    else { if (lp) LMRL_LM_LAUNCH(3, true); else LMRL_LM_LAUNCH(3, false); }
+    if (sp.rng == LMRL_RNG_JAX && !sp.greedy) {       // parity mode: always with the log-sum-exp variant (one instantiation per operand count)
+        if (nops == 1) LMRL_LM_LAUNCH(1, true, true); else if (nops == 2) LMRL_LM_LAUNCH(2, true, true); else LMRL_LM_LAUNCH(3, true, true);
+    }
+    else if (nops == 1) { if (lp) LMRL_LM_LAUNCH(1, true, false); else LMRL_LM_LAUNCH(1, false, false); }
+    else if (nops == 2) { if (lp) LMRL_LM_LAUNCH(2, true, false); else LMRL_LM_LAUNCH(2, false, false); }
+    else { if (lp) LMRL_LM_LAUNCH(3, true, false); else LMRL_LM_LAUNCH(3, false, false); }
 #undef LMRL_LM_LAUNCH
     }
     LMRL_CHECK_LAUNCH();
@@ -482,6 +507,14 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     return LMRL_OK;
 }
 
+// host faces of the LMRL_RNG_JAX stream (CPU-tier known-answer tests; no GPU needed)
+void lmrl_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]) { threefry2x32_20(key[0], key[1], ctr[0], ctr[1], out[0], out[1]); }
+int lmrl_jax_random_bits_host(const uint32_t key[2], uint32_t n, uint32_t i0, uint32_t count, uint32_t *out) {
+    if (!key || !out || (uint64_t)i0 + count > n) return LMRL_ERR_ARG;
+    for (uint32_t j = 0; j < count; j++) out[j] = jax_random_word(key[0], key[1], i0 + j, n);
+    return LMRL_OK;
+}
+
 int lmrl_sample_logits(const float *logits_d, int ld, int m, int vocab, const lmrl_sample_params *p, const uint8_t *active_d,
                        int32_t *token_d, float *logprob_d, void *stream) {
     LMRL_REQUIRE(logits_d && p && token_d && m > 0 && vocab > 0 && ld >= vocab, "lmrl_sample_logits: bad argument");
@@ -490,6 +523,10 @@ int lmrl_sample_logits(const float *logits_d, int ld, int m, int vocab, const lm
     sp.inv_temperature = sp.greedy ? 1.f : 1.f / p->temperature;
     sp.seed_lo = (uint32_t)p->seed; sp.seed_hi = (uint32_t)(p->seed >> 32); sp.step = p->step; sp.epoch = p->epoch_d;
     sp.steer_strength = 0.f; sp.beta = 0.f; sp.vocab = vocab;
+    sp.temperature = sp.greedy ? 1.f : p->temperature; sp.rng = p->rng;
+    LMRL_REQUIRE(p->rng == LMRL_RNG_PHILOX || p->rng == LMRL_RNG_JAX, "lmrl_sample_logits: unknown rng mode");
+    LMRL_REQUIRE(p->rng != LMRL_RNG_JAX || (double)m * vocab < 4294967296.0, "lmrl_sample_logits: LMRL_RNG_JAX needs rows * vocab < 2^32");
+    sp.jax_n = (uint32_t)m * (uint32_t)vocab;
     hipLaunchKernelGGL(topk_sample_kernel, dim3(m), dim3(256), 0, as_stream(stream), logits_d, ld, vocab, p->top_k, p->top_p, active_d,
                        token_d, logprob_d, sp, p->pad_token);
     LMRL_CHECK_LAUNCH();

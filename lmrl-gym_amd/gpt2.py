@@ -54,7 +54,10 @@ class _CConfig(ctypes.Structure):
 class SampleParams(ctypes.Structure):
     _fields_ = [("temperature", ctypes.c_float), ("top_k", ctypes.c_int32), ("seed", ctypes.c_uint64),
                 ("step", ctypes.c_uint32), ("steer_strength", ctypes.c_float), ("beta", ctypes.c_float),
-                ("pad_token", ctypes.c_int32), ("epoch_d", ctypes.c_void_p), ("top_p", ctypes.c_float)]
+                ("pad_token", ctypes.c_int32), ("epoch_d", ctypes.c_void_p), ("top_p", ctypes.c_float), ("rng", ctypes.c_int32)]
+
+
+RNG_PHILOX, RNG_JAX = 0, 1       # lmrl_sample_params.rng
 
 
 class _CKVPrefix(ctypes.Structure):      # lmrl_kv_prefix (include/lmrl_amd.h)

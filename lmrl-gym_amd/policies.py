@@ -17,7 +17,8 @@ import numpy as np
 
 from . import _lib
 from .environment import BatchedTextPolicy, Text, TextHistory, text_history_to_str
-from .gpt2 import FWD_RAGGED_ALWAYS, GPT2Engine, SampleParams
+from . import jax_prng
+from .gpt2 import FWD_RAGGED_ALWAYS, RNG_JAX, GPT2Engine, SampleParams
 
 
 class _Generator:
@@ -72,8 +73,16 @@ class GPT2PPOPolicy(BatchedTextPolicy):
                  temperature: Optional[float] = None, top_k: Optional[int] = None, top_p: Optional[float] = None,
                  eos_token_id: Optional[int] = None,
                  pad_token_id: Optional[int] = None, seed: int = 0, in_str_process: Optional[Callable[[str], str]] = None,
-                 out_str_process: Optional[Callable[[str], str]] = None, reuse_kv: bool = True):
+                 out_str_process: Optional[Callable[[str], str]] = None, reuse_kv: bool = True, sampler: str = "philox"):
+        """sampler: "philox" (default) — the package's counter-based stream, keyed by (seed, act() call, row, column, token position);
+        "jax" — the reference's stream: `seed` is the integer of `jax.random.PRNGKey(seed)` handed to the policy, split once per act()
+        (ppo/gpt2/interface.py:524-526) and once per generated token (HF-Flax `_sample`), each token drawn as
+        `jax.random.categorical(key, logits[B, V])` (lmrl_gym_amd/jax_prng.py + csrc/threefry.h; restated from jax 0.4.7's published
+        algorithm, unverified against jax itself)."""
+        assert sampler in ("philox", "jax")
         self.engine, self.tokenizer = engine, tokenizer
+        self.sampler = sampler
+        self.prng_key = jax_prng.prng_key(seed)
         self.reuse_kv = reuse_kv
         self.max_input_length, self.max_new_tokens = max_input_length, max_new_tokens
         self.temperature = (temperature if temperature is not None else 1.0) if do_sample else 0.0
@@ -116,6 +125,10 @@ class GPT2PPOPolicy(BatchedTextPolicy):
         import torch
         gen.prefill(prompts, reuse=self.reuse_kv)
         self.calls += 1                                     # one random stream per act() call, like the per-call key split
+        keys = None
+        if self.sampler == "jax":                           # self.prng_key, new_key = jax.random.split(self.prng_key)
+            self.prng_key, new_key = jax_prng.split(self.prng_key)
+            keys = jax_prng.SampleKeys(new_key)
         # Generation loop without a host sync per token: live flags, the generated ids and the next decode inputs stay on the
         # device (`lmrl_gen_accept`); the host only peeks at the live flags every `sync_every` tokens to stop early.
         L = _lib.lib()
@@ -132,7 +145,10 @@ class GPT2PPOPolicy(BatchedTextPolicy):
         for k in range(cap):
             if k % sync_every == 0 and k > 0 and not bool(active_d.any().item()):
                 break
-            p = SampleParams(self.temperature, self.top_k, self.seed + (self.calls << 20), k, 0.0, 0.0, self.pad, None, self.top_p)
+            if keys is not None:
+                p = SampleParams(self.temperature, self.top_k, jax_prng.key_to_seed(keys.next()), k, 0.0, 0.0, self.pad, None, self.top_p, RNG_JAX)
+            else:
+                p = SampleParams(self.temperature, self.top_k, self.seed + (self.calls << 20), k, 0.0, 0.0, self.pad, None, self.top_p)
             tok, _ = self._sample(gen, p, active_d, logits_out)
             _lib.check(L.lmrl_gen_accept(_lib.ptr(tok), _lib.ptr(active_d), _lib.ptr(out_tok), _lib.ptr(out_len), _lib.ptr(next_tok),
                                          _lib.ptr(next_cnt), -1 if self.eos is None else int(self.eos), cap, B, _lib.stream_ptr()), "lmrl_gen_accept")

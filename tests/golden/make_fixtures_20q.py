@@ -116,6 +116,28 @@ def main():
                 rec.append(dict(history=th(hists[i]), reward=rew, done=bool(dn)))
         rounds.append(rec); k += 1
     out["batched"] = dict(seeds=seeds, words=words, rounds=rounds)
+    # a second batched run whose slots WIN at different steps (word guessed + "Yes." -> reward 0, done; env.py:101-117 / data.py:83-116):
+    # deterministic words (seed % len(word_list)), 4 live slots in a batch of 4, question index k + i + 1
+    benv = BatchedTwentyQuestionsPolicyEnvironment(ScriptedOracle(), wl, max_conversation_length=5, bsize=4)
+    seeds = [10, 11, 24, 170]
+    hists = benv.reset(seeds, [{"deterministic": True}] * 4)
+    words = [w.words for w in benv.curr_words]
+    done = [False] * 4
+    rounds = []
+    k = 0
+    while not all(done):
+        acts = [None if done[i] else tuple(hists[i]) + (Text(QUESTIONS[(k + i + 1) % len(QUESTIONS)] + "\n", True),) for i in range(4)]
+        res = benv.step(acts, done)
+        rec = []
+        for i, r in enumerate(res):
+            if r is None:
+                rec.append(None)
+            else:
+                hists[i], rew, dn = r
+                done[i] = dn
+                rec.append(dict(history=th(hists[i]), reward=rew, done=bool(dn)))
+        rounds.append(rec); k += 1
+    out["batched_win"] = dict(seeds=seeds, words=words, rounds=rounds, question_offset=1, maxlen=5)
     path = os.path.join(HERE, "twenty_questions.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))

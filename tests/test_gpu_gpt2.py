@@ -194,6 +194,47 @@ def test_sampler_gumbel_stream_matches_documented_scheme(dev):
             assert np.array_equal(tk[safe], tok[safe])
 
 
+def test_sampler_jax_stream_equals_jax_random_categorical_restatement(dev):
+    """LMRL_RNG_JAX: the token of every row == `jax.random.categorical(key, logits / T)` as restated in
+    oracle/jax_random.py (threefry2x32-20 pinned by the Random123 vectors in tests/test_jax_prng.py) on the logits the device itself
+    materialised — fused LM-head epilogue and the top-k kernel alike; ONE key for the whole [B, V] noise array, word index = row * V +
+    column, so the draw of a row depends on the batch it is in, as in JAX."""
+    from lmrl_gym_amd import _lib, jax_prng as JP
+    from lmrl_gym_amd.gpt2 import RNG_JAX, SampleParams
+    from oracle import jax_random as JR
+    for B in (200, 37):                               # even and odd word counts (odd: the iota is padded with one 0)
+        cfg, eng, ses, hid, _ = _engine_and_hidden(dev, B)
+        lo = torch.zeros(B, cfg.vocab_padded, device=dev)
+        key = JP.split(JP.prng_key(1234 + B))[1]
+        T = 0.7
+        p = SampleParams(T, 0, JP.key_to_seed(key), 0, 0.0, 0.0, 0, None, 0.0, RNG_JAX)
+        tok, lp = ses.sample(p, hidden=hid, logits_out=lo)
+        z = lo.cpu().numpy()[:, : cfg.vocab].astype(np.float32)
+        g = JR.gumbel(np.array(key, np.uint32), (B, cfg.vocab))
+        score = z / np.float32(T) + g
+        srt = np.sort(score, 1)
+        safe = (srt[:, -1] - srt[:, -2]) > 1e-5        # float log: a few ulp between implementations
+        tok = tok.cpu().numpy()
+        assert safe.mean() > 0.98 and np.array_equal(tok[safe], score.argmax(1)[safe])
+        assert np.array_equal(tok[safe], JR.categorical(np.array(key, np.uint32), z / np.float32(T))[safe])
+        zt = z / np.float32(T)
+        lse = np.log(np.exp(zt - zt.max(1, keepdims=True)).sum(1)) + zt.max(1)
+        np.testing.assert_allclose(lp.cpu().numpy(), zt[np.arange(B), tok] - lse, atol=5e-3)
+        # a different key gives different draws; the Philox mode is untouched by the new field
+        tok2, _ = ses.sample(SampleParams(T, 0, JP.key_to_seed(JP.split(key)[0]), 0, 0.0, 0.0, 0, None, 0.0, RNG_JAX), hidden=hid)
+        assert (tok2.cpu().numpy() != tok).mean() > 0.5
+        for k in (5, cfg.vocab):
+            tk = torch.zeros(B, dtype=torch.int32, device=dev); lpk = torch.zeros(B, device=dev)
+            pk = SampleParams(T, k, JP.key_to_seed(key), 0, 0.0, 0.0, 0, None, 0.0, RNG_JAX)
+            _lib.check(_lib.lib().lmrl_sample_logits(_lib.ptr(lo), cfg.vocab_padded, B, cfg.vocab, ctypes.byref(pk), None,
+                                                     _lib.ptr(tk), _lib.ptr(lpk), _lib.stream_ptr()))
+            kth = np.sort(z, 1)[:, -k][:, None]
+            masked = np.where(z >= kth, score, -np.inf)      # TopKLogitsWarper then categorical on the same [B, V] noise array
+            m2 = np.sort(masked, 1)
+            ok = (m2[:, -1] - m2[:, -2]) > 1e-5
+            assert np.array_equal(tk.cpu().numpy()[ok], masked.argmax(1)[ok]), k
+
+
 def test_sampler_distribution_chi_square(dev):
     """Identical rows -> empirical token frequencies follow softmax(logits/T)."""
     from lmrl_gym_amd.gpt2 import SampleParams

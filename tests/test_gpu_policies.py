@@ -282,6 +282,167 @@ def test_twenty_questions_dual_model_rollout(setup):
         Q.set_pos_tagger(None)
 
 
+def _twentyq_fixture_pairs(fx):
+    """Every (word spellings, stripped question) -> answer the reference env saw in tests/golden/twenty_questions.json (its ScriptedOracle)."""
+    pairs = {}
+
+    def add(word, h):
+        pairs[(tuple(word), h[-2][0].strip())] = h[-1][0].strip()
+    for ep in fx["episodes"]:
+        for st in ep["steps"]:
+            add(ep["word"], st["history"])
+    for key in ("batched", "batched_win"):
+        b = fx[key]
+        for rnd in b["rounds"]:
+            for i, x in enumerate(rnd):
+                if x:
+                    add(b["words"][i], x["history"])
+    return pairs
+
+
+def test_twenty_questions_device_oracle_reproduces_reference_transitions():
+    """N4 against the oracle, not against itself.  The reference run behind tests/golden/twenty_questions.json used a
+    scripted oracle; here the oracle is a MODEL resident on the HIP engine whose weights are made to give those answers: a 2-layer GPT-2 is
+    fitted (this package's fp32 BC train step, a few hundred steps) to "oracle prompt -> yes / no" for every (object, question) pair of the
+    fixture, loaded into a `GPT2Engine`, and answers inside the lock-step loop through `GPT2EngineOracle` (prompt of oracle.py:20-28, greedy
+    <= 4 tokens, yes|no regex).  With a scripted asker the transition lists — histories, rewards, done flags — must equal the reference's
+    run transition by transition, INCLUDING the episodes that are won ("Yes." to a question naming the object: reward 0, done) and the
+    slots that finish early while the rest of the batch goes on."""
+    import json
+    import os
+    from lmrl_gym_amd import _lib, environment as E
+    from lmrl_gym_amd.algorithms import bc
+    from lmrl_gym_amd.envs import twenty_questions as Q
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32
+    dev = _lib.require_gpu()
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "twenty_questions.json")))
+    Q.set_pos_tagger(Q.rule_pos_tag)                    # the tagger the fixture was generated with (nltk is absent offline)
+    try:
+        cfg = GPT2Config(2, 2, 128, 512, 130, 256)
+        tok = CharTok(cfg.vocab)
+        wl = Q.get_default_word_list()
+        assert [w.words for w in wl] == fx["word_list"]
+        pairs = _twentyq_fixture_pairs(fx)
+        assert sum(a == "Yes." for a in pairs.values()) >= 10 and sum(a == "No." for a in pairs.values()) >= 10
+        # ---- fit the oracle model on the device train path
+        seqs, acts = [], []
+        for (w, q), a in pairs.items():
+            p = tok.encode(Q.get_oracle_prompt(Q.WordVariants.from_list(list(w)), q))
+            t = tok.encode(("yes" if a == "Yes." else "no") + "\n")
+            seqs.append(p + t); acts.append([False] * len(p) + [True] * len(t))
+        T = max(len(x) for x in seqs)
+        assert T <= 200
+        ids = np.full((len(seqs), T), tok.pad_token_id, dtype=np.int32)
+        ia = np.zeros((len(seqs), T), dtype=bool)
+        for i, (x, m) in enumerate(zip(seqs, acts)):
+            ids[i, :len(x)] = x; ia[i, :len(x)] = m
+        model = GPT2F32(init_hf_style_state_dict(cfg, seed=3), cfg.n_head, device=dev)
+        tr = bc.GPT2BCTrain(model, tok.pad_token_id, lr=2e-3)
+        loss = None
+        for step in range(400):
+            _, loss, _ = tr.step(ids, ia)
+            if step >= 150 and loss < 2e-6:
+                break
+        assert loss < 1e-4, loss
+        eng = GPT2Engine(cfg, {k: v.detach().cpu() for k, v in model.p.items()}, dev)
+        calls = []
+
+        class Spy(Q.GPT2EngineOracle):
+            def generate_answers(self, words, questions, return_full=False):
+                calls.append(len(words) if isinstance(words, list) else 1)
+                return super().generate_answers(words, questions, return_full)
+        oracle = Spy(eng, tok, max_input_length=200, max_new_tokens=4, eos_token_id=tok.eos_token_id)
+        # the fitted model says what the reference's oracle said, on every pair
+        keys = list(pairs)
+        got = oracle.generate_answers([Q.WordVariants.from_list(list(w)) for w, _ in keys], [q for _, q in keys])
+        assert got == [pairs[k] for k in keys]
+        QUESTIONS = None
+
+        class Asker(E.BatchedTextPolicy):
+            """Scripted asker: slot i asks question `order(round, i)` of the fixture generator's list (recovered from the fixture itself)."""
+            def __init__(self, script):
+                self.script, self.k = script, 0
+
+            def act(self, text_history, done=None):
+                out = []
+                for i, (h, d) in enumerate(zip(text_history, done or [False] * len(text_history))):
+                    out.append(None if (d or h is None) else tuple(h) + (E.Text(self.script[self.k][i], True),))
+                self.k += 1
+                return out
+        th = lambda hist: [[t.text, bool(t.is_action)] for t in hist]
+
+        def check(name, bsize, npad, maxlen):
+            b = fx[name]
+            n = len(b["seeds"])
+            script = [[(x["history"][-2][0] if x else None) for x in rnd] for rnd in b["rounds"]]
+            env = Q.BatchedTwentyQuestionsPolicyEnvironment(oracle, wl, max_conversation_length=maxlen, bsize=bsize)
+            opts = [{"deterministic": i % 2 == 0} for i in range(n)] if name == "batched" else [{"deterministic": True}] * n
+            inter = E.interact_environment(env, Asker(script), env_seed=b["seeds"], env_options=opts, bsize=n, npad=0)
+            assert [w.words for w in env.curr_words] == b["words"]
+            for i in range(n):
+                exp = [rnd[i] for rnd in b["rounds"] if rnd[i] is not None]
+                assert len(inter[i]) == len(exp), (name, i)
+                for tr_, e in zip(inter[i], exp):
+                    assert th(tr_.post_transition_history) == e["history"] and tr_.reward == e["reward"] and tr_.done == e["done"], (name, i)
+                    assert th(tr_.post_action_history) == e["history"][:-1] and th(tr_.pre_action_history) == e["history"][:-2]
+            return inter
+        inter = check("batched", 6, 0, 6)
+        win = check("batched_win", 4, 0, fx["batched_win"]["maxlen"])
+        won = [ep for ep in win if ep[-1].reward == 0.0 and ep[-1].done]
+        assert len(won) >= 2 and any(len(ep) == 1 for ep in won) and any(len(ep) == fx["batched_win"]["maxlen"] for ep in win)
+        # single-env episodes of the fixture (3 of them are won) through the TextEnv face
+        n_won = 0
+        for ep in fx["episodes"]:
+            env = Q.TwentyQuestionsPolicyEnvironment(oracle, wl, max_conversation_length=ep["maxlen"])
+            hist = env.reset(ep["seed"], {"deterministic": ep["deterministic"]})
+            assert env.curr_word.words == ep["word"]
+            for st in ep["steps"]:
+                hist, r, dn = env.step(tuple(hist) + (E.Text(st["question"], True),))
+                assert th(hist) == st["history"] and r == st["reward"] and dn == st["done"]
+            n_won += ep["steps"][-1]["reward"] == 0.0
+        assert n_won >= 3 and len(calls) > 20
+    finally:
+        Q.set_pos_tagger(None)
+
+
+def test_policy_jax_sampler_walks_the_reference_key_schedule(setup):
+    """`GPT2PPOPolicy(sampler="jax", seed=s)`: PRNGKey(s), one split per act() (ppo/gpt2/interface.py:524-526), one split per generated token
+    (HF-Flax `_sample`), token t of a call drawn with `categorical(key_t, logits[B, V])`.  Checked by re-deriving the keys with the oracle's
+    numpy restatement and re-scoring every generated token on the float64 oracle model's logits (decisive draws only: bf16 engine)."""
+    from lmrl_gym_amd import environment as E
+    from lmrl_gym_amd.policies import GPT2PPOPolicy
+    from oracle import gpt2 as O, jax_random as JR
+    dev, cfg, sd, sd_v, eng, eng_v = setup
+    tok = CharTok(cfg.vocab)
+    G = 5
+    pol = GPT2PPOPolicy(eng, tok, max_input_length=32, max_new_tokens=G, do_sample=True, temperature=1.0, seed=77, eos_token_id=None, sampler="jax")
+    hists = [(E.Text("obs %d: go\n" % i, False),) for i in range(6)]
+    key = JR.prng_key(77)
+    checked = 0
+    for call in range(2):
+        out = pol.act(hists, [False] * len(hists))
+        key, new_key = JR.split(key)
+        keys = JR.hf_flax_sample_keys(new_key, G)
+        prompts = [tok.encode(h[0].text) for h in hists]
+        gen = [tok.encode(o[-1].text) for o in out]
+        assert all(len(g) == G for g in gen)
+        for t in range(G):
+            lg = np.stack([O.forward(sd, torch.tensor([p + g[:t]]), cfg.n_head)[0, -1, : cfg.vocab].numpy() for p, g in zip(prompts, gen)]).astype(np.float32)
+            score = lg + JR.gumbel(keys[t], lg.shape)
+            srt = np.sort(score, 1)
+            for b in range(len(hists)):
+                if srt[b, -1] - srt[b, -2] > 0.15:          # bf16 logits vs float64: only draws that survive the engine's rounding
+                    assert int(score[b].argmax()) == gen[b][t], (call, t, b)
+                    checked += 1
+    assert checked >= 30
+    # same seed -> same stream; the default sampler is a different stream
+    pol2 = GPT2PPOPolicy(eng, tok, max_input_length=32, max_new_tokens=G, do_sample=True, temperature=1.0, seed=77, eos_token_id=None, sampler="jax")
+    a = [o[-1].text for o in pol2.act(hists, [False] * len(hists))]
+    pol3 = GPT2PPOPolicy(eng, tok, max_input_length=32, max_new_tokens=G, do_sample=True, temperature=1.0, seed=77, eos_token_id=None, sampler="jax")
+    assert a == [o[-1].text for o in pol3.act(hists, [False] * len(hists))]
+
+
 def test_kv_reuse_across_act_calls_forwards_only_new_tokens(setup):
     """`GPT2PPOPolicy(reuse_kv=True)` keeps the K/V rows of the longest common prefix of consecutive prompts (the reference re-runs the whole
     history in every act, ppo/gpt2/interface.py:519-546).  Over a multi-turn episode with growing histories: identical bookkeeping (cache
