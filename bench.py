@@ -155,7 +155,7 @@ def _dist_setup(torch):
     return world, rank, dev, backend, use_dist
 
 
-def run_train_step(mode, matmul, B, steps, warmup, dev, rank, world, use_dist, backend, measure_exposed=True):
+def run_train_step(mode, matmul, B, steps, warmup, dev, rank, world, use_dist, backend, measure_exposed=True, model="small"):
     """One train-step measurement (`mode` = "ilql-step" | "ppo-step") at the sizes SURVEY.md §8d names (M3: GPT-2-small, B = 32 x T = 512 per GPU;
     M4: B = 32 x T = 1024), synthetic ids ~ U[0, 50257) with the 6-on / 6-off action pattern after a 4-token header.  N > 1: pure data
     parallelism, every rank its own B sequences (weak scaling), ONE gradient all-reduce per step overlapped with the backward pass
@@ -167,8 +167,9 @@ def run_train_step(mode, matmul, B, steps, warmup, dev, rank, world, use_dist, b
     from lmrl_gym_amd.algorithms import ilql, ppo
     from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
     from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32, MLPHeadF32
-    cfg = GPT2Config.gpt2_small(50258)            # +1 added <|pad|> token (train_ilql_gpt2.py:115-116)
-    pad, n_params = 50257, 124.4e6
+    # +1 added <|pad|> token (train_ilql_gpt2.py:115-116); "medium" = configs[3]'s policy (chess/ppo/train_ppo_gpt2_online.py:201-222)
+    cfg = dict(small=GPT2Config.gpt2_small, medium=GPT2Config.gpt2_medium)[model](50258)
+    pad = 50257
     T = 512 if mode == "ilql-step" else 1024
     rng = np.random.RandomState(1000 + rank)
     ids = rng.randint(0, 50257, size=(B, T)).astype(np.int32)
@@ -192,9 +193,9 @@ def run_train_step(mode, matmul, B, steps, warmup, dev, rank, world, use_dist, b
         q_tok = int(sta.sum())          # no padding in the synthetic batch: attention_mask = 1
         head_flops = 2 * (d * d + d * V) * q_tok * (3 * 2) + 2 * (d * d + d) * tok * 2
         # matmul parameters of the transformer blocks only: the embedding tables do no flops and ILQL never forms LM logits
-        n_mm = n_params - V * d - cfg.n_pos * d
-        flops = (6 + 2) * n_mm * tok + head_flops + 12 * 6 * 2 * T * d * tok
-        workload = f"configs[2] / M3: ILQL train step, GPT-2-small fp32, B={B} x T={T} per GPU (train_ilql_gpt2.py:55-110), target base + 2 Q heads + V head; should_take_action on {100.0 * q_tok / tok:.0f} % of the tokens"
+        n_mm = cfg.n_layer * (4 * d * d + 2 * d * cfg.d_ff)
+        flops = (6 + 2) * n_mm * tok + head_flops + cfg.n_layer * 6 * 2 * T * d * tok
+        workload = f"configs[2] / M3: ILQL train step, GPT-2-{model} fp32, B={B} x T={T} per GPU (train_ilql_gpt2.py:55-110), target base + 2 Q heads + V head; should_take_action on {100.0 * q_tok / tok:.0f} % of the tokens"
     else:
         pol = GPT2F32(sd, cfg.n_head, device=dev, matmul=mmode)
         head = LinearHeadF32(dict(kernel=torch.randn(d, 1) * 0.01, bias=torch.tensor([-4.1])), dev)
@@ -204,9 +205,9 @@ def run_train_step(mode, matmul, B, steps, warmup, dev, rank, world, use_dist, b
         step = lambda: tr.step(ids, sta, olp, ov, oa, orr)
         # the tied LM head (V x d of the 124.4 M parameters) runs on the rows the loss reads only (GPT2PPOTrain.compact_rows): executed flops
         q_tok = int(sta.sum())
-        n_mm = n_params - V * d - cfg.n_pos * d          # transformer-block matmul parameters (embedding lookups do no flops)
-        flops = 6 * n_mm * tok + 6 * V * d * q_tok + 12 * 6 * 2 * T * d * tok
-        workload = (f"M4: PPO train step, GPT-2-small fp32, B={B} x T={T} per GPU (train_ppo_gpt2.py:60-112), LinearHead value function; "
+        n_mm = cfg.n_layer * (4 * d * d + 2 * d * cfg.d_ff)          # transformer-block matmul parameters (embedding lookups do no flops)
+        flops = 6 * n_mm * tok + 6 * V * d * q_tok + cfg.n_layer * 6 * 2 * T * d * tok
+        workload = (f"M4: PPO train step, GPT-2-{model} fp32, B={B} x T={T} per GPU (train_ppo_gpt2.py:60-112), LinearHead value function; "
                     f"should_take_action on {100.0 * q_tok / tok:.0f} % of the tokens")
 
     def barrier():
@@ -260,7 +261,7 @@ def main_train_step(args):
     """`--mode ilql-step` / `--mode ppo-step`: the train step of configs[2] as its own bench line (`value` = sequences / s over all ranks)."""
     import torch
     world, rank, dev, backend, use_dist = _dist_setup(torch)
-    r = run_train_step(args.mode, args.train_matmul, args.train_batch, args.steps, args.warmup, dev, rank, world, use_dist, backend)
+    r = run_train_step(args.mode, args.train_matmul, args.train_batch, args.steps, args.warmup, dev, rank, world, use_dist, backend, model=args.model)
     if rank == 0:
         bf = args.train_matmul == "bf16"
         B, T, ach = r["per_gpu_batch"], r["seq_len"], r["executed_tflops_per_gpu"]
@@ -275,7 +276,7 @@ def main_train_step(args):
                  "note": "model flops of one step / wall time of the whole step (lower bound for the GEMM kernel itself: 91 % of kernel time, "
                          "profiles/r01_train_kernel_stats_final.csv)"})
         line = {
-            "metric": f"{args.mode} sequences/sec (GPT-2-small {'bf16-matmul' if bf else 'fp32'}, B={B}, T={T})", "value": r["sequences_per_s"],
+            "metric": f"{args.mode} sequences/sec (GPT-2-{args.model} {'bf16-matmul' if bf else 'fp32'}, B={B}, T={T})", "value": r["sequences_per_s"],
             "unit": "sequences/s", "n_gpus": world, "steps": r["steps"], "warmup": r["warmup"], "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf else "f32", "data": "synthetic",
             "config": {"workload": r["workload"].replace("fp32", prec), "per_gpu_batch": B, "seq_len": T,
@@ -310,6 +311,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--mode", default="rollout", choices=["rollout", "ilql-step", "ppo-step"],
                     help="rollout (default): the headline env-steps/s line; ilql-step / ppo-step: the train step of configs[2] (M3 / M4 sizes)")
+    ap.add_argument("--model", default="small", choices=["small", "medium"], help="train-step modes: GPT-2 size (medium = configs[3]'s PPO policy)")
     ap.add_argument("--train-batch", type=int, default=32, help="sequences per GPU in the train-step modes")
     ap.add_argument("--train-matmul", default="f32", choices=["f32", "bf16"],
                     help="train-step modes: f32 = the reference's default arithmetic; bf16 = its optional bf16_activations mode (bf16 MFMA operands, "
@@ -324,6 +326,7 @@ def main():
                     "once per episode and broadcast to all envs (bit-identical to per-env prefill); 0: prefill the header per env")
     ap.add_argument("--streams", type=int, default=1, help="split the batch into this many sub-batches on separate HIP streams")
     ap.add_argument("--breakdown", action="store_true", help="after the timed region, print a per-kernel-class event breakdown to stderr")
+    ap.add_argument("--no-fp32-mode", action="store_true", help="skip the `fp32_mode` leg of the default line (the same rollout on the fp32 engine)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the `train_step` leg of the default line (ILQL M3 step, fp32 and bf16-matmul)")
     ap.add_argument("--train-steps", type=int, default=3, help="timed steps per arithmetic mode in the `train_step` leg of the default line")
     args = ap.parse_args()
@@ -564,6 +567,37 @@ def main():
     import gc
     gc.collect()
     torch.cuda.empty_cache()
+    if not args.no_fp32_mode:
+        # the reference's DEFAULT rollout arithmetic (eval_bc_gpt2.py:34,69: float32): the same workload on GPT2EngineF32 — fp32 weights,
+        # activations and K/V cache, exact-fp32 MFMA products, materialised fp32 logits, same sampler and env kernels; eager launches.
+        # Its every sampled token is pinned to the float64 oracle in tests/test_gpu_f32_engine.py.  Reported beside `value`, never as it.
+        from lmrl_gym_amd.gpt2_f32_engine import GPT2EngineF32
+        engf = GPT2EngineF32.random_init(cfg, seed=0, device=dev)
+        rof = WordleRolloutEngine(engf, vocab, B, max_new_tokens=6, bad_word_reward=-10.0, share_header=bool(args.share_header))
+        kwf = dict(temperature=1.0, sample_seed=1000 + rank * 16, steer_strength=30.0)
+        rof.run_episode(seeds_all[0], scripted_guesses=guesses[0], **kwf)
+        barrier()
+        tf0 = time.perf_counter()
+        nf = []
+        for i in range(2):
+            rof.run_episode(seeds_all[args.warmup + i], scripted_guesses=guesses[args.warmup + i], **kwf)
+            nf.append(rof.traj["n_steps"].sum())
+        barrier()
+        tf = torch.tensor([time.perf_counter() - tf0], dtype=torch.float64, device=dev)
+        nfs = torch.stack(nf).sum()
+        if use_dist:
+            if backend != "nccl":
+                tf, nfs = tf.cpu(), nfs.cpu()
+            torch.distributed.all_reduce(tf, op=torch.distributed.ReduceOp.MAX)
+            torch.distributed.all_reduce(nfs, op=torch.distributed.ReduceOp.SUM)
+        if rank == 0:
+            out["fp32_mode"] = {"value": round(int(nfs.item()) / float(tf.item()), 1), "unit": "env-steps/s", "ms_per_step": round(float(tf.item()) * 500.0, 2),
+                                "steps": 2, "dtype": "f32", "engine": "GPT2EngineF32: fp32 weights / activations / KV cache, v_mfma_f32_32x32x2_f32 GEMMs, "
+                                "materialised fp32 logits, eager launches", "parity": "every sampled token == float64 oracle (tests/test_gpu_f32_engine.py)"}
+        rof.close()
+        del rof, engf
+        gc.collect()
+        torch.cuda.empty_cache()
     if not args.no_train_step:
         # the gradient step of the path (configs[2]): ILQL M3 in the reference's default fp32 arithmetic and in its optional bf16-matmul mode;
         # for N > 1 every rank takes part (data parallel, one gradient all-reduce per step over RCCL)

@@ -355,6 +355,25 @@ int lmrl_gen_accept(const int32_t *sampled_d, uint8_t *active_d, int32_t *out_to
 /* Sample from materialised logits (temperature, top-k, top-p) with the same random stream. */
 int lmrl_sample_logits(const float *logits_d, int ld, int m, int vocab, const lmrl_sample_params *p,
                        const uint8_t *active_d, int32_t *token_d, float *logprob_d, void *stream);
+/* the same, after adding p->steer_strength to logits_d[row][steer_tok_d[row]] IN PLACE (synthetic workloads; the fused path does this in
+ * its epilogue) — the sampling step of the fp32 rollout mode, whose LM head is a plain fp32 GEMM */
+int lmrl_sample_logits_steer(float *logits_d, int ld, int m, int vocab, const lmrl_sample_params *p, const int32_t *steer_tok_d,
+                             const uint8_t *active_d, int32_t *token_d, float *logprob_d, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * fp32 rollout mode (csrc/attn_cached_f32.hip + the fp32 train-step kernels below): the reference's DEFAULT rollout arithmetic is float32
+ * (llm_rl_scripts/wordle/bc/eval_bc_gpt2.py:34,69); `lmrl_gym_amd.gpt2_f32_engine.GPT2EngineF32` sequences these calls — lmrl_embed_fwd,
+ * lmrl_layernorm_fwd, lmrl_sgemm (exact fp32 MFMA), lmrl_gelu_fwd — around an fp32 K/V cache.
+ *   lmrl_chunk_begin_f32  pos[b*c + j] = len[b] + j for j < cnt[b]; padding slots get position 0 and token id 0
+ *   lmrl_attn_cached_f32  one layer's attention for the c new tokens of every env: qkv_d fp32 [b*c][3*H*64]; kcache_d / vcache_d fp32
+ *                         [b][tmax][H*64]; query j sees the cached positions [0, len[b]) and the chunk's tokens [0, j]; appends the new
+ *                         K / V rows at len[b] + j; out_d fp32 [b*c][H*64] (padding slots untouched).  tmax <= 1024.
+ *   lmrl_chunk_end_f32    last_d[b] = x_d[b*c + cnt[b] - 1] (envs with cnt == 0 keep theirs), then len[b] += cnt[b]
+ * ------------------------------------------------------------------------------------------ */
+int lmrl_chunk_begin_f32(const int32_t *len_d, const int32_t *cnt_d, int32_t *ids_d, int32_t *pos_d, int b, int c, int n_pos, void *stream);
+int lmrl_attn_cached_f32(const float *qkv_d, float *kcache_d, float *vcache_d, const int32_t *len_d, const int32_t *cnt_d, float *out_d, int b, int c,
+                         int n_head, int tmax, void *stream);
+int lmrl_chunk_end_f32(const float *x_d, const int32_t *cnt_d, float *last_d, int32_t *len_d, int b, int c, int d, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * On-device token <-> game bookkeeping for lock-step Wordle rollouts (csrc/wordle_tokens.hip).

@@ -51,6 +51,10 @@ _SIGS = {
     "lmrl_gpt2_kv_broadcast": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmrl_sgemm_set_variant": (None, [c_int]),
     "lmrl_sample_ws_bytes": (c_size_t, [c_int, c_int]),
+    "lmrl_sample_logits_steer": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lmrl_chunk_begin_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "lmrl_attn_cached_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "lmrl_chunk_end_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lmrl_threefry2x32": (None, [c_void_p, c_void_p, c_void_p]),
     "lmrl_jax_random_bits_host": (c_int, [c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, c_void_p]),
     "lmrl_lm_head_sample": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int] + [c_void_p] * 8),

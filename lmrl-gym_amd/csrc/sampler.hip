@@ -435,6 +435,14 @@ __global__ void gen_accept_kernel(const int32_t *__restrict__ sampled, uint8_t *
     next_cnt[e] = cnt;
 }
 
+// synthetic-workload hook on MATERIALISED logits (the fused path adds it in its epilogue): logits[row][steer_tok[row]] += strength
+__global__ void steer_add_kernel(float *__restrict__ logits, int ld, const int32_t *__restrict__ steer_tok, float strength, int vocab, int m) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const int st = steer_tok[r];
+    if (st >= 0 && st < vocab) logits[(size_t)r * ld + st] += strength;
+}
+
 }  // namespace lmrl
 
 using namespace lmrl;
@@ -505,6 +513,16 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     }
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
+}
+
+int lmrl_sample_logits_steer(float *logits_d, int ld, int m, int vocab, const lmrl_sample_params *p, const int32_t *steer_tok_d,
+                             const uint8_t *active_d, int32_t *token_d, float *logprob_d, void *stream) {
+    LMRL_REQUIRE(logits_d && p && m > 0, "lmrl_sample_logits_steer: bad argument");
+    if (steer_tok_d && p->steer_strength != 0.f) {
+        hipLaunchKernelGGL(steer_add_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, as_stream(stream), logits_d, ld, steer_tok_d, p->steer_strength, vocab, m);
+        LMRL_CHECK_LAUNCH();
+    }
+    return lmrl_sample_logits(logits_d, ld, m, vocab, p, active_d, token_d, logprob_d, stream);
 }
 
 // host faces of the LMRL_RNG_JAX stream (CPU-tier known-answer tests; no GPU needed)

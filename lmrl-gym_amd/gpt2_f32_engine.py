@@ -1,0 +1,144 @@
+"""fp32 rollout engine — the reference's DEFAULT rollout arithmetic.
+
+`GPT2Engine` (gpt2.py) is the throughput mode: bf16 weights / activations, the reference's OPTIONAL `bf16_activations` setting.  The
+reference's default is float32 (llm_rl_scripts/wordle/bc/eval_bc_gpt2.py:34,69 — `bf16_activations: bool=False` -> jnp.float32), and
+BASELINE.json asks for sampled actions within fp32 tolerance.  `GPT2EngineF32` is that mode: fp32 weights, fp32 activations, an fp32
+K/V cache, every matmul on the f32-input MFMA (`lmrl_sgemm`, bit-for-bit an fmaf chain), LayerNorm / gelu / embeddings from the fp32
+train-step kernels, attention in `csrc/attn_cached_f32.hip`, the LM head as a plain fp32 GEMM into materialised logits followed by the
+same sampler (`lmrl_sample_logits_steer`: identical random streams, top-k / top-p warpers).  `KVSessionF32` has the interface of
+`KVSession` (reset / forward / sample / broadcast_prefix_from / last_hidden / token), so `WordleRolloutEngine`, the text policies and
+the tests drive either engine unchanged; `tests/test_gpu_f32_engine.py` compares EVERY sampled token of a rollout with the float64
+oracle.  It trades throughput for exactness (plain fp32 GEMMs at ~0.5 of the 157 TFLOP/s f32 MFMA peak; `bench.py` reports it as
+`fp32_mode`).  There is no ILQL-perturbed sampling here (the Q-head operands of the fused sampler are bf16): policy rollouts only.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from .gpt2 import GPT2Config, SampleParams, init_hf_style_state_dict
+from .train import ops
+
+
+class GPT2EngineF32:
+    def __init__(self, cfg: GPT2Config, state_dict: Dict[str, "torch.Tensor"], device=None):
+        import torch
+        self.cfg = cfg
+        self.device = device or _lib.require_gpu()
+        self._L = _lib.lib()
+        assert cfg.d_model == cfg.n_head * 64, "head dim 64 (every GPT-2 size)"
+        sd = {k[len("transformer."):] if k.startswith("transformer.") else k: v for k, v in state_dict.items()}
+        f32 = lambda t: t.to(self.device, torch.float32).contiguous()
+        wte = torch.zeros(cfg.vocab_padded, cfg.d_model, dtype=torch.float32, device=self.device)
+        wte[: cfg.vocab] = f32(sd["wte.weight"][: cfg.vocab])
+        self.wte, self.wpe = wte, f32(sd["wpe.weight"])
+        self.lnf_g, self.lnf_b = f32(sd["ln_f.weight"]), f32(sd["ln_f.bias"])
+        names = ("ln_1.weight", "ln_1.bias", "attn.c_attn.weight", "attn.c_attn.bias", "attn.c_proj.weight", "attn.c_proj.bias",
+                 "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias")
+        self.layers = [{n: f32(sd[f"h.{l}.{n}"]) for n in names} for l in range(cfg.n_layer)]     # Conv1D kernels stay [in][out]
+
+    @classmethod
+    def random_init(cls, cfg: GPT2Config, seed: int = 0, device=None) -> "GPT2EngineF32":
+        return cls(cfg, init_hf_style_state_dict(cfg, seed), device)
+
+    def session(self, batch: int, tmax: int, flags: int = 0) -> "KVSessionF32":
+        return KVSessionF32(self, batch, tmax)
+
+
+class KVSessionF32:
+    """fp32 twin of `gpt2.KVSession`: persistent fp32 K/V cache [layer][K|V][B][tmax][d] + workspaces for chunk forwards."""
+
+    def __init__(self, eng: GPT2EngineF32, batch: int, tmax: int):
+        import torch
+        t = torch
+        self.eng, self.B, self.tmax, self.flags = eng, batch, tmax, 0
+        c, dev = eng.cfg, eng.device
+        assert tmax <= 1024
+        self.kv = t.zeros(c.n_layer, 2, batch, tmax, c.d_model, dtype=t.float32, device=dev)
+        self.len = t.zeros(batch, dtype=t.int32, device=dev)
+        self.last_hidden = t.zeros(batch, c.d_model, dtype=t.float32, device=dev)      # ln_f of each env's last token
+        self._last_x = t.zeros(batch, c.d_model, dtype=t.float32, device=dev)
+        self.token = t.zeros(batch, dtype=t.int32, device=dev)
+        self.logprob = t.zeros(batch, dtype=t.float32, device=dev)
+        self.logits = t.zeros(batch, c.vocab_padded, dtype=t.float32, device=dev)
+        self._ws = {}
+        self._len_bound = 0
+
+    def _bufs(self, C):
+        import torch
+        t = torch
+        if C not in self._ws:
+            c, R, dev = self.eng.cfg, self.B * C, self.eng.device
+            f = lambda *s: t.empty(*s, dtype=t.float32, device=dev)
+            self._ws[C] = dict(ids=t.zeros(R, dtype=t.int32, device=dev), pos=t.zeros(R, dtype=t.int32, device=dev), x=f(R, c.d_model), h=f(R, c.d_model),
+                               qkv=f(R, 3 * c.d_model), att=f(R, c.d_model), ff=f(R, c.d_ff), mean=f(R), rstd=f(R))
+        return self._ws[C]
+
+    def reset(self):
+        self.len.zero_()
+        self._len_bound = 0
+
+    def forward(self, tokens, cnt, chunk: int, all_hidden=None, len_bound_after: Optional[int] = None):
+        """tokens int32 [B*chunk], cnt int32 [B] (env b's new tokens are slots b*chunk .. b*chunk + cnt[b] - 1): appends them to the cache,
+        advances self.len, leaves ln_f(hidden of each env's last new token) in self.last_hidden."""
+        e, c, L, sp = self.eng, self.eng.cfg, self.eng._L, _lib.stream_ptr()
+        C, B, d, R = chunk, self.B, c.d_model, self.B * chunk
+        self._len_bound = self._len_bound + C if len_bound_after is None else int(len_bound_after)
+        if self._len_bound > self.tmax:
+            raise _lib.LmrlError(f"KV cache overflow: up to {self._len_bound} positions into a cache of tmax = {self.tmax}")
+        w = self._bufs(C)
+        w["ids"].copy_(tokens.view(-1)[:R])
+        _lib.check(L.lmrl_chunk_begin_f32(_lib.ptr(self.len), _lib.ptr(cnt), _lib.ptr(w["ids"]), _lib.ptr(w["pos"]), B, C, c.n_pos, sp), "lmrl_chunk_begin_f32")
+        x, h, qkv, att, ff = w["x"], w["h"], w["qkv"], w["att"], w["ff"]
+        ops.embed_fwd(e.wte, e.wpe, w["ids"], w["pos"], x, R, d)
+        for l, p in enumerate(e.layers):
+            ops.layernorm_fwd(x, p["ln_1.weight"], p["ln_1.bias"], h, w["mean"], w["rstd"], R, d, c.ln_eps)
+            ops.sgemm(h, p["attn.c_attn.weight"], qkv, R, 3 * d, d, lda=d, ldb=3 * d, ldc=3 * d, bias=p["attn.c_attn.bias"])
+            _lib.check(L.lmrl_attn_cached_f32(_lib.ptr(qkv), _lib.ptr(self.kv[l, 0]), _lib.ptr(self.kv[l, 1]), _lib.ptr(self.len), _lib.ptr(cnt),
+                                              _lib.ptr(att), B, C, c.n_head, self.tmax, sp), "lmrl_attn_cached_f32")
+            # x += att . Wproj + b   (bias through a beta = 1 accumulate: h = att.W + b, then x += h)
+            ops.sgemm(att, p["attn.c_proj.weight"], h, R, d, d, lda=d, ldb=d, ldc=d, bias=p["attn.c_proj.bias"])
+            ops.axpby(1.0, h, 1.0, x, x)
+            ops.layernorm_fwd(x, p["ln_2.weight"], p["ln_2.bias"], h, w["mean"], w["rstd"], R, d, c.ln_eps)
+            ops.sgemm(h, p["mlp.c_fc.weight"], ff, R, c.d_ff, d, lda=d, ldb=c.d_ff, ldc=c.d_ff, bias=p["mlp.c_fc.bias"])
+            ops.gelu_fwd(ff, ff)
+            ops.sgemm(ff, p["mlp.c_proj.weight"], h, R, d, c.d_ff, lda=c.d_ff, ldb=d, ldc=d, bias=p["mlp.c_proj.bias"])
+            ops.axpby(1.0, h, 1.0, x, x)
+        if all_hidden is not None:
+            ops.layernorm_fwd(x, e.lnf_g, e.lnf_b, all_hidden, w["mean"], w["rstd"], R, d, c.ln_eps)
+        _lib.check(L.lmrl_chunk_end_f32(_lib.ptr(x), _lib.ptr(cnt), _lib.ptr(self._last_x), _lib.ptr(self.len), B, C, d, sp), "lmrl_chunk_end_f32")
+        ops.layernorm_fwd(self._last_x, e.lnf_g, e.lnf_b, self.last_hidden, w["mean"], w["rstd"], B, d, c.ln_eps)
+        return self.last_hidden
+
+    def broadcast_prefix_from(self, src: "KVSessionF32", n_pos: int):
+        """Every env starts with the n_pos-token prefix held by the 1-env session `src` (device-to-device row copies)."""
+        assert src.B == 1 and src.eng is self.eng
+        self.kv[:, :, :, :n_pos].copy_(src.kv[:, :, :, :n_pos].expand(-1, -1, self.B, -1, -1))
+        self._last_x.copy_(src._last_x.expand(self.B, -1))
+        self.last_hidden.copy_(src.last_hidden.expand(self.B, -1))
+        self.len.fill_(n_pos)
+        self._len_bound = max(self._len_bound, n_pos)
+
+    def lm_logits(self, hidden=None):
+        """logits fp32 [B][vocab_padded] = hidden . wte^T (tied LM head) into self.logits."""
+        c = self.eng.cfg
+        h = self.last_hidden if hidden is None else hidden
+        ops.sgemm(h, self.eng.wte, self.logits, self.B, c.vocab_padded, c.d_model, trans_b=True, lda=c.d_model, ldb=c.d_model, ldc=c.vocab_padded)
+        return self.logits
+
+    def sample(self, params: SampleParams, steer_tok=None, active=None, hidden=None, logits_out=None, q1=None, q2=None, want_logprob: bool = True):
+        """One token per env from `hidden` (default: last_hidden): fp32 LM head, then the sampler on the materialised logits (same streams and
+        warpers as the fused bf16 path)."""
+        if q1 is not None or q2 is not None:
+            raise _lib.LmrlError("GPT2EngineF32 samples from the policy logits only (the ILQL Q-head operands of the fused sampler are bf16)")
+        c = self.eng.cfg
+        lg = self.lm_logits(hidden)
+        _lib.check(self.eng._L.lmrl_sample_logits_steer(_lib.ptr(lg), c.vocab_padded, self.B, c.vocab, ctypes.byref(params), _lib.ptr(steer_tok),
+                                                        _lib.ptr(active), _lib.ptr(self.token), _lib.ptr(self.logprob) if want_logprob else None,
+                                                        _lib.stream_ptr()), "lmrl_sample_logits_steer")
+        if logits_out is not None:
+            logits_out.copy_(lg)           # (after the steer offset, as the fused path reports its combined logits)
+        return self.token, (self.logprob if want_logprob else None)

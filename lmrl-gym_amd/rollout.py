@@ -188,13 +188,13 @@ class WordleRolloutEngine:
         _lib.check(rc, what)
 
     def run_episode(self, seeds: np.ndarray, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0,
-                    scripted_guesses=None, steer_strength: float = 0.0, n_turns: int = W.N_TRIES, epoch=None):
+                    scripted_guesses=None, steer_strength: float = 0.0, n_turns: int = W.N_TRIES, epoch=None, sampler: str = "philox"):
         """One full episode for all B envs (asynchronous: returns after enqueueing; read results after a sync).
 
         scripted_guesses: optional int32 device tensor [n_turns][B] of packed guesses; with steer_strength > 0 the
         sampler is steered towards spelling them (synthetic-workload hook; every logit is still computed and sampled).
         """
-        for _ in self.episode_phases(seeds, temperature, top_k, sample_seed, scripted_guesses, steer_strength, n_turns, epoch):
+        for _ in self.episode_phases(seeds, temperature, top_k, sample_seed, scripted_guesses, steer_strength, n_turns, epoch, sampler):
             pass
         return self.traj
 
@@ -230,9 +230,18 @@ class WordleRolloutEngine:
         return self.traj
 
     def episode_phases(self, seeds: np.ndarray, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0,
-                       scripted_guesses=None, steer_strength: float = 0.0, n_turns: int = W.N_TRIES, epoch=None):
+                       scripted_guesses=None, steer_strength: float = 0.0, n_turns: int = W.N_TRIES, epoch=None, sampler: str = "philox"):
         """Generator form of `run_episode`: enqueues one phase (a model forward + its sampling / env bookkeeping) per
-        `next()`, so a host loop can interleave several engines on different HIP streams."""
+        `next()`, so a host loop can interleave several engines on different HIP streams.
+
+        sampler="jax": the reference's random stream instead of the package's Philox stream — a policy freshly built with
+        `prng_key=jax.random.PRNGKey(sample_seed)` splits its key once per turn (one `act()` per lock-step turn,
+        ppo/gpt2/interface.py:524-526) and HF-Flax `_sample` once per generated token; every token of the batch is one
+        `jax.random.categorical(key, logits[B, V])` (jax_prng.py, csrc/threefry.h).  Eager launches only (keys are host-walked)."""
+        from . import jax_prng
+        from .gpt2 import RNG_JAX
+        assert sampler in ("philox", "jax")
+        pol_key = jax_prng.prng_key(sample_seed) if sampler == "jax" else None
         L, sp, tr, B = self._L, _lib.stream_ptr(), ctypes.byref(self._ctraj), self.B
         self.env.reset_device(seeds if not isinstance(seeds, np.ndarray) else np.asarray(seeds, dtype=np.uint64))
         pairs = [(self.ses, self.ses1)] + ([(self.vses, self.vses1)] if self.vses is not None else [])     # (pi_beta), (value base)
@@ -253,12 +262,20 @@ class WordleRolloutEngine:
             logits_out = torch.empty(B, self.eng.cfg.vocab_padded, dtype=torch.float32, device=self.dev)
         steered = scripted_guesses is not None and steer_strength != 0.0
         for turn in range(n_turns):
+            tok_keys = None
+            if pol_key is not None:
+                pol_key, new_key = jax_prng.split(pol_key)
+                tok_keys = jax_prng.SampleKeys(new_key)
             if steered:     # one launch spells the whole scripted guess of this turn
                 self._ck(L.lmrl_wordle_tok_steer(self._tok, _lib.ptr(scripted_guesses[turn]), -1, _lib.ptr(self.steer), B, sp), "tok_steer")
             for k in range(self.max_new):
                 steer = self.steer[min(k, 5)] if steered else None
-                p = SampleParams(temperature, top_k, sample_seed, self.sample_step, steer_strength, self.beta, self.tokens.pad,
-                                 _lib.ptr(epoch))
+                if tok_keys is not None:
+                    p = SampleParams(temperature, top_k, jax_prng.key_to_seed(tok_keys.next()), self.sample_step, steer_strength, self.beta,
+                                     self.tokens.pad, None, 0.0, RNG_JAX)
+                else:
+                    p = SampleParams(temperature, top_k, sample_seed, self.sample_step, steer_strength, self.beta, self.tokens.pad,
+                                     _lib.ptr(epoch))
                 self.sample_step += 1
                 qops = [None, None]
                 if self.vses is not None:     # Q heads on the value base's last hidden state: relu(dense1) here, dense2 inside the sampler

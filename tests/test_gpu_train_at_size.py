@@ -1,0 +1,269 @@
+"""GPU tier: train-step parity AT THE SIZE THE BENCH TIMES (VERDICT r02 item 3 / "what's weak" #5).
+
+Two layers of evidence, both at GPT-2-small's full depth (12 layers, d = 768, 12 heads, V = 50257):
+ (a) a float64 ANCHOR: ILQL at B = 4 x T = 512 and PPO at B = 2 x T = 1024 against torch-CPU float64 autograd of the oracle restatement
+     (oracle/gpt2.py, oracle/rl.py) — loss and every log entry within 1e-4 relative, every gradient within 3e-4 of the tensor's largest
+     entry (the tolerances of tests/test_gpu_train_width.py).  Full depth, full sequence length: flash attention over 8 / 16 key tiles,
+     LayerNorm / residual error accumulation over 12 blocks, row compaction on ~1 000 rows, deterministic split-K on K = 2 048.
+ (b) the EXACT bench shapes (ILQL B = 32 x T = 512 — M3; PPO B = 32 x T = 1024 — M4; `bench.py::run_train_step` batches) where float64
+     on the host would need minutes and ~50 GB: the default step (flash attention, Q / LM heads on the masked rows only, 128 x 128 sgemm
+     tiles with split-K at K = 16 384 / 32 768) against an independent second path through the same C ABI — materialised [B*H, T, T]
+     attention + softmax kernels, vocabulary heads on ALL rows, every matmul on the 64 x 64-tile sgemm kernel without split-K
+     (`lmrl_sgemm_set_variant(1)`).  Different kernels, different association orders (fp32 sums over K = 16 384 / 32 768 rows in two
+     different orders): loss / logs within 2e-5 relative; gradients: relative L2 error of every tensor <= 1e-4 and every entry within 3e-3
+     of the tensor's largest entry (`_same_gradient`).  (a) ties the family of paths to float64; (b) carries it to the timed size.
+Reference: LLM_RL/algorithms/ilql/gpt2/interface.py:88-367, ppo/gpt2/interface.py:72-211, train_ilql_gpt2.py:58,65, train_ppo_gpt2.py:74-75.
+"""
+import numpy as np
+import pytest
+
+import lmrl_gym_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+V = 50257
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from lmrl_gym_amd import _lib
+    return _lib.require_gpu()
+
+
+def _close(got, exp, rtol, name=""):
+    got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
+    np.testing.assert_allclose(got, exp, rtol=rtol, atol=rtol * max(float(np.abs(exp).max()), 1e-12), err_msg=name)
+
+
+def _flat_logs(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(_flat_logs(v, prefix + k + "."))
+        else:
+            out[prefix + k] = float(v)
+    return out
+
+
+def _model(seed, n_pos):
+    from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
+    cfg = GPT2Config(12, 12, 768, 3072, V, n_pos)
+    sd = init_hf_style_state_dict(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    for k in sd:   # non-trivial biases / LN parameters, weights above the 0.02 init so that no gradient vanishes through 12 blocks
+        sd[k] = sd[k] * 1.5 + (0.1 * torch.randn(sd[k].shape, generator=g) if sd[k].dim() == 1 else 0)
+    return cfg, sd
+
+
+def _batch(rng, B, T, pad, ragged=True):
+    ids = rng.randint(1, V - 1, size=(B, T)).astype(np.int32)
+    lens = np.full(B, T)
+    if ragged:
+        lens[1::2] = T - 1 - rng.randint(0, T // 3, size=len(lens[1::2]))
+    for b in range(B):
+        ids[b, lens[b]:] = pad
+    t = np.arange(T - 1)
+    sta = np.broadcast_to(((t >= 4) & (((t - 4) // 6) % 2 == 0))[None, :], (B, T - 1)).copy()     # 6-on / 6-off after a 4-token header (M3)
+    sta &= t[None, :] < (lens[:, None] - 1)
+    return ids, sta
+
+
+def _heads(d, g, outs):
+    mk = lambda out: {"dense1.kernel": torch.randn(d, d, generator=g) * 0.05, "dense1.bias": torch.randn(d, generator=g) * 0.1,
+                      "dense2.kernel": torch.randn(d, out, generator=g) * 0.05, "dense2.bias": torch.full((out,), -0.4)}
+    return [mk(o) for o in outs]
+
+
+def _am_pos(ids, pad):
+    am = torch.from_numpy((ids != pad).astype(np.int64))
+    return am, (am.cumsum(-1) - 1).clamp(min=0)
+
+
+# --------------------------------------------------------------------------------------------------------------- (a) float64 anchors
+def test_ilql_step_12_layers_T512_vs_float64(dev):
+    from lmrl_gym_amd.algorithms import ilql
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    from oracle import gpt2 as O, rl
+    B, T = 4, 512
+    cfg, sd = _model(7, T)
+    _, tsd = _model(8, T)
+    pad = V - 1
+    rng = np.random.RandomState(9)
+    d = cfg.d_model
+    ids, sta = _batch(rng, B, T, pad)
+    assert sta.sum() > 900
+    rewards = (rng.randn(B, T - 1) * sta).astype(np.float32)
+    dones = np.array([1, 0, 0, 1], dtype=np.float32)
+    hq1, hq2, hv = _heads(d, torch.Generator().manual_seed(11), (V, V, 1))
+    kw = dict(gamma=0.99, tau=0.7, cql_weight=0.01)
+    psd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    req = lambda h: {k: v.double().requires_grad_(True) for k, v in h.items()}
+    rq1, rq2, rv = req(hq1), req(hq2), req(hv)
+    am, pos = _am_pos(ids, pad)
+    idt = torch.from_numpy(ids).long()
+    _, hid = O.forward(psd, idt, cfg.n_head, attention_mask=am, position_ids=pos, return_hidden=True)
+    with torch.no_grad():
+        _, thid = O.forward({k: v.double() for k, v in tsd.items()}, idt, cfg.n_head, attention_mask=am, position_ids=pos, return_hidden=True)
+    mh = lambda x, h: rl.mlp_head(x, h["dense1.kernel"], h["dense1.bias"], h["dense2.kernel"], h["dense2.bias"])
+    q1o, q2o, vo = mh(hid, rq1), mh(hid, rq2), mh(hid, rv)
+    with torch.no_grad():
+        tq1o, tq2o = mh(thid, {k: v.detach() for k, v in rq1.items()}), mh(thid, {k: v.detach() for k, v in rq2.items()})
+    q1, q2, v, v_final, tq1, tq2 = rl.ilql_gather_qv(q1o, q2o, vo, tq1o, tq2o, idt, am, torch.from_numpy(sta), torch.from_numpy(dones))
+    del tq1o, tq2o
+    loss_ref, logs_ref = rl.ilql_loss(q1, q2, v, v_final, tq1, tq2, q1o[:, :-1], q2o[:, :-1], idt[:, 1:], am[:, 1:].double(),
+                                      torch.from_numpy(sta), torch.from_numpy(rewards).double(), **kw)
+    loss_ref.backward()
+    base = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
+    tbase = GPT2F32({k: v.clone() for k, v in tsd.items()}, cfg.n_head, device=dev)
+    assert base.attention == "flash"
+    cp = lambda h: {k: v.clone() for k, v in h.items()}
+    tr = ilql.GPT2ILQLTrain(base, MLPHeadF32(cp(hq1), dev), MLPHeadF32(cp(hq2), dev), MLPHeadF32(cp(hv), dev), pad, kw,
+                            target_base=tbase, lr=1e-4, polyak_alpha=0.005)
+    assert tr.compact_q_rows
+    _, loss, logs = tr.step(ids, sta, rewards, dones)
+    assert abs(loss - float(loss_ref)) <= 1e-4 * abs(float(loss_ref)), (loss, float(loss_ref))
+    rf, gf = _flat_logs(logs_ref), _flat_logs(logs)
+    assert set(rf) == set(gf)
+    for k in rf:
+        assert abs(gf[k] - rf[k]) <= 1e-4 * max(1.0, abs(rf[k])), (k, gf[k], rf[k])
+    bg, g1, g2, gv = tr.last_grads
+    for k in psd:
+        _close(bg[k].cpu(), psd[k].grad, 3e-4, k)
+    for got, ref in ((g1, rq1), (g2, rq2), (gv, rv)):
+        for k in ref:
+            _close(got[k].cpu(), ref[k].grad, 3e-4, k)
+
+
+def test_ppo_step_12_layers_T1024_vs_float64(dev):
+    from lmrl_gym_amd.algorithms import ppo
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
+    from oracle import gpt2 as O, rl
+    B, T = 2, 1024
+    cfg, sd = _model(3, T)
+    pad = V - 1
+    rng = np.random.RandomState(4)
+    ids, sta = _batch(rng, B, T, pad)
+    hk, hb = torch.randn(cfg.d_model, 1, generator=torch.Generator().manual_seed(1)) * 0.05, torch.tensor([-4.1])
+    olp, ov, oa, orr = (rng.randn(B, T - 1).astype(np.float32) * s for s in (0.2, 1, 1, 1))
+    kw = dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0)
+    psd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    hkr, hbr = hk.double().requires_grad_(True), hb.double().requires_grad_(True)
+    am, pos = _am_pos(ids, pad)
+    logits, hid = O.forward(psd, torch.from_numpy(ids).long(), cfg.n_head, attention_mask=am, position_ids=pos, return_hidden=True)
+    values = rl.linear_head(hid, hkr, hbr)[:, :-1, 0]
+    logprobs = rl.token_logprobs_from_logits(logits, torch.from_numpy(ids))
+    olp = logprobs.detach().numpy().astype(np.float32) + olp
+    td = lambda x: torch.from_numpy(np.asarray(x)).double()
+    loss_ref, logs_ref = rl.ppo_loss(am[:, 1:].double(), logprobs, values, torch.from_numpy(sta), td(olp), td(ov), td(oa), td(orr), **kw)
+    loss_ref.backward()
+    pol = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
+    head = LinearHeadF32(dict(kernel=hk.clone(), bias=hb.clone()), dev)
+    tr = ppo.GPT2PPOTrain(pol, head, pad, kw, lr=1e-4, weight_decay=0.01)
+    _, loss, logs = tr.step(ids, sta, olp, ov, oa, orr)
+    assert abs(loss - float(loss_ref)) <= 1e-4 * abs(float(loss_ref)), (loss, float(loss_ref))
+    rf, gf = _flat_logs(logs_ref), _flat_logs(logs)
+    for k in rf:
+        assert abs(gf[k] - rf[k]) <= 1e-4 * max(1.0, abs(rf[k])), (k, gf[k], rf[k])
+    pg, hg = tr.last_grads
+    for k in psd:
+        _close(pg[k].cpu(), psd[k].grad, 3e-4, k)
+    _close(hg["kernel"].cpu(), hkr.grad, 3e-4); _close(hg["bias"].cpu(), hbr.grad, 3e-4)
+
+
+# --------------------------------------------------------------------------------------------------------------- (b) the bench shapes
+def _second_path(fn):
+    """Run `fn` with every matmul on the 64 x 64-tile sgemm kernel, no split-K (tools hook; process-wide, so restored in `finally`)."""
+    from lmrl_gym_amd import _lib
+    L = _lib.lib()
+    L.lmrl_sgemm_set_variant(1)
+    try:
+        return fn()
+    finally:
+        L.lmrl_sgemm_set_variant(0)
+
+
+def _same_gradient(ga, gb, name):
+    """Two fp32 paths over 16 k - 32 k rows: the tensors must agree in the large (relative L2 error <= 1e-4, measured up to 3.9e-5 — a wrong split-K slice, a
+    missing compacted row or a wrong attention tile would give O(1)) and entry by entry within 3e-3 of the tensor's largest entry (a handful
+    of rows with residual-stream outliers amplify fp32 rounding through the LayerNorm backward: measured 0.005 % of the entries of the
+    embedding gradient beyond 3e-4 of the maximum, none beyond 2.2e-3; the float64 anchors above hold 3e-4 everywhere at B = 2 - 4)."""
+    a, b = ga.double(), gb.double()
+    nb = float(b.norm())
+    assert float((a - b).norm()) <= 1e-4 * max(nb, 1e-30), (name, float((a - b).norm()), nb)
+    _close(a, b, 3e-3, name)
+
+
+def _grads_to_host(gds):
+    return [{k: v.detach().cpu().clone() for k, v in g.items()} for g in gds]
+
+
+def test_ilql_step_at_bench_size_default_path_equals_second_path(dev):
+    from lmrl_gym_amd.algorithms import ilql
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    B, T = 32, 512                                         # M3 (train_ilql_gpt2.py:58,65), the batch bench.py times
+    cfg, sd = _model(17, T)
+    _, tsd = _model(18, T)
+    pad = V - 1
+    rng = np.random.RandomState(19)
+    ids, sta = _batch(rng, B, T, pad)
+    assert sta.sum() > 7000                                # row compaction on thousands of rows
+    rewards = np.where(sta & ~np.roll(sta, -1, axis=1), -1.0, 0.0).astype(np.float32)
+    dones = (rng.rand(B) < 0.5).astype(np.float32)
+    heads = _heads(cfg.d_model, torch.Generator().manual_seed(21), (V, V, 1))
+    kw = dict(gamma=0.99, tau=0.7, cql_weight=0.01)
+
+    def run(attention, compact):
+        base = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev, attention=attention)
+        tbase = GPT2F32({k: v.clone() for k, v in tsd.items()}, cfg.n_head, device=dev, attention=attention)
+        cp = lambda h: {k: v.clone() for k, v in h.items()}
+        tr = ilql.GPT2ILQLTrain(base, MLPHeadF32(cp(heads[0]), dev), MLPHeadF32(cp(heads[1]), dev), MLPHeadF32(cp(heads[2]), dev), pad, kw,
+                                target_base=tbase, lr=3e-5, compact_q_rows=compact)
+        _, loss, logs = tr.step(ids, sta, rewards, dones)
+        out = (loss, _flat_logs(logs), _grads_to_host(tr.last_grads))
+        del tr, base, tbase
+        torch.cuda.empty_cache()
+        return out
+    loss_a, logs_a, g_a = run("flash", True)
+    loss_b, logs_b, g_b = _second_path(lambda: run("materialized", False))
+    assert np.isfinite(loss_a) and abs(loss_a - loss_b) <= 2e-5 * abs(loss_b), (loss_a, loss_b)
+    assert set(logs_a) == set(logs_b)
+    for k in logs_b:
+        assert abs(logs_a[k] - logs_b[k]) <= 2e-5 * max(1.0, abs(logs_b[k])), (k, logs_a[k], logs_b[k])
+    for ga, gb in zip(g_a, g_b):
+        for k in gb:
+            assert float(gb[k].abs().max()) > 0 or float(ga[k].abs().max()) == 0, k
+            _same_gradient(ga[k], gb[k], k)
+
+
+def test_ppo_step_at_bench_size_default_path_equals_second_path(dev):
+    from lmrl_gym_amd.algorithms import ppo
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
+    B, T = 32, 1024                                        # M4 (train_ppo_gpt2.py:74-75)
+    cfg, sd = _model(27, T)
+    pad = V - 1
+    rng = np.random.RandomState(28)
+    ids, sta = _batch(rng, B, T, pad)
+    hk, hb = torch.randn(cfg.d_model, 1, generator=torch.Generator().manual_seed(2)) * 0.05, torch.tensor([-4.1])
+    f = lambda s_: (rng.randn(B, T - 1) * s_).astype(np.float32)
+    olp, ov, oa, orr = f(0.1) - 10.8, f(1), f(1), f(1)
+    kw = dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0)
+
+    def run(attention, compact):
+        pol = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev, attention=attention)
+        head = LinearHeadF32(dict(kernel=hk.clone(), bias=hb.clone()), dev)
+        tr = ppo.GPT2PPOTrain(pol, head, pad, kw, lr=1e-5)
+        tr.compact_rows = compact
+        _, loss, logs = tr.step(ids, sta, olp, ov, oa, orr)
+        out = (loss, _flat_logs(logs), _grads_to_host(tr.last_grads))
+        del tr, pol
+        torch.cuda.empty_cache()
+        return out
+    loss_a, logs_a, g_a = run("flash", True)
+    loss_b, logs_b, g_b = _second_path(lambda: run("materialized", False))
+    assert np.isfinite(loss_a) and abs(loss_a - loss_b) <= 2e-5 * abs(loss_b), (loss_a, loss_b)
+    for k in logs_b:
+        assert abs(logs_a[k] - logs_b[k]) <= 2e-5 * max(1.0, abs(logs_b[k])), (k, logs_a[k], logs_b[k])
+    for ga, gb in zip(g_a, g_b):
+        for k in gb:
+            _same_gradient(ga[k], gb[k], k)

@@ -4,7 +4,7 @@
 # gfx950 FETCH_SIZE x2 correction is applied by the reader, not here).
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python /root/repo/bench.py --graph 0 --steps 1 --warmup 1 --no-cpu-baseline --no-train-step > /dev/null 2>&1 || echo "pass $c failed/timeout"
+  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python /root/repo/bench.py --graph 0 --steps 1 --warmup 1 --no-cpu-baseline --no-train-step --no-fp32-mode > /dev/null 2>&1 || echo "pass $c failed/timeout"
 done
 python - <<'PY'
 import csv, glob, json, collections
@@ -24,7 +24,7 @@ for c, key in (("FETCH_SIZE", "fetch_kb_avg"), ("WRITE_SIZE", "write_kb_avg")):
 import sys
 sys.path.insert(0, "/root/repo")
 import bench
-out["__meta__"] = {"csrc_digest": bench.csrc_digest(), "command": "bench.py --graph 0 --steps 1 --warmup 1 --no-cpu-baseline --no-train-step"}
+out["__meta__"] = {"csrc_digest": bench.csrc_digest(), "command": "bench.py --graph 0 --steps 1 --warmup 1 --no-cpu-baseline --no-train-step --no-fp32-mode"}
 json.dump(out, open("/root/repo/gpurun_out/pmc_fetch_write.json", "w"), indent=1)
 out.pop("__meta__")
 for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("fetch_kb_avg", 0) * kv[1].get("launches", 0))[:10]:
