@@ -18,9 +18,21 @@ from . import _lib
 from .envs import wordle as W
 from .gpt2 import GPT2Engine, SampleParams
 
-# GPT-2 BPE ids quoted from memory of the public vocabulary; NOT verifiable in the build container (no tokenizer
-# files offline).  Use `WordleTokenTable.from_tokenizer` whenever a tokenizer is available; for
-# random-init synthetic benchmarks only injectivity matters.
+def gpt2_byte_token_id(byte: int) -> int:
+    """Id of the single-byte token of `byte` in GPT-2's byte-level BPE vocabulary, from the PUBLISHED construction (openai/gpt-2
+    encoder.py `bytes_to_unicode` + vocabulary order): the 188 printable bytes '!'..'~', 0xA1..0xAC, 0xAE..0xFF take ids 0..187 in that
+    order, the remaining 68 bytes (0x00..0x20, 0x7F..0xA0, 0xAD) ids 188..255 in increasing byte order.  Hence 'a'..'z' = 64..89,
+    ':' = 25, '\n' = 198, ' ' = 220."""
+    printable = list(range(33, 127)) + list(range(161, 173)) + list(range(174, 256))
+    if byte in printable:
+        return printable.index(byte)
+    return 188 + [b for b in range(256) if b not in printable].index(byte)
+
+
+# Ids of the MERGED tokens (' a'..' z', 'Word', 'le') = 256 + their rank in merges.txt: quoted from memory of the public vocabulary and
+# NOT verifiable in the build container (no tokenizer files offline, SURVEY.md §8c) — the single-byte ids above are derived, these are
+# not.  `WordleTokenTable.from_tokenizer` is the authoritative path whenever a tokenizer is available (scripts/harness.py uses it when
+# transformers finds the gpt2 files); for random-init synthetic benchmarks only injectivity matters.
 _GPT2_SP_LETTERS = [257, 275, 269, 288, 304, 277, 308, 289, 1312, 474, 479, 300, 285, 299, 267, 279, 10662, 374, 264, 256,
                     334, 410, 266, 2124, 331, 1976]
 
@@ -68,10 +80,11 @@ class WordleTokenTable:
 
     @classmethod
     def default_gpt2(cls, pad: int = 50256) -> "WordleTokenTable":
-        lf = list(range(64, 90))                      # 'a'..'z'
+        lf = [gpt2_byte_token_id(97 + i) for i in range(26)]          # 'a'..'z' = 64..89 (derived, see gpt2_byte_token_id)
         ls = list(_GPT2_SP_LETTERS)
-        t = cls(newline=198, pad=pad, letter_first=lf, letter_sp=ls,
-                sym_first=[lf[6], lf[24], lf[1]], sym_sp=[ls[6], ls[24], ls[1]], header=[26449, 293, 25, 198])
+        nl, colon = gpt2_byte_token_id(10), gpt2_byte_token_id(58)    # 198, 25
+        t = cls(newline=nl, pad=pad, letter_first=lf, letter_sp=ls,
+                sym_first=[lf[6], lf[24], lf[1]], sym_sp=[ls[6], ls[24], ls[1]], header=[26449, 293, colon, nl])
         t.strings = {198: "\n", 26449: "Word", 293: "le", 25: ":"}
         for i in range(26):
             t.strings[lf[i]] = chr(97 + i)
@@ -316,23 +329,33 @@ class WordleRolloutEngine:
         post-transition histories, the step reward and the done flag.  `decode(ids) -> str` defaults to the token table."""
         from .environment import InteractionTransition, Text
         dec = decode or (lambda ids: "".join(self.tokens.strings.get(int(i), "") for i in ids))
+        tok = self.traj["tokens"].cpu().numpy(); ia = self.traj["is_action"].cpu().numpy().astype(bool)
+        rw = self.traj["reward"].cpu().numpy(); ntok = self.traj["n_tok"].cpu().numpy(); done = self.traj["env_done"].cpu().numpy().astype(bool)
+        # run boundaries of every env in one vectorised pass: positions where is_action changes (the Text items alternate header, action,
+        # observation, action, ...); the few thousand distinct token runs of a batch are decoded once each (Text is immutable: shared)
+        cache = {}
+
+        def text_of(run, is_action):
+            key = (run.tobytes(), is_action)
+            t = cache.get(key)
+            if t is None:
+                t = cache[key] = Text(dec(run), is_action)
+            return t
         out = []
-        for tok, ia, rw, dn in self.token_trajectories():
-            hist, trans, i, n = [], [], 0, len(tok)
-            while i < n:                                   # split the record into runs of equal is_action = the Text items
-                j = i
-                while j < n and ia[j] == ia[i]:
-                    j += 1
-                # runs alternate: header, action, observation, action, ... (an action is always followed by its observation)
-                hist.append((Text(dec(tok[i:j]), bool(ia[i])), float(rw[j - 1]) if ia[i] else 0.0))
-                i = j
-            texts = [h for h, _ in hist]
-            for k, (t, r) in enumerate(hist):
-                if t.is_action:
-                    has_obs = k + 1 < len(texts)
-                    post = tuple(texts[: k + 2]) if has_obs else tuple(texts[: k + 1])
-                    last = not any(x.is_action for x in texts[k + 1:])
-                    trans.append(InteractionTransition(tuple(texts[:k]), tuple(texts[: k + 1]), post, r, bool(dn) and last))
+        for b in range(self.B):
+            n = int(ntok[b])
+            iab = ia[b, :n]
+            cuts = np.flatnonzero(iab[1:] != iab[:-1]) + 1
+            bounds = [0] + cuts.tolist() + [n]
+            texts = tuple(text_of(tok[b, bounds[k]:bounds[k + 1]], bool(iab[bounds[k]])) for k in range(len(bounds) - 1) if bounds[k + 1] > bounds[k])
+            nt = len(texts)
+            last_action = max((k for k in range(nt) if texts[k].is_action), default=-1)
+            trans = []
+            for k in range(nt):
+                if texts[k].is_action:
+                    # an action is always followed by its observation; reward sits on the action's last token (environment.py:370)
+                    post = texts[: k + 2] if k + 1 < nt else texts[: k + 1]
+                    trans.append(InteractionTransition(texts[:k], texts[: k + 1], post, float(rw[b, bounds[k + 1] - 1]), bool(done[b]) and k == last_action))
             out.append(trans)
         return out
 

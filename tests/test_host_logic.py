@@ -326,3 +326,16 @@ def test_compat_import_paths_resolve_to_the_package():
         sys.path.remove(os.path.abspath(root))
         for k in [k for k in sys.modules if k == "LLM_RL" or k.startswith("LLM_RL.") or k == "llm_rl_scripts" or k.startswith("llm_rl_scripts.")]:
             del sys.modules[k]
+
+
+def test_gpt2_single_byte_token_ids_follow_the_published_construction():
+    """The byte-level part of `WordleTokenTable.default_gpt2()` is DERIVED from openai/gpt-2's `bytes_to_unicode` order (the merged-token
+    ids stay quoted and unverifiable offline — `from_tokenizer` is the authoritative path)."""
+    from lmrl_gym_amd.rollout import WordleTokenTable, gpt2_byte_token_id
+    assert [gpt2_byte_token_id(b) for b in (33, 126, 161, 172, 174, 255)] == [0, 93, 94, 105, 106, 187]
+    assert gpt2_byte_token_id(0) == 188 and gpt2_byte_token_id(10) == 198 and gpt2_byte_token_id(32) == 220 and gpt2_byte_token_id(173) == 255
+    assert sorted(gpt2_byte_token_id(b) for b in range(256)) == list(range(256))
+    t = WordleTokenTable.default_gpt2()
+    assert t.letter_first == list(range(64, 90)) and t.newline == 198 and t.header[-2:] == [25, 198]
+    ids = t.letter_first + t.letter_sp + [t.newline] + t.header
+    assert len(set(t.letter_first + t.letter_sp + [t.newline])) == 53          # injective: the device decoding relies on it
