@@ -1061,6 +1061,9 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
         hipLaunchKernelGGL(attn_bytes_kernel, dim3(1), dim3(256), 0, s, cnt_d, len_d, b, c, cf.n_head * cf.n_layer, ctr, c == 1 ? n_shared : 0);
     LMRL_REQUIRE(!((flags & LMRL_FWD_RAGGED_ALWAYS) && (flags & LMRL_FWD_RAGGED_NEVER)), "lmrl_gpt2_forward: contradictory ragged flags");
     const bool fused = !(flags & LMRL_FWD_LN_STANDALONE) && g_gemm_variant != 1 && ln_fusion_nq(d) != 0;
+    // TIMING-ONLY ablation (tools/bench_ablate_decode.py; results are garbage): leave out one launch class of the single-token decode layers to
+    // measure what removing / hiding that launch could buy at most inside the real dependent chain
+    const unsigned ablate = (c == 1) ? ((flags >> LMRL_FWD_ABLATE_SHIFT) & 0x1fu) : 0u;
     const int nsl = Gpt2Ws::nslots(cf);
     // ragged batches (LN-folded path, unless the caller wants every row's hidden state back): by default only the forwards of
     // large batches qualify (b*c >= 2048); LMRL_FWD_RAGGED_ALWAYS compacts every forward (generation loops whose rows finish at
@@ -1109,7 +1112,8 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
     for (int l = 0; l < cf.n_layer; l++) {
         const Gpt2Layer &L = m->layers[l];
         uint16_t *kc = (uint16_t *)kv_d + (size_t)(2 * l) * kv_layer, *vc = kc + kv_layer;
-        if (fused) {
+        if (fused && (ablate & LMRL_ABLATE_QKV)) {
+        } else if (fused) {
             GemmArgs g{w.h, L.wf_qkv, L.bf_qkv, w.qkv, M, 3 * d, d, d, 3 * d, 3 * d, w.stats, nullptr, L.cs_qkv, nsl, 1.f / (float)d, cf.ln_eps, m_dev};
             if (kv_from_gemm) {   // decode: the new K / V rows go to the cache from this GEMM's epilogue, the attention kernel only reads
                 g.kv_k = kc; g.kv_v = vc; g.kv_len = len_d; g.kv_cnt = cnt_d; g.kv_rowmap = row_map; g.kv_tmax = tmax; g.kv_d = d;
@@ -1129,7 +1133,8 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
         hipEvent_t ev_a, ev_b;
         // decode: the single-shot kernel; LMRL_FWD_ATTN_VALU keeps the multi-round-trip per-head kernel as the cross-check
         const bool shot = c == 1 && !(flags & LMRL_FWD_ATTN_VALU);
-        if (shot) {
+        if (ablate & LMRL_ABLATE_ATTN) {
+        } else if (shot) {
             const bool ev = prof_kernel_events(PROF_ATTN_DECODE, -1.0, &ev_a, &ev_b);   // start/stop events attached to the dispatch itself
             DecodePrefix dp{};
             if (pfx) {
@@ -1175,11 +1180,12 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
             }
         } else if (fused) {
             GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
-            LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, s));
+            if (!(ablate & LMRL_ABLATE_PROJ)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, s));
             GemmArgs gf{w.h, L.wf_fc, L.bf_fc, w.ff, M, cf.d_ff, d, d, cf.d_ff, cf.d_ff, w.stats, nullptr, L.cs_fc, nsl, 1.f / (float)d, cf.ln_eps, m_dev};
-            LMRL_CHECK_HIP(gemm_launch_ln<EPI_GELU_BF16_LN>(gf, s));
+            if (!(ablate & LMRL_ABLATE_FC)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_GELU_BF16_LN>(gf, s));
             GemmArgs g2{w.ff, L.w_fc2, L.b_fc2, w.x, M, d, cf.d_ff, cf.d_ff, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
-            if (l + 1 < cf.n_layer) LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(g2, s));
+            if (ablate & LMRL_ABLATE_FC2) {}
+            else if (l + 1 < cf.n_layer) LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(g2, s));
             else LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(g2, s));      // ln_f reads the fp32 stream directly
         } else {
             GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d};
