@@ -303,6 +303,11 @@ int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *
  * transposed operands of the train step's dW products, k = B*T) are padded so that the rows of a tile do not all start in one HBM channel */
 int lmrl_gemm_bf16_ld(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc, int n_store,
                       int epilogue, void *stream);
+/* c[m][n_store] fp32 = resid[m][..] + a . w^T + bias with the residual operand in ANOTHER buffer (row pitch ldr): the residual add of a
+ * transformer block (x_mid = x + attn.c_proj(att), x_out = x_mid + mlp.c_proj(g)) folded into the projection's epilogue when the block's
+ * input / middle / output streams are kept as separate tensors — the train step's forward (its LayerNorm backward reads all three). */
+int lmrl_gemm_bf16_resid(const void *a_d, const void *w_d, const float *bias_d, const float *resid_d, int ldr, float *c_d, int m, int n, int k, int lda,
+                         int ldw, int ldc, int n_store, void *stream);
 
 /* Split-K form for products with few output tiles and a long K (the train step's weight-gradient products dW = x^T . dy: K = B*T):
  * S copies of the 128 x 128 tile grid each accumulate a slice of K into fp32 partials in ws_d, a fixed-order reduce then writes

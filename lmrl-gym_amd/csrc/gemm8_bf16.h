@@ -313,7 +313,8 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
                     m = m < Mr ? m : Mr - 1;
                     int n = n0 + wn * TN + i * 16 + lq * 4;
                     n = n < g.n_store ? n : 0;
-                    xres[i][j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(g.C) + (size_t)m * g.ldc + n);
+                    xres[i][j] = (EPI == EPI_RESID_F32 && g.resid) ? *reinterpret_cast<const f32x4 *>(g.resid + (size_t)m * g.ldr + n)
+                                                                   : *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(g.C) + (size_t)m * g.ldc + n);
                 }
         };
         g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, prefetch);

@@ -117,6 +117,10 @@ struct GemmArgs {
     uint16_t *kv_k, *kv_v;
     const int *kv_len, *kv_cnt, *kv_rowmap;
     int kv_tmax, kv_d;
+    // EPI_RESID_F32 only: the residual operand when it is NOT the output buffer — C = resid + acc + bias (null: in place, C += acc + bias).
+    // The train step keeps a block's input, middle and output residual streams as separate tensors (its LayerNorm backward reads them).
+    const float *resid;
+    int ldr;
 };
 
 // cache row (b * tmax + len[b]) the K/V columns of GEMM row m are appended to, or -1.  Loads are unconditional on clamped indices (selects, no
@@ -243,7 +247,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
                 *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc + n) = o;
             } else if (EPI == EPI_RESID_F32) {
                 f32x4 *p = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n);
-                *p = *p + v;
+                const f32x4 r = g.resid ? *reinterpret_cast<const f32x4 *>(g.resid + (size_t)m * g.ldr + n) : *p;
+                *p = r + v;
             } else {
                 *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n) = v;
             }
@@ -486,7 +491,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
                     m = m < Mr ? m : Mr - 1;
                     int n = n0 + wn * (BN / 2) + i * 16 + lq * 4;
                     n = n < g.n_store ? n : 0;
-                    xres[i][j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(g.C) + (size_t)m * g.ldc + n);
+                    xres[i][j] = (EPI == EPI_RESID_F32 && g.resid) ? *reinterpret_cast<const f32x4 *>(g.resid + (size_t)m * g.ldr + n)
+                                                                   : *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(g.C) + (size_t)m * g.ldc + n);
                 }
         };
         glds_mainloop<BM, BN, STAGES, FN * FM>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, prefetch);

@@ -98,6 +98,9 @@ inline hipError_t gemm_launch(const GemmArgs &g, hipStream_t s) {
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || EPI == EPI_F32) {
         if (g.M >= 2048 && g.N % 128 == 0 && g.K < 2048) return gemm8_launch<128, 128, 2, 4, 2, EPI>(g, s);   // wide prefill GEMMs: 8-wave 128x128 tiles
     }
+    if constexpr (EPI == EPI_RESID_F32) {      // the train forward's projection + residual add (separate residual operand): same tile as its EPI_F32 form
+        if (g.resid && g.M >= 2048 && g.N % 128 == 0 && g.K < 2048) return gemm8_launch<128, 128, 2, 4, 2, EPI>(g, s);
+    }
     if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI>(g, s);
     if (g.K >= 2048) {
         // dW products (K = B*T): more 64x64 tiles than can be co-resident (512) -> 128x128 tiles in one round (dw fc: 165 vs 228 us)

@@ -1301,6 +1301,17 @@ int lmrl_gemm_bf16_ld(const void *a_d, const void *w_d, const float *bias_d, voi
     return LMRL_OK;
 }
 
+int lmrl_gemm_bf16_resid(const void *a_d, const void *w_d, const float *bias_d, const float *resid_d, int ldr, float *c_d, int m, int n, int k, int lda,
+                         int ldw, int ldc, int n_store, void *stream) {
+    LMRL_REQUIRE(a_d && w_d && c_d && resid_d && m > 0 && n > 0 && k > 0, "lmrl_gemm_bf16_resid: bad argument");
+    LMRL_REQUIRE(n % 64 == 0 && k % 64 == 0 && lda % 8 == 0 && ldc % 4 == 0 && ldr % 4 == 0 && lda >= k && (ldw == 0 || (ldw >= k && ldw % 8 == 0)),
+                 "lmrl_gemm_bf16_resid: n, k must be multiples of 64 and the operand pitches multiples of 8 (4 for fp32) elements covering k");
+    GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, bias_d, c_d, m, n, k, lda, ldc, n_store > 0 ? n_store : n};
+    g.ldw = ldw; g.resid = resid_d; g.ldr = ldr;
+    LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(g, as_stream(stream)));
+    return LMRL_OK;
+}
+
 int lmrl_gemm_bf16(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda, int ldc, int n_store, int epilogue,
                    void *stream) {
     return lmrl_gemm_bf16_ld(a_d, w_d, bias_d, c_d, m, n, k, lda, 0, ldc, n_store, epilogue, stream);

@@ -149,8 +149,7 @@ class GPT2F32:
             ops.sgemm(P, qkv, att, T, hd, T, lda=T, ldb=3 * d, ldc=d, b_off=2 * d, batch=(B, H), sa=(H * T * T, T * T),
                       sb=(T * 3 * d, hd), sc=(T * d, hd))
         x_mid = new(R, d)
-        ops.linear_fwd(att, p[q + "attn.c_proj.weight"], p[q + "attn.c_proj.bias"], x_mid, R, d, d, mm=self.mm, xb=attb)
-        ops.axpby(1.0, x_mid, 1.0, x, x_mid)
+        ops.linear_fwd(att, p[q + "attn.c_proj.weight"], p[q + "attn.c_proj.bias"], x_mid, R, d, d, mm=self.mm, xb=attb, resid=x)      # x_mid = x + proj(att)
         c["m2"], c["r2"] = new(R), new(R)
         h2 = h2b = None
         if stage:
@@ -169,8 +168,7 @@ class GPT2F32:
             g = new(R, self.d_ff)
             ops.gelu_fwd(f, g)
         x_out = new(R, d)
-        ops.linear_fwd(g, p[q + "mlp.c_proj.weight"], p[q + "mlp.c_proj.bias"], x_out, R, self.d_ff, d, mm=self.mm, xb=gb)
-        ops.axpby(1.0, x_out, 1.0, x_mid, x_out)
+        ops.linear_fwd(g, p[q + "mlp.c_proj.weight"], p[q + "mlp.c_proj.bias"], x_out, R, self.d_ff, d, mm=self.mm, xb=gb, resid=x_mid)     # x_out = x_mid + mlp
         c.update(h1b=h1b, attb=attb, h2b=h2b, gb=gb)
         c.update(h1=h1, qkv=qkv, P=P, att=att, x_mid=x_mid, h2=h2, f=f, g=g)
         return x_out, c

@@ -122,10 +122,15 @@ class MatmulBF16:
             self.w[key] = bp
         return self.w[key]
 
-    def gemm(self, a, w, bias, c, m, n, k, ldc, n_store, accumulate=False):
+    def gemm(self, a, w, bias, c, m, n, k, ldc, n_store, accumulate=False, resid=None):
         """c[m][n_store] (=|+=) a[m][k] . w[n][k]^T + bias, fp32 out (lmrl_gemm_bf16 epilogues 3 / 2); a, w staged by `cast`
-        (row pitch _pitch(k))."""
+        (row pitch _pitch(k)).  resid (fp32 [m][ldc], another buffer): c = resid + a . w^T + bias in the same launch."""
         ld = _pitch(k)
+        if resid is not None:
+            assert not accumulate
+            _lib.check(_L().lmrl_gemm_bf16_resid(a.data_ptr(), w.data_ptr(), _lib.ptr(bias), resid.data_ptr(), ldc, c.data_ptr(), m, n, _pad(k), ld, ld, ldc,
+                                                 n_store, _sp()), "lmrl_gemm_bf16_resid")
+            return
         if bias is None:       # few output tiles, long K (the dW products): split-K over ~2 workgroups per CU + a fixed-order reduce
             nws = _L().lmrl_gemm_bf16_splitk_ws_bytes(m, n, _pad(k))
             if nws:
@@ -137,18 +142,33 @@ class MatmulBF16:
                                           2 if accumulate else 3, _sp()), "lmrl_gemm_bf16")
 
 
-def linear_fwd(x, w, b, y, rows, k, n, mm: Optional[MatmulBF16] = None, ldy=None, xb=None):
+# bf16-matmul mode: residual add inside the projection GEMM's epilogue (lmrl_gemm_bf16_resid) instead of a separate axpby launch.  Measured on
+# one box, ILQL M3 step, A/B twice (tools/ab_train_resid.py, profiles/r03_train_resid_ab.txt): fused 46.93 / 47.31 ms, two launches 46.26 /
+# 46.73 ms — the residual slice prefetched under the K loop costs the 128x128 / 256x256 tiles more registers than the 30 us axpby (150 MB at
+# 5 TB/s) costs time.  Identical arithmetic (same loss to the last bit).  Kept as an A/B hook, OFF.
+FUSE_RESIDUAL = False
+
+
+def linear_fwd(x, w, b, y, rows, k, n, mm: Optional[MatmulBF16] = None, ldy=None, xb=None, resid=None):
     """y[rows][n] = x[rows][k] @ w[k][n] + b   (flax Dense / HF Conv1D kernel layout [in, out]); row stride of y = ldy (default n).
-    xb: the bf16 operand of x if its producer already staged it (`MatmulBF16.stage`, LayerNorm / gelu / attention `_staged` forms)."""
+    xb: the bf16 operand of x if its producer already staged it (`MatmulBF16.stage`, LayerNorm / gelu / attention `_staged` forms).
+    resid (fp32, same shape and pitch as y): y = resid + x @ w + b — the block's residual add inside the projection (one launch in the
+    bf16-matmul mode; fp32 mode: the product, then one axpby, as before)."""
     ldy = ldy or n
+    if mm is not None and resid is not None and not FUSE_RESIDUAL:      # A/B hook (tools/bench_train.py): the two-launch form
+        linear_fwd(x, w, b, y, rows, k, n, mm=mm, ldy=ldy, xb=xb)
+        axpby(1.0, y, 1.0, resid, y)
+        return
     if mm is None:
         sgemm(x, w, y, rows, n, k, lda=k, ldb=n, ldc=ldy, bias=b)
+        if resid is not None:
+            axpby(1.0, y, 1.0, resid, y)
         return
     assert ldy % 4 == 0 and ldy >= _pad(n, 4), "bf16 matmul mode: the output row stride must cover whole 4-column groups"
     if xb is None:
         xb = mm.cast("x", x, rows, k, k)
     wt = mm.cast(("wT", w.data_ptr()), w, k, n, n, transpose=True, keep=True)          # [pad(n)][pad(k)]
-    mm.gemm(xb, wt, mm.bias(b, n) if b is not None else None, y, rows, _padn(n), k, ldy, n)
+    mm.gemm(xb, wt, mm.bias(b, n) if b is not None else None, y, rows, _padn(n), k, ldy, n, resid=resid)
 
 
 def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_beta=0.0, mm: Optional[MatmulBF16] = None, lddy=None, dyb=None,
