@@ -94,6 +94,10 @@ int lmrl_wordle_reset(lmrl_wordle_ctx *ctx, void *state_d, void *mt_d, const uin
 int lmrl_wordle_step(lmrl_wordle_ctx *ctx, void *state_d, void *mt_d, const uint32_t *guess_d,
                      const uint8_t *active_d, uint32_t *obs_d, float *reward_d, uint8_t *flags_d, int n,
                      void *stream);
+/* Kernel form of lmrl_wordle_step: 0 (default) = by batch size — one wavefront per env for the lock-step rollout batches (the 64 lanes sweep
+ * the vocabulary together), one LANE per env for env-only workloads from 65 536 envs up (262 144 with a vocabulary above 1024 words): every
+ * state access of a wave is one coalesced line, no cross-lane work; 1 / 2 force either.  Both forms are bit-identical (tests/test_gpu_envs.py). */
+int lmrl_wordle_set_variant(lmrl_wordle_ctx *ctx, int variant);
 /* Export the knowledge state as the reference's 26x5 trits (0 NOT_HERE / 1 POSSIBLE / 2 HERE) + counts. */
 int lmrl_wordle_export_state(const void *state_d, uint8_t *trits_d /* [N][26][5] */,
                              uint32_t *n_filtered_d, uint32_t *n_actions_d, int n, void *stream);

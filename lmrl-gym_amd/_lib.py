@@ -29,6 +29,7 @@ _SIGS = {
     "lmrl_wordle_state_bytes": (c_size_t, [c_int]),
     "lmrl_wordle_reset": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lmrl_wordle_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_wordle_set_variant": (c_int, [c_void_p, c_int]),
     "lmrl_wordle_export_state": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lmrl_maze_create": (c_void_p, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "lmrl_maze_destroy": (None, [c_void_p]),

@@ -25,6 +25,7 @@ struct WordleCtx {
     int V = 0;
     int require = 1;
     float bad_reward = -1.f;
+    int step_variant = 0;          // 0: by batch size, 1: one wave per env, 2: one lane per env (lmrl_wordle_set_variant)
 };
 
 // rows of the SoA game-state buffer
@@ -159,6 +160,86 @@ __global__ __launch_bounds__(256) void wordle_step_kernel(const uint32_t *__rest
     }
 }
 
+// ---- lane-per-env form of the same step, for LARGE batches (env-only workloads, tens of thousands of envs): lane = env, so every state word
+// is one coalesced 256-byte access per wave (the SoA layout of DESIGN.md section 3 taken literally), the vocabulary sits in LDS and is read at
+// one (broadcast) address per iteration, and there are no cross-lane operations.  A lane walks the whole vocabulary serially (3 passes), so the
+// kernel needs thousands of waves to fill the chip: lmrl_wordle_step picks it from 65 536 envs up (262 144 for the long word list), the
+// wave-per-env kernel below that (1024 envs: 12 us there vs ~40 us here).  Same arithmetic, same RNG calls in the same order: bit-identical states and outputs.
+__global__ __launch_bounds__(256) void wordle_step_lanes_kernel(const uint32_t *__restrict__ words, const uint32_t *__restrict__ wmasks, int V,
+                                                                int require, float bad_reward, uint32_t *st, void *mt, const uint32_t *guess,
+                                                                const uint8_t *active, uint32_t *obs, float *reward, uint8_t *flags, int n) {
+    extern __shared__ uint32_t voc[];                  // [V] words, [V] letter masks
+    for (int i = threadIdx.x; i < V; i += blockDim.x) { voc[i] = words[i]; voc[V + i] = wmasks[i]; }
+    __syncthreads();
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || (active && !active[e])) return;
+    WordleMasks s;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        s.forb[i] = st[(size_t)(ROW_FORB + i) * n + e];
+        s.must[i] = st[(size_t)(ROW_MUST + i) * n + e];
+    }
+    wordle_derive(s);
+    const uint32_t nfilt = st[(size_t)ROW_NFILT * n + e];
+    const uint32_t nact = st[(size_t)ROW_NACT * n + e];
+    const uint32_t g = guess[e];
+    const bool shaped = (g != kBadGuess);
+    bool member = false;
+    if (shaped)
+        for (int i = 0; i < V; i++) member |= (voc[i] == g);
+    const bool would_choose = shaped && (member || !require);
+    const bool empty_choice = would_choose && nfilt == 0;
+    const bool valid = would_choose && nfilt > 0;
+    const bool bad_word = !(shaped && member);
+    uint32_t new_nfilt = nfilt, o = 0, uniq = kBadGuess;
+    if (valid) {
+        const uint32_t r = mt_randbelow(mt_ref(mt, n, e), nfilt);      // rng.choice(filtered_vocab) (game.py:219)
+        uint32_t cnt = 0, target = g;
+        for (int i = 0; i < V; i++) {
+            const uint32_t w = voc[i];
+            const bool ok = wordle_consistent(s, w, voc[V + i]);
+            target = (ok && cnt == r) ? w : target;
+            cnt += ok ? 1u : 0u;
+        }
+        wordle_transition(s, g, target);
+        cnt = 0;
+        for (int i = 0; i < V; i++) {
+            const uint32_t w = voc[i];
+            const bool ok = wordle_consistent(s, w, voc[V + i]);
+            uniq = (ok && cnt == 0) ? w : uniq;
+            cnt += ok ? 1u : 0u;
+        }
+        new_nfilt = cnt;
+        o = wordle_obs(s, g);
+    }
+    if (nact < (uint32_t)kWordleTries) st[(size_t)(ROW_HIST + nact) * n + e] = g;
+    const uint32_t new_nact = nact + 1;
+    float rew;
+    if (bad_word) {
+        rew = bad_reward;
+    } else {
+        bool win = false;
+        if (new_nfilt == 1) {
+            win = (uniq == g);
+            for (uint32_t k = 0; k < nact && k < (uint32_t)kWordleTries; k++) win |= (st[(size_t)(ROW_HIST + k) * n + e] == uniq);
+        }
+        rew = win ? 0.f : -1.f;
+    }
+    const bool done = (new_nact == (uint32_t)kWordleTries) || (rew == 0.f);
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            st[(size_t)(ROW_FORB + i) * n + e] = s.forb[i];
+            st[(size_t)(ROW_MUST + i) * n + e] = s.must[i];
+        }
+        st[(size_t)ROW_NFILT * n + e] = new_nfilt;
+    }
+    st[(size_t)ROW_NACT * n + e] = new_nact;
+    obs[e] = o;
+    reward[e] = rew;
+    flags[e] = (uint8_t)(((done || empty_choice) ? 1 : 0) | (valid ? 2 : 0) | (bad_word ? 4 : 0) | (empty_choice ? 8 : 0));
+}
+
 __global__ void wordle_export_kernel(const uint32_t *st, uint8_t *trits, uint32_t *nf, uint32_t *na, int n) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
@@ -229,6 +310,12 @@ void lmrl_wordle_destroy(lmrl_wordle_ctx *ctx) {
     delete ctx;
 }
 
+int lmrl_wordle_set_variant(lmrl_wordle_ctx *ctx, int variant) {
+    LMRL_REQUIRE(ctx && variant >= 0 && variant <= 2, "lmrl_wordle_set_variant: 0 = by batch size, 1 = one wave per env, 2 = one lane per env");
+    ctx->step_variant = variant;
+    return LMRL_OK;
+}
+
 size_t lmrl_wordle_state_bytes(int n) { return (size_t)kWordleStateWords * (size_t)n * sizeof(uint32_t); }
 
 int lmrl_wordle_reset(lmrl_wordle_ctx *ctx, void *state_d, void *mt_d, const uint64_t *seeds_d, const uint8_t *mask_d,
@@ -256,6 +343,16 @@ int lmrl_wordle_step(lmrl_wordle_ctx *ctx, void *state_d, void *mt_d, const uint
                  "lmrl_wordle_step: null pointer or negative n");
     if (n == 0) return LMRL_OK;
     ProfScope ps(PROF_WORDLE_STEP, as_stream(stream), 96.0 * n);   // ~96 algorithmic bytes per env-step
+    const size_t voc_lds = (size_t)ctx->V * 2 * sizeof(uint32_t);
+    // measured (tools/bench_env.py, profiles/r03_env_only_microbench.txt; steps only, M env-steps/s, wave/env vs lane/env):
+    //   V = 431:  65 536 envs 678 vs 746, 262 144 envs 711 vs 1549;   V = 2315:  65 536 envs 222 vs 151, 262 144 envs 233 vs 309
+    const bool lanes = ctx->step_variant == 2 || (ctx->step_variant == 0 && (n >= 262144 || (n >= 65536 && ctx->V <= 1024)));
+    if (lanes && voc_lds <= 64 * 1024) {      // lane = env: large batches (the vocabulary tables fit LDS for any Wordle word list: 18.5 KB at V = 2315)
+        hipLaunchKernelGGL(wordle_step_lanes_kernel, dim3(ceil_div(n, 256)), dim3(256), voc_lds, as_stream(stream), ctx->words_d, ctx->wmask_d, ctx->V,
+                           ctx->require, ctx->bad_reward, (uint32_t *)state_d, mt_d, guess_d, active_d, obs_d, reward_d, flags_d, n);
+        LMRL_CHECK_LAUNCH();
+        return LMRL_OK;
+    }
     hipLaunchKernelGGL(wordle_step_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, as_stream(stream), ctx->words_d,
                        ctx->wmask_d, ctx->V, ctx->require, ctx->bad_reward, (uint32_t *)state_d, mt_d, guess_d, active_d,
                        obs_d, reward_d, flags_d, n);

@@ -159,6 +159,59 @@ def test_wordle_vs_oracle_batched(dev, fname, n):
     env.close()
 
 
+def test_wordle_lane_per_env_kernel_is_bit_identical_to_wave_per_env(dev):
+    """`lmrl_wordle_step` has two kernel forms (one wavefront per env for rollout-sized batches, one LANE per env from 16 384 envs up):
+    same state words, observations, rewards, flags and RNG consumption, step for step, on 20 000 envs with valid / unknown / malformed
+    guesses and inactive slots — and the lane form against the C oracle directly on a sample of envs."""
+    from oracle.wordle import OracleWordleEnv
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.envs import wordle as W
+    L = _lib.lib()
+    for fname in ("wordle_official_400.txt", "wordle_official.txt"):
+        vocab = W.Vocabulary.builtin(fname)
+        words = vocab.all_vocab
+        n = 20000
+        rng = np.random.RandomState(3)
+        seeds = rng.randint(0, 2**31 - 1, size=n).astype(np.uint64)
+        packed = np.array([W.pack_guess(w) for w in words], dtype=np.uint32)
+        envs = []
+        for variant in (1, 2):
+            e = W.VectorWordleEnv(vocab, True, -10.0)
+            e.reset_device(seeds)
+            _lib.check(L.lmrl_wordle_set_variant(e._ctx, variant))
+            envs.append(e)
+        sample = list(range(0, n, n // 48))
+        oracles = {i: OracleWordleEnv(words, True, -10.0) for i in sample}
+        for i, o in oracles.items():
+            o.reset(int(seeds[i]))
+        done = np.zeros(n, dtype=bool)
+        for t in range(6):
+            gi = rng.randint(0, len(words), size=n)
+            g = packed[gi].copy()
+            texts = [words[k] for k in gi]
+            junk = np.nonzero(rng.rand(n) < 0.15)[0]
+            for i in junk:
+                texts[i] = "".join(rng.choice(list("abcdefghijklmnopqrstuvwxyz"), 5)) if rng.rand() < 0.6 else "q"
+                g[i] = W.pack_guess(texts[i])
+            active = (~done & (rng.rand(n) < 0.97)).astype(np.uint8)          # a few live envs sit a step out
+            gd, ad = torch.from_numpy(g.view(np.int32)).to(dev), torch.from_numpy(active).to(dev)
+            for e in envs:
+                e.step_device(gd, ad)
+            a, b = envs
+            act = torch.from_numpy(active.astype(bool)).to(dev)
+            assert torch.equal(a.state, b.state) and torch.equal(a.mt, b.mt)
+            assert torch.equal(a.obs[act], b.obs[act]) and torch.equal(a.reward[act], b.reward[act]) and torch.equal(a.flags[act], b.flags[act])
+            obs = b.obs.cpu().numpy().view(np.uint32); rew = b.reward.cpu().numpy(); flg = b.flags.cpu().numpy()
+            for i in sample:
+                if active[i]:
+                    h, r, d = oracles[i].step((("Wordle:\n", False), (texts[i], True)))
+                    assert h[-1][0] == W.reformat_history((W.Text(W.transition_text(int(obs[i])), False),))[-1].text
+                    assert float(r) == float(rew[i]) and d == bool(flg[i] & 1)
+            done |= (flg & 1).astype(bool) & active.astype(bool)
+        for e in envs:
+            e.close()
+
+
 def test_wordle_full_size_properties(dev):
     """BASELINE-size batch (65 536 envs, V=2315): determinism, termination after <= 6 steps, reward range,
     win <=> filtered set collapsed to one word; an inactive slot is untouched."""
