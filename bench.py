@@ -434,6 +434,21 @@ def main():
     th = time.perf_counter()
     n_trans = sum(len(ep) for r in ros for ep in r.interactions())
     host_materialise_ms = (time.perf_counter() - th) * 1e3
+    # ... and the public call itself on the same steered workload: `WordleRolloutEngine.text_env_eval` over 4 episode batches (graph
+    # replays; the host builds batch k's transition lists while the device runs batch k + 1), env steps returned / wall time
+    tev = None
+    if S == 1:
+        n_b = min(4, n_eps)
+        gen_seeds = iter(range(10 ** 6, 10 ** 9))
+        kwf = dict(scripted_guesses_fn=lambda bid: guesses[bid % n_eps], steer_strength=30.0, temperature=1.0, sample_seed=9)
+        ro.text_env_eval(B, seed_generator=gen_seeds, **kwf)       # warm: pinned buffers, graph capture
+        torch.cuda.synchronize(); th = time.perf_counter()
+        inter_all, _summary = ro.text_env_eval(n_b * B, seed_generator=gen_seeds, **kwf)
+        tev_s = time.perf_counter() - th
+        tev = dict(value=round(sum(len(ep) for ep in inter_all) / tev_s, 1), unit="env-steps/s", episode_batches=n_b, ms_per_batch=round(tev_s * 1e3 / n_b, 2),
+                   note="rank 0: WordleRolloutEngine.text_env_eval(n_rollouts = 4 x B) end to end — device episodes (hipGraph replays) + host lists of "
+                        "InteractionTransition + summary dict, host materialisation of batch k overlapped with the device work of batch k + 1")
+        del inter_all
 
     ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
 
@@ -560,6 +575,7 @@ def main():
             "host_materialise_note": f"rank 0, one episode batch: device->host copy of the records + {n_trans} InteractionTransition objects built in "
                                      "Python (what text_env_eval returns); not inside `value`, which ends on the device",
             "value_incl_host_materialise": round(n_env_steps / (dt_max + args.steps * host_materialise_ms * 1e-3), 1),
+            "text_env_eval": tev,
         }
     for r in ros:
         r.close()

@@ -327,10 +327,32 @@ class WordleRolloutEngine:
         """The finished episode as `List[List[InteractionTransition]]` — what `interact_environment` returns for the same
         rollout (LLM_RL/environment.py:154-207): one transition per env step with the pre-action, post-action and
         post-transition histories, the step reward and the done flag.  `decode(ids) -> str` defaults to the token table."""
+        return self._build_interactions(self.snapshot_records(), decode)
+
+    def snapshot_records(self):
+        """Enqueue device -> pinned-host copies of the episode record behind the episode's kernels and return a handle; the record buffers may
+        be overwritten by the next episode as soon as this returns (stream order).  `_build_interactions(handle)` waits for the copies only —
+        the next episode's launches, enqueued in between, run on the device while the host builds the Python objects of this one."""
+        import torch
+        names = ("tokens", "is_action", "reward", "n_tok", "env_done")
+        if getattr(self, "_pinned", None) is None:
+            self._pinned = [{n: torch.empty(self.traj[n].shape, dtype=self.traj[n].dtype, pin_memory=True) for n in names} for _ in range(2)]
+            self._pin_i = 0
+        buf = self._pinned[self._pin_i]
+        self._pin_i ^= 1
+        for n in names:
+            buf[n].copy_(self.traj[n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return buf, ev
+
+    def _build_interactions(self, handle, decode=None):
         from .environment import InteractionTransition, Text
         dec = decode or (lambda ids: "".join(self.tokens.strings.get(int(i), "") for i in ids))
-        tok = self.traj["tokens"].cpu().numpy(); ia = self.traj["is_action"].cpu().numpy().astype(bool)
-        rw = self.traj["reward"].cpu().numpy(); ntok = self.traj["n_tok"].cpu().numpy(); done = self.traj["env_done"].cpu().numpy().astype(bool)
+        buf, ev = handle
+        ev.synchronize()
+        tok = buf["tokens"].numpy(); ia = buf["is_action"].numpy().astype(bool)
+        rw = buf["reward"].numpy(); ntok = buf["n_tok"].numpy(); done = buf["env_done"].numpy().astype(bool)
         # run boundaries of every env in one vectorised pass: positions where is_action changes (the Text items alternate header, action,
         # observation, action, ...); the few thousand distinct token runs of a batch are decoded once each (Text is immutable: shared)
         cache = {}
@@ -360,23 +382,47 @@ class WordleRolloutEngine:
         return out
 
     def text_env_eval(self, n_rollouts: int, seed_generator=None, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0,
-                      interaction_callback=None, decode=None):
+                      interaction_callback=None, decode=None, scripted_guesses_fn=None, steer_strength: float = 0.0, use_graph: bool = True):
         """`text_env_eval(env, policy, n_rollouts, bsize=B)` (LLM_RL/environment.py:211-267) with env, policy and the whole
-        lock-step loop on the device: ceil(n / B) episodes batches, the same (interactions, summary) return value."""
+        lock-step loop on the device: ceil(n / B) episodes batches, the same (interactions, summary) return value.
+        use_graph (default; plain sampling only): the episode is captured into a hipGraph once per (temperature, sample_seed, steering) and
+        replayed per batch — one host call instead of ~3400 launches; every replay draws fresh noise (the sampler's epoch word advances).
+        `scripted_guesses_fn(batch_id) -> int32 device tensor [n_turns][B]` + `steer_strength`: synthetic workloads (bench.py)."""
         inter, rewards, dones, lengths = [], [], [], []
-        batch_id = 0
-        while len(inter) < n_rollouts:
-            actual = min(n_rollouts - len(inter), self.B)
-            seeds = np.zeros(self.B, dtype=np.uint64)
-            seeds[:actual] = [next(seed_generator) for _ in range(actual)] if seed_generator is not None else \
-                np.random.randint(0, 2 ** 31 - 1, size=actual)
-            self.run_episode(seeds, temperature=temperature, top_k=top_k, sample_seed=sample_seed + (batch_id << 20))
-            batch_id += 1
-            for ep in self.interactions(decode)[:actual]:
+
+        def absorb(handle, actual):
+            for ep in self._build_interactions(handle, decode)[:actual]:
                 inter.append(ep)
                 rewards.append(sum(t.reward for t in ep)); dones.append(ep[-1].done); lengths.append(len(ep))
                 if interaction_callback is not None:
                     interaction_callback(ep)
+        # episode batches are pipelined: batch k's record is copied to pinned host memory behind its kernels, batch k + 1 is enqueued, and only
+        # then the host turns batch k into InteractionTransition lists — the Python work overlaps the device work of the next batch
+        batch_id, launched, pending = 0, 0, None
+        while launched < n_rollouts:
+            actual = min(n_rollouts - launched, self.B)
+            seeds = np.zeros(self.B, dtype=np.uint64)
+            seeds[:actual] = [next(seed_generator) for _ in range(actual)] if seed_generator is not None else \
+                np.random.randint(0, 2 ** 31 - 1, size=actual)
+            g = scripted_guesses_fn(batch_id) if scripted_guesses_fn is not None else None
+            if use_graph and top_k == 0 and self.vses is None:
+                key = (float(temperature), int(sample_seed), float(steer_strength), g is not None)
+                if getattr(self, "_eval_graph_key", None) != key:
+                    self.capture_episode(temperature=temperature, sample_seed=sample_seed, steer_strength=steer_strength, scripted=g is not None)
+                    self._eval_graph_key = key
+                import torch
+                self.replay_episode(torch.from_numpy(seeds.view(np.int64)).to(self.dev), g)
+            else:
+                self.run_episode(seeds, temperature=temperature, top_k=top_k, sample_seed=sample_seed + (batch_id << 20), scripted_guesses=g,
+                                 steer_strength=steer_strength)
+            batch_id += 1
+            launched += actual
+            handle = self.snapshot_records()
+            if pending is not None:
+                absorb(*pending)
+            pending = (handle, actual)
+        if pending is not None:
+            absorb(*pending)
         summ = lambda x: dict(mean=np.mean(x), std=np.std(x), min=np.min(x), max=np.max(x))
         return inter, dict(reward=summ(np.asarray(rewards, dtype=np.float32)), done=summ(np.asarray(dones, dtype=np.float32)), length=summ(lengths))
 
