@@ -8,7 +8,7 @@
 
 Hyper-parameter names and defaults are the reference scripts' own.  Not carried over: tyro, wandb, GCS, mesh-shape flags (one
 process per GPU + `torch.distributed.run` instead).  `--model` is a checkpoint directory in the reference layout
-(`lmrl_gym_amd.checkpoints`) or `random:<tiny|small>`; the GPT-2 tokenizer is `transformers.AutoTokenizer('gpt2')` when its
+(`lmrl_gym_amd.checkpoints`) or `random:<tiny|small|medium>`; the GPT-2 tokenizer is `transformers.AutoTokenizer('gpt2')` when its
 files are available, else the Wordle-alphabet adapter (`datasets.WordleTokenizer`).
 """
 from __future__ import annotations
@@ -68,7 +68,7 @@ def _model(spec: str, vocab: int):
     from lmrl_gym_amd import checkpoints as C
     from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
     if spec.startswith("random:"):
-        cfg = dict(tiny=GPT2Config(2, 2, 128, 256, vocab, 128), small=GPT2Config.gpt2_small(vocab))[spec.split(":")[1]]
+        cfg = dict(tiny=GPT2Config(2, 2, 128, 256, vocab, 128), small=GPT2Config.gpt2_small(vocab), medium=GPT2Config.gpt2_medium(vocab))[spec.split(":")[1]]
         return cfg, init_hf_style_state_dict(cfg, seed=0)
     import torch
     loader = C.load_hf_pytorch_gpt2 if os.path.exists(os.path.join(spec, "model.safetensors")) or os.path.exists(os.path.join(spec, "pytorch_model.bin")) \
@@ -183,7 +183,7 @@ def cmd_ppo(a):
     from lmrl_gym_amd.policies import GPT2PPOPolicy
     from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
     dev = _lib.require_gpu()
-    tok = _tokenizer()
+    tok = _tokenizer(wordle=a.env != "chess")        # FEN / SAN text needs every byte: the byte tokenizer when no GPT-2 files are around
     cfg, sd = _model(a.model, max(len(tok), 50257))
     mm = dict(matmul="bf16" if a.bf16_activations else "f32")
     pol_f32 = GPT2F32(sd, cfg.n_head, device=dev, gradient_checkpointing=a.gradient_checkpointing, **mm)
@@ -213,7 +213,10 @@ def cmd_ppo(a):
     else:
         vocab, env = _wordle_env(a)
     step = 0
+    limit = None if a.max_steps is None else int(a.max_steps)
     for rnd in range(a.n_rounds):
+        if limit is not None and step >= limit:
+            break
         if a.device_rollouts:       # env + policy + lock-step loop on the GPU; same (interactions, summary) as text_env_eval
             ro = _device_rollouts(policy.engine, vocab, tok, a.rollout_bsize, a.bad_word_reward, min(a.max_output_length, 12))
             raw, summary = ro.text_env_eval(a.n_rollouts, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)), temperature=a.policy_temperature or 1.0,
@@ -231,6 +234,8 @@ def cmd_ppo(a):
         ds = ppo.PPODataset.from_ppo_data_list(datas, tok, bs)
         bc_iter = None
         for epoch in range(a.epochs):
+            if limit is not None and step >= limit:
+                break
             for batch in DS.dataloader(np.random.default_rng(rnd * 1000 + epoch), ds, min(a.train_bsize, len(ds)), truncate=True):
                 extra = {}
                 if bc is not None:
