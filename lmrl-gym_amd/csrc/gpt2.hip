@@ -1063,7 +1063,17 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
     const bool fused = !(flags & LMRL_FWD_LN_STANDALONE) && g_gemm_variant != 1 && ln_fusion_nq(d) != 0;
     // TIMING-ONLY ablation (tools/bench_ablate_decode.py; results are garbage): leave out one launch class of the single-token decode layers to
     // measure what removing / hiding that launch could buy at most inside the real dependent chain
-    const unsigned ablate = (c == 1) ? ((flags >> LMRL_FWD_ABLATE_SHIFT) & 0x1fu) : 0u;
+    const unsigned ablate = (c == 1) ? ((flags >> LMRL_FWD_ABLATE_SHIFT) & 0x3fu) : 0u;
+    // LMRL_ABLATE_PROJ_CONCURRENT (timing only, garbage results): the proj GEMM is launched on an auxiliary stream that waits for the qkv GEMM
+    // only, i.e. it runs CONCURRENTLY with the attention launch on stale data — the most any attention -> proj overlap scheme could hide,
+    // contention between the two launches included
+    static hipStream_t aux_stream = nullptr;
+    static hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+    if ((ablate & LMRL_ABLATE_PROJ_CONCURRENT) && !aux_stream) {
+        LMRL_CHECK_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+        LMRL_CHECK_HIP(hipEventCreateWithFlags(&aux_fork, hipEventDisableTiming));
+        LMRL_CHECK_HIP(hipEventCreateWithFlags(&aux_join, hipEventDisableTiming));
+    }
     const int nsl = Gpt2Ws::nslots(cf);
     // ragged batches (LN-folded path, unless the caller wants every row's hidden state back): by default only the forwards of
     // large batches qualify (b*c >= 2048); LMRL_FWD_RAGGED_ALWAYS compacts every forward (generation loops whose rows finish at
@@ -1133,6 +1143,13 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
         hipEvent_t ev_a, ev_b;
         // decode: the single-shot kernel; LMRL_FWD_ATTN_VALU keeps the multi-round-trip per-head kernel as the cross-check
         const bool shot = c == 1 && !(flags & LMRL_FWD_ATTN_VALU);
+        if (fused && (ablate & LMRL_ABLATE_PROJ_CONCURRENT)) {     // fork: proj on the aux stream, behind the qkv GEMM only
+            LMRL_CHECK_HIP(hipEventRecord(aux_fork, s));
+            LMRL_CHECK_HIP(hipStreamWaitEvent(aux_stream, aux_fork, 0));
+            GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
+            LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, aux_stream));
+            LMRL_CHECK_HIP(hipEventRecord(aux_join, aux_stream));
+        }
         if (ablate & LMRL_ABLATE_ATTN) {
         } else if (shot) {
             const bool ev = prof_kernel_events(PROF_ATTN_DECODE, -1.0, &ev_a, &ev_b);   // start/stop events attached to the dispatch itself
@@ -1180,7 +1197,8 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
             }
         } else if (fused) {
             GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
-            if (!(ablate & LMRL_ABLATE_PROJ)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, s));
+            if (ablate & LMRL_ABLATE_PROJ_CONCURRENT) LMRL_CHECK_HIP(hipStreamWaitEvent(s, aux_join, 0));      // join
+            else if (!(ablate & LMRL_ABLATE_PROJ)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, s));
             GemmArgs gf{w.h, L.wf_fc, L.bf_fc, w.ff, M, cf.d_ff, d, d, cf.d_ff, cf.d_ff, w.stats, nullptr, L.cs_fc, nsl, 1.f / (float)d, cf.ln_eps, m_dev};
             if (!(ablate & LMRL_ABLATE_FC)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_GELU_BF16_LN>(gf, s));
             GemmArgs g2{w.ff, L.w_fc2, L.b_fc2, w.x, M, d, cf.d_ff, cf.d_ff, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
