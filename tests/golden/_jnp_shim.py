@@ -366,6 +366,36 @@ def softmax_cross_entropy_with_integer_labels(logits, labels):
     return log_norm - label_logits
 
 
+def squeeze(a, axis=None):
+    return _wrap(np.squeeze(_raw(a), axis=axis))
+
+
+def matmul(a, b):
+    """jnp.matmul / `@` on Arr operands (flax Dense: x @ kernel), float32 arithmetic."""
+    return _wrap(np.matmul(_raw(a), _raw(b)))
+
+
+def cond(pred, true_fun, false_fun, *operands):
+    """jax.lax.cond with a concrete predicate."""
+    return true_fun(*operands) if bool(np.asarray(pred)) else false_fun(*operands)
+
+
+def _tree_map2(f, a, b):
+    if isinstance(a, dict):
+        return {k: _tree_map2(f, a[k], b[k]) for k in a}
+    return f(a, b)
+
+
+def incremental_update(new_tensors, old_tensors, step_size):
+    """optax.incremental_update (optax 0.1.3 `_src/update.py`): step_size * new + (1 - step_size) * old on every leaf (Polyak averaging)."""
+    return _tree_map2(lambda n, o: step_size * n + (1.0 - step_size) * o, new_tensors, old_tensors)
+
+
+def periodic_update(new_tensors, old_tensors, steps, update_period):
+    """optax.periodic_update: `new` when steps % update_period == 0, else `old`."""
+    return new_tensors if int(np.asarray(steps)) % int(update_period) == 0 else old_tensors
+
+
 def make_modules():
     """`jax`, `jax.numpy`, `jax.nn`, `jax.lax`, `optax` module objects backed by this file."""
     g = globals()
@@ -375,11 +405,16 @@ def make_modules():
                  "zeros", "full", "concatenate", "expand_dims", "cumprod", "triu", "take_along_axis", "flip"):
         setattr(jnp, name, g[name])
     jnp.sum = sum_
+    jnp.matmul = jnp.dot = matmul
+    jnp.squeeze = squeeze
     nn = types.ModuleType("jax.nn")
     nn.one_hot = one_hot
     lax = types.ModuleType("jax.lax")
     lax.stop_gradient = stop_gradient
+    lax.cond = cond
     optax = types.ModuleType("optax")
     optax.l2_loss = l2_loss
     optax.softmax_cross_entropy_with_integer_labels = softmax_cross_entropy_with_integer_labels
+    optax.incremental_update = incremental_update
+    optax.periodic_update = periodic_update
     return {"jax.numpy": jnp, "jax.nn": nn, "jax.lax": lax, "optax": optax}

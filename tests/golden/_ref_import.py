@@ -39,10 +39,11 @@ class _AnyMeta(type):
 
 class _Any(metaclass=_AnyMeta):
     """Callable / subscriptable / subclassable placeholder."""
+    _is_placeholder = True
 
     def __new__(cls, *args, **kwargs):
-        # decorator use: @pjit, @partial-like
-        if cls is _Any and len(args) == 1 and not kwargs and callable(args[0]) and not isinstance(args[0], type):
+        # decorator use: @pjit, @partial-like (placeholders only — a reference class that merely SUBCLASSES a placeholder constructs normally)
+        if cls.__dict__.get("_is_placeholder") and len(args) == 1 and not kwargs and callable(args[0]) and not isinstance(args[0], type):
             return args[0]
         return super().__new__(cls)
 
@@ -73,7 +74,10 @@ class _StubModule(types.ModuleType):
     def __getattr__(self, name):
         if name.startswith("__") and name.endswith("__"):
             raise AttributeError(name)
-        return _Any
+        # one distinct placeholder class per module attribute, so that `class X(mod.A, mod.B)` has two different bases
+        ph = type(name, (_Any,), {"_is_placeholder": True})
+        self.__dict__[name] = ph
+        return ph
 
 
 class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
@@ -102,20 +106,30 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
             import importlib
             for sub in ("numpy", "nn", "lax"):
                 setattr(module, sub, importlib.import_module("jax." + sub))
+        # stand-in sub-modules registered by `install(extra=...)` (e.g. flax.linen, flax.struct) are also reachable as attributes of their parent
+        import importlib
+        for key in list(_SHIM_MODULES):
+            parent, _, child = key.rpartition(".")
+            if parent == module.__name__ and child not in module.__dict__ and key not in ("jax.numpy", "jax.nn", "jax.lax"):
+                setattr(module, child, importlib.import_module(key))
 
 
 _SHIM_MODULES = {}
 
 
-def install(jnp_shim: bool = False):
+def install(jnp_shim: bool = False, extra=None):
     """jnp_shim=True additionally backs `jax.numpy`, `jax.nn`, `jax.lax` and `optax` with the numpy restatements of
-    tests/golden/_jnp_shim.py so that the reference's loss functions execute (every other jax/flax name stays a placeholder)."""
-    if jnp_shim and not _SHIM_MODULES:
+    tests/golden/_jnp_shim.py so that the reference's loss functions execute (every other jax/flax name stays a placeholder).
+    extra: {module name: module object} of further stand-ins (tests/golden/_flax_shim.py: `flax.linen`, `flax.struct`)."""
+    if jnp_shim and "jax.numpy" not in _SHIM_MODULES:
         import os
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         import _jnp_shim
         _SHIM_MODULES.update(_jnp_shim.make_modules())
         assert not any(k in sys.modules for k in _SHIM_MODULES), "install(jnp_shim=True) must run before the reference is imported"
+    if extra:
+        assert not any(k in sys.modules for k in extra), "install(extra=...) must run before the reference is imported"
+        _SHIM_MODULES.update(extra)
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     if not any(isinstance(f, _StubFinder) for f in sys.meta_path):

@@ -1,0 +1,91 @@
+"""GPU tier: `GPT2ILQLTrain.step` (heads, Q gathers, both `v_final` branches, the loss, the target updates) against tests/golden/rl_steps.json —
+outputs of the reference's OWN `_step` closure (ilql/gpt2/interface.py:88-367) run under numpy stand-ins for jax / flax with the oracle GPT-2 in
+the transformer slot (tests/golden/make_step_fixtures.py).  Loss and every log entry within 1e-4 relative (fp32 device vs the fixture's fp32 numpy
+on float64 hidden states); the Polyak / periodic / micro-step target-update rule against the fixture's parameter digests."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import lmrl_gym_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import step_cases as C  # noqa: E402
+from conftest import load_golden  # noqa: E402
+
+
+def _flat(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(_flat(v, prefix + k + "."))
+        else:
+            out[prefix + k] = float(v)
+    return out
+
+
+@pytest.mark.parametrize("case", C.ILQL_CASES, ids=[c["name"] for c in C.ILQL_CASES])
+def test_ilql_step_equals_reference_closure(case):
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.algorithms import ilql
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    dev = _lib.require_gpu()
+    fx = load_golden("rl_steps.json")[case["name"]]
+    V = C.CFG["vocab"]
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    sd = {k: t(v) for k, v in C.state_dict(10 + case["seed"]).items()}
+    tsd = {k: t(v) for k, v in C.state_dict(20 + case["seed"]).items()}
+    hp = [{k: t(v) for k, v in C.flat_head(C.mlp_head(s + case["seed"], o)).items()} for s, o in ((30, V), (40, V), (50, 1), (60, V), (70, V))]
+    base = GPT2F32(sd, C.CFG["n_head"], device=dev)
+    tbase = GPT2F32(tsd, C.CFG["n_head"], device=dev) if case["target_base"] else None
+    tr = ilql.GPT2ILQLTrain(base, MLPHeadF32(hp[0], dev), MLPHeadF32(hp[1], dev), MLPHeadF32(hp[2], dev), C.PAD, C.LOSS_KW, target_base=tbase, lr=1e-4,
+                            polyak_alpha=case["polyak_alpha"], hard_update_every=case["hard_update_every"])
+    tr.q1_target, tr.q2_target = MLPHeadF32(hp[3], dev), MLPHeadF32(hp[4], dev)      # the fixture's target heads differ from the online ones
+    b = C.ilql_batch(case["seed"])
+    kw = dict(next_token_ids=b["next_token_ids"], next_dones=b["next_dones"]) if case["use_next"] else {}
+    loss, logs = ilql.GPT2ILQLInference(base, tr.q1, tr.q2, tr.v, C.PAD, loss_kwargs=C.LOSS_KW, target_base=tbase, q1_target_head=tr.q1_target,
+                                        q2_target_head=tr.q2_target).eval_loss(b["input_ids"], b["should_take_action"], b["rewards"], b["dones"], **kw)
+    assert abs(loss - fx["loss"]) <= 1e-4 * abs(fx["loss"]), (loss, fx["loss"])
+    got = _flat(logs)
+    assert set(got) == set(fx["logs"])
+    for k, e in fx["logs"].items():
+        assert abs(got[k] - e) <= 1e-4 * max(1.0, abs(e)), (k, got[k], e)
+    # the train step itself gives the same loss / logs (same forward) ...
+    _, loss2, logs2 = tr.step(b["input_ids"], b["should_take_action"], b["rewards"], b["dones"], **kw)
+    assert abs(loss2 - loss) <= 1e-6 * abs(loss)
+    # ... and the target-update rule, applied to the fixture's (online x 0.9, target) pair at the fixture's step counter
+    online = {k: (v * 0.9).to(dev) for k, v in hp[0].items()}
+    target = {k: v.clone().to(dev) for k, v in hp[3].items()}
+    if case["mini_step"] in (None, 0):            # (an accumulating micro-step leaves the targets alone: the trainer does not call the update)
+        tr._update_targets(online, target, fx["step_after"])
+    torch.cuda.synchronize()
+    for name, d in fx["q1_target"].items():
+        a = target[name].double().cpu().numpy().ravel()
+        assert abs(float(a.sum()) - d[0]) <= 1e-4 * max(1.0, abs(d[0])), (case["name"], name)
+        np.testing.assert_allclose(a[:3], d[2:], rtol=1e-5, atol=1e-7)
+
+
+def test_ppo_step_equals_reference_closure():
+    """`GPT2PPOTrain.step` loss / logs == the reference's PPO `_step` closure (ppo/gpt2/interface.py:72-211) on the plain case."""
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.algorithms import ppo
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
+    dev = _lib.require_gpu()
+    case = C.PPO_CASES[0]
+    fx = load_golden("rl_steps.json")[case["name"]]
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    sd = {k: t(v) for k, v in C.state_dict(80 + case["seed"]).items()}
+    vh = C.flat_head(C.linear_head(90 + case["seed"]))
+    pol = GPT2F32(sd, C.CFG["n_head"], device=dev)
+    head = LinearHeadF32(dict(kernel=t(vh["dense.kernel"]), bias=t(vh["dense.bias"])), dev)
+    tr = ppo.GPT2PPOTrain(pol, head, C.PAD, C.PPO_KW, lr=1e-5)
+    b = C.ppo_batch(case["seed"])
+    _, loss, logs = tr.step(b["input_ids"], b["should_take_action"], b["old_logprobs"], b["old_values"], b["old_advantages"], b["old_returns"])
+    assert abs(loss - fx["loss"]) <= 1e-4 * abs(fx["loss"]), (loss, fx["loss"])
+    got = _flat(logs)
+    assert set(got) == set(fx["logs"])
+    for k, e in fx["logs"].items():
+        assert abs(got[k] - e) <= 1e-4 * max(1.0, abs(e)), (k, got[k], e)

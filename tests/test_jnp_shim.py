@@ -116,3 +116,46 @@ def test_complex_step_mode_gives_directional_derivatives_and_honours_stop_gradie
     assert abs(deriv - fd) <= 1e-6 * max(1.0, abs(fd)), (deriv, fd)
     with pytest.raises(TypeError):
         a(np.zeros(2, dtype=np.complex128))                 # complex arrays only exist in derivative mode
+
+
+def test_round3_stand_ins_squeeze_matmul_cond_and_optax_updates():
+    """The stand-ins added for executing the reference's train-step closures (tests/golden/make_step_fixtures.py): jnp.squeeze / matmul,
+    jax.lax.cond with a concrete predicate, optax.incremental_update (Polyak: step_size * new + (1 - step_size) * old per leaf) and
+    optax.periodic_update (new iff steps % period == 0) on nested dict pytrees."""
+    a = S.asarray(np.arange(6, dtype=np.float32).reshape(2, 3, 1))
+    assert S.squeeze(a, axis=-1).shape == (2, 3) and isinstance(S.squeeze(a, axis=-1), S.Arr)
+    x, w = S.asarray(np.ones((2, 3), np.float32)), S.asarray(np.arange(12, dtype=np.float32).reshape(3, 4))
+    np.testing.assert_array_equal(np.asarray(S.matmul(x, w)), np.ones((2, 3), np.float32) @ np.arange(12, dtype=np.float32).reshape(3, 4))
+    assert S.cond(np.bool_(True), lambda p, q: p + q, lambda p, q: p - q, 5, 3) == 8 and S.cond(False, lambda p: p, lambda p: -p, 2) == -2
+    new = {"l": {"k": np.array([1.0, 2.0], np.float32)}, "b": np.array([4.0], np.float32)}
+    old = {"l": {"k": np.array([3.0, 0.0], np.float32)}, "b": np.array([0.0], np.float32)}
+    upd = S.incremental_update(new, old, 0.25)
+    np.testing.assert_allclose(upd["l"]["k"], [2.5, 0.5]); np.testing.assert_allclose(upd["b"], [1.0])
+    assert S.periodic_update(new, old, 8, 4) is new and S.periodic_update(new, old, 7, 4) is old
+    m = S.make_modules()
+    assert m["jax.lax"].cond is S.cond and m["optax"].incremental_update is S.incremental_update and m["jax.numpy"].squeeze is S.squeeze
+
+
+def test_flax_stand_ins_run_dense_modules():
+    """tests/golden/_flax_shim.py: `Module.apply({'params': p}, x)` binds `nn.Dense` sub-modules created in `setup()` to p[<attribute name>]
+    and `Dense` computes x @ kernel + bias (kernel [in, out]) — flax's published behaviour, enough for the reference's head modules."""
+    import _flax_shim as F
+
+    class Head(F.Module):
+        width: int
+        scale: float = 2.0
+
+        def setup(self):
+            self.dense1 = F.Dense(features=self.width)
+            self.out = F.Dense(features=1, use_bias=False)
+
+        def __call__(self, x, *, train):
+            return self.out(F.relu(self.dense1(x))) * self.scale
+
+    rng = np.random.RandomState(0)
+    p = {"dense1": {"kernel": rng.randn(3, 4).astype(np.float32), "bias": rng.randn(4).astype(np.float32)}, "out": {"kernel": rng.randn(4, 1).astype(np.float32)}}
+    x = rng.randn(5, 3).astype(np.float32)
+    y = Head(4).apply({"params": p}, S.asarray(x), train=False, rngs=None)
+    np.testing.assert_allclose(np.asarray(y), np.maximum(x @ p["dense1"]["kernel"] + p["dense1"]["bias"], 0) @ p["out"]["kernel"] * 2.0, rtol=1e-6)
+    node = F.PyTreeNode(a=1, b=2).replace(b=3)
+    assert (node.a, node.b) == (1, 3)

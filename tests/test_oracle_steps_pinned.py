@@ -1,0 +1,114 @@
+"""CPU tier: `oracle/rl.py`'s restatement of the ILQL train-step closure (heads, Q(s, a) gathers, v / v_final in both branches, the loss
+call) against tests/golden/rl_steps.json — outputs of the reference's OWN `GPT2ILQLTrain._step` (ilql/gpt2/interface.py:88-367) executed
+under numpy stand-ins for jax / flax (tests/golden/make_step_fixtures.py).  The transformer slot of the closure was filled with this
+oracle's GPT-2, so the comparison isolates exactly the code between the model calls and the returned loss.  Tolerance: the reference ran
+in float32 (numpy), the oracle in float64 — 2e-5 relative."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import step_cases as C  # noqa: E402
+from conftest import load_golden  # noqa: E402
+from oracle import gpt2 as O, rl  # noqa: E402
+
+
+def _flat(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(_flat(v, prefix + k + "."))
+        else:
+            out[prefix + k] = float(v)
+    return out
+
+
+def oracle_step(case):
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    V = C.CFG["vocab"]
+    sd = {k: t(v) for k, v in C.state_dict(10 + case["seed"]).items()}
+    tsd = {k: t(v) for k, v in C.state_dict(20 + case["seed"]).items()} if case["target_base"] else sd
+    heads = [C.flat_head(C.mlp_head(s + case["seed"], o)) for s, o in ((30, V), (40, V), (50, 1), (60, V), (70, V))]
+    mh = lambda x, h: rl.mlp_head(x, t(h["dense1.kernel"]), t(h["dense1.bias"]), t(h["dense2.kernel"]), t(h["dense2.bias"]))
+    b = C.ilql_batch(case["seed"])
+    ids, am, pos = t(b["input_ids"]).long(), t(b["attention_mask"]), t(b["position_ids"]).long()
+    _, hid = O.forward(sd, ids, C.CFG["n_head"], attention_mask=am, position_ids=pos, return_hidden=True)
+    _, thid = O.forward(tsd, ids, C.CFG["n_head"], attention_mask=am, position_ids=pos, return_hidden=True)
+    q1o, q2o, vo, tq1o, tq2o = mh(hid, heads[0]), mh(hid, heads[1]), mh(hid, heads[2]), mh(thid, heads[3]), mh(thid, heads[4])
+    nxt = {}
+    if case["use_next"]:
+        nam = t(b["next_tokens_attention_mask"])
+        _, nhid = O.forward(sd, t(b["next_token_ids"]).long(), C.CFG["n_head"], attention_mask=nam, position_ids=t(b["next_tokens_position_ids"]).long(),
+                            return_hidden=True)
+        nxt = dict(next_v_head_out=mh(nhid, heads[2]), next_attention_mask=nam, next_dones=t(b["next_dones"]))
+    sta = t(b["should_take_action"])
+    q1, q2, v, v_final, tq1, tq2 = rl.ilql_gather_qv(q1o, q2o, vo, tq1o, tq2o, ids, am, sta, t(b["dones"]), **nxt)
+    loss, logs = rl.ilql_loss(q1, q2, v, v_final, tq1, tq2, q1o[:, :-1], q2o[:, :-1], ids[:, 1:], am[:, 1:].double(), sta, t(b["rewards"]).double(), **C.LOSS_KW)
+    return float(loss), _flat(logs)
+
+
+@pytest.mark.parametrize("case", C.ILQL_CASES, ids=[c["name"] for c in C.ILQL_CASES])
+def test_oracle_ilql_closure_equals_reference_step(case):
+    fx = load_golden("rl_steps.json")[case["name"]]
+    loss, logs = oracle_step(case)
+    assert abs(loss - fx["loss"]) <= 2e-5 * abs(fx["loss"]), (loss, fx["loss"])
+    assert set(logs) == set(fx["logs"])
+    for k, e in fx["logs"].items():
+        assert abs(logs[k] - e) <= 2e-5 * max(1.0, abs(e)), (k, logs[k], e)
+
+
+def test_reference_target_updates_follow_the_stated_rule():
+    """The fixture's target parameters after the step: the closure's stand-in optimizer scaled every online parameter by 0.9; targets then are
+    Polyak-averaged (`optax.incremental_update`), hard-copied when `TrainState.step` (AFTER its increment) hits `hard_update_every`, and left
+    alone on an accumulating micro-step (`opt_state.mini_step != 0`) — interface.py:327-365.  (The package's device implementation is compared
+    with the same digests in tests/test_gpu_train_steps_pinned.py.)"""
+    V = C.CFG["vocab"]
+    fxs = load_golden("rl_steps.json")
+    for case in C.ILQL_CASES:
+        fx = fxs[case["name"]]
+        assert fx["step_after"] == case["step0"] + 1
+        online, target = C.flat_head(C.mlp_head(30 + case["seed"], V)), C.flat_head(C.mlp_head(60 + case["seed"], V))
+        a = case["polyak_alpha"]
+        hard = case["hard_update_every"] is not None and fx["step_after"] % case["hard_update_every"] == 0
+        for name, old in target.items():
+            new = (online[name] * np.float32(0.9)).astype(np.float32)
+            if case["mini_step"] not in (None, 0):
+                exp = old
+            elif hard:
+                exp = new
+            else:
+                exp = (np.float32(a) * new + np.float32(1.0 - a) * old).astype(np.float32)
+            got = fx["q1_target"][name]
+            assert abs(got[0] - float(exp.astype(np.float64).sum())) <= 1e-4 * max(1.0, abs(got[0])), (case["name"], name)
+            np.testing.assert_allclose(got[2:], exp.ravel()[:3].astype(np.float64), rtol=1e-5, atol=1e-7)
+        assert (fx["target_base"] is None) == (not case["target_base"])
+
+
+@pytest.mark.parametrize("case", C.PPO_CASES, ids=[c["name"] for c in C.PPO_CASES])
+def test_oracle_ppo_closure_equals_reference_step(case):
+    """ppo/gpt2/interface.py:111-133: values = LinearHead(hidden)[:, :-1], logprobs = -CE(logits[:, :-1], ids[:, 1:]), the loss call, and
+    (:180-203) info = {'ppo', 'bc', 'total_loss'}, loss = ppo + bc_loss_weight * bc (the fixture's bc callable returned 1.75)."""
+    fx = load_golden("rl_steps.json")[case["name"]]
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    sd = {k: t(v) for k, v in C.state_dict(80 + case["seed"]).items()}
+    vh = C.flat_head(C.linear_head(90 + case["seed"]))
+    b = C.ppo_batch(case["seed"])
+    ids, am = t(b["input_ids"]).long(), t(b["attention_mask"])
+    logits, hid = O.forward(sd, ids, C.CFG["n_head"], attention_mask=am, position_ids=t(b["position_ids"]).long(), return_hidden=True)
+    values = rl.linear_head(hid, t(vh["dense.kernel"]), t(vh["dense.bias"]))[:, :-1, 0]
+    logprobs = rl.token_logprobs_from_logits(logits, ids)
+    td = lambda k: t(b[k]).double()
+    loss, logs = rl.ppo_loss(am[:, 1:].double(), logprobs, values, t(b["should_take_action"]), td("old_logprobs"), td("old_values"), td("old_advantages"),
+                             td("old_returns"), **C.PPO_KW)
+    got = _flat(logs)
+    if case["bc_weight"] is not None:
+        total = float(loss) + 1.75 * case["bc_weight"]
+        got = {**{"ppo." + k: v for k, v in got.items()}, "bc.loss": 1.75, "total_loss": total}
+        loss = total
+    assert abs(float(loss) - fx["loss"]) <= 2e-5 * abs(fx["loss"]), (float(loss), fx["loss"])
+    assert set(got) == set(fx["logs"])
+    for k, e in fx["logs"].items():
+        assert abs(got[k] - e) <= 2e-5 * max(1.0, abs(e)), (k, got[k], e)
