@@ -77,4 +77,8 @@ def make_modules():
     linen.compact = lambda f: f
     struct = types.ModuleType("flax.struct")
     struct.PyTreeNode, struct.field = PyTreeNode, field
-    return {"flax.linen": linen, "flax.struct": struct}
+    core = types.ModuleType("flax.core")                      # FrozenDict is only an immutability wrapper: identity on plain dicts
+    core.freeze = core.unfreeze = lambda d: d
+    frozen = types.ModuleType("flax.core.frozen_dict")
+    frozen.freeze = frozen.unfreeze = core.freeze
+    return {"flax.linen": linen, "flax.struct": struct, "flax.core": core, "flax.core.frozen_dict": frozen}

@@ -1,4 +1,6 @@
-"""Generate tests/golden/rl_steps.json by EXECUTING the reference's own ILQL train-step closure.
+"""Generate tests/golden/rl_steps.json by EXECUTING the reference's own train-step closures and its value-RL generation call:
+`GPT2ILQLTrain._step` (below), `GPT2PPOTrain._step` (ppo/gpt2/interface.py:72-211: values / log-prob wiring, the loss call, the BC combination),
+`GPT2MCTrain._step` (mc_returns/gpt2/interface.py:38-160) and `GPT2ValueRLGeneration.__call__` (value_rl_base/gpt2/generation.py:36-121).
 
     python tests/golden/make_step_fixtures.py          (build container only: reads /root/reference)
 
@@ -61,6 +63,9 @@ from LLM_RL.heads.mlp_head import MLPHead, MLPHeadConfig  # noqa: E402
 from LLM_RL.heads.linear_head import LinearHead, LinearHeadConfig  # noqa: E402
 from LLM_RL.algorithms.ppo.gpt2.interface import GPT2PPOTrain  # noqa: E402
 from LLM_RL.algorithms.ppo.base_interface import ppo_loss_fn  # noqa: E402
+from LLM_RL.algorithms.mc_returns.gpt2.interface import GPT2MCTrain  # noqa: E402
+from LLM_RL.algorithms.mc_returns.base_interface import mc_loss  # noqa: E402
+from LLM_RL.algorithms.value_rl_base.gpt2.generation import GPT2ValueRLGeneration  # noqa: E402
 from functools import partial  # noqa: E402
 
 
@@ -68,11 +73,16 @@ class FakeGPT2:
     """The transformer slot of the closure: hidden states of the float64 oracle GPT-2 for the parameters it is handed."""
     config = types.SimpleNamespace(mesh="mesh", get_partition_rules=lambda: [])
 
-    def __call__(self, input_ids, attention_mask, position_ids, params, dropout_rng=None, train=True, output_hidden_states=True):
+    def __call__(self, input_ids, attention_mask=None, position_ids=None, params=None, dropout_rng=None, train=True, output_hidden_states=True,
+                 past_key_values=None):
+        if position_ids is None:
+            am_ = np.asarray(attention_mask)
+            position_ids = np.maximum(np.cumsum(am_, axis=1) - 1, 0)
         sd = {k: torch.from_numpy(np.asarray(v, dtype=np.float32)) for k, v in params.items()}
         lg, hid = OG.forward(sd, torch.from_numpy(np.asarray(input_ids)).long(), C.CFG["n_head"], attention_mask=torch.from_numpy(np.asarray(attention_mask)),
                              position_ids=torch.from_numpy(np.asarray(position_ids)).long(), return_hidden=True)
-        return types.SimpleNamespace(hidden_states=(None, S.asarray(hid.numpy().astype(np.float32))), logits=S.asarray(lg.numpy().astype(np.float32)))
+        return types.SimpleNamespace(hidden_states=(None, S.asarray(hid.numpy().astype(np.float32))), logits=S.asarray(lg.numpy().astype(np.float32)),
+                                     past_key_values=None)
 
 
 def _scale(tree, f):
@@ -161,6 +171,30 @@ def main():
         _, _, loss, info = res
         out[case["name"]] = dict(loss=float(np.asarray(loss)), logs=flat_logs(info))
         print(case["name"], "loss", out[case["name"]]["loss"])
+    # ---- MC-returns closure (mc_returns/gpt2/interface.py:38-160): Q head, Q(s, a) gather, the mc_loss call
+    case = C.MC_CASE
+    sd, qh = C.state_dict(110 + case["seed"]), C.mlp_head(120 + case["seed"], V)
+    q_model = MLPHead(MLPHeadConfig(input_dim=d, hidden_dim=d, output_dim=V, mesh="mesh"))
+    train = GPT2MCTrain.load_train(base_train_state=FakeTrainState(sd, 0, None), q_head_train_state=FakeTrainState(qh, 0, None), base_model=FakeGPT2(),
+                                   q_head_model=q_model, tokenizer=None, loss_fn=partial(mc_loss, cql_weight=case["cql_weight"]), detach_q=False)
+    b = C.mc_batch(case["seed"])
+    A = S.asarray
+    res = train._step(train.base_train_state, train.q_head_train_state, A(b["input_ids"]), A(b["attention_mask"]), A(b["position_ids"]),
+                      A(b["should_take_action"]), A(b["returns"]), None, True)
+    out[case["name"]] = dict(loss=float(np.asarray(res[-2])), logs=flat_logs(res[-1]))
+    print(case["name"], "loss", out[case["name"]]["loss"])
+    # ---- GPT2ValueRLGeneration.__call__ (value_rl_base/gpt2/generation.py:36-121): logits = pi_beta + beta * min(q1, q2) at every position
+    for case in C.VALUE_RL_CASES:
+        pi_sd, base_sd = C.state_dict(130 + case["seed"]), C.state_dict(140 + case["seed"])
+        q1, q2 = C.mlp_head(150 + case["seed"], V), C.mlp_head(160 + case["seed"], V)
+        gen = GPT2ValueRLGeneration(types.SimpleNamespace(), FakeGPT2() if case["pi_beta"] else None, FakeGPT2(), q_model, case["beta"])
+        b = C.ilql_batch(case["seed"])
+        o = gen(A(b["input_ids"]), attention_mask=A(b["attention_mask"]), params=(pi_sd if case["pi_beta"] else None, base_sd, q1, q2 if case["q2"] else None),
+                position_ids=A(b["position_ids"]))
+        lg = np.asarray(o.logits, dtype=np.float64)
+        last = b["attention_mask"].sum(1) - 1
+        out[case["name"]] = dict(last_logits=[[float(x) for x in lg[i, last[i]]] for i in range(lg.shape[0])], all_sum=float(lg.sum()), all_sq=float((lg * lg).sum()))
+        print(case["name"], "sum", out[case["name"]]["all_sum"])
     path = os.path.join(HERE, "rl_steps.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))

@@ -87,3 +87,15 @@ def ppo_batch(seed: int):
 
 PPO_CASES = [dict(name="ppo_plain", seed=5, bc_weight=None), dict(name="ppo_with_bc_term", seed=6, bc_weight=0.7)]
 PPO_KW = dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0)
+
+
+def mc_batch(seed: int):
+    b = ilql_batch(seed)
+    r = np.random.RandomState(200 + seed)
+    return dict(input_ids=b["input_ids"], attention_mask=b["attention_mask"], position_ids=b["position_ids"], should_take_action=b["should_take_action"],
+                returns=(r.randn(B, T - 1) * b["should_take_action"]).astype(np.float32))
+
+
+MC_CASE = dict(name="mc_step", seed=7, cql_weight=0.05)
+VALUE_RL_CASES = [dict(name="value_rl_logits_pi_beta_two_heads", seed=8, pi_beta=True, q2=True, beta=32.0),
+                  dict(name="value_rl_logits_value_only_one_head", seed=9, pi_beta=False, q2=False, beta=8.0)]

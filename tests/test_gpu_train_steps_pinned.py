@@ -89,3 +89,48 @@ def test_ppo_step_equals_reference_closure():
     assert set(got) == set(fx["logs"])
     for k, e in fx["logs"].items():
         assert abs(got[k] - e) <= 1e-4 * max(1.0, abs(e)), (k, got[k], e)
+
+
+def test_mc_step_equals_reference_closure():
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.algorithms import mc_returns as mc
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    dev = _lib.require_gpu()
+    case = C.MC_CASE
+    fx = load_golden("rl_steps.json")[case["name"]]
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    base = GPT2F32({k: t(v) for k, v in C.state_dict(110 + case["seed"]).items()}, C.CFG["n_head"], device=dev)
+    head = MLPHeadF32({k: t(v) for k, v in C.flat_head(C.mlp_head(120 + case["seed"], C.CFG["vocab"])).items()}, dev)
+    tr = mc.GPT2MCTrain(base, head, C.PAD, dict(cql_weight=case["cql_weight"]), lr=1e-4)
+    b = C.mc_batch(case["seed"])
+    _, loss, logs = tr.step(b["input_ids"], b["should_take_action"], b["returns"])
+    assert abs(loss - fx["loss"]) <= 1e-4 * abs(fx["loss"]), (loss, fx["loss"])
+    got = _flat(logs)
+    assert set(got) == set(fx["logs"])
+    for k, e in fx["logs"].items():
+        assert abs(got[k] - e) <= 1e-4 * max(1.0, abs(e)), (k, got[k], e)
+
+
+@pytest.mark.parametrize("case", C.VALUE_RL_CASES, ids=[c["name"] for c in C.VALUE_RL_CASES])
+def test_value_rl_logits_equal_reference_generation_call(case):
+    """`GPT2ILQLInference.forward` (fp32 kernels) -> pi_beta + beta * min(q1, q2) == the reference's `GPT2ValueRLGeneration.__call__` output."""
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.algorithms import ilql
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    dev = _lib.require_gpu()
+    fx = load_golden("rl_steps.json")[case["name"]]
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    V = C.CFG["vocab"]
+    pi = GPT2F32({k: t(v) for k, v in C.state_dict(130 + case["seed"]).items()}, C.CFG["n_head"], device=dev)
+    base = GPT2F32({k: t(v) for k, v in C.state_dict(140 + case["seed"]).items()}, C.CFG["n_head"], device=dev)
+    q1 = MLPHeadF32({k: t(v) for k, v in C.flat_head(C.mlp_head(150 + case["seed"], V)).items()}, dev)
+    q2 = MLPHeadF32({k: t(v) for k, v in C.flat_head(C.mlp_head(160 + case["seed"], V)).items()}, dev)
+    b = C.ilql_batch(case["seed"])
+    out = ilql.GPT2ILQLInference(base, q1, q2 if case["q2"] else None, None, C.PAD).forward(b["input_ids"])
+    q = np.minimum(out.q1, out.q2) if case["q2"] else out.q1
+    lg = np.float32(case["beta"]) * q
+    if case["pi_beta"]:
+        lg = ilql.GPT2ILQLInference(pi, q1, None, None, C.PAD).forward(b["input_ids"]).base_logits + lg
+    last = b["attention_mask"].sum(1) - 1
+    exp = np.asarray(fx["last_logits"])
+    np.testing.assert_allclose(np.stack([lg[i, last[i]] for i in range(len(last))]), exp, rtol=0, atol=1e-4 * np.abs(exp).max())

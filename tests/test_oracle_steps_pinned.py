@@ -112,3 +112,45 @@ def test_oracle_ppo_closure_equals_reference_step(case):
     assert set(got) == set(fx["logs"])
     for k, e in fx["logs"].items():
         assert abs(got[k] - e) <= 2e-5 * max(1.0, abs(e)), (k, got[k], e)
+
+
+def test_oracle_mc_closure_equals_reference_step():
+    """mc_returns/gpt2/interface.py:96-121: Q head on the base hidden states, Q(s, a) gather on the shifted ids, mc_loss."""
+    case = C.MC_CASE
+    fx = load_golden("rl_steps.json")[case["name"]]
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    sd = {k: t(v) for k, v in C.state_dict(110 + case["seed"]).items()}
+    qh = C.flat_head(C.mlp_head(120 + case["seed"], C.CFG["vocab"]))
+    b = C.mc_batch(case["seed"])
+    ids, am = t(b["input_ids"]).long(), t(b["attention_mask"])
+    _, hid = O.forward(sd, ids, C.CFG["n_head"], attention_mask=am, position_ids=t(b["position_ids"]).long(), return_hidden=True)
+    qo = rl.mlp_head(hid, t(qh["dense1.kernel"]), t(qh["dense1.bias"]), t(qh["dense2.kernel"]), t(qh["dense2.bias"]))
+    q = qo[:, :-1].gather(2, ids[:, 1:].unsqueeze(-1)).squeeze(2)
+    loss, logs = rl.mc_loss(q, qo[:, :-1], ids[:, 1:], am[:, 1:].double(), t(b["should_take_action"]), t(b["returns"]).double(), cql_weight=case["cql_weight"])
+    assert abs(float(loss) - fx["loss"]) <= 2e-5 * abs(fx["loss"])
+    got = _flat(logs)
+    assert set(got) == set(fx["logs"])
+    for k, e in fx["logs"].items():
+        assert abs(got[k] - e) <= 2e-5 * max(1.0, abs(e)), (k, got[k], e)
+
+
+@pytest.mark.parametrize("case", C.VALUE_RL_CASES, ids=[c["name"] for c in C.VALUE_RL_CASES])
+def test_oracle_value_rl_logits_equal_reference_generation_call(case):
+    """value_rl_base/gpt2/generation.py:36-121 executed as it is (pi_beta optional, q2 optional): logits = pi_beta + beta * min(q1, q2)."""
+    fx = load_golden("rl_steps.json")[case["name"]]
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    V = C.CFG["vocab"]
+    pi_sd = {k: t(v) for k, v in C.state_dict(130 + case["seed"]).items()}
+    base_sd = {k: t(v) for k, v in C.state_dict(140 + case["seed"]).items()}
+    h1, h2 = C.flat_head(C.mlp_head(150 + case["seed"], V)), C.flat_head(C.mlp_head(160 + case["seed"], V))
+    mh = lambda x, h: rl.mlp_head(x, t(h["dense1.kernel"]), t(h["dense1.bias"]), t(h["dense2.kernel"]), t(h["dense2.bias"]))
+    b = C.ilql_batch(case["seed"])
+    ids, am, pos = t(b["input_ids"]).long(), t(b["attention_mask"]), t(b["position_ids"]).long()
+    pi_logits = O.forward(pi_sd, ids, C.CFG["n_head"], attention_mask=am, position_ids=pos) if case["pi_beta"] else None
+    _, hid = O.forward(base_sd, ids, C.CFG["n_head"], attention_mask=am, position_ids=pos, return_hidden=True)
+    lg = rl.value_rl_logits(pi_logits, mh(hid, h1), mh(hid, h2) if case["q2"] else None, case["beta"]).numpy()
+    last = b["attention_mask"].sum(1) - 1
+    exp = np.asarray(fx["last_logits"])
+    scale = np.abs(exp).max()
+    np.testing.assert_allclose(np.stack([lg[i, last[i]] for i in range(len(last))]), exp, rtol=0, atol=3e-5 * scale)
+    assert abs(float(lg.sum()) - fx["all_sum"]) <= 1e-5 * abs(fx["all_sum"]) and abs(float((lg * lg).sum()) - fx["all_sq"]) <= 1e-5 * fx["all_sq"]
