@@ -366,6 +366,17 @@ def softmax_cross_entropy_with_integer_labels(logits, labels):
     return log_norm - label_logits
 
 
+def log_softmax(x, axis=-1):
+    """jax.nn.log_softmax: x - logsumexp(x), max-shifted, float32."""
+    x = _raw(x)
+    m = np.max(x, axis=axis, keepdims=True)
+    return _wrap((x - m) - np.log(np.sum(np.exp(x - m), axis=axis, keepdims=True)))
+
+
+def empty(shape, dtype=np.float32):
+    return _wrap(np.zeros(shape, dtype=dtype))
+
+
 def squeeze(a, axis=None):
     return _wrap(np.squeeze(_raw(a), axis=axis))
 
@@ -407,8 +418,10 @@ def make_modules():
     jnp.sum = sum_
     jnp.matmul = jnp.dot = matmul
     jnp.squeeze = squeeze
+    jnp.empty = empty
     nn = types.ModuleType("jax.nn")
     nn.one_hot = one_hot
+    nn.log_softmax = log_softmax
     lax = types.ModuleType("jax.lax")
     lax.stop_gradient = stop_gradient
     lax.cond = cond

@@ -66,6 +66,11 @@ from LLM_RL.algorithms.ppo.base_interface import ppo_loss_fn  # noqa: E402
 from LLM_RL.algorithms.mc_returns.gpt2.interface import GPT2MCTrain  # noqa: E402
 from LLM_RL.algorithms.mc_returns.base_interface import mc_loss  # noqa: E402
 from LLM_RL.algorithms.value_rl_base.gpt2.generation import GPT2ValueRLGeneration  # noqa: E402
+from LLM_RL.algorithms.ppo.score_fn import build_ppo_score_fn, build_bc_score_fn  # noqa: E402
+from LLM_RL.algorithms.ilql.gpt2.score_fn import build_ilql_score_fn  # noqa: E402
+from LLM_RL.environment import Text  # noqa: E402
+
+jax.device_get = lambda x: x
 from functools import partial  # noqa: E402
 
 
@@ -195,6 +200,34 @@ def main():
         last = b["attention_mask"].sum(1) - 1
         out[case["name"]] = dict(last_logits=[[float(x) for x in lg[i, last[i]]] for i in range(lg.shape[0])], all_sum=float(lg.sum()), all_sq=float((lg * lg).sum()))
         print(case["name"], "sum", out[case["name"]]["all_sum"])
+    # ---- score functions (ppo/score_fn.py:10-126, ilql/gpt2/score_fn.py:11-68): token windows, prefix lengths, masked sums over the last action
+    case = C.SCORE_CASE
+    tok = C.CharTok()
+    hists = [tuple(Text(t, a) for t, a in h) for h in C.score_histories()]
+    pol_sd, base_sd = C.state_dict(170 + case["seed"]), C.state_dict(180 + case["seed"])
+    q1, q2, vh = C.mlp_head(190 + case["seed"], V), C.mlp_head(200 + case["seed"], V), C.mlp_head(210 + case["seed"], 1)
+    fake = FakeGPT2()
+
+    def fwd(sd, tokens, attention_mask=None):
+        am = np.asarray(attention_mask if attention_mask is not None else (np.asarray(tokens) != tok.pad_token_id)).astype(np.int64)
+        return fake(tokens, attention_mask=am, params=sd)
+    ppo_inf = types.SimpleNamespace(forward=lambda t_, attention_mask=None, train=False, prng_key=None: types.SimpleNamespace(policy_raw_output=fwd(pol_sd, t_, attention_mask)))
+    bc_inf = types.SimpleNamespace(forward=lambda t_, attention_mask=None, train=False, prng_key=None: fwd(pol_sd, t_, attention_mask))
+
+    def ilql_forward(batch):
+        o = fwd(base_sd, batch)
+        h = o.hidden_states[-1]
+        return types.SimpleNamespace(q1=q_model.apply({"params": q1}, h, train=False), q2=q_model.apply({"params": q2}, h, train=False),
+                                     v=S.squeeze(v_model_mlp.apply({"params": vh}, h, train=False), axis=2))
+    v_model_mlp = MLPHead(MLPHeadConfig(input_dim=d, hidden_dim=d, output_dim=1, mesh="mesh"))
+    ilql_inf = types.SimpleNamespace(forward=ilql_forward)
+    pib_inf = types.SimpleNamespace(get_logits_from_tokens=lambda batch: fwd(pol_sd, batch).logits)
+    L, bs = C.SCORE_MAX_LENGTH, C.SCORE_BSIZE
+    out[case["name"]] = dict(
+        ppo=build_ppo_score_fn(ppo_inf, tok, L, bs)(hists), bc=build_bc_score_fn(bc_inf, tok, L, bs)(hists),
+        ilql=build_ilql_score_fn(ilql_inf, None, tok, L, case["value_weight"], None, bs)(hists),
+        ilql_with_logits=build_ilql_score_fn(ilql_inf, pib_inf, tok, L, case["value_weight"], case["logit_weight"], bs)(hists))
+    print(case["name"], [round(x, 3) for x in out[case["name"]]["ppo"]], [round(x, 3) for x in out[case["name"]]["ilql_with_logits"]])
     path = os.path.join(HERE, "rl_steps.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))

@@ -99,3 +99,24 @@ def mc_batch(seed: int):
 MC_CASE = dict(name="mc_step", seed=7, cql_weight=0.05)
 VALUE_RL_CASES = [dict(name="value_rl_logits_pi_beta_two_heads", seed=8, pi_beta=True, q2=True, beta=32.0),
                   dict(name="value_rl_logits_value_only_one_head", seed=9, pi_beta=False, q2=False, beta=8.0)]
+
+
+class CharTok:
+    """One token per character (ids < PAD), pad = PAD: the tokenizer handed to the score functions."""
+    pad_token_id = PAD
+
+    def encode(self, s):
+        return [ord(c) % PAD for c in s]
+
+
+def score_histories():
+    """[(text, is_action), ...] per candidate: last item is the action; different prefix / action lengths, one longer than max_length."""
+    return [[("maze: go\n", False), ("move left\n", True)],
+            [("maze: go\n", False), ("move right\n", True)],
+            [("a\n", False), ("up\n", True), ("wall\n", False), ("down\n", True)],
+            [("x" * 30 + "\n", False), ("move up\n", True)],          # 39 tokens > max_length: the reference keeps the LAST max_length tokens
+            [("q\n", False), ("z\n", True)]]
+
+
+SCORE_MAX_LENGTH, SCORE_BSIZE = 28, 2
+SCORE_CASE = dict(name="score_fns", seed=11, value_weight=1.5, logit_weight=0.25)

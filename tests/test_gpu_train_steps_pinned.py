@@ -134,3 +134,32 @@ def test_value_rl_logits_equal_reference_generation_call(case):
     last = b["attention_mask"].sum(1) - 1
     exp = np.asarray(fx["last_logits"])
     np.testing.assert_allclose(np.stack([lg[i, last[i]] for i in range(len(last))]), exp, rtol=0, atol=1e-4 * np.abs(exp).max())
+
+
+def test_score_functions_equal_reference_score_fns():
+    """`build_ppo_score_fn` / `build_bc_score_fn` / `build_ilql_score_fn` (token window = last max_length tokens right-padded, prefix length of
+    the UNtruncated history, masked sum over the last action — incl. the reference's empty-slice result for an over-long history) against the
+    reference's own functions executed under the stand-ins (ppo/score_fn.py:10-126, ilql/gpt2/score_fn.py:11-68)."""
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.algorithms import reranker
+    from lmrl_gym_amd.environment import Text
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    dev = _lib.require_gpu()
+    case = C.SCORE_CASE
+    fx = load_golden("rl_steps.json")[case["name"]]
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    V = C.CFG["vocab"]
+    pol = GPT2F32({k: t(v) for k, v in C.state_dict(170 + case["seed"]).items()}, C.CFG["n_head"], device=dev)
+    base = GPT2F32({k: t(v) for k, v in C.state_dict(180 + case["seed"]).items()}, C.CFG["n_head"], device=dev)
+    mk = lambda s, o: MLPHeadF32({k: t(v) for k, v in C.flat_head(C.mlp_head(s + case["seed"], o)).items()}, dev)
+    q1, q2, vh = mk(190, V), mk(200, V), mk(210, 1)
+    tok = C.CharTok()
+    hists = [tuple(Text(x, a) for x, a in h) for h in C.score_histories()]
+    L, bs = C.SCORE_MAX_LENGTH, C.SCORE_BSIZE
+    close = lambda got, exp: np.testing.assert_allclose(got, exp, rtol=1e-4, atol=2e-4)
+    close(reranker.build_ppo_score_fn(pol, tok, L, bs)(hists), fx["ppo"])
+    close(reranker.build_bc_score_fn(pol, tok, L, bs)(hists), fx["bc"])
+    close(reranker.build_ilql_score_fn(base, q1, q2, vh, tok, L, bs, value_weight=case["value_weight"])(hists), fx["ilql"])
+    close(reranker.build_ilql_score_fn(base, q1, q2, vh, tok, L, bs, value_weight=case["value_weight"], pi_beta=pol, logit_weight=case["logit_weight"])(hists),
+          fx["ilql_with_logits"])
+    assert fx["ppo"][3] == 0.0 and fx["ppo"][0] < -50          # the over-long history scores exactly 0 in the reference (empty slice); others are real sums

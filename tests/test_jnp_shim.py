@@ -159,3 +159,12 @@ def test_flax_stand_ins_run_dense_modules():
     np.testing.assert_allclose(np.asarray(y), np.maximum(x @ p["dense1"]["kernel"] + p["dense1"]["bias"], 0) @ p["out"]["kernel"] * 2.0, rtol=1e-6)
     node = F.PyTreeNode(a=1, b=2).replace(b=3)
     assert (node.a, node.b) == (1, 3)
+
+
+def test_log_softmax_and_empty():
+    x = RNG.randn(3, 5).astype(np.float32) * 4
+    ls = S.log_softmax(a(x), axis=-1)
+    np.testing.assert_allclose(np.exp(np.asarray(ls)).sum(-1), 1.0, rtol=1e-6)
+    np.testing.assert_allclose(np.asarray(ls), x - np.log(np.exp(x.astype(np.float64)).sum(-1, keepdims=True)), rtol=1e-5, atol=1e-6)
+    e = S.empty((4,), dtype=np.float32)
+    assert e.shape == (4,) and e.dtype == np.float32 and isinstance(e.at[1].set(2.0), S.Arr)
