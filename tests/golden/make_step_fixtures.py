@@ -1,6 +1,7 @@
 """Generate tests/golden/rl_steps.json by EXECUTING the reference's own train-step closures and its value-RL generation call:
 `GPT2ILQLTrain._step` (below), `GPT2PPOTrain._step` (ppo/gpt2/interface.py:72-211: values / log-prob wiring, the loss call, the BC combination),
-`GPT2MCTrain._step` (mc_returns/gpt2/interface.py:38-160) and `GPT2ValueRLGeneration.__call__` (value_rl_base/gpt2/generation.py:36-121).
+`GPT2MCTrain._step` (mc_returns/gpt2/interface.py:38-160), `GPT2ValueRLGeneration.__call__` (value_rl_base/gpt2/generation.py:36-121), the score
+functions (ppo/score_fn.py, ilql/gpt2/score_fn.py) and `PPOInference.get_ppo_data_from_token_trajectory_chain` (ppo/base_interface.py:464-669).
 
     python tests/golden/make_step_fixtures.py          (build container only: reads /root/reference)
 
@@ -228,6 +229,65 @@ def main():
         ilql=build_ilql_score_fn(ilql_inf, None, tok, L, case["value_weight"], None, bs)(hists),
         ilql_with_logits=build_ilql_score_fn(ilql_inf, pib_inf, tok, L, case["value_weight"], case["logit_weight"], bs)(hists))
     print(case["name"], [round(x, 3) for x in out[case["name"]]["ppo"]], [round(x, 3) for x in out[case["name"]]["ilql_with_logits"]])
+    # ---- PPOInference.get_ppo_data_from_token_trajectory_chain (ppo/base_interface.py:464-669), the whole function: forwards in batches,
+    # un-padding, bootstrap value x (1 - done), KL penalty on the rewards, GAE per chain, whitening over the batch, chunk unrolling
+    import enum
+    from typing import NamedTuple
+    import LLM_RL.algorithms.ppo.base_interface as PB
+    from LLM_RL.environment import TokenTrajectory, TokenTrajectoryChain
+
+    class Padding(enum.Enum):
+        LEFT = "left"; RIGHT = "right"
+
+    class Truncation(enum.Enum):
+        LEFT = "left"; RIGHT = "right"
+
+    class BlockingStrategy(NamedTuple):
+        padding: Padding
+        truncation: Truncation
+        max_length: object
+
+    def block_sequences(sequences, pad_value, dtype, blocking_strategy):
+        # JaxSeq.utils.block_sequences (third party, absent): pad / truncate to max_length (default: the longest sequence)
+        L = blocking_strategy.max_length or max(len(x) for x in sequences)
+        o = np.full((len(sequences), L), pad_value, dtype=dtype)
+        for i, x in enumerate(sequences):
+            x = list(x)[:L] if blocking_strategy.truncation == Truncation.RIGHT else list(x)[-L:]
+            if blocking_strategy.padding == Padding.RIGHT:
+                o[i, :len(x)] = x
+            else:
+                o[i, L - len(x):] = x
+        return o
+    PB.Padding, PB.Truncation, PB.BlockingStrategy, PB.block_sequences = Padding, Truncation, BlockingStrategy, block_sequences
+    PB.multihost_device_get = lambda x, mesh=None: x
+    case = C.PPO_DATA_CASE
+    init_sd, vh = C.state_dict(230 + case["seed"]), C.linear_head(240 + case["seed"])
+    pol_sd = C.perturbed(init_sd, 220 + case["seed"])
+    lin_model = LinearHead(LinearHeadConfig(input_dim=d, output_dim=1, mesh="mesh"))
+    fake = FakeGPT2()
+
+    def ppo_forward(tokens_batch, train=False, prng_key=None):
+        am = (np.asarray(tokens_batch) != C.PAD).astype(np.int64)
+        po, io = fake(tokens_batch, attention_mask=am, params=pol_sd), fake(tokens_batch, attention_mask=am, params=init_sd)
+        values = S.squeeze(lin_model.apply({"params": vh}, po.hidden_states[-1], train=False), axis=2)
+        return types.SimpleNamespace(initial_policy_raw_output=io, policy_raw_output=po, values=values)
+    fake_self = types.SimpleNamespace(initial_policy_model=types.SimpleNamespace(config=types.SimpleNamespace(mesh="mesh")), initial_policy_params=init_sd,
+                                      policy_model=types.SimpleNamespace(config=types.SimpleNamespace(mesh="mesh")),
+                                      tokenizer=types.SimpleNamespace(pad_token_id=C.PAD), forward=ppo_forward,
+                                      token_logprobs_from_logits=PB.PPOInference.token_logprobs_from_logits)
+    chains = []
+    for ch in C.ppo_chains(case["seed"]):
+        node = None
+        for tt in reversed(ch):
+            node = TokenTrajectoryChain(TokenTrajectory(tt["tokens"], tt["is_action"], tt["reward"], np.asarray(tt["done"])), node)
+        chains.append(node)
+    datas, kls = PB.PPOInference.get_ppo_data_from_token_trajectory_chain(fake_self, chains, case["bsize"], None, verbose=False, gamma=case["gamma"],
+                                                                          lam=case["lam"], kl_weight=case["kl_weight"])
+    tl = lambda a: [float(x) for x in np.asarray(a).ravel()]
+    out[case["name"]] = dict(kls=tl(kls), datas=[dict(input_ids=[int(x) for x in dd.input_ids], should_take_action=[bool(x) for x in dd.should_take_action],
+                                                      old_logprobs=tl(dd.old_logprobs), old_values=tl(dd.old_values), old_advantages=tl(dd.old_advantages),
+                                                      old_returns=tl(dd.old_returns)) for dd in datas])
+    print(case["name"], len(datas), "chunks,", len(kls), "action tokens, mean kl", float(np.mean(kls)))
     path = os.path.join(HERE, "rl_steps.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))

@@ -120,3 +120,32 @@ def score_histories():
 
 SCORE_MAX_LENGTH, SCORE_BSIZE = 28, 2
 SCORE_CASE = dict(name="score_fns", seed=11, value_weight=1.5, logit_weight=0.25)
+
+
+def ppo_chains(seed: int):
+    """Token trajectory chains as plain dicts: [[{tokens, is_action, reward, done}, ...chunks], ...chains].  Later chunks start with a state
+    (the reference asserts it, ppo/base_interface.py:319-327); rewards sit on action tokens; only a chain's last chunk may be done."""
+    r = np.random.RandomState(300 + seed)
+    spec = [[(9, True)], [(8, False), (6, True)], [(5, False), (7, False), (4, False)], [(6, False)]]
+    chains = []
+    for ch in spec:
+        chunks = []
+        for n, done in ch:
+            tokens = r.randint(0, PAD, size=n).astype(np.int32)
+            is_action = np.zeros(n, dtype=bool)
+            is_action[2:] = (np.arange(n - 2) % 3) != 2          # runs of 2 action tokens separated by a state token, after a 2-token header
+            if not is_action.any():
+                is_action[-1] = True
+            reward = (r.randn(n) * is_action).astype(np.float32)
+            chunks.append(dict(tokens=tokens, is_action=is_action, reward=reward, done=bool(done)))
+        chains.append(chunks)
+    return chains
+
+
+PPO_DATA_CASE = dict(name="ppo_data_pipeline", seed=12, bsize=3, gamma=0.97, lam=0.9, kl_weight=0.05)
+
+
+def perturbed(sd, seed: int, eps: float = 0.03):
+    """A nearby parameter set (the policy a few updates after `sd`): every tensor + eps * std * noise."""
+    r = np.random.RandomState(seed)
+    return {k: (v + eps * max(float(v.std()), 1e-3) * r.randn(*v.shape)).astype(np.float32) for k, v in sd.items()}

@@ -163,3 +163,35 @@ def test_score_functions_equal_reference_score_fns():
     close(reranker.build_ilql_score_fn(base, q1, q2, vh, tok, L, bs, value_weight=case["value_weight"], pi_beta=pol, logit_weight=case["logit_weight"])(hists),
           fx["ilql_with_logits"])
     assert fx["ppo"][3] == 0.0 and fx["ppo"][0] < -50          # the over-long history scores exactly 0 in the reference (empty slice); others are real sums
+
+
+def test_ppo_data_pipeline_equals_reference_function():
+    """`GPT2PPOInference.get_ppo_data_from_token_trajectory_chain` on the device == the reference's whole function (ppo/base_interface.py:464-669)."""
+    from lmrl_gym_amd import _lib, environment as E
+    from lmrl_gym_amd.algorithms.ppo_inference import GPT2PPOInference
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
+    dev = _lib.require_gpu()
+    case = C.PPO_DATA_CASE
+    fx = load_golden("rl_steps.json")[case["name"]]
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    init_np = C.state_dict(230 + case["seed"])
+    vh = C.flat_head(C.linear_head(240 + case["seed"]))
+    pol = GPT2F32({k: t(v) for k, v in C.perturbed(init_np, 220 + case["seed"]).items()}, C.CFG["n_head"], device=dev)
+    init = GPT2F32({k: t(v) for k, v in init_np.items()}, C.CFG["n_head"], device=dev)
+    inf = GPT2PPOInference(pol, LinearHeadF32(dict(kernel=t(vh["dense.kernel"]), bias=t(vh["dense.bias"])), dev), C.PAD, initial_policy=init)
+    chains = []
+    for ch in C.ppo_chains(case["seed"]):
+        node = None
+        for tt in reversed(ch):
+            node = E.TokenTrajectoryChain(E.TokenTrajectory(tt["tokens"], tt["is_action"], tt["reward"], np.asarray(tt["done"])), node)
+        chains.append(node)
+    datas, kls = inf.get_ppo_data_from_token_trajectory_chain(chains, bsize=case["bsize"], max_length=None, gamma=case["gamma"], lam=case["lam"],
+                                                              kl_weight=case["kl_weight"])
+    np.testing.assert_allclose(kls, fx["kls"], rtol=2e-3, atol=2e-5)
+    assert len(datas) == len(fx["datas"])
+    for d, e in zip(datas, fx["datas"]):
+        assert d.input_ids.tolist() == e["input_ids"] and [bool(x) for x in d.should_take_action] == e["should_take_action"]
+        np.testing.assert_allclose(d.old_logprobs, e["old_logprobs"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(d.old_values, e["old_values"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(d.old_returns, e["old_returns"], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(d.old_advantages, e["old_advantages"], rtol=2e-3, atol=2e-3)

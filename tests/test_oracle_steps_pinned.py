@@ -154,3 +154,41 @@ def test_oracle_value_rl_logits_equal_reference_generation_call(case):
     scale = np.abs(exp).max()
     np.testing.assert_allclose(np.stack([lg[i, last[i]] for i in range(len(last))]), exp, rtol=0, atol=3e-5 * scale)
     assert abs(float(lg.sum()) - fx["all_sum"]) <= 1e-5 * abs(fx["all_sum"]) and abs(float((lg * lg).sum()) - fx["all_sq"]) <= 1e-5 * fx["all_sq"]
+
+
+def test_oracle_ppo_data_pipeline_equals_reference_function():
+    """`rl.ppo_data_from_chains` (+ the oracle forwards) against the reference's WHOLE `get_ppo_data_from_token_trajectory_chain`
+    (ppo/base_interface.py:464-669) executed under the stand-ins: per-chunk PPOData fields and the KL vector."""
+    case = C.PPO_DATA_CASE
+    fx = load_golden("rl_steps.json")[case["name"]]
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    init_np = C.state_dict(230 + case["seed"])
+    init_sd = {k: t(v) for k, v in init_np.items()}
+    pol_sd = {k: t(v) for k, v in C.perturbed(init_np, 220 + case["seed"]).items()}
+    vh = C.flat_head(C.linear_head(240 + case["seed"]))
+    chains = C.ppo_chains(case["seed"])
+    lp_c, ilp_c, v_c, chain_dicts = [], [], [], []
+    for ch in chains:
+        lps, ilps, vs = [], [], []
+        for tt in ch:
+            ids = t(tt["tokens"]).long()[None]
+            lg, hid = O.forward(pol_sd, ids, C.CFG["n_head"], return_hidden=True)
+            ilg = O.forward(init_sd, ids, C.CFG["n_head"])
+            lps.append(rl.token_logprobs_from_logits(lg, ids)[0].numpy()); ilps.append(rl.token_logprobs_from_logits(ilg, ids)[0].numpy())
+            v = rl.linear_head(hid, t(vh["dense.kernel"]), t(vh["dense.bias"]))[0, :, 0].numpy()
+            vs.append(v[:-1]); last = v[-1]
+        lp_c.append(np.concatenate(lps)); ilp_c.append(np.concatenate(ilps))
+        v_c.append(np.concatenate(vs + [np.array([last * (1.0 - float(ch[-1]["done"]))])]))
+        chain_dicts.append([dict(tokens=tt["tokens"].tolist(), is_action=tt["is_action"].tolist(), reward=tt["reward"].tolist(), done=tt["done"]) for tt in ch])
+    ref, kls = rl.ppo_data_from_chains(chain_dicts, lp_c, ilp_c, v_c, gamma=case["gamma"], lam=case["lam"], kl_weight=case["kl_weight"])
+    np.testing.assert_allclose(kls, fx["kls"], rtol=2e-4, atol=2e-6)
+    k = 0
+    for ch, r in zip(chains, ref):
+        offs = np.cumsum([0] + r["chunk_lens"])
+        for j, tt in enumerate(ch):
+            d = fx["datas"][k]; k += 1
+            sl = slice(offs[j], offs[j + 1])
+            assert d["input_ids"] == tt["tokens"].tolist() and d["should_take_action"] == [bool(x) for x in r["should_take_action"][sl]]
+            for name in ("old_logprobs", "old_values", "old_advantages", "old_returns"):
+                np.testing.assert_allclose(r[name][sl], d[name], rtol=3e-5, atol=3e-5, err_msg=name)
+    assert k == len(fx["datas"])
