@@ -1063,13 +1063,13 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
     const bool fused = !(flags & LMRL_FWD_LN_STANDALONE) && g_gemm_variant != 1 && ln_fusion_nq(d) != 0;
     // TIMING-ONLY ablation (tools/bench_ablate_decode.py; results are garbage): leave out one launch class of the single-token decode layers to
     // measure what removing / hiding that launch could buy at most inside the real dependent chain
-    const unsigned ablate = (c == 1) ? ((flags >> LMRL_FWD_ABLATE_SHIFT) & 0x3fu) : 0u;
+    const unsigned ablate = (c == 1) ? ((flags >> LMRL_FWD_ABLATE_SHIFT) & 0x1ffu) : 0u;
     // LMRL_ABLATE_PROJ_CONCURRENT (timing only, garbage results): the proj GEMM is launched on an auxiliary stream that waits for the qkv GEMM
     // only, i.e. it runs CONCURRENTLY with the attention launch on stale data — the most any attention -> proj overlap scheme could hide,
     // contention between the two launches included
     static hipStream_t aux_stream = nullptr;
     static hipEvent_t aux_fork = nullptr, aux_join = nullptr;
-    if ((ablate & LMRL_ABLATE_PROJ_CONCURRENT) && !aux_stream) {
+    if ((ablate & (LMRL_ABLATE_PROJ_CONCURRENT | LMRL_ABLATE_FC2_SPLITK2 | LMRL_ABLATE_FC2_HALFK | LMRL_ABLATE_PROJ_AUX_SERIAL)) && !aux_stream) {
         LMRL_CHECK_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
         LMRL_CHECK_HIP(hipEventCreateWithFlags(&aux_fork, hipEventDisableTiming));
         LMRL_CHECK_HIP(hipEventCreateWithFlags(&aux_join, hipEventDisableTiming));
@@ -1197,12 +1197,34 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
             }
         } else if (fused) {
             GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
-            if (ablate & LMRL_ABLATE_PROJ_CONCURRENT) LMRL_CHECK_HIP(hipStreamWaitEvent(s, aux_join, 0));      // join
+            if (ablate & LMRL_ABLATE_PROJ_AUX_SERIAL) {        // calibration: the SAME dependency chain routed through the aux stream (fork after the attention)
+                LMRL_CHECK_HIP(hipEventRecord(aux_fork, s));
+                LMRL_CHECK_HIP(hipStreamWaitEvent(aux_stream, aux_fork, 0));
+                LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, aux_stream));
+                LMRL_CHECK_HIP(hipEventRecord(aux_join, aux_stream));
+                LMRL_CHECK_HIP(hipStreamWaitEvent(s, aux_join, 0));
+            }
+            else if (ablate & LMRL_ABLATE_PROJ_CONCURRENT) LMRL_CHECK_HIP(hipStreamWaitEvent(s, aux_join, 0));      // join
             else if (!(ablate & LMRL_ABLATE_PROJ)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, s));
             GemmArgs gf{w.h, L.wf_fc, L.bf_fc, w.ff, M, cf.d_ff, d, d, cf.d_ff, cf.d_ff, w.stats, nullptr, L.cs_fc, nsl, 1.f / (float)d, cf.ln_eps, m_dev};
             if (!(ablate & LMRL_ABLATE_FC)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_GELU_BF16_LN>(gf, s));
             GemmArgs g2{w.ff, L.w_fc2, L.b_fc2, w.x, M, d, cf.d_ff, cf.d_ff, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
             if (ablate & LMRL_ABLATE_FC2) {}
+            else if (ablate & (LMRL_ABLATE_FC2_SPLITK2 | LMRL_ABLATE_FC2_HALFK)) {
+                // timing only: fc2 over HALF of K — alone (what a K loop of half the length costs), or as two such launches running concurrently on two
+                // streams (racy read-modify-write of x: garbage) = a split-K = 2 form without its reduction seam
+                GemmArgs ga = g2; ga.K = cf.d_ff / 2;
+                GemmArgs gb = ga; gb.A = ga.A + cf.d_ff / 2; gb.W = ga.W + cf.d_ff / 2; gb.ldw = cf.d_ff;
+                ga.ldw = cf.d_ff;
+                if (ablate & LMRL_ABLATE_FC2_SPLITK2) {
+                    LMRL_CHECK_HIP(hipEventRecord(aux_fork, s));
+                    LMRL_CHECK_HIP(hipStreamWaitEvent(aux_stream, aux_fork, 0));
+                    LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gb, aux_stream));
+                    LMRL_CHECK_HIP(hipEventRecord(aux_join, aux_stream));
+                }
+                LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(ga, s));
+                if (ablate & LMRL_ABLATE_FC2_SPLITK2) LMRL_CHECK_HIP(hipStreamWaitEvent(s, aux_join, 0));
+            }
             else if (l + 1 < cf.n_layer) LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(g2, s));
             else LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(g2, s));      // ln_f reads the fp32 stream directly
         } else {

@@ -25,9 +25,10 @@ vocab = W.Vocabulary.builtin("wordle_official_400.txt")
 B, N = 1024, 6
 g = torch.from_numpy(scripted_guesses(vocab.all_vocab, N + 1, 6, B, seed=1).view(np.int32)).to(dev)
 seeds = torch.arange((N + 1) * B, dtype=torch.int64, device=dev).view(N + 1, B)
-names = [("full episode", 0), ("without decode qkv GEMM", 1), ("without decode attention", 2), ("without decode proj GEMM", 4),
+names = [("full episode", 0), ("proj via the aux stream, SERIAL (cost of one fork / join per layer)", 256), ("without decode qkv GEMM", 1), ("without decode attention", 2), ("without decode proj GEMM", 4),
          ("without decode fc GEMM", 8), ("without decode fc2 GEMM", 16), ("without proj + fc2", 20), ("without all five", 31),
-         ("proj CONCURRENT with attention (aux stream, stale data)", 32)]
+         ("proj CONCURRENT with attention (aux stream, stale data)", 32), ("fc2 over half of K only", 128),
+         ("fc2 as two CONCURRENT half-K launches (split-K 2, no seam)", 64)]
 base = None
 n_dec = 30 * 12                                                   # decode layers per episode: 30 forwards x 12 layers
 for name, bits in names * 2:                                     # two passes: the second one is reported (clocks settled)
@@ -42,6 +43,6 @@ for name, bits in names * 2:                                     # two passes: t
     ms = (time.perf_counter() - t0) / N * 1e3
     if bits == 0:
         base = ms
-    print(f"{name:56s} {ms:7.2f} ms per episode   delta {base - ms:6.2f} ms = {(base - ms) * 1e3 / n_dec:6.2f} us per decode layer", flush=True)
+    print(f"{name:68s} {ms:7.2f} ms per episode   delta {base - ms:6.2f} ms = {(base - ms) * 1e3 / n_dec:6.2f} us per decode layer", flush=True)
     ro.close()
     del ro
