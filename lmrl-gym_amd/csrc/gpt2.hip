@@ -479,7 +479,7 @@ struct DecodePrefix {
     int tmax;
 };
 
-template <int U, bool PFX>
+template <int U, bool PFX, bool HALF = false>   // HALF: timing-only ablation — only the first half of the cached positions is read (half the cache lines and bytes)
 __global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *__restrict__ qkv,   // [rows][3d]
                                                                uint16_t *__restrict__ kcache, uint16_t *__restrict__ vcache,
                                                                const int32_t *__restrict__ cnt, const int32_t *__restrict__ len,
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *_
     const uint4 qv = *reinterpret_cast<const uint4 *>(qbase);
     const uint4 knew = *reinterpret_cast<const uint4 *>(qbase + d), vnew = *reinterpret_cast<const uint4 *>(qbase + 2 * d);
     if (cnt[b] <= 0) return;                                         // wave-uniform: finished env (its rows are not in the batch)
-    const int L0 = len[b];
+    const int L0 = HALF ? (len[b] + 1) / 2 : len[b];
     // PFX: positions < pn come from row prow of the prefix session (wave-uniform scalars; the per-lane choice is two selects)
     uint32_t pn = 0u, prow = 0u;
     const char *pkc = kc, *pvc = vc;
@@ -1063,7 +1063,7 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
     const bool fused = !(flags & LMRL_FWD_LN_STANDALONE) && g_gemm_variant != 1 && ln_fusion_nq(d) != 0;
     // TIMING-ONLY ablation (tools/bench_ablate_decode.py; results are garbage): leave out one launch class of the single-token decode layers to
     // measure what removing / hiding that launch could buy at most inside the real dependent chain
-    const unsigned ablate = (c == 1) ? ((flags >> LMRL_FWD_ABLATE_SHIFT) & 0x1ffu) : 0u;
+    const unsigned ablate = (c == 1) ? ((flags >> LMRL_FWD_ABLATE_SHIFT) & 0x3ffu) : 0u;
     // LMRL_ABLATE_PROJ_CONCURRENT (timing only, garbage results): the proj GEMM is launched on an auxiliary stream that waits for the qkv GEMM
     // only, i.e. it runs CONCURRENTLY with the attention launch on stale data — the most any attention -> proj overlap scheme could hide,
     // contention between the two launches included
@@ -1168,6 +1168,9 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
             } while (0)
             // 32 cached positions per batch of loads, 72 VGPRs -> 7 waves per SIMD (measured best of U = 4 / 6 / 8 / 10)
             if (pfx) LMRL_DEC_LAUNCH(4, true);
+            else if (ablate & LMRL_ABLATE_ATTN_HALF_BYTES)
+                hipLaunchKernelGGL((attention_decode_kernel<4, false, true>), dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, (const uint16_t *)w.qkv, kc, vc,
+                                   cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off, n_shared, append_in_attn, dp);
             else LMRL_DEC_LAUNCH(4, false);
 #undef LMRL_DEC_LAUNCH
         } else if (c == 1 && prof_kernel_events(PROF_ATTN_DECODE, -1.0, &ev_a, &ev_b)) {

@@ -27,7 +27,7 @@ g = torch.from_numpy(scripted_guesses(vocab.all_vocab, N + 1, 6, B, seed=1).view
 seeds = torch.arange((N + 1) * B, dtype=torch.int64, device=dev).view(N + 1, B)
 names = [("full episode", 0), ("proj via the aux stream, SERIAL (cost of one fork / join per layer)", 256), ("without decode qkv GEMM", 1), ("without decode attention", 2), ("without decode proj GEMM", 4),
          ("without decode fc GEMM", 8), ("without decode fc2 GEMM", 16), ("without proj + fc2", 20), ("without all five", 31),
-         ("proj CONCURRENT with attention (aux stream, stale data)", 32), ("fc2 over half of K only", 128),
+         ("proj CONCURRENT with attention (aux stream, stale data)", 32), ("fc2 over half of K only", 128), ("decode attention over HALF of the cached positions", 512),
          ("fc2 as two CONCURRENT half-K launches (split-K 2, no seam)", 64)]
 base = None
 n_dec = 30 * 12                                                   # decode layers per episode: 30 forwards x 12 layers
