@@ -347,6 +347,18 @@ class WordleRolloutEngine:
         return buf, ev
 
     def _build_interactions(self, handle, decode=None):
+        """Host lists of one episode batch.  The cyclic garbage collector is paused while the ~25 k tuples of a 1024-env batch are created: none
+        of them is garbage, and generation-2 scans of everything the caller already holds cost more than the construction itself."""
+        import gc
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            return self._build_interactions_nogc(handle, decode)
+        finally:
+            if was_enabled:
+                gc.enable()
+
+    def _build_interactions_nogc(self, handle, decode=None):
         from .environment import InteractionTransition, Text
         dec = decode or (lambda ids: "".join(self.tokens.strings.get(int(i), "") for i in ids))
         buf, ev = handle
