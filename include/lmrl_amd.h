@@ -389,7 +389,7 @@ int lmrl_sample_logits_steer(float *logits_d, int ld, int m, int vocab, const lm
  *   lmrl_chunk_begin_f32  pos[b*c + j] = len[b] + j for j < cnt[b]; padding slots get position 0 and token id 0
  *   lmrl_attn_cached_f32  one layer's attention for the c new tokens of every env: qkv_d fp32 [b*c][3*H*64]; kcache_d / vcache_d fp32
  *                         [b][tmax][H*64]; query j sees the cached positions [0, len[b]) and the chunk's tokens [0, j]; appends the new
- *                         K / V rows at len[b] + j; out_d fp32 [b*c][H*64] (padding slots untouched).  tmax <= 1024.
+ *                         K / V rows at len[b] + j; out_d fp32 [b*c][H*64] (padding slots untouched).
  *   lmrl_chunk_end_f32    last_d[b] = x_d[b*c + cnt[b] - 1] (envs with cnt == 0 keep theirs), then len[b] += cnt[b]
  * ------------------------------------------------------------------------------------------ */
 int lmrl_chunk_begin_f32(const int32_t *len_d, const int32_t *cnt_d, int32_t *ids_d, int32_t *pos_d, int b, int c, int n_pos, void *stream);
@@ -592,6 +592,10 @@ int lmrl_flash_attn_bwd_staged(const float *qkv_d, const uint8_t *key_mask_d, co
  * lmrl_cast_bf16: dst [rows_dst][ld_dst] bf16 := round-to-nearest-even of src [rows][cols] fp32 (transpose = 0) or of its transpose
  * (transpose = 1: dst[c][r] = src[r][c]); everything outside the source extent is zero-filled (K padding to multiples of 64). */
 int lmrl_cast_bf16(const float *src_d, long ld_src, int rows, int cols, void *dst_d, long ld_dst, int rows_dst, int transpose, void *stream);
+/* "bf16 x 3" operand of an fp32 matrix: dst [rows][ld_dst >= 3 cols] bf16 := [hi(x) | lo(x) | hi(x)], hi = bf16(x), lo = bf16(x - hi).  Against
+ * weight rows [hi(w) | hi(w) | lo(w)], lmrl_gemm_bf16 with K' = 3 cols accumulates hi.hi + lo.hi + hi.lo in fp32: ~16 mantissa bits per product at
+ * 3x the bf16 MFMA cost (the f32-input MFMA costs 16x) — the matmul mode "bf16x3" of the fp32 rollout engine (GPT2EngineF32). */
+int lmrl_split3_bf16(const float *src_d, long ld_src, int rows, int cols, void *dst_d, long ld_dst, void *stream);
 /* transposed cast (as lmrl_cast_bf16 with transpose = 1) that also produces colsum_d[c] (=|+=) sum_r src[r][c] — the bias gradient of a
  * Dense layer falls out of staging dy^T for the dW product instead of a second pass over dy.  ws_d: lmrl_cast_bf16_t_colsum_ws_bytes. */
 size_t lmrl_cast_bf16_t_colsum_ws_bytes(int rows, int rows_dst);

@@ -2,8 +2,8 @@
 //
 // The reference's default rollout arithmetic is float32 (llm_rl_scripts/wordle/bc/eval_bc_gpt2.py:34,69: bf16_activations=False ->
 // jnp.float32 params and activations; HF-Flax GPT-2 attention with `init_cache`).  The bf16 engine (csrc/gpt2.hip) is the throughput mode;
-// this kernel serves the parity mode in which EVERY sampled token is compared with the float64 oracle, so it is written for exactness
-// and clarity first: fp32 operands, fp32 accumulation, one wave per (env, head, new token).
+// this kernel serves the parity mode in which EVERY sampled token is compared with the float64 oracle: fp32 operands, fp32 accumulation,
+// one wave per (env, head, new token).
 //
 // Layout: per layer, kcache / vcache fp32 [B][tmax][H * 64] (token-major, as the bf16 cache); qkv fp32 [B * C][3 * H * 64] holds the C new
 // tokens' rows of env b at rows b * C .. b * C + cnt[b] - 1 (slots beyond cnt[b] are padding and are skipped).
@@ -16,17 +16,10 @@ namespace lmrl {
 
 constexpr int kDh = 64;
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
+// One wave per (env, head, new token).  A wave instruction covers 4 key positions x 256 contiguous bytes: lane l = (g = l >> 4: position slot,
+// c = l & 15: float4 column of the 64-float row), so K / V rows are read as coalesced 256-byte segments.  Scores: 4 fmaf per lane, summed over the
+// 16 lanes of a slot (xor 1, 2, 4, 8); online softmax per slot (running max / sum / rescaled output, as the bf16 decode kernel), the 4 slots
+// merged once at the end (xor 16, 32).  fp32 throughout.
 __global__ __launch_bounds__(256) void attn_cached_f32_kernel(const float *__restrict__ qkv, float *__restrict__ kcache, float *__restrict__ vcache,
                                                               const int32_t *__restrict__ len, const int32_t *__restrict__ cnt,
                                                               float *__restrict__ out, int B, int C, int H, int tmax) {
@@ -38,64 +31,49 @@ __global__ __launch_bounds__(256) void attn_cached_f32_kernel(const float *__res
     const int b = (int)(w / ((long)H * C));
     if (j >= cnt[b]) return;                                           // padding slot (wave-uniform)
     const int d = H * kDh, L = len[b];
+    const int g = lane >> 4, c = lane & 15;
     const float *row = qkv + ((size_t)b * C + j) * 3 * d;
-    const float *q = row + h * kDh;
+    const float4 q4 = *reinterpret_cast<const float4 *>(row + h * kDh + c * 4);
     // append this token's K / V rows (lane = dim: one coalesced 256-byte store each)
     const size_t crow = ((size_t)b * tmax + (L + j)) * d + h * kDh;
     kcache[crow + lane] = row[d + h * kDh + lane];
     vcache[crow + lane] = row[2 * d + h * kDh + lane];
-    // ---- scores: lane p handles positions p, p + 64, ... of the n = L + j + 1 visible keys
-    const int n = L + j + 1;
-    float qreg[kDh];
-#pragma unroll
-    for (int i = 0; i < kDh; i += 4) {
-        const float4 t = *reinterpret_cast<const float4 *>(q + i);
-        qreg[i] = t.x; qreg[i + 1] = t.y; qreg[i + 2] = t.z; qreg[i + 3] = t.w;
+    const int n = L + j + 1;                                           // visible keys: cached [0, L) + this chunk's tokens [0, j]
+    float m = -INFINITY, l = 0.f;
+    float4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int p0 = 0; p0 < n; p0 += 4) {                                // wave-uniform trip count
+        const int p = p0 + g;
+        const bool ok = p < n;
+        const int pc = ok ? p : n - 1;
+        const float *kr = pc < L ? kcache + ((size_t)b * tmax + pc) * d + h * kDh : qkv + ((size_t)b * C + (pc - L)) * 3 * d + d + h * kDh;
+        const float *vr = pc < L ? vcache + ((size_t)b * tmax + pc) * d + h * kDh : qkv + ((size_t)b * C + (pc - L)) * 3 * d + 2 * d + h * kDh;
+        const float4 k4 = *reinterpret_cast<const float4 *>(kr + c * 4);
+        const float4 v4 = *reinterpret_cast<const float4 *>(vr + c * 4);
+        float s = fmaf(q4.x, k4.x, fmaf(q4.y, k4.y, fmaf(q4.z, k4.z, q4.w * k4.w)));
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        s *= 0.125f;                                                    // 1 / sqrt(64)
+        const float m_new = ok ? fmaxf(m, s) : m;
+        const float alpha = (m == -INFINITY) ? 0.f : expf(m - m_new);
+        const float pr = ok ? expf(s - m_new) : 0.f;
+        l = l * alpha + pr;
+        o.x = fmaf(pr, v4.x, o.x * alpha); o.y = fmaf(pr, v4.y, o.y * alpha); o.z = fmaf(pr, v4.z, o.z * alpha); o.w = fmaf(pr, v4.w, o.w * alpha);
+        m = m_new;
     }
-    constexpr int kMaxIter = 16;                                        // up to 1024 visible positions
-    float sc[kMaxIter];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int it = 0; it < kMaxIter; it++) {
-        const int p = it * 64 + lane;
-        float s = -INFINITY;
-        if (it * 64 < n && p < n) {
-            const float *kr = p < L ? kcache + ((size_t)b * tmax + p) * d + h * kDh : qkv + ((size_t)b * C + (p - L)) * 3 * d + d + h * kDh;
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < kDh; i += 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(kr + i);
-                acc = fmaf(qreg[i], t.x, acc); acc = fmaf(qreg[i + 1], t.y, acc); acc = fmaf(qreg[i + 2], t.z, acc); acc = fmaf(qreg[i + 3], t.w, acc);
-            }
-            s = acc * 0.125f;                                           // 1 / sqrt(64)
-        }
-        sc[it] = s;
-        mx = fmaxf(mx, s);
+    // merge the 4 position slots
+    float mm = fmaxf(m, __shfl_xor(m, 16));
+    mm = fmaxf(mm, __shfl_xor(mm, 32));
+    const float wgt = (m == -INFINITY) ? 0.f : expf(m - mm);
+    float lt = l * wgt;
+    lt += __shfl_xor(lt, 16); lt += __shfl_xor(lt, 32);
+    float4 r = {o.x * wgt, o.y * wgt, o.z * wgt, o.w * wgt};
+    r.x += __shfl_xor(r.x, 16); r.x += __shfl_xor(r.x, 32);
+    r.y += __shfl_xor(r.y, 16); r.y += __shfl_xor(r.y, 32);
+    r.z += __shfl_xor(r.z, 16); r.z += __shfl_xor(r.z, 32);
+    r.w += __shfl_xor(r.w, 16); r.w += __shfl_xor(r.w, 32);
+    if (g == 0) {
+        const float inv = 1.f / lt;
+        *reinterpret_cast<float4 *>(out + ((size_t)b * C + j) * d + h * kDh + c * 4) = float4{r.x * inv, r.y * inv, r.z * inv, r.w * inv};
     }
-    mx = wave_max(mx);
-    float sum = 0.f;
-#pragma unroll
-    for (int it = 0; it < kMaxIter; it++) {
-        const float e = (sc[it] == -INFINITY) ? 0.f : expf(sc[it] - mx);
-        sc[it] = e;
-        sum += e;
-    }
-    sum = wave_sum(sum);
-    const float inv = 1.f / sum;
-    // ---- output: lane = dim; probabilities broadcast position by position
-    float o = 0.f;
-#pragma unroll
-    for (int it = 0; it < kMaxIter; it++) {
-        if (it * 64 >= n) break;                                        // wave-uniform
-        const int lim = min(64, n - it * 64);
-        for (int pl = 0; pl < lim; pl++) {
-            const float pr = __shfl(sc[it], pl);
-            const int p = it * 64 + pl;
-            const float *vr = p < L ? vcache + ((size_t)b * tmax + p) * d + h * kDh : qkv + ((size_t)b * C + (p - L)) * 3 * d + 2 * d + h * kDh;
-            o = fmaf(pr, vr[lane], o);
-        }
-    }
-    out[((size_t)b * C + j) * d + h * kDh + lane] = o * inv;
 }
 
 // last valid row of every env's chunk -> dst[b] (envs with cnt == 0 keep their previous row)
@@ -132,8 +110,8 @@ extern "C" {
 
 int lmrl_attn_cached_f32(const float *qkv_d, float *kcache_d, float *vcache_d, const int32_t *len_d, const int32_t *cnt_d, float *out_d, int b, int c,
                          int n_head, int tmax, void *stream) {
-    LMRL_REQUIRE(qkv_d && kcache_d && vcache_d && len_d && cnt_d && out_d && b > 0 && c > 0 && n_head > 0 && tmax > 0 && tmax <= 1024,
-                 "lmrl_attn_cached_f32: bad argument (tmax <= 1024)");
+    LMRL_REQUIRE(qkv_d && kcache_d && vcache_d && len_d && cnt_d && out_d && b > 0 && c > 0 && n_head > 0 && tmax > 0,
+                 "lmrl_attn_cached_f32: bad argument");
     const long waves = (long)b * c * n_head;
     hipLaunchKernelGGL(attn_cached_f32_kernel, dim3(ceil_div(waves, 4)), dim3(256), 0, as_stream(stream), qkv_d, kcache_d, vcache_d, len_d, cnt_d, out_d,
                        b, c, n_head, tmax);

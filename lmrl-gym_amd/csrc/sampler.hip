@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256) void topk_sample_kernel(const float *__restric
     __shared__ int red_i[4];
     uint32_t prefix = 0, remaining = (uint32_t)(top_k < vocab ? top_k : vocab);
     if (top_k <= 0) remaining = (uint32_t)vocab;
-    for (int pass = 0; pass < 4; pass++) {
+    const bool topk_on = top_k > 0 && top_k < vocab;        // block-uniform: without top-k the threshold below is 0 and the four select passes are skipped
+    for (int pass = 0; pass < (topk_on ? 4 : 0); pass++) {
         const int shift = 24 - 8 * pass;
         hist[tid] = 0;
         __syncthreads();

@@ -37,6 +37,35 @@ __global__ __launch_bounds__(128) void cast_bf16_kernel(const float *__restrict_
     }
 }
 
+// Three-term bf16 split of an fp32 operand for "bf16 x 3" products: x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi); the row
+// [hi(x) | lo(x) | hi(x)] (3 * cols bf16) against a weight row [hi(w) | hi(w) | lo(w)] makes ONE bf16 GEMM with K' = 3 K accumulate
+// hi.hi + lo.hi + hi.lo in fp32 — every term of x.w but lo.lo (2^-16 relative), i.e. ~16 mantissa bits at three times the bf16 MFMA cost instead
+// of the sixteen times of the f32-input MFMA.  One workgroup per row, 8 columns per lane and iteration (32 B in, 3 x 16 B out).
+__global__ __launch_bounds__(128) void split3_bf16_kernel(const float *__restrict__ src, long ld_src, int rows, int cols, uint16_t *__restrict__ dst,
+                                                          long ld_dst) {
+    const int r = blockIdx.x;
+    const float *p = src + (long)r * ld_src;
+    uint16_t *q = dst + (long)r * ld_dst;
+    for (int c0 = threadIdx.x * 8; c0 < cols; c0 += 128 * 8) {
+        const float4 a = *reinterpret_cast<const float4 *>(p + c0), b = *reinterpret_cast<const float4 *>(p + c0 + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        float lo[8];
+        uint4 hi;
+        hi.x = pack_bf16x2(v[0], v[1]); hi.y = pack_bf16x2(v[2], v[3]); hi.z = pack_bf16x2(v[4], v[5]); hi.w = pack_bf16x2(v[6], v[7]);
+        const uint32_t hw[4] = {hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            lo[2 * k] = v[2 * k] - __uint_as_float(hw[k] << 16);
+            lo[2 * k + 1] = v[2 * k + 1] - __uint_as_float(hw[k] & 0xffff0000u);
+        }
+        uint4 l;
+        l.x = pack_bf16x2(lo[0], lo[1]); l.y = pack_bf16x2(lo[2], lo[3]); l.z = pack_bf16x2(lo[4], lo[5]); l.w = pack_bf16x2(lo[6], lo[7]);
+        *reinterpret_cast<uint4 *>(q + c0) = hi;
+        *reinterpret_cast<uint4 *>(q + cols + c0) = l;
+        *reinterpret_cast<uint4 *>(q + 2 * cols + c0) = hi;
+    }
+}
+
 // dst[c][r] = bf16(src[r][c]) for r < rows, c < cols; zero elsewhere in [rows_dst][ld_dst].  64 x 64 tiles through LDS: coalesced 256-B
 // reads along c, 128-B writes along r.
 __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float *__restrict__ src, long ld_src, int rows, int cols, uint16_t *__restrict__ dst,
@@ -224,6 +253,14 @@ int lmrl_cast_bf16(const float *src_d, long ld_src, int rows, int cols, void *ds
         hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((int)((ld_dst + 63) / 64), (rows_dst + 63) / 64), dim3(256), 0, s, src_d, ld_src, rows, cols,
                            (uint16_t *)dst_d, ld_dst, rows_dst, (float *)nullptr);
     }
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_split3_bf16(const float *src_d, long ld_src, int rows, int cols, void *dst_d, long ld_dst, void *stream) {
+    LMRL_REQUIRE(src_d && dst_d && rows > 0 && cols > 0 && cols % 8 == 0 && ld_src % 4 == 0 && ld_dst % 8 == 0 && ld_dst >= 3L * cols &&
+                 ((reinterpret_cast<uintptr_t>(src_d) & 15) == 0), "lmrl_split3_bf16: bad argument (cols % 8, 16-byte aligned rows, ld_dst >= 3 cols)");
+    hipLaunchKernelGGL(split3_bf16_kernel, dim3(rows), dim3(128), 0, as_stream(stream), src_d, ld_src, rows, cols, (uint16_t *)dst_d, ld_dst);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

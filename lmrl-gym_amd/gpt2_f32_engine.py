@@ -24,8 +24,15 @@ from .train import ops
 
 
 class GPT2EngineF32:
-    def __init__(self, cfg: GPT2Config, state_dict: Dict[str, "torch.Tensor"], device=None):
+    def __init__(self, cfg: GPT2Config, state_dict: Dict[str, "torch.Tensor"], device=None, matmul: str = "f32"):
+        """matmul = "f32": every product on the f32-input MFMA (exact fp32, 157 TFLOP/s peak).
+        matmul = "bf16x3": every Dense / LM-head product as ONE bf16 GEMM over K' = 3 K on three-term splits of the fp32 operands
+        (activations [hi | lo | hi] by `lmrl_split3_bf16`, weights [hi | hi | lo] staged here): hi.hi + lo.hi + hi.lo accumulated in fp32, i.e.
+        ~16 mantissa bits per product (more than the TF32 products XLA uses by default for float32 matmuls on GPUs) at 3/16 of the f32 MFMA's
+        cost.  LayerNorm, gelu, the residual stream, the K/V cache and the attention stay fp32 in both modes."""
         import torch
+        assert matmul in ("f32", "bf16x3")
+        self.matmul = matmul
         self.cfg = cfg
         self.device = device or _lib.require_gpu()
         self._L = _lib.lib()
@@ -39,10 +46,29 @@ class GPT2EngineF32:
         names = ("ln_1.weight", "ln_1.bias", "attn.c_attn.weight", "attn.c_attn.bias", "attn.c_proj.weight", "attn.c_proj.bias",
                  "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias")
         self.layers = [{n: f32(sd[f"h.{l}.{n}"]) for n in names} for l in range(cfg.n_layer)]     # Conv1D kernels stay [in][out]
+        if matmul == "bf16x3":
+            def x3(w_out_in):        # fp32 [out][in] -> bf16 [out][3 in] = [hi | hi | lo]
+                hi = w_out_in.to(torch.bfloat16)
+                lo = (w_out_in - hi.float()).to(torch.bfloat16)
+                return torch.cat([hi, hi, lo], dim=1).contiguous()
+            for p in self.layers:
+                for n in ("attn.c_attn.weight", "attn.c_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight"):
+                    p[n + ".x3"] = x3(p[n].t().contiguous())
+            self.wte_x3 = x3(self.wte)
+
+    def linear(self, x, rows, k, n, w_name, p, y, scratch):
+        """y[rows][n] = x[rows][k] @ W + b for a layer's Dense `w_name` in this engine's matmul mode (`scratch`: bf16 [rows][3 k] split buffer)."""
+        if self.matmul == "f32":
+            ops.sgemm(x, p[w_name + ".weight"], y, rows, n, k, lda=k, ldb=n, ldc=n, bias=p[w_name + ".bias"])
+            return
+        L = self._L
+        _lib.check(L.lmrl_split3_bf16(x.data_ptr(), k, rows, k, scratch.data_ptr(), 3 * k, _lib.stream_ptr()), "lmrl_split3_bf16")
+        _lib.check(L.lmrl_gemm_bf16(scratch.data_ptr(), p[w_name + ".weight.x3"].data_ptr(), p[w_name + ".bias"].data_ptr(), y.data_ptr(), rows, n, 3 * k, 3 * k,
+                                    n, n, 3, _lib.stream_ptr()), "lmrl_gemm_bf16 (bf16x3)")
 
     @classmethod
-    def random_init(cls, cfg: GPT2Config, seed: int = 0, device=None) -> "GPT2EngineF32":
-        return cls(cfg, init_hf_style_state_dict(cfg, seed), device)
+    def random_init(cls, cfg: GPT2Config, seed: int = 0, device=None, matmul: str = "f32") -> "GPT2EngineF32":
+        return cls(cfg, init_hf_style_state_dict(cfg, seed), device, matmul=matmul)
 
     def session(self, batch: int, tmax: int, flags: int = 0) -> "KVSessionF32":
         return KVSessionF32(self, batch, tmax)
@@ -56,7 +82,6 @@ class KVSessionF32:
         t = torch
         self.eng, self.B, self.tmax, self.flags = eng, batch, tmax, 0
         c, dev = eng.cfg, eng.device
-        assert tmax <= 1024
         self.kv = t.zeros(c.n_layer, 2, batch, tmax, c.d_model, dtype=t.float32, device=dev)
         self.len = t.zeros(batch, dtype=t.int32, device=dev)
         self.last_hidden = t.zeros(batch, c.d_model, dtype=t.float32, device=dev)      # ln_f of each env's last token
@@ -74,7 +99,8 @@ class KVSessionF32:
             c, R, dev = self.eng.cfg, self.B * C, self.eng.device
             f = lambda *s: t.empty(*s, dtype=t.float32, device=dev)
             self._ws[C] = dict(ids=t.zeros(R, dtype=t.int32, device=dev), pos=t.zeros(R, dtype=t.int32, device=dev), x=f(R, c.d_model), h=f(R, c.d_model),
-                               qkv=f(R, 3 * c.d_model), att=f(R, c.d_model), ff=f(R, c.d_ff), mean=f(R), rstd=f(R))
+                               qkv=f(R, 3 * c.d_model), att=f(R, c.d_model), ff=f(R, c.d_ff), mean=f(R), rstd=f(R),
+                               split=t.empty(R * 3 * c.d_ff, dtype=t.bfloat16, device=dev) if self.eng.matmul == "bf16x3" else None)
         return self._ws[C]
 
     def reset(self):
@@ -96,16 +122,16 @@ class KVSessionF32:
         ops.embed_fwd(e.wte, e.wpe, w["ids"], w["pos"], x, R, d)
         for l, p in enumerate(e.layers):
             ops.layernorm_fwd(x, p["ln_1.weight"], p["ln_1.bias"], h, w["mean"], w["rstd"], R, d, c.ln_eps)
-            ops.sgemm(h, p["attn.c_attn.weight"], qkv, R, 3 * d, d, lda=d, ldb=3 * d, ldc=3 * d, bias=p["attn.c_attn.bias"])
+            e.linear(h, R, d, 3 * d, "attn.c_attn", p, qkv, w["split"])
             _lib.check(L.lmrl_attn_cached_f32(_lib.ptr(qkv), _lib.ptr(self.kv[l, 0]), _lib.ptr(self.kv[l, 1]), _lib.ptr(self.len), _lib.ptr(cnt),
                                               _lib.ptr(att), B, C, c.n_head, self.tmax, sp), "lmrl_attn_cached_f32")
             # x += att . Wproj + b   (bias through a beta = 1 accumulate: h = att.W + b, then x += h)
-            ops.sgemm(att, p["attn.c_proj.weight"], h, R, d, d, lda=d, ldb=d, ldc=d, bias=p["attn.c_proj.bias"])
+            e.linear(att, R, d, d, "attn.c_proj", p, h, w["split"])
             ops.axpby(1.0, h, 1.0, x, x)
             ops.layernorm_fwd(x, p["ln_2.weight"], p["ln_2.bias"], h, w["mean"], w["rstd"], R, d, c.ln_eps)
-            ops.sgemm(h, p["mlp.c_fc.weight"], ff, R, c.d_ff, d, lda=d, ldb=c.d_ff, ldc=c.d_ff, bias=p["mlp.c_fc.bias"])
+            e.linear(h, R, d, c.d_ff, "mlp.c_fc", p, ff, w["split"])
             ops.gelu_fwd(ff, ff)
-            ops.sgemm(ff, p["mlp.c_proj.weight"], h, R, d, c.d_ff, lda=c.d_ff, ldb=d, ldc=d, bias=p["mlp.c_proj.bias"])
+            e.linear(ff, R, c.d_ff, d, "mlp.c_proj", p, h, w["split"])
             ops.axpby(1.0, h, 1.0, x, x)
         if all_hidden is not None:
             ops.layernorm_fwd(x, e.lnf_g, e.lnf_b, all_hidden, w["mean"], w["rstd"], R, d, c.ln_eps)
@@ -124,9 +150,17 @@ class KVSessionF32:
 
     def lm_logits(self, hidden=None):
         """logits fp32 [B][vocab_padded] = hidden . wte^T (tied LM head) into self.logits."""
-        c = self.eng.cfg
+        c, e = self.eng.cfg, self.eng
         h = self.last_hidden if hidden is None else hidden
-        ops.sgemm(h, self.eng.wte, self.logits, self.B, c.vocab_padded, c.d_model, trans_b=True, lda=c.d_model, ldb=c.d_model, ldc=c.vocab_padded)
+        if e.matmul == "f32":
+            ops.sgemm(h, e.wte, self.logits, self.B, c.vocab_padded, c.d_model, trans_b=True, lda=c.d_model, ldb=c.d_model, ldc=c.vocab_padded)
+        else:
+            import torch
+            if getattr(self, "_lm_split", None) is None:
+                self._lm_split = torch.empty(self.B * 3 * c.d_model, dtype=torch.bfloat16, device=e.device)
+            _lib.check(e._L.lmrl_split3_bf16(h.data_ptr(), c.d_model, self.B, c.d_model, self._lm_split.data_ptr(), 3 * c.d_model, _lib.stream_ptr()), "lmrl_split3_bf16")
+            _lib.check(e._L.lmrl_gemm_bf16(self._lm_split.data_ptr(), e.wte_x3.data_ptr(), None, self.logits.data_ptr(), self.B, c.vocab_padded, 3 * c.d_model,
+                                           3 * c.d_model, c.vocab_padded, c.vocab_padded, 3, _lib.stream_ptr()), "lmrl_gemm_bf16 (bf16x3 LM head)")
         return self.logits
 
     def sample(self, params: SampleParams, steer_tok=None, active=None, hidden=None, logits_out=None, q1=None, q2=None, want_logprob: bool = True):

@@ -210,7 +210,7 @@ def test_bench_gpus_2_spawns_two_ranks_and_reports_the_train_step():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["envs_per_gpu"] == 64
     assert out["config"]["env_steps_timed"] >= 2 * 64            # both ranks' env steps are summed
-    assert out["fp32_mode"]["value"] > 0 and out["host_materialise_ms"] > 0
+    assert out["fp32_mode"]["value"] > 0 and out["bf16x3_mode"]["value"] > 0 and out["host_materialise_ms"] > 0
     ts = out["train_step"]
     for k in ("ilql_f32", "ilql_bf16"):
         assert ts[k]["ms_per_step"] > 0 and np.isfinite(ts[k]["last_loss"])

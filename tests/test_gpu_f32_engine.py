@@ -7,7 +7,9 @@ actions within fp32 tolerance.  Here, with fp32 weights / activations / K-V cach
     re-derived from the float64 oracle's logits and the reference's own random stream (`jax.random.categorical` under the per-turn /
     per-token key splits, oracle/jax_random.py), together with the env replay on the oracle env.
 Tolerance on a draw: the device's perturbed scores carry fp32 rounding (logits ~1e-5, float log a few ulp); a draw is compared unless the
-oracle's top-2 perturbed scores are closer than 2e-4 — such draws must be rare (< 0.5 %) and every other draw must match exactly."""
+oracle's top-2 perturbed scores are closer than 2e-4 — such draws must be rare (< 0.5 %) and every other draw must match exactly.
+The same two tests run on the engine's "bf16x3" matmul mode (three-term bf16 splits: ~16 mantissa bits per product, 3x the bf16 MFMA cost
+instead of 16x): hidden states within 3e-4, every draw whose top-2 gap exceeds 3e-3 identical (near-ties < 3 % of the draws)."""
 import numpy as np
 import pytest
 
@@ -23,7 +25,8 @@ def dev():
     return _lib.require_gpu()
 
 
-def test_f32_engine_hidden_states_and_cache_vs_float64(dev):
+@pytest.mark.parametrize("matmul,tol", [("f32", 2e-5), ("bf16x3", 3e-4)])
+def test_f32_engine_hidden_states_and_cache_vs_float64(dev, matmul, tol):
     """Prefill in 16-token chunks with ragged per-env lengths, then single-token decode steps: last hidden state / logits of every env after
     every forward == the float64 oracle on the env's full token prefix, at fp32 tolerance."""
     from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
@@ -34,7 +37,7 @@ def test_f32_engine_hidden_states_and_cache_vs_float64(dev):
     g = torch.Generator().manual_seed(4)
     for k in sd:
         sd[k] = sd[k] * 3 + (0.1 * torch.randn(sd[k].shape, generator=g) if sd[k].dim() == 1 else 0)
-    eng = GPT2EngineF32(cfg, sd, dev)
+    eng = GPT2EngineF32(cfg, sd, dev, matmul=matmul)       # "bf16x3": three-term bf16 splits of the fp32 operands, ~16 mantissa bits per product
     B = 9
     ses = eng.session(B, 96)
     ses.reset()
@@ -57,8 +60,8 @@ def test_f32_engine_hidden_states_and_cache_vs_float64(dev):
                 continue
             ref_lg, ref_h = O.forward(sd, torch.tensor([seqs[b]]), cfg.n_head, return_hidden=True)
             ref_h, ref_lg = ref_h[0, -1].numpy(), ref_lg[0, -1].numpy()
-            assert np.abs(hid[b] - ref_h).max() <= 2e-5 * max(1.0, np.abs(ref_h).max()), (b, np.abs(hid[b] - ref_h).max())
-            assert np.abs(lg[b] - ref_lg).max() <= 2e-5 * max(1.0, np.abs(ref_lg).max()), (b, np.abs(lg[b] - ref_lg).max())
+            assert np.abs(hid[b] - ref_h).max() <= tol * max(1.0, np.abs(ref_h).max()), (b, np.abs(hid[b] - ref_h).max())
+            assert np.abs(lg[b] - ref_lg).max() <= tol * max(1.0, np.abs(ref_lg).max()), (b, np.abs(lg[b] - ref_lg).max())
     step(16, [16, 16, 5, 16, 1, 16, 9, 16, 16])
     step(16, [16, 3, 0, 16, 0, 7, 16, 1, 16])
     step(8, [8, 8, 8, 2, 8, 0, 8, 8, 8])
@@ -77,7 +80,8 @@ def test_f32_engine_hidden_states_and_cache_vs_float64(dev):
     assert torch.equal(sa.len, sb.len) and torch.equal(sa.last_hidden, sb.last_hidden) and torch.equal(sa.kv[:, :, :, :5], sb.kv[:, :, :, :5])
 
 
-def test_f32_rollout_every_sampled_token_equals_float64_oracle_with_jax_stream(dev):
+@pytest.mark.parametrize("matmul,tie", [("f32", 2e-4), ("bf16x3", 3e-3)])
+def test_f32_rollout_every_sampled_token_equals_float64_oracle_with_jax_stream(dev, matmul, tie):
     from lmrl_gym_amd import jax_prng as JP
     from lmrl_gym_amd.envs import wordle as W
     from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
@@ -87,7 +91,7 @@ def test_f32_rollout_every_sampled_token_equals_float64_oracle_with_jax_stream(d
     from oracle.wordle import OracleWordleEnv
     cfg = GPT2Config.gpt2_small()
     sd = init_hf_style_state_dict(cfg, seed=0)               # the bench's weights, NOT rounded to bf16: this engine keeps fp32
-    eng = GPT2EngineF32(cfg, sd, dev)
+    eng = GPT2EngineF32(cfg, sd, dev, matmul=matmul)
     vocab = W.Vocabulary.builtin("wordle_official_400.txt")
     words = vocab.all_vocab
     B, STEER, SEED = 64, 12.5, 2024      # +12.5 on the scripted token: it wins ~3 draws in 4 (e^12.5 against ~50 k logits of unit scale)
@@ -156,10 +160,10 @@ def test_f32_rollout_every_sampled_token_equals_float64_oracle_with_jax_stream(d
                 z[st] += STEER
                 score = z + noise[b]
                 top2 = np.partition(score, -2)[-2:]
-                if top2[1] - top2[0] < 2e-4:
+                if top2[1] - top2[0] < tie:
                     near_tie += 1
                     continue
                 checked += 1
                 assert int(score.argmax()) == int(trajs[b][0][start + k]), (turn, k, b)
-    assert checked > 1200 and near_tie <= 0.005 * (checked + near_tie), (checked, near_tie)
+    assert checked > 1200 and near_tie <= (0.005 if matmul == "f32" else 0.03) * (checked + near_tie), (checked, near_tie)
     ro.close()

@@ -10,7 +10,8 @@ from lmrl_gym_amd.gpt2_f32_engine import GPT2EngineF32
 from lmrl_gym_amd.rollout import WordleRolloutEngine
 from bench import scripted_guesses
 dev = _lib.require_gpu()
-eng = GPT2EngineF32.random_init(GPT2Config.gpt2_small(), seed=0, device=dev)
+MM = os.environ.get("MATMUL", "f32")
+eng = GPT2EngineF32.random_init(GPT2Config.gpt2_small(), seed=0, device=dev, matmul=MM)
 vocab = W.Vocabulary.builtin("wordle_official_400.txt")
 B = 1024
 ro = WordleRolloutEngine(eng, vocab, B, max_new_tokens=6)
@@ -23,4 +24,4 @@ for i in (1, 2):
     ro.run_episode(seeds[i], scripted_guesses=g[i], steer_strength=30.0)
     n += int(ro.traj["n_steps"].sum())
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(f"fp32 rollout: {n / dt:.0f} env-steps/s, {dt / 2 * 1e3:.1f} ms per episode")
+print(f"{MM} rollout: {n / dt:.0f} env-steps/s, {dt / 2 * 1e3:.1f} ms per episode")
