@@ -318,6 +318,20 @@ int lmrl_gemm_bf16_ld(const void *a_d, const void *w_d, const float *bias_d, voi
 int lmrl_gemm_bf16_resid(const void *a_d, const void *w_d, const float *bias_d, const float *resid_d, int ldr, float *c_d, int m, int n, int k, int lda,
                          int ldw, int ldc, int n_store, void *stream);
 
+/* Train step, bf16-matmul mode: Dense products whose epilogue writes the NEXT kernel's bf16 operand, so that no stand-alone elementwise pass
+ * re-reads an [B*T][n] fp32 tensor (n a multiple of 128, k of 64; a, w as for lmrl_gemm_bf16_ld).  The HF GPT-2 block the reference differentiates
+ * (ppo/gpt2/interface.py:111-133, ilql/gpt2/interface.py:139-177):
+ *   gelu_dual : c fp32 [m][ldc] = a . w^T + bias (mlp.c_fc pre-activation, read again by the backward) AND act bf16 [m][ldact] = gelu_new(c)
+ *   qkv_heads : attn.c_attn straight into the flash kernels' per-head bf16 matrices q | k | v = [3][batch*heads][pad64(t)][64] (plane_elems
+ *               apart, from lmrl_flash_attn_stage_ptrs), q scaled by 1/8; follow with lmrl_flash_attn_finish_staging; m = batch * t rows
+ *   gelu_bwd  : c bf16 [m][ldc] = (a . w^T) * gelu_new'(pre[m][n]) — d(pre-activation) of mlp.c_fc as the bf16 dy operand of its backward products */
+int lmrl_gemm_bf16_gelu_dual(const void *a_d, const void *w_d, const float *bias_d, float *c_d, int ldc, void *act_bf16_d, int ldact, int m, int n, int k,
+                             int lda, int ldw, void *stream);
+int lmrl_gemm_bf16_qkv_heads(const void *a_d, const void *w_d, const float *bias_d, void *q_heads_d, long plane_elems, int m, int k, int lda, int ldw,
+                             int heads, int t, void *stream);
+int lmrl_gemm_bf16_gelu_bwd(const void *a_d, const void *w_d, const float *pre_d, int ldpre, void *c_bf16_d, int ldc, int m, int n, int k, int lda,
+                            int ldw, void *stream);
+
 /* Split-K form for products with few output tiles and a long K (the train step's weight-gradient products dW = x^T . dy: K = B*T):
  * S copies of the 128 x 128 tile grid each accumulate a slice of K into fp32 partials in ws_d, a fixed-order reduce then writes
  * c (=|+=) their sum — deterministic.  lmrl_gemm_bf16_splitk_ws_bytes returns 0 when the shape is better served by lmrl_gemm_bf16_ld. */
@@ -581,6 +595,11 @@ int lmrl_flash_attn_fwd(const float *qkv_d, const uint8_t *key_mask_d, float *at
 /* forward that also writes the bf16 copy of att (row pitch ldb elements): the operand of the output projection in the bf16-matmul train mode */
 int lmrl_flash_attn_fwd_staged(const float *qkv_d, const uint8_t *key_mask_d, float *att_d, float *lse_d, void *ws_d, void *att_bf16_d, long ldb, int batch,
                                int heads, int t, int bf16, void *stream);
+/* bf16 workspace: where lmrl_gemm_bf16_qkv_heads writes (q matrix; k and v follow plane_elems apart); lmrl_flash_attn_finish_staging then adds the
+ * transposed forms and zeroes the padded token rows, after which lmrl_flash_attn_fwd_staged(qkv_d = NULL, ...) and
+ * lmrl_flash_attn_bwd_staged(qkv_d = NULL, ..., qkv_staged = 1) run on ws_d as if they had staged it themselves. */
+int lmrl_flash_attn_stage_ptrs(void *ws_d, int batch, int heads, int t, void **q_heads_out, long *plane_elems_out);
+int lmrl_flash_attn_finish_staging(void *ws_d, int batch, int heads, int t, void *stream);
 int lmrl_flash_attn_bwd(const float *qkv_d, const uint8_t *key_mask_d, const float *att_d, const float *datt_d, const float *lse_d, float *dqkv_d,
                         void *ws_d, int batch, int heads, int t, int bf16,
                         int qkv_staged /* ws_d still holds what lmrl_flash_attn_fwd staged from these qkv: skip the re-staging */, void *stream);

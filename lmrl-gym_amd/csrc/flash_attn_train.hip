@@ -193,6 +193,36 @@ __global__ __launch_bounds__(256) void flash_stage_kernel(const float *__restric
     }
 }
 
+// bf16 only: the q / k / v matrices were written in their natural per-head form [3][BH][Tp][64] by the c_attn GEMM's epilogue
+// (gemm8_bf16.h EPI_BF16_HEADS: no fp32 qkv tensor exists); this pass adds the transposed forms [3][BH][64][Tp] and zeroes the rows t >= T of
+// both (the GEMM stores token rows only).  One workgroup per (64 tokens, head, matrix); 8 elements per lane both ways.
+__global__ __launch_bounds__(256) void flash_transpose_staged_kernel(uint16_t *__restrict__ Xn0, uint16_t *__restrict__ XT0, long plane, int T, int Tp) {
+    __shared__ uint32_t tile[64][65];          // one element per dword, odd pitch: both passes are conflict-free (bank = row + column)
+    const int t0 = blockIdx.x * 64, bh = blockIdx.y;
+    uint16_t *Xn = Xn0 + blockIdx.z * plane + ((long)bh * Tp + t0) * 64;
+    uint16_t *XT = XT0 + blockIdx.z * plane + (long)bh * 64 * Tp + t0;
+    const int c8 = (threadIdx.x & 7) * 8, rr = threadIdx.x >> 3;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int r = rr + 32 * k;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (t0 + r < T) v = *reinterpret_cast<const uint4 *>(Xn + (long)r * 64 + c8);
+        else *reinterpret_cast<uint4 *>(Xn + (long)r * 64 + c8) = v;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) { tile[r][c8 + 2 * e] = w[e] & 0xffffu; tile[r][c8 + 2 * e + 1] = w[e] >> 16; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int r = rr + 32 * k;             // head dimension
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) w[e] = tile[c8 + 2 * e][r] | (tile[c8 + 2 * e + 1][r] << 16);
+        *reinterpret_cast<uint4 *>(XT + (long)r * Tp + c8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ forward
 template <class E, bool PF>
 __global__ __launch_bounds__(256) void flash_fwd_kernel(const typename E::T *__restrict__ Qn, const typename E::T *__restrict__ Kn,
@@ -592,8 +622,10 @@ static int flash_fwd(const float *qkv, const uint8_t *km, float *att, float *lse
     typedef typename E::T T;
     const int tp = (t + 63) / 64 * 64, bh = batch * heads, d = heads * 64;
     FlashWs w; w.carve(ws, bh, tp, E::SZ);
-    int rc = flash_stage_qkv<E>(qkv, w, batch, heads, t, tp, s);
-    if (rc) return rc;
+    if (qkv) {             // null: the six q / k / v matrices are already staged in ws (lmrl_gemm_bf16_qkv_heads + lmrl_flash_attn_finish_staging)
+        int rc = flash_stage_qkv<E>(qkv, w, batch, heads, t, tp, s);
+        if (rc) return rc;
+    }
     const size_t lds = 2 * E::TILE + 64;
     constexpr bool PF = FlashPrefetch<E>::fwd;
     LMRL_CHECK_HIP(allow_lds(flash_fwd_kernel<E, PF>, lds));
@@ -638,6 +670,25 @@ size_t lmrl_flash_attn_ws_bytes(int batch, int heads, int t, int bf16) {
 }
 size_t lmrl_flash_attn_lse_bytes(int batch, int heads, int t) { return (size_t)batch * heads * ((t + 63) / 64 * 64) * sizeof(float); }
 
+int lmrl_flash_attn_stage_ptrs(void *ws_d, int batch, int heads, int t, void **q_heads_out, long *plane_elems_out) {
+    LMRL_REQUIRE(ws_d && q_heads_out && plane_elems_out && batch > 0 && heads > 0 && t > 0, "lmrl_flash_attn_stage_ptrs: bad argument");
+    const int tp = (t + 63) / 64 * 64;
+    FlashWs w; w.carve(ws_d, batch * heads, tp, 2);
+    *q_heads_out = w.Qn;
+    *plane_elems_out = (long)(FlashWs::mat_bytes(batch * heads, tp, 2) / 2);
+    return LMRL_OK;
+}
+
+int lmrl_flash_attn_finish_staging(void *ws_d, int batch, int heads, int t, void *stream) {
+    LMRL_REQUIRE(ws_d && batch > 0 && heads > 0 && t > 0, "lmrl_flash_attn_finish_staging: bad argument");
+    const int tp = (t + 63) / 64 * 64, bh = batch * heads;
+    FlashWs w; w.carve(ws_d, bh, tp, 2);
+    hipLaunchKernelGGL(flash_transpose_staged_kernel, dim3(tp / 64, bh, 3), dim3(256), 0, as_stream(stream), (uint16_t *)w.Qn, (uint16_t *)w.QT,
+                       (long)(FlashWs::mat_bytes(bh, tp, 2) / 2), t, tp);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
 int lmrl_flash_attn_fwd(const float *qkv_d, const uint8_t *key_mask_d, float *att_d, float *lse_d, void *ws_d, int batch, int heads, int t, int bf16,
                         void *stream) {
     LMRL_REQUIRE(qkv_d && att_d && lse_d && ws_d && batch > 0 && heads > 0 && t > 0, "lmrl_flash_attn_fwd: bad argument");
@@ -647,8 +698,8 @@ int lmrl_flash_attn_fwd(const float *qkv_d, const uint8_t *key_mask_d, float *at
 
 int lmrl_flash_attn_fwd_staged(const float *qkv_d, const uint8_t *key_mask_d, float *att_d, float *lse_d, void *ws_d, void *att_bf16_d, long ldb, int batch,
                                int heads, int t, int bf16, void *stream) {
-    LMRL_REQUIRE(qkv_d && att_d && lse_d && ws_d && att_bf16_d && ldb >= heads * 64 && ldb % 4 == 0 && batch > 0 && heads > 0 && t > 0,
-                 "lmrl_flash_attn_fwd_staged: bad argument");
+    LMRL_REQUIRE((qkv_d || bf16) && att_d && lse_d && ws_d && att_bf16_d && ldb >= heads * 64 && ldb % 4 == 0 && batch > 0 && heads > 0 && t > 0,
+                 "lmrl_flash_attn_fwd_staged: bad argument");       // qkv_d null (bf16): q / k / v already staged in ws_d by the c_attn GEMM
     return bf16 ? flash_fwd<ElemBF16>(qkv_d, key_mask_d, att_d, lse_d, ws_d, batch, heads, t, as_stream(stream), att_bf16_d, ldb)
                 : flash_fwd<ElemF32>(qkv_d, key_mask_d, att_d, lse_d, ws_d, batch, heads, t, as_stream(stream), att_bf16_d, ldb);
 }
@@ -662,8 +713,8 @@ int lmrl_flash_attn_bwd(const float *qkv_d, const uint8_t *key_mask_d, const flo
 
 int lmrl_flash_attn_bwd_staged(const float *qkv_d, const uint8_t *key_mask_d, const float *att_d, const float *datt_d, const float *lse_d,
                                void *dqkv_bf16_d, long ldb, void *ws_d, int batch, int heads, int t, int qkv_staged, void *stream) {
-    LMRL_REQUIRE(qkv_d && att_d && datt_d && lse_d && dqkv_bf16_d && ws_d && ldb >= 3 * heads * 64 && ldb % 4 == 0 && batch > 0 && heads > 0 && t > 0,
-                 "lmrl_flash_attn_bwd_staged: bad argument");
+    LMRL_REQUIRE((qkv_d || qkv_staged) && att_d && datt_d && lse_d && dqkv_bf16_d && ws_d && ldb >= 3 * heads * 64 && ldb % 4 == 0 && batch > 0 &&
+                     heads > 0 && t > 0, "lmrl_flash_attn_bwd_staged: bad argument");
     return flash_bwd<ElemBF16>(qkv_d, key_mask_d, att_d, datt_d, lse_d, nullptr, (uint16_t *)dqkv_bf16_d, ldb, ws_d, batch, heads, t, as_stream(stream),
                                qkv_staged);
 }

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
     LMRL_G8_STAMP(2);
 
     // ---- epilogues (same arithmetic as gemm_bf16_glds_kernel; a lane holds C[m][n..n+3], n = n0 + wn*TN + 16 i + 4 lq, m = m0 + wm*TM + 16 j + lr)
-    if (EPI == EPI_RESID_F32_STATS) {
+    if constexpr (EPI == EPI_RESID_F32_STATS) {
         // x += acc + bias ; xb = bf16(x) ; the wave's TN columns are TN/32 stat slots of the row: slot s holds (sum x, sum x^2) of columns
         // [32 s, 32 s + 32).  A fragment i covers 16 columns: slot = (n0 + wn*TN + 16 i) / 32, two fragments per slot.
         static_assert(TN % 32 == 0, "stat slots are 32 columns wide");
@@ -361,7 +361,38 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
         return;
     }
 
-    constexpr bool BF16_OUT = (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || LN_IN);
+    if constexpr (EPI == EPI_F32_GELU_BF16) {
+        // train forward, c_fc: the fp32 pre-activation (the gelu backward reads it) and the bf16 gelu output (the c_proj operand and, transposed,
+        // the operand of its dW product) from one accumulator pass — no stand-alone gelu launch re-reading [M][N] floats
+        static_assert(FN % 2 == 0, "fragment pairs");
+#pragma unroll
+        for (int i = 0; i < FN; i += 2) {
+            const int nA = n0 + wn * TN + i * 16 + lq * 4, nB = nA + 16;
+            f32x4 bA = f32x4{0.f, 0.f, 0.f, 0.f}, bB = bA;
+            if (g.bias) { bA = *reinterpret_cast<const f32x4 *>(g.bias + nA); bB = *reinterpret_cast<const f32x4 *>(g.bias + nB); }
+            const int n_st = n0 + wn * TN + (i + (lq & 1)) * 16 + (lq >> 1) * 8;
+#pragma unroll
+            for (int j = 0; j < FM; j++) {
+                const int m = m0 + wm * TM + j * 16 + lr;
+                f32x4 vA = acc[i][j] + bA, vB = acc[i + 1][j] + bB;
+                if (m < Mr && nA < g.n_store) *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + nA) = vA;
+                if (m < Mr && nB < g.n_store) *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + nB) = vB;
+#pragma unroll
+                for (int r = 0; r < 4; r++) { vA[r] = gelu_new(vA[r]); vB[r] = gelu_new(vB[r]); }
+                uint32_t a0 = pack_bf16x2(vA[0], vA[1]), a1 = pack_bf16x2(vA[2], vA[3]);
+                uint32_t b0 = pack_bf16x2(vB[0], vB[1]), b1 = pack_bf16x2(vB[2], vB[3]);
+                auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                if (m < Mr && n_st < g.n_store) *reinterpret_cast<u32x4 *>(g.xb + (size_t)m * g.ldxb + n_st) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LMRL_G8_STAMP(3);
+        return;
+    }
+
+    constexpr bool BF16_OUT = (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || LN_IN || EPI == EPI_BF16_HEADS || EPI == EPI_GELU_BWD_BF16);
+    static_assert(!(EPI == EPI_BF16_HEADS || EPI == EPI_GELU_BWD_BF16) || FN % 2 == 0, "the train-step bf16 epilogues store fragment pairs");
     if (BF16_OUT && (FN % 2 == 0)) {
         // bf16 outputs, fragment pairs (i, i+1): a lane holds columns [16i + 4lq, +4) of both; v_permlane16_swap (odd 16-lane rows of the
         // first operand <-> even rows of the second) regroups them so that every lane owns 8 CONSECUTIVE columns (16 B) of one fragment:
@@ -374,12 +405,35 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
             if (g.bias) { bA = *reinterpret_cast<const f32x4 *>(g.bias + nA); bB = *reinterpret_cast<const f32x4 *>(g.bias + nB); }
             if (LN_IN) { cA = *reinterpret_cast<const f32x4 *>(g.colsum + nA); cB = *reinterpret_cast<const f32x4 *>(g.colsum + nB); }
             const int n_st = n0 + wn * TN + (i + (lq & 1)) * 16 + (lq >> 1) * 8;      // first of this lane's 8 columns after the regrouping
+            // EPI_BF16_HEADS: both fragments lie in one 32-column group, i.e. in one head of one of q / k / v
+            const int hd_d = g.hd_H * 64;
+            const float hd_scale = (EPI == EPI_BF16_HEADS && nA < hd_d) ? 0.125f : 1.f;
+            long hd_col = 0;
+            if constexpr (EPI == EPI_BF16_HEADS) {
+                const int which = n_st / hd_d, c = n_st - which * hd_d;
+                hd_col = (long)which * g.hd_plane + (long)(c >> 6) * g.hd_Tp * 64 + (c & 63);
+            }
+            f32x4 fA[FM], fB[FM];          // EPI_GELU_BWD_BF16: the pre-activations under this lane's 2 x 4 columns, all rows of the fragment pair
+            if constexpr (EPI == EPI_GELU_BWD_BF16) {
+#pragma unroll
+                for (int j = 0; j < FM; j++) {
+                    int m = m0 + wm * TM + j * 16 + lr;
+                    m = m < Mr ? m : Mr - 1;
+                    fA[j] = *reinterpret_cast<const f32x4 *>(g.resid + (size_t)m * g.ldr + (nA < g.n_store ? nA : 0));
+                    fB[j] = *reinterpret_cast<const f32x4 *>(g.resid + (size_t)m * g.ldr + (nB < g.n_store ? nB : 0));
+                }
+            }
 #pragma unroll
             for (int j = 0; j < FM; j++) {
                 const int m = m0 + wm * TM + j * 16 + lr;
                 f32x4 vA, vB;
                 if (LN_IN) { vA = (acc[i][j] - cA * ln_mu[j]) * ln_rs[j] + bA; vB = (acc[i + 1][j] - cB * ln_mu[j]) * ln_rs[j] + bB; }
                 else { vA = acc[i][j] + bA; vB = acc[i + 1][j] + bB; }
+                if constexpr (EPI == EPI_BF16_HEADS) { vA = vA * hd_scale; vB = vB * hd_scale; }
+                if constexpr (EPI == EPI_GELU_BWD_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { vA[r] *= gelu_new_grad(fA[j][r]); vB[r] *= gelu_new_grad(fB[j][r]); }
+                }
                 if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_BF16_LN) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) { vA[r] = gelu_new(vA[r]); vB[r] = gelu_new(vB[r]); }
@@ -393,7 +447,13 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
                 // after the swaps: lq = 0: (A.r0, A.r1) ; lq = 1: (B.r0, B.r1) ; lq = 2: (A.r2, A.r3) ; lq = 3: (B.r2, B.r3)   (r = source lane row)
                 auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                 auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-                if (m < Mr && n_st < g.n_store)
+                if constexpr (EPI == EPI_BF16_HEADS) {
+                    if (m < Mr && n_st < g.n_store) {
+                        const int b = m / g.hd_T, t = m - b * g.hd_T;
+                        *reinterpret_cast<u32x4 *>(reinterpret_cast<uint16_t *>(g.C) + hd_col + ((long)b * g.hd_H * g.hd_Tp + t) * 64) =
+                            u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    }
+                } else if (m < Mr && n_st < g.n_store)
                     *reinterpret_cast<u32x4 *>(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc + n_st) = u32x4{s0[0], s1[0], s0[1], s1[1]};
                 if constexpr (EPI == EPI_BF16_LN_KV) {
                     if (g.kv_k && n_st >= g.kv_d && n_st < g.n_store && kvrow[j] >= 0) {

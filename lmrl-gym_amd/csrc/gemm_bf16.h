@@ -46,6 +46,11 @@ enum GemmEpi {
     EPI_BF16_LN = 6,
     EPI_GELU_BF16_LN = 7,
     EPI_BF16_LN_KV = 8,  // EPI_BF16_LN + the K / V columns of every row also appended to the KV cache (GemmArgs::kv_*)
+    // ---- train step, bf16-matmul mode (gemm8_bf16.h tiles only): epilogues that write the NEXT kernel's bf16 operand themselves
+    EPI_F32_GELU_BF16 = 9,   // C f32 = acc + bias (the pre-activation the backward reads) AND xb bf16 [M][ldxb] = gelu_new(C)
+    EPI_BF16_HEADS = 10,     // the c_attn product straight into the flash kernels' per-head matrices: column n = which * d + h * 64 + e of row
+                             // m = b * T + t -> C + which * hd_plane + ((b * H + h) * Tp + t) * 64 + e, bf16, q columns (which = 0) times 1/8
+    EPI_GELU_BWD_BF16 = 11,  // C bf16 = acc * gelu_new'(resid[m][n]): d(pre-activation) as the bf16 operand of the c_fc backward products
 };
 
 // fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32); the integer bit trick it replaces
@@ -65,6 +70,15 @@ __device__ __forceinline__ float gelu_new(float x) {
     const float t = x * fmaf(0.044715f * x, x, 1.0f);                                  // x + 0.044715 x^3
     const float e = __builtin_amdgcn_exp2f(t * (-2.0f * 0.7978845608028654f * 1.4426950408889634f));   // e^(-2u)
     return x * __builtin_amdgcn_rcpf(1.f + e);
+}
+
+// d gelu_new(x) / dx with the same sigmoid form: g = x s, s = sigmoid(2u), u = c (x + a x^3)  ->  g' = s + x s (1 - s) 2c (1 + 3a x^2)
+__device__ __forceinline__ float gelu_new_grad(float x) {
+    const float c2 = 2.0f * 0.7978845608028654f;
+    const float t = x * fmaf(0.044715f * x, x, 1.0f);
+    const float e = __builtin_amdgcn_exp2f(t * (-c2 * 1.4426950408889634f));
+    const float s = __builtin_amdgcn_rcpf(1.f + e);
+    return fmaf(x * s * (1.f - s), c2 * fmaf(3.f * 0.044715f * x, x, 1.0f), s);
 }
 
 // Per-row LayerNorm moments from the producer's (sum x, sum x^2) slots: ONE association order everywhere — four partial sums of nslots/8
@@ -121,6 +135,9 @@ struct GemmArgs {
     // The train step keeps a block's input, middle and output residual streams as separate tensors (its LayerNorm backward reads them).
     const float *resid;
     int ldr;
+    int ldxb;                 // EPI_F32_GELU_BF16: row pitch of xb (elements)
+    int hd_T, hd_Tp, hd_H;    // EPI_BF16_HEADS: tokens per sequence, its padding to 64, heads
+    long hd_plane;            // EPI_BF16_HEADS: elements between the q, k and v matrices
 };
 
 // cache row (b * tmax + len[b]) the K/V columns of GEMM row m are appended to, or -1.  Loads are unconditional on clamped indices (selects, no

@@ -52,6 +52,49 @@ inline hipError_t gemm_launch_ln(const GemmArgs &g, hipStream_t s) {
     }
 }
 
+// Large-tile choice for the train step's products (M = B*T = 16 k rows, or the vocabulary; one 8-wave workgroup per CU for the 256-row tiles,
+// two for 128x128).  Cost = whole rounds of the 256 CUs x tile area (a partly filled round costs a full tile time), from
+// tools/gemm8_bench.hip `train` on one box (profiles/r03_train_gemm_tiles.txt): N = 768 (proj, fc2, every dX): 256x192 = 256 tiles = ONE round,
+// 71.5 vs 90.4 us at K = 3072 (256x256: 192 tiles, a quarter of the CUs idle); N = 2304 (qkv): 768 tiles of 256x192 = 3 full rounds, 75.5 vs
+// 92.4 (256x256, 2.25 rounds) / 82.2 us (128x128); N = 3072: a tie, 256x256 kept.  hipBLASLt on the same bf16 -> fp32 shapes:
+// 71.8 / 77.4 / 97.0 us (profiles/r03_vs_hipblaslt_f32out.txt).
+enum TrainTile { TT_NONE = 0, TT_256x256, TT_256x192, TT_128x128 };
+inline TrainTile pick_train_tile(int M, int N, int K) {
+    if (M < 2048 || N % 64 != 0) return TT_NONE;
+    const long mt256 = (M + 255) / 256;
+    double best = 1e300;
+    TrainTile t = TT_NONE;
+    if (M >= 4096 && N % 256 == 0) {
+        const long tiles = mt256 * (N / 256);
+        if (tiles >= 160) { best = (double)((tiles + 255) / 256) * 256 * 256; t = TT_256x256; }
+    }
+    if (M >= 4096 && N % 192 == 0) {
+        const long tiles = mt256 * (N / 192);
+        const double c = (double)((tiles + 255) / 256) * 256 * 192;
+        if (tiles >= 160 && c < best) { best = c; t = TT_256x192; }
+    }
+    if (N % 128 == 0 && K < 2048) {
+        const long tiles = (long)((M + 127) / 128) * (N / 128);
+        const double c = (double)((tiles + 511) / 512) * 2 * 128 * 128 * 1.1;      // two co-resident workgroups per CU, ~10 % less efficient each
+        if (c < best) { best = c; t = TT_128x128; }
+    }
+    return t;
+}
+
+// The train step's fused epilogues (gemm8_bf16.h only): EPI_F32_GELU_BF16, EPI_BF16_HEADS, EPI_GELU_BWD_BF16.  bf16 outputs store fragment
+// PAIRS, so the 256x192 tile runs as 4 x 2 waves (64 x 96 per wave) there.
+template <int EPI>
+inline hipError_t gemm_launch_train(const GemmArgs &g, hipStream_t s) {
+    static_assert(EPI == EPI_F32_GELU_BF16 || EPI == EPI_BF16_HEADS || EPI == EPI_GELU_BWD_BF16, "train-step epilogues only");
+    switch (pick_train_tile(g.M, g.N, g.K)) {
+        case TT_256x256: return gemm8_launch<256, 256, 2, 4, 2, EPI>(g, s);
+        case TT_256x192: return gemm8_launch<256, 192, 4, 2, 2, EPI>(g, s);
+        default: break;
+    }
+    if (g.N % 128 == 0) return gemm8_launch<128, 128, 2, 4, 2, EPI>(g, s);
+    return hipErrorInvalidValue;
+}
+
 // Tile choice: keep >= ~1 workgroup per CU (256 CUs) when the problem allows it.
 template <int EPI>
 inline hipError_t gemm_launch(const GemmArgs &g, hipStream_t s) {
@@ -87,6 +130,16 @@ inline hipError_t gemm_launch(const GemmArgs &g, hipStream_t s) {
     // tiles) want occupancy: 2-stage rings, 3 workgroups per CU.  The decode GEMMs (M = 1024) have only 192-768 tiles, i.e.
     // 1-3 per CU, and are bound by the latency chain of their K loop: as many stages as still leave every tile resident
     // at once (768 tiles: 3 stages = 48 KiB -> 3 WG/CU; 192 tiles: 4 stages = 64 KiB -> 2 WG/CU).
+    if constexpr (EPI == EPI_F32) {
+        if (g_gemm_variant != 108) {             // 108: the round-2 policy below (A/B hook)
+            switch (pick_train_tile(g.M, g.N, g.K)) {
+                case TT_256x256: return gemm8_launch<256, 256, 2, 4, 2, EPI>(g, s);
+                case TT_256x192: return gemm8_launch<256, 192, 2, 4, 2, EPI>(g, s);
+                case TT_128x128: return gemm8_launch<128, 128, 2, 4, 2, EPI>(g, s);
+                default: break;
+            }
+        }
+    }
     if constexpr (EPI == EPI_F32 || EPI == EPI_RESID_F32) {
         // fp32-output products of the train step's bf16-matmul mode (M = B*T = 16 k rows, or the vocabulary): 256x256 tiles halve the LDS
         // and L2 traffic per flop; taken when the tile count fills whole rounds of the 256 CUs (tools/bench_train_gemm.py, profiles/r02_train_gemm_sweep.txt:

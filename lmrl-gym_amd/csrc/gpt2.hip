@@ -922,14 +922,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     }
 }
 
-// Split-K plan for C[m][n] = A[m][k] . W[n][k]^T with few output tiles and a long K (the dW products): S copies of the 128 x 128 tile grid
-// so that ~2 workgroups per CU are busy; 0 = not worth splitting.
-static int splitk_plan(int m, int n, int k, int *kchunk) {
-    if (k < 4096 || n % 128 != 0 || k % 64 != 0) return 0;
-    const long tiles = (long)((m + 127) / 128) * (n / 128);
-    if (tiles > 200) return 0;
+// Split-K plan for C[m][n] = A[m][k] . W[n][k]^T with few output tiles and a long K: S copies of the tile grid; 0 = not worth splitting.
+// kind 0 (the dW products, m, n <= a few thousand, k = B*T): 128 x 128 tiles, ~2 workgroups per CU busy.
+// kind 1 (the vocabulary-wide heads' dX, m = rows, n = 768 .. 1536, k = V): 256 x 192 tiles — 128 .. 256 of them — times S = 2 .. so that every
+//         CU holds one (unsplit: 96 tiles of 256 x 256 on 256 CUs, 848 us; profiles/r03_train_gemm_tiles.txt).
+static int splitk_plan(int m, int n, int k, int *kchunk, int *kind) {
+    *kind = 0;
+    if (k < 4096 || k % 64 != 0) return 0;
     const int ksteps = k / 64;
-    int S = (int)(512 / tiles);
+    int S = 0;
+    const long tiles = (long)((m + 127) / 128) * (n / 128);
+    if (n % 128 == 0 && tiles <= 200) {
+        S = (int)(512 / tiles);
+    } else if (m >= 2048 && n % 192 == 0 && k >= 8192) {
+        const long t192 = (long)((m + 255) / 256) * (n / 192);
+        if (t192 > 128) return 0;
+        *kind = 1;
+        S = (int)(256 / t192);
+    } else {
+        return 0;
+    }
     S = std::min(S, ksteps / 16);                 // >= 16 K-steps per copy: the ring prologue / epilogue stay a small part of a copy's life
     if (S < 2) return 0;
     const int per = (ksteps + S - 1) / S;
@@ -1300,21 +1312,22 @@ int lmrl_gpt2_kv_gather(const lmrl_gpt2 *m, const void *src_kv_d, int src_b, int
 }
 
 size_t lmrl_gemm_bf16_splitk_ws_bytes(int m, int n, int k) {
-    int kchunk = 0;
-    const int S = lmrl::splitk_plan(m, n, k, &kchunk);
+    int kchunk = 0, kind = 0;
+    const int S = lmrl::splitk_plan(m, n, k, &kchunk, &kind);
     return S ? (size_t)S * m * n * sizeof(float) : 0;
 }
 
 int lmrl_gemm_bf16_splitk(const void *a_d, const void *w_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc, int n_store, int accumulate,
                           void *ws_d, void *stream) {
     LMRL_REQUIRE(a_d && w_d && c_d && ws_d && m > 0 && n > 0 && k > 0 && n_store > 0 && n_store <= n, "lmrl_gemm_bf16_splitk: bad argument");
-    int kchunk = 0;
-    const int S = lmrl::splitk_plan(m, n, k, &kchunk);
+    int kchunk = 0, kind = 0;
+    const int S = lmrl::splitk_plan(m, n, k, &kchunk, &kind);
     LMRL_REQUIRE(S >= 2, "lmrl_gemm_bf16_splitk: no split-K plan for this shape (lmrl_gemm_bf16_splitk_ws_bytes returned 0)");
     hipStream_t s = as_stream(stream);
     GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, nullptr, ws_d, m, n, k, lda, n, n};
     g.ldw = ldw;
-    LMRL_CHECK_HIP((gemm8_launch_splitk<128, 128, 2, 4, 2>(g, (float *)ws_d, S, kchunk, s)));
+    if (kind == 1) LMRL_CHECK_HIP((gemm8_launch_splitk<256, 192, 2, 4, 2>(g, (float *)ws_d, S, kchunk, s)));
+    else LMRL_CHECK_HIP((gemm8_launch_splitk<128, 128, 2, 4, 2>(g, (float *)ws_d, S, kchunk, s)));
     const long total = (long)m * ((n_store + 3) / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, (const float *)ws_d, S,
                        (long)m * n, n, (float *)c_d, ldc, m, n_store, accumulate);
@@ -1352,6 +1365,44 @@ int lmrl_gemm_bf16_resid(const void *a_d, const void *w_d, const float *bias_d, 
     GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, bias_d, c_d, m, n, k, lda, ldc, n_store > 0 ? n_store : n};
     g.ldw = ldw; g.resid = resid_d; g.ldr = ldr;
     LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(g, as_stream(stream)));
+    return LMRL_OK;
+}
+
+// ---- train step, bf16-matmul mode: products whose epilogue writes the next kernel's bf16 operand (gemm8_bf16.h EPI_F32_GELU_BF16 /
+// EPI_BF16_HEADS / EPI_GELU_BWD_BF16)
+static bool train_gemm_args_ok(int m, int n, int k, int lda, int ldw) {
+    return m > 0 && n > 0 && k > 0 && n % 128 == 0 && k % 64 == 0 && lda % 8 == 0 && lda >= k && (ldw == 0 || (ldw >= k && ldw % 8 == 0));
+}
+
+int lmrl_gemm_bf16_gelu_dual(const void *a_d, const void *w_d, const float *bias_d, float *c_d, int ldc, void *act_bf16_d, int ldact, int m, int n, int k,
+                             int lda, int ldw, void *stream) {
+    LMRL_REQUIRE(a_d && w_d && c_d && act_bf16_d && train_gemm_args_ok(m, n, k, lda, ldw) && ldc % 4 == 0 && ldc >= n && ldact % 8 == 0 && ldact >= n,
+                 "lmrl_gemm_bf16_gelu_dual: bad argument (n a multiple of 128, k of 64, pitches covering n / k)");
+    GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, bias_d, c_d, m, n, k, lda, ldc, n};
+    g.ldw = ldw; g.xb = (uint16_t *)act_bf16_d; g.ldxb = ldact;
+    LMRL_CHECK_HIP(gemm_launch_train<EPI_F32_GELU_BF16>(g, as_stream(stream)));
+    return LMRL_OK;
+}
+
+int lmrl_gemm_bf16_qkv_heads(const void *a_d, const void *w_d, const float *bias_d, void *q_heads_d, long plane_elems, int m, int k, int lda, int ldw,
+                             int heads, int t, void *stream) {
+    const int n = 3 * heads * 64, tp = (t + 63) / 64 * 64;
+    LMRL_REQUIRE(a_d && w_d && q_heads_d && heads > 0 && t > 0 && m % t == 0 && train_gemm_args_ok(m, n, k, lda, ldw) &&
+                     plane_elems >= (long)(m / t) * heads * tp * 64,
+                 "lmrl_gemm_bf16_qkv_heads: bad argument (3 * heads * 64 a multiple of 128, m = batch * t)");
+    GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, bias_d, q_heads_d, m, n, k, lda, n, n};
+    g.ldw = ldw; g.hd_T = t; g.hd_Tp = tp; g.hd_H = heads; g.hd_plane = plane_elems;
+    LMRL_CHECK_HIP(gemm_launch_train<EPI_BF16_HEADS>(g, as_stream(stream)));
+    return LMRL_OK;
+}
+
+int lmrl_gemm_bf16_gelu_bwd(const void *a_d, const void *w_d, const float *pre_d, int ldpre, void *c_bf16_d, int ldc, int m, int n, int k, int lda,
+                            int ldw, void *stream) {
+    LMRL_REQUIRE(a_d && w_d && pre_d && c_bf16_d && train_gemm_args_ok(m, n, k, lda, ldw) && ldc % 8 == 0 && ldc >= n && ldpre % 4 == 0 && ldpre >= n,
+                 "lmrl_gemm_bf16_gelu_bwd: bad argument");
+    GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, nullptr, c_bf16_d, m, n, k, lda, ldc, n};
+    g.ldw = ldw; g.resid = pre_d; g.ldr = ldpre;
+    LMRL_CHECK_HIP(gemm_launch_train<EPI_GELU_BWD_BF16>(g, as_stream(stream)));
     return LMRL_OK;
 }
 

@@ -126,15 +126,22 @@ class GPT2F32:
         else:
             h1 = new(R, d)
             ops.layernorm_fwd(x, p[q + "ln_1.weight"], p[q + "ln_1.bias"], h1, c["m1"], c["r1"], R, d, self.eps)
-        qkv = new(R, 3 * d)
-        ops.linear_fwd(h1, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], qkv, R, d, 3 * d, mm=self.mm, xb=h1b)
+        qkv_fused = stage and flash and ops.fused_ok(3 * d, ops.FUSE_QKV)      # c_attn writes the flash kernels' staged q / k / v itself: no fp32 qkv
+        fws = None
+        if flash:
+            # a workspace per block and per forward call: the q / k / v matrices staged here are the ones the block's backward sweeps
+            fws = c["flash_ws"] = t.empty_like(self._flash_ws[0])
+        if qkv_fused:
+            qkv = None
+            ops.linear_fwd_qkv_heads(mm, h1b, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], fws, R, d, B, H, T)
+        else:
+            qkv = new(R, 3 * d)
+            ops.linear_fwd(h1, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], qkv, R, d, 3 * d, mm=self.mm, xb=h1b)
         att = new(R, d)
         attb = None
         if flash:
             P = None
             c["lse"] = new(lse_n)
-            # a workspace per block and per forward call: the q / k / v matrices staged here are the ones the block's backward sweeps
-            fws = c["flash_ws"] = t.empty_like(self._flash_ws[0])
             if stage:
                 attb, ldb = mm.stash(R, d)
                 ops.flash_attn_fwd_staged(qkv, km, att, c["lse"], fws, attb, ldb, B, H, T, True)
@@ -159,12 +166,16 @@ class GPT2F32:
             h2 = new(R, d)
             ops.layernorm_fwd(x_mid, p[q + "ln_2.weight"], p[q + "ln_2.bias"], h2, c["m2"], c["r2"], R, d, self.eps)
         f = new(R, self.d_ff)
-        ops.linear_fwd(h2, p[q + "mlp.c_fc.weight"], p[q + "mlp.c_fc.bias"], f, R, d, self.d_ff, mm=self.mm, xb=h2b)
         g = gb = None
-        if stage:
+        if stage and ops.fused_ok(self.d_ff, ops.FUSE_GELU):          # c_fc writes the pre-activation and the bf16 gelu output in one launch
+            gb, ldb = mm.stash(R, self.d_ff)
+            ops.linear_fwd_gelu(mm, h2b, p[q + "mlp.c_fc.weight"], p[q + "mlp.c_fc.bias"], f, gb, ldb, R, d, self.d_ff)
+        elif stage:
+            ops.linear_fwd(h2, p[q + "mlp.c_fc.weight"], p[q + "mlp.c_fc.bias"], f, R, d, self.d_ff, mm=self.mm, xb=h2b)
             gb, ldb = mm.stash(R, self.d_ff)
             ops.gelu_fwd_staged(f, None, gb, ldb, R, self.d_ff)
         else:
+            ops.linear_fwd(h2, p[q + "mlp.c_fc.weight"], p[q + "mlp.c_fc.bias"], f, R, d, self.d_ff, mm=self.mm, xb=h2b)
             g = new(R, self.d_ff)
             ops.gelu_fwd(f, g)
         x_out = new(R, d)
@@ -305,11 +316,20 @@ class GPT2F32:
             if "h1" not in c:              # checkpointed block: recompute its intermediates from the stored input
                 _, c = self._layer_forward(l, c["x_in"], B, T, cache["km"], cache["flash"], cache["lse_n"])
             # MLP: x_out = x_mid + gelu(h2 W_fc + b) W_proj + b
-            dg = new(R, self.d_ff)
-            ops.linear_bwd(c["g"], p[q + "mlp.c_proj.weight"], dx, dg, grads[q + "mlp.c_proj.weight"], grads[q + "mlp.c_proj.bias"], R, self.d_ff, d, ws, mm=mm,
-                           dyb=dxb[0], xb=c.get("gb"))
             dfb = None
-            if mm is not None:             # df only feeds the c_fc backward products: written as their bf16 operand, no fp32 copy
+            if mm is not None and dxb[0] is not None and c.get("gb") is not None and ops.fused_ok(self.d_ff, ops.FUSE_GELU_BWD):
+                # dg = dx @ W_proj^T never exists: the dX product's epilogue multiplies by gelu'(f) and writes df as the bf16 operand of c_fc's backward
+                df, dfb = None, ops.linear_bwd_dx_gelu(mm, dxb[0], p[q + "mlp.c_proj.weight"], c["f"], R, self.d_ff, d)
+                ops.linear_bwd(None, p[q + "mlp.c_proj.weight"], dx, None, grads[q + "mlp.c_proj.weight"], grads[q + "mlp.c_proj.bias"], R, self.d_ff, d, ws,
+                               mm=mm, dyb=dxb[0], xb=c["gb"])
+                dg = None
+            else:
+                dg = new(R, self.d_ff)
+                ops.linear_bwd(c["g"], p[q + "mlp.c_proj.weight"], dx, dg, grads[q + "mlp.c_proj.weight"], grads[q + "mlp.c_proj.bias"], R, self.d_ff, d, ws,
+                               mm=mm, dyb=dxb[0], xb=c.get("gb"))
+            if dfb is not None:
+                pass
+            elif mm is not None:           # df only feeds the c_fc backward products: written as their bf16 operand, no fp32 copy
                 df, dfb = None, ops.gelu_bwd_staged(mm, dg, c["f"], R, self.d_ff)
             else:
                 df = dg

@@ -142,6 +142,46 @@ class MatmulBF16:
                                           2 if accumulate else 3, _sp()), "lmrl_gemm_bf16")
 
 
+# bf16-matmul mode: Dense products whose epilogue writes the next kernel's bf16 operand (lmrl_gemm_bf16_gelu_dual / _qkv_heads / _gelu_bwd) instead of
+# an elementwise pass over an [B*T][n] fp32 tensor.  A/B hook for tools/ and the second-path tests; the arithmetic differs from the unfused form
+# only in gelu_new / its derivative being evaluated in the sigmoid form (v_exp + v_rcp, ~1e-7 relative) before the bf16 rounding.
+FUSE_EPILOGUES = 7          # bit 0: c_attn -> staged q / k / v, bit 1: c_fc -> (pre-activation, bf16 gelu), bit 2: c_proj dX -> bf16 d(pre-activation)
+FUSE_QKV, FUSE_GELU, FUSE_GELU_BWD = 1, 2, 4
+
+
+def fused_ok(n: int, which: int) -> bool:
+    return bool(int(FUSE_EPILOGUES) & which) and n % 128 == 0
+
+
+def linear_fwd_gelu(mm: "MatmulBF16", xb, w, b, f, gb, ldg, rows, k, n):
+    """f[rows][n] fp32 = x @ w + b and gb[rows][ldg] bf16 = gelu_new(f) in one launch (xb: the staged bf16 operand of x)."""
+    wt = mm.cast(("wT", w.data_ptr()), w, k, n, n, transpose=True, keep=True)
+    _lib.check(_L().lmrl_gemm_bf16_gelu_dual(xb.data_ptr(), wt.data_ptr(), _lib.ptr(mm.bias(b, n)), f.data_ptr(), n, gb.data_ptr(), ldg, rows, n, _pad(k),
+                                             _pitch(k), _pitch(k), _sp()), "lmrl_gemm_bf16_gelu_dual")
+
+
+def linear_fwd_qkv_heads(mm: "MatmulBF16", xb, w, b, flash_ws, rows, k, batch, heads, t):
+    """attn.c_attn whose output goes straight into the flash kernels' staged q / k / v matrices in `flash_ws` (no fp32 qkv tensor)."""
+    import ctypes
+    n = 3 * heads * 64
+    wt = mm.cast(("wT", w.data_ptr()), w, k, n, n, transpose=True, keep=True)
+    q, plane = ctypes.c_void_p(), ctypes.c_long()
+    _lib.check(_L().lmrl_flash_attn_stage_ptrs(flash_ws.data_ptr(), batch, heads, t, ctypes.byref(q), ctypes.byref(plane)), "lmrl_flash_attn_stage_ptrs")
+    _lib.check(_L().lmrl_gemm_bf16_qkv_heads(xb.data_ptr(), wt.data_ptr(), _lib.ptr(mm.bias(b, n)), q, plane, rows, _pad(k), _pitch(k), _pitch(k), heads, t,
+                                             _sp()), "lmrl_gemm_bf16_qkv_heads")
+    _lib.check(_L().lmrl_flash_attn_finish_staging(flash_ws.data_ptr(), batch, heads, t, _sp()), "lmrl_flash_attn_finish_staging")
+
+
+def linear_bwd_dx_gelu(mm: "MatmulBF16", dyb, w, pre, rows, k, n):
+    """-> bf16 [pad(rows)][pitch(k)] = (dy @ w^T) * gelu_new'(pre): the dX product of mlp.c_proj fused with the gelu backward, written as the dy
+    operand of the c_fc backward (`linear_bwd(dyb=...)`); dyb: the staged bf16 dy [rows][pitch(n)], w [k][n], pre fp32 [rows][k]."""
+    wb = mm.cast(("w", w.data_ptr()), w, k, n, n, keep=True)                     # [k][pad(n)]
+    dst, ldd = mm._buf("dy2", _padn(rows) * _pitch(k)), _pitch(k)
+    _lib.check(_L().lmrl_gemm_bf16_gelu_bwd(dyb.data_ptr(), wb.data_ptr(), pre.data_ptr(), k, dst.data_ptr(), ldd, rows, k, _pad(n), _pitch(n), _pitch(n),
+                                            _sp()), "lmrl_gemm_bf16_gelu_bwd")
+    return dst
+
+
 # bf16-matmul mode: residual add inside the projection GEMM's epilogue (lmrl_gemm_bf16_resid) instead of a separate axpby launch.  Measured on
 # one box, ILQL M3 step, A/B twice (tools/ab_train_resid.py, profiles/r03_train_resid_ab.txt): fused 46.93 / 47.31 ms, two launches 46.26 /
 # 46.73 ms — the residual slice prefetched under the K loop costs the 128x128 / 256x256 tiles more registers than the 30 us axpby (150 MB at
@@ -358,7 +398,8 @@ def flash_attn_fwd(qkv, key_mask, att, lse, ws, batch, heads, t, bf16):
 
 
 def flash_attn_fwd_staged(qkv, key_mask, att, lse, ws, att_b, ldb, batch, heads, t, bf16):
-    _lib.check(_L().lmrl_flash_attn_fwd_staged(qkv.data_ptr(), _lib.ptr(key_mask), att.data_ptr(), lse.data_ptr(), ws.data_ptr(), att_b.data_ptr(), ldb,
+    """qkv None (bf16): `ws` already holds the staged q / k / v (`linear_fwd_qkv_heads`)."""
+    _lib.check(_L().lmrl_flash_attn_fwd_staged(_lib.ptr(qkv), _lib.ptr(key_mask), att.data_ptr(), lse.data_ptr(), ws.data_ptr(), att_b.data_ptr(), ldb,
                                                batch, heads, t, int(bf16), _sp()), "lmrl_flash_attn_fwd_staged")
 
 
@@ -372,6 +413,6 @@ def flash_attn_bwd(qkv, key_mask, att, datt, lse, dqkv, ws, batch, heads, t, bf1
 def flash_attn_bwd_staged(mm, qkv, key_mask, att, datt, lse, ws, batch, heads, t, qkv_staged=False):
     """bf16 kernels; d(qkv) written only as the bf16 dy operand of the c_attn `linear_bwd(dyb=...)`"""
     dst, ldb = mm.stage_dy(batch * t, 3 * heads * 64)
-    _lib.check(_L().lmrl_flash_attn_bwd_staged(qkv.data_ptr(), _lib.ptr(key_mask), att.data_ptr(), datt.data_ptr(), lse.data_ptr(), dst.data_ptr(), ldb,
+    _lib.check(_L().lmrl_flash_attn_bwd_staged(_lib.ptr(qkv), _lib.ptr(key_mask), att.data_ptr(), datt.data_ptr(), lse.data_ptr(), dst.data_ptr(), ldb,
                                                ws.data_ptr(), batch, heads, t, int(qkv_staged), _sp()), "lmrl_flash_attn_bwd_staged")
     return dst

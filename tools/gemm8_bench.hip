@@ -63,6 +63,19 @@ int main(int argc, char **argv) {
     if (quick) { shapes = {shapes[0], shapes[2], shapes[4]}; }
     if (argc > 1 && std::string(argv[1]) == "decode") { shapes = {{1024, 2304, 768, "decode qkv"}, {1024, 768, 768, "decode proj"}, {1024, 3072, 768, "decode fc"}, {1024, 768, 3072, "decode fc2"}}; }
     if (argc > 1 && std::string(argv[1]) == "resid") { shapes = {{1024, 768, 768, "decode proj"}, {1024, 768, 3072, "decode fc2"}, {7168, 768, 768, "prefill proj"}, {7168, 768, 3072, "prefill fc2"}}; }
+    const bool train = argc > 1 && std::string(argv[1]) == "train";
+    if (train) { shapes = {{16384, 3072, 768, "train fc"}, {16384, 768, 3072, "train fc2"}, {16384, 2304, 768, "train qkv"}, {16384, 768, 768, "train proj"}, {8192, 50432, 768, "train head"}, {16384, 768, 2304, "train dx qkv"}, {8192, 768, 50304, "train dx head"}}; }
+    std::vector<Cfg> cfgs_train = {
+        {"g8 256x256 2x4 s2 f32out", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<256, 256, 2, 4, 2, EPI_F32>(g, s); }, 256, 256, true},
+        {"g8 256x256 2x2 s2 f32out (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<256, 256, 2, 2, 2, EPI_F32>(g, s); }, 256, 256, true},
+        {"g8 256x256 4x2 s2 f32out", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<256, 256, 4, 2, 2, EPI_F32>(g, s); }, 256, 256, true},
+        {"g8 256x192 2x4 s2 f32out", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<256, 192, 2, 4, 2, EPI_F32>(g, s); }, 256, 192, true},
+        {"g8 256x192 4x2 s2 f32out", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<256, 192, 4, 2, 2, EPI_F32>(g, s); }, 256, 192, true},
+        {"g8 128x192 2x4 s3 f32out", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 192, 2, 4, 3, EPI_F32>(g, s); }, 128, 192, true},
+        {"g8 256x128 2x2 s3 f32out (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<256, 128, 2, 2, 3, EPI_F32>(g, s); }, 256, 128, true},
+        {"g8 128x256 2x2 s3 f32out (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 256, 2, 2, 3, EPI_F32>(g, s); }, 128, 256, true},
+        {"g8 128x128 2x4 s2 f32out", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 4, 2, EPI_F32>(g, s); }, 128, 128, true},
+    };
     std::vector<Cfg> cfgs = {
         {"ring 128x64 s2 (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<128, 64, 2, EPI_BF16>(g, s); }, 128, 64},
         {"ring 64x64 s3 (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<64, 64, 3, EPI_BF16>(g, s); }, 64, 64},
@@ -103,6 +116,7 @@ int main(int argc, char **argv) {
         {"ring 128x64 s2 GELU", [](const GemmArgs &g, hipStream_t s) { return gemm_launch_glds<128, 64, 2, EPI_GELU_BF16>(g, s); }, 128, 64, false, true},
         {"g8 128x128 2x4 s2 GELU", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 4, 2, EPI_GELU_BF16>(g, s); }, 128, 128, false, true},
     };
+    if (train) cfgs = cfgs_train;
     hipStream_t st; CK(hipStreamCreate(&st));
     for (const Shape &sh : shapes) {
         const int M = sh.M, N = sh.N, K = sh.K, NWC = getenv("LMRL_NWC") ? atoi(getenv("LMRL_NWC")) : (N > 10000 ? 2 : 12);   // LMRL_NWC=1: hot L2

@@ -1,0 +1,21 @@
+#!/bin/bash
+# rocprofv3 --kernel-trace --stats of one train-step bench command -> gpurun_out/<tag>_kernel_stats.csv
+# usage: tools/prof_train.sh <tag> [bench args; default: --mode ilql-step --train-matmul bf16]
+TAG=${1:-train}; shift
+ARGS=${@:---mode ilql-step --train-matmul bf16}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_$TAG
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $REPO/bench.py $ARGS --steps 3 --warmup 1 > /tmp/prof_$TAG.out 2>&1 || echo "rocprofv3 failed/timeout"
+tail -2 /tmp/prof_$TAG.out | cut -c1-400
+F=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
+mkdir -p $REPO/gpurun_out
+cp "$F" $REPO/gpurun_out/${TAG}_kernel_stats.csv
+python - "$F" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print("total kernel time %.2f ms over %d launches (4 steps incl. warm-up)" % (tot / 1e6, sum(int(r["Calls"]) for r in rows)))
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:45]:
+    print("%-100s n=%6s avg %8.2f us  %5.1f %%" % (r["Name"][:100], r["Calls"], float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+PY
