@@ -541,6 +541,8 @@ int lmrl_sgemm(int trans_a, int trans_b, int m, int n, int k, float alpha, const
                long sc_outer, long sc_inner, int nb_outer, int nb_inner, const float *bias_d, void *stream);
 /* A/B hook: 0 = auto (128x128 tiles when m, n >= 128), 1 = always the 64x64-tile kernel */
 void lmrl_sgemm_set_variant(int v);
+/* TOOLS / TESTS ONLY: bit 0 = LayerNorm forward on the strided one-pass-per-moment kernel (A/B of lmrl_layernorm_add_fwd's register-row kernel) */
+void lmrl_train_ops_set_variant(int v);
 int lmrl_embed_fwd(const float *wte_d, const float *wpe_d, const int32_t *ids_d, const int32_t *pos_d, float *x_d, int rows, int d, void *stream);
 int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d, float *dwte_d, float *dwpe_d, int rows, int d, void *stream);
 /* Row compaction for the vocabulary-wide heads of the train steps: the losses read the Q / policy logits only on rows whose mask is set
@@ -555,6 +557,12 @@ int lmrl_layernorm_fwd(const float *x_d, const float *g_d, const float *b_d, flo
  * as the operand of the layer's dW product). */
 int lmrl_layernorm_fwd_staged(const float *x_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, void *yb_d, long ldb,
                               int rows, int d, float eps, void *stream);
+/* x[r] += resid[r] (resid_d NULL: no add) and then LayerNorm of the updated row, in one pass: y (fp32, optional) and / or yb (bf16 [rows][ldb], the
+ * operand of the consuming GEMM), mean / rstd for the backward.  The residual adds of an HF GPT-2 block (x + attn(ln_1 x), x + mlp(ln_2 x)) folded
+ * into the LayerNorm that follows each of them (ln_2, the next block's ln_1, ln_f): x_d is the projection's raw output on entry, the residual
+ * stream on exit. */
+int lmrl_layernorm_add_fwd(float *x_d, const float *resid_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, void *yb_d,
+                           long ldb, int rows, int d, float eps, void *stream);
 int lmrl_gelu_fwd_staged(const float *x_d, float *y_d, void *yb_d, long ldb, int rows, int cols, void *stream);
 /* dx (=|+=) LN backward; dy_xhat_d (optional [rows][d]) receives dy*xhat whose column sum is d gamma */
 int lmrl_layernorm_bwd(const float *dy_d, const float *x_d, const float *g_d, const float *mean_d, const float *rstd_d, float *dx_d,
@@ -570,6 +578,10 @@ int lmrl_layernorm_bwd_fused(const float *dy_d, const float *x_d, const float *g
                              long ldb, void *stream);
 size_t lmrl_colsum_ws_bytes(int cols);
 int lmrl_colsum(const float *x_d, int rows, int cols, int ld, float *out_d, int accumulate, float *ws_d, void *stream);
+/* out[c] (=|+=) sum_r wrow[r * ldw] * x[r][c]: the weight gradient x^T . dy of a Dense layer with ONE output unit (heads/linear_head.py:112-119 as
+ * the PPO value head, the V head of heads/mlp_head.py:139-148) — a matrix-vector product; ws_d as for lmrl_colsum. */
+int lmrl_colsum_weighted(const float *x_d, int rows, int cols, int ld, const float *wrow_d, int ldw, float *out_d, int accumulate, float *ws_d,
+                         void *stream);
 /* elementwise ops: in-place calls are supported (y_d == x_d, dx_d == dy_d, out_d == x_d or y_d) */
 int lmrl_gelu_fwd(const float *x_d, float *y_d, size_t n, void *stream);
 int lmrl_gelu_bwd(const float *dy_d, const float *x_d, float *dx_d, size_t n, void *stream);

@@ -52,6 +52,7 @@ _SIGS = {
     "lmrl_gemm_set_variant": (None, [c_int]),
     "lmrl_gpt2_kv_broadcast": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmrl_sgemm_set_variant": (None, [c_int]),
+    "lmrl_train_ops_set_variant": (None, [c_int]),
     "lmrl_sample_ws_bytes": (c_size_t, [c_int, c_int]),
     "lmrl_sample_logits_steer": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmrl_chunk_begin_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -121,6 +122,7 @@ _SIGS = {
     "lmrl_flash_attn_finish_staging": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "lmrl_flash_attn_bwd_staged": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_adamw_segments": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_int, c_void_p]),
+    "lmrl_layernorm_add_fwd": (c_int, [c_void_p] * 8 + [ctypes.c_long, c_int, c_int, c_float, c_void_p]),
     "lmrl_layernorm_fwd_staged": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_int, c_float, c_void_p]),
     "lmrl_gelu_fwd_staged": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]),
     "lmrl_embed_bwd": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
@@ -135,6 +137,7 @@ _SIGS = {
     "lmrl_scatter_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lmrl_colsum_ws_bytes": (c_size_t, [c_int]),
     "lmrl_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "lmrl_colsum_weighted": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "lmrl_gelu_fwd": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "lmrl_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lmrl_relu_fwd": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

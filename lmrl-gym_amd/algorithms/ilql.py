@@ -176,7 +176,8 @@ class GPT2ILQLTrain:
         self.base, self.q1, self.q2, self.v = base, q1_head, q2_head, v_head
         self.target_base = target_base
         dev = base.dev
-        clone = lambda head: MLPHeadF32({k: t.clone() for k, t in head.p.items()}, dev)
+        # the target heads compute in the arithmetic mode of the heads they track (their hidden layer was fp32 in the bf16-matmul mode: 2 x 190 us)
+        clone = lambda head: MLPHeadF32({k: t.clone() for k, t in head.p.items()}, dev, matmul="bf16" if head.mm is not None else "f32")
         self.q1_target, self.q2_target = clone(q1_head), clone(q2_head)
         self.pad, self.loss_kwargs = pad_token_id, dict(loss_kwargs)
         self.alpha, self.hard_every = polyak_alpha, hard_update_every
@@ -319,6 +320,8 @@ class GPT2ILQLTrain:
         red = D.GradReducer()
         base.backward(cache, d_hidden, bgrads, on_final=red.ready(bgrads))
         self.last_grads = (bgrads, g1, g2, gv)
+        if getattr(self, "keep_head_caches", False):      # tests: the heads' pre-activations (which side of relu each unit took) and their row set
+            self.last_head_caches = (q1c, q2c, vc, q_rows if compact else None)
         red.finish([g1, g2, gv])
         self.calls += 1                                 # TrainState.step of the reference: one per apply_gradients call
         upd = self.base_opt.apply(bgrads)

@@ -183,20 +183,28 @@ __global__ __launch_bounds__(256) void ce_bwd_bf16_kernel(const float *__restric
     }
 }
 
-// out[c] (+)= sum over row blocks of colpart[rb][c], in row-block order (deterministic)
-__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float *__restrict__ colpart, int nrb, int ldp, int cols, float *__restrict__ out,
-                                                             int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int rb = 0;
-    for (; rb + 3 < nrb; rb += 4) {
-        s0 += colpart[(long)rb * ldp + c]; s1 += colpart[(long)(rb + 1) * ldp + c];
-        s2 += colpart[(long)(rb + 2) * ldp + c]; s3 += colpart[(long)(rb + 3) * ldp + c];
+// out[c] (+)= sum over row blocks of colpart[rb][c] (deterministic: fixed partition and order).  One workgroup per 64 columns, 16 lane groups
+// each summing every 16th row block, combined through LDS in group order — the one-thread-per-column form walked 256 dependent strided loads
+// from 3 .. 12 workgroups (20.8 us per call, 53 calls per ILQL step: profiles/r03_ilql_bf16_step_kernel_stats_before_fusion.csv).
+__global__ __launch_bounds__(1024) void colpart_reduce_kernel(const float *__restrict__ colpart, int nrb, int ldp, int cols, float *__restrict__ out,
+                                                              int accumulate) {
+    __shared__ float part[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < cols) {
+        int rb = ty;
+        for (; rb + 16 < nrb; rb += 32) { s0 += colpart[(long)rb * ldp + c]; s1 += colpart[(long)(rb + 16) * ldp + c]; }
+        if (rb < nrb) s0 += colpart[(long)rb * ldp + c];
     }
-    for (; rb < nrb; rb++) s0 += colpart[(long)rb * ldp + c];
-    const float s = (s0 + s1) + (s2 + s3);
-    out[c] = accumulate ? out[c] + s : s;
+    part[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty == 0 && c < cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) s += part[k][tx];
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
 // dst[j][i] = beta * dst[j][i] + src[i][j]   (src [n][k], dst [k][n]): 32 x 32 tiles through LDS
@@ -275,7 +283,7 @@ int lmrl_cast_bf16_t_colsum(const float *src_d, long ld_src, int rows, int cols,
     const int nrb = (rows + 63) / 64;       // row blocks that hold source rows (blocks beyond only zero-fill the padding)
     hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((int)((ld_dst + 63) / 64), (rows_dst + 63) / 64), dim3(256), 0, s, src_d, ld_src, rows, cols,
                        (uint16_t *)dst_d, ld_dst, rows_dst, ws_d);
-    hipLaunchKernelGGL(colpart_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, (const float *)ws_d, nrb, rows_dst, cols, colsum_d, accumulate);
+    hipLaunchKernelGGL(colpart_reduce_kernel, dim3((cols + 63) / 64), dim3(1024), 0, s, (const float *)ws_d, nrb, rows_dst, cols, colsum_d, accumulate);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }
@@ -289,7 +297,7 @@ int lmrl_transpose_bf16_colsum(const void *src_d, long ld_src, int rows, int col
     hipLaunchKernelGGL(transpose_bf16_kernel, dim3((int)((ld_dst + 63) / 64), (rows_dst + 63) / 64), dim3(256), 0, s, (const uint16_t *)src_d, ld_src,
                        rows, cols, (uint16_t *)dst_d, ld_dst, rows_dst, colsum_d ? ws_d : (float *)nullptr);
     if (colsum_d)
-        hipLaunchKernelGGL(colpart_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, (const float *)ws_d, nrb, rows_dst, cols, colsum_d,
+        hipLaunchKernelGGL(colpart_reduce_kernel, dim3((cols + 63) / 64), dim3(1024), 0, s, (const float *)ws_d, nrb, rows_dst, cols, colsum_d,
                            accumulate);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;

@@ -121,6 +121,57 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
     }
     if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
 }
+// The same with the row held in registers (d = 256 NV: 768, 1024, 1280, ...): one 16-byte load per lane and 256 columns, the row read ONCE, and
+// optionally the block's residual add in front — x[r] += resid[r] (in place: x is the projection's output, afterwards the residual stream the
+// backward's LayerNorm reads) — so that no stand-alone `x + proj(...)` pass over [B*T][d] floats runs between a projection and the LayerNorm behind it.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(float *x, const float *__restrict__ resid, const float *__restrict__ g,
+                                                         const float *__restrict__ b, float *__restrict__ y, float *__restrict__ mean,
+                                                         float *__restrict__ rstd, int R, float eps, uint16_t *__restrict__ yb, long ldb) {
+    constexpr int d = NV * 256;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    float *xr = x + (size_t)r * d + lane * 4;
+    float4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = *reinterpret_cast<const float4 *>(xr + k * 256);
+    if (resid) {
+        const float *rr = resid + (size_t)r * d + lane * 4;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const float4 o = *reinterpret_cast<const float4 *>(rr + k * 256);
+            v[k].x += o.x; v[k].y += o.y; v[k].z += o.z; v[k].w += o.w;
+            *reinterpret_cast<float4 *>(xr + k * 256) = v[k];
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    const float mu = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const float a0 = v[k].x - mu, a1 = v[k].y - mu, a2 = v[k].z - mu, a3 = v[k].w - mu;
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const int c = k * 256 + lane * 4;
+        const float4 gg = *reinterpret_cast<const float4 *>(g + c), bb = *reinterpret_cast<const float4 *>(b + c);
+        float4 o;
+        o.x = (v[k].x - mu) * rs * gg.x + bb.x; o.y = (v[k].y - mu) * rs * gg.y + bb.y;
+        o.z = (v[k].z - mu) * rs * gg.z + bb.z; o.w = (v[k].w - mu) * rs * gg.w + bb.w;
+        if (y) *reinterpret_cast<float4 *>(y + (size_t)r * d + c) = o;
+        if (yb) {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16_rne(o.x) | ((uint32_t)f32_to_bf16_rne(o.y) << 16);
+            pk.y = (uint32_t)f32_to_bf16_rne(o.z) | ((uint32_t)f32_to_bf16_rne(o.w) << 16);
+            *reinterpret_cast<uint2 *>(yb + (size_t)r * ldb + c) = pk;
+        }
+    }
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+}
 // dx = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)),  dyg = dy * g ; also emits xhat*dy for the gamma gradient
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                      const float *__restrict__ g, const float *__restrict__ mean,
@@ -217,8 +268,10 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restr
 
 // ------------------------------------------------------------------------------------------ column sums (bias / LN grads)
 // out[c] (+)= sum_r x[r][c] ; deterministic two-stage: stage 1 = SPLIT row slabs -> partial[SPLIT][C], stage 2 sums them.
+// wrow (optional): per-row weights, out[c] = sum_r wrow[r * ldw] x[r][c] — the weight gradient x^T dy of a Dense layer with ONE output (the V /
+// value heads): a matrix-vector product, which the 64 x 64-tile sgemm ran as 12 tiles over K = B*T (820 us per ILQL step)
 __global__ __launch_bounds__(256) void colsum_stage1(const float *__restrict__ x, float *__restrict__ partial, int R, int C, int ld,
-                                                     int rows_per_slab) {
+                                                     int rows_per_slab, const float *__restrict__ wrow, int ldw) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const int r0 = blockIdx.y * rows_per_slab, r1 = min(R, r0 + rows_per_slab);
@@ -229,10 +282,15 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float *__restrict__ x
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) v[u] = x[(size_t)(r + u) * ld + c];
+        if (wrow) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) a[u] += v[u];
+            for (int u = 0; u < 8; u++) a[u] = fmaf(v[u], wrow[(size_t)(r + u) * ldw], a[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] += v[u];
+        }
     }
-    for (; r < r1; r++) a[0] += x[(size_t)r * ld + c];
+    for (; r < r1; r++) a[0] += x[(size_t)r * ld + c] * (wrow ? wrow[(size_t)r * ldw] : 1.f);
     partial[(size_t)blockIdx.y * C + c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 __global__ __launch_bounds__(256) void colsum_stage2(const float *__restrict__ partial, float *__restrict__ out, int C, int nslab,
@@ -552,6 +610,30 @@ int lmrl_layernorm_fwd_staged(const float *x_d, const float *g_d, const float *b
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }
+static int g_train_ops_variant = 0;      // tools / tests only: bit 0 = LayerNorm forward on the strided (round-2) kernel
+void lmrl_train_ops_set_variant(int v) { g_train_ops_variant = v; }
+int lmrl_layernorm_add_fwd(float *x_d, const float *resid_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, void *yb_d,
+                           long ldb, int rows, int d, float eps, void *stream) {
+    LMRL_REQUIRE(x_d && g_d && b_d && mean_d && rstd_d && (y_d || yb_d) && (!yb_d || (ldb >= d && ldb % 4 == 0)) && rows > 0 && d > 0,
+                 "lmrl_layernorm_add_fwd: bad argument");
+#define LMRL_LNV(NV_)                                                                                                                   \
+    hipLaunchKernelGGL(ln_fwd_vec_kernel<NV_>, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, x_d, resid_d, g_d, b_d, y_d, mean_d, rstd_d, rows, eps, \
+                       (uint16_t *)yb_d, ldb)
+    switch ((d % 256 == 0 && !(g_train_ops_variant & 1)) ? d / 256 : 0) {
+        case 1: LMRL_LNV(1); break;
+        case 2: LMRL_LNV(2); break;
+        case 3: LMRL_LNV(3); break;
+        case 4: LMRL_LNV(4); break;
+        case 5: LMRL_LNV(5); break;
+        default:                     // other widths: the residual add as its own pass, then the strided kernel
+            if (resid_d) hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid((size_t)rows * d)), dim3(256), 0, ST, 1.f, x_d, 1.f, resid_d, x_d, (size_t)rows * d);
+            hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, x_d, g_d, b_d, y_d, mean_d, rstd_d, rows, d, eps,
+                               (uint16_t *)yb_d, ldb);
+    }
+#undef LMRL_LNV
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
 int lmrl_gelu_fwd_staged(const float *x_d, float *y_d, void *yb_d, long ldb, int rows, int cols, void *stream) {
     LMRL_REQUIRE(x_d && yb_d && rows > 0 && cols > 0 && ldb >= cols, "lmrl_gelu_fwd_staged: bad argument");
     hipLaunchKernelGGL(gelu_fwd_staged_kernel, dim3(rows), dim3(256), 0, ST, x_d, y_d, (uint16_t *)yb_d, ldb, rows, cols);
@@ -601,7 +683,18 @@ int lmrl_colsum(const float *x_d, int rows, int cols, int ld, float *out_d, int 
     const int nslab = rows < 64 ? rows : 64;
     const int per = (rows + nslab - 1) / nslab;
     const int slabs = (rows + per - 1) / per;
-    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(cols, 256), slabs), dim3(256), 0, ST, x_d, ws_d, rows, cols, ld, per);
+    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(cols, 256), slabs), dim3(256), 0, ST, x_d, ws_d, rows, cols, ld, per, (const float *)nullptr, 0);
+    hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(cols, 256)), dim3(256), 0, ST, ws_d, out_d, cols, slabs, accumulate);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_colsum_weighted(const float *x_d, int rows, int cols, int ld, const float *wrow_d, int ldw, float *out_d, int accumulate, float *ws_d,
+                         void *stream) {
+    LMRL_REQUIRE(x_d && wrow_d && out_d && ws_d && rows > 0 && cols > 0 && ldw > 0, "lmrl_colsum_weighted: bad argument");
+    const int nslab = rows < 64 ? rows : 64;
+    const int per = (rows + nslab - 1) / nslab;
+    const int slabs = (rows + per - 1) / per;
+    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(cols, 256), slabs), dim3(256), 0, ST, x_d, ws_d, rows, cols, ld, per, wrow_d, ldw);
     hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(cols, 256)), dim3(256), 0, ST, ws_d, out_d, cols, slabs, accumulate);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;

@@ -106,8 +106,10 @@ class GPT2F32:
         self.mm = ops.MatmulBF16(self.dev) if matmul == "bf16" else None
         self.ld_vocab = ops._pad(self.vocab) if self.mm is not None else self.vocab     # row stride of [rows, V] logits
 
-    def _layer_forward(self, l: int, x, B: int, T: int, km, flash: bool, lse_n: int):
-        """One transformer block: x [B*T, d] -> (x_out, cache of every intermediate the backward pass reads)."""
+    def _layer_forward(self, l: int, x, B: int, T: int, km, flash: bool, lse_n: int, resid_in=None):
+        """One transformer block: x [B*T, d] -> (x_out, pending, cache of every intermediate the backward pass reads).  resid_in: a residual
+        still to be added to x (the previous block's `x_mid`, when its second residual add was left to this block's ln_1: x += resid_in in place,
+        inside the LayerNorm launch).  pending: likewise this block's x_mid if x_out is returned WITHOUT it (ops.FUSE_ADD_LN), else None."""
         t = self.t
         R, d, H, p = B * T, self.d, self.n_head, self.p
         hd = d // H
@@ -120,12 +122,13 @@ class GPT2F32:
         # transposes for the dW products — no fp32 copies of h1 / h2 / g exist in this mode (att keeps one: the flash backward reads it)
         c["m1"], c["r1"] = new(R), new(R)
         h1 = h1b = None
+        fuse_add = ops.FUSE_ADD_LN
         if stage:
             h1b, ldb = mm.stash(R, d)
-            ops.layernorm_fwd_staged(x, p[q + "ln_1.weight"], p[q + "ln_1.bias"], None, c["m1"], c["r1"], h1b, ldb, R, d, self.eps)
+            ops.layernorm_add_fwd(x, resid_in, p[q + "ln_1.weight"], p[q + "ln_1.bias"], None, c["m1"], c["r1"], h1b, ldb, R, d, self.eps)
         else:
             h1 = new(R, d)
-            ops.layernorm_fwd(x, p[q + "ln_1.weight"], p[q + "ln_1.bias"], h1, c["m1"], c["r1"], R, d, self.eps)
+            ops.layernorm_add_fwd(x, resid_in, p[q + "ln_1.weight"], p[q + "ln_1.bias"], h1, c["m1"], c["r1"], None, 0, R, d, self.eps)
         qkv_fused = stage and flash and ops.fused_ok(3 * d, ops.FUSE_QKV)      # c_attn writes the flash kernels' staged q / k / v itself: no fp32 qkv
         fws = None
         if flash:
@@ -156,15 +159,16 @@ class GPT2F32:
             ops.sgemm(P, qkv, att, T, hd, T, lda=T, ldb=3 * d, ldc=d, b_off=2 * d, batch=(B, H), sa=(H * T * T, T * T),
                       sb=(T * 3 * d, hd), sc=(T * d, hd))
         x_mid = new(R, d)
-        ops.linear_fwd(att, p[q + "attn.c_proj.weight"], p[q + "attn.c_proj.bias"], x_mid, R, d, d, mm=self.mm, xb=attb, resid=x)      # x_mid = x + proj(att)
+        # x_mid = x + proj(att): the add inside the GEMM epilogue / as one axpby (resid=x), or left to the ln_2 launch below (fuse_add)
+        ops.linear_fwd(att, p[q + "attn.c_proj.weight"], p[q + "attn.c_proj.bias"], x_mid, R, d, d, mm=self.mm, xb=attb, resid=None if fuse_add else x)
         c["m2"], c["r2"] = new(R), new(R)
         h2 = h2b = None
         if stage:
             h2b, ldb = mm.stash(R, d)
-            ops.layernorm_fwd_staged(x_mid, p[q + "ln_2.weight"], p[q + "ln_2.bias"], None, c["m2"], c["r2"], h2b, ldb, R, d, self.eps)
+            ops.layernorm_add_fwd(x_mid, x if fuse_add else None, p[q + "ln_2.weight"], p[q + "ln_2.bias"], None, c["m2"], c["r2"], h2b, ldb, R, d, self.eps)
         else:
             h2 = new(R, d)
-            ops.layernorm_fwd(x_mid, p[q + "ln_2.weight"], p[q + "ln_2.bias"], h2, c["m2"], c["r2"], R, d, self.eps)
+            ops.layernorm_add_fwd(x_mid, x if fuse_add else None, p[q + "ln_2.weight"], p[q + "ln_2.bias"], h2, c["m2"], c["r2"], None, 0, R, d, self.eps)
         f = new(R, self.d_ff)
         g = gb = None
         if stage and ops.fused_ok(self.d_ff, ops.FUSE_GELU):          # c_fc writes the pre-activation and the bf16 gelu output in one launch
@@ -179,10 +183,11 @@ class GPT2F32:
             g = new(R, self.d_ff)
             ops.gelu_fwd(f, g)
         x_out = new(R, d)
-        ops.linear_fwd(g, p[q + "mlp.c_proj.weight"], p[q + "mlp.c_proj.bias"], x_out, R, self.d_ff, d, mm=self.mm, xb=gb, resid=x_mid)     # x_out = x_mid + mlp
+        # x_out = x_mid + mlp: as above, or left to the NEXT LayerNorm (the following block's ln_1 / ln_f) through `pending`
+        ops.linear_fwd(g, p[q + "mlp.c_proj.weight"], p[q + "mlp.c_proj.bias"], x_out, R, self.d_ff, d, mm=self.mm, xb=gb, resid=None if fuse_add else x_mid)
         c.update(h1b=h1b, attb=attb, h2b=h2b, gb=gb)
         c.update(h1=h1, qkv=qkv, P=P, att=att, x_mid=x_mid, h2=h2, f=f, g=g)
-        return x_out, c
+        return x_out, (x_mid if fuse_add else None), c
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids, attention_mask, position_ids, tag: str = "fwd"):
@@ -209,14 +214,16 @@ class GPT2F32:
             lse_n = self._flash_ws[1]
         cache["flash"] = flash
         cache["lse_n"] = lse_n
+        pending = None
         for l in range(self.n_layer):
-            x_out, c = self._layer_forward(l, x, B, T, km, flash, lse_n)
-            # gradient_checkpointing (train_ilql_gpt2.py:201-202): keep only the block input; backward() recomputes the block — the same
-            # launches on the same inputs, i.e. bit-identical intermediates — right before it differentiates it
+            x_out, nxt, c = self._layer_forward(l, x, B, T, km, flash, lse_n, resid_in=pending)
+            # gradient_checkpointing (train_ilql_gpt2.py:201-202): keep only the block input (x: complete once the block's ln_1 launch has added the
+            # pending residual in place); backward() recomputes the block — the same launches on the same inputs, i.e. bit-identical
+            # intermediates — right before it differentiates it
             cache["layers"].append(dict(x_in=x) if self.gradient_checkpointing else c)
-            x = x_out
+            x, pending = x_out, nxt
         hid, cache["mf"], cache["rf"] = new(R, d), new(R), new(R)
-        ops.layernorm_fwd(x, p["ln_f.weight"], p["ln_f.bias"], hid, cache["mf"], cache["rf"], R, d, self.eps)
+        ops.layernorm_add_fwd(x, pending, p["ln_f.weight"], p["ln_f.bias"], hid, cache["mf"], cache["rf"], None, 0, R, d, self.eps)
         cache["x_final"] = x
         cache["hidden"] = hid
         return hid, cache
@@ -314,7 +321,7 @@ class GPT2F32:
             q = f"h.{l}."
             c = cache["layers"][l]
             if "h1" not in c:              # checkpointed block: recompute its intermediates from the stored input
-                _, c = self._layer_forward(l, c["x_in"], B, T, cache["km"], cache["flash"], cache["lse_n"])
+                _, _, c = self._layer_forward(l, c["x_in"], B, T, cache["km"], cache["flash"], cache["lse_n"])
             # MLP: x_out = x_mid + gelu(h2 W_fc + b) W_proj + b
             dfb = None
             if mm is not None and dxb[0] is not None and c.get("gb") is not None and ops.fused_ok(self.d_ff, ops.FUSE_GELU_BWD):
@@ -391,7 +398,7 @@ class LinearHeadF32:
         self.t, self.dev = torch, device
         self.p = {k: v.to(device, torch.float32).contiguous() for k, v in params.items()}   # kernel [in,out], bias [out]
         self.din, self.dout = self.p["kernel"].shape
-        self._ws = torch.empty(64 * max(self.dout, 1), dtype=torch.float32, device=device)
+        self._ws = torch.empty(64 * max(self.dout, self.din), dtype=torch.float32, device=device)   # colsum / matrix-vector scratch
         self.mm = ops.MatmulBF16(device) if matmul == "bf16" and self.dout >= 64 else None
         self.ld_out = ops._pad(self.dout) if self.mm is not None else self.dout
 
@@ -442,6 +449,19 @@ class MLPHeadF32:
         z = t.empty(rows, self.dh, dtype=t.float32, device=self.dev)
         ops.linear_fwd(x, self.p["dense1.kernel"], self.p["dense1.bias"], z, rows, self.din, self.dh, mm=self.mm)
         a = t.empty_like(z)
+        if getattr(self, "branch_z", None) is not None:
+            # tests only (cross-checks of two arithmetic paths): evaluate the head on a GIVEN side of relu for every hidden unit — `branch_z` =
+            # (row indices or None, pre-activations of another run of the same head on those rows).  relu' jumps at 0; two fp32 paths put a
+            # handful of the millions of units on different sides, and each such unit moves one token's whole backward signal.
+            rows_idx, zb = self.branch_z
+            zz = z.clone()
+            if rows_idx is None:
+                zz.copy_(zb)
+            else:
+                zz[rows_idx.long()] = zb
+            self.branch_flips = int(((zz > 0) != (z > 0)).sum())
+            t.mul(z, (zz > 0).to(z.dtype), out=a)
+            return a, zz
         ops.relu_fwd(z, a)
         return a, z
 

@@ -220,7 +220,11 @@ def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_b
     if mm is None:
         if dx is not None:
             sgemm(dy, w, dx, rows, k, n, trans_b=True, lda=lddy, ldb=n, ldc=k, beta=dx_beta)
-        sgemm(x, dy, dw, k, n, rows, trans_a=True, lda=k, ldb=lddy, ldc=n, beta=1.0 if accumulate_dw else 0.0)
+        if n == 1 and ws.numel() >= 64 * k:     # one output unit (value heads): x^T dy is a matrix-vector product, not 12 sgemm tiles over K = rows
+            _lib.check(_L().lmrl_colsum_weighted(x.data_ptr(), rows, k, k, dy.data_ptr(), lddy, dw.data_ptr(), int(accumulate_dw), ws.data_ptr(), _sp()),
+                       "lmrl_colsum_weighted")
+        else:
+            sgemm(x, dy, dw, k, n, rows, trans_a=True, lda=k, ldb=lddy, ldc=n, beta=1.0 if accumulate_dw else 0.0)
     else:
         assert dx_beta in (0.0, 1.0)
         if dx is not None:
@@ -282,6 +286,16 @@ def layernorm_fwd(x, g, b, y, mean, rstd, rows, d, eps):
 def layernorm_fwd_staged(x, g, b, y, mean, rstd, yb, ldb, rows, d, eps):
     _lib.check(_L().lmrl_layernorm_fwd_staged(x.data_ptr(), g.data_ptr(), b.data_ptr(), _lib.ptr(y), mean.data_ptr(), rstd.data_ptr(), yb.data_ptr(), ldb,
                                               rows, d, float(eps), _sp()), "lmrl_layernorm_fwd_staged")
+
+
+# the residual adds of a block folded into the LayerNorm behind them (lmrl_layernorm_add_fwd); False: one axpby launch per add (A/B hook)
+FUSE_ADD_LN = True
+
+
+def layernorm_add_fwd(x, resid, g, b, y, mean, rstd, yb, ldb, rows, d, eps):
+    """x += resid (None: no add), then y / yb = LayerNorm(x) — one pass; x is updated in place."""
+    _lib.check(_L().lmrl_layernorm_add_fwd(x.data_ptr(), _lib.ptr(resid), g.data_ptr(), b.data_ptr(), _lib.ptr(y), mean.data_ptr(), rstd.data_ptr(),
+                                           _lib.ptr(yb), ldb, rows, d, float(eps), _sp()), "lmrl_layernorm_add_fwd")
 
 
 def gelu_fwd_staged(x, y, yb, ldb, rows, cols):

@@ -12,6 +12,11 @@ Two layers of evidence, both at GPT-2-small's full depth (12 layers, d = 768, 12
      (`lmrl_sgemm_set_variant(1)`).  Different kernels, different association orders (fp32 sums over K = 16 384 / 32 768 rows in two
      different orders): loss / logs within 2e-5 relative; gradients: relative L2 error of every tensor <= 5e-4 and every entry within 3e-3
      of the tensor's largest entry (`_same_gradient`).  (a) ties the family of paths to float64; (b) carries it to the timed size.
+relu branches: the MLP heads' relu' jumps at 0; among the millions of hidden units of a step a handful have |pre-activation| below the fp32
+error, and the two sides of a comparison can put them on different sides — ONE such unit changes a token's whole backward signal (measured: 3
+units -> 4e-4 relative L2 on every gradient tensor vs float64).  Both layers therefore compare on the SAME piecewise-linear branch: the float64
+anchor takes each unit's side from the device's pre-activations, the second path from the first path's (`MLPHeadF32.branch_z`); the number of
+units involved is printed and bounded.
 Reference: LLM_RL/algorithms/ilql/gpt2/interface.py:88-367, ppo/gpt2/interface.py:72-211, train_ilql_gpt2.py:58,65, train_ppo_gpt2.py:74-75.
 """
 import numpy as np
@@ -97,6 +102,19 @@ def test_ilql_step_12_layers_T512_vs_float64(dev):
     dones = np.array([1, 0, 0, 1], dtype=np.float32)
     hq1, hq2, hv = _heads(d, torch.Generator().manual_seed(11), (V, V, 1))
     kw = dict(gamma=0.99, tau=0.7, cql_weight=0.01)
+    # the device step first: its heads' pre-activations say which side of relu every hidden unit took (see `mh` below)
+    base = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
+    tbase = GPT2F32({k: v.clone() for k, v in tsd.items()}, cfg.n_head, device=dev)
+    assert base.attention == "flash"
+    cp = lambda h: {k: v.clone() for k, v in h.items()}
+    tr = ilql.GPT2ILQLTrain(base, MLPHeadF32(cp(hq1), dev), MLPHeadF32(cp(hq2), dev), MLPHeadF32(cp(hv), dev), pad, kw,
+                            target_base=tbase, lr=1e-4, polyak_alpha=0.005)
+    assert tr.compact_q_rows
+    tr.keep_head_caches = True
+    _, loss, logs = tr.step(ids, sta, rewards, dones)
+    q1c, q2c, vc, q_rows = tr.last_head_caches
+    assert q_rows is not None and len(q_rows) == int(sta.sum())
+
     psd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
     req = lambda h: {k: v.double().requires_grad_(True) for k, v in h.items()}
     rq1, rq2, rv = req(hq1), req(hq2), req(hv)
@@ -105,8 +123,30 @@ def test_ilql_step_12_layers_T512_vs_float64(dev):
     _, hid = O.forward(psd, idt, cfg.n_head, attention_mask=am, position_ids=pos, return_hidden=True)
     with torch.no_grad():
         _, thid = O.forward({k: v.double() for k, v in tsd.items()}, idt, cfg.n_head, attention_mask=am, position_ids=pos, return_hidden=True)
-    mh = lambda x, h: rl.mlp_head(x, h["dense1.kernel"], h["dense1.bias"], h["dense2.kernel"], h["dense2.bias"])
-    q1o, q2o, vo = mh(hid, rq1), mh(hid, rq2), mh(hid, rv)
+
+    def mh(x, h, dev_z=None, rows=None):
+        """heads/mlp_head.py:139-148 in float64.  relu'(z) jumps at z = 0 and ~2.3 M hidden units x 1e-6 relative fp32 error leave a handful of
+        units whose fp32 pre-activation has the other sign than the float64 one; each such unit moves one token's whole backward signal (measured:
+        4e-4 relative L2 on EVERY gradient tensor from one flipped unit).  The device differentiates the function IT evaluated, so the anchor takes
+        the branch of every unit from the device (`dev_z` > 0 on `rows`, float64's own sign elsewhere: rows no loss term reads) — values agree
+        to ~1e-6 either way (the disagreeing units have |z| ~ 1e-6), gradients are then comparable at the 3e-4 bound below."""
+        z = x @ h["dense1.kernel"] + h["dense1.bias"]
+        mask = (z.detach() > 0)
+        if dev_z is not None:
+            flat = mask.reshape(-1, mask.shape[-1]).clone()
+            dz = (dev_z.detach().cpu() > 0)
+            if rows is None:
+                n_flip = int((flat != dz).sum())
+                flat = dz
+            else:
+                ridx = torch.from_numpy(np.asarray(rows, dtype=np.int64))
+                n_flip = int((flat[ridx] != dz).sum())
+                flat[ridx] = dz
+            print(f"relu units on the other side of zero than in float64: {n_flip}")
+            assert n_flip <= 64, n_flip                      # a handful of near-zero units, not a different function
+            mask = flat.reshape(mask.shape)
+        return (z * mask.double()) @ h["dense2.kernel"] + h["dense2.bias"]
+    q1o, q2o, vo = mh(hid, rq1, q1c["z"], q_rows), mh(hid, rq2, q2c["z"], q_rows), mh(hid, rv, vc["z"])
     with torch.no_grad():
         tq1o, tq2o = mh(thid, {k: v.detach() for k, v in rq1.items()}), mh(thid, {k: v.detach() for k, v in rq2.items()})
     q1, q2, v, v_final, tq1, tq2 = rl.ilql_gather_qv(q1o, q2o, vo, tq1o, tq2o, idt, am, torch.from_numpy(sta), torch.from_numpy(dones))
@@ -114,14 +154,6 @@ def test_ilql_step_12_layers_T512_vs_float64(dev):
     loss_ref, logs_ref = rl.ilql_loss(q1, q2, v, v_final, tq1, tq2, q1o[:, :-1], q2o[:, :-1], idt[:, 1:], am[:, 1:].double(),
                                       torch.from_numpy(sta), torch.from_numpy(rewards).double(), **kw)
     loss_ref.backward()
-    base = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev)
-    tbase = GPT2F32({k: v.clone() for k, v in tsd.items()}, cfg.n_head, device=dev)
-    assert base.attention == "flash"
-    cp = lambda h: {k: v.clone() for k, v in h.items()}
-    tr = ilql.GPT2ILQLTrain(base, MLPHeadF32(cp(hq1), dev), MLPHeadF32(cp(hq2), dev), MLPHeadF32(cp(hv), dev), pad, kw,
-                            target_base=tbase, lr=1e-4, polyak_alpha=0.005)
-    assert tr.compact_q_rows
-    _, loss, logs = tr.step(ids, sta, rewards, dones)
     assert abs(loss - float(loss_ref)) <= 1e-4 * abs(float(loss_ref)), (loss, float(loss_ref))
     rf, gf = _flat_logs(logs_ref), _flat_logs(logs)
     assert set(rf) == set(gf)
@@ -213,15 +245,31 @@ def test_ilql_step_at_bench_size_default_path_equals_second_path(dev):
     heads = _heads(cfg.d_model, torch.Generator().manual_seed(21), (V, V, 1))
     kw = dict(gamma=0.99, tau=0.7, cql_weight=0.01)
 
+    branches = {}
+
     def run(attention, compact):
         base = GPT2F32({k: v.clone() for k, v in sd.items()}, cfg.n_head, device=dev, attention=attention)
         tbase = GPT2F32({k: v.clone() for k, v in tsd.items()}, cfg.n_head, device=dev, attention=attention)
         cp = lambda h: {k: v.clone() for k, v in h.items()}
-        tr = ilql.GPT2ILQLTrain(base, MLPHeadF32(cp(heads[0]), dev), MLPHeadF32(cp(heads[1]), dev), MLPHeadF32(cp(heads[2]), dev), pad, kw,
-                                target_base=tbase, lr=3e-5, compact_q_rows=compact)
+        hs = [MLPHeadF32(cp(h), dev) for h in heads]
+        tr = ilql.GPT2ILQLTrain(base, hs[0], hs[1], hs[2], pad, kw, target_base=tbase, lr=3e-5, compact_q_rows=compact)
+        if branches:
+            # second run: every relu unit on the side the first run put it (MLPHeadF32.branch_z: relu' jumps at 0, the two paths' fp32
+            # pre-activations differ in the last bits, and ONE unit on the other side moves a token's whole backward signal — measured 7e-4
+            # relative L2 on layer-0 gradients from a dozen such units among 19 M).  The Q heads ran on the compacted rows in the first run.
+            ridx = torch.from_numpy(branches["rows"].astype(np.int64)).to(dev)
+            hs[0].branch_z, hs[1].branch_z, hs[2].branch_z = (ridx, branches["q1"]), (ridx, branches["q2"]), (None, branches["v"])
+        tr.keep_head_caches = True
         _, loss, logs = tr.step(ids, sta, rewards, dones)
+        if not branches:
+            q1c, q2c, vc, q_rows = tr.last_head_caches
+            branches.update(q1=q1c["z"].clone(), q2=q2c["z"].clone(), v=vc["z"].clone(), rows=np.asarray(q_rows))
+        else:
+            flips = [h.branch_flips for h in hs]
+            print(f"relu units the second path alone would put on the other side: {flips}")
+            assert sum(flips) <= 256, flips                # a handful among 19 M: the same function, not a different one
         out = (loss, _flat_logs(logs), _grads_to_host(tr.last_grads))
-        del tr, base, tbase
+        del tr, base, tbase, hs
         torch.cuda.empty_cache()
         return out
     loss_a, logs_a, g_a = run("flash", True)

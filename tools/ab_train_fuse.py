@@ -13,9 +13,10 @@ from lmrl_gym_amd.train import ops
 mode = sys.argv[1] if len(sys.argv) > 1 else "ilql-step"
 world, rank, dev, backend, use_dist = bench._dist_setup(torch)
 for rep in range(2):
-    for fuse, variant in ((True, 0), (False, 0), (True, 108), (False, 108)):
+    for fuse, variant, add_ln in ((True, 0, True), (True, 0, False), (False, 0, False), (False, 108, False)):
         ops.FUSE_EPILOGUES = 7 if fuse else 0
+        ops.FUSE_ADD_LN = add_ln
         _lib.lib().lmrl_gemm_set_variant(variant)
         r = bench.run_train_step(mode, "bf16", 32, 6, 2, dev, 0, 1, False, "nccl")
-        print(f"fused={fuse!s:5s} tiles={'r3' if variant == 0 else 'r2'}  {r['ms_per_step']:7.2f} ms  loss {r['last_loss']}", flush=True)
+        print(f"add_ln={add_ln!s:5s} fused={fuse!s:5s} tiles={'r3' if variant == 0 else 'r2'}  {r['ms_per_step']:7.2f} ms  loss {r['last_loss']}", flush=True)
 _lib.lib().lmrl_gemm_set_variant(0)
