@@ -541,7 +541,8 @@ int lmrl_sgemm(int trans_a, int trans_b, int m, int n, int k, float alpha, const
                long sc_outer, long sc_inner, int nb_outer, int nb_inner, const float *bias_d, void *stream);
 /* A/B hook: 0 = auto (128x128 tiles when m, n >= 128), 1 = always the 64x64-tile kernel */
 void lmrl_sgemm_set_variant(int v);
-/* TOOLS / TESTS ONLY: bit 0 = LayerNorm forward on the strided one-pass-per-moment kernel (A/B of lmrl_layernorm_add_fwd's register-row kernel) */
+/* TOOLS / TESTS ONLY: bit 0 = LayerNorm forward, bit 1 = fused LayerNorm backward on the strided 4-byte-access kernels (A/B of the 16-byte-access
+ * register-row kernels) */
 void lmrl_train_ops_set_variant(int v);
 int lmrl_embed_fwd(const float *wte_d, const float *wpe_d, const int32_t *ids_d, const int32_t *pos_d, float *x_d, int rows, int d, void *stream);
 int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d, float *dwte_d, float *dwpe_d, int rows, int d, void *stream);
@@ -623,6 +624,15 @@ int lmrl_flash_attn_bwd_staged(const float *qkv_d, const uint8_t *key_mask_d, co
  * lmrl_cast_bf16: dst [rows_dst][ld_dst] bf16 := round-to-nearest-even of src [rows][cols] fp32 (transpose = 0) or of its transpose
  * (transpose = 1: dst[c][r] = src[r][c]); everything outside the source extent is zero-filled (K padding to multiples of 64). */
 int lmrl_cast_bf16(const float *src_d, long ld_src, int rows, int cols, void *dst_d, long ld_dst, int rows_dst, int transpose, void *stream);
+/* The bf16 staging of EVERY weight matrix of a parameter arena in one launch (per train step the fp32 masters move: the natural copy [rows][ld_nat]
+ * feeds the dX products, the transposed copy [cols][ld_t] the forward products).  Offsets in elements: src_off into src_d (fp32, dense
+ * [rows][cols]), nat_off / t_off into dst_d (bf16; < 0: that copy is not wanted); tile0 = number of 64 x 64 tiles of the segments before this one,
+ * total_tiles = their sum over all segments.  Only source extents are written — zero-fill dst_d once. */
+typedef struct {
+    long src_off, nat_off, t_off;
+    int rows, cols, ld_nat, ld_t, tile0, pad_;
+} lmrl_cast_seg;
+int lmrl_cast_bf16_segments(const float *src_d, const lmrl_cast_seg *segs_d, int nseg, int total_tiles, void *dst_d, void *stream);
 /* "bf16 x 3" operand of an fp32 matrix: dst [rows][ld_dst >= 3 cols] bf16 := [hi(x) | lo(x) | hi(x)], hi = bf16(x), lo = bf16(x - hi).  Against
  * weight rows [hi(w) | hi(w) | lo(w)], lmrl_gemm_bf16 with K' = 3 cols accumulates hi.hi + lo.hi + hi.lo in fp32: ~16 mantissa bits per product at
  * 3x the bf16 MFMA cost (the f32-input MFMA costs 16x) — the matmul mode "bf16x3" of the fp32 rollout engine (GPT2EngineF32). */

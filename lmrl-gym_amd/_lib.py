@@ -100,6 +100,7 @@ _SIGS = {
                            ctypes.c_long, ctypes.c_long, c_float, c_void_p, c_int, ctypes.c_long, ctypes.c_long, c_int, c_int, c_void_p, c_void_p]),
     "lmrl_embed_fwd": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "lmrl_cast_bf16": (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]),
+    "lmrl_cast_bf16_segments": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lmrl_split3_bf16": (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, ctypes.c_long, c_void_p]),
     "lmrl_cast_bf16_t_colsum_ws_bytes": (c_size_t, [c_int, c_int]),
     "lmrl_cast_bf16_t_colsum": (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, ctypes.c_long, c_int, c_void_p, c_int, c_void_p, c_void_p]),

@@ -66,6 +66,69 @@ __global__ __launch_bounds__(128) void split3_bf16_kernel(const float *__restric
     }
 }
 
+// All weight matrices of a parameter arena in ONE launch (the per-step bf16 staging of the fp32 masters: ~170 launches of 7 - 9 us for
+// GPT-2-small's policy + target otherwise).  Segment i: src + src_off is a [rows][cols] fp32 matrix (dense); workgroups [tile0, tile0 + tiles)
+// own its 64 x 64 tiles; the natural copy goes to dst + nat_off ([rows][ld_nat], skipped when nat_off < 0), the transposed copy to
+// dst + t_off ([cols][ld_t], skipped when t_off < 0).  Only the source extent is written: the caller zero-fills the destination once.
+__global__ __launch_bounds__(256) void cast_bf16_segments_kernel(const float *__restrict__ src0, const lmrl_cast_seg *__restrict__ segs, int nseg,
+                                                                 uint16_t *__restrict__ dst0) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = nseg - 1;                  // last segment with tile0 <= blockIdx.x (workgroup-uniform)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const lmrl_cast_seg sg = segs[lo];
+    const int tl = blockIdx.x - sg.tile0, tcn = (sg.cols + 63) / 64;
+    const int r0 = (tl / tcn) * 64, c0 = (tl % tcn) * 64;
+    const float *src = src0 + sg.src_off;
+    const bool vec = (sg.cols & 3) == 0 && (sg.src_off & 3) == 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int idx = threadIdx.x + 256 * k, rl = idx >> 4, c4 = (idx & 15) * 4;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int r = r0 + rl, c = c0 + c4;
+        if (r < sg.rows) {
+            if (vec && c + 4 <= sg.cols) x = *reinterpret_cast<const float4 *>(src + (long)r * sg.cols + c);
+            else {
+                if (c < sg.cols) x.x = src[(long)r * sg.cols + c];
+                if (c + 1 < sg.cols) x.y = src[(long)r * sg.cols + c + 1];
+                if (c + 2 < sg.cols) x.z = src[(long)r * sg.cols + c + 2];
+                if (c + 3 < sg.cols) x.w = src[(long)r * sg.cols + c + 3];
+            }
+        }
+        tile[rl][c4] = x.x; tile[rl][c4 + 1] = x.y; tile[rl][c4 + 2] = x.z; tile[rl][c4 + 3] = x.w;
+    }
+    __syncthreads();
+    const int e8 = (threadIdx.x & 7) * 8, q = threadIdx.x >> 3;
+    if (sg.nat_off >= 0) {                       // natural: row r0 + q (+32), 8 columns from c0 + e8 (ld_nat is a multiple of 64 >= cols: in bounds)
+        uint16_t *dn = dst0 + sg.nat_off;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int rl = q + 32 * k;
+            if (r0 + rl < sg.rows && c0 + e8 < sg.cols) {
+                uint4 o;
+                o.x = pack_bf16x2(tile[rl][e8 + 0], tile[rl][e8 + 1]); o.y = pack_bf16x2(tile[rl][e8 + 2], tile[rl][e8 + 3]);
+                o.z = pack_bf16x2(tile[rl][e8 + 4], tile[rl][e8 + 5]); o.w = pack_bf16x2(tile[rl][e8 + 6], tile[rl][e8 + 7]);
+                *reinterpret_cast<uint4 *>(dn + (long)(r0 + rl) * sg.ld_nat + c0 + e8) = o;
+            }
+        }
+    }
+    if (sg.t_off >= 0) {                         // transposed: row c0 + q (+32), 8 source rows from r0 + e8
+        uint16_t *dt = dst0 + sg.t_off;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int cl = q + 32 * k;
+            if (c0 + cl < sg.cols && r0 + e8 < sg.rows) {
+                uint4 o;
+                o.x = pack_bf16x2(tile[e8 + 0][cl], tile[e8 + 1][cl]); o.y = pack_bf16x2(tile[e8 + 2][cl], tile[e8 + 3][cl]);
+                o.z = pack_bf16x2(tile[e8 + 4][cl], tile[e8 + 5][cl]); o.w = pack_bf16x2(tile[e8 + 6][cl], tile[e8 + 7][cl]);
+                *reinterpret_cast<uint4 *>(dt + (long)(c0 + cl) * sg.ld_t + r0 + e8) = o;
+            }
+        }
+    }
+}
+
 // dst[c][r] = bf16(src[r][c]) for r < rows, c < cols; zero elsewhere in [rows_dst][ld_dst].  64 x 64 tiles through LDS: coalesced 256-B
 // reads along c, 128-B writes along r.
 __global__ __launch_bounds__(256) void cast_bf16_t_kernel(const float *__restrict__ src, long ld_src, int rows, int cols, uint16_t *__restrict__ dst,
@@ -261,6 +324,13 @@ int lmrl_cast_bf16(const float *src_d, long ld_src, int rows, int cols, void *ds
         hipLaunchKernelGGL(cast_bf16_t_kernel, dim3((int)((ld_dst + 63) / 64), (rows_dst + 63) / 64), dim3(256), 0, s, src_d, ld_src, rows, cols,
                            (uint16_t *)dst_d, ld_dst, rows_dst, (float *)nullptr);
     }
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_cast_bf16_segments(const float *src_d, const lmrl_cast_seg *segs_d, int nseg, int total_tiles, void *dst_d, void *stream) {
+    LMRL_REQUIRE(src_d && segs_d && dst_d && nseg > 0 && total_tiles > 0, "lmrl_cast_bf16_segments: bad argument");
+    hipLaunchKernelGGL(cast_bf16_segments_kernel, dim3(total_tiles), dim3(256), 0, as_stream(stream), src_d, segs_d, nseg, (uint16_t *)dst_d);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

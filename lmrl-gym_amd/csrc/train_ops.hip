@@ -245,6 +245,73 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float *__restri
         out[i] = (sm[0][which][c] + sm[1][which][c]) + (sm[2][which][c] + sm[3][which][c]);
     }
 }
+// the same for d = 256 NV with 16-byte accesses: a lane owns columns 4 lane + 256 k + {0..3} (one float4 load of x / dy / dx and one 8-byte
+// bf16 store per 256 columns instead of four 4-byte / 2-byte ones: 70 -> ~45 us on [16384][768], an HBM-bound sweep of 225 MB).  Every
+// column's running sums see the same rows in the same order as in the strided kernel: dgamma / dbeta are bit-identical to it.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_fused_vec_kernel(const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ g,
+                                                               const float *__restrict__ mean, const float *__restrict__ rstd, float *dx,
+                                                               float *__restrict__ partial, int R, int rows_per_wg, int accumulate,
+                                                               uint16_t *__restrict__ dxb, long ldb) {
+    constexpr int d = NV * 256;
+    __shared__ float sm[4][2][d];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float4 gv[NV], ag[NV], ab[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        gv[k] = *reinterpret_cast<const float4 *>(g + k * 256 + lane * 4);
+        ag[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab[k] = ag[k];
+    }
+    const int r_end = min(R, (int)(blockIdx.x + 1) * rows_per_wg);
+    for (int r = blockIdx.x * rows_per_wg + wave; r < r_end; r += 4) {
+        const float mu = mean[r], rs = rstd[r];
+        const float *xr = x + (size_t)r * d + lane * 4, *dyr = dy + (size_t)r * d + lane * 4;
+        float *dxr = dx + (size_t)r * d + lane * 4;
+        float4 xh[NV], dv[NV], acc[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            xh[k] = *reinterpret_cast<const float4 *>(xr + k * 256);
+            dv[k] = *reinterpret_cast<const float4 *>(dyr + k * 256);
+            if (accumulate) acc[k] = *reinterpret_cast<const float4 *>(dxr + k * 256);
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            xh[k].x = (xh[k].x - mu) * rs; xh[k].y = (xh[k].y - mu) * rs; xh[k].z = (xh[k].z - mu) * rs; xh[k].w = (xh[k].w - mu) * rs;
+            const float g0 = dv[k].x * gv[k].x, g1 = dv[k].y * gv[k].y, g2 = dv[k].z * gv[k].z, g3 = dv[k].w * gv[k].w;
+            s1 += (g0 + g1) + (g2 + g3);
+            s2 += (g0 * xh[k].x + g1 * xh[k].y) + (g2 * xh[k].z + g3 * xh[k].w);
+        }
+        s1 = wave_sum(s1) / (float)d; s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            float4 v;
+            v.x = rs * (dv[k].x * gv[k].x - s1 - xh[k].x * s2); v.y = rs * (dv[k].y * gv[k].y - s1 - xh[k].y * s2);
+            v.z = rs * (dv[k].z * gv[k].z - s1 - xh[k].z * s2); v.w = rs * (dv[k].w * gv[k].w - s1 - xh[k].w * s2);
+            if (accumulate) { v.x += acc[k].x; v.y += acc[k].y; v.z += acc[k].z; v.w += acc[k].w; }
+            *reinterpret_cast<float4 *>(dxr + k * 256) = v;
+            if (dxb) {
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16_rne(v.x) | ((uint32_t)f32_to_bf16_rne(v.y) << 16);
+                pk.y = (uint32_t)f32_to_bf16_rne(v.z) | ((uint32_t)f32_to_bf16_rne(v.w) << 16);
+                *reinterpret_cast<uint2 *>(dxb + (size_t)r * ldb + k * 256 + lane * 4) = pk;
+            }
+            ag[k].x += dv[k].x * xh[k].x; ag[k].y += dv[k].y * xh[k].y; ag[k].z += dv[k].z * xh[k].z; ag[k].w += dv[k].w * xh[k].w;
+            ab[k].x += dv[k].x; ab[k].y += dv[k].y; ab[k].z += dv[k].z; ab[k].w += dv[k].w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        *reinterpret_cast<float4 *>(&sm[wave][0][k * 256 + lane * 4]) = ag[k];
+        *reinterpret_cast<float4 *>(&sm[wave][1][k * 256 + lane * 4]) = ab[k];
+    }
+    __syncthreads();
+    float *out = partial + (size_t)blockIdx.x * 2 * d;
+    for (int i = threadIdx.x; i < 2 * d; i += 256) {
+        const int which = i >= d, c = i - which * d;
+        out[i] = (sm[0][which][c] + sm[1][which][c]) + (sm[2][which][c] + sm[3][which][c]);
+    }
+}
 // dgamma[c] (+)= sum_slab partial[slab][0][c], dbeta likewise: 16 columns per workgroup, 16 slab phases per column merged through LDS in a
 // fixed order (2d / 16 workgroups: enough of them to pull the 2 x nslab x d partial matrix at HBM rate)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float *__restrict__ partial, int nslab, int d, float *dgamma, float *dbeta,
@@ -664,15 +731,21 @@ int lmrl_layernorm_bwd_fused(const float *dy_d, const float *x_d, const float *g
     hipLaunchKernelGGL(ln_bwd_fused_kernel<NC_>, dim3(nslab), dim3(256), 0, ST,                                                               \
                        dy_d, x_d, g_d, mean_d, rstd_d, dx_d, ws_d, rows, rpw, accumulate_dx, \
                        (uint16_t *)dxb_d, ldb)
+#define LMRL_LNBV(NV_)                                                                                                                       \
+    hipLaunchKernelGGL(ln_bwd_fused_vec_kernel<NV_>, dim3(nslab), dim3(256), 0, ST,                                                           \
+                       dy_d, x_d, g_d, mean_d, rstd_d, dx_d, ws_d, rows, rpw, accumulate_dx, \
+                       (uint16_t *)dxb_d, ldb)
+    const bool vec = !(g_train_ops_variant & 2) && (!dxb_d || ldb % 4 == 0);
     switch (d / 64) {
         case 2: LMRL_LNB(2); break;
-        case 4: LMRL_LNB(4); break;
-        case 12: LMRL_LNB(12); break;
-        case 16: LMRL_LNB(16); break;
-        case 20: LMRL_LNB(20); break;
+        case 4: if (vec) LMRL_LNBV(1); else LMRL_LNB(4); break;
+        case 12: if (vec) LMRL_LNBV(3); else LMRL_LNB(12); break;
+        case 16: if (vec) LMRL_LNBV(4); else LMRL_LNB(16); break;
+        case 20: if (vec) LMRL_LNBV(5); else LMRL_LNB(20); break;
         default: LMRL_LNB(25); break;
     }
 #undef LMRL_LNB
+#undef LMRL_LNBV
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(ceil_div(2 * d, 16)), dim3(256), 0, ST, ws_d, nslab, d, dgamma_d, dbeta_d, accumulate_dg);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;

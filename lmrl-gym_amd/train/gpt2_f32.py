@@ -195,6 +195,7 @@ class GPT2F32:
         t = self.t
         if self.mm is not None:
             self.mm.begin_step()          # the optimizer may have moved the fp32 masters since the last forward: re-stage the bf16 copies
+            self._stage_weights(True)     # ... of every block's Dense kernels, one launch (the forward operands; backward() adds the dX operands)
         B, T = input_ids.shape
         R, d, H, p = B * T, self.d, self.n_head, self.p
         hd = d // H
@@ -227,6 +228,11 @@ class GPT2F32:
         cache["x_final"] = x
         cache["hidden"] = hid
         return hid, cache
+
+    def _stage_weights(self, transposed: bool):
+        mats = [self.p[f"h.{l}.{n}"] for l in range(self.n_layer) for n in ("attn.c_attn.weight", "attn.c_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight")]
+        if getattr(self.p, "flat", None) is not None and all(m.shape[0] % 64 == 0 and m.shape[1] % 64 == 0 for m in mats):
+            self.mm.stage_arena(self.p.flat, mats, transposed)
 
     def lm_logits(self, hidden, rows: int):
         """logits [rows, ld_vocab] (columns [0, V) valid) = hidden @ wte^T (tied head), fp32 — PPOInference.token_logprobs_from_logits casts
@@ -298,6 +304,8 @@ class GPT2F32:
         new = lambda *shape: t.empty(shape, dtype=t.float32, device=self.dev)
         dx = new(R, d)
         mm = self.mm
+        if mm is not None:
+            self._stage_weights(False)
         dxb = [None]       # bf16-matmul mode: the bf16 copy of dx the LayerNorm backward leaves behind = the dy operand of the next c_proj backward
         if ops.layernorm_bwd_fused_supported(d):
             lws = new(ops.layernorm_bwd_fused_ws_floats(R, d))

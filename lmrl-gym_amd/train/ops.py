@@ -58,6 +58,39 @@ class MatmulBF16:
     def begin_step(self):
         self.w.clear()
 
+    def stage_arena(self, flat, mats, transposed: bool):
+        """Stage the bf16 copies of ALL the Dense kernels `mats` (fp32 [in][out] views into the parameter arena `flat`) in one launch
+        (lmrl_cast_bf16_segments) and register them as this step's kept copies: transposed=True the forward operands ("wT": [pad(out)][pitch(in)]),
+        False the dX operands ("w": [pad(in)][pitch(out)]) — what `cast(..., keep=True)` would produce one launch per matrix."""
+        import numpy as np
+        if not hasattr(self, "_plans"):
+            self._plans = {}
+        key = (flat.data_ptr(), bool(transposed), tuple(w.data_ptr() for w in mats))
+        plan = self._plans.get(key)
+        if plan is None:
+            dt = np.dtype([("src_off", "<i8"), ("nat_off", "<i8"), ("t_off", "<i8"), ("rows", "<i4"), ("cols", "<i4"), ("ld_nat", "<i4"), ("ld_t", "<i4"),
+                           ("tile0", "<i4"), ("pad", "<i4")])
+            assert dt.itemsize == 48
+            segs = np.zeros(len(mats), dtype=dt)
+            off, tile0, views = 0, 0, []
+            for i, w in enumerate(mats):
+                k, n = w.shape
+                assert w.is_contiguous() and (w.data_ptr() - flat.data_ptr()) % 4 == 0
+                rd, ld = (_padn(n), _pitch(k)) if transposed else (_padn(k), _pitch(n))
+                segs[i] = ((w.data_ptr() - flat.data_ptr()) // 4, -1 if transposed else off, off if transposed else -1, k, n,
+                           0 if transposed else ld, ld if transposed else 0, tile0, 0)
+                views.append((off, rd * ld))
+                off += (rd * ld + 127) // 128 * 128
+                tile0 += ((k + 63) // 64) * ((n + 63) // 64)
+            dst = self.t.zeros(off, dtype=self.t.bfloat16, device=self.dev)
+            segs_d = self.t.from_numpy(segs.view(np.uint8).copy()).to(self.dev)
+            plan = self._plans[key] = (segs_d, len(mats), tile0, dst, views)
+        segs_d, nseg, tiles, dst, views = plan
+        _lib.check(_L().lmrl_cast_bf16_segments(flat.data_ptr(), segs_d.data_ptr(), nseg, tiles, dst.data_ptr(), _sp()), "lmrl_cast_bf16_segments")
+        tag = "wT" if transposed else "w"
+        for w, (o, sz) in zip(mats, views):
+            self.w[(tag, w.data_ptr())] = dst[o:o + sz]
+
     def _buf(self, name, numel):
         b = self.scratch.get(name)
         if b is None or b.numel() < numel:

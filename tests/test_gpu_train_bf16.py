@@ -349,3 +349,28 @@ def test_c_fc_gelu_and_gelu_backward_epilogues(dev, R):
     dref = xx.grad
     assert rel(d1, d0) <= 1e-4 and rel(d1, dref) <= rel(d0, dref) * 1.001 + 1e-7, (rel(d1, d0), rel(d1, dref), rel(d0, dref))
     assert float(((d1 - dref).abs() / (dref.abs() + 1e-3)).max()) <= 2.0 ** -8
+
+
+def test_arena_weight_staging_equals_per_matrix_casts(dev):
+    """lmrl_cast_bf16_segments (all Dense kernels of an arena, one launch) leaves the same bf16 operands as one lmrl_cast_bf16 per matrix."""
+    from lmrl_gym_amd.train import ops
+    g = torch.Generator().manual_seed(3)
+    shapes = [(768, 2304), (768, 768), (3072, 768), (64, 192), (128, 512)]
+    flat = torch.randn(sum(k * n for k, n in shapes) + 64, generator=g).to(dev)
+    mats, off = [], 32
+    for k, n in shapes:
+        mats.append(flat[off:off + k * n].view(k, n))
+        off += k * n
+    for transposed in (True, False):
+        mm, ref = ops.MatmulBF16(dev), ops.MatmulBF16(dev)
+        mm.stage_arena(flat, mats, transposed)
+        for w in mats:
+            k, n = w.shape
+            if transposed:
+                want = ref.cast(("wT", w.data_ptr()), w, k, n, n, transpose=True, keep=True)
+                got = mm.w[("wT", w.data_ptr())]
+            else:
+                want = ref.cast(("w", w.data_ptr()), w, k, n, n, keep=True)
+                got = mm.w[("w", w.data_ptr())]
+            torch.cuda.synchronize()
+            assert got.numel() == want.numel() and torch.equal(got, want), (k, n, transposed)
