@@ -339,6 +339,15 @@ size_t lmrl_gemm_bf16_splitk_ws_bytes(int m, int n, int k);
 int lmrl_gemm_bf16_splitk(const void *a_d, const void *w_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc, int n_store, int accumulate,
                           void *ws_d, void *stream);
 
+/* The same product on the operands as their producers staged them — a_d = x [k][lda], w_d = dy [k][ldw], both bf16 with k = B*T rows:
+ * c[m][n] (=|+=) sum_kk a[kk][m] * w[kk][n]  (m, n multiples of 128, k of 64; a 128 x 128 split-K plan must exist: lmrl_gemm_bf16_splitk_ws_bytes).
+ * No transposed copy of x or dy is needed (the kernel gathers MFMA operands with ds_read_b64_tr_b16). */
+int lmrl_gemm_bf16_splitk_kmajor(const void *a_d, const void *w_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc, int n_store, int accumulate,
+                                 void *ws_d, void *stream);
+/* colsum_d[c] (=|+=) sum_r src[r][c] of a staged bf16 matrix [rows][ld_src] — a Dense layer's bias gradient from its staged dy; ws_d: at least
+ * ceil(rows / 64) * cols floats.  Deterministic (fixed partition and order). */
+int lmrl_colsum_bf16(const void *src_d, long ld_src, int rows, int cols, float *colsum_d, int accumulate, float *ws_d, void *stream);
+
 /* TOOLS ONLY (tools/bench_gemm.py tile-configuration sweeps; never called by the package): forces a GEMM tile configuration,
  * 0 = the shape policy, 1 = the round-1 register-staged kernels, 10.. = fixed tiles. */
 void lmrl_gemm_set_variant(int v);

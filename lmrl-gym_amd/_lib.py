@@ -105,6 +105,8 @@ _SIGS = {
     "lmrl_cast_bf16_t_colsum_ws_bytes": (c_size_t, [c_int, c_int]),
     "lmrl_cast_bf16_t_colsum": (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, ctypes.c_long, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "lmrl_gemm_bf16_splitk_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "lmrl_gemm_bf16_splitk_kmajor": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "lmrl_colsum_bf16": (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "lmrl_gemm_bf16_splitk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lmrl_ce_bwd_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_long, c_int, c_void_p]),
     "lmrl_transpose_bf16_colsum": (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, ctypes.c_long, c_int, c_void_p, c_int, c_void_p,

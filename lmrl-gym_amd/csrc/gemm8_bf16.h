@@ -32,7 +32,21 @@ struct G8NoHook { __device__ __forceinline__ void operator()() const {} };
 // can be called repeatedly on the same LDS ring (fused multi-operand kernels).  `head()` runs right after the ring prologue has been
 // issued: either plain global loads whose results are first used after the loop (they fly under it), or a block that ends with
 // vmcnt(0) (the LayerNorm moments, which need LDS scratch OUTSIDE the ring: every slot is being filled).
-template <int BM, int BN, int WM, int WN, int STAGES, class Head = G8NoHook>
+// KM ("K-major in memory", the train step's weight-gradient products dW = x^T . dy on the operands as their producers left them): A is
+// [K][lda >= M] and W is [K][ldw >= N] — row kk holds x[kk][:] / dy[kk][:] — instead of [M][K] / [N][K].  A stage is then 64 kk-rows of BM (BN)
+// columns; one wave-wide global_load_lds covers 4 rows x 256 B (BM = BN = 128), and the MFMA operand "8 consecutive kk of column m" is gathered
+// by two ds_read_b64_tr_b16 (each hands lane (i, g) column i of a [4 kk][16 col] block whose sixteen 8-byte row pieces the group's lanes
+// address: tools/tr_probe.hip).  The 32-byte column chunks of row r sit at chunk index c ^ key(r), key = (r & 3) | ((r >> 3) & 1) << 2, applied
+// on the SOURCE address of the lane-linear load: the 32 lanes of a half-wave then read 8 distinct chunks = all 64 banks once.  No transposed
+// copy of x or dy is ever written (98 transpose launches, 2.6 ms of a 37.6 ms ILQL step: profiles/r03_ilql_bf16_step_kernel_stats_fused_epilogues.csv).
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 g8_tr_frag(const char *p) {
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t *)(p));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t *)(p + 1024));   // 4 rows of 256 B further
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, class Head = G8NoHook, bool KM = false>
 __device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int lda, const uint16_t *__restrict__ W, int ldw, int K, int Mr, int m0,
                                             int n0,
                                             char *smem, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], Head head = Head()) {
@@ -52,14 +66,30 @@ __device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int 
 
     const uint16_t *ap[LA];
     const uint16_t *wp[LW];
+    if constexpr (KM) {
+        static_assert(BM == 128 && BN == 128, "K-major operands: 256-byte tile rows (128 x 128 tiles)");
 #pragma unroll
-    for (int i = 0; i < LA; i++) {
-        int m = m0 + (wave + NW * i) * 8 + lrow;
-        m = m < Mr ? m : Mr - 1;
-        ap[i] = A + (size_t)m * lda + src_c * 8;
+        for (int i = 0; i < LA; i++) {
+            const int r = 4 * (wave + NW * i) + (lane >> 4), key = (r & 3) | (((r >> 3) & 1) << 2);
+            ap[i] = A + (size_t)r * lda + m0 + ((((lane & 15) >> 1) ^ key) << 4) + (lane & 1) * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < LW; i++) {
+            const int r = 4 * (wave + NW * i) + (lane >> 4), key = (r & 3) | (((r >> 3) & 1) << 2);
+            wp[i] = W + (size_t)r * ldw + n0 + ((((lane & 15) >> 1) ^ key) << 4) + (lane & 1) * 8;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < LA; i++) {
+            int m = m0 + (wave + NW * i) * 8 + lrow;
+            m = m < Mr ? m : Mr - 1;
+            ap[i] = A + (size_t)m * lda + src_c * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < LW; i++) wp[i] = W + (size_t)(n0 + (wave + NW * i) * 8 + lrow) * ldw + src_c * 8;
     }
-#pragma unroll
-    for (int i = 0; i < LW; i++) wp[i] = W + (size_t)(n0 + (wave + NW * i) * 8 + lrow) * ldw + src_c * 8;
+    const size_t kstep_a = KM ? (size_t)BK * lda : (size_t)BK, kstep_w = KM ? (size_t)BK * ldw : (size_t)BK;   // elements per K-step
+    const int km_key = (lr >> 2) | ((lq & 1) << 2), km_row = 8 * lq + (lr >> 2), km_piece = (lr & 3) * 8;            // KM fragment gather
 
 #ifndef LMRL_G8_W_AUX
 #define LMRL_G8_W_AUX 0   /* cache policy bits of the weight-stream loads (tools: -DLMRL_G8_W_AUX=2 = nt) */
@@ -68,16 +98,24 @@ __device__ __forceinline__ void g8_mainloop(const uint16_t *__restrict__ A, int 
     do {                                                                                                              \
         char *sb_ = smem + (SLOT) * STAGE;                                                                            \
         _Pragma("unroll") for (int i_ = 0; i_ < LA; i_++)                                                             \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ap[i_] + (size_t)(KT) * BK), \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ap[i_] + (size_t)(KT) * kstep_a), \
                                              (__attribute__((address_space(3))) void *)(sb_ + (wave + NW * i_) * 1024), 16, 0, 0); \
         _Pragma("unroll") for (int i_ = 0; i_ < LW; i_++)                                                             \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wp[i_] + (size_t)(KT) * BK), \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wp[i_] + (size_t)(KT) * kstep_w), \
                                              (__attribute__((address_space(3))) void *)(sb_ + BM * 128 + (wave + NW * i_) * 1024), 16, 0, LMRL_G8_W_AUX); \
     } while (0)
 #define LMRL_G8_READ(FW, FA, SLOT, KK)                                                                                \
     do {                                                                                                              \
         const char *sA_ = smem + (SLOT) * STAGE;                                                                      \
         const char *sW_ = sA_ + BM * 128;                                                                             \
+        if constexpr (KM) {                                                                                           \
+            const int ro_ = ((KK) * 32 + km_row) * 256 + km_piece;                                                    \
+            _Pragma("unroll") for (int i_ = 0; i_ < FN; i_++)                                                         \
+                FW[i_] = g8_tr_frag(sW_ + ro_ + (((wn * FN + i_) ^ km_key) << 5));                                    \
+            _Pragma("unroll") for (int j_ = 0; j_ < FM; j_++)                                                         \
+                FA[j_] = g8_tr_frag(sA_ + ro_ + (((wm * FM + j_) ^ km_key) << 5));                                    \
+            break;                                                                                                    \
+        }                                                                                                             \
         const int c_ = (KK) * 4 + lq;                                                                                 \
         _Pragma("unroll") for (int i_ = 0; i_ < FN; i_++) {                                                           \
             const int row_ = wn * TN + i_ * 16 + lr;                                                                  \
@@ -168,6 +206,9 @@ __device__ __forceinline__ void g8_mainloop_pair(const uint16_t *__restrict__ A,
     const int lr = lane & 15, lq = lane >> 4;
     const int np = K / BK / 2;                              // pairs of K-steps
     const int lrow = lane >> 3, src_c = (lane & 7) ^ lrow;
+    constexpr bool KM = false;                              // (the shared ISSUE / READ macros: K-major operands run on g8_mainloop only)
+    constexpr size_t kstep_a = BK, kstep_w = BK;
+    constexpr int km_key = 0, km_row = 0, km_piece = 0;
     const uint16_t *ap[LA];
     const uint16_t *wp[LW];
 #pragma unroll
@@ -220,7 +261,7 @@ __device__ __forceinline__ void g8_mainloop_pair(const uint16_t *__restrict__ A,
 // tiles): the grid holds kv_tmax = S copies of the tile grid; copy z accumulates K-steps [z * kv_d, min(K, (z + 1) * kv_d)) and stores its
 // partial tile to C + z * M * ldc (splitk_reduce_kernel adds the copies in a fixed order).  The two ints alias the kv_* fields, which only
 // EPI_BF16_LN_KV reads: no other instantiation's argument block changes.
-template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0, bool PAIR = false, bool SPLITK = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0, bool PAIR = false, bool SPLITK = false, bool KM = false>
 __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap xm) {
     static_assert(!PAIR || STAGES == 4, "the paired K loop runs on a 4-slot ring");
     constexpr int NW = WM * WN, NT = NW * 64;
@@ -237,7 +278,8 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
         const int per = gridDim.x / g.kv_tmax, z = wg_id / per;      // per is a multiple of 8: id % 8 (the XCD) is unchanged
         wg_id -= z * per;
         const int k0 = z * g.kv_d;
-        g.A += k0; g.W += k0;
+        if constexpr (KM) { g.A += (size_t)k0 * g.lda; g.W += (size_t)k0 * (g.ldw > 0 ? g.ldw : g.N); }
+        else { g.A += k0; g.W += k0; }
         g.K = min(g.kv_d, g.K - k0);
         g.C = reinterpret_cast<float *>(g.C) + (size_t)z * g.M * g.ldc;
     }
@@ -319,7 +361,8 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
         };
         g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, prefetch);
     } else {
-        if constexpr (PAIR) g8_mainloop_pair<BM, BN, WM, WN>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc);
+        if constexpr (KM) g8_mainloop<BM, BN, WM, WN, STAGES, G8NoHook, true>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.N, g.K, Mr, m0, n0, smem, acc);
+        else if constexpr (PAIR) g8_mainloop_pair<BM, BN, WM, WN>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc);
         else g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc);
     }
     LMRL_G8_STAMP(2);
@@ -535,7 +578,7 @@ inline hipError_t gemm8_launch(const GemmArgs &g, hipStream_t s) {
 }
 
 // Split-K launch of the fp32-output kernel: S copies of the tile grid, partials to ws [S][M][ldc = N] (see gemm8_kernel<.., SPLITK>).
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, bool KM = false>
 inline hipError_t gemm8_launch_splitk(GemmArgs g, float *ws, int S, int kchunk, hipStream_t s) {
     constexpr size_t shmem = (size_t)STAGES * (BM + BN) * 128;
     const XcdMap xm = make_xcd_map((g.M + BM - 1) / BM, g.N / BN, 2.0 * g.M * g.K / S, 2.0 * g.N * g.K / S);
@@ -544,12 +587,12 @@ inline hipError_t gemm8_launch_splitk(GemmArgs g, float *ws, int S, int kchunk, 
     g.kv_tmax = S; g.kv_d = kchunk;
     static bool attr_set = false;
     if (!attr_set && shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8_kernel<BM, BN, WM, WN, STAGES, EPI_F32, 0, false, true>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8_kernel<BM, BN, WM, WN, STAGES, EPI_F32, 0, false, true, KM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm8_kernel<BM, BN, WM, WN, STAGES, EPI_F32, 0, false, true>), dim3(tiles * S), dim3(WM * WN * 64), shmem, s, g, xm);
+    hipLaunchKernelGGL((gemm8_kernel<BM, BN, WM, WN, STAGES, EPI_F32, 0, false, true, KM>), dim3(tiles * S), dim3(WM * WN * 64), shmem, s, g, xm);
     return hipGetLastError();
 }
 

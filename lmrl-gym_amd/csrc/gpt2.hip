@@ -1335,6 +1335,27 @@ int lmrl_gemm_bf16_splitk(const void *a_d, const void *w_d, void *c_d, int m, in
     return LMRL_OK;
 }
 
+// dW = x^T . dy on the operands as their producers staged them: a_d = x [k][lda] (k = B*T rows, m = layer input width), w_d = dy [k][ldw];
+// c[m][n] (=|+=) sum_kk a[kk][m] w[kk][n].  Same split-K plan / reduce as lmrl_gemm_bf16_splitk; the kernel gathers its MFMA operands with
+// ds_read_b64_tr_b16 (gemm8_bf16.h, KM), so no transposed copy of either operand exists.
+int lmrl_gemm_bf16_splitk_kmajor(const void *a_d, const void *w_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc, int n_store, int accumulate,
+                                 void *ws_d, void *stream) {
+    LMRL_REQUIRE(a_d && w_d && c_d && ws_d && m > 0 && n > 0 && k > 0 && n_store > 0 && n_store <= n && m % 128 == 0 && n % 128 == 0 && k % 64 == 0 &&
+                     lda >= m && ldw >= n && lda % 8 == 0 && ldw % 8 == 0, "lmrl_gemm_bf16_splitk_kmajor: bad argument (m, n multiples of 128, k of 64)");
+    int kchunk = 0, kind = 0;
+    const int S = lmrl::splitk_plan(m, n, k, &kchunk, &kind);
+    LMRL_REQUIRE(S >= 2 && kind == 0, "lmrl_gemm_bf16_splitk_kmajor: no 128 x 128 split-K plan for this shape");
+    hipStream_t s = as_stream(stream);
+    GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, nullptr, ws_d, m, n, k, lda, n, n};
+    g.ldw = ldw;
+    LMRL_CHECK_HIP((gemm8_launch_splitk<128, 128, 2, 4, 2, true>(g, (float *)ws_d, S, kchunk, s)));
+    const long total = (long)m * ((n_store + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, (const float *)ws_d, S,
+                       (long)m * n, n, (float *)c_d, ldc, m, n_store, accumulate);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
 void lmrl_gemm_set_variant(int v) { lmrl::g_gemm_variant = v; }
 
 // Plain bf16 GEMM entry (heads, LM-head logits): C = A.W^T + bias with a selectable epilogue.

@@ -246,6 +246,36 @@ __global__ __launch_bounds__(256) void ce_bwd_bf16_kernel(const float *__restric
     }
 }
 
+// colpart[rb][c] = sum of the 64 rows of block rb of a bf16 matrix [rows][ld] (fixed order): the bias gradient of a Dense layer from its staged dy
+// when no transposing pass over dy runs any more (lmrl_gemm_bf16_splitk_kmajor).  64 lanes x 8 columns, 4 row phases merged through LDS.
+__global__ __launch_bounds__(256) void colpart_bf16_kernel(const uint16_t *__restrict__ src, long ld, int rows, int cols, float *__restrict__ colpart,
+                                                           int ldp) {
+    __shared__ float sm[4][64][9];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + tx) * 8, r0 = blockIdx.y * 64;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < cols) {
+#pragma unroll 4
+        for (int k = 0; k < 16; k++) {
+            const int r = r0 + ty + 4 * k;
+            if (r < rows) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(src + (long)r * ld + c0);      // padding columns of a staged operand are zero
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) { a[2 * e] += __uint_as_float(w[e] << 16); a[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) sm[ty][tx][e] = a[e];
+    __syncthreads();
+    if (ty == 0 && c0 < cols) {
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (c0 + e < ldp) colpart[(long)blockIdx.y * ldp + c0 + e] = (sm[0][tx][e] + sm[1][tx][e]) + (sm[2][tx][e] + sm[3][tx][e]);
+    }
+}
+
 // out[c] (+)= sum over row blocks of colpart[rb][c] (deterministic: fixed partition and order).  One workgroup per 64 columns, 16 lane groups
 // each summing every 16th row block, combined through LDS in group order — the one-thread-per-column form walked 256 dependent strided loads
 // from 3 .. 12 workgroups (20.8 us per call, 53 calls per ILQL step: profiles/r03_ilql_bf16_step_kernel_stats_before_fusion.csv).
@@ -369,6 +399,16 @@ int lmrl_transpose_bf16_colsum(const void *src_d, long ld_src, int rows, int col
     if (colsum_d)
         hipLaunchKernelGGL(colpart_reduce_kernel, dim3((cols + 63) / 64), dim3(1024), 0, s, (const float *)ws_d, nrb, rows_dst, cols, colsum_d,
                            accumulate);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_colsum_bf16(const void *src_d, long ld_src, int rows, int cols, float *colsum_d, int accumulate, float *ws_d, void *stream) {
+    LMRL_REQUIRE(src_d && colsum_d && ws_d && rows > 0 && cols > 0 && ld_src % 8 == 0 && ld_src >= (cols + 7) / 8 * 8, "lmrl_colsum_bf16: bad argument");
+    hipStream_t s = as_stream(stream);
+    const int nrb = (rows + 63) / 64;
+    hipLaunchKernelGGL(colpart_bf16_kernel, dim3((cols + 511) / 512, nrb), dim3(256), 0, s, (const uint16_t *)src_d, ld_src, rows, cols, ws_d, cols);
+    hipLaunchKernelGGL(colpart_reduce_kernel, dim3((cols + 63) / 64), dim3(1024), 0, s, (const float *)ws_d, nrb, cols, cols, colsum_d, accumulate);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

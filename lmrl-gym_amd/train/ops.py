@@ -268,6 +268,17 @@ def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_b
             assert k % 64 == 0, "bf16 matmul mode: layer widths must be multiples of 64"
             wb = mm.cast(("w", w.data_ptr()), w, k, n, n, keep=True)                     # [k][pad(n)]
             mm.gemm(dyb_, wb, None, dx, rows, k, n, k, k, accumulate=dx_beta == 1.0)
+        if (FUSE_KMAJOR_DW and xb is not None and dyb is not None and k % 128 == 0 and n % 128 == 0 and rows % 64 == 0
+                and _L().lmrl_gemm_bf16_splitk_ws_bytes(k, n, rows) > 0):
+            # dW straight from the staged x [rows][pitch(k)] and dy [rows][pitch(n)] (no transposed copies); the bias gradient from dy's column sums
+            nws = max(_L().lmrl_gemm_bf16_splitk_ws_bytes(k, n, rows), ((rows + 63) // 64) * n * 4)
+            wsb = mm._buf("splitk_ws", nws // 2)
+            if db is not None:
+                _lib.check(_L().lmrl_colsum_bf16(dyb.data_ptr(), _pitch(n), rows, n, db.data_ptr(), int(accumulate_dw), wsb.data_ptr(), _sp()),
+                           "lmrl_colsum_bf16")
+            _lib.check(_L().lmrl_gemm_bf16_splitk_kmajor(xb.data_ptr(), dyb.data_ptr(), dw.data_ptr(), k, n, rows, _pitch(k), _pitch(n), n, n,
+                                                         int(accumulate_dw), wsb.data_ptr(), _sp()), "lmrl_gemm_bf16_splitk_kmajor")
+            return
         if xb is None:
             xt = mm.cast("xT", x, rows, k, k, transpose=True)                           # [pad(k)][pad(rows)]
         else:
@@ -323,6 +334,8 @@ def layernorm_fwd_staged(x, g, b, y, mean, rstd, yb, ldb, rows, d, eps):
 
 # the residual adds of a block folded into the LayerNorm behind them (lmrl_layernorm_add_fwd); False: one axpby launch per add (A/B hook)
 FUSE_ADD_LN = True
+# bf16-matmul mode: weight gradients from the operands as staged (lmrl_gemm_bf16_splitk_kmajor) instead of from transposed copies (A/B hook)
+FUSE_KMAJOR_DW = True
 
 
 def layernorm_add_fwd(x, resid, g, b, y, mean, rstd, yb, ldb, rows, d, eps):

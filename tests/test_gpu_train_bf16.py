@@ -374,3 +374,36 @@ def test_arena_weight_staging_equals_per_matrix_casts(dev):
                 got = mm.w[("w", w.data_ptr())]
             torch.cuda.synchronize()
             assert got.numel() == want.numel() and torch.equal(got, want), (k, n, transposed)
+
+
+@pytest.mark.parametrize("rows,k,n", [(4096, 768, 768), (16384, 768, 2304), (4160, 3072, 768), (8192, 256, 128)])
+def test_weight_gradient_from_untransposed_operands(dev, rows, k, n):
+    """lmrl_gemm_bf16_splitk_kmajor (dW = x^T dy gathered from the staged x / dy with the LDS transpose read) against the product on transposed
+    copies: same split-K plan, same K order -> the SAME bits; the bias gradient (column sums of the bf16 dy, different partition) to fp32 rounding.
+    Operands are random in every element, so a transposed / permuted fragment would show as O(1) error."""
+    from lmrl_gym_amd.train import ops
+    g = torch.Generator().manual_seed(rows + k + n)
+    x = torch.randn(rows, k, generator=g).to(dev)
+    dy = (torch.randn(rows, n, generator=g) * 0.3).to(dev)
+    w = torch.randn(k, n, generator=g).to(dev)
+    out = {}
+    old = ops.FUSE_KMAJOR_DW
+    try:
+        for fuse in (False, True):
+            ops.FUSE_KMAJOR_DW = fuse
+            mm = ops.MatmulBF16(dev)
+            xb, dyb = mm.cast("xs", x, rows, k, k), mm.cast("dys", dy, rows, n, n)
+            dw = torch.full((k, n), 0.5, device=dev)
+            db = torch.full((n,), -0.25, device=dev)
+            ws = torch.empty(64 * max(k, n), device=dev)
+            ops.linear_bwd(None, w, None, None, dw, db, rows, k, n, ws, mm=mm, dyb=dyb, xb=xb)
+            torch.cuda.synchronize()
+            out[fuse] = (dw.clone(), db.clone())
+    finally:
+        ops.FUSE_KMAJOR_DW = old
+    assert ops._L().lmrl_gemm_bf16_splitk_ws_bytes(k, n, rows) > 0          # the shape takes the split-K plan the new path needs
+    assert torch.equal(out[True][0], out[False][0])
+    ref_db = -0.25 + dyb.view(-1, ops._pitch(n))[:rows, :n].double().sum(0)
+    assert float((out[True][1].double() - ref_db).abs().max()) <= 1e-5 * max(1.0, float(ref_db.abs().max()))
+    ref = 0.5 + xb.view(-1, ops._pitch(k))[:rows, :k].double().t() @ dyb.view(-1, ops._pitch(n))[:rows, :n].double()
+    assert float((out[True][0].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
