@@ -39,13 +39,14 @@ def sgemm(a, b, c, m, n, k, **kw):
 
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "ilql-step"
+matmul = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 world, rank, dev, backend, use_dist = bench._dist_setup(torch)
-bench.run_train_step(mode, "bf16", 32, 1, 1, dev, 0, 1, False, "nccl")
+bench.run_train_step(mode, matmul, 32, 1, 1, dev, 0, 1, False, "nccl")
 rec.clear()
 ops.MatmulBF16.gemm = gemm
 ops.sgemm = sgemm
 import lmrl_gym_amd.train.gpt2_f32 as G
-bench.run_train_step(mode, "bf16", 32, 1, 0, dev, 0, 1, False, "nccl")
+bench.run_train_step(mode, matmul, 32, 1, 0, dev, 0, 1, False, "nccl")
 tot = sum(v[1] for v in rec.values())
 for k, v in sorted(rec.items(), key=lambda kv: -kv[1][1]):
     fl = 2.0 * k[1] * k[2] * k[3] * v[0]
