@@ -332,6 +332,19 @@ int lmrl_gemm_bf16_qkv_heads(const void *a_d, const void *w_d, const float *bias
 int lmrl_gemm_bf16_gelu_bwd(const void *a_d, const void *w_d, const float *pre_d, int ldpre, void *c_bf16_d, int ldc, int m, int n, int k, int lda,
                             int ldw, void *stream);
 
+/* Vocabulary-wide heads (the Q heads of ILQL / MC, heads/mlp_head.py:139-148; the tied LM head of PPO) in the bf16-matmul mode: logits written ONCE,
+ * in bf16 ([m][ldc], columns [0, n_store)), with everything the cross-entropy / take_along_axis terms need taken from the fp32 accumulators in the
+ * same launch — partials_d [m][lmrl_gemm_bf16_ce_slots(m, n, k)] (max, sum exp) pairs -> lmrl_lse_from_partials gives log-sum-exp (and the target's
+ * log-probability), tgt_logit_d[r] = logit[r][targets_d[r]] in fp32.  Replaces an fp32 [m][V] logits tensor + a pass over it
+ * (optax.softmax_cross_entropy_with_integer_labels forward, ilql/base_interface.py:57-66 gathers).  lmrl_ce_bwd_bf16_inplace then turns the bf16
+ * logits into the bf16 d(logits) operand of the head's backward products in place (padding rows / columns zeroed). */
+int lmrl_gemm_bf16_ce_slots(int m, int n, int k);
+int lmrl_gemm_bf16_ce(const void *a_d, const void *w_d, const float *bias_d, void *logits_bf16_d, int ldc, int m, int n, int k, int lda, int ldw, int n_store,
+                      const int32_t *targets_d, float *tgt_logit_d, void *partials_d, void *stream);
+int lmrl_lse_from_partials(const void *partials_d, int nslots, int rows, const float *tgt_logit_d, float *lse_d, float *logprob_d, void *stream);
+int lmrl_ce_bwd_bf16_inplace(void *logits_bf16_d, long ld, int vocab, const float *lse_d, const int32_t *targets_d, const float *coef_ce_d,
+                             const float *coef_gather_d, int rows, int rows_dst, void *stream);
+
 /* Split-K form for products with few output tiles and a long K (the train step's weight-gradient products dW = x^T . dy: K = B*T):
  * S copies of the 128 x 128 tile grid each accumulate a slice of K into fp32 partials in ws_d, a fixed-order reduce then writes
  * c (=|+=) their sum — deterministic.  lmrl_gemm_bf16_splitk_ws_bytes returns 0 when the shape is better served by lmrl_gemm_bf16_ld. */

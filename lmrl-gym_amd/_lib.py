@@ -118,6 +118,10 @@ _SIGS = {
     "lmrl_flash_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_flash_attn_fwd_staged": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_flash_attn_bwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lmrl_gemm_bf16_ce_slots": (c_int, [c_int, c_int, c_int]),
+    "lmrl_gemm_bf16_ce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lmrl_lse_from_partials": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lmrl_ce_bwd_bf16_inplace": (c_int, [c_void_p, ctypes.c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "lmrl_gemm_bf16_gelu_dual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_gemm_bf16_qkv_heads": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_gemm_bf16_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

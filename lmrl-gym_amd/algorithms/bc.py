@@ -67,9 +67,7 @@ def masked_ce_forward_backward(m: GPT2F32, ids: np.ndarray, am: np.ndarray, pos:
         wfull = np.zeros((B, T), dtype=np.float32)
         wfull[:, :-1] = wn
         coef = _t(wfull.reshape(-1), np.float32)
-    logits = m.lm_logits(hq, Rq)
-    lp, lse = torch.empty(Rq, dtype=torch.float32, device=dev), torch.empty(Rq, dtype=torch.float32, device=dev)
-    ops.lse_gather(logits, m.ld_vocab, m.vocab, tgt, Rq, logprob=lp, lse=lse)
+    logits, logits_b, lse, lp = m.lm_ce(hq, Rq, tgt)
     # loss = sum(coef * CE) = -sum(coef * logprob): a dot product done as a 1 x 1 x R GEMM on the matrix core
     out = torch.zeros(1, dtype=torch.float32, device=dev)
     ops.sgemm(coef, lp, out, 1, 1, Rq, alpha=-1.0, lda=Rq, ldb=1, ldc=1)
@@ -79,7 +77,7 @@ def masked_ce_forward_backward(m: GPT2F32, ids: np.ndarray, am: np.ndarray, pos:
     if grads is not None:
         if grad_scale != 1.0:
             ops.axpby(grad_scale, coef, 0.0, None, coef)
-        dlogits, dlb = m.ce_bwd(logits, lse, tgt, coef, None, Rq)
+        dlogits, dlb = m.ce_bwd_any(logits, logits_b, lse, tgt, coef, None, Rq)
         if compact:
             dhq = torch.empty(Ra, m.d, dtype=torch.float32, device=dev)
             m.lm_head_backward(hq, dlogits, Ra, dhq, grads, accumulate_dh=False, dlb=dlb)

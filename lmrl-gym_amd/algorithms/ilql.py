@@ -244,14 +244,20 @@ class GPT2ILQLTrain:
             Rq = Ra
         else:
             idx, hq, tgt_q, Rq = None, hid, tgt, R
-        q1o, q1c = self.q1.forward(hq, Rq)
-        q2o, q2c = self.q2.forward(hq, Rq)
         newq = lambda: torch.empty(Rq, dtype=torch.float32, device=dev)
-        q1sa_q, lse1, lp1 = newq(), newq(), newq()
-        q2sa_q, lse2, lp2 = newq(), newq(), newq()
-        ld = self.q1.ld_out
-        ops.lse_gather(q1o, ld, V, tgt_q, Rq, logprob=lp1, lse=lse1, target_logit=q1sa_q)
-        ops.lse_gather(q2o, ld, V, tgt_q, Rq, logprob=lp2, lse=lse2, target_logit=q2sa_q)
+        fuse_ce = self.q1.fused_ce_ok() and self.q2.fused_ce_ok()      # bf16-matmul mode: no fp32 [rows][V] logits (ops.FUSE_CE)
+        if fuse_ce:
+            q1o = q2o = None
+            lse1, q1sa_q, lp1, q1c = self.q1.forward_ce(hq, Rq, tgt_q)
+            lse2, q2sa_q, lp2, q2c = self.q2.forward_ce(hq, Rq, tgt_q)
+        else:
+            q1o, q1c = self.q1.forward(hq, Rq)
+            q2o, q2c = self.q2.forward(hq, Rq)
+            q1sa_q, lse1, lp1 = newq(), newq(), newq()
+            q2sa_q, lse2, lp2 = newq(), newq(), newq()
+            ld = self.q1.ld_out
+            ops.lse_gather(q1o, ld, V, tgt_q, Rq, logprob=lp1, lse=lse1, target_logit=q1sa_q)
+            ops.lse_gather(q2o, ld, V, tgt_q, Rq, logprob=lp2, lse=lse2, target_logit=q2sa_q)
         ce1_q, ce2_q = newq(), newq()
         ops.axpby(-1.0, lp1, 0.0, None, ce1_q)
         ops.axpby(-1.0, lp2, 0.0, None, ce2_q)
@@ -296,8 +302,12 @@ class GPT2ILQLTrain:
             coef_q, dq1_q, dq2_q = (ops.gather_rows(x.view(R, 1), idx, Ra, 1).view(Ra) for x in (coef_r, dq1_r, dq2_r))
         else:
             coef_q, dq1_q, dq2_q = coef_r, dq1_r, dq2_r
-        dq1o, dq1b = self.q1.ce_bwd(q1o, lse1, tgt_q, coef_q, dq1_q, Rq)
-        dq2o, dq2b = self.q2.ce_bwd(q2o, lse2, tgt_q, coef_q, dq2_q, Rq)
+        if fuse_ce:
+            dq1o, dq1b = None, self.q1.ce_bwd_fused(q1c, lse1, tgt_q, coef_q, dq1_q, Rq)
+            dq2o, dq2b = None, self.q2.ce_bwd_fused(q2c, lse2, tgt_q, coef_q, dq2_q, Rq)
+        else:
+            dq1o, dq1b = self.q1.ce_bwd(q1o, lse1, tgt_q, coef_q, dq1_q, Rq)
+            dq2o, dq2b = self.q2.ce_bwd(q2o, lse2, tgt_q, coef_q, dq2_q, Rq)
         bgrads, g1, g2, gv = base.zero_grads(), self.q1.zero_grads(), self.q2.zero_grads(), self.v.zero_grads()
         d_hidden = torch.empty(R, base.d, dtype=torch.float32, device=dev)
         # detach_q1 / detach_q2 / detach_v (interface.py:120-139: stop_gradient on the hidden states fed to that head): the head still trains,

@@ -150,11 +150,17 @@ class GPT2MCTrain:
             idx, hq, Rq = None, hid, R
             tgt = torch.zeros(R, dtype=torch.int32, device=dev)
             tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
-        qo, qc = self.q_head.forward(hq, Rq)
         newq = lambda: torch.empty(Rq, dtype=torch.float32, device=dev)
-        qsa_q, lse, lp, ce_q = newq(), newq(), newq(), newq()
-        ld = self.q_head.ld_out
-        ops.lse_gather(qo, ld, V, tgt, Rq, logprob=lp, lse=lse, target_logit=qsa_q)
+        fuse_ce = self.q_head.fused_ce_ok()              # bf16-matmul mode: no fp32 [rows][V] logits (ops.FUSE_CE)
+        if fuse_ce:
+            qo = None
+            lse, qsa_q, lp, qc = self.q_head.forward_ce(hq, Rq, tgt)
+            ce_q = newq()
+        else:
+            qo, qc = self.q_head.forward(hq, Rq)
+            qsa_q, lse, lp, ce_q = newq(), newq(), newq(), newq()
+            ld = self.q_head.ld_out
+            ops.lse_gather(qo, ld, V, tgt, Rq, logprob=lp, lse=lse, target_logit=qsa_q)
         ops.axpby(-1.0, lp, 0.0, None, ce_q)
         if compact:
             qsa, ce = torch.zeros(R, dtype=torch.float32, device=dev), torch.zeros(R, dtype=torch.float32, device=dev)
@@ -171,7 +177,10 @@ class GPT2MCTrain:
         coef_r, dq_r = full(coef), full(dq)
         if compact:
             coef_r, dq_r = (ops.gather_rows(x.view(R, 1), idx, Ra, 1).view(Ra) for x in (coef_r, dq_r))
-        dqo, dqb = self.q_head.ce_bwd(qo, lse, tgt, coef_r, dq_r, Rq)          # d loss / d q logits
+        if fuse_ce:
+            dqo, dqb = None, self.q_head.ce_bwd_fused(qc, lse, tgt, coef_r, dq_r, Rq)
+        else:
+            dqo, dqb = self.q_head.ce_bwd(qo, lse, tgt, coef_r, dq_r, Rq)          # d loss / d q logits
         bgrads, qgrads = base.zero_grads(), self.q_head.zero_grads()
         if compact:
             dhq = torch.empty(Ra, base.d, dtype=torch.float32, device=dev)

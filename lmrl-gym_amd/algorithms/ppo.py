@@ -273,10 +273,7 @@ class GPT2PPOTrain:
             hq, tgt_q, Rq = ops.gather_rows(hid, idx, Ra, pol.d), _t(ids[:, 1:][p_mask].astype(np.int32), np.int32), Ra
         else:
             idx, hq, tgt_q, Rq = None, hid, tgt, R
-        logits = pol.lm_logits(hq, Rq)                                           # fp32 [Rq, V]
-        lp_q = torch.empty(Rq, dtype=torch.float32, device=dev)
-        lse = torch.empty(Rq, dtype=torch.float32, device=dev)
-        ops.lse_gather(logits, pol.ld_vocab, pol.vocab, tgt_q, Rq, logprob=lp_q, lse=lse)
+        logits, logits_b, lse, lp_q = pol.lm_ce(hq, Rq, tgt_q)                    # fp32 [Rq, V] logits, or (bf16-matmul mode) bf16 ones + fp32-exact lse
         if compact:
             logprob_all = torch.zeros(R, dtype=torch.float32, device=dev)          # zeros off the mask (multiplied by the zero mask in the loss)
             ops.scatter_rows(lp_q, idx, logprob_all, Ra, 1, False)
@@ -300,7 +297,7 @@ class GPT2PPOTrain:
         ops.axpby(-1.0, dlp, 0.0, None, neg)
         coef.view(B, T)[:, :-1] = neg
         coef_q = ops.gather_rows(coef.view(R, 1), idx, Ra, 1).view(Ra) if compact else coef
-        dlogits, dlb = pol.ce_bwd(logits, lse, tgt_q, coef_q, None, Rq)   # in place (fp32) / the staged bf16 operand (bf16-matmul mode)
+        dlogits, dlb = pol.ce_bwd_any(logits, logits_b, lse, tgt_q, coef_q, None, Rq)   # in place (fp32 / bf16 logits)
         pgrads, hgrads = pol.zero_grads(), head.zero_grads()
         if compact:
             dhq = torch.empty(Ra, pol.d, dtype=torch.float32, device=dev)

@@ -434,8 +434,50 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
         return;
     }
 
-    constexpr bool BF16_OUT = (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || LN_IN || EPI == EPI_BF16_HEADS || EPI == EPI_GELU_BWD_BF16);
-    static_assert(!(EPI == EPI_BF16_HEADS || EPI == EPI_GELU_BWD_BF16) || FN % 2 == 0, "the train-step bf16 epilogues store fragment pairs");
+    if constexpr (EPI == EPI_BF16_CE) {
+        // log-sum-exp partials and the target column's logit from the fp32 accumulators, before the bf16 rounding of the stored logits.  A lane holds,
+        // for each of its FM rows, 4 columns of each of the FN fragments; the row's other columns of this wave's TN-wide slab sit in the lanes lq ^ 1,
+        // lq ^ 2 (xor 16 / 32).  One (max, sum exp) per (row, slab): slot = tile_n * WN + wn, pitch g.nslots.  Columns >= n_store are padding.
+        const int slot = tile_n * WN + wn;
+#pragma unroll
+        for (int j = 0; j < FM; j++) {
+            const int m = m0 + wm * TM + j * 16 + lr;
+            const int mc = m < Mr ? m : Mr - 1;
+            const int tgt = g.ce_targets ? g.ce_targets[mc] : -1;
+            float vmax = -INFINITY;
+            f32x4 v[FN];
+#pragma unroll
+            for (int i = 0; i < FN; i++) {
+                const int n = n0 + wn * TN + i * 16 + lq * 4;
+                f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (g.bias) b4 = *reinterpret_cast<const f32x4 *>(g.bias + n);
+                v[i] = acc[i][j] + b4;
+                acc[i][j] = v[i];                                   // the stored logits below: the same values
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (n + e < g.n_store) vmax = fmaxf(vmax, v[i][e]);
+                    if (n + e == tgt && m < Mr) g.ce_tgt_logit[m] = v[i][e];
+                }
+            }
+            vmax = fmaxf(vmax, __shfl_xor(vmax, 16));
+            vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < FN; i++) {
+                const int n = n0 + wn * TN + i * 16 + lq * 4;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (n + e < g.n_store) sum += __expf(v[i][e] - vmax);
+            }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            if (lq == 0 && m < Mr) g.stats[(size_t)m * g.nslots + slot] = make_float2(vmax, sum);
+        }
+    }
+
+    constexpr bool BF16_OUT = (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || LN_IN || EPI == EPI_BF16_HEADS || EPI == EPI_GELU_BWD_BF16 ||
+                               EPI == EPI_BF16_CE);
+    static_assert(!(EPI == EPI_BF16_HEADS || EPI == EPI_GELU_BWD_BF16 || EPI == EPI_BF16_CE) || FN % 2 == 0, "the train-step bf16 epilogues store fragment pairs");
     if (BF16_OUT && (FN % 2 == 0)) {
         // bf16 outputs, fragment pairs (i, i+1): a lane holds columns [16i + 4lq, +4) of both; v_permlane16_swap (odd 16-lane rows of the
         // first operand <-> even rows of the second) regroups them so that every lane owns 8 CONSECUTIVE columns (16 B) of one fragment:
@@ -445,7 +487,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
         for (int i = 0; i < FN; i += 2) {
             const int nA = n0 + wn * TN + i * 16 + lq * 4, nB = nA + 16;
             f32x4 bA = f32x4{0.f, 0.f, 0.f, 0.f}, bB = bA, cA = bA, cB = bA;
-            if (g.bias) { bA = *reinterpret_cast<const f32x4 *>(g.bias + nA); bB = *reinterpret_cast<const f32x4 *>(g.bias + nB); }
+            if (g.bias && EPI != EPI_BF16_CE) { bA = *reinterpret_cast<const f32x4 *>(g.bias + nA); bB = *reinterpret_cast<const f32x4 *>(g.bias + nB); }
             if (LN_IN) { cA = *reinterpret_cast<const f32x4 *>(g.colsum + nA); cB = *reinterpret_cast<const f32x4 *>(g.colsum + nB); }
             const int n_st = n0 + wn * TN + (i + (lq & 1)) * 16 + (lq >> 1) * 8;      // first of this lane's 8 columns after the regrouping
             // EPI_BF16_HEADS: both fragments lie in one 32-column group, i.e. in one head of one of q / k / v

@@ -51,6 +51,9 @@ enum GemmEpi {
     EPI_BF16_HEADS = 10,     // the c_attn product straight into the flash kernels' per-head matrices: column n = which * d + h * 64 + e of row
                              // m = b * T + t -> C + which * hd_plane + ((b * H + h) * Tp + t) * 64 + e, bf16, q columns (which = 0) times 1/8
     EPI_GELU_BWD_BF16 = 11,  // C bf16 = acc * gelu_new'(resid[m][n]): d(pre-activation) as the bf16 operand of the c_fc backward products
+    EPI_BF16_CE = 12,        // vocabulary heads: C bf16 = acc + bias, AND from the fp32 accumulators: per (row, wave-column-slab) partial
+                             // (max, sum exp) -> stats[m][slot] (log-sum-exp without a pass over the logits) and the fp32 logit of column
+                             // ce_targets[m] -> ce_tgt_logit[m] (Q(s, a) / the token's logit: take_along_axis)
 };
 
 // fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32); the integer bit trick it replaces
@@ -135,6 +138,8 @@ struct GemmArgs {
     // The train step keeps a block's input, middle and output residual streams as separate tensors (its LayerNorm backward reads them).
     const float *resid;
     int ldr;
+    const int *ce_targets;    // EPI_BF16_CE: [M] column whose fp32 logit goes to ce_tgt_logit (or null)
+    float *ce_tgt_logit;      // EPI_BF16_CE: [M]
     int ldxb;                 // EPI_F32_GELU_BF16: row pitch of xb (elements)
     int hd_T, hd_Tp, hd_H;    // EPI_BF16_HEADS: tokens per sequence, its padding to 64, heads
     long hd_plane;            // EPI_BF16_HEADS: elements between the q, k and v matrices

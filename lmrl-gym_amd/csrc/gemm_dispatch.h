@@ -85,7 +85,7 @@ inline TrainTile pick_train_tile(int M, int N, int K) {
 // PAIRS, so the 256x192 tile runs as 4 x 2 waves (64 x 96 per wave) there.
 template <int EPI>
 inline hipError_t gemm_launch_train(const GemmArgs &g, hipStream_t s) {
-    static_assert(EPI == EPI_F32_GELU_BF16 || EPI == EPI_BF16_HEADS || EPI == EPI_GELU_BWD_BF16, "train-step epilogues only");
+    static_assert(EPI == EPI_F32_GELU_BF16 || EPI == EPI_BF16_HEADS || EPI == EPI_GELU_BWD_BF16 || EPI == EPI_BF16_CE, "train-step epilogues only");
     switch (pick_train_tile(g.M, g.N, g.K)) {
         case TT_256x256: return gemm8_launch<256, 256, 2, 4, 2, EPI>(g, s);
         case TT_256x192: return gemm8_launch<256, 192, 4, 2, 2, EPI>(g, s);

@@ -1417,6 +1417,26 @@ int lmrl_gemm_bf16_qkv_heads(const void *a_d, const void *w_d, const float *bias
     return LMRL_OK;
 }
 
+// slabs per row of lmrl_gemm_bf16_ce's log-sum-exp partials for this shape (follows the tile the shape policy picks)
+static int ce_slots(int m, int n, int k) {
+    switch (pick_train_tile(m, n, k)) {
+        case TT_256x256: return n / 256 * 4;
+        case TT_256x192: return n / 192 * 2;
+        default: return n / 128 * 4;
+    }
+}
+int lmrl_gemm_bf16_ce_slots(int m, int n, int k) { return (n > 0 && n % 128 == 0) ? ce_slots(m, n, k) : 0; }
+
+int lmrl_gemm_bf16_ce(const void *a_d, const void *w_d, const float *bias_d, void *logits_bf16_d, int ldc, int m, int n, int k, int lda, int ldw, int n_store,
+                      const int32_t *targets_d, float *tgt_logit_d, void *partials_d, void *stream) {
+    LMRL_REQUIRE(a_d && w_d && logits_bf16_d && partials_d && train_gemm_args_ok(m, n, k, lda, ldw) && ldc % 8 == 0 && ldc >= n_store && n_store > 0 &&
+                     n_store <= n && (!targets_d || tgt_logit_d), "lmrl_gemm_bf16_ce: bad argument");
+    GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, bias_d, logits_bf16_d, m, n, k, lda, ldc, n_store};
+    g.ldw = ldw; g.stats = (float2 *)partials_d; g.nslots = ce_slots(m, n, k); g.ce_targets = targets_d; g.ce_tgt_logit = tgt_logit_d;
+    LMRL_CHECK_HIP(gemm_launch_train<EPI_BF16_CE>(g, as_stream(stream)));
+    return LMRL_OK;
+}
+
 int lmrl_gemm_bf16_gelu_bwd(const void *a_d, const void *w_d, const float *pre_d, int ldpre, void *c_bf16_d, int ldc, int m, int n, int k, int lda,
                             int ldw, void *stream) {
     LMRL_REQUIRE(a_d && w_d && pre_d && c_bf16_d && train_gemm_args_ok(m, n, k, lda, ldw) && ldc % 8 == 0 && ldc >= n && ldpre % 4 == 0 && ldpre >= n,

@@ -246,6 +246,67 @@ __global__ __launch_bounds__(256) void ce_bwd_bf16_kernel(const float *__restric
     }
 }
 
+// The same on bf16 logits, IN PLACE: q[r][c] := bf16(dlogit) for r < rows, c < V; 0 in the padding (rows up to rows_dst, columns up to ld) — the
+// vocabulary heads' logits were written once, in bf16, by the head GEMM (EPI_BF16_CE, which also produced lse from its fp32 accumulators), and
+// become the dy operand of the head's backward products without another [rows][V] buffer.
+__global__ __launch_bounds__(256) void ce_bwd_bf16_inplace_kernel(uint16_t *__restrict__ q0, long ld, int V, const float *__restrict__ lse,
+                                                                  const int32_t *__restrict__ targets, const float *__restrict__ coef_ce,
+                                                                  const float *__restrict__ coef_gather, int rows) {
+    const int r = blockIdx.x;
+    uint16_t *q = q0 + (long)r * ld;
+    if (r >= rows) {
+        for (int c0 = threadIdx.x * 8; c0 < ld; c0 += 256 * 8) *reinterpret_cast<uint4 *>(q + c0) = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    const float l = lse[r], cc = coef_ce ? coef_ce[r] : 0.f, cg = coef_gather ? coef_gather[r] : 0.f;
+    int t = targets[r];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    for (int c0 = threadIdx.x * 8; c0 < ld; c0 += 256 * 8) {
+        const uint4 in = *reinterpret_cast<const uint4 *>(q + c0);
+        const uint32_t w[4] = {in.x, in.y, in.z, in.w};
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int c = c0 + k;
+            const float x = __uint_as_float((k & 1) ? (w[k >> 1] & 0xffff0000u) : (w[k >> 1] << 16));
+            float g = 0.f;
+            if (c < V) {
+                g = cc == 0.f ? 0.f : cc * expf(x - l);
+                if (c == t) g += cg - cc;
+            }
+            v[k] = g;
+        }
+        uint4 o;
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<uint4 *>(q + c0) = o;
+    }
+}
+
+// lse[r] = log sum_c exp(logit[r][c]) from the head GEMM's per-slab partials (max, sum exp) [rows][nslots] (slabs of padding columns carry
+// max = -inf); logprob[r] = tgt_logit[r] - lse[r] when asked.  One wave per row, fixed order.
+__global__ __launch_bounds__(256) void lse_from_partials_kernel(const float2 *__restrict__ part, int nslots, int rows, const float *__restrict__ tgt_logit,
+                                                                float *__restrict__ lse, float *__restrict__ logprob) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float2 *p = part + (size_t)r * nslots;
+    float m = -INFINITY;
+    for (int k = lane; k < nslots; k += 64) m = fmaxf(m, p[k].x);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+    for (int k = lane; k < nslots; k += 64) {
+        const float2 v = p[k];
+        if (v.x != -INFINITY) s += v.y * expf(v.x - m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        const float l = m + logf(s);
+        lse[r] = l;
+        if (logprob) logprob[r] = tgt_logit[r] - l;
+    }
+}
+
 // colpart[rb][c] = sum of the 64 rows of block rb of a bf16 matrix [rows][ld] (fixed order): the bias gradient of a Dense layer from its staged dy
 // when no transposing pass over dy runs any more (lmrl_gemm_bf16_splitk_kmajor).  64 lanes x 8 columns, 4 row phases merged through LDS.
 __global__ __launch_bounds__(256) void colpart_bf16_kernel(const uint16_t *__restrict__ src, long ld, int rows, int cols, float *__restrict__ colpart,
@@ -399,6 +460,24 @@ int lmrl_transpose_bf16_colsum(const void *src_d, long ld_src, int rows, int col
     if (colsum_d)
         hipLaunchKernelGGL(colpart_reduce_kernel, dim3((cols + 63) / 64), dim3(1024), 0, s, (const float *)ws_d, nrb, rows_dst, cols, colsum_d,
                            accumulate);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_ce_bwd_bf16_inplace(void *logits_bf16_d, long ld, int vocab, const float *lse_d, const int32_t *targets_d, const float *coef_ce_d,
+                             const float *coef_gather_d, int rows, int rows_dst, void *stream) {
+    LMRL_REQUIRE(logits_bf16_d && lse_d && targets_d && rows > 0 && vocab > 0 && ld >= vocab && ld % 8 == 0 && rows_dst >= rows,
+                 "lmrl_ce_bwd_bf16_inplace: bad argument");
+    hipLaunchKernelGGL(ce_bwd_bf16_inplace_kernel, dim3(rows_dst), dim3(256), 0, as_stream(stream), (uint16_t *)logits_bf16_d, ld, vocab, lse_d, targets_d,
+                       coef_ce_d, coef_gather_d, rows);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_lse_from_partials(const void *partials_d, int nslots, int rows, const float *tgt_logit_d, float *lse_d, float *logprob_d, void *stream) {
+    LMRL_REQUIRE(partials_d && lse_d && nslots > 0 && rows > 0 && (!logprob_d || tgt_logit_d), "lmrl_lse_from_partials: bad argument");
+    hipLaunchKernelGGL(lse_from_partials_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), (const float2 *)partials_d, nslots, rows,
+                       tgt_logit_d, lse_d, logprob_d);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

@@ -247,6 +247,24 @@ class GPT2F32:
             mm.gemm(hb, wb, None, logits, rows, ops._padn(V), d, ld, V)
         return logits
 
+    def lm_ce(self, hidden, rows: int, targets):
+        """What the CE / token-log-probability terms need of the tied LM head's logits -> (logits, yb, lse, logprob): fp32 logits [rows, ld_vocab]
+        + a pass over them (fp32 mode: yb None), or in the bf16-matmul mode bf16 logits `yb` with lse / log-probabilities taken from the GEMM's
+        fp32 accumulators (logits None; ops.FUSE_CE).  `ce_bwd_any` turns either into d(logits) for `lm_head_backward`."""
+        t = self.t
+        if ops.FUSE_CE and self.mm is not None and self.d % 64 == 0 and ops._padn(self.vocab) % 128 == 0:
+            yb, lse, _, lp = ops.head_fwd_ce(self.mm, hidden, self.p["wte.weight"], None, rows, self.d, self.vocab, targets, w_is_nk=True)
+            return None, yb, lse, lp
+        logits = self.lm_logits(hidden, rows)
+        lp, lse = t.empty(rows, dtype=t.float32, device=self.dev), t.empty(rows, dtype=t.float32, device=self.dev)
+        ops.lse_gather(logits, self.ld_vocab, self.vocab, targets, rows, logprob=lp, lse=lse)
+        return logits, None, lse, lp
+
+    def ce_bwd_any(self, logits, yb, lse, targets, coef_ce, coef_gather, rows: int):
+        if yb is not None:
+            return None, ops.ce_bwd_inplace(yb, self.vocab, lse, targets, coef_ce, coef_gather, rows)
+        return self.ce_bwd(logits, lse, targets, coef_ce, coef_gather, rows)
+
     # ------------------------------------------------------------------ backward
     def grad_order(self):
         """Parameter names in the order `backward` finalises their gradients: ln_f, blocks last to first, then the embeddings (wte also
@@ -480,6 +498,20 @@ class MLPHeadF32:
         y = t.empty(rows, self.ld_out, dtype=t.float32, device=self.dev)
         ops.linear_fwd(a, self.p["dense2.kernel"], self.p["dense2.bias"], y, rows, self.dh, self.dout, mm=self.mm2, ldy=self.ld_out)
         return y, dict(x=x, z=z, a=a, rows=rows)
+
+    def fused_ce_ok(self) -> bool:
+        return ops.FUSE_CE and self.mm2 is not None and self.dh % 64 == 0 and ops._padn(self.dout) % 128 == 0
+
+    def forward_ce(self, x, rows, targets):
+        """The head's logits only as far as the CE / take_along_axis terms need them (bf16-matmul mode): -> (lse [rows], target logit [rows],
+        target log-probability [rows], cache); the cache keeps the bf16 logits for `ce_bwd_fused`."""
+        a, z = self.hidden(x, rows)
+        yb, lse, tl, lp = ops.head_fwd_ce(self.mm2, a, self.p["dense2.kernel"], self.p["dense2.bias"], rows, self.dh, self.dout, targets)
+        return lse, tl, lp, dict(x=x, z=z, a=a, rows=rows, yb=yb)
+
+    def ce_bwd_fused(self, cache, lse, targets, coef_ce, coef_gather, rows):
+        """d loss / d logits of the CE (+ gather) terms as the bf16 dy operand of `backward(dyb=...)`, formed in place on the cached logits"""
+        return ops.ce_bwd_inplace(cache["yb"], self.dout, lse, targets, coef_ce, coef_gather, rows)
 
     def forward_at(self, x, rows, idx):
         """y[r, idx[r]] for every row without forming y: `take_along_axis(head(x), idx)` — how the ILQL loss reads the TARGET Q heads

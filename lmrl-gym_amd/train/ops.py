@@ -215,6 +215,39 @@ def linear_bwd_dx_gelu(mm: "MatmulBF16", dyb, w, pre, rows, k, n):
     return dst
 
 
+# bf16-matmul mode, vocabulary-wide heads: logits written once in bf16 with the log-sum-exp partials and the target's fp32 logit out of the GEMM's
+# accumulators (lmrl_gemm_bf16_ce), d(logits) formed in place (lmrl_ce_bwd_bf16_inplace) — no fp32 [rows][V] tensor, no lse pass over it.  The
+# softmax of the backward then reads bf16-rounded logits (2^-9 relative per logit); lse, Q(s, a) and the token log-probabilities stay fp32-exact.
+FUSE_CE = True
+
+
+def head_fwd_ce(mm: "MatmulBF16", x, w, b, rows, k, n, targets, w_is_nk: bool = False):
+    """logits = x @ w + b for a vocabulary-wide head (w a Dense kernel [k][n]; w_is_nk: an embedding matrix [n][k], the tied LM head), never in
+    fp32 -> (logits_bf16 [pad(rows)][pitch(n)] (fresh buffer), lse [rows], target logit [rows] fp32, target log-probability [rows])."""
+    t = mm.t
+    xb = mm.cast("x", x, rows, k, k)
+    if w_is_nk:
+        wt = mm.cast(("w", w.data_ptr()), w, n, k, k, keep=True)                     # [pad(n)][pitch(k)]
+    else:
+        wt = mm.cast(("wT", w.data_ptr()), w, k, n, n, transpose=True, keep=True)
+    N = _padn(n)
+    nslots = _L().lmrl_gemm_bf16_ce_slots(rows, N, _pad(k))
+    yb = t.empty(_padn(rows) * _pitch(n), dtype=t.bfloat16, device=mm.dev)
+    part = t.empty(rows * nslots * 2, dtype=t.float32, device=mm.dev)
+    lse, tl, lp = (t.empty(rows, dtype=t.float32, device=mm.dev) for _ in range(3))
+    _lib.check(_L().lmrl_gemm_bf16_ce(xb.data_ptr(), wt.data_ptr(), _lib.ptr(mm.bias(b, n) if b is not None else None), yb.data_ptr(), _pitch(n), rows, N,
+                                      _pad(k), _pitch(k), _pitch(k), n, targets.data_ptr(), tl.data_ptr(), part.data_ptr(), _sp()), "lmrl_gemm_bf16_ce")
+    _lib.check(_L().lmrl_lse_from_partials(part.data_ptr(), nslots, rows, tl.data_ptr(), lse.data_ptr(), lp.data_ptr(), _sp()), "lmrl_lse_from_partials")
+    return yb, lse, tl, lp
+
+
+def ce_bwd_inplace(yb, n, lse, targets, coef_ce, coef_gather, rows):
+    """the bf16 logits `yb` of `head_fwd_ce` -> the bf16 d(logits) operand of the head's backward products, in place"""
+    _lib.check(_L().lmrl_ce_bwd_bf16_inplace(yb.data_ptr(), _pitch(n), n, lse.data_ptr(), targets.data_ptr(), _lib.ptr(coef_ce), _lib.ptr(coef_gather),
+                                             rows, _padn(rows), _sp()), "lmrl_ce_bwd_bf16_inplace")
+    return yb
+
+
 # bf16-matmul mode: residual add inside the projection GEMM's epilogue (lmrl_gemm_bf16_resid) instead of a separate axpby launch.  Measured on
 # one box, ILQL M3 step, A/B twice (tools/ab_train_resid.py, profiles/r03_train_resid_ab.txt): fused 46.93 / 47.31 ms, two launches 46.26 /
 # 46.73 ms — the residual slice prefetched under the K loop costs the 128x128 / 256x256 tiles more registers than the 30 us axpby (150 MB at

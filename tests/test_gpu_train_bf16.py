@@ -407,3 +407,40 @@ def test_weight_gradient_from_untransposed_operands(dev, rows, k, n):
     assert float((out[True][1].double() - ref_db).abs().max()) <= 1e-5 * max(1.0, float(ref_db.abs().max()))
     ref = 0.5 + xb.view(-1, ops._pitch(k))[:rows, :k].double().t() @ dyb.view(-1, ops._pitch(n))[:rows, :n].double()
     assert float((out[True][0].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("rows,n", [(1000, 50257), (4200, 50257), (300, 1000)])
+def test_vocabulary_head_ce_from_the_gemm_accumulators(dev, rows, n):
+    """lmrl_gemm_bf16_ce: bf16 logits + log-sum-exp partials + the target's fp32 logit out of one launch, against the fp32-logits product followed by
+    lse_gather: the target logit is the SAME fp32 number, lse agrees to fp32 rounding, the stored logits are the bf16 rounding of the fp32 ones;
+    lmrl_ce_bwd_bf16_inplace then equals the float64 formula evaluated on those bf16 logits, with zeroed padding.  4200 rows: 256-row tiles."""
+    from lmrl_gym_amd.train import ops
+    k = 768
+    g = torch.Generator().manual_seed(rows + n)
+    mm = ops.MatmulBF16(dev)
+    x = torch.randn(rows, k, generator=g).to(dev)
+    w = (torch.randn(k, n, generator=g) * 0.08).to(dev)
+    b = (torch.randn(n, generator=g) * 0.5).to(dev)
+    tgt = torch.randint(0, n, (rows,), generator=g).int().to(dev)
+    ld = ops._pad(n)
+    y = torch.empty(rows, ld, device=dev)
+    ops.linear_fwd(x, w, b, y, rows, k, n, mm=mm, ldy=ld)
+    lse0, lp0, tl0 = (torch.empty(rows, device=dev) for _ in range(3))
+    ops.lse_gather(y, ld, n, tgt, rows, logprob=lp0, lse=lse0, target_logit=tl0)
+    yb, lse, tl, lp = ops.head_fwd_ce(mm, x, w, b, rows, k, n, tgt)
+    torch.cuda.synchronize()
+    assert torch.equal(tl, tl0)
+    assert float((lse - lse0).abs().max()) <= 2e-5 and float((lp - lp0).abs().max()) <= 2e-5
+    Y = yb.view(-1, ops._pitch(n))
+    assert torch.equal(Y[:rows, :n], y[:, :n].to(torch.bfloat16))
+    cc = (torch.rand(rows, generator=g) * 0.01).to(dev)
+    cg = (torch.randn(rows, generator=g) * 0.1).to(dev)
+    L = Y[:rows, :n].double()
+    ref = cc.double()[:, None] * torch.exp(L - lse.double()[:, None])
+    ref[torch.arange(rows), tgt.long()] += (cg - cc).double()
+    ops.ce_bwd_inplace(yb, n, lse, tgt, cc, cg, rows)
+    torch.cuda.synchronize()
+    D = yb.view(-1, ops._pitch(n))
+    err = (D[:rows, :n].double() - ref).abs() / (ref.abs() + 1e-6)
+    assert float(err.max()) <= 2.0 ** -8, float(err.max())
+    assert float(D[rows:].abs().max() if D.shape[0] > rows else 0.0) == 0.0 and float(D[:rows, n:].abs().max()) == 0.0
