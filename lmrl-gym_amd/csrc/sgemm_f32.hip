@@ -28,6 +28,7 @@ struct SgemmArgs {
     long sAo, sAi, sBo, sBi, sCo, sCi;   // batch strides (outer, inner) in elements
     int nb_inner;
     float alpha, beta;
+    int k_total;   // split-K launches: the whole K (slice z = blockIdx.z covers [z * K, min(k_total, (z + 1) * K)); 0: K is the extent
 };
 
 constexpr int SG_BM = 64, SG_BN = 64, SG_BK = 16, SG_LD = 68;   // LDS row stride (floats): 68 % 32 = 4 -> spread banks
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256) void sgemm_f32_128_kernel(SgemmArgs g) {
     const float *B = g.B + bo * g.sBo + bi * g.sBi;
     float *C = g.C + bo * g.sCo + bi * g.sCi;
     const int m0 = blockIdx.y * SG2_BM, n0 = blockIdx.x * SG2_BN;
+    if (g.k_total > 0) g.K = min(g.K, g.k_total - (int)blockIdx.z * g.K);      // the last split-K slice may be shorter
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -200,9 +202,11 @@ __global__ __launch_bounds__(256) void sgemm_f32_128_kernel(SgemmArgs g) {
             for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
     float ra[8], rb[8];
     // full, 16-byte-aligned tiles take the float4 path (workgroup-uniform per operand)
-    const bool kfull = (g.K % SG2_BK) == 0;
-    const bool va = kfull && m0 + SG2_BM <= g.M && (g.lda & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-    const bool vb = kfull && n0 + SG2_BN <= g.N && (g.ldb & 3) == 0 && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    // (a K that is not a multiple of the 16-wide step — the vocabulary, 50 257 — keeps the 16-byte path on every full step: only the last,
+    //  partial step takes the guarded 4-byte loads; before, such products ran guarded throughout: 71 vs 113 TFLOP/s on the heads' dX)
+    const bool va0 = m0 + SG2_BM <= g.M && (g.lda & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const bool vb0 = n0 + SG2_BN <= g.N && (g.ldb & 3) == 0 && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    bool va = va0 && SG2_BK <= g.K, vb = vb0 && SG2_BK <= g.K;
     if (va) sg2_load_vec<!TA>(A, g.lda, m0, 0, t, ra); else sg2_load<!TA>(A, g.lda, m0, g.M, 0, g.K, t, ra);
     if (vb) sg2_load_vec<TB>(B, g.ldb, n0, 0, t, rb); else sg2_load<TB>(B, g.ldb, n0, g.N, 0, g.K, t, rb);
     if (va) sg2_store_vec<!TA>(sA[0], t, ra); else sg2_store<!TA>(sA[0], t, ra);
@@ -212,6 +216,8 @@ __global__ __launch_bounds__(256) void sgemm_f32_128_kernel(SgemmArgs g) {
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
         if (kt + 1 < nk) {
+            const bool full = (kt + 2) * SG2_BK <= g.K;          // workgroup-uniform
+            va = va0 && full; vb = vb0 && full;
             if (va) sg2_load_vec<!TA>(A, g.lda, m0, (kt + 1) * SG2_BK, t, ra); else sg2_load<!TA>(A, g.lda, m0, g.M, (kt + 1) * SG2_BK, g.K, t, ra);
             if (vb) sg2_load_vec<TB>(B, g.ldb, n0, (kt + 1) * SG2_BK, t, rb); else sg2_load<TB>(B, g.ldb, n0, g.N, (kt + 1) * SG2_BK, g.K, t, rb);
         }
@@ -292,11 +298,21 @@ extern "C" int lmrl_sgemm(int trans_a, int trans_b, int m, int n, int k, float a
     // split K across workgroups into a workspace and add the partials in a fixed order (no atomics -> deterministic).
     if (g_sgemm_variant == 0 && m >= 128 && n >= 128 && nb_outer * nb_inner == 1 && k >= 4096) {
         const long tiles = (long)ceil_div(n, SG2_BN) * ceil_div(m, SG2_BM);
-        int S = 1;
-        if (tiles < 256) {
-            S = (int)((512 + tiles - 1) / tiles);
-            if (S > 16) S = 16;
-            while (S > 1 && (k % (S * SG2_BK) != 0 || k / S < 1024)) S--;
+        // S slices: tiles * S workgroups run in rounds of the 256 CUs and a round costs one slice (K / S), so time ~ ceil(tiles S / 256) / S — S = 4
+        // on 144 tiles is 2.25 rounds = 3 (0.75 of a full-K tile time, the measured 85 vs 113 TFLOP/s), S = 7 is 3.94 = 4 (0.57) — plus the
+        // partials' round trip through HBM (2 S m n floats at ~5 TB/s against ~0.5 TFLOP/s per CU).  Slices of unequal length (the last one shorter).
+        // (also above 256 tiles: 384 tiles — the vocabulary heads' dX, K = 50 257 — are 1.5 rounds = 2 unsplit, 3 rounds of half the K when split in two)
+        int S = 1, kc = k;
+        if (tiles < 1024) {
+            double best = 1e300;
+            const double t_tile = 2.0 * SG2_BM * SG2_BN * (double)k / 0.5e12, t_part = 8.0 * (double)m * n / 5e12;
+            for (int c = 1; c <= 16; c++) {
+                const int per = ceil_div(ceil_div(k, SG2_BK), c) * SG2_BK;      // slice length, a multiple of the K-step
+                const int slices = ceil_div(k, per);
+                if (c > 1 && (per < 1024 || slices < 2)) continue;
+                const double cost = (double)ceil_div((int)(tiles * slices), 256) * t_tile * per / k + (slices > 1 ? slices * t_part : 0.0);
+                if (cost < best - 1e-12) { best = cost; S = slices; kc = per; }
+            }
         }
         if (S > 1) {
             const size_t need = (size_t)S * m * n;
@@ -305,9 +321,8 @@ extern "C" int lmrl_sgemm(int trans_a, int trans_b, int m, int n, int k, float a
                 LMRL_CHECK_HIP(hipMalloc(&g_splitk_ws, need * sizeof(float)));
                 g_splitk_ws_floats = need;
             }
-            const int kc = k / S;
             SgemmArgs gs{a_d, b_d, g_splitk_ws, nullptr, m, n, kc, lda, ldb, n,
-                         trans_a ? (long)kc * lda : (long)kc, 0, trans_b ? (long)kc : (long)kc * ldb, 0, (long)m * n, 0, 1, 1.f, 0.f};
+                         trans_a ? (long)kc * lda : (long)kc, 0, trans_b ? (long)kc : (long)kc * ldb, 0, (long)m * n, 0, 1, 1.f, 0.f, k};
             dim3 grid2(ceil_div(n, SG2_BN), ceil_div(m, SG2_BM), S);
             if (!trans_a && !trans_b) hipLaunchKernelGGL((sgemm_f32_128_kernel<false, false>), grid2, dim3(256), 0, s, gs);
             else if (!trans_a && trans_b) hipLaunchKernelGGL((sgemm_f32_128_kernel<false, true>), grid2, dim3(256), 0, s, gs);

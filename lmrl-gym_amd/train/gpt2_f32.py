@@ -104,7 +104,7 @@ class GPT2F32:
         self.ws = Workspace(self.dev)
         self._colsum_ws = torch.empty(64 * max(self.d_ff, 3 * self.d, self.vocab), dtype=torch.float32, device=self.dev)
         self.mm = ops.MatmulBF16(self.dev) if matmul == "bf16" else None
-        self.ld_vocab = ops._pad(self.vocab) if self.mm is not None else self.vocab     # row stride of [rows, V] logits
+        self.ld_vocab = ops._pad(self.vocab) if self.mm is not None else ops._pad(self.vocab, 4)     # row stride of [rows, V] logits (fp32: 16-byte aligned rows)
 
     def _layer_forward(self, l: int, x, B: int, T: int, km, flash: bool, lse_n: int, resid_in=None):
         """One transformer block: x [B*T, d] -> (x_out, pending, cache of every intermediate the backward pass reads).  resid_in: a residual
@@ -465,7 +465,9 @@ class MLPHeadF32:
         self._ws = torch.empty(64 * max(self.dout, self.dh), dtype=torch.float32, device=device)
         self.mm = ops.MatmulBF16(device) if matmul == "bf16" else None
         self.mm2 = self.mm if self.dout >= 64 else None           # a scalar output (V head) stays on the fp32 kernel
-        self.ld_out = ops._pad(self.dout) if self.mm2 is not None else self.dout
+        # row pitch of the [rows, dout] outputs: whole 64-column groups in the bf16-matmul mode; fp32: 16-byte aligned rows for a vocabulary-wide
+        # head (its dlogits are the K-contiguous operand of the dX product: 50 257 floats per row would force 4-byte loads)
+        self.ld_out = ops._pad(self.dout) if self.mm2 is not None else (ops._pad(self.dout, 4) if self.dout >= 64 else self.dout)
 
     def hidden(self, x, rows):
         """relu(x @ W1 + b1) -> (a, z)"""
@@ -491,12 +493,28 @@ class MLPHeadF32:
         ops.relu_fwd(z, a)
         return a, z
 
+    def _w2(self, refresh: bool):
+        """(dense2.kernel operand, its row pitch) for the fp32 products: a vocabulary-wide kernel has 50 257-float rows, none of them 16-byte
+        aligned, which forces the guarded 4-byte loads on the whole dX product (74 vs 113 TFLOP/s); a copy with the rows padded to a multiple of
+        4 floats, refreshed once per forward (the optimizer moves the master), takes the 16-byte path.  Same values, same products."""
+        w = self.p["dense2.kernel"]
+        if self.mm2 is not None or self.dout < 64 or self.dout % 4 == 0:
+            return w, None
+        ld = ops._pad(self.dout, 4)
+        if getattr(self, "_w2_al", None) is None:
+            self._w2_al = self.t.zeros(self.dh, ld, dtype=self.t.float32, device=self.dev)
+            refresh = True
+        if refresh:
+            self._w2_al[:, :self.dout].copy_(w)
+        return self._w2_al, ld
+
     def forward(self, x, rows):
         """-> (y [rows, ld_out] with columns [0, dout) valid, cache)"""
         t = self.t
         a, z = self.hidden(x, rows)
         y = t.empty(rows, self.ld_out, dtype=t.float32, device=self.dev)
-        ops.linear_fwd(a, self.p["dense2.kernel"], self.p["dense2.bias"], y, rows, self.dh, self.dout, mm=self.mm2, ldy=self.ld_out)
+        w2, ldw = self._w2(True)
+        ops.linear_fwd(a, w2, self.p["dense2.bias"], y, rows, self.dh, self.dout, mm=self.mm2, ldy=self.ld_out, ldw=ldw)
         return y, dict(x=x, z=z, a=a, rows=rows)
 
     def fused_ce_ok(self) -> bool:
@@ -531,8 +549,9 @@ class MLPHeadF32:
     def backward(self, cache, dy, grads, dx=None, accumulate_dx=False, dyb=None):
         t, rows = self.t, cache["rows"]
         da = t.empty(rows, self.dh, dtype=t.float32, device=self.dev)
-        ops.linear_bwd(cache["a"], self.p["dense2.kernel"], dy, da, grads["dense2.kernel"], grads["dense2.bias"], rows, self.dh, self.dout, self._ws,
-                       mm=self.mm2, lddy=self.ld_out, dyb=dyb)
+        w2, ldw = self._w2(False)
+        ops.linear_bwd(cache["a"], w2, dy, da, grads["dense2.kernel"], grads["dense2.bias"], rows, self.dh, self.dout, self._ws,
+                       mm=self.mm2, lddy=self.ld_out, dyb=dyb, ldw=ldw)
         ops.relu_bwd(da, cache["z"], da)
         ops.linear_bwd(cache["x"], self.p["dense1.kernel"], da, dx, grads["dense1.kernel"], grads["dense1.bias"], rows, self.din, self.dh, self._ws,
                        dx_beta=1.0 if accumulate_dx else 0.0, mm=self.mm)

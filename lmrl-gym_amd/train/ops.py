@@ -255,7 +255,7 @@ def ce_bwd_inplace(yb, n, lse, targets, coef_ce, coef_gather, rows):
 FUSE_RESIDUAL = False
 
 
-def linear_fwd(x, w, b, y, rows, k, n, mm: Optional[MatmulBF16] = None, ldy=None, xb=None, resid=None):
+def linear_fwd(x, w, b, y, rows, k, n, mm: Optional[MatmulBF16] = None, ldy=None, xb=None, resid=None, ldw=None):
     """y[rows][n] = x[rows][k] @ w[k][n] + b   (flax Dense / HF Conv1D kernel layout [in, out]); row stride of y = ldy (default n).
     xb: the bf16 operand of x if its producer already staged it (`MatmulBF16.stage`, LayerNorm / gelu / attention `_staged` forms).
     resid (fp32, same shape and pitch as y): y = resid + x @ w + b — the block's residual add inside the projection (one launch in the
@@ -266,7 +266,7 @@ def linear_fwd(x, w, b, y, rows, k, n, mm: Optional[MatmulBF16] = None, ldy=None
         axpby(1.0, y, 1.0, resid, y)
         return
     if mm is None:
-        sgemm(x, w, y, rows, n, k, lda=k, ldb=n, ldc=ldy, bias=b)
+        sgemm(x, w, y, rows, n, k, lda=k, ldb=ldw or n, ldc=ldy, bias=b)       # ldw: row pitch of w when it is a padded copy (fp32 mode)
         if resid is not None:
             axpby(1.0, y, 1.0, resid, y)
         return
@@ -278,14 +278,14 @@ def linear_fwd(x, w, b, y, rows, k, n, mm: Optional[MatmulBF16] = None, ldy=None
 
 
 def linear_bwd(x, w, dy, dx, dw, db, rows, k, n, ws, *, accumulate_dw=True, dx_beta=0.0, mm: Optional[MatmulBF16] = None, lddy=None, dyb=None,
-               xb=None):
+               xb=None, ldw=None):
     """dx = dy @ w^T ; dw (+)= x^T @ dy ; db (+)= colsum(dy).  dyb (bf16 mode): dy already staged by its producer as the bf16 operand
     `mm.stage_dy(rows, n)` — then `dy` is not read (may be None) and the bias gradient sums the bf16 values.  xb (bf16 mode): the bf16
     operand of x the forward kept (`mm.stash(rows, k)`) — then `x` is not read (may be None)."""
     lddy = lddy or n
     if mm is None:
         if dx is not None:
-            sgemm(dy, w, dx, rows, k, n, trans_b=True, lda=lddy, ldb=n, ldc=k, beta=dx_beta)
+            sgemm(dy, w, dx, rows, k, n, trans_b=True, lda=lddy, ldb=ldw or n, ldc=k, beta=dx_beta)
         if n == 1 and ws.numel() >= 64 * k:     # one output unit (value heads): x^T dy is a matrix-vector product, not 12 sgemm tiles over K = rows
             _lib.check(_L().lmrl_colsum_weighted(x.data_ptr(), rows, k, k, dy.data_ptr(), lddy, dw.data_ptr(), int(accumulate_dw), ws.data_ptr(), _sp()),
                        "lmrl_colsum_weighted")
