@@ -6,8 +6,11 @@ the reference drives the native engine, and weights trained here can be handed b
 The tensors are flax `msgpack` pytrees (`flax.serialization.msgpack_serialize`, called by JaxSeq `save_pytree`): nested
 string-keyed maps whose leaves are msgpack ExtType 1 = packed `(shape, dtype name, raw bytes)`, ExtType 3 = numpy scalar,
 and — for arrays above 2^30 bytes — a `{"__msgpack_chunked_array__": True, "shape": ..., "chunks": {...}}` map.  flax and
-jax are not installable here, so the reader follows the published format and is exercised against byte strings built
-directly with `msgpack` in the tests: parity with real reference checkpoints is **unpinned**.
+jax are not installable here, so the leaf encoding follows the published format: **unpinned** against a real flax blob.  The file LAYOUT has two
+forms: one msgpack map (`flax.serialization.to_bytes(tree)`), or the streaming form — a concatenation of `(key path, to_bytes(leaf))` records —
+which the reference's own `save_pytree` writes (llm_rl_scripts/twenty_questions/env/convert_checkpoints.py:36-47, adapted from EasyLM as JaxSeq's
+is); that one IS pinned: tests/golden/ckpt_stream.json holds a file written by that reference function (executed with its flax / jax calls on
+stand-ins), `load_msgpack_tree` reads it back leaf for leaf and `save_msgpack_tree(streaming=True)` reproduces its bytes.
 
 Parameter naming: HF-Flax GPT-2 (`transformer/{wte,wpe}/embedding`, `transformer/h/<l>/{ln_1,ln_2}/{scale,bias}`,
 `.../attn/{c_attn,c_proj}/{kernel,bias}`, `.../mlp/{c_fc,c_proj}/{kernel,bias}`, `transformer/ln_f/{scale,bias}`) with
@@ -73,7 +76,32 @@ def load_msgpack_tree(path: str) -> Dict[str, Any]:
                 arr = u.view(np.float32).reshape(shape)
                 return arr.copy() if code == 1 else arr[()]
         return _ext_hook(code, data)
+    streamed = _load_streamed(raw, hook)
+    if streamed is not None:
+        return streamed
     return _unchunk(msgpack.unpackb(raw, ext_hook=hook, raw=False, strict_map_key=False))
+
+
+def _load_streamed(raw: bytes, hook) -> Optional[Dict[str, Any]]:
+    """The streaming layout (`save_pytree` of llm_rl_scripts/twenty_questions/env/convert_checkpoints.py:36-47, adapted from EasyLM like JaxSeq's):
+    a concatenation of msgpack records `(key path, flax to_bytes(leaf))` over the flattened state dict, instead of ONE msgpack map.  Returns None
+    when `raw` is not in that layout.  Pinned to a file written by the reference's own function (tests/golden/ckpt_stream.json)."""
+    import io
+    import msgpack
+    unp = msgpack.Unpacker(io.BytesIO(raw), raw=False, strict_map_key=False, ext_hook=hook, max_buffer_size=0)
+    tree: Dict[str, Any] = {}
+    n = 0
+    for rec in unp:
+        if not (isinstance(rec, (list, tuple)) and len(rec) == 2 and isinstance(rec[0], (list, tuple)) and len(rec[0]) > 0
+                and all(isinstance(k, str) for k in rec[0]) and isinstance(rec[1], (bytes, bytearray))):
+            return None
+        leaf = msgpack.unpackb(rec[1], ext_hook=hook, raw=False, strict_map_key=False) if len(rec[1]) else {}
+        node = tree
+        for k in rec[0][:-1]:
+            node = node.setdefault(k, {})
+        node[rec[0][-1]] = _unchunk(leaf)
+        n += 1
+    return tree if n else None
 
 
 def _pack_leaf(x):
@@ -90,12 +118,24 @@ def _pack_leaf(x):
     return x
 
 
-def save_msgpack_tree(path: str, tree: Dict[str, Any]) -> None:
+def save_msgpack_tree(path: str, tree: Dict[str, Any], streaming: bool = False) -> None:
+    """streaming=False: one flax `to_bytes` map; True: the record-per-leaf layout of the reference's streaming `save_pytree` (see `_load_streamed`)."""
     import msgpack
     conv = lambda t: {k: conv(v) for k, v in t.items()} if isinstance(t, dict) else _pack_leaf(t)
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "wb") as f:
-        f.write(msgpack.packb(conv(tree), use_bin_type=True))
+        if not streaming:
+            f.write(msgpack.packb(conv(tree), use_bin_type=True))
+            return
+        packer = msgpack.Packer()
+
+        def walk(t, prefix):
+            for k, v in t.items():
+                if isinstance(v, dict) and v:
+                    walk(v, prefix + (k,))
+                else:
+                    f.write(packer.pack((prefix + (k,), msgpack.packb(conv(v) if isinstance(v, dict) else _pack_leaf(v), use_bin_type=True))))
+        walk(tree, ())
 
 
 def _np(x) -> np.ndarray:

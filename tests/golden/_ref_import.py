@@ -17,7 +17,7 @@ REFERENCE_ROOT = "/root/reference"
 
 _STUB_ROOTS = (
     "jax", "jaxlib", "flax", "optax", "chex", "JaxSeq", "jaxtyping", "gcsfs", "wandb",
-    "tyro", "transformers", "termcolor", "IPython", "skimage", "tiktoken", "openai", "nltk",
+    "tyro", "transformers", "termcolor", "IPython", "skimage", "tiktoken", "openai", "nltk", "jax_models",
 )
 
 
