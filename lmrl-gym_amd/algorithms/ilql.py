@@ -328,11 +328,12 @@ class GPT2ILQLTrain:
         # data parallel: the head gradients (final already) and the base gradients are all-reduced while the base backward runs — arena
         # slices go to RCCL as blocks finish (dist.GradReducer); the one data-path collective of an ILQL step (~815 MB fp32, GPT-2-small)
         red = D.GradReducer()
+        late = red.early([g1, g2, gv])                 # the heads' gradients are final: reduced under the base backward, not after it
         base.backward(cache, d_hidden, bgrads, on_final=red.ready(bgrads))
         self.last_grads = (bgrads, g1, g2, gv)
         if getattr(self, "keep_head_caches", False):      # tests: the heads' pre-activations (which side of relu each unit took) and their row set
             self.last_head_caches = (q1c, q2c, vc, q_rows if compact else None)
-        red.finish([g1, g2, gv])
+        red.finish(late)
         self.calls += 1                                 # TrainState.step of the reference: one per apply_gradients call
         upd = self.base_opt.apply(bgrads)
         self.q1_opt.apply(g1); self.q2_opt.apply(g2); self.v_opt.apply(gv)

@@ -194,9 +194,10 @@ class GPT2MCTrain:
             if self.detach_q:
                 d_hidden.zero_()
         red = D.GradReducer()                        # gradient all-reduce overlapped with the base backward (data parallel)
+        late = red.early([qgrads])                   # the head's gradients are final already
         base.backward(cache, d_hidden, bgrads, on_final=red.ready(bgrads))
         self.last_grads = (bgrads, qgrads)
-        red.finish([qgrads])
+        red.finish(late)
         self.base_opt.apply(bgrads)
         self.q_opt.apply(qgrads)
         return self, loss, logs
