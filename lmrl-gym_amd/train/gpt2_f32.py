@@ -119,7 +119,8 @@ class GPT2F32:
         mm = self.mm
         stage = mm is not None and d % 64 == 0 and self.d_ff % 64 == 0     # producers write the bf16 GEMM operands themselves (no cast pass)
         # stage: LayerNorm / gelu / attention write the bf16 operand of the consuming GEMM themselves, into per-layer buffers the backward
-        # transposes for the dW products — no fp32 copies of h1 / h2 / g exist in this mode (att keeps one: the flash backward reads it)
+        # reads as they are for the dW products (ops.FUSE_KMAJOR_DW; transposed where that kernel's shape conditions do not hold) — no fp32 copies of
+        # h1 / h2 / g exist in this mode (att keeps one: the flash backward reads it)
         c["m1"], c["r1"] = new(R), new(R)
         h1 = h1b = None
         fuse_add = ops.FUSE_ADD_LN
@@ -349,24 +350,20 @@ class GPT2F32:
             if "h1" not in c:              # checkpointed block: recompute its intermediates from the stored input
                 _, _, c = self._layer_forward(l, c["x_in"], B, T, cache["km"], cache["flash"], cache["lse_n"])
             # MLP: x_out = x_mid + gelu(h2 W_fc + b) W_proj + b
-            dfb = None
             if mm is not None and dxb[0] is not None and c.get("gb") is not None and ops.fused_ok(self.d_ff, ops.FUSE_GELU_BWD):
                 # dg = dx @ W_proj^T never exists: the dX product's epilogue multiplies by gelu'(f) and writes df as the bf16 operand of c_fc's backward
                 df, dfb = None, ops.linear_bwd_dx_gelu(mm, dxb[0], p[q + "mlp.c_proj.weight"], c["f"], R, self.d_ff, d)
                 ops.linear_bwd(None, p[q + "mlp.c_proj.weight"], dx, None, grads[q + "mlp.c_proj.weight"], grads[q + "mlp.c_proj.bias"], R, self.d_ff, d, ws,
                                mm=mm, dyb=dxb[0], xb=c["gb"])
-                dg = None
             else:
                 dg = new(R, self.d_ff)
                 ops.linear_bwd(c["g"], p[q + "mlp.c_proj.weight"], dx, dg, grads[q + "mlp.c_proj.weight"], grads[q + "mlp.c_proj.bias"], R, self.d_ff, d, ws,
                                mm=mm, dyb=dxb[0], xb=c.get("gb"))
-            if dfb is not None:
-                pass
-            elif mm is not None:           # df only feeds the c_fc backward products: written as their bf16 operand, no fp32 copy
-                df, dfb = None, ops.gelu_bwd_staged(mm, dg, c["f"], R, self.d_ff)
-            else:
-                df = dg
-                ops.gelu_bwd(dg, c["f"], df)
+                if mm is not None:         # df only feeds the c_fc backward products: written as their bf16 operand, no fp32 copy
+                    df, dfb = None, ops.gelu_bwd_staged(mm, dg, c["f"], R, self.d_ff)
+                else:
+                    df, dfb = dg, None
+                    ops.gelu_bwd(dg, c["f"], df)
             dh2 = new(R, d)
             ops.linear_bwd(c["h2"], p[q + "mlp.c_fc.weight"], df, dh2, grads[q + "mlp.c_fc.weight"], grads[q + "mlp.c_fc.bias"], R, d, self.d_ff, ws, mm=mm,
                            dyb=dfb, xb=c.get("h2b"))

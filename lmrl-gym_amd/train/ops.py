@@ -135,7 +135,8 @@ class MatmulBF16:
 
     def stash(self, rows, k):
         """(fresh buffer, row pitch) for a staged operand [rows][k] that must outlive the next `stage`: the forward keeps its bf16 operands
-        per layer, the backward transposes them for the dW products (`linear_bwd(xb=...)`) — no fp32 copy of those activations exists."""
+        per layer, the backward's dW products read them as staged (`linear_bwd(xb=...)`: `lmrl_gemm_bf16_splitk_kmajor`, or a bf16 transpose where
+        that kernel does not apply) — no fp32 copy of those activations exists."""
         assert k % 64 == 0
         return self.t.empty(_padn(rows) * _pitch(k), dtype=self.t.bfloat16, device=self.dev), _pitch(k)
 
