@@ -99,6 +99,7 @@ class KVSessionF32:
             c, R, dev = self.eng.cfg, self.B * C, self.eng.device
             f = lambda *s: t.empty(*s, dtype=t.float32, device=dev)
             self._ws[C] = dict(ids=t.zeros(R, dtype=t.int32, device=dev), pos=t.zeros(R, dtype=t.int32, device=dev), x=f(R, c.d_model), h=f(R, c.d_model),
+                               r=f(R, c.d_model),
                                qkv=f(R, 3 * c.d_model), att=f(R, c.d_model), ff=f(R, c.d_ff), mean=f(R), rstd=f(R),
                                split=t.empty(R * 3 * c.d_ff, dtype=t.bfloat16, device=dev) if self.eng.matmul == "bf16x3" else None)
         return self._ws[C]
@@ -120,21 +121,22 @@ class KVSessionF32:
         _lib.check(L.lmrl_chunk_begin_f32(_lib.ptr(self.len), _lib.ptr(cnt), _lib.ptr(w["ids"]), _lib.ptr(w["pos"]), B, C, c.n_pos, sp), "lmrl_chunk_begin_f32")
         x, h, qkv, att, ff = w["x"], w["h"], w["qkv"], w["att"], w["ff"]
         ops.embed_fwd(e.wte, e.wpe, w["ids"], w["pos"], x, R, d)
+        r, pending = w["r"], None              # residual adds ride in the LayerNorm launch behind them (lmrl_layernorm_add_fwd: x += pending, then LN)
         for l, p in enumerate(e.layers):
-            ops.layernorm_fwd(x, p["ln_1.weight"], p["ln_1.bias"], h, w["mean"], w["rstd"], R, d, c.ln_eps)
+            ops.layernorm_add_fwd(x, pending, p["ln_1.weight"], p["ln_1.bias"], h, w["mean"], w["rstd"], None, 0, R, d, c.ln_eps)
             e.linear(h, R, d, 3 * d, "attn.c_attn", p, qkv, w["split"])
             _lib.check(L.lmrl_attn_cached_f32(_lib.ptr(qkv), _lib.ptr(self.kv[l, 0]), _lib.ptr(self.kv[l, 1]), _lib.ptr(self.len), _lib.ptr(cnt),
                                               _lib.ptr(att), B, C, c.n_head, self.tmax, sp), "lmrl_attn_cached_f32")
-            # x += att . Wproj + b   (bias through a beta = 1 accumulate: h = att.W + b, then x += h)
-            e.linear(att, R, d, d, "attn.c_proj", p, h, w["split"])
-            ops.axpby(1.0, h, 1.0, x, x)
-            ops.layernorm_fwd(x, p["ln_2.weight"], p["ln_2.bias"], h, w["mean"], w["rstd"], R, d, c.ln_eps)
+            e.linear(att, R, d, d, "attn.c_proj", p, r, w["split"])                 # r = att . Wproj + b ; x += r inside the ln_2 launch
+            ops.layernorm_add_fwd(x, r, p["ln_2.weight"], p["ln_2.bias"], h, w["mean"], w["rstd"], None, 0, R, d, c.ln_eps)
             e.linear(h, R, d, c.d_ff, "mlp.c_fc", p, ff, w["split"])
             ops.gelu_fwd(ff, ff)
-            e.linear(ff, R, c.d_ff, d, "mlp.c_proj", p, h, w["split"])
-            ops.axpby(1.0, h, 1.0, x, x)
+            e.linear(ff, R, c.d_ff, d, "mlp.c_proj", p, r, w["split"])              # r = mlp output ; added by the next LayerNorm launch
+            pending = r
         if all_hidden is not None:
-            ops.layernorm_fwd(x, e.lnf_g, e.lnf_b, all_hidden, w["mean"], w["rstd"], R, d, c.ln_eps)
+            ops.layernorm_add_fwd(x, pending, e.lnf_g, e.lnf_b, all_hidden, w["mean"], w["rstd"], None, 0, R, d, c.ln_eps)
+        elif pending is not None:
+            ops.axpby(1.0, pending, 1.0, x, x)
         _lib.check(L.lmrl_chunk_end_f32(_lib.ptr(x), _lib.ptr(cnt), _lib.ptr(self._last_x), _lib.ptr(self.len), B, C, d, sp), "lmrl_chunk_end_f32")
         ops.layernorm_fwd(self._last_x, e.lnf_g, e.lnf_b, self.last_hidden, w["mean"], w["rstd"], B, d, c.ln_eps)
         return self.last_hidden
