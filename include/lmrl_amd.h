@@ -586,6 +586,11 @@ int lmrl_layernorm_fwd_staged(const float *x_d, const float *g_d, const float *b
  * stream on exit. */
 int lmrl_layernorm_add_fwd(float *x_d, const float *resid_d, const float *g_d, const float *b_d, float *y_d, float *mean_d, float *rstd_d, void *yb_d,
                            long ldb, int rows, int d, float eps, void *stream);
+/* the same with the output written only as the "bf16 x 3" operand [rows][3 d] = [hi | lo | hi] (lmrl_split3_bf16's row format) — LayerNorm + split in one
+ * pass for GPT2EngineF32's bf16x3 matmul mode (d a multiple of 256, <= 1280); lmrl_gelu_split3: gelu_new + split likewise ([rows][3 cols]). */
+int lmrl_layernorm_add_fwd_split3(float *x_d, const float *resid_d, const float *g_d, const float *b_d, float *mean_d, float *rstd_d, void *split_d,
+                                  int rows, int d, float eps, void *stream);
+int lmrl_gelu_split3(const float *x_d, int rows, int cols, void *split_d, void *stream);
 int lmrl_gelu_fwd_staged(const float *x_d, float *y_d, void *yb_d, long ldb, int rows, int cols, void *stream);
 /* dx (=|+=) LN backward; dy_xhat_d (optional [rows][d]) receives dy*xhat whose column sum is d gamma */
 int lmrl_layernorm_bwd(const float *dy_d, const float *x_d, const float *g_d, const float *mean_d, const float *rstd_d, float *dx_d,

@@ -124,7 +124,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
 // The same with the row held in registers (d = 256 NV: 768, 1024, 1280, ...): one 16-byte load per lane and 256 columns, the row read ONCE, and
 // optionally the block's residual add in front — x[r] += resid[r] (in place: x is the projection's output, afterwards the residual stream the
 // backward's LayerNorm reads) — so that no stand-alone `x + proj(...)` pass over [B*T][d] floats runs between a projection and the LayerNorm behind it.
-template <int NV>
+// SPLIT3: yb is the "bf16 x 3" operand [R][3 d] = [hi | lo | hi] of the LayerNorm output (hi = bf16(v), lo = bf16(v - hi): lmrl_split3_bf16's row
+// format, GPT2EngineF32's bf16x3 matmul mode) instead of its plain bf16 copy.
+__device__ __forceinline__ void split3_pack4(float a, float b, float c, float d, uint2 &hi, uint2 &lo) {
+    const uint16_t h0 = f32_to_bf16_rne(a), h1 = f32_to_bf16_rne(b), h2 = f32_to_bf16_rne(c), h3 = f32_to_bf16_rne(d);
+    hi.x = (uint32_t)h0 | ((uint32_t)h1 << 16); hi.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+    const float l0 = a - __uint_as_float((uint32_t)h0 << 16), l1 = b - __uint_as_float((uint32_t)h1 << 16);
+    const float l2 = c - __uint_as_float((uint32_t)h2 << 16), l3 = d - __uint_as_float((uint32_t)h3 << 16);
+    lo.x = (uint32_t)f32_to_bf16_rne(l0) | ((uint32_t)f32_to_bf16_rne(l1) << 16); lo.y = (uint32_t)f32_to_bf16_rne(l2) | ((uint32_t)f32_to_bf16_rne(l3) << 16);
+}
+template <int NV, bool SPLIT3 = false>
 __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(float *x, const float *__restrict__ resid, const float *__restrict__ g,
                                                          const float *__restrict__ b, float *__restrict__ y, float *__restrict__ mean,
                                                          float *__restrict__ rstd, int R, float eps, uint16_t *__restrict__ yb, long ldb) {
@@ -164,10 +173,17 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(float *x, const float *
         o.z = (v[k].z - mu) * rs * gg.z + bb.z; o.w = (v[k].w - mu) * rs * gg.w + bb.w;
         if (y) *reinterpret_cast<float4 *>(y + (size_t)r * d + c) = o;
         if (yb) {
-            uint2 pk;
-            pk.x = (uint32_t)f32_to_bf16_rne(o.x) | ((uint32_t)f32_to_bf16_rne(o.y) << 16);
-            pk.y = (uint32_t)f32_to_bf16_rne(o.z) | ((uint32_t)f32_to_bf16_rne(o.w) << 16);
-            *reinterpret_cast<uint2 *>(yb + (size_t)r * ldb + c) = pk;
+            if constexpr (SPLIT3) {
+                uint2 hi, lo;
+                split3_pack4(o.x, o.y, o.z, o.w, hi, lo);
+                uint16_t *q = yb + (size_t)r * ldb + c;
+                *reinterpret_cast<uint2 *>(q) = hi; *reinterpret_cast<uint2 *>(q + d) = lo; *reinterpret_cast<uint2 *>(q + 2 * d) = hi;
+            } else {
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16_rne(o.x) | ((uint32_t)f32_to_bf16_rne(o.y) << 16);
+                pk.y = (uint32_t)f32_to_bf16_rne(o.z) | ((uint32_t)f32_to_bf16_rne(o.w) << 16);
+                *reinterpret_cast<uint2 *>(yb + (size_t)r * ldb + c) = pk;
+            }
         }
     }
     if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
@@ -377,6 +393,18 @@ __device__ __forceinline__ float gelu_new_exact(float x) {
 // (the elementwise kernels below may be called in place — out == x or out == y: no __restrict__ on the pairs that may alias)
 __global__ void gelu_fwd_kernel(const float *x, float *y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = gelu_new_exact(x[i]);
+}
+// gelu_new(x) written as the bf16 x 3 operand [rows][3 cols] (see SPLIT3 above): gelu + lmrl_split3_bf16 in one pass.  cols a multiple of 4.
+__global__ __launch_bounds__(256) void gelu_split3_kernel(const float *__restrict__ x, int rows, int cols, uint16_t *__restrict__ dst) {
+    const long n4 = (long)rows * (cols / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / (cols / 4)), c = (int)(i - (long)r * (cols / 4)) * 4;
+        const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)r * cols + c);
+        uint2 hi, lo;
+        split3_pack4(gelu_new_exact(v.x), gelu_new_exact(v.y), gelu_new_exact(v.z), gelu_new_exact(v.w), hi, lo);
+        uint16_t *q = dst + (size_t)r * 3 * cols + c;
+        *reinterpret_cast<uint2 *>(q) = hi; *reinterpret_cast<uint2 *>(q + cols) = lo; *reinterpret_cast<uint2 *>(q + 2 * cols) = hi;
+    }
 }
 // the same on a [rows][cols] matrix, writing the bf16 copy (row pitch ldb) the consuming GEMM reads and, optionally, the fp32 result
 // (bf16-matmul train mode keeps only the bf16 copy: it is both the c_proj operand and, transposed, the operand of its dW product).
@@ -698,6 +726,30 @@ int lmrl_layernorm_add_fwd(float *x_d, const float *resid_d, const float *g_d, c
                                (uint16_t *)yb_d, ldb);
     }
 #undef LMRL_LNV
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_layernorm_add_fwd_split3(float *x_d, const float *resid_d, const float *g_d, const float *b_d, float *mean_d, float *rstd_d, void *split_d,
+                                  int rows, int d, float eps, void *stream) {
+    LMRL_REQUIRE(x_d && g_d && b_d && mean_d && rstd_d && split_d && rows > 0 && d > 0 && d % 256 == 0 && d <= 1280,
+                 "lmrl_layernorm_add_fwd_split3: bad argument (d a multiple of 256 up to 1280)");
+#define LMRL_LNS(NV_)                                                                                                                   \
+    hipLaunchKernelGGL((ln_fwd_vec_kernel<NV_, true>), dim3(ceil_div(rows, 4)), dim3(256), 0, ST, x_d, resid_d, g_d, b_d, (float *)nullptr, mean_d, \
+                       rstd_d, rows, eps, (uint16_t *)split_d, (long)3 * d)
+    switch (d / 256) {
+        case 1: LMRL_LNS(1); break;
+        case 2: LMRL_LNS(2); break;
+        case 3: LMRL_LNS(3); break;
+        case 4: LMRL_LNS(4); break;
+        default: LMRL_LNS(5); break;
+    }
+#undef LMRL_LNS
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+int lmrl_gelu_split3(const float *x_d, int rows, int cols, void *split_d, void *stream) {
+    LMRL_REQUIRE(x_d && split_d && rows > 0 && cols > 0 && cols % 4 == 0, "lmrl_gelu_split3: bad argument");
+    hipLaunchKernelGGL(gelu_split3_kernel, dim3(ew_grid((size_t)rows * cols / 4)), dim3(256), 0, ST, x_d, rows, cols, (uint16_t *)split_d);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

@@ -62,7 +62,8 @@ class GPT2EngineF32:
             ops.sgemm(x, p[w_name + ".weight"], y, rows, n, k, lda=k, ldb=n, ldc=n, bias=p[w_name + ".bias"])
             return
         L = self._L
-        _lib.check(L.lmrl_split3_bf16(x.data_ptr(), k, rows, k, scratch.data_ptr(), 3 * k, _lib.stream_ptr()), "lmrl_split3_bf16")
+        if x is not None:          # None: `scratch` already holds the split operand (written by the producing LayerNorm / gelu launch)
+            _lib.check(L.lmrl_split3_bf16(x.data_ptr(), k, rows, k, scratch.data_ptr(), 3 * k, _lib.stream_ptr()), "lmrl_split3_bf16")
         _lib.check(L.lmrl_gemm_bf16(scratch.data_ptr(), p[w_name + ".weight.x3"].data_ptr(), p[w_name + ".bias"].data_ptr(), y.data_ptr(), rows, n, 3 * k, 3 * k,
                                     n, n, 3, _lib.stream_ptr()), "lmrl_gemm_bf16 (bf16x3)")
 
@@ -122,16 +123,27 @@ class KVSessionF32:
         x, h, qkv, att, ff = w["x"], w["h"], w["qkv"], w["att"], w["ff"]
         ops.embed_fwd(e.wte, e.wpe, w["ids"], w["pos"], x, R, d)
         r, pending = w["r"], None              # residual adds ride in the LayerNorm launch behind them (lmrl_layernorm_add_fwd: x += pending, then LN)
+        x3 = e.matmul == "bf16x3" and d % 256 == 0 and d <= 1280      # bf16x3: LayerNorm / gelu write the three-term split operand themselves
+
+        def ln(resid, g, b):
+            if x3:
+                _lib.check(L.lmrl_layernorm_add_fwd_split3(x.data_ptr(), _lib.ptr(resid), g.data_ptr(), b.data_ptr(), w["mean"].data_ptr(), w["rstd"].data_ptr(),
+                                                           w["split"].data_ptr(), R, d, float(c.ln_eps), sp), "lmrl_layernorm_add_fwd_split3")
+                return None
+            ops.layernorm_add_fwd(x, resid, g, b, h, w["mean"], w["rstd"], None, 0, R, d, c.ln_eps)
+            return h
         for l, p in enumerate(e.layers):
-            ops.layernorm_add_fwd(x, pending, p["ln_1.weight"], p["ln_1.bias"], h, w["mean"], w["rstd"], None, 0, R, d, c.ln_eps)
-            e.linear(h, R, d, 3 * d, "attn.c_attn", p, qkv, w["split"])
+            e.linear(ln(pending, p["ln_1.weight"], p["ln_1.bias"]), R, d, 3 * d, "attn.c_attn", p, qkv, w["split"])
             _lib.check(L.lmrl_attn_cached_f32(_lib.ptr(qkv), _lib.ptr(self.kv[l, 0]), _lib.ptr(self.kv[l, 1]), _lib.ptr(self.len), _lib.ptr(cnt),
                                               _lib.ptr(att), B, C, c.n_head, self.tmax, sp), "lmrl_attn_cached_f32")
             e.linear(att, R, d, d, "attn.c_proj", p, r, w["split"])                 # r = att . Wproj + b ; x += r inside the ln_2 launch
-            ops.layernorm_add_fwd(x, r, p["ln_2.weight"], p["ln_2.bias"], h, w["mean"], w["rstd"], None, 0, R, d, c.ln_eps)
-            e.linear(h, R, d, c.d_ff, "mlp.c_fc", p, ff, w["split"])
-            ops.gelu_fwd(ff, ff)
-            e.linear(ff, R, c.d_ff, d, "mlp.c_proj", p, r, w["split"])              # r = mlp output ; added by the next LayerNorm launch
+            e.linear(ln(r, p["ln_2.weight"], p["ln_2.bias"]), R, d, c.d_ff, "mlp.c_fc", p, ff, w["split"])
+            if x3:
+                _lib.check(L.lmrl_gelu_split3(ff.data_ptr(), R, c.d_ff, w["split"].data_ptr(), sp), "lmrl_gelu_split3")
+                e.linear(None, R, c.d_ff, d, "mlp.c_proj", p, r, w["split"])
+            else:
+                ops.gelu_fwd(ff, ff)
+                e.linear(ff, R, c.d_ff, d, "mlp.c_proj", p, r, w["split"])          # r = mlp output ; added by the next LayerNorm launch
             pending = r
         if all_hidden is not None:
             ops.layernorm_add_fwd(x, pending, e.lnf_g, e.lnf_b, all_hidden, w["mean"], w["rstd"], None, 0, R, d, c.ln_eps)
