@@ -200,27 +200,35 @@ __global__ __launch_bounds__(256) void sgemm_f32_128_kernel(SgemmArgs g) {
         for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[a][b][i] = 0.f;
-    float ra[8], rb[8];
-    // full, 16-byte-aligned tiles take the float4 path (workgroup-uniform per operand)
+    // Global -> register -> LDS staging with the loads TWO K-steps ahead of their use: a K-step is 32 MFMAs = 2048 cycles (~0.85 us), less than a
+    // loaded HBM / L2 round trip, so with the loads one step ahead a wave sat on vmcnt(0) before its LDS stores (SQ_VALU_MFMA_BUSY 0.72 - 0.77 of
+    // the CU-busy cycles at 3 waves per SIMD: tools/pmc_mfma_sgemm.sh).  rn* = the step after next (in flight), rc* = the next step (landed).
+    float rca[8], rcb[8], rna[8], rnb[8];
+    // full, 16-byte-aligned tiles take the float4 path (workgroup-uniform per operand and K-step)
     // (a K that is not a multiple of the 16-wide step — the vocabulary, 50 257 — keeps the 16-byte path on every full step: only the last,
     //  partial step takes the guarded 4-byte loads; before, such products ran guarded throughout: 71 vs 113 TFLOP/s on the heads' dX)
     const bool va0 = m0 + SG2_BM <= g.M && (g.lda & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const bool vb0 = n0 + SG2_BN <= g.N && (g.ldb & 3) == 0 && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-    bool va = va0 && SG2_BK <= g.K, vb = vb0 && SG2_BK <= g.K;
-    if (va) sg2_load_vec<!TA>(A, g.lda, m0, 0, t, ra); else sg2_load<!TA>(A, g.lda, m0, g.M, 0, g.K, t, ra);
-    if (vb) sg2_load_vec<TB>(B, g.ldb, n0, 0, t, rb); else sg2_load<TB>(B, g.ldb, n0, g.N, 0, g.K, t, rb);
-    if (va) sg2_store_vec<!TA>(sA[0], t, ra); else sg2_store<!TA>(sA[0], t, ra);
-    if (vb) sg2_store_vec<TB>(sB[0], t, rb); else sg2_store<TB>(sB[0], t, rb);
-    __syncthreads();
     const int nk = (g.K + SG2_BK - 1) / SG2_BK;
+#define SG2_LOAD(RA, RB, KT)                                                                                                         \
+    do {                                                                                                                             \
+        const bool full_ = ((KT) + 1) * SG2_BK <= g.K;                                                                               \
+        if (va0 && full_) sg2_load_vec<!TA>(A, g.lda, m0, (KT) * SG2_BK, t, RA); else sg2_load<!TA>(A, g.lda, m0, g.M, (KT) * SG2_BK, g.K, t, RA); \
+        if (vb0 && full_) sg2_load_vec<TB>(B, g.ldb, n0, (KT) * SG2_BK, t, RB); else sg2_load<TB>(B, g.ldb, n0, g.N, (KT) * SG2_BK, g.K, t, RB);   \
+    } while (0)
+#define SG2_STORE(RA, RB, KT, BUF)                                                                                                   \
+    do {                                                                                                                             \
+        const bool full_ = ((KT) + 1) * SG2_BK <= g.K;                                                                               \
+        if (va0 && full_) sg2_store_vec<!TA>(sA[BUF], t, RA); else sg2_store<!TA>(sA[BUF], t, RA);                                   \
+        if (vb0 && full_) sg2_store_vec<TB>(sB[BUF], t, RB); else sg2_store<TB>(sB[BUF], t, RB);                                     \
+    } while (0)
+    SG2_LOAD(rca, rcb, 0);
+    SG2_STORE(rca, rcb, 0, 0);
+    if (nk > 1) SG2_LOAD(rca, rcb, 1);              // in flight across the whole of step 0
+    __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            const bool full = (kt + 2) * SG2_BK <= g.K;          // workgroup-uniform
-            va = va0 && full; vb = vb0 && full;
-            if (va) sg2_load_vec<!TA>(A, g.lda, m0, (kt + 1) * SG2_BK, t, ra); else sg2_load<!TA>(A, g.lda, m0, g.M, (kt + 1) * SG2_BK, g.K, t, ra);
-            if (vb) sg2_load_vec<TB>(B, g.ldb, n0, (kt + 1) * SG2_BK, t, rb); else sg2_load<TB>(B, g.ldb, n0, g.N, (kt + 1) * SG2_BK, g.K, t, rb);
-        }
+        if (kt + 2 < nk) SG2_LOAD(rna, rnb, kt + 2);
         const float *pa = sA[buf] + (lane >> 5) * SG2_LD + wm * 64 + (lane & 31);
         const float *pb = sB[buf] + (lane >> 5) * SG2_LD + wn * 64 + (lane & 31);
 #pragma unroll
@@ -232,12 +240,13 @@ __global__ __launch_bounds__(256) void sgemm_f32_128_kernel(SgemmArgs g) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (kt + 1 < nk) {
-            if (va) sg2_store_vec<!TA>(sA[buf ^ 1], t, ra); else sg2_store<!TA>(sA[buf ^ 1], t, ra);
-            if (vb) sg2_store_vec<TB>(sB[buf ^ 1], t, rb); else sg2_store<TB>(sB[buf ^ 1], t, rb);
-        }
+        if (kt + 1 < nk) SG2_STORE(rca, rcb, kt + 1, buf ^ 1);
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; i++) { rca[i] = rna[i]; rcb[i] = rnb[i]; }
     }
+#undef SG2_LOAD
+#undef SG2_STORE
 #pragma unroll
     for (int b = 0; b < 2; b++) {
         const int col = n0 + wn * 64 + b * 32 + (lane & 31);
