@@ -243,19 +243,7 @@ size_t lmrl_gpt2_ws_bytes(const lmrl_gpt2 *m, int b, int c);
 #define LMRL_FWD_ATTN_VALU     8u  /* per-(env, head) multi-round-trip attention kernels instead of the default ones (cross-check) */
 #define LMRL_FWD_KV_FROM_GEMM  16u /* decode: the qkv GEMM epilogue appends the new K/V rows, the attention kernel only reads (A/B: attention faster, GEMM slower, net slower) */
 #define LMRL_FWD_FULL_LAST_LAYER 32u /* chunk forwards: run the last layer's projection + MLP on every row (default: only on each env's last new token — the only row whose hidden state is returned; A/B and cross-check, bit-identical) */
-/* bits 16-25: TIMING-ONLY ablation of the single-token decode layers (tools/bench_ablate_decode.py): the named launch is left out, results are
- * garbage — measures, inside the real dependent chain, what removing or hiding that launch could buy at most.  Never set by the package. */
-#define LMRL_FWD_ABLATE_SHIFT 16
-#define LMRL_ABLATE_QKV 1u
-#define LMRL_ABLATE_ATTN 2u
-#define LMRL_ABLATE_PROJ 4u
-#define LMRL_ABLATE_FC 8u
-#define LMRL_ABLATE_FC2 16u
-#define LMRL_ABLATE_FC2_SPLITK2 64u  /* fc2 as two concurrent half-K launches (two streams, racy): split-K = 2 without its seam */
-#define LMRL_ABLATE_FC2_HALFK 128u   /* fc2 over half of K only: the cost of a K loop of half the length */
-#define LMRL_ABLATE_PROJ_AUX_SERIAL 256u /* calibration of the two above: proj on the aux stream but AFTER the attention (same chain): the cost of a fork / join */
-#define LMRL_ABLATE_ATTN_HALF_BYTES 512u /* the decode attention reads only the first half of the cached positions (half the cache lines): an optimistic bound on what a 1-byte cache element could buy (reading half of every 128-B row instead changes nothing: the line is fetched whole) */
-#define LMRL_ABLATE_PROJ_CONCURRENT 32u /* proj GEMM on an auxiliary stream behind the qkv GEMM only: concurrent with the attention launch (stale data) */
+/* bits 16-31: reserved — the product library rejects them (LMRL_ERR_ARG). */
 /* bits 8-15: LMRL_FWD_SHARED_PREFIX(n) — positions [0, n) of EVERY env's cache hold the same K/V rows as env 0's (the caller copied them
  * with lmrl_gpt2_kv_broadcast and has not reset the cache since): the decode attention then reads them from env 0 (one L2-resident copy)
  * instead of once per env.  Results are bit-identical; a wrong promise reads env 0's prefix for every env. */

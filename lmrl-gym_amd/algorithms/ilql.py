@@ -331,8 +331,6 @@ class GPT2ILQLTrain:
         late = red.early([g1, g2, gv])                 # the heads' gradients are final: reduced under the base backward, not after it
         base.backward(cache, d_hidden, bgrads, on_final=red.ready(bgrads))
         self.last_grads = (bgrads, g1, g2, gv)
-        if getattr(self, "keep_head_caches", False):      # tests: the heads' pre-activations (which side of relu each unit took) and their row set
-            self.last_head_caches = (q1c, q2c, vc, q_rows if compact else None)
         red.finish(late)
         self.calls += 1                                 # TrainState.step of the reference: one per apply_gradients call
         upd = self.base_opt.apply(bgrads)

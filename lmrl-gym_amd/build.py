@@ -1,6 +1,9 @@
 """In-tree build of liblmrl_amd.so for gfx950 (hipcc cross-compiles without a GPU).
 
-    python lmrl-gym_amd/build.py [--force] [--verbose]
+    python lmrl-gym_amd/build.py [--force] [--verbose] [--tools]
+
+`--tools` builds a SECOND library, liblmrl_amd_tools.so (objects under csrc/_obj_tools/, `-DLMRL_TOOLS`): the same sources plus the timing-only
+launch ablations of csrc/ablate_tools.h.  Only tools/bench_ablate_decode.py loads it; the package, the tests and bench.py never do.
 
 Every csrc/*.hip is compiled to csrc/_obj/*.o and linked into lmrl-gym_amd/liblmrl_amd.so.  Staleness is decided by
 CONTENT, not mtime: csrc/_obj/manifest.json records, per object, the sha256 of its source + every header under csrc/ and
@@ -42,8 +45,11 @@ def _sha(paths, extra: str = "") -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, tools: bool = False) -> str:
     hipcc = _hipcc()
+    OBJ = os.path.join(CSRC, "_obj_tools" if tools else "_obj")
+    SO = os.path.join(HERE, "liblmrl_amd_tools.so" if tools else "liblmrl_amd.so")
+    FLAGS = globals()["FLAGS"] + (["-DLMRL_TOOLS"] if tools else [])
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "lmrl_amd.h")]
@@ -96,4 +102,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv, tools="--tools" in sys.argv))

@@ -23,6 +23,9 @@
 #include "common.h"
 #include <hip/hip_ext.h>
 #include "gemm_dispatch.h"
+#ifdef LMRL_TOOLS
+#include "ablate_tools.h"
+#endif
 
 namespace lmrl {
 
@@ -44,6 +47,9 @@ struct Gpt2Model {
     const uint16_t *wte, *wpe;
     const float *lnf_g, *lnf_b;
     Gpt2Layer *layers;
+#ifdef LMRL_TOOLS
+    AblateAux ablate_aux;
+#endif
 };
 
 // ------------------------------------------------------------------------------------------ layernorm
@@ -1038,6 +1044,9 @@ void lmrl_gpt2_destroy(lmrl_gpt2 *m) {
         (void)hipFree(L.wf_qkv); (void)hipFree(L.cs_qkv); (void)hipFree(L.bf_qkv);
         (void)hipFree(L.wf_fc); (void)hipFree(L.cs_fc); (void)hipFree(L.bf_fc);
     }
+#ifdef LMRL_TOOLS
+    if (m->ablate_aux.stream) { (void)hipStreamDestroy(m->ablate_aux.stream); (void)hipEventDestroy(m->ablate_aux.fork); (void)hipEventDestroy(m->ablate_aux.join); }
+#endif
     delete[] m->layers;
     delete m;
 }
@@ -1073,19 +1082,25 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
         hipLaunchKernelGGL(attn_bytes_kernel, dim3(1), dim3(256), 0, s, cnt_d, len_d, b, c, cf.n_head * cf.n_layer, ctr, c == 1 ? n_shared : 0);
     LMRL_REQUIRE(!((flags & LMRL_FWD_RAGGED_ALWAYS) && (flags & LMRL_FWD_RAGGED_NEVER)), "lmrl_gpt2_forward: contradictory ragged flags");
     const bool fused = !(flags & LMRL_FWD_LN_STANDALONE) && g_gemm_variant != 1 && ln_fusion_nq(d) != 0;
-    // TIMING-ONLY ablation (tools/bench_ablate_decode.py; results are garbage): leave out one launch class of the single-token decode layers to
-    // measure what removing / hiding that launch could buy at most inside the real dependent chain
+    // Bits >= 16 of `flags` are reserved.  Only the -DLMRL_TOOLS build (`python lmrl-gym_amd/build.py --tools` -> liblmrl_amd_tools.so, loaded by
+    // tools/bench_ablate_decode.py alone) gives them a meaning: timing-only launch ablations of the single-token decode layers whose RESULTS ARE
+    // GARBAGE (csrc/ablate_tools.h).  The product library refuses them.
+#ifdef LMRL_TOOLS
     const unsigned ablate = (c == 1) ? ((flags >> LMRL_FWD_ABLATE_SHIFT) & 0x3ffu) : 0u;
-    // LMRL_ABLATE_PROJ_CONCURRENT (timing only, garbage results): the proj GEMM is launched on an auxiliary stream that waits for the qkv GEMM
-    // only, i.e. it runs CONCURRENTLY with the attention launch on stale data — the most any attention -> proj overlap scheme could hide,
-    // contention between the two launches included
-    static hipStream_t aux_stream = nullptr;
-    static hipEvent_t aux_fork = nullptr, aux_join = nullptr;
-    if ((ablate & (LMRL_ABLATE_PROJ_CONCURRENT | LMRL_ABLATE_FC2_SPLITK2 | LMRL_ABLATE_FC2_HALFK | LMRL_ABLATE_PROJ_AUX_SERIAL)) && !aux_stream) {
-        LMRL_CHECK_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
-        LMRL_CHECK_HIP(hipEventCreateWithFlags(&aux_fork, hipEventDisableTiming));
-        LMRL_CHECK_HIP(hipEventCreateWithFlags(&aux_join, hipEventDisableTiming));
+#define LMRL_ABL(bit) ((ablate & (bit)) != 0u)
+    AblateAux &aux = m->ablate_aux;     // per model (= per device), created on first use, destroyed with the model
+    if ((ablate & (LMRL_ABLATE_PROJ_CONCURRENT | LMRL_ABLATE_FC2_SPLITK2 | LMRL_ABLATE_FC2_HALFK | LMRL_ABLATE_PROJ_AUX_SERIAL)) && !aux.stream) {
+        LMRL_CHECK_HIP(hipStreamCreateWithFlags(&aux.stream, hipStreamNonBlocking));
+        LMRL_CHECK_HIP(hipEventCreateWithFlags(&aux.fork, hipEventDisableTiming));
+        LMRL_CHECK_HIP(hipEventCreateWithFlags(&aux.join, hipEventDisableTiming));
     }
+    hipStream_t aux_stream = aux.stream; hipEvent_t aux_fork = aux.fork, aux_join = aux.join;
+#else
+    LMRL_REQUIRE((flags >> 16) == 0u, "lmrl_gpt2_forward: flag bits >= 16 are reserved (launch ablations exist only in the LMRL_TOOLS build)");
+#define LMRL_ABL(bit) false
+    constexpr hipStream_t aux_stream = nullptr; constexpr hipEvent_t aux_fork = nullptr, aux_join = nullptr;   // dead branches below still parse
+    (void)aux_stream; (void)aux_fork; (void)aux_join;
+#endif
     const int nsl = Gpt2Ws::nslots(cf);
     // ragged batches (LN-folded path, unless the caller wants every row's hidden state back): by default only the forwards of
     // large batches qualify (b*c >= 2048); LMRL_FWD_RAGGED_ALWAYS compacts every forward (generation loops whose rows finish at
@@ -1134,7 +1149,7 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
     for (int l = 0; l < cf.n_layer; l++) {
         const Gpt2Layer &L = m->layers[l];
         uint16_t *kc = (uint16_t *)kv_d + (size_t)(2 * l) * kv_layer, *vc = kc + kv_layer;
-        if (fused && (ablate & LMRL_ABLATE_QKV)) {
+        if (fused && LMRL_ABL(LMRL_ABLATE_QKV)) {
         } else if (fused) {
             GemmArgs g{w.h, L.wf_qkv, L.bf_qkv, w.qkv, M, 3 * d, d, d, 3 * d, 3 * d, w.stats, nullptr, L.cs_qkv, nsl, 1.f / (float)d, cf.ln_eps, m_dev};
             if (kv_from_gemm) {   // decode: the new K / V rows go to the cache from this GEMM's epilogue, the attention kernel only reads
@@ -1155,14 +1170,14 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
         hipEvent_t ev_a, ev_b;
         // decode: the single-shot kernel; LMRL_FWD_ATTN_VALU keeps the multi-round-trip per-head kernel as the cross-check
         const bool shot = c == 1 && !(flags & LMRL_FWD_ATTN_VALU);
-        if (fused && (ablate & LMRL_ABLATE_PROJ_CONCURRENT)) {     // fork: proj on the aux stream, behind the qkv GEMM only
+        if (fused && LMRL_ABL(LMRL_ABLATE_PROJ_CONCURRENT)) {     // fork: proj on the aux stream, behind the qkv GEMM only
             LMRL_CHECK_HIP(hipEventRecord(aux_fork, s));
             LMRL_CHECK_HIP(hipStreamWaitEvent(aux_stream, aux_fork, 0));
             GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
             LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, aux_stream));
             LMRL_CHECK_HIP(hipEventRecord(aux_join, aux_stream));
         }
-        if (ablate & LMRL_ABLATE_ATTN) {
+        if (LMRL_ABL(LMRL_ABLATE_ATTN)) {
         } else if (shot) {
             const bool ev = prof_kernel_events(PROF_ATTN_DECODE, -1.0, &ev_a, &ev_b);   // start/stop events attached to the dispatch itself
             DecodePrefix dp{};
@@ -1180,9 +1195,11 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
             } while (0)
             // 32 cached positions per batch of loads, 72 VGPRs -> 7 waves per SIMD (measured best of U = 4 / 6 / 8 / 10)
             if (pfx) LMRL_DEC_LAUNCH(4, true);
-            else if (ablate & LMRL_ABLATE_ATTN_HALF_BYTES)
+#ifdef LMRL_TOOLS
+            else if (LMRL_ABL(LMRL_ABLATE_ATTN_HALF_BYTES))
                 hipLaunchKernelGGL((attention_decode_kernel<4, false, true>), dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, (const uint16_t *)w.qkv, kc, vc,
                                    cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off, n_shared, append_in_attn, dp);
+#endif
             else LMRL_DEC_LAUNCH(4, false);
 #undef LMRL_DEC_LAUNCH
         } else if (c == 1 && prof_kernel_events(PROF_ATTN_DECODE, -1.0, &ev_a, &ev_b)) {
@@ -1212,33 +1229,33 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
             }
         } else if (fused) {
             GemmArgs gp{w.att, L.w_proj, L.b_proj, w.x, M, d, d, d, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
-            if (ablate & LMRL_ABLATE_PROJ_AUX_SERIAL) {        // calibration: the SAME dependency chain routed through the aux stream (fork after the attention)
+            if (LMRL_ABL(LMRL_ABLATE_PROJ_AUX_SERIAL)) {        // calibration: the SAME dependency chain routed through the aux stream (fork after the attention)
                 LMRL_CHECK_HIP(hipEventRecord(aux_fork, s));
                 LMRL_CHECK_HIP(hipStreamWaitEvent(aux_stream, aux_fork, 0));
                 LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, aux_stream));
                 LMRL_CHECK_HIP(hipEventRecord(aux_join, aux_stream));
                 LMRL_CHECK_HIP(hipStreamWaitEvent(s, aux_join, 0));
             }
-            else if (ablate & LMRL_ABLATE_PROJ_CONCURRENT) LMRL_CHECK_HIP(hipStreamWaitEvent(s, aux_join, 0));      // join
-            else if (!(ablate & LMRL_ABLATE_PROJ)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, s));
+            else if (LMRL_ABL(LMRL_ABLATE_PROJ_CONCURRENT)) LMRL_CHECK_HIP(hipStreamWaitEvent(s, aux_join, 0));      // join
+            else if (!LMRL_ABL(LMRL_ABLATE_PROJ)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, s));
             GemmArgs gf{w.h, L.wf_fc, L.bf_fc, w.ff, M, cf.d_ff, d, d, cf.d_ff, cf.d_ff, w.stats, nullptr, L.cs_fc, nsl, 1.f / (float)d, cf.ln_eps, m_dev};
-            if (!(ablate & LMRL_ABLATE_FC)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_GELU_BF16_LN>(gf, s));
+            if (!LMRL_ABL(LMRL_ABLATE_FC)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_GELU_BF16_LN>(gf, s));
             GemmArgs g2{w.ff, L.w_fc2, L.b_fc2, w.x, M, d, cf.d_ff, cf.d_ff, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
-            if (ablate & LMRL_ABLATE_FC2) {}
-            else if (ablate & (LMRL_ABLATE_FC2_SPLITK2 | LMRL_ABLATE_FC2_HALFK)) {
+            if (LMRL_ABL(LMRL_ABLATE_FC2)) {}
+            else if (LMRL_ABL(LMRL_ABLATE_FC2_SPLITK2 | LMRL_ABLATE_FC2_HALFK)) {
                 // timing only: fc2 over HALF of K — alone (what a K loop of half the length costs), or as two such launches running concurrently on two
                 // streams (racy read-modify-write of x: garbage) = a split-K = 2 form without its reduction seam
                 GemmArgs ga = g2; ga.K = cf.d_ff / 2;
                 GemmArgs gb = ga; gb.A = ga.A + cf.d_ff / 2; gb.W = ga.W + cf.d_ff / 2; gb.ldw = cf.d_ff;
                 ga.ldw = cf.d_ff;
-                if (ablate & LMRL_ABLATE_FC2_SPLITK2) {
+                if (LMRL_ABL(LMRL_ABLATE_FC2_SPLITK2)) {
                     LMRL_CHECK_HIP(hipEventRecord(aux_fork, s));
                     LMRL_CHECK_HIP(hipStreamWaitEvent(aux_stream, aux_fork, 0));
                     LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gb, aux_stream));
                     LMRL_CHECK_HIP(hipEventRecord(aux_join, aux_stream));
                 }
                 LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(ga, s));
-                if (ablate & LMRL_ABLATE_FC2_SPLITK2) LMRL_CHECK_HIP(hipStreamWaitEvent(s, aux_join, 0));
+                if (LMRL_ABL(LMRL_ABLATE_FC2_SPLITK2)) LMRL_CHECK_HIP(hipStreamWaitEvent(s, aux_join, 0));
             }
             else if (l + 1 < cf.n_layer) LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(g2, s));
             else LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(g2, s));      // ln_f reads the fp32 stream directly

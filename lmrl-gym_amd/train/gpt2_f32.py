@@ -474,19 +474,6 @@ class MLPHeadF32:
         z = t.empty(rows, self.dh, dtype=t.float32, device=self.dev)
         ops.linear_fwd(x, self.p["dense1.kernel"], self.p["dense1.bias"], z, rows, self.din, self.dh, mm=self.mm)
         a = t.empty_like(z)
-        if getattr(self, "branch_z", None) is not None:
-            # tests only (cross-checks of two arithmetic paths): evaluate the head on a GIVEN side of relu for every hidden unit — `branch_z` =
-            # (row indices or None, pre-activations of another run of the same head on those rows).  relu' jumps at 0; two fp32 paths put a
-            # handful of the millions of units on different sides, and each such unit moves one token's whole backward signal.
-            rows_idx, zb = self.branch_z
-            zz = z.clone()
-            if rows_idx is None:
-                zz.copy_(zb)
-            else:
-                zz[rows_idx.long()] = zb
-            self.branch_flips = int(((zz > 0) != (z > 0)).sum())
-            t.mul(z, (zz > 0).to(z.dtype), out=a)
-            return a, zz
         ops.relu_fwd(z, a)
         return a, z
 

@@ -1,5 +1,6 @@
 """What could fusing / hiding one launch of the decode layer buy AT MOST?  The bench episode (1024 envs, GPT-2-small, hipGraph replay) timed
-with one launch class of the single-token decode layers left out (`LMRL_FWD_ABLATE_*`: timing only, results are garbage).  The difference
+with one launch class of the single-token decode layers left out (`LMRL_ABLATE_*` of csrc/ablate_tools.h: timing only, results are garbage; they exist only in the
+-DLMRL_TOOLS build of the library, `python lmrl-gym_amd/build.py --tools`, which this script loads INSTEAD of the product library).  The difference
 to the full episode is the in-situ cost of that launch including its share of ramp / tail / boundary — the upper bound for any scheme
 that overlaps it with its neighbours.
 
@@ -14,6 +15,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import lmrl_gym_amd  # noqa: E402,F401
 from lmrl_gym_amd import _lib  # noqa: E402
+_lib.SO_PATH = os.path.join(os.path.dirname(_lib.SO_PATH), "liblmrl_amd_tools.so")   # the tools build; the product library rejects the ablation bits
+assert os.path.exists(_lib.SO_PATH), "build it first: python lmrl-gym_amd/build.py --tools"
 from lmrl_gym_amd.envs import wordle as W  # noqa: E402
 from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine  # noqa: E402
 from lmrl_gym_amd.rollout import WordleRolloutEngine  # noqa: E402
