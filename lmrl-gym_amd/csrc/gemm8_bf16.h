@@ -435,7 +435,10 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
     }
 
     if constexpr (EPI == EPI_BF16_CE) {
-        // log-sum-exp partials and the target column's logit from the fp32 accumulators, before the bf16 rounding of the stored logits.  A lane holds,
+        // log-sum-exp partials of the logits AS STORED (their bf16 rounding, widened back to fp32: the reference's bf16 mode rounds the logits once
+        // and evaluates lse and softmax on those), and the target column's logit from the fp32 accumulators (Q(s, a) of the TD terms keeps its
+        // fp32 value).  lse and the backward's exp(stored logit - lse) then describe the SAME numbers: softmax rows sum to 1 whatever |logit| is
+        // (with lse taken from the unrounded accumulators every p was off by exp(|x| 2^-9): 10 - 30 % at |x| ~ 50 - 100).  A lane holds,
         // for each of its FM rows, 4 columns of each of the FN fragments; the row's other columns of this wave's TN-wide slab sit in the lanes lq ^ 1,
         // lq ^ 2 (xor 16 / 32).  One (max, sum exp) per (row, slab): slot = tile_n * WN + wn, pitch g.nslots.  Columns >= n_store are padding.
         const int slot = tile_n * WN + wn;
@@ -451,12 +454,14 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
                 const int n = n0 + wn * TN + i * 16 + lq * 4;
                 f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (g.bias) b4 = *reinterpret_cast<const f32x4 *>(g.bias + n);
-                v[i] = acc[i][j] + b4;
-                acc[i][j] = v[i];                                   // the stored logits below: the same values
+                const f32x4 full = acc[i][j] + b4;
+                acc[i][j] = full;                                   // the stored logits below: bf16 of these values
+                const uint32_t p0 = pack_bf16x2(full[0], full[1]), p1 = pack_bf16x2(full[2], full[3]);
+                v[i] = f32x4{__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u), __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     if (n + e < g.n_store) vmax = fmaxf(vmax, v[i][e]);
-                    if (n + e == tgt && m < Mr) g.ce_tgt_logit[m] = v[i][e];
+                    if (n + e == tgt && m < Mr) g.ce_tgt_logit[m] = full[e];
                 }
             }
             vmax = fmaxf(vmax, __shfl_xor(vmax, 16));

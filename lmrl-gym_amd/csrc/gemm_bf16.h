@@ -51,8 +51,9 @@ enum GemmEpi {
     EPI_BF16_HEADS = 10,     // the c_attn product straight into the flash kernels' per-head matrices: column n = which * d + h * 64 + e of row
                              // m = b * T + t -> C + which * hd_plane + ((b * H + h) * Tp + t) * 64 + e, bf16, q columns (which = 0) times 1/8
     EPI_GELU_BWD_BF16 = 11,  // C bf16 = acc * gelu_new'(resid[m][n]): d(pre-activation) as the bf16 operand of the c_fc backward products
-    EPI_BF16_CE = 12,        // vocabulary heads: C bf16 = acc + bias, AND from the fp32 accumulators: per (row, wave-column-slab) partial
-                             // (max, sum exp) -> stats[m][slot] (log-sum-exp without a pass over the logits) and the fp32 logit of column
+    EPI_BF16_CE = 12,        // vocabulary heads: C bf16 = acc + bias, AND from the registers: per (row, wave-column-slab) partial
+                             // (max, sum exp) of the logits AS STORED (bf16-rounded) -> stats[m][slot] (log-sum-exp without a pass over the
+                             // logits, consistent with the backward's softmax on the stored logits) and the fp32 logit of column
                              // ce_targets[m] -> ce_tgt_logit[m] (Q(s, a) / the token's logit: take_along_axis)
 };
 

@@ -72,8 +72,10 @@ def allreduce_grads(grad_dicts: Sequence[Dict[str, "torch.Tensor"]], bucket_byte
         return 0
     ws = dist.get_world_size(group)
     n_coll = 0
+    works: list = []
     for chunk in _flat_chunks(grad_dicts, bucket_bytes):
-        _all_reduce_inplace(chunk, group)
+        _reduce_grad_slice(chunk, group, works)
+        _finish_works(works)
         if average:
             chunk.div_(ws)
         n_coll += 1
@@ -91,6 +93,50 @@ def set_grad_reduce(enabled: bool) -> None:
     _GRAD_REDUCE_ENABLED = bool(enabled)
 
 
+# Optional bf16-compressed gradient all-reduce (SURVEY.md §5.8 allows one): the fp32 arena slice is rounded to bf16 (RNE), the bf16 copy is
+# SUM-all-reduced (half the bytes on the xGMI links: 815 -> 408 MB per ILQL step and rank) and widened back into the fp32 arena; parameters,
+# optimizer state and the local gradients stay fp32.  Every rank receives the same reduced bf16 values, so ranks stay bit-identical to each
+# other; against the fp32 reduction each element carries <= 2^-8 relative rounding of every addend and of the sum (tests/test_dist_cpu.py,
+# tests/test_gpu_dist.py hold the written tolerance).  OFF by default: the north star asks for 1e-4 train-step parity, which is the fp32 wire.
+_GRAD_COMPRESSION: Optional[str] = None
+
+
+def set_grad_compression(mode: Optional[str]) -> None:
+    """None / "f32": exact fp32 wire (default).  "bf16": bf16 wire format for the gradient all-reduce only."""
+    global _GRAD_COMPRESSION
+    assert mode in (None, "f32", "bf16"), mode
+    _GRAD_COMPRESSION = None if mode in (None, "f32") else mode
+
+
+def grad_compression() -> Optional[str]:
+    return _GRAD_COMPRESSION
+
+
+def _reduce_grad_slice(sl, group, works: list) -> int:
+    """Enqueue the SUM all-reduce of one flat fp32 gradient slice (async where the backend allows it) -> bytes put on the wire.  `works`
+    collects (work handle or None, completion callback or None); `_finish_works` waits and runs the callbacks (the bf16 wire format
+    needs one: widen the reduced copy back into the fp32 arena)."""
+    import torch
+    if _GRAD_COMPRESSION == "bf16":
+        wire = sl.to(torch.bfloat16)
+        w = _all_reduce_inplace(wire, group, async_op=True)
+        works.append((w, lambda: sl.copy_(wire)))
+        return wire.numel() * wire.element_size()
+    w = _all_reduce_inplace(sl, group, async_op=True)
+    if w is not None:
+        works.append((w, None))
+    return sl.numel() * sl.element_size()
+
+
+def _finish_works(works: list) -> None:
+    for w, done in works:
+        if w is not None:
+            w.wait()
+        if done is not None:
+            done()
+    works.clear()
+
+
 class GradReducer:
     """Overlaps the data-parallel gradient all-reduce with the backward pass.  `GPT2F32.backward(..., on_final=reducer.ready(arena))`
     reports parameter groups whose gradients are final (ln_f, then block after block, then the embeddings — the arena is laid out in that
@@ -105,11 +151,8 @@ class GradReducer:
 
     def _flush(self):
         if self._arena is not None and self._hi > self._lo:
-            w = _all_reduce_inplace(self._arena.flat[self._lo:self._hi], self.group, async_op=True)
-            if w is not None:
-                self.works.append(w)
+            self.n_bytes += _reduce_grad_slice(self._arena.flat[self._lo:self._hi], self.group, self.works)
             self.n_coll += 1
-            self.n_bytes += (self._hi - self._lo) * self._arena.flat.element_size()
             self._lo = self._hi
 
     def ready(self, arena):
@@ -140,11 +183,8 @@ class GradReducer:
                 continue
             for lo in range(0, flat.numel(), max(1, self.bucket_bytes // flat.element_size())):
                 sl = flat[lo:lo + max(1, self.bucket_bytes // flat.element_size())]
-                w = _all_reduce_inplace(sl, self.group, async_op=True)
-                if w is not None:
-                    self.works.append(w)
+                self.n_bytes += _reduce_grad_slice(sl, self.group, self.works)
                 self.n_coll += 1
-                self.n_bytes += sl.numel() * sl.element_size()
         return later
 
     def finish(self, more: Sequence[Dict[str, "torch.Tensor"]] = ()):
@@ -154,13 +194,10 @@ class GradReducer:
         if self._arena is not None:
             self._hi = self._arena.flat.numel()              # whatever has not been handed over yet (normally the last partial bucket)
             self._flush()
-        self.n_coll += allreduce_grads(more, group=self.group)
-        for d in more:
-            flat = getattr(d, "flat", None)
-            self.n_bytes += flat.numel() * flat.element_size() if flat is not None else sum(g.numel() * g.element_size() for g in d.values())
-        for w in self.works:
-            w.wait()
-        self.works = []
+        for chunk in _flat_chunks(more, 256 << 20):
+            self.n_bytes += _reduce_grad_slice(chunk, self.group, self.works)
+            self.n_coll += 1
+        _finish_works(self.works)
         LAST_REDUCE_BYTES = self.n_bytes
         return self.n_coll
 

@@ -158,6 +158,7 @@ class WordleRolloutEngine:
         import torch
         t = torch
         self.eng, self.vocab, self.B = engine, vocab, batch
+        self.episodes = 0            # eager episodes run by text_env_eval over this engine's life: part of the sampler stream key
         self.tokens = tokens or WordleTokenTable.default_gpt2(pad=engine.cfg.vocab - 1)
         self.max_new, self.cap = max_new_tokens, traj_cap
         self.dev = engine.device
@@ -394,11 +395,15 @@ class WordleRolloutEngine:
         return out
 
     def text_env_eval(self, n_rollouts: int, seed_generator=None, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0,
-                      interaction_callback=None, decode=None, scripted_guesses_fn=None, steer_strength: float = 0.0, use_graph: bool = True):
+                      interaction_callback=None, decode=None, scripted_guesses_fn=None, steer_strength: float = 0.0, use_graph: Optional[bool] = None):
         """`text_env_eval(env, policy, n_rollouts, bsize=B)` (LLM_RL/environment.py:211-267) with env, policy and the whole
         lock-step loop on the device: ceil(n / B) episodes batches, the same (interactions, summary) return value.
-        use_graph (default; plain sampling only): the episode is captured into a hipGraph once per (temperature, sample_seed, steering) and
-        replayed per batch — one host call instead of ~3400 launches; every replay draws fresh noise (the sampler's epoch word advances).
+        use_graph (plain sampling only): the episode is captured into a hipGraph once per (temperature, sample_seed, steering) and replayed per
+        batch — one host call instead of ~3400 launches; every replay draws fresh noise (the sampler's epoch word advances).  A capture costs
+        two extra episodes (warm-up + capture), so the default (None) uses the graph only when this engine already holds one for the same key
+        or the call runs >= 4 batches; True / False force it.  The two paths draw DIFFERENT noise for the same `sample_seed`: the graph's
+        stream is keyed by (sample_seed, replay epoch), the eager one by (sample_seed + (episode counter << 20)) — the counter runs across calls
+        (`self.episodes`), so neither repeats noise between calls; both are reproducible for a fixed call history.
         `scripted_guesses_fn(batch_id) -> int32 device tensor [n_turns][B]` + `steer_strength`: synthetic workloads (bench.py)."""
         inter, rewards, dones, lengths = [], [], [], []
 
@@ -417,16 +422,22 @@ class WordleRolloutEngine:
             seeds[:actual] = [next(seed_generator) for _ in range(actual)] if seed_generator is not None else \
                 np.random.randint(0, 2 ** 31 - 1, size=actual)
             g = scripted_guesses_fn(batch_id) if scripted_guesses_fn is not None else None
-            if use_graph and top_k == 0 and self.vses is None:
-                key = (float(temperature), int(sample_seed), float(steer_strength), g is not None)
+            key = (float(temperature), int(sample_seed), float(steer_strength), g is not None)
+            graph_ok = top_k == 0 and self.vses is None
+            if use_graph is None:
+                want_graph = graph_ok and (getattr(self, "_eval_graph_key", None) == key or -(-n_rollouts // self.B) >= 4)
+            else:
+                want_graph = bool(use_graph) and graph_ok
+            if want_graph:
                 if getattr(self, "_eval_graph_key", None) != key:
                     self.capture_episode(temperature=temperature, sample_seed=sample_seed, steer_strength=steer_strength, scripted=g is not None)
                     self._eval_graph_key = key
                 import torch
                 self.replay_episode(torch.from_numpy(seeds.view(np.int64)).to(self.dev), g)
             else:
-                self.run_episode(seeds, temperature=temperature, top_k=top_k, sample_seed=sample_seed + (batch_id << 20), scripted_guesses=g,
+                self.run_episode(seeds, temperature=temperature, top_k=top_k, sample_seed=sample_seed + (self.episodes << 20), scripted_guesses=g,
                                  steer_strength=steer_strength)
+                self.episodes += 1
             batch_id += 1
             launched += actual
             handle = self.snapshot_records()

@@ -237,7 +237,8 @@ class GPT2F32:
 
     def lm_logits(self, hidden, rows: int):
         """logits [rows, ld_vocab] (columns [0, V) valid) = hidden @ wte^T (tied head), fp32 — PPOInference.token_logprobs_from_logits casts
-        to f32 too.  ld_vocab = V in fp32 mode, V padded to a multiple of 64 in bf16-matmul mode."""
+        to f32 too.  The ROW PITCH is `self.ld_vocab` (V padded to a multiple of 4 floats in fp32 mode — 16-byte rows —, to a multiple of 64 in
+        bf16-matmul mode): only columns [0, V) are valid; view as `[B, T, ld_vocab][..., :V]`, never as `[B, T, V]`."""
         V, d, ld, mm = self.vocab, self.d, self.ld_vocab, self.mm
         logits = self.t.empty(rows, ld, dtype=self.t.float32, device=self.dev)
         if mm is None:

@@ -217,8 +217,10 @@ def linear_bwd_dx_gelu(mm: "MatmulBF16", dyb, w, pre, rows, k, n):
 
 
 # bf16-matmul mode, vocabulary-wide heads: logits written once in bf16 with the log-sum-exp partials and the target's fp32 logit out of the GEMM's
-# accumulators (lmrl_gemm_bf16_ce), d(logits) formed in place (lmrl_ce_bwd_bf16_inplace) — no fp32 [rows][V] tensor, no lse pass over it.  The
-# softmax of the backward then reads bf16-rounded logits (2^-9 relative per logit); lse, Q(s, a) and the token log-probabilities stay fp32-exact.
+# registers (lmrl_gemm_bf16_ce), d(logits) formed in place (lmrl_ce_bwd_bf16_inplace) — no fp32 [rows][V] tensor, no lse pass over it.  The
+# logits are rounded to bf16 ONCE; lse is the log-sum-exp of those stored values and the backward's softmax reads the same values, so its rows
+# sum to 1 at any logit magnitude (the reference's bf16 mode: round once, then lse and softmax on the rounded logits); Q(s, a) / the target
+# token's logit keep their fp32 accumulator value.
 FUSE_CE = True
 
 

@@ -85,6 +85,29 @@ def _worker(rank, world, port, ret):
             raise RuntimeError("expected an assertion")
         except AssertionError:
             pass
+        # 4c. optional bf16 wire format of the gradient all-reduce (dist.set_grad_compression): fp32 arena in, fp32 arena out, every rank the SAME
+        # bits, and within the written tolerance of the fp32 reduction: each addend and the sum are rounded to 8 mantissa bits ->
+        # |err| <= 2^-8 * (sum of |addends| + |sum|) <= 3 * 2^-8 * sum |addends| (loose bound; RNE halves it)
+        D.set_grad_compression("bf16")
+        try:
+            for k in params:
+                ar[k].copy_(per_rank[rank][k])
+            red = D.GradReducer(bucket_bytes=60)
+            cb = red.ready(ar)
+            cb(["ln_f.weight"]); cb(["h.1.w", "h.1.b"]); cb(["h.0.w", "h.0.b"]); cb(["wte"])
+            red.finish()
+            assert D.LAST_REDUCE_BYTES == ar.flat.numel() * 2                     # half the bytes on the wire
+            assert ar.flat.dtype == torch.float32
+            for k in params:
+                bound = 3 * 2.0 ** -8 * sum(per_rank[r][k].abs() for r in range(world)) + 1e-30
+                assert bool(((ar[k] - expect[k]).abs() <= bound).all()), k
+                assert float((ar[k] - expect[k]).norm() / expect[k].norm()) < 2.0 ** -7, k
+            mine_bits = ar.flat.clone()
+            both = [torch.empty_like(mine_bits) for _ in range(world)]
+            dist.all_gather(both, mine_bits)
+            assert all(torch.equal(both[0], b) for b in both)                       # ranks cannot drift apart: identical reduced values
+        finally:
+            D.set_grad_compression(None)
         # 5. bench reduction: max time, summed steps
         t = torch.tensor([0.5 + rank], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
         n = torch.tensor([100 + rank]); dist.all_reduce(n, op=dist.ReduceOp.SUM)
@@ -113,6 +136,22 @@ def test_single_process_is_a_no_op():
     assert D.shard_range(10, 0, 1) == (0, 10)
 
 
+def test_bench_refuses_a_silent_gloo_fallback():
+    """more ranks than GPUs -> non-zero exit unless gloo is asked for BY NAME; one GPU per rank -> RCCL."""
+    import importlib
+    import pytest
+    bench = importlib.import_module("bench")
+    assert bench._resolve_backend(1, 1, None) == "nccl" and bench._resolve_backend(8, 8, None) == "nccl"
+    with pytest.raises(SystemExit) as e:
+        bench._resolve_backend(8, 1, None)
+    assert e.value.code not in (0, None) and "LMRL_BENCH_BACKEND=gloo" in str(e.value.code)
+    with pytest.raises(SystemExit):
+        bench._resolve_backend(2, 1, "")
+    assert bench._resolve_backend(2, 1, "gloo") == "gloo" and bench._resolve_backend(2, 1, "nccl") == "nccl"
+    with pytest.raises(SystemExit):
+        bench._resolve_backend(2, 2, "mpi")
+
+
 def test_bench_spawn_command(monkeypatch):
     """`python bench.py --gpus N` without a launcher environment re-execs itself under torch.distributed.run with N ranks on 127.0.0.1
     (the driver's own N > 1 line); with WORLD_SIZE set (external launcher) it must not spawn again."""
@@ -121,6 +160,7 @@ def test_bench_spawn_command(monkeypatch):
     bench = importlib.import_module("bench")
     seen = {}
     monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setenv("LMRL_BENCH_SKIP_DEVICE_CHECK", "1")     # no GPU in this tier: the device-count refusal is tested on its own above
     assert bench._spawn_ranks(["--gpus", "4", "--steps", "3"], 4) == 0
     cmd = seen["cmd"]
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd

@@ -166,6 +166,23 @@ def _dp_worker(rank, world, port, path, ret):
             for k in ("h.0.attn.c_attn.weight", "ln_f.weight", "wte.weight"):     # AdamW step 1 = lr * sign-like update: compare where the gradient is not ~0
                 big = e_gd[k].abs() > 1e-4 * e_gd[k].abs().max()
                 assert float((pd[k] - e_pd[k])[big].abs().max()) < 1e-5, (algo, k)
+        # optional bf16 wire format of the gradient all-reduce (dist.set_grad_compression("bf16")): loss / logs do not pass
+        # through it (exact as above); every reduced gradient tensor within 2^-7 relative L2 of the full-batch fp32 gradient and each element
+        # within 3 * 2^-8 of the tensor's largest entry (each addend and the sum rounded to 8 mantissa bits); gradients stay fp32 tensors
+        D.set_grad_compression("bf16")
+        try:
+            lo, hi = D.shard_range(8, rank, world)
+            loss, logs, gd, pd = _run_algo("ilql", dev, slice(lo, hi))
+            e_loss, e_logs, e_gd, e_pd = ref["ilql"]
+            assert abs(loss - e_loss) <= 2e-6 * max(1.0, abs(e_loss))
+            assert D.LAST_REDUCE_BYTES == 2 * sum(v.numel() for v in e_gd.values())
+            for k in e_gd:
+                assert gd[k].dtype == torch.float32
+                nrm = float(e_gd[k].norm())
+                assert float((gd[k] - e_gd[k]).norm()) <= 2.0 ** -7 * nrm + 1e-12, (k, float((gd[k] - e_gd[k]).norm()), nrm)
+                assert float((gd[k] - e_gd[k]).abs().max()) <= 3 * 2.0 ** -8 * float(e_gd[k].abs().max()) + 1e-12, k
+        finally:
+            D.set_grad_compression(None)
         ret[rank] = "ok"
     except Exception as e:
         import traceback
@@ -194,14 +211,21 @@ def test_two_ranks_half_batch_equal_one_rank_full_batch(tmp_path):
 
 def test_bench_gpus_2_spawns_two_ranks_and_reports_the_train_step():
     """the plain driver command `python bench.py --gpus 2 ...` must itself launch 2 ranks (torch.distributed.run, one
-    process per GPU; on this 1-GPU tier the ranks share the GPU and the group falls back to gloo) and rank 0 must print ONE JSON line with
+    process per GPU; on this 1-GPU tier the ranks share the GPU, which the bench refuses unless LMRL_BENCH_BACKEND=gloo is explicit) and rank 0 must print ONE JSON line with
     n_gpus = 2 whose `train_step` object carries the ILQL step with its gradient all-reduce (bytes, exposed time)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LMRL_BENCH_BACKEND")}
+    if torch.cuda.device_count() < 2:
+        # two ranks on ONE GPU: without the explicit override the bench must refuse (non-zero) instead of quietly measuring gloo
+        r0 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "64", "--no-fp32-mode",
+                             "--no-train-step", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+        assert r0.returncode != 0 and "LMRL_BENCH_BACKEND=gloo" in (r0.stderr + r0.stdout), (r0.returncode, r0.stderr[-1500:])
+        assert not [ln for ln in r0.stdout.splitlines() if ln.startswith("{")]
+        env["LMRL_BENCH_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "64",
                         "--train-batch", "2", "--train-steps", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -209,6 +233,10 @@ def test_bench_gpus_2_spawns_two_ranks_and_reports_the_train_step():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["envs_per_gpu"] == 64
+    # the line verifies itself: what the process group reports, per-rank devices
+    assert out["world_size"] == 2 and out["backend"] == ("gloo" if torch.cuda.device_count() < 2 else "nccl")
+    assert [rd["rank"] for rd in out["dist"]["rank_devices"]] == [0, 1] and out["dist"]["ranks_share_devices"] == (torch.cuda.device_count() < 2)
+    assert (out["rccl_version"] is not None) == (out["backend"] == "nccl")
     assert out["config"]["env_steps_timed"] >= 2 * 64            # both ranks' env steps are summed
     assert out["fp32_mode"]["value"] > 0 and out["bf16x3_mode"]["value"] > 0 and out["host_materialise_ms"] > 0
     ts = out["train_step"]

@@ -412,27 +412,39 @@ def test_weight_gradient_from_untransposed_operands(dev, rows, k, n):
 @pytest.mark.parametrize("rows,n", [(1000, 50257), (4200, 50257), (300, 1000)])
 def test_vocabulary_head_ce_from_the_gemm_accumulators(dev, rows, n):
     """lmrl_gemm_bf16_ce: bf16 logits + log-sum-exp partials + the target's fp32 logit out of one launch, against the fp32-logits product followed by
-    lse_gather: the target logit is the SAME fp32 number, lse agrees to fp32 rounding, the stored logits are the bf16 rounding of the fp32 ones;
-    lmrl_ce_bwd_bf16_inplace then equals the float64 formula evaluated on those bf16 logits, with zeroed padding.  4200 rows: 256-row tiles."""
+    lse_gather: the target logit is the SAME fp32 number, the stored logits are the bf16 rounding of the fp32 ones, and lse is the log-sum-exp OF
+    THE STORED (rounded) LOGITS to fp32 rounding — so the backward's exp(stored logit - lse) is a softmax whose rows sum to 1 at any logit
+    magnitude (with lse from the unrounded accumulators every probability carried exp(|x| 2^-9)).  `shift` moves every logit by
+    a constant, the magnitudes pretrained LM / Q heads reach.  lmrl_ce_bwd_bf16_inplace then equals the float64 formula evaluated on those
+    bf16 logits, with zeroed padding.  4200 rows: 256-row tiles."""
     from lmrl_gym_amd.train import ops
     k = 768
     g = torch.Generator().manual_seed(rows + n)
     mm = ops.MatmulBF16(dev)
-    x = torch.randn(rows, k, generator=g).to(dev)
-    w = (torch.randn(k, n, generator=g) * 0.08).to(dev)
-    b = (torch.randn(n, generator=g) * 0.5).to(dev)
-    tgt = torch.randint(0, n, (rows,), generator=g).int().to(dev)
-    ld = ops._pad(n)
-    y = torch.empty(rows, ld, device=dev)
-    ops.linear_fwd(x, w, b, y, rows, k, n, mm=mm, ldy=ld)
-    lse0, lp0, tl0 = (torch.empty(rows, device=dev) for _ in range(3))
-    ops.lse_gather(y, ld, n, tgt, rows, logprob=lp0, lse=lse0, target_logit=tl0)
-    yb, lse, tl, lp = ops.head_fwd_ce(mm, x, w, b, rows, k, n, tgt)
-    torch.cuda.synchronize()
-    assert torch.equal(tl, tl0)
-    assert float((lse - lse0).abs().max()) <= 2e-5 and float((lp - lp0).abs().max()) <= 2e-5
-    Y = yb.view(-1, ops._pitch(n))
-    assert torch.equal(Y[:rows, :n], y[:, :n].to(torch.bfloat16))
+    for shift in (0.0, -80.0):
+        x = torch.randn(rows, k, generator=g).to(dev)
+        w = (torch.randn(k, n, generator=g) * 0.08).to(dev)
+        b = (torch.randn(n, generator=g) * 0.5 + shift).to(dev)
+        tgt = torch.randint(0, n, (rows,), generator=g).int().to(dev)
+        ld = ops._pad(n)
+        y = torch.empty(rows, ld, device=dev)
+        ops.linear_fwd(x, w, b, y, rows, k, n, mm=mm, ldy=ld)
+        lse0, lp0, tl0 = (torch.empty(rows, device=dev) for _ in range(3))
+        ops.lse_gather(y, ld, n, tgt, rows, logprob=lp0, lse=lse0, target_logit=tl0)
+        yb, lse, tl, lp = ops.head_fwd_ce(mm, x, w, b, rows, k, n, tgt)
+        torch.cuda.synchronize()
+        assert torch.equal(tl, tl0)
+        Y = yb.view(-1, ops._pitch(n))
+        assert torch.equal(Y[:rows, :n], y[:, :n].to(torch.bfloat16))
+        lse_stored = torch.logsumexp(Y[:rows, :n].double(), dim=1)
+        tol = 2e-5 if shift == 0.0 else 1e-4            # a few fp32 ulps of lse: 2^-23 |lse| = 1e-5 at |lse| ~ 70
+        assert float((lse.double() - lse_stored).abs().max()) <= tol, float((lse.double() - lse_stored).abs().max())
+        assert float((lp.double() - (tl.double() - lse_stored)).abs().max()) <= tol
+        # against the fp32-logits path: one rounding of the logits away (|x| 2^-9 per logit, averaged by the softmax weights)
+        assert float((lse - lse0).abs().max()) <= 2.0 ** -9 * (abs(shift) + 8.0)
+        # softmax rows of the backward sum to one: sum_c exp(stored - lse) == 1 to fp32 rounding at EVERY magnitude
+        rowsum = torch.exp(Y[:rows, :n].double() - lse.double()[:, None]).sum(1)
+        assert float((rowsum - 1).abs().max()) <= 2 * tol, float((rowsum - 1).abs().max())
     cc = (torch.rand(rows, generator=g) * 0.01).to(dev)
     cg = (torch.randn(rows, generator=g) * 0.1).to(dev)
     L = Y[:rows, :n].double()

@@ -13,7 +13,7 @@ vocab = W.Vocabulary.builtin("wordle_official_400.txt")
 B = 1024
 ro = WordleRolloutEngine(eng, vocab, B, max_new_tokens=6)
 g = torch.from_numpy(scripted_guesses(vocab.all_vocab, 8, 6, B, seed=1).view(np.int32)).to(dev)
-kw = dict(scripted_guesses_fn=lambda bid: g[bid % 8], steer_strength=30.0, temperature=1.0, sample_seed=9)
+kw = dict(scripted_guesses_fn=lambda bid: g[bid % 8], steer_strength=30.0, temperature=1.0, sample_seed=9, use_graph=True)
 gen = iter(range(10**6, 10**9))
 ro.text_env_eval(B, seed_generator=gen, **kw)
 for nb in (4, 8, 4, 8):
