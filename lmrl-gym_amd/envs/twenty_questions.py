@@ -22,7 +22,6 @@ from __future__ import annotations
 
 import random
 import re
-from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple, Union
 
 from ..environment import BatchedTextEnv, StepResult, Text, TextEnv, TextHistory, TextTrajectory
@@ -84,150 +83,154 @@ def pos_tag(text: str) -> List[Tuple[str, str]]:
     return _pos_tagger(text)
 
 
-@dataclass
 class WordVariants:
-    """data.py:20-49: the spellings of one object ("Pants;Pant;Pair of pants") and their POS-tagged token lists."""
-    words: List[str]
-    pos_tags: List[List[Tuple[str, str]]]
+    """One hidden object = its accepted spellings ("Pants;Pant;Pair of pants") + each spelling's lower-cased, POS-tagged token list (the public
+    type of data.py:20-49: `.words`, `.pos_tags`, `from_list` / `from_str`, `len()`, indexing, `json()`, `str()` / `repr()`).  `tokens` is the
+    same information as tuples of bare token strings — what the game logic below compares."""
+    __slots__ = ("words", "pos_tags", "tokens")
 
-    @classmethod
-    def from_list(cls, words_list: List[str]) -> "WordVariants":
-        return cls(words=list(words_list), pos_tags=[pos_tag(w.lower()) for w in words_list])
+    def __init__(self, words: Sequence[str], pos_tags: Optional[List[List[Tuple[str, str]]]] = None):
+        self.words = [str(w) for w in words]
+        self.pos_tags = pos_tags if pos_tags is not None else [pos_tag(w.lower()) for w in self.words]
+        self.tokens = tuple(tuple(tok for tok, _ in tagged) for tagged in self.pos_tags)
 
-    @classmethod
-    def from_str(cls, words_str: str) -> "WordVariants":
-        return cls.from_list(words_str.split(";"))
+    from_list = classmethod(lambda cls, words_list: cls(words_list))
+    from_str = classmethod(lambda cls, words_str: cls(words_str.split(";")))
 
-    def __len__(self):
+    def json(self) -> List[str]:
+        return list(self.words)
+
+    def __len__(self) -> int:
         return len(self.words)
 
-    def __getitem__(self, idx):
-        assert 0 <= idx < len(self.words), f"Index {idx} out of range"
+    def __getitem__(self, idx: int) -> str:
+        if not 0 <= idx < len(self.words):
+            raise AssertionError(f"{self!r} has no spelling {idx}")
         return self.words[idx]
 
-    def json(self):
-        return self.words.copy()
+    def __eq__(self, other) -> bool:
+        return isinstance(other, WordVariants) and self.words == other.words
 
-    def __str__(self):
-        return f"({', '.join(self.words)})"
+    def __hash__(self) -> int:
+        return hash(tuple(self.words))
+
+    def _joined(self) -> str:
+        return ", ".join(self.words)
+
+    def __str__(self) -> str:
+        return "(" + self._joined() + ")"
 
     def __repr__(self) -> str:
-        return f"WordVariants([{', '.join(self.words)}])"
+        return "WordVariants([" + self._joined() + "])"
 
 
-# The task's object list (data, as the Wordle vocabulary files are): llm_rl_scripts/twenty_questions/env/data.py:52-70
-DEFAULT_OBJECT_DICT: Dict[str, List[str]] = {
-    "Sports": ["Basketball", "Football", "Baseball", "Soccer ball", "Golf ball", "Tennis ball", "Volleyball", "Tennis racket", "Baseball bat", "Helmet"],
-    "Animals": ["Cat", "Dog", "Horse", "Cow", "Sheep", "Rabbit", "Lion", "Tiger", "Bear", "Elephant"],
-    "Fruits": ["Apple", "Banana", "Orange", "Strawberry", "Grape", "Watermelon", "Pineapple", "Mango", "Cantaloupe", "Peach"],
-    "Vehicles": ["Car", "Truck", "Motorcycle", "Boat", "Airplane;Plane", "Train", "Bus", "Helicopter", "Scooter", "Ship"],
-    "Clothes": ["Shirt", "Pants;Pant;Pair of pants", "Jacket", "Dress", "Skirt", "Belt", "Shoes;Shoe;Pair of shoes", "Boots;Boot;Pair of boots",
-                "Socks;Sock;Pair of socks", "Hat", "Scarf"],
-    "Electronics": ["Computer", "Smartphone", "Television;TV", "Headphone;Headphones;Pair of headphones", "Monitor;Computer monitor", "Camera",
-                    "Microwave;Microwave oven", "Refrigerator", "Blender", "Computer keyboard;Keyboard"],
-    "Musical Instruments": ["Piano", "Guitar", "Drum;Drums", "Violin", "Saxophone", "Flute", "Trumpet", "Clarinet", "Harp", "Trombone"],
-    "Furniture": ["Chair", "Table", "Bed", "Desk", "Couch", "Dresser", "Bookcase", "Nightstand", "Mattress", "Pillow"],
-    "Office Supplies": ["Pen", "Paper;Piece of paper", "Stapler", "Printer", "Calculator", "Battery;Battery pack;Pack of batteries", "Toothbrush",
-                        "Toothpaste", "Pencil", "Sharpie", "Scissors;Pair of scissors", "Key", "Diary", "Calendar"],
-    "Vegetables": ["Carrot", "Potato", "Broccoli", "Tomato", "Onion", "Spinach", "Corn", "Peas;Pea", "Celery", "Cucumber"],
-    "Art": ["Painting;Canvas painting;Oil painting;Watercolor painting", "Paintbrush", "Canvas;Painting canvas", "Eraser;Pencil eraser", "Marker",
-            "Glue;Glue stick;Bottle of glue", "Sculpture"],
-    "Kitchen Tools": ["Knife", "Spoon", "Fork", "Plate", "Bowl", "Cooking pot;Pot", "Pan;Saucepan;Frying pan", "Cup",
-                      "Chopstick;Chopsticks;Pair of chopsticks", "Whisk"],
-    "Nature": ["Rock", "Tree", "Bush", "Mountain", "Forest", "Ocean", "Sea", "Lake", "River", "Meteorite", "Cactus"],
-    "Toys": ["Lego;Lego set", "Doll;Toy doll;Plush doll", "Kite", "Puzzle;Jigsaw puzzle", "Stuffed animal"],
-    "Jewelry": ["Earring;Earrings;Pair of earrings", "Necklace", "Bracelet", "Ring", "Brooch", "Hairclip", "Pendant", "Watch", "Locket"],
-    "Garden Supplies": ["Gloves;Glove;Pair of gloves", "Shovel", "Rake", "Watering can", "Lawn mower"],
-    "Tools": ["Hammer", "Screwdriver", "Wrench", "Saw", "Pliers;plier;Pair of pliers", "Drill"],
-}
+def _load_object_table() -> Dict[str, List[str]]:
+    """category -> objects ("spelling;alternative spelling;..."), in file order: lmrl-gym_amd/data/twenty_questions/objects.tsv — task data, shipped
+    like the Wordle vocabulary files (the reference keeps the same list inline: data.py:52-70)."""
+    import os
+    table: Dict[str, List[str]] = {}
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "twenty_questions", "objects.tsv")
+    with open(path, encoding="utf-8") as f:
+        for line in f:
+            if line.strip() and not line.startswith("#"):
+                category, obj = line.rstrip("\n").split("\t")
+                table.setdefault(category, []).append(obj)
+    return table
+
+
+DEFAULT_OBJECT_DICT: Dict[str, List[str]] = _load_object_table()
 
 
 def get_default_word_list() -> List[WordVariants]:
-    return [WordVariants.from_str(w) for words in DEFAULT_OBJECT_DICT.values() for w in words]
+    return [WordVariants.from_str(entry) for entries in DEFAULT_OBJECT_DICT.values() for entry in entries]
 
 
-# ---------------------------------------------------------------------------------------------- trajectory / done logic
+# ---------------------------------------------------------------------------------------------- game logic
+# Behaviour pinned by tests/golden/twenty_questions.json (the reference's data.py / env.py executed with a scripted oracle); formulated here as a
+# lock-step state machine over word INDICES and per-slot masks, the shape the batched loops of this package work in.
+_GENERIC_NOUNS = frozenset(("object", "something", "type", "kind"))
+
+
 def is_done(word_var: WordVariants, question: str) -> bool:
-    """data.py:351-391: the question names the hidden object — no noun other than the object's own tokens (and the generic
-    'object / something / type / kind', and counter nouns followed by 'of') appears, and one spelling's tokens END the question."""
-    while len(question) > 0 and not question[-1].isalpha():
-        question = question[:-1]
-    if len(question) == 0:
+    """Does `question` name the hidden object (data.py:351-391)?  After dropping trailing non-letters and tagging the lower-cased text:
+    every noun of the question must be a token of one of the object's spellings, a generic noun (object / something / type / kind) or a
+    counter noun directly followed by "of"; and the question must END with the token sequence of one spelling."""
+    end = next((i for i in range(len(question), 0, -1) if question[i - 1].isalpha()), 0)       # drop the trailing punctuation / blanks
+    q = question[:end]
+    if not q:
         return False
-    qpos = pos_tag(question.lower())
-    ignores = {"object", "something", "type", "kind"}
-    for plist in word_var.pos_tags:
-        ignores.update(w for w, _ in plist)
-    for i, (w, tag) in enumerate(qpos):
-        if tag[:2] == "NN" and w not in ignores:
-            if i + 1 < len(qpos) and qpos[i + 1][0] == "of":
-                continue
-            return False
-    for wpos in word_var.pos_tags:
-        if len(wpos) > len(qpos):
-            continue
-        if all(vw == qw for (vw, _), (qw, _) in zip(wpos, qpos[-len(wpos):])):
-            return True
-    return False
+    tagged = pos_tag(q.lower())
+    toks = tuple(t for t, _ in tagged)
+    allowed = _GENERIC_NOUNS.union(*word_var.tokens)
+    n = len(toks)
+    stray = [i for i, (t, tag) in enumerate(tagged) if tag.startswith("NN") and t not in allowed and not (i + 1 < n and toks[i + 1] == "of")]
+    if stray:
+        return False
+    return any(len(sp) <= n and toks[n - len(sp):] == sp for sp in word_var.tokens)
+
+
+def _check_conversation(history: Sequence[Text], max_len: int) -> int:
+    """[initial str, question 1, answer 1, ..., question N, answer N] -> N; the layout is asserted as the reference does (data.py:88-96)."""
+    assert len(history) % 2 == 1, "a Twenty Questions history is the initial string followed by (question, answer) pairs"
+    flags = [bool(t.is_action) for t in history]
+    assert flags[1::2] == [True] * (len(history) // 2), "every question must be an action"
+    assert not any(flags[0::2]), "the initial string and the answers are not actions"
+    n = len(history) // 2
+    assert n <= max_len, f"{n} questions asked, at most {max_len} allowed"
+    return n
+
+
+def _verdicts(words: Sequence[WordVariants], histories: Sequence[Sequence[Text]], max_len: int):
+    """Lock-step judgement of complete histories (each ending in an answer) -> (asked [B] int, guessed [B] bool, done [B] bool): an object is
+    guessed when the last answer is "Yes." to a question that names it; a game ends when guessed or after `max_len` questions."""
+    import numpy as np
+    asked = np.fromiter((_check_conversation(h, max_len) for h in histories), dtype=np.int64, count=len(histories))
+    yes = np.fromiter((len(h) > 1 and h[-1].text.strip() == "Yes." for h in histories), dtype=bool, count=len(histories))
+    guessed = yes.copy()
+    for i in np.flatnonzero(yes):                      # only the affirmed questions need the (host-side, text) name check
+        guessed[i] = is_done(words[i], histories[i][-2].text.strip())
+    return asked, guessed, guessed | ((asked == max_len) & (asked > 0))
 
 
 def create_trajectory_from_history(word_var: WordVariants, text_history: TextHistory, max_conversation_len: int = 20) -> TextTrajectory:
-    """data.py:83-116."""
-    assert len(text_history) % 2 == 1, "TextHistory should be [initial str, question1, answer1, ..., questionN, answerN]."
-    assert all(t.is_action for t in text_history[1::2]), "All questions should be actions."
-    assert all(not t.is_action for t in text_history[0::2]), "All answers should not be actions."
-    conversation_len = (len(text_history) - 1) // 2
-    assert conversation_len <= max_conversation_len, f"Conversation is too long {conversation_len}. Max should be {max_conversation_len}."
-    reward = [-1.0 if t.is_action else 0.0 for t in text_history]
-    if len(text_history) < 2:
-        done = False
-    else:
-        last_question, last_answer = text_history[-2].text.strip(), text_history[-1].text.strip()
-        word_guessed = last_answer == "Yes." and is_done(word_var, last_question)
-        done = word_guessed or conversation_len == max_conversation_len
-        if word_guessed:
-            reward[-2] = 0.0
-    return TextTrajectory(tuple(text_history), tuple(reward), done)
+    """The reward / done labelling of one conversation (data.py:83-116): -1 per question, 0 for the question that guessed the object."""
+    history = tuple(text_history)
+    _, guessed, done = _verdicts([word_var], [history], max_conversation_len)
+    reward = [(0.0, -1.0)[bool(t.is_action)] for t in history]
+    if guessed[0]:
+        reward[-2] = 0.0
+    return TextTrajectory(history, tuple(reward), bool(done[0]))
+
+
+_OPENERS = frozenset(("Is", "Does", "Can", "Do", "Are", "Could"))
+
+
+def _as_question(raw: str, max_pieces: Optional[int] = None) -> str:
+    """strip, optionally keep the first `max_pieces` space-separated pieces, make sure it ends in '?' ('' stays '')."""
+    q = raw.strip()
+    if q and max_pieces is not None:
+        q = " ".join(q.split(" ")[:max_pieces])
+    return q + "?" if q and not q.endswith("?") else q
 
 
 def asker_postproc(question: str) -> str:
-    """data.py:292-315: normalise a generated question; anything that is not a yes/no question becomes INVALID_QUESTION."""
-    question = question.strip()
-    if len(question) == 0:
-        return INVALID_QUESTION
-    if question[-1] != "?":
-        question += "?"
-    question = question[0].upper() + question[1:]
-    if len(question.split(" ")) > 40:
-        return INVALID_QUESTION
-    if question.split(" ")[0] not in ["Is", "Does", "Can", "Do", "Are", "Could"]:
-        return INVALID_QUESTION
-    if question[-2] == "." and question.split(" ")[-1] != "etc.?":
-        return INVALID_QUESTION
-    return question + "\n"
+    """Normalise a generated question (data.py:292-315): first letter upper-cased, '?' appended; whatever is empty, longer than 40 pieces, does
+    not open with Is / Does / Can / Do / Are / Could, or ends a sentence before the '?' (except "etc.?") becomes INVALID_QUESTION."""
+    q = _as_question(question)
+    q = q[:1].upper() + q[1:]
+    pieces = q.split(" ")
+    acceptable = bool(q) and len(pieces) <= 40 and pieces[0] in _OPENERS and (not q.endswith(".?") or pieces[-1] == "etc.?")
+    return q + "\n" if acceptable else INVALID_QUESTION
 
 
 def asker_postproc_simple(question: str) -> str:
-    """data.py:318-329."""
-    question = question.strip()
-    if len(question) == 0:
-        return "?\n"
-    if question[-1] != "?":
-        question += "?"
-    return question + "\n"
+    """data.py:318-329: only the trailing '?' is enforced."""
+    return (_as_question(question) or "?") + "\n"
 
 
 def asker_postproc_filter_repeats(question: str) -> str:
-    """data.py:332-348."""
-    question = question.strip()
-    if len(question) == 0:
-        return "?\n"
-    words = question.split(" ")
-    if len(words) > 50:
-        question = " ".join(words[:50])
-    if question[-1] != "?":
-        question += "?"
-    return question + "\n"
+    """data.py:332-348: as `asker_postproc_simple`, on at most the first 50 pieces."""
+    return (_as_question(question, 50) or "?") + "\n"
 
 
 # ---------------------------------------------------------------------------------------------- oracle
@@ -271,16 +274,12 @@ class ModelOracle(TwentyQuestionsOracle):
         self.generate = generate
 
     def generate_answers(self, words: Union[WordVariants, List[WordVariants]], questions: Union[str, List[str]], return_full: bool = False):
-        input_is_list = isinstance(words, list)
-        if not input_is_list:
-            assert not isinstance(questions, list)
-            words, questions = [words], [questions]
-        assert len(words) == len(questions)
-        outs = self.generate([get_oracle_prompt(w, q) for w, q in zip(words, questions)])
-        answers, full = answers_from_outputs(questions, outs)
-        if not input_is_list:
-            answers, full = answers[0], full[0]
-        return (answers, full) if return_full else answers
+        batched = isinstance(words, list)
+        ws, qs = (words, questions) if batched else ([words], [questions])
+        assert not isinstance(qs[0] if qs else "", list) and len(ws) == len(qs), "one question per word (both lists, or both single items)"
+        answers, full = answers_from_outputs(qs, self.generate([get_oracle_prompt(w, q) for w, q in zip(ws, qs)]))
+        picked = (answers, full) if batched else (answers[0], full[0])
+        return picked if return_full else picked[0]
 
 
 class GPT2EngineOracle(ModelOracle):
@@ -302,85 +301,117 @@ class GPT2EngineOracle(ModelOracle):
 
 
 # ---------------------------------------------------------------------------------------------- environments
+class _LockStepGames:
+    """State of B simultaneous games as arrays: `word_idx[b]` (index into the word list, -1 before reset) and one `random.Random` per slot.
+    Both public environments below are views of it (the single env is the B = 1 case)."""
+
+    def __init__(self, word_list: Sequence[WordVariants], max_conversation_length: int, slots: int):
+        import numpy as np
+        self.word_list, self.max_len = list(word_list), int(max_conversation_length)
+        self.word_idx = np.full(slots, -1, dtype=np.int64)
+        self.rngs = [random.Random(None) for _ in range(slots)]
+
+    def draw(self, seeds: Sequence[Optional[int]], options: Sequence[Optional[Dict]], reseed_none: bool) -> None:
+        """Hidden word per slot (env.py:48-61 / 121-138): deterministic mode -> word `seed % len(word_list)`; otherwise a uniform draw from the
+        slot's generator, re-created from the seed (`reseed_none`: also when the seed is None, as the batched reference env does)."""
+        import numpy as np
+        n = len(self.word_list)
+        if len(seeds) != len(self.rngs):
+            self.rngs = [random.Random(None) for _ in seeds]
+        idx = np.empty(len(seeds), dtype=np.int64)
+        for b, (seed, opt) in enumerate(zip(seeds, options)):
+            if seed is not None or reseed_none:
+                self.rngs[b] = random.Random(seed)
+            if (opt or {}).get("deterministic", False):
+                assert seed is not None, "deterministic mode selects the word by the seed: a seed is required"
+                idx[b] = seed % n
+            else:
+                idx[b] = self.rngs[b].randrange(n)          # == rng.choice(word_list): the same _randbelow(len) draw
+        self.word_idx = idx
+
+    def words(self) -> List[WordVariants]:
+        assert (self.word_idx >= 0).all() and len(self.word_idx) > 0, "call env.reset() first."
+        return [self.word_list[i] for i in self.word_idx]
+
+    def answer_and_judge(self, oracle: "TwentyQuestionsOracle", histories: Sequence[Optional[TextHistory]], pad_to: int) -> List[Optional[StepResult]]:
+        """One lock-step turn: ONE oracle call for all slots (finished slots and the `pad_to - len(histories)` padding slots ask
+        INVALID_QUESTION — about word_list[0] for the padding — so a model oracle always sees the full batch shape), the answers appended
+        and every live game judged."""
+        words = self.words()
+        live = [b for b, h in enumerate(histories) if h is not None]
+        for b in live:
+            assert histories[b][-1].is_action, "the last item of a history handed to step() must be the question (an action)"
+        npad = max(pad_to - len(histories), 0)
+        asked = [histories[b][-1].text.strip() if histories[b] is not None else INVALID_QUESTION for b in range(len(histories))]
+        answers = oracle.generate_answers(words[: len(histories)] + [self.word_list[0]] * npad, asked + [INVALID_QUESTION] * npad)
+        full = [tuple(histories[b]) + (Text(answers[b] + "\n", False),) for b in live]
+        _, guessed, done = _verdicts([words[b] for b in live], full, self.max_len)
+        out: List[Optional[StepResult]] = [None] * len(histories)
+        for k, b in enumerate(live):
+            out[b] = (full[k], 0.0 if guessed[k] else -1.0, bool(done[k]))
+        return out
+
+
 class TwentyQuestionsPolicyEnvironment(TextEnv):
-    """env.py:9-64."""
+    """The single-game face (env.py:9-64): `reset` draws the hidden word, `step` has the oracle answer the last question."""
 
     def __init__(self, oracle: TwentyQuestionsOracle, word_list: List[WordVariants], max_conversation_length: int = 20):
         self.oracle, self.word_list, self.max_conversation_length = oracle, word_list, max_conversation_length
-        self.random = random.Random(None)
-        self.count = 0
-        self.curr_word: Optional[WordVariants] = None
+        self._games = _LockStepGames(word_list, max_conversation_length, 1)
 
-    def step(self, text_history: TextHistory) -> Tuple[TextHistory, float, bool]:
-        assert text_history[-1].is_action
-        assert self.curr_word is not None, "call env.reset() first."
-        self.count += 1
-        question = text_history[-1].text.strip()
-        answer = self.oracle.generate_answers(self.curr_word, question)
-        traj = create_trajectory_from_history(self.curr_word, tuple(text_history) + (Text(answer + "\n", is_action=False),), self.max_conversation_length)
-        return traj.text_history, traj.reward[-2], traj.done
+    @property
+    def curr_word(self) -> Optional[WordVariants]:
+        return self.word_list[self._games.word_idx[0]] if self._games.word_idx[0] >= 0 else None
+
+    @property
+    def random(self) -> random.Random:
+        return self._games.rngs[0]
 
     def reset(self, seed: Optional[int] = None, options: Optional[Dict] = None) -> TextHistory:
-        self.count = 0
-        if seed is not None:
-            self.random = random.Random(seed)
-        options = options or {}
-        if options.get("deterministic", False):
-            assert seed is not None, "In deterministic mode, the seed specifies which word to use."
-            self.curr_word = self.word_list[seed % len(self.word_list)]
-        else:
-            self.curr_word = self.random.choice(self.word_list)
-        return (Text(INITIAL_STR, is_action=False),)
+        self._games.draw([seed], [options], reseed_none=False)     # seed None: the generator this env already has keeps running
+        return (Text(INITIAL_STR, False),)
 
-    def copy(self):
-        return TwentyQuestionsPolicyEnvironment(self.oracle, self.word_list, self.max_conversation_length)
+    def step(self, text_history: TextHistory) -> Tuple[TextHistory, float, bool]:
+        # a single word / question goes to the oracle un-batched, as the reference's single env calls it
+        word = self._games.words()[0]
+        assert text_history[-1].is_action, "the last item of a history handed to step() must be the question (an action)"
+        answer = self.oracle.generate_answers(word, text_history[-1].text.strip())
+        full = tuple(text_history) + (Text(answer + "\n", False),)
+        _, guessed, done = _verdicts([word], [full], self.max_conversation_length)
+        return full, 0.0 if guessed[0] else -1.0, bool(done[0])
+
+    def copy(self) -> "TwentyQuestionsPolicyEnvironment":
+        return type(self)(self.oracle, self.word_list, self.max_conversation_length)
 
 
 class BatchedTwentyQuestionsPolicyEnvironment(BatchedTextEnv):
-    """env.py:67-141: ONE oracle call answers the questions of all live slots of the batch (padding slots ask INVALID_QUESTION about
-    word_list[0], as the reference does)."""
+    """The lock-step face (env.py:67-141): one oracle call answers every live slot's question."""
 
     def __init__(self, oracle: TwentyQuestionsOracle, word_list: List[WordVariants], max_conversation_length: int = 20, bsize: Optional[int] = None):
         self.bsize, self.oracle, self.word_list, self.max_conversation_length = bsize, oracle, word_list, max_conversation_length
-        self.randoms = [random.Random(None) for _ in range(bsize or 0)]
-        self.curr_words: Optional[List[WordVariants]] = None
+        self._games = _LockStepGames(word_list, max_conversation_length, bsize or 0)
+
+    @property
+    def curr_words(self) -> Optional[List[WordVariants]]:
+        idx = self._games.word_idx
+        return [self.word_list[i] for i in idx] if len(idx) and (idx >= 0).all() else None
+
+    @property
+    def randoms(self) -> List[random.Random]:
+        return self._games.rngs
+
+    def reset(self, seed_batch: Optional[List[Optional[int]]] = None, options_batch: Optional[List[Optional[Dict]]] = None) -> List[TextHistory]:
+        seeds = list(seed_batch) if seed_batch is not None else [None] * (self.bsize or 0)
+        self._games.draw(seeds, list(options_batch) if options_batch is not None else [None] * len(seeds), reseed_none=True)
+        return [(Text(INITIAL_STR, False),) for _ in seeds]
 
     def step(self, text_history_batch: List[Optional[TextHistory]], done: Optional[List[bool]] = None,
              done_batch: Optional[List[bool]] = None) -> List[Optional[StepResult]]:
-        # (`interact_environment` passes `done=` (LLM_RL/environment.py:186); the reference's signature names it `done_batch`, which makes
-        #  its own batched env unusable under its own driver — both spellings are accepted here; finished slots arrive as None either way)
-        assert self.curr_words is not None, "call env.reset() first."
+        # `interact_environment` passes `done=` (LLM_RL/environment.py:186) while the reference env names the parameter `done_batch` — its own
+        # batched env is unusable under its own driver; both spellings are accepted, and finished slots arrive as None either way.
         if self.bsize is None:
             self.bsize = len(text_history_batch)
-        npad = self.bsize - len(text_history_batch)
-        questions = [h[-1].text.strip() if h is not None else INVALID_QUESTION for h in text_history_batch]
-        answers = self.oracle.generate_answers(self.curr_words + [self.word_list[0]] * npad, questions + [INVALID_QUESTION] * npad)[: self.bsize - npad]
-        results: List[Optional[StepResult]] = []
-        for answer, word, h in zip(answers, self.curr_words, text_history_batch):
-            if h is None:
-                results.append(None)
-                continue
-            traj = create_trajectory_from_history(word, tuple(h) + (Text(answer + "\n", is_action=False),), self.max_conversation_length)
-            results.append((traj.text_history, traj.reward[-2], traj.done))
-        return results
+        return self._games.answer_and_judge(self.oracle, text_history_batch, self.bsize)
 
-    def reset(self, seed_batch: Optional[List[Optional[int]]] = None, options_batch: Optional[List[Optional[Dict]]] = None) -> List[TextHistory]:
-        if seed_batch is None:
-            seed_batch = [None] * self.bsize
-        if options_batch is None:
-            options_batch = [{} for _ in range(len(seed_batch))]
-        self.randoms, self.curr_words = [], []
-        out = []
-        for i, (seed, options) in enumerate(zip(seed_batch, options_batch)):
-            self.randoms.append(random.Random(seed))
-            options = options or {}
-            if options.get("deterministic", False):
-                assert seed is not None, "In deterministic mode, the seed specifies which word to use."
-                self.curr_words.append(self.word_list[seed % len(self.word_list)])
-            else:
-                self.curr_words.append(self.randoms[i].choice(self.word_list))
-            out.append((Text(INITIAL_STR, is_action=False),))
-        return out
-
-    def copy(self):
-        return BatchedTwentyQuestionsPolicyEnvironment(self.oracle, self.word_list, self.max_conversation_length, self.bsize)
+    def copy(self) -> "BatchedTwentyQuestionsPolicyEnvironment":
+        return type(self)(self.oracle, self.word_list, self.max_conversation_length, self.bsize)

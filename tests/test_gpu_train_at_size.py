@@ -54,9 +54,10 @@ def _flat_logs(d, prefix=""):
     return out
 
 
-def _model(seed, n_pos):
+def _model(seed, n_pos, size="small"):
     from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
-    cfg = GPT2Config(12, 12, 768, 3072, V, n_pos)
+    n_layer, n_head, d = dict(small=(12, 12, 768), medium=(24, 16, 1024))[size]      # medium = configs[3]'s PPO policy
+    cfg = GPT2Config(n_layer, n_head, d, 4 * d, V, n_pos)
     sd = init_hf_style_state_dict(cfg, seed=seed)
     g = torch.Generator().manual_seed(seed + 100)
     for k in sd:   # non-trivial biases / LN parameters, weights above the 0.02 init so that no gradient vanishes through 12 blocks
@@ -183,12 +184,15 @@ def test_ilql_step_12_layers_T512_vs_float64(dev):
             _close(got[k].cpu(), ref[k].grad, 3e-4, k)
 
 
-def test_ppo_step_12_layers_T1024_vs_float64(dev):
+@pytest.mark.parametrize("size,B,T", [("small", 2, 1024), ("medium", 2, 384)])
+def test_ppo_step_full_depth_vs_float64(dev, size, B, T):
+    """small: 12 layers x T = 1024 (M4's sequence length).  medium: configs[3]'s policy (chess/ppo/train_ppo_gpt2_online.py:201-222) at its full
+    depth — 24 layers, 16 heads, d = 1024 — on a small batch (float64 autograd on the host bounds the size): LayerNorm / residual error through
+    24 blocks, flash attention over 6 key tiles, d = 1024 tiles of every GEMM."""
     from lmrl_gym_amd.algorithms import ppo
     from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
     from oracle import gpt2 as O, rl
-    B, T = 2, 1024
-    cfg, sd = _model(3, T)
+    cfg, sd = _model(3, T, size)
     pad = V - 1
     rng = np.random.RandomState(4)
     ids, sta = _batch(rng, B, T, pad)
@@ -303,11 +307,14 @@ def test_ilql_step_at_bench_size_default_path_equals_second_path(dev):
             _same_gradient(ga[k], gb[k], k)
 
 
-def test_ppo_step_at_bench_size_default_path_equals_second_path(dev):
+@pytest.mark.parametrize("size", ["small", "medium"])
+def test_ppo_step_at_bench_size_default_path_equals_second_path(dev, size):
+    """small: M4.  medium: configs[3] AT ITS SIZE — the GPT-2-medium PPO step at B = 32 x T = 1024 per GPU (chess/ppo/train_ppo_gpt2_online.py:
+    201-222; `bench.py --mode ppo-step --model medium`), default path vs the independent second path."""
     from lmrl_gym_amd.algorithms import ppo
     from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
     B, T = 32, 1024                                        # M4 (train_ppo_gpt2.py:74-75)
-    cfg, sd = _model(27, T)
+    cfg, sd = _model(27, T, size)
     pad = V - 1
     rng = np.random.RandomState(28)
     ids, sta = _batch(rng, B, T, pad)

@@ -440,8 +440,8 @@ def test_vocabulary_head_ce_from_the_gemm_accumulators(dev, rows, n):
         tol = 2e-5 if shift == 0.0 else 1e-4            # a few fp32 ulps of lse: 2^-23 |lse| = 1e-5 at |lse| ~ 70
         assert float((lse.double() - lse_stored).abs().max()) <= tol, float((lse.double() - lse_stored).abs().max())
         assert float((lp.double() - (tl.double() - lse_stored)).abs().max()) <= tol
-        # against the fp32-logits path: one rounding of the logits away (|x| 2^-9 per logit, averaged by the softmax weights)
-        assert float((lse - lse0).abs().max()) <= 2.0 ** -9 * (abs(shift) + 8.0)
+        # against the fp32-logits path: one RNE rounding of the logits away (<= 2^-8 |x| per logit, averaged by the softmax weights)
+        assert float((lse - lse0).abs().max()) <= 2.0 ** -8 * float(y[:, :n].abs().max())
         # softmax rows of the backward sum to one: sum_c exp(stored - lse) == 1 to fp32 rounding at EVERY magnitude
         rowsum = torch.exp(Y[:rows, :n].double() - lse.double()[:, None]).sum(1)
         assert float((rowsum - 1).abs().max()) <= 2 * tol, float((rowsum - 1).abs().max())
