@@ -135,7 +135,48 @@ def cpu_baseline(vocab_words, budget_s=14.0):
                        f"turn as the reference does + C oracle env; {t_all:.1f} s",
                 one_thread=dict(value=s_one / t_one, cores=1, sample=f"16 envs x {turns_one} turns, same path; {t_one:.1f} s"),
                 env_only=dict(value=env_steps / te, unit="env-steps/s", cores=1,
-                              sample=f"C oracle env alone (no LM), 2048 envs x 6 scripted steps, one thread; {te:.2f} s"))
+                              sample=f"C oracle env alone (no LM), 2048 envs x 6 scripted steps, one thread; {te:.2f} s",
+                              reference_python_env=dict(value_v431=204.0, value_v2315=45.0, unit="env-steps/s", cores=1, kind="reference",
+                                                        note="the reference's OWN Python env (llm_rl_scripts/wordle/env, no LM) as timed by the survey "
+                                                             "session in the build container (BASELINE.md section 2); it cannot travel to the GPU box")))
+
+
+def gpu_env_only(vocab, dev):
+    """M1: the batched Wordle step kernel alone — scripted guesses (10 % non-words), reset + 6 steps per episode, no LM — at the
+    bench's 1024 envs and at 262 144 envs (where the lane-per-env kernel fills the chip).  The kernel's bound is NOT the 96 B / env-step of
+    state traffic BASELINE.md's table assumes (0.02 of HBM peak at best) but the O(V) vocabulary filter: ~100 VALU instructions per vocabulary
+    word per valid step (two consistency sweeps + the membership sweep; counted in the gfx950 ISA of wordle_step_lanes_kernel), i.e.
+    `valu_frac` = env-steps/s x V x 100 / (256 CU x 4 SIMD x 1.2 G wave-instructions/s) of the VALU issue peak."""
+    import torch
+    from lmrl_gym_amd.envs import wordle as W
+    packed = np.array([W.pack_guess(w) for w in vocab.all_vocab], dtype=np.uint32)
+    out = {}
+    for n in (1024, 262144):
+        env = W.VectorWordleEnv(vocab, True, -10.0)
+        env._alloc(n)
+        rng = np.random.RandomState(12345)
+        g = packed[rng.randint(0, len(packed), size=(6, n))]
+        g[rng.rand(6, n) < 0.1] = W.BAD_GUESS
+        gd = torch.from_numpy(g.view(np.int32)).to(dev)
+        seeds = np.arange(n, dtype=np.uint64)
+        env.reset_device(seeds)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        t_reset = t_step = 0.0
+        reps = 10
+        for _ in range(reps):
+            ev[0].record(); env.reset_device(seeds); ev[1].record()
+            for t in range(6):
+                env.step_device(gd[t], None)
+            ev[2].record(); torch.cuda.synchronize()
+            t_reset += ev[0].elapsed_time(ev[1]); t_step += ev[1].elapsed_time(ev[2])
+        rate = 6 * n / (t_step / reps / 1e3)
+        out[str(n)] = dict(env_steps_per_s_steps_only=round(rate, 0), env_steps_per_s_incl_reset=round(6 * n / ((t_reset + t_step) / reps / 1e3), 0),
+                           valu_frac=round(rate * 0.9 * len(packed) * 100.0 / (256 * 4 * 1.2e9), 3))
+        env.close()
+    return dict(unit="env-steps/s", vocab_words=len(packed), envs=out, bound="valu",
+                note="Wordle step kernel alone on this GPU (reset + 6 scripted steps, 10 % non-words skip the sweeps: x 0.9 in valu_frac); "
+                     "bound = VALU issue (O(V) vocabulary filter), not HBM: DESIGN.md section 4")
 
 
 def _resolve_backend(world, n_dev, explicit):
@@ -689,6 +730,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vocab.all_vocab)
+            out["env_only"] = gpu_env_only(vocab, dev)
         print(json.dumps(out), flush=True)
     if use_dist:
         torch.distributed.destroy_process_group()

@@ -178,11 +178,26 @@ class KVSessionF32:
         return self.logits
 
     def sample(self, params: SampleParams, steer_tok=None, active=None, hidden=None, logits_out=None, q1=None, q2=None, want_logprob: bool = True):
-        """One token per env from `hidden` (default: last_hidden): fp32 LM head, then the sampler on the materialised logits (same streams and
-        warpers as the fused bf16 path)."""
+        """One token per env from `hidden` (default: last_hidden).  matmul = "f32": fp32 LM head into materialised logits, then the sampler on them
+        (same streams and warpers as the fused bf16 path); matmul = "bf16x3": the fused LM-head sampler on the split operands."""
         if q1 is not None or q2 is not None:
             raise _lib.LmrlError("GPT2EngineF32 samples from the policy logits only (the ILQL Q-head operands of the fused sampler are bf16)")
-        c = self.eng.cfg
+        c, e = self.eng.cfg, self.eng
+        if e.matmul == "bf16x3":
+            # the LM head and the sampler in ONE launch (`lm_head_sample_kernel`, the bf16 engine's): the tied-head product runs as a bf16 GEMM over
+            # K' = 3 d on the split operands and the Gumbel-max / arg-max epilogue reads the fp32 accumulators — no [B][V] fp32 logits written and
+            # re-read per token (2 x 206 MB at B = 1024), same random streams (Philox or LMRL_RNG_JAX: keyed by row / column / step, not by K)
+            import torch
+            h = self.last_hidden if hidden is None else hidden
+            if getattr(self, "_lm_split", None) is None:
+                self._lm_split = torch.empty(self.B * 3 * c.d_model, dtype=torch.bfloat16, device=e.device)
+                self._sample_ws = torch.empty(e._L.lmrl_sample_ws_bytes(self.B, c.vocab_padded), dtype=torch.uint8, device=e.device)
+            _lib.check(e._L.lmrl_split3_bf16(h.data_ptr(), c.d_model, self.B, c.d_model, self._lm_split.data_ptr(), 3 * c.d_model, _lib.stream_ptr()), "lmrl_split3_bf16")
+            _lib.check(e._L.lmrl_lm_head_sample(_lib.ptr(self._lm_split), _lib.ptr(e.wte_x3), None, None, None, None, None, None, self.B, 3 * c.d_model, c.vocab,
+                                                c.vocab_padded, ctypes.byref(params), _lib.ptr(steer_tok), _lib.ptr(active), _lib.ptr(self.token),
+                                                _lib.ptr(self.logprob) if want_logprob else None, _lib.ptr(logits_out), _lib.ptr(self._sample_ws),
+                                                _lib.stream_ptr()), "lmrl_lm_head_sample (bf16x3)")
+            return self.token, (self.logprob if want_logprob else None)
         lg = self.lm_logits(hidden)
         _lib.check(self.eng._L.lmrl_sample_logits_steer(_lib.ptr(lg), c.vocab_padded, self.B, c.vocab, ctypes.byref(params), _lib.ptr(steer_tok),
                                                         _lib.ptr(active), _lib.ptr(self.token), _lib.ptr(self.logprob) if want_logprob else None,
