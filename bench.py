@@ -146,7 +146,8 @@ def gpu_env_only(vocab, dev):
     bench's 1024 envs and at 262 144 envs (where the lane-per-env kernel fills the chip).  The kernel's bound is NOT the 96 B / env-step of
     state traffic BASELINE.md's table assumes (0.02 of HBM peak at best) but the O(V) vocabulary filter: ~100 VALU instructions per vocabulary
     word per valid step (two consistency sweeps + the membership sweep; counted in the gfx950 ISA of wordle_step_lanes_kernel), i.e.
-    `valu_frac` = env-steps/s x V x 100 / (256 CU x 4 SIMD x 1.2 G wave-instructions/s) of the VALU issue peak."""
+    `valu_frac` = env-steps/s x V x 100 / 64 lanes / (256 CU x 4 SIMD x 1.2 G wave-instructions/s) of the VALU issue peak (lane = env:
+    one wave-instruction serves 64 envs)."""
     import torch
     from lmrl_gym_amd.envs import wordle as W
     packed = np.array([W.pack_guess(w) for w in vocab.all_vocab], dtype=np.uint32)
@@ -172,7 +173,7 @@ def gpu_env_only(vocab, dev):
             t_reset += ev[0].elapsed_time(ev[1]); t_step += ev[1].elapsed_time(ev[2])
         rate = 6 * n / (t_step / reps / 1e3)
         out[str(n)] = dict(env_steps_per_s_steps_only=round(rate, 0), env_steps_per_s_incl_reset=round(6 * n / ((t_reset + t_step) / reps / 1e3), 0),
-                           valu_frac=round(rate * 0.9 * len(packed) * 100.0 / (256 * 4 * 1.2e9), 3))
+                           valu_frac=round(rate * 0.9 * len(packed) * 100.0 / 64.0 / (256 * 4 * 1.2e9), 3))
         env.close()
     return dict(unit="env-steps/s", vocab_words=len(packed), envs=out, bound="valu",
                 note="Wordle step kernel alone on this GPU (reset + 6 scripted steps, 10 % non-words skip the sweeps: x 0.9 in valu_frac); "
@@ -689,18 +690,30 @@ def main():
         # activations and K/V cache, exact-fp32 MFMA products, materialised fp32 logits, same sampler and env kernels; eager launches.
         # Its every sampled token is pinned to the float64 oracle in tests/test_gpu_f32_engine.py.  Reported beside `value`, never as it.
         from lmrl_gym_amd.gpt2_f32_engine import GPT2EngineF32
-        for key_, mm_, desc_ in (("fp32_mode", "f32", "GPT2EngineF32: fp32 weights / activations / KV cache, v_mfma_f32_32x32x2_f32 GEMMs, materialised fp32 logits, eager launches"),
+        for key_, mm_, desc_ in (("fp32_mode", "f32", "GPT2EngineF32: fp32 weights / activations / KV cache, v_mfma_f32_32x32x2_f32 GEMMs, materialised fp32 logits"),
                                  ("bf16x3_mode", "bf16x3", "GPT2EngineF32(matmul='bf16x3'): fp32 activations / KV cache / attention, every Dense + LM-head product as one "
-                                                           "bf16 GEMM over three-term splits of the fp32 operands (~16 mantissa bits per product), eager launches")):
+                                                           "bf16 GEMM over three-term splits of the fp32 operands (~16 mantissa bits per product), fused LM-head sampler")):
             engf = GPT2EngineF32.random_init(cfg, seed=0, device=dev, matmul=mm_)
             rof = WordleRolloutEngine(engf, vocab, B, max_new_tokens=6, bad_word_reward=-10.0, share_header=bool(args.share_header))
             kwf = dict(temperature=1.0, sample_seed=1000 + rank * 16, steer_strength=30.0)
-            rof.run_episode(seeds_all[0], scripted_guesses=guesses[0], **kwf)
+            graph_f = bool(args.graph)
+            if graph_f:
+                try:
+                    rof.capture_episode(scripted=True, **kwf)
+                except Exception as e:
+                    print(f"[bench] rank {rank}: hipGraph capture of the {mm_} engine failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+                    graph_f = False
+            if use_dist:
+                flagf = torch.tensor([int(graph_f)], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+                torch.distributed.all_reduce(flagf, op=torch.distributed.ReduceOp.MIN)
+                graph_f = bool(int(flagf.item()))
+            runf = (lambda i: rof.replay_episode(seeds_all[i], guesses[i])) if graph_f else (lambda i: rof.run_episode(seeds_all[i], scripted_guesses=guesses[i], **kwf))
+            runf(0)
             barrier()
             tf0 = time.perf_counter()
             nf = []
             for i in range(2):
-                rof.run_episode(seeds_all[args.warmup + i], scripted_guesses=guesses[args.warmup + i], **kwf)
+                runf(args.warmup + i)
                 nf.append(rof.traj["n_steps"].sum())
             barrier()
             tf = torch.tensor([time.perf_counter() - tf0], dtype=torch.float64, device=dev)
@@ -712,7 +725,7 @@ def main():
                 torch.distributed.all_reduce(nfs, op=torch.distributed.ReduceOp.SUM)
             if rank == 0:
                 out[key_] = {"value": round(int(nfs.item()) / float(tf.item()), 1), "unit": "env-steps/s", "ms_per_step": round(float(tf.item()) * 500.0, 2),
-                             "steps": 2, "dtype": "f32" if mm_ == "f32" else "bf16x3 products, f32 everything else", "engine": desc_,
+                             "steps": 2, "dtype": "f32" if mm_ == "f32" else "bf16x3 products, f32 everything else", "engine": desc_, "hip_graph": graph_f,
                              "parity": ("every sampled token == float64 oracle" if mm_ == "f32" else "every sampled token whose top-2 gap exceeds 3e-3 == float64 oracle")
                                        + " (tests/test_gpu_f32_engine.py)"}
             rof.close()

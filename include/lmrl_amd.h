@@ -339,6 +339,10 @@ int lmrl_ce_bwd_bf16_inplace(void *logits_bf16_d, long ld, int vocab, const floa
 size_t lmrl_gemm_bf16_splitk_ws_bytes(int m, int n, int k);
 int lmrl_gemm_bf16_splitk(const void *a_d, const void *w_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc, int n_store, int accumulate,
                           void *ws_d, void *stream);
+/* the same product with a bias and no accumulation, c[m][n] = sum_k a[m][k] w[n][k] + bias[n] (128 x 128 split-K plans only: m < 2048) — the MLP output
+ * projection of the bf16x3 rollout mode at decode size (K' = 3 d_ff = 9216 on 48 tiles) */
+int lmrl_gemm_bf16_splitk_bias(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc,
+                               void *ws_d, void *stream);
 
 /* The same product on the operands as their producers staged them — a_d = x [k][lda], w_d = dy [k][ldw], both bf16 with k = B*T rows:
  * c[m][n] (=|+=) sum_kk a[kk][m] * w[kk][n]  (m, n multiples of 128, k of 64; a 128 x 128 split-K plan must exist: lmrl_gemm_bf16_splitk_ws_bytes).
@@ -413,12 +417,17 @@ int lmrl_sample_logits_steer(float *logits_d, int ld, int m, int vocab, const lm
  *   lmrl_chunk_begin_f32  pos[b*c + j] = len[b] + j for j < cnt[b]; padding slots get position 0 and token id 0
  *   lmrl_attn_cached_f32  one layer's attention for the c new tokens of every env: qkv_d fp32 [b*c][3*H*64]; kcache_d / vcache_d fp32
  *                         [b][tmax][H*64]; query j sees the cached positions [0, len[b]) and the chunk's tokens [0, j]; appends the new
- *                         K / V rows at len[b] + j; out_d fp32 [b*c][H*64] (padding slots untouched).
+ *                         K / V rows at len[b] + j; out_d fp32 [b*c][H*64] (padding slots untouched).  c == 1 (single-token decode) runs the
+ *                         batched-load kernel (one wave per (env, head), 32 cached positions requested before any arithmetic).
+ *   lmrl_attn_cached_f32_split3  the same, and (split3_out_d != NULL) the output ALSO as the bf16 three-term split operand
+ *                         [b*c][3*H*64] = [hi | lo | hi] of the projection GEMM of the bf16x3 mode (lmrl_split3_bf16's layout and rounding)
  *   lmrl_chunk_end_f32    last_d[b] = x_d[b*c + cnt[b] - 1] (envs with cnt == 0 keep theirs), then len[b] += cnt[b]
  * ------------------------------------------------------------------------------------------ */
 int lmrl_chunk_begin_f32(const int32_t *len_d, const int32_t *cnt_d, int32_t *ids_d, int32_t *pos_d, int b, int c, int n_pos, void *stream);
 int lmrl_attn_cached_f32(const float *qkv_d, float *kcache_d, float *vcache_d, const int32_t *len_d, const int32_t *cnt_d, float *out_d, int b, int c,
                          int n_head, int tmax, void *stream);
+int lmrl_attn_cached_f32_split3(const float *qkv_d, float *kcache_d, float *vcache_d, const int32_t *len_d, const int32_t *cnt_d, float *out_d,
+                                void *split3_out_d, int b, int c, int n_head, int tmax, void *stream);
 int lmrl_chunk_end_f32(const float *x_d, const int32_t *cnt_d, float *last_d, int32_t *len_d, int b, int c, int d, void *stream);
 
 /* ------------------------------------------------------------------------------------------

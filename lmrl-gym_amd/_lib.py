@@ -57,6 +57,7 @@ _SIGS = {
     "lmrl_sample_logits_steer": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmrl_chunk_begin_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lmrl_attn_cached_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "lmrl_attn_cached_f32_split3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_chunk_end_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lmrl_threefry2x32": (None, [c_void_p, c_void_p, c_void_p]),
     "lmrl_jax_random_bits_host": (c_int, [c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, c_void_p]),
@@ -108,6 +109,7 @@ _SIGS = {
     "lmrl_gemm_bf16_splitk_kmajor": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lmrl_colsum_bf16": (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "lmrl_gemm_bf16_splitk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "lmrl_gemm_bf16_splitk_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lmrl_ce_bwd_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_long, c_int, c_void_p]),
     "lmrl_transpose_bf16_colsum": (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, ctypes.c_long, c_int, c_void_p, c_int, c_void_p,
                                            c_void_p]),

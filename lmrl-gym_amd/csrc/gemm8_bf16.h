@@ -573,7 +573,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
             f32x4 v;
             if (LN_IN) v = (acc[i][j] - c4 * ln_mu[j]) * ln_rs[j] + b4;
             else v = acc[i][j] + b4;
-            if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_BF16_LN) {
+            if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_BF16_LN || EPI == EPI_GELU_SPLIT3) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = gelu_new(v[r]);
             }
@@ -592,6 +592,8 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
                         *reinterpret_cast<uint2 *>((isv ? g.kv_v : g.kv_k) + kvrow[j] * g.kv_d + (n - (isv ? 2 : 1) * g.kv_d)) = o;
                     }
                 }
+            } else if (EPI == EPI_GELU_SPLIT3) {
+                store_split3_x4(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc, g.N, n, v);
             } else if (EPI == EPI_RESID_F32) {
                 *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n) = xres[i][j] + v;
             } else {

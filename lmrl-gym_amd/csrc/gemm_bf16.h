@@ -55,6 +55,9 @@ enum GemmEpi {
                              // (max, sum exp) of the logits AS STORED (bf16-rounded) -> stats[m][slot] (log-sum-exp without a pass over the
                              // logits, consistent with the backward's softmax on the stored logits) and the fp32 logit of column
                              // ce_targets[m] -> ce_tgt_logit[m] (Q(s, a) / the token's logit: take_along_axis)
+    // ---- fp32-accurate rollout mode "bf16x3" (gpt2_f32_engine.py): the c_fc product writes the NEXT product's three-term split operand itself
+    EPI_GELU_SPLIT3 = 13,    // C bf16 [M][ldc >= 3 N] = [hi | lo | hi](gelu_new(acc + bias)), hi = bf16(y) RNE, lo = bf16(y - hi): lmrl_split3_bf16's
+                             // layout — no fp32 [M][d_ff] pre-activation written, re-read by a gelu + split pass and written again
 };
 
 // fp32 -> bf16, round to nearest even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32); the integer bit trick it replaces
@@ -67,6 +70,16 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ uint16_t f32_to_bf16_rn(float f) { return (uint16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// the split operand of 4 consecutive columns n .. n + 3 of row `row16` (pitch 3 N: [hi | lo | hi]) — EPI_GELU_SPLIT3
+__device__ __forceinline__ void store_split3_x4(uint16_t *row16, int N, int n, f32x4 v) {
+    const uint32_t h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
+    const uint32_t l0 = pack_bf16x2(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u));
+    const uint32_t l1 = pack_bf16x2(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u));
+    *reinterpret_cast<uint2 *>(row16 + n) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2 *>(row16 + N + n) = make_uint2(l0, l1);
+    *reinterpret_cast<uint2 *>(row16 + 2 * N + n) = make_uint2(h0, h1);
+}
 
 __device__ __forceinline__ float gelu_new(float x) {
     // GPT-2 "gelu_new": 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3)  ==  x * sigmoid(2u) = x / (1 + e^(-2u)).
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
             const int m = m0 + wm * (BM / 2) + j * 16 + lr;
             if (m >= g.M) continue;
             f32x4 v = acc[i][j] + b4;
-            if (EPI == EPI_GELU_BF16) {
+            if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_SPLIT3) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = gelu_new(v[r]);
             }
@@ -268,6 +281,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
                 o.x = pack_bf16x2(v[0], v[1]);
                 o.y = pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc + n) = o;
+            } else if (EPI == EPI_GELU_SPLIT3) {
+                store_split3_x4(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc, g.N, n, v);
             } else if (EPI == EPI_RESID_F32) {
                 f32x4 *p = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n);
                 const f32x4 r = g.resid ? *reinterpret_cast<const f32x4 *>(g.resid + (size_t)m * g.ldr + n) : *p;
@@ -573,7 +588,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
             } else {
                 v = acc[i][j] + b4;
             }
-            if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_BF16_LN) {
+            if (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_BF16_LN || EPI == EPI_GELU_SPLIT3) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) v[r] = gelu_new(v[r]);
             }
@@ -593,6 +608,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(GemmArgs g, XcdMap 
                         *reinterpret_cast<uint2 *>(dst) = o;
                     }
                 }
+            } else if (EPI == EPI_GELU_SPLIT3) {
+                store_split3_x4(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc, g.N, n, v);
             } else if (EPI == EPI_RESID_F32) {
                 *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + n) = xres[i][j] + v;
             } else {

@@ -130,7 +130,11 @@ inline hipError_t gemm_launch(const GemmArgs &g, hipStream_t s) {
     // tiles) want occupancy: 2-stage rings, 3 workgroups per CU.  The decode GEMMs (M = 1024) have only 192-768 tiles, i.e.
     // 1-3 per CU, and are bound by the latency chain of their K loop: as many stages as still leave every tile resident
     // at once (768 tiles: 3 stages = 48 KiB -> 3 WG/CU; 192 tiles: 4 stages = 64 KiB -> 2 WG/CU).
-    if constexpr (EPI == EPI_F32) {
+    if constexpr (EPI == EPI_F32 || EPI == EPI_GELU_SPLIT3) {
+        // decode-sized products with a LONG K (the bf16x3 rollout mode: K' = 3 K = 2304 / 9216 at M = one row per env): the 8-wave 128 x 128 tile,
+        // one workgroup per CU with a 3-slot ring (as the bf16 engine's decode qkv / fc), instead of the 4-wave 2-slot ring the K >= 2048 rule below picks
+        if (g.M >= 512 && g.M < 2048 && g.N % 128 == 0 && g.K >= 2048 && t128 >= 128 && g_gemm_variant != 109)
+            return gemm8_launch<128, 128, 2, 4, 3, EPI>(g, s);
         if (g_gemm_variant != 108) {             // 108: the round-2 policy below (A/B hook)
             switch (pick_train_tile(g.M, g.N, g.K)) {
                 case TT_256x256: return gemm8_launch<256, 256, 2, 4, 2, EPI>(g, s);
@@ -148,7 +152,7 @@ inline hipError_t gemm_launch(const GemmArgs &g, hipStream_t s) {
         if (g.M >= 4096 && g.N % 256 == 0 && t256 >= 160 && (g.K >= 2048 || t256 <= 256 || t256 % 256 == 0 || t256 >= 1024))
             return gemm8_launch<256, 256, 2, 4, 2, EPI>(g, s);
     }
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || EPI == EPI_F32) {
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || EPI == EPI_F32 || EPI == EPI_GELU_SPLIT3) {
         if (g.M >= 2048 && g.N % 128 == 0 && g.K < 2048) return gemm8_launch<128, 128, 2, 4, 2, EPI>(g, s);   // wide prefill GEMMs: 8-wave 128x128 tiles
     }
     if constexpr (EPI == EPI_RESID_F32) {      // the train forward's projection + residual add (separate residual operand): same tile as its EPI_F32 form

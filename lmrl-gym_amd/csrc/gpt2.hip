@@ -910,7 +910,7 @@ __global__ void attn_bytes_kernel(const int32_t *cnt, const int32_t *len, int B,
 
 // c[m][n] (=|+=) sum_z ws[z][m][n] for n < n_store, z in order (deterministic); ws rows have pitch ldw
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int S, long zstride, int ldw, float *c, int ldc, int M,
-                                                            int n_store, int accumulate) {
+                                                            int n_store, int accumulate, const float *__restrict__ bias = nullptr) {
     const int n4 = (n_store + 3) / 4;
     const long total = (long)M * n4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -918,6 +918,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
         const float *p = ws + (long)m * ldw + n;
         f32x4 a = *reinterpret_cast<const f32x4 *>(p);
         for (int z = 1; z < S; z++) a += *reinterpret_cast<const f32x4 *>(p + z * zstride);
+        if (bias) a += *reinterpret_cast<const f32x4 *>(bias + n);          // (bias rows are padded to the GEMM's N, a multiple of 128)
         float *o = c + (long)m * ldc + n;
         if (n + 4 <= n_store && (ldc & 3) == 0) {
             if (accumulate) a += *reinterpret_cast<const f32x4 *>(o);
@@ -1352,6 +1353,26 @@ int lmrl_gemm_bf16_splitk(const void *a_d, const void *w_d, void *c_d, int m, in
     return LMRL_OK;
 }
 
+// The same split-K product with a bias: c[m][n] = sum_k a[m][k] w[n][k] + bias[n] — the bf16x3 rollout mode's c_proj of the MLP at decode size
+// (M = one row per env, N = d_model: 48 tiles of 128 x 128, K' = 3 d_ff = 9216: 144 K-steps on a fifth of the CUs unsplit).  `plan_k` lets the caller
+// ask whether a plan exists (lmrl_gemm_bf16_splitk_ws_bytes) — the plain product (lmrl_gemm_bf16) is the fallback.
+int lmrl_gemm_bf16_splitk_bias(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc,
+                               void *ws_d, void *stream) {
+    LMRL_REQUIRE(a_d && w_d && c_d && ws_d && m > 0 && n > 0 && k > 0 && n % 128 == 0 && ldc >= n, "lmrl_gemm_bf16_splitk_bias: bad argument");
+    int kchunk = 0, kind = 0;
+    const int S = lmrl::splitk_plan(m, n, k, &kchunk, &kind);
+    LMRL_REQUIRE(S >= 2 && kind == 0, "lmrl_gemm_bf16_splitk_bias: no 128 x 128 split-K plan for this shape (lmrl_gemm_bf16_splitk_ws_bytes returned 0)");
+    hipStream_t s = as_stream(stream);
+    GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, nullptr, ws_d, m, n, k, lda, n, n};
+    g.ldw = ldw;
+    LMRL_CHECK_HIP((gemm8_launch_splitk<128, 128, 2, 4, 2>(g, (float *)ws_d, S, kchunk, s)));
+    const long total = (long)m * (n / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, (const float *)ws_d, S,
+                       (long)m * n, n, (float *)c_d, ldc, m, n, 0, bias_d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
 // dW = x^T . dy on the operands as their producers staged them: a_d = x [k][lda] (k = B*T rows, m = layer input width), w_d = dy [k][ldw];
 // c[m][n] (=|+=) sum_kk a[kk][m] w[kk][n].  Same split-K plan / reduce as lmrl_gemm_bf16_splitk; the kernel gathers its MFMA operands with
 // ds_read_b64_tr_b16 (gemm8_bf16.h, KM), so no transposed copy of either operand exists.
@@ -1390,6 +1411,9 @@ int lmrl_gemm_bf16_ld(const void *a_d, const void *w_d, const float *bias_d, voi
         case EPI_RESID_F32: LMRL_CHECK_HIP(gemm_launch<EPI_RESID_F32>(g, s)); break;
         case EPI_F32: LMRL_CHECK_HIP(gemm_launch<EPI_F32>(g, s)); break;
         case EPI_RELU_BF16: LMRL_CHECK_HIP(gemm_launch<EPI_RELU_BF16>(g, s)); break;
+        case EPI_GELU_SPLIT3:
+            LMRL_REQUIRE(ldc >= 3 * n && ldc % 4 == 0 && g.n_store == n, "lmrl_gemm_bf16: EPI_GELU_SPLIT3 writes [m][3 n] bf16 (ldc >= 3 n, n_store = n)");
+            LMRL_CHECK_HIP(gemm_launch<EPI_GELU_SPLIT3>(g, s)); break;
         default: LMRL_REQUIRE(false, "lmrl_gemm_bf16: unknown epilogue");
     }
     return LMRL_OK;

@@ -305,8 +305,14 @@ extern "C" int lmrl_sgemm(int trans_a, int trans_b, int m, int n, int k, float a
     hipStream_t s = as_stream(stream);
     // Weight-gradient shapes (dW = X^T dY: small M x N, K = all tokens of the batch) have fewer 128 x 128 tiles than CUs:
     // split K across workgroups into a workspace and add the partials in a fixed order (no atomics -> deterministic).
-    if (g_sgemm_variant == 0 && m >= 128 && n >= 128 && nb_outer * nb_inner == 1 && k >= 4096) {
-        const long tiles = (long)ceil_div(n, SG2_BN) * ceil_div(m, SG2_BM);
+    // The fp32 ROLLOUT's decode products (M = one row per env, ~1024; gpt2_f32_engine.py) have the same problem at a short K: the output
+    // projections (N = d_model) are 48 tiles of 128 x 128 on 256 CUs — K = 768 / 3072 split 3 / 5 ways puts a workgroup on (almost) every CU
+    // (41 -> ~17 us and 164 -> ~40 us by the cost model below); slices down to 128 long are allowed there.
+    const long tiles0 = (long)ceil_div(n, SG2_BN) * ceil_div(m, SG2_BM);
+    const bool short_k_few_tiles = m <= 2048 && k >= 512 && tiles0 <= 160;
+    if (g_sgemm_variant == 0 && m >= 128 && n >= 128 && nb_outer * nb_inner == 1 && (k >= 4096 || short_k_few_tiles)) {
+        const long tiles = tiles0;
+        const int min_slice = k >= 4096 ? 1024 : 128;
         // S slices: tiles * S workgroups run in rounds of the 256 CUs and a round costs one slice (K / S), so time ~ ceil(tiles S / 256) / S — S = 4
         // on 144 tiles is 2.25 rounds = 3 (0.75 of a full-K tile time, the measured 85 vs 113 TFLOP/s), S = 7 is 3.94 = 4 (0.57) — plus the
         // partials' round trip through HBM (2 S m n floats at ~5 TB/s against ~0.5 TFLOP/s per CU).  Slices of unequal length (the last one shorter).
@@ -318,7 +324,7 @@ extern "C" int lmrl_sgemm(int trans_a, int trans_b, int m, int n, int k, float a
             for (int c = 1; c <= 16; c++) {
                 const int per = ceil_div(ceil_div(k, SG2_BK), c) * SG2_BK;      // slice length, a multiple of the K-step
                 const int slices = ceil_div(k, per);
-                if (c > 1 && (per < 1024 || slices < 2)) continue;
+                if (c > 1 && (per < min_slice || slices < 2)) continue;
                 const double cost = (double)ceil_div((int)(tiles * slices), 256) * t_tile * per / k + (slices > 1 ? slices * t_part : 0.0);
                 if (cost < best - 1e-12) { best = cost; S = slices; kc = per; }
             }

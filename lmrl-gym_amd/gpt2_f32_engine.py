@@ -56,14 +56,31 @@ class GPT2EngineF32:
                     p[n + ".x3"] = x3(p[n].t().contiguous())
             self.wte_x3 = x3(self.wte)
 
-    def linear(self, x, rows, k, n, w_name, p, y, scratch):
-        """y[rows][n] = x[rows][k] @ W + b for a layer's Dense `w_name` in this engine's matmul mode (`scratch`: bf16 [rows][3 k] split buffer)."""
+    def linear(self, x, rows, k, n, w_name, p, y, scratch, gelu_split=None):
+        """y[rows][n] = x[rows][k] @ W + b for a layer's Dense `w_name` in this engine's matmul mode (`scratch`: bf16 [rows][3 k] split buffer).
+        bf16x3 with `gelu_split` (a bf16 buffer of >= rows * 3 n elements): gelu_new(y) is written there as a split operand instead of y."""
         if self.matmul == "f32":
             ops.sgemm(x, p[w_name + ".weight"], y, rows, n, k, lda=k, ldb=n, ldc=n, bias=p[w_name + ".bias"])
             return
         L = self._L
         if x is not None:          # None: `scratch` already holds the split operand (written by the producing LayerNorm / gelu launch)
             _lib.check(L.lmrl_split3_bf16(x.data_ptr(), k, rows, k, scratch.data_ptr(), 3 * k, _lib.stream_ptr()), "lmrl_split3_bf16")
+        if gelu_split is not None:
+            # c_fc: the epilogue applies gelu_new and writes the c_proj product's split operand [rows][3 n] itself (EPI_GELU_SPLIT3 = 13): no fp32
+            # pre-activation tensor, no gelu + split pass over it
+            _lib.check(L.lmrl_gemm_bf16(scratch.data_ptr(), p[w_name + ".weight.x3"].data_ptr(), p[w_name + ".bias"].data_ptr(), gelu_split.data_ptr(), rows, n,
+                                        3 * k, 3 * k, 3 * n, n, 13, _lib.stream_ptr()), "lmrl_gemm_bf16 (bf16x3, gelu + split epilogue)")
+            return
+        if rows < 2048 and n % 128 == 0:
+            # decode-sized product with few output tiles and a long K' (the MLP's c_proj: 48 tiles, K' = 9216): deterministic split-K
+            nb = L.lmrl_gemm_bf16_splitk_ws_bytes(rows, n, 3 * k)
+            if nb:
+                if getattr(self, "_splitk_ws", None) is None or self._splitk_ws.numel() < nb:
+                    import torch
+                    self._splitk_ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+                _lib.check(L.lmrl_gemm_bf16_splitk_bias(scratch.data_ptr(), p[w_name + ".weight.x3"].data_ptr(), p[w_name + ".bias"].data_ptr(), y.data_ptr(), rows, n,
+                                                        3 * k, 3 * k, 3 * k, n, self._splitk_ws.data_ptr(), _lib.stream_ptr()), "lmrl_gemm_bf16_splitk_bias (bf16x3)")
+                return
         _lib.check(L.lmrl_gemm_bf16(scratch.data_ptr(), p[w_name + ".weight.x3"].data_ptr(), p[w_name + ".bias"].data_ptr(), y.data_ptr(), rows, n, 3 * k, 3 * k,
                                     n, n, 3, _lib.stream_ptr()), "lmrl_gemm_bf16 (bf16x3)")
 
@@ -102,7 +119,8 @@ class KVSessionF32:
             self._ws[C] = dict(ids=t.zeros(R, dtype=t.int32, device=dev), pos=t.zeros(R, dtype=t.int32, device=dev), x=f(R, c.d_model), h=f(R, c.d_model),
                                r=f(R, c.d_model),
                                qkv=f(R, 3 * c.d_model), att=f(R, c.d_model), ff=f(R, c.d_ff), mean=f(R), rstd=f(R),
-                               split=t.empty(R * 3 * c.d_ff, dtype=t.bfloat16, device=dev) if self.eng.matmul == "bf16x3" else None)
+                               split=t.zeros(R * 3 * c.d_model, dtype=t.bfloat16, device=dev) if self.eng.matmul == "bf16x3" else None,
+                               split2=t.zeros(R * 3 * c.d_ff, dtype=t.bfloat16, device=dev) if self.eng.matmul == "bf16x3" else None)
         return self._ws[C]
 
     def reset(self):
@@ -134,16 +152,18 @@ class KVSessionF32:
             return h
         for l, p in enumerate(e.layers):
             e.linear(ln(pending, p["ln_1.weight"], p["ln_1.bias"]), R, d, 3 * d, "attn.c_attn", p, qkv, w["split"])
-            _lib.check(L.lmrl_attn_cached_f32(_lib.ptr(qkv), _lib.ptr(self.kv[l, 0]), _lib.ptr(self.kv[l, 1]), _lib.ptr(self.len), _lib.ptr(cnt),
-                                              _lib.ptr(att), B, C, c.n_head, self.tmax, sp), "lmrl_attn_cached_f32")
-            e.linear(att, R, d, d, "attn.c_proj", p, r, w["split"])                 # r = att . Wproj + b ; x += r inside the ln_2 launch
-            e.linear(ln(r, p["ln_2.weight"], p["ln_2.bias"]), R, d, c.d_ff, "mlp.c_fc", p, ff, w["split"])
+            # (bf16x3: the attention lanes that hold the output also write it as the projection GEMM's split operand — no split pass)
+            _lib.check(L.lmrl_attn_cached_f32_split3(_lib.ptr(qkv), _lib.ptr(self.kv[l, 0]), _lib.ptr(self.kv[l, 1]), _lib.ptr(self.len), _lib.ptr(cnt),
+                                                     _lib.ptr(att), _lib.ptr(w["split"]) if x3 else None, B, C, c.n_head, self.tmax, sp), "lmrl_attn_cached_f32")
+            e.linear(None if x3 else att, R, d, d, "attn.c_proj", p, r, w["split"])   # r = att . Wproj + b ; x += r inside the ln_2 launch
             if x3:
-                _lib.check(L.lmrl_gelu_split3(ff.data_ptr(), R, c.d_ff, w["split"].data_ptr(), sp), "lmrl_gelu_split3")
-                e.linear(None, R, c.d_ff, d, "mlp.c_proj", p, r, w["split"])
+                # c_fc reads the LayerNorm's split operand (w["split"], pitch 3 d) and writes gelu's split operand (w["split2"], pitch 3 d_ff)
+                e.linear(ln(r, p["ln_2.weight"], p["ln_2.bias"]), R, d, c.d_ff, "mlp.c_fc", p, None, w["split"], gelu_split=w["split2"])
+                e.linear(None, R, c.d_ff, d, "mlp.c_proj", p, r, w["split2"])
             else:
+                e.linear(ln(r, p["ln_2.weight"], p["ln_2.bias"]), R, d, c.d_ff, "mlp.c_fc", p, ff, w["split"])
                 ops.gelu_fwd(ff, ff)
-                e.linear(ff, R, c.d_ff, d, "mlp.c_proj", p, r, w["split"])          # r = mlp output ; added by the next LayerNorm launch
+                e.linear(ff, R, c.d_ff, d, "mlp.c_proj", p, r, w["split2"])         # r = mlp output ; added by the next LayerNorm launch
             pending = r
         if all_hidden is not None:
             ops.layernorm_add_fwd(x, pending, e.lnf_g, e.lnf_b, all_hidden, w["mean"], w["rstd"], None, 0, R, d, c.ln_eps)
