@@ -683,6 +683,11 @@ int lmrl_gather_dot_f32(const float *a_d, long lda, const float *w_d, long ldw, 
  * the weight-decay coefficient of each tensor (the optax mask: 0 for biases / LayerNorm).  Element for element the arithmetic of lmrl_adamw. */
 int lmrl_adamw_segments(float *p_d, const float *g_d, float *m_d, float *v_d, long n, const long *seg_end_d, const float *seg_wd_d, int nseg, float lr,
                         float b1, float b2, float eps, int step, void *stream);
+/* the same update and, in the same sweep, the Polyak target update of the reference's step (optax.incremental_update(new_params, target, alpha) right
+ * after apply_gradients, ilql/gpt2/interface.py:327-347): target_d (nullable; same arena layout) = alpha * p_new + one_minus_alpha * target_d.
+ * 16-byte accesses; arenas 16-byte aligned. */
+int lmrl_adamw_segments_polyak(float *p_d, const float *g_d, float *m_d, float *v_d, long n, const long *seg_end_d, const float *seg_wd_d, int nseg, float lr,
+                               float b1, float b2, float eps, int step, float *target_d, float alpha, float one_minus_alpha, void *stream);
 /* P = causal (+ key padding mask [batch][t] uint8) softmax of S [batch*heads][t][t]; in place allowed */
 int lmrl_softmax_causal_fwd(const float *s_d, const uint8_t *key_mask_d, float *p_d, int batch, int heads, int t, void *stream);
 int lmrl_softmax_bwd(const float *p_d, float *dp_d, long rows, int t, void *stream);

@@ -131,6 +131,8 @@ _SIGS = {
     "lmrl_flash_attn_finish_staging": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "lmrl_flash_attn_bwd_staged": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_adamw_segments": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_int, c_void_p]),
+    "lmrl_adamw_segments_polyak": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_int,
+                                           c_void_p, c_float, c_float, c_void_p]),
     "lmrl_layernorm_add_fwd_split3": (c_int, [c_void_p] * 7 + [c_int, c_int, c_float, c_void_p]),
     "lmrl_gelu_split3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lmrl_layernorm_add_fwd": (c_int, [c_void_p] * 8 + [ctypes.c_long, c_int, c_int, c_float, c_void_p]),

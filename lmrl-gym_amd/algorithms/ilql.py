@@ -333,13 +333,17 @@ class GPT2ILQLTrain:
         self.last_grads = (bgrads, g1, g2, gv)
         red.finish(late)
         self.calls += 1                                 # TrainState.step of the reference: one per apply_gradients call
-        upd = self.base_opt.apply(bgrads)
-        self.q1_opt.apply(g1); self.q2_opt.apply(g2); self.v_opt.apply(gv)
-        if upd:   # targets move only when MultiSteps.mini_step == 0 (interface.py:343-347)
-            if self.target_base is not None:
-                self._update_targets(base.p, self.target_base.p, self.calls)
-            self._update_targets(self.q1.p, self.q1_target.p, self.calls)
-            self._update_targets(self.q2.p, self.q2_target.p, self.calls)
+        # targets move only when MultiSteps.mini_step == 0 (interface.py:343-347); their Polyak step rides in the AdamW sweep over the same arena
+        # (one pass over parameters + optimizer state + target instead of an update pass and a second pass that re-reads the parameters)
+        pairs = [(self.base_opt, base.p, self.target_base.p if self.target_base is not None else None, bgrads),
+                 (self.q1_opt, self.q1.p, self.q1_target.p, g1), (self.q2_opt, self.q2.p, self.q2_target.p, g2)]
+        hard = self.hard_every is not None and self.calls % self.hard_every == 0
+        upd = False
+        for opt, online, target, grads in pairs:
+            upd = opt.apply(grads, polyak=None if (target is None or hard) else (target, self.alpha))
+            if upd and target is not None and not opt.polyak_fused:
+                self._update_targets(online, target, self.calls)
+        self.v_opt.apply(gv)
         return self, loss, logs
 
 

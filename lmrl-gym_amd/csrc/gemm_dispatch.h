@@ -24,6 +24,10 @@ inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
             return gemm8_launch<128, 128, 2, 4, 3, EPI, NQ>(g, s);
         }
     }
+    if constexpr (EPI == EPI_RESID_F32_STATS) {      // tools/ab_rollout_variants.py (A/B hooks; the product path never sets a variant)
+        if (g.M >= 2048 && g_gemm_variant == 201) return gemm8_launch<128, 128, 2, 4, 2, EPI, NQ>(g, s);
+        if (g.M >= 2048 && g_gemm_variant == 203) return gemm_launch_glds<128, 64, 3, EPI, NQ>(g, s);
+    }
     if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI, NQ>(g, s);
     // (decode residual producers, N = d_model, 192 tiles: the 8-wave 64x64 form of gemm8_bf16.h is ~10 % faster in isolation but measured
     //  SLOWER inside the episode — 14.6 vs 13.4 us — so they stay on the 4-wave ring; profiles/r02_gemm8_bench.txt)

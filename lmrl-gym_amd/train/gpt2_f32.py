@@ -578,9 +578,12 @@ class AdamW:
         self.step_count = 0     # number of applied updates
         self.mini_step = 0
 
-    def apply(self, grads: Dict[str, "torch.Tensor"]) -> bool:
-        """Returns True when parameters were updated on this call (MultiSteps.mini_step wrapped to 0)."""
+    def apply(self, grads: Dict[str, "torch.Tensor"], polyak=None) -> bool:
+        """Returns True when parameters were updated on this call (MultiSteps.mini_step wrapped to 0).
+        polyak = (target parameter arena of the same layout, alpha): when this call updates the parameters, the target's soft update
+        target = alpha p_new + (1 - alpha) target rides in the AdamW sweep (`self.polyak_fused` says whether it did — it does on the arena path)."""
         fast = self.arena and self.params.same_layout(grads)
+        self.polyak_fused = False
         if self.k > 1:
             if fast:
                 ops.axpby(1.0, self.acc.flat, 1.0 / self.k, grads.flat, self.acc.flat)
@@ -594,8 +597,11 @@ class AdamW:
             grads = self.acc
         self.step_count += 1
         if fast:
+            tgt = None
+            if polyak is not None and getattr(polyak[0], "flat", None) is not None and polyak[0].order == self.params.order:
+                tgt, self.polyak_fused = polyak[0].flat, True
             ops.adamw_segments(self.params.flat, grads.flat, self.m.flat, self.v.flat, self._seg_end, self._seg_wd, self.lr, self.b1, self.b2,
-                               self.eps, self.step_count)
+                               self.eps, self.step_count, target=tgt, alpha=polyak[1] if tgt is not None else 0.0)
         else:
             for k, p in self.params.items():
                 wd = 0.0 if self.no_decay(k) else self.wd

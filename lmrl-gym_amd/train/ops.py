@@ -437,9 +437,12 @@ def adamw(p, g, m, v, lr, b1, b2, eps, wd, step):
                                float(eps), float(wd), int(step), _sp()), "lmrl_adamw")
 
 
-def adamw_segments(p, g, m, v, seg_end, seg_wd, lr, b1, b2, eps, step):
-    _lib.check(_L().lmrl_adamw_segments(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), seg_end.data_ptr(), seg_wd.data_ptr(),
-                                        seg_end.numel(), float(lr), float(b1), float(b2), float(eps), int(step), _sp()), "lmrl_adamw_segments")
+def adamw_segments(p, g, m, v, seg_end, seg_wd, lr, b1, b2, eps, step, target=None, alpha=0.0):
+    """AdamW over a parameter arena in one launch; `target` (an arena of the same layout): the Polyak update target = alpha p_new + (1 - alpha)
+    target in the same sweep (the coefficients are rounded to fp32 on the host exactly as the stand-alone `axpby` form passes them)."""
+    _lib.check(_L().lmrl_adamw_segments_polyak(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), seg_end.data_ptr(), seg_wd.data_ptr(),
+                                               seg_end.numel(), float(lr), float(b1), float(b2), float(eps), int(step),
+                                               None if target is None else target.data_ptr(), float(alpha), float(1.0 - alpha), _sp()), "lmrl_adamw_segments")
 
 
 def embed_fwd(wte, wpe, ids, pos, x, rows, d):

@@ -22,14 +22,16 @@ from lmrl_gym_amd.policies import GPT2PPOPolicy  # noqa: E402
 
 
 class ByteTok:
-    """One token per byte; ids < 256 (the models keep GPT-2's 50 257-row tables)."""
+    """One token per byte (the models keep GPT-2's 50 257-row tables).  A random-init model samples ids all over the table: ids >= 256 decode to a
+    printable character (32 + id % 95) so that a generated question has as many characters as tokens — with ids >= 256 dropped, every question was
+    "?" and every oracle prompt equal to the previous one (K/V reuse then forwards 4 tokens per call: a degenerate workload)."""
     pad_token_id, eos_token_id = 50256, 10
 
     def encode(self, s):
-        return list(s.encode("utf-8", errors="replace"))
+        return list(s.encode("latin-1", errors="replace"))
 
     def decode(self, ids, skip_special_tokens=True):
-        return bytes(int(i) & 0xFF for i in ids if int(i) < 256).decode("latin-1")
+        return bytes((int(i) if int(i) < 256 else 32 + int(i) % 95) for i in ids if int(i) != self.pad_token_id).decode("latin-1")
 
 
 def main():
@@ -48,13 +50,38 @@ def main():
     asker = GPT2PPOPolicy(guesser, tok, max_input_length=64 + a.turns * (a.q_tokens + 8), max_new_tokens=a.q_tokens, do_sample=True, temperature=1.0,
                           seed=3, eos_token_id=10, out_str_process=Q.asker_postproc_filter_repeats)
     env = Q.BatchedTwentyQuestionsPolicyEnvironment(oracle, wl, max_conversation_length=a.turns, bsize=a.envs)
+    n_gen = {"guesser": 0, "oracle": 0}                     # tokens the engines actually generated (counted where the policies decode them)
+    for name, pol in (("guesser", asker), ("oracle", oracle._policy)):
+        def counted(ids, _dec=pol._decode_generation, _name=name):
+            n_gen[_name] += len(ids)
+            return _dec(ids)
+        pol._decode_generation = counted
     for rep in range(2):                       # first pass: allocation / first-touch
+        for pol in (asker, oracle._policy):
+            if pol._gen is not None:
+                pol._gen.prefilled_tokens = 0
+        n_gen.update(guesser=0, oracle=0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         inter = E.interact_environment(env, asker, env_seed=list(range(a.envs)), env_options=[{"deterministic": True}] * a.envs, bsize=a.envs)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     n = sum(len(ep) for ep in inter)
     print(f"Twenty Questions dual-model rollout: GPT-2-medium guesser + GPT-2-large oracle, {a.envs} envs x {a.turns} turns, <= {a.q_tokens} question tokens: "
           f"{n / dt:.1f} env-steps/s ({dt * 1e3 / a.turns:.0f} ms per lock-step turn, {n} env steps in {dt:.2f} s; text protocol, host tokenisation)")
+    # what the loop computes: tokens actually forwarded by the two models (prefill counters of the generators + one decode forward per generated
+    # token but the last), priced at 2 x (matmul parameters) flops per token — the loop is GPU-bound (rocprofv3: kernel time == wall time,
+    # profiles/r04_twentyq_kernel_stats.csv), so its rate is set by these flops, not by the host text protocol
+    def mm_params(cfg):
+        return cfg.n_layer * (4 * cfg.d_model ** 2 + 2 * cfg.d_model * cfg.d_ff)
+
+    def head_params(cfg):
+        return cfg.vocab_padded * cfg.d_model                                      # the tied LM head runs once per SAMPLED token only
+    g_pre, o_pre = asker._gen.prefilled_tokens, oracle._policy._gen.prefilled_tokens
+    g_dec, o_dec = max(n_gen["guesser"] - n, 0), max(n_gen["oracle"] - n, 0)        # decode forwards: one per generated token but the last
+    fl = 2.0 * (mm_params(guesser.cfg) * (g_pre + g_dec) + mm_params(oracle_eng.cfg) * (o_pre + o_dec) +
+                head_params(guesser.cfg) * n_gen["guesser"] + head_params(oracle_eng.cfg) * n_gen["oracle"])
+    print(f"tokens forwarded per env-step: guesser {(g_pre + g_dec) / n:.1f} (prefill {g_pre / n:.1f}), oracle {(o_pre + o_dec) / n:.1f} (prefill {o_pre / n:.1f}); "
+          f"{fl / 1e12:.1f} TFLOP in {dt:.2f} s = {fl / dt / 1e12:.0f} TFLOP/s = {fl / dt / 2.5e15:.2f} of the dense bf16 MFMA peak; "
+          f"at 100 % of that peak this workload would reach {n / (fl / 2.5e15):.0f} env-steps/s (byte-level stand-in tokenizer: ~4x the tokens of GPT-2 BPE)")
     yes = sum(t.post_transition_history[-1].text == "Yes.\n" for ep in inter for t in ep)
     print(f"answers: {yes} Yes / {n - yes} No (random-init oracle)")
 
