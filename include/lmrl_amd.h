@@ -339,7 +339,7 @@ int lmrl_ce_bwd_bf16_inplace(void *logits_bf16_d, long ld, int vocab, const floa
 size_t lmrl_gemm_bf16_splitk_ws_bytes(int m, int n, int k);
 int lmrl_gemm_bf16_splitk(const void *a_d, const void *w_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc, int n_store, int accumulate,
                           void *ws_d, void *stream);
-/* the same product with a bias and no accumulation, c[m][n] = sum_k a[m][k] w[n][k] + bias[n] (128 x 128 split-K plans only: m < 2048) — the MLP output
+/* the same product with a bias and no accumulation, c[m][n] = sum_k a[m][k] w[n][k] + bias[n] (any shape lmrl_gemm_bf16_splitk_ws_bytes has a plan for) — the MLP output
  * projection of the bf16x3 rollout mode at decode size (K' = 3 d_ff = 9216 on 48 tiles) */
 int lmrl_gemm_bf16_splitk_bias(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc,
                                void *ws_d, void *stream);

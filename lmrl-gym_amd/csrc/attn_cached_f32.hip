@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_chunk_f32_kernel(const float *__rest
 #pragma unroll
     for (int j = 0; j < C; j++) { m[j] = -1e30f; l[j] = 0.f; o[j] = float4{0.f, 0.f, 0.f, 0.f}; }
     const int n = L + nq;                                              // visible positions of the LAST query
-    constexpr int U = 2;                                               // 8 positions requested per batch
+    constexpr int U = 4;                                               // 16 positions requested per batch
     for (int t0 = 0; t0 < n; t0 += 4 * U) {
         float4 kr[U], vr[U];
 #pragma unroll
@@ -150,25 +150,35 @@ __global__ __launch_bounds__(256) void attn_chunk_f32_kernel(const float *__rest
                 kr[u] = *reinterpret_cast<const float4 *>(kp);
                 vr[u] = *reinterpret_cast<const float4 *>(vp);
             }
+        // per query: the batch's U scores first, then ONE rescale of the running state (U + 1 exps per U positions instead of 2 U)
 #pragma unroll
-        for (int u = 0; u < U; u++)
-            if (t0 + u * 4 < n) {
-                const int t = t0 + u * 4 + g;
+        for (int j = 0; j < C; j++) {
+            if (j < nq) {                                              // wave-uniform
+                float sc[U];
+                float mb = m[j];
 #pragma unroll
-                for (int j = 0; j < C; j++) {
-                    if (j < nq) {                                      // wave-uniform
+                for (int u = 0; u < U; u++) {
+                    sc[u] = -1e30f;
+                    if (t0 + u * 4 < n) {
+                        const int t = t0 + u * 4 + g;
                         float s = fmaf(q[j].x, kr[u].x, fmaf(q[j].y, kr[u].y, fmaf(q[j].z, kr[u].z, q[j].w * kr[u].w)));
                         s += dpp_mov<0xB1>(s); s += dpp_mov<0x4E>(s); s += dpp_mov<0x141>(s); s += dpp_mov<0x140>(s);
-                        const bool ok = t <= L + j && t < n;           // causal
-                        const float mn = ok ? fmaxf(m[j], s) : m[j];
-                        const float alpha = expf(m[j] - mn), pr = ok ? expf(s - mn) : 0.f;
-                        l[j] = l[j] * alpha + pr;
-                        o[j].x = fmaf(pr, vr[u].x, o[j].x * alpha); o[j].y = fmaf(pr, vr[u].y, o[j].y * alpha);
-                        o[j].z = fmaf(pr, vr[u].z, o[j].z * alpha); o[j].w = fmaf(pr, vr[u].w, o[j].w * alpha);
-                        m[j] = mn;
+                        if (t <= L + j && t < n) { sc[u] = s; mb = fmaxf(mb, s); }          // causal
                     }
                 }
+                const float alpha = expf(m[j] - mb);
+                l[j] *= alpha; o[j].x *= alpha; o[j].y *= alpha; o[j].z *= alpha; o[j].w *= alpha;
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (t0 + u * 4 < n) {
+                        const float pr = sc[u] > -1e29f ? expf(sc[u] - mb) : 0.f;
+                        l[j] += pr;
+                        o[j].x = fmaf(pr, vr[u].x, o[j].x); o[j].y = fmaf(pr, vr[u].y, o[j].y);
+                        o[j].z = fmaf(pr, vr[u].z, o[j].z); o[j].w = fmaf(pr, vr[u].w, o[j].w);
+                    }
+                m[j] = mb;
             }
+        }
     }
 #pragma unroll
     for (int j = 0; j < C; j++) {

@@ -1354,18 +1354,20 @@ int lmrl_gemm_bf16_splitk(const void *a_d, const void *w_d, void *c_d, int m, in
 }
 
 // The same split-K product with a bias: c[m][n] = sum_k a[m][k] w[n][k] + bias[n] — the bf16x3 rollout mode's c_proj of the MLP at decode size
-// (M = one row per env, N = d_model: 48 tiles of 128 x 128, K' = 3 d_ff = 9216: 144 K-steps on a fifth of the CUs unsplit).  `plan_k` lets the caller
-// ask whether a plan exists (lmrl_gemm_bf16_splitk_ws_bytes) — the plain product (lmrl_gemm_bf16) is the fallback.
+// (M = one row per env, N = d_model: 48 tiles of 128 x 128, K' = 3 d_ff = 9216: 144 K-steps on a fifth of the CUs unsplit) and at chunk size (M = 8192:
+// 128 tiles of 256 x 192, split in two: one full round of the CUs).  lmrl_gemm_bf16_splitk_ws_bytes says whether a plan exists — the plain product
+// (lmrl_gemm_bf16) is the fallback.
 int lmrl_gemm_bf16_splitk_bias(const void *a_d, const void *w_d, const float *bias_d, void *c_d, int m, int n, int k, int lda, int ldw, int ldc,
                                void *ws_d, void *stream) {
-    LMRL_REQUIRE(a_d && w_d && c_d && ws_d && m > 0 && n > 0 && k > 0 && n % 128 == 0 && ldc >= n, "lmrl_gemm_bf16_splitk_bias: bad argument");
+    LMRL_REQUIRE(a_d && w_d && c_d && ws_d && m > 0 && n > 0 && k > 0 && n % 64 == 0 && ldc >= n, "lmrl_gemm_bf16_splitk_bias: bad argument");
     int kchunk = 0, kind = 0;
     const int S = lmrl::splitk_plan(m, n, k, &kchunk, &kind);
-    LMRL_REQUIRE(S >= 2 && kind == 0, "lmrl_gemm_bf16_splitk_bias: no 128 x 128 split-K plan for this shape (lmrl_gemm_bf16_splitk_ws_bytes returned 0)");
+    LMRL_REQUIRE(S >= 2, "lmrl_gemm_bf16_splitk_bias: no split-K plan for this shape (lmrl_gemm_bf16_splitk_ws_bytes returned 0)");
     hipStream_t s = as_stream(stream);
     GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, nullptr, ws_d, m, n, k, lda, n, n};
     g.ldw = ldw;
-    LMRL_CHECK_HIP((gemm8_launch_splitk<128, 128, 2, 4, 2>(g, (float *)ws_d, S, kchunk, s)));
+    if (kind == 1) LMRL_CHECK_HIP((gemm8_launch_splitk<256, 192, 2, 4, 2>(g, (float *)ws_d, S, kchunk, s)));      // chunk-sized M, N = d_model: 256 x 192 tiles
+    else LMRL_CHECK_HIP((gemm8_launch_splitk<128, 128, 2, 4, 2>(g, (float *)ws_d, S, kchunk, s)));
     const long total = (long)m * (n / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, (const float *)ws_d, S,
                        (long)m * n, n, (float *)c_d, ldc, m, n, 0, bias_d);

@@ -71,8 +71,9 @@ class GPT2EngineF32:
             _lib.check(L.lmrl_gemm_bf16(scratch.data_ptr(), p[w_name + ".weight.x3"].data_ptr(), p[w_name + ".bias"].data_ptr(), gelu_split.data_ptr(), rows, n,
                                         3 * k, 3 * k, 3 * n, n, 13, _lib.stream_ptr()), "lmrl_gemm_bf16 (bf16x3, gelu + split epilogue)")
             return
-        if rows < 2048 and n % 128 == 0:
-            # decode-sized product with few output tiles and a long K' (the MLP's c_proj: 48 tiles, K' = 9216): deterministic split-K
+        if n % 64 == 0 and 3 * k >= 4096:
+            # few output tiles and a long K' (the MLP's c_proj, K' = 9216: 48 tiles of 128 x 128 at decode size, 128 tiles of 256 x 192 at chunk size):
+            # deterministic split-K
             nb = L.lmrl_gemm_bf16_splitk_ws_bytes(rows, n, 3 * k)
             if nb:
                 if getattr(self, "_splitk_ws", None) is None or self._splitk_ws.numel() < nb:
