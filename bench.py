@@ -422,7 +422,7 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="after the timed region, print a per-kernel-class event breakdown to stderr")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the `fp32_mode` leg of the default line (the same rollout on the fp32 engine)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the `train_step` leg of the default line (ILQL M3 step, fp32 and bf16-matmul)")
-    ap.add_argument("--train-steps", type=int, default=3, help="timed steps per arithmetic mode in the `train_step` leg of the default line")
+    ap.add_argument("--train-steps", type=int, default=5, help="timed steps per arithmetic mode in the `train_step` leg of the default line")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: spawn the N ranks ourselves (an external torch.distributed.run launch sets WORLD_SIZE and skips this)
@@ -737,7 +737,7 @@ def main():
         # for N > 1 every rank takes part (data parallel, one gradient all-reduce per step over RCCL)
         ts = {}
         for mm in ("f32", "bf16"):
-            ts["ilql_" + mm] = run_train_step("ilql-step", mm, args.train_batch, args.train_steps, 1, dev, rank, world, use_dist, backend)
+            ts["ilql_" + mm] = run_train_step("ilql-step", mm, args.train_batch, args.train_steps, 2, dev, rank, world, use_dist, backend)
         if rank == 0:
             out["train_step"] = ts
     if rank == 0:

@@ -167,3 +167,39 @@ def test_f32_rollout_every_sampled_token_equals_float64_oracle_with_jax_stream(d
                 assert int(score.argmax()) == int(trajs[b][0][start + k]), (turn, k, b)
     assert checked > 1200 and near_tie <= (0.005 if matmul == "f32" else 0.03) * (checked + near_tie), (checked, near_tie)
     ro.close()
+
+
+@pytest.mark.parametrize("matmul", ["f32", "bf16x3"])
+def test_f32_engines_graph_replay_is_bit_identical_to_eager(dev, matmul):
+    """The fp32-accurate rollout modes under hipGraph replay (what bench.py times as `fp32_mode` / `bf16x3_mode`): capture_episode + replay == the
+    eager episode with the same seeds / guesses / epoch word, bit for bit — tokens, action flags, rewards, counters — for two replays with fresh
+    noise.  Covers the deterministic split-K products (fixed-order reduces) and, in bf16x3, the fused LM-head sampler on the split operands."""
+    from lmrl_gym_amd.envs import wordle as W
+    from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
+    from lmrl_gym_amd.gpt2_f32_engine import GPT2EngineF32
+    from lmrl_gym_amd.rollout import WordleRolloutEngine
+    cfg = GPT2Config(2, 4, 256, 1024, 50257, 128)
+    eng = GPT2EngineF32(cfg, init_hf_style_state_dict(cfg, seed=1), dev, matmul=matmul)
+    vocab = W.Vocabulary.builtin("wordle_official_400.txt")
+    B = 192
+    ro = WordleRolloutEngine(eng, vocab, B, max_new_tokens=6, bad_word_reward=-10.0)
+    rng = np.random.RandomState(3)
+    packed = np.array([W.pack_guess(w) for w in vocab.all_vocab], dtype=np.uint32)
+    guesses = torch.from_numpy(packed[rng.randint(0, len(packed), size=(6, B))].view(np.int32)).to(dev)
+    seeds = (torch.arange(B, dtype=torch.int64) + 900).to(dev)
+    kw = dict(temperature=1.0, sample_seed=11, steer_strength=12.5)
+    ro.capture_episode(scripted=True, **kw)
+    snap = lambda: {k: ro.traj[k].clone() for k in ("tokens", "is_action", "reward", "n_tok", "n_steps", "ep_reward", "env_done")}
+    outs = []
+    for rep in range(2):
+        ro.replay_episode(seeds + rep, guesses)
+        g = snap()
+        epoch = ro.g_epoch.clone()
+        ro.sample_step = 0                                  # the captured graph baked steps 0..35
+        ro.run_episode(seeds + rep, scripted_guesses=guesses, epoch=epoch, **kw)
+        e = snap()
+        for k in g:
+            assert torch.equal(g[k], e[k]), (matmul, rep, k)
+        outs.append(g)
+    assert int(outs[0]["n_steps"].sum()) > 3 * B and not torch.equal(outs[0]["tokens"], outs[1]["tokens"])
+    ro.close()
