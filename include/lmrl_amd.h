@@ -387,6 +387,7 @@ typedef struct {
 void lmrl_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]);
 int lmrl_jax_random_bits_host(const uint32_t key[2], uint32_t n, uint32_t i0, uint32_t count, uint32_t *out);
 
+/* workspace of lmrl_lm_head_sample (per-tile partials).  One workspace per concurrent stream. */
 size_t lmrl_sample_ws_bytes(int m, int vocab_padded);
 /* hidden_d bf16 [m][d] . wte_d bf16 [vocab_padded][d]^T -> token_d[m] (+ logprob_d[m] under the sampling
  * distribution).  Optional ILQL operands: q_hidden{1,2}_d bf16 [m][d] (= relu(dense1(h)) of each Q head),

@@ -257,6 +257,98 @@ __device__ __forceinline__ void g8_mainloop_pair(const uint16_t *__restrict__ A,
 #undef LMRL_G8_READ
 #undef LMRL_G8_MFMA
 
+// ---- persistent form of g8_mainloop for a SEQUENCE of tiles on a 2-slot ring (K / 64 even): the ring never drains between tiles.  On entry the
+// first two stages of THIS tile are already in flight or landed — issued by g8_stream_prime (first tile of the workgroup) or by the previous
+// tile's call — and on exit the first two stages of the NEXT tile (if any) are in flight, so that its operands stream into LDS under this tile's
+// epilogue instead of behind a cold ring prologue (a 128 x 128 tile with K = 768 is 12 K-steps behind ~1.2 us of fill latency).  Every wait is
+// vmcnt(0): with two slots nothing else may be outstanding at a wait anyway, and the epilogue's own global accesses then never enter a counted wait.
+// The epilogue must not touch the ring (it is being filled) and must use raw s_barrier (a __syncthreads carries vmcnt(0): it would wait for the DMA).
+template <int BM, int BN, int WM, int WN>
+struct G8Stream {
+    static constexpr int NW = WM * WN, BK = 64, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    static constexpr int LA = BM / 8 / NW, LW = BN / 8 / NW, STAGE = (BM + BN) * 128;
+    const uint16_t *A, *W;       // wave-uniform operand bases (SGPRs); a tile is (m0, n0), also wave-uniform: per-lane state is recomputed per issue (a handful of
+    int lda, ldw, Mr;            // VALU) instead of being held in VGPRs across the K loop and the epilogue — the kernel must stay within 128 VGPRs (2 workgroups / CU)
+
+    // stage kt of tile (m0, n0) -> ring slot `slot`.  Operands below 4 GiB (32-bit byte offsets).
+    __device__ __forceinline__ void issue(int m0, int n0, int kt, int slot, char *smem) const {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lrow = lane >> 3, src_c = (lane & 7) ^ lrow;
+        char *sb = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < LA; i++) {
+            int m = m0 + (wave + NW * i) * 8 + lrow;
+            m = m < Mr ? m : Mr - 1;
+            const uint32_t off = ((uint32_t)m * (uint32_t)lda + (uint32_t)(src_c * 8 + kt * BK)) * 2u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(A) + off),
+                                             (__attribute__((address_space(3))) void *)(sb + (wave + NW * i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < LW; i++) {
+            const uint32_t off = ((uint32_t)(n0 + (wave + NW * i) * 8 + lrow) * (uint32_t)ldw + (uint32_t)(src_c * 8 + kt * BK)) * 2u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const char *>(W) + off),
+                                             (__attribute__((address_space(3))) void *)(sb + BM * 128 + (wave + NW * i) * 1024), 16, 0, 0);
+        }
+    }
+};
+
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void g8_stream_tile(const G8Stream<BM, BN, WM, WN> &st, int m0, int n0, bool has_next, int m0n, int n0n, int K, char *smem,
+                                               f32x4 (&acc)[BN / WN / 16][BM / WM / 16]) {
+    typedef G8Stream<BM, BN, WM, WN> S;
+    constexpr int TM = S::TM, TN = S::TN, FM = S::FM, FN = S::FN, STAGE = S::STAGE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int nk = K / 64;
+#define LMRL_G8S_READ(FW, FA, SLOT, KK)                                                                               \
+    do {                                                                                                              \
+        const char *sA_ = smem + (SLOT) * STAGE;                                                                      \
+        const char *sW_ = sA_ + BM * 128;                                                                             \
+        const int c_ = (KK) * 4 + lq;                                                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < FN; i_++) {                                                           \
+            const int row_ = wn * TN + i_ * 16 + lr;                                                                  \
+            FW[i_] = *reinterpret_cast<const bf16x8 *>(sW_ + row_ * 128 + ((c_ ^ (row_ & 7)) << 4));                  \
+        }                                                                                                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < FM; j_++) {                                                           \
+            const int row_ = wm * TM + j_ * 16 + lr;                                                                  \
+            FA[j_] = *reinterpret_cast<const bf16x8 *>(sA_ + row_ * 128 + ((c_ ^ (row_ & 7)) << 4));                  \
+        }                                                                                                             \
+    } while (0)
+#define LMRL_G8S_MFMA(FW, FA)                                                                                         \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < FN; i_++)                                                             \
+            _Pragma("unroll") for (int j_ = 0; j_ < FM; j_++)                                                         \
+                acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FW[i_], FA[j_], acc[i_][j_], 0, 0, 0);          \
+    } while (0)
+    wait_vmcnt<0>();                         // this tile's stages 0 and 1 (issued one tile ago, or by the caller for the first tile) have landed for this wave ...
+    __builtin_amdgcn_s_barrier();            // ... and for every wave
+    bf16x8 fw0[FN], fa0[FM], fw1[FN], fa1[FM];
+    LMRL_G8S_READ(fw0, fa0, 0, 0);
+    int slot = 0;
+    for (int t = 0; t < nk; t++) {
+        LMRL_G8S_READ(fw1, fa1, slot, 1);
+        LMRL_G8S_MFMA(fw0, fa0);
+        const int nslot = slot ^ 1;
+        if (t + 1 < nk) {
+            wait_vmcnt<0>();                                           // stage t + 1 has landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                              // every wave holds stage t in registers: its slot is free
+            if (t + 2 < nk) st.issue(m0, n0, t + 2, slot, smem);
+            else if (has_next) st.issue(m0n, n0n, 0, slot, smem);      // t = nk - 2: the next tile's stage 0 (slot 0: nk is even)
+            LMRL_G8S_READ(fw0, fa0, nslot, 0);
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (has_next) st.issue(m0n, n0n, 1, slot, smem);           // t = nk - 1: the next tile's stage 1 (slot 1)
+        }
+        LMRL_G8S_MFMA(fw1, fa1);
+        slot = nslot;
+    }
+#undef LMRL_G8S_READ
+#undef LMRL_G8S_MFMA
+}
+
 // SPLITK (fp32-output epilogue only; the weight-gradient products of the train step: K = B*T = 16 k .. 32 k against an output of a few dozen
 // tiles): the grid holds kv_tmax = S copies of the tile grid; copy z accumulates K-steps [z * kv_d, min(K, (z + 1) * kv_d)) and stores its
 // partial tile to C + z * M * ldc (splitk_reduce_kernel adds the copies in a fixed order).  The two ints alias the kv_* fields, which only

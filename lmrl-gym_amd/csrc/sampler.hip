@@ -90,6 +90,103 @@ __device__ __forceinline__ void merge_partial(RowPartial &a, float om, float os,
     if (ob > a.best || (ob == a.best && oc < a.best_col)) { a.best = ob; a.best_col = oc; a.best_z = oz; }
 }
 
+// ---- sampling epilogue of one 128 x 128 tile (shared by the one-tile-per-workgroup kernel and the persistent one).  `st_pre[j]`: the steered column of
+// this lane's row j (or -1), loaded by the caller; `xch`: LDS hand-off area [WM][TM rows][WN - 1][5] floats; RAW: raw s_barrier + lgkmcnt(0) instead of
+// __syncthreads (whose release carries a vmcnt(0): the persistent kernel has the NEXT tile's LDS-DMA in flight here and must not wait for it).
+template <bool RAW>
+__device__ __forceinline__ void lm_barrier() {
+    if (RAW) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    else __syncthreads();
+}
+template <int NOPS, bool WANT_LP, bool JAX, bool RAW>
+__device__ __forceinline__ void lm_sample_epilogue(f32x4 (&z)[kLmBN / kLmWN / 16][kLmBM / kLmWM / 16], f32x4 (&qmin)[kLmBN / kLmWN / 16][kLmBM / kLmWM / 16],
+                                                   const int (&st_pre)[kLmBM / kLmWM / 16], int m0, int n0, int tile_n, int tiles_n, int M,
+                                                   float *__restrict__ partials, float *__restrict__ logits_out, int ldo, const SampleParams &sp, float *xch) {
+    constexpr int BM = kLmBM, BN = kLmBN, WM = kLmWM, WN = kLmWN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lq = lane >> 4;
+    // ---- sampling epilogue: every wave first reduces ALL its rows (FM partials per lane, lane groups merged by shuffles), then ONE
+    // exchange through LDS merges the WN column quarters — two barriers per tile instead of two per 16-row fragment
+    const uint32_t epoch = sp.epoch ? *sp.epoch : 0u;
+    RowPartial rps[FM];
+#pragma unroll
+    for (int j = 0; j < FM; j++) {
+        const int m = m0 + wm * TM + j * 16 + lr;
+        const int st = st_pre[j];
+        RowPartial rp{-INFINITY, 0.f, -INFINITY, 0.f, 0x7fffffff};
+        float vv[FN][4];
+#pragma unroll
+        for (int i = 0; i < FN; i++) {
+            const int n = n0 + wn * TN + i * 16 + lq * 4;
+            uint32_t rnd[4] = {0, 0, 0, 0};
+            if (!JAX && !sp.greedy) philox4x32_10((uint32_t)m, (uint32_t)(n >> 2), sp.step, epoch, sp.seed_lo, sp.seed_hi, rnd);
+            float zz[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = z[i][j][r];
+                if (NOPS > 1) v += sp.beta * qmin[i][j][r];   // generation.py:112-117
+                if (n + r == st) v += sp.steer_strength;
+                zz[r] = v;
+            }
+            if (logits_out && m < M) *reinterpret_cast<f32x4 *>(logits_out + (size_t)m * ldo + n) = f32x4{zz[0], zz[1], zz[2], zz[3]};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const bool colok = (n + r) < sp.vocab;
+                float v, sc;
+                if (JAX) {      // jax.random.categorical(key, logits / T): key = (seed_hi, seed_lo), word index = row * V + column
+                    v = colok ? zz[r] / sp.temperature : -INFINITY;
+                    sc = (sp.greedy || !colok || m >= M) ? v : v + gumbel_jax(sp.seed_hi, sp.seed_lo, (uint32_t)m * (uint32_t)sp.vocab + (uint32_t)(n + r), sp.jax_n);
+                } else {
+                    v = colok ? zz[r] * sp.inv_temperature : -INFINITY;
+                    sc = sp.greedy ? v : v + gumbel_from_bits(rnd[r]);
+                }
+                const bool take = sc > rp.best;                 // a padding column scores -inf and never wins; selects, not branches
+                rp.best = take ? sc : rp.best; rp.best_col = take ? n + r : rp.best_col; rp.best_z = take ? v : rp.best_z;
+                vv[i][r] = v;
+                if (WANT_LP) rp.pmax = fmaxf(rp.pmax, v);
+            }
+        }
+        // this lane's 4*FN logits: one exp each against the lane maximum (padding columns are -inf -> exp = 0)
+        if (WANT_LP && rp.pmax > -INFINITY) {
+#pragma unroll
+            for (int i = 0; i < FN; i++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) rp.psum += __expf(vv[i][r] - rp.pmax);
+        }
+        // merge the 4 lane groups (lq) that hold the same row: xor 16, 32
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1)
+            merge_partial<WANT_LP>(rp, __shfl_xor(rp.pmax, o), __shfl_xor(rp.psum, o), __shfl_xor(rp.best, o), __shfl_xor(rp.best_z, o),
+                                   __shfl_xor(rp.best_col, o));
+        rps[j] = rp;
+    }
+    lm_barrier<RAW>();                                 // (one-tile kernel: the LDS ring is free and doubles as the hand-off area)
+    if (wn > 0 && lq == 0) {
+#pragma unroll
+        for (int j = 0; j < FM; j++) {
+            float *sl = xch + ((((size_t)wm * TM + j * 16 + lr) * (WN - 1)) + (wn - 1)) * 5;
+            sl[0] = rps[j].pmax; sl[1] = rps[j].psum; sl[2] = rps[j].best; sl[3] = rps[j].best_z; sl[4] = __int_as_float(rps[j].best_col);
+        }
+    }
+    lm_barrier<RAW>();
+    if (wn == 0 && lq == 0) {
+#pragma unroll
+        for (int j = 0; j < FM; j++) {
+            const int m = m0 + wm * TM + j * 16 + lr;
+            const float *slot = xch + (((size_t)wm * TM + j * 16 + lr) * (WN - 1)) * 5;
+            RowPartial rp = rps[j];
+#pragma unroll
+            for (int w = 0; w < WN - 1; w++)            // fixed order: column quarters 1, 2, 3
+                merge_partial<WANT_LP>(rp, slot[w * 5 + 0], slot[w * 5 + 1], slot[w * 5 + 2], slot[w * 5 + 3], __float_as_int(slot[w * 5 + 4]));
+            if (m < M) {
+                float *p = partials + ((size_t)m * tiles_n + tile_n) * kPartialFloats;
+                p[0] = rp.pmax; p[1] = rp.psum; p[2] = rp.best; p[3] = __int_as_float(rp.best_col); p[4] = rp.best_z; p[5] = 0.f;
+            }
+        }
+    }
+}
+
 template <int NOPS, bool WANT_LP, bool JAX = false>
 __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const uint16_t *__restrict__ A0, const uint16_t *__restrict__ W0,
                                                              const uint16_t *__restrict__ A1, const uint16_t *__restrict__ W1,
@@ -142,85 +239,67 @@ __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const
         }
     }
 
-    // ---- sampling epilogue: every wave first reduces ALL its rows (FM partials per lane, lane groups merged by shuffles), then ONE
-    // exchange through LDS merges the WN column quarters — two barriers per tile instead of two per 16-row fragment
-    const uint32_t epoch = sp.epoch ? *sp.epoch : 0u;
-    RowPartial rps[FM];
+    int st_pre[FM];
 #pragma unroll
     for (int j = 0; j < FM; j++) {
         const int m = m0 + wm * TM + j * 16 + lr;
-        const int st = (steer_tok && m < M) ? steer_tok[m] : -1;
-        RowPartial rp{-INFINITY, 0.f, -INFINITY, 0.f, 0x7fffffff};
-        float vv[FN][4];
-#pragma unroll
-        for (int i = 0; i < FN; i++) {
-            const int n = n0 + wn * TN + i * 16 + lq * 4;
-            uint32_t rnd[4] = {0, 0, 0, 0};
-            if (!JAX && !sp.greedy) philox4x32_10((uint32_t)m, (uint32_t)(n >> 2), sp.step, epoch, sp.seed_lo, sp.seed_hi, rnd);
-            float zz[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = z[i][j][r];
-                if (NOPS > 1) v += sp.beta * qmin[i][j][r];   // generation.py:112-117
-                if (n + r == st) v += sp.steer_strength;
-                zz[r] = v;
-            }
-            if (logits_out && m < M) *reinterpret_cast<f32x4 *>(logits_out + (size_t)m * ldo + n) = f32x4{zz[0], zz[1], zz[2], zz[3]};
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const bool colok = (n + r) < sp.vocab;
-                float v, sc;
-                if (JAX) {      // jax.random.categorical(key, logits / T): key = (seed_hi, seed_lo), word index = row * V + column
-                    v = colok ? zz[r] / sp.temperature : -INFINITY;
-                    sc = (sp.greedy || !colok || m >= M) ? v : v + gumbel_jax(sp.seed_hi, sp.seed_lo, (uint32_t)m * (uint32_t)sp.vocab + (uint32_t)(n + r), sp.jax_n);
-                } else {
-                    v = colok ? zz[r] * sp.inv_temperature : -INFINITY;
-                    sc = sp.greedy ? v : v + gumbel_from_bits(rnd[r]);
-                }
-                const bool take = sc > rp.best;                 // a padding column scores -inf and never wins; selects, not branches
-                rp.best = take ? sc : rp.best; rp.best_col = take ? n + r : rp.best_col; rp.best_z = take ? v : rp.best_z;
-                vv[i][r] = v;
-                if (WANT_LP) rp.pmax = fmaxf(rp.pmax, v);
-            }
-        }
-        // this lane's 4*FN logits: one exp each against the lane maximum (padding columns are -inf -> exp = 0)
-        if (WANT_LP && rp.pmax > -INFINITY) {
-#pragma unroll
-            for (int i = 0; i < FN; i++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) rp.psum += __expf(vv[i][r] - rp.pmax);
-        }
-        // merge the 4 lane groups (lq) that hold the same row: xor 16, 32
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1)
-            merge_partial<WANT_LP>(rp, __shfl_xor(rp.pmax, o), __shfl_xor(rp.psum, o), __shfl_xor(rp.best, o), __shfl_xor(rp.best_z, o),
-                                   __shfl_xor(rp.best_col, o));
-        rps[j] = rp;
+        st_pre[j] = (steer_tok && m < M) ? steer_tok[m] : -1;
     }
-    __syncthreads();                                   // the LDS ring is free: reuse it for the column-quarter hand-off
-    float *xch = reinterpret_cast<float *>(smem);      // [WM][TM rows][WN - 1][5]
-    if (wn > 0 && lq == 0) {
-#pragma unroll
-        for (int j = 0; j < FM; j++) {
-            float *sl = xch + ((((size_t)wm * TM + j * 16 + lr) * (WN - 1)) + (wn - 1)) * 5;
-            sl[0] = rps[j].pmax; sl[1] = rps[j].psum; sl[2] = rps[j].best; sl[3] = rps[j].best_z; sl[4] = __int_as_float(rps[j].best_col);
-        }
-    }
-    __syncthreads();
-    if (wn == 0 && lq == 0) {
+    lm_sample_epilogue<NOPS, WANT_LP, JAX, false>(z, qmin, st_pre, m0, n0, tile_n, tiles_n, M, partials, logits_out, ldo, sp, reinterpret_cast<float *>(smem));
+}
+
+// ---- persistent form of the policy-only LM head (NOPS = 1, Philox / greedy): the first `n_persist` workgroups (two per CU) each walk `rounds` tile ids of
+// the XCD map — b, b + n_persist, ... (the stride is a multiple of 8: a workgroup stays on its XCD's vocabulary slice and on ONE m-tile) — with the LDS ring
+// running ahead into the next tile while the current tile's sampling epilogue executes (g8_stream_tile): a 128 x 128 tile with K = 768 is only 12 K-steps, and
+// in the one-tile-per-workgroup kernel every tile starts behind a cold ring prologue.  The ids beyond rounds * n_persist (128 of 3200 at the bench shape) are
+// one-tile workgroups at the END of the grid: the dispatcher starts them as the persistent ones retire, so the remainder spreads over the whole chip instead
+// of giving a quarter of the workgroups a seventh tile.  (A dynamic work list — per-XCD heads pulled with returning atomics, stealing across XCDs — was built
+// and measured: 168 us against 138 us for this static form, back to back: the pulls' round trips under a streaming load cost more than the balance buys.)
+// Same arithmetic per tile, same association orders: bit-identical partials to the one-tile kernel (tests/test_gpu_timed_path.py).
+// LDS: 2 x 32 KB ring + 7.7 KB hand-off area = 2 workgroups per CU.
+template <bool WANT_LP>
+__global__ __launch_bounds__(kLmWM *kLmWN * 64, 4) void lm_head_sample_persist_kernel(const uint16_t *__restrict__ A0, const uint16_t *__restrict__ W0,
+                                                                                      const int32_t *__restrict__ steer_tok, float *__restrict__ partials,
+                                                                                      float *__restrict__ logits_out, int M, int N, int K, int ldo,
+                                                                                      SampleParams sp, XcdMap xm, int n_persist, int rounds) {
+    constexpr int BM = kLmBM, BN = kLmBN, WM = kLmWM, WN = kLmWN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    typedef G8Stream<BM, BN, WM, WN> Stream;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xch = reinterpret_cast<float *>(smem + 2 * Stream::STAGE);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN;
+    const int lr = lane & 15;
+    const int tiles_n = N / BN;
+    // this workgroup's ids: [first, first + stride, ...), `count` of them (workgroup-uniform)
+    const bool tail = (int)blockIdx.x >= n_persist;
+    const int stride = n_persist, count = tail ? 1 : rounds;
+    const int first = tail ? rounds * n_persist + ((int)blockIdx.x - n_persist) : (int)blockIdx.x;
+    int k = 0, tile_m = 0, tile_n = 0;
+    while (k < count && !xcd_tile(xm, first + k * stride, tile_m, tile_n)) k++;       // surplus ids of the XCD map fall outside the problem
+    if (k >= count) return;
+    const Stream st{A0, W0, K, K, M};
+    st.issue(tile_m * BM, tile_n * BN, 0, 0, smem);
+    st.issue(tile_m * BM, tile_n * BN, 1, 1, smem);
+    while (true) {
+        const int m0 = tile_m * BM, n0 = tile_n * BN, this_tile_n = tile_n;
+        int nk_ = k + 1, ntm = 0, ntn = 0;
+        while (nk_ < count && !xcd_tile(xm, first + nk_ * stride, ntm, ntn)) nk_++;
+        const bool has_next = nk_ < count;
+        int st_pre[FM];                                                // issued before the K loop: retired by its first wait, never behind the next tile's DMA
 #pragma unroll
         for (int j = 0; j < FM; j++) {
             const int m = m0 + wm * TM + j * 16 + lr;
-            const float *slot = xch + (((size_t)wm * TM + j * 16 + lr) * (WN - 1)) * 5;
-            RowPartial rp = rps[j];
-#pragma unroll
-            for (int w = 0; w < WN - 1; w++)            // fixed order: column quarters 1, 2, 3
-                merge_partial<WANT_LP>(rp, slot[w * 5 + 0], slot[w * 5 + 1], slot[w * 5 + 2], slot[w * 5 + 3], __float_as_int(slot[w * 5 + 4]));
-            if (m < M) {
-                float *p = partials + ((size_t)m * tiles_n + tile_n) * kPartialFloats;
-                p[0] = rp.pmax; p[1] = rp.psum; p[2] = rp.best; p[3] = __int_as_float(rp.best_col); p[4] = rp.best_z; p[5] = 0.f;
-            }
+            st_pre[j] = (steer_tok && m < M) ? steer_tok[m] : -1;
         }
+        f32x4 z[FN][FM];
+#pragma unroll
+        for (int i = 0; i < FN; i++)
+#pragma unroll
+            for (int j = 0; j < FM; j++) z[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        g8_stream_tile<BM, BN, WM, WN>(st, m0, n0, has_next, ntm * BM, ntn * BN, K, smem, z);
+        lm_sample_epilogue<1, WANT_LP, false, true>(z, z, st_pre, m0, n0, this_tile_n, tiles_n, M, partials, logits_out, ldo, sp, xch);
+        if (!has_next) break;
+        k = nk_; tile_m = ntm; tile_n = ntn;
     }
 }
 
@@ -494,7 +573,26 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     hipLaunchKernelGGL((lm_head_sample_kernel<NOPS_, LP_, JAX_>), dim3(tiles), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, \
                        q_b2_d, steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm)
     const bool lp = logprob_d != nullptr;      // the log-sum-exp (one exp per logit) is computed only when the log-prob is wanted
-    if (sp.rng == LMRL_RNG_JAX && !sp.greedy) {       // parity mode: always with the log-sum-exp variant (one instantiation per operand count)
+    // policy-only sampling on the Philox / greedy path: the persistent kernel (ring running ahead across tiles); needs K / 64 even and enough tiles
+    // to give every one of the 512 resident workgroups at least two.  g_gemm_variant 301 (tools) forces the one-tile-per-workgroup kernel for the A/B.
+    const bool persist = nops == 1 && !(sp.rng == LMRL_RNG_JAX && !sp.greedy) && (d_model / 64) % 2 == 0 && d_model >= 128 && tiles >= 1024 &&
+                         g_gemm_variant != 301;
+    if (persist) {
+        const int grid = 512;                                          // 2 workgroups per CU x 256 CUs (a multiple of 8: XCD affinity preserved)
+        const size_t shp = shmem + (size_t)kLmWM * (kLmBM / kLmWM) * (kLmWN - 1) * 5 * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp));
+            LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp));
+            attr_set = true;
+        }
+        const int rounds = tiles / grid, n_tail = tiles - rounds * grid;          // ids: xcd_grid(xm) (a multiple of 8), a few of them surplus
+        if (lp) hipLaunchKernelGGL((lm_head_sample_persist_kernel<true>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,
+                                   logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm, grid, rounds);
+        else hipLaunchKernelGGL((lm_head_sample_persist_kernel<false>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,
+                                logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm, grid, rounds);
+    }
+    else if (sp.rng == LMRL_RNG_JAX && !sp.greedy) {       // parity mode: always with the log-sum-exp variant (one instantiation per operand count)
         if (nops == 1) LMRL_LM_LAUNCH(1, true, true); else if (nops == 2) LMRL_LM_LAUNCH(2, true, true); else LMRL_LM_LAUNCH(3, true, true);
     }
     else if (nops == 1) { if (lp) LMRL_LM_LAUNCH(1, true, false); else LMRL_LM_LAUNCH(1, false, false); }

@@ -212,7 +212,7 @@ class KVSessionF32:
             h = self.last_hidden if hidden is None else hidden
             if getattr(self, "_lm_split", None) is None:
                 self._lm_split = torch.empty(self.B * 3 * c.d_model, dtype=torch.bfloat16, device=e.device)
-                self._sample_ws = torch.empty(e._L.lmrl_sample_ws_bytes(self.B, c.vocab_padded), dtype=torch.uint8, device=e.device)
+                self._sample_ws = torch.zeros(e._L.lmrl_sample_ws_bytes(self.B, c.vocab_padded), dtype=torch.uint8, device=e.device)   # zero-filled once (work-list heads)
             _lib.check(e._L.lmrl_split3_bf16(h.data_ptr(), c.d_model, self.B, c.d_model, self._lm_split.data_ptr(), 3 * c.d_model, _lib.stream_ptr()), "lmrl_split3_bf16")
             _lib.check(e._L.lmrl_lm_head_sample(_lib.ptr(self._lm_split), _lib.ptr(e.wte_x3), None, None, None, None, None, None, self.B, 3 * c.d_model, c.vocab,
                                                 c.vocab_padded, ctypes.byref(params), _lib.ptr(steer_tok), _lib.ptr(active), _lib.ptr(self.token),

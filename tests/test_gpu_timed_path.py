@@ -222,3 +222,36 @@ def test_lm_head_sampler_at_bench_shape(small):
     t2 = np.partition(zg, -2, axis=1)[:, -2:]
     ok = (t2[:, 1] - t2[:, 0]) > 1e-3
     assert np.array_equal(tok_g.cpu().numpy()[ok], zg.argmax(1)[ok])
+
+
+def test_persistent_lm_head_equals_one_tile_per_workgroup_kernel(small):
+    """Round 4: the policy-only LM-head sampler runs as a PERSISTENT kernel (512 workgroups walk the tile list, the LDS ring running ahead into the next
+    tile under the current tile's sampling epilogue).  Same per-tile arithmetic and association orders as the one-tile-per-workgroup kernel it replaced
+    (kept as the ILQL / LMRL_RNG_JAX path and reachable through the tools hook `lmrl_gemm_set_variant(301)`): tokens, log-probabilities and materialised
+    logits must be bit-identical, with and without the log-prob variant, sampling and greedy, a ragged row count (M = 1000: a partial last m-tile)."""
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.gpt2 import SampleParams
+    dev, cfg, sd, eng, vocab = small
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    for rows in (B, 1000):
+        ses = eng.session(rows, 8)
+        hid = (torch.randn(rows, cfg.d_model, generator=g) * 2.0).to(torch.bfloat16).to(dev)
+        steer = torch.randint(0, cfg.vocab, (rows,), generator=g).to(torch.int32).to(dev)
+        outs = {}
+        for variant in (0, 301):
+            L.lmrl_gemm_set_variant(variant)
+            try:
+                res = []
+                for T, want_lp, want_logits in ((1.0, True, True), (1.0, False, False), (0.0, True, False)):
+                    lo = torch.zeros(rows, cfg.vocab_padded, device=dev) if want_logits else None
+                    tok, lp = ses.sample(SampleParams(T, 0, 0x1234, 7, 3.0, 0.0, 50256), hidden=hid, logits_out=lo, steer_tok=steer, want_logprob=want_lp)
+                    torch.cuda.synchronize()
+                    res.append((tok.clone(), None if lp is None else lp.clone(), None if lo is None else lo.clone()))
+                outs[variant] = res
+            finally:
+                L.lmrl_gemm_set_variant(0)
+        for a, b in zip(outs[0], outs[301]):
+            assert torch.equal(a[0], b[0])
+            assert (a[1] is None and b[1] is None) or torch.equal(a[1], b[1])
+            assert (a[2] is None and b[2] is None) or torch.equal(a[2], b[2])
