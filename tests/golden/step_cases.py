@@ -149,3 +149,18 @@ def perturbed(sd, seed: int, eps: float = 0.03):
     """A nearby parameter set (the policy a few updates after `sd`): every tensor + eps * std * noise."""
     r = np.random.RandomState(seed)
     return {k: (v + eps * max(float(v.std()), 1e-3) * r.randn(*v.shape)).astype(np.float32) for k, v in sd.items()}
+
+
+def direction(seed: int, params: dict) -> dict:
+    """A seeded direction in parameter space for the directional-derivative fixtures (rl_step_grads.json): per tensor, unit-variance noise scaled by the
+    tensor's RMS (0.05 where the tensor is ~0), walked in sorted key order.  `params`: FLAT {name: array}."""
+    r = np.random.RandomState(seed)
+    out = {}
+    for k in sorted(params):
+        v = np.asarray(params[k], dtype=np.float64)
+        rms = float(np.sqrt((v * v).mean()))
+        out[k] = r.randn(*v.shape) * (rms if rms > 1e-3 else 0.05)
+    return out
+
+
+GRAD_DIRECTION_SEEDS = (1001, 1002, 1003)

@@ -195,3 +195,77 @@ def test_ppo_data_pipeline_equals_reference_function():
         np.testing.assert_allclose(d.old_values, e["old_values"], rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(d.old_returns, e["old_returns"], rtol=2e-4, atol=2e-4)
         np.testing.assert_allclose(d.old_advantages, e["old_advantages"], rtol=2e-3, atol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# DEVICE GRADIENTS against the reference's own closures: tests/golden/rl_step_grads.json = <dL/dtheta, v> by complex-step
+# differentiation through the reference's `_step` code (tests/golden/make_step_grad_fixtures.py).  Tolerance: 3e-4 of sum |g_i v_i| (fp32 device;
+# the float64 restatement agrees with the fixture to 1e-9: tests/test_oracle_steps_pinned.py).
+def _check_directions(case_name, grads: dict, params: dict):
+    fx = load_golden("rl_step_grads.json")
+    for dseed, ref in zip(fx["direction_seeds"], fx[case_name]["ddir"]):
+        v = C.direction(dseed, params)
+        got = sum(float((grads[k].double().cpu().numpy() * v[k]).sum()) for k in v)
+        scale = sum(float(np.abs(grads[k].double().cpu().numpy() * v[k]).sum()) for k in v)
+        assert abs(got - ref) <= 3e-4 * scale, (case_name, dseed, got, ref, scale)
+
+
+@pytest.mark.parametrize("case", C.ILQL_CASES, ids=[c["name"] for c in C.ILQL_CASES])
+def test_ilql_step_gradients_equal_reference_complex_step(case):
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.algorithms import ilql
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, MLPHeadF32
+    dev = _lib.require_gpu()
+    V = C.CFG["vocab"]
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    sd_np = C.state_dict(10 + case["seed"])
+    heads_np = [C.flat_head(C.mlp_head(s + case["seed"], o)) for s, o in ((30, V), (40, V), (50, 1), (60, V), (70, V))]
+    base = GPT2F32({k: t(v) for k, v in sd_np.items()}, C.CFG["n_head"], device=dev)
+    tbase = GPT2F32({k: t(v) for k, v in C.state_dict(20 + case["seed"]).items()}, C.CFG["n_head"], device=dev) if case["target_base"] else None
+    hp = [{k: t(v) for k, v in h.items()} for h in heads_np]
+    tr = ilql.GPT2ILQLTrain(base, MLPHeadF32(hp[0], dev), MLPHeadF32(hp[1], dev), MLPHeadF32(hp[2], dev), C.PAD, C.LOSS_KW, target_base=tbase, lr=1e-4,
+                            polyak_alpha=case["polyak_alpha"], hard_update_every=case["hard_update_every"])
+    tr.q1_target, tr.q2_target = MLPHeadF32(hp[3], dev), MLPHeadF32(hp[4], dev)
+    b = C.ilql_batch(case["seed"])
+    kw = dict(next_token_ids=b["next_token_ids"], next_dones=b["next_dones"]) if case["use_next"] else {}
+    tr.step(b["input_ids"], b["should_take_action"], b["rewards"], b["dones"], **kw)
+    bg, g1, g2, gv = tr.last_grads
+    grads = {"base." + k: bg[k] for k in sd_np}
+    params = {"base." + k: v for k, v in sd_np.items()}
+    for n, g, h in (("q1", g1, heads_np[0]), ("q2", g2, heads_np[1]), ("v", gv, heads_np[2])):
+        grads.update({f"{n}.{k}": g[k] for k in h})
+        params.update({f"{n}.{k}": v for k, v in h.items()})
+    _check_directions(case["name"], grads, params)
+
+
+def test_ppo_and_mc_step_gradients_equal_reference_complex_step():
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.algorithms import mc_returns as mc, ppo
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32, MLPHeadF32
+    dev = _lib.require_gpu()
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    case = C.PPO_CASES[0]
+    sd_np, vh = C.state_dict(80 + case["seed"]), C.flat_head(C.linear_head(90 + case["seed"]))
+    pol = GPT2F32({k: t(v) for k, v in sd_np.items()}, C.CFG["n_head"], device=dev)
+    head = LinearHeadF32(dict(kernel=t(vh["dense.kernel"]), bias=t(vh["dense.bias"])), dev)
+    tr = ppo.GPT2PPOTrain(pol, head, C.PAD, C.PPO_KW, lr=1e-5)
+    b = C.ppo_batch(case["seed"])
+    tr.step(b["input_ids"], b["should_take_action"], b["old_logprobs"], b["old_values"], b["old_advantages"], b["old_returns"])
+    pg, hg = tr.last_grads
+    grads = {"base." + k: pg[k] for k in sd_np}
+    grads.update({"head.dense.kernel": hg["kernel"], "head.dense.bias": hg["bias"]})
+    params = {"base." + k: v for k, v in sd_np.items()}
+    params.update({"head." + k: v for k, v in vh.items()})
+    _check_directions(case["name"], grads, params)
+    case = C.MC_CASE
+    sd_np, qh = C.state_dict(110 + case["seed"]), C.flat_head(C.mlp_head(120 + case["seed"], C.CFG["vocab"]))
+    base = GPT2F32({k: t(v) for k, v in sd_np.items()}, C.CFG["n_head"], device=dev)
+    trm = mc.GPT2MCTrain(base, MLPHeadF32({k: t(v) for k, v in qh.items()}, dev), C.PAD, dict(cql_weight=case["cql_weight"]), lr=1e-4)
+    b = C.mc_batch(case["seed"])
+    trm.step(b["input_ids"], b["should_take_action"], b["returns"])
+    bg, qg = trm.last_grads
+    grads = {"base." + k: bg[k] for k in sd_np}
+    grads.update({"head." + k: qg[k] for k in qh})
+    params = {"base." + k: v for k, v in sd_np.items()}
+    params.update({"head." + k: v for k, v in qh.items()})
+    _check_directions(case["name"], grads, params)

@@ -192,3 +192,58 @@ def test_oracle_ppo_data_pipeline_equals_reference_function():
             for name in ("old_logprobs", "old_values", "old_advantages", "old_returns"):
                 np.testing.assert_allclose(r[name][sl], d[name], rtol=3e-5, atol=3e-5, err_msg=name)
     assert k == len(fx["datas"])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# GRADIENTS pinned to the reference: tests/golden/rl_step_grads.json holds <dL/dtheta, v> of the reference's own `_step`
+# closures, obtained by complex-step differentiation THROUGH THE REFERENCE'S CODE (stop_gradient drops the imaginary part; generator
+# tests/golden/make_step_grad_fixtures.py).  Here: float64 autograd of the restatement, contracted with the same seeded directions.
+def _dot(grads: dict, v: dict) -> float:
+    return float(sum((np.asarray(grads[k], dtype=np.float64) * v[k]).sum() for k in v))
+
+
+def _oracle_ilql_grads(case):
+    t = lambda a: torch.from_numpy(np.asarray(a)).double()
+    V = C.CFG["vocab"]
+    sd = {k: t(v).requires_grad_(True) for k, v in C.state_dict(10 + case["seed"]).items()}
+    tsd = {k: t(v) for k, v in C.state_dict(20 + case["seed"]).items()} if case["target_base"] else {k: v.detach() for k, v in sd.items()}
+    names = (("q1", 30, V), ("q2", 40, V), ("v", 50, 1))
+    heads = {n: {k: t(x).requires_grad_(True) for k, x in C.flat_head(C.mlp_head(s + case["seed"], o)).items()} for n, s, o in names}
+    tq = [{k: t(x) for k, x in C.flat_head(C.mlp_head(s + case["seed"], V)).items()} for s in (60, 70)]
+    mh = lambda x, h: rl.mlp_head(x, h["dense1.kernel"], h["dense1.bias"], h["dense2.kernel"], h["dense2.bias"])
+    b = C.ilql_batch(case["seed"])
+    ti = lambda a: torch.from_numpy(np.asarray(a))
+    ids, am, pos = ti(b["input_ids"]).long(), ti(b["attention_mask"]), ti(b["position_ids"]).long()
+    _, hid = O.forward(sd, ids, C.CFG["n_head"], attention_mask=am, position_ids=pos, return_hidden=True)
+    with torch.no_grad():
+        _, thid = O.forward(tsd, ids, C.CFG["n_head"], attention_mask=am, position_ids=pos, return_hidden=True)
+        tq1o, tq2o = mh(thid, tq[0]), mh(thid, tq[1])
+    q1o, q2o, vo = mh(hid, heads["q1"]), mh(hid, heads["q2"]), mh(hid, heads["v"])
+    nxt = {}
+    if case["use_next"]:
+        nam = ti(b["next_tokens_attention_mask"])
+        _, nhid = O.forward(sd, ti(b["next_token_ids"]).long(), C.CFG["n_head"], attention_mask=nam, position_ids=ti(b["next_tokens_position_ids"]).long(),
+                            return_hidden=True)
+        nxt = dict(next_v_head_out=mh(nhid, heads["v"]), next_attention_mask=nam, next_dones=ti(b["next_dones"]))
+    sta = ti(b["should_take_action"])
+    q1, q2, v, v_final, tq1, tq2 = rl.ilql_gather_qv(q1o, q2o, vo, tq1o, tq2o, ids, am, sta, ti(b["dones"]), **nxt)
+    loss, _ = rl.ilql_loss(q1, q2, v, v_final, tq1, tq2, q1o[:, :-1], q2o[:, :-1], ids[:, 1:], am[:, 1:].double(), sta, ti(b["rewards"]).double(), **C.LOSS_KW)
+    loss.backward()
+    g = {"base." + k: p.grad.numpy() for k, p in sd.items()}
+    flat = {"base." + k: p.detach().numpy() for k, p in sd.items()}
+    for n, h in heads.items():
+        g.update({f"{n}.{k}": p.grad.numpy() for k, p in h.items()})
+        flat.update({f"{n}.{k}": p.detach().numpy() for k, p in h.items()})
+    return float(loss), g, flat
+
+
+@pytest.mark.parametrize("case", C.ILQL_CASES, ids=[c["name"] for c in C.ILQL_CASES])
+def test_oracle_ilql_gradients_equal_reference_complex_step(case):
+    fx = load_golden("rl_step_grads.json")
+    loss, g, flat = _oracle_ilql_grads(case)
+    assert abs(loss - fx[case["name"]]["loss"]) <= 1e-9 * abs(loss)
+    for dseed, ref in zip(fx["direction_seeds"], fx[case["name"]]["ddir"]):
+        v = C.direction(dseed, flat)
+        got = _dot(g, v)
+        scale = sum(float(np.abs(np.asarray(g[k]) * v[k]).sum()) for k in v)          # no cancellation hiding: relative to sum |g_i v_i|
+        assert abs(got - ref) <= 1e-9 * scale, (case["name"], dseed, got, ref)
