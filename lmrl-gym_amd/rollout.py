@@ -415,12 +415,18 @@ class WordleRolloutEngine:
                     interaction_callback(ep)
         # episode batches are pipelined: batch k's record is copied to pinned host memory behind its kernels, batch k + 1 is enqueued, and only
         # then the host turns batch k into InteractionTransition lists — the Python work overlaps the device work of the next batch
+        # the env seeds of ALL batches are drawn (in the reference's order: one per rollout) and uploaded once: a per-batch host -> device copy of a
+        # pageable array waits for the stream, i.e. for the batch in flight, and the next replay could not be enqueued under it
+        n_batches = -(-n_rollouts // self.B)
+        seeds_all = np.zeros((n_batches, self.B), dtype=np.uint64)
+        for k in range(n_batches):
+            n_k = min(n_rollouts - k * self.B, self.B)
+            seeds_all[k, :n_k] = [next(seed_generator) for _ in range(n_k)] if seed_generator is not None else np.random.randint(0, 2 ** 31 - 1, size=n_k)
+        seeds_dev = None
         batch_id, launched, pending = 0, 0, None
         while launched < n_rollouts:
             actual = min(n_rollouts - launched, self.B)
-            seeds = np.zeros(self.B, dtype=np.uint64)
-            seeds[:actual] = [next(seed_generator) for _ in range(actual)] if seed_generator is not None else \
-                np.random.randint(0, 2 ** 31 - 1, size=actual)
+            seeds = seeds_all[batch_id]
             g = scripted_guesses_fn(batch_id) if scripted_guesses_fn is not None else None
             key = (float(temperature), int(sample_seed), float(steer_strength), g is not None)
             graph_ok = top_k == 0 and self.vses is None
@@ -432,8 +438,10 @@ class WordleRolloutEngine:
                 if getattr(self, "_eval_graph_key", None) != key:
                     self.capture_episode(temperature=temperature, sample_seed=sample_seed, steer_strength=steer_strength, scripted=g is not None)
                     self._eval_graph_key = key
-                import torch
-                self.replay_episode(torch.from_numpy(seeds.view(np.int64)).to(self.dev), g)
+                if seeds_dev is None:
+                    import torch
+                    seeds_dev = torch.from_numpy(seeds_all.view(np.int64)).to(self.dev)
+                self.replay_episode(seeds_dev[batch_id], g)
             else:
                 self.run_episode(seeds, temperature=temperature, top_k=top_k, sample_seed=sample_seed + (self.episodes << 20), scripted_guesses=g,
                                  steer_strength=steer_strength)
