@@ -272,4 +272,19 @@ def test_ilql_value_policy_on_the_device_engine(setup):
                 assert int(top2.indices[0]) == int(tok[i]), (i, int(top2.indices[0]), int(tok[i]))
                 checked += 1
     assert checked >= 20, checked
+    # the value base's forwards run on a second HIP stream (fork / join per forward): same records as the single-stream order, sampled and under graph replay
+    snaps = {}
+    for dual in (True, False):
+        ro.dual_stream = dual
+        ro.sample_step = 0
+        ro.run_episode(np.arange(B, dtype=np.uint64) + 50, temperature=1.0, sample_seed=9, n_turns=3)
+        torch.cuda.synchronize()
+        snaps[dual] = {k: ro.traj[k].clone() for k in ("tokens", "is_action", "reward", "n_tok", "n_steps")}
+    for k in snaps[True]:
+        assert torch.equal(snaps[True][k], snaps[False][k]), k
+    ro.dual_stream = True
+    ro.capture_episode(temperature=1.0, sample_seed=9, n_turns=3)
+    ro.replay_episode(torch.arange(B, dtype=torch.int64, device=dev) + 50)
+    torch.cuda.synchronize()
+    assert int(ro.traj["n_steps"].sum()) >= B
     ro.close()
