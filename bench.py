@@ -548,6 +548,18 @@ def main():
                    note="rank 0: WordleRolloutEngine.text_env_eval(n_rollouts = 4 x B) end to end — device episodes (hipGraph replays) + host lists of "
                         "InteractionTransition + summary dict, host materialisation of batch k overlapped with the device work of batch k + 1")
         del inter_all
+        # three episode batches in flight (concurrent=3: twin engines — own KV cache, env state, graph — on their own HIP streams over the same
+        # weights): each batch is still one lock-step batch of B envs; the dependent launch chains fill each other's gaps on the 256 CUs
+        n_b2 = 12
+        ro.text_env_eval(3 * B, seed_generator=gen_seeds, concurrent=3, **kwf)      # warm: twin engines, their graphs, pinned buffers
+        torch.cuda.synchronize(); th = time.perf_counter()
+        inter_all, _summary = ro.text_env_eval(n_b2 * B, seed_generator=gen_seeds, concurrent=3, **kwf)
+        tev2_s = time.perf_counter() - th
+        tev["three_batches_in_flight"] = dict(value=round(sum(len(ep) for ep in inter_all) / tev2_s, 1), unit="env-steps/s", episode_batches=n_b2,
+                                            ms_per_batch=round(tev2_s * 1e3 / n_b2, 2),
+                                            note="text_env_eval(n_rollouts = 12 x B, concurrent=3): batches k .. k + 2 run at once on three HIP streams "
+                                                 "(3 x B envs in flight; the headline `value` stays one batch of B); tools/bench_text_env_eval_lanes.py: 1 / 2 / 3 lanes")
+        del inter_all
 
     ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
 

@@ -158,6 +158,9 @@ class WordleRolloutEngine:
         import torch
         t = torch
         self.eng, self.vocab, self.B = engine, vocab, batch
+        self._twin_args = dict(tokens=tokens, max_new_tokens=max_new_tokens, require_words_in_vocab=require_words_in_vocab,
+                               bad_word_reward=bad_word_reward, traj_cap=traj_cap, share_header=share_header)
+        self._lanes = None           # text_env_eval(concurrent=n): [(engine, stream)], this engine first
         self.episodes = 0            # eager episodes run by text_env_eval over this engine's life: part of the sampler stream key
         self.tokens = tokens or WordleTokenTable.default_gpt2(pad=engine.cfg.vocab - 1)
         self.max_new, self.cap = max_new_tokens, traj_cap
@@ -202,6 +205,9 @@ class WordleRolloutEngine:
             self._L.lmrl_wordle_tok_destroy(self._tok)
             self._tok = None
         self.env.close()
+        for twin, _ in (self._lanes or [])[1:]:
+            twin.close()
+        self._lanes = None
 
     def _ck(self, rc, what):
         _lib.check(rc, what)
@@ -416,8 +422,23 @@ class WordleRolloutEngine:
             out.append(trans)
         return out
 
+    def _eval_lanes(self, n: int, main):
+        """[(engine, stream)] for `text_env_eval(concurrent=n)`: this engine on the caller's stream + n - 1 twins (same model, vocabulary, batch and
+        record layout; own sessions / env state / records) on their own streams.  Built once and kept."""
+        import torch
+        assert self.vses is None, "concurrent lanes are for the plain sampling policy"
+        if self._lanes is None:
+            self._lanes = [(self, None)]
+        while len(self._lanes) < n:
+            st = torch.cuda.Stream(device=self.dev)
+            with torch.cuda.stream(st):
+                twin = WordleRolloutEngine(self.eng, self.vocab, self.B, **dict(self._twin_args, tokens=self.tokens))
+            self._lanes.append((twin, st))
+        return [(self, main)] + self._lanes[1:n]
+
     def text_env_eval(self, n_rollouts: int, seed_generator=None, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0,
-                      interaction_callback=None, decode=None, scripted_guesses_fn=None, steer_strength: float = 0.0, use_graph: Optional[bool] = None):
+                      interaction_callback=None, decode=None, scripted_guesses_fn=None, steer_strength: float = 0.0, use_graph: Optional[bool] = None,
+                      concurrent: int = 1):
         """`text_env_eval(env, policy, n_rollouts, bsize=B)` (LLM_RL/environment.py:211-267) with env, policy and the whole
         lock-step loop on the device: ceil(n / B) episodes batches, the same (interactions, summary) return value.
         use_graph (plain sampling only): the episode is captured into a hipGraph once per (temperature, sample_seed, steering) and replayed per
@@ -426,11 +447,17 @@ class WordleRolloutEngine:
         or the call runs >= 4 batches; True / False force it.  The two paths draw DIFFERENT noise for the same `sample_seed`: the graph's
         stream is keyed by (sample_seed, replay epoch), the eager one by (sample_seed + (episode counter << 20)) — the counter runs across calls
         (`self.episodes`), so neither repeats noise between calls; both are reproducible for a fixed call history.
+        concurrent = n > 1 (graph path, >= 2 batches): n episode batches in flight at once, each a full lock-step batch of B envs with its own
+        KV cache, env state and graph on its own HIP stream over the SAME weights (`_eval_lanes`).  One lock-step batch is a dependent chain of
+        ~3400 launches, many of them too small to fill 256 CUs; two independent chains fill each other's gaps.  Batches are independent in the
+        reference too (a fresh env reset + its own generate calls per batch), and the interactions come back in batch order.
         `scripted_guesses_fn(batch_id) -> int32 device tensor [n_turns][B]` + `steer_strength`: synthetic workloads (bench.py)."""
+        import torch
+        from collections import deque
         inter, rewards, dones, lengths = [], [], [], []
 
-        def absorb(handle, actual):
-            for ep in self._build_interactions(handle, decode)[:actual]:
+        def absorb(eng, handle, actual):
+            for ep in eng._build_interactions(handle, decode)[:actual]:
                 inter.append(ep)
                 rewards.append(sum(t.reward for t in ep)); dones.append(ep[-1].done); lengths.append(len(ep))
                 if interaction_callback is not None:
@@ -444,38 +471,52 @@ class WordleRolloutEngine:
         for k in range(n_batches):
             n_k = min(n_rollouts - k * self.B, self.B)
             seeds_all[k, :n_k] = [next(seed_generator) for _ in range(n_k)] if seed_generator is not None else np.random.randint(0, 2 ** 31 - 1, size=n_k)
+        scripted = scripted_guesses_fn is not None
+        key = (float(temperature), int(sample_seed), float(steer_strength), scripted)
+        graph_ok = top_k == 0 and self.vses is None
+        if use_graph is None:
+            want_graph = graph_ok and (getattr(self, "_eval_graph_key", None) == key or n_batches >= 4)
+        else:
+            want_graph = bool(use_graph) and graph_ok
+        main = torch.cuda.current_stream(self.dev)
+        lanes = [(self, main)]
+        if concurrent > 1 and want_graph and n_batches >= 2:
+            lanes = self._eval_lanes(min(int(concurrent), n_batches), main)
         seeds_dev = None
-        batch_id, launched, pending = 0, 0, None
+        if want_graph:
+            seeds_dev = torch.from_numpy(seeds_all.view(np.int64)).to(self.dev)
+            for l, (e, st) in enumerate(lanes):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    if getattr(e, "_eval_graph_key", None) != key:
+                        # lanes draw from different noise streams: the same (seed, epoch) key on two lanes would repeat one batch's noise in the next
+                        e.capture_episode(temperature=temperature, sample_seed=(sample_seed + l * 0x9E3779B97F4A7C15) & (2 ** 64 - 1),
+                                          steer_strength=steer_strength, scripted=scripted)
+                        e._eval_graph_key = key
+        batch_id, launched, pending = 0, 0, deque()
         while launched < n_rollouts:
             actual = min(n_rollouts - launched, self.B)
-            seeds = seeds_all[batch_id]
-            g = scripted_guesses_fn(batch_id) if scripted_guesses_fn is not None else None
-            key = (float(temperature), int(sample_seed), float(steer_strength), g is not None)
-            graph_ok = top_k == 0 and self.vses is None
-            if use_graph is None:
-                want_graph = graph_ok and (getattr(self, "_eval_graph_key", None) == key or -(-n_rollouts // self.B) >= 4)
-            else:
-                want_graph = bool(use_graph) and graph_ok
-            if want_graph:
-                if getattr(self, "_eval_graph_key", None) != key:
-                    self.capture_episode(temperature=temperature, sample_seed=sample_seed, steer_strength=steer_strength, scripted=g is not None)
-                    self._eval_graph_key = key
-                if seeds_dev is None:
-                    import torch
-                    seeds_dev = torch.from_numpy(seeds_all.view(np.int64)).to(self.dev)
-                self.replay_episode(seeds_dev[batch_id], g)
-            else:
-                self.run_episode(seeds, temperature=temperature, top_k=top_k, sample_seed=sample_seed + (self.episodes << 20), scripted_guesses=g,
-                                 steer_strength=steer_strength)
-                self.episodes += 1
+            g = scripted_guesses_fn(batch_id) if scripted else None
+            e, st = lanes[batch_id % len(lanes)]
+            with torch.cuda.stream(st):
+                if g is not None and st is not main:
+                    st.wait_stream(main)            # the caller built g on its stream
+                if want_graph:
+                    e.replay_episode(seeds_dev[batch_id], g)
+                else:
+                    e.run_episode(seeds_all[batch_id], temperature=temperature, top_k=top_k, sample_seed=sample_seed + (self.episodes << 20),
+                                  scripted_guesses=g, steer_strength=steer_strength)
+                    self.episodes += 1
+                handle = e.snapshot_records()
             batch_id += 1
             launched += actual
-            handle = self.snapshot_records()
-            if pending is not None:
-                absorb(*pending)
-            pending = (handle, actual)
-        if pending is not None:
-            absorb(*pending)
+            pending.append((e, handle, actual))
+            while len(pending) > len(lanes):
+                absorb(*pending.popleft())
+        while pending:
+            absorb(*pending.popleft())
+        for _, st in lanes[1:]:
+            main.wait_stream(st)
         summ = lambda x: dict(mean=np.mean(x), std=np.std(x), min=np.min(x), max=np.max(x))
         return inter, dict(reward=summ(np.asarray(rewards, dtype=np.float32)), done=summ(np.asarray(dones, dtype=np.float32)), length=summ(lengths))
 

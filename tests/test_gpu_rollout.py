@@ -227,6 +227,19 @@ def test_device_text_env_eval_matches_reference_protocol(setup):
     inter2, summary = ro.text_env_eval(70, seed_generator=iter(range(1000)), temperature=1.0, sample_seed=4)
     assert len(inter2) == 70 and set(summary) == {"reward", "done", "length"} and set(summary["reward"]) == {"mean", "std", "min", "max"}
     assert all(ep[-1].done for ep in inter2) and summary["length"]["max"] <= 6
+    # two episode batches in flight (twin engine on a second stream): the steered episodes are noise-independent, so the interactions of the
+    # 5 batches must come back identical, and in the same order, as from the one-lane call
+    g_dev = [torch.from_numpy(np.roll(packed, k, axis=1).copy().view(np.int32)).to(dev) for k in range(5)]
+    kw = dict(scripted_guesses_fn=lambda bid: g_dev[bid], steer_strength=200.0, temperature=1.0, sample_seed=2, use_graph=True)
+    one, s1 = ro.text_env_eval(5 * B - 7, seed_generator=iter(range(5000, 9000)), **kw)
+    two, s2 = ro.text_env_eval(5 * B - 7, seed_generator=iter(range(5000, 9000)), concurrent=2, **kw)
+    assert len(ro._lanes) == 2 and len(one) == len(two) == 5 * B - 7
+    assert one == two and s1 == s2
+    again, _ = ro.text_env_eval(5 * B - 7, seed_generator=iter(range(5000, 9000)), concurrent=2, **kw)      # lanes and graphs are reused
+    assert again == one
+    # unsteered, two lanes: different noise per lane (not the same stream twice), every episode still ends within 6 turns
+    free, sf = ro.text_env_eval(4 * B, seed_generator=iter(range(1000)), temperature=1.0, sample_seed=4, use_graph=True, concurrent=2)
+    assert len(free) == 4 * B and all(ep[-1].done for ep in free)
     ro.close()
 
 
