@@ -220,7 +220,7 @@ def cmd_ppo(a):
         if a.device_rollouts:       # env + policy + lock-step loop on the GPU; same (interactions, summary) as text_env_eval
             ro = _device_rollouts(policy.engine, vocab, tok, a.rollout_bsize, a.bad_word_reward, min(a.max_output_length, 12))
             raw, summary = ro.text_env_eval(a.n_rollouts, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)), temperature=a.policy_temperature or 1.0,
-                                            top_k=int(a.policy_top_k or 0), sample_seed=rnd)
+                                            top_k=int(a.policy_top_k or 0), sample_seed=rnd, concurrent=a.rollout_lanes)
             ro.close()
         else:
             raw, summary = E.text_env_eval(env, policy, n_rollouts=a.n_rollouts, bsize=a.rollout_bsize, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)),
@@ -284,7 +284,7 @@ def cmd_filtered_bc(a):
         if a.device_rollouts:
             ro = _device_rollouts(policy.engine, vocab, tok, a.rollout_bsize, a.bad_word_reward, min(a.max_output_length, 12))
             raw, summary = ro.text_env_eval(a.n_rollouts, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)), temperature=a.policy_temperature or 1.0,
-                                            top_k=int(a.policy_top_k or 0), sample_seed=rnd)
+                                            top_k=int(a.policy_top_k or 0), sample_seed=rnd, concurrent=a.rollout_lanes)
             ro.close()
         else:
             raw, summary = E.text_env_eval(env, policy, n_rollouts=a.n_rollouts, bsize=a.rollout_bsize, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)),
@@ -322,7 +322,7 @@ def cmd_bc_eval(a):
     if a.device_rollouts:       # same call, env + policy + loop on the GPU
         ro = _device_rollouts(policy.engine, vocab, tok, a.policy_bsize, -1.0, min(a.policy_max_output_length, 12))
         _, summary = ro.text_env_eval(a.policy_n_rollouts, seed_generator=iter(range(10 ** 9)), temperature=a.policy_temperature or 1.0,
-                                      top_k=int(a.policy_top_k or 0))
+                                      top_k=int(a.policy_top_k or 0), concurrent=a.rollout_lanes)
         ro.close()
     else:
         _, summary = E.text_env_eval(env, policy, n_rollouts=a.policy_n_rollouts, bsize=a.policy_bsize, seed_generator=iter(range(10 ** 9)), verbose=False)
@@ -360,6 +360,8 @@ def build_parser() -> argparse.ArgumentParser:
         p.add_argument("--vocab-file", default="wordle_official_400.txt")
         p.add_argument("--out", default=None)
         p.add_argument("--device-rollouts", type=int, default=0, help="1 = run the Wordle rollouts (bc-eval, ilql evaluation, ppo data collection) on the device-resident engine")
+        p.add_argument("--rollout-lanes", type=int, default=1, help="device rollouts: independent episode batches in flight at once "
+                                                                     "(WordleRolloutEngine.text_env_eval(concurrent=n); >= 4 batches use the graph path)")
         _add(p, defaults)
     sub.choices["ilql"].add_argument("--train-data", required=True)
     sub.choices["ilql"].add_argument("--eval-data", default=None)
