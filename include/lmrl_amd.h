@@ -564,6 +564,9 @@ void lmrl_sgemm_set_variant(int v);
 /* TOOLS / TESTS ONLY: bit 0 = LayerNorm forward, bit 1 = fused LayerNorm backward on the strided 4-byte-access kernels (A/B of the 16-byte-access
  * register-row kernels) */
 void lmrl_train_ops_set_variant(int v);
+/* TOOLS / TESTS ONLY: bit 0 = bf16 flash-attention forward, bit 1 = dQ, bit 2 = dK/dV on the round-3 kernels (A/B and equality tests of the
+ * round-4 sweeps: 128 queries per workgroup, two query groups per wave, global_load_lds tile ring) */
+void lmrl_flash_set_variant(int v);
 int lmrl_embed_fwd(const float *wte_d, const float *wpe_d, const int32_t *ids_d, const int32_t *pos_d, float *x_d, int rows, int d, void *stream);
 int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d, float *dwte_d, float *dwpe_d, int rows, int d, void *stream);
 /* Row compaction for the vocabulary-wide heads of the train steps: the losses read the Q / policy logits only on rows whose mask is set

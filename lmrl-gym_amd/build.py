@@ -30,6 +30,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
          "-ffp-contract=off"]
 
 
+# per-source flags.  flash_attn_train: the sweeps interleave MFMAs with per-element VALU work on their results; with the default AGPR form of the
+# MFMA destination the compiler copies every score through v_accvgpr_read/_write (a quarter of the loop's VALU instructions) — keep C/D in VGPRs
+EXTRA_FLAGS = {"flash_attn_train": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -68,13 +73,13 @@ def build(force: bool = False, verbose: bool = False, tools: bool = False) -> st
         name = os.path.basename(s)[:-4]
         o = os.path.join(OBJ, name + ".o")
         objs.append(o)
-        digests[name] = _sha([s], extra=common)
+        digests[name] = _sha([s], extra=common + " ".join(EXTRA_FLAGS.get(name, [])))
         if force or not os.path.exists(o) or manifest.get(name) != digests[name]:
             jobs.append((s, o))
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s)[:-4], []) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

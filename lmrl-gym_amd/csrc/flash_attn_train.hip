@@ -347,6 +347,202 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const typename E::T *__r
     if (lq == 0) lse[(long)bh * Tp + qi] = (qi < T && l > 0.f) ? m + __logf(l) : INFINITY;
 }
 
+// ------------------------------------------------------------------------------------------ forward, bf16, round 4
+// Same arithmetic and operand layouts as flash_fwd_kernel<ElemBF16>, rebuilt around what tools/pmc_flash.sh and the timing-only ablations of
+// tools/bench_flash_ablate.py showed (the sweep is bound by VALU issue + exposed latencies, not by MFMA rate; profiles/r04_flash_*):
+//   * K / V^T tiles go L2 -> LDS with global_load_lds into a 2-slot ring (the GEMM kernels' lane-linear image + source-side XOR swizzle): the
+//     next block's tiles land while the current block is computed; ONE barrier per key block, no staging registers, no ds_write pass — and
+//     with that 117 VGPRs: four waves per SIMD (the register-staged kernel holds 124 + the MFMA results in AGPRs)
+//   * XCD-aware 1-D grid: all query tiles of one (batch, head) run on ONE XCD, longest sweep first, so its K / V^T enter that L2 once
+//   * key validity as a 64-bit ballot (no LDS bytes, no per-block LDS scan); blocks below the diagonal with all keys valid take a
+//     straight-line path in which all 8 QK^T MFMAs are issued before the first score is read
+//   * exp(s - m) as v_exp_f32(fma(s, log2 e, -m log2 e)); the 4-row max / sum reductions with v_permlane16_swap / v_permlane32_swap
+//     (VALU) instead of ds_bpermute
+//   * K fragments are read from LDS conflict-free: the K tile's chunk swizzle follows the row set one ds_read_b128 lane group touches
+// Measured (B = 32, H = 12, 10 back to back): T = 512 70.7 -> 48.8 us, T = 1024 174.9 -> 135.6 us.  Also measured: two query groups per wave
+// (128-query workgroups, every fragment read feeds two MFMAs) 63 / 189 us at 168 VGPRs = three waves per SIMD — occupancy beats reuse here.
+template <bool KSW>
+__device__ __forceinline__ int flash_swz(int row) {       // chunk XOR of a tile row: V^T (and the GEMM tiles) row & 7; K: see flash_k_frag
+    return KSW ? (((row >> 1) & 1) | (((row >> 3) & 3) << 1)) : (row & 7);
+}
+template <bool KSW, int NW>
+__device__ __forceinline__ void flash_dma_tile(char *dst, const uint16_t *src, long ld, int wave, int lane) {
+    const int lrow = lane >> 3;
+#pragma unroll
+    for (int i = 0; i < 8 / NW; i++) {
+        const int seg = wave + NW * i, row = seg * 8 + lrow;
+        const int src_c = (lane & 7) ^ flash_swz<KSW>(row);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (long)row * ld + src_c * 8),
+                                         (__attribute__((address_space(3))) void *)(dst + seg * 1024), 16, 0, 0);
+    }
+}
+// K fragment: a 16-lane group of ds_read_b128 touches rows {0-3, 24-27} with chunk c and {8-11, 16-19} with chunk c + 1 (slab_row); with the
+// chunk XOR ((row >> 1) & 1) | ((row >> 3) & 3) << 1 its 16 lanes fall on 16 distinct 16-byte bank groups (row & 7 gives 2-way conflicts)
+__device__ __forceinline__ ElemBF16::Frag flash_k_frag(const char *tile, int row, int e0) {
+    ElemBF16::Frag f;
+    f.v = *reinterpret_cast<const bf16x8 *>(tile + row * 128 + (((e0 >> 3) ^ flash_swz<true>(row)) << 4));
+    return f;
+}
+// max / sum over the four 16-lane rows of a wave (the lanes that share lane & 15), all VALU: v_permlane16_swap pairs rows (0,1) and (2,3),
+// v_permlane32_swap the two halves — no LDS round trip (ds_bpermute) on the softmax's critical path
+__device__ __forceinline__ float quad_row_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
+}
+__device__ __forceinline__ float quad_row_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(c[0]) + __uint_as_float(c[1]);
+}
+// one 64-key block for this wave's 16 queries.  MASKED false: every key of the block is valid and at or below every query of the wave
+template <bool MASKED, int ABL>
+__device__ __forceinline__ void flash_fwd2_block(const char *sK, const char *sV, unsigned long long vm, int kb, int qi, const ElemBF16::Frag (&qf)[2],
+                                                 float &m, float &l, f32x4 (&o)[4], int lr, int lq, int ra) {
+    typedef ElemBF16 E;
+    constexpr float LOG2E = 1.4426950408889634f;
+    f32x4 sc[2][2];                 // [32-key slab][half]: this lane's keys slab * 32 + lq * 8 + half * 4 + e of query lr
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                const E::Frag kf = flash_k_frag(sK, p * 32 + ra + 4 * hf, sl * 32 + lq * 8);
+                const f32x4 c = sl == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : sc[p][hf];
+                if (ABL & 1) { sc[p][hf] = c; sc[p][hf][0] += __builtin_bit_cast(f32x4, kf.v)[0] * __builtin_bit_cast(f32x4, qf[sl].v)[0]; }
+                else sc[p][hf] = mma(E(), c, kf, qf[sl]);
+            }
+    if (MASKED) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const unsigned mb = (unsigned)(vm >> (p * 32 + lq * 8)) & 0xffu;          // validity bits of this lane's 8 keys of the slab
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int kk = kb * 64 + p * 32 + lq * 8 + e;
+                const bool ok = (kk <= qi) & (((mb >> e) & 1u) != 0);
+                sc[p][e >> 2][e & 3] = ok ? sc[p][e >> 2][e & 3] : -INFINITY;
+            }
+        }
+    }
+    float mloc = fmaxf(fmaxf(sc[0][0][0], sc[0][0][1]), fmaxf(sc[0][0][2], sc[0][0][3]));
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+            if (p + hf > 0) mloc = fmaxf(mloc, fmaxf(fmaxf(sc[p][hf][0], sc[p][hf][1]), fmaxf(sc[p][hf][2], sc[p][hf][3])));
+    mloc = quad_row_max(mloc);
+    const float m_new = fmaxf(m, mloc);
+    const float m_safe = (MASKED && m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f((m - m_safe) * LOG2E);
+    const float mb2 = -m_safe * LOG2E;
+    float rs = 0.f;
+    E::Frag pf[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        float e8[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float a = __builtin_fmaf(sc[p][e >> 2][e & 3], LOG2E, mb2);
+            e8[e] = (ABL & 2) ? a : __builtin_amdgcn_exp2f(a);
+            rs += e8[e];
+        }
+        pf[p] = make_frag(E(), e8);
+    }
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] *= alpha;
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int db = 0; db < 4; db++) {
+            const E::Frag vf = ld_frag_lds(E(), sV, db * 16 + lr, p * 32 + lq * 8);
+            if (ABL & 4) o[db][0] += __builtin_bit_cast(f32x4, vf.v)[p] * __builtin_bit_cast(f32x4, pf[p].v)[db];
+            else o[db] = mma(E(), o[db], vf, pf[p]);
+        }
+}
+// NW waves per workgroup, 16 queries per wave
+template <int NW, int ABL>
+__global__ __launch_bounds__(64 * NW, 4) void flash_fwd2_bf16_kernel(const uint16_t *__restrict__ Qn, const uint16_t *__restrict__ Kn,
+                                                                     const uint16_t *__restrict__ VT, const uint8_t *__restrict__ km,
+                                                                     float *__restrict__ att, float *__restrict__ lse, int BH, int H, int T, int Tp, int d,
+                                                                     uint16_t *__restrict__ att_b, long ldb) {
+    typedef ElemBF16 E;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SLOT = 2 * E::TILE, QT = 16 * NW;
+    // XCD-aware 1-D grid: workgroup id -> XCD id % 8 (observed placement, as in gemm_bf16.h).  All query tiles of one (batch, head) go to ONE XCD,
+    // consecutively and longest sweep first: its K / V^T (2 x Tp x 128 B) enter that XCD's L2 once and the other tiles' fills hit there,
+    // instead of eight L2s each pulling every head's tiles over the fabric.  Heads beyond the last full group of 8 wrap onto the XCDs in order.
+    const int nq = (Tp + QT - 1) / QT;
+    int bh, qb;
+    {
+        const int id = blockIdx.x, xcd = id & 7, k = id >> 3;          // k-th workgroup of this XCD
+        const int full = (BH / 8) * 8;
+        if (k < (BH / 8) * nq) { bh = (k / nq) * 8 + xcd; qb = nq - 1 - k % nq; }
+        else {                                                         // the BH % 8 remaining heads: their tiles dealt round-robin
+            const int r = (k - (BH / 8) * nq) * 8 + xcd;
+            bh = full + r / nq; qb = nq - 1 - r % nq;
+            if (bh >= BH) return;                                      // workgroup-uniform
+        }
+    }
+    const int b = bh / H, h = bh - b * H;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 15, lq = lane >> 4;
+    const int nkb = min(((qb + 1) * QT + 63) / 64, Tp / 64);      // key blocks of this query tile
+    const uint16_t *Kb = Kn + (long)bh * Tp * 64, *Vb = VT + (long)bh * 64 * Tp;
+    const uint8_t *kmb = km ? km + (long)b * T : nullptr;
+    flash_dma_tile<true, NW>(smem, Kb, 64, wave, lane);
+    flash_dma_tile<false, NW>(smem + E::TILE, Vb, Tp, wave, lane);
+    uint8_t rm = key_valid_fetch(kmb, 0, T);
+    const int q0 = qb * QT + wave * 16, qi = q0 + lr;
+    E::Frag qf[2];
+    {
+        const int qc = qi < Tp ? qi : Tp - 1;
+#pragma unroll
+        for (int s = 0; s < 2; s++) qf[s] = ld_frag_glb(E(), Qn + ((long)bh * Tp + qc) * 64 + s * 32 + lq * 8);
+    }
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ra = slab_row(lr);
+    for (int kb = 0; kb < nkb; kb++) {
+        const char *sK = smem + (kb & 1) * SLOT, *sV = sK + E::TILE;
+        const unsigned long long vm = __ballot(rm != 0);          // key validity of block kb, one bit per key (every wave fetched all 64 bytes)
+        if (!(ABL & 8) || kb == 0) {        // tools, bit 3: no waits, no barriers after the first block
+            wait_vmcnt<0>();
+            __syncthreads();        // block kb's tiles are in LDS; every wave is done with the other slot
+        }
+        if (kb + 1 < nkb && !(ABL & 16)) {  // tools, bit 4: no tile traffic after the first block
+            char *nx = smem + ((kb + 1) & 1) * SLOT;
+            flash_dma_tile<true, NW>(nx, Kb + (long)(kb + 1) * 64 * 64, 64, wave, lane);
+            flash_dma_tile<false, NW>(nx + E::TILE, Vb + (kb + 1) * 64, Tp, wave, lane);
+            rm = key_valid_fetch(kmb, (kb + 1) * 64, T);
+        }
+        // wave-uniform (SGPR) case split
+        if (kb * 64 > q0 + 15) continue;                          // NW = 8: the block lies entirely above this wave's queries
+        if (vm == ~0ull && kb * 64 + 63 <= q0) flash_fwd2_block<false, ABL>(sK, sV, vm, kb, qi, qf, m, l, o, lr, lq, ra);
+        else flash_fwd2_block<true, ABL>(sK, sV, vm, kb, qi, qf, m, l, o, lr, lq, ra);
+    }
+    l = quad_row_sum(l);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    if (qi < T) {
+#pragma unroll
+        for (int db = 0; db < 4; db++) {
+            const f32x4 v = o[db] * inv;
+            *reinterpret_cast<f32x4 *>(att + ((long)b * T + qi) * d + h * 64 + db * 16 + lq * 4) = v;
+            if (att_b) {     // bf16 copy: the operand of the output projection in the bf16-matmul train mode
+                uint2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2 *>(att_b + ((long)b * T + qi) * ldb + h * 64 + db * 16 + lq * 4) = pk;
+            }
+        }
+    }
+    if (lq == 0 && qi < Tp) lse[(long)bh * Tp + qi] = (qi < T && l > 0.f) ? m + __logf(l) : INFINITY;
+}
+
 // ------------------------------------------------------------------------------------------ backward: dQ
 template <class E, bool PF>
 __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const typename E::T *__restrict__ Qn, const typename E::T *__restrict__ Kn,
@@ -582,6 +778,7 @@ template <> struct FlashPrefetch<ElemF32> {
     static constexpr bool fwd = (LMRL_FLASH_PF & 8) != 0, dq = (LMRL_FLASH_PF & 16) != 0, dkv = (LMRL_FLASH_PF & 32) != 0;
 };
 
+int g_flash_variant = 0;        // tools / tests only (lmrl_flash_set_variant): bit 0 = the round-3 forward sweep for bf16 operands
 struct FlashWs {
     char *Qn, *Kn, *Vn, *QT, *KT, *VT, *dOn, *dOT;
     float *D;
@@ -626,6 +823,36 @@ static int flash_fwd(const float *qkv, const uint8_t *km, float *att, float *lse
         int rc = flash_stage_qkv<E>(qkv, w, batch, heads, t, tp, s);
         if (rc) return rc;
     }
+    if constexpr (E::SZ == 2) {
+        if (!(g_flash_variant & 1)) {
+            size_t lds2 = 4 * E::TILE;            // 32 KiB
+            const int nw = (g_flash_variant & 8) ? 4 : 8;                                 // 8-wave workgroups (128 queries); tools: bit 3 = 4 waves (64 queries: 3 % slower)
+            const int nq2 = (tp + 16 * nw - 1) / (16 * nw);
+            const int fwd2_grid = (bh / 8) * nq2 * 8 + ((bh % 8) * nq2 + 7) / 8 * 8;      // whole rounds of the 8 XCDs
+#define LMRL_FWD2(NW_, ABL_)                                                                                                                     \
+    hipLaunchKernelGGL((flash_fwd2_bf16_kernel<NW_, ABL_>), dim3(fwd2_grid), dim3(64 * NW_), lds2, s, (const uint16_t *)w.Qn, (const uint16_t *)w.Kn, \
+                       (const uint16_t *)w.VT, km, att, lse, bh, heads, t, tp, d, (uint16_t *)att_b, ldb)
+#ifdef LMRL_TOOLS           /* timing-only ablations (tools/bench_flash_ablate.py): results are garbage; bits 16-23: extra (unused) LDS per workgroup, KB */
+            lds2 += (size_t)((g_flash_variant >> 16) & 0xff) * 1024;
+            LMRL_CHECK_HIP(allow_lds(flash_fwd2_bf16_kernel<8, 0>, lds2));
+            switch ((g_flash_variant >> 8) & 0xff) {
+                case 1: LMRL_FWD2(8, 1); break;
+                case 2: LMRL_FWD2(8, 2); break;
+                case 4: LMRL_FWD2(8, 4); break;
+                case 7: LMRL_FWD2(8, 7); break;
+                case 8: LMRL_FWD2(8, 8); break;
+                case 24: LMRL_FWD2(8, 24); break;
+                case 31: LMRL_FWD2(8, 31); break;
+                default: if (nw == 8) LMRL_FWD2(8, 0); else LMRL_FWD2(4, 0);
+            }
+#else
+            if (nw == 8) LMRL_FWD2(8, 0); else LMRL_FWD2(4, 0);
+#endif
+#undef LMRL_FWD2
+            LMRL_CHECK_LAUNCH();
+            return LMRL_OK;
+        }
+    }
     const size_t lds = 2 * E::TILE + 64;
     constexpr bool PF = FlashPrefetch<E>::fwd;
     LMRL_CHECK_HIP(allow_lds(flash_fwd_kernel<E, PF>, lds));
@@ -665,6 +892,7 @@ using namespace lmrl;
 
 extern "C" {
 
+void lmrl_flash_set_variant(int v) { g_flash_variant = v; }
 size_t lmrl_flash_attn_ws_bytes(int batch, int heads, int t, int bf16) {
     return FlashWs::bytes(batch * heads, (t + 63) / 64 * 64, bf16 ? 2 : 4);
 }
