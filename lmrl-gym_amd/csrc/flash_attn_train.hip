@@ -762,6 +762,226 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const typename E::T 
     }
 }
 
+// ------------------------------------------------------------------------------------------ backward, bf16, round 4
+// The two backward sweeps rebuilt like flash_fwd2_bf16_kernel: 8 waves x 16 queries (dQ) / 16 keys (dK, dV) per workgroup, global_load_lds
+// tile ring with one barrier per block, XCD-local heads, ballot / lse-based masking, exp2 with the log2 e factor folded into an FMA, all
+// QK^T and dP MFMAs of a block issued before the first score is read.  Same operands, same summation order per output element as the
+// round-3 kernels (the bf16 results differ only through exp2(fma) vs exp(sub): ~1 ulp of P before its bf16 rounding).
+__device__ __forceinline__ int flash_xcd_tile(int BH, int nt, int &bh, int &tile) {       // -> 0 if this workgroup has no tile; tile 0 first
+    const int id = blockIdx.x, xcd = id & 7, k = id >> 3;
+    if (k < (BH / 8) * nt) { bh = (k / nt) * 8 + xcd; tile = k % nt; return 1; }
+    const int r = (k - (BH / 8) * nt) * 8 + xcd;
+    bh = (BH / 8) * 8 + r / nt; tile = r % nt;
+    return bh < BH;
+}
+inline int flash_xcd_grid(int bh, int nt) { return (bh / 8) * nt * 8 + ((bh % 8) * nt + 7) / 8 * 8; }
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 4) void flash_bwd2_dq_bf16_kernel(const uint16_t *__restrict__ Qn, const uint16_t *__restrict__ Kn,
+                                                                        const uint16_t *__restrict__ Vn, const uint16_t *__restrict__ KT,
+                                                                        const uint16_t *__restrict__ dOn, const float *__restrict__ Dsum,
+                                                                        const float *__restrict__ lse, const uint8_t *__restrict__ km,
+                                                                        float *__restrict__ dqkv, uint16_t *__restrict__ dqb, long ldb, int BH, int H,
+                                                                        int T, int Tp, int d) {
+    typedef ElemBF16 E;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SLOT = 3 * E::TILE, QT = 16 * NW;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int nq = (Tp + QT - 1) / QT;
+    int bh, t_;
+    if (!flash_xcd_tile(BH, nq, bh, t_)) return;
+    const int qb = nq - 1 - t_;                                   // longest sweeps first
+    const int b = bh / H, h = bh - b * H;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 15, lq = lane >> 4;
+    const int nkb = min(((qb + 1) * QT + 63) / 64, Tp / 64);
+    const uint16_t *Kb = Kn + (long)bh * Tp * 64, *Vb = Vn + (long)bh * Tp * 64, *KTb = KT + (long)bh * 64 * Tp;
+    const uint8_t *kmb = km ? km + (long)b * T : nullptr;
+    flash_dma_tile<true, NW>(smem, Kb, 64, wave, lane);
+    flash_dma_tile<true, NW>(smem + E::TILE, Vb, 64, wave, lane);
+    flash_dma_tile<false, NW>(smem + 2 * E::TILE, KTb, Tp, wave, lane);
+    uint8_t rm = key_valid_fetch(kmb, 0, T);
+    const int q0 = qb * QT + wave * 16, qi = q0 + lr, qc = qi < Tp ? qi : Tp - 1;
+    E::Frag qf[2], dof[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        qf[s] = ld_frag_glb(E(), Qn + ((long)bh * Tp + qc) * 64 + s * 32 + lq * 8);
+        dof[s] = ld_frag_glb(E(), dOn + ((long)bh * Tp + qc) * 64 + s * 32 + lq * 8);
+    }
+    // lse = +inf marks a query without a valid key (and the rows t >= T): exp2(s c - inf) = 0, no separate test
+    const float nL2 = -(qi < T ? lse[(long)bh * Tp + qc] : INFINITY) * LOG2E, Dq = Dsum[(long)bh * Tp + qc];
+    f32x4 dq[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ra = slab_row(lr);
+    for (int kb = 0; kb < nkb; kb++) {
+        const char *sK = smem + (kb & 1) * SLOT, *sV = sK + E::TILE, *sKT = sK + 2 * E::TILE;
+        const unsigned long long vm = __ballot(rm != 0);
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (kb + 1 < nkb) {
+            char *nx = smem + ((kb + 1) & 1) * SLOT;
+            flash_dma_tile<true, NW>(nx, Kb + (long)(kb + 1) * 64 * 64, 64, wave, lane);
+            flash_dma_tile<true, NW>(nx + E::TILE, Vb + (long)(kb + 1) * 64 * 64, 64, wave, lane);
+            flash_dma_tile<false, NW>(nx + 2 * E::TILE, KTb + (kb + 1) * 64, Tp, wave, lane);
+            rm = key_valid_fetch(kmb, (kb + 1) * 64, T);
+        }
+        if (kb * 64 > q0 + 15) continue;                          // the block lies entirely above this wave's queries (wave-uniform)
+        const bool masked = !(vm == ~0ull && kb * 64 + 63 <= q0);
+        f32x4 sc[2][2], dp[2][2];
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                    sc[p][hf] = mma(E(), sl == 0 ? z : sc[p][hf], flash_k_frag(sK, p * 32 + ra + 4 * hf, sl * 32 + lq * 8), qf[sl]);
+                    dp[p][hf] = mma(E(), sl == 0 ? z : dp[p][hf], flash_k_frag(sV, p * 32 + ra + 4 * hf, sl * 32 + lq * 8), dof[sl]);
+                }
+        E::Frag dsf[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            float ds[8];
+            const unsigned mb = (unsigned)(vm >> (p * 32 + lq * 8)) & 0xffu;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[p][e >> 2][e & 3], LOG2E, nL2));
+                if (masked) {                                     // SGPR condition
+                    const int kk = kb * 64 + p * 32 + lq * 8 + e;
+                    pr = ((kk <= qi) & (((mb >> e) & 1u) != 0)) ? pr : 0.f;
+                }
+                ds[e] = pr * (dp[p][e >> 2][e & 3] - Dq);
+            }
+            dsf[p] = make_frag(E(), ds);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int db = 0; db < 4; db++) dq[db] = mma(E(), dq[db], ld_frag_lds(E(), sKT, db * 16 + lr, p * 32 + lq * 8), dsf[p]);
+    }
+    if (qi < T) {
+#pragma unroll
+        for (int db = 0; db < 4; db++) {
+            const f32x4 v = dq[db] * 0.125f;
+            if (dqb)       // bf16-matmul train mode: dqkv is only the dy operand of the c_attn backward products — written as that operand
+                *reinterpret_cast<uint2 *>(dqb + ((long)b * T + qi) * ldb + h * 64 + db * 16 + lq * 4) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            else
+                *reinterpret_cast<f32x4 *>(dqkv + ((long)b * T + qi) * 3 * d + h * 64 + db * 16 + lq * 4) = v;
+        }
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 4) void flash_bwd2_dkv_bf16_kernel(const uint16_t *__restrict__ Qn, const uint16_t *__restrict__ Kn,
+                                                                         const uint16_t *__restrict__ Vn, const uint16_t *__restrict__ QT,
+                                                                         const uint16_t *__restrict__ dOn, const uint16_t *__restrict__ dOT,
+                                                                         const float *__restrict__ Dsum, const float *__restrict__ lse,
+                                                                         const uint8_t *__restrict__ km, float *__restrict__ dqkv,
+                                                                         uint16_t *__restrict__ dqb, long ldb, int BH, int H, int T, int Tp, int d) {
+    typedef ElemBF16 E;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SLOT = 4 * E::TILE + 512, KT_ = 16 * NW;       // per slot: Q, dO, Q^T, dO^T tiles + 64 lse + 64 D floats
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int nkt = (Tp + KT_ - 1) / KT_;
+    int bh, kt;
+    if (!flash_xcd_tile(BH, nkt, bh, kt)) return;                 // key tile 0 has the longest sweep: first
+    const int b = bh / H, h = bh - b * H;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 15, lq = lane >> 4;
+    const int k0 = kt * KT_ + wave * 16, kj = k0 + lr, kc = kj < Tp ? kj : Tp - 1;
+    const uint16_t *Qb = Qn + (long)bh * Tp * 64, *dOb = dOn + (long)bh * Tp * 64, *QTb = QT + (long)bh * 64 * Tp, *dOTb = dOT + (long)bh * 64 * Tp;
+    const float *Lb = lse + (long)bh * Tp, *Db = Dsum + (long)bh * Tp;
+    const int qb0 = kt * KT_ / 64, nqb = Tp / 64;
+    auto issue = [&](int qb, char *slot) {
+        flash_dma_tile<true, NW>(slot, Qb + (long)qb * 64 * 64, 64, wave, lane);
+        flash_dma_tile<true, NW>(slot + E::TILE, dOb + (long)qb * 64 * 64, 64, wave, lane);
+        flash_dma_tile<false, NW>(slot + 2 * E::TILE, QTb + qb * 64, Tp, wave, lane);
+        flash_dma_tile<false, NW>(slot + 3 * E::TILE, dOTb + qb * 64, Tp, wave, lane);
+        if (wave == 0)          // 64 floats = one 4-byte-per-lane DMA
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Lb + qb * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)(slot + 4 * E::TILE), 4, 0, 0);
+        if (wave == 1)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Db + qb * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)(slot + 4 * E::TILE + 256), 4, 0, 0);
+    };
+    issue(qb0, smem);
+    E::Frag kf[2], vf[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        kf[s] = ld_frag_glb(E(), Kn + ((long)bh * Tp + kc) * 64 + s * 32 + lq * 8);
+        vf[s] = ld_frag_glb(E(), Vn + ((long)bh * Tp + kc) * 64 + s * 32 + lq * 8);
+    }
+    const uint8_t kmv = km ? km[(long)b * T + (kj < T ? kj : T - 1)] : (uint8_t)1;
+    const bool key_ok = (kj < T) & (kmv != 0);
+    const bool keys_ok = __ballot(key_ok) == ~0ull;               // all 16 keys of this wave valid (each key appears in 4 lanes)
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = dk[i]; }
+    const int ra = slab_row(lr);
+    for (int qb = qb0; qb < nqb; qb++) {
+        const int it = qb - qb0;
+        const char *sQ = smem + (it & 1) * SLOT, *sdO = sQ + E::TILE, *sQT = sQ + 2 * E::TILE, *sdOT = sQ + 3 * E::TILE;
+        const float *sL = reinterpret_cast<const float *>(sQ + 4 * E::TILE), *sD = sL + 64;
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (qb + 1 < nqb) issue(qb + 1, smem + ((it + 1) & 1) * SLOT);
+        if (qb * 64 + 63 < k0) continue;                          // every query of the block precedes this wave's keys (wave-uniform)
+        // queries t >= T and queries without a valid key carry lse = +inf: P = 0 without a test; what is left to mask is the diagonal and invalid keys
+        const bool masked = !(keys_ok && qb * 64 >= k0 + 15);
+        f32x4 sc[2][2], dp[2][2];
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++)
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                    sc[p][hf] = mma(E(), sl == 0 ? z : sc[p][hf], flash_k_frag(sQ, p * 32 + ra + 4 * hf, sl * 32 + lq * 8), kf[sl]);
+                    dp[p][hf] = mma(E(), sl == 0 ? z : dp[p][hf], flash_k_frag(sdO, p * 32 + ra + 4 * hf, sl * 32 + lq * 8), vf[sl]);
+                }
+        E::Frag pf[2], dsf[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            float pr[8], ds[8];
+            const f32x4 l0 = *reinterpret_cast<const f32x4 *>(sL + p * 32 + lq * 8), l1 = *reinterpret_cast<const f32x4 *>(sL + p * 32 + lq * 8 + 4);
+            const f32x4 d0 = *reinterpret_cast<const f32x4 *>(sD + p * 32 + lq * 8), d1 = *reinterpret_cast<const f32x4 *>(sD + p * 32 + lq * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float Lq = e < 4 ? l0[e & 3] : l1[e & 3], Dq = e < 4 ? d0[e & 3] : d1[e & 3];
+                float x = __builtin_amdgcn_exp2f((sc[p][e >> 2][e & 3] - Lq) * LOG2E);
+                if (masked) {                                     // SGPR condition
+                    const int qq = qb * 64 + p * 32 + lq * 8 + e;
+                    x = (key_ok & (qq >= kj)) ? x : 0.f;
+                }
+                pr[e] = x;
+                ds[e] = x * (dp[p][e >> 2][e & 3] - Dq);
+            }
+            pf[p] = make_frag(E(), pr);
+            dsf[p] = make_frag(E(), ds);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int db = 0; db < 4; db++) {
+                dv[db] = mma(E(), dv[db], ld_frag_lds(E(), sdOT, db * 16 + lr, p * 32 + lq * 8), pf[p]);
+                dk[db] = mma(E(), dk[db], ld_frag_lds(E(), sQT, db * 16 + lr, p * 32 + lq * 8), dsf[p]);
+            }
+    }
+    if (kj < T) {
+#pragma unroll
+        for (int db = 0; db < 4; db++) {
+            if (dqb) {
+                uint16_t *row = dqb + ((long)b * T + kj) * ldb + h * 64 + db * 16 + lq * 4;
+                *reinterpret_cast<uint2 *>(row + d) = make_uint2(pack_bf16x2(dk[db][0], dk[db][1]), pack_bf16x2(dk[db][2], dk[db][3]));
+                *reinterpret_cast<uint2 *>(row + 2 * d) = make_uint2(pack_bf16x2(dv[db][0], dv[db][1]), pack_bf16x2(dv[db][2], dv[db][3]));
+            } else {
+                float *row = dqkv + ((long)b * T + kj) * 3 * d + h * 64 + db * 16 + lq * 4;
+                *reinterpret_cast<f32x4 *>(row + d) = dk[db];
+                *reinterpret_cast<f32x4 *>(row + 2 * d) = dv[db];
+            }
+        }
+    }
+}
+
 // which sweeps fetch the next tile through registers under the current tile's MFMAs — A/B per kernel and arithmetic mode on one box
 // (tools/bench_flash_train.py under rocprofv3, B = 32, H = 12, T = 512 / 1024; plain -> prefetch): bf16 forward 75 -> 68 / 245 -> 212 us, bf16 dQ 108 -> 94 /
 // 341 -> 292 us, fp32 forward 282 -> 255 / 965 -> 926 us, fp32 dQ 412 -> 373 / 1413 -> 1348 us; the dK/dV kernels (four tiles per step: the
@@ -876,12 +1096,31 @@ static int flash_bwd(const float *qkv, const uint8_t *km, const float *att, cons
     LMRL_CHECK_LAUNCH();
     const size_t lds_q = 3 * E::TILE + 64, lds_kv = 4 * E::TILE + 512;
     constexpr bool PFQ = FlashPrefetch<E>::dq, PFKV = FlashPrefetch<E>::dkv;
-    LMRL_CHECK_HIP(allow_lds(flash_bwd_dq_kernel<E, PFQ>, lds_q));
-    LMRL_CHECK_HIP(allow_lds(flash_bwd_dkv_kernel<E, PFKV>, lds_kv));
-    hipLaunchKernelGGL((flash_bwd_dq_kernel<E, PFQ>), dim3(tp / 64, bh), dim3(256), lds_q, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.Vn, (const T *)w.KT,
-                       (const T *)w.dOn, (const float *)w.D, lse, km, dqkv, dqb, ldb, heads, t, tp, d);
-    hipLaunchKernelGGL((flash_bwd_dkv_kernel<E, PFKV>), dim3(tp / 64, bh), dim3(256), lds_kv, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.Vn,
-                       (const T *)w.QT, (const T *)w.dOn, (const T *)w.dOT, (const float *)w.D, lse, km, dqkv, dqb, ldb, heads, t, tp, d);
+    constexpr bool BF = E::SZ == 2;
+    constexpr int NW = 8;
+    const int nt = (tp + 16 * NW - 1) / (16 * NW);
+    if (BF && !(g_flash_variant & 2)) {
+        const size_t lds2 = 6 * E::TILE;
+        LMRL_CHECK_HIP(allow_lds(flash_bwd2_dq_bf16_kernel<NW>, lds2));
+        hipLaunchKernelGGL(flash_bwd2_dq_bf16_kernel<NW>, dim3(flash_xcd_grid(bh, nt)), dim3(64 * NW), lds2, s, (const uint16_t *)w.Qn, (const uint16_t *)w.Kn,
+                           (const uint16_t *)w.Vn, (const uint16_t *)w.KT, (const uint16_t *)w.dOn, (const float *)w.D, lse, km, dqkv, dqb, ldb, bh, heads, t,
+                           tp, d);
+    } else {
+        LMRL_CHECK_HIP(allow_lds(flash_bwd_dq_kernel<E, PFQ>, lds_q));
+        hipLaunchKernelGGL((flash_bwd_dq_kernel<E, PFQ>), dim3(tp / 64, bh), dim3(256), lds_q, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.Vn, (const T *)w.KT,
+                           (const T *)w.dOn, (const float *)w.D, lse, km, dqkv, dqb, ldb, heads, t, tp, d);
+    }
+    if (BF && !(g_flash_variant & 4)) {
+        const size_t lds2 = 2 * (4 * E::TILE + 512);
+        LMRL_CHECK_HIP(allow_lds(flash_bwd2_dkv_bf16_kernel<NW>, lds2));
+        hipLaunchKernelGGL(flash_bwd2_dkv_bf16_kernel<NW>, dim3(flash_xcd_grid(bh, nt)), dim3(64 * NW), lds2, s, (const uint16_t *)w.Qn, (const uint16_t *)w.Kn,
+                           (const uint16_t *)w.Vn, (const uint16_t *)w.QT, (const uint16_t *)w.dOn, (const uint16_t *)w.dOT, (const float *)w.D, lse, km, dqkv,
+                           dqb, ldb, bh, heads, t, tp, d);
+    } else {
+        LMRL_CHECK_HIP(allow_lds(flash_bwd_dkv_kernel<E, PFKV>, lds_kv));
+        hipLaunchKernelGGL((flash_bwd_dkv_kernel<E, PFKV>), dim3(tp / 64, bh), dim3(256), lds_kv, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.Vn,
+                           (const T *)w.QT, (const T *)w.dOn, (const T *)w.dOT, (const float *)w.D, lse, km, dqkv, dqb, ldb, heads, t, tp, d);
+    }
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }
