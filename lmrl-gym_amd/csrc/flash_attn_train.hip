@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void flash_stage_kernel(const float *__restric
 #pragma unroll
         for (int e = 0; e < 8; e++) { a[e] = tile[r][c8 + e]; bt[e] = tile[c8 + e][r]; }
         st_vec8(Xn + ((long)bh * Tp + t0 + r) * 64 + c8, a);
-        st_vec8(XT + ((long)bh * 64 + r) * Tp + t0 + c8, bt);
+        if (XT) st_vec8(XT + ((long)bh * 64 + r) * Tp + t0 + c8, bt);      // null: the round-4 bf16 sweeps read the natural matrix both ways
     }
     if (other && threadIdx.x < 64) {
         float s = 0.f;
@@ -221,6 +221,13 @@ __global__ __launch_bounds__(256) void flash_transpose_staged_kernel(uint16_t *_
         for (int e = 0; e < 4; e++) w[e] = tile[c8 + 2 * e][r] | (tile[c8 + 2 * e + 1][r] << 16);
         *reinterpret_cast<uint4 *>(XT + (long)r * Tp + c8) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+}
+
+// the round-4 sweeps read only the natural matrices: all that is left of the pass above is zeroing their rows t in [T, Tp) (Tp > T only)
+__global__ __launch_bounds__(256) void flash_zero_pad_rows_kernel(uint16_t *__restrict__ Xn0, long plane, int T, int Tp) {
+    const int bh = blockIdx.x, n = (Tp - T) * 8;                  // 16-byte pieces of the pad rows of one head
+    uint16_t *Xn = Xn0 + blockIdx.y * plane + ((long)bh * Tp + T) * 64;
+    for (int i = threadIdx.x; i < n; i += 256) reinterpret_cast<uint4 *>(Xn)[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // ------------------------------------------------------------------------------------------ forward
@@ -361,26 +368,40 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const typename E::T *__r
 //   * K fragments are read from LDS conflict-free: the K tile's chunk swizzle follows the row set one ds_read_b128 lane group touches
 // Measured (B = 32, H = 12, 10 back to back): T = 512 70.7 -> 48.8 us, T = 1024 174.9 -> 135.6 us.  Also measured: two query groups per wave
 // (128-query workgroups, every fragment read feeds two MFMAs) 63 / 189 us at 168 VGPRs = three waves per SIMD — occupancy beats reuse here.
-template <bool KSW>
-__device__ __forceinline__ int flash_swz(int row) {       // chunk XOR of a tile row: V^T (and the GEMM tiles) row & 7; K: see flash_k_frag
-    return KSW ? (((row >> 1) & 1) | (((row >> 3) & 3) << 1)) : (row & 7);
-}
-template <bool KSW, int NW>
-__device__ __forceinline__ void flash_dma_tile(char *dst, const uint16_t *src, long ld, int wave, int lane) {
+// Every tile of the round-4 sweeps is a NATURAL [64 rows][64 head dims] block (128-byte rows) read two ways from the same LDS image:
+//   * row fragments ("8 consecutive head dims of row r", the QK^T / dP operand: rows slab_row(lr) + 4 hf + 32 p, chunk 4 sl + lq) by ds_read_b128
+//   * column fragments ("8 consecutive ROWS of head dim c", the PV / dQ / dK / dV operand) by two ds_read_b64_tr_b16 — no transposed copy of
+//     K, V, Q or dO exists in memory (round 3 staged six extra matrices per layer and DMA'd their tiles as well)
+// One chunk swizzle serves both: 16-byte chunk c of row r sits at c ^ flash_swz(r), flash_swz(r) = (bit 1 of r | bit 3 of r << 1) << 1.  The row
+// set of one ds_read_b128 lane group ({0-3, 24-27} with chunk c, {8-11, 16-19} with c ^ 1) then covers 16 distinct 16-byte bank groups, and the
+// 32 lanes of a ds_read_b64_tr_b16 half-wave (rows 8 lq + (lr >> 2), lq in {0, 1} or {2, 3}: four 32-byte pieces on each row parity) all 64 banks once.
+typedef __bf16 flash_bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int flash_swz(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }
+template <int NW>
+__device__ __forceinline__ void flash_dma_tile(char *dst, const uint16_t *src, int wave, int lane) {       // src: 64 contiguous rows of 128 B
     const int lrow = lane >> 3;
 #pragma unroll
     for (int i = 0; i < 8 / NW; i++) {
         const int seg = wave + NW * i, row = seg * 8 + lrow;
-        const int src_c = (lane & 7) ^ flash_swz<KSW>(row);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (long)row * ld + src_c * 8),
+        const int src_c = (lane & 7) ^ flash_swz(row);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + row * 64 + src_c * 8),
                                          (__attribute__((address_space(3))) void *)(dst + seg * 1024), 16, 0, 0);
     }
 }
-// K fragment: a 16-lane group of ds_read_b128 touches rows {0-3, 24-27} with chunk c and {8-11, 16-19} with chunk c + 1 (slab_row); with the
-// chunk XOR ((row >> 1) & 1) | ((row >> 3) & 3) << 1 its 16 lanes fall on 16 distinct 16-byte bank groups (row & 7 gives 2-way conflicts)
 __device__ __forceinline__ ElemBF16::Frag flash_k_frag(const char *tile, int row, int e0) {
     ElemBF16::Frag f;
-    f.v = *reinterpret_cast<const bf16x8 *>(tile + row * 128 + (((e0 >> 3) ^ flash_swz<true>(row)) << 4));
+    f.v = *reinterpret_cast<const bf16x8 *>(tile + row * 128 + (((e0 >> 3) ^ flash_swz(row)) << 4));
+    return f;
+}
+// column fragment: lane (lr, lq) <- rows r0 + 8 lq + 0..7 of head dim db * 16 + lr.  A 16-lane group addresses the sixteen 8-byte pieces of
+// 4 rows x 16 columns (lane -> row lr >> 2, piece lr & 3) and ds_read_b64_tr_b16 hands lane lr column lr of that block (gemm8_bf16.h g8_tr_frag)
+__device__ __forceinline__ ElemBF16::Frag flash_t_frag(const char *tile, int r0, int db, int lr, int lq) {
+    const int row = r0 + 8 * lq + (lr >> 2), j = lr & 3;
+    const char *p = tile + row * 128 + (((db * 2 + (j >> 1)) ^ flash_swz(row)) << 4) + (j & 1) * 8;      // flash_swz(row + 4) == flash_swz(row) here
+    const flash_bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) flash_bf16x4_t *)(p));
+    const flash_bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) flash_bf16x4_t *)(p + 4 * 128));
+    ElemBF16::Frag f;
+    f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return f;
 }
 // max / sum over the four 16-lane rows of a wave (the lanes that share lane & 15), all VALU: v_permlane16_swap pairs rows (0,1) and (2,3),
@@ -459,7 +480,7 @@ __device__ __forceinline__ void flash_fwd2_block(const char *sK, const char *sV,
     for (int p = 0; p < 2; p++)
 #pragma unroll
         for (int db = 0; db < 4; db++) {
-            const E::Frag vf = ld_frag_lds(E(), sV, db * 16 + lr, p * 32 + lq * 8);
+            const E::Frag vf = flash_t_frag(sV, p * 32, db, lr, lq);
             if (ABL & 4) o[db][0] += __builtin_bit_cast(f32x4, vf.v)[p] * __builtin_bit_cast(f32x4, pf[p].v)[db];
             else o[db] = mma(E(), o[db], vf, pf[p]);
         }
@@ -467,7 +488,7 @@ __device__ __forceinline__ void flash_fwd2_block(const char *sK, const char *sV,
 // NW waves per workgroup, 16 queries per wave
 template <int NW, int ABL>
 __global__ __launch_bounds__(64 * NW, 4) void flash_fwd2_bf16_kernel(const uint16_t *__restrict__ Qn, const uint16_t *__restrict__ Kn,
-                                                                     const uint16_t *__restrict__ VT, const uint8_t *__restrict__ km,
+                                                                     const uint16_t *__restrict__ Vn, const uint8_t *__restrict__ km,
                                                                      float *__restrict__ att, float *__restrict__ lse, int BH, int H, int T, int Tp, int d,
                                                                      uint16_t *__restrict__ att_b, long ldb) {
     typedef ElemBF16 E;
@@ -491,10 +512,10 @@ __global__ __launch_bounds__(64 * NW, 4) void flash_fwd2_bf16_kernel(const uint1
     const int b = bh / H, h = bh - b * H;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 15, lq = lane >> 4;
     const int nkb = min(((qb + 1) * QT + 63) / 64, Tp / 64);      // key blocks of this query tile
-    const uint16_t *Kb = Kn + (long)bh * Tp * 64, *Vb = VT + (long)bh * 64 * Tp;
+    const uint16_t *Kb = Kn + (long)bh * Tp * 64, *Vb = Vn + (long)bh * Tp * 64;
     const uint8_t *kmb = km ? km + (long)b * T : nullptr;
-    flash_dma_tile<true, NW>(smem, Kb, 64, wave, lane);
-    flash_dma_tile<false, NW>(smem + E::TILE, Vb, Tp, wave, lane);
+    flash_dma_tile<NW>(smem, Kb, wave, lane);
+    flash_dma_tile<NW>(smem + E::TILE, Vb, wave, lane);
     uint8_t rm = key_valid_fetch(kmb, 0, T);
     const int q0 = qb * QT + wave * 16, qi = q0 + lr;
     E::Frag qf[2];
@@ -517,8 +538,8 @@ __global__ __launch_bounds__(64 * NW, 4) void flash_fwd2_bf16_kernel(const uint1
         }
         if (kb + 1 < nkb && !(ABL & 16)) {  // tools, bit 4: no tile traffic after the first block
             char *nx = smem + ((kb + 1) & 1) * SLOT;
-            flash_dma_tile<true, NW>(nx, Kb + (long)(kb + 1) * 64 * 64, 64, wave, lane);
-            flash_dma_tile<false, NW>(nx + E::TILE, Vb + (kb + 1) * 64, Tp, wave, lane);
+            flash_dma_tile<NW>(nx, Kb + (long)(kb + 1) * 64 * 64, wave, lane);
+            flash_dma_tile<NW>(nx + E::TILE, Vb + (long)(kb + 1) * 64 * 64, wave, lane);
             rm = key_valid_fetch(kmb, (kb + 1) * 64, T);
         }
         // wave-uniform (SGPR) case split
@@ -778,14 +799,14 @@ inline int flash_xcd_grid(int bh, int nt) { return (bh / 8) * nt * 8 + ((bh % 8)
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 4) void flash_bwd2_dq_bf16_kernel(const uint16_t *__restrict__ Qn, const uint16_t *__restrict__ Kn,
-                                                                        const uint16_t *__restrict__ Vn, const uint16_t *__restrict__ KT,
+                                                                        const uint16_t *__restrict__ Vn,
                                                                         const uint16_t *__restrict__ dOn, const float *__restrict__ Dsum,
                                                                         const float *__restrict__ lse, const uint8_t *__restrict__ km,
                                                                         float *__restrict__ dqkv, uint16_t *__restrict__ dqb, long ldb, int BH, int H,
                                                                         int T, int Tp, int d) {
     typedef ElemBF16 E;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SLOT = 3 * E::TILE, QT = 16 * NW;
+    constexpr int SLOT = 2 * E::TILE, QT = 16 * NW;
     constexpr float LOG2E = 1.4426950408889634f;
     const int nq = (Tp + QT - 1) / QT;
     int bh, t_;
@@ -794,11 +815,10 @@ __global__ __launch_bounds__(64 * NW, 4) void flash_bwd2_dq_bf16_kernel(const ui
     const int b = bh / H, h = bh - b * H;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 15, lq = lane >> 4;
     const int nkb = min(((qb + 1) * QT + 63) / 64, Tp / 64);
-    const uint16_t *Kb = Kn + (long)bh * Tp * 64, *Vb = Vn + (long)bh * Tp * 64, *KTb = KT + (long)bh * 64 * Tp;
+    const uint16_t *Kb = Kn + (long)bh * Tp * 64, *Vb = Vn + (long)bh * Tp * 64;
     const uint8_t *kmb = km ? km + (long)b * T : nullptr;
-    flash_dma_tile<true, NW>(smem, Kb, 64, wave, lane);
-    flash_dma_tile<true, NW>(smem + E::TILE, Vb, 64, wave, lane);
-    flash_dma_tile<false, NW>(smem + 2 * E::TILE, KTb, Tp, wave, lane);
+    flash_dma_tile<NW>(smem, Kb, wave, lane);
+    flash_dma_tile<NW>(smem + E::TILE, Vb, wave, lane);
     uint8_t rm = key_valid_fetch(kmb, 0, T);
     const int q0 = qb * QT + wave * 16, qi = q0 + lr, qc = qi < Tp ? qi : Tp - 1;
     E::Frag qf[2], dof[2];
@@ -814,15 +834,14 @@ __global__ __launch_bounds__(64 * NW, 4) void flash_bwd2_dq_bf16_kernel(const ui
     for (int i = 0; i < 4; i++) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ra = slab_row(lr);
     for (int kb = 0; kb < nkb; kb++) {
-        const char *sK = smem + (kb & 1) * SLOT, *sV = sK + E::TILE, *sKT = sK + 2 * E::TILE;
+        const char *sK = smem + (kb & 1) * SLOT, *sV = sK + E::TILE;
         const unsigned long long vm = __ballot(rm != 0);
         wait_vmcnt<0>();
         __syncthreads();
         if (kb + 1 < nkb) {
             char *nx = smem + ((kb + 1) & 1) * SLOT;
-            flash_dma_tile<true, NW>(nx, Kb + (long)(kb + 1) * 64 * 64, 64, wave, lane);
-            flash_dma_tile<true, NW>(nx + E::TILE, Vb + (long)(kb + 1) * 64 * 64, 64, wave, lane);
-            flash_dma_tile<false, NW>(nx + 2 * E::TILE, KTb + (kb + 1) * 64, Tp, wave, lane);
+            flash_dma_tile<NW>(nx, Kb + (long)(kb + 1) * 64 * 64, wave, lane);
+            flash_dma_tile<NW>(nx + E::TILE, Vb + (long)(kb + 1) * 64 * 64, wave, lane);
             rm = key_valid_fetch(kmb, (kb + 1) * 64, T);
         }
         if (kb * 64 > q0 + 15) continue;                          // the block lies entirely above this wave's queries (wave-uniform)
@@ -857,7 +876,7 @@ __global__ __launch_bounds__(64 * NW, 4) void flash_bwd2_dq_bf16_kernel(const ui
 #pragma unroll
         for (int p = 0; p < 2; p++)
 #pragma unroll
-            for (int db = 0; db < 4; db++) dq[db] = mma(E(), dq[db], ld_frag_lds(E(), sKT, db * 16 + lr, p * 32 + lq * 8), dsf[p]);
+            for (int db = 0; db < 4; db++) dq[db] = mma(E(), dq[db], flash_t_frag(sK, p * 32, db, lr, lq), dsf[p]);
     }
     if (qi < T) {
 #pragma unroll
@@ -873,14 +892,13 @@ __global__ __launch_bounds__(64 * NW, 4) void flash_bwd2_dq_bf16_kernel(const ui
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 4) void flash_bwd2_dkv_bf16_kernel(const uint16_t *__restrict__ Qn, const uint16_t *__restrict__ Kn,
-                                                                         const uint16_t *__restrict__ Vn, const uint16_t *__restrict__ QT,
-                                                                         const uint16_t *__restrict__ dOn, const uint16_t *__restrict__ dOT,
+                                                                         const uint16_t *__restrict__ Vn, const uint16_t *__restrict__ dOn,
                                                                          const float *__restrict__ Dsum, const float *__restrict__ lse,
                                                                          const uint8_t *__restrict__ km, float *__restrict__ dqkv,
                                                                          uint16_t *__restrict__ dqb, long ldb, int BH, int H, int T, int Tp, int d) {
     typedef ElemBF16 E;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SLOT = 4 * E::TILE + 512, KT_ = 16 * NW;       // per slot: Q, dO, Q^T, dO^T tiles + 64 lse + 64 D floats
+    constexpr int SLOT = 2 * E::TILE + 512, KT_ = 16 * NW;       // per slot: Q and dO tiles + 64 lse + 64 D floats
     constexpr float LOG2E = 1.4426950408889634f;
     const int nkt = (Tp + KT_ - 1) / KT_;
     int bh, kt;
@@ -888,20 +906,18 @@ __global__ __launch_bounds__(64 * NW, 4) void flash_bwd2_dkv_bf16_kernel(const u
     const int b = bh / H, h = bh - b * H;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 15, lq = lane >> 4;
     const int k0 = kt * KT_ + wave * 16, kj = k0 + lr, kc = kj < Tp ? kj : Tp - 1;
-    const uint16_t *Qb = Qn + (long)bh * Tp * 64, *dOb = dOn + (long)bh * Tp * 64, *QTb = QT + (long)bh * 64 * Tp, *dOTb = dOT + (long)bh * 64 * Tp;
+    const uint16_t *Qb = Qn + (long)bh * Tp * 64, *dOb = dOn + (long)bh * Tp * 64;
     const float *Lb = lse + (long)bh * Tp, *Db = Dsum + (long)bh * Tp;
     const int qb0 = kt * KT_ / 64, nqb = Tp / 64;
     auto issue = [&](int qb, char *slot) {
-        flash_dma_tile<true, NW>(slot, Qb + (long)qb * 64 * 64, 64, wave, lane);
-        flash_dma_tile<true, NW>(slot + E::TILE, dOb + (long)qb * 64 * 64, 64, wave, lane);
-        flash_dma_tile<false, NW>(slot + 2 * E::TILE, QTb + qb * 64, Tp, wave, lane);
-        flash_dma_tile<false, NW>(slot + 3 * E::TILE, dOTb + qb * 64, Tp, wave, lane);
+        flash_dma_tile<NW>(slot, Qb + (long)qb * 64 * 64, wave, lane);
+        flash_dma_tile<NW>(slot + E::TILE, dOb + (long)qb * 64 * 64, wave, lane);
         if (wave == 0)          // 64 floats = one 4-byte-per-lane DMA
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Lb + qb * 64 + lane),
-                                             (__attribute__((address_space(3))) void *)(slot + 4 * E::TILE), 4, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(slot + 2 * E::TILE), 4, 0, 0);
         if (wave == 1)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Db + qb * 64 + lane),
-                                             (__attribute__((address_space(3))) void *)(slot + 4 * E::TILE + 256), 4, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(slot + 2 * E::TILE + 256), 4, 0, 0);
     };
     issue(qb0, smem);
     E::Frag kf[2], vf[2];
@@ -919,8 +935,8 @@ __global__ __launch_bounds__(64 * NW, 4) void flash_bwd2_dkv_bf16_kernel(const u
     const int ra = slab_row(lr);
     for (int qb = qb0; qb < nqb; qb++) {
         const int it = qb - qb0;
-        const char *sQ = smem + (it & 1) * SLOT, *sdO = sQ + E::TILE, *sQT = sQ + 2 * E::TILE, *sdOT = sQ + 3 * E::TILE;
-        const float *sL = reinterpret_cast<const float *>(sQ + 4 * E::TILE), *sD = sL + 64;
+        const char *sQ = smem + (it & 1) * SLOT, *sdO = sQ + E::TILE;
+        const float *sL = reinterpret_cast<const float *>(sQ + 2 * E::TILE), *sD = sL + 64;
         wait_vmcnt<0>();
         __syncthreads();
         if (qb + 1 < nqb) issue(qb + 1, smem + ((it + 1) & 1) * SLOT);
@@ -962,8 +978,8 @@ __global__ __launch_bounds__(64 * NW, 4) void flash_bwd2_dkv_bf16_kernel(const u
         for (int p = 0; p < 2; p++)
 #pragma unroll
             for (int db = 0; db < 4; db++) {
-                dv[db] = mma(E(), dv[db], ld_frag_lds(E(), sdOT, db * 16 + lr, p * 32 + lq * 8), pf[p]);
-                dk[db] = mma(E(), dk[db], ld_frag_lds(E(), sQT, db * 16 + lr, p * 32 + lq * 8), dsf[p]);
+                dv[db] = mma(E(), dv[db], flash_t_frag(sdO, p * 32, db, lr, lq), pf[p]);
+                dk[db] = mma(E(), dk[db], flash_t_frag(sQ, p * 32, db, lr, lq), dsf[p]);
             }
     }
     if (kj < T) {
@@ -1051,7 +1067,7 @@ static int flash_fwd(const float *qkv, const uint8_t *km, float *att, float *lse
             const int fwd2_grid = (bh / 8) * nq2 * 8 + ((bh % 8) * nq2 + 7) / 8 * 8;      // whole rounds of the 8 XCDs
 #define LMRL_FWD2(NW_, ABL_)                                                                                                                     \
     hipLaunchKernelGGL((flash_fwd2_bf16_kernel<NW_, ABL_>), dim3(fwd2_grid), dim3(64 * NW_), lds2, s, (const uint16_t *)w.Qn, (const uint16_t *)w.Kn, \
-                       (const uint16_t *)w.VT, km, att, lse, bh, heads, t, tp, d, (uint16_t *)att_b, ldb)
+                       (const uint16_t *)w.Vn, km, att, lse, bh, heads, t, tp, d, (uint16_t *)att_b, ldb)
 #ifdef LMRL_TOOLS           /* timing-only ablations (tools/bench_flash_ablate.py): results are garbage; bits 16-23: extra (unused) LDS per workgroup, KB */
             lds2 += (size_t)((g_flash_variant >> 16) & 0xff) * 1024;
             LMRL_CHECK_HIP(allow_lds(flash_fwd2_bf16_kernel<8, 0>, lds2));
@@ -1092,7 +1108,9 @@ static int flash_bwd(const float *qkv, const uint8_t *km, const float *att, cons
         int rc = flash_stage_qkv<E>(qkv, w, batch, heads, t, tp, s);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(flash_stage_kernel<E>, dim3(tp / 64, bh), dim3(256), 0, s, datt, (long)d, 0, 1.f, (T *)w.dOn, (T *)w.dOT, att, w.D, heads, t, tp);
+    const bool need_dot = E::SZ != 2 || (g_flash_variant & 6) != 0;         // fp32 sweeps and the round-3 bf16 dQ / dK/dV read dO^T
+    hipLaunchKernelGGL(flash_stage_kernel<E>, dim3(tp / 64, bh), dim3(256), 0, s, datt, (long)d, 0, 1.f, (T *)w.dOn, need_dot ? (T *)w.dOT : (T *)nullptr, att, w.D,
+                       heads, t, tp);
     LMRL_CHECK_LAUNCH();
     const size_t lds_q = 3 * E::TILE + 64, lds_kv = 4 * E::TILE + 512;
     constexpr bool PFQ = FlashPrefetch<E>::dq, PFKV = FlashPrefetch<E>::dkv;
@@ -1100,22 +1118,20 @@ static int flash_bwd(const float *qkv, const uint8_t *km, const float *att, cons
     constexpr int NW = 8;
     const int nt = (tp + 16 * NW - 1) / (16 * NW);
     if (BF && !(g_flash_variant & 2)) {
-        const size_t lds2 = 6 * E::TILE;
+        const size_t lds2 = 4 * E::TILE;
         LMRL_CHECK_HIP(allow_lds(flash_bwd2_dq_bf16_kernel<NW>, lds2));
         hipLaunchKernelGGL(flash_bwd2_dq_bf16_kernel<NW>, dim3(flash_xcd_grid(bh, nt)), dim3(64 * NW), lds2, s, (const uint16_t *)w.Qn, (const uint16_t *)w.Kn,
-                           (const uint16_t *)w.Vn, (const uint16_t *)w.KT, (const uint16_t *)w.dOn, (const float *)w.D, lse, km, dqkv, dqb, ldb, bh, heads, t,
-                           tp, d);
+                           (const uint16_t *)w.Vn, (const uint16_t *)w.dOn, (const float *)w.D, lse, km, dqkv, dqb, ldb, bh, heads, t, tp, d);
     } else {
         LMRL_CHECK_HIP(allow_lds(flash_bwd_dq_kernel<E, PFQ>, lds_q));
         hipLaunchKernelGGL((flash_bwd_dq_kernel<E, PFQ>), dim3(tp / 64, bh), dim3(256), lds_q, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.Vn, (const T *)w.KT,
                            (const T *)w.dOn, (const float *)w.D, lse, km, dqkv, dqb, ldb, heads, t, tp, d);
     }
     if (BF && !(g_flash_variant & 4)) {
-        const size_t lds2 = 2 * (4 * E::TILE + 512);
+        const size_t lds2 = 2 * (2 * E::TILE + 512);
         LMRL_CHECK_HIP(allow_lds(flash_bwd2_dkv_bf16_kernel<NW>, lds2));
         hipLaunchKernelGGL(flash_bwd2_dkv_bf16_kernel<NW>, dim3(flash_xcd_grid(bh, nt)), dim3(64 * NW), lds2, s, (const uint16_t *)w.Qn, (const uint16_t *)w.Kn,
-                           (const uint16_t *)w.Vn, (const uint16_t *)w.QT, (const uint16_t *)w.dOn, (const uint16_t *)w.dOT, (const float *)w.D, lse, km, dqkv,
-                           dqb, ldb, bh, heads, t, tp, d);
+                           (const uint16_t *)w.Vn, (const uint16_t *)w.dOn, (const float *)w.D, lse, km, dqkv, dqb, ldb, bh, heads, t, tp, d);
     } else {
         LMRL_CHECK_HIP(allow_lds(flash_bwd_dkv_kernel<E, PFKV>, lds_kv));
         hipLaunchKernelGGL((flash_bwd_dkv_kernel<E, PFKV>), dim3(tp / 64, bh), dim3(256), lds_kv, s, (const T *)w.Qn, (const T *)w.Kn, (const T *)w.Vn,
@@ -1150,8 +1166,12 @@ int lmrl_flash_attn_finish_staging(void *ws_d, int batch, int heads, int t, void
     LMRL_REQUIRE(ws_d && batch > 0 && heads > 0 && t > 0, "lmrl_flash_attn_finish_staging: bad argument");
     const int tp = (t + 63) / 64 * 64, bh = batch * heads;
     FlashWs w; w.carve(ws_d, bh, tp, 2);
-    hipLaunchKernelGGL(flash_transpose_staged_kernel, dim3(tp / 64, bh, 3), dim3(256), 0, as_stream(stream), (uint16_t *)w.Qn, (uint16_t *)w.QT,
-                       (long)(FlashWs::mat_bytes(bh, tp, 2) / 2), t, tp);
+    if (g_flash_variant & 7)        // tools / tests: a round-3 sweep is selected — it reads the transposed forms as well
+        hipLaunchKernelGGL(flash_transpose_staged_kernel, dim3(tp / 64, bh, 3), dim3(256), 0, as_stream(stream), (uint16_t *)w.Qn, (uint16_t *)w.QT,
+                           (long)(FlashWs::mat_bytes(bh, tp, 2) / 2), t, tp);
+    else if (tp > t)
+        hipLaunchKernelGGL(flash_zero_pad_rows_kernel, dim3(bh, 3), dim3(256), 0, as_stream(stream), (uint16_t *)w.Qn,
+                           (long)(FlashWs::mat_bytes(bh, tp, 2) / 2), t, tp);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

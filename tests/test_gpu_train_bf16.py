@@ -279,8 +279,9 @@ def test_fused_epilogues_track_fp32_like_the_unfused_passes(dev, B, T):
 
 @pytest.mark.parametrize("B,T,H", [(2, 96, 12), (5, 200, 4), (16, 512, 12)])
 def test_c_attn_into_staged_heads_is_bit_identical(dev, B, T, H):
-    """lmrl_gemm_bf16_qkv_heads + lmrl_flash_attn_finish_staging leave exactly the six per-head matrices the flash forward stages from the fp32
-    qkv tensor (q scaled by 1/8, rows t >= T zero) — same bytes."""
+    """lmrl_gemm_bf16_qkv_heads + lmrl_flash_attn_finish_staging leave exactly the per-head matrices the flash forward stages from the fp32
+    qkv tensor (q scaled by 1/8, rows t >= T zero) — same bytes: the three natural matrices the round-4 sweeps read, and with a round-3 sweep
+    selected (lmrl_flash_set_variant) also the three transposed ones."""
     from lmrl_gym_amd.train import ops
     d, R = 64 * H, B * T
     g = torch.Generator().manual_seed(B * 1000 + T)
@@ -298,13 +299,21 @@ def test_c_attn_into_staged_heads_is_bit_identical(dev, B, T, H):
     lse0, lse1 = torch.empty(lse_n, device=dev), torch.empty(lse_n, device=dev)
     ab0, ld = mm.stash(R, d)
     ab1, _ = mm.stash(R, d)
-    ops.flash_attn_fwd_staged(qkv, km, att0, lse0, ws0, ab0, ld, B, H, T, True)
-    ops.linear_fwd_qkv_heads(mm, xb, w, b, ws1, R, d, B, H, T)
-    ops.flash_attn_fwd_staged(None, km, att1, lse1, ws1, ab1, ld, B, H, T, True)
-    torch.cuda.synchronize()
-    n6 = 6 * B * H * ((T + 63) // 64 * 64) * 64 * 2
-    assert torch.equal(ws0[:n6], ws1[:n6])
-    assert torch.equal(att0, att1) and torch.equal(lse0, lse1)
+    from lmrl_gym_amd import _lib
+    L = _lib.lib()
+    plane = B * H * ((T + 63) // 64 * 64) * 64 * 2
+    try:
+        for variant, planes in ((0, 3), (7, 6)):
+            L.lmrl_flash_set_variant(variant)
+            ws0.zero_(); ws1.fill_(0x5a)
+            ops.flash_attn_fwd_staged(qkv, km, att0, lse0, ws0, ab0, ld, B, H, T, True)
+            ops.linear_fwd_qkv_heads(mm, xb, w, b, ws1, R, d, B, H, T)
+            ops.flash_attn_fwd_staged(None, km, att1, lse1, ws1, ab1, ld, B, H, T, True)
+            torch.cuda.synchronize()
+            assert torch.equal(ws0[:planes * plane], ws1[:planes * plane]), variant
+            assert torch.equal(att0, att1) and torch.equal(lse0, lse1), variant
+    finally:
+        L.lmrl_flash_set_variant(0)
 
 
 @pytest.mark.parametrize("R", [192, 4608])
