@@ -159,7 +159,8 @@ class WordleRolloutEngine:
         t = torch
         self.eng, self.vocab, self.B = engine, vocab, batch
         self._twin_args = dict(tokens=tokens, max_new_tokens=max_new_tokens, require_words_in_vocab=require_words_in_vocab,
-                               bad_word_reward=bad_word_reward, traj_cap=traj_cap, share_header=share_header)
+                               bad_word_reward=bad_word_reward, traj_cap=traj_cap, share_header=share_header, value_engine=value_engine,
+                               q1_head=q1_head, q2_head=q2_head, beta=beta)
         self._lanes = None           # text_env_eval(concurrent=n): [(engine, stream)], this engine first
         self.episodes = 0            # eager episodes run by text_env_eval over this engine's life: part of the sampler stream key
         self.tokens = tokens or WordleTokenTable.default_gpt2(pad=engine.cfg.vocab - 1)
@@ -426,7 +427,6 @@ class WordleRolloutEngine:
         """[(engine, stream)] for `text_env_eval(concurrent=n)`: this engine on the caller's stream + n - 1 twins (same model, vocabulary, batch and
         record layout; own sessions / env state / records) on their own streams.  Built once and kept."""
         import torch
-        assert self.vses is None, "concurrent lanes are for the plain sampling policy"
         if self._lanes is None:
             self._lanes = [(self, None)]
         while len(self._lanes) < n:
@@ -441,7 +441,7 @@ class WordleRolloutEngine:
                       concurrent: int = 1):
         """`text_env_eval(env, policy, n_rollouts, bsize=B)` (LLM_RL/environment.py:211-267) with env, policy and the whole
         lock-step loop on the device: ceil(n / B) episodes batches, the same (interactions, summary) return value.
-        use_graph (plain sampling only): the episode is captured into a hipGraph once per (temperature, sample_seed, steering) and replayed per
+        use_graph (top_k = 0; the ILQL value policy included): the episode is captured into a hipGraph once per (temperature, sample_seed, steering) and replayed per
         batch — one host call instead of ~3400 launches; every replay draws fresh noise (the sampler's epoch word advances).  A capture costs
         two extra episodes (warm-up + capture), so the default (None) uses the graph only when this engine already holds one for the same key
         or the call runs >= 4 batches; True / False force it.  The two paths draw DIFFERENT noise for the same `sample_seed`: the graph's
@@ -473,7 +473,7 @@ class WordleRolloutEngine:
             seeds_all[k, :n_k] = [next(seed_generator) for _ in range(n_k)] if seed_generator is not None else np.random.randint(0, 2 ** 31 - 1, size=n_k)
         scripted = scripted_guesses_fn is not None
         key = (float(temperature), int(sample_seed), float(steer_strength), scripted)
-        graph_ok = top_k == 0 and self.vses is None
+        graph_ok = top_k == 0
         if use_graph is None:
             want_graph = graph_ok and (getattr(self, "_eval_graph_key", None) == key or n_batches >= 4)
         else:

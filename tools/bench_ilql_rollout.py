@@ -34,3 +34,15 @@ for i in range(warm, warm + steps):
     ro.replay_episode(seeds[i], guesses[i]); n += ro.traj["n_steps"].sum()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print("ILQL value-policy rollouts: %.1f env-steps/s  (%.2f ms per 1024-env episode, %d env steps)" % (int(n) / dt, dt * 1e3 / steps, int(n)))
+
+# the public call, host lists included, 1 / 2 lanes (independent 1024-env batches in flight; each lane runs its two transformers on two streams)
+kw = dict(scripted_guesses_fn=lambda bid: guesses[bid % (steps + warm)], steer_strength=30.0 + 32.0 * 5, temperature=1.0, sample_seed=5, use_graph=True)
+gen = iter(range(10 ** 6, 10 ** 9))
+for lanes in (1, 2):
+    ro.text_env_eval(lanes * B, seed_generator=gen, concurrent=lanes, **kw)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    inter, _ = ro.text_env_eval(8 * B, seed_generator=gen, concurrent=lanes, **kw)
+    dt = time.perf_counter() - t0
+    print("text_env_eval(8 x B, concurrent=%d): %.1f env-steps/s incl. host lists (%.2f ms per batch)" % (lanes, sum(len(e) for e in inter) / dt, dt * 1e3 / 8))
+    del inter
+ro.close()
