@@ -486,14 +486,18 @@ __device__ __forceinline__ void flash_fwd2_block(const char *sK, const char *sV,
         }
 }
 // NW waves per workgroup, 16 queries per wave
-template <int NW, int ABL>
+// NW waves per workgroup, 16 queries per wave; RS ring slots: RS - 1 key blocks in flight ahead of the one being computed (counted vmcnt waits).
+// RS = 3 measured no faster than 2 (T = 512: 119.0 vs 117.3 us incl. staging, T = 1024: 293 vs 280): the parked time is waves waiting for each other at
+// the barrier, not tiles still in flight
+template <int NW, int ABL, int RS = 2>
 __global__ __launch_bounds__(64 * NW, 4) void flash_fwd2_bf16_kernel(const uint16_t *__restrict__ Qn, const uint16_t *__restrict__ Kn,
                                                                      const uint16_t *__restrict__ Vn, const uint8_t *__restrict__ km,
                                                                      float *__restrict__ att, float *__restrict__ lse, int BH, int H, int T, int Tp, int d,
                                                                      uint16_t *__restrict__ att_b, long ldb) {
     typedef ElemBF16 E;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SLOT = 2 * E::TILE, QT = 16 * NW;
+    constexpr int SLOT = 2 * E::TILE, QT = 16 * NW, OPS = 2 * (8 / NW);     // OPS: tile DMAs per wave per key block
+    uint8_t *sKey = reinterpret_cast<uint8_t *>(smem + RS * SLOT);             // [Tp] key validity of the whole row of this batch element
     // XCD-aware 1-D grid: workgroup id -> XCD id % 8 (observed placement, as in gemm_bf16.h).  All query tiles of one (batch, head) go to ONE XCD,
     // consecutively and longest sweep first: its K / V^T (2 x Tp x 128 B) enter that XCD's L2 once and the other tiles' fills hit there,
     // instead of eight L2s each pulling every head's tiles over the fabric.  Heads beyond the last full group of 8 wrap onto the XCDs in order.
@@ -514,9 +518,14 @@ __global__ __launch_bounds__(64 * NW, 4) void flash_fwd2_bf16_kernel(const uint1
     const int nkb = min(((qb + 1) * QT + 63) / 64, Tp / 64);      // key blocks of this query tile
     const uint16_t *Kb = Kn + (long)bh * Tp * 64, *Vb = Vn + (long)bh * Tp * 64;
     const uint8_t *kmb = km ? km + (long)b * T : nullptr;
-    flash_dma_tile<NW>(smem, Kb, wave, lane);
-    flash_dma_tile<NW>(smem + E::TILE, Vb, wave, lane);
-    uint8_t rm = key_valid_fetch(kmb, 0, T);
+    for (int i = threadIdx.x; i < Tp; i += 64 * NW) sKey[i] = (i < T && (!kmb || kmb[i] != 0)) ? 1 : 0;      // visible after the first barrier
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < RS - 1; j++)
+        if (j < nkb) {
+            flash_dma_tile<NW>(smem + j * SLOT, Kb + (long)j * 64 * 64, wave, lane);
+            flash_dma_tile<NW>(smem + j * SLOT + E::TILE, Vb + (long)j * 64 * 64, wave, lane);
+        }
     const int q0 = qb * QT + wave * 16, qi = q0 + lr;
     E::Frag qf[2];
     {
@@ -529,19 +538,26 @@ __global__ __launch_bounds__(64 * NW, 4) void flash_fwd2_bf16_kernel(const uint1
 #pragma unroll
     for (int i = 0; i < 4; i++) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ra = slab_row(lr);
+    int slot = 0;
     for (int kb = 0; kb < nkb; kb++) {
-        const char *sK = smem + (kb & 1) * SLOT, *sV = sK + E::TILE;
-        const unsigned long long vm = __ballot(rm != 0);          // key validity of block kb, one bit per key (every wave fetched all 64 bytes)
+        const char *sK = smem + slot * SLOT, *sV = sK + E::TILE;
         if (!(ABL & 8) || kb == 0) {        // tools, bit 3: no waits, no barriers after the first block
-            wait_vmcnt<0>();
-            __syncthreads();        // block kb's tiles are in LDS; every wave is done with the other slot
+            // block kb's tiles must have landed; the RS - 2 younger blocks (fewer at the end of the sweep) stay in flight
+            const int ahead = nkb - 1 - kb;
+            if (RS >= 4 && ahead >= 2) wait_vmcnt<2 * OPS>();
+            else if (RS >= 3 && ahead >= 1) wait_vmcnt<OPS>();
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (first block: the sKey stores)
+            __builtin_amdgcn_s_barrier();          // raw barrier (__syncthreads would drain vmcnt): ... for every wave; and every wave is done with the slot of block kb - 1
+            asm volatile("" ::: "memory");
         }
-        if (kb + 1 < nkb && !(ABL & 16)) {  // tools, bit 4: no tile traffic after the first block
-            char *nx = smem + ((kb + 1) & 1) * SLOT;
-            flash_dma_tile<NW>(nx, Kb + (long)(kb + 1) * 64 * 64, wave, lane);
-            flash_dma_tile<NW>(nx + E::TILE, Vb + (long)(kb + 1) * 64 * 64, wave, lane);
-            rm = key_valid_fetch(kmb, (kb + 1) * 64, T);
+        if (kb + RS - 1 < nkb && !(ABL & 16)) {  // tools, bit 4: no tile traffic after the prologue
+            char *nx = smem + (slot == 0 ? RS - 1 : slot - 1) * SLOT;          // the slot block kb - 1 just left
+            flash_dma_tile<NW>(nx, Kb + (long)(kb + RS - 1) * 64 * 64, wave, lane);
+            flash_dma_tile<NW>(nx + E::TILE, Vb + (long)(kb + RS - 1) * 64 * 64, wave, lane);
         }
+        slot = slot + 1 == RS ? 0 : slot + 1;
+        const unsigned long long vm = __ballot(sKey[kb * 64 + lane] != 0);     // key validity of block kb, one bit per key
         // wave-uniform (SGPR) case split
         if (kb * 64 > q0 + 15) continue;                          // NW = 8: the block lies entirely above this wave's queries
         if (vm == ~0ull && kb * 64 + 63 <= q0) flash_fwd2_block<false, ABL>(sK, sV, vm, kb, qi, qf, m, l, o, lr, lq, ra);
@@ -1061,7 +1077,8 @@ static int flash_fwd(const float *qkv, const uint8_t *km, float *att, float *lse
     }
     if constexpr (E::SZ == 2) {
         if (!(g_flash_variant & 1)) {
-            size_t lds2 = 4 * E::TILE;            // 32 KiB
+            const int rs = (g_flash_variant & 16) ? 3 : 2;                                // ring slots; tools: bit 4 = 3 slots (two blocks ahead: no faster)
+            size_t lds2 = (size_t)rs * 2 * E::TILE + (size_t)tp;                          // + key validity bytes of one row
             const int nw = (g_flash_variant & 8) ? 4 : 8;                                 // 8-wave workgroups (128 queries); tools: bit 3 = 4 waves (64 queries: 3 % slower)
             const int nq2 = (tp + 16 * nw - 1) / (16 * nw);
             const int fwd2_grid = (bh / 8) * nq2 * 8 + ((bh % 8) * nq2 + 7) / 8 * 8;      // whole rounds of the 8 XCDs
@@ -1079,10 +1096,15 @@ static int flash_fwd(const float *qkv, const uint8_t *km, float *att, float *lse
                 case 8: LMRL_FWD2(8, 8); break;
                 case 24: LMRL_FWD2(8, 24); break;
                 case 31: LMRL_FWD2(8, 31); break;
-                default: if (nw == 8) LMRL_FWD2(8, 0); else LMRL_FWD2(4, 0);
+                default:
+                    if (rs == 3) hipLaunchKernelGGL((flash_fwd2_bf16_kernel<8, 0, 3>), dim3(fwd2_grid), dim3(512), lds2, s, (const uint16_t *)w.Qn,
+                                                    (const uint16_t *)w.Kn, (const uint16_t *)w.Vn, km, att, lse, bh, heads, t, tp, d, (uint16_t *)att_b, ldb);
+                    else if (nw == 8) LMRL_FWD2(8, 0); else LMRL_FWD2(4, 0);
             }
 #else
-            if (nw == 8) LMRL_FWD2(8, 0); else LMRL_FWD2(4, 0);
+            if (rs == 3) hipLaunchKernelGGL((flash_fwd2_bf16_kernel<8, 0, 3>), dim3(fwd2_grid), dim3(512), lds2, s, (const uint16_t *)w.Qn, (const uint16_t *)w.Kn,
+                                            (const uint16_t *)w.Vn, km, att, lse, bh, heads, t, tp, d, (uint16_t *)att_b, ldb);
+            else if (nw == 8) LMRL_FWD2(8, 0); else LMRL_FWD2(4, 0);
 #endif
 #undef LMRL_FWD2
             LMRL_CHECK_LAUNCH();
