@@ -21,7 +21,10 @@ inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
             // (paired K-steps — one barrier per two K-steps on a 4-slot ring, g8_mainloop_pair — are 5 % faster in isolation, 12.6 -> 11.9 us,
             //  and measured SLOWER inside the episode, 49.72 vs 49.22 ms on the same box: variant 107 keeps the A/B)
             if (g.K % 128 == 0 && g_gemm_variant == 107) return gemm8_launch<128, 128, 2, 4, 4, EPI, NQ, true>(g, s);
-            return gemm8_launch<128, 128, 2, 4, 3, EPI, NQ>(g, s);
+            // round 4: 16 waves (4 x 4, 32 x 32 per wave) = four waves per SIMD on the one workgroup a CU holds — more fragment reads per MFMA, but the
+            // per-step latency chain of a single resident workgroup overlaps better: 48.43 -> 48.14 ms per episode in situ (variant 110 = the 8-wave form)
+            if (g_gemm_variant == 110) return gemm8_launch<128, 128, 2, 4, 3, EPI, NQ>(g, s);
+            return gemm8_launch<128, 128, 4, 4, 3, EPI, NQ>(g, s);
         }
     }
     if constexpr (EPI == EPI_RESID_F32_STATS) {      // tools/ab_rollout_variants.py (A/B hooks; the product path never sets a variant)
@@ -138,7 +141,7 @@ inline hipError_t gemm_launch(const GemmArgs &g, hipStream_t s) {
         // decode-sized products with a LONG K (the bf16x3 rollout mode: K' = 3 K = 2304 / 9216 at M = one row per env): the 8-wave 128 x 128 tile,
         // one workgroup per CU with a 3-slot ring (as the bf16 engine's decode qkv / fc), instead of the 4-wave 2-slot ring the K >= 2048 rule below picks
         if (g.M >= 512 && g.M < 2048 && g.N % 128 == 0 && g.K >= 2048 && t128 >= 128 && g_gemm_variant != 109)
-            return gemm8_launch<128, 128, 2, 4, 3, EPI>(g, s);
+            return g_gemm_variant == 110 ? gemm8_launch<128, 128, 2, 4, 3, EPI>(g, s) : gemm8_launch<128, 128, 4, 4, 3, EPI>(g, s);   // 16 waves: as the bf16 engine's decode qkv / fc
         if (g_gemm_variant != 108) {             // 108: the round-2 policy below (A/B hook)
             switch (pick_train_tile(g.M, g.N, g.K)) {
                 case TT_256x256: return gemm8_launch<256, 256, 2, 4, 2, EPI>(g, s);
