@@ -14,6 +14,7 @@ inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
     // M >= 2048 (prefill): the LN consumers (qkv, fc: wide N) run on the 8-wave 128x128 tile of gemm8_bf16.h, two workgroups per CU
     // (measured +15..19 % over the 4-wave 128x64 ring, profiles/r02_gemm8_bench.txt); the residual producers (N = d_model) stay on the ring
     if constexpr (EPI != EPI_RESID_F32_STATS && NQ > 0) {
+        if (g.M >= 2048 && g.N % 128 == 0 && g_gemm_variant == 206) return gemm8_launch<128, 128, 4, 4, 2, EPI, NQ>(g, s);      // A/B: 16 waves x 2 WGs per CU
         if (g.M >= 2048 && g.N % 128 == 0 && g_gemm_variant != 105) return gemm8_launch<128, 128, 2, 4, 2, EPI, NQ>(g, s);
         // decode (M ~ 1024) LN consumers with a wide N (qkv 144 tiles, fc 192 tiles of 128x128): one 8-wave workgroup per CU moves half the
         // bytes per flop of the 64x64 ring and measured 12.5 vs 15.0 us (profiles/r02_gemm8_bench.txt); 3 slots: nothing else shares the LDS
@@ -30,10 +31,16 @@ inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
     if constexpr (EPI == EPI_RESID_F32_STATS) {      // tools/ab_rollout_variants.py (A/B hooks; the product path never sets a variant)
         if (g.M >= 2048 && g_gemm_variant == 201) return gemm8_launch<128, 128, 2, 4, 2, EPI, NQ>(g, s);
         if (g.M >= 2048 && g_gemm_variant == 203) return gemm_launch_glds<128, 64, 3, EPI, NQ>(g, s);
+        if (g.M >= 2048 && g_gemm_variant == 204) return gemm8_launch<128, 64, 4, 2, 2, EPI, NQ>(g, s);      // 8 waves (32 x 32 per wave), 48 KB ring: 3 WGs per CU
+        if (g.M >= 2048 && g_gemm_variant == 205) return gemm8_launch<128, 64, 4, 2, 3, EPI, NQ>(g, s);      // ... 72 KB ring: 2 WGs per CU
     }
     if (g.M >= 2048) return gemm_launch_glds<128, 64, 2, EPI, NQ>(g, s);
     // (decode residual producers, N = d_model, 192 tiles: the 8-wave 64x64 form of gemm8_bf16.h is ~10 % faster in isolation but measured
     //  SLOWER inside the episode — 14.6 vs 13.4 us — so they stay on the 4-wave ring; profiles/r02_gemm8_bench.txt)
+    // round 4 (with the MFMA results in VGPRs, build.py): the LONG-K residual producer (fc2: 192 tiles x 48 K-steps) on 8 waves (4 x 2, 16 x 32 per wave)
+    // and a 4-slot ring: 48.2 -> 47.85 ms per episode in situ; the short-K one (proj, 12 K-steps) gains nothing from it (48.15), 3 slots lose (49.06).
+    // Variant 116 = the 4-wave ring for both (A/B hook)
+    if (g.K >= 2048 && g_gemm_variant != 116) return gemm8_launch<64, 64, 4, 2, 4, EPI, NQ>(g, s);
     if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
     if (g_gemm_variant == 101) return gemm_launch_glds<64, 64, 2, EPI, NQ>(g, s);
     const long tiles = (long)((g.M + 63) / 64) * (g.N / 64);
