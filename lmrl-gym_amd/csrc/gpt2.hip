@@ -631,8 +631,11 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
                                                                     const int32_t *__restrict__ len, uint16_t *__restrict__ out, int B,
                                                                     int H, int Tmax, int d, const int32_t *__restrict__ off) {
     static_assert(C == 8 || C == 16, "the query block is one 16-column MFMA tile");
-    constexpr int VROW = 136;
+    // per-wave [32 keys][64 dims] V block, 128-byte rows; 16-byte chunk c of row r at c ^ chunk_swz(r): the 32 lanes of a ds_read_b64_tr_b16
+    // half-wave (rows 8 g + (j >> 2), g in {0, 1} or {2, 3}) then cover all 64 banks once (flash_attn_train.hip: flash_swz)
+    constexpr int VROW = 128;
     __shared__ __attribute__((aligned(16))) unsigned char vlds_all[4][32 * VROW];
+    auto chunk_swz = [](int r) { return (((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1; };
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wave_id = blockIdx.x * 4 + wave;
     if (wave_id >= B * H) return;
@@ -673,35 +676,40 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
     float m = -1e30f, l = 0.f;
     const int qpos = L0 + j;   // position of this lane's query
 
-    for (int t0 = 0; t0 < T; t0 += 32) {
-        // ---- stage the V block [32 keys][64 dims] into LDS (row stride 136 B)
+    // Two register sets, ping-pong: block n + 1's K fragments and V rows are requested from HBM before block n is computed (a wave walks its
+    // 2 - 4 blocks strictly in sequence; without the prefetch every block pays the full load latency).
+    struct Blk { u32x4 v[4]; bf16x8_t kf[2][2]; };
+    auto load_blk = [&](int t0, Blk &x) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int id = lane + 64 * i, kl = id >> 3, c = id & 7;
             int t = t0 + kl; t = t < T ? t : T - 1;
             const uint16_t *vp = t < L0 ? vc + (size_t)t * d + c * 8 : qbase + (size_t)(t - L0) * ld + 2 * d + c * 8;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(vp);
-            unsigned long long *dst = reinterpret_cast<unsigned long long *>(vlds + kl * VROW + c * 16);
-            dst[0] = ((unsigned long long)v[1] << 32) | v[0];
-            dst[1] = ((unsigned long long)v[3] << 32) | v[2];
+            x.v[i] = *reinterpret_cast<const u32x4 *>(vp);
         }
-        // The LDS tile is written as 64-bit words and read back as 16-bit elements by OTHER lanes of this wave: type-based
-        // alias analysis would let the compiler move those reads above the writes, so pin the order (LDS itself is in-order
-        // per wave; no s_barrier needed because the tile is private to the wave).
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int sb = 0; sb < 2; sb++) {
+            int t = t0 + (j >> 2) * 8 + sb * 4 + (j & 3);
+            t = t < T ? t : T - 1;
+            const uint16_t *kp = t < L0 ? kc + (size_t)t * d : qbase + (size_t)(t - L0) * ld + d;
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) x.kf[sb][kk] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4 *>(kp + kk * 32 + g * 8));
+        }
+    };
+    auto proc_blk = [&](int t0, const Blk &x) {
+        // ---- stage the V block [32 keys][64 dims] into LDS
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int id = lane + 64 * i, kl = id >> 3, c = id & 7;
+            *reinterpret_cast<u32x4 *>(vlds + kl * VROW + ((c ^ chunk_swz(kl)) << 4)) = x.v[i];
+        }
         // ---- step A: scores of keys t0 + 8g + (sb*4 + r) for query j
         f32x4 sacc[2];
 #pragma unroll
         for (int sb = 0; sb < 2; sb++) {
             sacc[sb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            int t = t0 + (j >> 2) * 8 + sb * 4 + (j & 3);
-            t = t < T ? t : T - 1;
-            const uint16_t *kp = t < L0 ? kc + (size_t)t * d : qbase + (size_t)(t - L0) * ld + d;
 #pragma unroll
-            for (int kk = 0; kk < 2; kk++) {
-                const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4 *>(kp + kk * 32 + g * 8));
-                sacc[sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], sacc[sb], 0, 0, 0);
-            }
+            for (int kk = 0; kk < 2; kk++) sacc[sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.kf[sb][kk], qf[kk], sacc[sb], 0, 0, 0);
         }
         // ---- step B: online softmax for query j over its 8 keys, max shared across the 4 lane groups
         float sv[8];
@@ -730,22 +738,36 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
         l = l * alpha + psum;
         m = m_new;
         const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, u32x4{pk[0], pk[1], pk[2], pk[3]});
-        // ---- step C: O^T[dim][query] = alpha * O^T + V^T . P^T ; V^T fragment gathered from LDS
+        // The LDS tile was written as 16-byte vectors and is read back transposed by OTHER lanes of this wave: pin the order (LDS itself is
+        // in-order per wave; no s_barrier needed because the tile is private to the wave).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- step C: O^T[dim][query] = alpha * O^T + V^T . P^T ; V^T fragment read transposed from LDS
 #pragma unroll
         for (int f = 0; f < 4; f++) {
-            uint32_t vw[4];
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const uint16_t a0 = *reinterpret_cast<const uint16_t *>(vlds + (g * 8 + e) * VROW + (f * 16 + j) * 2);
-                const uint16_t a1 = *reinterpret_cast<const uint16_t *>(vlds + (g * 8 + e + 1) * VROW + (f * 16 + j) * 2);
-                vw[e >> 1] = (uint32_t)a0 | ((uint32_t)a1 << 16);
-            }
-            const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, u32x4{vw[0], vw[1], vw[2], vw[3]});
+            // lane (j, g) <- keys 8 g .. 8 g + 7 of dim 16 f + j: two transposed LDS reads (a 16-lane group addresses the sixteen 8-byte pieces of
+            // 4 rows x 16 dims: lane -> row j >> 2, piece j & 3; the instruction hands lane j column j) instead of sixteen 2-byte gathers
+            const int vr = 8 * g + (j >> 2), vp8 = j & 3;
+            const unsigned char *va = vlds + vr * VROW + (((f * 2 + (vp8 >> 1)) ^ chunk_swz(vr)) << 4) + (vp8 & 1) * 8;
+            typedef __bf16 bf16x4_v __attribute__((ext_vector_type(4)));
+            const bf16x4_v vlo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_v *)(va));
+            const bf16x4_v vhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_v *)(va + 4 * VROW));
+            const bf16x8_t vf = __builtin_shufflevector(vlo, vhi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int r = 0; r < 4; r++) oacc[f][r] *= alpha;
             oacc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[f], 0, 0, 0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all V^T gathers done before the next block overwrites the tile
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all V^T reads done before the next block overwrites the tile
+    };
+    {
+        Blk ba, bb;
+        load_blk(0, ba);
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const bool second = t0 + 32 < T;
+            if (second) load_blk(t0 + 32, bb);
+            proc_blk(t0, ba);
+            if (t0 + 64 < T) load_blk(t0 + 64, ba);
+            if (second) proc_blk(t0 + 32, bb);
+        }
     }
     // ---- finish: l over the 4 lane groups, write query j's 16 dims per lane (4 per fragment)
     l += __shfl_xor(l, 16);
