@@ -25,6 +25,8 @@ inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
             // round 4: 16 waves (4 x 4, 32 x 32 per wave) = four waves per SIMD on the one workgroup a CU holds — more fragment reads per MFMA, but the
             // per-step latency chain of a single resident workgroup overlaps better: 48.43 -> 48.14 ms per episode in situ (variant 110 = the 8-wave form)
             if (g_gemm_variant == 110) return gemm8_launch<128, 128, 2, 4, 3, EPI, NQ>(g, s);
+            if (g_gemm_variant == 117) return gemm8_launch<128, 128, 4, 4, 4, EPI, NQ>(g, s);      // A/B: 16 waves, 4 slots
+            if (g_gemm_variant == 118) return gemm8_launch<128, 128, 4, 4, 2, EPI, NQ>(g, s);      // A/B: 16 waves, 2 slots
             return gemm8_launch<128, 128, 4, 4, 3, EPI, NQ>(g, s);
         }
     }
