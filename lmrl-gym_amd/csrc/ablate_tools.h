@@ -14,6 +14,9 @@
 #define LMRL_ABLATE_FC2_HALFK 128u   /* fc2 over half of K only: the cost of a K loop of half the length */
 #define LMRL_ABLATE_PROJ_AUX_SERIAL 256u /* calibration of the two above: proj on the aux stream but AFTER the attention (same chain): the cost of a fork / join */
 #define LMRL_ABLATE_ATTN_HALF_BYTES 512u /* the decode attention reads only the first half of the cached positions (half the cache lines): an optimistic bound on what a 1-byte cache element could buy (reading half of every 128-B row instead changes nothing: the line is fetched whole) */
+#define LMRL_ABLATE_FC2_SEAM3 1024u /* fc2 as ONE split-K = 3 launch (64 x 64 tiles, 8 waves) + a plain reduce launch: what the split costs WITH its seam (the reduce lacks the bf16 / stats stores: a lower bound) */
+#define LMRL_ABLATE_FC2_SEAM2 2048u /* the same with split-K = 2 */
+#define LMRL_ABLATE_FC2_SEAM6 4096u /* the same on 128 x 128 tiles, split-K = 6 */
 #define LMRL_ABLATE_PROJ_CONCURRENT 32u /* proj GEMM on an auxiliary stream behind the qkv GEMM only: concurrent with the attention launch (stale data) */
 
 namespace lmrl {

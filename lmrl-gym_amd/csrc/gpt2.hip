@@ -1109,7 +1109,7 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
     // tools/bench_ablate_decode.py alone) gives them a meaning: timing-only launch ablations of the single-token decode layers whose RESULTS ARE
     // GARBAGE (csrc/ablate_tools.h).  The product library refuses them.
 #ifdef LMRL_TOOLS
-    const unsigned ablate = (c == 1) ? ((flags >> LMRL_FWD_ABLATE_SHIFT) & 0x3ffu) : 0u;
+    const unsigned ablate = (c == 1) ? ((flags >> LMRL_FWD_ABLATE_SHIFT) & 0x1fffu) : 0u;
 #define LMRL_ABL(bit) ((ablate & (bit)) != 0u)
     AblateAux &aux = m->ablate_aux;     // per model (= per device), created on first use, destroyed with the model
     if ((ablate & (LMRL_ABLATE_PROJ_CONCURRENT | LMRL_ABLATE_FC2_SPLITK2 | LMRL_ABLATE_FC2_HALFK | LMRL_ABLATE_PROJ_AUX_SERIAL)) && !aux.stream) {
@@ -1265,6 +1265,22 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
             if (!LMRL_ABL(LMRL_ABLATE_FC)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_GELU_BF16_LN>(gf, s));
             GemmArgs g2{w.ff, L.w_fc2, L.b_fc2, w.x, M, d, cf.d_ff, cf.d_ff, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
             if (LMRL_ABL(LMRL_ABLATE_FC2)) {}
+#ifdef LMRL_TOOLS
+            else if (LMRL_ABL(LMRL_ABLATE_FC2_SEAM3 | LMRL_ABLATE_FC2_SEAM2 | LMRL_ABLATE_FC2_SEAM6)) {
+                static float *seam_ws = nullptr;           // timing only
+                if (!seam_ws) LMRL_CHECK_HIP(hipMalloc(&seam_ws, (size_t)6 * 2048 * 1280 * sizeof(float)));
+                GemmArgs gs = g2; gs.ldw = cf.d_ff;
+                int S = 3;
+                if (LMRL_ABL(LMRL_ABLATE_FC2_SEAM6)) { S = 6; LMRL_CHECK_HIP((gemm8_launch_splitk<128, 128, 2, 4, 2>(gs, seam_ws, S, cf.d_ff / S, s))); }
+                else {
+                    S = LMRL_ABL(LMRL_ABLATE_FC2_SEAM2) ? 2 : 3;
+                    LMRL_CHECK_HIP((gemm8_launch_splitk<64, 64, 4, 2, 4>(gs, seam_ws, S, cf.d_ff / S, s)));
+                }
+                const long total = (long)M * (d / 4);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, (const float *)seam_ws, S,
+                                   (long)M * d, d, w.x, d, M, d, 1, L.b_fc2);
+            }
+#endif
             else if (LMRL_ABL(LMRL_ABLATE_FC2_SPLITK2 | LMRL_ABLATE_FC2_HALFK)) {
                 // timing only: fc2 over HALF of K — alone (what a K loop of half the length costs), or as two such launches running concurrently on two
                 // streams (racy read-modify-write of x: garbage) = a split-K = 2 form without its reduction seam

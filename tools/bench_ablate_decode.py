@@ -31,7 +31,11 @@ seeds = torch.arange((N + 1) * B, dtype=torch.int64, device=dev).view(N + 1, B)
 names = [("full episode", 0), ("proj via the aux stream, SERIAL (cost of one fork / join per layer)", 256), ("without decode qkv GEMM", 1), ("without decode attention", 2), ("without decode proj GEMM", 4),
          ("without decode fc GEMM", 8), ("without decode fc2 GEMM", 16), ("without proj + fc2", 20), ("without all five", 31),
          ("proj CONCURRENT with attention (aux stream, stale data)", 32), ("fc2 over half of K only", 128), ("decode attention over HALF of the cached positions", 512),
-         ("fc2 as two CONCURRENT half-K launches (split-K 2, no seam)", 64)]
+         ("fc2 as two CONCURRENT half-K launches (split-K 2, no seam)", 64),
+         ("fc2 as ONE split-K 3 launch (64x64) + reduce launch (seam)", 1024), ("fc2 as ONE split-K 2 launch (64x64) + reduce launch (seam)", 2048),
+         ("fc2 as ONE split-K 6 launch (128x128) + reduce launch (seam)", 4096)]
+if "--seam" in sys.argv:
+    names = [names[0]] + names[-3:]
 base = None
 n_dec = 30 * 12                                                   # decode layers per episode: 30 forwards x 12 layers
 for name, bits in names * 2:                                     # two passes: the second one is reported (clocks settled)
