@@ -678,15 +678,8 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
 
     // Two register sets, ping-pong: block n + 1's K fragments and V rows are requested from HBM before block n is computed (a wave walks its
     // 2 - 4 blocks strictly in sequence; without the prefetch every block pays the full load latency).
-    struct Blk { u32x4 v[4]; bf16x8_t kf[2][2]; };
+    struct Blk { bf16x8_t kf[2][2]; };
     auto load_blk = [&](int t0, Blk &x) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int id = lane + 64 * i, kl = id >> 3, c = id & 7;
-            int t = t0 + kl; t = t < T ? t : T - 1;
-            const uint16_t *vp = t < L0 ? vc + (size_t)t * d + c * 8 : qbase + (size_t)(t - L0) * ld + 2 * d + c * 8;
-            x.v[i] = *reinterpret_cast<const u32x4 *>(vp);
-        }
 #pragma unroll
         for (int sb = 0; sb < 2; sb++) {
             int t = t0 + (j >> 2) * 8 + sb * 4 + (j & 3);
@@ -697,11 +690,14 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
         }
     };
     auto proc_blk = [&](int t0, const Blk &x) {
-        // ---- stage the V block [32 keys][64 dims] into LDS
+        // ---- this block's V rows [32 keys][64 dims]: requested now, written to LDS after the softmax (their latency sits under steps A and B)
+        u32x4 vreg[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int id = lane + 64 * i, kl = id >> 3, c = id & 7;
-            *reinterpret_cast<u32x4 *>(vlds + kl * VROW + ((c ^ chunk_swz(kl)) << 4)) = x.v[i];
+            int t = t0 + kl; t = t < T ? t : T - 1;
+            const uint16_t *vp = t < L0 ? vc + (size_t)t * d + c * 8 : qbase + (size_t)(t - L0) * ld + 2 * d + c * 8;
+            vreg[i] = *reinterpret_cast<const u32x4 *>(vp);
         }
         // ---- step A: scores of keys t0 + 8g + (sb*4 + r) for query j
         f32x4 sacc[2];
@@ -738,6 +734,11 @@ __global__ __launch_bounds__(256) void attention_chunk_mfma_kernel(const uint16_
         l = l * alpha + psum;
         m = m_new;
         const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, u32x4{pk[0], pk[1], pk[2], pk[3]});
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int id = lane + 64 * i, kl = id >> 3, c = id & 7;
+            *reinterpret_cast<u32x4 *>(vlds + kl * VROW + ((c ^ chunk_swz(kl)) << 4)) = vreg[i];
+        }
         // The LDS tile was written as 16-byte vectors and is read back transposed by OTHER lanes of this wave: pin the order (LDS itself is
         // in-order per wave; no s_barrier needed because the tile is private to the wave).
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
