@@ -218,7 +218,7 @@ class GPT2ILQLTrain:
         V = self.q1.dout
         ids_d, pos_d, am_d = _t(ids, np.int32), _t(pos, np.int32), _t(am, np.uint8)
         hid, cache = base.forward(ids_d, am_d, pos_d)
-        thid = self.target_base.forward(ids_d, am_d, pos_d)[0] if self.target_base is not None else hid
+        thid = self.target_base.forward(ids_d, am_d, pos_d, inference=True)[0] if self.target_base is not None else hid      # never differentiated
         vo, vc = self.v.forward(hid, R)
         tgt = torch.zeros(R, dtype=torch.int32, device=dev)
         tgt.view(B, T)[:, :-1] = ids_d[:, 1:]

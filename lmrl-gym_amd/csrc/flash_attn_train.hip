@@ -569,7 +569,7 @@ __global__ __launch_bounds__(64 * NW, 4) void flash_fwd2_bf16_kernel(const uint1
 #pragma unroll
         for (int db = 0; db < 4; db++) {
             const f32x4 v = o[db] * inv;
-            *reinterpret_cast<f32x4 *>(att + ((long)b * T + qi) * d + h * 64 + db * 16 + lq * 4) = v;
+            if (att) *reinterpret_cast<f32x4 *>(att + ((long)b * T + qi) * d + h * 64 + db * 16 + lq * 4) = v;      // null: a forward nobody differentiates
             if (att_b) {     // bf16 copy: the operand of the output projection in the bf16-matmul train mode
                 uint2 pk;
                 pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
@@ -1207,8 +1207,9 @@ int lmrl_flash_attn_fwd(const float *qkv_d, const uint8_t *key_mask_d, float *at
 
 int lmrl_flash_attn_fwd_staged(const float *qkv_d, const uint8_t *key_mask_d, float *att_d, float *lse_d, void *ws_d, void *att_bf16_d, long ldb, int batch,
                                int heads, int t, int bf16, void *stream) {
-    LMRL_REQUIRE((qkv_d || bf16) && att_d && lse_d && ws_d && att_bf16_d && ldb >= heads * 64 && ldb % 4 == 0 && batch > 0 && heads > 0 && t > 0,
-                 "lmrl_flash_attn_fwd_staged: bad argument");       // qkv_d null (bf16): q / k / v already staged in ws_d by the c_attn GEMM
+    LMRL_REQUIRE((qkv_d || bf16) && (att_d || (bf16 && !(g_flash_variant & 1))) && lse_d && ws_d && att_bf16_d && ldb >= heads * 64 && ldb % 4 == 0 && batch > 0 &&
+                     heads > 0 && t > 0,
+                 "lmrl_flash_attn_fwd_staged: bad argument");       // qkv_d null (bf16): q / k / v already staged in ws_d by the c_attn GEMM; att_d null (bf16): no fp32 output
     return bf16 ? flash_fwd<ElemBF16>(qkv_d, key_mask_d, att_d, lse_d, ws_d, batch, heads, t, as_stream(stream), att_bf16_d, ldb)
                 : flash_fwd<ElemF32>(qkv_d, key_mask_d, att_d, lse_d, ws_d, batch, heads, t, as_stream(stream), att_bf16_d, ldb);
 }

@@ -510,8 +510,10 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
             for (int j = 0; j < FM; j++) {
                 const int m = m0 + wm * TM + j * 16 + lr;
                 f32x4 vA = acc[i][j] + bA, vB = acc[i + 1][j] + bB;
-                if (m < Mr && nA < g.n_store) *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + nA) = vA;
-                if (m < Mr && nB < g.n_store) *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + nB) = vB;
+                if (g.C) {         // null: a forward nobody differentiates (the ILQL target network) — the pre-activation is not stored
+                    if (m < Mr && nA < g.n_store) *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + nA) = vA;
+                    if (m < Mr && nB < g.n_store) *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + nB) = vB;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; r++) { vA[r] = gelu_new(vA[r]); vB[r] = gelu_new(vB[r]); }
                 uint32_t a0 = pack_bf16x2(vA[0], vA[1]), a1 = pack_bf16x2(vA[2], vA[3]);

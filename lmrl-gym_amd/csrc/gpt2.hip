@@ -1479,8 +1479,8 @@ static bool train_gemm_args_ok(int m, int n, int k, int lda, int ldw) {
 
 int lmrl_gemm_bf16_gelu_dual(const void *a_d, const void *w_d, const float *bias_d, float *c_d, int ldc, void *act_bf16_d, int ldact, int m, int n, int k,
                              int lda, int ldw, void *stream) {
-    LMRL_REQUIRE(a_d && w_d && c_d && act_bf16_d && train_gemm_args_ok(m, n, k, lda, ldw) && ldc % 4 == 0 && ldc >= n && ldact % 8 == 0 && ldact >= n,
-                 "lmrl_gemm_bf16_gelu_dual: bad argument (n a multiple of 128, k of 64, pitches covering n / k)");
+    LMRL_REQUIRE(a_d && w_d && act_bf16_d && train_gemm_args_ok(m, n, k, lda, ldw) && (!c_d || (ldc % 4 == 0 && ldc >= n)) && ldact % 8 == 0 && ldact >= n,
+                 "lmrl_gemm_bf16_gelu_dual: bad argument (n a multiple of 128, k of 64, pitches covering n / k)");       // c_d null: bf16 gelu output only
     GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, bias_d, c_d, m, n, k, lda, ldc, n};
     g.ldw = ldw; g.xb = (uint16_t *)act_bf16_d; g.ldxb = ldact;
     LMRL_CHECK_HIP(gemm_launch_train<EPI_F32_GELU_BF16>(g, as_stream(stream)));

@@ -106,10 +106,13 @@ class GPT2F32:
         self.mm = ops.MatmulBF16(self.dev) if matmul == "bf16" else None
         self.ld_vocab = ops._pad(self.vocab) if self.mm is not None else ops._pad(self.vocab, 4)     # row stride of [rows, V] logits (fp32: 16-byte aligned rows)
 
-    def _layer_forward(self, l: int, x, B: int, T: int, km, flash: bool, lse_n: int, resid_in=None):
+    def _layer_forward(self, l: int, x, B: int, T: int, km, flash: bool, lse_n: int, resid_in=None, inference: bool = False):
         """One transformer block: x [B*T, d] -> (x_out, pending, cache of every intermediate the backward pass reads).  resid_in: a residual
         still to be added to x (the previous block's `x_mid`, when its second residual add was left to this block's ln_1: x += resid_in in place,
-        inside the LayerNorm launch).  pending: likewise this block's x_mid if x_out is returned WITHOUT it (ops.FUSE_ADD_LN), else None."""
+        inside the LayerNorm launch).  pending: likewise this block's x_mid if x_out is returned WITHOUT it (ops.FUSE_ADD_LN), else None.
+        inference (bf16-matmul mode with the fused flash / gelu paths): nobody differentiates this forward (the ILQL target network) — what only a
+        backward pass would read is not written: the fp32 c_fc pre-activation ([rows][d_ff] floats per block), the fp32 attention output, a flash
+        workspace per block; same launches otherwise, bit-identical hidden states."""
         t = self.t
         R, d, H, p = B * T, self.d, self.n_head, self.p
         hd = d // H
@@ -132,16 +135,17 @@ class GPT2F32:
             ops.layernorm_add_fwd(x, resid_in, p[q + "ln_1.weight"], p[q + "ln_1.bias"], h1, c["m1"], c["r1"], None, 0, R, d, self.eps)
         qkv_fused = stage and flash and ops.fused_ok(3 * d, ops.FUSE_QKV)      # c_attn writes the flash kernels' staged q / k / v itself: no fp32 qkv
         fws = None
+        lean = inference and stage and flash and qkv_fused and ops.fused_ok(self.d_ff, ops.FUSE_GELU)
         if flash:
             # a workspace per block and per forward call: the q / k / v matrices staged here are the ones the block's backward sweeps
-            fws = c["flash_ws"] = t.empty_like(self._flash_ws[0])
+            fws = c["flash_ws"] = self._flash_ws[0] if lean else t.empty_like(self._flash_ws[0])
         if qkv_fused:
             qkv = None
             ops.linear_fwd_qkv_heads(mm, h1b, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], fws, R, d, B, H, T)
         else:
             qkv = new(R, 3 * d)
             ops.linear_fwd(h1, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], qkv, R, d, 3 * d, mm=self.mm, xb=h1b)
-        att = new(R, d)
+        att = None if lean else new(R, d)
         attb = None
         if flash:
             P = None
@@ -170,7 +174,7 @@ class GPT2F32:
         else:
             h2 = new(R, d)
             ops.layernorm_add_fwd(x_mid, x if fuse_add else None, p[q + "ln_2.weight"], p[q + "ln_2.bias"], h2, c["m2"], c["r2"], None, 0, R, d, self.eps)
-        f = new(R, self.d_ff)
+        f = None if lean else new(R, self.d_ff)
         g = gb = None
         if stage and ops.fused_ok(self.d_ff, ops.FUSE_GELU):          # c_fc writes the pre-activation and the bf16 gelu output in one launch
             gb, ldb = mm.stash(R, self.d_ff)
@@ -191,8 +195,9 @@ class GPT2F32:
         return x_out, (x_mid if fuse_add else None), c
 
     # ------------------------------------------------------------------ forward
-    def forward(self, input_ids, attention_mask, position_ids, tag: str = "fwd"):
-        """input_ids / position_ids int32 [B,T], attention_mask uint8 [B,T] -> (final hidden [B*T, d], cache)."""
+    def forward(self, input_ids, attention_mask, position_ids, tag: str = "fwd", inference: bool = False):
+        """input_ids / position_ids int32 [B,T], attention_mask uint8 [B,T] -> (final hidden [B*T, d], cache).  inference: the cache will not be
+        differentiated (`backward` must not be called on it): see `_layer_forward`."""
         t = self.t
         if self.mm is not None:
             self.mm.begin_step()          # the optimizer may have moved the fp32 masters since the last forward: re-stage the bf16 copies
@@ -218,11 +223,11 @@ class GPT2F32:
         cache["lse_n"] = lse_n
         pending = None
         for l in range(self.n_layer):
-            x_out, nxt, c = self._layer_forward(l, x, B, T, km, flash, lse_n, resid_in=pending)
+            x_out, nxt, c = self._layer_forward(l, x, B, T, km, flash, lse_n, resid_in=pending, inference=inference)
             # gradient_checkpointing (train_ilql_gpt2.py:201-202): keep only the block input (x: complete once the block's ln_1 launch has added the
             # pending residual in place); backward() recomputes the block — the same launches on the same inputs, i.e. bit-identical
             # intermediates — right before it differentiates it
-            cache["layers"].append(dict(x_in=x) if self.gradient_checkpointing else c)
+            cache["layers"].append(dict(x_in=x) if (self.gradient_checkpointing or inference) else c)
             x, pending = x_out, nxt
         hid, cache["mf"], cache["rf"] = new(R, d), new(R), new(R)
         ops.layernorm_add_fwd(x, pending, p["ln_f.weight"], p["ln_f.bias"], hid, cache["mf"], cache["rf"], None, 0, R, d, self.eps)

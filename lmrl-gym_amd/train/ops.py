@@ -188,9 +188,10 @@ def fused_ok(n: int, which: int) -> bool:
 
 
 def linear_fwd_gelu(mm: "MatmulBF16", xb, w, b, f, gb, ldg, rows, k, n):
-    """f[rows][n] fp32 = x @ w + b and gb[rows][ldg] bf16 = gelu_new(f) in one launch (xb: the staged bf16 operand of x)."""
+    """f[rows][n] fp32 = x @ w + b and gb[rows][ldg] bf16 = gelu_new(f) in one launch (xb: the staged bf16 operand of x).  f None: only gb is
+    written (a forward nobody differentiates)."""
     wt = mm.cast(("wT", w.data_ptr()), w, k, n, n, transpose=True, keep=True)
-    _lib.check(_L().lmrl_gemm_bf16_gelu_dual(xb.data_ptr(), wt.data_ptr(), _lib.ptr(mm.bias(b, n)), f.data_ptr(), n, gb.data_ptr(), ldg, rows, n, _pad(k),
+    _lib.check(_L().lmrl_gemm_bf16_gelu_dual(xb.data_ptr(), wt.data_ptr(), _lib.ptr(mm.bias(b, n)), _lib.ptr(f), n, gb.data_ptr(), ldg, rows, n, _pad(k),
                                              _pitch(k), _pitch(k), _sp()), "lmrl_gemm_bf16_gelu_dual")
 
 
@@ -498,7 +499,7 @@ def flash_attn_fwd(qkv, key_mask, att, lse, ws, batch, heads, t, bf16):
 
 def flash_attn_fwd_staged(qkv, key_mask, att, lse, ws, att_b, ldb, batch, heads, t, bf16):
     """qkv None (bf16): `ws` already holds the staged q / k / v (`linear_fwd_qkv_heads`)."""
-    _lib.check(_L().lmrl_flash_attn_fwd_staged(_lib.ptr(qkv), _lib.ptr(key_mask), att.data_ptr(), lse.data_ptr(), ws.data_ptr(), att_b.data_ptr(), ldb,
+    _lib.check(_L().lmrl_flash_attn_fwd_staged(_lib.ptr(qkv), _lib.ptr(key_mask), _lib.ptr(att), lse.data_ptr(), ws.data_ptr(), att_b.data_ptr(), ldb,
                                                batch, heads, t, int(bf16), _sp()), "lmrl_flash_attn_fwd_staged")
 
 

@@ -465,3 +465,25 @@ def test_vocabulary_head_ce_from_the_gemm_accumulators(dev, rows, n):
     err = (D[:rows, :n].double() - ref).abs() / (ref.abs() + 1e-6)
     assert float(err.max()) <= 2.0 ** -8, float(err.max())
     assert float(D[rows:].abs().max() if D.shape[0] > rows else 0.0) == 0.0 and float(D[:rows, n:].abs().max()) == 0.0
+
+
+def test_inference_forward_is_bit_identical_and_leaner(dev):
+    """GPT2F32.forward(inference=True) (the ILQL target network's forward: nobody differentiates it) skips the stores only a backward pass would
+    read — fp32 c_fc pre-activations, fp32 attention outputs, per-block flash workspaces — and returns the same bits."""
+    from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32
+    cfg = GPT2Config(3, 12, 768, 3072, 1024, 256)
+    sd = init_hf_style_state_dict(cfg, seed=11)
+    B, T = 3, 200
+    rng = np.random.RandomState(2)
+    ids = torch.from_numpy(rng.randint(0, cfg.vocab, size=(B, T)).astype(np.int32)).to(dev)
+    am = np.ones((B, T), dtype=np.uint8); am[0, T - 9:] = 0; am[2, :4] = 0
+    pos = torch.from_numpy(np.maximum(np.cumsum(am, axis=1) - 1, 0).astype(np.int32)).to(dev)
+    am = torch.from_numpy(am).to(dev)
+    m = GPT2F32(sd, cfg.n_head, device=dev, matmul="bf16")
+    h_full, c_full = m.forward(ids, am, pos)
+    h_full = h_full.clone()
+    h_lean, c_lean = m.forward(ids, am, pos, inference=True)
+    torch.cuda.synchronize()
+    assert torch.equal(h_full, h_lean)
+    assert all(set(c) == {"x_in"} for c in c_lean["layers"]) and all("f" in c and c["f"] is not None for c in c_full["layers"])
