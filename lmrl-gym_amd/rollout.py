@@ -482,7 +482,12 @@ class WordleRolloutEngine:
         lanes = [(self, main)]
         if concurrent > 1 and want_graph and n_batches >= 2:
             lanes = self._eval_lanes(min(int(concurrent), n_batches), main)
+        # scripted batches: every batch's guesses are taken BEFORE anything is enqueued, so that one wait per lane (below) orders the lanes behind
+        # their producer — a per-batch wait on the caller's stream would queue a lane behind the episode lane 0 has in flight
+        gs = [scripted_guesses_fn(k) for k in range(n_batches)] if scripted else None
         seeds_dev = None
+        for _, st in lanes[1:]:
+            st.wait_stream(main)
         if want_graph:
             seeds_dev = torch.from_numpy(seeds_all.view(np.int64)).to(self.dev)
             for l, (e, st) in enumerate(lanes):
@@ -496,11 +501,9 @@ class WordleRolloutEngine:
         batch_id, launched, pending = 0, 0, deque()
         while launched < n_rollouts:
             actual = min(n_rollouts - launched, self.B)
-            g = scripted_guesses_fn(batch_id) if scripted else None
+            g = gs[batch_id] if scripted else None
             e, st = lanes[batch_id % len(lanes)]
             with torch.cuda.stream(st):
-                if g is not None and st is not main:
-                    st.wait_stream(main)            # the caller built g on its stream
                 if want_graph:
                     e.replay_episode(seeds_dev[batch_id], g)
                 else:
