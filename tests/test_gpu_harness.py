@@ -193,10 +193,11 @@ def test_harness_script_subcommands_at_toy_scale(tmp_path, capsys):
     H.main(["bc-eval", "--model", str(tmp_path / "ckpt" / "base"), "--policy-n-rollouts", "4", "--policy-bsize", "2", "--policy-max-input-length", "88",
             "--policy-max-output-length", "8"])
     H.main(["bc-eval", "--device-rollouts", "1", "--policy-n-rollouts", "6", "--policy-bsize", "4"])
+    H.main(["bc-eval", "--device-rollouts", "1", "--policy-n-rollouts", "40", "--policy-bsize", "8", "--rollout-lanes", "2"])       # 5 batches: graph path, two lanes
     H.main(["maze-eval", "--max-steps", "3", "--generation-bsize", "8", "--max-input-length", "160", "--max-output-length", "6"])
     lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
     tags = [next(iter(l)) for l in lines]
-    assert tags.count("eval") >= 9 and tags.count("data_collection") >= 5 and "gen_data" in tags and "data_collection" in tags and "maze_eval" in tags and "train" in tags
+    assert tags.count("eval") >= 10 and tags.count("data_collection") >= 5 and "gen_data" in tags and "data_collection" in tags and "maze_eval" in tags and "train" in tags
     me = next(l["maze_eval"] for l in lines if "maze_eval" in l)
     assert me["n"] == 26 and 0.0 <= me["move_accuracy"] <= 100.0
 
