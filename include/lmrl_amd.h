@@ -319,6 +319,13 @@ int lmrl_gemm_bf16_qkv_heads(const void *a_d, const void *w_d, const float *bias
                              int heads, int t, void *stream);
 int lmrl_gemm_bf16_gelu_bwd(const void *a_d, const void *w_d, const float *pre_d, int ldpre, void *c_bf16_d, int ldc, int m, int n, int k, int lda,
                             int ldw, void *stream);
+/* The two entries above with the pre-activation stored ROUNDED TO bf16 ([m][ldpre] bf16 elements, ldpre a multiple of 8): the gelu backward is its
+ * only reader (ppo/gpt2/interface.py:72-211 and ilql/gpt2/interface.py:88-367 differentiate HF-Flax GPT-2's gelu_new; its bf16 mode keeps every
+ * activation in bf16) — half the bytes written by the forward and read by the backward. */
+int lmrl_gemm_bf16_gelu_dual_prebf16(const void *a_d, const void *w_d, const float *bias_d, void *pre_bf16_d, int ldpre, void *act_bf16_d, int ldact, int m,
+                                     int n, int k, int lda, int ldw, void *stream);
+int lmrl_gemm_bf16_gelu_bwd_prebf16(const void *a_d, const void *w_d, const void *pre_bf16_d, int ldpre, void *c_bf16_d, int ldc, int m, int n, int k,
+                                    int lda, int ldw, void *stream);
 
 /* Vocabulary-wide heads (the Q heads of ILQL / MC, heads/mlp_head.py:139-148; the tied LM head of PPO) in the bf16-matmul mode: logits written ONCE,
  * in bf16 ([m][ldc], columns [0, n_store)), with everything the cross-entropy / take_along_axis terms need taken from the fp32 accumulators in the

@@ -128,6 +128,8 @@ _SIGS = {
     "lmrl_gemm_bf16_gelu_dual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_gemm_bf16_qkv_heads": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_gemm_bf16_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lmrl_gemm_bf16_gelu_dual_prebf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "lmrl_gemm_bf16_gelu_bwd_prebf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_flash_attn_stage_ptrs": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_long)]),
     "lmrl_flash_attn_finish_staging": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "lmrl_flash_attn_bwd_staged": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

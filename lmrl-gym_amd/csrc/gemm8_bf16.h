@@ -510,7 +510,11 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
             for (int j = 0; j < FM; j++) {
                 const int m = m0 + wm * TM + j * 16 + lr;
                 f32x4 vA = acc[i][j] + bA, vB = acc[i + 1][j] + bB;
-                if (g.C) {         // null: a forward nobody differentiates (the ILQL target network) — the pre-activation is not stored
+                if (g.C && g.pre_bf16) {      // the pre-activation rounded to bf16 (all the gelu backward reads of it): half the bytes, same 16-byte stores as the gelu output
+                    auto p0 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(vA[0], vA[1]), pack_bf16x2(vB[0], vB[1]), false, false);
+                    auto p1 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(vA[2], vA[3]), pack_bf16x2(vB[2], vB[3]), false, false);
+                    if (m < Mr && n_st < g.n_store) *reinterpret_cast<u32x4 *>(reinterpret_cast<uint16_t *>(g.C) + (size_t)m * g.ldc + n_st) = u32x4{p0[0], p1[0], p0[1], p1[1]};
+                } else if (g.C) {  // null: a forward nobody differentiates (the ILQL target network) — the pre-activation is not stored
                     if (m < Mr && nA < g.n_store) *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + nA) = vA;
                     if (m < Mr && nB < g.n_store) *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(g.C) + (size_t)m * g.ldc + nB) = vB;
                 }
@@ -603,8 +607,15 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
                 for (int j = 0; j < FM; j++) {
                     int m = m0 + wm * TM + j * 16 + lr;
                     m = m < Mr ? m : Mr - 1;
-                    fA[j] = *reinterpret_cast<const f32x4 *>(g.resid + (size_t)m * g.ldr + (nA < g.n_store ? nA : 0));
-                    fB[j] = *reinterpret_cast<const f32x4 *>(g.resid + (size_t)m * g.ldr + (nB < g.n_store ? nB : 0));
+                    if (g.pre_bf16) {      // bf16 pre-activations (row pitch ldr elements): 8 bytes per fragment
+                        const uint16_t *pr = reinterpret_cast<const uint16_t *>(g.resid) + (size_t)m * g.ldr;
+                        const uint2 ua = *reinterpret_cast<const uint2 *>(pr + (nA < g.n_store ? nA : 0)), ub = *reinterpret_cast<const uint2 *>(pr + (nB < g.n_store ? nB : 0));
+                        fA[j] = f32x4{__uint_as_float(ua.x << 16), __uint_as_float(ua.x & 0xffff0000u), __uint_as_float(ua.y << 16), __uint_as_float(ua.y & 0xffff0000u)};
+                        fB[j] = f32x4{__uint_as_float(ub.x << 16), __uint_as_float(ub.x & 0xffff0000u), __uint_as_float(ub.y << 16), __uint_as_float(ub.y & 0xffff0000u)};
+                    } else {
+                        fA[j] = *reinterpret_cast<const f32x4 *>(g.resid + (size_t)m * g.ldr + (nA < g.n_store ? nA : 0));
+                        fB[j] = *reinterpret_cast<const f32x4 *>(g.resid + (size_t)m * g.ldr + (nB < g.n_store ? nB : 0));
+                    }
                 }
             }
 #pragma unroll

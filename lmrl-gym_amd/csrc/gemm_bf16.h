@@ -157,6 +157,7 @@ struct GemmArgs {
     int ldxb;                 // EPI_F32_GELU_BF16: row pitch of xb (elements)
     int hd_T, hd_Tp, hd_H;    // EPI_BF16_HEADS: tokens per sequence, its padding to 64, heads
     long hd_plane;            // EPI_BF16_HEADS: elements between the q, k and v matrices
+    int pre_bf16;             // EPI_F32_GELU_BF16 / EPI_GELU_BWD_BF16: the pre-activation (C / resid) is stored as bf16 with row pitch ldc / ldr ELEMENTS
 };
 
 // cache row (b * tmax + len[b]) the K/V columns of GEMM row m are appended to, or -1.  Loads are unconditional on clamped indices (selects, no

@@ -1487,6 +1487,28 @@ int lmrl_gemm_bf16_gelu_dual(const void *a_d, const void *w_d, const float *bias
     return LMRL_OK;
 }
 
+// the same with the pre-activation stored ROUNDED TO bf16 ([m][ldpre] elements): the gelu backward is its only reader, and the reference's bf16 mode keeps
+// every activation in bf16 — 100 MB instead of 201 MB per block at the ILQL batch, written here and read back by lmrl_gemm_bf16_gelu_bwd_prebf16
+int lmrl_gemm_bf16_gelu_dual_prebf16(const void *a_d, const void *w_d, const float *bias_d, void *pre_bf16_d, int ldpre, void *act_bf16_d, int ldact, int m, int n,
+                                     int k, int lda, int ldw, void *stream) {
+    LMRL_REQUIRE(a_d && w_d && pre_bf16_d && act_bf16_d && train_gemm_args_ok(m, n, k, lda, ldw) && ldpre % 8 == 0 && ldpre >= n && ldact % 8 == 0 && ldact >= n,
+                 "lmrl_gemm_bf16_gelu_dual_prebf16: bad argument (n a multiple of 128, k of 64, pitches multiples of 8 covering n / k)");
+    GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, bias_d, pre_bf16_d, m, n, k, lda, ldpre, n};
+    g.ldw = ldw; g.xb = (uint16_t *)act_bf16_d; g.ldxb = ldact; g.pre_bf16 = 1;
+    LMRL_CHECK_HIP(gemm_launch_train<EPI_F32_GELU_BF16>(g, as_stream(stream)));
+    return LMRL_OK;
+}
+
+int lmrl_gemm_bf16_gelu_bwd_prebf16(const void *a_d, const void *w_d, const void *pre_bf16_d, int ldpre, void *c_bf16_d, int ldc, int m, int n, int k, int lda,
+                                    int ldw, void *stream) {
+    LMRL_REQUIRE(a_d && w_d && pre_bf16_d && c_bf16_d && train_gemm_args_ok(m, n, k, lda, ldw) && ldc % 8 == 0 && ldc >= n && ldpre % 4 == 0 && ldpre >= n,
+                 "lmrl_gemm_bf16_gelu_bwd_prebf16: bad argument");
+    GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, nullptr, c_bf16_d, m, n, k, lda, ldc, n};
+    g.ldw = ldw; g.resid = (const float *)pre_bf16_d; g.ldr = ldpre; g.pre_bf16 = 1;
+    LMRL_CHECK_HIP(gemm_launch_train<EPI_GELU_BWD_BF16>(g, as_stream(stream)));
+    return LMRL_OK;
+}
+
 int lmrl_gemm_bf16_qkv_heads(const void *a_d, const void *w_d, const float *bias_d, void *q_heads_d, long plane_elems, int m, int k, int lda, int ldw,
                              int heads, int t, void *stream) {
     const int n = 3 * heads * 64, tp = (t + 63) / 64 * 64;

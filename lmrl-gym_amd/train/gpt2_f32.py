@@ -174,7 +174,9 @@ class GPT2F32:
         else:
             h2 = new(R, d)
             ops.layernorm_add_fwd(x_mid, x if fuse_add else None, p[q + "ln_2.weight"], p[q + "ln_2.bias"], h2, c["m2"], c["r2"], None, 0, R, d, self.eps)
-        f = None if lean else new(R, self.d_ff)
+        # the pre-activation's only reader is the gelu backward; with both fused epilogues on it is kept rounded to bf16 (ops.PRE_BF16)
+        f_bf16 = stage and ops.PRE_BF16 and ops.fused_ok(self.d_ff, ops.FUSE_GELU) and ops.fused_ok(self.d_ff, ops.FUSE_GELU_BWD)
+        f = None if lean else (t.empty(R, ops._pitch(self.d_ff), dtype=t.bfloat16, device=self.dev) if f_bf16 else new(R, self.d_ff))
         g = gb = None
         if stage and ops.fused_ok(self.d_ff, ops.FUSE_GELU):          # c_fc writes the pre-activation and the bf16 gelu output in one launch
             gb, ldb = mm.stash(R, self.d_ff)
@@ -365,6 +367,8 @@ class GPT2F32:
                 dg = new(R, self.d_ff)
                 ops.linear_bwd(c["g"], p[q + "mlp.c_proj.weight"], dx, dg, grads[q + "mlp.c_proj.weight"], grads[q + "mlp.c_proj.bias"], R, self.d_ff, d, ws,
                                mm=mm, dyb=dxb[0], xb=c.get("gb"))
+                if c["f"].dtype != t.float32:       # a bf16 pre-activation met the unfused backward (dx not staged): widen it for the elementwise kernel
+                    c["f"] = c["f"][:, :self.d_ff].float().contiguous()
                 if mm is not None:         # df only feeds the c_fc backward products: written as their bf16 operand, no fp32 copy
                     df, dfb = None, ops.gelu_bwd_staged(mm, dg, c["f"], R, self.d_ff)
                 else:

@@ -187,10 +187,19 @@ def fused_ok(n: int, which: int) -> bool:
     return bool(int(FUSE_EPILOGUES) & which) and n % 128 == 0
 
 
+# bf16-matmul mode: the c_fc pre-activation kept for the gelu backward is stored rounded to bf16 (its only reader is gelu'; the reference's
+# `bf16_activations` keeps every activation in bf16): 100 instead of 201 MB per block written and read back at the ILQL batch.  False: fp32.
+PRE_BF16 = True
+
+
 def linear_fwd_gelu(mm: "MatmulBF16", xb, w, b, f, gb, ldg, rows, k, n):
     """f[rows][n] fp32 = x @ w + b and gb[rows][ldg] bf16 = gelu_new(f) in one launch (xb: the staged bf16 operand of x).  f None: only gb is
-    written (a forward nobody differentiates)."""
+    written (a forward nobody differentiates).  f a bf16 tensor ([rows][pitch(n)]): the pre-activation rounded to bf16."""
     wt = mm.cast(("wT", w.data_ptr()), w, k, n, n, transpose=True, keep=True)
+    if f is not None and f.dtype == mm.t.bfloat16:
+        _lib.check(_L().lmrl_gemm_bf16_gelu_dual_prebf16(xb.data_ptr(), wt.data_ptr(), _lib.ptr(mm.bias(b, n)), f.data_ptr(), _pitch(n), gb.data_ptr(), ldg, rows, n,
+                                                         _pad(k), _pitch(k), _pitch(k), _sp()), "lmrl_gemm_bf16_gelu_dual_prebf16")
+        return
     _lib.check(_L().lmrl_gemm_bf16_gelu_dual(xb.data_ptr(), wt.data_ptr(), _lib.ptr(mm.bias(b, n)), _lib.ptr(f), n, gb.data_ptr(), ldg, rows, n, _pad(k),
                                              _pitch(k), _pitch(k), _sp()), "lmrl_gemm_bf16_gelu_dual")
 
@@ -212,6 +221,10 @@ def linear_bwd_dx_gelu(mm: "MatmulBF16", dyb, w, pre, rows, k, n):
     operand of the c_fc backward (`linear_bwd(dyb=...)`); dyb: the staged bf16 dy [rows][pitch(n)], w [k][n], pre fp32 [rows][k]."""
     wb = mm.cast(("w", w.data_ptr()), w, k, n, n, keep=True)                     # [k][pad(n)]
     dst, ldd = mm._buf("dy2", _padn(rows) * _pitch(k)), _pitch(k)
+    if pre.dtype == mm.t.bfloat16:                                                # [rows][pitch(k)] bf16 (linear_fwd_gelu with a bf16 f)
+        _lib.check(_L().lmrl_gemm_bf16_gelu_bwd_prebf16(dyb.data_ptr(), wb.data_ptr(), pre.data_ptr(), _pitch(k), dst.data_ptr(), ldd, rows, k, _pad(n), _pitch(n),
+                                                        _pitch(n), _sp()), "lmrl_gemm_bf16_gelu_bwd_prebf16")
+        return dst
     _lib.check(_L().lmrl_gemm_bf16_gelu_bwd(dyb.data_ptr(), wb.data_ptr(), pre.data_ptr(), k, dst.data_ptr(), ldd, rows, k, _pad(n), _pitch(n), _pitch(n),
                                             _sp()), "lmrl_gemm_bf16_gelu_bwd")
     return dst

@@ -358,6 +358,18 @@ def test_c_fc_gelu_and_gelu_backward_epilogues(dev, R):
     dref = xx.grad
     assert rel(d1, d0) <= 1e-4 and rel(d1, dref) <= rel(d0, dref) * 1.001 + 1e-7, (rel(d1, d0), rel(d1, dref), rel(d0, dref))
     assert float(((d1 - dref).abs() / (dref.abs() + 1e-3)).max()) <= 2.0 ** -8
+    # the bf16 pre-activation form (ops.PRE_BF16): f rounded to bf16 by the forward epilogue == the fp32 pre-activation rounded afterwards, the
+    # gelu outputs are the same bits, and the backward reads gelu' at the rounded values — against float64 AT those values: within bf16 rounding
+    fb = torch.empty(R, ops._pitch(N), dtype=torch.bfloat16, device=dev)
+    g2, _ = mm.stash(R, N)
+    ops.linear_fwd_gelu(mm, xb, w, b, fb, g2, ld, R, K, N)
+    torch.cuda.synchronize()
+    assert torch.equal(fb[:, :N], f0.to(torch.bfloat16)) and torch.equal(g2.view(-1, ld)[:R, :N], g1.view(-1, ld)[:R, :N])
+    d2 = ops.linear_bwd_dx_gelu(mm, dyb, w2, fb, R, N, K).view(-1, ops._pitch(N))[:R, :N].double().clone()
+    xb2 = fb[:, :N].double().requires_grad_(True)
+    torch.nn.functional.gelu(xb2, approximate="tanh").backward(dg.double())
+    assert float(((d2 - xb2.grad).abs() / (xb2.grad.abs() + 1e-3)).max()) <= 2.0 ** -8
+    assert rel(d2, dref) <= 4e-3, rel(d2, dref)            # vs gelu' at the unrounded pre-activation: the 2^-9 rounding of its argument
 
 
 def test_arena_weight_staging_equals_per_matrix_casts(dev):
