@@ -654,6 +654,10 @@ int lmrl_flash_attn_bwd(const float *qkv_d, const uint8_t *key_mask_d, const flo
 /* bf16 kernels, d(qkv) written only as the bf16 dy operand [batch*t][ldb] of the c_attn backward products (bf16-matmul train mode) */
 int lmrl_flash_attn_bwd_staged(const float *qkv_d, const uint8_t *key_mask_d, const float *att_d, const float *datt_d, const float *lse_d,
                                void *dqkv_bf16_d, long ldb, void *ws_d, int batch, int heads, int t, int qkv_staged, void *stream);
+/* ... with D = rowsum(dO o O) from the bf16 attention output of lmrl_flash_attn_fwd_staged (att_bf16_d [batch * t][ld_att]); the forward may then be
+ * called with att_d = NULL: no fp32 copy of the attention output exists in the bf16-matmul train mode. */
+int lmrl_flash_attn_bwd_staged_attb(const float *qkv_d, const uint8_t *key_mask_d, const void *att_bf16_d, long ld_att, const float *datt_d, const float *lse_d,
+                                    void *dqkv_bf16_d, long ldb, void *ws_d, int batch, int heads, int t, int qkv_staged, void *stream);
 /* ---- bf16-MFMA matmul mode of the train step (csrc/train_bf16.hip): the reference's optional `bf16_activations`
  * (train_ilql_gpt2.py:193; model dtype bf16, fp32 parameters).  Operands are staged as K-major bf16 matrices for lmrl_gemm_bf16.
  * lmrl_cast_bf16: dst [rows_dst][ld_dst] bf16 := round-to-nearest-even of src [rows][cols] fp32 (transpose = 0) or of its transpose

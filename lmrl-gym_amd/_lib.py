@@ -133,6 +133,7 @@ _SIGS = {
     "lmrl_flash_attn_stage_ptrs": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_long)]),
     "lmrl_flash_attn_finish_staging": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "lmrl_flash_attn_bwd_staged": (c_int, [c_void_p] * 6 + [ctypes.c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "lmrl_flash_attn_bwd_staged_attb": (c_int, [c_void_p] * 3 + [ctypes.c_long] + [c_void_p] * 3 + [ctypes.c_long, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_adamw_segments": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_int, c_void_p]),
     "lmrl_adamw_segments_polyak": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_long, c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_int,
                                            c_void_p, c_float, c_float, c_void_p]),

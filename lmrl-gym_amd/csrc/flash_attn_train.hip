@@ -153,7 +153,9 @@ __device__ __forceinline__ void st_vec8(float *p, const float (&v)[8]) {
 template <class E>
 __global__ __launch_bounds__(256) void flash_stage_kernel(const float *__restrict__ src, long ld, int col0, float scale, typename E::T *__restrict__ Xn,
                                                           typename E::T *__restrict__ XT, const float *__restrict__ other, float *__restrict__ rowdot,
-                                                          int H, int T, int Tp) {
+                                                          int H, int T, int Tp, const uint16_t *__restrict__ other_b = nullptr, long ldob = 0) {
+    // other_b (instead of other): the second factor of the row dot products as bf16 [B*T][ldob] — D = rowsum(dO o O) from the bf16 attention output the
+    // forward wrote for the output projection (then no fp32 copy of O exists)
     __shared__ float tile[64][65];
     __shared__ float prod[64][65];
     const int t0 = blockIdx.x * 64, bh = blockIdx.y, b = bh / H, h = bh - b * H;
@@ -166,10 +168,14 @@ __global__ __launch_bounds__(256) void flash_stage_kernel(const float *__restric
             const long at = ((long)b * T + t) * ld + col0 + h * 64 + c4;
             v = *reinterpret_cast<const f32x4 *>(src + at) * scale;
             if (other) o = *reinterpret_cast<const f32x4 *>(other + at);
+            else if (other_b) {
+                const uint2 u = *reinterpret_cast<const uint2 *>(other_b + ((long)b * T + t) * ldob + col0 + h * 64 + c4);
+                o = f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; e++) tile[r][c4 + e] = v[e];
-        if (other) {
+        if (other || other_b) {
 #pragma unroll
             for (int e = 0; e < 4; e++) prod[r][c4 + e] = v[e] * o[e];
         }
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256) void flash_stage_kernel(const float *__restric
         st_vec8(Xn + ((long)bh * Tp + t0 + r) * 64 + c8, a);
         if (XT) st_vec8(XT + ((long)bh * 64 + r) * Tp + t0 + c8, bt);      // null: the round-4 bf16 sweeps read the natural matrix both ways
     }
-    if (other && threadIdx.x < 64) {
+    if ((other || other_b) && threadIdx.x < 64) {
         float s = 0.f;
         for (int c = 0; c < 64; c++) s += prod[threadIdx.x][c];
         rowdot[(long)bh * Tp + t0 + threadIdx.x] = s;
@@ -1122,7 +1128,7 @@ static int flash_fwd(const float *qkv, const uint8_t *km, float *att, float *lse
 
 template <class E>
 static int flash_bwd(const float *qkv, const uint8_t *km, const float *att, const float *datt, const float *lse, float *dqkv, uint16_t *dqb,
-                     long ldb, void *ws, int batch, int heads, int t, hipStream_t s, int qkv_staged) {
+                     long ldb, void *ws, int batch, int heads, int t, hipStream_t s, int qkv_staged, const uint16_t *att_b = nullptr, long ld_attb = 0) {
     typedef typename E::T T;
     const int tp = (t + 63) / 64 * 64, bh = batch * heads, d = heads * 64;
     FlashWs w; w.carve(ws, bh, tp, E::SZ);
@@ -1132,7 +1138,7 @@ static int flash_bwd(const float *qkv, const uint8_t *km, const float *att, cons
     }
     const bool need_dot = E::SZ != 2 || (g_flash_variant & 6) != 0;         // fp32 sweeps and the round-3 bf16 dQ / dK/dV read dO^T
     hipLaunchKernelGGL(flash_stage_kernel<E>, dim3(tp / 64, bh), dim3(256), 0, s, datt, (long)d, 0, 1.f, (T *)w.dOn, need_dot ? (T *)w.dOT : (T *)nullptr, att, w.D,
-                       heads, t, tp);
+                       heads, t, tp, att ? (const uint16_t *)nullptr : att_b, ld_attb);
     LMRL_CHECK_LAUNCH();
     const size_t lds_q = 3 * E::TILE + 64, lds_kv = 4 * E::TILE + 512;
     constexpr bool PFQ = FlashPrefetch<E>::dq, PFKV = FlashPrefetch<E>::dkv;
@@ -1227,6 +1233,16 @@ int lmrl_flash_attn_bwd_staged(const float *qkv_d, const uint8_t *key_mask_d, co
                      heads > 0 && t > 0, "lmrl_flash_attn_bwd_staged: bad argument");
     return flash_bwd<ElemBF16>(qkv_d, key_mask_d, att_d, datt_d, lse_d, nullptr, (uint16_t *)dqkv_bf16_d, ldb, ws_d, batch, heads, t, as_stream(stream),
                                qkv_staged);
+}
+
+// lmrl_flash_attn_bwd_staged with D = rowsum(dO o O) taken from the bf16 attention output the forward wrote for the output projection
+// (att_bf16_d [batch * t][ld_att]): the forward then needs no fp32 copy of O at all (lmrl_flash_attn_fwd_staged with att_d = NULL)
+int lmrl_flash_attn_bwd_staged_attb(const float *qkv_d, const uint8_t *key_mask_d, const void *att_bf16_d, long ld_att, const float *datt_d, const float *lse_d,
+                                    void *dqkv_bf16_d, long ldb, void *ws_d, int batch, int heads, int t, int qkv_staged, void *stream) {
+    LMRL_REQUIRE((qkv_d || qkv_staged) && att_bf16_d && ld_att >= heads * 64 && ld_att % 4 == 0 && datt_d && lse_d && dqkv_bf16_d && ws_d && ldb >= 3 * heads * 64 &&
+                     ldb % 4 == 0 && batch > 0 && heads > 0 && t > 0, "lmrl_flash_attn_bwd_staged_attb: bad argument");
+    return flash_bwd<ElemBF16>(qkv_d, key_mask_d, nullptr, datt_d, lse_d, nullptr, (uint16_t *)dqkv_bf16_d, ldb, ws_d, batch, heads, t, as_stream(stream),
+                               qkv_staged, (const uint16_t *)att_bf16_d, ld_att);
 }
 
 }  // extern "C"

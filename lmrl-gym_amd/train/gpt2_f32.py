@@ -145,7 +145,7 @@ class GPT2F32:
         else:
             qkv = new(R, 3 * d)
             ops.linear_fwd(h1, p[q + "attn.c_attn.weight"], p[q + "attn.c_attn.bias"], qkv, R, d, 3 * d, mm=self.mm, xb=h1b)
-        att = None if lean else new(R, d)
+        att = None if (lean or (stage and flash and ops.D_FROM_BF16_O)) else new(R, d)       # bf16 mode: the backward takes D from the bf16 output
         attb = None
         if flash:
             P = None
@@ -385,7 +385,8 @@ class GPT2F32:
             qkv, P = c["qkv"], c["P"]
             dqkv, dqkvb = None, None
             if cache["flash"] and mm is not None:
-                dqkvb = ops.flash_attn_bwd_staged(mm, qkv, cache["km"], c["att"], datt, c["lse"], c["flash_ws"], B, H, T, qkv_staged=True)
+                dqkvb = ops.flash_attn_bwd_staged(mm, qkv, cache["km"], c["att"], datt, c["lse"], c["flash_ws"], B, H, T, qkv_staged=True,
+                                                  attb=c.get("attb"), ld_attb=ops._pitch(d))
             elif cache["flash"]:
                 dqkv = new(R, 3 * d)
                 ops.flash_attn_bwd(qkv, cache["km"], c["att"], datt, c["lse"], dqkv, c["flash_ws"], B, H, T, False, qkv_staged=True)

@@ -523,9 +523,18 @@ def flash_attn_bwd(qkv, key_mask, att, datt, lse, dqkv, ws, batch, heads, t, bf1
                                         ws.data_ptr(), batch, heads, t, int(bf16), int(qkv_staged), _sp()), "lmrl_flash_attn_bwd")
 
 
-def flash_attn_bwd_staged(mm, qkv, key_mask, att, datt, lse, ws, batch, heads, t, qkv_staged=False):
-    """bf16 kernels; d(qkv) written only as the bf16 dy operand of the c_attn `linear_bwd(dyb=...)`"""
+# bf16-matmul mode: D = rowsum(dO o O) of the flash backward from the bf16 attention output (the projection's operand) — no fp32 copy of O is written
+# by the forward or read by the backward (50 MB per block each way at the ILQL batch).  False: the fp32 copy, as before.
+D_FROM_BF16_O = True
+
+
+def flash_attn_bwd_staged(mm, qkv, key_mask, att, datt, lse, ws, batch, heads, t, qkv_staged=False, attb=None, ld_attb=0):
+    """bf16 kernels; d(qkv) written only as the bf16 dy operand of the c_attn `linear_bwd(dyb=...)`.  att None: D from the bf16 output `attb`."""
     dst, ldb = mm.stage_dy(batch * t, 3 * heads * 64)
+    if att is None:
+        _lib.check(_L().lmrl_flash_attn_bwd_staged_attb(_lib.ptr(qkv), _lib.ptr(key_mask), attb.data_ptr(), ld_attb, datt.data_ptr(), lse.data_ptr(), dst.data_ptr(),
+                                                        ldb, ws.data_ptr(), batch, heads, t, int(qkv_staged), _sp()), "lmrl_flash_attn_bwd_staged_attb")
+        return dst
     _lib.check(_L().lmrl_flash_attn_bwd_staged(_lib.ptr(qkv), _lib.ptr(key_mask), att.data_ptr(), datt.data_ptr(), lse.data_ptr(), dst.data_ptr(), ldb,
                                                ws.data_ptr(), batch, heads, t, int(qkv_staged), _sp()), "lmrl_flash_attn_bwd_staged")
     return dst

@@ -77,6 +77,15 @@ def test_flash_attention_fwd_bwd(B, T, H, pad, bf16):
         dst = ops.flash_attn_bwd_staged(mm, qkv, km, att, datt, lse, ws, B, H, T, qkv_staged=True)
         ldb = ops._pitch(3 * d)
         assert torch.equal(dst[: B * T * ldb].view(B * T, ldb)[:, : 3 * d], dqkv.to(torch.bfloat16))
+        # D = rowsum(dO o O) from the bf16 copy of the attention output (ops.D_FROM_BF16_O: no fp32 O in the bf16-matmul train mode): within the bf16 tolerance
+        lda = ops._pitch(d)
+        attb = torch.zeros(B * T, lda, dtype=torch.bfloat16, device=dev)
+        attb[:, :d] = att.to(torch.bfloat16)
+        dst2 = ops.flash_attn_bwd_staged(mm, qkv, km, None, datt, lse, ws, B, H, T, qkv_staged=True, attb=attb, ld_attb=lda)
+        g2 = dst2[: B * T * ldb].view(B * T, ldb)[:, : 3 * d].double().cpu()
+        for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+            scale = float(g_ref[:, sl].abs().max()) or float(g_ref.abs().max())
+            assert float((g2[:, sl] - g_ref[:, sl]).abs().max()) / scale <= tol, name
 
 
 def test_flash_and_materialized_train_paths_agree():
