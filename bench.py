@@ -754,7 +754,7 @@ def main():
         if rank == 0:
             out["train_step"] = ts
     if rank == 0:
-        if world == 1 and not args.no_batch_sweep and B == 1024 and S == 1:
+        if world == 1 and not args.no_batch_sweep and not args.no_cpu_baseline and B == 1024 and S == 1 and args.graph:       # the full default line only (the profiling tools pass --no-cpu-baseline)
             # the same engine, kernels and timed region at 4096 envs per GPU (a child process: this one's sessions and graphs stay as they are).  Not the
             # metric's configuration (1024 envs) — reported because the roofline kernel's fraction is a function of the launch size: north_star's
             # ">= 100 k env-steps/s at >= 60 % of the HBM roofline" holds together from 4096 envs per GPU up (profiles/r04_bench_batch_sweep.txt)
