@@ -363,16 +363,16 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const typename E::T *__r
 // ------------------------------------------------------------------------------------------ forward, bf16, round 4
 // Same arithmetic and operand layouts as flash_fwd_kernel<ElemBF16>, rebuilt around what tools/pmc_flash.sh and the timing-only ablations of
 // tools/bench_flash_ablate.py showed (the sweep is bound by VALU issue + exposed latencies, not by MFMA rate; profiles/r04_flash_*):
-//   * K / V^T tiles go L2 -> LDS with global_load_lds into a 2-slot ring (the GEMM kernels' lane-linear image + source-side XOR swizzle): the
-//     next block's tiles land while the current block is computed; ONE barrier per key block, no staging registers, no ds_write pass — and
-//     with that 117 VGPRs: four waves per SIMD (the register-staged kernel holds 124 + the MFMA results in AGPRs)
-//   * XCD-aware 1-D grid: all query tiles of one (batch, head) run on ONE XCD, longest sweep first, so its K / V^T enter that L2 once
-//   * key validity as a 64-bit ballot (no LDS bytes, no per-block LDS scan); blocks below the diagonal with all keys valid take a
-//     straight-line path in which all 8 QK^T MFMAs are issued before the first score is read
+//   * K / V tiles (natural rows, see below) go L2 -> LDS with global_load_lds into a 2-slot ring (the GEMM kernels' lane-linear image + source-side
+//     XOR swizzle): the next block's tiles land while the current block is computed; ONE barrier per key block, no staging registers, no ds_write
+//     pass — and with that 109-118 VGPRs: four waves per SIMD (the register-staged kernel holds 124 + the MFMA results in AGPRs)
+//   * XCD-aware 1-D grid: all query tiles of one (batch, head) run on ONE XCD, longest sweep first, so its K / V enter that L2 once
+//   * key validity: one byte per key in LDS for the whole row (written once per workgroup), a 64-bit ballot per block; blocks below the diagonal
+//     with all keys valid take a straight-line path in which all 8 QK^T MFMAs are issued before the first score is read
 //   * exp(s - m) as v_exp_f32(fma(s, log2 e, -m log2 e)); the 4-row max / sum reductions with v_permlane16_swap / v_permlane32_swap
 //     (VALU) instead of ds_bpermute
-//   * K fragments are read from LDS conflict-free: the K tile's chunk swizzle follows the row set one ds_read_b128 lane group touches
-// Measured (B = 32, H = 12, 10 back to back): T = 512 70.7 -> 48.8 us, T = 1024 174.9 -> 135.6 us.  Also measured: two query groups per wave
+//   * one chunk swizzle (flash_swz, below) that is conflict-free for both kinds of fragment read
+// Measured (B = 32, H = 12, 10 back to back): T = 512 70.7 -> 46.9 us, T = 1024 174.9 -> 130.9 us (8-wave workgroups; 4 waves: 48.3 / 134.6).  Also measured: two query groups per wave
 // (128-query workgroups, every fragment read feeds two MFMAs) 63 / 189 us at 168 VGPRs = three waves per SIMD — occupancy beats reuse here.
 // Every tile of the round-4 sweeps is a NATURAL [64 rows][64 head dims] block (128-byte rows) read two ways from the same LDS image:
 //   * row fragments ("8 consecutive head dims of row r", the QK^T / dP operand: rows slab_row(lr) + 4 hf + 32 p, chunk 4 sl + lq) by ds_read_b128
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(64 * NW, 4) void flash_fwd2_bf16_kernel(const uint1
     constexpr int SLOT = 2 * E::TILE, QT = 16 * NW, OPS = 2 * (8 / NW);     // OPS: tile DMAs per wave per key block
     uint8_t *sKey = reinterpret_cast<uint8_t *>(smem + RS * SLOT);             // [Tp] key validity of the whole row of this batch element
     // XCD-aware 1-D grid: workgroup id -> XCD id % 8 (observed placement, as in gemm_bf16.h).  All query tiles of one (batch, head) go to ONE XCD,
-    // consecutively and longest sweep first: its K / V^T (2 x Tp x 128 B) enter that XCD's L2 once and the other tiles' fills hit there,
+    // consecutively and longest sweep first: its K / V (2 x Tp x 128 B) enter that XCD's L2 once and the other tiles' fills hit there,
     // instead of eight L2s each pulling every head's tiles over the fabric.  Heads beyond the last full group of 8 wrap onto the XCDs in order.
     const int nq = (Tp + QT - 1) / QT;
     int bh, qb;
