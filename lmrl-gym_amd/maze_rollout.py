@@ -81,6 +81,12 @@ class MazeRolloutEngine:
                  q2_head: Optional[dict] = None, beta: float = 0.0, session_flags: int = FWD_RAGGED_ALWAYS):
         import torch
         t = torch
+        # text_env_eval(concurrent=n): a twin engine needs its own vectorised env (device state) — possible when the caller handed over a MazeEnv
+        self._twin_args = dict(tokenizer=tokenizer, env=env if isinstance(env, M.MazeEnv) else None, batch=batch, max_new_tokens=max_new_tokens,
+                               eos_token_id=eos_token_id, max_input_length=max_input_length, in_str_process=in_str_process, prefix_cache=prefix_cache,
+                               prefix_indexed=prefix_indexed, max_turns=max_turns, value_engine=value_engine, q1_head=q1_head, q2_head=q2_head, beta=beta,
+                               session_flags=session_flags)
+        self._lanes = None
         venv = env.as_batched() if isinstance(env, M.MazeEnv) else env
         if venv.last_k != 1:
             raise ValueError("MazeRolloutEngine: the device loop covers one-item histories (last_k = 1); use interact_environment with "
@@ -159,6 +165,12 @@ class MazeRolloutEngine:
             self._L.lmrl_maze_tok_destroy(self._tok)
             self._tok = None
         self.env.close()
+        self._drop_lanes()
+
+    def _drop_lanes(self):
+        for twin, _ in (self._lanes or [])[1:]:
+            twin.close()
+        self._lanes = None
 
     # ---- prompt-prefix cache ------------------------------------------------------------------------------------------------------
     def refresh_prefix_cache(self):
@@ -183,6 +195,7 @@ class MazeRolloutEngine:
         self.eng = self.engines[0] = engine
         self.sessions[0] = self.ses = engine.session(self.B, self.ses.tmax, flags=self.ses.flags)
         self.turn_graph = None
+        self._drop_lanes()          # twins hold the old weights' sessions / prefix caches: rebuilt on the next concurrent call
         if self.prefix_cache:
             self.refresh_prefix_cache()
 
@@ -248,6 +261,16 @@ class MazeRolloutEngine:
                     use_graph: bool = False, sync_every: int = 8, max_turns: Optional[int] = None):
         """One full episode for all B envs; returns the device record dict (read after a sync).  The host peeks at the live flags every
         `sync_every` turns to stop early (0: never — fixed T turns, fully asynchronous)."""
+        turn = self._episode_begin(seeds, options, temperature, top_k, sample_seed, episode, use_graph)
+        n = self.T if max_turns is None else min(self.T, max_turns)
+        for i in range(n):
+            if sync_every and i and i % sync_every == 0 and not bool(self.traj["live"].any().item()):
+                break
+            turn()
+        return self.traj
+
+    def _episode_begin(self, seeds, options, temperature, top_k, sample_seed, episode, use_graph):
+        """Reset + first bookkeeping of an episode on the CURRENT stream; returns the callable that enqueues one lock-step turn."""
         import torch
         t = torch
         if use_graph:
@@ -260,15 +283,7 @@ class MazeRolloutEngine:
         self.env.reset_device(list(seeds), options)
         _lib.check(self._L.lmrl_maze_tok_begin(self._tok, ctypes.byref(self._ctraj), self.B, _lib.stream_ptr()), "maze_tok_begin")
         self.epoch.fill_(int(episode) << 12)
-        n = self.T if max_turns is None else min(self.T, max_turns)
-        for turn in range(n):
-            if sync_every and turn and turn % sync_every == 0 and not bool(self.traj["live"].any().item()):
-                break
-            if use_graph:
-                self.turn_graph.replay()
-            else:
-                self._turn(temperature, top_k, sample_seed, logits)
-        return self.traj
+        return self.turn_graph.replay if use_graph else (lambda: self._turn(temperature, top_k, sample_seed, logits))
 
     # ---- host views ----------------------------------------------------------------------------------------------------------------
     def records(self):
@@ -297,48 +312,159 @@ class MazeRolloutEngine:
     def interactions(self):
         """The finished episodes as `List[List[InteractionTransition]]` — what `interact_environment` returns for the same rollouts
         (LLM_RL/environment.py:154-207; histories per maze/env/env.py:161-184 with last_k = 1)."""
+        h = {k: v.cpu().numpy() for k, v in self.traj.items() if k in ("pos", "gen", "gen_len", "reward", "kind", "n_turns")}
+        return self._build_interactions(h, self.env.positions())
+
+    def snapshot_records(self):
+        """Enqueue device -> pinned-host copies of the episode record and the env state behind the episode's kernels (current stream) and return a
+        handle for `_build_interactions_from(handle)`: the buffers may be reused by the next episode as soon as this returns (stream order)."""
+        import torch
+        names = ("pos", "gen", "gen_len", "reward", "kind", "n_turns")
+        if getattr(self, "_pinned", None) is None:
+            mk = lambda x: torch.empty(x.shape, dtype=x.dtype, pin_memory=True)
+            self._pinned = [dict({n: mk(self.traj[n]) for n in names}, state=mk(self.env.state)) for _ in range(2)]
+            self._pin_i = 0
+        buf = self._pinned[self._pin_i]
+        self._pin_i ^= 1
+        for n in names:
+            buf[n].copy_(self.traj[n], non_blocking=True)
+        buf["state"].copy_(self.env.state, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return buf, ev
+
+    def _build_interactions_from(self, handle):
+        import gc
+        buf, ev = handle
+        ev.synchronize()
+        was = gc.isenabled()
+        gc.disable()                    # tens of thousands of live tuples are created: no cyclic garbage among them (as WordleRolloutEngine)
+        try:
+            return self._build_interactions({k: v.numpy() for k, v in buf.items() if k != "state"}, buf["state"].numpy().T)
+        finally:
+            if was:
+                gc.enable()
+
+    def _build_interactions(self, h, st):
+        """Host lists from host copies of the record (`h`) and the env state rows (`st`: row, col, goal row, goal col per env).  The observation
+        texts are the ones rendered once per (goal, cell) for the token table (`_obs_text`: the same `describe_function` call the reference makes
+        per step); Text objects are immutable and shared; generated ids are decoded once per distinct sequence."""
         from .environment import InteractionTransition, Text
-        maze = self.env.maze
+        C = self.env.maze.shape[1]
+        obs_cache, act_cache = self.__dict__.setdefault("_obs_Text", {}), {}
+        fail, succ = (Text("Failure\n", False),), (Text("Success\n", False),)
+
+        def desc(gi, r, c):
+            key = (gi, r, c)
+            t = obs_cache.get(key)
+            if t is None:
+                t = obs_cache[key] = (Text(self._obs_text[key], False),)
+            return t
+
+        def action(ids):
+            t = act_cache.get(ids)
+            if t is None:
+                t = act_cache[ids] = Text(maze_out_str_process(self._decode(list(ids))), True)
+            return t
+        pos, gen, gen_len, reward, kinds, n_turns = h["pos"], h["gen"], h["gen_len"], h["reward"], h["kind"], h["n_turns"]
         out = []
-        for rec in self.records():
-            g = [rec["goal"][0], rec["goal"][1]]
-            desc = lambda p: Text(self.env.describe_function(maze, [int(p[0]), int(p[1])], g, None, []), False)
-            n = len(rec["gen"])
+        for b in range(self.B):
+            n = int(n_turns[b])
+            gi = int(self.goal_slot[int(st[b, 2]) * C + int(st[b, 3])])
+            pr, pc = (pos[b, :n] >> 16).tolist(), (pos[b, :n] & 0xFFFF).tolist()
+            gl, kd, rw = gen_len[b, :n].tolist(), kinds[b, :n].tolist(), reward[b, :n].tolist()
+            gb = gen[b]
             trans = []
             for i in range(n):
-                pre = (desc(rec["pos"][i]),)
-                post_action = pre + (Text(maze_out_str_process(self._decode(rec["gen"][i])), True),)
-                kind = int(rec["kind"][i])
+                pre = desc(gi, pr[i], pc[i])
+                post_action = pre + (action(tuple(gb[i, :gl[i]].tolist())),)
+                kind = kd[i]
                 if kind == M.KIND_FAILURE:
-                    post, done = (Text("Failure\n", False),), True
+                    post, done = fail, True
                 elif kind == M.KIND_SUCCESS:
-                    post, done = (Text("Success\n", False),), True
+                    post, done = succ, True
                 else:
-                    nxt = rec["pos"][i + 1] if i + 1 < n else rec["final_pos"]
-                    post, done = (desc(nxt),), False
-                trans.append(InteractionTransition(pre, post_action, post, float(rec["reward"][i]), done))
+                    post, done = (desc(gi, pr[i + 1], pc[i + 1]) if i + 1 < n else desc(gi, int(st[b, 0]), int(st[b, 1]))), False
+                trans.append(InteractionTransition(pre, post_action, post, float(rw[i]), done))
             out.append(trans)
         return out
 
+    def _eval_lanes(self, n: int, main):
+        """[(engine, stream)]: this engine on the caller's stream + n - 1 twins (same weights, tokenizer and maze; own env state, sessions, prefix
+        cache, records and turn graph) on their own streams.  Built once, dropped by `set_params`."""
+        import torch
+        if self._twin_args["env"] is None:
+            return [(self, main)]                   # built from an already vectorised env: no second env state to be had
+        if self._lanes is None:
+            self._lanes = [(self, None)]
+        while len(self._lanes) < n:
+            st = torch.cuda.Stream(device=self.dev)
+            with torch.cuda.stream(st):
+                twin = MazeRolloutEngine(self.eng, **self._twin_args)
+            self._lanes.append((twin, st))
+        return [(self, main)] + self._lanes[1:n]
+
     def text_env_eval(self, n_rollouts: int, seed_generator=None, env_options=None, temperature: float = 1.0, top_k: int = 0,
-                      sample_seed: int = 0, interaction_callback=None, use_graph: bool = True):
+                      sample_seed: int = 0, interaction_callback=None, use_graph: bool = True, concurrent: int = 1, sync_every: int = 8):
         """`text_env_eval(env, policy, n_rollouts, bsize=B, env_options=...)` (LLM_RL/environment.py:211-267) with the whole lock-step
         loop on the device: ceil(n / B) episode batches, the same (interactions, summary) return value.  The sampler's episode word keeps
         counting across calls (`self.episodes`, as GPT2PPOPolicy splits its PRNG key on every act(), ppo/gpt2/interface.py:524-526): two PPO
         rounds with the same `sample_seed` do not replay the same noise."""
+        import torch
         inter, rewards, dones, lengths = [], [], [], []
-        while len(inter) < n_rollouts:
-            actual = min(n_rollouts - len(inter), self.B)
-            seeds = [0] * self.B
-            seeds[:actual] = [next(seed_generator) for _ in range(actual)] if seed_generator is not None else \
-                np.random.randint(0, 2 ** 31 - 1, size=actual).tolist()
-            options = [env_options] * self.B if env_options is not None else None
-            self.run_episode(seeds, options, temperature=temperature, top_k=top_k, sample_seed=sample_seed, episode=self.episodes, use_graph=use_graph)
-            self.episodes += 1
-            for ep in self.interactions()[:actual]:
-                inter.append(ep)
-                rewards.append(sum(t.reward for t in ep)); dones.append(ep[-1].done); lengths.append(len(ep))
-                if interaction_callback is not None:
-                    interaction_callback(ep)
+        main = torch.cuda.current_stream(self.dev)
+        n_batches = -(-n_rollouts // self.B)
+        lanes = self._eval_lanes(min(int(concurrent), n_batches), main) if concurrent > 1 and n_batches >= 2 else [(self, main)]
+        for _, st in lanes[1:]:
+            st.wait_stream(main)
+        options = [env_options] * self.B if env_options is not None else None
+
+        def absorb(handles):
+            for eng, handle, actual in handles or ():
+                for ep in eng._build_interactions_from(handle)[:actual]:
+                    inter.append(ep)
+                    rewards.append(sum(t.reward for t in ep)); dones.append(ep[-1].done); lengths.append(len(ep))
+                    if interaction_callback is not None:
+                        interaction_callback(ep)
+        launched, pending = 0, None
+        while launched < n_rollouts:
+            # one GROUP of up to len(lanes) episode batches, their turns enqueued alternately: every lane is a dependent chain of small launches,
+            # two chains fill each other's idle CUs (as WordleRolloutEngine.text_env_eval(concurrent=n)); batches are independent in the reference too
+            group = []
+            for eng, st in lanes:
+                if launched >= n_rollouts:
+                    break
+                actual = min(n_rollouts - launched, self.B)
+                seeds = [0] * self.B
+                seeds[:actual] = [next(seed_generator) for _ in range(actual)] if seed_generator is not None else \
+                    np.random.randint(0, 2 ** 31 - 1, size=actual).tolist()
+                with torch.cuda.stream(st):
+                    turn = eng._episode_begin(seeds, options, temperature, top_k, sample_seed, self.episodes, use_graph)
+                self.episodes += 1
+                launched += actual
+                group.append([eng, st, turn, actual, True])
+            for i in range(self.T):
+                if sync_every and i and i % sync_every == 0:
+                    for g in group:
+                        if g[4]:
+                            with torch.cuda.stream(g[1]):
+                                g[4] = bool(g[0].traj["live"].any().item())       # waits for THIS lane's stream only; the other lanes' queued turns keep running
+                    if not any(g[4] for g in group):
+                        break
+                for g in group:
+                    if g[4]:
+                        with torch.cuda.stream(g[1]):
+                            g[2]()
+            handles = []
+            for eng, st, _, actual, _ in group:
+                with torch.cuda.stream(st):
+                    handles.append((eng, eng.snapshot_records(), actual))
+            # the previous group's host lists are built now, while this group's turns run on the device (sync_every = 0: everything above was
+            # enqueued without waiting; with early-exit peeks the host has already waited for most of it)
+            absorb(pending)
+            pending = handles
+        absorb(pending)
+        for _, st in lanes[1:]:
+            main.wait_stream(st)
         summ = lambda x: dict(mean=np.mean(x), std=np.std(x), min=np.min(x), max=np.max(x))
         return inter, dict(reward=summ(np.asarray(rewards, dtype=np.float32)), done=summ(np.asarray(dones, dtype=np.float32)), length=summ(lengths))

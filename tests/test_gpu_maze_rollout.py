@@ -171,3 +171,21 @@ def test_greedy_device_loop_equals_generic_text_path():
     assert n_steps >= B * 3
     kinds = {t.post_action_history[-1].text for ep in mine for t in ep}
     assert len(kinds) >= 3, kinds                                # several distinct actions were taken
+
+
+def test_text_env_eval_lanes_return_the_one_lane_interactions():
+    """`MazeRolloutEngine.text_env_eval(concurrent=2)`: two episode batches in flight on twin engines / two HIP streams (their turns enqueued
+    alternately).  Every batch draws its own noise (the episode word), independent of the lane it runs on: the interactions of 5 batches must
+    equal the one-lane call's, transition for transition and in the same order; the early-exit peeks are per lane."""
+    from lmrl_gym_amd import _lib
+    dev = _lib.require_gpu()
+    B, max_new, max_steps = 32, 3, 9
+    out = []
+    for lanes in (1, 2):
+        eng, *_ = _setup(dev, B, max_new, max_steps)
+        inter, summ = eng.text_env_eval(5 * B - 3, seed_generator=iter(range(400, 4000)), temperature=0.8, sample_seed=3, use_graph=True, concurrent=lanes,
+                                        sync_every=4)
+        assert (eng._lanes is not None and len(eng._lanes) == 2) == (lanes == 2)
+        out.append((inter, summ))
+        eng.close()
+    assert len(out[0][0]) == 5 * B - 3 and out[0][0] == out[1][0] and out[0][1] == out[1][1]
