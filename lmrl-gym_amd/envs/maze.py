@@ -188,8 +188,15 @@ class VectorMazeEnv(BatchedTextEnv):
         return self.state.cpu().numpy().T.copy()
 
     def _describe(self, st_row, i: int) -> str:
-        return self.describe_function(self.maze, [int(st_row[0]), int(st_row[1])], [int(st_row[2]), int(st_row[3])],
-                                      self.initial_positions[i], self.move_history[i])
+        pos, goal = [int(st_row[0]), int(st_row[1])], [int(st_row[2]), int(st_row[3])]
+        if self.describe_function in _DESCRIBERS.values():      # the module's describers depend on (position, goal) only: render each pair once
+            memo = self.__dict__.setdefault("_describe_memo", {})
+            key = (pos[0], pos[1], goal[0], goal[1])
+            text = memo.get(key)
+            if text is None:
+                text = memo[key] = self.describe_function(self.maze, pos, goal, None, [])
+            return text
+        return self.describe_function(self.maze, pos, goal, self.initial_positions[i], self.move_history[i])
 
     def reset_device(self, seed, options=None) -> None:
         """MazeEnv.reset for len(seed) envs without leaving the device: state only, no observation text (device rollout loops)."""

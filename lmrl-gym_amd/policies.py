@@ -110,11 +110,17 @@ class GPT2PPOPolicy(BatchedTextPolicy):
         eos_str = self.tokenizer.decode([self.eos]) if self.eos is not None else ""
         raw = [eos_str if d else self.in_str_process(text_history_to_str(h)) for h, d in zip(text_history, done)]
         prompts = []
+        memo = self.__dict__.setdefault("_encode_memo", {})    # prompt string -> ids: envs with few distinct observations (Maze: 130) repeat them every turn
+        if len(memo) > 65536:
+            memo.clear()
         for s in raw:
-            ids = list(self.tokenizer.encode(s))
-            if len(ids) > self.max_input_length:           # Truncation.LEFT
-                ids = ids[len(ids) - self.max_input_length:]
-            prompts.append(ids if ids else [self.pad])
+            ids = memo.get(s)
+            if ids is None:
+                ids = list(self.tokenizer.encode(s))
+                if len(ids) > self.max_input_length:       # Truncation.LEFT
+                    ids = ids[len(ids) - self.max_input_length:]
+                ids = memo[s] = ids if ids else [self.pad]
+            prompts.append(ids)
         tmax = -(-(self.max_input_length + self.max_new_tokens + 16) // 16) * 16
         if self._gen is None or self._gen.B != B or self._gen.tmax != tmax:
             self._gen = _Generator(self._engines(), B, tmax)
