@@ -1136,6 +1136,13 @@ static int flash_bwd(const float *qkv, const uint8_t *km, const float *att, cons
         int rc = flash_stage_qkv<E>(qkv, w, batch, heads, t, tp, s);
         if (rc) return rc;
     }
+    if (E::SZ == 2 && qkv_staged && (g_flash_variant & 6)) {
+        // a round-3 bf16 sweep is selected NOW: it reads Q^T / K^T, which the forward's staging wrote only if a round-3 bit was set THEN
+        // (lmrl_flash_attn_finish_staging).  Derive them here from the natural forms, so a variant flipped between a forward and its backward
+        // (tools / A-B tests) cannot make the sweeps read uninitialised transposes; the default path (variant 0) never gets here.
+        hipLaunchKernelGGL(flash_transpose_staged_kernel, dim3(tp / 64, bh, 3), dim3(256), 0, s, (uint16_t *)w.Qn, (uint16_t *)w.QT,
+                           (long)(FlashWs::mat_bytes(bh, tp, 2) / 2), t, tp);
+    }
     const bool need_dot = E::SZ != 2 || (g_flash_variant & 6) != 0;         // fp32 sweeps and the round-3 bf16 dQ / dK/dV read dO^T
     hipLaunchKernelGGL(flash_stage_kernel<E>, dim3(tp / 64, bh), dim3(256), 0, s, datt, (long)d, 0, 1.f, (T *)w.dOn, need_dot ? (T *)w.dOT : (T *)nullptr, att, w.D,
                        heads, t, tp, att ? (const uint16_t *)nullptr : att_b, ld_attb);

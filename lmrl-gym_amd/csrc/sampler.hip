@@ -17,6 +17,7 @@
 // greedy decoding (temperature == 0) is deterministic and is what parity tests pin.
 #include "../../include/lmrl_amd.h"
 #include "common.h"
+#include <atomic>
 #include "gemm_dispatch.h"
 #include "threefry.h"
 
@@ -580,11 +581,16 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     if (persist) {
         const int grid = 512;                                          // 2 workgroups per CU x 256 CUs (a multiple of 8: XCD affinity preserved)
         const size_t shp = shmem + (size_t)kLmWM * (kLmBM / kLmWM) * (kLmWN - 1) * 5 * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        // the dynamic-LDS opt-in is a PER-DEVICE function attribute: one bit per device ordinal, set on the first launch there (the eager warm-up
+        // episode, i.e. before any graph capture on that device); atomic: ranks / lanes may arrive from several host threads
+        static std::atomic<unsigned long long> attr_set{0ull};
+        int dev_id = 0;
+        LMRL_CHECK_HIP(hipGetDevice(&dev_id));
+        const unsigned long long dev_bit = 1ull << (dev_id & 63);
+        if (dev_id >= 64 || !(attr_set.load(std::memory_order_acquire) & dev_bit)) {
             LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp));
             LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp));
-            attr_set = true;
+            attr_set.fetch_or(dev_bit, std::memory_order_release);
         }
         const int rounds = tiles / grid, n_tail = tiles - rounds * grid;          // ids: xcd_grid(xm) (a multiple of 8), a few of them surplus
         if (lp) hipLaunchKernelGGL((lm_head_sample_persist_kernel<true>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,

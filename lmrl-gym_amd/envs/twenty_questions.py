@@ -307,7 +307,7 @@ class _LockStepGames:
 
     def __init__(self, word_list: Sequence[WordVariants], max_conversation_length: int, slots: int):
         import numpy as np
-        self.word_list, self.max_len = list(word_list), int(max_conversation_length)
+        self.word_list, self.max_len = word_list, int(max_conversation_length)     # the caller's list itself: later edits of env.word_list are seen
         self.word_idx = np.full(slots, -1, dtype=np.int64)
         self.rngs = [random.Random(None) for _ in range(slots)]
 
@@ -358,6 +358,7 @@ class TwentyQuestionsPolicyEnvironment(TextEnv):
     def __init__(self, oracle: TwentyQuestionsOracle, word_list: List[WordVariants], max_conversation_length: int = 20):
         self.oracle, self.word_list, self.max_conversation_length = oracle, word_list, max_conversation_length
         self._games = _LockStepGames(word_list, max_conversation_length, 1)
+        self.count = 0                       # questions asked since the last reset (public in the reference env: env.py:27,40,56)
 
     @property
     def curr_word(self) -> Optional[WordVariants]:
@@ -368,6 +369,7 @@ class TwentyQuestionsPolicyEnvironment(TextEnv):
         return self._games.rngs[0]
 
     def reset(self, seed: Optional[int] = None, options: Optional[Dict] = None) -> TextHistory:
+        self.count = 0
         self._games.draw([seed], [options], reseed_none=False)     # seed None: the generator this env already has keeps running
         return (Text(INITIAL_STR, False),)
 
@@ -375,6 +377,7 @@ class TwentyQuestionsPolicyEnvironment(TextEnv):
         # a single word / question goes to the oracle un-batched, as the reference's single env calls it
         word = self._games.words()[0]
         assert text_history[-1].is_action, "the last item of a history handed to step() must be the question (an action)"
+        self.count += 1
         answer = self.oracle.generate_answers(word, text_history[-1].text.strip())
         full = tuple(text_history) + (Text(answer + "\n", False),)
         _, guessed, done = _verdicts([word], [full], self.max_conversation_length)

@@ -56,9 +56,22 @@ class GPT2EngineF32:
                     p[n + ".x3"] = x3(p[n].t().contiguous())
             self.wte_x3 = x3(self.wte)
 
-    def linear(self, x, rows, k, n, w_name, p, y, scratch, gelu_split=None):
+    def splitk_ws_bytes(self, rows: int) -> int:
+        """Bytes of split-K partial-sum workspace ONE caller needs for this engine's products on `rows` rows (0: no product takes the split-K
+        path).  The workspace belongs to the CALLER (a KV session sizes it once, before any graph capture): sessions on different HIP streams
+        (`text_env_eval(concurrent=n)` lanes) share this engine and must not share partial sums, and a captured hipGraph keeps the pointer."""
+        if self.matmul != "bf16x3":
+            return 0
+        c, need = self.cfg, 0
+        for k, n in ((c.d_model, 3 * c.d_model), (c.d_model, c.d_model), (c.d_model, c.d_ff), (c.d_ff, c.d_model)):
+            if n % 64 == 0 and 3 * k >= 4096:
+                need = max(need, int(self._L.lmrl_gemm_bf16_splitk_ws_bytes(rows, n, 3 * k)))
+        return need
+
+    def linear(self, x, rows, k, n, w_name, p, y, scratch, gelu_split=None, splitk_ws=None):
         """y[rows][n] = x[rows][k] @ W + b for a layer's Dense `w_name` in this engine's matmul mode (`scratch`: bf16 [rows][3 k] split buffer).
-        bf16x3 with `gelu_split` (a bf16 buffer of >= rows * 3 n elements): gelu_new(y) is written there as a split operand instead of y."""
+        bf16x3 with `gelu_split` (a bf16 buffer of >= rows * 3 n elements): gelu_new(y) is written there as a split operand instead of y.
+        `splitk_ws`: the caller's uint8 workspace of >= `splitk_ws_bytes(rows)` bytes (see there); without one the long-K products run unsplit."""
         if self.matmul == "f32":
             ops.sgemm(x, p[w_name + ".weight"], y, rows, n, k, lda=k, ldb=n, ldc=n, bias=p[w_name + ".bias"])
             return
@@ -75,12 +88,11 @@ class GPT2EngineF32:
             # few output tiles and a long K' (the MLP's c_proj, K' = 9216: 48 tiles of 128 x 128 at decode size, 128 tiles of 256 x 192 at chunk size):
             # deterministic split-K
             nb = L.lmrl_gemm_bf16_splitk_ws_bytes(rows, n, 3 * k)
-            if nb:
-                if getattr(self, "_splitk_ws", None) is None or self._splitk_ws.numel() < nb:
-                    import torch
-                    self._splitk_ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            if nb and splitk_ws is not None:
+                if splitk_ws.numel() < nb:
+                    raise _lib.LmrlError(f"split-K workspace of {splitk_ws.numel()} B < {nb} B needed for {rows} x {n} x {3 * k}")
                 _lib.check(L.lmrl_gemm_bf16_splitk_bias(scratch.data_ptr(), p[w_name + ".weight.x3"].data_ptr(), p[w_name + ".bias"].data_ptr(), y.data_ptr(), rows, n,
-                                                        3 * k, 3 * k, 3 * k, n, self._splitk_ws.data_ptr(), _lib.stream_ptr()), "lmrl_gemm_bf16_splitk_bias (bf16x3)")
+                                                        3 * k, 3 * k, 3 * k, n, splitk_ws.data_ptr(), _lib.stream_ptr()), "lmrl_gemm_bf16_splitk_bias (bf16x3)")
                 return
         _lib.check(L.lmrl_gemm_bf16(scratch.data_ptr(), p[w_name + ".weight.x3"].data_ptr(), p[w_name + ".bias"].data_ptr(), y.data_ptr(), rows, n, 3 * k, 3 * k,
                                     n, n, 3, _lib.stream_ptr()), "lmrl_gemm_bf16 (bf16x3)")
@@ -121,7 +133,10 @@ class KVSessionF32:
                                r=f(R, c.d_model),
                                qkv=f(R, 3 * c.d_model), att=f(R, c.d_model), ff=f(R, c.d_ff), mean=f(R), rstd=f(R),
                                split=t.zeros(R * 3 * c.d_model, dtype=t.bfloat16, device=dev) if self.eng.matmul == "bf16x3" else None,
-                               split2=t.zeros(R * 3 * c.d_ff, dtype=t.bfloat16, device=dev) if self.eng.matmul == "bf16x3" else None)
+                               split2=t.zeros(R * 3 * c.d_ff, dtype=t.bfloat16, device=dev) if self.eng.matmul == "bf16x3" else None,
+                               # split-K partial sums of THIS session's long-K products: per session and per chunk size, sized once here (never
+                               # reallocated: captured graphs hold the pointer; never shared: lanes on other streams own theirs)
+                               splitk=t.empty(self.eng.splitk_ws_bytes(R), dtype=t.uint8, device=dev) if self.eng.splitk_ws_bytes(R) else None)
         return self._ws[C]
 
     def reset(self):
@@ -160,11 +175,11 @@ class KVSessionF32:
             if x3:
                 # c_fc reads the LayerNorm's split operand (w["split"], pitch 3 d) and writes gelu's split operand (w["split2"], pitch 3 d_ff)
                 e.linear(ln(r, p["ln_2.weight"], p["ln_2.bias"]), R, d, c.d_ff, "mlp.c_fc", p, None, w["split"], gelu_split=w["split2"])
-                e.linear(None, R, c.d_ff, d, "mlp.c_proj", p, r, w["split2"])
+                e.linear(None, R, c.d_ff, d, "mlp.c_proj", p, r, w["split2"], splitk_ws=w["splitk"])
             else:
                 e.linear(ln(r, p["ln_2.weight"], p["ln_2.bias"]), R, d, c.d_ff, "mlp.c_fc", p, ff, w["split"])
                 ops.gelu_fwd(ff, ff)
-                e.linear(ff, R, c.d_ff, d, "mlp.c_proj", p, r, w["split2"])         # r = mlp output ; added by the next LayerNorm launch
+                e.linear(ff, R, c.d_ff, d, "mlp.c_proj", p, r, w["split2"], splitk_ws=w["splitk"])         # r = mlp output ; added by the next LayerNorm launch
             pending = r
         if all_hidden is not None:
             ops.layernorm_add_fwd(x, pending, e.lnf_g, e.lnf_b, all_hidden, w["mean"], w["rstd"], None, 0, R, d, c.ln_eps)

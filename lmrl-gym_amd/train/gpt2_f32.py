@@ -213,7 +213,7 @@ class GPT2F32:
         new = lambda *shape: t.empty(shape, dtype=t.float32, device=self.dev)
         x = new(R, d)
         ops.embed_fwd(p["wte.weight"], p["wpe.weight"], ids, pos, x, R, d)
-        cache = dict(B=B, T=T, ids=ids, pos=pos, km=km, layers=[])
+        cache = dict(B=B, T=T, ids=ids, pos=pos, km=km, layers=[], inference=bool(inference))
         flash = self.attention == "flash" and hd == 64
         lse_n = 0
         if flash:
@@ -324,6 +324,8 @@ class GPT2F32:
         `on_final(names)` (optional) is called after the launches that complete the gradients `names` have been enqueued — ln_f, then one
         call per block (last to first), then the embeddings — so a data-parallel reducer can start on them while the rest of the backward runs."""
         t = self.t
+        if cache.get("inference"):
+            raise ValueError("GPT2F32.backward: this cache comes from forward(inference=True) — the lean forward does not keep what a backward reads")
         B, T = cache["B"], cache["T"]
         R, d, H, p, ws = B * T, self.d, self.n_head, self.p, self._colsum_ws
         hd = d // H

@@ -203,3 +203,28 @@ def test_f32_engines_graph_replay_is_bit_identical_to_eager(dev, matmul):
         outs.append(g)
     assert int(outs[0]["n_steps"].sum()) > 3 * B and not torch.equal(outs[0]["tokens"], outs[1]["tokens"])
     ro.close()
+
+
+def test_bf16x3_lanes_own_their_split_k_workspace(dev):
+    """the split-K partial sums of the bf16x3 c_proj products used to live on the ENGINE, which `text_env_eval(concurrent=n)`
+    lanes share across HIP streams — one lane's reduce could read the other's partials.  They belong to the session now (sized once per chunk
+    size, before any capture).  Greedy episodes are noise-independent, so the same batches must come back bit-identical from one lane and from
+    two lanes in flight, on a width whose c_proj takes the split-K path at decode AND chunk size."""
+    from lmrl_gym_amd.envs import wordle as W
+    from lmrl_gym_amd.gpt2 import GPT2Config, init_hf_style_state_dict
+    from lmrl_gym_amd.gpt2_f32_engine import GPT2EngineF32
+    from lmrl_gym_amd.rollout import WordleRolloutEngine
+    cfg = GPT2Config(2, 4, 256, 2048, 50257, 128)
+    eng = GPT2EngineF32(cfg, init_hf_style_state_dict(cfg, seed=2), dev, matmul="bf16x3")
+    B = 256
+    assert eng.splitk_ws_bytes(B) > 0 and eng.splitk_ws_bytes(8 * B) > 0 and not hasattr(eng, "_splitk_ws")
+    vocab = W.Vocabulary.builtin("wordle_official_400.txt")
+    ro = WordleRolloutEngine(eng, vocab, B, max_new_tokens=6, bad_word_reward=-10.0)
+    kw = dict(temperature=0.0, sample_seed=3, use_graph=True)
+    one, s1 = ro.text_env_eval(6 * B, seed_generator=iter(range(100, 10 ** 6)), **kw)
+    two, s2 = ro.text_env_eval(6 * B, seed_generator=iter(range(100, 10 ** 6)), concurrent=2, **kw)
+    three, _ = ro.text_env_eval(6 * B, seed_generator=iter(range(100, 10 ** 6)), concurrent=3, **kw)
+    assert len(ro._lanes) == 3 and one == two == three and s1 == s2
+    ws = [e.ses._ws[c]["splitk"].data_ptr() for e, _ in ro._lanes for c in sorted(e.ses._ws)]
+    assert len(set(ws)) == len(ws)                        # every lane / chunk size has its own partial-sum buffer
+    ro.close()
