@@ -203,6 +203,60 @@ int lmrl_whiten_apply(const float *x_d, const uint8_t *mask_d, const double *mom
                       int shift_mean, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Rollout records -> PPO data without leaving the device (csrc/ppo_data.hip).
+ * Replaces the host side of PPOInference.get_ppo_data_from_token_trajectory_chain
+ * (LLM_RL/algorithms/ppo/base_interface.py:464-669) as the task scripts feed it
+ * (llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py:301-353), PPOData.block / PPODataset
+ * (LLM_RL/algorithms/ppo/data.py:9-114) and the masks GPT2PPOTrain.step derives from a batch
+ * (base_interface.py:172-228).  The forwards between lmrl_ppo_block and lmrl_ppo_shape, lmrl_gae and
+ * lmrl_whiten_* between lmrl_ppo_shape and lmrl_ppo_unroll are the caller's.
+ * ------------------------------------------------------------------------------------------ */
+/* n token trajectories = the fields of TokenTrajectory (LLM_RL/environment.py:329-380) as the rollout engines record
+ * them, grouped into n_chains TokenTrajectoryChains (environment.py:383-420).  All pointers are device pointers. */
+typedef struct {
+    const int32_t *tokens;      /* [n][cap] */
+    const uint8_t *is_action;   /* [n][cap] */
+    const float *reward;        /* [n][cap] */
+    const int32_t *n_tok;       /* [n] tokens of each trajectory (<= cap) */
+    const uint8_t *done;        /* [n_chains] `done` of each chain's LAST trajectory (every earlier one must be not done, :310) */
+    const int32_t *chain;       /* [n] chain of trajectory k, or NULL: trajectory k is chain k (n_chains == n) */
+    const int32_t *pos;         /* [n] where trajectory k starts in its chain's concatenation (sum of earlier len - 1), or NULL: 0 */
+    const uint8_t *last;        /* [n] 1 when trajectory k ends its chain, or NULL: all 1 */
+    int32_t n, cap, n_chains;
+} lmrl_ppo_records;
+/* Per trajectory: effective length = min(n_tok, max_len) (max_len <= 0: no truncation; Truncation.RIGHT, :500-512), rows that predict a next
+ * token (len - 1) and action tokens (is_action[1:len]), with their exclusive scans.  cnt_d [2n] scratch; off_rows_d / off_act_d [n + 1];
+ * meta_d [4] = {rows, action tokens, longest effective length, pad ids found below a length}. */
+int lmrl_ppo_count(const lmrl_ppo_records *rec, int max_len, int pad, int32_t *cnt_d, int32_t *off_rows_d, int32_t *off_act_d, int32_t *meta_d,
+                   void *stream);
+/* block_sequences(Padding.RIGHT, pad) to width tf + initialize_attn_mask_pos_ids + the compacted list of rows k * tf + t (t < len - 1) with
+ * their next-token targets (the LM head of token_logprobs_from_logits, :396-403, runs on these rows only): ids / am / pos [n][tf],
+ * rows_idx / tgt [meta[0]]. */
+int lmrl_ppo_block(const lmrl_ppo_records *rec, int max_len, int pad, int tf, const int32_t *off_rows_d, int32_t *ids_d, uint8_t *am_d, int32_t *pos_d,
+                   int32_t *rows_idx_d, int32_t *tgt_d, void *stream);
+/* :543-584 + the PPOData rows: logprobs_d / init_logprobs_d [meta[0]] in row-list order, values_d [n][tf].  Writes per chain
+ * (concatenated trajectories, row pitch lc / lc + 1, lc >= every chain's length): values incl. the bootstrap slot value * (1 - done), KL-shaped
+ * rewards, should_take_action, the chain length; kls_d [meta[1]] = exp(lr) - 1 - lr over the action tokens in trajectory order; and the blocked
+ * dataset rows of width tp (>= the longest effective length): ds_ids [n][tp], ds_sta / ds_logprobs / ds_values [n][tp - 1]. */
+int lmrl_ppo_shape(const lmrl_ppo_records *rec, int max_len, int tf, const int32_t *off_rows_d, const int32_t *off_act_d, const float *logprobs_d,
+                   const float *init_logprobs_d, const float *values_d, float kl_weight, int lc, float *chain_values_d, float *chain_rewards_d,
+                   uint8_t *chain_sta_d, int32_t *chain_len_d, float *kls_d, int pad, int tp, int32_t *ds_ids_d, uint8_t *ds_sta_d, float *ds_logprobs_d,
+                   float *ds_values_d, void *stream);
+/* unroll_arr (:335-343, :635-660): chain rows of advantages / returns [n_chains][lc] back to ds_adv / ds_ret [n][tp - 1] (0 past a length) */
+int lmrl_ppo_unroll(const lmrl_ppo_records *rec, int max_len, int tf, int lc, const float *chain_adv_d, const float *chain_ret_d, int tp, float *ds_adv_d,
+                    float *ds_ret_d, void *stream);
+/* initialize_attn_mask_pos_ids (JaxSeq; call sites base_interface.py:190-195): am = ids != pad, pos = max(cumsum(am) - 1, 0); [b][t].
+ * am_next_f32_d (optional) [b][t - 1] = float(am[:, 1:]), the mask ppo_loss_fn multiplies in (base_interface.py:208-214). */
+int lmrl_seq_mask_pos(const int32_t *ids_d, int pad, uint8_t *am_d, int32_t *pos_d, float *am_next_f32_d, int b, int t, void *stream);
+/* rows r = row * t + i (i < t - 1) with sta[row][i] && am[row][i + 1] (am NULL: sta alone), increasing, + tgt = ids[row][i + 1] (tgt NULL: no
+ * targets) — the rows of [b * t, d] hidden states whose LM-head outputs a masked loss reads.  cnt_d [b] scratch, off_d [b + 1] (off_d[b] = count),
+ * idx_d / tgt_d capacity b * (t - 1). */
+int lmrl_masked_rows(const uint8_t *sta_d, const uint8_t *am_d, const int32_t *ids_d, int b, int t, int32_t *cnt_d, int32_t *off_d, int32_t *idx_d,
+                     int32_t *tgt_d, void *stream);
+/* dst[i] = src[idx[i]] for rows of row_bytes bytes (a shuffled batch of a device-resident dataset: ppo/data.py:88-98) */
+int lmrl_gather_rows_bytes(const void *src_d, const int32_t *idx_d, void *dst_d, int n, long row_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * GPT-2 rollout forward with a persistent per-env KV cache (csrc/gpt2.hip).
  * Replaces the model side of GPT2PPOPolicy.act / GPT2ValuePolicy.act
  * (LLM_RL/algorithms/ppo/gpt2/interface.py:507-546, value_rl_base/gpt2/interface.py:281-320), whose
@@ -226,6 +280,10 @@ typedef struct lmrl_gpt2 lmrl_gpt2;
 lmrl_gpt2 *lmrl_gpt2_create(const lmrl_gpt2_config *cfg, const void *wte_d, const void *wpe_d, const float *lnf_g_d,
                             const float *lnf_b_d, const void *const *layer_ptrs /* host array [n_layer*12] */);
 void lmrl_gpt2_destroy(lmrl_gpt2 *m);
+/* The caller has overwritten the weight tensors handed to lmrl_gpt2_create IN PLACE (the online loops copy the trainer's parameters into the
+ * rollout engine after every round: train_ppo_gpt2.py `policy.set_params(...)`): re-derive the model-owned LayerNorm-folded copies on `stream`.
+ * Pointers held by sessions and captured hipGraphs stay valid. */
+int lmrl_gpt2_refresh(lmrl_gpt2 *m, void *stream);
 size_t lmrl_gpt2_kv_bytes(const lmrl_gpt2 *m, int b, int tmax);
 size_t lmrl_gpt2_ws_bytes(const lmrl_gpt2 *m, int b, int c);
 /*
@@ -332,7 +390,8 @@ int lmrl_gemm_bf16_gelu_bwd_prebf16(const void *a_d, const void *w_d, const void
  * same launch — partials_d [m][lmrl_gemm_bf16_ce_slots(m, n, k)] (max, sum exp) pairs -> lmrl_lse_from_partials gives log-sum-exp (and the target's
  * log-probability), tgt_logit_d[r] = logit[r][targets_d[r]] in fp32.  Replaces an fp32 [m][V] logits tensor + a pass over it
  * (optax.softmax_cross_entropy_with_integer_labels forward, ilql/base_interface.py:57-66 gathers).  lmrl_ce_bwd_bf16_inplace then turns the bf16
- * logits into the bf16 d(logits) operand of the head's backward products in place (padding rows / columns zeroed). */
+ * logits into the bf16 d(logits) operand of the head's backward products in place (padding rows / columns zeroed).
+ * logits_bf16_d NULL (inference: PPOInference.forward's token log-probabilities, ppo/base_interface.py:396-403): no logits are stored at all. */
 int lmrl_gemm_bf16_ce_slots(int m, int n, int k);
 int lmrl_gemm_bf16_ce(const void *a_d, const void *w_d, const float *bias_d, void *logits_bf16_d, int ldc, int m, int n, int k, int lda, int ldw, int n_store,
                       const int32_t *targets_d, float *tgt_logit_d, void *partials_d, void *stream);

@@ -40,6 +40,15 @@ _SIGS = {
     "lmrl_rtg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "lmrl_whiten_moments": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lmrl_whiten_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "lmrl_ppo_count": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lmrl_ppo_block": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lmrl_ppo_shape": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lmrl_ppo_unroll": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "lmrl_seq_mask_pos": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "lmrl_masked_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lmrl_gather_rows_bytes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.c_long, c_void_p]),
+    "lmrl_gpt2_refresh": (c_int, [c_void_p, c_void_p]),
     "lmrl_gpt2_create": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmrl_gpt2_destroy": (None, [c_void_p]),
     "lmrl_gpt2_kv_bytes": (c_size_t, [c_void_p, c_int, c_int]),

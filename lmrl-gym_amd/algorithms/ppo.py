@@ -42,8 +42,20 @@ def _dev():
     return _lib.require_gpu()
 
 
-def _t(x, dtype):
+_TORCH_OF = {np.float32: "float32", np.int32: "int32", np.uint8: "uint8", np.int64: "int64", np.float64: "float64"}
+
+
+def _on_device(x) -> bool:
     import torch
+    return isinstance(x, torch.Tensor) and x.is_cuda
+
+
+def _t(x, dtype):
+    """numpy (the reference's host batches) -> device tensor; a tensor already in HBM (a `DevicePPODataset` batch) passes through."""
+    import torch
+    if _on_device(x):
+        want = getattr(torch, _TORCH_OF[dtype])
+        return (x if x.dtype == want else x.to(want)).contiguous()
     return torch.from_numpy(np.ascontiguousarray(x, dtype=dtype)).to(_dev())
 
 
@@ -252,26 +264,45 @@ class GPT2PPOTrain:
              attention_mask=None, position_ids=None, bc_data_input_ids=None, bc_data_input_attention_mask=None,
              bc_data_input_position_ids=None, bc_data_input_training_mask=None, train: bool = True):
         import torch
-        ids = np.asarray(input_ids, dtype=np.int32)
-        am, pos = initialize_attn_mask_pos_ids(ids, self.pad, attention_mask, position_ids)
-        B, T = ids.shape
-        R = B * T
         pol, head = self.policy, self.value_head
         dev = pol.dev
-        ids_d, pos_d, am_d = _t(ids, np.int32), _t(pos, np.int32), _t(am, np.uint8)
+        f32 = lambda x: _t(x, np.float32)
+        if _on_device(input_ids):
+            # a batch that never left the device (`ppo_device.DevicePPODataset.batch`): masks, positions, the masked row list and its
+            # next-token targets come from csrc/ppo_data.hip; the host learns one integer (the row count that sizes the LM-head product)
+            from .ppo_device import mask_pos_device, masked_rows_device
+            ids_d = _t(input_ids, np.int32)
+            B, T = ids_d.shape
+            R = B * T
+            if attention_mask is None and position_ids is None:
+                am_d, pos_d, attn_s = mask_pos_device(ids_d, self.pad, shifted=True)
+            else:
+                am0, pos0 = mask_pos_device(ids_d, self.pad)
+                am_d = _t(attention_mask, np.uint8) if attention_mask is not None else am0
+                pos_d = _t(position_ids, np.int32) if position_ids is not None else pos0
+                attn_s = f32(am_d[:, 1:])
+            sta_d = _t(should_take_action, np.uint8)
+            idx, tgt_rows, Ra = masked_rows_device(sta_d, am_d, ids_d, T)
+        else:
+            ids = np.asarray(input_ids, dtype=np.int32)
+            am, pos = initialize_attn_mask_pos_ids(ids, self.pad, attention_mask, position_ids)
+            B, T = ids.shape
+            R = B * T
+            ids_d, pos_d, am_d = _t(ids, np.int32), _t(pos, np.int32), _t(am, np.uint8)
+            # logprobs[b, t] = log p(ids[b, t+1] | ids[b, :t+1]) for t < T-1 : row r = b*T + t, target ids[b, t+1] — needed on the masked rows only
+            p_mask = np.asarray(should_take_action, dtype=bool) & (np.asarray(am)[:, 1:] != 0)
+            rows_h = masked_rows(p_mask, T)
+            Ra = int(rows_h.size)
+            idx, tgt_rows = _t(rows_h, np.int32), _t(ids[:, 1:][p_mask].astype(np.int32), np.int32)
+            attn_s, sta_d = f32(am[:, 1:]), _t(should_take_action, np.uint8)
         hid, cache = pol.forward(ids_d, am_d, pos_d)
         values_full, hcache = head.forward(hid, R)                               # [R, 1]
-        # logprobs[b, t] = log p(ids[b, t+1] | ids[b, :t+1]) for t < T-1 : row r = b*T + t, target ids[b, t+1] — needed on the masked rows only
-        p_mask = np.asarray(should_take_action, dtype=bool) & (np.asarray(am)[:, 1:] != 0)
-        rows_h = masked_rows(p_mask, T)
-        Ra = int(rows_h.size)
         compact = self.compact_rows and 0 < Ra < R
-        tgt = torch.zeros(R, dtype=torch.int32, device=dev)
-        tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
         if compact:
-            idx = _t(rows_h, np.int32)
-            hq, tgt_q, Rq = ops.gather_rows(hid, idx, Ra, pol.d), _t(ids[:, 1:][p_mask].astype(np.int32), np.int32), Ra
+            hq, tgt_q, Rq = ops.gather_rows(hid, idx, Ra, pol.d), tgt_rows, Ra
         else:
+            tgt = torch.zeros(R, dtype=torch.int32, device=dev)
+            tgt.view(B, T)[:, :-1] = ids_d[:, 1:]
             idx, hq, tgt_q, Rq = None, hid, tgt, R
         logits, logits_b, lse, lp_q = pol.lm_ce(hq, Rq, tgt_q)                    # fp32 [Rq, V] logits, or (bf16-matmul mode) bf16 ones + fp32-exact lse
         if compact:
@@ -280,9 +311,7 @@ class GPT2PPOTrain:
         else:
             logprob_all = lp_q
         sl = lambda x: x.view(B, T)[:, :-1].contiguous()
-        f32 = lambda x: _t(x, np.float32)
-        attn_s = f32(am[:, 1:])
-        loss, logs, dlp, dv = ppo_loss_device(attn_s, sl(logprob_all), sl(values_full.view(R)), _t(should_take_action, np.uint8),
+        loss, logs, dlp, dv = ppo_loss_device(attn_s, sl(logprob_all), sl(values_full.view(R)), sta_d,
                                               f32(old_logprobs), f32(old_values), f32(old_advantages), f32(old_returns), **self.loss_kwargs)
         use_bc = bc_data_input_ids is not None
         if use_bc and not train:

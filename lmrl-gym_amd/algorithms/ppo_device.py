@@ -1,0 +1,239 @@
+"""Rollout records -> PPO data -> PPO batches without leaving the device.
+
+The reference's online loop is `text_env_eval -> TextTrajectoryChain -> get_ppo_data_from_text_trajectory_chain -> PPODataset -> train`
+(llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py:301-353, LLM_RL/algorithms/ppo/base_interface.py:464-669, LLM_RL/algorithms/ppo/data.py:9-114): Python
+text, a re-tokenisation, per-chain numpy loops.  The rollout engines of this package already leave `TokenTrajectory` fields in HBM
+(`tokens / is_action / reward / n_tok / done`), so here the same function runs on those records where they lie:
+
+    records --lmrl_ppo_count / lmrl_ppo_block--> ids, mask, positions, LM-head row list        (csrc/ppo_data.hip)
+            --policy, initial policy (inference forwards), value head--> log-probs on the listed rows, values
+            --lmrl_ppo_shape--> KL terms, KL-shaped rewards, chain rows --lmrl_gae, lmrl_whiten_*--> --lmrl_ppo_unroll--> DevicePPODataset
+
+and `GPT2PPOTrain.step` takes `DevicePPODataset.batch(...)` (device tensors) as it takes the reference's numpy batches.  No `[B, T, V]` logits
+exist at any point (bf16-matmul mode: log-sum-exp from the LM-head GEMM's accumulators; fp32: one row-chunk scratch).  The host reads back
+(n + 5) integers per call (row offsets + the four totals) to size the launches.
+
+`get_ppo_data_from_token_trajectory_chain` in ppo_inference.py stays as the host-array form (the reference's own signature); both are tested
+against the reference function's fixture and against each other (tests/test_gpu_ppo_device.py).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .. import _lib
+from .. import dist as D
+from ..train import ops
+from .ppo import PPODataset
+
+
+class _CRecords(ctypes.Structure):            # lmrl_ppo_records (include/lmrl_amd.h)
+    _fields_ = [(n, ctypes.c_void_p) for n in ("tokens", "is_action", "reward", "n_tok", "done", "chain", "pos", "last")] + \
+               [("n", ctypes.c_int32), ("cap", ctypes.c_int32), ("n_chains", ctypes.c_int32)]
+
+
+class PPORecords:
+    """n token trajectories in HBM, grouped into chains: what a rollout engine hands over (`WordleRolloutEngine.ppo_records()`), or what
+    `from_token_trajectory_chains` uploads for chains built on the host."""
+
+    def __init__(self, tokens, is_action, reward, n_tok, done, chain=None, pos=None, last=None, n_chains: Optional[int] = None,
+                 chain_len_bound: Optional[int] = None):
+        """tokens int32 [n, cap], is_action uint8 [n, cap], reward float32 [n, cap], n_tok int32 [n], done uint8 [n_chains] — device tensors.
+        chain / pos (int32 [n]) / last (uint8 [n]): see include/lmrl_amd.h::lmrl_ppo_records; None = every trajectory is its own chain.
+        chain_len_bound: an upper bound of the longest chain's concatenated length (multi-trajectory chains only)."""
+        self.tokens, self.is_action, self.reward, self.n_tok, self.done = tokens, is_action, reward, n_tok, done
+        self.chain, self.pos, self.last = chain, pos, last
+        self.n, self.cap = int(tokens.shape[0]), int(tokens.shape[1])
+        self.n_chains = self.n if n_chains is None else int(n_chains)
+        self.chain_len_bound = chain_len_bound
+        assert (chain is None) == (pos is None) == (last is None)
+        assert chain is not None or self.n_chains == self.n
+        for x in (tokens, is_action, reward):
+            assert x.is_contiguous() and tuple(x.shape) == (self.n, self.cap)
+
+    def c_struct(self) -> _CRecords:
+        p = _lib.ptr
+        return _CRecords(p(self.tokens), p(self.is_action), p(self.reward), p(self.n_tok), p(self.done), p(self.chain), p(self.pos), p(self.last),
+                         self.n, self.cap, self.n_chains)
+
+    @classmethod
+    def from_token_trajectory_chains(cls, chains, max_length: Optional[int] = None, device=None) -> "PPORecords":
+        """Upload host `TokenTrajectoryChain`s (LLM_RL/environment.py:383-420): one row per trajectory, chains concatenated in order."""
+        import torch
+        dev = device or _lib.require_gpu()
+        tts, chain, pos, last, done = [], [], [], [], []
+        for c, ch in enumerate(chains):
+            lst = ch.to_list()
+            assert not any(bool(tt.done) for tt in lst[:-1]), "done can only be true at the end of the chain"
+            p = 0
+            for i, tt in enumerate(lst):
+                n = int(tt.tokens.shape[0]) if max_length is None else min(int(tt.tokens.shape[0]), int(max_length))
+                tts.append(tt); chain.append(c); pos.append(p); last.append(i == len(lst) - 1)
+                p += max(n - 1, 0)
+            done.append(bool(lst[-1].done))
+        cap = max(int(tt.tokens.shape[0]) for tt in tts)
+        tok = np.zeros((len(tts), cap), np.int32); ia = np.zeros((len(tts), cap), np.uint8); rw = np.zeros((len(tts), cap), np.float32)
+        for k, tt in enumerate(tts):
+            n = int(tt.tokens.shape[0])
+            tok[k, :n], ia[k, :n], rw[k, :n] = tt.tokens, np.asarray(tt.is_action, dtype=np.uint8), tt.reward
+        up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+        bound = max(p + max((int(tt.tokens.shape[0]) if max_length is None else min(int(tt.tokens.shape[0]), int(max_length))) - 1, 0)
+                    for p, tt in zip(pos, tts))
+        return cls(up(tok, np.int32), up(ia, np.uint8), up(rw, np.float32), up([int(tt.tokens.shape[0]) for tt in tts], np.int32), up(done, np.uint8),
+                   up(chain, np.int32), up(pos, np.int32), up(last, np.uint8), n_chains=len(done), chain_len_bound=bound)
+
+
+class DevicePPODataset:
+    """`PPODataset` (LLM_RL/algorithms/ppo/data.py:63-114) with its six blocked arrays resident in HBM: input_ids int32 [N, T],
+    should_take_action uint8 [N, T-1], old_logprobs / old_values / old_advantages / old_returns float32 [N, T-1]."""
+
+    FIELDS = ("input_ids", "should_take_action", "old_logprobs", "old_values", "old_advantages", "old_returns")
+
+    def __init__(self, **arrays):
+        for k in self.FIELDS:
+            setattr(self, k, arrays[k])
+        n, t = self.input_ids.shape
+        for k in self.FIELDS[1:]:
+            assert tuple(getattr(self, k).shape) == (n, t - 1)
+
+    def __len__(self) -> int:
+        return int(self.input_ids.shape[0])
+
+    def batch(self, index) -> Dict[str, "torch.Tensor"]:
+        """Rows `index` (a device int32 tensor, or anything numpy can turn into indices) of every array: a shuffled batch of the dataloader
+        (`lmrl_gather_rows_bytes`), keyword-compatible with `GPT2PPOTrain.step(**batch)`."""
+        import torch
+        if not isinstance(index, torch.Tensor):
+            index = torch.from_numpy(np.ascontiguousarray(index, dtype=np.int32)).to(self.input_ids.device)
+        index = index.to(torch.int32).contiguous()
+        n = int(index.numel())
+        out = {}
+        for k in self.FIELDS:
+            src = getattr(self, k)
+            dst = torch.empty((n, src.shape[1]), dtype=src.dtype, device=src.device)
+            _lib.check(_lib.lib().lmrl_gather_rows_bytes(src.data_ptr(), index.data_ptr(), dst.data_ptr(), n, src.shape[1] * src.element_size(),
+                                                         _lib.stream_ptr()), "lmrl_gather_rows_bytes")
+            out[k] = dst
+        return out
+
+    def to_host(self) -> PPODataset:
+        """The reference's host dataset (numpy) — parity tests, pickling (`save_ppo_dataset`)."""
+        h = {k: getattr(self, k).cpu().numpy() for k in self.FIELDS}
+        h["should_take_action"] = h["should_take_action"].astype(np.bool_)
+        return PPODataset(**h)
+
+
+def ppo_data_from_records(inference, rec: PPORecords, *, gamma: float, lam: float, kl_weight: float, max_length: Optional[int] = None,
+                          use_advantage_whitening: bool = True, bsize: int = 256, pad_to: Optional[int] = None, lm_head_rows: int = 8192,
+                          timings: Optional[dict] = None) -> Tuple[DevicePPODataset, "torch.Tensor"]:
+    """`PPOInference.get_ppo_data_from_token_trajectory_chain` (ppo/base_interface.py:464-669) + `PPODataset.from_ppo_data_list` on device
+    records -> (DevicePPODataset, all_kls float32 device tensor).
+
+    inference: `GPT2PPOInference` (policy, initial_policy, value_head, pad id).  max_length: the blocking width of the reference call
+    (trajectories are truncated to it on the right); pad_to: width T of the dataset arrays (default: max_length, as the task scripts block the
+    dataset; without a max_length the longest trajectory).  bsize: sequences per forward (`ppo_data_bsize`).  The forwards run on
+    ceil8(longest trajectory) columns — right padding never reaches a kept position of a causal model, so this equals the reference's
+    [bsize, max_length] forwards on the kept positions.  A trajectory's length is its record's `n_tok`: a pad id BELOW the length (a policy
+    whose vocabulary contains the pad id can sample it) is an ordinary, attended token here, whereas the reference derives masks from `ids != pad`,
+    cuts at the first pad (`unpad_array`) and then fails on the shape mismatch; such tokens are counted on the device (`timings["pad_ids_inside"]`).
+    timings: optional dict, filled with HIP-event milliseconds per phase (bench.py's `ppo_iteration` leg)."""
+    import torch
+    assert inference.initial_policy is not None
+    L, sp = _lib.lib(), _lib.stream_ptr()
+    pol, init, head, pad = inference.policy, inference.initial_policy, inference.value_head, int(inference.pad)
+    dev = pol.dev
+    n, ml = rec.n, int(max_length) if max_length is not None else 0
+    i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=dev)
+    f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    c = rec.c_struct()
+    marks = []
+
+    def mark(name):
+        if timings is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((name, ev))
+    mark("start")
+    cnt, off_rows, off_act, meta = i32(2 * n), i32(n + 1), i32(n + 1), i32(4)
+    _lib.check(L.lmrl_ppo_count(ctypes.byref(c), ml, pad, _lib.ptr(cnt), _lib.ptr(off_rows), _lib.ptr(off_act), _lib.ptr(meta), sp), "lmrl_ppo_count")
+    n_rows, n_act, longest, pads = (int(x) for x in meta.cpu().numpy())        # the one readback that sizes what follows
+    if n_rows == 0:
+        raise ValueError("no trajectory has two tokens: nothing to build PPO data from")
+    tf = -(-longest // 8) * 8
+    tp = int(pad_to) if pad_to is not None else (ml if ml > 0 else longest)
+    if tp < longest:
+        raise ValueError(f"pad_to = {tp} is narrower than the longest (truncated) trajectory ({longest} tokens)")
+    ids, am, pos = i32(n, tf), torch.empty(n, tf, dtype=torch.uint8, device=dev), i32(n, tf)
+    rows_idx, tgt = i32(n_rows), i32(n_rows)
+    _lib.check(L.lmrl_ppo_block(ctypes.byref(c), ml, pad, tf, _lib.ptr(off_rows), _lib.ptr(ids), _lib.ptr(am), _lib.ptr(pos), _lib.ptr(rows_idx),
+                                _lib.ptr(tgt), sp), "lmrl_ppo_block")
+    mark("block")
+    # ---- the three models (base_interface.py:514-541): per `bsize` sequences one inference forward each; final hidden states kept for the heads
+    hid_p, hid_i, values = f32(n * tf, pol.d), f32(n * tf, init.d), f32(n * tf)
+    for s0 in range(0, n, bsize):
+        s1 = min(n, s0 + bsize)
+        for model, dst in ((init, hid_i), (pol, hid_p)):
+            h, _ = model.forward(ids[s0:s1], am[s0:s1], pos[s0:s1], inference=True)
+            dst[s0 * tf:s1 * tf].copy_(h)
+        v, _ = head.forward(hid_p[s0 * tf:s1 * tf], (s1 - s0) * tf)
+        values[s0 * tf:s1 * tf].copy_(v.view(-1) if head.ld_out == 1 else v[:, 0])
+    mark("forward")
+    init_lp = init.token_logprobs(hid_i, rows_idx, tgt, n_rows, chunk=lm_head_rows)
+    del hid_i
+    lp = pol.token_logprobs(hid_p, rows_idx, tgt, n_rows, chunk=lm_head_rows)
+    del hid_p
+    mark("logprobs")
+    # ---- :543-584 on the device, chain rows for the GAE
+    lc = max(longest - 1, 1) if rec.chain is None else int(rec.chain_len_bound or n * max(longest - 1, 1))
+    C = rec.n_chains
+    cv, cr, cs, clen = f32(C, lc + 1), f32(C, lc), torch.empty(C, lc, dtype=torch.uint8, device=dev), i32(C)
+    kls = f32(max(n_act, 1))
+    ds = dict(input_ids=i32(n, tp), should_take_action=torch.empty(n, tp - 1, dtype=torch.uint8, device=dev), old_logprobs=f32(n, tp - 1),
+              old_values=f32(n, tp - 1), old_advantages=f32(n, tp - 1), old_returns=f32(n, tp - 1))
+    _lib.check(L.lmrl_ppo_shape(ctypes.byref(c), ml, tf, _lib.ptr(off_rows), _lib.ptr(off_act), _lib.ptr(lp), _lib.ptr(init_lp), _lib.ptr(values),
+                                float(kl_weight), lc, _lib.ptr(cv), _lib.ptr(cr), _lib.ptr(cs), _lib.ptr(clen), _lib.ptr(kls), pad, tp,
+                                _lib.ptr(ds["input_ids"]), _lib.ptr(ds["should_take_action"]), _lib.ptr(ds["old_logprobs"]), _lib.ptr(ds["old_values"]), sp),
+               "lmrl_ppo_shape")
+    adv, ret = f32(C, lc), f32(C, lc)
+    _lib.check(L.lmrl_gae(_lib.ptr(cv), _lib.ptr(cr), _lib.ptr(cs), _lib.ptr(clen), _lib.ptr(adv), _lib.ptr(ret), C, lc, float(gamma), float(lam), sp), "lmrl_gae")
+    if use_advantage_whitening:                                            # over the action tokens of the whole batch (all ranks), :609-615
+        adv = D.whiten_distributed(adv.view(-1), cs.view(-1), shift_mean=True).view(C, lc)
+    _lib.check(L.lmrl_ppo_unroll(ctypes.byref(c), ml, tf, lc, _lib.ptr(adv), _lib.ptr(ret), tp, _lib.ptr(ds["old_advantages"]), _lib.ptr(ds["old_returns"]), sp),
+               "lmrl_ppo_unroll")
+    mark("shape_gae")
+    if timings is not None:
+        torch.cuda.synchronize()
+        for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
+            timings[name + "_ms"] = timings.get(name + "_ms", 0.0) + a.elapsed_time(b)
+        timings.update(rows=n_rows, action_tokens=n_act, forward_width=tf, sequences=n, pad_ids_inside=timings.get("pad_ids_inside", 0) + pads)
+    return DevicePPODataset(**ds), kls[:n_act]
+
+
+def masked_rows_device(should_take_action, attention_mask, input_ids, T: int):
+    """`common.masked_rows` + the next-token targets of those rows for a batch that lives in HBM -> (idx int32 [Ra], targets int32 [Ra], Ra).
+    One 4-byte readback (Ra sizes the LM-head product)."""
+    import torch
+    B = int(should_take_action.shape[0])
+    dev = should_take_action.device
+    cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    off = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    idx = torch.empty(B * (T - 1), dtype=torch.int32, device=dev)
+    tgt = torch.empty(B * (T - 1), dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().lmrl_masked_rows(_lib.ptr(should_take_action), _lib.ptr(attention_mask), _lib.ptr(input_ids), B, T, _lib.ptr(cnt), _lib.ptr(off),
+                                           _lib.ptr(idx), _lib.ptr(tgt), _lib.stream_ptr()), "lmrl_masked_rows")
+    ra = int(off[B:].cpu().numpy()[0])
+    return idx[:ra], tgt[:ra], ra
+
+
+def mask_pos_device(input_ids, pad: int, shifted: bool = False):
+    """`initialize_attn_mask_pos_ids` for device ids [B, T] -> (attention_mask uint8 [B, T], position_ids int32 [B, T]) and, with
+    `shifted`, float32 attention_mask[:, 1:] [B, T-1] (the loss's mask operand)."""
+    import torch
+    B, T = input_ids.shape
+    am = torch.empty(B, T, dtype=torch.uint8, device=input_ids.device)
+    pos = torch.empty(B, T, dtype=torch.int32, device=input_ids.device)
+    nxt = torch.empty(B, T - 1, dtype=torch.float32, device=input_ids.device) if shifted else None
+    _lib.check(_lib.lib().lmrl_seq_mask_pos(_lib.ptr(input_ids), int(pad), _lib.ptr(am), _lib.ptr(pos), _lib.ptr(nxt), B, T, _lib.stream_ptr()), "lmrl_seq_mask_pos")
+    return (am, pos, nxt) if shifted else (am, pos)

@@ -576,6 +576,10 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
             sum += __shfl_xor(sum, 32);
             if (lq == 0 && m < Mr) g.stats[(size_t)m * g.nslots + slot] = make_float2(vmax, sum);
         }
+        if (!g.C) {       // inference (token log-probabilities only): nobody reads the logits themselves
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
     }
 
     constexpr bool BF16_OUT = (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_RELU_BF16 || LN_IN || EPI == EPI_BF16_HEADS || EPI == EPI_GELU_BWD_BF16 ||

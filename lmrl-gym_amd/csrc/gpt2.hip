@@ -1061,6 +1061,20 @@ lmrl_gpt2 *lmrl_gpt2_create(const lmrl_gpt2_config *cfg, const void *wte, const 
     return m;
 }
 
+int lmrl_gpt2_refresh(lmrl_gpt2 *m, void *stream) {
+    LMRL_REQUIRE(m && m->layers, "lmrl_gpt2_refresh: bad argument");
+    const int d = m->cfg.d_model, dff = m->cfg.d_ff;
+    for (int l = 0; l < m->cfg.n_layer; l++) {
+        Gpt2Layer &L = m->layers[l];
+        hipLaunchKernelGGL(fold_ln_kernel, dim3(ceil_div(3 * d, 4)), dim3(256), 0, as_stream(stream), L.w_qkv, L.ln1_g, L.ln1_b, L.b_qkv, L.wf_qkv, L.cs_qkv,
+                           L.bf_qkv, 3 * d, d);
+        hipLaunchKernelGGL(fold_ln_kernel, dim3(ceil_div(dff, 4)), dim3(256), 0, as_stream(stream), L.w_fc, L.ln2_g, L.ln2_b, L.b_fc, L.wf_fc, L.cs_fc,
+                           L.bf_fc, dff, d);
+    }
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
 void lmrl_gpt2_destroy(lmrl_gpt2 *m) {
     if (!m) return;
     for (int l = 0; m->layers && l < m->cfg.n_layer; l++) {
@@ -1533,7 +1547,7 @@ int lmrl_gemm_bf16_ce_slots(int m, int n, int k) { return (n > 0 && n % 128 == 0
 
 int lmrl_gemm_bf16_ce(const void *a_d, const void *w_d, const float *bias_d, void *logits_bf16_d, int ldc, int m, int n, int k, int lda, int ldw, int n_store,
                       const int32_t *targets_d, float *tgt_logit_d, void *partials_d, void *stream) {
-    LMRL_REQUIRE(a_d && w_d && logits_bf16_d && partials_d && train_gemm_args_ok(m, n, k, lda, ldw) && ldc % 8 == 0 && ldc >= n_store && n_store > 0 &&
+    LMRL_REQUIRE(a_d && w_d && partials_d && train_gemm_args_ok(m, n, k, lda, ldw) && (!logits_bf16_d || (ldc % 8 == 0 && ldc >= n_store)) && n_store > 0 &&
                      n_store <= n && (!targets_d || tgt_logit_d), "lmrl_gemm_bf16_ce: bad argument");
     GemmArgs g{(const uint16_t *)a_d, (const uint16_t *)w_d, bias_d, logits_bf16_d, m, n, k, lda, ldc, n_store};
     g.ldw = ldw; g.stats = (float2 *)partials_d; g.nslots = ce_slots(m, n, k); g.ce_targets = targets_d; g.ce_tgt_logit = tgt_logit_d;

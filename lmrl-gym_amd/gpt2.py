@@ -120,6 +120,25 @@ class GPT2Engine:
         if not self._h:
             raise _lib.LmrlError(self._L.lmrl_last_error().decode())
 
+    def load_params(self, params: Dict[str, "torch.Tensor"]) -> None:
+        """Overwrite this engine's weights IN PLACE from a parameter dict of the same architecture (HF names; fp32 masters of a trainer,
+        device or host) — the online loops' `policy.set_params(train_state.params)` after every round (llm_rl_scripts/wordle/ppo/
+        train_ppo_gpt2.py via LLM_RL/algorithms/ppo/train.py) without a host round trip or a new engine: device-to-device copies with the
+        bf16 rounding / [out][in] layout of `__init__`, then the LayerNorm-folded copies are re-derived (`lmrl_gpt2_refresh`).  Sessions, KV
+        caches and captured hipGraphs of this engine stay valid (same addresses)."""
+        cfg = self.cfg
+        sd = {k[len("transformer."):] if k.startswith("transformer.") else k: v for k, v in params.items()}
+        self.wte[: cfg.vocab].copy_(sd["wte.weight"][: cfg.vocab])
+        self.wpe.copy_(sd["wpe.weight"])
+        self.lnf_g.copy_(sd["ln_f.weight"]); self.lnf_b.copy_(sd["ln_f.bias"])
+        names = ("ln_1.weight", "ln_1.bias", "attn.c_attn.weight", "attn.c_attn.bias", "attn.c_proj.weight", "attn.c_proj.bias",
+                 "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias")
+        for l, tensors in enumerate(self.layers):
+            for name, dst in zip(names, tensors):
+                src = sd[f"h.{l}.{name}"]
+                dst.copy_(src.t() if (name.endswith(".weight") and src.dim() == 2) else src)      # Conv1D kernels [in][out] -> [out][in]
+        _lib.check(self._L.lmrl_gpt2_refresh(self._h, _lib.stream_ptr()), "lmrl_gpt2_refresh")
+
     @classmethod
     def random_init(cls, cfg: GPT2Config, seed: int = 0, device=None) -> "GPT2Engine":
         return cls(cfg, init_hf_style_state_dict(cfg, seed), device)

@@ -352,6 +352,84 @@ class WordleRolloutEngine:
         rw = self.traj["reward"].cpu().numpy(); n = self.traj["n_tok"].cpu().numpy(); dn = self.traj["env_done"].cpu().numpy().astype(bool)
         return [(tok[b, :n[b]].copy(), ia[b, :n[b]].copy(), rw[b, :n[b]].copy(), bool(dn[b])) for b in range(self.B)]
 
+    # ---- the online-RL hand-over: the finished episode as PPO data, on the device -------------------------------------
+    def ppo_records(self, n: Optional[int] = None):
+        """The episode record as `algorithms.ppo_device.PPORecords` — views of the engine's own buffers (no copy; valid until the next episode
+        is enqueued): one single-trajectory chain per env (the first `n` envs), exactly the `TextTrajectoryChain(text_trajectory, None)` the task
+        script builds from a rollout (llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py:317-342) after `TokenTrajectory.from_text_trajectory` — reward on
+        the last token of every action, `done` from the env."""
+        from .algorithms.ppo_device import PPORecords
+        tr, n = self.traj, self.B if n is None else int(n)
+        return PPORecords(tr["tokens"][:n], tr["is_action"][:n], tr["reward"][:n], tr["n_tok"][:n], tr["env_done"][:n])
+
+    def ppo_data(self, inference, *, gamma: float, lam: float, kl_weight: float, max_length: Optional[int] = None, n: Optional[int] = None, **kw):
+        """`ppo_dataset_loader` of the task script on the episode this engine just ran (train_ppo_gpt2.py:301-353 -> ppo/base_interface.py:464-669),
+        without host text, re-tokenisation or materialised logits -> (DevicePPODataset, all_kls device tensor); see `ppo_device.ppo_data_from_records`.
+        The script's length rule (episodes whose tokenisation reaches `max_length` lose their last turns) cannot trigger when max_length exceeds the
+        record capacity (asserted); a Wordle episode always has its three texts."""
+        from .algorithms.ppo_device import ppo_data_from_records
+        if max_length is not None and max_length <= self.cap:
+            raise ValueError(f"max_length = {max_length} does not exceed the record capacity {self.cap}: the script's drop-the-last-turns rule "
+                             "(train_ppo_gpt2.py:323-338) would apply — use the host path for such lengths")
+        return ppo_data_from_records(inference, self.ppo_records(n), gamma=gamma, lam=lam, kl_weight=kl_weight, max_length=max_length, **kw)
+
+    def ppo_rollouts(self, inference, n_rollouts: int, seed_generator=None, *, gamma: float, lam: float, kl_weight: float, max_length: Optional[int] = None,
+                     use_advantage_whitening: bool = True, temperature: float = 1.0, sample_seed: int = 0, use_graph: Optional[bool] = None,
+                     scripted_guesses_fn=None, steer_strength: float = 0.0, timings: Optional[dict] = None, **kw):
+        """One data-collection round of the online PPO loop on the device: `text_env_eval(n_rollouts, bsize=B)` + `ppo_dataset_loader`
+        (train_ppo_gpt2.py:301-353) -> (DevicePPODataset over all rollouts, all_kls, summary).  Per episode batch: the lock-step episode, then
+        its PPO data while the record is still in the engine's buffers; advantages are whitened once over the action tokens of ALL rollouts of
+        the round (ppo/base_interface.py:609-615 whitens over every chain handed to the call), and `summary` has `text_env_eval`'s shape, from the
+        per-env counters (no text is built)."""
+        import torch
+        from .algorithms.ppo_device import DevicePPODataset
+        from . import dist as D
+        n_batches = -(-n_rollouts // self.B)
+        seeds_all = np.zeros((n_batches, self.B), dtype=np.uint64)
+        for k in range(n_batches):
+            n_k = min(n_rollouts - k * self.B, self.B)
+            seeds_all[k, :n_k] = [next(seed_generator) for _ in range(n_k)] if seed_generator is not None else np.random.randint(0, 2 ** 31 - 1, size=n_k)
+        scripted = scripted_guesses_fn is not None
+        key = (float(temperature), int(sample_seed), float(steer_strength), scripted)
+        want_graph = (getattr(self, "_eval_graph_key", None) == key or n_batches >= 4) if use_graph is None else bool(use_graph)
+        seeds_dev = torch.from_numpy(seeds_all.view(np.int64)).to(self.dev)
+        if want_graph and getattr(self, "_eval_graph_key", None) != key:
+            self.capture_episode(temperature=temperature, sample_seed=sample_seed, steer_strength=steer_strength, scripted=scripted)
+            self._eval_graph_key = key
+        parts, kls, stats = [], [], []
+        ev = lambda: (lambda e: (e.record(), e)[1])(torch.cuda.Event(enable_timing=True))
+        t_roll = 0.0
+        for k in range(n_batches):
+            n_k = min(n_rollouts - k * self.B, self.B)
+            g = scripted_guesses_fn(k) if scripted else None
+            e0 = ev() if timings is not None else None
+            if want_graph:
+                self.replay_episode(seeds_dev[k], g)
+            else:
+                self.run_episode(seeds_all[k], temperature=temperature, sample_seed=sample_seed + (self.episodes << 20), scripted_guesses=g,
+                                 steer_strength=steer_strength)
+                self.episodes += 1
+            if timings is not None:
+                e1 = ev()
+            ds, kl = self.ppo_data(inference, gamma=gamma, lam=lam, kl_weight=kl_weight, max_length=max_length, n=n_k, use_advantage_whitening=False,
+                                   timings=timings, **kw)
+            if timings is not None:
+                torch.cuda.synchronize()
+                t_roll += e0.elapsed_time(e1)
+            parts.append(ds); kls.append(kl)
+            stats.append(np.stack([self.traj[name][:n_k].cpu().numpy().astype(np.float64) for name in ("ep_reward", "env_done", "n_steps")]))
+        cat = (lambda name: parts[0].__dict__[name]) if len(parts) == 1 else (lambda name: torch.cat([p.__dict__[name] for p in parts]))
+        ds = DevicePPODataset(**{name: cat(name) for name in DevicePPODataset.FIELDS})
+        if use_advantage_whitening:
+            adv = ds.old_advantages
+            ds.old_advantages = D.whiten_distributed(adv.view(-1), ds.should_take_action.view(-1), shift_mean=True).view(adv.shape)
+        st = np.concatenate(stats, axis=1)
+        summ = lambda x: dict(mean=np.mean(x), std=np.std(x), min=np.min(x), max=np.max(x))
+        summary = dict(reward=summ(st[0].astype(np.float32)), done=summ(st[1].astype(np.float32)), length=summ(st[2].astype(np.int64)))
+        if timings is not None:
+            timings["rollout_ms"] = timings.get("rollout_ms", 0.0) + t_roll
+        return ds, (kls[0] if len(kls) == 1 else torch.cat(kls)), summary
+
     # ---- the script-level call on the device engine -----------------------------------------------------------------
     def interactions(self, decode=None):
         """The finished episode as `List[List[InteractionTransition]]` — what `interact_environment` returns for the same

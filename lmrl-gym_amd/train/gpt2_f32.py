@@ -269,6 +269,28 @@ class GPT2F32:
         ops.lse_gather(logits, self.ld_vocab, self.vocab, targets, rows, logprob=lp, lse=lse)
         return logits, None, lse, lp
 
+    def token_logprobs(self, hidden_all, rows_idx, targets, n_rows: int, chunk: int = 8192):
+        """log p(targets[i] | row rows_idx[i]) for `n_rows` rows of `hidden_all` [*, d] (final hidden states), nothing differentiated —
+        `token_logprobs_from_logits` of PPOInference.forward (ppo/base_interface.py:396-403, gpt2/interface.py:264-302) on the rows that have a
+        next token only, in row chunks: bf16-matmul mode takes log-sum-exp and the target logit out of the LM-head GEMM's accumulators and stores
+        no logits; fp32 mode keeps one [chunk, V] fp32 logits scratch.  -> float32 [n_rows] (device)."""
+        t = self.t
+        out = t.empty(max(n_rows, 1), dtype=t.float32, device=self.dev)
+        fused = ops.FUSE_CE and self.mm is not None and self.d % 64 == 0 and ops._padn(self.vocab) % 128 == 0
+        # (bf16-matmul mode: the tied head's bf16 copy is staged on first use after the `forward` that produced `hidden_all` dropped the stale ones)
+        for r0 in range(0, n_rows, chunk):
+            n = min(chunk, n_rows - r0)
+            hq = ops.gather_rows(hidden_all, rows_idx[r0:r0 + n], n, self.d)
+            tg = targets[r0:r0 + n]
+            if fused:
+                _, _, _, lp = ops.head_fwd_ce(self.mm, hq, self.p["wte.weight"], None, n, self.d, self.vocab, tg, w_is_nk=True, keep_logits=False)
+                out[r0:r0 + n].copy_(lp)
+            else:
+                logits = self.lm_logits(hq, n)
+                ops.lse_gather(logits, self.ld_vocab, self.vocab, tg, n, logprob=out[r0:r0 + n])
+                del logits
+        return out[:n_rows]
+
     def ce_bwd_any(self, logits, yb, lse, targets, coef_ce, coef_gather, rows: int):
         if yb is not None:
             return None, ops.ce_bwd_inplace(yb, self.vocab, lse, targets, coef_ce, coef_gather, rows)

@@ -238,9 +238,10 @@ def linear_bwd_dx_gelu(mm: "MatmulBF16", dyb, w, pre, rows, k, n):
 FUSE_CE = True
 
 
-def head_fwd_ce(mm: "MatmulBF16", x, w, b, rows, k, n, targets, w_is_nk: bool = False):
+def head_fwd_ce(mm: "MatmulBF16", x, w, b, rows, k, n, targets, w_is_nk: bool = False, keep_logits: bool = True):
     """logits = x @ w + b for a vocabulary-wide head (w a Dense kernel [k][n]; w_is_nk: an embedding matrix [n][k], the tied LM head), never in
-    fp32 -> (logits_bf16 [pad(rows)][pitch(n)] (fresh buffer), lse [rows], target logit [rows] fp32, target log-probability [rows])."""
+    fp32 -> (logits_bf16 [pad(rows)][pitch(n)] (fresh buffer), lse [rows], target logit [rows] fp32, target log-probability [rows]).
+    keep_logits=False (inference: nobody differentiates this head): the logits are not stored at all (first result None)."""
     t = mm.t
     xb = mm.cast("x", x, rows, k, k)
     if w_is_nk:
@@ -249,10 +250,10 @@ def head_fwd_ce(mm: "MatmulBF16", x, w, b, rows, k, n, targets, w_is_nk: bool = 
         wt = mm.cast(("wT", w.data_ptr()), w, k, n, n, transpose=True, keep=True)
     N = _padn(n)
     nslots = _L().lmrl_gemm_bf16_ce_slots(rows, N, _pad(k))
-    yb = t.empty(_padn(rows) * _pitch(n), dtype=t.bfloat16, device=mm.dev)
+    yb = t.empty(_padn(rows) * _pitch(n), dtype=t.bfloat16, device=mm.dev) if keep_logits else None
     part = t.empty(rows * nslots * 2, dtype=t.float32, device=mm.dev)
     lse, tl, lp = (t.empty(rows, dtype=t.float32, device=mm.dev) for _ in range(3))
-    _lib.check(_L().lmrl_gemm_bf16_ce(xb.data_ptr(), wt.data_ptr(), _lib.ptr(mm.bias(b, n) if b is not None else None), yb.data_ptr(), _pitch(n), rows, N,
+    _lib.check(_L().lmrl_gemm_bf16_ce(xb.data_ptr(), wt.data_ptr(), _lib.ptr(mm.bias(b, n) if b is not None else None), _lib.ptr(yb), _pitch(n), rows, N,
                                       _pad(k), _pitch(k), _pitch(k), n, targets.data_ptr(), tl.data_ptr(), part.data_ptr(), _sp()), "lmrl_gemm_bf16_ce")
     _lib.check(_L().lmrl_lse_from_partials(part.data_ptr(), nslots, rows, tl.data_ptr(), lse.data_ptr(), lp.data_ptr(), _sp()), "lmrl_lse_from_partials")
     return yb, lse, tl, lp
