@@ -342,6 +342,149 @@ def run_train_step(mode, matmul, B, steps, warmup, dev, rank, world, use_dist, b
     return out
 
 
+def run_ppo_iteration(matmul, B, vocab, dev, rank, world, use_dist, backend, iters=2, train_steps=4, train_bsize=32, max_length=1024, host_path=True):
+    """One ONLINE PPO iteration end to end (llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py:301-353 + LLM_RL/algorithms/ppo/train.py):
+    B-env lock-step rollouts on the device engine -> PPO data (policy + initial-policy log-probs, values, KL-shaped rewards, GAE, whitening) ->
+    `train_steps` gradient steps of `train_bsize` x `max_length` (the script's blocking: max_input_length + max_output_length = 1024) -> the new
+    weights pushed into the rollout engine.  Device-resident path (`WordleRolloutEngine.ppo_rollouts` -> `DevicePPODataset` ->
+    `GPT2PPOTrain.step(**device batch)` -> `GPT2Engine.load_params`): no host text, no re-tokenisation, no [B, T, V] logits.  `host_path`: the same
+    iteration through the reference-shaped host functions (`text_env_eval` -> text chains -> `get_ppo_data_from_text_trajectory_chain` ->
+    `PPODataset` -> numpy batches -> a rebuilt engine), once, on rank 0's clock.  N > 1: rollouts and data are rank-local, the advantage moments and
+    the gradients are all-reduced (RCCL)."""
+    import torch
+    import lmrl_gym_amd  # noqa: F401
+    from lmrl_gym_amd.algorithms import ppo
+    from lmrl_gym_amd.algorithms.common import BlockingStrategy, Padding, Truncation
+    from lmrl_gym_amd.algorithms.ppo_inference import GPT2PPOInference, text_trajectory_chains_from_interactions
+    from lmrl_gym_amd.datasets import WordleTokenizer
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
+    from lmrl_gym_amd.rollout import WordleRolloutEngine, WordleTokenTable
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
+    cfg = GPT2Config.gpt2_small(50258)                      # + the added <|pad|> token (train_ppo_gpt2.py:121-122)
+    pad = 50257
+    sd = init_hf_style_state_dict(cfg, seed=0)
+    eng = GPT2Engine(cfg, sd, dev)
+    table = WordleTokenTable.default_gpt2(pad=pad)
+    ro = WordleRolloutEngine(eng, vocab, B, tokens=table, max_new_tokens=6, bad_word_reward=-10.0)
+    pol, init = GPT2F32(sd, cfg.n_head, device=dev, matmul=matmul), GPT2F32(sd, cfg.n_head, device=dev, matmul=matmul)
+    head = LinearHeadF32(dict(kernel=torch.zeros(cfg.d_model, 1), bias=torch.tensor([-4.1])), dev)          # train_ppo_gpt2.py:254-260
+    lk = dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0)
+    inf = GPT2PPOInference(pol, head, pad, initial_policy=init, tokenizer=WordleTokenizer(table, pad_token_id=pad), loss_kwargs=lk)
+    tr = ppo.GPT2PPOTrain(pol, head, pad, lk, lr=1e-5)
+    n_it = iters + 1
+    g = torch.from_numpy(scripted_guesses(vocab.all_vocab, n_it + 1, 6, B, seed=777 + rank).view(np.int32)).to(dev)
+    kw = dict(gamma=1.0, lam=0.95, kl_weight=0.001, max_length=max_length)
+    rng = np.random.default_rng(5 + rank)
+    seeds = iter(range(10 ** 7 * (rank + 1), 10 ** 9))
+
+    def barrier():
+        if use_dist:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def device_iteration(it, tm, trim=False):
+        ds, kls, summary = ro.ppo_rollouts(inf, B, seed_generator=seeds, scripted_guesses_fn=lambda bid: g[it], steer_strength=30.0, temperature=1.0,
+                                           sample_seed=4000 + rank, use_graph=True, timings=tm, **kw)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        perm = rng.permutation(len(ds))
+        loss = None
+        for k in range(train_steps):
+            _, loss, _ = tr.step(**ds.batch(perm[k * train_bsize:(k + 1) * train_bsize], width=ds.trimmed_width() if trim else None))
+        tm["batch_width"] = ds.trimmed_width() if trim else int(ds.input_ids.shape[1])
+        e1.record()
+        eng.load_params(pol.p)
+        e2.record()
+        torch.cuda.synchronize()
+        tm["train_ms"] = tm.get("train_ms", 0.0) + e0.elapsed_time(e1)
+        tm["push_weights_ms"] = tm.get("push_weights_ms", 0.0) + e1.elapsed_time(e2)
+        return int(round(summary["length"]["mean"] * B)), float(loss), float(kls.mean())
+
+    device_iteration(0, {})                                  # warm: graph capture, workspaces, optimizer state
+    tm = {}
+    barrier()
+    t0 = time.perf_counter()
+    n_steps, loss, kl = 0, None, None
+    for it in range(1, n_it):
+        ns, loss, kl = device_iteration(it, tm)
+        n_steps += ns
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt, float(n_steps)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if use_dist:
+        mx = tt[:1].clone(); sm = tt[1:].clone()
+        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(sm, op=torch.distributed.ReduceOp.SUM)
+        dt, n_steps = float(mx.item()), int(sm.item())
+    ph = {k: round(v / iters, 2) for k, v in tm.items() if k.endswith("_ms")}
+    out = dict(value=round(n_steps / dt, 1), unit="env-steps/s", ms_per_iteration=round(dt * 1e3 / iters, 2), iterations=iters, matmul=matmul,
+               envs_per_gpu=B, train_steps_per_iteration=train_steps, train_batch=f"{train_bsize} x {max_length}",
+               phases_ms=dict(rollout=ph.get("rollout_ms"), data_block=ph.get("block_ms"), data_forwards=ph.get("forward_ms"),
+                              data_logprobs=ph.get("logprobs_ms"), data_shape_gae_whiten=ph.get("shape_gae_ms"), train=ph.get("train_ms"),
+                              push_weights=ph.get("push_weights_ms")),
+               data_rows=dict(sequences=tm.get("sequences"), forward_width=tm.get("forward_width"), lm_head_rows=tm.get("rows"),
+                              action_tokens=tm.get("action_tokens"), pad_ids_inside=tm.get("pad_ids_inside")),
+               last_loss=loss, mean_kl=kl,
+               note=f"rank-local {B}-env rollouts (hipGraph replay) -> device PPO data -> {train_steps} steps of {train_bsize} x {max_length} "
+                    f"(an epoch over {B} rollouts would be {B // train_bsize} steps; the script's defaults are 128 rollouts = 4 steps) -> weights pushed into the engine; "
+                    "phases: HIP events on the launch stream, value: wall clock over whole iterations")
+    # the same iteration with every train batch cut to the round's longest episode (`DevicePPODataset.batch(width=trimmed_width())`): identical loss /
+    # gradients (right padding of a causal model), 8 x fewer rows than the script's fixed 1024-column blocking, which exists for XLA's static shapes
+    device_iteration(0, {}, trim=True)
+    tm2 = {}
+    barrier()
+    t0 = time.perf_counter()
+    n2 = 0
+    for it in range(1, n_it):
+        n2 += device_iteration(it, tm2, trim=True)[0]
+    barrier()
+    dt2 = time.perf_counter() - t0
+    tt2 = torch.tensor([dt2, float(n2)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if use_dist:
+        mx = tt2[:1].clone(); sm = tt2[1:].clone()
+        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(sm, op=torch.distributed.ReduceOp.SUM)
+        dt2, n2 = float(mx.item()), int(sm.item())
+    out["trimmed_batches"] = dict(value=round(n2 / dt2, 1), unit="env-steps/s", ms_per_iteration=round(dt2 * 1e3 / iters, 2),
+                                  train_batch=f"{train_bsize} x {tm2.get('batch_width')}", train_ms=round(tm2.get("train_ms", 0.0) / iters, 2),
+                                  note="train batches cut to ceil64(longest episode of the round) columns instead of max_length; everything else as above")
+    if host_path and rank == 0 and world == 1:
+        # the same iteration through the host-array functions with the reference's signatures (what scripts/harness.py ran before this round)
+        tok = inf.tokenizer
+        bs = BlockingStrategy(Padding.RIGHT, Truncation.RIGHT, max_length)
+        th = {}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        raw, _ = ro.text_env_eval(B, seed_generator=seeds, scripted_guesses_fn=lambda bid: g[n_it], steer_strength=30.0, temperature=1.0, sample_seed=4000, use_graph=True)
+        torch.cuda.synchronize(); th["rollout_and_host_lists"] = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        chains = text_trajectory_chains_from_interactions(raw, tok, max_length, kw["gamma"])
+        th["text_chains_and_length_rule"] = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        datas, kls_h = inf.get_ppo_data_from_text_trajectory_chain(chains, bsize=32, max_length=max_length, gamma=kw["gamma"], lam=kw["lam"], kl_weight=kw["kl_weight"])
+        dsh = ppo.PPODataset.from_ppo_data_list(datas, tok, bs)
+        torch.cuda.synchronize(); th["ppo_data"] = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        perm = rng.permutation(len(dsh))
+        for k in range(train_steps):
+            tr.step(**dsh[perm[k * train_bsize:(k + 1) * train_bsize]])
+        torch.cuda.synchronize(); th["train"] = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        eng2 = GPT2Engine(cfg, {k: v.detach().cpu() for k, v in pol.p.items()}, dev)
+        torch.cuda.synchronize(); th["push_weights"] = time.perf_counter() - t1
+        th_total = time.perf_counter() - t0
+        del eng2
+        out["host_path"] = dict(value=round(sum(len(ep) for ep in raw) / th_total, 1), unit="env-steps/s", ms_per_iteration=round(th_total * 1e3, 1), iterations=1,
+                                phases_ms={k: round(v * 1e3, 1) for k, v in th.items()},
+                                note="text_env_eval -> text chains -> get_ppo_data_from_text_trajectory_chain (bsize 32, [32, 1024, V] fp32 logits per forward) -> "
+                                     "PPODataset -> numpy batches -> a new engine from host copies of the parameters")
+    ro.close()
+    del ro, eng, pol, init, tr, inf
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main_train_step(args):
     """`--mode ilql-step` / `--mode ppo-step`: the train step of configs[2] as its own bench line (`value` = sequences / s over all ranks)."""
     import torch
@@ -423,6 +566,10 @@ def main():
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the `fp32_mode` leg of the default line (the same rollout on the fp32 engine)")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the informational `larger_batches` leg of the default line (the same run at 4096 and 8192 envs per GPU, child processes)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the `train_step` leg of the default line (ILQL M3 step, fp32 and bf16-matmul)")
+    ap.add_argument("--no-ppo-iteration", action="store_true", help="skip the `ppo_iteration` leg of the default line (rollouts -> PPO data -> 4 train steps -> weights pushed back, device-resident and host path)")
+    ap.add_argument("--ppo-iters", type=int, default=2, help="`ppo_iteration` leg: timed iterations per arithmetic mode (after one warm-up iteration)")
+    ap.add_argument("--ppo-train-steps", type=int, default=4, help="`ppo_iteration` leg: gradient steps per iteration (32 sequences each)")
+    ap.add_argument("--ppo-max-length", type=int, default=1024, help="`ppo_iteration` leg: blocking width of the PPO data / train batches (the script's 512 + 512)")
     ap.add_argument("--train-steps", type=int, default=5, help="timed steps per arithmetic mode in the `train_step` leg of the default line")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -753,6 +900,20 @@ def main():
             ts["ilql_" + mm] = run_train_step("ilql-step", mm, args.train_batch, args.train_steps, 2, dev, rank, world, use_dist, backend)
         if rank == 0:
             out["train_step"] = ts
+    if not args.no_ppo_iteration and S == 1 and args.graph:
+        # the online loop end to end (rollouts -> PPO data -> train steps -> weights back into the engine), device-resident, in the headline's bf16
+        # mode and in the reference's default fp32 arithmetic; the host-array path of the same iteration beside the bf16 one
+        pi = {}
+        for mm in ("bf16", "f32"):
+            try:
+                pi[mm] = run_ppo_iteration(mm, B, vocab, dev, rank, world, use_dist, backend, iters=args.ppo_iters, train_steps=args.ppo_train_steps,
+                                           train_bsize=min(32, B), max_length=args.ppo_max_length, host_path=(mm == "bf16"))
+            except Exception as e:          # an informational leg never loses the headline line (N > 1: a failing rank fails the collectives of all)
+                if use_dist:
+                    raise
+                pi[mm] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if rank == 0:
+            out["ppo_iteration"] = pi
     if rank == 0:
         if world == 1 and not args.no_batch_sweep and not args.no_cpu_baseline and B == 1024 and S == 1 and args.graph:       # the full default line only (the profiling tools pass --no-cpu-baseline)
             # the same engine, kernels and timed region at 4096 envs per GPU (a child process: this one's sessions and graphs stay as they are).  Not the
@@ -765,7 +926,7 @@ def main():
             for b_ in (4096, 8192):
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--batch", str(b_), "--steps", "4", "--warmup", "1", "--no-train-step", "--no-fp32-mode",
-                                        "--no-cpu-baseline", "--no-batch-sweep"], capture_output=True, text=True, timeout=240)
+                                        "--no-cpu-baseline", "--no-batch-sweep", "--no-ppo-iteration"], capture_output=True, text=True, timeout=240)
                     d4 = json.loads(r.stdout.strip().splitlines()[-1])
                     out["larger_batches"][str(b_)] = {"value": d4["value"], "unit": d4["unit"], "ms_per_step": d4["ms_per_step"], "steps": d4["steps"],
                                                       "roofline_frac": d4["roofline"]["frac"], "roofline_kernel": d4["roofline"]["kernel"]}

@@ -634,7 +634,11 @@ void lmrl_train_ops_set_variant(int v);
  * round-4 sweeps: 128 queries per workgroup, two query groups per wave, global_load_lds tile ring) */
 void lmrl_flash_set_variant(int v);
 int lmrl_embed_fwd(const float *wte_d, const float *wpe_d, const int32_t *ids_d, const int32_t *pos_d, float *x_d, int rows, int d, void *stream);
-int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d, float *dwte_d, float *dwpe_d, int rows, int d, void *stream);
+/* dwte[ids[r]] += dx[r], dwpe[pos[r]] += dx[r] without atomics (one owner wave per distinct index, fixed order: bit-reproducible).
+ * live_d (optional, uint8 [rows]): rows with flag 0 are skipped — the padded positions of a right-padded batch (attention_mask == 0), whose dx is
+ * exactly zero and which would otherwise all pile onto the pad id's owner wave. */
+int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d, const uint8_t *live_d, float *dwte_d, float *dwpe_d, int rows, int d,
+                   void *stream);
 /* Row compaction for the vocabulary-wide heads of the train steps: the losses read the Q / policy logits only on rows whose mask is set
  * (should_take_action x attention mask: ilql/base_interface.py:22-119, ppo/base_interface.py:72-142), so a head runs on the gathered rows
  * dst[i] = src[idx[i]] and its input gradient goes back with dst[idx[i]] (=|+=) src[i].  idx_d holds DISTINCT rows (no atomics). */

@@ -151,7 +151,7 @@ _SIGS = {
     "lmrl_layernorm_add_fwd": (c_int, [c_void_p] * 8 + [ctypes.c_long, c_int, c_int, c_float, c_void_p]),
     "lmrl_layernorm_fwd_staged": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_int, c_float, c_void_p]),
     "lmrl_gelu_fwd_staged": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]),
-    "lmrl_embed_bwd": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "lmrl_embed_bwd": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),
     "lmrl_layernorm_fwd": (c_int, [c_void_p] * 6 + [c_int, c_int, c_float, c_void_p]),
     "lmrl_layernorm_bwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
     "lmrl_layernorm_bwd_fused_supported": (c_int, [c_int]),

@@ -91,32 +91,54 @@ class DevicePPODataset:
 
     FIELDS = ("input_ids", "should_take_action", "old_logprobs", "old_values", "old_advantages", "old_returns")
 
-    def __init__(self, **arrays):
+    def __init__(self, longest: Optional[int] = None, **arrays):
+        """longest: number of tokens of the longest trajectory in the dataset (known from the build's one readback), for `batch(width=...)`."""
         for k in self.FIELDS:
             setattr(self, k, arrays[k])
         n, t = self.input_ids.shape
         for k in self.FIELDS[1:]:
             assert tuple(getattr(self, k).shape) == (n, t - 1)
+        self.longest = int(longest) if longest is not None else int(t)
+
+    def trimmed_width(self, multiple: int = 64) -> int:
+        """The narrowest batch width (a multiple of `multiple`) that still holds every trajectory."""
+        return min(int(self.input_ids.shape[1]), -(-self.longest // multiple) * multiple)
 
     def __len__(self) -> int:
         return int(self.input_ids.shape[0])
 
-    def batch(self, index) -> Dict[str, "torch.Tensor"]:
+    def batch(self, index, width: Optional[int] = None) -> Dict[str, "torch.Tensor"]:
         """Rows `index` (a device int32 tensor, or anything numpy can turn into indices) of every array: a shuffled batch of the dataloader
-        (`lmrl_gather_rows_bytes`), keyword-compatible with `GPT2PPOTrain.step(**batch)`."""
+        (`lmrl_gather_rows_bytes`), keyword-compatible with `GPT2PPOTrain.step(**batch)`.
+        width (>= `longest`, default: the dataset's blocking width): the batch keeps only the first `width` columns.  The reference blocks every
+        batch to max_input_length + max_output_length because XLA wants one static shape; a right-padded causal model computes the same loss,
+        logs (but `padding_percentage`) and gradients on `trimmed_width()` columns — at 70-token Wordle episodes 8 x fewer rows than 1024."""
         import torch
         if not isinstance(index, torch.Tensor):
             index = torch.from_numpy(np.ascontiguousarray(index, dtype=np.int32)).to(self.input_ids.device)
         index = index.to(torch.int32).contiguous()
         n = int(index.numel())
+        T = int(self.input_ids.shape[1])
+        w = T if width is None else int(width)
+        if not (self.longest <= w <= T):
+            raise ValueError(f"batch width {w} must lie between the longest trajectory ({self.longest}) and the dataset width ({T})")
         out = {}
         for k in self.FIELDS:
             src = getattr(self, k)
+            cols = w if k == "input_ids" else w - 1
             dst = torch.empty((n, src.shape[1]), dtype=src.dtype, device=src.device)
             _lib.check(_lib.lib().lmrl_gather_rows_bytes(src.data_ptr(), index.data_ptr(), dst.data_ptr(), n, src.shape[1] * src.element_size(),
                                                          _lib.stream_ptr()), "lmrl_gather_rows_bytes")
-            out[k] = dst
+            out[k] = dst if cols == src.shape[1] else dst[:, :cols].contiguous()
         return out
+
+    def batches(self, rng, bsize: int, truncate: bool = True, width: Optional[int] = None):
+        """One epoch of shuffled batches (`datasets.dataloader` / ppo/train.py:264 on the device dataset)."""
+        n = len(self)
+        order = np.arange(n) if rng is None else rng.permutation(n)
+        stop = n - (n % bsize) if truncate else n
+        for i in range(0, stop, bsize):
+            yield self.batch(order[i:i + bsize], width=width)
 
     def to_host(self) -> PPODataset:
         """The reference's host dataset (numpy) — parity tests, pickling (`save_ppo_dataset`)."""
@@ -208,7 +230,7 @@ def ppo_data_from_records(inference, rec: PPORecords, *, gamma: float, lam: floa
         for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
             timings[name + "_ms"] = timings.get(name + "_ms", 0.0) + a.elapsed_time(b)
         timings.update(rows=n_rows, action_tokens=n_act, forward_width=tf, sequences=n, pad_ids_inside=timings.get("pad_ids_inside", 0) + pads)
-    return DevicePPODataset(**ds), kls[:n_act]
+    return DevicePPODataset(longest=longest, **ds), kls[:n_act]
 
 
 def masked_rows_device(should_take_action, attention_mask, input_ids, T: int):

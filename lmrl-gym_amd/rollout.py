@@ -366,11 +366,12 @@ class WordleRolloutEngine:
         """`ppo_dataset_loader` of the task script on the episode this engine just ran (train_ppo_gpt2.py:301-353 -> ppo/base_interface.py:464-669),
         without host text, re-tokenisation or materialised logits -> (DevicePPODataset, all_kls device tensor); see `ppo_device.ppo_data_from_records`.
         The script's length rule (episodes whose tokenisation reaches `max_length` lose their last turns) cannot trigger when max_length exceeds the
-        record capacity (asserted); a Wordle episode always has its three texts."""
+        longest possible episode (checked); a Wordle episode always has its three texts."""
         from .algorithms.ppo_device import ppo_data_from_records
-        if max_length is not None and max_length <= self.cap:
-            raise ValueError(f"max_length = {max_length} does not exceed the record capacity {self.cap}: the script's drop-the-last-turns rule "
-                             "(train_ppo_gpt2.py:323-338) would apply — use the host path for such lengths")
+        longest = min(self.cap, len(self.tokens.header) + W.N_TRIES * (self.max_new + 1 + 6))   # header + 6 x (action + forced '\n' + 'g y b b y\n')
+        if max_length is not None and max_length <= longest:
+            raise ValueError(f"max_length = {max_length} does not exceed the longest possible episode ({longest} tokens): the script's drop-the-last-turns "
+                             "rule (train_ppo_gpt2.py:323-338) could apply — use the host path for such lengths")
         return ppo_data_from_records(inference, self.ppo_records(n), gamma=gamma, lam=lam, kl_weight=kl_weight, max_length=max_length, **kw)
 
     def ppo_rollouts(self, inference, n_rollouts: int, seed_generator=None, *, gamma: float, lam: float, kl_weight: float, max_length: Optional[int] = None,
@@ -419,7 +420,7 @@ class WordleRolloutEngine:
             parts.append(ds); kls.append(kl)
             stats.append(np.stack([self.traj[name][:n_k].cpu().numpy().astype(np.float64) for name in ("ep_reward", "env_done", "n_steps")]))
         cat = (lambda name: parts[0].__dict__[name]) if len(parts) == 1 else (lambda name: torch.cat([p.__dict__[name] for p in parts]))
-        ds = DevicePPODataset(**{name: cat(name) for name in DevicePPODataset.FIELDS})
+        ds = DevicePPODataset(longest=max(p.longest for p in parts), **{name: cat(name) for name in DevicePPODataset.FIELDS})
         if use_advantage_whitening:
             adv = ds.old_advantages
             ds.old_advantages = D.whiten_distributed(adv.view(-1), ds.should_take_action.view(-1), shift_mean=True).view(adv.shape)

@@ -424,7 +424,8 @@ class GPT2F32:
             if on_final is not None:
                 on_final([q + n for n in ("mlp.c_proj.weight", "mlp.c_proj.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "ln_2.weight", "ln_2.bias",
                                           "attn.c_proj.weight", "attn.c_proj.bias", "attn.c_attn.weight", "attn.c_attn.bias", "ln_1.weight", "ln_1.bias")])
-        ops.embed_bwd(dx, cache["ids"], cache["pos"], grads["wte.weight"], grads["wpe.weight"], R, d)
+        # padded positions (attention_mask 0) are never read by a loss term nor attended to: their dx is exactly zero — skipped (ops.embed_bwd)
+        ops.embed_bwd(dx, cache["ids"], cache["pos"], grads["wte.weight"], grads["wpe.weight"], R, d, live=cache["km"])
         if on_final is not None:
             on_final(["wpe.weight", "wte.weight"])
         return grads

@@ -464,8 +464,9 @@ def embed_fwd(wte, wpe, ids, pos, x, rows, d):
     _lib.check(_L().lmrl_embed_fwd(wte.data_ptr(), wpe.data_ptr(), ids.data_ptr(), pos.data_ptr(), x.data_ptr(), rows, d, _sp()), "lmrl_embed_fwd")
 
 
-def embed_bwd(dx, ids, pos, dwte, dwpe, rows, d):
-    _lib.check(_L().lmrl_embed_bwd(dx.data_ptr(), ids.data_ptr(), pos.data_ptr(), dwte.data_ptr(), dwpe.data_ptr(), rows, d, _sp()), "lmrl_embed_bwd")
+def embed_bwd(dx, ids, pos, dwte, dwpe, rows, d, live=None):
+    """live (uint8 [rows], optional): the attention mask — padded rows (flag 0) are skipped (their dx is exactly zero)."""
+    _lib.check(_L().lmrl_embed_bwd(dx.data_ptr(), ids.data_ptr(), pos.data_ptr(), _lib.ptr(live), dwte.data_ptr(), dwpe.data_ptr(), rows, d, _sp()), "lmrl_embed_bwd")
 
 
 def softmax_causal_fwd(s, key_mask, p, batch, heads, t):

@@ -214,9 +214,43 @@ def cmd_ppo(a):
         vocab, env = _wordle_env(a)
     step = 0
     limit = None if a.max_steps is None else int(a.max_steps)
+    # --device-rollouts without warpers / a BC batch: the whole iteration stays in HBM — rollout records -> PPO data -> device batches -> train
+    # steps -> the trainer's parameters copied into the engine in place (WordleRolloutEngine.ppo_rollouts, algorithms/ppo_device.py)
+    resident = a.device_rollouts and not int(a.policy_top_k or 0) and a.policy_top_p is None
+    ro_res = _device_rollouts(policy.engine, vocab, tok, a.rollout_bsize, a.bad_word_reward, min(a.max_output_length, 12)) if resident else None
     for rnd in range(a.n_rounds):
         if limit is not None and step >= limit:
             break
+        if resident:
+            ds, kls, summary = ro_res.ppo_rollouts(inf, a.n_rollouts, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)), gamma=a.gamma, lam=a.lam,
+                                                   kl_weight=ctl.value, max_length=max_len, use_advantage_whitening=a.use_advantage_whitening,
+                                                   temperature=a.policy_temperature or 1.0, sample_seed=rnd, bsize=max(a.ppo_data_bsize, 64))
+            mean_kl = float(kls.cpu().numpy().mean()) if kls.numel() else 0.0
+            ctl.update(mean_kl, a.train_bsize)
+            _log("data_collection", dict(round=rnd, env_interaction=summary, mean_kl=mean_kl, kl_ctrl_value=ctl.value, n_chains=len(ds), device_resident=True))
+            bc_iter = None
+            for epoch in range(a.epochs):
+                if limit is not None and step >= limit:
+                    break
+                for batch in ds.batches(np.random.default_rng(rnd * 1000 + epoch), min(a.train_bsize, len(ds)), truncate=True,
+                                        width=ds.trimmed_width() if a.trim_batches else None):
+                    extra = {}
+                    if bc is not None:
+                        if bc_iter is None:
+                            bc_iter = DS.dataloader(np.random.default_rng(7 + step), bc, int(a.train_bc_bsize or a.train_bsize), truncate=True)
+                        try:
+                            bb = next(bc_iter)
+                        except StopIteration:
+                            bc_iter = DS.dataloader(np.random.default_rng(7 + step), bc, int(a.train_bc_bsize or a.train_bsize), truncate=True)
+                            bb = next(bc_iter)
+                        extra = dict(bc_data_input_ids=bb["input_ids"], bc_data_input_training_mask=bb["input_training_mask"])
+                    _, loss, logs = tr.step(**batch, **extra)
+                    step += 1
+                    _log("train", dict(step=step, round=rnd, loss=loss))
+                    if limit is not None and step >= limit:
+                        break
+            policy.engine.load_params(pol_f32.p)
+            continue
         if a.device_rollouts:       # env + policy + lock-step loop on the GPU; same (interactions, summary) as text_env_eval
             ro = _device_rollouts(policy.engine, vocab, tok, a.rollout_bsize, a.bad_word_reward, min(a.max_output_length, 12))
             raw, summary = ro.text_env_eval(a.n_rollouts, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)), temperature=a.policy_temperature or 1.0,
@@ -368,6 +402,8 @@ def build_parser() -> argparse.ArgumentParser:
     sub.choices["ppo"].add_argument("--bc-data", default=None)
     pp = sub.choices["ppo"]
     pp.add_argument("--env", default="wordle", choices=["wordle", "chess"])
+    pp.add_argument("--trim-batches", type=int, default=0, help="device-resident loop: train on batches cut to the round's longest episode (multiple of 64) instead of "
+                                                                  "max_input_length + max_output_length columns — same loss and gradients, fewer padded rows")
     pp.add_argument("--chess-engine", default=os.environ.get("CHESS_ENGINE_PATH"), help="UCI engine binary (the reference: stockfish/stockfish-ubuntu-20.04-x86-64-avx2)")
     pp.add_argument("--chess-use-nnue", default="true", help="'false' for a binary built without the net file")
     pp.add_argument("--chess-random-opponent", type=int, default=0)

@@ -222,12 +222,13 @@ def test_bench_gpus_2_spawns_two_ranks_and_reports_the_train_step():
     if torch.cuda.device_count() < 2:
         # two ranks on ONE GPU: without the explicit override the bench must refuse (non-zero) instead of quietly measuring gloo
         r0 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "64", "--no-fp32-mode",
-                             "--no-train-step", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+                             "--no-train-step", "--no-cpu-baseline", "--no-ppo-iteration"], capture_output=True, text=True, timeout=600, env=env)
         assert r0.returncode != 0 and "LMRL_BENCH_BACKEND=gloo" in (r0.stderr + r0.stdout), (r0.returncode, r0.stderr[-1500:])
         assert not [ln for ln in r0.stdout.splitlines() if ln.startswith("{")]
         env["LMRL_BENCH_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "64",
-                        "--train-batch", "2", "--train-steps", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+                        "--train-batch", "2", "--train-steps", "1", "--no-cpu-baseline", "--ppo-iters", "1", "--ppo-train-steps", "1", "--ppo-max-length", "192"],
+                       capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -239,6 +240,10 @@ def test_bench_gpus_2_spawns_two_ranks_and_reports_the_train_step():
     assert (out["rccl_version"] is not None) == (out["backend"] == "nccl")
     assert out["config"]["env_steps_timed"] >= 2 * 64            # both ranks' env steps are summed
     assert out["fp32_mode"]["value"] > 0 and out["bf16x3_mode"]["value"] > 0 and out["host_materialise_ms"] > 0
+    # the online PPO iteration as a 2-rank data-parallel job: rank-local rollouts and PPO data, advantage moments and gradients all-reduced
+    for mm in ("bf16", "f32"):
+        pi = out["ppo_iteration"][mm]
+        assert pi["value"] > 0 and np.isfinite(pi["last_loss"]) and pi["envs_per_gpu"] == 64 and pi["phases_ms"]["train"] > 0, pi
     ts = out["train_step"]
     for k in ("ilql_f32", "ilql_bf16"):
         assert ts[k]["ms_per_step"] > 0 and np.isfinite(ts[k]["last_loss"])

@@ -178,6 +178,9 @@ def test_harness_script_subcommands_at_toy_scale(tmp_path, capsys):
             "--max-input-length", "72", "--max-output-length", "12"])
     H.main(["ppo", "--n-rollouts", "6", "--rollout-bsize", "4", "--ppo-data-bsize", "4", "--train-bsize", "2", "--max-steps", "1",
             "--max-input-length", "96", "--max-output-length", "6", "--device-rollouts", "1"])
+    # the device-resident iteration (records -> PPO data -> device batches -> steps -> weights back in place), two rounds, BC batch, trimmed batches
+    H.main(["ppo", "--bc-data", data, "--n-rollouts", "10", "--rollout-bsize", "4", "--train-bsize", "4", "--n-rounds", "2", "--max-steps", "3",
+            "--max-input-length", "96", "--max-output-length", "6", "--device-rollouts", "1", "--trim-batches", "1", "--bf16-activations", "1"])
     # online filtered BC (wordle/online_filtered_bc): rollouts -> top 50 % by reward -> BC on the action tokens, text path and device loop
     H.main(["filtered-bc", "--n-rollouts", "6", "--rollout-bsize", "3", "--filter-percengage", "0.5", "--train-bsize", "2", "--max-steps", "1",
             "--max-input-length", "96", "--max-output-length", "8"])
@@ -197,7 +200,7 @@ def test_harness_script_subcommands_at_toy_scale(tmp_path, capsys):
     H.main(["maze-eval", "--max-steps", "3", "--generation-bsize", "8", "--max-input-length", "160", "--max-output-length", "6"])
     lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
     tags = [next(iter(l)) for l in lines]
-    assert tags.count("eval") >= 10 and tags.count("data_collection") >= 5 and "gen_data" in tags and "data_collection" in tags and "maze_eval" in tags and "train" in tags
+    assert tags.count("eval") >= 10 and tags.count("data_collection") >= 7 and "gen_data" in tags and "data_collection" in tags and "maze_eval" in tags and "train" in tags
     me = next(l["maze_eval"] for l in lines if "maze_eval" in l)
     assert me["n"] == 26 and 0.0 <= me["move_accuracy"] <= 100.0
 

@@ -162,7 +162,13 @@ def test_device_path_equals_host_form_on_engine_episodes(wordle_setup):
     assert h2.input_ids.shape == (s["B"], 160) and (h2.input_ids[:, max_length:] == inf.pad).all()
     np.testing.assert_allclose(h2.old_advantages[:, :max_length - 1], host2.old_advantages, rtol=1e-5, atol=1e-5)
     with pytest.raises(ValueError):
-        ro.ppo_data(inf, max_length=ro.cap, **kw)                                    # the script's drop-the-last-turns rule could apply
+        ro.ppo_data(inf, max_length=76, **kw)                                        # <= 4 + 6 x (7 + 6) tokens: the script's drop-the-last-turns rule could apply
+    # batches cut to the longest episode: the same rows, fewer padded columns
+    w = ds.trimmed_width()
+    assert ds.longest == int(n_tok.max()) and w == 128 and ds2.trimmed_width() == 128
+    full, cut = ds2.batch(np.arange(8)), ds2.batch(np.arange(8), width=w)
+    for k in full:
+        assert torch.equal(full[k][:, :cut[k].shape[1]], cut[k]) and cut[k].shape[1] == (w if k == "input_ids" else w - 1) and cut[k].is_contiguous()
 
 
 def test_device_path_in_the_bf16_matmul_mode(wordle_setup):
