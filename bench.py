@@ -342,6 +342,90 @@ def run_train_step(mode, matmul, B, steps, warmup, dev, rank, world, use_dist, b
     return out
 
 
+def run_rl_reduce(dev, chains=(4096, 65536), L=96, budget_bytes=640 << 20, iters=40):
+    """M5 (north_star's "per-token reward-to-go / GAE scan ... as wavefront shuffle kernels ... rocprof HBM GB/s"): `lmrl_gae`,
+    `lmrl_rtg`, `lmrl_whiten_moments` + `lmrl_whiten_apply` on token chains of the rollout's shape (L = 96 slots, 40..96 of them used, 6-on /
+    6-off action runs after a 4-token header), timed with HIP events over `iters` launches that ROTATE through enough independent buffer sets to
+    exceed the 256 MB memory-side cache (a loop over one 100 MB set would be served from it).  `achieved` = ALGORITHMIC bytes per launch / average
+    launch time: inputs only below each chain's length (values 4 B + rewards 4 B + flag 1 B per used slot, + bootstrap value and length per
+    chain), outputs for every slot (adv + ret 8 B; rtg 4 B); whitening: 5 B per element read by each pass + 4 B written by the second.
+    Reference code: ppo/base_interface.py:245-293, mc_returns/data.py:10-14."""
+    import torch
+    import lmrl_gym_amd  # noqa: F401
+    from lmrl_gym_amd import _lib
+    Lb, sp = _lib.lib(), _lib.stream_ptr
+    out = {}
+    for B in chains:
+        rng = np.random.RandomState(B)
+        lens = rng.randint(40, L + 1, size=B).astype(np.int32)
+        t = np.arange(L)[None, :]
+        sta = ((t >= 4) & (((t - 4) // 6) % 2 == 0) & (t < lens[:, None])).astype(np.uint8)
+        n = B * L
+        used = int(lens.sum())
+        set_bytes = n * (4 + 4 + 1 + 8 + 4 + 4) + B * 8
+        n_sets = int(min(64, max(2, -(-budget_bytes // set_bytes))))
+        sets = []
+        for _ in range(n_sets):
+            sets.append(dict(v=torch.randn(B, L + 1, device=dev), r=torch.randn(B, L, device=dev), s=torch.from_numpy(sta).to(dev),
+                             ln=torch.from_numpy(lens).to(dev), adv=torch.empty(B, L, device=dev), ret=torch.empty(B, L, device=dev),
+                             rtg=torch.empty(B, L, device=dev), y=torch.empty(B, L, device=dev), mom=torch.zeros(3, dtype=torch.float64, device=dev)))
+        p = lambda x: x.data_ptr()
+        fns = dict(
+            gae=(lambda d: _lib.check(Lb.lmrl_gae(p(d["v"]), p(d["r"]), p(d["s"]), p(d["ln"]), p(d["adv"]), p(d["ret"]), B, L, 0.99, 0.95, sp())),
+                 used * 9 + B * 8 + n * 8),
+            rtg=(lambda d: _lib.check(Lb.lmrl_rtg(p(d["r"]), p(d["s"]), p(d["ln"]), p(d["rtg"]), B, L, 0.99, sp())), used * 5 + B * 4 + n * 4),
+            whiten_moments=(lambda d: _lib.check(Lb.lmrl_whiten_moments(p(d["adv"]), p(d["s"]), p(d["mom"]), n, sp())), n * 5),
+            whiten_apply=(lambda d: _lib.check(Lb.lmrl_whiten_apply(p(d["adv"]), p(d["s"]), p(d["mom"]), p(d["y"]), n, 1, sp())), n * 9))
+        res = {}
+        for name, (fn, nbytes) in fns.items():
+            for d in sets[:4]:
+                fn(d)
+            torch.cuda.synchronize()
+            # the `iters` launches as ONE hipGraph replay: a Python / ctypes launch costs ~7 us of host time, more than these kernels run
+            st = torch.cuda.Stream(device=dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(st):
+                with torch.cuda.graph(graph, stream=st, capture_error_mode="thread_local"):
+                    for i in range(iters):
+                        fn(sets[i % n_sets])
+                graph.replay()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                graph.replay()
+                e1.record(st)
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            del graph
+            gbs = nbytes / (us * 1e-6) / 1e9
+            res[name] = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), avg_launch_us=round(us, 2),
+                             algorithmic_bytes_per_launch=int(nbytes), traffic=None)
+        # HBM traffic per launch from the committed counter passes of this same leg (tools/prof_rl_reduce.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # separate runs; 2 x FETCH + WRITE per the gfx950 correction of the microarch guide) — not measurable from inside the process
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_rl_reduce_pmc.json")))
+            pick = max if B == max(chains) else min
+            for name, pat in (("gae", "chain_scan_row2_kernel<true"), ("rtg", "chain_scan_row2_kernel<false"), ("whiten_moments", "whiten_moments_kernel"),
+                              ("whiten_apply", "whiten_apply_kernel")):
+                ks = [k for k in pmc if pat in k]
+                if ks:
+                    k = pick(ks, key=lambda q: int(q.split("grid=")[1]))
+                    res[name]["traffic"] = round((2.0 * pmc[k].get("fetch_size_kb_avg", 0.0) + pmc[k].get("write_size_kb_avg", 0.0)) * 1024)
+                    res[name]["traffic_source"] = "profiles/r05_rl_reduce_pmc.json (2*FETCH_SIZE + WRITE_SIZE)"
+        except Exception:
+            pass
+        res["action_tokens_per_s_gae"] = round(float(sta.sum()) / (res["gae"]["avg_launch_us"] * 1e-6), 0)
+        res["buffer_sets"] = n_sets
+        out[str(B)] = res
+        del sets
+        torch.cuda.empty_cache()
+    return dict(chains=out, slots_per_chain=L, kernels="chain_scan_row2_kernel<GAE|RTG, 3> (four chains per wave, one per 16-lane DPP row, two slots per lane: register-resident reverse scans "
+                "of affine maps by row_shl DPP steps, no LDS, streaming accesses), whiten_moments_kernel + whiten_finish_kernel / whiten_apply_kernel (16-byte accesses, fp64 partials)",
+                note="HIP events around ONE hipGraph replay of 40 launches rotating through `buffer_sets` independent input / output sets (> 256 MB in total: not "
+                     "served by the memory-side cache); avg_launch_us therefore includes the ~1 us dispatch gap between graph nodes; rocprofv3 summary of the same "
+                     "command: profiles/r05_rl_reduce_kernel_stats.csv")
+
+
 def run_ppo_iteration(matmul, B, vocab, dev, rank, world, use_dist, backend, iters=2, train_steps=4, train_bsize=32, max_length=1024, host_path=True):
     """One ONLINE PPO iteration end to end (llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py:301-353 + LLM_RL/algorithms/ppo/train.py):
     B-env lock-step rollouts on the device engine -> PPO data (policy + initial-policy log-probs, values, KL-shaped rewards, GAE, whitening) ->
@@ -566,6 +650,8 @@ def main():
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the `fp32_mode` leg of the default line (the same rollout on the fp32 engine)")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the informational `larger_batches` leg of the default line (the same run at 4096 and 8192 envs per GPU, child processes)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the `train_step` leg of the default line (ILQL M3 step, fp32 and bf16-matmul)")
+    ap.add_argument("--no-rl-reduce", action="store_true", help="skip the `rl_reduce` leg of the default line (GAE / reward-to-go / whitening kernels at 4096 and 65536 chains)")
+    ap.add_argument("--mode-rl-reduce-only", action="store_true", help="run ONLY the `rl_reduce` leg and print it as a JSON line (profiling: tools/prof_rl_reduce.sh)")
     ap.add_argument("--no-ppo-iteration", action="store_true", help="skip the `ppo_iteration` leg of the default line (rollouts -> PPO data -> 4 train steps -> weights pushed back, device-resident and host path)")
     ap.add_argument("--ppo-iters", type=int, default=2, help="`ppo_iteration` leg: timed iterations per arithmetic mode (after one warm-up iteration)")
     ap.add_argument("--ppo-train-steps", type=int, default=4, help="`ppo_iteration` leg: gradient steps per iteration (32 sequences each)")
@@ -581,6 +667,11 @@ def main():
         _D.set_grad_compression(args.grad_allreduce)
     if args.mode != "rollout":
         return main_train_step(args)
+    if args.mode_rl_reduce_only:
+        import torch
+        torch.cuda.set_device(0)
+        print(json.dumps({"rl_reduce": run_rl_reduce(torch.device("cuda", 0))}), flush=True)
+        return
 
     import torch
     import lmrl_gym_amd  # noqa: F401
@@ -900,6 +991,8 @@ def main():
             ts["ilql_" + mm] = run_train_step("ilql-step", mm, args.train_batch, args.train_steps, 2, dev, rank, world, use_dist, backend)
         if rank == 0:
             out["train_step"] = ts
+    if rank == 0 and not args.no_rl_reduce:
+        out["rl_reduce"] = run_rl_reduce(dev)
     if not args.no_ppo_iteration and S == 1 and args.graph:
         # the online loop end to end (rollouts -> PPO data -> train steps -> weights back into the engine), device-resident, in the headline's bf16
         # mode and in the reference's default fp32 arithmetic; the host-array path of the same iteration beside the bf16 one
@@ -926,7 +1019,7 @@ def main():
             for b_ in (4096, 8192):
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--batch", str(b_), "--steps", "4", "--warmup", "1", "--no-train-step", "--no-fp32-mode",
-                                        "--no-cpu-baseline", "--no-batch-sweep", "--no-ppo-iteration"], capture_output=True, text=True, timeout=240)
+                                        "--no-cpu-baseline", "--no-batch-sweep", "--no-ppo-iteration", "--no-rl-reduce"], capture_output=True, text=True, timeout=240)
                     d4 = json.loads(r.stdout.strip().splitlines()[-1])
                     out["larger_batches"][str(b_)] = {"value": d4["value"], "unit": d4["unit"], "ms_per_step": d4["ms_per_step"], "steps": d4["steps"],
                                                       "roofline_frac": d4["roofline"]["frac"], "roofline_kernel": d4["roofline"]["kernel"]}

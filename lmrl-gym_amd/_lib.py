@@ -62,6 +62,7 @@ _SIGS = {
     "lmrl_gpt2_kv_broadcast": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmrl_sgemm_set_variant": (None, [c_int]),
     "lmrl_train_ops_set_variant": (None, [c_int]),
+    "lmrl_rl_reduce_set_variant": (None, [c_int]),
     "lmrl_flash_set_variant": (None, [c_int]),
     "lmrl_sample_ws_bytes": (c_size_t, [c_int, c_int]),
     "lmrl_sample_logits_steer": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

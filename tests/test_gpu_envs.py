@@ -356,7 +356,9 @@ def _chains(rng, B, L):
     return sta, lens, values, rewards
 
 
-@pytest.mark.parametrize("B,L,gamma,lam", [(64, 37, 0.99, 0.95), (512, 200, 1.0, 0.95), (33, 1024, 0.9, 0.5), (5, 3, 1.0, 1.0)])
+# (L <= 512: the register-resident scan kernels with 1 .. 8 chunks of 64 slots; longer chains: the LDS-compaction kernel)
+@pytest.mark.parametrize("B,L,gamma,lam", [(64, 37, 0.99, 0.95), (512, 200, 1.0, 0.95), (33, 1024, 0.9, 0.5), (5, 3, 1.0, 1.0), (700, 96, 0.99, 0.95),
+                                           (41, 128, 1.0, 0.95), (37, 300, 0.97, 0.9), (19, 512, 0.99, 0.95), (19, 513, 0.99, 0.95), (9, 64, 0.5, 1.0)])
 def test_gae_kernel(dev, B, L, gamma, lam):
     from oracle import rl
     from lmrl_gym_amd import _lib
@@ -381,7 +383,7 @@ def test_gae_kernel(dev, B, L, gamma, lam):
         np.testing.assert_allclose(ret[b], er, rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("B,L,gamma", [(40, 61, 0.99), (300, 130, 1.0), (7, 1024, 0.95)])
+@pytest.mark.parametrize("B,L,gamma", [(40, 61, 0.99), (300, 130, 1.0), (7, 1024, 0.95), (500, 96, 0.99), (23, 400, 1.0), (11, 512, 0.9)])
 def test_rtg_kernel(dev, B, L, gamma):
     from oracle import rl
     from lmrl_gym_amd import _lib
@@ -401,11 +403,38 @@ def test_rtg_kernel(dev, B, L, gamma):
         np.testing.assert_allclose(out[b], exp, rtol=3e-5, atol=3e-5)
 
 
-def test_whiten_kernel(dev):
+def test_register_scan_kernels_equal_the_compaction_kernels(dev):
+    """The round-5 register-resident scans against the round-1 LDS-compaction kernels on the same chains (`lmrl_rl_reduce_set_variant(1)`): the two
+    associate the same recurrence differently — equal within fp32 rounding, identical zero pattern."""
+    from lmrl_gym_amd import _lib
+    L_ = _lib.lib()
+    rng = np.random.RandomState(3)
+    B, L = 3000, 96
+    sta, lens, values, rewards = _chains(rng, B, L)
+    dv = lambda x: torch.from_numpy(x).to(dev)
+    v_d, r_d, s_d, l_d = dv(values), dv(rewards), dv(sta.astype(np.uint8)), dv(lens)
+    outs = []
+    try:
+        for variant in (0, 1, 2, 3):
+            L_.lmrl_rl_reduce_set_variant(variant)
+            adv, ret, rtg = (torch.full((B, L), 5.0, device=dev) for _ in range(3))
+            _lib.check(L_.lmrl_gae(_lib.ptr(v_d), _lib.ptr(r_d), _lib.ptr(s_d), _lib.ptr(l_d), _lib.ptr(adv), _lib.ptr(ret), B, L, 0.99, 0.95, _lib.stream_ptr()))
+            _lib.check(L_.lmrl_rtg(_lib.ptr(r_d), _lib.ptr(s_d), _lib.ptr(l_d), _lib.ptr(rtg), B, L, 0.99, _lib.stream_ptr()))
+            outs.append([t.cpu().numpy() for t in (adv, ret, rtg)])
+    finally:
+        L_.lmrl_rl_reduce_set_variant(0)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert ((a == 0) == (b == 0)).all() and (a[~sta] == 0).all()
+            np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("n", [100_003, 100_004, 65536 * 96])
+def test_whiten_kernel(dev, n):
     from oracle import rl
     from lmrl_gym_amd import _lib
     rng = np.random.RandomState(9)
-    x = (rng.randn(100_003) * 3 + 1.5).astype(np.float32)
+    x = (rng.randn(n) * 3 + 1.5).astype(np.float32)
     mask = rng.rand(x.size) < 0.3
     L = _lib.lib()
     xd = torch.from_numpy(x).to(dev); md = torch.from_numpy(mask.astype(np.uint8)).to(dev)
