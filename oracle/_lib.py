@@ -36,6 +36,9 @@ def lib() -> ctypes.CDLL:
         L.orc_wordle_get_state.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_int)]
         L.orc_wordle_run.restype = ctypes.c_long
         L.orc_wordle_run.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int]
+        L.orc_wordle_run_mt.restype = ctypes.c_long
+        L.orc_wordle_run_mt.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_int)]
         _lib = L
     return _lib
 

@@ -81,6 +81,27 @@ class OracleWordleEnv:
         return np.frombuffer(buf, dtype=np.uint8).reshape(26, 5).copy(), nf.value
 
 
+def run_scripted_timed(words: Sequence[str], n_envs: int, guess_idx: np.ndarray, require: bool = True, bad: float = -10.0, threads: int = 1):
+    """cpu_baseline driver -> (env steps executed, seconds of the stepping loop alone, threads used): the envs are created and reset outside the
+    clock, then stepped on `threads` host threads (OpenMP over the independent envs; <= 0: all of them)."""
+    import time
+    L = _lib.lib()
+    blob = "".join(words).encode("ascii")
+    hs = (ctypes.c_void_p * n_envs)()
+    for e in range(n_envs):
+        hs[e] = L.orc_wordle_create(blob, len(words), int(require), float(bad))
+        key, klen = _lib.seed_key(e)
+        L.orc_wordle_reset(hs[e], key, klen)
+    g = np.ascontiguousarray(guess_idx, dtype=np.int32)
+    used = ctypes.c_int(0)
+    t0 = time.perf_counter()
+    n = L.orc_wordle_run_mt(hs, n_envs, g.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), g.shape[0], int(threads), ctypes.byref(used))
+    dt = time.perf_counter() - t0
+    for e in range(n_envs):
+        L.orc_wordle_destroy(hs[e])
+    return int(n), dt, int(used.value)
+
+
 def run_scripted(words: Sequence[str], n_envs: int, guess_idx: np.ndarray, require: bool = True, bad: float = -10.0) -> int:
     """cpu_baseline driver: returns the number of env steps executed (single thread)."""
     L = _lib.lib()

@@ -269,3 +269,39 @@ long orc_wordle_run(orc_wordle **envs, int N, const int32_t *guess_idx /* [steps
     }
     return count;
 }
+
+/*
+ * The same driver on all host cores (OpenMP, one env per loop iteration: envs are independent — SURVEY.md section 8(d)'s "all-cores env baseline").
+ * Every env runs its `steps` scripted steps back to back; same per-env results as orc_wordle_run.  `threads` <= 0: the OpenMP default.
+ */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+long orc_wordle_run_mt(orc_wordle **envs, int N, const int32_t *guess_idx /* [steps][N] */, int steps, int threads, int *threads_used) {
+    long count = 0;
+    int used = 1;
+#ifdef _OPENMP
+    omp_set_num_threads(threads > 0 ? threads : omp_get_num_procs());
+#pragma omp parallel
+    {
+#pragma omp single
+        used = omp_get_num_threads();
+    }
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(static) reduction(+ : count)
+    for (int e = 0; e < N; e++) {
+        char obs[8]; int ol, rint, done; double rew;
+        orc_wordle *g = envs[e];
+        for (int s = 0; s < steps; s++) {
+            int gi = guess_idx[(size_t)s * N + e];
+            if (gi >= 0) orc_wordle_step(g, g->words + (size_t)gi * NCH, NCH, obs, &ol, &rew, &rint, &done);
+            else orc_wordle_step(g, "qqqqq", NCH, obs, &ol, &rew, &rint, &done);
+            count++;
+            if (done) { uint32_t key = (uint32_t)(e + 1000003u * (uint32_t)(s + 1)); orc_wordle_reset(g, &key, 1); }
+        }
+    }
+    if (threads_used) *threads_used = used;
+    return count;
+}
