@@ -257,6 +257,121 @@ __device__ __forceinline__ void g8_mainloop_pair(const uint16_t *__restrict__ A,
 #undef LMRL_G8_READ
 #undef LMRL_G8_MFMA
 
+// ---- WD ("weights direct"), round 5: for the decode-sized products (M ~ 1024: 144 - 192 tiles, ONE workgroup per CU) the K loop is bound by
+// what a CU ingests through global_load_lds (~56 GB/s per CU): both operands of a K-step, (BM + BN) * 128 B, pass through that one
+// path.  The weight operand does not need LDS at all: the MFMA fragment of W that lane (lr, lq) of wave (wm, wn) feeds — row n0 + wn TN + 16 i + lr,
+// 8 consecutive k at 32 kk + 8 lq — is 16 contiguous bytes of the K-major weight matrix, i.e. exactly one global_load_dwordx4 into the VGPRs the
+// MFMA reads.  Here only the ACTIVATION tile rides the LDS ring (BM * 128 B per stage: half the DMA bytes, half the LDS), the weight fragments of
+// K-step t + STAGES are requested straight into a register ring right after step t's MFMAs released them, and both streams share the counted
+// vmcnt waits (per K index: LA DMA instructions, then 2 FN register loads; everything retires in order).  The WM waves that share a weight row
+// block fetch the same lines — the first miss fills the CU's L1, the others hit it.  K / 64 must be a multiple of STAGES (the register ring is
+// indexed statically: the loop is unrolled STAGES-fold).  Same products in the same order as g8_mainloop: bit-identical results.
+// The register loads are ordinary (compiler-visible) loads: the compiler's own s_waitcnt pass then guards every fragment's first use.  For that
+// pass to arrive at the SAME counted waits as the hand-placed ones (and not at vmcnt(0) at the loop's back edge) the steady-state loop body is
+// branch-free and issues its VMEM instructions in exactly the order the prologue does (compiler barriers pin the order of the register loads
+// relative to the LDS-DMA builtins); the last STAGES K-steps — which issue nothing — are peeled.  (Inline-asm loads, which the compiler cannot see
+// as asynchronous, were tried first: the register allocator is then free to re-use or copy a destination register while its load is in flight.)
+__device__ __forceinline__ bf16x8 g8_load_frag(const uint16_t *p) { return *reinterpret_cast<const bf16x8 *>(p); }
+
+template <int BM, int BN, int WM, int WN, int STAGES, class Head = G8NoHook>
+__device__ __forceinline__ void g8_mainloop_wd(const uint16_t *__restrict__ A, int lda, const uint16_t *__restrict__ W, int ldw, int K, int Mr, int m0,
+                                               int n0, char *smem, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], Head head = Head()) {
+    constexpr int NW = WM * WN, BK = 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int LA = BM / 8 / NW;                      // global_load_lds instructions per wave per stage (activation tile only)
+    constexpr int L = LA + 2 * FN;                       // VMEM instructions per wave per K index
+    constexpr int STAGE = BM * 128;
+    static_assert(BM % (8 * NW) == 0 && TM % 16 == 0 && TN % 16 == 0, "tile / wave layout");
+    static_assert(STAGES >= 2 && STAGES <= 4, "2 to 4 ring slots (4 FN VGPRs each for the weight ring)");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int nk = K / BK;
+    const int lrow = lane >> 3, src_c = (lane & 7) ^ lrow;
+    const uint16_t *ap[LA];
+#pragma unroll
+    for (int i = 0; i < LA; i++) {
+        int m = m0 + (wave + NW * i) * 8 + lrow;
+        m = m < Mr ? m : Mr - 1;
+        ap[i] = A + (size_t)m * lda + src_c * 8;
+    }
+    const uint16_t *wq[FN];
+#pragma unroll
+    for (int i = 0; i < FN; i++) wq[i] = W + (size_t)(n0 + wn * TN + i * 16 + lr) * ldw + lq * 8;
+    bf16x8 wr[STAGES][2][FN];                            // weight fragments of K indices t .. t + STAGES - 1 (ring slot = index % STAGES)
+
+#define LMRL_WD_ISSUE(KT, R)                                                                                          \
+    do {                                                                                                              \
+        char *sb_ = smem + (R) * STAGE;                                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < LA; i_++)                                                             \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ap[i_] + (size_t)(KT) * BK), \
+                                             (__attribute__((address_space(3))) void *)(sb_ + (wave + NW * i_) * 1024), 16, 0, 0); \
+        asm volatile("" ::: "memory");                                                                                \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 2; kk_++)                                                           \
+            _Pragma("unroll") for (int i_ = 0; i_ < FN; i_++) wr[R][kk_][i_] = g8_load_frag(wq[i_] + (size_t)(KT) * BK + kk_ * 32); \
+        asm volatile("" ::: "memory");                                                                                \
+    } while (0)
+#define LMRL_WD_READ_A(FA, SLOT, KK)                                                                                  \
+    do {                                                                                                              \
+        const char *sA_ = smem + (SLOT) * STAGE;                                                                      \
+        const int c_ = (KK) * 4 + lq;                                                                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < FM; j_++) {                                                           \
+            const int row_ = wm * TM + j_ * 16 + lr;                                                                  \
+            FA[j_] = *reinterpret_cast<const bf16x8 *>(sA_ + row_ * 128 + ((c_ ^ (row_ & 7)) << 4));                  \
+        }                                                                                                             \
+    } while (0)
+#define LMRL_WD_MFMA(R, KK, FA)                                                                                       \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < FN; i_++)                                                             \
+            _Pragma("unroll") for (int j_ = 0; j_ < FM; j_++)                                                         \
+                acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[R][KK][i_], FA[j_], acc[i_][j_], 0, 0, 0);   \
+    } while (0)
+
+    __builtin_amdgcn_s_barrier();   // every wave is done reading the ring from a previous call
+#pragma unroll
+    for (int s = 0; s < STAGES; s++) LMRL_WD_ISSUE(s, s);              // (K / 64 is a multiple of STAGES: every slot has its first index)
+    head();
+    asm volatile("" ::: "memory");
+    wait_vmcnt<(STAGES - 1) * L>();
+    __builtin_amdgcn_s_barrier();
+    LMRL_G8_STAMP(1);
+    bf16x8 fa0[FM], fa1[FM];
+    LMRL_WD_READ_A(fa0, 0, 0);
+    // one K-step on ring slot R: activation fragments of its second half, MFMAs of the first half, [counted wait for index t + 1 ; barrier],
+    // DMA + register loads of index t + STAGES (ISSUE_), activation fragments of the next step's first half, MFMAs of the second half
+#define LMRL_WD_STEP(R, WAITN, ISSUE_, MORE_)                                                                         \
+    do {                                                                                                              \
+        constexpr int RN_ = (R) + 1 == STAGES ? 0 : (R) + 1;                                                          \
+        LMRL_WD_READ_A(fa1, R, 1);                                                                                    \
+        LMRL_WD_MFMA(R, 0, fa0);                                                                                      \
+        if (MORE_) {                                                                                                  \
+            wait_vmcnt<(WAITN)>();                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+            __builtin_amdgcn_s_barrier();                                                                             \
+        }                                                                                                             \
+        if (MORE_) LMRL_WD_READ_A(fa0, RN_, 0);                               /* flies under the MFMAs below */       \
+        LMRL_WD_MFMA(R, 1, fa1);                                                                                      \
+        if (ISSUE_) LMRL_WD_ISSUE(t0 + (R) + STAGES, R);                      /* slot R: its LDS tile and its registers are free now */ \
+    } while (0)
+    int t0 = 0;
+    for (; t0 + STAGES < nk; t0 += STAGES) {             // steady state: every step issues index t + STAGES; (STAGES - 2) newer indices behind t + 1
+        LMRL_WD_STEP(0, (STAGES - 2) * L, true, true);
+        LMRL_WD_STEP(1, (STAGES - 2) * L, true, true);
+        if constexpr (STAGES >= 3) LMRL_WD_STEP(2, (STAGES - 2) * L, true, true);
+        if constexpr (STAGES >= 4) LMRL_WD_STEP(3, (STAGES - 2) * L, true, true);
+    }
+    // the last STAGES steps: nothing left to issue, one index fewer in flight per step
+    LMRL_WD_STEP(0, (STAGES - 2) * L, false, true);
+    if constexpr (STAGES == 2) { LMRL_WD_STEP(1, 0, false, false); }
+    if constexpr (STAGES == 3) { LMRL_WD_STEP(1, 0, false, true); LMRL_WD_STEP(2, 0, false, false); }
+    if constexpr (STAGES == 4) { LMRL_WD_STEP(1, L, false, true); LMRL_WD_STEP(2, 0, false, true); LMRL_WD_STEP(3, 0, false, false); }
+#undef LMRL_WD_STEP
+#undef LMRL_WD_MFMA
+#undef LMRL_WD_READ_A
+#undef LMRL_WD_ISSUE
+}
+
 // ---- persistent form of g8_mainloop for a SEQUENCE of tiles on a 2-slot ring (K / 64 even): the ring never drains between tiles.  On entry the
 // first two stages of THIS tile are already in flight or landed — issued by g8_stream_prime (first tile of the workgroup) or by the previous
 // tile's call — and on exit the first two stages of the NEXT tile (if any) are in flight, so that its operands stream into LDS under this tile's
@@ -353,9 +468,10 @@ __device__ __forceinline__ void g8_stream_tile(const G8Stream<BM, BN, WM, WN> &s
 // tiles): the grid holds kv_tmax = S copies of the tile grid; copy z accumulates K-steps [z * kv_d, min(K, (z + 1) * kv_d)) and stores its
 // partial tile to C + z * M * ldc (splitk_reduce_kernel adds the copies in a fixed order).  The two ints alias the kv_* fields, which only
 // EPI_BF16_LN_KV reads: no other instantiation's argument block changes.
-template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0, bool PAIR = false, bool SPLITK = false, bool KM = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0, bool PAIR = false, bool SPLITK = false, bool KM = false, bool WD = false>
 __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap xm) {
     static_assert(!PAIR || STAGES == 4, "the paired K loop runs on a 4-slot ring");
+    static_assert(!WD || (!PAIR && !SPLITK && !KM), "weights-direct: the plain K loop only");
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int TM = BM / WM, TN = BN / WN;            // per-wave output tile
     constexpr int FM = TM / 16, FN = TN / 16;
@@ -389,7 +505,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
         for (int j = 0; j < FM; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr bool RESID = (EPI == EPI_RESID_F32_STATS || EPI == EPI_RESID_F32);
-    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int STAGE = WD ? BM * 128 : (BM + BN) * 128;
     float ln_mu[FM], ln_rs[FM];          // LN_IN: this lane's rows' (mu, rstd)
     f32x4 xres[FN][FM];                  // RESID: this lane's slice of the residual stream, prefetched under the K loop
     long kvrow[FM];                      // EPI_BF16_LN_KV: cache rows this lane's K / V columns are appended to (looked up in the prologue)
@@ -435,7 +551,8 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
                 ln_mu[j] = p2.x; ln_rs[j] = p2.y;
             }
         };
-        if constexpr (PAIR) g8_mainloop_pair<BM, BN, WM, WN>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, head);
+        if constexpr (WD) g8_mainloop_wd<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, head);
+        else if constexpr (PAIR) g8_mainloop_pair<BM, BN, WM, WN>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, head);
         else g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, head);
     } else if (RESID) {
         auto prefetch = [&]() {
@@ -451,8 +568,11 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
                                                                    : *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(g.C) + (size_t)m * g.ldc + n);
                 }
         };
-        g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, prefetch);
+        if constexpr (WD) g8_mainloop_wd<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, prefetch);
+        else g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, prefetch);
     } else {
+        if constexpr (WD) g8_mainloop_wd<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc);
+        else
         if constexpr (KM) g8_mainloop<BM, BN, WM, WN, STAGES, G8NoHook, true>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.N, g.K, Mr, m0, n0, smem, acc);
         else if constexpr (PAIR) g8_mainloop_pair<BM, BN, WM, WN>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc);
         else g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc);
@@ -714,23 +834,23 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
     LMRL_G8_STAMP(3);
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0, bool PAIR = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, int NQ = 0, bool PAIR = false, bool WD = false>
 inline hipError_t gemm8_launch(const GemmArgs &g, hipStream_t s) {
     constexpr bool LN_IN = (EPI == EPI_BF16_LN || EPI == EPI_GELU_BF16_LN || EPI == EPI_BF16_LN_KV);
-    constexpr size_t shmem = (size_t)STAGES * (BM + BN) * 128 + (LN_IN ? (size_t)BM * 4 * NQ * 8 + BM * 8 : 0);   // ring (+ LayerNorm-moment scratch)
+    constexpr size_t shmem = (size_t)STAGES * (WD ? BM : BM + BN) * 128 + (LN_IN ? (size_t)BM * 4 * NQ * 8 + BM * 8 : 0);   // ring (+ LayerNorm-moment scratch)
     static_assert(shmem <= 160 * 1024, "LDS ring exceeds 160 KiB");
     const XcdMap xm = make_xcd_map((g.M + BM - 1) / BM, g.N / BN, 2.0 * g.M * g.K, 2.0 * g.N * g.K);
     const int tiles = xcd_grid(xm);
     static bool attr_set = false;
     if (!attr_set && shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8_kernel<BM, BN, WM, WN, STAGES, EPI, NQ, PAIR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm8_kernel<BM, BN, WM, WN, STAGES, EPI, NQ, PAIR, false, false, WD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     {
         ProfScope ps(PROF_GEMM_128x128, s, 2.0 * (double)g.M * (double)g.N * (double)g.K);
-        hipLaunchKernelGGL((gemm8_kernel<BM, BN, WM, WN, STAGES, EPI, NQ, PAIR>), dim3(tiles), dim3(WM * WN * 64), shmem, s, g, xm);
+        hipLaunchKernelGGL((gemm8_kernel<BM, BN, WM, WN, STAGES, EPI, NQ, PAIR, false, false, WD>), dim3(tiles), dim3(WM * WN * 64), shmem, s, g, xm);
     }
     return hipGetLastError();
 }

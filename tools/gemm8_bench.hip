@@ -95,6 +95,18 @@ int main(int argc, char **argv) {
         {"g8 128x128 4x4 s4 (16w)", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 4, 4, 4, EPI_BF16>(g, s); }, 128, 128},
         {"g8 128x128 4x4 s3 BF16_LN", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 4, 4, 3, EPI_BF16_LN, 3>(g, s); }, 128, 128, false, true},
         {"g8 64x128 2x4 s4", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<64, 128, 2, 4, 4, EPI_BF16>(g, s); }, 64, 128},
+        {"g8 64x64 4x2 s4", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<64, 64, 4, 2, 4, EPI_BF16>(g, s); }, 64, 64},
+        {"WD 64x64 4x2 s4", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<64, 64, 4, 2, 4, EPI_BF16, 0, false, true>(g, s); }, 64, 64},
+        {"WD 64x64 4x2 s3", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<64, 64, 4, 2, 3, EPI_BF16, 0, false, true>(g, s); }, 64, 64},
+        {"WD 64x64 2x2 s4 (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<64, 64, 2, 2, 4, EPI_BF16, 0, false, true>(g, s); }, 64, 64},
+        {"WD 64x64 1x4 s4 (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<64, 64, 1, 4, 4, EPI_BF16, 0, false, true>(g, s); }, 64, 64},
+        {"WD 64x64 2x4 s4", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<64, 64, 2, 4, 4, EPI_BF16, 0, false, true>(g, s); }, 64, 64},
+        {"WD 128x128 4x4 s3 (16w)", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 4, 4, 3, EPI_BF16, 0, false, true>(g, s); }, 128, 128},
+        {"WD 128x128 4x4 s4 (16w)", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 4, 4, 4, EPI_BF16, 0, false, true>(g, s); }, 128, 128},
+        {"WD 128x128 2x4 s3", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 4, 3, EPI_BF16, 0, false, true>(g, s); }, 128, 128},
+        {"WD 128x128 2x8 s4 (16w)", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 8, 4, EPI_BF16, 0, false, true>(g, s); }, 128, 128},
+        {"WD 128x64 4x2 s4", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 64, 4, 2, 4, EPI_BF16, 0, false, true>(g, s); }, 128, 64},
+        {"WD 64x128 2x4 s4", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<64, 128, 2, 4, 4, EPI_BF16, 0, false, true>(g, s); }, 64, 128},
         {"g8 128x128 2x2 s3 (4w)", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 2, 3, EPI_BF16>(g, s); }, 128, 128},
         {"g8 128x128 2x4 s2 f32out", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 4, 2, EPI_F32>(g, s); }, 128, 128, true},
         {"g8 256x256 2x4 s2 f32out", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<256, 256, 2, 4, 2, EPI_F32>(g, s); }, 256, 256, true},
@@ -117,6 +129,13 @@ int main(int argc, char **argv) {
         {"g8 128x128 2x4 s2 GELU", [](const GemmArgs &g, hipStream_t s) { return gemm8_launch<128, 128, 2, 4, 2, EPI_GELU_BF16>(g, s); }, 128, 128, false, true},
     };
     if (train) cfgs = cfgs_train;
+    if (const char *f = getenv("LMRL_CFG")) {            // LMRL_CFG="WD,g8 64x64": only configurations whose name contains one of the comma-separated pieces
+        std::vector<std::string> keys; std::string cur;
+        for (const char *p = f;; p++) { if (*p == ',' || !*p) { if (!cur.empty()) keys.push_back(cur); cur.clear(); if (!*p) break; } else cur += *p; }
+        std::vector<Cfg> kept;
+        for (auto &c : cfgs) for (auto &k : keys) if (c.name.find(k) != std::string::npos) { kept.push_back(c); break; }
+        cfgs = kept;
+    }
     hipStream_t st; CK(hipStreamCreate(&st));
     for (const Shape &sh : shapes) {
         const int M = sh.M, N = sh.N, K = sh.K, NWC = getenv("LMRL_NWC") ? atoi(getenv("LMRL_NWC")) : (N > 10000 ? 2 : 12);   // LMRL_NWC=1: hot L2
