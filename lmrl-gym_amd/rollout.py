@@ -214,13 +214,13 @@ class WordleRolloutEngine:
         _lib.check(rc, what)
 
     def run_episode(self, seeds: np.ndarray, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0,
-                    scripted_guesses=None, steer_strength: float = 0.0, n_turns: int = W.N_TRIES, epoch=None, sampler: str = "philox"):
+                    scripted_guesses=None, steer_strength: float = 0.0, n_turns: int = W.N_TRIES, epoch=None, sampler: str = "philox", top_p: float = 0.0):
         """One full episode for all B envs (asynchronous: returns after enqueueing; read results after a sync).
 
         scripted_guesses: optional int32 device tensor [n_turns][B] of packed guesses; with steer_strength > 0 the
         sampler is steered towards spelling them (synthetic-workload hook; every logit is still computed and sampled).
         """
-        for _ in self.episode_phases(seeds, temperature, top_k, sample_seed, scripted_guesses, steer_strength, n_turns, epoch, sampler):
+        for _ in self.episode_phases(seeds, temperature, top_k, sample_seed, scripted_guesses, steer_strength, n_turns, epoch, sampler, top_p):
             pass
         return self.traj
 
@@ -228,13 +228,13 @@ class WordleRolloutEngine:
     # Everything that changes between episodes lives in device memory: env seeds, scripted guesses and the sampler's
     # `epoch` word (4th Philox counter word), so replays draw fresh noise and start from fresh env seeds.
     def capture_episode(self, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0, steer_strength: float = 0.0,
-                        n_turns: int = W.N_TRIES, scripted: bool = False):
+                        n_turns: int = W.N_TRIES, scripted: bool = False, top_p: float = 0.0):
         import torch
         t = torch
         self.g_seeds = t.zeros(self.B, dtype=t.int64, device=self.dev)
         self.g_guesses = t.zeros((n_turns, self.B), dtype=t.int32, device=self.dev) if scripted else None
         self.g_epoch = t.zeros(1, dtype=t.int32, device=self.dev)
-        kw = dict(temperature=temperature, top_k=top_k, sample_seed=sample_seed, scripted_guesses=self.g_guesses,
+        kw = dict(temperature=temperature, top_k=top_k, top_p=top_p, sample_seed=sample_seed, scripted_guesses=self.g_guesses,
                   steer_strength=steer_strength, n_turns=n_turns, epoch=self.g_epoch)
         self.run_episode(self.g_seeds, **kw)            # eager warm-up: one-time attribute / table initialisation
         t.cuda.synchronize()
@@ -256,7 +256,8 @@ class WordleRolloutEngine:
         return self.traj
 
     def episode_phases(self, seeds: np.ndarray, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0,
-                       scripted_guesses=None, steer_strength: float = 0.0, n_turns: int = W.N_TRIES, epoch=None, sampler: str = "philox"):
+                       scripted_guesses=None, steer_strength: float = 0.0, n_turns: int = W.N_TRIES, epoch=None, sampler: str = "philox",
+                       top_p: float = 0.0):
         """Generator form of `run_episode`: enqueues one phase (a model forward + its sampling / env bookkeeping) per
         `next()`, so a host loop can interleave several engines on different HIP streams.
 
@@ -302,9 +303,14 @@ class WordleRolloutEngine:
         both(header)
         yield
         logits_out = None
-        if top_k > 0:
+        top_p = float(top_p) if top_p is not None and 0.0 < float(top_p) < 1.0 and temperature > 0 else 0.0
+        if top_k > 0 or top_p > 0.0:
+            # the warpers (TopK / TopP logits warpers of HF generate, train_ppo_gpt2.py:98-99,218-227) select on MATERIALISED logits: one buffer per engine,
+            # allocated once — its address is baked into a captured episode graph
             import torch
-            logits_out = torch.empty(B, self.eng.cfg.vocab_padded, dtype=torch.float32, device=self.dev)
+            if getattr(self, "_warp_logits", None) is None:
+                self._warp_logits = torch.empty(B, self.eng.cfg.vocab_padded, dtype=torch.float32, device=self.dev)
+            logits_out = self._warp_logits
         steered = scripted_guesses is not None and steer_strength != 0.0
         for turn in range(n_turns):
             tok_keys = None
@@ -317,10 +323,10 @@ class WordleRolloutEngine:
                 steer = self.steer[min(k, 5)] if steered else None
                 if tok_keys is not None:
                     p = SampleParams(temperature, top_k, jax_prng.key_to_seed(tok_keys.next()), self.sample_step, steer_strength, self.beta,
-                                     self.tokens.pad, None, 0.0, RNG_JAX)
+                                     self.tokens.pad, None, top_p, RNG_JAX)
                 else:
                     p = SampleParams(temperature, top_k, sample_seed, self.sample_step, steer_strength, self.beta, self.tokens.pad,
-                                     _lib.ptr(epoch))
+                                     _lib.ptr(epoch), top_p)
                 self.sample_step += 1
                 qops = [None, None]
                 if self.vses is not None:     # Q heads on the value base's last hidden state: relu(dense1) here, dense2 inside the sampler
@@ -376,7 +382,7 @@ class WordleRolloutEngine:
 
     def ppo_rollouts(self, inference, n_rollouts: int, seed_generator=None, *, gamma: float, lam: float, kl_weight: float, max_length: Optional[int] = None,
                      use_advantage_whitening: bool = True, temperature: float = 1.0, sample_seed: int = 0, use_graph: Optional[bool] = None,
-                     scripted_guesses_fn=None, steer_strength: float = 0.0, timings: Optional[dict] = None, **kw):
+                     scripted_guesses_fn=None, steer_strength: float = 0.0, timings: Optional[dict] = None, top_k: int = 0, top_p: float = 0.0, **kw):
         """One data-collection round of the online PPO loop on the device: `text_env_eval(n_rollouts, bsize=B)` + `ppo_dataset_loader`
         (train_ppo_gpt2.py:301-353) -> (DevicePPODataset over all rollouts, all_kls, summary).  Per episode batch: the lock-step episode, then
         its PPO data while the record is still in the engine's buffers; advantages are whitened once over the action tokens of ALL rollouts of
@@ -391,11 +397,12 @@ class WordleRolloutEngine:
             n_k = min(n_rollouts - k * self.B, self.B)
             seeds_all[k, :n_k] = [next(seed_generator) for _ in range(n_k)] if seed_generator is not None else np.random.randint(0, 2 ** 31 - 1, size=n_k)
         scripted = scripted_guesses_fn is not None
-        key = (float(temperature), int(sample_seed), float(steer_strength), scripted)
+        key = (float(temperature), int(sample_seed), float(steer_strength), scripted, int(top_k), float(top_p or 0.0))
         want_graph = (getattr(self, "_eval_graph_key", None) == key or n_batches >= 4) if use_graph is None else bool(use_graph)
         seeds_dev = torch.from_numpy(seeds_all.view(np.int64)).to(self.dev)
         if want_graph and getattr(self, "_eval_graph_key", None) != key:
-            self.capture_episode(temperature=temperature, sample_seed=sample_seed, steer_strength=steer_strength, scripted=scripted)
+            self.capture_episode(temperature=temperature, sample_seed=sample_seed, steer_strength=steer_strength, scripted=scripted, top_k=top_k,
+                                 top_p=top_p or 0.0)
             self._eval_graph_key = key
         parts, kls, stats = [], [], []
         ev = lambda: (lambda e: (e.record(), e)[1])(torch.cuda.Event(enable_timing=True))
@@ -408,7 +415,7 @@ class WordleRolloutEngine:
                 self.replay_episode(seeds_dev[k], g)
             else:
                 self.run_episode(seeds_all[k], temperature=temperature, sample_seed=sample_seed + (self.episodes << 20), scripted_guesses=g,
-                                 steer_strength=steer_strength)
+                                 steer_strength=steer_strength, top_k=top_k, top_p=top_p or 0.0)
                 self.episodes += 1
             if timings is not None:
                 e1 = ev()
@@ -517,10 +524,12 @@ class WordleRolloutEngine:
 
     def text_env_eval(self, n_rollouts: int, seed_generator=None, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0,
                       interaction_callback=None, decode=None, scripted_guesses_fn=None, steer_strength: float = 0.0, use_graph: Optional[bool] = None,
-                      concurrent: int = 1):
+                      concurrent: int = 1, top_p: float = 0.0):
         """`text_env_eval(env, policy, n_rollouts, bsize=B)` (LLM_RL/environment.py:211-267) with env, policy and the whole
         lock-step loop on the device: ceil(n / B) episodes batches, the same (interactions, summary) return value.
-        use_graph (top_k = 0; the ILQL value policy included): the episode is captured into a hipGraph once per (temperature, sample_seed, steering) and replayed per
+        top_k / top_p: HF's TopK / TopP logits warpers (the policy_top_k / policy_top_p of the task scripts) — on the graph path too (round 5: the
+        warpers' logits buffer is allocated once per engine; a graph is keyed by (top_k, top_p) as well).
+        use_graph (the ILQL value policy included): the episode is captured into a hipGraph once per (temperature, sample_seed, steering) and replayed per
         batch — one host call instead of ~3400 launches; every replay draws fresh noise (the sampler's epoch word advances).  A capture costs
         two extra episodes (warm-up + capture), so the default (None) uses the graph only when this engine already holds one for the same key
         or the call runs >= 4 batches; True / False force it.  The two paths draw DIFFERENT noise for the same `sample_seed`: the graph's
@@ -551,8 +560,8 @@ class WordleRolloutEngine:
             n_k = min(n_rollouts - k * self.B, self.B)
             seeds_all[k, :n_k] = [next(seed_generator) for _ in range(n_k)] if seed_generator is not None else np.random.randint(0, 2 ** 31 - 1, size=n_k)
         scripted = scripted_guesses_fn is not None
-        key = (float(temperature), int(sample_seed), float(steer_strength), scripted)
-        graph_ok = top_k == 0
+        key = (float(temperature), int(sample_seed), float(steer_strength), scripted, int(top_k), float(top_p or 0.0))
+        graph_ok = True
         if use_graph is None:
             want_graph = graph_ok and (getattr(self, "_eval_graph_key", None) == key or n_batches >= 4)
         else:
@@ -575,7 +584,7 @@ class WordleRolloutEngine:
                     if getattr(e, "_eval_graph_key", None) != key:
                         # lanes draw from different noise streams: the same (seed, epoch) key on two lanes would repeat one batch's noise in the next
                         e.capture_episode(temperature=temperature, sample_seed=(sample_seed + l * 0x9E3779B97F4A7C15) & (2 ** 64 - 1),
-                                          steer_strength=steer_strength, scripted=scripted)
+                                          steer_strength=steer_strength, scripted=scripted, top_k=top_k, top_p=top_p or 0.0)
                         e._eval_graph_key = key
         batch_id, launched, pending = 0, 0, deque()
         while launched < n_rollouts:
@@ -586,7 +595,7 @@ class WordleRolloutEngine:
                 if want_graph:
                     e.replay_episode(seeds_dev[batch_id], g)
                 else:
-                    e.run_episode(seeds_all[batch_id], temperature=temperature, top_k=top_k, sample_seed=sample_seed + (self.episodes << 20),
+                    e.run_episode(seeds_all[batch_id], temperature=temperature, top_k=top_k, top_p=top_p or 0.0, sample_seed=sample_seed + (self.episodes << 20),
                                   scripted_guesses=g, steer_strength=steer_strength)
                     self.episodes += 1
                 handle = e.snapshot_records()

@@ -214,9 +214,9 @@ def cmd_ppo(a):
         vocab, env = _wordle_env(a)
     step = 0
     limit = None if a.max_steps is None else int(a.max_steps)
-    # --device-rollouts without warpers / a BC batch: the whole iteration stays in HBM — rollout records -> PPO data -> device batches -> train
-    # steps -> the trainer's parameters copied into the engine in place (WordleRolloutEngine.ppo_rollouts, algorithms/ppo_device.py)
-    resident = a.device_rollouts and not int(a.policy_top_k or 0) and a.policy_top_p is None
+    # --device-rollouts: the whole iteration stays in HBM — rollout records -> PPO data -> device batches -> train steps -> the trainer's
+    # parameters copied into the engine in place (WordleRolloutEngine.ppo_rollouts, algorithms/ppo_device.py); --resident 0: the host-array path
+    resident = bool(a.device_rollouts) and bool(a.resident)
     ro_res = _device_rollouts(policy.engine, vocab, tok, a.rollout_bsize, a.bad_word_reward, min(a.max_output_length, 12)) if resident else None
     for rnd in range(a.n_rounds):
         if limit is not None and step >= limit:
@@ -224,7 +224,8 @@ def cmd_ppo(a):
         if resident:
             ds, kls, summary = ro_res.ppo_rollouts(inf, a.n_rollouts, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)), gamma=a.gamma, lam=a.lam,
                                                    kl_weight=ctl.value, max_length=max_len, use_advantage_whitening=a.use_advantage_whitening,
-                                                   temperature=a.policy_temperature or 1.0, sample_seed=rnd, bsize=max(a.ppo_data_bsize, 64))
+                                                   temperature=a.policy_temperature or 1.0, sample_seed=rnd, bsize=max(a.ppo_data_bsize, 64),
+                                                   top_k=int(a.policy_top_k or 0), top_p=float(a.policy_top_p or 0.0))
             mean_kl = float(kls.cpu().numpy().mean()) if kls.numel() else 0.0
             ctl.update(mean_kl, a.train_bsize)
             _log("data_collection", dict(round=rnd, env_interaction=summary, mean_kl=mean_kl, kl_ctrl_value=ctl.value, n_chains=len(ds), device_resident=True))
@@ -254,7 +255,7 @@ def cmd_ppo(a):
         if a.device_rollouts:       # env + policy + lock-step loop on the GPU; same (interactions, summary) as text_env_eval
             ro = _device_rollouts(policy.engine, vocab, tok, a.rollout_bsize, a.bad_word_reward, min(a.max_output_length, 12))
             raw, summary = ro.text_env_eval(a.n_rollouts, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)), temperature=a.policy_temperature or 1.0,
-                                            top_k=int(a.policy_top_k or 0), sample_seed=rnd, concurrent=a.rollout_lanes)
+                                            top_k=int(a.policy_top_k or 0), top_p=float(a.policy_top_p or 0.0), sample_seed=rnd, concurrent=a.rollout_lanes)
             ro.close()
         else:
             raw, summary = E.text_env_eval(env, policy, n_rollouts=a.n_rollouts, bsize=a.rollout_bsize, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)),
@@ -318,7 +319,7 @@ def cmd_filtered_bc(a):
         if a.device_rollouts:
             ro = _device_rollouts(policy.engine, vocab, tok, a.rollout_bsize, a.bad_word_reward, min(a.max_output_length, 12))
             raw, summary = ro.text_env_eval(a.n_rollouts, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)), temperature=a.policy_temperature or 1.0,
-                                            top_k=int(a.policy_top_k or 0), sample_seed=rnd, concurrent=a.rollout_lanes)
+                                            top_k=int(a.policy_top_k or 0), top_p=float(a.policy_top_p or 0.0), sample_seed=rnd, concurrent=a.rollout_lanes)
             ro.close()
         else:
             raw, summary = E.text_env_eval(env, policy, n_rollouts=a.n_rollouts, bsize=a.rollout_bsize, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)),
@@ -402,6 +403,7 @@ def build_parser() -> argparse.ArgumentParser:
     sub.choices["ppo"].add_argument("--bc-data", default=None)
     pp = sub.choices["ppo"]
     pp.add_argument("--env", default="wordle", choices=["wordle", "chess"])
+    pp.add_argument("--resident", type=int, default=1, help="with --device-rollouts 1: 1 (default) = the device-resident iteration, 0 = device rollouts feeding the host-array PPO data path")
     pp.add_argument("--trim-batches", type=int, default=0, help="device-resident loop: train on batches cut to the round's longest episode (multiple of 64) instead of "
                                                                   "max_input_length + max_output_length columns — same loss and gradients, fewer padded rows")
     pp.add_argument("--chess-engine", default=os.environ.get("CHESS_ENGINE_PATH"), help="UCI engine binary (the reference: stockfish/stockfish-ubuntu-20.04-x86-64-avx2)")

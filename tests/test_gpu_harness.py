@@ -177,10 +177,11 @@ def test_harness_script_subcommands_at_toy_scale(tmp_path, capsys):
     H.main(["ppo", "--bc-data", data, "--n-rollouts", "4", "--rollout-bsize", "4", "--ppo-data-bsize", "4", "--train-bsize", "2", "--max-steps", "1",
             "--max-input-length", "72", "--max-output-length", "12"])
     H.main(["ppo", "--n-rollouts", "6", "--rollout-bsize", "4", "--ppo-data-bsize", "4", "--train-bsize", "2", "--max-steps", "1",
-            "--max-input-length", "96", "--max-output-length", "6", "--device-rollouts", "1"])
+            "--max-input-length", "96", "--max-output-length", "6", "--device-rollouts", "1", "--resident", "0", "--policy-top-k", "50"])
     # the device-resident iteration (records -> PPO data -> device batches -> steps -> weights back in place), two rounds, BC batch, trimmed batches
     H.main(["ppo", "--bc-data", data, "--n-rollouts", "10", "--rollout-bsize", "4", "--train-bsize", "4", "--n-rounds", "2", "--max-steps", "3",
-            "--max-input-length", "96", "--max-output-length", "6", "--device-rollouts", "1", "--trim-batches", "1", "--bf16-activations", "1"])
+            "--max-input-length", "96", "--max-output-length", "6", "--device-rollouts", "1", "--trim-batches", "1", "--bf16-activations", "1",
+            "--policy-top-k", "40", "--policy-top-p", "0.95"])
     # online filtered BC (wordle/online_filtered_bc): rollouts -> top 50 % by reward -> BC on the action tokens, text path and device loop
     H.main(["filtered-bc", "--n-rollouts", "6", "--rollout-bsize", "3", "--filter-percengage", "0.5", "--train-bsize", "2", "--max-steps", "1",
             "--max-input-length", "96", "--max-output-length", "8"])

@@ -301,3 +301,35 @@ def test_ilql_value_policy_on_the_device_engine(setup):
     torch.cuda.synchronize()
     assert int(ro.traj["n_steps"].sum()) >= B
     ro.close()
+
+
+@pytest.mark.parametrize("top_k,top_p", [(7, 0.0), (0, 0.9), (40, 0.95)])
+def test_warper_episodes_replay_from_a_graph(setup, top_k, top_p):
+    """VERDICT r04 missing #5: `policy_top_k` / `policy_top_p` (train_ppo_gpt2.py:98-99,218-227) used to drop an episode off the hipGraph path.  The
+    warpers' logits buffer now lives with the engine, so a warper episode is captured and replayed like any other: replay == eager launches with
+    the same seeds / epoch word, bit for bit, for two replays with fresh noise; and `text_env_eval(top_k=..., top_p=...)` takes the graph path
+    (the warper semantics themselves — support, renormalised log-probs — are tests/test_gpu_gpt2.py's)."""
+    from lmrl_gym_amd.rollout import WordleRolloutEngine
+    dev, cfg, sd, eng, vocab = setup
+    B = 48
+    ro = WordleRolloutEngine(eng, vocab, B, max_new_tokens=6)
+    seeds = (torch.arange(B, dtype=torch.int64) + 70).to(dev)
+    kw = dict(temperature=2.5, sample_seed=21, top_k=top_k, top_p=top_p)
+    ro.capture_episode(**kw)
+    snap = lambda: {k: ro.traj[k].clone() for k in ("tokens", "is_action", "reward", "n_tok", "n_steps", "ep_reward", "env_done")}
+    outs = []
+    for rep in range(2):
+        ro.replay_episode(seeds + rep)
+        g = snap()
+        epoch = ro.g_epoch.clone()
+        ro.sample_step = 0
+        ro.run_episode(seeds + rep, epoch=epoch, **kw)
+        e = snap()
+        for k in g:
+            assert torch.equal(g[k], e[k]), (rep, k)
+        outs.append(g)
+    # (this tiny model's tied embedding makes it repeat its last token with a large logit: inside a top-7 / top-0.9 support the two replays may well
+    # draw the same tokens; that replays draw fresh noise is the unwarped graph tests' business)
+    inter, summary = ro.text_env_eval(3 * B, seed_generator=iter(range(1000)), temperature=0.8, sample_seed=21, top_k=top_k, top_p=top_p, use_graph=True)
+    assert len(inter) == 3 * B and ro._eval_graph_key[-2:] == (top_k, top_p) and all(ep[-1].done for ep in inter)
+    ro.close()
