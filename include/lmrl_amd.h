@@ -630,6 +630,8 @@ void lmrl_sgemm_set_variant(int v);
 /* TOOLS / TESTS ONLY: bit 0 = LayerNorm forward, bit 1 = fused LayerNorm backward on the strided 4-byte-access kernels (A/B of the 16-byte-access
  * register-row kernels) */
 void lmrl_train_ops_set_variant(int v);
+/* TOOLS / TESTS ONLY: 1 = top-k / top-p sampling on the strided-row warper kernel also where the register-row kernel applies (A/B, equality tests) */
+void lmrl_sampler_set_variant(int v);
 /* TOOLS / TESTS ONLY: 1 = lmrl_gae / lmrl_rtg on the round-1 LDS-compaction kernel and the scalar whitening kernels, 2 = the 64-lane register
  * kernel also for chains of <= 128 slots, 3 = one slot per lane in the 16-lane DPP-row kernel (A/B, cross-checks of the two-slots-per-lane form) */
 void lmrl_rl_reduce_set_variant(int v);

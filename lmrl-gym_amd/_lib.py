@@ -63,6 +63,7 @@ _SIGS = {
     "lmrl_sgemm_set_variant": (None, [c_int]),
     "lmrl_train_ops_set_variant": (None, [c_int]),
     "lmrl_rl_reduce_set_variant": (None, [c_int]),
+    "lmrl_sampler_set_variant": (None, [c_int]),
     "lmrl_flash_set_variant": (None, [c_int]),
     "lmrl_sample_ws_bytes": (c_size_t, [c_int, c_int]),
     "lmrl_sample_logits_steer": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

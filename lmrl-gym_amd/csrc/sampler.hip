@@ -497,6 +497,257 @@ __global__ __launch_bounds__(256) void topk_sample_kernel(const float *__restric
     }
 }
 
+// ---- the same selection with the ROW IN REGISTERS (round 5): topk_sample_kernel above walks its 200 KB row up to ten times (4 radix passes for
+// top-k, the row maximum + 4 mass passes for top-p, the sampling pass) with 4-byte loads — 410 us per sampled token at 1024 x 50 257, 15 ms of a
+// 62 ms warper episode.  Here one 1024-thread workgroup reads the row ONCE (16-byte loads, NV float4 per thread: chunk c = tid + 1024 j holds columns
+// 4 c .. 4 c + 3) and every pass runs on registers.  Same keys, same histograms (integer / 32.32 fixed-point: order independent), same thresholds, same
+// Philox counter per 4-column chunk, same arg-max tie rule: the sampled token is bit-identical to the kernel above; the log-probability's
+// sum runs in a different order (fp32 rounding).
+// Scan of a 256-bucket histogram from the top by ONE wave (lane l owns buckets 4 l .. 4 l + 3): the largest bucket b whose suffix sum
+// S(b) = sum_{b' >= b} h[b'] reaches `target` (b = 0 if none does), and `above` = S(b + 1) + base.  What thread 0 of topk_sample_kernel finds with a
+// serial loop of up to 256 dependent LDS reads (x 8 - 12 passes per row).  Integer sums: identical results.
+template <class T>
+__device__ __forceinline__ void wave_scan_from_top(const T *h, T target, T base, int lane, uint32_t &b_out, T &above_out) {
+    T hv[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) hv[k] = h[4 * lane + k];
+    const T mine = hv[0] + hv[1] + hv[2] + hv[3];
+    T suf = mine;                                            // -> inclusive suffix sum over lanes l' >= lane
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const T o = __shfl_down(suf, d);
+        if (lane + d < 64) suf += o;
+    }
+    T run = suf - mine + base;                               // S(4 lane + 4) + base: everything above this lane's buckets
+    int found = -1;
+    T above = run;
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+        if (found < 0) {
+            if (run + hv[k] >= target) { found = 4 * lane + k; above = run; }
+            else run += hv[k];
+        }
+    }
+    const unsigned long long bal = __ballot(found >= 0);
+    if (bal) {
+        const int src = 63 - __builtin_clzll(bal);           // the highest lane that holds a crossing bucket
+        b_out = (uint32_t)__shfl(found, src);
+        above_out = __shfl(above, src);
+    } else {                                                 // nothing reaches the target: bucket 0, everything above it
+        b_out = 0u;
+        const T s0 = __shfl(run, 0);                         // lane 0 ran through all of its buckets: run = S(0) + base
+        const T h00 = __shfl(hv[0], 0);
+        above_out = s0 - h00;
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(1024) void topk_sample_reg_kernel(const float *__restrict__ logits, int ld, int vocab, int top_k, float top_p,
+                                                               const uint8_t *__restrict__ active, int32_t *__restrict__ token,
+                                                               float *__restrict__ logprob, SampleParams sp, int pad_token) {
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (active && !active[m]) {
+        if (tid == 0) { token[m] = pad_token; if (logprob) logprob[m] = 0.f; }
+        return;
+    }
+    const float *row = logits + (size_t)m * ld;
+    __shared__ uint32_t hist[256];
+    __shared__ unsigned long long mhist[256];
+    __shared__ uint32_t sel_prefix, sel_remaining;
+    __shared__ unsigned long long sel_above, sel_total;
+    __shared__ float red_f[16][4];
+    __shared__ int red_i[16];
+    // the row as ORDER KEYS (what every selection pass compares; the logit itself is one xor away: key_to_f32) — holding both the values and the
+    // keys the passes keep re-deriving is what pushed the kernel over its 128 VGPRs
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int n4 = 4 * (tid + 1024 * j);
+        const f32x4 x = n4 < ld ? *reinterpret_cast<const f32x4 *>(row + n4) : f32x4{0.f, 0.f, 0.f, 0.f};      // (ld a multiple of 4: whole chunks)
+        v[j] = u32x4_t{f32_order_key(x[0]), f32_order_key(x[1]), f32_order_key(x[2]), f32_order_key(x[3])};
+        asm volatile("" : "+v"(v[j]));                      // the keys are the stored form: do not re-derive them from a second copy
+    }
+    auto key_to_f32 = [](uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); };
+    // every element this thread holds: n its column, raw its logit (columns >= vocab skipped)
+    // (a scheduling barrier per chunk: without it the 13 - 16 unrolled chunk bodies are interleaved and the kernel spills 135 VGPRs at 128)
+#define LMRL_TK_FOREACH(BODY)                                                                                  \
+    _Pragma("unroll") for (int j_ = 0; j_ < NV; j_++) {                                                        \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; r_++) {                                                     \
+            const int n = 4 * (tid + 1024 * j_) + r_;                                                          \
+            if (n < vocab) { const uint32_t key = v[j_][r_]; BODY }                                            \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }
+    uint32_t prefix = 0, remaining = (uint32_t)(top_k < vocab ? top_k : vocab);
+    if (top_k <= 0) remaining = (uint32_t)vocab;
+    const bool topk_on = top_k > 0 && top_k < vocab;
+    // Pre-filter (top_k <= 1024): the k-th largest of the 1024 per-thread maxima is a LOWER bound of the row's k-th largest value (those are k
+    // distinct elements at or above it), so only elements at or above it can be selected.  The four radix passes then histogram a few multiples of
+    // k candidates instead of all 50 k elements — whose top byte falls into three or four buckets, i.e. 50 k LDS atomics on the same few addresses
+    // (the first pass alone cost ~20 us per workgroup).  The threshold found is the same: every element >= the true k-th largest is a candidate.
+    uint32_t floor_key = 0;
+    if (topk_on && top_k <= 1024) {
+        uint32_t tkey = 0;                                   // this thread's largest key (0: it holds no valid column)
+        LMRL_TK_FOREACH({ tkey = key > tkey ? key : tkey; })
+        uint32_t fp = 0, frem = (uint32_t)top_k;
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 24 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            if (pass == 0 || (tkey >> (shift + 8)) == (fp >> (shift + 8))) atomicAdd(&hist[(tkey >> shift) & 255u], 1u);
+            __syncthreads();
+            if (wave == 0) {
+                uint32_t b, above;
+                wave_scan_from_top<uint32_t>(hist, frem, 0u, lane, b, above);
+                if (lane == 0) { sel_prefix = fp | (b << shift); sel_remaining = frem - above; }
+            }
+            __syncthreads();
+            fp = sel_prefix; frem = sel_remaining;
+            __syncthreads();
+        }
+        floor_key = fp;
+    }
+    for (int pass = 0; pass < (topk_on ? 4 : 0); pass++) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        LMRL_TK_FOREACH({
+            const bool match = key >= floor_key && (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8)));
+            if (match) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        })
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t b, above;
+            wave_scan_from_top<uint32_t>(hist, remaining, 0u, lane, b, above);
+            if (lane == 0) { sel_prefix = prefix | (b << shift); sel_remaining = remaining - above; }
+        }
+        __syncthreads();
+        prefix = sel_prefix; remaining = sel_remaining;
+        __syncthreads();
+    }
+    uint32_t thr_key = prefix;
+    if (top_k <= 0 || top_k >= vocab) thr_key = 0;
+    if (top_p > 0.f && top_p < 1.f && !sp.greedy) {
+        float rmax = -INFINITY;
+        LMRL_TK_FOREACH({ if (key >= thr_key) rmax = fmaxf(rmax, key_to_f32(key)); })
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o));
+        if (lane == 0) red_f[wave][0] = rmax;
+        __syncthreads();
+        rmax = red_f[0][0];
+#pragma unroll
+        for (int w = 1; w < 16; w++) rmax = fmaxf(rmax, red_f[w][0]);
+        __syncthreads();
+        uint32_t pprefix = 0;
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 24 - 8 * pass;
+            if (tid < 256) mhist[tid] = 0ull;
+            __syncthreads();
+            LMRL_TK_FOREACH({
+                if (key >= thr_key) {
+                    const bool match = pass == 0 || (key >> (shift + 8)) == (pprefix >> (shift + 8));
+                    if (match) {
+                        const float e = __expf((key_to_f32(key) - rmax) * sp.inv_temperature);
+                        atomicAdd(&mhist[(key >> shift) & 255u], (unsigned long long)((double)e * 4294967296.0));
+                    }
+                }
+            })
+            __syncthreads();
+            if (wave == 0) {
+                unsigned long long tgt = sel_total;
+                if (pass == 0) {
+                    unsigned long long tot = mhist[4 * lane] + mhist[4 * lane + 1] + mhist[4 * lane + 2] + mhist[4 * lane + 3];
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
+                    tgt = (unsigned long long)((double)top_p * (double)tot);
+                    if (tgt == 0) tgt = 1;
+                }
+                uint32_t b;
+                unsigned long long ab;
+                wave_scan_from_top<unsigned long long>(mhist, tgt, pass == 0 ? 0ull : sel_above, lane, b, ab);      // the crossing token lives in bucket b
+                if (lane == 0) { sel_total = tgt; sel_above = ab; sel_prefix = pprefix | (b << shift); }
+            }
+            __syncthreads();
+            pprefix = sel_prefix;
+            __syncthreads();
+        }
+        if (pprefix > thr_key) thr_key = pprefix;
+    }
+    const uint32_t epoch = sp.epoch ? *sp.epoch : 0u;
+    float pmax = -INFINITY, psum = 0.f, best = -INFINITY, best_z = 0.f;
+    int best_col = 0x7fffffff;
+    const bool jax = sp.rng == LMRL_RNG_JAX;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int c4 = tid + 1024 * j, n4 = 4 * c4;
+        if (n4 >= vocab) continue;
+        // (with top-k on, a handful of the row's 12.5 k chunks hold a kept column: the others need neither noise nor a softmax term)
+        if (v[j][0] < thr_key && v[j][1] < thr_key && v[j][2] < thr_key && v[j][3] < thr_key) continue;
+        uint32_t rnd[4] = {0, 0, 0, 0};
+        if (!sp.greedy && !jax) philox4x32_10((uint32_t)m, (uint32_t)c4, sp.step, epoch, sp.seed_lo, sp.seed_hi, rnd);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int n = n4 + r;
+            if (n >= vocab) continue;
+            if (v[j][r] < thr_key) continue;
+            const float raw = key_to_f32(v[j][r]);
+            const float vv = jax ? raw / sp.temperature : raw * sp.inv_temperature;
+            const float sc = sp.greedy ? vv : vv + (jax ? gumbel_jax(sp.seed_hi, sp.seed_lo, (uint32_t)m * (uint32_t)vocab + (uint32_t)n, sp.jax_n)
+                                                        : gumbel_from_bits(rnd[r]));
+            if (sc > best || (sc == best && n < best_col)) { best = sc; best_col = n; best_z = vv; }
+            const float nm = fmaxf(pmax, vv);
+            psum = psum * ((pmax == -INFINITY) ? 0.f : __expf(pmax - nm)) + __expf(vv - nm);
+            pmax = nm;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef LMRL_TK_FOREACH
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float om = __shfl_xor(pmax, o), os = __shfl_xor(psum, o), ob = __shfl_xor(best, o), oz = __shfl_xor(best_z, o);
+        const int oc = __shfl_xor(best_col, o);
+        const float nm = fmaxf(pmax, om);
+        const float e1 = (pmax == -INFINITY) ? 0.f : __expf(pmax - nm), e2 = (om == -INFINITY) ? 0.f : __expf(om - nm);
+        psum = psum * e1 + os * e2; pmax = nm;
+        if (ob > best || (ob == best && oc < best_col)) { best = ob; best_col = oc; best_z = oz; }
+    }
+    if (lane == 0) { red_f[wave][0] = pmax; red_f[wave][1] = psum; red_f[wave][2] = best; red_f[wave][3] = best_z; red_i[wave] = best_col; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; w++) {
+            const float om = red_f[w][0], os = red_f[w][1], ob = red_f[w][2], oz = red_f[w][3];
+            const int oc = red_i[w];
+            const float nm = fmaxf(pmax, om);
+            const float e1 = (pmax == -INFINITY) ? 0.f : __expf(pmax - nm), e2 = (om == -INFINITY) ? 0.f : __expf(om - nm);
+            psum = psum * e1 + os * e2; pmax = nm;
+            if (ob > best || (ob == best && oc < best_col)) { best = ob; best_col = oc; best_z = oz; }
+        }
+        token[m] = best_col;
+        if (logprob) logprob[m] = best_z - (pmax + __logf(psum));
+    }
+}
+
+int g_sampler_variant = 0;      // tools / tests only: 1 = the round-2 strided-row warper kernel also where the register-row kernel applies
+
+// top-k / top-p sampling from materialised logits: the register-row kernel where the row fits (vocab <= 16 float4 x 1024 threads, 16-byte aligned rows)
+static void launch_topk_sample(const float *logits_d, int ld, int m, int vocab, int top_k, float top_p, const uint8_t *active_d, int32_t *token_d,
+                               float *logprob_d, const SampleParams &sp, int pad_token, hipStream_t s) {
+    const bool reg_ok = g_sampler_variant != 1 && ld % 4 == 0 && (uintptr_t)logits_d % 16 == 0 && vocab <= 16 * 4096 && vocab > 4096;
+    if (reg_ok) {
+        const int nv = (ld / 4 + 1023) / 1024;      // float4 chunks per thread
+#define LMRL_TK_LAUNCH(NV_) hipLaunchKernelGGL(topk_sample_reg_kernel<NV_>, dim3(m), dim3(1024), 0, s, logits_d, ld, vocab, top_k, top_p, active_d, token_d, logprob_d, sp, pad_token)
+        if (nv <= 4) LMRL_TK_LAUNCH(4);
+        else if (nv <= 8) LMRL_TK_LAUNCH(8);
+        else if (nv <= 13) LMRL_TK_LAUNCH(13);
+        else if (nv <= 16) LMRL_TK_LAUNCH(16);
+        else hipLaunchKernelGGL(topk_sample_kernel, dim3(m), dim3(256), 0, s, logits_d, ld, vocab, top_k, top_p, active_d, token_d, logprob_d, sp, pad_token);
+#undef LMRL_TK_LAUNCH
+        return;
+    }
+    hipLaunchKernelGGL(topk_sample_kernel, dim3(m), dim3(256), 0, s, logits_d, ld, vocab, top_k, top_p, active_d, token_d, logprob_d, sp, pad_token);
+}
+
 // ---- generic generation bookkeeping (any tokenizer / env): append the sampled token of every live sequence, stop a sequence
 // at eos or at `cap` tokens, and emit the next decode step's inputs — so a whole `generate` runs without a host sync.
 __global__ void gen_accept_kernel(const int32_t *__restrict__ sampled, uint8_t *__restrict__ active, int32_t *__restrict__ out_tokens,
@@ -529,6 +780,7 @@ __global__ void steer_add_kernel(float *__restrict__ logits, int ld, const int32
 using namespace lmrl;
 
 extern "C" {
+void lmrl_sampler_set_variant(int v) { g_sampler_variant = v; }
 
 int lmrl_gen_accept(const int32_t *sampled_d, uint8_t *active_d, int32_t *out_tokens_d, int32_t *out_len_d, int32_t *next_tok_d,
                     int32_t *next_cnt_d, int eos_token, int cap, int n, void *stream) {
@@ -610,8 +862,7 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     const bool nucleus = p->top_p > 0.f && p->top_p < 1.f && !sp.greedy;
     if ((p->top_k > 0 && p->top_k < vocab) || nucleus) {
         LMRL_REQUIRE(logits_out_d, "lmrl_lm_head_sample: top_k / top_p sampling needs logits_out_d (materialised logits)");
-        hipLaunchKernelGGL(topk_sample_kernel, dim3(m), dim3(256), 0, s, logits_out_d, vocab_padded, vocab, p->top_k, p->top_p, active_d,
-                           token_d, logprob_d, sp, p->pad_token);
+        launch_topk_sample(logits_out_d, vocab_padded, m, vocab, p->top_k, p->top_p, active_d, token_d, logprob_d, sp, p->pad_token, s);
     } else {
         hipLaunchKernelGGL(sample_reduce_kernel, dim3(ceil_div(m, 4)), dim3(256), 0, s, partials, active_d, token_d, logprob_d, m,
                            vocab_padded / kLmBN, p->pad_token);
@@ -650,8 +901,7 @@ int lmrl_sample_logits(const float *logits_d, int ld, int m, int vocab, const lm
     LMRL_REQUIRE(p->rng == LMRL_RNG_PHILOX || p->rng == LMRL_RNG_JAX, "lmrl_sample_logits: unknown rng mode");
     LMRL_REQUIRE(p->rng != LMRL_RNG_JAX || (double)m * vocab < 4294967296.0, "lmrl_sample_logits: LMRL_RNG_JAX needs rows * vocab < 2^32");
     sp.jax_n = (uint32_t)m * (uint32_t)vocab;
-    hipLaunchKernelGGL(topk_sample_kernel, dim3(m), dim3(256), 0, as_stream(stream), logits_d, ld, vocab, p->top_k, p->top_p, active_d,
-                       token_d, logprob_d, sp, p->pad_token);
+    launch_topk_sample(logits_d, ld, m, vocab, p->top_k, p->top_p, active_d, token_d, logprob_d, sp, p->pad_token, as_stream(stream));
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

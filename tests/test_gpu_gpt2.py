@@ -322,6 +322,44 @@ def test_sampler_top_p_and_top_k_warpers(dev):
         assert chi2 < dof + 6 * np.sqrt(2 * dof) + 10, (chi2, dof, temp, top_k, top_p)
 
 
+@pytest.mark.parametrize("V,ld", [(50257, 50304), (20000, 20000), (65000, 65536)])
+def test_register_row_warper_kernel_equals_the_strided_one(dev, V, ld):
+    """Round 5: top-k / top-p selection with the whole row in the registers of a 1024-thread workgroup (`topk_sample_reg_kernel`: one read of the
+    row instead of ten) against the strided-row kernel pinned to the HF warper semantics above (`lmrl_sampler_set_variant(1)`): the same
+    thresholds and the same draw — every sampled token identical, log-probabilities to fp32 rounding — over top-k only, top-p only, both, greedy,
+    inactive rows, both random streams, a GPT-2-sized and two other row lengths."""
+    import ctypes
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.gpt2 import RNG_JAX, SampleParams
+    L = _lib.lib()
+    B = 96
+    g = torch.Generator().manual_seed(V)
+    logits = torch.zeros(B, ld)
+    logits[:, :V] = torch.randn(B, V, generator=g) * 3.0
+    n7 = (V - 1) // 7
+    logits[:, 0:7 * n7:7] = logits[:, 1:7 * n7 + 1:7]                                           # exact ties across columns
+    logits = logits.to(dev)
+    active = torch.ones(B, dtype=torch.uint8); active[5::11] = 0
+    active = active.to(dev)
+    cases = [(1.0, 40, 0.0, 0), (0.7, 0, 0.9, 0), (1.3, 50, 0.95, 0), (1.0, 1, 0.0, 0), (0.0, 40, 0.0, 0), (1.0, 5, 0.5, RNG_JAX), (1.0, 1024, 0.0, 0),
+             (1.0, 3000, 0.8, 0)]
+    for temp, top_k, top_p, rng in cases:
+        outs = []
+        for variant in (1, 0):
+            L.lmrl_sampler_set_variant(variant)
+            try:
+                sp = SampleParams(temp, top_k, 0xC0FFEE, 3, 0.0, 0.0, 7, None, top_p, rng)
+                tok = torch.zeros(B, dtype=torch.int32, device=dev); lp = torch.zeros(B, dtype=torch.float32, device=dev)
+                _lib.check(L.lmrl_sample_logits(_lib.ptr(logits), ld, B, V, ctypes.byref(sp), _lib.ptr(active), _lib.ptr(tok), _lib.ptr(lp), _lib.stream_ptr()))
+                torch.cuda.synchronize()
+                outs.append((tok.cpu().numpy(), lp.cpu().numpy()))
+            finally:
+                L.lmrl_sampler_set_variant(0)
+        assert np.array_equal(outs[0][0], outs[1][0]), (V, temp, top_k, top_p, rng)
+        np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=2e-5)
+        assert (outs[0][0][active.cpu().numpy() == 0] == 7).all() and (outs[0][0] < V).all()
+
+
 def test_sampler_steer_and_ilql_perturbation(dev):
     """logits = pi + beta * min(q1, q2)  (value_rl_base/gpt2/generation.py:112-117), greedy."""
     from lmrl_gym_amd.gpt2 import SampleParams
