@@ -524,6 +524,15 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *_
         pvc = reinterpret_cast<const char *>(pfx.v + (size_t)h * 64);
     }
     uint4 kr[U], vr[U];
+    // every cached K / V byte is read by exactly ONE wave per decode step (the few broadcast-header rows aside): streaming (nt) loads — round 5,
+    // A/B on one box (tools/_ab, bench.py --steps 10, twice each): 25.2 / 25.7 -> 23.4 / 24.4 us per launch, episode 47.34 / 47.41 -> 46.74 / 46.98 ms.
+    // Same bytes, same arithmetic: bit-identical results.  -DLMRL_DEC_NO_NT (LMRL_GPT2_EXTRA of build.py): the default cache policy, for the A/B.
+#ifndef LMRL_DEC_NO_NT
+    typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+#define LMRL_DEC_LD16(P) __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt *>(P)))
+#else
+#define LMRL_DEC_LD16(P) (*reinterpret_cast<const uint4 *>(P))
+#endif
 #define LMRL_DEC_LOAD(TBASE)                                                                                   \
     _Pragma("unroll") for (int u = 0; u < U; u++)                                                             \
         if ((TBASE) + u * 8 < L0) {                                  /* wave-uniform: block u holds cached positions */ \
@@ -536,8 +545,8 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *_
                 vr[u] = *reinterpret_cast<const uint4 *>((in_p_ ? pvc : vc) + bo_);                           \
             } else {                                                                                          \
                 const uint32_t bo_ = (((tc_ < (uint32_t)n_shared ? 0u : env_row) + tc_) * (uint32_t)d + (uint32_t)cc * 8u) * 2u; \
-                kr[u] = *reinterpret_cast<const uint4 *>(kc + bo_);                                           \
-                vr[u] = *reinterpret_cast<const uint4 *>(vc + bo_);                                           \
+                kr[u] = LMRL_DEC_LD16(kc + bo_);                                                              \
+                vr[u] = LMRL_DEC_LD16(vc + bo_);                                                              \
             }                                                                                                 \
         }
     LMRL_DEC_LOAD(0);
@@ -584,6 +593,7 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *_
         LMRL_DEC_ROW(knew, vnew, ok);
     }
 #undef LMRL_DEC_LOAD
+#undef LMRL_DEC_LD16
 #undef LMRL_DEC_ROW
     // merge the 8 row-groups: M = max m_g ; weight w_g = exp(m_g - M)
     float mm = m;
