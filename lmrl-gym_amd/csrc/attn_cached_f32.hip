@@ -238,8 +238,10 @@ __global__ __launch_bounds__(256) void attn_decode_f32_kernel(const float *__res
             if (t0 + u * 4 < L) {                                      // wave-uniform: block u holds cached positions
                 const int t = t0 + u * 4 + g;
                 const size_t ro = (size_t)(t < L ? t : L - 1) * d;
-                kr[u] = *reinterpret_cast<const float4 *>(kc + ro);
-                vr[u] = *reinterpret_cast<const float4 *>(vc + ro);
+                // (streaming loads: every cached row is read by ONE wave per decode step — as in the bf16 engine's decode attention, csrc/gpt2.hip)
+                typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+                kr[u] = __builtin_bit_cast(float4, __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(kc + ro)));
+                vr[u] = __builtin_bit_cast(float4, __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(vc + ro)));
             }
         float sc[U];
         float mb = m;
