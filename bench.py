@@ -36,8 +36,8 @@ if ROOT not in sys.path:
 # that streams the KV cache) — the largest HBM-bound kernel of the step and the one the north star's ">= 60 % of HBM roofline" refers to.
 ROOFLINE_TAG = "attention_decode"
 ROOFLINE_KERNEL = "attention_decode_kernel"                 # its name in the rocprofv3 / PMC summaries
-PROFILE_STATS = "profiles/r04_bench_kernel_stats.csv"       # committed `rocprofv3 --kernel-trace --stats` summary of this command
-PROFILE_PMC = "profiles/r04_pmc_fetch_write.json"           # committed FETCH_SIZE / WRITE_SIZE passes (tools/pmc_fetch_write.sh)
+PROFILE_STATS = "profiles/r05_bench_kernel_stats.csv"       # committed `rocprofv3 --kernel-trace --stats` summary of this command
+PROFILE_PMC = "profiles/r05_pmc_fetch_write.json"           # committed FETCH_SIZE / WRITE_SIZE passes (tools/pmc_fetch_write.sh)
 SECONDARY_TAGS = ["gemm_bf16_64x64", "gemm_bf16_64x128", "gemm_bf16_128x128", "lm_head_sample", "attention_chunk"]
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md (dense, no sparsity)
 HBM_PEAK_GBS = 8000.0                  # same guide: 8 TB/s spec (6.3 TB/s measured achievable)
