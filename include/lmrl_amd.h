@@ -253,6 +253,8 @@ int lmrl_seq_mask_pos(const int32_t *ids_d, int pad, uint8_t *am_d, int32_t *pos
  * idx_d / tgt_d capacity b * (t - 1). */
 int lmrl_masked_rows(const uint8_t *sta_d, const uint8_t *am_d, const int32_t *ids_d, int b, int t, int32_t *cnt_d, int32_t *off_d, int32_t *idx_d,
                      int32_t *tgt_d, void *stream);
+/* out_d [n + 1] = exclusive prefix sums of in_d [n] (out_d[n] = the total); one workgroup */
+int lmrl_exclusive_scan_i32(const int32_t *in_d, int32_t *out_d, int n, void *stream);
 /* dst[i] = src[idx[i]] for rows of row_bytes bytes (a shuffled batch of a device-resident dataset: ppo/data.py:88-98) */
 int lmrl_gather_rows_bytes(const void *src_d, const int32_t *idx_d, void *dst_d, int n, long row_bytes, void *stream);
 
@@ -601,6 +603,14 @@ int lmrl_maze_tok_prompt(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, int j, 
 /* generated ids -> action code: text = concat(token bytes, special tokens skipped); `text.removesuffix('\n') + '\n'`
  * (the Maze scripts' out_str_process) compared with the four action strings; records ids and code */
 int lmrl_maze_tok_action(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, int n, void *stream);
+/* The finished episodes as PPO records (lmrl_ppo_records): one token trajectory per transition — observation ids ++ action ids (generated ids minus
+ * special tokens, + newline_tok when the decoded text does not end in a newline), the step reward on the action's last token — chained per episode,
+ * as the online scripts build them (llm_rl_scripts/maze/ppo/train_ppo_online.py:444-465 + LLM_RL/environment.py:359-370).  off_d [n + 1] =
+ * exclusive scan of tr->n_turns (lmrl_exclusive_scan_i32); rows off_d[e] + t; outputs [off_d[n]][cap] / [off_d[n]], done_d / chain_total_d [n]
+ * (a chain's concatenated length: the GAE row pitch is their maximum). */
+int lmrl_maze_tok_ppo_records(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, const int32_t *off_d, int newline_tok, int cap,
+                              int32_t *tokens_d, uint8_t *is_action_d, float *reward_d, int32_t *n_tok_d, int32_t *chain_d, int32_t *pos_d, uint8_t *last_d,
+                              uint8_t *done_d, int32_t *chain_total_d, void *stream);
 /* outputs of lmrl_maze_step -> record (reward, kind), counters, live &= !done */
 int lmrl_maze_tok_result(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const float *reward_d, const uint8_t *done_d,
                          const uint8_t *kind_d, int n, void *stream);

@@ -108,6 +108,73 @@ __global__ void maze_result_kernel(lmrl_maze_traj tr, const float *__restrict__ 
     if (done[e]) tr.live[e] = 0;
 }
 
+// ---- the finished episodes as PPO records (round 5): one token trajectory per TRANSITION, chained per episode — what the Maze / chess online
+// scripts hand to get_ppo_data_from_text_trajectory_chain (llm_rl_scripts/maze/ppo/train_ppo_online.py:444-465: TextTrajectory(post_action_history,
+// reward = [0, r], done) linked in episode order) after TokenTrajectory.from_text_trajectory (LLM_RL/environment.py:359-370): tokens = the
+// observation's ids ++ the action's ids, is_action, the step reward on the action's last token.  The action's ids are the GENERATED ids with
+// special tokens dropped and one newline id appended when the decoded text does not end in a newline — the ids of `removesuffix('\n') + '\n'`
+// whenever the tokenizer's encoding of the decoded action is the generated sequence (byte-level tokenizers always).
+// One wave per env; trajectory rows are compacted over the valid turns (row = off[env] + turn).
+__global__ __launch_bounds__(256) void maze_ppo_records_kernel(lmrl_maze_traj tr, const int32_t *__restrict__ state, const int32_t *__restrict__ goal_slot,
+                                                               const int32_t *__restrict__ obs_tok, const int32_t *__restrict__ obs_len, int obs_cap,
+                                                               const uint8_t *__restrict__ tok_bytes, const uint8_t *__restrict__ tok_blen, int vocab,
+                                                               int rows, int cols, int max_new, int max_turns, int n, const int32_t *__restrict__ off,
+                                                               int newline_tok, int cap, int32_t *__restrict__ tokens, uint8_t *__restrict__ is_action,
+                                                               float *__restrict__ reward, int32_t *__restrict__ n_tok, int32_t *__restrict__ chain,
+                                                               int32_t *__restrict__ pos, uint8_t *__restrict__ last, uint8_t *__restrict__ done,
+                                                               int32_t *__restrict__ chain_total) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + wave;
+    if (e >= n) return;
+    const int nt = tr.n_turns[e];
+    const int gr = state[2 * n + e], gc = state[3 * n + e];
+    const int slot = goal_slot[gr * cols + gc];
+    int offset = 0;
+    for (int t = 0; t < nt; t++) {
+        const size_t row = (size_t)off[e] + t;
+        const int pc = tr.pos[(size_t)e * max_turns + t];
+        const int idx = slot >= 0 ? (slot * rows + (pc >> 16)) * cols + (pc & 0xFFFF) : -1;
+        const int ol = idx >= 0 ? min(obs_len[idx], cap) : 0;
+        for (int k = lane; k < ol; k += 64) {
+            tokens[row * cap + k] = obs_tok[(size_t)idx * obs_cap + k];
+            is_action[row * cap + k] = 0;
+            reward[row * cap + k] = 0.f;
+        }
+        // the action: generated ids minus special tokens (byte length 0), in order (wave-uniform walk: at most max_new ids)
+        const int gl = tr.gen_len[(size_t)e * max_turns + t];
+        int na = 0, last_byte = -1;
+        for (int k = 0; k < gl; k++) {
+            const int tok = tr.gen[((size_t)e * max_turns + t) * max_new + k];
+            const int bl = (tok >= 0 && tok < vocab) ? tok_blen[tok] : 255;
+            if (bl == 0) continue;                                   // skip_special_tokens
+            if (lane == 0 && ol + na < cap) tokens[row * cap + ol + na] = tok;
+            last_byte = bl == 255 ? -1 : tok_bytes[(size_t)tok * kTokBytes + bl - 1];
+            na++;
+        }
+        if (last_byte != '\n') {                                     // removesuffix('\n') + '\n' on a text without a trailing newline
+            if (lane == 0 && ol + na < cap) tokens[row * cap + ol + na] = newline_tok;
+            na++;
+        }
+        const int total = min(ol + na, cap);
+        for (int k = ol + lane; k < total; k += 64) {
+            is_action[row * cap + k] = 1;
+            reward[row * cap + k] = k == total - 1 ? tr.reward[(size_t)e * max_turns + t] : 0.f;
+        }
+        if (lane == 0) {
+            n_tok[row] = total;
+            chain[row] = e;
+            pos[row] = offset;
+            last[row] = t == nt - 1;
+        }
+        offset += total > 0 ? total - 1 : 0;
+    }
+    if (lane == 0) {
+        const int k = nt > 0 ? tr.kind[(size_t)e * max_turns + nt - 1] : 0;
+        done[e] = (k == 1 || k == 2) ? 1 : 0;                        // the episode's last transition ended in Failure / Success (maze/env/env.py:164-184)
+        chain_total[e] = offset;
+    }
+}
+
 }  // namespace lmrl
 
 using namespace lmrl;
@@ -172,6 +239,18 @@ int lmrl_maze_tok_action(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, int n, 
     LMRL_REQUIRE(c && tr && n > 0, "lmrl_maze_tok_action: bad argument");
     hipLaunchKernelGGL(maze_action_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), *tr, c->tok_bytes_d, c->tok_blen_d, c->vocab,
                        c->max_new, c->max_turns, n);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_maze_tok_ppo_records(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, const int32_t *off_d, int newline_tok, int cap,
+                              int32_t *tokens_d, uint8_t *is_action_d, float *reward_d, int32_t *n_tok_d, int32_t *chain_d, int32_t *pos_d, uint8_t *last_d,
+                              uint8_t *done_d, int32_t *chain_total_d, void *stream) {
+    LMRL_REQUIRE(c && tr && state_d && n > 0 && off_d && cap >= 2 && tokens_d && is_action_d && reward_d && n_tok_d && chain_d && pos_d && last_d && done_d &&
+                     chain_total_d, "lmrl_maze_tok_ppo_records: bad argument");
+    hipLaunchKernelGGL(maze_ppo_records_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, as_stream(stream), *tr, (const int32_t *)state_d, c->goal_slot_d,
+                       c->obs_tok_d, c->obs_len_d, c->obs_cap, c->tok_bytes_d, c->tok_blen_d, c->vocab, c->rows, c->cols, c->max_new, c->max_turns, n, off_d,
+                       newline_tok, cap, tokens_d, is_action_d, reward_d, n_tok_d, chain_d, pos_d, last_d, done_d, chain_total_d);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

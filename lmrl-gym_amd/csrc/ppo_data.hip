@@ -333,6 +333,13 @@ int lmrl_masked_rows(const uint8_t *sta_d, const uint8_t *am_d, const int32_t *i
     return LMRL_OK;
 }
 
+int lmrl_exclusive_scan_i32(const int32_t *in_d, int32_t *out_d, int n, void *stream) {
+    LMRL_REQUIRE(in_d && out_d && n > 0, "lmrl_exclusive_scan_i32: bad argument");
+    hipLaunchKernelGGL(scan2_kernel, dim3(1), dim3(1024), 0, as_stream(stream), in_d, (const int32_t *)nullptr, n, out_d, (int32_t *)nullptr, (int32_t *)nullptr);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
 int lmrl_gather_rows_bytes(const void *src_d, const int32_t *idx_d, void *dst_d, int n, long row_bytes, void *stream) {
     LMRL_REQUIRE(src_d && idx_d && dst_d && n >= 0 && row_bytes > 0, "lmrl_gather_rows_bytes: bad argument");
     if (n == 0) return LMRL_OK;

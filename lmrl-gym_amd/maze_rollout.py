@@ -101,6 +101,7 @@ class MazeRolloutEngine:
         self.pad = getattr(tokenizer, "pad_token_id", 0) or 0
         self.dev, self._L = engine.device, _lib.lib()
         self.in_str_process = in_str_process or (lambda x: x)
+        self._max_input_length = int(max_input_length)
         self.prefix_cache = prefix_cache
         self.prefix_indexed = prefix_indexed        # read the prompt rows from the prefix cache (no per-turn copy) vs copy them per env
         # ---- observation table: one row per (goal slot, cell)
@@ -284,6 +285,44 @@ class MazeRolloutEngine:
         _lib.check(self._L.lmrl_maze_tok_begin(self._tok, ctypes.byref(self._ctraj), self.B, _lib.stream_ptr()), "maze_tok_begin")
         self.epoch.fill_(int(episode) << 12)
         return self.turn_graph.replay if use_graph else (lambda: self._turn(temperature, top_k, sample_seed, logits))
+
+    # ---- the online-RL hand-over: the finished episodes as PPO data, on the device --------------------------------------------------
+    def ppo_records(self):
+        """The finished episodes as `algorithms.ppo_device.PPORecords`: one token trajectory per transition (observation ids ++ action ids,
+        reward on the action's last token), chained per episode — the chains the Maze / chess online scripts build from `raw_results`
+        (llm_rl_scripts/maze/ppo/train_ppo_online.py:444-465) after `TokenTrajectory.from_text_trajectory`.  Two small readbacks (the number of
+        transitions, the longest chain) size the arrays.  The action ids are the generated ids (special tokens dropped, a newline id appended
+        when the text has no trailing newline): the reference's re-tokenisation of the post-processed action text whenever the tokenizer
+        encodes the decoded action as the generated sequence (byte-level tokenizers); the observation ids are the
+        prompt table's rows (`in_str_process` must be the identity and no prompt may have been left-truncated: checked)."""
+        import torch
+        from .algorithms.ppo_device import PPORecords
+        t, L, sp = torch, self._L, _lib.stream_ptr()
+        if self.in_str_process("\x00probe") != "\x00probe" or self.obs_len_h.max() >= self._max_input_length:
+            raise ValueError("ppo_records: the PPO chains tokenise the raw observation text — in_str_process must be the identity and prompts untruncated")
+        B = self.B
+        off = t.empty(B + 1, dtype=t.int32, device=self.dev)
+        _lib.check(L.lmrl_exclusive_scan_i32(_lib.ptr(self.traj["n_turns"]), _lib.ptr(off), B, sp), "lmrl_exclusive_scan_i32")
+        N = int(off[B:].cpu().numpy()[0])
+        if N == 0:
+            raise ValueError("ppo_records: no transition recorded (run an episode first)")
+        nl = self.tok.encode("\n")
+        assert len(nl) == 1, "the newline must be one token"
+        cap = int(self.max_obs_len) + self.max_new + 1
+        z = lambda *s_, dt: t.zeros(*s_, dtype=dt, device=self.dev)
+        tokens, ia, rw = z(N, cap, dt=t.int32), z(N, cap, dt=t.uint8), z(N, cap, dt=t.float32)
+        n_tok, chain, pos, last = z(N, dt=t.int32), z(N, dt=t.int32), z(N, dt=t.int32), z(N, dt=t.uint8)
+        done, total = z(B, dt=t.uint8), z(B, dt=t.int32)
+        _lib.check(L.lmrl_maze_tok_ppo_records(self._tok, ctypes.byref(self._ctraj), _lib.ptr(self.env.state), B, _lib.ptr(off), int(nl[0]), cap, _lib.ptr(tokens),
+                                               _lib.ptr(ia), _lib.ptr(rw), _lib.ptr(n_tok), _lib.ptr(chain), _lib.ptr(pos), _lib.ptr(last), _lib.ptr(done),
+                                               _lib.ptr(total), sp), "lmrl_maze_tok_ppo_records")
+        return PPORecords(tokens, ia, rw, n_tok, done, chain, pos, last, n_chains=B, chain_len_bound=max(int(total.cpu().numpy().max()), 1))
+
+    def ppo_data(self, inference, *, gamma: float, lam: float, kl_weight: float, max_length: Optional[int] = None, **kw):
+        """`ppo_dataset_loader` of the Maze online script on the episodes this engine just ran -> (DevicePPODataset, all_kls): see
+        `algorithms.ppo_device.ppo_data_from_records`."""
+        from .algorithms.ppo_device import ppo_data_from_records
+        return ppo_data_from_records(inference, self.ppo_records(), gamma=gamma, lam=lam, kl_weight=kl_weight, max_length=max_length, **kw)
 
     # ---- host views ----------------------------------------------------------------------------------------------------------------
     def records(self):

@@ -197,3 +197,77 @@ def test_text_env_eval_lanes_return_the_one_lane_interactions():
         out.append((inter, summ))
         eng.close()
     assert len(out[0][0]) == 5 * B - 3 and out[0][0] == out[1][0] and out[0][1] == out[1][1]
+
+
+def test_maze_ppo_records_and_device_ppo_data_equal_the_host_chain_path():
+    """Round 5: the Maze twin of `WordleRolloutEngine.ppo_data`.  The finished device episodes as token-trajectory chains in HBM
+    (`MazeRolloutEngine.ppo_records`: one trajectory per transition, chained per episode) == the chains the online script builds from
+    `raw_results` (llm_rl_scripts/maze/ppo/train_ppo_online.py:444-465) after `TokenTrajectory.from_text_trajectory` — tokens, action flags, reward
+    placement, done — and the device PPO data built from them == the host-array `get_ppo_data_from_token_trajectory_chain` on those chains
+    (multi-trajectory chains: bootstrap from the chain's last trajectory, GAE across trajectory boundaries, whitening over all transitions)."""
+    from lmrl_gym_amd import _lib, environment as E
+    from lmrl_gym_amd.algorithms import ppo
+    from lmrl_gym_amd.algorithms.common import BlockingStrategy, Padding, Truncation
+    from lmrl_gym_amd.algorithms.ppo_inference import GPT2PPOInference, text_trajectory_chains_from_transitions
+    from lmrl_gym_amd.datasets import ByteTokenizer
+    from lmrl_gym_amd.envs import maze as M
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
+    from lmrl_gym_amd.maze_rollout import MazeRolloutEngine
+    from lmrl_gym_amd.policies import heads_to_engine_layout
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
+    dev = _lib.require_gpu()
+    tok = ByteTokenizer()
+    cfg = GPT2Config(2, 2, 128, 256, len(tok) + 3, 256)
+    sd = init_hf_style_state_dict(cfg, seed=3)
+    pi, vb = GPT2Engine(cfg, sd, dev), GPT2Engine.random_init(cfg, seed=4, device=dev)
+    d, V = cfg.d_model, cfg.vocab
+    g = torch.Generator().manual_seed(6)
+    bias = torch.full((V,), -30.0)                                 # sampled ids: the letters of the action strings, ' ' and the newline (plain ASCII bytes)
+    for ch in "movelftrighupdwn \n":
+        bias[ord(ch)] = 0.0
+    bias[10] = 1.5
+    head = heads_to_engine_layout({"dense1.kernel": torch.randn(d, d, generator=g) * 0.05, "dense1.bias": torch.zeros(d),
+                                   "dense2.kernel": torch.randn(d, V, generator=g) * 0.3, "dense2.bias": bias}, cfg.vocab_padded, dev)
+    env = M.setup_maze_env("double_t_maze", "describe_observation_give_position", "standard_reward", last_k=1, max_steps=7)
+    B = 40
+    eng = MazeRolloutEngine(pi, tok, env, B, max_new_tokens=4, eos_token_id=tok.eos_token_id, value_engine=vb, q1_head=head, q2_head=None, beta=1.0)
+    eng.run_episode([11 * i + 2 for i in range(B)], None, temperature=1.0, sample_seed=8, use_graph=False, sync_every=0)
+    torch.cuda.synchronize()
+    # ---- records == the script's chains
+    chains = [E.TokenTrajectoryChain.from_text_trajectory_chain(c, tok) for c in text_trajectory_chains_from_transitions(eng.interactions())]
+    rec = eng.ppo_records()
+    flat = [tt for c in chains for tt in c.to_list()]
+    assert rec.n == len(flat) > 3 * B and rec.n_chains == B == len(chains)
+    h = {k: getattr(rec, k).cpu().numpy() for k in ("tokens", "is_action", "reward", "n_tok", "done", "chain", "pos", "last")}
+    k = 0
+    n_act_lens = set()
+    for c, ch in enumerate(chains):
+        lst, p = ch.to_list(), 0
+        for i, tt in enumerate(lst):
+            n = int(h["n_tok"][k])
+            assert n == len(tt.tokens) and h["tokens"][k, :n].tolist() == tt.tokens.tolist(), (c, i)
+            assert h["is_action"][k, :n].astype(bool).tolist() == tt.is_action.tolist() and np.array_equal(h["reward"][k, :n], tt.reward)
+            assert h["chain"][k] == c and h["pos"][k] == p and bool(h["last"][k]) == (i == len(lst) - 1)
+            n_act_lens.add(int(tt.is_action.sum()))
+            p += n - 1
+            k += 1
+        assert bool(h["done"][c]) == bool(lst[-1].done)
+    assert len(n_act_lens) >= 3                                    # actions of 1 .. 5 tokens (early newline, forced newline after max_new ids)
+    # ---- device PPO data == host-array form on the same chains
+    pol = GPT2F32({kk: v + 0.02 * torch.randn(v.shape, generator=g) * v.abs().mean().clamp_min(1e-3) for kk, v in sd.items()}, cfg.n_head, device=dev)
+    init = GPT2F32(sd, cfg.n_head, device=dev)
+    vh = LinearHeadF32(dict(kernel=torch.randn(d, 1, generator=g) * 0.05, bias=torch.tensor([0.2])), dev)
+    inf = GPT2PPOInference(pol, vh, tok.pad_token_id, initial_policy=init)
+    kw = dict(gamma=0.97, lam=0.9, kl_weight=0.05)
+    max_length = rec.cap + 1
+    ds, kls = eng.ppo_data(inf, max_length=max_length, bsize=64, **kw)
+    datas, kls_h = inf.get_ppo_data_from_token_trajectory_chain(chains, bsize=32, max_length=max_length, **kw)
+    host = ppo.PPODataset.from_ppo_data_list(datas, tok, BlockingStrategy(Padding.RIGHT, Truncation.RIGHT, max_length))
+    got = ds.to_host()
+    assert (got.input_ids == host.input_ids).all() and (got.should_take_action == host.should_take_action).all()
+    np.testing.assert_allclose(got.old_logprobs, host.old_logprobs, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got.old_values, host.old_values, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got.old_returns, host.old_returns, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got.old_advantages, host.old_advantages, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(kls.cpu().numpy(), kls_h, rtol=1e-5, atol=5e-6)
+    eng.close()
