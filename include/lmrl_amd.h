@@ -607,8 +607,8 @@ int lmrl_maze_tok_action(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, int n, 
  * special tokens, + newline_tok when the decoded text does not end in a newline), the step reward on the action's last token — chained per episode,
  * as the online scripts build them (llm_rl_scripts/maze/ppo/train_ppo_online.py:444-465 + LLM_RL/environment.py:359-370).  off_d [n + 1] =
  * exclusive scan of tr->n_turns (lmrl_exclusive_scan_i32); rows off_d[e] + t; outputs [off_d[n]][cap] / [off_d[n]], done_d / chain_total_d [n]
- * (a chain's concatenated length: the GAE row pitch is their maximum). */
-int lmrl_maze_tok_ppo_records(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, const int32_t *off_d, int newline_tok, int cap,
+ * (a chain's concatenated length: the GAE row pitch is their maximum).  The first n of the engine's n_envs envs are exported. */
+int lmrl_maze_tok_ppo_records(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, int n_envs, const int32_t *off_d, int newline_tok, int cap,
                               int32_t *tokens_d, uint8_t *is_action_d, float *reward_d, int32_t *n_tok_d, int32_t *chain_d, int32_t *pos_d, uint8_t *last_d,
                               uint8_t *done_d, int32_t *chain_total_d, void *stream);
 /* outputs of lmrl_maze_step -> record (reward, kind), counters, live &= !done */

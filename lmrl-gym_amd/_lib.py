@@ -50,7 +50,7 @@ _SIGS = {
     "lmrl_gather_rows_bytes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.c_long, c_void_p]),
     "lmrl_gpt2_refresh": (c_int, [c_void_p, c_void_p]),
     "lmrl_exclusive_scan_i32": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
-    "lmrl_maze_tok_ppo_records": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int] + [c_void_p] * 10),
+    "lmrl_maze_tok_ppo_records": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 10),
     "lmrl_gpt2_create": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmrl_gpt2_destroy": (None, [c_void_p]),
     "lmrl_gpt2_kv_bytes": (c_size_t, [c_void_p, c_int, c_int]),

@@ -118,7 +118,7 @@ __global__ void maze_result_kernel(lmrl_maze_traj tr, const float *__restrict__ 
 __global__ __launch_bounds__(256) void maze_ppo_records_kernel(lmrl_maze_traj tr, const int32_t *__restrict__ state, const int32_t *__restrict__ goal_slot,
                                                                const int32_t *__restrict__ obs_tok, const int32_t *__restrict__ obs_len, int obs_cap,
                                                                const uint8_t *__restrict__ tok_bytes, const uint8_t *__restrict__ tok_blen, int vocab,
-                                                               int rows, int cols, int max_new, int max_turns, int n, const int32_t *__restrict__ off,
+                                                               int rows, int cols, int max_new, int max_turns, int n, int pitch, const int32_t *__restrict__ off,
                                                                int newline_tok, int cap, int32_t *__restrict__ tokens, uint8_t *__restrict__ is_action,
                                                                float *__restrict__ reward, int32_t *__restrict__ n_tok, int32_t *__restrict__ chain,
                                                                int32_t *__restrict__ pos, uint8_t *__restrict__ last, uint8_t *__restrict__ done,
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void maze_ppo_records_kernel(lmrl_maze_traj tr
     const int e = blockIdx.x * 4 + wave;
     if (e >= n) return;
     const int nt = tr.n_turns[e];
-    const int gr = state[2 * n + e], gc = state[3 * n + e];
+    const int gr = state[2 * pitch + e], gc = state[3 * pitch + e];       // (state rows have the env batch's pitch; n <= pitch envs are exported)
     const int slot = goal_slot[gr * cols + gc];
     int offset = 0;
     for (int t = 0; t < nt; t++) {
@@ -243,13 +243,13 @@ int lmrl_maze_tok_action(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, int n, 
     return LMRL_OK;
 }
 
-int lmrl_maze_tok_ppo_records(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, const int32_t *off_d, int newline_tok, int cap,
+int lmrl_maze_tok_ppo_records(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, int n_envs, const int32_t *off_d, int newline_tok, int cap,
                               int32_t *tokens_d, uint8_t *is_action_d, float *reward_d, int32_t *n_tok_d, int32_t *chain_d, int32_t *pos_d, uint8_t *last_d,
                               uint8_t *done_d, int32_t *chain_total_d, void *stream) {
-    LMRL_REQUIRE(c && tr && state_d && n > 0 && off_d && cap >= 2 && tokens_d && is_action_d && reward_d && n_tok_d && chain_d && pos_d && last_d && done_d &&
+    LMRL_REQUIRE(c && tr && state_d && n > 0 && n <= n_envs && off_d && cap >= 2 && tokens_d && is_action_d && reward_d && n_tok_d && chain_d && pos_d && last_d && done_d &&
                      chain_total_d, "lmrl_maze_tok_ppo_records: bad argument");
     hipLaunchKernelGGL(maze_ppo_records_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, as_stream(stream), *tr, (const int32_t *)state_d, c->goal_slot_d,
-                       c->obs_tok_d, c->obs_len_d, c->obs_cap, c->tok_bytes_d, c->tok_blen_d, c->vocab, c->rows, c->cols, c->max_new, c->max_turns, n, off_d,
+                       c->obs_tok_d, c->obs_len_d, c->obs_cap, c->tok_bytes_d, c->tok_blen_d, c->vocab, c->rows, c->cols, c->max_new, c->max_turns, n, n_envs, off_d,
                        newline_tok, cap, tokens_d, is_action_d, reward_d, n_tok_d, chain_d, pos_d, last_d, done_d, chain_total_d);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;

@@ -200,6 +200,14 @@ class MazeRolloutEngine:
         if self.prefix_cache:
             self.refresh_prefix_cache()
 
+    def load_params(self, params) -> None:
+        """The trainer's fp32 parameters into the policy engine IN PLACE (`GPT2Engine.load_params`: captured turns stay valid, they read the same
+        weight buffers), then the observation prefix cache again — its K/V rows were computed by the old weights."""
+        self.eng.load_params(params)
+        self._drop_lanes()
+        if self.prefix_cache:
+            self.refresh_prefix_cache()
+
     # ---- one lock-step turn ----------------------------------------------------------------------------------------------------------
     def _turn(self, temperature: float, top_k: int, sample_seed: int, logits_out=None):
         L, sp, tr, B = self._L, _lib.stream_ptr(), ctypes.byref(self._ctraj), self.B
@@ -287,8 +295,8 @@ class MazeRolloutEngine:
         return self.turn_graph.replay if use_graph else (lambda: self._turn(temperature, top_k, sample_seed, logits))
 
     # ---- the online-RL hand-over: the finished episodes as PPO data, on the device --------------------------------------------------
-    def ppo_records(self):
-        """The finished episodes as `algorithms.ppo_device.PPORecords`: one token trajectory per transition (observation ids ++ action ids,
+    def ppo_records(self, n: Optional[int] = None):
+        """The finished episodes (of the first `n` envs; default all) as `algorithms.ppo_device.PPORecords`: one token trajectory per transition (observation ids ++ action ids,
         reward on the action's last token), chained per episode — the chains the Maze / chess online scripts build from `raw_results`
         (llm_rl_scripts/maze/ppo/train_ppo_online.py:444-465) after `TokenTrajectory.from_text_trajectory`.  Two small readbacks (the number of
         transitions, the longest chain) size the arrays.  The action ids are the generated ids (special tokens dropped, a newline id appended
@@ -300,7 +308,7 @@ class MazeRolloutEngine:
         t, L, sp = torch, self._L, _lib.stream_ptr()
         if self.in_str_process("\x00probe") != "\x00probe" or self.obs_len_h.max() >= self._max_input_length:
             raise ValueError("ppo_records: the PPO chains tokenise the raw observation text — in_str_process must be the identity and prompts untruncated")
-        B = self.B
+        B = self.B if n is None else int(n)
         off = t.empty(B + 1, dtype=t.int32, device=self.dev)
         _lib.check(L.lmrl_exclusive_scan_i32(_lib.ptr(self.traj["n_turns"]), _lib.ptr(off), B, sp), "lmrl_exclusive_scan_i32")
         N = int(off[B:].cpu().numpy()[0])
@@ -313,16 +321,54 @@ class MazeRolloutEngine:
         tokens, ia, rw = z(N, cap, dt=t.int32), z(N, cap, dt=t.uint8), z(N, cap, dt=t.float32)
         n_tok, chain, pos, last = z(N, dt=t.int32), z(N, dt=t.int32), z(N, dt=t.int32), z(N, dt=t.uint8)
         done, total = z(B, dt=t.uint8), z(B, dt=t.int32)
-        _lib.check(L.lmrl_maze_tok_ppo_records(self._tok, ctypes.byref(self._ctraj), _lib.ptr(self.env.state), B, _lib.ptr(off), int(nl[0]), cap, _lib.ptr(tokens),
+        _lib.check(L.lmrl_maze_tok_ppo_records(self._tok, ctypes.byref(self._ctraj), _lib.ptr(self.env.state), B, self.B, _lib.ptr(off), int(nl[0]), cap, _lib.ptr(tokens),
                                                _lib.ptr(ia), _lib.ptr(rw), _lib.ptr(n_tok), _lib.ptr(chain), _lib.ptr(pos), _lib.ptr(last), _lib.ptr(done),
                                                _lib.ptr(total), sp), "lmrl_maze_tok_ppo_records")
         return PPORecords(tokens, ia, rw, n_tok, done, chain, pos, last, n_chains=B, chain_len_bound=max(int(total.cpu().numpy().max()), 1))
 
-    def ppo_data(self, inference, *, gamma: float, lam: float, kl_weight: float, max_length: Optional[int] = None, **kw):
+    def ppo_data(self, inference, *, gamma: float, lam: float, kl_weight: float, max_length: Optional[int] = None, n: Optional[int] = None, **kw):
         """`ppo_dataset_loader` of the Maze online script on the episodes this engine just ran -> (DevicePPODataset, all_kls): see
         `algorithms.ppo_device.ppo_data_from_records`."""
         from .algorithms.ppo_device import ppo_data_from_records
-        return ppo_data_from_records(inference, self.ppo_records(), gamma=gamma, lam=lam, kl_weight=kl_weight, max_length=max_length, **kw)
+        return ppo_data_from_records(inference, self.ppo_records(n), gamma=gamma, lam=lam, kl_weight=kl_weight, max_length=max_length, **kw)
+
+    def ppo_rollouts(self, inference, n_rollouts: int, seed_generator=None, env_options=None, *, gamma: float, lam: float, kl_weight: float,
+                     max_length: Optional[int] = None, use_advantage_whitening: bool = True, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0,
+                     use_graph: bool = True, **kw):
+        """One data-collection round of the Maze online PPO loop on the device: `text_env_eval(n_rollouts, bsize=B)` + `ppo_dataset_loader`
+        (maze/ppo/train_ppo_online.py:431-483) -> (DevicePPODataset over all transitions of all rollouts, all_kls, summary).  Per episode batch: the
+        lock-step episode, then its PPO data while the record is in the engine's buffers; advantages whitened once over the action tokens of the whole
+        round; `summary` has `text_env_eval`'s shape (from the per-env counters; no text is built)."""
+        import torch
+        from .algorithms.ppo_device import DevicePPODataset
+        from . import dist as D
+        parts, kls, stats = [], [], []
+        launched = 0
+        while launched < n_rollouts:
+            actual = min(n_rollouts - launched, self.B)
+            seeds = [0] * self.B
+            seeds[:actual] = [next(seed_generator) for _ in range(actual)] if seed_generator is not None else np.random.randint(0, 2 ** 31 - 1, size=actual).tolist()
+            self.run_episode(seeds, env_options, temperature=temperature, top_k=top_k, sample_seed=sample_seed, episode=self.episodes, use_graph=use_graph)
+            self.episodes += 1
+            launched += actual
+            ds, kl = self.ppo_data(inference, gamma=gamma, lam=lam, kl_weight=kl_weight, max_length=max_length, n=actual, use_advantage_whitening=False, **kw)
+            parts.append(ds); kls.append(kl)
+            kind = self.traj["kind"][:actual].cpu().numpy(); nt = self.traj["n_turns"][:actual].cpu().numpy()
+            last_kind = kind[np.arange(actual), np.maximum(nt - 1, 0)]
+            stats.append(np.stack([self.traj["ep_reward"][:actual].cpu().numpy().astype(np.float64), ((last_kind == 1) | (last_kind == 2)).astype(np.float64),
+                                   nt.astype(np.float64)]))
+        if len(parts) > 1:
+            T = max(p.input_ids.shape[1] for p in parts)
+            assert all(p.input_ids.shape[1] == T for p in parts), "batches of one round share the blocking width (pass max_length)"
+        cat = (lambda name: getattr(parts[0], name)) if len(parts) == 1 else (lambda name: torch.cat([getattr(p, name) for p in parts]))
+        ds = DevicePPODataset(longest=max(p.longest for p in parts), **{name: cat(name) for name in DevicePPODataset.FIELDS})
+        if use_advantage_whitening:
+            adv = ds.old_advantages
+            ds.old_advantages = D.whiten_distributed(adv.view(-1), ds.should_take_action.view(-1), shift_mean=True).view(adv.shape)
+        st = np.concatenate(stats, axis=1)
+        summ = lambda x: dict(mean=np.mean(x), std=np.std(x), min=np.min(x), max=np.max(x))
+        return ds, (kls[0] if len(kls) == 1 else torch.cat(kls)), dict(reward=summ(st[0].astype(np.float32)), done=summ(st[1].astype(np.float32)),
+                                                                       length=summ(st[2].astype(np.int64)))
 
     # ---- host views ----------------------------------------------------------------------------------------------------------------
     def records(self):

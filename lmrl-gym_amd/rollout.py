@@ -359,6 +359,11 @@ class WordleRolloutEngine:
         return [(tok[b, :n[b]].copy(), ia[b, :n[b]].copy(), rw[b, :n[b]].copy(), bool(dn[b])) for b in range(self.B)]
 
     # ---- the online-RL hand-over: the finished episode as PPO data, on the device -------------------------------------
+    def load_params(self, params) -> None:
+        """The trainer's fp32 parameters into the policy engine IN PLACE (`GPT2Engine.load_params`): captured episodes stay valid (they read the same
+        weight buffers; the shared header's K/V are recomputed at every episode start)."""
+        self.eng.load_params(params)
+
     def ppo_records(self, n: Optional[int] = None):
         """The episode record as `algorithms.ppo_device.PPORecords` — views of the engine's own buffers (no copy; valid until the next episode
         is enqueued): one single-trajectory chain per env (the first `n` envs), exactly the `TextTrajectoryChain(text_trajectory, None)` the task

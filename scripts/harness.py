@@ -183,7 +183,7 @@ def cmd_ppo(a):
     from lmrl_gym_amd.policies import GPT2PPOPolicy
     from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
     dev = _lib.require_gpu()
-    tok = _tokenizer(wordle=a.env != "chess")        # FEN / SAN text needs every byte: the byte tokenizer when no GPT-2 files are around
+    tok = _tokenizer(wordle=a.env == "wordle")       # FEN / SAN text needs every byte: the byte tokenizer when no GPT-2 files are around
     cfg, sd = _model(a.model, max(len(tok), 50257))
     mm = dict(matmul="bf16" if a.bf16_activations else "f32")
     pol_f32 = GPT2F32(sd, cfg.n_head, device=dev, gradient_checkpointing=a.gradient_checkpointing, **mm)
@@ -210,6 +210,10 @@ def cmd_ppo(a):
                                    **({} if a.chess_random_opponent else dict(engine_path=a.chess_engine, engine_options={"Use NNUE": a.chess_use_nnue},
                                                                               movetime_ms=a.chess_movetime_ms)))
         vocab = None
+    elif a.env == "maze":       # configs[0]'s online script: llm_rl_scripts/maze/ppo/train_ppo_online.py:260-300, 431-483
+        from lmrl_gym_amd.envs import maze as M
+        env = M.setup_maze_env(a.maze_name, a.maze_describe_function, a.maze_reward_function, last_k=a.maze_last_k, max_steps=a.maze_max_steps)
+        vocab = None
     else:
         vocab, env = _wordle_env(a)
     step = 0
@@ -217,15 +221,20 @@ def cmd_ppo(a):
     # --device-rollouts: the whole iteration stays in HBM — rollout records -> PPO data -> device batches -> train steps -> the trainer's
     # parameters copied into the engine in place (WordleRolloutEngine.ppo_rollouts, algorithms/ppo_device.py); --resident 0: the host-array path
     resident = bool(a.device_rollouts) and bool(a.resident)
-    ro_res = _device_rollouts(policy.engine, vocab, tok, a.rollout_bsize, a.bad_word_reward, min(a.max_output_length, 12)) if resident else None
+    if resident and a.env == "maze":
+        from lmrl_gym_amd.maze_rollout import MazeRolloutEngine
+        ro_res = MazeRolloutEngine(policy.engine, tok, env, a.rollout_bsize, max_new_tokens=min(a.max_output_length, 12), eos_token_id=tok.encode("\n")[0],
+                                   max_input_length=a.max_input_length)
+    else:
+        ro_res = _device_rollouts(policy.engine, vocab, tok, a.rollout_bsize, a.bad_word_reward, min(a.max_output_length, 12)) if resident else None
     for rnd in range(a.n_rounds):
         if limit is not None and step >= limit:
             break
         if resident:
+            warp = dict(top_k=int(a.policy_top_k or 0)) if a.env == "maze" else dict(top_k=int(a.policy_top_k or 0), top_p=float(a.policy_top_p or 0.0))
             ds, kls, summary = ro_res.ppo_rollouts(inf, a.n_rollouts, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)), gamma=a.gamma, lam=a.lam,
                                                    kl_weight=ctl.value, max_length=max_len, use_advantage_whitening=a.use_advantage_whitening,
-                                                   temperature=a.policy_temperature or 1.0, sample_seed=rnd, bsize=max(a.ppo_data_bsize, 64),
-                                                   top_k=int(a.policy_top_k or 0), top_p=float(a.policy_top_p or 0.0))
+                                                   temperature=a.policy_temperature or 1.0, sample_seed=rnd, bsize=max(a.ppo_data_bsize, 64), **warp)
             mean_kl = float(kls.cpu().numpy().mean()) if kls.numel() else 0.0
             ctl.update(mean_kl, a.train_bsize)
             _log("data_collection", dict(round=rnd, env_interaction=summary, mean_kl=mean_kl, kl_ctrl_value=ctl.value, n_chains=len(ds), device_resident=True))
@@ -250,9 +259,16 @@ def cmd_ppo(a):
                     _log("train", dict(step=step, round=rnd, loss=loss))
                     if limit is not None and step >= limit:
                         break
-            policy.engine.load_params(pol_f32.p)
+            ro_res.load_params(pol_f32.p)
             continue
-        if a.device_rollouts:       # env + policy + lock-step loop on the GPU; same (interactions, summary) as text_env_eval
+        if a.device_rollouts and a.env == "maze":
+            from lmrl_gym_amd.maze_rollout import MazeRolloutEngine
+            ro = MazeRolloutEngine(policy.engine, tok, env, a.rollout_bsize, max_new_tokens=min(a.max_output_length, 12), eos_token_id=tok.encode("\n")[0],
+                                   max_input_length=a.max_input_length)
+            raw, summary = ro.text_env_eval(a.n_rollouts, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)), temperature=a.policy_temperature or 1.0,
+                                            top_k=int(a.policy_top_k or 0), sample_seed=rnd)
+            ro.close()
+        elif a.device_rollouts:     # env + policy + lock-step loop on the GPU; same (interactions, summary) as text_env_eval
             ro = _device_rollouts(policy.engine, vocab, tok, a.rollout_bsize, a.bad_word_reward, min(a.max_output_length, 12))
             raw, summary = ro.text_env_eval(a.n_rollouts, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)), temperature=a.policy_temperature or 1.0,
                                             top_k=int(a.policy_top_k or 0), top_p=float(a.policy_top_p or 0.0), sample_seed=rnd, concurrent=a.rollout_lanes)
@@ -260,7 +276,7 @@ def cmd_ppo(a):
         else:
             raw, summary = E.text_env_eval(env, policy, n_rollouts=a.n_rollouts, bsize=a.rollout_bsize, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)),
                                            verbose=False)
-        chains = text_trajectory_chains_from_transitions(raw) if a.env == "chess" else text_trajectory_chains_from_interactions(raw, tok, max_len, a.gamma)
+        chains = text_trajectory_chains_from_transitions(raw) if a.env in ("chess", "maze") else text_trajectory_chains_from_interactions(raw, tok, max_len, a.gamma)
         datas, kls = inf.get_ppo_data_from_text_trajectory_chain(chains, bsize=a.ppo_data_bsize, max_length=max_len, gamma=a.gamma, lam=a.lam,
                                                                  kl_weight=ctl.value, use_advantage_whitening=a.use_advantage_whitening)
         mean_kl = float(kls.mean()) if len(kls) else 0.0
@@ -402,7 +418,10 @@ def build_parser() -> argparse.ArgumentParser:
     sub.choices["ilql"].add_argument("--eval-data", default=None)
     sub.choices["ppo"].add_argument("--bc-data", default=None)
     pp = sub.choices["ppo"]
-    pp.add_argument("--env", default="wordle", choices=["wordle", "chess"])
+    pp.add_argument("--env", default="wordle", choices=["wordle", "chess", "maze"])
+    pp.add_argument("--maze-name", default="double_t_maze"); pp.add_argument("--maze-describe-function", default="describe_observation_give_position")
+    pp.add_argument("--maze-reward-function", default="standard_reward"); pp.add_argument("--maze-last-k", type=int, default=1)
+    pp.add_argument("--maze-max-steps", type=int, default=100)
     pp.add_argument("--resident", type=int, default=1, help="with --device-rollouts 1: 1 (default) = the device-resident iteration, 0 = device rollouts feeding the host-array PPO data path")
     pp.add_argument("--trim-batches", type=int, default=0, help="device-resident loop: train on batches cut to the round's longest episode (multiple of 64) instead of "
                                                                   "max_input_length + max_output_length columns — same loss and gradients, fewer padded rows")

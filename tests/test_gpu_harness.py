@@ -190,6 +190,12 @@ def test_harness_script_subcommands_at_toy_scale(tmp_path, capsys):
     # configs[3] at toy scale: online PPO against the chess env (random opponent; and the reference-built engine when present)
     H.main(["ppo", "--env", "chess", "--chess-random-opponent", "1", "--chess-pieces", "kQK", "--chess-max-moves", "3", "--n-rollouts", "4", "--rollout-bsize", "4",
             "--ppo-data-bsize", "4", "--train-bsize", "2", "--max-steps", "1", "--max-input-length", "160", "--max-output-length", "8"])
+    # configs[0]'s online script at toy scale (maze/ppo/train_ppo_online.py): text path, device rollouts -> host data, and the device-resident loop
+    mz = ["ppo", "--env", "maze", "--maze-max-steps", "3", "--n-rollouts", "6", "--rollout-bsize", "4", "--ppo-data-bsize", "4", "--train-bsize", "4",
+          "--max-steps", "2", "--max-input-length", "160", "--max-output-length", "6"]
+    H.main(mz)
+    H.main(mz + ["--device-rollouts", "1", "--resident", "0"])
+    H.main(mz + ["--device-rollouts", "1", "--n-rounds", "2", "--trim-batches", "1", "--bf16-activations", "1"])
     sf = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "stockfish")
     if os.path.exists(sf):
         H.main(["ppo", "--env", "chess", "--chess-engine", sf, "--chess-use-nnue", "false", "--chess-movetime-ms", "10", "--chess-max-moves", "2", "--n-rollouts", "2",
@@ -201,7 +207,7 @@ def test_harness_script_subcommands_at_toy_scale(tmp_path, capsys):
     H.main(["maze-eval", "--max-steps", "3", "--generation-bsize", "8", "--max-input-length", "160", "--max-output-length", "6"])
     lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
     tags = [next(iter(l)) for l in lines]
-    assert tags.count("eval") >= 10 and tags.count("data_collection") >= 7 and "gen_data" in tags and "data_collection" in tags and "maze_eval" in tags and "train" in tags
+    assert tags.count("eval") >= 13 and tags.count("data_collection") >= 10 and "gen_data" in tags and "data_collection" in tags and "maze_eval" in tags and "train" in tags
     me = next(l["maze_eval"] for l in lines if "maze_eval" in l)
     assert me["n"] == 26 and 0.0 <= me["move_accuracy"] <= 100.0
 

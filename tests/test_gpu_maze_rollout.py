@@ -254,7 +254,8 @@ def test_maze_ppo_records_and_device_ppo_data_equal_the_host_chain_path():
         assert bool(h["done"][c]) == bool(lst[-1].done)
     assert len(n_act_lens) >= 3                                    # actions of 1 .. 5 tokens (early newline, forced newline after max_new ids)
     # ---- device PPO data == host-array form on the same chains
-    pol = GPT2F32({kk: v + 0.02 * torch.randn(v.shape, generator=g) * v.abs().mean().clamp_min(1e-3) for kk, v in sd.items()}, cfg.n_head, device=dev)
+    sd2 = {kk: v + 0.02 * torch.randn(v.shape, generator=g) * v.abs().mean().clamp_min(1e-3) for kk, v in sd.items()}
+    pol = GPT2F32(sd2, cfg.n_head, device=dev)
     init = GPT2F32(sd, cfg.n_head, device=dev)
     vh = LinearHeadF32(dict(kernel=torch.randn(d, 1, generator=g) * 0.05, bias=torch.tensor([0.2])), dev)
     inf = GPT2PPOInference(pol, vh, tok.pad_token_id, initial_policy=init)
@@ -270,4 +271,33 @@ def test_maze_ppo_records_and_device_ppo_data_equal_the_host_chain_path():
     np.testing.assert_allclose(got.old_returns, host.old_returns, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(got.old_advantages, host.old_advantages, rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(kls.cpu().numpy(), kls_h, rtol=1e-5, atol=5e-6)
+    # ---- a partial export (the last episode batch of a round: the first n envs only) is the prefix of the full one
+    part = eng.ppo_records(12)
+    assert part.n_chains == 12 and part.n == int((h["chain"] < 12).sum())
+    assert (part.tokens.cpu().numpy() == h["tokens"][:part.n]).all() and (part.done.cpu().numpy() == h["done"][:12]).all()
+    # ---- one data-collection round (text_env_eval + ppo_dataset_loader of the online script): 52 rollouts = one full batch + 12 envs of a second
+    seeds = iter(range(100, 1000))
+    ds2, kls2, summ = eng.ppo_rollouts(inf, 52, seeds, None, max_length=max_length, bsize=64, temperature=1.0, sample_seed=8, use_graph=True, **kw)
+    sta = ds2.should_take_action
+    assert ds2.input_ids.shape[1] == max_length and kls2.numel() == int(sta.sum().item())
+    assert 52 * 1 <= ds2.input_ids.shape[0] <= 52 * 8 and abs(ds2.input_ids.shape[0] - 52 * float(summ["length"]["mean"])) < 1e-3
+    adv = ds2.old_advantages[sta.bool()].double()
+    assert abs(float(adv.mean())) < 1e-4 and abs(float(adv.var(unbiased=False)) - 1.0) < 1e-3       # whitened once over the whole round
+    assert summ["reward"]["min"] >= -8 * 4 and 0.0 <= summ["done"]["mean"] <= 1.0
+    # ---- the trained weights back into the engine in place (+ the observation prefix cache recomputed) == an engine built from them
+    eng.load_params(pol.p)
+    fresh = MazeRolloutEngine(GPT2Engine(cfg, sd2, dev), tok, env, B, max_new_tokens=4, eos_token_id=tok.eos_token_id, value_engine=vb, q1_head=head,
+                              q2_head=None, beta=1.0)
+    recs = []
+    for e in (eng, fresh):
+        e.run_episode([5 * i + 1 for i in range(B)], None, temperature=1.0, sample_seed=3, episode=0, use_graph=True, sync_every=0)
+        torch.cuda.synchronize()
+        recs.append({k2: e.traj[k2].cpu().numpy().copy() for k2 in ("gen", "gen_len", "action", "reward", "n_turns")})
+    live = np.arange(recs[0]["gen"].shape[1])[None, :] < recs[0]["n_turns"][:, None]                      # (slots past an episode's end keep older episodes' ids)
+    for k2 in ("n_turns", "gen_len", "action", "reward"):
+        assert (np.where(live, recs[0][k2], 0) == np.where(live, recs[1][k2], 0)).all() if k2 != "n_turns" else (recs[0][k2] == recs[1][k2]).all(), k2
+    tokm = live[:, :, None] & (np.arange(recs[0]["gen"].shape[2])[None, None, :] < recs[0]["gen_len"][:, :, None])
+    assert (np.where(tokm, recs[0]["gen"], 0) == np.where(tokm, recs[1]["gen"], 0)).all() and tokm.sum() > 3 * B
+    fresh.close()
+    eng.close()
     eng.close()
