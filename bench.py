@@ -452,6 +452,37 @@ def run_rl_reduce(dev, chains=(4096, 65536), L=96, budget_bytes=640 << 20, iters
                      "command: profiles/r05_rl_reduce_kernel_stats.csv")
 
 
+def run_maze_rollout(dev, batches=(8, 1024), max_steps=20, max_new=12, reps=3):
+    """configs[0]'s environment on the device loop (informational leg, rank 0): the fully observed Maze (`double_t_maze`,
+    `describe_observation_give_position`, llm_rl_scripts/maze/bc/fully_observed_bc.py:230-283) with a random-init GPT-2-small policy and the byte-level
+    stand-in tokenizer, `MazeRolloutEngine.run_episode` under per-turn hipGraph replay with the prompt-prefix cache: env-steps/s at configs[0]'s batch of 8
+    and at the metric's 1024 envs, and one online-PPO data round (`ppo_rollouts`: episodes -> PPO data in HBM) at 1024."""
+    import torch
+    from lmrl_gym_amd import datasets as DS
+    from lmrl_gym_amd.envs import maze as M
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine
+    from lmrl_gym_amd.maze_rollout import MazeRolloutEngine
+    tok = DS.ByteTokenizer()
+    eng = GPT2Engine.random_init(GPT2Config.gpt2_small(), seed=0, device=dev)
+    out = {"workload": f"double_t_maze, describe_observation_give_position, last_k=1, max_steps={max_steps}, max_new_tokens={max_new}, GPT-2-small random init, "
+                       "byte tokenizer (prompt rows 129-141 tokens), temperature 1", "unit": "env-steps/s", "by_batch": {}}
+    for B in batches:
+        env = M.setup_maze_env("double_t_maze", "describe_observation_give_position", "standard_reward", last_k=1, max_steps=max_steps)
+        r = MazeRolloutEngine(eng, tok, env, B, max_new_tokens=max_new, eos_token_id=tok.eos_token_id, max_input_length=160)
+        r.run_episode(list(range(B)), sample_seed=1, use_graph=True, sync_every=0)           # capture + warm-up
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        steps = torch.zeros((), dtype=torch.int64, device=dev)
+        for e in range(reps):
+            r.run_episode(list(range(100 + e * B, 100 + (e + 1) * B)), sample_seed=1, episode=e + 1, use_graph=True, sync_every=0)
+            steps += r.traj["n_turns"].sum()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out["by_batch"][str(B)] = {"value": round(int(steps.item()) / dt, 1), "ms_per_episode": round(dt * 1e3 / reps, 2), "episodes": reps,
+                                   "ms_per_lockstep_turn": round(dt * 1e3 / reps / r.T, 3)}
+        r.close()
+        del r
+    return out
+
+
 def run_ppo_iteration(matmul, B, vocab, dev, rank, world, use_dist, backend, iters=2, train_steps=4, train_bsize=32, max_length=1024, host_path=True):
     """One ONLINE PPO iteration end to end (llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py:301-353 + LLM_RL/algorithms/ppo/train.py):
     B-env lock-step rollouts on the device engine -> PPO data (policy + initial-policy log-probs, values, KL-shaped rewards, GAE, whitening) ->
@@ -678,6 +709,7 @@ def main():
     ap.add_argument("--no-train-step", action="store_true", help="skip the `train_step` leg of the default line (ILQL M3 step, fp32 and bf16-matmul)")
     ap.add_argument("--no-rl-reduce", action="store_true", help="skip the `rl_reduce` leg of the default line (GAE / reward-to-go / whitening kernels at 4096 and 65536 chains)")
     ap.add_argument("--mode-rl-reduce-only", action="store_true", help="run ONLY the `rl_reduce` leg and print it as a JSON line (profiling: tools/prof_rl_reduce.sh)")
+    ap.add_argument("--no-maze", action="store_true", help="skip the `maze_rollout` leg of the default line (configs[0]'s Maze env on the device loop, 8 and 1024 envs)")
     ap.add_argument("--no-ppo-iteration", action="store_true", help="skip the `ppo_iteration` leg of the default line (rollouts -> PPO data -> 4 train steps -> weights pushed back, device-resident and host path)")
     ap.add_argument("--ppo-iters", type=int, default=2, help="`ppo_iteration` leg: timed iterations per arithmetic mode (after one warm-up iteration)")
     ap.add_argument("--ppo-train-steps", type=int, default=4, help="`ppo_iteration` leg: gradient steps per iteration (32 sequences each)")
@@ -1019,6 +1051,12 @@ def main():
             out["train_step"] = ts
     if rank == 0 and not args.no_rl_reduce:
         out["rl_reduce"] = run_rl_reduce(dev)
+    if rank == 0 and world == 1 and not args.no_maze and S == 1 and args.graph:
+        try:
+            out["maze_rollout"] = run_maze_rollout(dev)
+        except Exception as e:              # informational leg: never fails the line
+            out["maze_rollout"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        gc.collect(); torch.cuda.empty_cache()
     if not args.no_ppo_iteration and S == 1 and args.graph:
         # the online loop end to end (rollouts -> PPO data -> train steps -> weights back into the engine), device-resident, in the headline's bf16
         # mode and in the reference's default fp32 arithmetic; the host-array path of the same iteration beside the bf16 one
@@ -1045,7 +1083,7 @@ def main():
             for b_ in (4096, 8192):
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--batch", str(b_), "--steps", "4", "--warmup", "1", "--no-train-step", "--no-fp32-mode",
-                                        "--no-cpu-baseline", "--no-batch-sweep", "--no-ppo-iteration", "--no-rl-reduce"], capture_output=True, text=True, timeout=240)
+                                        "--no-cpu-baseline", "--no-batch-sweep", "--no-ppo-iteration", "--no-rl-reduce", "--no-maze"], capture_output=True, text=True, timeout=240)
                     d4 = json.loads(r.stdout.strip().splitlines()[-1])
                     out["larger_batches"][str(b_)] = {"value": d4["value"], "unit": d4["unit"], "ms_per_step": d4["ms_per_step"], "steps": d4["steps"],
                                                       "roofline_frac": d4["roofline"]["frac"], "roofline_kernel": d4["roofline"]["kernel"]}

@@ -10,7 +10,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   #  this summary; the roofline kernel's and every other class's is.  Up to 3 attempts per pass.)
   for attempt in 1 2 3; do
     rm -rf /tmp/pmc_$c
-    timeout 420 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "attention_|lm_head|gemm_bf16_glds|embed_|final_ln|sample_reduce|tok_|wordle_" --output-format csv -d /tmp/pmc_$c -- python /root/repo/bench.py --graph 0 --steps 1 --warmup 1 --no-cpu-baseline --no-train-step --no-fp32-mode --no-ppo-iteration --no-rl-reduce > /dev/null 2>&1 && break
+    timeout 420 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "attention_|lm_head|gemm_bf16_glds|embed_|final_ln|sample_reduce|tok_|wordle_" --output-format csv -d /tmp/pmc_$c -- python /root/repo/bench.py --graph 0 --steps 1 --warmup 1 --no-cpu-baseline --no-train-step --no-fp32-mode --no-ppo-iteration --no-rl-reduce --no-maze > /dev/null 2>&1 && break
     echo "pass $c attempt $attempt failed/timeout"
   done
 done
@@ -32,7 +32,7 @@ for c, key in (("FETCH_SIZE", "fetch_kb_avg"), ("WRITE_SIZE", "write_kb_avg")):
 import sys
 sys.path.insert(0, "/root/repo")
 import bench
-out["__meta__"] = {"csrc_digest": bench.csrc_digest(), "command": "bench.py --graph 0 --steps 1 --warmup 1 --no-cpu-baseline --no-train-step --no-fp32-mode --no-ppo-iteration --no-rl-reduce"}
+out["__meta__"] = {"csrc_digest": bench.csrc_digest(), "command": "bench.py --graph 0 --steps 1 --warmup 1 --no-cpu-baseline --no-train-step --no-fp32-mode --no-ppo-iteration --no-rl-reduce --no-maze"}
 json.dump(out, open("/root/repo/gpurun_out/pmc_fetch_write.json", "w"), indent=1)
 out.pop("__meta__")
 for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("fetch_kb_avg", 0) * kv[1].get("launches", 0))[:10]:

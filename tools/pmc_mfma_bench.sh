@@ -5,7 +5,7 @@
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_mfma_b
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_mfma_b -- python $REPO/bench.py --graph 0 --steps 1 --warmup 1 --no-cpu-baseline --no-train-step --no-fp32-mode --no-ppo-iteration --no-rl-reduce > /tmp/pmc_mfma_b.log 2>&1 || echo "pmc pass failed/timeout"
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_mfma_b -- python $REPO/bench.py --graph 0 --steps 1 --warmup 1 --no-cpu-baseline --no-train-step --no-fp32-mode --no-ppo-iteration --no-rl-reduce --no-maze > /tmp/pmc_mfma_b.log 2>&1 || echo "pmc pass failed/timeout"
 f=$(find /tmp/pmc_mfma_b -name "*counter_collection.csv" | head -1)
 python - $f <<'PY' > $REPO/gpurun_out/pmc_mfma_bench.txt
 import csv, sys, collections

@@ -5,7 +5,7 @@ TAG=${1:-prof}; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $REPO/bench.py --graph 0 --steps 2 --warmup 1 --no-cpu-baseline --no-train-step --no-fp32-mode --no-ppo-iteration --no-rl-reduce "$@" > /tmp/prof_$TAG.out 2>&1 || echo "rocprofv3 failed/timeout"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $REPO/bench.py --graph 0 --steps 2 --warmup 1 --no-cpu-baseline --no-train-step --no-fp32-mode --no-ppo-iteration --no-rl-reduce --no-maze "$@" > /tmp/prof_$TAG.out 2>&1 || echo "rocprofv3 failed/timeout"
 F=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
 mkdir -p $REPO/gpurun_out
 cp "$F" $REPO/gpurun_out/${TAG}_kernel_stats.csv
