@@ -2,6 +2,7 @@
 
     python scripts/harness.py ilql     --train-data d.jsonl [--eval-data e.jsonl]    # llm_rl_scripts/wordle/ilql/train_ilql_gpt2.py
     python scripts/harness.py ppo      [--bc-data d.jsonl]                           # llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py
+    python scripts/harness.py ppo      --env maze --device-rollouts 1                # llm_rl_scripts/maze/ppo/train_ppo_online.py (device-resident loop)
     python scripts/harness.py bc-eval                                                # llm_rl_scripts/wordle/bc/eval_bc_gpt2.py
     python scripts/harness.py maze-eval                                              # llm_rl_scripts/maze/bc/fully_observed_bc.py (eval part)
     python scripts/harness.py gen-data --n-data 1000 --out d.jsonl                   # llm_rl_scripts/wordle/misc/data_gen.py
@@ -423,7 +424,7 @@ def build_parser() -> argparse.ArgumentParser:
     pp.add_argument("--maze-reward-function", default="standard_reward"); pp.add_argument("--maze-last-k", type=int, default=1)
     pp.add_argument("--maze-max-steps", type=int, default=100)
     pp.add_argument("--resident", type=int, default=1, help="with --device-rollouts 1: 1 (default) = the device-resident iteration, 0 = device rollouts feeding the host-array PPO data path")
-    pp.add_argument("--trim-batches", type=int, default=0, help="device-resident loop: train on batches cut to the round's longest episode (multiple of 64) instead of "
+    pp.add_argument("--trim-batches", type=int, default=1, help="device-resident loop: train on batches cut to the round's longest episode (multiple of 64) instead of "
                                                                   "max_input_length + max_output_length columns — same loss and gradients, fewer padded rows")
     pp.add_argument("--chess-engine", default=os.environ.get("CHESS_ENGINE_PATH"), help="UCI engine binary (the reference: stockfish/stockfish-ubuntu-20.04-x86-64-avx2)")
     pp.add_argument("--chess-use-nnue", default="true", help="'false' for a binary built without the net file")
