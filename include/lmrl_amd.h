@@ -432,7 +432,8 @@ void lmrl_gemm_set_variant(int v);
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     float temperature;      /* <= 0: greedy (do_sample=False) */
-    int32_t top_k;          /* <= 0: off; needs logits_out_d */
+    int32_t top_k;          /* <= 0: off; needs logits_out_d (1 .. 64 on the policy-only Philox path: scratch of the rare rows the fused
+                             * candidate selection hands back; otherwise the logits are materialised there) */
     uint64_t seed;          /* Philox key */
     uint32_t step;          /* counter word: one per sampled token position */
     float steer_strength;   /* added to logit[steer_tok_d[row]] (synthetic workloads only; 0 = off) */
@@ -455,12 +456,16 @@ typedef struct {
 void lmrl_threefry2x32(const uint32_t key[2], const uint32_t ctr[2], uint32_t out[2]);
 int lmrl_jax_random_bits_host(const uint32_t key[2], uint32_t n, uint32_t i0, uint32_t count, uint32_t *out);
 
-/* workspace of lmrl_lm_head_sample (per-tile partials).  One workspace per concurrent stream. */
+/* workspace of lmrl_lm_head_sample (per-(row, tile) partials or top-k candidate records + the flagged-row list).  One workspace per concurrent stream. */
 size_t lmrl_sample_ws_bytes(int m, int vocab_padded);
 /* hidden_d bf16 [m][d] . wte_d bf16 [vocab_padded][d]^T -> token_d[m] (+ logprob_d[m] under the sampling
  * distribution).  Optional ILQL operands: q_hidden{1,2}_d bf16 [m][d] (= relu(dense1(h)) of each Q head),
  * q_w{1,2}_d bf16 [vocab_padded][d] (dense2 kernels, [out][in]), q_b{1,2}_d f32 [vocab_padded].
- * logits_out_d (optional f32 [m][vocab_padded]) receives the combined (untempered) logits. */
+ * logits_out_d (optional f32 [m][vocab_padded]) receives the combined (untempered) logits — except on the fused top-k path
+ * (policy-only operands, LMRL_RNG_PHILOX, temperature > 0, 0 < top_k <= 64: `FlaxTopKLogitsWarper` of train_ppo_gpt2.py:98-99, 218-227 inside
+ * the LM-head epilogue): there the epilogue keeps the 8 largest logits of every (row, 128-column tile), a reduce kernel finds the row's k-th
+ * largest among them, checks that no tile can hide a larger one, applies top_p and draws; logits_out_d is written only for the 128-row blocks of
+ * rows that fail the check (they are re-done from materialised logits: same tokens as the materialised path in every case). */
 int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_hidden1_d, const void *q_w1_d,
                         const float *q_b1_d, const void *q_hidden2_d, const void *q_w2_d, const float *q_b2_d, int m,
                         int d_model, int vocab, int vocab_padded, const lmrl_sample_params *p, const int32_t *steer_tok_d,

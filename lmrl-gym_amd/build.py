@@ -33,7 +33,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
 # per-source flags.  flash_attn_train: the sweeps interleave MFMAs with per-element VALU work on their results; with the default AGPR form of the
 # MFMA destination the compiler copies every score through v_accvgpr_read/_write (a quarter of the loop's VALU instructions) — keep C/D in VGPRs
 EXTRA_FLAGS = {"flash_attn_train": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "gpt2": ["-mllvm", "-amdgpu-mfma-vgpr-form"] + os.environ.get("LMRL_GPT2_EXTRA", "").split(),
-               "train_bf16": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+               "train_bf16": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "sampler": os.environ.get("LMRL_SAMPLER_EXTRA", "").split()}
 
 
 def _hipcc() -> str:

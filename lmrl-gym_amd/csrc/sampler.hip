@@ -57,6 +57,13 @@ __device__ __forceinline__ float gumbel_jax(uint32_t k0, uint32_t k1, uint32_t i
     return -logf(-logf(jax_uniform_open(jax_random_word(k0, k1, i, n))));
 }
 
+// order-preserving unsigned key of a float (radix selects, candidate lists): a < b  <=>  key(a) < key(b); key 0 is below every float's key
+__device__ __forceinline__ uint32_t f32_order_key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_order_key(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+
 struct SampleParams {
     float inv_temperature;   // 1/T ; greedy when `greedy` != 0
     float temperature;       // T (LMRL_RNG_JAX divides, as the TemperatureLogitsWarper does)
@@ -180,7 +187,7 @@ __device__ __forceinline__ void lm_sample_epilogue(f32x4 (&z)[kLmBN / kLmWN / 16
 #pragma unroll
             for (int w = 0; w < WN - 1; w++)            // fixed order: column quarters 1, 2, 3
                 merge_partial<WANT_LP>(rp, slot[w * 5 + 0], slot[w * 5 + 1], slot[w * 5 + 2], slot[w * 5 + 3], __float_as_int(slot[w * 5 + 4]));
-            if (m < M) {
+            if (m < M && partials) {        // (partials == NULL: the fused top-k path's re-run of a flagged row block, which only wants logits_out)
                 float *p = partials + ((size_t)m * tiles_n + tile_n) * kPartialFloats;
                 p[0] = rp.pmax; p[1] = rp.psum; p[2] = rp.best; p[3] = __int_as_float(rp.best_col); p[4] = rp.best_z; p[5] = 0.f;
             }
@@ -188,7 +195,192 @@ __device__ __forceinline__ void lm_sample_epilogue(f32x4 (&z)[kLmBN / kLmWN / 16
     }
 }
 
-template <int NOPS, bool WANT_LP, bool JAX = false>
+// ---- fused top-k (round 5): candidate epilogue.  With top_k <= kTopCMaxK the sampled token can only be one of the row's k largest logits, and a
+// 128-column tile holds eight or more of those only in rare rows: the epilogue keeps, per (row, tile), the tile's kTopC = 8 largest logits (order keys)
+// with their columns — 64 bytes instead of 512 bytes of logits, and no noise at all: the Gumbel draw happens in the reduce kernel, for the k kept
+// columns only — and topc_reduce_sample_kernel selects the row's k-th largest among the 8 x tiles candidates.  That selection is EXACT whenever no
+// tile's 8th candidate reaches the k-th largest (everything a tile did not report lies at or below its 8th candidate); a row where one does is
+// flagged and re-done from materialised logits (lmrl_lm_head_sample: re-run of the flagged 128-row blocks + the register-row kernel on the listed
+// rows), so the result is the materialised path's, bit for bit, in every case.
+// Selection in two steps, on VALUES only (v_max_u32 / v_min_u32 networks on order keys, no column payload): (1) the tile's 8th largest key per row —
+// per lane a 19-comparator sort of its 8 keys, bitonic top-8 merges across the 4 lanes and (through LDS) the 4 waves that share a row; (2) every lane
+// appends its keys at or above that threshold to the row's record through an LDS slot counter.  Ties beyond 8 slots are dropped: they equal the
+// record's minimum, which the reduce kernel's check treats as "possibly hidden".
+constexpr int kTopC = 8, kCandWords = 2 * kTopC, kTopCMaxK = 64, kFbHeader = 16, kFbMaxBlocks = 64;      // record: 8 x {key, tile-local column} = 64 B
+constexpr int kTopcCompactCap = 1024;             // reduce kernel: candidates at or above the pre-filter floor kept in LDS per row (more: the row is handed back)
+constexpr int kTopcLdsBytes = (kLmBM * (kLmWN - 1) * kTopC + 2 * kLmBM) * 4;                                // merge lists [BM][WN-1][8] (re-used as the records) + thresholds + slot counters
+
+#define LMRL_CE(x, y) do { const uint32_t mx_ = (x) > (y) ? (x) : (y); (y) = (x) > (y) ? (y) : (x); (x) = mx_; } while (0)
+__device__ __forceinline__ void sort8_desc(uint32_t (&a)[8]) {          // Batcher's odd-even merge sort, 19 comparators
+    LMRL_CE(a[0], a[1]); LMRL_CE(a[2], a[3]); LMRL_CE(a[4], a[5]); LMRL_CE(a[6], a[7]);
+    LMRL_CE(a[0], a[2]); LMRL_CE(a[1], a[3]); LMRL_CE(a[4], a[6]); LMRL_CE(a[5], a[7]);
+    LMRL_CE(a[1], a[2]); LMRL_CE(a[5], a[6]);
+    LMRL_CE(a[0], a[4]); LMRL_CE(a[1], a[5]); LMRL_CE(a[2], a[6]); LMRL_CE(a[3], a[7]);
+    LMRL_CE(a[2], a[4]); LMRL_CE(a[3], a[5]);
+    LMRL_CE(a[1], a[2]); LMRL_CE(a[3], a[4]); LMRL_CE(a[5], a[6]);
+}
+// a bitonic sequence -> sorted descending (x, y sorted descending: max(x[i], y[7 - i]) is a bitonic sequence holding the 8 largest of the union)
+__device__ __forceinline__ void bitonic8_desc(uint32_t (&a)[8]) {
+    LMRL_CE(a[0], a[4]); LMRL_CE(a[1], a[5]); LMRL_CE(a[2], a[6]); LMRL_CE(a[3], a[7]);
+    LMRL_CE(a[0], a[2]); LMRL_CE(a[1], a[3]); LMRL_CE(a[4], a[6]); LMRL_CE(a[5], a[7]);
+    LMRL_CE(a[0], a[1]); LMRL_CE(a[2], a[3]); LMRL_CE(a[4], a[5]); LMRL_CE(a[6], a[7]);
+}
+#undef LMRL_CE
+
+// cand: [M][tiles_n][8] {key, column} (a row's records are contiguous: the reduce kernel reads them coalesced; a tile scatters 128 x 64 B).  `lds`: kTopcLdsBytes.
+template <bool RAW>
+__device__ __forceinline__ void lm_topc_epilogue(f32x4 (&z)[kLmBN / kLmWN / 16][kLmBM / kLmWM / 16], const int (&st_pre)[kLmBM / kLmWM / 16], int m0, int n0,
+                                                 int tile_n, int tiles_n, int M, uint32_t *__restrict__ cand, const SampleParams &sp, char *lds) {
+    constexpr int BM = kLmBM, BN = kLmBN, WM = kLmWM, WN = kLmWN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    static_assert(FN * 4 == 8 && FM == 4 && WN == 4, "lm_topc_epilogue: 8 keys per lane and row, 4 rows per lane, 4 column-quarter waves");
+    uint32_t *lists = reinterpret_cast<uint32_t *>(lds);                // [BM][WN - 1][8]
+    uint32_t *thr_l = lists + BM * (WN - 1) * kTopC;                    // [BM] {threshold key, slot range ends of the 4 column quarters (4 bytes)}
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lq = lane >> 4;
+    if (!RAW) __syncthreads();                         // one-tile kernel: the LDS ring doubles as the hand-off area — every wave is done reading it
+    uint32_t keys[FM][8], my8[8];                      // my8 (column-quarter 0 waves): the list of row j = lq, the row this lane merges across waves below
+#pragma unroll
+    for (int e = 0; e < 8; e++) my8[e] = 0u;
+    // keys of this lane's 4 x 8 logits.  Wave-uniform fast path: no padding column in the tile and no steered column of any of the wave's rows in it
+    bool st_here = false;
+#pragma unroll
+    for (int j = 0; j < FM; j++) st_here |= (unsigned)(st_pre[j] - n0) < (unsigned)BN;
+    if (n0 + BN > sp.vocab || __ballot(st_here) != 0ull) {
+#pragma unroll
+        for (int j = 0; j < FM; j++)
+#pragma unroll
+            for (int i = 0; i < FN; i++) {
+                const int n = n0 + wn * TN + i * 16 + lq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float v = z[i][j][r];
+                    if (n + r == st_pre[j]) v += sp.steer_strength;
+                    keys[j][i * 4 + r] = (n + r) < sp.vocab ? f32_order_key(v) : 0u;      // padding columns: the empty key
+                }
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < FM; j++)
+#pragma unroll
+            for (int i = 0; i < FN; i++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) keys[j][i * 4 + r] = f32_order_key(z[i][j][r]);
+    }
+#pragma unroll
+    for (int j = 0; j < FM; j++) {
+        uint32_t a[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) a[e] = keys[j][e];
+        sort8_desc(a);
+        // the 4 lane groups (lq) that hold the same row, all VALU: v_permlane16_swap(v, v) hands BOTH lanes of a row pair {even row's v, odd row's v},
+        // v_permlane32_swap(v, v) {lower half's v, upper half's v} — the two lists of a merge arrive in the same registers on both sides, no selects
+        {
+            uint32_t x[8], y[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(a[e], a[e], false, false);
+                x[e] = sw[0]; y[e] = sw[1];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) a[e] = x[e] > y[7 - e] ? x[e] : y[7 - e];
+            bitonic8_desc(a);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(a[e], a[e], false, false);
+                x[e] = sw[0]; y[e] = sw[1];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) a[e] = x[e] > y[7 - e] ? x[e] : y[7 - e];
+            bitonic8_desc(a);
+        }
+        if (wn > 0) {
+            if (lq == 0) {
+                typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                u32x4_t *dst = reinterpret_cast<u32x4_t *>(lists + ((size_t)(wm * TM + j * 16 + lr) * (WN - 1) + (wn - 1)) * kTopC);
+                dst[0] = u32x4_t{a[0], a[1], a[2], a[3]};
+                dst[1] = u32x4_t{a[4], a[5], a[6], a[7]};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) my8[e] = lq == j ? a[e] : my8[e];
+        }
+        __builtin_amdgcn_sched_barrier(0);             // one row at a time: interleaving the four rows' networks only adds register pressure
+    }
+    lm_barrier<RAW>();
+    unsigned long long *cand64 = reinterpret_cast<unsigned long long *>(cand);
+    if (wn == 0) {                                     // lane group lq merges row j = lq of this wave's 64 rows with the three other column quarters
+        const int row = wm * TM + lq * 16 + lr;
+        uint32_t lw[WN][8];                            // the four quarters' lists (quarter 0: this wave's own)
+#pragma unroll
+        for (int e = 0; e < 8; e++) lw[0][e] = my8[e];
+#pragma unroll
+        for (int w = 1; w < WN; w++) {
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t *src = reinterpret_cast<const u32x4_t *>(lists + ((size_t)row * (WN - 1) + (w - 1)) * kTopC);
+            const u32x4_t b0 = src[0], b1 = src[1];
+            lw[w][0] = b0[0]; lw[w][1] = b0[1]; lw[w][2] = b0[2]; lw[w][3] = b0[3]; lw[w][4] = b1[0]; lw[w][5] = b1[1]; lw[w][6] = b1[2]; lw[w][7] = b1[3];
+#pragma unroll
+            for (int e = 0; e < 8; e++) my8[e] = my8[e] > lw[w][7 - e] ? my8[e] : lw[w][7 - e];
+            bitonic8_desc(my8);
+        }
+        // thr: the tile's 8th largest key of this row (>= 1: an empty key never hits).  Slot ranges instead of a slot counter (LDS return atomics cost this
+        // step 18 us per launch): per column quarter, how many of its keys lie ABOVE thr (at most 7 in all: they get the first slots, in quarter order) and
+        // how many EQUAL it (the slots after those, clipped at 8: a dropped key equals the record's minimum) — each quarter's list holds every key of its
+        // quarter above thr, so the counts are exact
+        const uint32_t thr = my8[7] > 1u ? my8[7] : 1u;
+        uint32_t g[WN], q[WN];
+#pragma unroll
+        for (int w = 0; w < WN; w++) {
+            g[w] = 0; q[w] = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) { g[w] += lw[w][e] > thr ? 1u : 0u; q[w] += lw[w][e] == thr ? 1u : 0u; }
+        }
+        const uint32_t g1 = g[0], g2 = g1 + g[1], g3 = g2 + g[2], gt = g3 + g[3];
+        auto c8 = [](uint32_t x) { return x < 8u ? x : 8u; };
+        const uint32_t e0 = gt, e1 = c8(e0 + q[0]), e2 = c8(e1 + q[1]), e3 = c8(e2 + q[2]), total = c8(e3 + q[3]);
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2_t *>(thr_l + 2 * row) = u32x2_t{thr, (g1 << 4) | (g2 << 8) | (g3 << 12) | (e0 << 16) | (e1 << 20) | (e2 << 24) | (e3 << 28)};
+        if (total < (uint32_t)kTopC && m0 + row < M)   // fewer than 8 real columns (the vocabulary's last tile): empty slots
+            for (uint32_t sl = total; sl < (uint32_t)kTopC; sl++) cand64[((size_t)(m0 + row) * tiles_n + tile_n) * kTopC + sl] = 0ull;
+    }
+    lm_barrier<RAW>();
+#pragma unroll
+    for (int j = 0; j < FM; j++) {
+        const int row = wm * TM + j * 16 + lr;
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t tb = *reinterpret_cast<const u32x2_t *>(thr_l + 2 * row);
+        const uint32_t thr = tb[0];
+        uint32_t hg = 0, he = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { hg |= keys[j][e] > thr ? (1u << e) : 0u; he |= keys[j][e] == thr ? (1u << e) : 0u; }
+        // slots of the 4 lanes that share the row, in lane-group order: both counts through the two swaps (even / odd row of the pair, lower / upper half)
+        const uint32_t c = (uint32_t)__popc(hg) | ((uint32_t)__popc(he) << 8);
+        const auto s16 = __builtin_amdgcn_permlane16_swap(c, c, false, false);
+        const uint32_t pair = s16[0] + s16[1];
+        const auto s32 = __builtin_amdgcn_permlane32_swap(pair, pair, false, false);
+        const uint32_t off = ((lq & 2) ? s32[0] : 0u) + ((lq & 1) ? s16[0] : 0u);
+        uint32_t sg = ((tb[1] >> (4 * wn)) & (wn == 0 ? 0u : 15u)) + (off & 255u), se = ((tb[1] >> (16 + 4 * wn)) & 15u) + (off >> 8);
+        uint32_t hit = hg | he;
+        if (hit && m0 + row < M) {                     // (1 / 16 of the keys: a loop over the set bits, typically one or two trips per wave)
+            unsigned long long *dst = cand64 + ((size_t)(m0 + row) * tiles_n + tile_n) * kTopC;
+            while (hit) {
+                const int e = __ffs((int)hit) - 1;
+                hit &= hit - 1u;
+                uint32_t k = keys[j][0];
+#pragma unroll
+                for (int qq = 1; qq < 8; qq++) k = e == qq ? keys[j][qq] : k;
+                const bool above = (hg >> e) & 1u;
+                const uint32_t slot = above ? sg : se;
+                sg += above ? 1u : 0u; se += above ? 0u : 1u;
+                if (slot < (uint32_t)kTopC) dst[slot] = (unsigned long long)k | ((unsigned long long)(uint32_t)(wn * TN + (e >> 2) * 16 + lq * 4 + (e & 3)) << 32);
+            }
+        }
+    }
+}
+
+// FLAGGED (the fused top-k path's hand-back): grid = the vocabulary's tiles; a workgroup walks the 128-row blocks and computes only those whose flag is set
+template <int NOPS, bool WANT_LP, bool JAX = false, bool TOPC = false, bool FLAGGED = false>
 __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const uint16_t *__restrict__ A0, const uint16_t *__restrict__ W0,
                                                              const uint16_t *__restrict__ A1, const uint16_t *__restrict__ W1,
                                                              const float *__restrict__ bias1,
@@ -197,14 +389,26 @@ __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const
                                                              const int32_t *__restrict__ steer_tok,
                                                              float *__restrict__ partials,   // [M][tiles_n][kPartialFloats]
                                                              float *__restrict__ logits_out, // optional [M][ldo] f32
-                                                             int M, int N, int K, int ldo, SampleParams sp, XcdMap xm) {
+                                                             int M, int N, int K, int ldo, SampleParams sp, XcdMap xm,
+                                                             const int32_t *__restrict__ block_flag,   // optional: run only the 128-row blocks whose flag is set
+                                                             int32_t *__restrict__ fb) {               // TOPC: header of the flagged-row list, cleared here
     constexpr int BM = kLmBM, BN = kLmBN, WM = kLmWM, WN = kLmWN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    static_assert(!TOPC || NOPS == 1, "the candidate epilogue is built for the policy-only head");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = N / BN;
-    int tile_m, tile_n;
-    if (!xcd_tile(xm, blockIdx.x, tile_m, tile_n)) return;   // workgroup-uniform
+    if (TOPC && blockIdx.x == 0 && tid < kFbHeader + kFbMaxBlocks) fb[tid] = 0;     // (the reduce kernel of THIS step fills it, after this kernel)
+    int tile_m = 0, tile_n = (int)blockIdx.x, tm_end = (M + BM - 1) / BM;
+    if (!FLAGGED) {
+        if (!xcd_tile(xm, blockIdx.x, tile_m, tile_n)) return;   // workgroup-uniform
+        tm_end = tile_m + 1;
+    }
+    for (; tile_m < tm_end; tile_m++) {
+    if (FLAGGED) {
+        if (!block_flag[tile_m]) continue;
+        __syncthreads();                               // (the previous block's epilogue is done with the LDS)
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int lr = lane & 15, lq = lane >> 4;
 
@@ -246,7 +450,9 @@ __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const
         const int m = m0 + wm * TM + j * 16 + lr;
         st_pre[j] = (steer_tok && m < M) ? steer_tok[m] : -1;
     }
-    lm_sample_epilogue<NOPS, WANT_LP, JAX, false>(z, qmin, st_pre, m0, n0, tile_n, tiles_n, M, partials, logits_out, ldo, sp, reinterpret_cast<float *>(smem));
+    if (TOPC) lm_topc_epilogue<false>(z, st_pre, m0, n0, tile_n, tiles_n, M, reinterpret_cast<uint32_t *>(partials), sp, smem);
+    else lm_sample_epilogue<NOPS, WANT_LP, JAX, false>(z, qmin, st_pre, m0, n0, tile_n, tiles_n, M, partials, logits_out, ldo, sp, reinterpret_cast<float *>(smem));
+    }
 }
 
 // ---- persistent form of the policy-only LM head (NOPS = 1, Philox / greedy): the first `n_persist` workgroups (two per CU) each walk `rounds` tile ids of
@@ -258,11 +464,12 @@ __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const
 // and measured: 168 us against 138 us for this static form, back to back: the pulls' round trips under a streaming load cost more than the balance buys.)
 // Same arithmetic per tile, same association orders: bit-identical partials to the one-tile kernel (tests/test_gpu_timed_path.py).
 // LDS: 2 x 32 KB ring + 7.7 KB hand-off area = 2 workgroups per CU.
-template <bool WANT_LP>
+template <bool WANT_LP, bool TOPC = false>
 __global__ __launch_bounds__(kLmWM *kLmWN * 64, 4) void lm_head_sample_persist_kernel(const uint16_t *__restrict__ A0, const uint16_t *__restrict__ W0,
                                                                                       const int32_t *__restrict__ steer_tok, float *__restrict__ partials,
                                                                                       float *__restrict__ logits_out, int M, int N, int K, int ldo,
-                                                                                      SampleParams sp, XcdMap xm, int n_persist, int rounds) {
+                                                                                      SampleParams sp, XcdMap xm, int n_persist, int rounds, int32_t *__restrict__ fb) {
+    if (TOPC && blockIdx.x == 0 && threadIdx.x < kFbHeader + kFbMaxBlocks) fb[threadIdx.x] = 0;      // flagged-row list header (filled by this step's reduce kernel)
     constexpr int BM = kLmBM, BN = kLmBN, WM = kLmWM, WN = kLmWN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
     typedef G8Stream<BM, BN, WM, WN> Stream;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -298,7 +505,8 @@ __global__ __launch_bounds__(kLmWM *kLmWN * 64, 4) void lm_head_sample_persist_k
 #pragma unroll
             for (int j = 0; j < FM; j++) z[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         g8_stream_tile<BM, BN, WM, WN>(st, m0, n0, has_next, ntm * BM, ntn * BN, K, smem, z);
-        lm_sample_epilogue<1, WANT_LP, false, true>(z, z, st_pre, m0, n0, this_tile_n, tiles_n, M, partials, logits_out, ldo, sp, xch);
+        if (TOPC) lm_topc_epilogue<true>(z, st_pre, m0, n0, this_tile_n, tiles_n, M, reinterpret_cast<uint32_t *>(partials), sp, reinterpret_cast<char *>(xch));
+        else lm_sample_epilogue<1, WANT_LP, false, true>(z, z, st_pre, m0, n0, this_tile_n, tiles_n, M, partials, logits_out, ldo, sp, xch);
         if (!has_next) break;
         k = nk_; tile_m = ntm; tile_n = ntn;
     }
@@ -344,15 +552,10 @@ __global__ __launch_bounds__(256) void sample_reduce_kernel(const float *__restr
 // Radix select (4 passes of 8 bits over the order-preserving uint key) finds the k-th largest value; tokens with
 // logit >= that value are kept (ties kept, as HF's TopKLogitsWarper `scores < kth` removal rule) and sampled with
 // the same Philox/Gumbel stream as the fused path.
-__device__ __forceinline__ uint32_t f32_order_key(float f) {
-    const uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-__global__ __launch_bounds__(256) void topk_sample_kernel(const float *__restrict__ logits, int ld, int vocab, int top_k, float top_p,
-                                                          const uint8_t *__restrict__ active, int32_t *__restrict__ token,
-                                                          float *__restrict__ logprob, SampleParams sp, int pad_token) {
-    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void topk_sample_row(int m, const float *__restrict__ logits, int ld, int vocab, int top_k, float top_p,
+                                                const uint8_t *__restrict__ active, int32_t *__restrict__ token,
+                                                float *__restrict__ logprob, const SampleParams &sp, int pad_token) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (active && !active[m]) {
         if (tid == 0) { token[m] = pad_token; if (logprob) logprob[m] = 0.f; }
         return;
@@ -497,6 +700,19 @@ __global__ __launch_bounds__(256) void topk_sample_kernel(const float *__restric
     }
 }
 
+// row_list (fused top-k: only the rows its reduce kernel flagged): a small grid walks the list
+__global__ __launch_bounds__(256) void topk_sample_kernel(const float *__restrict__ logits, int ld, int vocab, int top_k, float top_p,
+                                                          const uint8_t *__restrict__ active, int32_t *__restrict__ token,
+                                                          float *__restrict__ logprob, SampleParams sp, int pad_token,
+                                                          const int32_t *__restrict__ row_list, const int32_t *__restrict__ row_count) {
+    if (!row_list) { topk_sample_row((int)blockIdx.x, logits, ld, vocab, top_k, top_p, active, token, logprob, sp, pad_token); return; }
+    const int cnt = *row_count;
+    for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
+        topk_sample_row(row_list[i], logits, ld, vocab, top_k, top_p, active, token, logprob, sp, pad_token);
+        __syncthreads();
+    }
+}
+
 // ---- the same selection with the ROW IN REGISTERS (round 5): topk_sample_kernel above walks its 200 KB row up to ten times (4 radix passes for
 // top-k, the row maximum + 4 mass passes for top-p, the sampling pass) with 4-byte loads — 410 us per sampled token at 1024 x 50 257, 15 ms of a
 // 62 ms warper episode.  Here one 1024-thread workgroup reads the row ONCE (16-byte loads, NV float4 per thread: chunk c = tid + 1024 j holds columns
@@ -542,10 +758,10 @@ __device__ __forceinline__ void wave_scan_from_top(const T *h, T target, T base,
 }
 
 template <int NV>
-__global__ __launch_bounds__(1024) void topk_sample_reg_kernel(const float *__restrict__ logits, int ld, int vocab, int top_k, float top_p,
-                                                               const uint8_t *__restrict__ active, int32_t *__restrict__ token,
-                                                               float *__restrict__ logprob, SampleParams sp, int pad_token) {
-    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void topk_sample_reg_row(int m, const float *__restrict__ logits, int ld, int vocab, int top_k, float top_p,
+                                                    const uint8_t *__restrict__ active, int32_t *__restrict__ token,
+                                                    float *__restrict__ logprob, const SampleParams &sp, int pad_token) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (active && !active[m]) {
         if (tid == 0) { token[m] = pad_token; if (logprob) logprob[m] = 0.f; }
         return;
@@ -568,7 +784,7 @@ __global__ __launch_bounds__(1024) void topk_sample_reg_kernel(const float *__re
         v[j] = u32x4_t{f32_order_key(x[0]), f32_order_key(x[1]), f32_order_key(x[2]), f32_order_key(x[3])};
         asm volatile("" : "+v"(v[j]));                      // the keys are the stored form: do not re-derive them from a second copy
     }
-    auto key_to_f32 = [](uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); };
+    auto key_to_f32 = [](uint32_t k) { return f32_from_order_key(k); };
     // every element this thread holds: n its column, raw its logit (columns >= vocab skipped)
     // (a scheduling barrier per chunk: without it the 13 - 16 unrolled chunk bodies are interleaved and the kernel spills 135 VGPRs at 128)
 #define LMRL_TK_FOREACH(BODY)                                                                                  \
@@ -728,24 +944,233 @@ __global__ __launch_bounds__(1024) void topk_sample_reg_kernel(const float *__re
     }
 }
 
-int g_sampler_variant = 0;      // tools / tests only: 1 = the round-2 strided-row warper kernel also where the register-row kernel applies
+template <int NV>
+__global__ __launch_bounds__(1024) void topk_sample_reg_kernel(const float *__restrict__ logits, int ld, int vocab, int top_k, float top_p,
+                                                               const uint8_t *__restrict__ active, int32_t *__restrict__ token,
+                                                               float *__restrict__ logprob, SampleParams sp, int pad_token,
+                                                               const int32_t *__restrict__ row_list, const int32_t *__restrict__ row_count) {
+    if (!row_list) { topk_sample_reg_row<NV>((int)blockIdx.x, logits, ld, vocab, top_k, top_p, active, token, logprob, sp, pad_token); return; }
+    const int cnt = *row_count;
+    for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
+        topk_sample_reg_row<NV>(row_list[i], logits, ld, vocab, top_k, top_p, active, token, logprob, sp, pad_token);
+        __syncthreads();
+    }
+}
+
+// ---- fused top-k, second half: the row's k-th largest logit among the 8 x tiles candidates of lm_topc_epilogue, the exactness check, (top-p,) the draw.
+// ONE WAVE per row (four rows per workgroup, lane l holds the records of tiles l, l + 64, ...: NT of them), so that the eight to twelve histogram passes
+// need no workgroup barrier — a wave's LDS operations execute in order; each pass is a few predicated LDS atomics and one 64-lane suffix scan.  (The
+// 256-threads-per-row form of the same passes took 20 us per launch against 5 us for the plain sampler's merge kernel.)  Same keys, same radix selects,
+// same 32.32 fixed-point mass histograms, same Philox word per column and same arg-max tie rule as topk_sample_kernel on the materialised row: whenever
+// the check passes the kept set is the row's true top-k (ties kept) and the sampled token is identical.  A row that fails the check is appended to the
+// list in `fb` ({count, -, ..., block flags [kFbMaxBlocks], rows [M]}) and left to the materialised path.
+template <int NT>
+__global__ __launch_bounds__(256) void topc_reduce_sample_kernel(const uint32_t *__restrict__ cand, int M, int tiles_n, int vocab, int top_k, float top_p,
+                                                                 const uint8_t *__restrict__ active, int32_t *__restrict__ token,
+                                                                 float *__restrict__ logprob, SampleParams sp, int pad_token, int32_t *__restrict__ fb) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= M) return;
+    if (active && !active[m]) {
+        if (lane == 0) { token[m] = pad_token; if (logprob) logprob[m] = 0.f; }
+        return;
+    }
+    __shared__ uint32_t hist_s[4][256];
+    __shared__ unsigned long long mhist_s[4][256];
+    __shared__ uint32_t ck_s[4][kTopcCompactCap], cn_s[4][kTopcCompactCap];
+    uint32_t *hist = hist_s[wave], *ck = ck_s[wave], *cn = cn_s[wave];
+    unsigned long long *mhist = mhist_s[wave];
+#define LMRL_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+    uint32_t key[NT][kTopC], colw[NT][2];
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+        const int t = lane + 64 * q;
+        if (t < tiles_n) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(cand + ((size_t)m * tiles_n + t) * kCandWords);  // 64-byte records {key, column} x 8
+            const uint4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+            key[q][0] = r0.x; key[q][1] = r0.z; key[q][2] = r1.x; key[q][3] = r1.z; key[q][4] = r2.x; key[q][5] = r2.z; key[q][6] = r3.x; key[q][7] = r3.z;
+            colw[q][0] = (r0.y & 255u) | ((r0.w & 255u) << 8) | ((r1.y & 255u) << 16) | ((r1.w & 255u) << 24);
+            colw[q][1] = (r2.y & 255u) | ((r2.w & 255u) << 8) | ((r3.y & 255u) << 16) | ((r3.w & 255u) << 24);
+        } else {
+#pragma unroll
+            for (int e = 0; e < kTopC; e++) key[q][e] = 0u;
+            colw[q][0] = colw[q][1] = 0u;
+        }
+    }
+    // every candidate this lane holds: k_ its key (0 = empty slot), n its column
+#define LMRL_TC_FOREACH(BODY)                                                                                  \
+    _Pragma("unroll") for (int q_ = 0; q_ < NT; q_++) {                                                        \
+        _Pragma("unroll") for (int e_ = 0; e_ < kTopC; e_++) {                                                 \
+            const uint32_t k_ = key[q_][e_];                                                                   \
+            if (k_ != 0u) { const int n = (lane + 64 * q_) * kLmBN + (int)((colw[q_][e_ >> 2] >> (8 * (e_ & 3))) & 255u); (void)n; BODY } \
+        }                                                                                                      \
+    }
+    // top-k threshold: radix select over the candidates, pre-filtered by the k-th largest per-lane maximum (k <= 64 lanes: a lower bound of the k-th
+    // largest candidate — those are k distinct candidates at or above it)
+    uint32_t tkey = 0;
+    LMRL_TC_FOREACH({ tkey = k_ > tkey ? k_ : tkey; })
+    uint32_t floor_key = 0;
+    {
+        uint32_t fp = 0, frem = (uint32_t)top_k;
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 24 - 8 * pass;
+#pragma unroll
+            for (int i = 0; i < 4; i++) hist[4 * lane + i] = 0;
+            LMRL_WAVE_SYNC();
+            if (tkey != 0u && (pass == 0 || (tkey >> (shift + 8)) == (fp >> (shift + 8)))) atomicAdd(&hist[(tkey >> shift) & 255u], 1u);
+            LMRL_WAVE_SYNC();
+            uint32_t b, above;
+            wave_scan_from_top<uint32_t>(hist, frem, 0u, lane, b, above);
+            fp |= b << shift; frem -= above;
+            LMRL_WAVE_SYNC();
+        }
+        floor_key = fp;
+    }
+    // the candidates at or above the floor (a few multiples of k out of 8 x tiles), compacted into LDS: every later pass walks ceil(count / 64) of them per
+    // lane instead of 8 x NT predicated slots (most of which hold a candidate in SOME lane, so none could be skipped)
+    uint32_t mine_n = 0;
+    LMRL_TC_FOREACH({ mine_n += k_ >= floor_key ? 1u : 0u; })
+    uint32_t incl = mine_n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += o;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    // exactness, part 1: a tile whose record is full reports its smallest key as the bound of what it did not report
+    uint32_t hidden_max = 0;
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+        uint32_t mn = key[q][0];
+#pragma unroll
+        for (int e = 1; e < kTopC; e++) mn = key[q][e] < mn ? key[q][e] : mn;
+        hidden_max = mn > hidden_max ? mn : hidden_max;        // (a record with an empty slot hides nothing: mn = 0)
+    }
+    {
+        uint32_t at = incl - mine_n;
+        if (total <= (uint32_t)kTopcCompactCap)
+            LMRL_TC_FOREACH({ if (k_ >= floor_key) { ck[at] = k_; cn[at] = (uint32_t)n; at++; } })
+    }
+#undef LMRL_TC_FOREACH
+    LMRL_WAVE_SYNC();
+    uint32_t prefix = 0, remaining = (uint32_t)top_k;
+    if (total <= (uint32_t)kTopcCompactCap) {
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 24 - 8 * pass;
+#pragma unroll
+            for (int i = 0; i < 4; i++) hist[4 * lane + i] = 0;
+            LMRL_WAVE_SYNC();
+            for (uint32_t i = lane; i < total; i += 64) {
+                const uint32_t k_ = ck[i];
+                if (pass == 0 || (k_ >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(k_ >> shift) & 255u], 1u);
+            }
+            LMRL_WAVE_SYNC();
+            uint32_t b, above;
+            wave_scan_from_top<uint32_t>(hist, remaining, 0u, lane, b, above);
+            prefix |= b << shift; remaining -= above;
+            LMRL_WAVE_SYNC();
+        }
+    }
+    uint32_t thr_key = prefix;                           // key of the k-th largest candidate
+    // exactness, part 2: a full record whose smallest key reaches the threshold may hide a logit at or above it (or: too many candidates to compact —
+    // degenerate rows, e.g. all logits equal)
+    if (__ballot(hidden_max >= thr_key && hidden_max != 0u) != 0ull || total > (uint32_t)kTopcCompactCap) {
+        if (lane == 0) {
+            const int idx = atomicAdd(&fb[0], 1);
+            fb[kFbHeader + kFbMaxBlocks + idx] = m;
+            fb[kFbHeader + m / kLmBM] = 1;
+        }
+        return;
+    }
+    if (top_p > 0.f && top_p < 1.f) {
+        float rmax = -INFINITY;
+        for (uint32_t i = lane; i < total; i += 64) { const uint32_t k_ = ck[i]; if (k_ >= thr_key) rmax = fmaxf(rmax, f32_from_order_key(k_)); }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o));
+        uint32_t pprefix = 0;
+        unsigned long long tgt = 0, sabove = 0;
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 24 - 8 * pass;
+#pragma unroll
+            for (int i = 0; i < 4; i++) mhist[4 * lane + i] = 0ull;
+            LMRL_WAVE_SYNC();
+            for (uint32_t i = lane; i < total; i += 64) {
+                const uint32_t k_ = ck[i];
+                if (k_ >= thr_key && (pass == 0 || (k_ >> (shift + 8)) == (pprefix >> (shift + 8)))) {
+                    const float e = __expf((f32_from_order_key(k_) - rmax) * sp.inv_temperature);
+                    atomicAdd(&mhist[(k_ >> shift) & 255u], (unsigned long long)((double)e * 4294967296.0));
+                }
+            }
+            LMRL_WAVE_SYNC();
+            if (pass == 0) {
+                unsigned long long tot = mhist[4 * lane] + mhist[4 * lane + 1] + mhist[4 * lane + 2] + mhist[4 * lane + 3];
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
+                tgt = (unsigned long long)((double)top_p * (double)tot);
+                if (tgt == 0) tgt = 1;
+            }
+            uint32_t b;
+            unsigned long long ab;
+            wave_scan_from_top<unsigned long long>(mhist, tgt, pass == 0 ? 0ull : sabove, lane, b, ab);
+            sabove = ab; pprefix |= b << shift;
+            LMRL_WAVE_SYNC();
+        }
+        if (pprefix > thr_key) thr_key = pprefix;
+    }
+#undef LMRL_WAVE_SYNC
+    const uint32_t epoch = sp.epoch ? *sp.epoch : 0u;
+    float pmax = -INFINITY, psum = 0.f, best = -INFINITY, best_z = 0.f;
+    int best_col = 0x7fffffff;
+    for (uint32_t i = lane; i < total; i += 64) {
+        const uint32_t k_ = ck[i];
+        if (k_ >= thr_key) {
+            const int n = (int)cn[i];
+            uint32_t rnd[4];
+            philox4x32_10((uint32_t)m, (uint32_t)(n >> 2), sp.step, epoch, sp.seed_lo, sp.seed_hi, rnd);
+            const float vv = f32_from_order_key(k_) * sp.inv_temperature;
+            const uint32_t rw = (n & 3) == 0 ? rnd[0] : ((n & 3) == 1 ? rnd[1] : ((n & 3) == 2 ? rnd[2] : rnd[3]));
+            const float sc = vv + gumbel_from_bits(rw);
+            if (sc > best || (sc == best && n < best_col)) { best = sc; best_col = n; best_z = vv; }
+            const float nm = fmaxf(pmax, vv);
+            psum = psum * ((pmax == -INFINITY) ? 0.f : __expf(pmax - nm)) + __expf(vv - nm);
+            pmax = nm;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float om = __shfl_xor(pmax, o), os = __shfl_xor(psum, o), ob = __shfl_xor(best, o), oz = __shfl_xor(best_z, o);
+        const int oc = __shfl_xor(best_col, o);
+        const float nm = fmaxf(pmax, om);
+        const float e1 = (pmax == -INFINITY) ? 0.f : __expf(pmax - nm), e2 = (om == -INFINITY) ? 0.f : __expf(om - nm);
+        psum = psum * e1 + os * e2; pmax = nm;
+        if (ob > best || (ob == best && oc < best_col)) { best = ob; best_col = oc; best_z = oz; }
+    }
+    if (lane == 0) {
+        token[m] = best_col;
+        if (logprob) logprob[m] = best_z - (pmax + __logf(psum));
+    }
+}
+
+int g_sampler_variant = 0;      // tools / tests only: 1 = materialised logits + the round-2 strided-row warper kernel, 2 = materialised logits + the register-row kernel (no fused top-k)
 
 // top-k / top-p sampling from materialised logits: the register-row kernel where the row fits (vocab <= 16 float4 x 1024 threads, 16-byte aligned rows)
 static void launch_topk_sample(const float *logits_d, int ld, int m, int vocab, int top_k, float top_p, const uint8_t *active_d, int32_t *token_d,
-                               float *logprob_d, const SampleParams &sp, int pad_token, hipStream_t s) {
+                               float *logprob_d, const SampleParams &sp, int pad_token, hipStream_t s, const int32_t *row_list = nullptr,
+                               const int32_t *row_count = nullptr) {
+    const int grid = row_list ? (m < 32 ? m : 32) : m;
     const bool reg_ok = g_sampler_variant != 1 && ld % 4 == 0 && (uintptr_t)logits_d % 16 == 0 && vocab <= 16 * 4096 && vocab > 4096;
     if (reg_ok) {
         const int nv = (ld / 4 + 1023) / 1024;      // float4 chunks per thread
-#define LMRL_TK_LAUNCH(NV_) hipLaunchKernelGGL(topk_sample_reg_kernel<NV_>, dim3(m), dim3(1024), 0, s, logits_d, ld, vocab, top_k, top_p, active_d, token_d, logprob_d, sp, pad_token)
+#define LMRL_TK_LAUNCH(NV_) hipLaunchKernelGGL(topk_sample_reg_kernel<NV_>, dim3(grid), dim3(1024), 0, s, logits_d, ld, vocab, top_k, top_p, active_d, token_d, logprob_d, sp, pad_token, row_list, row_count)
         if (nv <= 4) LMRL_TK_LAUNCH(4);
         else if (nv <= 8) LMRL_TK_LAUNCH(8);
         else if (nv <= 13) LMRL_TK_LAUNCH(13);
         else if (nv <= 16) LMRL_TK_LAUNCH(16);
-        else hipLaunchKernelGGL(topk_sample_kernel, dim3(m), dim3(256), 0, s, logits_d, ld, vocab, top_k, top_p, active_d, token_d, logprob_d, sp, pad_token);
+        else hipLaunchKernelGGL(topk_sample_kernel, dim3(grid), dim3(256), 0, s, logits_d, ld, vocab, top_k, top_p, active_d, token_d, logprob_d, sp, pad_token, row_list, row_count);
 #undef LMRL_TK_LAUNCH
         return;
     }
-    hipLaunchKernelGGL(topk_sample_kernel, dim3(m), dim3(256), 0, s, logits_d, ld, vocab, top_k, top_p, active_d, token_d, logprob_d, sp, pad_token);
+    hipLaunchKernelGGL(topk_sample_kernel, dim3(grid), dim3(256), 0, s, logits_d, ld, vocab, top_k, top_p, active_d, token_d, logprob_d, sp, pad_token, row_list, row_count);
 }
 
 // ---- generic generation bookkeeping (any tokenizer / env): append the sampled token of every live sequence, stop a sequence
@@ -791,8 +1216,10 @@ int lmrl_gen_accept(const int32_t *sampled_d, uint8_t *active_d, int32_t *out_to
     return LMRL_OK;
 }
 
+// per-(row, tile) partials of the plain sampler (6 floats) or candidate records of the fused top-k path (10 words), then that path's flagged-row list
 size_t lmrl_sample_ws_bytes(int m, int vocab_padded) {
-    return (size_t)m * (size_t)(vocab_padded / kLmBN) * kPartialFloats * sizeof(float);
+    static_assert(kCandWords >= kPartialFloats, "the candidate records are the larger form");
+    return (size_t)m * (size_t)(vocab_padded / kLmBN) * kCandWords * sizeof(uint32_t) + (size_t)(kFbHeader + kFbMaxBlocks + m) * sizeof(int32_t);
 }
 
 int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_hidden1_d, const void *q_w1_d,
@@ -817,6 +1244,8 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     const size_t shmem = (size_t)kLmStages * (kLmBM + kLmBN) * 128;
     const int nops = (q_hidden1_d && q_w1_d) ? ((q_hidden2_d && q_w2_d) ? 3 : 2) : 1;
     float *partials = (float *)ws_d;
+    bool topc = false;
+    int32_t *fb = nullptr;
     const uint16_t *A0 = (const uint16_t *)hidden_d, *W0 = (const uint16_t *)wte_d;
     const uint16_t *A1 = (const uint16_t *)q_hidden1_d, *W1 = (const uint16_t *)q_w1_d;
     const uint16_t *A2 = (const uint16_t *)q_hidden2_d, *W2 = (const uint16_t *)q_w2_d;
@@ -824,15 +1253,23 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     ProfScope ps(PROF_LM_HEAD_SAMPLE, s, 2.0 * (double)m * (double)vocab_padded * (double)d_model * nops);
 #define LMRL_LM_LAUNCH(NOPS_, LP_, JAX_)                                                                                                    \
     hipLaunchKernelGGL((lm_head_sample_kernel<NOPS_, LP_, JAX_>), dim3(tiles), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, \
-                       q_b2_d, steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm)
+                       q_b2_d, steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm, (const int32_t *)nullptr, (int32_t *)nullptr)
     const bool lp = logprob_d != nullptr;      // the log-sum-exp (one exp per logit) is computed only when the log-prob is wanted
+    // fused top-k (policy-only head, Philox stream, 0 < top_k <= 64): candidate epilogue + reduce, no logits in HBM; `logits_out_d` stays the scratch of
+    // the rare rows the exactness check hands back to the materialised path.  g_sampler_variant 1 / 2 (tools, tests): always materialise.
+    const int tiles_n = vocab_padded / kLmBN, tiles_m = (m + kLmBM - 1) / kLmBM;
+    topc = nops == 1 && sp.rng == LMRL_RNG_PHILOX && !sp.greedy && p->top_k > 0 && p->top_k <= kTopCMaxK && p->top_k < vocab && tiles_n <= 512 &&
+           tiles_m <= kFbMaxBlocks && logits_out_d && g_sampler_variant == 0;
+    fb = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(ws_d) + (size_t)m * tiles_n * kCandWords * sizeof(uint32_t));
     // policy-only sampling on the Philox / greedy path: the persistent kernel (ring running ahead across tiles); needs K / 64 even and enough tiles
     // to give every one of the 512 resident workgroups at least two.  g_gemm_variant 301 (tools) forces the one-tile-per-workgroup kernel for the A/B.
     const bool persist = nops == 1 && !(sp.rng == LMRL_RNG_JAX && !sp.greedy) && (d_model / 64) % 2 == 0 && d_model >= 128 && tiles >= 1024 &&
                          g_gemm_variant != 301;
     if (persist) {
         const int grid = 512;                                          // 2 workgroups per CU x 256 CUs (a multiple of 8: XCD affinity preserved)
-        const size_t shp = shmem + (size_t)kLmWM * (kLmBM / kLmWM) * (kLmWN - 1) * 5 * sizeof(float);
+        const size_t shp_plain = shmem + (size_t)kLmWM * (kLmBM / kLmWM) * (kLmWN - 1) * 5 * sizeof(float);
+        const size_t shp = topc ? shmem + (size_t)kTopcLdsBytes : shp_plain, shp_max = shmem + (size_t)kTopcLdsBytes;
+        static_assert((size_t)kTopcLdsBytes >= (size_t)kLmWM * (kLmBM / kLmWM) * (kLmWN - 1) * 5 * sizeof(float), "the opt-in below is sized by the candidate form");
         // the dynamic-LDS opt-in is a PER-DEVICE function attribute: one bit per device ordinal, set on the first launch there (the eager warm-up
         // episode, i.e. before any graph capture on that device); atomic: ranks / lanes may arrive from several host threads
         static std::atomic<unsigned long long> attr_set{0ull};
@@ -840,15 +1277,22 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
         LMRL_CHECK_HIP(hipGetDevice(&dev_id));
         const unsigned long long dev_bit = 1ull << (dev_id & 63);
         if (dev_id >= 64 || !(attr_set.load(std::memory_order_acquire) & dev_bit)) {
-            LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp));
-            LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp));
+            LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp_max));
+            LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp_max));
+            LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp_max));
             attr_set.fetch_or(dev_bit, std::memory_order_release);
         }
         const int rounds = tiles / grid, n_tail = tiles - rounds * grid;          // ids: xcd_grid(xm) (a multiple of 8), a few of them surplus
-        if (lp) hipLaunchKernelGGL((lm_head_sample_persist_kernel<true>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,
-                                   logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm, grid, rounds);
-        else hipLaunchKernelGGL((lm_head_sample_persist_kernel<false>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,
-                                logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm, grid, rounds);
+        if (topc) hipLaunchKernelGGL((lm_head_sample_persist_kernel<false, true>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,
+                                     (float *)nullptr, m, vocab_padded, d_model, vocab_padded, sp, xm, grid, rounds, fb);
+        else if (lp) hipLaunchKernelGGL((lm_head_sample_persist_kernel<true, false>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,
+                                        logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm, grid, rounds, (int32_t *)nullptr);
+        else hipLaunchKernelGGL((lm_head_sample_persist_kernel<false, false>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,
+                                logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm, grid, rounds, (int32_t *)nullptr);
+    }
+    else if (topc) {
+        hipLaunchKernelGGL((lm_head_sample_kernel<1, false, false, true>), dim3(tiles), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
+                           steer_tok_d, partials, (float *)nullptr, m, vocab_padded, d_model, vocab_padded, sp, xm, (const int32_t *)nullptr, fb);
     }
     else if (sp.rng == LMRL_RNG_JAX && !sp.greedy) {       // parity mode: always with the log-sum-exp variant (one instantiation per operand count)
         if (nops == 1) LMRL_LM_LAUNCH(1, true, true); else if (nops == 2) LMRL_LM_LAUNCH(2, true, true); else LMRL_LM_LAUNCH(3, true, true);
@@ -860,7 +1304,23 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     }
     LMRL_CHECK_LAUNCH();
     const bool nucleus = p->top_p > 0.f && p->top_p < 1.f && !sp.greedy;
-    if ((p->top_k > 0 && p->top_k < vocab) || nucleus) {
+    if (topc) {
+        const int tiles_n = vocab_padded / kLmBN;
+#define LMRL_TCR_LAUNCH(NT_) hipLaunchKernelGGL(topc_reduce_sample_kernel<NT_>, dim3((m + 3) / 4), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(ws_d), m, \
+                                               tiles_n, vocab, p->top_k, p->top_p, active_d, token_d, logprob_d, sp, p->pad_token, fb)
+        if (tiles_n <= 64) LMRL_TCR_LAUNCH(1); else if (tiles_n <= 128) LMRL_TCR_LAUNCH(2); else if (tiles_n <= 256) LMRL_TCR_LAUNCH(4); else LMRL_TCR_LAUNCH(8);
+#undef LMRL_TCR_LAUNCH
+        LMRL_CHECK_LAUNCH();
+        // the rows the check flagged (a tile holding eight or more of the row's top k: ~1e-8 of rows for spread-out logits): their 128-row blocks' logits
+        // from the SAME tile kernel (bit-identical logits, steer included; greedy flag: no noise is drawn), then the materialised selection on those rows
+        SampleParams sg = sp;
+        sg.greedy = 1;
+        hipLaunchKernelGGL((lm_head_sample_kernel<1, false, false, false, true>), dim3(tiles_n), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
+                           steer_tok_d, (float *)nullptr, logits_out_d, m, vocab_padded, d_model, vocab_padded, sg, xm, (const int32_t *)(fb + kFbHeader), (int32_t *)nullptr);
+        LMRL_CHECK_LAUNCH();
+        launch_topk_sample(logits_out_d, vocab_padded, m, vocab, p->top_k, p->top_p, active_d, token_d, logprob_d, sp, p->pad_token, s, fb + kFbHeader + kFbMaxBlocks, fb);
+    }
+    else if ((p->top_k > 0 && p->top_k < vocab) || nucleus) {
         LMRL_REQUIRE(logits_out_d, "lmrl_lm_head_sample: top_k / top_p sampling needs logits_out_d (materialised logits)");
         launch_topk_sample(logits_out_d, vocab_padded, m, vocab, p->top_k, p->top_p, active_d, token_d, logprob_d, sp, p->pad_token, s);
     } else {

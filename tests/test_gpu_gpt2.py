@@ -360,6 +360,70 @@ def test_register_row_warper_kernel_equals_the_strided_one(dev, V, ld):
         assert (outs[0][0][active.cpu().numpy() == 0] == 7).all() and (outs[0][0] < V).all()
 
 
+@pytest.mark.parametrize("B,vocab,d", [(1024, 50257, 128), (200, 9000, 128), (130, 300, 128)])
+def test_fused_topk_candidate_path_equals_the_materialised_one(dev, B, vocab, d):
+    """Round 5 (north_star: "fused token-sampling (top-k ...)"): with 0 < top_k <= 64 the LM-head epilogue keeps 8 candidates per (row, 128-column tile)
+    and the reduce kernel selects, checks exactness, applies top-p and draws — no logits in HBM (`lm_topc_epilogue`, `topc_reduce_sample_kernel`).
+    Against the materialised path (`lmrl_sampler_set_variant(2)`: logits written, register-row kernel; pinned to the HF warper semantics above): every
+    sampled token identical, log-probabilities to fp32 rounding — persistent kernel (1024 x GPT-2 vocabulary) and one-tile kernel, top-k alone and with
+    top-p, k = 1 .. 64, steered rows, inactive rows; and with a vocabulary whose large logits CLUSTER in a few tiles, so that the exactness check hands
+    rows back to the materialised path (the flagged-row list is read back: it was used)."""
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, SampleParams, init_hf_style_state_dict
+    L = _lib.lib()
+    cfg = GPT2Config(1, d // 64, d, 256, vocab, 32)
+    g = torch.Generator().manual_seed(vocab)
+    hid = _bf(torch.randn(B, d, generator=g)).to(dev)
+    steer = torch.randint(0, vocab, (B,), generator=g).to(torch.int32); steer[::3] = -1
+    active = torch.ones(B, dtype=torch.uint8); active[5::17] = 0
+    steer, active = steer.to(dev), active.to(dev)
+    tiles_n = -(-vocab // 128)
+    for clustered in (False, True):
+        sd = init_hf_style_state_dict(cfg, seed=3)
+        w = sd["wte.weight"] * 20
+        if clustered:                # twelve columns inside one tile carry most rows' largest logits (a shared direction, different gains)
+            u = torch.randn(d, generator=g)
+            c0 = 128 * (tiles_n // 2) + 7 if tiles_n > 2 else 3
+            for i in range(12):
+                w[c0 + 5 * i] = u * (0.6 + 0.03 * i) + w[c0 + 5 * i] * 0.2
+            hid_c = _bf(hid.cpu().float() + u[None] * 0.8).to(dev)
+        sd["wte.weight"] = w.to(torch.bfloat16).float()
+        eng = GPT2Engine(cfg, sd, dev)
+        ses = eng.session(B, 8)
+        h = hid_c if clustered else hid
+        lo = torch.zeros(B, cfg.vocab_padded, device=dev)
+        flagged = 0
+        for temp, top_k, top_p, strength in [(1.0, 40, 0.0, 0.0), (0.8, 50, 0.9, 0.0), (1.0, 1, 0.0, 0.0), (1.3, 64, 0.0, 6.0), (1.0, 5, 0.6, 0.0), (0.7, 20, 0.95, 3.0)]:
+            if top_k >= vocab:
+                continue
+            outs = []
+            for variant in (2, 0):
+                L.lmrl_sampler_set_variant(variant)
+                try:
+                    lo.fill_(float("nan"))
+                    sp = SampleParams(temp, top_k, 0xBEEF, 5, strength, 0.0, 9, None, top_p, 0)
+                    tok, lp = ses.sample(sp, hidden=h, steer_tok=steer, active=active, logits_out=lo)
+                    torch.cuda.synchronize()
+                    outs.append((tok.cpu().numpy().copy(), lp.cpu().numpy().copy()))
+                    if variant == 0:
+                        fb = ses.sample_ws[B * (cfg.vocab_padded // 128) * 64:].view(torch.int32)
+                        n_fb = int(fb[0].item())
+                        flagged += n_fb
+                        rows = fb[16 + 64: 16 + 64 + n_fb].cpu().numpy()
+                        assert len(set(rows.tolist())) == n_fb and all(fb[16 + r // 128].item() == 1 for r in rows)
+                        touched = ~torch.isnan(lo[:, 0]).cpu().numpy()               # logits exist only for the flagged rows' 128-row blocks
+                        assert touched.sum() <= 128 * max(n_fb, 0) and all(touched[r] for r in rows)
+                finally:
+                    L.lmrl_sampler_set_variant(0)
+            assert np.array_equal(outs[0][0], outs[1][0]), (clustered, temp, top_k, top_p)
+            np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=2e-5)
+            assert (outs[0][0][active.cpu().numpy() == 0] == 9).all()
+        if clustered and tiles_n > 2:
+            assert flagged > 0, "the clustered vocabulary was meant to exercise the hand-back to the materialised path"
+        elif not clustered and vocab > 5000:
+            assert flagged <= 2
+
+
 def test_sampler_steer_and_ilql_perturbation(dev):
     """logits = pi + beta * min(q1, q2)  (value_rl_base/gpt2/generation.py:112-117), greedy."""
     from lmrl_gym_amd.gpt2 import SampleParams
