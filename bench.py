@@ -452,6 +452,32 @@ def run_rl_reduce(dev, chains=(4096, 65536), L=96, budget_bytes=640 << 20, iters
                      "command: profiles/r05_rl_reduce_kernel_stats.csv")
 
 
+def run_warpers(vocab, guesses, seeds_all, B, dev, reps=3):
+    """The headline workload with the task scripts' logits warpers (policy_top_k / policy_top_p, train_ppo_gpt2.py:98-99, 218-227) — informational leg,
+    rank 0: top_k = 40 and top_k = 40 + top_p = 0.95 run on the FUSED top-k path (8 candidates per (row, tile) kept in the LM-head epilogue, no logits
+    in HBM: csrc/sampler.hip lm_topc_epilogue / topc_reduce_sample_kernel); hipGraph replays, env-steps/s."""
+    import torch
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine
+    from lmrl_gym_amd.rollout import WordleRolloutEngine
+    eng = GPT2Engine.random_init(GPT2Config.gpt2_small(), seed=0, device=dev)
+    out = {"unit": "env-steps/s", "note": "same engine / envs / steer as `value`; top_k <= 64: fused candidate epilogue (tokens identical to the materialised "
+                                          "path: tests/test_gpu_gpt2.py::test_fused_topk_candidate_path_equals_the_materialised_one)"}
+    for name, kw in (("top_k=40", dict(top_k=40)), ("top_k=40,top_p=0.95", dict(top_k=40, top_p=0.95))):
+        ro = WordleRolloutEngine(eng, vocab, B, max_new_tokens=6, bad_word_reward=-10.0)
+        ro.capture_episode(temperature=1.0, sample_seed=7, steer_strength=30.0, scripted=True, **kw)
+        ro.replay_episode(seeds_all[0, :B], guesses[0]); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps = torch.zeros((), dtype=torch.int64, device=dev)
+        for i in range(reps):
+            ro.replay_episode(seeds_all[1 + i, :B], guesses[1 + i])
+            steps += ro.traj["n_steps"].sum()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out[name] = {"value": round(int(steps.item()) / dt, 1), "ms_per_step": round(dt * 1e3 / reps, 2), "steps": reps}
+        ro.close()
+        del ro
+    return out
+
+
 def run_maze_rollout(dev, batches=(8, 1024), max_steps=20, max_new=12, reps=3):
     """configs[0]'s environment on the device loop (informational leg, rank 0): the fully observed Maze (`double_t_maze`,
     `describe_observation_give_position`, llm_rl_scripts/maze/bc/fully_observed_bc.py:230-283) with a random-init GPT-2-small policy and the byte-level
@@ -709,7 +735,7 @@ def main():
     ap.add_argument("--no-train-step", action="store_true", help="skip the `train_step` leg of the default line (ILQL M3 step, fp32 and bf16-matmul)")
     ap.add_argument("--no-rl-reduce", action="store_true", help="skip the `rl_reduce` leg of the default line (GAE / reward-to-go / whitening kernels at 4096 and 65536 chains)")
     ap.add_argument("--mode-rl-reduce-only", action="store_true", help="run ONLY the `rl_reduce` leg and print it as a JSON line (profiling: tools/prof_rl_reduce.sh)")
-    ap.add_argument("--no-maze", action="store_true", help="skip the `maze_rollout` leg of the default line (configs[0]'s Maze env on the device loop, 8 and 1024 envs)")
+    ap.add_argument("--no-maze", action="store_true", help="skip the `maze_rollout` and `sampling_warpers` legs of the default line (configs[0]'s Maze env on the device loop at 8 and 1024 envs; the headline workload with top-k / top-p)")
     ap.add_argument("--no-ppo-iteration", action="store_true", help="skip the `ppo_iteration` leg of the default line (rollouts -> PPO data -> 4 train steps -> weights pushed back, device-resident and host path)")
     ap.add_argument("--ppo-iters", type=int, default=2, help="`ppo_iteration` leg: timed iterations per arithmetic mode (after one warm-up iteration)")
     ap.add_argument("--ppo-train-steps", type=int, default=4, help="`ppo_iteration` leg: gradient steps per iteration (32 sequences each)")
@@ -1051,6 +1077,12 @@ def main():
             out["train_step"] = ts
     if rank == 0 and not args.no_rl_reduce:
         out["rl_reduce"] = run_rl_reduce(dev)
+    if rank == 0 and world == 1 and not args.no_maze and S == 1 and args.graph and n_eps >= 4:
+        try:
+            out["sampling_warpers"] = run_warpers(vocab, guesses, seeds_all, B, dev)
+        except Exception as e:              # informational leg: never fails the line
+            out["sampling_warpers"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        gc.collect(); torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_maze and S == 1 and args.graph:
         try:
             out["maze_rollout"] = run_maze_rollout(dev)
