@@ -378,10 +378,14 @@ def test_fused_topk_candidate_path_equals_the_materialised_one(dev, B, vocab, d)
     active = torch.ones(B, dtype=torch.uint8); active[5::17] = 0
     steer, active = steer.to(dev), active.to(dev)
     tiles_n = -(-vocab // 128)
-    for clustered in (False, True):
+    for clustered in (False, True, "ties"):
         sd = init_hf_style_state_dict(cfg, seed=3)
         w = sd["wte.weight"] * 20
-        if clustered:                # twelve columns inside one tile carry most rows' largest logits (a shared direction, different gains)
+        if clustered == "ties":      # few distinct embedding rows and a coarse grid of hidden values: most logits tie EXACTLY with many others (in and across tiles)
+            base = torch.round(torch.randn(37, d, generator=g) * 2) / 2
+            w = base[torch.randint(0, 37, (vocab,), generator=g)]
+            hid_c = _bf(torch.round(hid.cpu().float() * 2) / 2).to(dev)
+        elif clustered:              # twelve columns inside one tile carry most rows' largest logits (a shared direction, different gains)
             u = torch.randn(d, generator=g)
             c0 = 128 * (tiles_n // 2) + 7 if tiles_n > 2 else 3
             for i in range(12):
@@ -418,9 +422,9 @@ def test_fused_topk_candidate_path_equals_the_materialised_one(dev, B, vocab, d)
             assert np.array_equal(outs[0][0], outs[1][0]), (clustered, temp, top_k, top_p)
             np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=2e-5)
             assert (outs[0][0][active.cpu().numpy() == 0] == 9).all()
-        if clustered and tiles_n > 2:
+        if clustered is True and tiles_n > 2:
             assert flagged > 0, "the clustered vocabulary was meant to exercise the hand-back to the materialised path"
-        elif not clustered and vocab > 5000:
+        elif clustered is False and vocab > 5000:
             assert flagged <= 2
 
 
