@@ -204,11 +204,12 @@ __device__ __forceinline__ void lm_sample_epilogue(f32x4 (&z)[kLmBN / kLmWN / 16
 // rows), so the result is the materialised path's, bit for bit, in every case.
 // Selection in two steps, on VALUES only (v_max_u32 / v_min_u32 networks on order keys, no column payload): (1) the tile's 8th largest key per row —
 // per lane a 19-comparator sort of its 8 keys, bitonic top-8 merges across the 4 lanes and (through LDS) the 4 waves that share a row; (2) every lane
-// appends its keys at or above that threshold to the row's record through an LDS slot counter.  Ties beyond 8 slots are dropped: they equal the
-// record's minimum, which the reduce kernel's check treats as "possibly hidden".
+// stores its keys at or above that threshold into the row's record, at slots the merging lane laid out (keys above the threshold first, in column-quarter
+// order, then the keys equal to it; no slot-counter atomics).  Ties beyond 8 slots are dropped: they equal the record's minimum, which the reduce
+// kernel's check treats as "possibly hidden".
 constexpr int kTopC = 8, kCandWords = 2 * kTopC, kTopCMaxK = 64, kFbHeader = 16, kFbMaxBlocks = 64;      // record: 8 x {key, tile-local column} = 64 B
 constexpr int kTopcCompactCap = 1024;             // reduce kernel: candidates at or above the pre-filter floor kept in LDS per row (more: the row is handed back)
-constexpr int kTopcLdsBytes = (kLmBM * (kLmWN - 1) * kTopC + 2 * kLmBM) * 4;                                // merge lists [BM][WN-1][8] (re-used as the records) + thresholds + slot counters
+constexpr int kTopcLdsBytes = (kLmBM * (kLmWN - 1) * kTopC + 2 * kLmBM) * 4;                                // merge lists [BM][WN-1][8] + {threshold, slot ranges} [BM][2]
 
 #define LMRL_CE(x, y) do { const uint32_t mx_ = (x) > (y) ? (x) : (y); (y) = (x) > (y) ? (y) : (x); (x) = mx_; } while (0)
 __device__ __forceinline__ void sort8_desc(uint32_t (&a)[8]) {          // Batcher's odd-even merge sort, 19 comparators

@@ -195,7 +195,7 @@ def test_harness_script_subcommands_at_toy_scale(tmp_path, capsys):
           "--max-steps", "2", "--max-input-length", "160", "--max-output-length", "6"]
     H.main(mz)
     H.main(mz + ["--device-rollouts", "1", "--resident", "0"])
-    H.main(mz + ["--device-rollouts", "1", "--n-rounds", "2", "--trim-batches", "1", "--bf16-activations", "1"])
+    H.main(mz + ["--device-rollouts", "1", "--n-rounds", "2", "--trim-batches", "1", "--bf16-activations", "1", "--policy-top-k", "40"])      # (fused top-k epilogue)
     sf = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "stockfish")
     if os.path.exists(sf):
         H.main(["ppo", "--env", "chess", "--chess-engine", sf, "--chess-use-nnue", "false", "--chess-movetime-ms", "10", "--chess-max-moves", "2", "--n-rollouts", "2",
