@@ -394,14 +394,27 @@ def run_rl_reduce(dev, chains=(4096, 65536), L=96, budget_bytes=640 << 20, iters
         for _ in range(n_sets):
             sets.append(dict(v=torch.randn(B, L + 1, device=dev), r=torch.randn(B, L, device=dev), s=torch.from_numpy(sta).to(dev),
                              ln=torch.from_numpy(lens).to(dev), adv=torch.empty(B, L, device=dev), ret=torch.empty(B, L, device=dev),
-                             rtg=torch.empty(B, L, device=dev), y=torch.empty(B, L, device=dev), mom=torch.zeros(3, dtype=torch.float64, device=dev)))
+                             rtg=torch.empty(B, L, device=dev), y=torch.empty(B, L, device=dev), mom=torch.zeros(3, dtype=torch.float64, device=dev),
+                             part=torch.zeros(max(Lb.lmrl_gae_moments_partials(B, L), 1), 3, dtype=torch.float64, device=dev)))
         p = lambda x: x.data_ptr()
+        npart = Lb.lmrl_gae_moments_partials(B, L)
+
+        def chain4(d):      # get_advantages_and_returns + whiten as four launches (the round-5 pipeline)
+            _lib.check(Lb.lmrl_gae(p(d["v"]), p(d["r"]), p(d["s"]), p(d["ln"]), p(d["adv"]), p(d["ret"]), B, L, 0.99, 0.95, sp()))
+            _lib.check(Lb.lmrl_whiten_moments(p(d["adv"]), p(d["s"]), p(d["mom"]), n, sp()))
+            _lib.check(Lb.lmrl_whiten_apply(p(d["adv"]), p(d["s"]), p(d["mom"]), p(d["y"]), n, 1, sp()))
+
+        def chain2(d):      # the same as two: the GAE launch leaves the partial moments, the apply launch adds them up itself
+            _lib.check(Lb.lmrl_gae_moments(p(d["v"]), p(d["r"]), p(d["s"]), p(d["ln"]), p(d["adv"]), p(d["ret"]), B, L, 0.99, 0.95, p(d["part"]), sp()))
+            _lib.check(Lb.lmrl_whiten_apply_partials(p(d["adv"]), p(d["s"]), p(d["part"]), npart, p(d["y"]), n, 1, sp()))
         fns = dict(
             gae=(lambda d: _lib.check(Lb.lmrl_gae(p(d["v"]), p(d["r"]), p(d["s"]), p(d["ln"]), p(d["adv"]), p(d["ret"]), B, L, 0.99, 0.95, sp())),
                  used * 9 + B * 8 + n * 8),
             rtg=(lambda d: _lib.check(Lb.lmrl_rtg(p(d["r"]), p(d["s"]), p(d["ln"]), p(d["rtg"]), B, L, 0.99, sp())), used * 5 + B * 4 + n * 4),
             whiten_moments=(lambda d: _lib.check(Lb.lmrl_whiten_moments(p(d["adv"]), p(d["s"]), p(d["mom"]), n, sp())), n * 5),
-            whiten_apply=(lambda d: _lib.check(Lb.lmrl_whiten_apply(p(d["adv"]), p(d["s"]), p(d["mom"]), p(d["y"]), n, 1, sp())), n * 9))
+            whiten_apply=(lambda d: _lib.check(Lb.lmrl_whiten_apply(p(d["adv"]), p(d["s"]), p(d["mom"]), p(d["y"]), n, 1, sp())), n * 9),
+            gae_whiten_4_launches=(chain4, used * 9 + B * 8 + n * 8 + n * 5 + n * 9),
+            gae_whiten_2_launches=(chain2, used * 9 + B * 8 + n * 8 + n * 9))
         res = {}
         for name, (fn, nbytes) in fns.items():
             for d in sets[:4]:
@@ -429,7 +442,8 @@ def run_rl_reduce(dev, chains=(4096, 65536), L=96, budget_bytes=640 << 20, iters
         # HBM traffic per launch from the committed counter passes of this same leg (tools/prof_rl_reduce.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # separate runs; 2 x FETCH + WRITE per the gfx950 correction of the microarch guide) — not measurable from inside the process
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_rl_reduce_pmc.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_rl_reduce_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r06_rl_reduce_pmc.json"))
+                                              else "r05_rl_reduce_pmc.json")))
             pick = {4096: min, 65536: max}.get(B)          # the counter passes ran this leg's default sizes (tools/prof_rl_reduce.sh); other sizes: no counters
             for name, pat in (("gae", "chain_scan_row2_kernel<true"), ("rtg", "chain_scan_row2_kernel<false"), ("whiten_moments", "whiten_moments_kernel"),
                               ("whiten_apply", "whiten_apply_kernel")):
@@ -440,7 +454,15 @@ def run_rl_reduce(dev, chains=(4096, 65536), L=96, budget_bytes=640 << 20, iters
                     res[name]["traffic_source"] = "profiles/r05_rl_reduce_pmc.json (2*FETCH_SIZE + WRITE_SIZE)"
         except Exception:
             pass
-        res["action_tokens_per_s_gae"] = round(float(sta.sum()) / (res["gae"]["avg_launch_us"] * 1e-6), 0)
+        # SURVEY.md §8(d) / BASELINE.md count 20 B per ACTION token for GAE / RTG / whiten; the kernels work on the token-slot layout of PPOData (the
+        # scatter of :635-645 and the index build of :230-243 are part of the launch), so `frac` above prices every slot they read / write —
+        # `frac_per_action_token` is the same launch priced by §8(d)'s figure (the slots that are not action tokens count as overhead there)
+        n_act = float(sta.sum())
+        for name in ("gae", "rtg", "whiten_moments", "whiten_apply"):
+            res[name]["frac_per_action_token"] = round(20.0 * n_act / (res[name]["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            res[name]["action_slot_share_of_bytes"] = round(20.0 * n_act / res[name]["algorithmic_bytes_per_launch"], 3)
+        res["action_tokens"] = int(n_act)
+        res["action_tokens_per_s_gae"] = round(n_act / (res["gae"]["avg_launch_us"] * 1e-6), 0)
         res["buffer_sets"] = n_sets
         out[str(B)] = res
         del sets
@@ -527,8 +549,8 @@ def run_ppo_iteration(matmul, B, vocab, dev, rank, world, use_dist, backend, ite
     from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
     from lmrl_gym_amd.rollout import WordleRolloutEngine, WordleTokenTable
     from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
-    cfg = GPT2Config.gpt2_small(50258)                      # + the added <|pad|> token (train_ppo_gpt2.py:121-122)
-    pad = 50257
+    cfg = GPT2Config.gpt2_small()
+    pad = cfg.vocab                                         # the added <|pad|> token (train_ppo_gpt2.py:124-126): first id after the vocabulary, never sampled
     sd = init_hf_style_state_dict(cfg, seed=0)
     eng = GPT2Engine(cfg, sd, dev)
     table = WordleTokenTable.default_gpt2(pad=pad)

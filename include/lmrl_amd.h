@@ -199,6 +199,17 @@ int lmrl_rtg(const float *rewards_d, const uint8_t *sta_d, const int32_t *len_d,
  * moments_d (3 doubles: sum, sumsq, count) is caller scratch; when `moments_only` != 0 only the local
  * moments are produced (so ranks can all-reduce them) and `lmrl_whiten_apply` finishes the job. */
 int lmrl_whiten_moments(const float *x_d, const uint8_t *mask_d, double *moments_d, size_t n, void *stream);
+/* The rollout-sized chain GAE -> whiten in two launches instead of four: lmrl_gae_moments = lmrl_gae that also leaves per-workgroup partial moments
+ * of the advantages on action slots (partials_d: 3 doubles x lmrl_gae_moments_partials(b, l), 0 = shape not covered: use lmrl_gae +
+ * lmrl_whiten_moments); lmrl_whiten_apply_partials adds the partials in a fixed order in every workgroup and applies (one rank); ranks that
+ * all-reduce the moments call lmrl_whiten_finish (partials -> the 3 moments) + the collective + lmrl_whiten_apply.  Same numbers as the separate
+ * calls up to the fp64 association order of the moments (ppo/base_interface.py:245-293, 609-615). */
+int lmrl_gae_moments_partials(int b, int l);
+int lmrl_gae_moments(const float *values_d, const float *rewards_d, const uint8_t *sta_d, const int32_t *len_d, float *adv_d, float *ret_d, int b, int l,
+                     float gamma, float lam, double *partials_d, void *stream);
+int lmrl_whiten_finish(const double *partials_d, int n_partials, double *moments_d, void *stream);
+int lmrl_whiten_apply_partials(const float *x_d, const uint8_t *mask_d, const double *partials_d, int n_partials, float *y_d, size_t n, int shift_mean,
+                               void *stream);
 int lmrl_whiten_apply(const float *x_d, const uint8_t *mask_d, const double *moments_d, float *y_d, size_t n,
                       int shift_mean, void *stream);
 
@@ -226,7 +237,10 @@ typedef struct {
 } lmrl_ppo_records;
 /* Per trajectory: effective length = min(n_tok, max_len) (max_len <= 0: no truncation; Truncation.RIGHT, :500-512), rows that predict a next
  * token (len - 1) and action tokens (is_action[1:len]), with their exclusive scans.  cnt_d [2n] scratch; off_rows_d / off_act_d [n + 1];
- * meta_d [4] = {rows, action tokens, longest effective length, pad ids found below a length}. */
+ * meta_d [8] = {rows, action tokens, longest effective length, pad ids found below a length, action tokens CUT by max_len, trajectories that
+ * continue a chain but start with an action token, longest chain concatenation (max of pos + len - 1), 0}.  Words 4 and 5 are the two arms of the
+ * reference's 'trajectory truncation error' assert (CombinedTokenTrajectoryChain.from_token_trajectory_chain, :318-327): a caller mirrors it by
+ * refusing the batch when either is non-zero; word 6 is the `lc` lmrl_ppo_shape / lmrl_ppo_unroll need. */
 int lmrl_ppo_count(const lmrl_ppo_records *rec, int max_len, int pad, int32_t *cnt_d, int32_t *off_rows_d, int32_t *off_act_d, int32_t *meta_d,
                    void *stream);
 /* block_sequences(Padding.RIGHT, pad) to width tf + initialize_attn_mask_pos_ids + the compacted list of rows k * tf + t (t < len - 1) with
@@ -245,9 +259,24 @@ int lmrl_ppo_shape(const lmrl_ppo_records *rec, int max_len, int tf, const int32
 /* unroll_arr (:335-343, :635-660): chain rows of advantages / returns [n_chains][lc] back to ds_adv / ds_ret [n][tp - 1] (0 past a length) */
 int lmrl_ppo_unroll(const lmrl_ppo_records *rec, int max_len, int tf, int lc, const float *chain_adv_d, const float *chain_ret_d, int tp, float *ds_adv_d,
                     float *ds_ret_d, void *stream);
+/* The task scripts' length rule on single-trajectory chains (llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py:323-341, same loop in the chess / maze
+ * PPO scripts): while a trajectory has more than three texts (maximal runs of equal is_action flags) and n_tok >= max_len, drop its last two texts,
+ * add (sum of their rewards) * gamma to the reward of the previous action (its last token) and clear `done`; keep[k] = 0 for trajectories left
+ * with fewer than three texts or still >= max_len tokens (the script's two `continue`s).  reward_d [n][cap] is updated IN PLACE (pass a copy of a
+ * rollout engine's record), n_tok_out_d / done_out_d / keep_d [n]; meta_d [2] = {trajectories shortened, trajectories skipped}. */
+int lmrl_ppo_truncate_turns(const uint8_t *is_action_d, const int32_t *n_tok_d, const uint8_t *done_d, int n, int cap, int max_len, double gamma,
+                            float *reward_d, int32_t *n_tok_out_d, uint8_t *done_out_d, uint8_t *keep_d, int32_t *meta_d, void *stream);
+/* idx_d[j] = the j-th index k with flags_d[k] != 0, increasing; count_d[0] = how many (row compaction of a record after lmrl_ppo_truncate_turns:
+ * lmrl_gather_rows_bytes by idx_d); one workgroup */
+int lmrl_compact_flags(const uint8_t *flags_d, int n, int32_t *idx_d, int32_t *count_d, void *stream);
 /* initialize_attn_mask_pos_ids (JaxSeq; call sites base_interface.py:190-195): am = ids != pad, pos = max(cumsum(am) - 1, 0); [b][t].
  * am_next_f32_d (optional) [b][t - 1] = float(am[:, 1:]), the mask ppo_loss_fn multiplies in (base_interface.py:208-214). */
 int lmrl_seq_mask_pos(const int32_t *ids_d, int pad, uint8_t *am_d, int32_t *pos_d, float *am_next_f32_d, int b, int t, void *stream);
+/* The same two arrays for right-padded rows of KNOWN lengths (am[r][i] = i < len[r]): a device-resident PPO dataset hands the train step the masks its
+ * data build used instead of re-deriving them from `ids != pad` (lmrl_gym_amd.algorithms.ppo_device.DevicePPODataset.batch). */
+int lmrl_len_mask_pos(const int32_t *len_d, int b, int t, uint8_t *am_d, int32_t *pos_d, void *stream);
+/* out[i] = in[i] + c (row-list indices re-based to a chunk of the batch; lengths from row counts) */
+int lmrl_add_i32(const int32_t *in_d, int c, int32_t *out_d, int n, void *stream);
 /* rows r = row * t + i (i < t - 1) with sta[row][i] && am[row][i + 1] (am NULL: sta alone), increasing, + tgt = ids[row][i + 1] (tgt NULL: no
  * targets) — the rows of [b * t, d] hidden states whose LM-head outputs a masked loss reads.  cnt_d [b] scratch, off_d [b + 1] (off_d[b] = count),
  * idx_d / tgt_d capacity b * (t - 1). */
@@ -432,8 +461,9 @@ void lmrl_gemm_set_variant(int v);
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     float temperature;      /* <= 0: greedy (do_sample=False) */
-    int32_t top_k;          /* <= 0: off; needs logits_out_d (1 .. 64 on the policy-only Philox path: scratch of the rare rows the fused
-                             * candidate selection hands back; otherwise the logits are materialised there) */
+    int32_t top_k;          /* <= 0: off; needs logits_out_d (1 .. 64 on the Philox path — policy-only and ILQL value-policy heads alike: scratch of
+                             * the rare rows the fused candidate selection hands back, NOT the logits, unless `flags` asks for them; otherwise
+                             * the logits are materialised there) */
     uint64_t seed;          /* Philox key */
     uint32_t step;          /* counter word: one per sampled token position */
     float steer_strength;   /* added to logit[steer_tok_d[row]] (synthetic workloads only; 0 = off) */
@@ -448,7 +478,10 @@ typedef struct {
                              * (row, column) = element row * vocab + column of jax.random.gumbel(key, (m * vocab,)) — threefry2x32-20 over the
                              * iota split in halves (csrc/threefry.h); logits / temperature by division; `step` and `epoch_d` are unused (the
                              * caller walks the key schedule: lmrl_gym_amd/jax_prng.py).  All m rows of the call form ONE noise array. */
+    int32_t flags;          /* LMRL_SAMPLE_WANT_LOGITS: the caller reads logits_out_d after the call — materialise them even where the fused top-k
+                             * path would not (same tokens either way) */
 } lmrl_sample_params;
+#define LMRL_SAMPLE_WANT_LOGITS 1
 #define LMRL_RNG_PHILOX 0
 #define LMRL_RNG_JAX 1
 /* host faces of the LMRL_RNG_JAX stream: the Threefry-2x32 (20 rounds) block function and words [i0, i0 + count) of
@@ -458,6 +491,9 @@ int lmrl_jax_random_bits_host(const uint32_t key[2], uint32_t n, uint32_t i0, ui
 
 /* workspace of lmrl_lm_head_sample (per-(row, tile) partials or top-k candidate records + the flagged-row list).  One workspace per concurrent stream. */
 size_t lmrl_sample_ws_bytes(int m, int vocab_padded);
+/* byte offset, inside that workspace, of the fused top-k path's flagged-row list: int32 words — [0] = rows the exactness check handed back to the
+ * materialised path in the LAST call (diagnostics / tests), 15 reserved words, 64 per-row-block flags, then the row indices */
+size_t lmrl_sample_fb_offset(int m, int vocab_padded);
 /* hidden_d bf16 [m][d] . wte_d bf16 [vocab_padded][d]^T -> token_d[m] (+ logprob_d[m] under the sampling
  * distribution).  Optional ILQL operands: q_hidden{1,2}_d bf16 [m][d] (= relu(dense1(h)) of each Q head),
  * q_w{1,2}_d bf16 [vocab_padded][d] (dense2 kernels, [out][in]), q_b{1,2}_d f32 [vocab_padded].
@@ -653,12 +689,19 @@ void lmrl_rl_reduce_set_variant(int v);
 /* TOOLS / TESTS ONLY: bit 0 = bf16 flash-attention forward, bit 1 = dQ, bit 2 = dK/dV on the round-3 kernels (A/B and equality tests of the
  * round-4 sweeps: 128 queries per workgroup, two query groups per wave, global_load_lds tile ring) */
 void lmrl_flash_set_variant(int v);
-int lmrl_embed_fwd(const float *wte_d, const float *wpe_d, const int32_t *ids_d, const int32_t *pos_d, float *x_d, int rows, int d, void *stream);
+/* x[r] = wte[ids[r]] + wpe[pos[r]].  vocab > 0: wte has `vocab` rows and an id outside [0, vocab) embeds as a ZERO row — the pad id of a tokenizer
+ * whose `<|pad|>` is the first id after the model's vocabulary (train_ppo_gpt2.py:124-126; the reference resizes the embedding and forces those
+ * logits to -inf, ppo/gpt2/interface.py:330, so that id is never sampled and only ever sits at masked positions). */
+int lmrl_embed_fwd(const float *wte_d, const float *wpe_d, const int32_t *ids_d, const int32_t *pos_d, float *x_d, int rows, int d, int vocab,
+                   void *stream);
 /* dwte[ids[r]] += dx[r], dwpe[pos[r]] += dx[r] without atomics (one owner wave per distinct index, fixed order: bit-reproducible).
  * live_d (optional, uint8 [rows]): rows with flag 0 are skipped — the padded positions of a right-padded batch (attention_mask == 0), whose dx is
- * exactly zero and which would otherwise all pile onto the pad id's owner wave. */
+ * exactly zero and which would otherwise all pile onto the pad id's owner wave.  t_row > 0 (the T of a [B, T] batch): a row whose flag is 0
+ * but whose NEXT position in the same sequence has flag 1 stays live (the PPO / BC losses read row t wherever attention_mask[t + 1] is set, so
+ * with left padding or holes its dx is not zero); right-padded batches: exactly the flagged rows.  vocab > 0: ids outside [0, vocab) own no
+ * wte row (lmrl_embed_fwd) and are skipped. */
 int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d, const uint8_t *live_d, float *dwte_d, float *dwpe_d, int rows, int d,
-                   void *stream);
+                   int vocab, int t_row, void *stream);
 /* Row compaction for the vocabulary-wide heads of the train steps: the losses read the Q / policy logits only on rows whose mask is set
  * (should_take_action x attention mask: ilql/base_interface.py:22-119, ppo/base_interface.py:72-142), so a head runs on the gathered rows
  * dst[i] = src[idx[i]] and its input gradient goes back with dst[idx[i]] (=|+=) src[i].  idx_d holds DISTINCT rows (no atomics). */

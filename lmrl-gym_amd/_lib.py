@@ -39,12 +39,20 @@ _SIGS = {
     "lmrl_gae": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p]),
     "lmrl_rtg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "lmrl_whiten_moments": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lmrl_gae_moments_partials": (c_int, [c_int, c_int]),
+    "lmrl_gae_moments": (c_int, [c_void_p] * 6 + [c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
+    "lmrl_whiten_finish": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "lmrl_whiten_apply_partials": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "lmrl_whiten_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "lmrl_ppo_count": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmrl_ppo_block": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmrl_ppo_shape": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmrl_ppo_unroll": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "lmrl_ppo_truncate_turns": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lmrl_compact_flags": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "lmrl_len_mask_pos": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "lmrl_add_i32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "lmrl_seq_mask_pos": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "lmrl_masked_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmrl_gather_rows_bytes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.c_long, c_void_p]),
@@ -68,6 +76,7 @@ _SIGS = {
     "lmrl_sampler_set_variant": (None, [c_int]),
     "lmrl_flash_set_variant": (None, [c_int]),
     "lmrl_sample_ws_bytes": (c_size_t, [c_int, c_int]),
+    "lmrl_sample_fb_offset": (c_size_t, [c_int, c_int]),
     "lmrl_sample_logits_steer": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmrl_chunk_begin_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lmrl_attn_cached_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -113,7 +122,7 @@ _SIGS = {
     "lmrl_prof_read": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
     "lmrl_sgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, ctypes.c_long, ctypes.c_long, c_void_p, c_int,
                            ctypes.c_long, ctypes.c_long, c_float, c_void_p, c_int, ctypes.c_long, ctypes.c_long, c_int, c_int, c_void_p, c_void_p]),
-    "lmrl_embed_fwd": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "lmrl_embed_fwd": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_void_p]),
     "lmrl_cast_bf16": (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]),
     "lmrl_cast_bf16_segments": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lmrl_split3_bf16": (c_int, [c_void_p, ctypes.c_long, c_int, c_int, c_void_p, ctypes.c_long, c_void_p]),
@@ -155,7 +164,7 @@ _SIGS = {
     "lmrl_layernorm_add_fwd": (c_int, [c_void_p] * 8 + [ctypes.c_long, c_int, c_int, c_float, c_void_p]),
     "lmrl_layernorm_fwd_staged": (c_int, [c_void_p] * 7 + [ctypes.c_long, c_int, c_int, c_float, c_void_p]),
     "lmrl_gelu_fwd_staged": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_long, c_int, c_int, c_void_p]),
-    "lmrl_embed_bwd": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),
+    "lmrl_embed_bwd": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_int, c_void_p]),
     "lmrl_layernorm_fwd": (c_int, [c_void_p] * 6 + [c_int, c_int, c_float, c_void_p]),
     "lmrl_layernorm_bwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
     "lmrl_layernorm_bwd_fused_supported": (c_int, [c_int]),

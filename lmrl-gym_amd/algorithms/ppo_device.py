@@ -11,7 +11,7 @@ text, a re-tokenisation, per-chain numpy loops.  The rollout engines of this pac
 
 and `GPT2PPOTrain.step` takes `DevicePPODataset.batch(...)` (device tensors) as it takes the reference's numpy batches.  No `[B, T, V]` logits
 exist at any point (bf16-matmul mode: log-sum-exp from the LM-head GEMM's accumulators; fp32: one row-chunk scratch).  The host reads back
-(n + 5) integers per call (row offsets + the four totals) to size the launches.
+(2 n + 10) integers per call (row offsets + the totals and the reference's truncation checks) to size the launches.
 
 `get_ppo_data_from_token_trajectory_chain` in ppo_inference.py stays as the host-array form (the reference's own signature); both are tested
 against the reference function's fixture and against each other (tests/test_gpu_ppo_device.py).
@@ -91,14 +91,31 @@ class DevicePPODataset:
 
     FIELDS = ("input_ids", "should_take_action", "old_logprobs", "old_values", "old_advantages", "old_returns")
 
-    def __init__(self, longest: Optional[int] = None, **arrays):
-        """longest: number of tokens of the longest trajectory in the dataset (known from the build's one readback), for `batch(width=...)`."""
+    def __init__(self, longest: Optional[int] = None, lengths=None, **arrays):
+        """longest: number of tokens of the longest trajectory in the dataset (known from the build's one readback), for `batch(width=...)`.
+        lengths (int32 [N], device; optional): every row's trajectory length as the data build saw it.  With it a batch carries the build's OWN
+        `attention_mask` / `position_ids` (right-padded rows: 1 below the length), so the train step masks exactly what the log-probs / values were
+        computed under even when a token equal to the pad id sits inside a trajectory (a tokenizer whose pad id the policy can sample); without
+        it the step derives the masks from `ids != pad` as the reference does (ppo/base_interface.py:190-195)."""
         for k in self.FIELDS:
             setattr(self, k, arrays[k])
         n, t = self.input_ids.shape
         for k in self.FIELDS[1:]:
             assert tuple(getattr(self, k).shape) == (n, t - 1)
         self.longest = int(longest) if longest is not None else int(t)
+        self.lengths = lengths
+        assert lengths is None or tuple(lengths.shape) == (n,)
+
+    @classmethod
+    def concat(cls, parts: Sequence["DevicePPODataset"]) -> "DevicePPODataset":
+        """The datasets of several episode batches of one round as one (rows concatenated; the parts share the blocking width)."""
+        import torch
+        if len(parts) == 1:
+            return parts[0]
+        T = parts[0].input_ids.shape[1]
+        assert all(p.input_ids.shape[1] == T for p in parts), "batches of one round share the blocking width (pass max_length)"
+        lengths = torch.cat([p.lengths for p in parts]) if all(p.lengths is not None for p in parts) else None
+        return cls(longest=max(p.longest for p in parts), lengths=lengths, **{k: torch.cat([getattr(p, k) for p in parts]) for k in cls.FIELDS})
 
     def trimmed_width(self, multiple: int = 64) -> int:
         """The narrowest batch width (a multiple of `multiple`) that still holds every trajectory."""
@@ -130,6 +147,13 @@ class DevicePPODataset:
             _lib.check(_lib.lib().lmrl_gather_rows_bytes(src.data_ptr(), index.data_ptr(), dst.data_ptr(), n, src.shape[1] * src.element_size(),
                                                          _lib.stream_ptr()), "lmrl_gather_rows_bytes")
             out[k] = dst if cols == src.shape[1] else dst[:, :cols].contiguous()
+        if self.lengths is not None:
+            ln = torch.empty(n, dtype=torch.int32, device=index.device)
+            _lib.check(_lib.lib().lmrl_gather_rows_bytes(self.lengths.data_ptr(), index.data_ptr(), ln.data_ptr(), n, 4, _lib.stream_ptr()), "lmrl_gather_rows_bytes")
+            am = torch.empty(n, w, dtype=torch.uint8, device=index.device)
+            pos = torch.empty(n, w, dtype=torch.int32, device=index.device)
+            _lib.check(_lib.lib().lmrl_len_mask_pos(ln.data_ptr(), n, w, am.data_ptr(), pos.data_ptr(), _lib.stream_ptr()), "lmrl_len_mask_pos")
+            out["attention_mask"], out["position_ids"] = am, pos
         return out
 
     def batches(self, rng, bsize: int, truncate: bool = True, width: Optional[int] = None):
@@ -178,11 +202,24 @@ def ppo_data_from_records(inference, rec: PPORecords, *, gamma: float, lam: floa
             ev.record()
             marks.append((name, ev))
     mark("start")
-    cnt, off_rows, off_act, meta = i32(2 * n), i32(n + 1), i32(n + 1), i32(4)
+    scratch = i32(2 * n + 2 * (n + 1) + 8)
+    cnt, off_rows, off_act, meta = scratch[:2 * n], scratch[2 * n:3 * n + 1], scratch[3 * n + 1:4 * n + 2], scratch[4 * n + 2:]
     _lib.check(L.lmrl_ppo_count(ctypes.byref(c), ml, pad, _lib.ptr(cnt), _lib.ptr(off_rows), _lib.ptr(off_act), _lib.ptr(meta), sp), "lmrl_ppo_count")
-    n_rows, n_act, longest, pads = (int(x) for x in meta.cpu().numpy())        # the one readback that sizes what follows
+    host = scratch[2 * n:].cpu().numpy()                                       # the one readback that sizes what follows: row offsets + the totals
+    off_rows_h = host[:n + 1]
+    n_rows, n_act, longest, pads, cut_actions, bad_starts, chain_reach = (int(x) for x in host[2 * (n + 1):2 * (n + 1) + 7])
+    # CombinedTokenTrajectoryChain.from_token_trajectory_chain (base_interface.py:318-327) asserts both conditions; advantages over a cut chain
+    # would silently differ from anything the reference computes
+    if cut_actions or bad_starts:
+        raise ValueError(f"trajectory truncation error: {cut_actions} action token(s) lie beyond max_length = {ml}, {bad_starts} trajectories continue a "
+                         "chain but start with an action token (ppo/base_interface.py:318-327 refuses such chains)")
     if n_rows == 0:
         raise ValueError("no trajectory has two tokens: nothing to build PPO data from")
+    if pads:
+        import warnings
+        warnings.warn(f"{pads} token(s) equal to the pad id {pad} lie INSIDE trajectories (a policy that can sample its tokenizer's pad id): they are "
+                      "attended here (lengths come from the records) and the dataset carries those lengths to the train step; the reference's "
+                      "`ids != pad` masks would cut such a sequence short", RuntimeWarning, stacklevel=2)
     tf = -(-longest // 8) * 8
     tp = int(pad_to) if pad_to is not None else (ml if ml > 0 else longest)
     if tp < longest:
@@ -192,23 +229,38 @@ def ppo_data_from_records(inference, rec: PPORecords, *, gamma: float, lam: floa
     _lib.check(L.lmrl_ppo_block(ctypes.byref(c), ml, pad, tf, _lib.ptr(off_rows), _lib.ptr(ids), _lib.ptr(am), _lib.ptr(pos), _lib.ptr(rows_idx),
                                 _lib.ptr(tgt), sp), "lmrl_ppo_block")
     mark("block")
-    # ---- the three models (base_interface.py:514-541): per `bsize` sequences one inference forward each; final hidden states kept for the heads
-    hid_p, hid_i, values = f32(n * tf, pol.d), f32(n * tf, init.d), f32(n * tf)
-    for s0 in range(0, n, bsize):
+    # ---- the three models (base_interface.py:514-541): per `bsize` sequences one inference forward each, then the log-probs of THAT chunk's rows
+    # (the reference keeps one bsize chunk of outputs live too): only the values [n, tf] and the per-row log-probs outlive a chunk.  The bf16
+    # operand copies of the weights are staged once per call (nothing moves the masters in between), not once per chunk forward.
+    values, lp, init_lp = f32(n * tf), f32(n_rows), f32(n_rows)
+    t_fwd = t_lp = 0.0
+    evs = []
+    for ci, s0 in enumerate(range(0, n, bsize)):
         s1 = min(n, s0 + bsize)
-        for model, dst in ((init, hid_i), (pol, hid_p)):
-            h, _ = model.forward(ids[s0:s1], am[s0:s1], pos[s0:s1], inference=True)
-            dst[s0 * tf:s1 * tf].copy_(h)
-        v, _ = head.forward(hid_p[s0 * tf:s1 * tf], (s1 - s0) * tf)
-        values[s0 * tf:s1 * tf].copy_(v.view(-1) if head.ld_out == 1 else v[:, 0])
-    mark("forward")
-    init_lp = init.token_logprobs(hid_i, rows_idx, tgt, n_rows, chunk=lm_head_rows)
-    del hid_i
-    lp = pol.token_logprobs(hid_p, rows_idx, tgt, n_rows, chunk=lm_head_rows)
-    del hid_p
-    mark("logprobs")
+        r0, r1 = int(off_rows_h[s0]), int(off_rows_h[s1])
+        local = None
+        if r1 > r0:                                                            # the chunk's rows of the row list, as rows of the chunk's hidden states
+            local = i32(r1 - r0)
+            _lib.check(L.lmrl_add_i32(_lib.ptr(rows_idx[r0:r1]), -s0 * tf, _lib.ptr(local), r1 - r0, sp), "lmrl_add_i32")
+        for model, dst in ((init, init_lp), (pol, lp)):
+            if timings is not None:
+                evs.append(("f0", _ev(torch)))
+            h, _ = model.forward(ids[s0:s1], am[s0:s1], pos[s0:s1], inference=True, restage=(ci == 0))
+            if model is pol:
+                v, _ = head.forward(h, (s1 - s0) * tf)
+                values[s0 * tf:s1 * tf].copy_(v.view(-1) if head.ld_out == 1 else v[:, 0])
+            if timings is not None:
+                evs.append(("f1", _ev(torch)))
+            if local is not None:
+                dst[r0:r1].copy_(model.token_logprobs(h, local, tgt[r0:r1], r1 - r0, chunk=lm_head_rows))
+            if timings is not None:
+                evs.append(("l1", _ev(torch)))
+            del h
+    mark("models")
     # ---- :543-584 on the device, chain rows for the GAE
     lc = max(longest - 1, 1) if rec.chain is None else int(rec.chain_len_bound or n * max(longest - 1, 1))
+    if lc < chain_reach:            # lmrl_ppo_shape / lmrl_ppo_unroll would drop the slots beyond lc
+        raise ValueError(f"chain_len_bound = {lc} is shorter than the longest chain ({chain_reach} slots)")
     C = rec.n_chains
     cv, cr, cs, clen = f32(C, lc + 1), f32(C, lc), torch.empty(C, lc, dtype=torch.uint8, device=dev), i32(C)
     kls = f32(max(n_act, 1))
@@ -219,18 +271,71 @@ def ppo_data_from_records(inference, rec: PPORecords, *, gamma: float, lam: floa
                                 _lib.ptr(ds["input_ids"]), _lib.ptr(ds["should_take_action"]), _lib.ptr(ds["old_logprobs"]), _lib.ptr(ds["old_values"]), sp),
                "lmrl_ppo_shape")
     adv, ret = f32(C, lc), f32(C, lc)
-    _lib.check(L.lmrl_gae(_lib.ptr(cv), _lib.ptr(cr), _lib.ptr(cs), _lib.ptr(clen), _lib.ptr(adv), _lib.ptr(ret), C, lc, float(gamma), float(lam), sp), "lmrl_gae")
-    if use_advantage_whitening:                                            # over the action tokens of the whole batch (all ranks), :609-615
-        adv = D.whiten_distributed(adv.view(-1), cs.view(-1), shift_mean=True).view(C, lc)
+    npart = L.lmrl_gae_moments_partials(C, lc) if use_advantage_whitening else 0
+    if npart > 0:       # rollout-sized chains: the GAE launch leaves the whitening's partial moments, the apply launch adds them up itself
+        part = torch.empty(npart, 3, dtype=torch.float64, device=dev)
+        _lib.check(L.lmrl_gae_moments(_lib.ptr(cv), _lib.ptr(cr), _lib.ptr(cs), _lib.ptr(clen), _lib.ptr(adv), _lib.ptr(ret), C, lc, float(gamma), float(lam),
+                                      _lib.ptr(part), sp), "lmrl_gae_moments")
+        adv = D.whiten_distributed(adv.view(-1), cs.view(-1), shift_mean=True, partials=part).view(C, lc)
+    else:
+        _lib.check(L.lmrl_gae(_lib.ptr(cv), _lib.ptr(cr), _lib.ptr(cs), _lib.ptr(clen), _lib.ptr(adv), _lib.ptr(ret), C, lc, float(gamma), float(lam), sp), "lmrl_gae")
+        if use_advantage_whitening:                                        # over the action tokens of the whole batch (all ranks), :609-615
+            adv = D.whiten_distributed(adv.view(-1), cs.view(-1), shift_mean=True).view(C, lc)
     _lib.check(L.lmrl_ppo_unroll(ctypes.byref(c), ml, tf, lc, _lib.ptr(adv), _lib.ptr(ret), tp, _lib.ptr(ds["old_advantages"]), _lib.ptr(ds["old_returns"]), sp),
                "lmrl_ppo_unroll")
     mark("shape_gae")
     if timings is not None:
         torch.cuda.synchronize()
         for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
-            timings[name + "_ms"] = timings.get(name + "_ms", 0.0) + a.elapsed_time(b)
+            if name != "models":
+                timings[name + "_ms"] = timings.get(name + "_ms", 0.0) + a.elapsed_time(b)
+        for k in range(0, len(evs), 3):                                        # forwards and log-prob passes interleave per chunk: summed per kind
+            timings["forward_ms"] = timings.get("forward_ms", 0.0) + evs[k][1].elapsed_time(evs[k + 1][1])
+            timings["logprobs_ms"] = timings.get("logprobs_ms", 0.0) + evs[k + 1][1].elapsed_time(evs[k + 2][1])
         timings.update(rows=n_rows, action_tokens=n_act, forward_width=tf, sequences=n, pad_ids_inside=timings.get("pad_ids_inside", 0) + pads)
-    return DevicePPODataset(longest=longest, **ds), kls[:n_act]
+    lengths = i32(n)
+    _lib.check(L.lmrl_add_i32(_lib.ptr(cnt[:n]), 1, _lib.ptr(lengths), n, sp), "lmrl_add_i32")      # rows with a next token + 1 (0-token records: 1, all padding)
+    return DevicePPODataset(longest=longest, lengths=lengths, **ds), kls[:n_act]
+
+
+def _ev(torch):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def truncate_turns(rec: PPORecords, max_length: int, gamma: float) -> Tuple[PPORecords, Dict[str, int]]:
+    """The task scripts' length rule (llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py:323-341; the chess and maze PPO scripts carry the same loop) on
+    single-trajectory chains in HBM (`lmrl_ppo_truncate_turns`): while a trajectory has more than three texts and at least `max_length` tokens its
+    last (action, observation) pair is dropped, (the pair's rewards) x gamma go onto the previous action and `done` becomes False; trajectories
+    left with fewer than three texts or still too long are skipped -> (records of the kept trajectories, {"shortened": .., "skipped": ..}).
+    The input records are not modified (reward / n_tok / done are copied; tokens and flags are shared unless rows are skipped)."""
+    import torch
+    assert rec.chain is None, "the scripts apply this rule to chains of one trajectory"
+    L, sp, dev = _lib.lib(), _lib.stream_ptr(), rec.tokens.device
+    n = rec.n
+    reward = rec.reward.clone()
+    n_tok = torch.empty(n, dtype=torch.int32, device=dev)
+    done, keep = torch.empty(n, dtype=torch.uint8, device=dev), torch.empty(n, dtype=torch.uint8, device=dev)
+    meta = torch.empty(2, dtype=torch.int32, device=dev)
+    _lib.check(L.lmrl_ppo_truncate_turns(_lib.ptr(rec.is_action), _lib.ptr(rec.n_tok), _lib.ptr(rec.done), n, rec.cap, int(max_length), float(gamma),
+                                         _lib.ptr(reward), _lib.ptr(n_tok), _lib.ptr(done), _lib.ptr(keep), _lib.ptr(meta), sp), "lmrl_ppo_truncate_turns")
+    shortened, skipped = (int(x) for x in meta.cpu().numpy())
+    info = dict(shortened=shortened, skipped=skipped)
+    if skipped == 0:
+        return PPORecords(rec.tokens, rec.is_action, reward, n_tok, done), info
+    if skipped == n:
+        raise ValueError("every trajectory is skipped by the length rule (fewer than three texts, or still >= max_length tokens)")
+    idx, count = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.check(L.lmrl_compact_flags(_lib.ptr(keep), n, _lib.ptr(idx), _lib.ptr(count), sp), "lmrl_compact_flags")
+    m = n - skipped
+
+    def rows(src):
+        src2 = src.view(n, -1)
+        dst = torch.empty((m, src2.shape[1]), dtype=src.dtype, device=dev)
+        _lib.check(L.lmrl_gather_rows_bytes(src2.data_ptr(), idx.data_ptr(), dst.data_ptr(), m, src2.shape[1] * src2.element_size(), sp), "lmrl_gather_rows_bytes")
+        return dst if src.dim() == 2 else dst.view(m)
+    return PPORecords(rows(rec.tokens), rows(rec.is_action), rows(reward), rows(n_tok), rows(done)), info
 
 
 def masked_rows_device(should_take_action, attention_mask, input_ids, T: int):

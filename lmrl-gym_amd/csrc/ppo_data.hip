@@ -30,28 +30,38 @@ __device__ __forceinline__ int traj_len(const int32_t *__restrict__ n_tok, int k
     return (max_len > 0 && n > max_len) ? max_len : n;            // Truncation.RIGHT at max_length (base_interface.py:500-512)
 }
 
-// meta: [0] rows with a next token (sum of max(len - 1, 0)), [1] action tokens, [2] longest effective length, [3] pad ids found below a length
+// meta: [0] rows with a next token (sum of max(len - 1, 0)), [1] action tokens, [2] longest effective length, [3] pad ids found below a length,
+// [4] action tokens CUT by max_len (is_action[1:][max_len - 1:], the reference's 'trajectory truncation error', base_interface.py:318-327),
+// [5] trajectories that continue a chain but start with an action token (the same assert's other arm), [6] the longest chain concatenation
+// (max over trajectories of pos + len - 1: what `lc` of lmrl_ppo_shape / lmrl_ppo_unroll must reach), [7] reserved (0)
 __global__ __launch_bounds__(256) void ppo_count_kernel(const int32_t *__restrict__ tokens, const uint8_t *__restrict__ is_action,
-                                                        const int32_t *__restrict__ n_tok, int n, int cap, int max_len, int pad,
+                                                        const int32_t *__restrict__ n_tok, const int32_t *__restrict__ chain,
+                                                        const int32_t *__restrict__ pos, int n, int cap, int max_len, int pad,
                                                         int32_t *__restrict__ cnt_rows, int32_t *__restrict__ cnt_act, int32_t *__restrict__ meta) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + wave;
     if (k >= n) return;
     const int ne = traj_len(n_tok, k, cap, max_len);
-    int acts = 0, pads = 0;
-    for (int base = 0; base < ne; base += 64) {
+    const int nraw = traj_len(n_tok, k, cap, 0);
+    int acts = 0, pads = 0, cut = 0;
+    for (int base = 0; base < nraw; base += 64) {
         const int t = base + lane;
         const bool in = t < ne;
-        const bool a = in && t >= 1 && is_action[(size_t)k * cap + t] != 0;      // should_take_action = is_action[1:]
+        const bool act = t < nraw && t >= 1 && is_action[(size_t)k * cap + t] != 0;      // should_take_action = is_action[1:]
+        const bool a = in && act;
         const bool p = in && tokens[(size_t)k * cap + t] == pad;
         acts += __popcll(__ballot(a));
         pads += __popcll(__ballot(p));
+        cut += __popcll(__ballot(act && !in));
     }
     if (lane == 0) {
         cnt_rows[k] = ne > 0 ? ne - 1 : 0;
         cnt_act[k] = acts;
         atomicMax(&meta[2], ne);
         if (pads) atomicAdd(&meta[3], pads);
+        if (cut) atomicAdd(&meta[4], cut);
+        if (chain && k > 0 && chain[k] == chain[k - 1] && nraw > 0 && is_action[(size_t)k * cap] != 0) atomicAdd(&meta[5], 1);
+        atomicMax(&meta[6], (pos ? pos[k] : 0) + (ne > 0 ? ne - 1 : 0));
     }
 }
 
@@ -212,6 +222,24 @@ __global__ __launch_bounds__(256) void seq_mask_pos_kernel(const int32_t *__rest
     }
 }
 
+// right-padded rows of known lengths: am[b][i] = i < len[b], pos = clip(cumsum(am) - 1, 0) — the masks a data build made, carried to the train step
+__global__ __launch_bounds__(256) void len_mask_pos_kernel(const int32_t *__restrict__ len, int b, int t, uint8_t *__restrict__ am, int32_t *__restrict__ pos) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= b) return;
+    int n = len[row];
+    n = n < 0 ? 0 : (n > t ? t : n);
+    for (int i = lane; i < t; i += 64) {
+        am[(size_t)row * t + i] = i < n ? 1 : 0;
+        pos[(size_t)row * t + i] = i < n ? i : (n > 0 ? n - 1 : 0);
+    }
+}
+
+__global__ void add_i32_kernel(const int32_t *__restrict__ in, int c, int32_t *__restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] + c;
+}
+
 // mask[b][t] = sta[b][t] && am[b][t + 1] on the shifted grid (t < T - 1): count per row, then (after the scan) the row list + targets
 template <bool WRITE>
 __global__ __launch_bounds__(256) void masked_rows_kernel(const uint8_t *__restrict__ sta, const uint8_t *__restrict__ am, const int32_t *__restrict__ ids,
@@ -250,6 +278,75 @@ __global__ __launch_bounds__(256) void gather_rows_bytes_kernel(const uint8_t *_
     }
 }
 
+// The task scripts' length rule on single-trajectory chains (llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py:323-341): while a trajectory has more than
+// three texts and its tokenisation reaches max_len, its last two texts (action, observation) are dropped, their rewards x gamma are folded into the
+// previous action and the chain is no longer done; trajectories left with fewer than three texts, or still too long, are skipped.  On a token
+// record a "text" is a maximal run of equal is_action flags (header, action, observation, action, ... alternate), an item's reward sits on its
+// last token (TokenTrajectory.from_text_trajectory, environment.py:349-380).  One lane per trajectory: a few short backward scans over <= cap
+// flags.  The fold runs in double, as the script's Python floats do, and is rounded to float32 once (np.array(reward, dtype=np.float32)).
+__global__ __launch_bounds__(256) void ppo_truncate_turns_kernel(const uint8_t *__restrict__ is_action, const int32_t *__restrict__ n_tok,
+                                                                 const uint8_t *__restrict__ done, int n, int cap, int max_len, double gamma,
+                                                                 float *__restrict__ reward, int32_t *__restrict__ n_tok_out, uint8_t *__restrict__ done_out,
+                                                                 uint8_t *__restrict__ keep, int32_t *__restrict__ meta) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint8_t *ia = is_action + (size_t)k * cap;
+    float *rw = reward + (size_t)k * cap;
+    int nt = n_tok[k];
+    nt = nt < 0 ? 0 : (nt > cap ? cap : nt);
+    int items = nt > 0 ? 1 : 0;
+    for (int t = 1; t < nt; t++) items += (ia[t] != 0) != (ia[t - 1] != 0);
+    bool dn = done[k] != 0;
+    int target = -1, dropped = 0;      // token whose reward is held in `carry` (double) instead of rw[]
+    double carry = 0.0;
+    while (items > 3 && nt >= max_len) {
+        int s1 = nt - 1;
+        while (s1 > 0 && (ia[s1 - 1] != 0) == (ia[nt - 1] != 0)) s1--;          // last text = [s1, nt)
+        int s2 = s1 - 1;
+        while (s2 > 0 && (ia[s2 - 1] != 0) == (ia[s1 - 1] != 0)) s2--;          // the one before = [s2, s1)
+        double fold = 0.0;                                                       // sum(reward[-2:]) in the script's order
+        for (int t = s2; t < nt; t++) fold += (t == target) ? carry : (double)rw[t];
+        if (target >= s2) target = -1;                                           // the held token leaves with its text
+        nt = s2; items -= 2; dn = false; dropped += 2;
+        int t1 = nt - 1;
+        while (t1 > 0 && (ia[t1 - 1] != 0) == (ia[nt - 1] != 0)) t1--;           // new last text = [t1, nt); new_reward[-2] sits on token t1 - 1
+        const int tg = t1 - 1;
+        if (tg >= 0) {
+            if (target >= 0 && target != tg) rw[target] = (float)carry;
+            carry = ((tg == target) ? carry : (double)rw[tg]) + fold * gamma;
+            target = tg;
+        }
+    }
+    if (target >= 0) rw[target] = (float)carry;
+    const bool kp = items >= 3 && nt < max_len;
+    n_tok_out[k] = nt;
+    done_out[k] = dn ? 1 : 0;
+    keep[k] = kp ? 1 : 0;
+    if (dropped) atomicAdd(&meta[0], 1);
+    if (!kp) atomicAdd(&meta[1], 1);
+}
+
+// idx[j] = the j-th k with flags[k] != 0 (increasing), count[0] = their number; one workgroup (n up to a few 100 k)
+__global__ __launch_bounds__(1024) void compact_flags_kernel(const uint8_t *__restrict__ flags, int n, int32_t *__restrict__ idx, int32_t *__restrict__ count) {
+    __shared__ int sw[16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int carry = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const bool f = i < n && flags[i] != 0;
+        const unsigned long long bal = __ballot(f);
+        if (lane == 0) sw[wave] = __popcll(bal);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { if (w < wave) before += sw[w]; total += sw[w]; }
+        if (f) idx[carry + before + lanes_below(bal, lane)] = i;
+        carry += total;
+        __syncthreads();
+    }
+    if (tid == 0) count[0] = carry;
+}
+
 static PpoRecords records_of(const lmrl_ppo_records *r) {
     return PpoRecords{r->tokens, r->is_action, r->reward, r->n_tok, r->done, r->chain, r->pos, r->last, r->n, r->cap, r->n_chains};
 }
@@ -268,9 +365,9 @@ int lmrl_ppo_count(const lmrl_ppo_records *rec, int max_len, int pad, int32_t *c
                    void *stream) {
     LMRL_REQUIRE(records_ok(rec) && cnt_d && off_rows_d && off_act_d && meta_d, "lmrl_ppo_count: bad argument");
     hipStream_t s = as_stream(stream);
-    LMRL_CHECK_HIP(hipMemsetAsync(meta_d, 0, 4 * sizeof(int32_t), s));
-    hipLaunchKernelGGL(ppo_count_kernel, dim3(ceil_div(rec->n, 4)), dim3(256), 0, s, rec->tokens, rec->is_action, rec->n_tok, rec->n, rec->cap, max_len, pad,
-                       cnt_d, cnt_d + rec->n, meta_d);
+    LMRL_CHECK_HIP(hipMemsetAsync(meta_d, 0, 8 * sizeof(int32_t), s));
+    hipLaunchKernelGGL(ppo_count_kernel, dim3(ceil_div(rec->n, 4)), dim3(256), 0, s, rec->tokens, rec->is_action, rec->n_tok, rec->chain, rec->pos, rec->n,
+                       rec->cap, max_len, pad, cnt_d, cnt_d + rec->n, meta_d);
     hipLaunchKernelGGL(scan2_kernel, dim3(1), dim3(1024), 0, s, cnt_d, cnt_d + rec->n, rec->n, off_rows_d, off_act_d, meta_d);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
@@ -314,9 +411,42 @@ int lmrl_ppo_unroll(const lmrl_ppo_records *rec, int max_len, int tf, int lc, co
     return LMRL_OK;
 }
 
+int lmrl_ppo_truncate_turns(const uint8_t *is_action_d, const int32_t *n_tok_d, const uint8_t *done_d, int n, int cap, int max_len, double gamma,
+                            float *reward_d, int32_t *n_tok_out_d, uint8_t *done_out_d, uint8_t *keep_d, int32_t *meta_d, void *stream) {
+    LMRL_REQUIRE(is_action_d && n_tok_d && done_d && reward_d && n_tok_out_d && done_out_d && keep_d && meta_d && n > 0 && cap > 0 && max_len > 0,
+                 "lmrl_ppo_truncate_turns: bad argument");
+    hipStream_t s = as_stream(stream);
+    LMRL_CHECK_HIP(hipMemsetAsync(meta_d, 0, 2 * sizeof(int32_t), s));
+    hipLaunchKernelGGL(ppo_truncate_turns_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, is_action_d, n_tok_d, done_d, n, cap, max_len, gamma, reward_d,
+                       n_tok_out_d, done_out_d, keep_d, meta_d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_compact_flags(const uint8_t *flags_d, int n, int32_t *idx_d, int32_t *count_d, void *stream) {
+    LMRL_REQUIRE(flags_d && idx_d && count_d && n > 0, "lmrl_compact_flags: bad argument");
+    hipLaunchKernelGGL(compact_flags_kernel, dim3(1), dim3(1024), 0, as_stream(stream), flags_d, n, idx_d, count_d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
 int lmrl_seq_mask_pos(const int32_t *ids_d, int pad, uint8_t *am_d, int32_t *pos_d, float *am_next_f32_d, int b, int t, void *stream) {
     LMRL_REQUIRE(ids_d && am_d && pos_d && b > 0 && t > 0, "lmrl_seq_mask_pos: bad argument");
     hipLaunchKernelGGL(seq_mask_pos_kernel, dim3(ceil_div(b, 4)), dim3(256), 0, as_stream(stream), ids_d, pad, am_d, pos_d, am_next_f32_d, b, t);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_len_mask_pos(const int32_t *len_d, int b, int t, uint8_t *am_d, int32_t *pos_d, void *stream) {
+    LMRL_REQUIRE(len_d && am_d && pos_d && b > 0 && t > 0, "lmrl_len_mask_pos: bad argument");
+    hipLaunchKernelGGL(len_mask_pos_kernel, dim3(ceil_div(b, 4)), dim3(256), 0, as_stream(stream), len_d, b, t, am_d, pos_d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_add_i32(const int32_t *in_d, int c, int32_t *out_d, int n, void *stream) {
+    LMRL_REQUIRE(in_d && out_d && n > 0, "lmrl_add_i32: bad argument");
+    hipLaunchKernelGGL(add_i32_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), in_d, c, out_d, n);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

@@ -17,6 +17,9 @@ namespace lmrl {
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));      // (clang ext vectors: what __builtin_nontemporal_load / _store accept)
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// the values rows have L + 1 floats (the bootstrap slot): with an even L every other row starts 4 bytes off an 8-byte boundary.  gfx950 global loads
+// need dword alignment only (unaligned-access mode of the HSA ABI), so the value PAIR of a lane is still ONE 8-byte request
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
 // ---- round 5: the whole chain in registers.  Lane l of the wave owns token slots t = l + 64 j (j < K): every row read / written by a wave
 // instruction is 64 consecutive elements (256 B of floats), ALL loads of a chain are issued before anything depends on them (one memory latency
@@ -170,10 +173,15 @@ __global__ __launch_bounds__(256) void chain_scan_row_kernel(const float *__rest
 
 // The same with TWO consecutive slots per lane (t = 32 j + 2 g, + 1): half as many cross-lane scans per chain (the DPP steps are most of the
 // kernel's VALU work), 8-byte accesses on rewards / flags / outputs (a row instruction = one full 128 B line).  Needs an even L.
-template <bool GAE, int K>          // K = ceil(L / 32) chunks held in registers
+// MOM (GAE only): the launch also leaves per-workgroup partial moments (sum, sum of squares, count in fp64) of the advantages on action slots in
+// partials[3 * blockIdx.x ..] — what `whiten` over all action tokens needs (ppo/base_interface.py:245-251, 609-615) — so that no separate pass
+// re-reads the advantages: lmrl_gae_moments + lmrl_whiten_apply_partials are two launches where lmrl_gae + lmrl_whiten_moments (two) +
+// lmrl_whiten_apply were four.  Fixed association order (lane partials, wave tree, the four waves in order): bit-reproducible.
+template <bool GAE, int K, bool MOM = false, bool V4 = false>          // K = ceil(L / 32) chunks held in registers; V4: the round-5 value loads (A/B, variant 5)
 __global__ __launch_bounds__(256) void chain_scan_row2_kernel(const float *__restrict__ values, const float *__restrict__ rewards,
                                                                const uint8_t *__restrict__ sta, const int32_t *__restrict__ lens,
-                                                               float *__restrict__ out0, float *__restrict__ out1, int B, int L, float gamma, float lam) {
+                                                               float *__restrict__ out0, float *__restrict__ out1, int B, int L, float gamma, float lam,
+                                                               double *__restrict__ partials = nullptr) {
     const int g = threadIdx.x & 15;
     const int b = blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool live = b < B;
@@ -197,12 +205,18 @@ __global__ __launch_bounds__(256) void chain_scan_row2_kernel(const float *__res
         s0[j] = t < len && (ss & 0xffu) != 0;
         s1[j] = t + 1 < len && (ss >> 8) != 0;
         r0[j] = rr.x; r1[j] = t + 1 < len ? rr.y : 0.f;
-        v0[j] = (GAE && t < len) ? vrow[t] : 0.f;
-        v1[j] = (GAE && t + 1 < len) ? vrow[t + 1] : 0.f;
+        f32x2_t vv = {0.f, 0.f};
+        if (V4) {                 // two 4-byte default-policy loads (round 5)
+            vv.x = (GAE && t < len) ? vrow[t] : 0.f;
+            vv.y = (GAE && t + 1 < len) ? vrow[t + 1] : 0.f;
+        } else if (GAE && t < len) vv = __builtin_nontemporal_load(reinterpret_cast<const f32x2_a4 *>(vrow + t));      // (t + 1 <= len: the bootstrap slot at worst)
+        v0[j] = vv.x;
+        v1[j] = t + 1 < len ? vv.y : 0.f;
     }
     const float boot = GAE ? vrow[len] : 0.f;
     const float c = GAE ? gamma * lam : gamma;
     float carry_a = 0.f, carry_nv = boot;
+    double ms = 0.0, mss = 0.0, mc = 0.0;
 #pragma unroll
     for (int j = K - 1; j >= 0; j--) {
         float d0 = r0[j], d1 = r1[j];
@@ -241,6 +255,23 @@ __global__ __launch_bounds__(256) void chain_scan_row2_kernel(const float *__res
             const f32x2_t o0 = {s0[j] ? xb : 0.f, s1[j] ? A1 : 0.f}, o1 = {s0[j] ? xb + v0[j] : 0.f, s1[j] ? A1 + v1[j] : 0.f};
             __builtin_nontemporal_store(o0, reinterpret_cast<f32x2_t *>(out0 + (size_t)b * L + t));
             if (GAE) __builtin_nontemporal_store(o1, reinterpret_cast<f32x2_t *>(out1 + (size_t)b * L + t));
+            if (MOM) {
+                if (s0[j]) { const double a = (double)xb; ms += a; mss += a * a; mc += 1.0; }
+                if (s1[j]) { const double a = (double)A1; ms += a; mss += a * a; mc += 1.0; }
+            }
+        }
+    }
+    if (MOM) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { ms += __shfl_down(ms, d); mss += __shfl_down(mss, d); mc += __shfl_down(mc, d); }
+        __shared__ double red[3][4];
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { red[0][wave] = ms; red[1][wave] = mss; red[2][wave] = mc; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            partials[3 * blockIdx.x + 0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+            partials[3 * blockIdx.x + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+            partials[3 * blockIdx.x + 2] = ((red[2][0] + red[2][1]) + red[2][2]) + red[2][3];
         }
     }
 }
@@ -462,16 +493,69 @@ __global__ __launch_bounds__(256) void whiten_apply_kernel(const float *__restri
     }
 }
 
-int g_rl_reduce_variant = 0;      // tools / tests only: 1 = the round-1 LDS-compaction kernel for every length, 2 = the 64-lane register kernel also for L <= 128, 3 = one slot per lane in the DPP-row kernel
+// whiten_apply with the moments still as per-workgroup partials (lmrl_gae_moments): every workgroup adds the (few hundred) partials itself, in the
+// order whiten_finish_kernel uses — the same three doubles in every workgroup, and the same as the two-launch form's — then applies
+template <bool VEC>
+__global__ __launch_bounds__(256) void whiten_apply_partials_kernel(const float *__restrict__ x, const uint8_t *__restrict__ mask,
+                                                                     const double *__restrict__ partials, int nblocks, float *__restrict__ y,
+                                                                     size_t n, int shift_mean) {
+    double s = 0.0, ss = 0.0, cn = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) { s += partials[3 * b]; ss += partials[3 * b + 1]; cn += partials[3 * b + 2]; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { s += __shfl_down(s, d); ss += __shfl_down(ss, d); cn += __shfl_down(cn, d); }
+    __shared__ double red[3][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; red[2][wave] = cn; }
+    __syncthreads();
+    const double cnt = ((red[2][0] + red[2][1]) + red[2][2]) + red[2][3];
+    const double sum = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3], sq = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    const double mean = cnt > 0 ? sum / cnt : 0.0;
+    double var = cnt > 0 ? sq / cnt - mean * mean : 0.0;
+    if (var < 0) var = 0;
+    const double inv = 1.0 / sqrt(var + 1e-8);
+    auto w1 = [&](float v) {
+        double w = ((double)v - mean) * inv;
+        if (!shift_mean) w += mean;
+        return (float)w;
+    };
+    if (VEC) {
+        const size_t n4 = n / 4;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+            float4 v = reinterpret_cast<const float4 *>(x)[i];
+            const uint32_t m = mask ? reinterpret_cast<const uint32_t *>(mask)[i] : 0x01010101u;
+            if (m & 0x000000ffu) v.x = w1(v.x);
+            if (m & 0x0000ff00u) v.y = w1(v.y);
+            if (m & 0x00ff0000u) v.z = w1(v.z);
+            if (m & 0xff000000u) v.w = w1(v.w);
+            reinterpret_cast<float4 *>(y)[i] = v;
+        }
+        return;
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        y[i] = (!mask || mask[i]) ? w1(v) : v;
+    }
+}
+
+int g_rl_reduce_variant = 0;      // tools / tests only: 1 = the round-1 LDS-compaction kernel for every length, 2 = the 64-lane register kernel also for L <= 128, 3 = one slot per lane in the DPP-row kernel, 5 = GAE at 64 < L <= 96 with the round-5 4-byte value loads (A/B of the unaligned 8-byte pairs)
 
 template <bool GAE>
 static int scan_launch_t(const float *values, const float *rewards, const uint8_t *sta, const int32_t *lens, float *o0, float *o1, int b, int l, float gamma,
                          float lam, hipStream_t s) {
     const dim3 grid(ceil_div(b, 4)), block(256);
     const int k = (l + 63) / 64;
-    if ((g_rl_reduce_variant == 0 || g_rl_reduce_variant == 3) && l <= 128) {
+    if ((g_rl_reduce_variant == 0 || g_rl_reduce_variant == 3 || g_rl_reduce_variant == 5 || g_rl_reduce_variant == 6) && l <= 128) {
         const dim3 grid16(ceil_div(b, 16));
-        if (g_rl_reduce_variant == 0 && l % 2 == 0 && (uintptr_t)rewards % 8 == 0 && (uintptr_t)o0 % 8 == 0 && (!GAE || (uintptr_t)o1 % 8 == 0) && (uintptr_t)sta % 2 == 0) {
+        // the value pair of a lane: ONE unaligned 8-byte streaming load where the launch is latency-bound (rollout-sized batches: 3.76 vs 4.01 us at 4096
+        // chains), two 4-byte default-policy loads where it is bandwidth-bound (19.05 vs 20.56 us at 65 536 chains: the rows of `values` have L + 1
+        // floats, a pair straddles a 64-byte sector every 8th lane) — A/B on one box, profiles/r06_rl_reduce_vload_ab.txt; variant 5 / 6 force either form
+        const bool v4 = g_rl_reduce_variant == 5 || (g_rl_reduce_variant == 0 && b > 16384);
+        if (v4 && g_rl_reduce_variant != 6 && GAE && l % 2 == 0 && l > 64 && l <= 96 && (uintptr_t)rewards % 8 == 0 && (uintptr_t)o0 % 8 == 0 && (uintptr_t)o1 % 8 == 0 && (uintptr_t)sta % 2 == 0) {
+            hipLaunchKernelGGL((chain_scan_row2_kernel<GAE, 3, false, true>), grid16, block, 0, s, values, rewards, sta, lens, o0, o1, b, l, gamma, lam, (double *)nullptr);
+            LMRL_CHECK_LAUNCH();
+            return LMRL_OK;
+        }
+        if ((g_rl_reduce_variant == 0 || g_rl_reduce_variant == 5 || g_rl_reduce_variant == 6) && l % 2 == 0 && (uintptr_t)rewards % 8 == 0 && (uintptr_t)o0 % 8 == 0 && (!GAE || (uintptr_t)o1 % 8 == 0) && (uintptr_t)sta % 2 == 0) {
 #define LMRL_SCAN_ROW2(K_) hipLaunchKernelGGL((chain_scan_row2_kernel<GAE, K_>), grid16, block, 0, s, values, rewards, sta, lens, o0, o1, b, l, gamma, lam)
             switch ((l + 31) / 32) {
                 case 1: LMRL_SCAN_ROW2(1); break;
@@ -543,6 +627,52 @@ int lmrl_gae(const float *values_d, const float *rewards_d, const uint8_t *sta_d
     LMRL_REQUIRE(values_d && rewards_d && sta_d && adv_d && ret_d && b >= 0 && l > 0, "lmrl_gae: bad argument");
     if (b == 0) return LMRL_OK;
     return scan_launch(true, values_d, rewards_d, sta_d, len_d, adv_d, ret_d, b, l, gamma, lam, stream);
+}
+
+int lmrl_gae_moments_partials(int b, int l) {      // doubles triples lmrl_gae_moments writes (0: shape not covered by the fused kernel)
+    return (l <= 128 && l % 2 == 0 && b > 0) ? ceil_div(b, 16) : 0;
+}
+
+int lmrl_gae_moments(const float *values_d, const float *rewards_d, const uint8_t *sta_d, const int32_t *len_d, float *adv_d, float *ret_d, int b, int l,
+                     float gamma, float lam, double *partials_d, void *stream) {
+    LMRL_REQUIRE(values_d && rewards_d && sta_d && adv_d && ret_d && partials_d && b > 0 && l > 0, "lmrl_gae_moments: bad argument");
+    LMRL_REQUIRE(lmrl_gae_moments_partials(b, l) > 0 && (uintptr_t)rewards_d % 8 == 0 && (uintptr_t)adv_d % 8 == 0 && (uintptr_t)ret_d % 8 == 0 &&
+                     (uintptr_t)sta_d % 2 == 0,
+                 "lmrl_gae_moments: chains of an even number of <= 128 slots, 8-byte aligned rows (else lmrl_gae + lmrl_whiten_moments)");
+    const dim3 grid16(ceil_div(b, 16)), block(256);
+    hipStream_t s = as_stream(stream);
+#define LMRL_SCAN_ROW2M(K_) hipLaunchKernelGGL((chain_scan_row2_kernel<true, K_, true>), grid16, block, 0, s, values_d, rewards_d, sta_d, len_d, adv_d, ret_d, b, l, gamma, lam, partials_d)
+    if (b > 16384 && (l + 31) / 32 == 3)      // bandwidth-bound launches: the 4-byte value loads (see scan_launch_t)
+        hipLaunchKernelGGL((chain_scan_row2_kernel<true, 3, true, true>), grid16, block, 0, s, values_d, rewards_d, sta_d, len_d, adv_d, ret_d, b, l, gamma, lam, partials_d);
+    else switch ((l + 31) / 32) {
+        case 1: LMRL_SCAN_ROW2M(1); break;
+        case 2: LMRL_SCAN_ROW2M(2); break;
+        case 3: LMRL_SCAN_ROW2M(3); break;
+        default: LMRL_SCAN_ROW2M(4); break;
+    }
+#undef LMRL_SCAN_ROW2M
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_whiten_finish(const double *partials_d, int n_partials, double *moments_d, void *stream) {
+    LMRL_REQUIRE(partials_d && moments_d && n_partials > 0, "lmrl_whiten_finish: bad argument");
+    hipLaunchKernelGGL(whiten_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), partials_d, n_partials, moments_d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_whiten_apply_partials(const float *x_d, const uint8_t *mask_d, const double *partials_d, int n_partials, float *y_d, size_t n, int shift_mean,
+                               void *stream) {
+    LMRL_REQUIRE(x_d && partials_d && y_d && n_partials > 0, "lmrl_whiten_apply_partials: bad argument");
+    if (n == 0) return LMRL_OK;
+    const bool vec = n % 4 == 0 && (uintptr_t)x_d % 16 == 0 && (uintptr_t)y_d % 16 == 0 && (uintptr_t)mask_d % 4 == 0;
+    int grid = ceil_div((long)n, vec ? 256 * 4 : 256);
+    if (grid > 1024) grid = 1024;      // every workgroup re-adds the partials: keep that redundant read small next to the sweep
+    if (vec) hipLaunchKernelGGL(whiten_apply_partials_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), x_d, mask_d, partials_d, n_partials, y_d, n, shift_mean);
+    else hipLaunchKernelGGL(whiten_apply_partials_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), x_d, mask_d, partials_d, n_partials, y_d, n, shift_mean);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
 }
 
 int lmrl_rtg(const float *rewards_d, const uint8_t *sta_d, const int32_t *len_d, float *rtg_d, int b, int l, float gamma,

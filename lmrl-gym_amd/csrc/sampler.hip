@@ -394,7 +394,6 @@ __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const
                                                              const int32_t *__restrict__ block_flag,   // optional: run only the 128-row blocks whose flag is set
                                                              int32_t *__restrict__ fb) {               // TOPC: header of the flagged-row list, cleared here
     constexpr int BM = kLmBM, BN = kLmBN, WM = kLmWM, WN = kLmWN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
-    static_assert(!TOPC || NOPS == 1, "the candidate epilogue is built for the policy-only head");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -451,7 +450,19 @@ __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const
         const int m = m0 + wm * TM + j * 16 + lr;
         st_pre[j] = (steer_tok && m < M) ? steer_tok[m] : -1;
     }
-    if (TOPC) lm_topc_epilogue<false>(z, st_pre, m0, n0, tile_n, tiles_n, M, reinterpret_cast<uint32_t *>(partials), sp, smem);
+    if (TOPC) {
+        // ILQL value policy (generation.py:112-117): the candidates are taken AFTER logits = pi_beta + beta * min(q1, q2) is formed — the same
+        // expression (one fma per logit) as lm_sample_epilogue's, so a hand-back's materialised logits equal the values ranked here bit for bit
+        if (NOPS > 1) {
+#pragma unroll
+            for (int i = 0; i < FN; i++)
+#pragma unroll
+                for (int j = 0; j < FM; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) z[i][j][r] += sp.beta * qmin[i][j][r];
+        }
+        lm_topc_epilogue<false>(z, st_pre, m0, n0, tile_n, tiles_n, M, reinterpret_cast<uint32_t *>(partials), sp, smem);
+    }
     else lm_sample_epilogue<NOPS, WANT_LP, JAX, false>(z, qmin, st_pre, m0, n0, tile_n, tiles_n, M, partials, logits_out, ldo, sp, reinterpret_cast<float *>(smem));
     }
 }
@@ -1217,7 +1228,11 @@ int lmrl_gen_accept(const int32_t *sampled_d, uint8_t *active_d, int32_t *out_to
     return LMRL_OK;
 }
 
-// per-(row, tile) partials of the plain sampler (6 floats) or candidate records of the fused top-k path (10 words), then that path's flagged-row list
+// per-(row, tile) partials of the plain sampler (6 floats) or candidate records of the fused top-k path (kCandWords = 16 words: 8 x {order key, tile-local
+// column}), then that path's flagged-row list: a header of kFbHeader words ([0] = rows handed back), kFbMaxBlocks block flags, then the row list
+size_t lmrl_sample_fb_offset(int m, int vocab_padded) {      // byte offset of the flagged-row header inside the workspace
+    return (size_t)m * (size_t)(vocab_padded / kLmBN) * kCandWords * sizeof(uint32_t);
+}
 size_t lmrl_sample_ws_bytes(int m, int vocab_padded) {
     static_assert(kCandWords >= kPartialFloats, "the candidate records are the larger form");
     return (size_t)m * (size_t)(vocab_padded / kLmBN) * kCandWords * sizeof(uint32_t) + (size_t)(kFbHeader + kFbMaxBlocks + m) * sizeof(int32_t);
@@ -1256,12 +1271,14 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     hipLaunchKernelGGL((lm_head_sample_kernel<NOPS_, LP_, JAX_>), dim3(tiles), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, \
                        q_b2_d, steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm, (const int32_t *)nullptr, (int32_t *)nullptr)
     const bool lp = logprob_d != nullptr;      // the log-sum-exp (one exp per logit) is computed only when the log-prob is wanted
-    // fused top-k (policy-only head, Philox stream, 0 < top_k <= 64): candidate epilogue + reduce, no logits in HBM; `logits_out_d` stays the scratch of
-    // the rare rows the exactness check hands back to the materialised path.  g_sampler_variant 1 / 2 (tools, tests): always materialise.
+    // fused top-k (Philox stream, 0 < top_k <= 64; the policy-only head and — round 6 — the ILQL value policy's pi_beta + beta min(q1, q2),
+    // generation.py:97-119): candidate epilogue + reduce, no logits in HBM; `logits_out_d` stays the scratch of the rare rows the exactness check hands
+    // back to the materialised path.  LMRL_SAMPLE_WANT_LOGITS in `flags` (the caller reads logits_out_d afterwards) or g_sampler_variant 1 / 2 (tools,
+    // tests): always materialise.
     const int tiles_n = vocab_padded / kLmBN, tiles_m = (m + kLmBM - 1) / kLmBM;
-    topc = nops == 1 && sp.rng == LMRL_RNG_PHILOX && !sp.greedy && p->top_k > 0 && p->top_k <= kTopCMaxK && p->top_k < vocab && tiles_n <= 512 &&
-           tiles_m <= kFbMaxBlocks && logits_out_d && g_sampler_variant == 0;
-    fb = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(ws_d) + (size_t)m * tiles_n * kCandWords * sizeof(uint32_t));
+    topc = sp.rng == LMRL_RNG_PHILOX && !sp.greedy && p->top_k > 0 && p->top_k <= kTopCMaxK && p->top_k < vocab && tiles_n <= 512 &&
+           tiles_m <= kFbMaxBlocks && logits_out_d && g_sampler_variant == 0 && !(p->flags & LMRL_SAMPLE_WANT_LOGITS);
+    fb = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(ws_d) + lmrl_sample_fb_offset(m, vocab_padded));
     // policy-only sampling on the Philox / greedy path: the persistent kernel (ring running ahead across tiles); needs K / 64 even and enough tiles
     // to give every one of the 512 resident workgroups at least two.  g_gemm_variant 301 (tools) forces the one-tile-per-workgroup kernel for the A/B.
     const bool persist = nops == 1 && !(sp.rng == LMRL_RNG_JAX && !sp.greedy) && (d_model / 64) % 2 == 0 && d_model >= 128 && tiles >= 1024 &&
@@ -1292,8 +1309,11 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
                                 logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm, grid, rounds, (int32_t *)nullptr);
     }
     else if (topc) {
-        hipLaunchKernelGGL((lm_head_sample_kernel<1, false, false, true>), dim3(tiles), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
-                           steer_tok_d, partials, (float *)nullptr, m, vocab_padded, d_model, vocab_padded, sp, xm, (const int32_t *)nullptr, fb);
+#define LMRL_TOPC_LAUNCH(NOPS_) hipLaunchKernelGGL((lm_head_sample_kernel<NOPS_, false, false, true>), dim3(tiles), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, W1,  \
+                                                   q_b1_d, A2, W2, q_b2_d, steer_tok_d, partials, (float *)nullptr, m, vocab_padded, d_model, vocab_padded, sp, xm,      \
+                                                   (const int32_t *)nullptr, fb)
+        if (nops == 1) LMRL_TOPC_LAUNCH(1); else if (nops == 2) LMRL_TOPC_LAUNCH(2); else LMRL_TOPC_LAUNCH(3);
+#undef LMRL_TOPC_LAUNCH
     }
     else if (sp.rng == LMRL_RNG_JAX && !sp.greedy) {       // parity mode: always with the log-sum-exp variant (one instantiation per operand count)
         if (nops == 1) LMRL_LM_LAUNCH(1, true, true); else if (nops == 2) LMRL_LM_LAUNCH(2, true, true); else LMRL_LM_LAUNCH(3, true, true);
@@ -1316,8 +1336,11 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
         // from the SAME tile kernel (bit-identical logits, steer included; greedy flag: no noise is drawn), then the materialised selection on those rows
         SampleParams sg = sp;
         sg.greedy = 1;
-        hipLaunchKernelGGL((lm_head_sample_kernel<1, false, false, false, true>), dim3(tiles_n), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, q_b2_d,
-                           steer_tok_d, (float *)nullptr, logits_out_d, m, vocab_padded, d_model, vocab_padded, sg, xm, (const int32_t *)(fb + kFbHeader), (int32_t *)nullptr);
+#define LMRL_FLAGGED_LAUNCH(NOPS_) hipLaunchKernelGGL((lm_head_sample_kernel<NOPS_, false, false, false, true>), dim3(tiles_n), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, \
+                                                      W1, q_b1_d, A2, W2, q_b2_d, steer_tok_d, (float *)nullptr, logits_out_d, m, vocab_padded, d_model, vocab_padded, sg, xm,   \
+                                                      (const int32_t *)(fb + kFbHeader), (int32_t *)nullptr)
+        if (nops == 1) LMRL_FLAGGED_LAUNCH(1); else if (nops == 2) LMRL_FLAGGED_LAUNCH(2); else LMRL_FLAGGED_LAUNCH(3);
+#undef LMRL_FLAGGED_LAUNCH
         LMRL_CHECK_LAUNCH();
         launch_topk_sample(logits_out_d, vocab_padded, m, vocab, p->top_k, p->top_p, active_d, token_d, logprob_d, sp, p->pad_token, s, fb + kFbHeader + kFbMaxBlocks, fb);
     }

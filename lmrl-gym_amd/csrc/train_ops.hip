@@ -35,11 +35,18 @@ __device__ __forceinline__ float wave_max(float x) {
 // ------------------------------------------------------------------------------------------ embeddings
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const float *__restrict__ wte, const float *__restrict__ wpe,
                                                         const int32_t *__restrict__ ids, const int32_t *__restrict__ pos,
-                                                        float *__restrict__ x, int R, int d) {
+                                                        float *__restrict__ x, int R, int d, int vocab) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= R) return;
-    const float *te = wte + (size_t)ids[r] * d, *pe = wpe + (size_t)pos[r] * d;
-    for (int c = lane * 4; c < d; c += 256) *reinterpret_cast<v4f *>(x + (size_t)r * d + c) = *reinterpret_cast<const v4f *>(te + c) + *reinterpret_cast<const v4f *>(pe + c);
+    // ids outside [0, vocab) — the pad id of a tokenizer whose `<|pad|>` is the first id AFTER the model's vocabulary (train_ppo_gpt2.py:124-126; the
+    // reference resizes the embedding and masks those logits to -inf, ppo/gpt2/interface.py:330) — embed as a zero row and receive no gradient
+    const int id = ids[r];
+    const bool in = vocab <= 0 || (id >= 0 && id < vocab);
+    const float *te = wte + (size_t)(in ? id : 0) * d, *pe = wpe + (size_t)pos[r] * d;
+    for (int c = lane * 4; c < d; c += 256) {
+        const v4f e = in ? *reinterpret_cast<const v4f *>(te + c) : v4f{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<v4f *>(x + (size_t)r * d + c) = e + *reinterpret_cast<const v4f *>(pe + c);
+    }
 }
 // Row compaction for the vocabulary-wide heads: the RL losses read the Q / policy logits only on rows whose mask is set (should_take_action x
 // attention mask), so the heads run on the gathered rows and their input gradient is scattered back.  idx holds DISTINCT rows: no atomics.
@@ -73,26 +80,35 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float *__restri
 // `live` (optional, uint8 [R]): rows whose flag is 0 take no part — the padded positions of a right-padded batch (attention_mask == 0).  Their dx
 // is exactly zero (masked as keys, never read by a loss term), but they all carry the SAME token id (pad) and position: without the flag one
 // wave adds ~B (T - len) zero rows serially (30 k rows at B = 32, T = 1024 with 70-token episodes: 80 ms of a 124 ms PPO step).
+// A row with flag 0 can still carry a gradient when the NEXT position of its sequence is attended: the PPO / BC losses read row t's logits wherever
+// attention_mask[t + 1] is set (ppo/base_interface.py:208-214), which with left padding or a mask with holes includes rows whose own flag is 0.
+// `t_row` > 0 (the sequence length T of a [B, T] batch) makes such rows live too: live(r) = flag[r] | (flag[r + 1] within the same sequence) — for
+// a right-padded batch exactly the flagged rows.  Token ids outside [0, vocab) (embed_fwd_kernel) own no table row.
+__device__ __forceinline__ bool embed_row_live(const uint8_t *__restrict__ live, int j, int t_row) {
+    if (!live || live[j]) return true;
+    return t_row > 0 && (j + 1) % t_row != 0 && live[j + 1] != 0;
+}
 template <int NPL>   // floats per lane: d <= 64 * NPL
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float *__restrict__ dx, const int32_t *__restrict__ ids,
                                                         const int32_t *__restrict__ pos, const uint8_t *__restrict__ live, float *__restrict__ dwte,
-                                                        float *__restrict__ dwpe, int R, int d) {
+                                                        float *__restrict__ dwpe, int R, int d, int vocab, int t_row) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= R) return;
-    if (live && !live[r]) return;
+    if (!embed_row_live(live, r, t_row)) return;
     const int32_t *idx = blockIdx.y ? pos : ids;
     float *table = blockIdx.y ? dwpe : dwte;
     const int id = idx[r];
+    if (!blockIdx.y && vocab > 0 && (id < 0 || id >= vocab)) return;                      // zero embedding row: no parameter behind it
     for (int base = 0; base < r; base += 64) {
         const int j = base + lane;
-        if (__ballot(j < r && idx[j] == id && (!live || live[j]))) return;               // an earlier row owns this index (wave-uniform exit)
+        if (__ballot(j < r && idx[j] == id && embed_row_live(live, j, t_row))) return;      // an earlier row owns this index (wave-uniform exit)
     }
     float acc[NPL];
 #pragma unroll
     for (int k = 0; k < NPL; k++) acc[k] = lane + 64 * k < d ? dx[(size_t)r * d + lane + 64 * k] : 0.f;
     for (int base = r + 1; base < R; base += 64) {
         const int j = base + lane;
-        unsigned long long m = __ballot(j < R && idx[j] == id && (!live || live[j]));
+        unsigned long long m = __ballot(j < R && idx[j] == id && embed_row_live(live, j, t_row));
         while (m) {
             const int b = __ffsll((long long)m) - 1;
             m &= m - 1;
@@ -697,20 +713,21 @@ using namespace lmrl;
 
 extern "C" {
 
-int lmrl_embed_fwd(const float *wte_d, const float *wpe_d, const int32_t *ids_d, const int32_t *pos_d, float *x_d, int rows, int d, void *stream) {
+int lmrl_embed_fwd(const float *wte_d, const float *wpe_d, const int32_t *ids_d, const int32_t *pos_d, float *x_d, int rows, int d, int vocab,
+                   void *stream) {
     LMRL_REQUIRE(wte_d && wpe_d && ids_d && pos_d && x_d && rows > 0 && d % 4 == 0, "lmrl_embed_fwd: bad argument");
-    hipLaunchKernelGGL(embed_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, wte_d, wpe_d, ids_d, pos_d, x_d, rows, d);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, ST, wte_d, wpe_d, ids_d, pos_d, x_d, rows, d, vocab);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }
 int lmrl_embed_bwd(const float *dx_d, const int32_t *ids_d, const int32_t *pos_d, const uint8_t *live_d, float *dwte_d, float *dwpe_d, int rows, int d,
-                   void *stream) {
+                   int vocab, int t_row, void *stream) {
     LMRL_REQUIRE(dx_d && ids_d && pos_d && dwte_d && dwpe_d && rows > 0, "lmrl_embed_bwd: bad argument");
     LMRL_REQUIRE(d <= 64 * 32, "lmrl_embed_bwd: d_model up to 2048");
     const dim3 grid(ceil_div(rows, 4), 2);
-    if (d <= 64 * 12) hipLaunchKernelGGL(embed_bwd_kernel<12>, grid, dim3(256), 0, ST, dx_d, ids_d, pos_d, live_d, dwte_d, dwpe_d, rows, d);
-    else if (d <= 64 * 20) hipLaunchKernelGGL(embed_bwd_kernel<20>, grid, dim3(256), 0, ST, dx_d, ids_d, pos_d, live_d, dwte_d, dwpe_d, rows, d);
-    else hipLaunchKernelGGL(embed_bwd_kernel<32>, grid, dim3(256), 0, ST, dx_d, ids_d, pos_d, live_d, dwte_d, dwpe_d, rows, d);
+    if (d <= 64 * 12) hipLaunchKernelGGL(embed_bwd_kernel<12>, grid, dim3(256), 0, ST, dx_d, ids_d, pos_d, live_d, dwte_d, dwpe_d, rows, d, vocab, t_row);
+    else if (d <= 64 * 20) hipLaunchKernelGGL(embed_bwd_kernel<20>, grid, dim3(256), 0, ST, dx_d, ids_d, pos_d, live_d, dwte_d, dwpe_d, rows, d, vocab, t_row);
+    else hipLaunchKernelGGL(embed_bwd_kernel<32>, grid, dim3(256), 0, ST, dx_d, ids_d, pos_d, live_d, dwte_d, dwpe_d, rows, d, vocab, t_row);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

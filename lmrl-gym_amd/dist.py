@@ -218,14 +218,24 @@ def reduce_stat_partials(sums, mins, maxs, group=None):
     return tuple(out)
 
 
-def whiten_distributed(x, mask, shift_mean: bool = True, group=None):
+def whiten_distributed(x, mask, shift_mean: bool = True, group=None, partials=None):
     """`whiten` over the action tokens of ALL ranks (ppo/base_interface.py:609-615): local moments on the device
-    (lmrl_whiten_moments), one 3-double all-reduce, local apply (lmrl_whiten_apply)."""
+    (lmrl_whiten_moments), one 3-double all-reduce, local apply (lmrl_whiten_apply).
+    partials (float64 [n, 3], optional): the per-workgroup partial moments `lmrl_gae_moments` left beside these advantages — no moments pass
+    re-reads x: one rank applies straight from the partials (one launch), several ranks finish them (lmrl_whiten_finish) and all-reduce."""
     import torch
     from . import _lib
     L = _lib.lib()
+    if partials is not None and not is_distributed():
+        y = torch.empty_like(x)
+        _lib.check(L.lmrl_whiten_apply_partials(x.data_ptr(), _lib.ptr(mask), partials.data_ptr(), int(partials.shape[0]), y.data_ptr(), x.numel(),
+                                                int(shift_mean), _lib.stream_ptr()), "lmrl_whiten_apply_partials")
+        return y
     mom = torch.zeros(3, dtype=torch.float64, device=x.device)
-    _lib.check(L.lmrl_whiten_moments(x.data_ptr(), _lib.ptr(mask), mom.data_ptr(), x.numel(), _lib.stream_ptr()))
+    if partials is not None:
+        _lib.check(L.lmrl_whiten_finish(partials.data_ptr(), int(partials.shape[0]), mom.data_ptr(), _lib.stream_ptr()), "lmrl_whiten_finish")
+    else:
+        _lib.check(L.lmrl_whiten_moments(x.data_ptr(), _lib.ptr(mask), mom.data_ptr(), x.numel(), _lib.stream_ptr()))
     allreduce_sum_(mom, group)
     y = torch.empty_like(x)
     _lib.check(L.lmrl_whiten_apply(x.data_ptr(), _lib.ptr(mask), mom.data_ptr(), y.data_ptr(), x.numel(), int(shift_mean), _lib.stream_ptr()))

@@ -54,10 +54,12 @@ class _CConfig(ctypes.Structure):
 class SampleParams(ctypes.Structure):
     _fields_ = [("temperature", ctypes.c_float), ("top_k", ctypes.c_int32), ("seed", ctypes.c_uint64),
                 ("step", ctypes.c_uint32), ("steer_strength", ctypes.c_float), ("beta", ctypes.c_float),
-                ("pad_token", ctypes.c_int32), ("epoch_d", ctypes.c_void_p), ("top_p", ctypes.c_float), ("rng", ctypes.c_int32)]
+                ("pad_token", ctypes.c_int32), ("epoch_d", ctypes.c_void_p), ("top_p", ctypes.c_float), ("rng", ctypes.c_int32),
+                ("flags", ctypes.c_int32)]
 
 
 RNG_PHILOX, RNG_JAX = 0, 1       # lmrl_sample_params.rng
+SAMPLE_WANT_LOGITS = 1           # lmrl_sample_params.flags: materialise logits_out even where the fused top-k path would not
 
 
 class _CKVPrefix(ctypes.Structure):      # lmrl_kv_prefix (include/lmrl_amd.h)
@@ -273,6 +275,8 @@ class KVSession:
     def sample(self, params: SampleParams, steer_tok=None, active=None, hidden=None, logits_out=None,
                q1=None, q2=None, want_logprob: bool = True):
         """Fused LM head + sampling of one token per env from `hidden` (default: last_hidden).
+        logits_out: with 0 < top_k <= 64 on the Philox stream the call keeps candidates, not logits (logits_out is then only scratch for rows handed
+        back to the materialised selection); set `params.flags = SAMPLE_WANT_LOGITS` to have the logits written there as well.
         q1/q2: optional (q_hidden bf16 [B][d], w bf16 [Vp][d], bias f32 [Vp]) ILQL operands.
         want_logprob=False skips the log-sum-exp over the vocabulary (the reference's sampling step returns only the token;
         rollouts do not use the sampled token's log-probability) and returns (token, None)."""

@@ -155,7 +155,7 @@ class KVSessionF32:
         w["ids"].copy_(tokens.view(-1)[:R])
         _lib.check(L.lmrl_chunk_begin_f32(_lib.ptr(self.len), _lib.ptr(cnt), _lib.ptr(w["ids"]), _lib.ptr(w["pos"]), B, C, c.n_pos, sp), "lmrl_chunk_begin_f32")
         x, h, qkv, att, ff = w["x"], w["h"], w["qkv"], w["att"], w["ff"]
-        ops.embed_fwd(e.wte, e.wpe, w["ids"], w["pos"], x, R, d)
+        ops.embed_fwd(e.wte, e.wpe, w["ids"], w["pos"], x, R, d, vocab=c.vocab_padded)     # rows >= cfg.vocab of the engine table are zero; dead slots carry id 0
         r, pending = w["r"], None              # residual adds ride in the LayerNorm launch behind them (lmrl_layernorm_add_fwd: x += pending, then LN)
         x3 = e.matmul == "bf16x3" and d % 256 == 0 and d <= 1280      # bf16x3: LayerNorm / gelu write the three-term split operand themselves
 

@@ -357,11 +357,7 @@ class MazeRolloutEngine:
             last_kind = kind[np.arange(actual), np.maximum(nt - 1, 0)]
             stats.append(np.stack([self.traj["ep_reward"][:actual].cpu().numpy().astype(np.float64), ((last_kind == 1) | (last_kind == 2)).astype(np.float64),
                                    nt.astype(np.float64)]))
-        if len(parts) > 1:
-            T = max(p.input_ids.shape[1] for p in parts)
-            assert all(p.input_ids.shape[1] == T for p in parts), "batches of one round share the blocking width (pass max_length)"
-        cat = (lambda name: getattr(parts[0], name)) if len(parts) == 1 else (lambda name: torch.cat([getattr(p, name) for p in parts]))
-        ds = DevicePPODataset(longest=max(p.longest for p in parts), **{name: cat(name) for name in DevicePPODataset.FIELDS})
+        ds = DevicePPODataset.concat(parts)
         if use_advantage_whitening:
             adv = ds.old_advantages
             ds.old_advantages = D.whiten_distributed(adv.view(-1), ds.should_take_action.view(-1), shift_mean=True).view(adv.shape)

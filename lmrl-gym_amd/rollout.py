@@ -79,7 +79,8 @@ class WordleTokenTable:
     strings: dict = field(default_factory=dict)   # id -> decoded string (for the class table)
 
     @classmethod
-    def default_gpt2(cls, pad: int = 50256) -> "WordleTokenTable":
+    def default_gpt2(cls, pad: int = 50257) -> "WordleTokenTable":
+        """pad = 50257: the `<|pad|>` the task scripts add to the GPT-2 tokenizer (train_ppo_gpt2.py:124-126) — the first id after the vocabulary."""
         lf = [gpt2_byte_token_id(97 + i) for i in range(26)]          # 'a'..'z' = 64..89 (derived, see gpt2_byte_token_id)
         ls = list(_GPT2_SP_LETTERS)
         nl, colon = gpt2_byte_token_id(10), gpt2_byte_token_id(58)    # 198, 25
@@ -163,7 +164,10 @@ class WordleRolloutEngine:
                                q1_head=q1_head, q2_head=q2_head, beta=beta)
         self._lanes = None           # text_env_eval(concurrent=n): [(engine, stream)], this engine first
         self.episodes = 0            # eager episodes run by text_env_eval over this engine's life: part of the sampler stream key
-        self.tokens = tokens or WordleTokenTable.default_gpt2(pad=engine.cfg.vocab - 1)
+        # the pad id is the first id AFTER the policy's vocabulary, as in the reference: the task scripts add `<|pad|>` to the tokenizer (id 50257,
+        # train_ppo_gpt2.py:124-126) and the model forces every logit >= unpadded_vocab_size to -inf (ppo/gpt2/interface.py:330), so a policy can never
+        # draw it.  Here the sampler draws from [0, cfg.vocab) and the engine's embedding table has zero rows from cfg.vocab on
+        self.tokens = tokens or WordleTokenTable.default_gpt2(pad=engine.cfg.vocab)
         self.max_new, self.cap = max_new_tokens, traj_cap
         self.dev = engine.device
         self._L = _lib.lib()
@@ -376,14 +380,18 @@ class WordleRolloutEngine:
     def ppo_data(self, inference, *, gamma: float, lam: float, kl_weight: float, max_length: Optional[int] = None, n: Optional[int] = None, **kw):
         """`ppo_dataset_loader` of the task script on the episode this engine just ran (train_ppo_gpt2.py:301-353 -> ppo/base_interface.py:464-669),
         without host text, re-tokenisation or materialised logits -> (DevicePPODataset, all_kls device tensor); see `ppo_device.ppo_data_from_records`.
-        The script's length rule (episodes whose tokenisation reaches `max_length` lose their last turns) cannot trigger when max_length exceeds the
-        longest possible episode (checked); a Wordle episode always has its three texts."""
-        from .algorithms.ppo_device import ppo_data_from_records
+        The script's length rule (train_ppo_gpt2.py:323-341: an episode whose token count reaches `max_length` loses its last (action, observation)
+        pairs, their discounted reward goes to the previous action, `done` becomes False; episodes left with fewer than three texts are skipped) is
+        applied to the records on the device whenever `max_length` does not exceed the longest possible episode (`ppo_device.truncate_turns`); the
+        dataset then has one row per KEPT episode, in env order."""
+        from .algorithms.ppo_device import ppo_data_from_records, truncate_turns
+        rec = self.ppo_records(n)
         longest = min(self.cap, len(self.tokens.header) + W.N_TRIES * (self.max_new + 1 + 6))   # header + 6 x (action + forced '\n' + 'g y b b y\n')
         if max_length is not None and max_length <= longest:
-            raise ValueError(f"max_length = {max_length} does not exceed the longest possible episode ({longest} tokens): the script's drop-the-last-turns "
-                             "rule (train_ppo_gpt2.py:323-338) could apply — use the host path for such lengths")
-        return ppo_data_from_records(inference, self.ppo_records(n), gamma=gamma, lam=lam, kl_weight=kl_weight, max_length=max_length, **kw)
+            rec, info = truncate_turns(rec, int(max_length), gamma)
+            if kw.get("timings") is not None:
+                kw["timings"].update(episodes_shortened=info["shortened"], episodes_skipped=info["skipped"])
+        return ppo_data_from_records(inference, rec, gamma=gamma, lam=lam, kl_weight=kl_weight, max_length=max_length, **kw)
 
     def ppo_rollouts(self, inference, n_rollouts: int, seed_generator=None, *, gamma: float, lam: float, kl_weight: float, max_length: Optional[int] = None,
                      use_advantage_whitening: bool = True, temperature: float = 1.0, sample_seed: int = 0, use_graph: Optional[bool] = None,
@@ -431,8 +439,7 @@ class WordleRolloutEngine:
                 t_roll += e0.elapsed_time(e1)
             parts.append(ds); kls.append(kl)
             stats.append(np.stack([self.traj[name][:n_k].cpu().numpy().astype(np.float64) for name in ("ep_reward", "env_done", "n_steps")]))
-        cat = (lambda name: parts[0].__dict__[name]) if len(parts) == 1 else (lambda name: torch.cat([p.__dict__[name] for p in parts]))
-        ds = DevicePPODataset(longest=max(p.longest for p in parts), **{name: cat(name) for name in DevicePPODataset.FIELDS})
+        ds = DevicePPODataset.concat(parts)
         if use_advantage_whitening:
             adv = ds.old_advantages
             ds.old_advantages = D.whiten_distributed(adv.view(-1), ds.should_take_action.view(-1), shift_mean=True).view(adv.shape)

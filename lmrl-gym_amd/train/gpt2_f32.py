@@ -197,11 +197,12 @@ class GPT2F32:
         return x_out, (x_mid if fuse_add else None), c
 
     # ------------------------------------------------------------------ forward
-    def forward(self, input_ids, attention_mask, position_ids, tag: str = "fwd", inference: bool = False):
+    def forward(self, input_ids, attention_mask, position_ids, tag: str = "fwd", inference: bool = False, restage: bool = True):
         """input_ids / position_ids int32 [B,T], attention_mask uint8 [B,T] -> (final hidden [B*T, d], cache).  inference: the cache will not be
-        differentiated (`backward` must not be called on it): see `_layer_forward`."""
+        differentiated (`backward` must not be called on it): see `_layer_forward`.  restage=False (bf16-matmul mode): the caller knows that the fp32
+        masters have not moved since this model's previous forward (the chunk forwards of one PPO data build) — the bf16 operand copies are kept."""
         t = self.t
-        if self.mm is not None:
+        if self.mm is not None and restage:
             self.mm.begin_step()          # the optimizer may have moved the fp32 masters since the last forward: re-stage the bf16 copies
             self._stage_weights(True)     # ... of every block's Dense kernels, one launch (the forward operands; backward() adds the dX operands)
         B, T = input_ids.shape
@@ -212,7 +213,7 @@ class GPT2F32:
         km = attention_mask.to(t.uint8).contiguous()
         new = lambda *shape: t.empty(shape, dtype=t.float32, device=self.dev)
         x = new(R, d)
-        ops.embed_fwd(p["wte.weight"], p["wpe.weight"], ids, pos, x, R, d)
+        ops.embed_fwd(p["wte.weight"], p["wpe.weight"], ids, pos, x, R, d, vocab=self.vocab)
         cache = dict(B=B, T=T, ids=ids, pos=pos, km=km, layers=[], inference=bool(inference))
         flash = self.attention == "flash" and hd == 64
         lse_n = 0
@@ -424,8 +425,9 @@ class GPT2F32:
             if on_final is not None:
                 on_final([q + n for n in ("mlp.c_proj.weight", "mlp.c_proj.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "ln_2.weight", "ln_2.bias",
                                           "attn.c_proj.weight", "attn.c_proj.bias", "attn.c_attn.weight", "attn.c_attn.bias", "ln_1.weight", "ln_1.bias")])
-        # padded positions (attention_mask 0) are never read by a loss term nor attended to: their dx is exactly zero — skipped (ops.embed_bwd)
-        ops.embed_bwd(dx, cache["ids"], cache["pos"], grads["wte.weight"], grads["wpe.weight"], R, d, live=cache["km"])
+        # positions with attention_mask 0 whose NEXT position is masked too are never read by a loss term nor attended to: their dx is exactly zero —
+        # skipped (ops.embed_bwd; with right padding that is every padded position, with left padding / holes the row before an attended one stays)
+        ops.embed_bwd(dx, cache["ids"], cache["pos"], grads["wte.weight"], grads["wpe.weight"], R, d, live=cache["km"], vocab=self.vocab, t_row=cache["T"])
         if on_final is not None:
             on_final(["wpe.weight", "wte.weight"])
         return grads

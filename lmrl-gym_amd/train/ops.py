@@ -460,13 +460,16 @@ def adamw_segments(p, g, m, v, seg_end, seg_wd, lr, b1, b2, eps, step, target=No
                                                None if target is None else target.data_ptr(), float(alpha), float(1.0 - alpha), _sp()), "lmrl_adamw_segments")
 
 
-def embed_fwd(wte, wpe, ids, pos, x, rows, d):
-    _lib.check(_L().lmrl_embed_fwd(wte.data_ptr(), wpe.data_ptr(), ids.data_ptr(), pos.data_ptr(), x.data_ptr(), rows, d, _sp()), "lmrl_embed_fwd")
+def embed_fwd(wte, wpe, ids, pos, x, rows, d, vocab=0):
+    """vocab > 0: rows of `wte`; ids outside [0, vocab) (a pad id beyond the model's vocabulary) embed as a zero row."""
+    _lib.check(_L().lmrl_embed_fwd(wte.data_ptr(), wpe.data_ptr(), ids.data_ptr(), pos.data_ptr(), x.data_ptr(), rows, d, int(vocab), _sp()), "lmrl_embed_fwd")
 
 
-def embed_bwd(dx, ids, pos, dwte, dwpe, rows, d, live=None):
-    """live (uint8 [rows], optional): the attention mask — padded rows (flag 0) are skipped (their dx is exactly zero)."""
-    _lib.check(_L().lmrl_embed_bwd(dx.data_ptr(), ids.data_ptr(), pos.data_ptr(), _lib.ptr(live), dwte.data_ptr(), dwpe.data_ptr(), rows, d, _sp()), "lmrl_embed_bwd")
+def embed_bwd(dx, ids, pos, dwte, dwpe, rows, d, live=None, vocab=0, t_row=0):
+    """live (uint8 [rows], optional): the attention mask — rows with flag 0 are skipped (their dx is exactly zero) unless, with t_row = T of the
+    [B, T] batch, the next position of their sequence is attended (a loss term reads them then: left padding, masks with holes)."""
+    _lib.check(_L().lmrl_embed_bwd(dx.data_ptr(), ids.data_ptr(), pos.data_ptr(), _lib.ptr(live), dwte.data_ptr(), dwpe.data_ptr(), rows, d, int(vocab),
+                                   int(t_row), _sp()), "lmrl_embed_bwd")
 
 
 def softmax_causal_fwd(s, key_mask, p, batch, heads, t):

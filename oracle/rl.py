@@ -279,6 +279,37 @@ def ilql_data_from_chain(chain: List[dict]) -> dict:
                 rewards=list(cur["reward"][1:]), done=bool(cur["done"]), next_token_ids=next_token_ids, next_done=next_done)
 
 
+def truncate_turns_record(rec: dict, max_length: int, gamma: float) -> Optional[dict]:
+    """The task scripts' length rule (llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py:323-341) on ONE token record
+    {tokens, is_action, reward, done} of a single-trajectory chain, where a "text" is a maximal run of equal is_action flags and a text's
+    reward sits on its last token (environment.py:349-380).  Returns the kept record, or None when the script skips the episode.
+    PINNED against tests/golden/ppo_truncation.json (the reference's own loop executed, tests/test_oracle_rl.py)."""
+    tokens, ia = list(rec["tokens"]), [bool(x) for x in rec["is_action"]]
+    starts = [0] + [t for t in range(1, len(tokens)) if ia[t] != ia[t - 1]] if tokens else []
+    ends = starts[1:] + [len(tokens)]
+    reward = [float(np.float32(rec["reward"][e - 1])) for e in ends]          # one Python float per text, :319
+    done = bool(rec["done"])
+    n_items = len(starts)
+    while n_items > 3:                                                         # :323
+        if ends[n_items - 1] >= max_length:                                    # tokens of the (current) trajectory, :324
+            new_reward = reward[:n_items][:-2]
+            new_reward[-2] += sum(reward[:n_items][-2:]) * gamma               # :325-326
+            reward[:n_items - 2] = new_reward
+            n_items -= 2
+            done = False                                                       # :327-332
+        else:
+            break
+    if n_items < 3:                                                            # :336-337
+        return None
+    n = ends[n_items - 1]
+    if n >= max_length:                                                        # :338-339
+        return None
+    out_r = [0.0] * n
+    for k in range(n_items):
+        out_r[ends[k] - 1] = float(np.float32(reward[k]))                      # np.array(reward, dtype=np.float32), environment.py:377
+    return dict(tokens=tokens[:n], is_action=[int(x) for x in ia[:n]], reward=out_r, done=done)
+
+
 def combined_chain(chain: List[dict], max_length: Optional[int] = None) -> dict:
     """CombinedTokenTrajectoryChain.from_token_trajectory_chain (ppo/base_interface.py:303-336)."""
     if max_length is None:

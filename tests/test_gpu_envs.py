@@ -446,3 +446,41 @@ def test_whiten_kernel(dev, n):
         exp = x.copy(); exp[mask] = rl.whiten(x[mask], shift_mean=bool(shift))
         np.testing.assert_allclose(got, exp, rtol=1e-5, atol=1e-5)
         assert mom.cpu().numpy()[2] == mask.sum()
+
+
+@pytest.mark.parametrize("B,L", [(4096, 96), (777, 70), (65536, 96), (50, 128)])
+def test_gae_with_fused_whitening_moments(dev, B, L):
+    """`lmrl_gae_moments` (the GAE launch also leaves per-workgroup partial moments of the advantages on action slots) + `lmrl_whiten_apply_partials`
+    (every workgroup adds the partials in a fixed order, then applies) == `lmrl_gae` + `lmrl_whiten_moments` + `lmrl_whiten_apply`: advantages and
+    returns bit for bit (the same scan), the moments to fp64 rounding, the whitened advantages to 1 ulp-ish; `lmrl_whiten_finish` gives ranks
+    the three moments to all-reduce.  Odd row starts of `values` (L + 1 floats per row) are read as unaligned 8-byte pairs."""
+    from lmrl_gym_amd import _lib
+    Lb = _lib.lib()
+    rng = np.random.RandomState(B + L)
+    sta, lens, values, rewards = _chains(rng, B, L)
+    dv = lambda x: torch.from_numpy(x).to(dev)
+    v_d, r_d, s_d, l_d = dv(values), dv(rewards), dv(sta.astype(np.uint8)), dv(lens)
+    sp, p = _lib.stream_ptr, _lib.ptr
+    adv0, ret0, adv1, ret1 = (torch.full((B, L), 7.0, device=dev) for _ in range(4))
+    _lib.check(Lb.lmrl_gae(p(v_d), p(r_d), p(s_d), p(l_d), p(adv0), p(ret0), B, L, 0.99, 0.95, sp()))
+    npart = Lb.lmrl_gae_moments_partials(B, L)
+    assert npart == -(-B // 16)
+    part = torch.zeros(npart, 3, dtype=torch.float64, device=dev)
+    _lib.check(Lb.lmrl_gae_moments(p(v_d), p(r_d), p(s_d), p(l_d), p(adv1), p(ret1), B, L, 0.99, 0.95, p(part), sp()))
+    assert torch.equal(adv0, adv1) and torch.equal(ret0, ret1)
+    mom0, mom1 = torch.zeros(3, dtype=torch.float64, device=dev), torch.zeros(3, dtype=torch.float64, device=dev)
+    mask = s_d.view(-1)
+    _lib.check(Lb.lmrl_whiten_moments(p(adv0), p(mask), p(mom0), B * L, sp()))
+    _lib.check(Lb.lmrl_whiten_finish(p(part), npart, p(mom1), sp()))
+    m0, m1 = mom0.cpu().numpy(), mom1.cpu().numpy()
+    a = adv0.cpu().numpy().astype(np.float64)[sta]
+    assert m1[2] == m0[2] == sta.sum()
+    np.testing.assert_allclose(m1[:2], [a.sum(), (a * a).sum()], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(m1, m0, rtol=1e-12, atol=1e-9)
+    for shift in (1, 0):
+        y0, y1 = torch.empty_like(adv0), torch.empty_like(adv0)
+        _lib.check(Lb.lmrl_whiten_apply(p(adv0), p(mask), p(mom0), p(y0), B * L, shift, sp()))
+        _lib.check(Lb.lmrl_whiten_apply_partials(p(adv1), p(mask), p(part), npart, p(y1), B * L, shift, sp()))
+        np.testing.assert_allclose(y1.cpu().numpy(), y0.cpu().numpy(), rtol=1e-6, atol=1e-6)
+        assert (y1.cpu().numpy()[~sta] == 0).all()
+    assert Lb.lmrl_gae_moments_partials(100, 97) == 0 and Lb.lmrl_gae_moments_partials(100, 130) == 0

@@ -410,7 +410,7 @@ def test_fused_topk_candidate_path_equals_the_materialised_one(dev, B, vocab, d)
                     torch.cuda.synchronize()
                     outs.append((tok.cpu().numpy().copy(), lp.cpu().numpy().copy()))
                     if variant == 0:
-                        fb = ses.sample_ws[B * (cfg.vocab_padded // 128) * 64:].view(torch.int32)
+                        fb = ses.sample_ws[_lib.lib().lmrl_sample_fb_offset(B, cfg.vocab_padded):].view(torch.int32)
                         n_fb = int(fb[0].item())
                         flagged += n_fb
                         rows = fb[16 + 64: 16 + 64 + n_fb].cpu().numpy()
@@ -426,6 +426,126 @@ def test_fused_topk_candidate_path_equals_the_materialised_one(dev, B, vocab, d)
             assert flagged > 0, "the clustered vocabulary was meant to exercise the hand-back to the materialised path"
         elif clustered is False and vocab > 5000:
             assert flagged <= 2
+
+
+@pytest.mark.parametrize("B,vocab,d,nq", [(1024, 50257, 128, 2), (200, 9000, 128, 2), (130, 300, 128, 1), (300, 20000, 256, 2)])
+def test_fused_topk_for_the_ilql_value_policy_head(dev, B, vocab, d, nq):
+    """Round 6 (north_star: "fused token-sampling (top-k / logit-perturb from the ILQL Q-head)", value_rl_base/gpt2/generation.py:97-119): the candidate
+    epilogue on logits = pi_beta + beta * min(q1, q2) — candidates are taken after the perturbed logits are formed in registers — against the
+    materialised path of the same three-operand head (`lmrl_sampler_set_variant(2)`): every sampled token identical, log-probs to fp32 rounding;
+    one and two Q heads, top-k with / without top-p, steered and inactive rows, and a clustered vocabulary that forces the hand-back (whose
+    materialised logits are the three-operand ones)."""
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.gpt2 import SAMPLE_WANT_LOGITS, GPT2Config, GPT2Engine, SampleParams, init_hf_style_state_dict
+    L = _lib.lib()
+    cfg = GPT2Config(1, d // 64, d, 256, vocab, 32)
+    g = torch.Generator().manual_seed(vocab + nq)
+    hid = _bf(torch.randn(B, d, generator=g)).to(dev)
+    steer = torch.randint(0, vocab, (B,), generator=g).to(torch.int32); steer[::3] = -1
+    active = torch.ones(B, dtype=torch.uint8); active[5::17] = 0
+    steer, active = steer.to(dev), active.to(dev)
+    tiles_n = -(-vocab // 128)
+    qh = [_bf(torch.relu(torch.randn(B, d, generator=g))).to(dev) for _ in range(nq)]
+    for clustered in (False, True):
+        sd = init_hf_style_state_dict(cfg, seed=3)
+        w = sd["wte.weight"] * 20
+        qw = [torch.randn(cfg.vocab_padded, d, generator=g) * 0.3 for _ in range(nq)]
+        qb = [torch.randn(cfg.vocab_padded, generator=g).to(dev) for _ in range(nq)]
+        if clustered:                # the Q heads carry the cluster: twelve columns of one tile get most rows' largest PERTURBED logits
+            c0 = 128 * (tiles_n // 2) + 7 if tiles_n > 2 else 3
+            for i in range(12):
+                for k in range(nq):
+                    qw[k][c0 + 5 * i] = 0.35 + 0.01 * i
+        qw = [_bf(x).to(dev) for x in qw]
+        sd["wte.weight"] = w.to(torch.bfloat16).float()
+        eng = GPT2Engine(cfg, sd, dev)
+        ses = eng.session(B, 8)
+        q1 = (qh[0], qw[0], qb[0])
+        q2 = (qh[1], qw[1], qb[1]) if nq == 2 else None
+        lo = torch.zeros(B, cfg.vocab_padded, device=dev)
+        flagged = 0
+        for temp, top_k, top_p, strength, beta in [(1.0, 40, 0.0, 0.0, 1.0), (0.8, 50, 0.9, 0.0, 4.0), (1.0, 1, 0.0, 0.0, 0.5), (1.3, 64, 0.0, 6.0, 2.0), (0.7, 20, 0.95, 3.0, 16.0)]:
+            if top_k >= vocab:
+                continue
+            outs = []
+            for variant in (2, 0):
+                L.lmrl_sampler_set_variant(variant)
+                try:
+                    lo.fill_(float("nan"))
+                    sp = SampleParams(temp, top_k, 0xFEED, 9, strength, beta, 9, None, top_p, 0)
+                    tok, lp = ses.sample(sp, hidden=hid, steer_tok=steer, active=active, logits_out=lo, q1=q1, q2=q2)
+                    torch.cuda.synchronize()
+                    outs.append((tok.cpu().numpy().copy(), lp.cpu().numpy().copy()))
+                    if variant == 0:
+                        fb = ses.sample_ws[L.lmrl_sample_fb_offset(B, cfg.vocab_padded):].view(torch.int32)
+                        flagged += int(fb[0].item())
+                        assert torch.isnan(lo[:, 0]).sum().item() >= B - 128 * int(fb[0].item())       # no logits in HBM but the handed-back blocks'
+                    else:
+                        mat = lo.clone()
+                finally:
+                    L.lmrl_sampler_set_variant(0)
+            assert np.array_equal(outs[0][0], outs[1][0]), (clustered, temp, top_k, top_p, beta)
+            np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=2e-5)
+            assert (outs[0][0][active.cpu().numpy() == 0] == 9).all()
+        # LMRL_SAMPLE_WANT_LOGITS: the caller reads logits_out — materialised although top_k <= 64 (same tokens, the same logits as variant 2 wrote)
+        sp = SampleParams(0.7, 20, 0xFEED, 9, 3.0, 16.0, 9, None, 0.95, 0, SAMPLE_WANT_LOGITS)
+        lo.fill_(float("nan"))
+        tok, _ = ses.sample(sp, hidden=hid, steer_tok=steer, active=active, logits_out=lo, q1=q1, q2=q2)
+        torch.cuda.synchronize()
+        assert np.array_equal(tok.cpu().numpy(), outs[0][0]) and torch.equal(lo[:, :vocab], mat[:, :vocab])
+        if clustered and tiles_n > 2:
+            assert flagged > 0, "the clustered Q heads were meant to exercise the hand-back to the materialised three-operand path"
+
+
+@pytest.mark.parametrize("ilql", [False, True])
+def test_fused_topk_at_bench_size_against_the_float64_oracle(dev, ilql):
+    """The fused top-k path at the size the bench runs it (1024 rows x the GPT-2 vocabulary, d = 768), not against another HIP path but against
+    the warper SEMANTICS on float64 logits (HF TopK then softmax, train_ppo_gpt2.py:98-99, 218-227) and the documented noise stream
+    (oracle/gpt2.py::gumbel_noise): every sampled token lies in the oracle's top-k set (rows whose k-th / (k+1)-th logits are closer than the
+    bf16-product rounding are skipped), its log-probability is the renormalised one, and on the first 128 rows the token IS the oracle's
+    arg-max of logit / T + Gumbel over the kept set (near-ties of the perturbed scores skipped).  ilql: logits = pi + beta min(q1, q2)."""
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, SampleParams, init_hf_style_state_dict
+    from oracle import gpt2 as O
+    B, d, top_k, temp, beta = 1024, 768, 40, 0.9, 2.0
+    cfg = GPT2Config(1, 12, d, 3072, 50257, 32)
+    V = cfg.vocab
+    g = torch.Generator().manual_seed(77)
+    sd = init_hf_style_state_dict(cfg, seed=9)
+    sd["wte.weight"] = (sd["wte.weight"] * 6).to(torch.bfloat16).float()
+    eng = GPT2Engine(cfg, sd, dev)
+    ses = eng.session(B, 8)
+    hid = _bf(torch.randn(B, d, generator=g))
+    z = hid.double() @ sd["wte.weight"].double().t()                       # [B, V] float64 (bf16 operands: exact products)
+    q1 = q2 = None
+    if ilql:
+        qh = [_bf(torch.relu(torch.randn(B, d, generator=g))) for _ in range(2)]
+        qw = [_bf(torch.randn(cfg.vocab_padded, d, generator=g) * 0.05) for _ in range(2)]
+        qb = [torch.randn(cfg.vocab_padded, generator=g) * 0.5 for _ in range(2)]
+        qs = [qh[i].double() @ qw[i].double().t()[:, :V] + qb[i].double()[None, :V] for i in range(2)]
+        z = z + beta * torch.minimum(qs[0], qs[1])
+        q1, q2 = tuple(x.to(dev) for x in (qh[0], qw[0], qb[0])), tuple(x.to(dev) for x in (qh[1], qw[1], qb[1]))
+    lo = torch.zeros(B, cfg.vocab_padded, device=dev)
+    seed, step = 0xA5A5, 11
+    sp = SampleParams(temp, top_k, seed, step, 0.0, beta if ilql else 0.0, 3, None, 0.0, 0)
+    tok, lp = ses.sample(sp, hidden=hid.to(dev), logits_out=lo, q1=q1, q2=q2)
+    torch.cuda.synchronize()
+    tok, lp = tok.cpu().numpy(), lp.cpu().numpy()
+    zt = (z / temp).numpy()
+    srt = -np.sort(-zt, axis=1)[:, :top_k + 1]
+    clear = (srt[:, top_k - 1] - srt[:, top_k]) > 1e-3                       # the top-k boundary is decided beyond the fp32-accumulation noise (~3e-5 here)
+    assert clear.mean() > 0.9
+    kept = zt >= srt[:, top_k - 1:top_k]
+    assert kept[np.arange(B), tok][clear].all()
+    logp = zt - np.log(np.where(kept, np.exp(zt - srt[:, :1]), 0.0).sum(1, keepdims=True)) - srt[:, :1]
+    np.testing.assert_allclose(lp[clear], logp[np.arange(B), tok][clear], rtol=0, atol=3e-3)
+    n = 128
+    noise = O.gumbel_noise(n, V, seed, step).astype(np.float64)
+    score = np.where(kept[:n], zt[:n] + noise, -np.inf)
+    best = score.argmax(1)
+    top2 = -np.sort(-score, axis=1)[:, :2]
+    sure = clear[:n] & ((top2[:, 0] - top2[:, 1]) > 1e-3)
+    assert sure.mean() > 0.85 and (tok[:n][sure] == best[sure]).all()
+    assert len(set(tok.tolist())) > 200                                     # a real spread of draws, not one dominant column
 
 
 def test_sampler_steer_and_ilql_perturbation(dev):

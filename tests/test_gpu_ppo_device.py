@@ -109,10 +109,9 @@ def wordle_setup(dev):
     # draws against that: 41 .. 76-token episodes, valid and invalid words, 1 .. 7-token actions
     ro.run_episode(np.arange(B, dtype=np.uint64) + 40, temperature=1.0, sample_seed=3, scripted_guesses=guesses, steer_strength=24.0)
     torch.cuda.synchronize()
-    # the reference cuts a sequence at its first pad id (`unpad_array`); a random-init policy can sample the table's pad id as an ordinary token:
-    # such draws (~1e-5 of the tokens) are rewritten in the record so that both paths see legal input
-    tok = ro.traj["tokens"]
-    tok[tok == ro.tokens.pad] = 0
+    # the engine's pad id is the first id AFTER the policy's vocabulary (the reference's added `<|pad|>`, whose logit the model forces to -inf,
+    # ppo/gpt2/interface.py:330): it cannot be sampled, so the record needs no clean-up before the reference-shaped host path reads it
+    assert ro.tokens.pad == cfg.vocab and not bool((ro.traj["tokens"] == ro.tokens.pad).any())
     mk = lambda matmul: (GPT2F32(sd_pol, cfg.n_head, device=dev, matmul=matmul), GPT2F32(sd, cfg.n_head, device=dev, matmul=matmul))
     head = lambda: LinearHeadF32(dict(kernel=torch.randn(cfg.d_model, 1, generator=torch.Generator().manual_seed(2)) * 0.05, bias=torch.tensor([-0.3])), dev)
     pol, init = mk("f32")
@@ -161,14 +160,41 @@ def test_device_path_equals_host_form_on_engine_episodes(wordle_setup):
     h2 = ds2.to_host()
     assert h2.input_ids.shape == (s["B"], 160) and (h2.input_ids[:, max_length:] == inf.pad).all()
     np.testing.assert_allclose(h2.old_advantages[:, :max_length - 1], host2.old_advantages, rtol=1e-5, atol=1e-5)
-    with pytest.raises(ValueError):
-        ro.ppo_data(inf, max_length=76, **kw)                                        # <= 4 + 6 x (7 + 6) tokens: the script's drop-the-last-turns rule could apply
+    # max_length within reach of an episode: the script's drop-the-last-turns rule (train_ppo_gpt2.py:323-341) applies ON THE DEVICE — against the
+    # oracle's form of the rule on the same records (itself pinned to the reference's executed loop, tests/test_oracle_rl.py) + the host-array form
+    from lmrl_gym_amd import environment as E
+    from lmrl_gym_amd.algorithms import ppo
+    from lmrl_gym_amd.algorithms.common import BlockingStrategy, Padding, Truncation
+    from oracle import rl as ORL
+    ml = 60
+    assert (n_tok >= ml).sum() > 10 and (n_tok < ml).sum() > 10
+    tm = {}
+    ds3, kls3 = ro.ppo_data(inf, max_length=ml, timings=tm, **kw)
+    kept = [ORL.truncate_turns_record(dict(tokens=tok, is_action=ia, reward=rw, done=dn), ml, kw["gamma"]) for tok, ia, rw, dn in ro.token_trajectories()]
+    assert tm["episodes_shortened"] == sum(k is not None and len(k["tokens"]) < n for k, n in zip(kept, n_tok)) > 10
+    assert tm["episodes_skipped"] == sum(k is None for k in kept)
+    kept = [k for k in kept if k is not None]
+    chains3 = [E.TokenTrajectoryChain(E.TokenTrajectory(np.asarray(k["tokens"], np.int32), np.asarray(k["is_action"], bool), np.asarray(k["reward"], np.float32),
+                                                        np.asarray(k["done"])), None) for k in kept]
+    datas3, kls3_h = inf.get_ppo_data_from_token_trajectory_chain(chains3, bsize=32, max_length=ml, **kw)
+
+    class _Tok:
+        pad_token_id = inf.pad
+    host3 = ppo.PPODataset.from_ppo_data_list(datas3, _Tok, BlockingStrategy(Padding.RIGHT, Truncation.RIGHT, ml))
+    h3 = ds3.to_host()
+    assert h3.input_ids.shape == host3.input_ids.shape == (len(kept), ml)
+    assert (h3.input_ids == host3.input_ids).all() and (h3.should_take_action == host3.should_take_action).all()
+    np.testing.assert_allclose(h3.old_returns, host3.old_returns, rtol=1e-5, atol=1e-5)      # folded, discounted rewards + bootstrap values (done cleared)
+    np.testing.assert_allclose(h3.old_advantages, host3.old_advantages, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(kls3.cpu().numpy(), kls3_h, rtol=1e-5, atol=5e-6)
+    # the engine's own record is untouched by the rule (reward / n_tok / done are copied)
+    assert np.array_equal(ro.traj["n_tok"].cpu().numpy(), n_tok)
     # batches cut to the longest episode: the same rows, fewer padded columns
     w = ds.trimmed_width()
     assert ds.longest == int(n_tok.max()) and w == 128 and ds2.trimmed_width() == 128
     full, cut = ds2.batch(np.arange(8)), ds2.batch(np.arange(8), width=w)
     for k in full:
-        assert torch.equal(full[k][:, :cut[k].shape[1]], cut[k]) and cut[k].shape[1] == (w if k == "input_ids" else w - 1) and cut[k].is_contiguous()
+        assert torch.equal(full[k][:, :cut[k].shape[1]], cut[k]) and cut[k].shape[1] == (w if k in ("input_ids", "attention_mask", "position_ids") else w - 1) and cut[k].is_contiguous()
 
 
 def test_device_path_in_the_bf16_matmul_mode(wordle_setup):
@@ -309,3 +335,202 @@ def test_ppo_rollouts_round_and_online_iteration(wordle_setup):
     ds2, _, _ = ro.ppo_rollouts(inf, s["B"], seed_generator=iter(range(9000, 10 ** 6)), gamma=1.0, lam=0.95, kl_weight=0.001, max_length=ro.cap + 1,
                                 temperature=1.0, sample_seed=9, use_graph=True)          # the captured graph replays on the new weights
     assert len(ds2) == s["B"]
+
+
+def _records_from_dicts(recs, dev, cap=None):
+    from lmrl_gym_amd.algorithms.ppo_device import PPORecords
+    cap = cap or max(len(r["tokens"]) for r in recs)
+    n = len(recs)
+    tok, ia, rw = np.zeros((n, cap), np.int32), np.zeros((n, cap), np.uint8), np.zeros((n, cap), np.float32)
+    for k, r in enumerate(recs):
+        m = len(r["tokens"])
+        tok[k, :m], ia[k, :m], rw[k, :m] = r["tokens"], r["is_action"], r["reward"]
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return PPORecords(up(tok), up(ia), up(rw), up(np.array([len(r["tokens"]) for r in recs], np.int32)), up(np.array([r["done"] for r in recs], np.uint8)))
+
+
+def _dicts_from_records(rec):
+    tok, ia, rw = rec.tokens.cpu().numpy(), rec.is_action.cpu().numpy(), rec.reward.cpu().numpy()
+    n, dn = rec.n_tok.cpu().numpy(), rec.done.cpu().numpy()
+    return [dict(tokens=tok[k, :n[k]].tolist(), is_action=ia[k, :n[k]].astype(int).tolist(), reward=[float(x) for x in rw[k, :n[k]]], done=bool(dn[k]))
+            for k in range(rec.n)]
+
+
+def test_length_rule_on_the_device_equals_the_reference_loop(dev):
+    """`lmrl_ppo_truncate_turns` + row compaction against tests/golden/ppo_truncation.json — the reference script's own loop
+    (llm_rl_scripts/wordle/ppo/train_ppo_gpt2.py:317-341) EXECUTED on synthetic rollouts (make_truncation_fixture.py): kept episodes, their
+    tokens / flags, the folded float32 rewards and the cleared `done`, bit for bit; then larger random records against the oracle's form."""
+    from lmrl_gym_amd.algorithms.ppo_device import truncate_turns
+    from oracle import rl as ORL
+    fx = load_golden("ppo_truncation.json")
+    for case in fx["cases"]:
+        rec = _records_from_dicts(case["records"], dev)
+        before = rec.reward.clone()
+        out, info = truncate_turns(rec, case["max_length"], case["gamma"])
+        got = _dicts_from_records(out)
+        assert got == case["kept"], case["max_length"]
+        assert info["skipped"] == len(case["records"]) - len(case["kept"])
+        assert info["shortened"] >= sum(1 for g in got if not any(g["tokens"] == r["tokens"] for r in case["records"]))
+        assert torch.equal(rec.reward, before)                                   # the caller's record is not modified
+    # 3000 random records (up to 12 turns, cap 160, assorted rewards and gammas): device == oracle
+    rng = np.random.default_rng(3)
+    recs = []
+    for _ in range(3000):
+        toks, ia, rw = [1, 2, 3], [0, 0, 0], [0.0, 0.0, 0.0]
+        for turn in range(int(rng.integers(0, 13))):
+            na, no = int(rng.integers(1, 8)), int(rng.integers(1, 8))
+            toks += rng.integers(4, 90, size=na + no).tolist()
+            ia += [1] * na + [0] * no
+            rw += [0.0] * (na - 1) + [float(rng.choice([-1.0, 0.0, -10.0, 0.3, 2.5]))] + [0.0] * no
+        recs.append(dict(tokens=toks, is_action=ia, reward=rw, done=bool(rng.integers(0, 2))))
+    rec = _records_from_dicts(recs, dev, cap=3 + 12 * 14)
+    for ml, gamma in ((40, 0.9), (90, 1.0), (12, 0.37)):
+        exp = [k for k in (ORL.truncate_turns_record(r, ml, gamma) for r in recs) if k is not None]
+        out, info = truncate_turns(rec, ml, gamma)
+        got = _dicts_from_records(out)
+        assert len(got) == len(exp) == len(recs) - info["skipped"] and 0 < info["skipped"] < len(recs)
+        assert got == exp
+
+
+def test_reference_truncation_asserts_are_raised(wordle_setup, dev):
+    """CombinedTokenTrajectoryChain.from_token_trajectory_chain asserts 'trajectory truncation error' (ppo/base_interface.py:318-327) when max_length
+    cuts action tokens or a chain continues with an action token; the device path refuses the same inputs (it used to clip silently), and a
+    caller's chain_len_bound that is too short for its chains is an error instead of dropped GAE slots."""
+    from lmrl_gym_amd import environment as E
+    from lmrl_gym_amd.algorithms.ppo_device import PPORecords, ppo_data_from_records
+    s = wordle_setup
+    inf, ro = s["inf"], s["ro"]
+    kw = dict(gamma=1.0, lam=0.95, kl_weight=0.001)
+    with pytest.raises(ValueError, match="trajectory truncation error"):
+        ppo_data_from_records(inf, ro.ppo_records(), max_length=30, **kw)         # every episode has action tokens beyond 30 (the wrapper would apply the length rule first)
+    mk = lambda toks, ia, rw, dn: E.TokenTrajectory(np.asarray(toks, np.int32), np.asarray(ia, bool), np.asarray(rw, np.float32), np.asarray(dn))
+    a = mk([5, 6, 7, 8], [0, 0, 1, 1], [0, 0, 0, 1.0], False)
+    b_ok = mk([9, 10, 11], [0, 1, 1], [0, 0, -1.0], True)
+    b_bad = mk([9, 10, 11], [1, 1, 0], [0, 0.5, 0], True)
+    ds, _ = ppo_data_from_records(inf, PPORecords.from_token_trajectory_chains([E.TokenTrajectoryChain(a, E.TokenTrajectoryChain(b_ok, None))], device=dev), **kw)
+    assert len(ds) == 2
+    with pytest.raises(ValueError, match="trajectory truncation error"):
+        ppo_data_from_records(inf, PPORecords.from_token_trajectory_chains([E.TokenTrajectoryChain(a, E.TokenTrajectoryChain(b_bad, None))], device=dev), **kw)
+    rec = PPORecords.from_token_trajectory_chains([E.TokenTrajectoryChain(a, E.TokenTrajectoryChain(b_ok, None))], device=dev)
+    rec.chain_len_bound = 3                                                        # the chain has 3 + 2 slots
+    with pytest.raises(ValueError, match="chain_len_bound"):
+        ppo_data_from_records(inf, rec, **kw)
+
+
+def test_batches_carry_the_data_builds_own_masks(wordle_setup):
+    """A tokenizer whose pad id the policy CAN sample (not this package's default): a pad id inside a trajectory is an attended token of the data
+    build (lengths come from the records); the dataset hands those lengths to the train step as attention_mask / position_ids, so the first step
+    after a build still sees ratio == 1 — and the build warns."""
+    from lmrl_gym_amd.algorithms import ppo
+    from lmrl_gym_amd.algorithms.ppo_inference import GPT2PPOInference
+    s = wordle_setup
+    ro = s["ro"]
+    inside = int(ro.traj["tokens"][0, 6])                                           # an id that occurs inside trajectories: play "pad"
+    inf = GPT2PPOInference(s["inf"].policy, s["inf"].value_head, inside, initial_policy=s["inf"].initial_policy)
+    with pytest.warns(RuntimeWarning, match="INSIDE trajectories"):
+        ds, _ = ro.ppo_data(inf, gamma=1.0, lam=0.95, kl_weight=0.001, max_length=ro.cap + 1)
+    batch = ds.batch(np.arange(32))
+    n_tok = ro.traj["n_tok"][:32].cpu().numpy()
+    am = batch["attention_mask"].cpu().numpy()
+    assert (am.sum(1) == n_tok).all() and (am[:, :-1] >= am[:, 1:]).all()
+    assert ((batch["input_ids"].cpu().numpy() == inside) & (am != 0)).any()         # attended "pad" ids exist
+    pos = batch["position_ids"].cpu().numpy()
+    assert all((pos[b, :n] == np.arange(n)).all() and (pos[b, n:] == n - 1).all() for b, n in enumerate(n_tok))
+    tr = ppo.GPT2PPOTrain(inf.policy, inf.value_head, inside, dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0), lr=1e-5)
+    _, _, logs = tr.step(**batch, train=False)
+    assert abs(float(logs["ratio"]) - 1.0) < 1e-5 and abs(float(logs["policy"]["approx_kl"])) < 1e-5
+    masks_from_ids = {k: v for k, v in batch.items() if k not in ("attention_mask", "position_ids")}
+    _, _, logs2 = tr.step(**masks_from_ids, train=False)                            # the reference's `ids != pad` masks: a different sequence
+    assert abs(float(logs2["ratio"]) - 1.0) > 1e-4
+
+
+def test_embedding_rows_beyond_the_vocabulary_and_live_rows(dev):
+    """lmrl_embed_fwd: ids outside [0, vocab) (the pad id = first id after the vocabulary) embed as a zero row; lmrl_embed_bwd: they own no wte
+    row, and with t_row a row whose flag is 0 but whose next position is attended keeps its gradient (left padding / holes), == numpy."""
+    from lmrl_gym_amd.train import ops
+    rng = np.random.RandomState(0)
+    V, P, d, B, T = 37, 16, 128, 5, 9
+    R = B * T
+    wte, wpe = rng.randn(V, d).astype(np.float32), rng.randn(P, d).astype(np.float32)
+    ids = rng.randint(0, V + 2, size=R).astype(np.int32)
+    ids[::7] = V                                                                     # pad id
+    pos = rng.randint(0, P, size=R).astype(np.int32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    x = torch.empty(R, d, dtype=torch.float32, device=dev)
+    ops.embed_fwd(t(wte), t(wpe), t(ids), t(pos), x, R, d, vocab=V)
+    inb = (ids >= 0) & (ids < V)
+    exp = np.where(inb[:, None], wte[np.clip(ids, 0, V - 1)], 0.0) + wpe[pos]
+    assert np.array_equal(x.cpu().numpy(), exp.astype(np.float32))
+    am = (rng.rand(B, T) < 0.6).astype(np.uint8)
+    am[0] = [0, 0, 0, 1, 1, 1, 1, 1, 1]                                              # left padding
+    am[1] = [1, 1, 1, 1, 0, 0, 0, 0, 0]                                              # right padding
+    dx = rng.randn(R, d).astype(np.float32)
+    for t_row, live in ((0, am.reshape(-1) != 0), (T, (am != 0) | np.concatenate([am[:, 1:] != 0, np.zeros((B, 1), bool)], 1))):
+        live = np.asarray(live).reshape(-1)
+        dwte, dwpe = torch.zeros(V, d, device=dev), torch.zeros(P, d, device=dev)
+        ops.embed_bwd(t(dx), t(ids), t(pos), dwte, dwpe, R, d, live=t(am.reshape(-1).copy()), vocab=V, t_row=t_row)
+        e_wte, e_wpe = np.zeros((V, d), np.float64), np.zeros((P, d), np.float64)
+        for r in range(R):
+            if live[r]:
+                if inb[r]:
+                    e_wte[ids[r]] += dx[r]
+                e_wpe[pos[r]] += dx[r]
+        np.testing.assert_allclose(dwte.cpu().numpy(), e_wte, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(dwpe.cpu().numpy(), e_wpe, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("matmul", ["f32", "bf16"])
+def test_device_ppo_data_at_gpt2_small_size_equals_the_host_form(dev, matmul):
+    """The size `bench.py`'s ppo_iteration leg times, minus a factor 4 in envs: GPT-2-small (bench weights, a policy a few updates away from the
+    initial policy), 256 lock-step envs, real steered episodes of the device engine, the script's blocking width.  Device path
+    (ragged row list, forward width = ceil8(longest), per-chunk log-probs, bf16: CE out of the LM-head accumulators at V = 50 257 on compacted
+    rows) == the host-array form (`get_ppo_data_from_token_trajectory_chain`: [32, max_length] forwards, full [32, T, V] logits): ids / masks
+    identical, log-probs / values 1e-5 (f32), returns 1e-5, whitened advantages 2e-5, the KL list; in the bf16-matmul mode the two forms run
+    the same bf16 products on different paddings (2e-3) and sit within the bf16 bound of the f32 numbers."""
+    from lmrl_gym_amd.algorithms.ppo_inference import GPT2PPOInference
+    from lmrl_gym_amd.envs import wordle as W
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, init_hf_style_state_dict
+    from lmrl_gym_amd.rollout import WordleRolloutEngine
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
+    cfg = GPT2Config.gpt2_small()
+    sd = init_hf_style_state_dict(cfg, seed=0)
+    g = torch.Generator().manual_seed(21)
+    sd_pol = {k: v + 0.05 * v.abs().mean().clamp_min(1e-3) * torch.randn(v.shape, generator=g) for k, v in sd.items()}
+    eng = GPT2Engine(cfg, sd_pol, dev)
+    vocab = W.Vocabulary.builtin("wordle_official_400.txt")
+    B = 256
+    ro = WordleRolloutEngine(eng, vocab, B, max_new_tokens=6, bad_word_reward=-10.0)
+    rng = np.random.RandomState(8)
+    packed = np.array([W.pack_guess(w) for w in vocab.all_vocab], dtype=np.uint32)
+    guesses = torch.from_numpy(packed[rng.randint(0, len(packed), size=(6, B))].view(np.int32)).to(dev)
+    ro.run_episode(np.arange(B, dtype=np.uint64) + 900, temperature=1.0, sample_seed=6, scripted_guesses=guesses, steer_strength=13.0)
+    torch.cuda.synchronize()
+    n_tok = ro.traj["n_tok"].cpu().numpy()
+    assert ro.tokens.pad == cfg.vocab and len(set(n_tok.tolist())) > 3              # ragged episodes (valid words, junk actions), unsampleable pad
+    pol, init = GPT2F32(sd_pol, cfg.n_head, device=dev, matmul=matmul), GPT2F32(sd, cfg.n_head, device=dev, matmul=matmul)
+    head = LinearHeadF32(dict(kernel=torch.randn(cfg.d_model, 1, generator=torch.Generator().manual_seed(2)) * 0.05, bias=torch.tensor([-0.3])), dev)
+    inf = GPT2PPOInference(pol, head, ro.tokens.pad, initial_policy=init)
+    kw = dict(gamma=1.0, lam=0.95, kl_weight=0.001)
+    max_length = ro.cap + 1
+    host, kls_h, _ = _host_form(ro, inf, max_length, **kw)
+    ds, kls_d = ro.ppo_data(inf, max_length=max_length, bsize=96, lm_head_rows=7000, **kw)      # ragged sequence chunks and ragged row chunks
+    dh = ds.to_host()
+    assert (dh.input_ids == host.input_ids).all() and (dh.should_take_action == host.should_take_action).all()
+    assert host.should_take_action.sum() > 10 * B
+    tol = 1e-5 if matmul == "f32" else 2e-3
+    np.testing.assert_allclose(dh.old_logprobs, host.old_logprobs, rtol=0, atol=tol)
+    np.testing.assert_allclose(dh.old_values, host.old_values, rtol=0, atol=tol)
+    np.testing.assert_allclose(dh.old_returns, host.old_returns, rtol=tol, atol=tol)
+    np.testing.assert_allclose(dh.old_advantages, host.old_advantages, rtol=2 * tol, atol=2 * tol)
+    kd = kls_d.cpu().numpy()
+    assert kd.shape == kls_h.shape == (int(host.should_take_action.sum()),)
+    np.testing.assert_allclose(kd, kls_h, rtol=1e-5 if matmul == "f32" else 5e-2, atol=5e-6 if matmul == "f32" else 2e-4)
+    assert kd.mean() > 1e-6
+    if matmul == "bf16":                                                             # ... and within the bf16 bound of the f32 arithmetic
+        pol32, init32 = GPT2F32(sd_pol, cfg.n_head, device=dev), GPT2F32(sd, cfg.n_head, device=dev)
+        ds32, _ = ro.ppo_data(GPT2PPOInference(pol32, head, ro.tokens.pad, initial_policy=init32), max_length=max_length, **kw)
+        h32 = ds32.to_host()
+        m = h32.should_take_action
+        assert np.abs(dh.old_logprobs - h32.old_logprobs)[m].max() < 0.05 and np.abs(dh.old_logprobs - h32.old_logprobs)[m].mean() < 5e-3
+        assert np.abs(dh.old_values - h32.old_values).max() < 0.1 and np.abs(dh.old_values - h32.old_values)[m].mean() < 2e-2
+    ro.close()

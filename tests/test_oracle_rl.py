@@ -82,3 +82,45 @@ def test_ilql_loss_selection_equals_per_row_next_action():
             vns = v[b, pos[j + 1]] if j + 1 < len(pos) else vf[b]
             tot += 0.5 * (q1[b, p] - (r[b, p] + 0.99 * vns)) ** 2
     torch.testing.assert_close(logs["losses"]["q1_loss"], tot / n)
+
+
+def _episode_from_record(rec):
+    """A fixture record (character tokenizer: id = ord) back into the interaction list a rollout returns."""
+    from lmrl_gym_amd.environment import InteractionTransition, Text
+    ia = rec["is_action"]
+    cuts = [0] + [t for t in range(1, len(ia)) if ia[t] != ia[t - 1]] + [len(ia)]
+    texts = [Text("".join(chr(c) for c in rec["tokens"][a:b]), bool(ia[a])) for a, b in zip(cuts[:-1], cuts[1:])]
+    out = []
+    for k in range(1, len(texts), 2):
+        out.append(InteractionTransition(tuple(texts[:k]), tuple(texts[:k + 1]), tuple(texts[:k + 2]), float(rec["reward"][cuts[k + 1] - 1]),
+                                         rec["done"] and k + 2 >= len(texts)))
+    return out
+
+
+def test_length_rule_equals_the_reference_loop():
+    """tests/golden/ppo_truncation.json = outputs of the reference script's own drop-the-last-turns loop (train_ppo_gpt2.py:317-341, executed):
+    the oracle's token-record form and the package's host function (`text_trajectory_chains_from_interactions`) reproduce them exactly."""
+    import lmrl_gym_amd  # noqa: F401
+    from lmrl_gym_amd.algorithms.ppo_inference import text_trajectory_chains_from_interactions
+    from lmrl_gym_amd.environment import TokenTrajectory
+
+    class CharTok:
+        def encode(self, s):
+            return [ord(c) for c in s]
+    fx = load_golden("ppo_truncation.json")
+    n_short = n_skip = 0
+    for case in fx["cases"]:
+        kept = [rl.truncate_turns_record(r, case["max_length"], case["gamma"]) for r in case["records"]]
+        n_skip += sum(k is None for k in kept)
+        n_short += sum(k is not None and len(k["tokens"]) < len(r["tokens"]) for k, r in zip(kept, case["records"]))
+        kept = [k for k in kept if k is not None]
+        assert len(kept) == len(case["kept"])
+        for got, exp in zip(kept, case["kept"]):
+            assert got["tokens"] == exp["tokens"] and got["is_action"] == exp["is_action"] and got["done"] == exp["done"]
+            assert got["reward"] == exp["reward"]                                        # float32-exact: the fold runs in double, rounded once
+        chains = text_trajectory_chains_from_interactions([_episode_from_record(r) for r in case["records"]], CharTok(), case["max_length"], case["gamma"])
+        assert len(chains) == len(case["kept"])
+        for ch, exp in zip(chains, case["kept"]):
+            tt = TokenTrajectory.from_text_trajectory(ch.text_trajectory, CharTok())
+            assert tt.tokens.tolist() == exp["tokens"] and [float(x) for x in tt.reward] == exp["reward"] and bool(tt.done) == exp["done"]
+    assert n_short >= 20 and n_skip >= 20
