@@ -589,13 +589,16 @@ def run_ppo_iteration(matmul, B, vocab, dev, rank, world, use_dist, backend, ite
         tm["push_weights_ms"] = tm.get("push_weights_ms", 0.0) + e1.elapsed_time(e2)
         return int(round(summary["length"]["mean"] * B)), float(loss), float(kls.mean())
 
-    device_iteration(0, {})                                  # warm: graph capture, workspaces, optimizer state
+    # the headline of this leg trains on batches cut to the round's longest episode (`DevicePPODataset.batch(width=trimmed_width())`, what
+    # scripts/harness.py does by default): identical loss / logs / gradients to the script's fixed 1024-column blocking — asserted in
+    # tests/test_gpu_ppo_device.py::test_train_step_on_trimmed_batches_equals_the_full_width_step — which exists for XLA's static shapes
+    device_iteration(0, {}, trim=True)                       # warm: graph capture, workspaces, optimizer state
     tm = {}
     barrier()
     t0 = time.perf_counter()
     n_steps, loss, kl = 0, None, None
     for it in range(1, n_it):
-        ns, loss, kl = device_iteration(it, tm)
+        ns, loss, kl = device_iteration(it, tm, trim=True)
         n_steps += ns
     barrier()
     dt = time.perf_counter() - t0
@@ -607,25 +610,24 @@ def run_ppo_iteration(matmul, B, vocab, dev, rank, world, use_dist, backend, ite
         dt, n_steps = float(mx.item()), int(sm.item())
     ph = {k: round(v / iters, 2) for k, v in tm.items() if k.endswith("_ms")}
     out = dict(value=round(n_steps / dt, 1), unit="env-steps/s", ms_per_iteration=round(dt * 1e3 / iters, 2), iterations=iters, matmul=matmul,
-               envs_per_gpu=B, train_steps_per_iteration=train_steps, train_batch=f"{train_bsize} x {max_length}",
+               envs_per_gpu=B, train_steps_per_iteration=train_steps, train_batch=f"{train_bsize} x {tm.get('batch_width')} (blocking width {max_length}, cut to ceil64(longest episode))",
                phases_ms=dict(rollout=ph.get("rollout_ms"), data_block=ph.get("block_ms"), data_forwards=ph.get("forward_ms"),
                               data_logprobs=ph.get("logprobs_ms"), data_shape_gae_whiten=ph.get("shape_gae_ms"), train=ph.get("train_ms"),
                               push_weights=ph.get("push_weights_ms")),
                data_rows=dict(sequences=tm.get("sequences"), forward_width=tm.get("forward_width"), lm_head_rows=tm.get("rows"),
                               action_tokens=tm.get("action_tokens"), pad_ids_inside=tm.get("pad_ids_inside")),
                last_loss=loss, mean_kl=kl,
-               note=f"rank-local {B}-env rollouts (hipGraph replay) -> device PPO data -> {train_steps} steps of {train_bsize} x {max_length} "
+               note=f"rank-local {B}-env rollouts (hipGraph replay) -> device PPO data -> {train_steps} steps of {train_bsize} x {tm.get('batch_width')} "
                     f"(an epoch over {B} rollouts would be {B // train_bsize} steps; the script's defaults are 128 rollouts = 4 steps) -> weights pushed into the engine; "
                     "phases: HIP events on the launch stream, value: wall clock over whole iterations")
-    # the same iteration with every train batch cut to the round's longest episode (`DevicePPODataset.batch(width=trimmed_width())`): identical loss /
-    # gradients (right padding of a causal model), 8 x fewer rows than the script's fixed 1024-column blocking, which exists for XLA's static shapes
-    device_iteration(0, {}, trim=True)
+    # the same iteration on the script's fixed blocking (every train batch max_length = 1024 columns, 93 % of them padding)
+    device_iteration(0, {}, trim=False)
     tm2 = {}
     barrier()
     t0 = time.perf_counter()
     n2 = 0
     for it in range(1, n_it):
-        n2 += device_iteration(it, tm2, trim=True)[0]
+        n2 += device_iteration(it, tm2, trim=False)[0]
     barrier()
     dt2 = time.perf_counter() - t0
     tt2 = torch.tensor([dt2, float(n2)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -634,9 +636,9 @@ def run_ppo_iteration(matmul, B, vocab, dev, rank, world, use_dist, backend, ite
         torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(sm, op=torch.distributed.ReduceOp.SUM)
         dt2, n2 = float(mx.item()), int(sm.item())
-    out["trimmed_batches"] = dict(value=round(n2 / dt2, 1), unit="env-steps/s", ms_per_iteration=round(dt2 * 1e3 / iters, 2),
-                                  train_batch=f"{train_bsize} x {tm2.get('batch_width')}", train_ms=round(tm2.get("train_ms", 0.0) / iters, 2),
-                                  note="train batches cut to ceil64(longest episode of the round) columns instead of max_length; everything else as above")
+    out["full_width_batches"] = dict(value=round(n2 / dt2, 1), unit="env-steps/s", ms_per_iteration=round(dt2 * 1e3 / iters, 2),
+                                     train_batch=f"{train_bsize} x {tm2.get('batch_width')}", train_ms=round(tm2.get("train_ms", 0.0) / iters, 2),
+                                     note="train batches at the script's blocking width (max_input_length + max_output_length columns); everything else as above")
     if host_path and rank == 0 and world == 1:
         # the same iteration through the host-array functions with the reference's signatures (what scripts/harness.py ran before this round)
         tok = inf.tokenizer
@@ -751,6 +753,8 @@ def main():
     ap.add_argument("--share-header", type=int, default=1, help="1 (default): the K/V rows of the header text every env starts from are computed "
                     "once per episode and broadcast to all envs (bit-identical to per-env prefill); 0: prefill the header per env")
     ap.add_argument("--streams", type=int, default=1, help="split the batch into this many sub-batches on separate HIP streams")
+    ap.add_argument("--session-flags", type=int, default=0, help="lmrl_gpt2_forward variant bits of the headline engine's KV sessions (A/B runs: 64 / 128 = decode "
+                                                                 "attention with 2 / 3 (env, head) items per wave)")
     ap.add_argument("--breakdown", action="store_true", help="after the timed region, print a per-kernel-class event breakdown to stderr")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the `fp32_mode` leg of the default line (the same rollout on the fp32 engine)")
     ap.add_argument("--no-batch-sweep", action="store_true", help="skip the informational `larger_batches` leg of the default line (the same run at 4096 and 8192 envs per GPU, child processes)")
@@ -801,7 +805,8 @@ def main():
     ros = []
     for st in streams:
         with torch.cuda.stream(st):
-            ros.append(WordleRolloutEngine(eng, vocab, Bs, max_new_tokens=6, bad_word_reward=-10.0, share_header=bool(args.share_header)))
+            ros.append(WordleRolloutEngine(eng, vocab, Bs, max_new_tokens=6, bad_word_reward=-10.0, share_header=bool(args.share_header),
+                                           session_flags=args.session_flags))
     ro = ros[0]
     n_eps = max(args.steps, 2) + args.warmup + (1 if args.breakdown else 0)      # (the roofline leg replays episodes warmup .. warmup + 1 eagerly)
     guesses = torch.from_numpy(scripted_guesses(vocab.all_vocab, n_eps, n_turns, B, seed=12345 + rank).view(np.int32)).to(dev)

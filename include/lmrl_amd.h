@@ -331,6 +331,8 @@ size_t lmrl_gpt2_ws_bytes(const lmrl_gpt2 *m, int b, int c);
 #define LMRL_FWD_RAGGED_NEVER  4u  /* always run all b*c slots */
 #define LMRL_FWD_ATTN_VALU     8u  /* per-(env, head) multi-round-trip attention kernels instead of the default ones (cross-check) */
 #define LMRL_FWD_KV_FROM_GEMM  16u /* decode: the qkv GEMM epilogue appends the new K/V rows, the attention kernel only reads (A/B: attention faster, GEMM slower, net slower) */
+#define LMRL_FWD_ATTN_ITEMS2   64u /* decode attention: 2 (env, head) items per wave on a grid of half as many waves (A/B of the resident-size grid; bit-identical) */
+#define LMRL_FWD_ATTN_ITEMS3   128u /* ... 3 items per wave */
 #define LMRL_FWD_FULL_LAST_LAYER 32u /* chunk forwards: run the last layer's projection + MLP on every row (default: only on each env's last new token — the only row whose hidden state is returned; A/B and cross-check, bit-identical) */
 /* bits 16-31: reserved — the product library rejects them (LMRL_ERR_ARG). */
 /* bits 8-15: LMRL_FWD_SHARED_PREFIX(n) — positions [0, n) of EVERY env's cache hold the same K/V rows as env 0's (the caller copied them

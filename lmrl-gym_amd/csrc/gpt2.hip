@@ -485,18 +485,13 @@ struct DecodePrefix {
     int tmax;
 };
 
-template <int U, bool PFX, bool HALF = false>   // HALF: timing-only ablation — only the first half of the cached positions is read (half the cache lines and bytes)
-__global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *__restrict__ qkv,   // [rows][3d]
-                                                               uint16_t *__restrict__ kcache, uint16_t *__restrict__ vcache,
-                                                               const int32_t *__restrict__ cnt, const int32_t *__restrict__ len,
-                                                               uint16_t *__restrict__ out,          // [rows][d]
-                                                               int B, int H, int Tmax, int d, const int32_t *__restrict__ off, int n_shared,
-                                                               int append, DecodePrefix pfx) {
+template <int U, bool PFX, bool HALF>
+__device__ __forceinline__ void attention_decode_item(int wave_id, const uint16_t *__restrict__ qkv, uint16_t *__restrict__ kcache, uint16_t *__restrict__ vcache,
+                                                      const int32_t *__restrict__ cnt, const int32_t *__restrict__ len, uint16_t *__restrict__ out,
+                                                      int B, int H, int Tmax, int d, const int32_t *__restrict__ off, int n_shared, int append,
+                                                      const DecodePrefix &pfx) {
     typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
-    int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (PFX && pfx.order && (gridDim.x & 7) == 0)            // workgroup ids round-robin over the 8 XCDs: XCD x gets ids [x, x + 8, ..]
-        wave_id = ((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * 4 + (threadIdx.x >> 6);
     if (wave_id >= B * H) return;
     int b = wave_id / H;
     const int h = wave_id - b * H;
@@ -620,6 +615,24 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *_
             *reinterpret_cast<uint4 *>(const_cast<char *>(vc) + (((size_t)env_row + L0) * d + cc * 8) * 2) = vnew;
         }
     }
+}
+
+// NI (round 6, A/B): (env, head) items per wave.  1: one wave per item, B * H waves (1.7 resident rounds of the chip at 1024 envs x 12 heads).  2 / 3: a grid of
+// ceil(B * H / NI) waves — 6144 / 4096 at the bench shape, all resident at once — whose wave w sweeps items w, w + W, w + 2 W one after the other
+// (LMRL_FWD_ATTN_ITEMS2 / _ITEMS3).  Per-item arithmetic unchanged: bit-identical results.
+template <int U, bool PFX, bool HALF = false, int NI = 1>   // HALF: timing-only ablation — only the first half of the cached positions is read (half the cache lines and bytes)
+__global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *__restrict__ qkv,   // [rows][3d]
+                                                               uint16_t *__restrict__ kcache, uint16_t *__restrict__ vcache,
+                                                               const int32_t *__restrict__ cnt, const int32_t *__restrict__ len,
+                                                               uint16_t *__restrict__ out,          // [rows][d]
+                                                               int B, int H, int Tmax, int d, const int32_t *__restrict__ off, int n_shared,
+                                                               int append, DecodePrefix pfx) {
+    int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (PFX && pfx.order && (gridDim.x & 7) == 0)            // workgroup ids round-robin over the 8 XCDs: XCD x gets ids [x, x + 8, ..]
+        wave_id = ((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * 4 + (threadIdx.x >> 6);
+#pragma unroll 1
+    for (int it = 0; it < NI; it++)
+        attention_decode_item<U, PFX, HALF>(wave_id + it * (int)gridDim.x * 4, qkv, kcache, vcache, cnt, len, out, B, H, Tmax, d, off, n_shared, append, pfx);
 }
 
 // ------------------------------------------------------------------------------------------ chunk attention on MFMA
@@ -1233,22 +1246,25 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
                 dp.k = (const uint16_t *)pfx->kv_d + (size_t)(2 * l) * pfx_layer; dp.v = dp.k + pfx_layer;
                 dp.row = pfx->row_d; dp.n = pfx->n_d; dp.order = pfx->order_d; dp.tmax = pfx->tmax;
             }
-#define LMRL_DEC_LAUNCH(U_, PFX_)                                                                                                                    \
+#define LMRL_DEC_LAUNCH(U_, PFX_, NI_)                                                                                                               \
             do {                                                                                                                                     \
-                if (ev) hipExtLaunchKernelGGL((attention_decode_kernel<U_, PFX_>), dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, ev_a, ev_b, 0,   \
+                const dim3 grid_(ceil_div(ceil_div(b * cf.n_head, NI_), 4));                                                                         \
+                if (ev) hipExtLaunchKernelGGL((attention_decode_kernel<U_, PFX_, false, NI_>), grid_, dim3(256), 0, s, ev_a, ev_b, 0,                 \
                                               (const uint16_t *)w.qkv, kc, vc, cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off,     \
                                               n_shared, append_in_attn, dp);                                                                         \
-                else hipLaunchKernelGGL((attention_decode_kernel<U_, PFX_>), dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, (const uint16_t *)w.qkv,  \
+                else hipLaunchKernelGGL((attention_decode_kernel<U_, PFX_, false, NI_>), grid_, dim3(256), 0, s, (const uint16_t *)w.qkv,            \
                                         kc, vc, cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off, n_shared, append_in_attn, dp);      \
             } while (0)
             // 32 cached positions per batch of loads, 72 VGPRs -> 7 waves per SIMD (measured best of U = 4 / 6 / 8 / 10)
-            if (pfx) LMRL_DEC_LAUNCH(4, true);
+            if (pfx) LMRL_DEC_LAUNCH(4, true, 1);
 #ifdef LMRL_TOOLS
             else if (LMRL_ABL(LMRL_ABLATE_ATTN_HALF_BYTES))
                 hipLaunchKernelGGL((attention_decode_kernel<4, false, true>), dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, (const uint16_t *)w.qkv, kc, vc,
                                    cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off, n_shared, append_in_attn, dp);
 #endif
-            else LMRL_DEC_LAUNCH(4, false);
+            else if (flags & LMRL_FWD_ATTN_ITEMS3) LMRL_DEC_LAUNCH(4, false, 3);
+            else if (flags & LMRL_FWD_ATTN_ITEMS2) LMRL_DEC_LAUNCH(4, false, 2);
+            else LMRL_DEC_LAUNCH(4, false, 1);
 #undef LMRL_DEC_LAUNCH
         } else if (c == 1 && prof_kernel_events(PROF_ATTN_DECODE, -1.0, &ev_a, &ev_b)) {
             // the roofline kernel: start/stop events attached to the dispatch itself (kernel begin -> end, as rocprofv3 reports it)

@@ -152,8 +152,9 @@ class WordleRolloutEngine:
     def __init__(self, engine: GPT2Engine, vocab: W.Vocabulary, batch: int, tokens: Optional[WordleTokenTable] = None,
                  max_new_tokens: int = 6, require_words_in_vocab: bool = True, bad_word_reward: float = -10.0,
                  traj_cap: int = 128, share_header: bool = True, value_engine: Optional[GPT2Engine] = None, q1_head: Optional[dict] = None,
-                 q2_head: Optional[dict] = None, beta: float = 0.0):
-        """`value_engine` + `q1_head` (+ `q2_head`) + `beta` turn the policy into the ILQL value policy
+                 q2_head: Optional[dict] = None, beta: float = 0.0, session_flags: int = 0):
+        """`session_flags`: lmrl_gpt2_forward variants (gpt2.FWD_*) of this engine's KV sessions (A/B hooks; results are bit-identical).
+        `value_engine` + `q1_head` (+ `q2_head`) + `beta` turn the policy into the ILQL value policy
         (`GPT2ValueRLGeneration`, value_rl_base/gpt2/generation.py:97-119): `engine` is pi_beta, `value_engine` the value base
         whose last hidden state feeds the Q heads (`policies.heads_to_engine_layout` dicts); logits = pi_beta + beta * min(Q1, Q2)."""
         import torch
@@ -161,7 +162,7 @@ class WordleRolloutEngine:
         self.eng, self.vocab, self.B = engine, vocab, batch
         self._twin_args = dict(tokens=tokens, max_new_tokens=max_new_tokens, require_words_in_vocab=require_words_in_vocab,
                                bad_word_reward=bad_word_reward, traj_cap=traj_cap, share_header=share_header, value_engine=value_engine,
-                               q1_head=q1_head, q2_head=q2_head, beta=beta)
+                               q1_head=q1_head, q2_head=q2_head, beta=beta, session_flags=session_flags)
         self._lanes = None           # text_env_eval(concurrent=n): [(engine, stream)], this engine first
         self.episodes = 0            # eager episodes run by text_env_eval over this engine's life: part of the sampler stream key
         # the pad id is the first id AFTER the policy's vocabulary, as in the reference: the task scripts add `<|pad|>` to the tokenizer (id 50257,
@@ -173,13 +174,13 @@ class WordleRolloutEngine:
         self._L = _lib.lib()
         self.env = W.VectorWordleEnv(vocab, require_words_in_vocab, bad_word_reward)
         self.env._alloc(batch)
-        self.ses = engine.session(batch, traj_cap)
+        self.ses = engine.session(batch, traj_cap, int(session_flags))
         # every env starts from the same header text: its K/V are computed once per episode on a 1-env session and broadcast
         self.share_header = share_header
         self.ses1 = engine.session(1, 16) if share_header else None
         self.veng, self.q1, self.q2, self.beta = value_engine, q1_head, q2_head, float(beta)
         assert (value_engine is None) == (q1_head is None), "value_engine and q1_head come together"
-        self.vses = value_engine.session(batch, traj_cap) if value_engine is not None else None
+        self.vses = value_engine.session(batch, traj_cap, int(session_flags)) if value_engine is not None else None
         self.dual_stream = value_engine is not None          # ILQL value policy: the value base's forwards on a second HIP stream (episode_phases)
         if value_engine is not None:
             import torch as _t

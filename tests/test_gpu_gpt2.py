@@ -585,13 +585,15 @@ def test_ragged_prefill_is_bit_identical(dev):
             (1, torch.ones(B, dtype=torch.int64)), (8, torch.randint(3, 9, (B,), generator=g))]
     plan[0][1][0] = 0; plan[0][1][B - 1] = 8
     outs = []
-    from lmrl_gym_amd.gpt2 import FWD_FULL_LAST_LAYER, FWD_KV_FROM_GEMM, FWD_RAGGED_ALWAYS, FWD_RAGGED_NEVER
+    from lmrl_gym_amd.gpt2 import FWD_ATTN_ITEMS2, FWD_ATTN_ITEMS3, FWD_FULL_LAST_LAYER, FWD_KV_FROM_GEMM, FWD_RAGGED_ALWAYS, FWD_RAGGED_NEVER
     # the sessions are INTERLEAVED forward by forward: the variant is a property of the call, not of the process.  FWD_KV_FROM_GEMM: the
     # decode qkv GEMM's epilogue appends the new K / V rows instead of the attention kernel — same cache bytes, same outputs
     sess = [eng.session(B, 48, flags=FWD_RAGGED_ALWAYS), eng.session(B, 48, flags=FWD_RAGGED_NEVER),
             eng.session(B, 48, flags=FWD_RAGGED_ALWAYS | FWD_KV_FROM_GEMM), eng.session(B, 48, flags=FWD_RAGGED_NEVER | FWD_KV_FROM_GEMM),
             # FWD_FULL_LAST_LAYER: the last layer's projection + MLP on every chunk row instead of on each env's last new token only (the default)
-            eng.session(B, 48, flags=FWD_RAGGED_ALWAYS | FWD_FULL_LAST_LAYER), eng.session(B, 48, flags=FWD_RAGGED_NEVER | FWD_FULL_LAST_LAYER)]
+            eng.session(B, 48, flags=FWD_RAGGED_ALWAYS | FWD_FULL_LAST_LAYER), eng.session(B, 48, flags=FWD_RAGGED_NEVER | FWD_FULL_LAST_LAYER),
+            # FWD_ATTN_ITEMS2 / 3 (round 6, A/B): decode attention on a grid of half / a third as many waves, 2 / 3 (env, head) items per wave
+            eng.session(B, 48, flags=FWD_ATTN_ITEMS2), eng.session(B, 48, flags=FWD_RAGGED_ALWAYS | FWD_ATTN_ITEMS3)]
     hs = [[] for _ in sess]
     for C, cnt in plan:
         toks = torch.randint(0, cfg.vocab, (B * C,), generator=torch.Generator().manual_seed(C)).to(torch.int32).to(dev)

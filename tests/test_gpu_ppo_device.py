@@ -401,8 +401,14 @@ def test_reference_truncation_asserts_are_raised(wordle_setup, dev):
     s = wordle_setup
     inf, ro = s["inf"], s["ro"]
     kw = dict(gamma=1.0, lam=0.95, kl_weight=0.001)
+    long = _records_from_dicts([dict(tokens=list(range(5, 45)), is_action=[0] * 4 + [1, 1, 0, 0] * 9, reward=[0.0] * 40, done=True),
+                                dict(tokens=list(range(5, 25)), is_action=[0] * 4 + [1, 1, 0, 0] * 4, reward=[0.0] * 20, done=True)], dev)
+    ds, _ = ppo_data_from_records(inf, long, max_length=48, **kw)                   # nothing is cut
+    assert len(ds) == 2
+    ds, _ = ppo_data_from_records(inf, long, max_length=39, **kw)                   # one observation token is cut: allowed (ends_with_state)
+    assert ds.longest == 39
     with pytest.raises(ValueError, match="trajectory truncation error"):
-        ppo_data_from_records(inf, ro.ppo_records(), max_length=30, **kw)         # every episode has action tokens beyond 30 (the wrapper would apply the length rule first)
+        ppo_data_from_records(inf, long, max_length=30, **kw)                        # action tokens beyond 30 (the engines' wrappers apply the length rule first)
     mk = lambda toks, ia, rw, dn: E.TokenTrajectory(np.asarray(toks, np.int32), np.asarray(ia, bool), np.asarray(rw, np.float32), np.asarray(dn))
     a = mk([5, 6, 7, 8], [0, 0, 1, 1], [0, 0, 0, 1.0], False)
     b_ok = mk([9, 10, 11], [0, 1, 1], [0, 0, -1.0], True)
@@ -441,7 +447,8 @@ def test_batches_carry_the_data_builds_own_masks(wordle_setup):
     assert abs(float(logs["ratio"]) - 1.0) < 1e-5 and abs(float(logs["policy"]["approx_kl"])) < 1e-5
     masks_from_ids = {k: v for k, v in batch.items() if k not in ("attention_mask", "position_ids")}
     _, _, logs2 = tr.step(**masks_from_ids, train=False)                            # the reference's `ids != pad` masks: a different sequence
-    assert abs(float(logs2["ratio"]) - 1.0) > 1e-4
+    r2 = float(logs2["ratio"])
+    assert np.isnan(r2) or abs(r2 - 1.0) > 1e-4                                      # (nan: every action token of the batch equals the would-be pad id)
 
 
 def test_embedding_rows_beyond_the_vocabulary_and_live_rows(dev):
@@ -534,3 +541,42 @@ def test_device_ppo_data_at_gpt2_small_size_equals_the_host_form(dev, matmul):
         assert np.abs(dh.old_logprobs - h32.old_logprobs)[m].max() < 0.05 and np.abs(dh.old_logprobs - h32.old_logprobs)[m].mean() < 5e-3
         assert np.abs(dh.old_values - h32.old_values).max() < 0.1 and np.abs(dh.old_values - h32.old_values)[m].mean() < 2e-2
     ro.close()
+
+
+@pytest.mark.parametrize("matmul", ["f32", "bf16"])
+def test_train_step_on_trimmed_batches_equals_the_full_width_step(wordle_setup, matmul):
+    """`DevicePPODataset.batch(width=trimmed_width())` — the columns beyond the round's longest episode are dropped; the reference blocks every batch
+    to max_input_length + max_output_length only because XLA wants one static shape (train_ppo_gpt2.py:344-353).  Right padding of a causal model
+    never reaches a kept position: same loss, same logs (but padding_percentage), same gradients as the full-width batch — what lets
+    `bench.py`'s ppo_iteration and the harness train on 128 instead of 1024 columns."""
+    from lmrl_gym_amd.algorithms import ppo
+    from lmrl_gym_amd.algorithms.ppo_inference import GPT2PPOInference
+    s = wordle_setup
+    ro = s["ro"]
+    pol0, init0 = s["mk"](matmul)
+    inf = GPT2PPOInference(pol0, s["head"](), ro.tokens.pad, initial_policy=init0)
+    ds, _ = ro.ppo_data(inf, gamma=1.0, lam=0.95, kl_weight=0.001, max_length=ro.cap + 1, pad_to=512)
+    w = ds.trimmed_width()
+    assert w == 128 and ds.input_ids.shape[1] == 512
+    index = np.arange(32)
+    kw = dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0)
+    outs = []
+    for width in (None, w):
+        pol, _ = s["mk"](matmul)
+        tr = ppo.GPT2PPOTrain(pol, s["head"](), ro.tokens.pad, kw, lr=1e-3)
+        _, loss, logs = tr.step(**ds.batch(index, width=width))
+        torch.cuda.synchronize()
+        outs.append((loss, logs, tr.last_grads[0].flat.clone(), tr.last_grads[1].flat.clone()))
+    (l0, g0, pg0, hg0), (l1, g1, pg1, hg1) = outs
+    tol = 1e-5 if matmul == "f32" else 2e-3
+    assert abs(l0 - l1) <= tol * max(1.0, abs(l0))
+    for k in ("ratio",):
+        assert abs(float(g0[k]) - float(g1[k])) < tol
+    for grp in ("policy", "values"):
+        for k in g0[grp]:
+            a, b = float(np.asarray(g0[grp][k]).reshape(-1)[0]), float(np.asarray(g1[grp][k]).reshape(-1)[0])
+            assert abs(a - b) <= tol * max(1.0, abs(a)), (grp, k, a, b)
+    assert float(g0["padding_percentage"]) != float(g1["padding_percentage"])
+    scale = float(pg0.abs().max())
+    assert scale > 0 and float((pg0 - pg1).abs().max()) <= (1e-5 if matmul == "f32" else 2e-2) * scale
+    assert float((hg0 - hg1).abs().max()) <= (1e-5 if matmul == "f32" else 2e-2) * float(hg0.abs().max())

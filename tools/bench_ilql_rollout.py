@@ -35,6 +35,25 @@ for i in range(warm, warm + steps):
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print("ILQL value-policy rollouts: %.1f env-steps/s  (%.2f ms per 1024-env episode, %d env steps)" % (int(n) / dt, dt * 1e3 / steps, int(n)))
 
+# round 6: the task script's sampler — top-k on the perturbed logits (train_ilql_gpt2.py:384-403 `policy_top_k`, generation.py:97-119) — on the FUSED
+# candidate path of the three-operand head (no [B, V] logits in HBM) vs the materialised path of the same head (lmrl_sampler_set_variant(2))
+for name, variant, kw_s in (("top_k=40 fused (candidates in the LM-head epilogue)", 0, dict(top_k=40)), ("top_k=40 materialised logits", 2, dict(top_k=40)),
+                            ("top_k=40 + top_p=0.95 fused", 0, dict(top_k=40, top_p=0.95))):
+    _lib.lib().lmrl_sampler_set_variant(variant)
+    try:
+        ro2 = WordleRolloutEngine(pi_beta, vocab, B, max_new_tokens=6, bad_word_reward=-10.0, value_engine=base, q1_head=ro.q1, q2_head=ro.q2, beta=32.0)
+        ro2.capture_episode(temperature=1.0, sample_seed=5, steer_strength=30.0 + 32.0 * 5, scripted=True, **kw_s)
+        n2 = torch.zeros((), dtype=torch.int64, device=dev)
+        ro2.replay_episode(seeds[0], guesses[0])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(warm, warm + steps):
+            ro2.replay_episode(seeds[i], guesses[i]); n2 += ro2.traj["n_steps"].sum()
+        torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
+        print("  %-52s %.1f env-steps/s  (%.2f ms per episode)" % (name, int(n2) / dt2, dt2 * 1e3 / steps))
+        ro2.close()
+    finally:
+        _lib.lib().lmrl_sampler_set_variant(0)
+
 # the public call, host lists included, 1 / 2 lanes (independent 1024-env batches in flight; each lane runs its two transformers on two streams)
 kw = dict(scripted_guesses_fn=lambda bid: guesses[bid % (steps + warm)], steer_strength=30.0 + 32.0 * 5, temperature=1.0, sample_seed=5, use_graph=True)
 gen = iter(range(10 ** 6, 10 ** 9))
