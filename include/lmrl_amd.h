@@ -654,6 +654,41 @@ int lmrl_maze_tok_action(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, int n, 
 int lmrl_maze_tok_ppo_records(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, int n_envs, const int32_t *off_d, int newline_tok, int cap,
                               int32_t *tokens_d, uint8_t *is_action_d, float *reward_d, int32_t *n_tok_d, int32_t *chain_d, int32_t *pos_d, uint8_t *last_d,
                               uint8_t *done_d, int32_t *chain_total_d, void *stream);
+/* Histories of more than one item (MazeEnv(last_k > 1): `(history + [action] + [observation])[-last_k:]`, maze/env/env.py:182-184; the prompt is the
+ * window's text, left-truncated to max_input_length tokens, ppo/gpt2/interface.py:519-524; partially_observed_bc.py:241 runs last_k = 40) on a
+ * persistent per-env KV cache.  Per env: the episode's token history, the token offset of every item, and which part of the history is in the
+ * cache.  "Append" turns (window still growing: prompt t + 1 = prompt t ++ action ++ observation token for token) forward only the action's
+ * unforwarded tail + the new observation; "re-prefill" turns (window slid or truncated: every position shifts under GPT-2's absolute position
+ * embeddings) forward the window again from position 0.  The caller schedules the kind per turn (`reprefill`) from static bounds and says how many
+ * tokens per env the turn's chunk forwards cover (`feed_budget`); an env whose window moved in an append turn (e.g. restarted by an illegal action
+ * string) is simply re-forwarded within that budget; flags[0] bit 0 = it did not fit, bit 1 = history buffer / item table overflow.  len0_d / len1_d: the cache-length arrays of the
+ * policy's (and, optional, the value base's) KV session, kept in step by these calls. */
+typedef struct {
+    int32_t *hist;        /* [N][hcap] ids of every item of the episode, in order */
+    int32_t *item_off;    /* [N][max_items + 1] token offset of item k (item_off[k + 1]: its end) */
+    int32_t *n_items;     /* [N] */
+    int32_t *feed_start;  /* [N] first history token that goes through the model this turn */
+    int32_t *feed_len;    /* [N] */
+    int32_t *cache_len;   /* [N] history tokens [base, base + cache_len) sit in the KV cache at positions [0, cache_len) */
+    int32_t *base;        /* [N] */
+    int32_t *prompt_len;  /* [N] tokens of the current prompt */
+    int32_t *win_floor;   /* [N] first item of the window since the env last returned (observation,) alone (LMRL_MAZE_KIND_OBS_ONLY, env.py:179-180) */
+    int32_t *flags;       /* [1] */
+    int32_t hcap, max_items;
+} lmrl_maze_hist;
+int lmrl_maze_hist_begin(const lmrl_maze_hist *h, int32_t *len0_d, int32_t *len1_d, int n, void *stream);
+/* after lmrl_maze_tok_turn: the current observation joins the history; window / truncation / feed range of every env */
+int lmrl_maze_hist_observe(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const lmrl_maze_hist *h, int last_k, int max_input_length, int reprefill,
+                           int feed_budget, int32_t *len0_d, int32_t *len1_d, int n, void *stream);
+/* chunk j of this turn's feed for a prefill forward: chunk_tok_d [N][chunk], chunk_cnt_d [N] */
+int lmrl_maze_hist_chunk(const lmrl_maze_hist *h, int j, int chunk, int32_t *chunk_tok_d, int32_t *chunk_cnt_d, int n, void *stream);
+/* act_tok (host) [4][act_cap]: the tokenizer's encoding of 'move left\n' / 'move right\n' / 'move up\n' / 'move down\n' (LMRL_MAZE_LEFT ..), the length of
+ * each in its last slot — what a later prompt holds for a legal action, whatever ids the policy generated to spell it */
+int lmrl_maze_tok_set_actions(lmrl_maze_tok_ctx *c, const int32_t *act_tok, int act_cap);
+/* after lmrl_maze_tok_action: the action joins the history — a legal action as its encoding above, an illegal string (it never reaches a later
+ * prompt: the env answers with the observation alone) as its generated ids; the cache is cut back to the prompt + the forwarded generated ids
+ * that ARE the action's ids */
+int lmrl_maze_hist_action(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const lmrl_maze_hist *h, int32_t *len0_d, int32_t *len1_d, int n, void *stream);
 /* outputs of lmrl_maze_step -> record (reward, kind), counters, live &= !done */
 int lmrl_maze_tok_result(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const float *reward_d, const uint8_t *done_d,
                          const uint8_t *kind_d, int n, void *stream);

@@ -92,6 +92,11 @@ _SIGS = {
     "lmrl_maze_tok_prompt": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "lmrl_maze_tok_action": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "lmrl_maze_tok_result": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_maze_hist_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_maze_hist_observe": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_maze_hist_chunk": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_maze_hist_action": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lmrl_maze_tok_set_actions": (c_int, [c_void_p, c_void_p, c_int]),
     "lmrl_gpt2_kv_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "lmrl_gpt2_kv_attach": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmrl_gpt2_forward_prefixed": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,

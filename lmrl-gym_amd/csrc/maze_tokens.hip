@@ -1,4 +1,5 @@
-// maze_tokens.hip — on-device token <-> game bookkeeping for lock-step Maze rollouts with one-item histories (last_k = 1).
+// maze_tokens.hip — on-device token <-> game bookkeeping for lock-step Maze rollouts: one-item histories (last_k = 1: prompt table + prefix cache)
+// and, round 6, item windows (last_k > 1: a persistent per-env KV cache that grows with the history, lmrl_maze_hist_*).
 //
 // The reference's act()/step() cycle (LLM_RL/environment.py:180-206, ppo/gpt2/interface.py:519-546) renders the observation text of
 // the current cell, tokenises it, generates, decodes the ids, applies `out_str_process` and looks the string up in the action dict
@@ -14,6 +15,8 @@
 struct lmrl_maze_tok_ctx {
     int32_t *obs_tok_d = nullptr, *obs_len_d = nullptr, *goal_slot_d = nullptr;
     uint8_t *tok_bytes_d = nullptr, *tok_blen_d = nullptr;
+    int32_t *act_tok_d = nullptr;      // [4][act_cap] the tokenizer's encoding of the four action strings ('move left\n' ...), act_len in slot act_cap - 1 ... see lmrl_maze_tok_set_actions
+    int act_cap = 0;
     int n_obs = 0, obs_cap = 0, rows = 0, cols = 0, vocab = 0, max_new = 0, max_turns = 0;
 };
 
@@ -175,6 +178,118 @@ __global__ __launch_bounds__(256) void maze_ppo_records_kernel(lmrl_maze_traj tr
     }
 }
 
+// ---- histories longer than one item (round 6): `MazeEnv.step` returns (history + [action] + [observation])[-last_k:] (maze/env/env.py:182-184) and the
+// policy's prompt is the text of that window, left-truncated to max_input_length tokens (ppo/gpt2/interface.py:519-524; partially_observed_bc.py:241
+// runs last_k = 40).  While the window only GROWS — fewer than last_k items and max_input_length tokens — prompt t + 1 = prompt t ++ action ++ new
+// observation token for token (concatenative tokenizers: byte level), i.e. the K/V rows of prompt t stay valid at their positions: per turn only the
+// action's unforwarded tail and the new observation go through the model ("append" turns, as the Wordle loop).  Once the window slides, every position
+// shifts and GPT-2's learned absolute position embeddings enter every layer's K / V: the window is forwarded again from position 0 ("re-prefill"
+// turns — exact, and priced in DESIGN.md).  The host picks the kind of turn from static bounds; a turn scheduled as "append" that would have needed a
+// re-prefill of more tokens than its chunk budget raises flag bit 0.  An action string outside the action dict makes the env return (observation,)
+// alone (env.py:179-180): that env's window restarts — one observation long, so it fits an append turn's budget.  Per env: the episode's token
+// history and the token offset of every item.  One thread per env.
+struct MazeHist {               // lmrl_maze_hist, device pointers
+    int32_t *hist, *item_off, *n_items, *feed_start, *feed_len, *cache_len, *base, *prompt_len, *win_floor, *flags;
+    int32_t hcap, max_items;
+};
+
+__global__ void maze_hist_begin_kernel(MazeHist h, int32_t *__restrict__ len0, int32_t *__restrict__ len1, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e == 0) h.flags[0] = 0;
+    if (e >= n) return;
+    h.n_items[e] = 0;
+    h.item_off[(size_t)e * (h.max_items + 1)] = 0;
+    h.cache_len[e] = 0; h.base[e] = 0; h.feed_start[e] = 0; h.feed_len[e] = 0; h.prompt_len[e] = 0; h.win_floor[e] = 0;
+    len0[e] = 0;
+    if (len1) len1[e] = 0;
+}
+
+// turn start (after maze_turn_kernel): the current observation becomes the window's newest item; which history tokens go through the model this turn
+__global__ void maze_hist_observe_kernel(lmrl_maze_traj tr, MazeHist h, const int32_t *__restrict__ obs_tok, const int32_t *__restrict__ obs_len, int obs_cap,
+                                         int last_k, int max_input, int reprefill, int feed_budget, int max_turns, int32_t *__restrict__ len0,
+                                         int32_t *__restrict__ len1, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int idx = tr.obs_idx[e];
+    if (idx < 0) { h.feed_len[e] = 0; return; }
+    int32_t *off = h.item_off + (size_t)e * (h.max_items + 1);
+    int32_t *hist = h.hist + (size_t)e * h.hcap;
+    int ni = h.n_items[e], total = off[ni];
+    const int ol = obs_len[idx];
+    if (ni >= h.max_items || total + ol > h.hcap) { atomicOr(h.flags, 2); h.feed_len[e] = 0; tr.gen_active[e] = 0; return; }
+    // an action string outside the action dict makes the env return (observation,) alone (env.py:179-180): the window restarts at this observation
+    const int t = tr.n_turns[e];
+    if (t > 0 && tr.kind[(size_t)e * max_turns + t - 1] == LMRL_MAZE_KIND_OBS_ONLY) h.win_floor[e] = ni;
+    for (int k = 0; k < ol; k++) hist[total + k] = obs_tok[(size_t)idx * obs_cap + k];
+    total += ol; ni += 1;
+    off[ni] = total;
+    h.n_items[e] = ni;
+    const int floor_item = h.win_floor[e];
+    const int first_item = max(floor_item, ni > last_k ? ni - last_k : 0);      // [-last_k:] of the item list since the last restart
+    int start = off[first_item];
+    if (total - start > max_input) start = total - max_input;                   // Truncation.LEFT on the token level
+    h.prompt_len[e] = total - start;
+    int base = h.base[e], cached = h.cache_len[e];
+    if (reprefill || start != base) {
+        // this env's window moved (slide, truncation, restart): its rows are forwarded again from position 0.  In a turn scheduled as "append" that
+        // is fine as long as the window fits the turn's chunk budget (a restarted window is one observation long); otherwise the schedule was wrong
+        if (!reprefill && total - start > feed_budget) atomicOr(h.flags, 1);
+        base = start; cached = 0;
+    }
+    h.base[e] = base;
+    h.feed_start[e] = base + cached;
+    h.feed_len[e] = total - (base + cached);
+    h.cache_len[e] = total - base;                                              // after this turn's chunk forwards
+    len0[e] = cached;
+    if (len1) len1[e] = cached;
+}
+
+__global__ void maze_hist_chunk_kernel(MazeHist h, int j, int chunk, int32_t *__restrict__ chunk_tok, int32_t *__restrict__ chunk_cnt, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * chunk) return;
+    const int e = i / chunk, k = i - e * chunk;
+    const int len = h.feed_len[e], p = j * chunk + k;
+    chunk_tok[i] = p < len ? h.hist[(size_t)e * h.hcap + h.feed_start[e] + p] : 0;
+    if (k == 0) chunk_cnt[e] = max(0, min(chunk, len - j * chunk));
+}
+
+// after maze_action_kernel: the action joins the window.  A LEGAL action's ids are the tokenizer's own encoding of its string (`act_tok`: the next
+// prompt is tokenizer.encode(text of the window), whatever ids the policy generated to spell 'move left\n'); an illegal string never reaches a
+// later prompt (the env answers with (observation,) alone, env.py:179-180) — its generated ids are kept only as a place holder item.  The K/V rows of
+// the generated ids that were forwarded (all but the last one) stay valid as far as they ARE the action's ids: the cache is cut back to prompt +
+// that common prefix.  act_tok [4][act_cap]: ids of action a, its length in the last slot.
+__global__ void maze_hist_action_kernel(lmrl_maze_traj tr, MazeHist h, const uint8_t *__restrict__ tok_blen, int vocab, int max_new,
+                                        const int32_t *__restrict__ act_tok, int act_cap, int32_t *__restrict__ len0, int32_t *__restrict__ len1, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || tr.obs_idx[e] < 0) return;
+    int32_t *off = h.item_off + (size_t)e * (h.max_items + 1);
+    int32_t *hist = h.hist + (size_t)e * h.hcap;
+    int ni = h.n_items[e], total = off[ni];
+    const int gl = tr.out_len[e];
+    const int code = tr.act[e];
+    const int al = code < 4 ? act_tok[code * act_cap + act_cap - 1] : gl;
+    if (ni >= h.max_items || total + al > h.hcap) { atomicOr(h.flags, 2); return; }
+    const int fwd = gl > 0 ? gl - 1 : 0;                                        // generated ids that went through the model (lmrl_gen_accept)
+    int lcp = 0;
+    if (code < 4) {
+        bool same = true;
+        for (int k = 0; k < al; k++) {
+            const int tok = act_tok[code * act_cap + k];
+            hist[total + k] = tok;
+            same = same && k < fwd && tr.out_tok[(size_t)e * max_new + k] == tok;
+            if (same) lcp = k + 1;
+        }
+    } else {
+        for (int k = 0; k < gl; k++) hist[total + k] = tr.out_tok[(size_t)e * max_new + k];
+    }
+    off[ni + 1] = total + al;
+    h.n_items[e] = ni + 1;
+    const int cached = (total - h.base[e]) + lcp;                                // prompt rows + the generated rows that equal the action's ids
+    h.cache_len[e] = cached;
+    len0[e] = cached;
+    if (len1) len1[e] = cached;
+}
+
 }  // namespace lmrl
 
 using namespace lmrl;
@@ -206,7 +321,7 @@ lmrl_maze_tok_ctx *lmrl_maze_tok_create(const int32_t *obs_tok, const int32_t *o
 
 void lmrl_maze_tok_destroy(lmrl_maze_tok_ctx *c) {
     if (!c) return;
-    for (void *p : {(void *)c->obs_tok_d, (void *)c->obs_len_d, (void *)c->goal_slot_d, (void *)c->tok_bytes_d, (void *)c->tok_blen_d})
+    for (void *p : {(void *)c->obs_tok_d, (void *)c->obs_len_d, (void *)c->goal_slot_d, (void *)c->tok_bytes_d, (void *)c->tok_blen_d, (void *)c->act_tok_d})
         if (p) (void)hipFree(p);
     delete c;
 }
@@ -239,6 +354,58 @@ int lmrl_maze_tok_action(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, int n, 
     LMRL_REQUIRE(c && tr && n > 0, "lmrl_maze_tok_action: bad argument");
     hipLaunchKernelGGL(maze_action_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), *tr, c->tok_bytes_d, c->tok_blen_d, c->vocab,
                        c->max_new, c->max_turns, n);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+static MazeHist hist_of(const lmrl_maze_hist *h) {
+    return MazeHist{h->hist, h->item_off, h->n_items, h->feed_start, h->feed_len, h->cache_len, h->base, h->prompt_len, h->win_floor, h->flags, h->hcap, h->max_items};
+}
+static bool hist_ok(const lmrl_maze_hist *h) {
+    return h && h->hist && h->item_off && h->n_items && h->feed_start && h->feed_len && h->cache_len && h->base && h->prompt_len && h->win_floor && h->flags &&
+           h->hcap > 0 && h->max_items > 0;
+}
+
+int lmrl_maze_hist_begin(const lmrl_maze_hist *h, int32_t *len0_d, int32_t *len1_d, int n, void *stream) {
+    LMRL_REQUIRE(hist_ok(h) && len0_d && n > 0, "lmrl_maze_hist_begin: bad argument");
+    hipLaunchKernelGGL(maze_hist_begin_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), hist_of(h), len0_d, len1_d, n);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_maze_hist_observe(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const lmrl_maze_hist *h, int last_k, int max_input_length, int reprefill,
+                           int feed_budget, int32_t *len0_d, int32_t *len1_d, int n, void *stream) {
+    LMRL_REQUIRE(c && tr && hist_ok(h) && last_k >= 1 && max_input_length > 0 && feed_budget > 0 && len0_d && n > 0, "lmrl_maze_hist_observe: bad argument");
+    hipLaunchKernelGGL(maze_hist_observe_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), *tr, hist_of(h), c->obs_tok_d, c->obs_len_d, c->obs_cap,
+                       last_k, max_input_length, reprefill, feed_budget, c->max_turns, len0_d, len1_d, n);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_maze_hist_chunk(const lmrl_maze_hist *h, int j, int chunk, int32_t *chunk_tok_d, int32_t *chunk_cnt_d, int n, void *stream) {
+    LMRL_REQUIRE(hist_ok(h) && chunk_tok_d && chunk_cnt_d && j >= 0 && chunk > 0 && n > 0, "lmrl_maze_hist_chunk: bad argument");
+    hipLaunchKernelGGL(maze_hist_chunk_kernel, dim3(ceil_div(n * chunk, 256)), dim3(256), 0, as_stream(stream), hist_of(h), j, chunk, chunk_tok_d, chunk_cnt_d, n);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_maze_tok_set_actions(lmrl_maze_tok_ctx *c, const int32_t *act_tok, int act_cap) {
+    LMRL_REQUIRE(c && act_tok && act_cap >= 2, "lmrl_maze_tok_set_actions: bad argument");
+    for (int a = 0; a < 4; a++)
+        LMRL_REQUIRE(act_tok[a * act_cap + act_cap - 1] > 0 && act_tok[a * act_cap + act_cap - 1] < act_cap, "lmrl_maze_tok_set_actions: action length outside (0, act_cap)");
+    if (c->act_tok_d) (void)hipFree(c->act_tok_d);
+    c->act_tok_d = nullptr;
+    LMRL_CHECK_HIP(hipMalloc((void **)&c->act_tok_d, sizeof(int32_t) * 4 * (size_t)act_cap));
+    LMRL_CHECK_HIP(hipMemcpy(c->act_tok_d, act_tok, sizeof(int32_t) * 4 * (size_t)act_cap, hipMemcpyHostToDevice));
+    c->act_cap = act_cap;
+    return LMRL_OK;
+}
+
+int lmrl_maze_hist_action(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const lmrl_maze_hist *h, int32_t *len0_d, int32_t *len1_d, int n, void *stream) {
+    LMRL_REQUIRE(c && tr && hist_ok(h) && len0_d && n > 0, "lmrl_maze_hist_action: bad argument");
+    LMRL_REQUIRE(c->act_tok_d, "lmrl_maze_hist_action: call lmrl_maze_tok_set_actions first");
+    hipLaunchKernelGGL(maze_hist_action_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), *tr, hist_of(h), c->tok_blen_d, c->vocab, c->max_new,
+                       c->act_tok_d, c->act_cap, len0_d, len1_d, n);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

@@ -66,8 +66,20 @@ def token_byte_table(tokenizer, vocab: int):
     return tb, bl
 
 
+class _CHist(ctypes.Structure):            # lmrl_maze_hist (include/lmrl_amd.h)
+    _fields_ = [(n, ctypes.c_void_p) for n in ("hist", "item_off", "n_items", "feed_start", "feed_len", "cache_len", "base", "prompt_len", "win_floor", "flags")] + \
+               [("hcap", ctypes.c_int32), ("max_items", ctypes.c_int32)]
+
+
 class MazeRolloutEngine:
-    """B lock-step Maze episodes (last_k = 1) driven by a GPT-2 policy on one GPU.
+    """B lock-step Maze episodes driven by a GPT-2 policy on one GPU.
+
+    env.last_k == 1 (the fully observed scripts): the prompt is a function of (goal, cell) — prompt table + prefix cache, below.
+    env.last_k > 1 (round 6; partially_observed_bc.py:241 runs last_k = 40): the prompt is the text of the item window
+    `(history + [action] + [observation])[-last_k:]` (maze/env/env.py:182-184), left-truncated to `max_input_length` tokens.  The engine keeps a
+    persistent per-env KV cache: while the window only grows ("append" turns) just the action's unforwarded tail and the new observation go through
+    the model; once it slides or is truncated every position shifts (GPT-2's absolute position embeddings) and the window is forwarded again from
+    position 0 ("re-prefill" turns).  Needs a tokenizer whose encoding of a concatenation is the concatenation of the encodings (byte level).
 
     `value_engine` + `q1_head` (+ `q2_head`) + `beta` make it the ILQL value policy (value_rl_base/gpt2/generation.py:97-119), as in
     `WordleRolloutEngine`.  `prefix_cache=False` prefills the observation tokens per env per turn instead (16-token chunks): the
@@ -88,9 +100,9 @@ class MazeRolloutEngine:
                                session_flags=session_flags)
         self._lanes = None
         venv = env.as_batched() if isinstance(env, M.MazeEnv) else env
-        if venv.last_k != 1:
-            raise ValueError("MazeRolloutEngine: the device loop covers one-item histories (last_k = 1); use interact_environment with "
-                             "GPT2PPOPolicy for longer histories")
+        self.last_k = int(venv.last_k)
+        if self.last_k != 1:
+            prefix_cache = False                       # a prompt is no longer a function of (goal, cell)
         if max_turns is None:
             if venv.max_steps is None:
                 raise ValueError("MazeRolloutEngine: env without max_steps needs max_turns")
@@ -137,6 +149,8 @@ class MazeRolloutEngine:
             raise _lib.LmrlError(self._L.lmrl_last_error().decode())
         # ---- sessions
         tmax = self.obs_cap + -(-max_new_tokens // 16) * 16        # whole 16-token prompt chunks (per-turn prefill mode) + the generated ids
+        if self.last_k != 1:
+            tmax = -(-int(max_input_length) // 16) * 16 + -(-max_new_tokens // 16) * 16
         self.veng, self.q1, self.q2, self.beta = value_engine, q1_head, q2_head, float(beta)
         assert (value_engine is None) == (q1_head is None), "value_engine and q1_head come together"
         self.engines = [engine] + ([value_engine] if value_engine is not None else [])
@@ -160,6 +174,32 @@ class MazeRolloutEngine:
         self.episodes = 0                              # episode batches run by text_env_eval so far: successive calls draw fresh sampler noise
         if prefix_cache:
             self.refresh_prefix_cache()
+        if self.last_k != 1:
+            # ---- item-window state: token history of the whole episode + item offsets (2 items per turn after the first observation)
+            # a legal action enters later prompts as the tokenizer's encoding of its text, whatever ids spelled it (the next prompt is
+            # tokenizer.encode(window text)); requires an encoding that is concatenative across items (byte level; BPE: items end in a newline)
+            acts = [list(tokenizer.encode(self.in_str_process(a))) for a in ("move left\n", "move right\n", "move up\n", "move down\n")]
+            act_len = max(len(a) for a in acts)
+            act_cap = act_len + 1
+            at = np.zeros((4, act_cap), dtype=np.int32)
+            for i, a in enumerate(acts):
+                at[i, :len(a)] = a
+                at[i, act_cap - 1] = len(a)
+            _lib.check(self._L.lmrl_maze_tok_set_actions(self._tok, at.ctypes.data, act_cap), "lmrl_maze_tok_set_actions")
+            item_max = max(act_len, max_new_tokens)
+            max_items = 2 * T + 2
+            hcap = (T + 1) * (self.max_obs_len + item_max)
+            self.hist = dict(hist=z(B, hcap, dt=t.int32), item_off=z(B, max_items + 1, dt=t.int32), n_items=z(B, dt=t.int32), feed_start=z(B, dt=t.int32),
+                             feed_len=z(B, dt=t.int32), cache_len=z(B, dt=t.int32), base=z(B, dt=t.int32), prompt_len=z(B, dt=t.int32), win_floor=z(B, dt=t.int32),
+                             flags=z(1, dt=t.int32))
+            self._chist = _CHist(*[self.hist[n].data_ptr() for n, _ in _CHist._fields_[:10]], hcap, max_items)
+            self._turn_i = 0
+            self._turn_graphs = {}
+            # static schedule: turn t (0-based) has 2 t + 1 items and at most (t + 1) observations + t actions of tokens
+            pb = lambda i: (i + 1) * self.max_obs_len + i * act_len
+            self._prompt_bound = [min(pb(i), self._max_input_length) for i in range(T + 1)]
+            self._append_turn = [2 * i + 1 <= self.last_k and pb(i) <= self._max_input_length for i in range(T + 1)]
+            self._append_chunks = -(-(self.max_obs_len + act_len) // 16)
 
     def close(self):
         if getattr(self, "_tok", None):
@@ -167,6 +207,30 @@ class MazeRolloutEngine:
             self._tok = None
         self.env.close()
         self._drop_lanes()
+
+    _script = None      # (steer ids int32 [T][max_new][B], turn counter int32 [1], this turn's rows [max_new][B], strength)
+
+    def set_scripted_actions(self, codes, strength: float = 30.0) -> None:
+        """Synthetic-workload hook (bench.py / tools, as `WordleRolloutEngine`'s scripted guesses): `codes` int [T][B] of LMRL_MAZE_LEFT..DOWN — in
+        turn t the sampler of env b is steered (+`strength` on one logit per generated position; every logit is still computed and sampled) towards
+        spelling that move's text with the tokenizer's own ids, so that a random-init policy walks and its history window fills as a trained
+        policy's does.  None switches it off.  Captured turn graphs are dropped (the steer operand becomes part of a turn)."""
+        import torch
+        t = torch
+        self.turn_graph = None
+        if codes is None:
+            self._script = None
+            return
+        codes = np.asarray(codes, dtype=np.int64)
+        assert codes.shape == (self.T, self.B) and codes.min() >= 0 and codes.max() < 4
+        acts = [list(self.tok.encode(self.in_str_process(a))) for a in ("move left\n", "move right\n", "move up\n", "move down\n")]
+        table = np.full((4, self.max_new), -1, dtype=np.int32)
+        for i, a in enumerate(acts):
+            table[i, :min(len(a), self.max_new)] = a[:self.max_new]
+        steer = np.full((self.T + 4 * self.T + 8, self.max_new, self.B), -1, dtype=np.int32)   # [T (+ slack: capture warm-ups advance the counter too)][max_new][B]
+        steer[:self.T] = table[codes].transpose(0, 2, 1)
+        self._script = (t.from_numpy(steer).to(self.dev), t.zeros(1, dtype=t.int32, device=self.dev),
+                        t.full((self.max_new, self.B), -1, dtype=t.int32, device=self.dev), float(strength))
 
     def _drop_lanes(self):
         for twin, _ in (self._lanes or [])[1:]:
@@ -209,11 +273,29 @@ class MazeRolloutEngine:
             self.refresh_prefix_cache()
 
     # ---- one lock-step turn ----------------------------------------------------------------------------------------------------------
-    def _turn(self, temperature: float, top_k: int, sample_seed: int, logits_out=None):
+    def _turn(self, temperature: float, top_k: int, sample_seed: int, logits_out=None, turn_index: int = 0):
         L, sp, tr, B = self._L, _lib.stream_ptr(), ctypes.byref(self._ctraj), self.B
         ck = _lib.check
         ck(L.lmrl_maze_tok_turn(self._tok, tr, _lib.ptr(self.env.state), B, sp), "maze_tok_turn")
-        if self.prefix_cache:
+        if self.last_k != 1:
+            # item window on the persistent cache: this turn's feed = the action's unforwarded tail + the new observation (append), or the whole
+            # window from position 0 (re-prefill)
+            ti = min(turn_index, self.T)
+            append = self._append_turn[ti]
+            hs = ctypes.byref(self._chist)
+            len1 = _lib.ptr(self.vses.len) if self.vses is not None else None
+            n_chunks = self._append_chunks if append else -(-self._prompt_bound[ti] // 16)
+            ck(L.lmrl_maze_hist_observe(self._tok, tr, hs, self.last_k, self._max_input_length, 0 if append else 1, n_chunks * 16, _lib.ptr(self.ses.len), len1,
+                                        B, sp), "maze_hist_observe")
+            for ses in self.sessions:
+                ses._len_bound = 0
+                ses.shared_prefix = 0
+                ses._prefix = None
+            for j in range(n_chunks):
+                ck(L.lmrl_maze_hist_chunk(hs, j, 16, _lib.ptr(self.chunk_tok), _lib.ptr(self.chunk_cnt), B, sp), "maze_hist_chunk")
+                for ses in self.sessions:
+                    ses.forward(self.chunk_tok, self.chunk_cnt, 16, len_bound_after=self._prompt_bound[ti])
+        elif self.prefix_cache:
             for ses, cache in zip(self.sessions, self.caches):
                 if self.prefix_indexed:
                     ses.attach_prefix_from(cache, self.traj["obs_idx"], self.max_obs_len)
@@ -226,8 +308,11 @@ class MazeRolloutEngine:
                 ck(L.lmrl_maze_tok_prompt(self._tok, tr, j, 16, _lib.ptr(self.chunk_tok), _lib.ptr(self.chunk_cnt), B, sp), "maze_tok_prompt")
                 for ses in self.sessions:
                     ses.forward(self.chunk_tok, self.chunk_cnt, 16)
+        script = self._script
+        if script is not None:      # this turn's steer rows: row `turn counter` of the scripted table (a device-side index: the same launch in every replay)
+            ck(L.lmrl_gather_rows_bytes(script[0].data_ptr(), script[1].data_ptr(), script[2].data_ptr(), 1, self.max_new * B * 4, sp), "lmrl_gather_rows_bytes")
         for k in range(self.max_new):
-            p = SampleParams(temperature, top_k, sample_seed, k, 0.0, self.beta, self.pad, _lib.ptr(self.epoch))
+            p = SampleParams(temperature, top_k, sample_seed, k, script[3] if script is not None else 0.0, self.beta, self.pad, _lib.ptr(self.epoch))
             qops = [None, None]
             if self.vses is not None:
                 dv = self.veng.cfg.d_model
@@ -236,7 +321,8 @@ class MazeRolloutEngine:
                         ck(L.lmrl_gemm_bf16(_lib.ptr(self.vses.last_hidden), _lib.ptr(head["w1"]), _lib.ptr(head["b1"]), _lib.ptr(self.qh[i]),
                                             B, dv, dv, dv, dv, dv, 4, sp), "q head dense1 + relu")
                         qops[i] = (self.qh[i], head["w2"], head["b2"])
-            self.ses.sample(p, active=self.traj["gen_active"], logits_out=logits_out, q1=qops[0], q2=qops[1], want_logprob=False)
+            self.ses.sample(p, steer_tok=script[2][k] if script is not None else None, active=self.traj["gen_active"], logits_out=logits_out, q1=qops[0],
+                            q2=qops[1], want_logprob=False)
             ck(L.lmrl_gen_accept(_lib.ptr(self.ses.token), _lib.ptr(self.traj["gen_active"]), _lib.ptr(self.traj["out_tok"]),
                                  _lib.ptr(self.traj["out_len"]), _lib.ptr(self.next_tok), _lib.ptr(self.next_cnt),
                                  -1 if self.eos is None else int(self.eos), self.max_new, B, sp), "lmrl_gen_accept")
@@ -244,16 +330,66 @@ class MazeRolloutEngine:
                 for ses in self.sessions:
                     ses.forward(self.next_tok, self.next_cnt, 1)
         ck(L.lmrl_maze_tok_action(self._tok, tr, B, sp), "maze_tok_action")
+        if self.last_k != 1:
+            ck(L.lmrl_maze_hist_action(self._tok, tr, ctypes.byref(self._chist), _lib.ptr(self.ses.len),
+                                       _lib.ptr(self.vses.len) if self.vses is not None else None, B, sp), "maze_hist_action")
         e = self.env
         ck(L.lmrl_maze_step(e._ctx, _lib.ptr(e.state), _lib.ptr(self.traj["act"]), _lib.ptr(self.traj["stepping"]), _lib.ptr(e.reward),
                             _lib.ptr(e.done), _lib.ptr(e.kind), _lib.ptr(e.walls), B, sp), "lmrl_maze_step")
         ck(L.lmrl_maze_tok_result(self._tok, tr, _lib.ptr(e.reward), _lib.ptr(e.done), _lib.ptr(e.kind), B, sp), "maze_tok_result")
         self.epoch.add_(1)
+        if script is not None:
+            script[1].add_(1)
+
+    def _reset_script_counter(self):
+        if self._script is not None:
+            self._script[1].zero_()
+
+    def _capture_history_turns(self, temperature: float, top_k: int, sample_seed: int):
+        """last_k > 1: one hipGraph per KIND of turn — the append turn (a fixed number of 16-token chunks) and one re-prefill turn per distinct
+        chunk count of the schedule (the window's token bound grows until it reaches max_input_length)."""
+        import torch
+        t = torch
+        self._graph_args = (temperature, top_k, sample_seed)
+        self._logits = t.empty(self.B, self.eng.cfg.vocab_padded, dtype=t.float32, device=self.dev) if top_k > 0 else None
+        self._turn_graphs = {}
+        kinds = {}
+        for ti in range(self.T):
+            key = ("a",) if self._append_turn[ti] else ("r", -(-self._prompt_bound[ti] // 16))
+            kinds.setdefault(key, ti)
+        for key, ti in kinds.items():
+            self.env.reset_device([0] * self.B)
+            self._reset_script_counter()
+            self._hist_begin()
+            _lib.check(self._L.lmrl_maze_tok_begin(self._tok, ctypes.byref(self._ctraj), self.B, _lib.stream_ptr()), "maze_tok_begin")
+            self._turn(temperature, top_k, sample_seed, self._logits, turn_index=ti)           # eager warm-up
+            t.cuda.synchronize()
+            g = t.cuda.CUDAGraph()
+            with t.cuda.graph(g, capture_error_mode="thread_local"):
+                self._turn(temperature, top_k, sample_seed, self._logits, turn_index=ti)
+            self._turn_graphs[key] = g
+        self.turn_graph = True
+
+    def _hist_begin(self):
+        _lib.check(self._L.lmrl_maze_hist_begin(ctypes.byref(self._chist), _lib.ptr(self.ses.len), _lib.ptr(self.vses.len) if self.vses is not None else None,
+                                                self.B, _lib.stream_ptr()), "maze_hist_begin")
+        for ses in self.sessions:
+            ses._len_bound = 0
+            ses.shared_prefix = 0
+            ses._prefix = None
+        self._turn_i = 0
+
+    def history_flags(self) -> int:
+        """last_k > 1: 0 when every turn of the last episodes ran as scheduled (bit 0: an append turn would have needed a re-prefill — a prompt outgrew
+        the static bound; bit 1: history buffer overflow).  One readback."""
+        return int(self.hist["flags"].cpu().numpy()[0]) if self.last_k != 1 else 0
 
     def capture_turn(self, temperature: float = 1.0, top_k: int = 0, sample_seed: int = 0):
         """One turn (~ max_new x n_layer x 7 launches) as a hipGraph; `run_episode(..., use_graph=True)` replays it per turn."""
         import torch
         t = torch
+        if self.last_k != 1:
+            return self._capture_history_turns(temperature, top_k, sample_seed)
         self._graph_args = (temperature, top_k, sample_seed)
         self._logits = t.empty(self.B, self.eng.cfg.vocab_padded, dtype=t.float32, device=self.dev) if top_k > 0 else None
         self.env.reset_device([0] * self.B)
@@ -292,6 +428,22 @@ class MazeRolloutEngine:
         self.env.reset_device(list(seeds), options)
         _lib.check(self._L.lmrl_maze_tok_begin(self._tok, ctypes.byref(self._ctraj), self.B, _lib.stream_ptr()), "maze_tok_begin")
         self.epoch.fill_(int(episode) << 12)
+        if self._script is not None:
+            self._script[1].zero_()
+        if self.last_k != 1:
+            self._hist_begin()
+
+            def turn():
+                ti = min(self._turn_i, self.T - 1)
+                self._turn_i += 1
+                if use_graph:
+                    key = ("a",) if self._append_turn[ti] else ("r", -(-self._prompt_bound[ti] // 16))
+                    for ses in self.sessions:          # (host-side bounds only: the replayed launches carry their own)
+                        ses._len_bound = 0
+                    self._turn_graphs[key].replay()
+                else:
+                    self._turn(temperature, top_k, sample_seed, logits, turn_index=ti)
+            return turn
         return self.turn_graph.replay if use_graph else (lambda: self._turn(temperature, top_k, sample_seed, logits))
 
     # ---- the online-RL hand-over: the finished episodes as PPO data, on the device --------------------------------------------------
@@ -306,6 +458,8 @@ class MazeRolloutEngine:
         import torch
         from .algorithms.ppo_device import PPORecords
         t, L, sp = torch, self._L, _lib.stream_ptr()
+        if self.last_k != 1:
+            raise ValueError("ppo_records: the per-transition chains of the Maze online script are built for one-item histories (last_k = 1)")
         if self.in_str_process("\x00probe") != "\x00probe" or self.obs_len_h.max() >= self._max_input_length:
             raise ValueError("ppo_records: the PPO chains tokenise the raw observation text — in_str_process must be the identity and prompts untruncated")
         B = self.B if n is None else int(n)
@@ -456,16 +610,29 @@ class MazeRolloutEngine:
             gl, kd, rw = gen_len[b, :n].tolist(), kinds[b, :n].tolist(), reward[b, :n].tolist()
             gb = gen[b]
             trans = []
+            items = ()                  # last_k > 1: every item of the episode so far; a history is its last `last_k` items (maze/env/env.py:182-184)
             for i in range(n):
-                pre = desc(gi, pr[i], pc[i])
-                post_action = pre + (action(tuple(gb[i, :gl[i]].tolist())),)
+                obs_i = desc(gi, pr[i], pc[i])
+                if self.last_k == 1:
+                    pre = obs_i
+                else:
+                    items = items + obs_i if i == 0 else items
+                    pre = items[-self.last_k:]
+                act = action(tuple(gb[i, :gl[i]].tolist()))
+                post_action = pre + (act,)
                 kind = kd[i]
+                nxt = None
                 if kind == M.KIND_FAILURE:
                     post, done = fail, True
                 elif kind == M.KIND_SUCCESS:
                     post, done = succ, True
                 else:
-                    post, done = (desc(gi, pr[i + 1], pc[i + 1]) if i + 1 < n else desc(gi, int(st[b, 0]), int(st[b, 1]))), False
+                    nxt = desc(gi, pr[i + 1], pc[i + 1]) if i + 1 < n else desc(gi, int(st[b, 0]), int(st[b, 1]))
+                    post, done = nxt, False
+                if self.last_k != 1 and nxt is not None:
+                    # an action string outside the action dict: the env returns (observation,) alone and the window restarts there (env.py:179-180)
+                    items = nxt if kind == M.KIND_OBS_ONLY else items + (act,) + nxt
+                    post = items[-self.last_k:]
                 trans.append(InteractionTransition(pre, post_action, post, float(rw[i]), done))
             out.append(trans)
         return out

@@ -40,7 +40,7 @@ class MergedByteTokenizer:
 
 
 def _setup(dev, B, max_new, max_steps, describe="describe_observation_give_position", prefix_cache=True, seed=0, boost=12.0,
-           prefix_indexed=True, width="tiny"):
+           prefix_indexed=True, width="tiny", last_k=1, max_input_length=256, whole_actions_only=False):
     from lmrl_gym_amd.envs import maze as M
     from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine
     from lmrl_gym_amd.maze_rollout import MazeRolloutEngine
@@ -55,13 +55,13 @@ def _setup(dev, B, max_new, max_steps, describe="describe_observation_give_posit
     d, V = cfg.d_model, cfg.vocab
     g = torch.Generator().manual_seed(seed + 2)
     bias = torch.full((V,), -boost)
-    for i in (256, 257, 258, 259, 260, 261, 262, 263, 264, 10, 266, 267):     # action pieces and the eos
+    for i in ((256, 257, 258, 259) if whole_actions_only else (256, 257, 258, 259, 260, 261, 262, 263, 264, 10, 266, 267)):     # action pieces and the eos
         bias[i] = 0.0
     head = heads_to_engine_layout({"dense1.kernel": torch.randn(d, d, generator=g) * 0.05, "dense1.bias": torch.zeros(d),
                                    "dense2.kernel": torch.randn(d, V, generator=g) * 0.3, "dense2.bias": bias}, cfg.vocab_padded, dev)
-    env = M.setup_maze_env("double_t_maze", describe, "standard_reward", last_k=1, max_steps=max_steps)
+    env = M.setup_maze_env("double_t_maze", describe, "standard_reward", last_k=last_k, max_steps=max_steps)
     eng = MazeRolloutEngine(pi, tok, env, B, max_new_tokens=max_new, eos_token_id=tok.eos_token_id, prefix_cache=prefix_cache,
-                            prefix_indexed=prefix_indexed, value_engine=vb, q1_head=head, q2_head=None, beta=1.0)
+                            prefix_indexed=prefix_indexed, value_engine=vb, q1_head=head, q2_head=None, beta=1.0, max_input_length=max_input_length)
     return eng, tok, pi, vb, head, env
 
 
@@ -179,6 +179,62 @@ def test_greedy_device_loop_equals_generic_text_path(width, B):
     assert n_steps >= B * 3
     kinds = {t.post_action_history[-1].text for ep in mine for t in ep}
     assert len(kinds) >= 3, kinds                                # several distinct actions were taken
+
+
+@pytest.mark.parametrize("last_k,max_input_length,max_steps,describe,max_new", [
+    (40, 1024, 7, "describe_observation_only_walls", 1), (5, 512, 8, "describe_observation_only_walls", 1),
+    (40, 160, 6, "describe_observation_give_position", 1), (40, 1024, 7, "describe_observation_only_walls", 3), (4, 512, 6, "describe_observation_give_position", 2)])
+def test_history_windows_on_the_device_loop_equal_the_generic_text_path(last_k, max_input_length, max_steps, describe, max_new):
+    """MazeEnv(last_k > 1) — partially_observed_bc.py:241 runs last_k = 40 — on the device loop: the prompt is the window of the last k history items
+    (maze/env/env.py:182-184), left-truncated to max_input_length tokens (ppo/gpt2/interface.py:519-524).  Greedy decoding, same weights: the
+    transitions (windowed pre / post-action / post-transition histories, rewards, done) == interact_environment(env, GPT2ValuePolicy), the host
+    path that renders, tokenises and prefills every turn.  Regimes: the window only grows (append turns: just the action's tail + the new
+    observation are forwarded), it slides after two turns (last_k = 5 / 4: re-prefill turns), the token budget cuts it (max_input_length = 160),
+    and (max_new = 3: this policy then spells strings outside the action dict) the env answers with (observation,) alone, restarting the window
+    (env.py:179-180).  max_new = 1: one-token actions ('move left' + the forced newline) — legal moves, real windows.
+    Eager turns == graph replays; the schedule flags stay clear."""
+    from lmrl_gym_amd import _lib, environment as E
+    from lmrl_gym_amd.maze_rollout import maze_out_str_process
+    from lmrl_gym_amd.policies import GPT2ValuePolicy
+    dev = _lib.require_gpu()
+    B = 40
+    eng, tok, pi, vb, head, env = _setup(dev, B, max_new, max_steps, describe, boost=6.0 if max_new > 1 else 30.0, last_k=last_k, max_input_length=max_input_length,
+                                         whole_actions_only=max_new == 1)
+    assert eng.last_k == last_k and not eng.prefix_cache
+    kinds = {(("a",) if eng._append_turn[i] else "r") for i in range(eng.T)}
+    if last_k == 40 and max_input_length == 1024:
+        assert kinds == {("a",)}                                   # the window never slides nor overflows: every turn appends
+    else:
+        assert "r" in kinds and ("a",) in kinds
+    seeds = [5 + 13 * i for i in range(B)]
+    eng.run_episode(seeds, None, temperature=0.0, use_graph=False, sync_every=0)
+    torch.cuda.synchronize()
+    eager = eng.interactions()
+    assert eng.history_flags() == 0
+    eng.run_episode(seeds, None, temperature=0.0, use_graph=True, sync_every=0)
+    torch.cuda.synchronize()
+    mine = eng.interactions()
+    assert eng.history_flags() == 0
+    assert mine == eager
+    pol = GPT2ValuePolicy(pi, vb, head, None, 1.0, tok, max_input_length=max_input_length, max_new_tokens=max_new, do_sample=False,
+                          eos_token_id=tok.eos_token_id, out_str_process=maze_out_str_process)
+    ref = E.interact_environment(env, pol, env_seed=seeds, bsize=B)
+    assert len(mine) == len(ref) == B
+    n_steps = longest = 0
+    for b, (x, y) in enumerate(zip(mine, ref)):
+        assert len(x) == len(y), (b, len(x), len(y))
+        for i, (tx, ty) in enumerate(zip(x, y)):
+            assert tx == ty, (b, i, tx, ty)
+            n_steps += 1
+            longest = max(longest, len(tx.pre_action_history))
+    assert n_steps >= B * 3
+    if max_new == 1:
+        assert longest == min(last_k, 2 * max_steps + 1)             # legal moves all the way: the window reached its full size
+    elif max_new == 3:
+        assert longest == 1                                          # every action string was illegal: the window restarted every turn
+    with pytest.raises(ValueError):
+        eng.ppo_records()
+    eng.close()
 
 
 def test_text_env_eval_lanes_return_the_one_lane_interactions():
