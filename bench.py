@@ -131,6 +131,9 @@ def cpu_baseline(vocab_words, budget_s=14.0):
         if per_turn_1024 <= 10.0:
             st, tt, tu = _cpu_rollout(vocab_words, 1024, 2, 4.0)
             by_batch["1024"] = dict(value=round(st / tt, 2), unit="env-steps/s", cores=n_all, sample=f"1024 envs x {tu} turn(s), same path; {tt:.1f} s")
+        elif per_turn_1024 <= 30.0:      # the metric's own batch, ONE lock-step turn (a turn cannot be interrupted; ~10-30 s of CPU work is the leg's bound)
+            st, tt, tu = _cpu_rollout(vocab_words, 1024, 1, 0.0)
+            by_batch["1024"] = dict(value=round(st / tt, 2), unit="env-steps/s", cores=n_all, sample=f"1024 envs x {tu} turn, same path; {tt:.1f} s")
         else:
             by_batch["1024"] = dict(value=None, skipped=f"one 256-env turn took {tt / tu:.1f} s on this host: a 1024-env turn (~{per_turn_1024:.0f} s) would not fit the leg's bound")
     else:
@@ -150,12 +153,15 @@ def cpu_baseline(vocab_words, budget_s=14.0):
         st, tt, used = run_scripted_timed(vocab_words, n_mt, gi_mt, threads=thr)
         mt_runs[used] = st / tt
     used_best = max(mt_runs, key=mt_runs.get)
-    best_value = max([s_all / t_all] + [v["value"] for v in by_batch.values() if v.get("value")])
-    return dict(value=s_all / t_all, unit="env-steps/s", cores=n_best, kind="port",
+    # `value` = the host's BEST measured point (any batch, any thread count tried): the fairest single number to put beside the GPU's
+    points = [(s_all / t_all, n_best, f"32 envs x {turns_all} turns; {t_all:.1f} s")] + \
+             [(v["value"], v["cores"], v["sample"]) for v in by_batch.values() if v.get("value")]
+    best_value, best_cores, best_sample = max(points, key=lambda x: x[0])
+    return dict(value=best_value, unit="env-steps/s", cores=best_cores, kind="port",
                 by_threads={str(k): round(v[0] / v[1], 2) for k, v in runs.items()},
-                sample=f"32 envs x {turns_all} turns (valid scripted guesses), GPT-2-small fp32 on torch-CPU re-prefilling the history every "
-                       f"turn as the reference does + C oracle env; {t_all:.1f} s",
-                by_batch=by_batch, best_value_any_batch=round(best_value, 2),
+                sample=f"{best_sample} (valid scripted guesses), GPT-2-small fp32 on torch-CPU re-prefilling the history every "
+                       f"turn as the reference does + C oracle env; the best of the batch / thread points below",
+                value_32_envs=round(s_all / t_all, 2), by_batch=by_batch, best_value_any_batch=round(best_value, 2),
                 one_thread=dict(value=s_one / t_one, cores=1, sample=f"16 envs x {turns_one} turns, same path; {t_one:.1f} s"),
                 env_only=dict(value=env_steps / te, unit="env-steps/s", cores=1,
                               sample=f"C oracle env alone (no LM), 2048 envs x 6 scripted steps, one thread, stepping loop only; {te:.2f} s",
