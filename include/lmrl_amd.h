@@ -333,6 +333,9 @@ size_t lmrl_gpt2_ws_bytes(const lmrl_gpt2 *m, int b, int c);
 #define LMRL_FWD_KV_FROM_GEMM  16u /* decode: the qkv GEMM epilogue appends the new K/V rows, the attention kernel only reads (A/B: attention faster, GEMM slower, net slower) */
 #define LMRL_FWD_ATTN_ITEMS2   64u /* decode attention: 2 (env, head) items per wave on a grid of half as many waves (A/B of the resident-size grid; bit-identical) */
 #define LMRL_FWD_ATTN_ITEMS3   128u /* ... 3 items per wave */
+#define LMRL_FWD_SKINNY       (1u << 30) /* single-token decode of <= 16 sequences: the layer's Dense products on the skinny-M kernels (csrc/skinny_gemm.h: one MFMA row block,
+                                          * K split over the waves of a workgroup, every load issued up front) — 7-16 us -> ~3 us per product at 8 rows; same formulas, K summed in
+                                          * 8 slices (not bit-identical to the tile kernels: a per-session choice) */
 #define LMRL_FWD_FULL_LAST_LAYER 32u /* chunk forwards: run the last layer's projection + MLP on every row (default: only on each env's last new token — the only row whose hidden state is returned; A/B and cross-check, bit-identical) */
 /* bits 16-31: reserved — the product library rejects them (LMRL_ERR_ARG). */
 /* bits 8-15: LMRL_FWD_SHARED_PREFIX(n) — positions [0, n) of EVERY env's cache hold the same K/V rows as env 0's (the caller copied them

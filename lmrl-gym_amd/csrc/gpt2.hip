@@ -23,6 +23,7 @@
 #include "common.h"
 #include <hip/hip_ext.h>
 #include "gemm_dispatch.h"
+#include "skinny_gemm.h"
 #ifdef LMRL_TOOLS
 #include "ablate_tools.h"
 #endif
@@ -1157,7 +1158,7 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
     }
     hipStream_t aux_stream = aux.stream; hipEvent_t aux_fork = aux.fork, aux_join = aux.join;
 #else
-    LMRL_REQUIRE((flags >> 16) == 0u, "lmrl_gpt2_forward: flag bits >= 16 are reserved (launch ablations exist only in the LMRL_TOOLS build)");
+    LMRL_REQUIRE(((flags & ~LMRL_FWD_SKINNY) >> 16) == 0u, "lmrl_gpt2_forward: flag bits 16-29 are reserved (launch ablations exist only in the LMRL_TOOLS build)");
 #define LMRL_ABL(bit) false
     constexpr hipStream_t aux_stream = nullptr; constexpr hipEvent_t aux_fork = nullptr, aux_join = nullptr;   // dead branches below still parse
     (void)aux_stream; (void)aux_fork; (void)aux_join;
@@ -1192,6 +1193,9 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
     // only reads.  Measured: attention 25.3 -> 23.8 us (0.53 of the HBM roofline) but the qkv GEMM 12.7 -> 15.3 us (its tile scatters 16-byte
     // stores over 128 envs' cache pages), a net loss of 1.2 us per layer — so it is off by default and kept as a per-call variant.
     const bool kv_from_gemm = fused && c == 1 && (flags & LMRL_FWD_KV_FROM_GEMM) && !(flags & LMRL_FWD_ATTN_VALU);
+    // LMRL_FWD_SKINNY (single-token decode of <= 16 sequences, LN-folded path): the four Dense products of a layer on skinny_gemm.h (one MFMA row block,
+    // K split over the 16 waves of a workgroup, every operand load issued up front) instead of the 64 x 64-tile latency chains
+    const bool skinny = fused && c == 1 && (flags & LMRL_FWD_SKINNY) && M <= 16 && !kv_from_gemm;
     const int append_in_attn = kv_from_gemm ? 0 : 1;
     // chunk forwards that return at most the last token's hidden state: the last layer's projection + MLP run on ONE row per env (the same
     // per-row arithmetic as on the full chunk: bit-identical results), or not at all when no hidden state is asked for (a prompt's
@@ -1213,7 +1217,9 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
         if (fused && LMRL_ABL(LMRL_ABLATE_QKV)) {
         } else if (fused) {
             GemmArgs g{w.h, L.wf_qkv, L.bf_qkv, w.qkv, M, 3 * d, d, d, 3 * d, 3 * d, w.stats, nullptr, L.cs_qkv, nsl, 1.f / (float)d, cf.ln_eps, m_dev};
-            if (kv_from_gemm) {   // decode: the new K / V rows go to the cache from this GEMM's epilogue, the attention kernel only reads
+            if (skinny && skinny_ok(g)) {
+                LMRL_CHECK_HIP(skinny_launch<EPI_BF16_LN>(g, s));
+            } else if (kv_from_gemm) {   // decode: the new K / V rows go to the cache from this GEMM's epilogue, the attention kernel only reads
                 g.kv_k = kc; g.kv_v = vc; g.kv_len = len_d; g.kv_cnt = cnt_d; g.kv_rowmap = row_map; g.kv_tmax = tmax; g.kv_d = d;
                 LMRL_CHECK_HIP(gemm_launch_ln<EPI_BF16_LN_KV>(g, s));
             } else {
@@ -1301,11 +1307,17 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
                 LMRL_CHECK_HIP(hipStreamWaitEvent(s, aux_join, 0));
             }
             else if (LMRL_ABL(LMRL_ABLATE_PROJ_CONCURRENT)) LMRL_CHECK_HIP(hipStreamWaitEvent(s, aux_join, 0));      // join
+            else if (skinny && skinny_ok(gp)) LMRL_CHECK_HIP(skinny_launch<EPI_RESID_F32_STATS>(gp, s));
             else if (!LMRL_ABL(LMRL_ABLATE_PROJ)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, s));
             GemmArgs gf{w.h, L.wf_fc, L.bf_fc, w.ff, M, cf.d_ff, d, d, cf.d_ff, cf.d_ff, w.stats, nullptr, L.cs_fc, nsl, 1.f / (float)d, cf.ln_eps, m_dev};
-            if (!LMRL_ABL(LMRL_ABLATE_FC)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_GELU_BF16_LN>(gf, s));
+            if (skinny && skinny_ok(gf)) LMRL_CHECK_HIP(skinny_launch<EPI_GELU_BF16_LN>(gf, s));
+            else if (!LMRL_ABL(LMRL_ABLATE_FC)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_GELU_BF16_LN>(gf, s));
             GemmArgs g2{w.ff, L.w_fc2, L.b_fc2, w.x, M, d, cf.d_ff, cf.d_ff, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
             if (LMRL_ABL(LMRL_ABLATE_FC2)) {}
+            else if (skinny && skinny_ok(g2)) {
+                if (l + 1 < cf.n_layer) LMRL_CHECK_HIP(skinny_launch<EPI_RESID_F32_STATS>(g2, s));
+                else LMRL_CHECK_HIP(skinny_launch<EPI_RESID_F32>(g2, s));
+            }
 #ifdef LMRL_TOOLS
             else if (LMRL_ABL(LMRL_ABLATE_FC2_SEAM3 | LMRL_ABLATE_FC2_SEAM2 | LMRL_ABLATE_FC2_SEAM6)) {
                 static float *seam_ws = nullptr;           // timing only

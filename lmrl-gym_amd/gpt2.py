@@ -166,6 +166,7 @@ class GPT2Engine:
 # lmrl_gpt2_forward flags (include/lmrl_amd.h): per-call variants, held per SESSION — never process state
 FWD_LN_STANDALONE, FWD_RAGGED_ALWAYS, FWD_RAGGED_NEVER, FWD_ATTN_VALU, FWD_KV_FROM_GEMM, FWD_FULL_LAST_LAYER = 1, 2, 4, 8, 16, 32
 FWD_ATTN_ITEMS2, FWD_ATTN_ITEMS3 = 64, 128
+FWD_SKINNY = 1 << 30       # decode forwards of <= 16 sequences on the skinny-M Dense kernels (csrc/skinny_gemm.h)
 
 
 class KVSession:

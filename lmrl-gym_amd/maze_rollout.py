@@ -23,7 +23,7 @@ import numpy as np
 
 from . import _lib
 from .envs import maze as M
-from .gpt2 import FWD_RAGGED_ALWAYS, GPT2Engine, SampleParams
+from .gpt2 import FWD_RAGGED_ALWAYS, FWD_SKINNY, GPT2Engine, SampleParams
 
 _TOK_BYTES = 16
 
@@ -154,6 +154,8 @@ class MazeRolloutEngine:
         self.veng, self.q1, self.q2, self.beta = value_engine, q1_head, q2_head, float(beta)
         assert (value_engine is None) == (q1_head is None), "value_engine and q1_head come together"
         self.engines = [engine] + ([value_engine] if value_engine is not None else [])
+        if batch <= 16:
+            session_flags |= FWD_SKINNY             # a handful of envs (configs[0]: 8): decode products on the skinny-M kernels (csrc/skinny_gemm.h)
         self.sessions = [e.session(batch, tmax, flags=session_flags) for e in self.engines]
         self.ses = self.sessions[0]
         self.vses = self.sessions[1] if value_engine is not None else None

