@@ -486,7 +486,10 @@ struct DecodePrefix {
     int tmax;
 };
 
-template <int U, bool PFX, bool HALF>
+// SPLIT (round 6, small batches): 4 waves share ONE (env, head) item — wave w takes the position batches w, w + 4, ... (32 positions each), the four
+// (max, sum, o) states meet in LDS and wave 0 writes the row.  At 8 envs x 12 heads the one-wave form is 96 waves walking ~5 dependent load batches
+// each (8.3 us per launch for kilobytes, profiles/r06_maze_b8_kernel_stats.csv); split, every batch of an item is in flight at once.
+template <int U, bool PFX, bool HALF, int SPLIT = 1>
 __device__ __forceinline__ void attention_decode_item(int wave_id, const uint16_t *__restrict__ qkv, uint16_t *__restrict__ kcache, uint16_t *__restrict__ vcache,
                                                       const int32_t *__restrict__ cnt, const int32_t *__restrict__ len, uint16_t *__restrict__ out,
                                                       int B, int H, int Tmax, int d, const int32_t *__restrict__ off, int n_shared, int append,
@@ -545,7 +548,9 @@ __device__ __forceinline__ void attention_decode_item(int wave_id, const uint16_
                 vr[u] = LMRL_DEC_LD16(vc + bo_);                                                              \
             }                                                                                                 \
         }
-    LMRL_DEC_LOAD(0);
+    const int sw = SPLIT > 1 ? (int)(threadIdx.x >> 6) : 0;         // SPLIT: this wave's first position batch (and its stride below)
+    const int t_first = sw * 8 * U;
+    LMRL_DEC_LOAD(t_first);
     uint32_t qp[4];                                                  // query slice as packed bf16 pairs, pre-scaled by 1/sqrt(64) (exact)
     {
         const uint32_t w[4] = {qv.x, qv.y, qv.z, qv.w};
@@ -575,8 +580,8 @@ __device__ __forceinline__ void attention_decode_item(int wave_id, const uint16_
         }                                                                                                      \
         m = m_new_;                                                                                            \
     } while (0)
-    for (int t0 = 0; t0 < L0; t0 += 8 * U) {
-        if (t0 > 0) LMRL_DEC_LOAD(t0);
+    for (int t0 = t_first; t0 < L0; t0 += 8 * U * SPLIT) {
+        if (t0 > t_first) LMRL_DEC_LOAD(t0);
 #pragma unroll
         for (int u = 0; u < U; u++)
             if (t0 + u * 8 < L0) {                                   // wave-uniform
@@ -584,7 +589,7 @@ __device__ __forceinline__ void attention_decode_item(int wave_id, const uint16_
                 LMRL_DEC_ROW(kr[u], vr[u], ok);
             }
     }
-    {   // position L0 (this step's own token): row group 0 attends it last
+    if (sw == 0) {   // position L0 (this step's own token): row group 0 attends it last
         const bool ok = rr == 0;
         LMRL_DEC_ROW(knew, vnew, ok);
     }
@@ -597,14 +602,40 @@ __device__ __forceinline__ void attention_decode_item(int wave_id, const uint16_
     const float w = __expf(m - mm);
     float lt = l * w;
     lt += __shfl_xor(lt, 8); lt += __shfl_xor(lt, 16); lt += __shfl_xor(lt, 32);
-    const float inv = 1.f / lt;
     float r8[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         float a = o[e] * w;
         a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
-        r8[e] = a * inv;
+        r8[e] = a;
     }
+    if (SPLIT > 1) {      // the four waves' states of this item: (max, sum) + 64 unnormalised outputs each, merged by wave 0 in wave order
+        __shared__ float xs[4][66];
+        if (rr == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) xs[sw][cc * 8 + e] = r8[e];
+            if (cc == 0) { xs[sw][64] = mm; xs[sw][65] = lt; }
+        }
+        __syncthreads();
+        if (sw != 0) return;
+        float M4 = xs[0][64];
+#pragma unroll
+        for (int q = 1; q < 4; q++) M4 = fmaxf(M4, xs[q][64]);
+        float L4 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) r8[e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float sc = __expf(xs[q][64] - M4);
+            L4 += xs[q][65] * sc;
+#pragma unroll
+            for (int e = 0; e < 8; e++) r8[e] += xs[q][cc * 8 + e] * sc;
+        }
+        lt = L4;
+    }
+    const float inv = 1.f / lt;
+#pragma unroll
+    for (int e = 0; e < 8; e++) r8[e] *= inv;
     if (rr == 0) {
         uint4 pk;
         pk.x = pack_bf16x2(r8[0], r8[1]); pk.y = pack_bf16x2(r8[2], r8[3]);
@@ -634,6 +665,14 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const uint16_t *_
 #pragma unroll 1
     for (int it = 0; it < NI; it++)
         attention_decode_item<U, PFX, HALF>(wave_id + it * (int)gridDim.x * 4, qkv, kcache, vcache, cnt, len, out, B, H, Tmax, d, off, n_shared, append, pfx);
+}
+
+template <int U, bool PFX>   // one 4-wave workgroup per (env, head): small batches (LMRL_FWD_SKINNY)
+__global__ __launch_bounds__(256) void attention_decode_split_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ kcache, uint16_t *__restrict__ vcache,
+                                                                     const int32_t *__restrict__ cnt, const int32_t *__restrict__ len, uint16_t *__restrict__ out,
+                                                                     int B, int H, int Tmax, int d, const int32_t *__restrict__ off, int n_shared, int append,
+                                                                     DecodePrefix pfx) {
+    attention_decode_item<U, PFX, false, 4>((int)blockIdx.x, qkv, kcache, vcache, cnt, len, out, B, H, Tmax, d, off, n_shared, append, pfx);
 }
 
 // ------------------------------------------------------------------------------------------ chunk attention on MFMA
@@ -1195,7 +1234,15 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
     const bool kv_from_gemm = fused && c == 1 && (flags & LMRL_FWD_KV_FROM_GEMM) && !(flags & LMRL_FWD_ATTN_VALU);
     // LMRL_FWD_SKINNY (single-token decode of <= 16 sequences, LN-folded path): the four Dense products of a layer on skinny_gemm.h (one MFMA row block,
     // K split over the 16 waves of a workgroup, every operand load issued up front) instead of the 64 x 64-tile latency chains
-    const bool skinny = fused && c == 1 && (flags & LMRL_FWD_SKINNY) && M <= 16 && !kv_from_gemm;
+    // (the skinny residual producers write no LayerNorm slots, the skinny consumers read the fp32 rows instead: all of a layer's products switch together;
+    //  GPT-2-small / medium / large all qualify: K = d_model / d_ff of all three; other widths keep the whole session on the tile kernels)
+    bool skinny = fused && c == 1 && (flags & LMRL_FWD_SKINNY) && M <= 16 && !kv_from_gemm;
+    if (skinny) {
+        GemmArgs t1{}; t1.M = M; t1.N = 3 * d; t1.K = d; t1.lda = d;
+        GemmArgs t2 = t1; t2.N = d; t2.K = cf.d_ff; t2.lda = cf.d_ff;
+        GemmArgs t3 = t1; t3.N = cf.d_ff;
+        skinny = skinny_ok(t1) && skinny_ok(t2) && skinny_ok(t3);
+    }
     const int append_in_attn = kv_from_gemm ? 0 : 1;
     // chunk forwards that return at most the last token's hidden state: the last layer's projection + MLP run on ONE row per env (the same
     // per-row arithmetic as on the full chunk: bit-identical results), or not at all when no hidden state is asked for (a prompt's
@@ -1217,7 +1264,8 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
         if (fused && LMRL_ABL(LMRL_ABLATE_QKV)) {
         } else if (fused) {
             GemmArgs g{w.h, L.wf_qkv, L.bf_qkv, w.qkv, M, 3 * d, d, d, 3 * d, 3 * d, w.stats, nullptr, L.cs_qkv, nsl, 1.f / (float)d, cf.ln_eps, m_dev};
-            if (skinny && skinny_ok(g)) {
+            if (skinny) {
+                g.resid = w.x; g.ldr = d;                  // the consumer derives (mu, rstd) from the fp32 rows
                 LMRL_CHECK_HIP(skinny_launch<EPI_BF16_LN>(g, s));
             } else if (kv_from_gemm) {   // decode: the new K / V rows go to the cache from this GEMM's epilogue, the attention kernel only reads
                 g.kv_k = kc; g.kv_v = vc; g.kv_len = len_d; g.kv_cnt = cnt_d; g.kv_rowmap = row_map; g.kv_tmax = tmax; g.kv_d = d;
@@ -1262,7 +1310,13 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
                                         kc, vc, cnt_d, (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off, n_shared, append_in_attn, dp);      \
             } while (0)
             // 32 cached positions per batch of loads, 72 VGPRs -> 7 waves per SIMD (measured best of U = 4 / 6 / 8 / 10)
-            if (pfx) LMRL_DEC_LAUNCH(4, true, 1);
+            if (skinny && !ev) {        // a handful of envs: four waves per (env, head), every position batch of an item in flight at once
+                if (pfx) hipLaunchKernelGGL((attention_decode_split_kernel<4, true>), dim3(b * cf.n_head), dim3(256), 0, s, (const uint16_t *)w.qkv, kc, vc, cnt_d,
+                                            (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off, n_shared, append_in_attn, dp);
+                else hipLaunchKernelGGL((attention_decode_split_kernel<4, false>), dim3(b * cf.n_head), dim3(256), 0, s, (const uint16_t *)w.qkv, kc, vc, cnt_d,
+                                        (const int32_t *)len_d, w.att, b, cf.n_head, tmax, d, off, n_shared, append_in_attn, dp);
+            }
+            else if (pfx) LMRL_DEC_LAUNCH(4, true, 1);
 #ifdef LMRL_TOOLS
             else if (LMRL_ABL(LMRL_ABLATE_ATTN_HALF_BYTES))
                 hipLaunchKernelGGL((attention_decode_kernel<4, false, true>), dim3(ceil_div(b * cf.n_head, 4)), dim3(256), 0, s, (const uint16_t *)w.qkv, kc, vc,
@@ -1307,14 +1361,14 @@ static int gpt2_forward_impl(lmrl_gpt2 *m, void *kv_d, int tmax, void *ws_d, con
                 LMRL_CHECK_HIP(hipStreamWaitEvent(s, aux_join, 0));
             }
             else if (LMRL_ABL(LMRL_ABLATE_PROJ_CONCURRENT)) LMRL_CHECK_HIP(hipStreamWaitEvent(s, aux_join, 0));      // join
-            else if (skinny && skinny_ok(gp)) LMRL_CHECK_HIP(skinny_launch<EPI_RESID_F32_STATS>(gp, s));
+            else if (skinny) LMRL_CHECK_HIP(skinny_launch<EPI_RESID_F32_STATS>(gp, s));
             else if (!LMRL_ABL(LMRL_ABLATE_PROJ)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_RESID_F32_STATS>(gp, s));
             GemmArgs gf{w.h, L.wf_fc, L.bf_fc, w.ff, M, cf.d_ff, d, d, cf.d_ff, cf.d_ff, w.stats, nullptr, L.cs_fc, nsl, 1.f / (float)d, cf.ln_eps, m_dev};
-            if (skinny && skinny_ok(gf)) LMRL_CHECK_HIP(skinny_launch<EPI_GELU_BF16_LN>(gf, s));
+            if (skinny) { gf.resid = w.x; gf.ldr = d; LMRL_CHECK_HIP(skinny_launch<EPI_GELU_BF16_LN>(gf, s)); }
             else if (!LMRL_ABL(LMRL_ABLATE_FC)) LMRL_CHECK_HIP(gemm_launch_ln<EPI_GELU_BF16_LN>(gf, s));
             GemmArgs g2{w.ff, L.w_fc2, L.b_fc2, w.x, M, d, cf.d_ff, cf.d_ff, d, d, w.stats, w.h, nullptr, nsl, 0.f, 0.f, m_dev};
             if (LMRL_ABL(LMRL_ABLATE_FC2)) {}
-            else if (skinny && skinny_ok(g2)) {
+            else if (skinny) {
                 if (l + 1 < cf.n_layer) LMRL_CHECK_HIP(skinny_launch<EPI_RESID_F32_STATS>(g2, s));
                 else LMRL_CHECK_HIP(skinny_launch<EPI_RESID_F32>(g2, s));
             }

@@ -611,7 +611,7 @@ def test_skinny_decode_products_equal_the_tile_kernels(dev, B, model):
     """LMRL_FWD_SKINNY (round 6; configs[0]'s 8-env batch): decode forwards of <= 16 sequences run their four Dense products per layer on
     csrc/skinny_gemm.h (one MFMA row block, K split over the 16 waves of a workgroup) instead of the 64 x 64-tile kernels.  Same formulas, K summed
     in 8 slices: hidden states and K/V rows agree with the default session to bf16 rounding over a prefill + 12 decode steps (ragged counts,
-    finished rows, both row-compaction modes); a GPT-2-medium layer mixes skinny (K = 1024) and tile (K = 4096: outside the skinny shapes) products."""
+    finished rows, both row-compaction modes), at GPT-2-small and GPT-2-medium widths."""
     from lmrl_gym_amd.gpt2 import FWD_RAGGED_ALWAYS, FWD_SKINNY, GPT2Config, GPT2Engine, init_hf_style_state_dict
     cfg = GPT2Config(3, 12, 768, 3072, 1000, 64) if model == "small" else GPT2Config(2, 16, 1024, 4096, 1000, 64)
     eng = GPT2Engine(cfg, init_hf_style_state_dict(cfg, seed=6), dev)
