@@ -4,9 +4,9 @@ cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
-python $REPO/bench.py --mode-rl-reduce-only > $OUT/r05_rl_reduce_live.json 2> /tmp/rl_live.err || tail -5 /tmp/rl_live.err
+python $REPO/bench.py --mode-rl-reduce-only > $OUT/r06_rl_reduce_live.json 2> /tmp/rl_live.err || tail -5 /tmp/rl_live.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_rl -- python $REPO/bench.py --mode-rl-reduce-only > /tmp/prof_rl.out 2>&1 || echo "rocprofv3 failed/timeout"
-f=$(find /tmp/prof_rl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/r05_rl_reduce_kernel_stats.csv
+f=$(find /tmp/prof_rl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/r06_rl_reduce_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "chain_scan|whiten" --output-format csv -d /tmp/pmc_rl_$c -- python $REPO/bench.py --mode-rl-reduce-only > /dev/null 2>&1 || echo "pmc $c failed"
 done
@@ -23,12 +23,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in acc.items():
         out.setdefault(f"{k[0]} grid={k[1]}", {})[c.lower() + "_kb_avg"] = sum(v) / len(v)
         out[f"{k[0]} grid={k[1]}"]["launches"] = len(v)
-json.dump(out, open("$OUT/r05_rl_reduce_pmc.json", "w"), indent=1)
+json.dump(out, open("$OUT/r06_rl_reduce_pmc.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
 PY
-cat $OUT/r05_rl_reduce_live.json | python -c "
+cat $OUT/r06_rl_reduce_live.json | python -c "
 import json,sys
 d=json.load(sys.stdin)['rl_reduce']['chains']
 for b,r in d.items():
     print(b, {k:(v['avg_launch_us'], v['achieved'], v['frac']) for k,v in r.items() if isinstance(v,dict)})"
-head -12 $OUT/r05_rl_reduce_kernel_stats.csv
+head -12 $OUT/r06_rl_reduce_kernel_stats.csv
