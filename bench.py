@@ -451,7 +451,7 @@ def run_rl_reduce(dev, chains=(4096, 65536), L=96, budget_bytes=640 << 20, iters
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_rl_reduce_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r06_rl_reduce_pmc.json"))
                                               else "r05_rl_reduce_pmc.json")))
             pick = {4096: min, 65536: max}.get(B)          # the counter passes ran this leg's default sizes (tools/prof_rl_reduce.sh); other sizes: no counters
-            for name, pat in (("gae", "chain_scan_row2_kernel<true"), ("rtg", "chain_scan_row2_kernel<false"), ("whiten_moments", "whiten_moments_kernel"),
+            for name, pat in (("gae", "chain_scan_row2_kernel<true, 3, false"), ("rtg", "chain_scan_row2_kernel<false"), ("whiten_moments", "whiten_moments_kernel"),
                               ("whiten_apply", "whiten_apply_kernel")):
                 ks = [k for k in pmc if pat in k]
                 if ks and pick is not None:
@@ -534,6 +534,27 @@ def run_maze_rollout(dev, batches=(8, 1024), max_steps=20, max_new=12, reps=3):
                                    "ms_per_lockstep_turn": round(dt * 1e3 / reps / r.T, 3)}
         r.close()
         del r
+    # the partially observed task's item window (last_k = 40, llm_rl_scripts/maze/bc/partially_observed_bc.py:241) on the persistent per-env KV cache
+    # (round 6): 7-turn episodes at 1024 envs — every turn appends the action's tail + the new observation; the sampler is steered to random LEGAL
+    # moves (a random-init policy never spells one, and an illegal string restarts the window, maze/env/env.py:179-180); tools/bench_maze_history.py
+    # holds the longer regimes (re-prefill turns)
+    B = batches[-1]
+    env = M.setup_maze_env("double_t_maze", "describe_observation_only_walls", "standard_reward", last_k=40, max_steps=6)
+    r = MazeRolloutEngine(eng, tok, env, B, max_new_tokens=max_new, eos_token_id=tok.eos_token_id, max_input_length=512)
+    r.set_scripted_actions(np.random.RandomState(7).randint(0, 4, size=(r.T, B)), strength=30.0)
+    r.run_episode(list(range(B)), sample_seed=3, use_graph=True, sync_every=0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    steps = torch.zeros((), dtype=torch.int64, device=dev)
+    for e in range(reps):
+        r.run_episode(list(range(100 + e * B, 100 + (e + 1) * B)), sample_seed=3, episode=e + 1, use_graph=True, sync_every=0)
+        steps += r.traj["n_turns"].sum()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    out["last_k40_window_growing"] = {"value": round(int(steps.item()) / dt, 1), "envs": B, "ms_per_lockstep_turn": round(dt * 1e3 / reps / r.T, 3), "turns": r.T,
+                                      "schedule_flags": r.history_flags(),
+                                      "note": "describe_observation_only_walls, last_k=40, max_input_length=512: append turns only (45-token observation + 11-token "
+                                              "action forwarded per env and turn on the persistent cache + 12 decode steps)"}
+    r.close()
+    del r
     return out
 
 
