@@ -36,8 +36,8 @@ if ROOT not in sys.path:
 # that streams the KV cache) — the largest HBM-bound kernel of the step and the one the north star's ">= 60 % of HBM roofline" refers to.
 ROOFLINE_TAG = "attention_decode"
 ROOFLINE_KERNEL = "attention_decode_kernel"                 # its name in the rocprofv3 / PMC summaries
-PROFILE_STATS = "profiles/r05_bench_kernel_stats.csv"       # committed `rocprofv3 --kernel-trace --stats` summary of this command
-PROFILE_PMC = "profiles/r05_pmc_fetch_write.json"           # committed FETCH_SIZE / WRITE_SIZE passes (tools/pmc_fetch_write.sh)
+PROFILE_STATS = "profiles/r06_bench_kernel_stats.csv"       # committed `rocprofv3 --kernel-trace --stats` summary of this command
+PROFILE_PMC = "profiles/r06_pmc_fetch_write.json"           # committed FETCH_SIZE / WRITE_SIZE passes (tools/pmc_fetch_write.sh)
 SECONDARY_TAGS = ["gemm_bf16_64x64", "gemm_bf16_64x128", "gemm_bf16_128x128", "lm_head_sample", "attention_chunk"]
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md (dense, no sparsity)
 HBM_PEAK_GBS = 8000.0                  # same guide: 8 TB/s spec (6.3 TB/s measured achievable)
@@ -477,7 +477,7 @@ def run_rl_reduce(dev, chains=(4096, 65536), L=96, budget_bytes=640 << 20, iters
                 "of affine maps by row_shl DPP steps, no LDS, streaming accesses), whiten_moments_kernel + whiten_finish_kernel / whiten_apply_kernel (16-byte accesses, fp64 partials)",
                 note="HIP events around ONE hipGraph replay of 40 launches rotating through `buffer_sets` independent input / output sets (> 256 MB in total: not "
                      "served by the memory-side cache); avg_launch_us therefore includes the ~1 us dispatch gap between graph nodes; rocprofv3 summary of the same "
-                     "command: profiles/r05_rl_reduce_kernel_stats.csv")
+                     "command: profiles/r06_rl_reduce_kernel_stats.csv")
 
 
 def run_warpers(vocab, guesses, seeds_all, B, dev, reps=3):
