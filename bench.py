@@ -457,7 +457,7 @@ def run_rl_reduce(dev, chains=(4096, 65536), L=96, budget_bytes=640 << 20, iters
                 if ks and pick is not None:
                     k = pick(ks, key=lambda q: int(q.split("grid=")[1]))
                     res[name]["traffic"] = round((2.0 * pmc[k].get("fetch_size_kb_avg", 0.0) + pmc[k].get("write_size_kb_avg", 0.0)) * 1024)
-                    res[name]["traffic_source"] = "profiles/r05_rl_reduce_pmc.json (2*FETCH_SIZE + WRITE_SIZE)"
+                    res[name]["traffic_source"] = "profiles/r06_rl_reduce_pmc.json (2*FETCH_SIZE + WRITE_SIZE)"
         except Exception:
             pass
         # SURVEY.md §8(d) / BASELINE.md count 20 B per ACTION token for GAE / RTG / whiten; the kernels work on the token-slot layout of PPOData (the
