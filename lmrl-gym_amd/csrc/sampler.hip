@@ -84,6 +84,13 @@ constexpr int kPartialFloats = 6;   // {max, sumexp, best_score, best_col, best_
 // workgroups per CU; up to three GEMM passes over the same output tile (pi, q1, q2) combined in registers.  The four column-quarter
 // waves of a row merge their partials through LDS so exactly one partial per (row, 128-column tile) reaches HBM.
 constexpr int kLmBM = 128, kLmBN = 128, kLmWM = 2, kLmWN = 4, kLmStages = 2;
+// The Q-head forms (two or three products per tile, three accumulator sets: 173 VGPRs) fit ONE workgroup per CU whatever the ring — so they take a
+// 4-slot ring (128 KB of the CU's 160 KB LDS): three stages in flight behind the one being consumed instead of one (round 6)
+#ifdef LMRL_LM_Q_STAGES
+constexpr int kLmQStages = LMRL_LM_Q_STAGES;
+#else
+constexpr int kLmQStages = 4;
+#endif
 
 struct RowPartial { float pmax, psum, best, best_z; int best_col; };
 
@@ -424,7 +431,11 @@ __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const
         for (int i = 0; i < FN; i++)
 #pragma unroll
             for (int j = 0; j < FM; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        g8_mainloop<BM, BN, WM, WN, kLmStages>(A, K, W, K, K, M, m0, n0, smem, acc);
+#ifdef LMRL_LM_Q_PAIR
+        if (NOPS > 1 && (K / 64) % 2 == 0) g8_mainloop_pair<BM, BN, WM, WN>(A, K, W, K, K, M, m0, n0, smem, acc);
+        else
+#endif
+        g8_mainloop<BM, BN, WM, WN, (NOPS > 1 ? kLmQStages : kLmStages)>(A, K, W, K, K, M, m0, n0, smem, acc);
 #pragma unroll
         for (int i = 0; i < FN; i++) {
             const int n = n0 + wn * TN + i * 16 + lq * 4;
@@ -1257,8 +1268,21 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     hipStream_t s = as_stream(stream);
     const XcdMap xm = make_xcd_map((m + kLmBM - 1) / kLmBM, vocab_padded / kLmBN, 2.0 * m * d_model, 2.0 * (double)vocab_padded * d_model);
     const int tiles = xcd_grid(xm);
-    const size_t shmem = (size_t)kLmStages * (kLmBM + kLmBN) * 128;
     const int nops = (q_hidden1_d && q_w1_d) ? ((q_hidden2_d && q_w2_d) ? 3 : 2) : 1;
+    const size_t shmem = (size_t)(nops > 1 ? kLmQStages : kLmStages) * (kLmBM + kLmBN) * 128;
+    if (nops > 1) {      // 128 KB of dynamic LDS: a per-device opt-in of every Q-head instantiation, set on the first such launch there (before any graph capture)
+        static std::atomic<unsigned long long> q_attr_set{0ull};
+        int dev_id = 0;
+        LMRL_CHECK_HIP(hipGetDevice(&dev_id));
+        const unsigned long long dev_bit = 1ull << (dev_id & 63);
+        if (dev_id >= 64 || !(q_attr_set.load(std::memory_order_acquire) & dev_bit)) {
+#define LMRL_Q_OPTIN(...) LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
+            LMRL_Q_OPTIN(2, true, false); LMRL_Q_OPTIN(2, false, false); LMRL_Q_OPTIN(2, true, true); LMRL_Q_OPTIN(2, false, false, true); LMRL_Q_OPTIN(2, false, false, false, true);
+            LMRL_Q_OPTIN(3, true, false); LMRL_Q_OPTIN(3, false, false); LMRL_Q_OPTIN(3, true, true); LMRL_Q_OPTIN(3, false, false, true); LMRL_Q_OPTIN(3, false, false, false, true);
+#undef LMRL_Q_OPTIN
+            q_attr_set.fetch_or(dev_bit, std::memory_order_release);
+        }
+    }
     float *partials = (float *)ws_d;
     bool topc = false;
     int32_t *fb = nullptr;
