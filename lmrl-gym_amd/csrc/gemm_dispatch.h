@@ -42,10 +42,14 @@ inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
     // round 4 (with the MFMA results in VGPRs, build.py): the LONG-K residual producer (fc2: 192 tiles x 48 K-steps) on 8 waves (4 x 2, 16 x 32 per wave)
     // and a 4-slot ring: 48.2 -> 47.85 ms per episode in situ; the short-K one (proj, 12 K-steps) gains nothing from it (48.15), 3 slots lose (49.06).
     // Variant 116 = the 4-wave ring for both (A/B hook)
+    if (g.K >= 2048 && g_gemm_variant == 120) return gemm8_launch<64, 64, 4, 2, 6, EPI, NQ>(g, s);      // A/B (round 6): 6-slot ring (96 KB), 5 stages in flight
+    if (g.K >= 2048 && g_gemm_variant == 121) return gemm8_launch<64, 64, 4, 2, 5, EPI, NQ>(g, s);
     if (g.K >= 2048 && g_gemm_variant != 116) return gemm8_launch<64, 64, 4, 2, 4, EPI, NQ>(g, s);
     if (g.K >= 2048) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
     if (g_gemm_variant == 101) return gemm_launch_glds<64, 64, 2, EPI, NQ>(g, s);
     const long tiles = (long)((g.M + 63) / 64) * (g.N / 64);
+    if (tiles <= 256 && g_gemm_variant == 122) return gemm_launch_glds<64, 64, 6, EPI, NQ>(g, s);          // A/B (round 6): proj on a 6-slot ring
+    if (tiles <= 256 && g_gemm_variant == 123) return gemm8_launch<64, 64, 4, 2, 6, EPI, NQ>(g, s);       // A/B: proj on the 8-wave kernel, 6 slots
     if (tiles <= 512) return gemm_launch_glds<64, 64, 4, EPI, NQ>(g, s);
     if (tiles <= 768) return gemm_launch_glds<64, 64, 3, EPI, NQ>(g, s);
     return gemm_launch_glds<64, 64, 2, EPI, NQ>(g, s);
