@@ -75,7 +75,21 @@ struct SampleParams {
     float steer_strength;    // added to the logit of steer_tok[row] (synthetic-workload hook, see bench.py)
     float beta;              // ILQL: logits = pi + beta*min(q1,q2) ; 0 with no q operands
     int vocab;               // logical vocabulary (columns >= vocab are padding -> -inf)
+    unsigned long long *tile_mass;   // fused top-p WITHOUT top-k: [M][tiles_n] probability mass of every 128-column tile relative to the tile's own maximum (else null)
 };
+
+// 32.32 fixed-point probability mass of a logit relative to `ref` (>= the logit): the unit of every top-p sum — integers, so that LDS / shuffle sums
+// come out the same in any order and in every kernel that forms them
+__device__ __forceinline__ unsigned long long mass_fixed(float v, float ref, float inv_t) {
+    const float e = __expf((v - ref) * inv_t);          // in (0, 1]
+    return (unsigned long long)((double)e * 4294967296.0);
+}
+// The nucleus total when top-k is off, TILE-WISE (so that the fused path can form it without the row's logits): per 128-column tile t the integer sum
+// S_t of mass_fixed(. , tile maximum), rescaled to the row maximum in one double product; total = sum_t tile_mass_rescaled(S_t, max_t, row max).
+// Within 1e-5 (relative) of the sum of the per-column masses relative to the row maximum, and the same integer in every kernel.
+__device__ __forceinline__ unsigned long long tile_mass_rescaled(unsigned long long s_t, float tmax, float rmax, float inv_t) {
+    return (unsigned long long)((double)s_t * (double)__expf((tmax - rmax) * inv_t));
+}
 
 constexpr int kPartialFloats = 6;   // {max, sumexp, best_score, best_col, best_z, pad}
 
@@ -214,7 +228,7 @@ __device__ __forceinline__ void lm_sample_epilogue(f32x4 (&z)[kLmBN / kLmWN / 16
 // stores its keys at or above that threshold into the row's record, at slots the merging lane laid out (keys above the threshold first, in column-quarter
 // order, then the keys equal to it; no slot-counter atomics).  Ties beyond 8 slots are dropped: they equal the record's minimum, which the reduce
 // kernel's check treats as "possibly hidden".
-constexpr int kTopC = 8, kCandWords = 2 * kTopC, kTopCMaxK = 64, kFbHeader = 16, kFbMaxBlocks = 64;      // record: 8 x {key, tile-local column} = 64 B
+constexpr int kTopC = 8, kCandWords = 2 * kTopC, kTopCMaxK = 256, kFbHeader = 16, kFbMaxBlocks = 64;      // record: 8 x {key, tile-local column} = 64 B
 constexpr int kTopcCompactCap = 1024;             // reduce kernel: candidates at or above the pre-filter floor kept in LDS per row (more: the row is handed back)
 constexpr int kTopcLdsBytes = (kLmBM * (kLmWN - 1) * kTopC + 2 * kLmBM) * 4;                                // merge lists [BM][WN-1][8] + {threshold, slot ranges} [BM][2]
 
@@ -236,7 +250,7 @@ __device__ __forceinline__ void bitonic8_desc(uint32_t (&a)[8]) {
 #undef LMRL_CE
 
 // cand: [M][tiles_n][8] {key, column} (a row's records are contiguous: the reduce kernel reads them coalesced; a tile scatters 128 x 64 B).  `lds`: kTopcLdsBytes.
-template <bool RAW>
+template <bool RAW, bool MASS>      // MASS: also the tile's probability mass per row (top-p without top-k)
 __device__ __forceinline__ void lm_topc_epilogue(f32x4 (&z)[kLmBN / kLmWN / 16][kLmBM / kLmWM / 16], const int (&st_pre)[kLmBM / kLmWM / 16], int m0, int n0,
                                                  int tile_n, int tiles_n, int M, uint32_t *__restrict__ cand, const SampleParams &sp, char *lds) {
     constexpr int BM = kLmBM, BN = kLmBN, WM = kLmWM, WN = kLmWN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
@@ -349,6 +363,7 @@ __device__ __forceinline__ void lm_topc_epilogue(f32x4 (&z)[kLmBN / kLmWN / 16][
         const uint32_t e0 = gt, e1 = c8(e0 + q[0]), e2 = c8(e1 + q[1]), e3 = c8(e2 + q[2]), total = c8(e3 + q[3]);
         typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
         *reinterpret_cast<u32x2_t *>(thr_l + 2 * row) = u32x2_t{thr, (g1 << 4) | (g2 << 8) | (g3 << 12) | (e0 << 16) | (e1 << 20) | (e2 << 24) | (e3 << 28)};
+        if (MASS) lists[(size_t)row * (WN - 1) * kTopC] = my8[0];      // the tile's largest key of this row, into the row's own (now read) list area
         if (total < (uint32_t)kTopC && m0 + row < M)   // fewer than 8 real columns (the vocabulary's last tile): empty slots
             for (uint32_t sl = total; sl < (uint32_t)kTopC; sl++) cand64[((size_t)(m0 + row) * tiles_n + tile_n) * kTopC + sl] = 0ull;
     }
@@ -385,10 +400,35 @@ __device__ __forceinline__ void lm_topc_epilogue(f32x4 (&z)[kLmBN / kLmWN / 16][
             }
         }
     }
+    if (MASS) {
+        // top-p without top-k: the tile's probability mass per row, relative to the tile's own maximum (tile_mass_rescaled) — integer sums over the lane's
+        // 8 columns, the 4 lanes of the row, the 4 column-quarter waves (through the row's list area: 12 eight-byte words, word 0 holds the maximum)
+        unsigned long long *mx = reinterpret_cast<unsigned long long *>(lists);
+#pragma unroll
+        for (int j = 0; j < FM; j++) {
+            const int row = wm * TM + j * 16 + lr;
+            const uint32_t tk = lists[(size_t)row * (WN - 1) * kTopC];
+            const float tmax = f32_from_order_key(tk);
+            unsigned long long sm = 0ull;
+            if (tk != 0u && tmax != -INFINITY) {
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    if (keys[j][e] != 0u) sm += mass_fixed(f32_from_order_key(keys[j][e]), tmax, sp.inv_temperature);
+            }
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            if (lq == 0) mx[(size_t)row * 12 + 1 + wn] = sm;
+        }
+        lm_barrier<RAW>();
+        if (wn == 0) {
+            const int row = wm * TM + lq * 16 + lr;
+            if (m0 + row < M) sp.tile_mass[(size_t)(m0 + row) * tiles_n + tile_n] = (mx[(size_t)row * 12 + 1] + mx[(size_t)row * 12 + 2]) + (mx[(size_t)row * 12 + 3] + mx[(size_t)row * 12 + 4]);
+        }
+    }
 }
 
 // FLAGGED (the fused top-k path's hand-back): grid = the vocabulary's tiles; a workgroup walks the 128-row blocks and computes only those whose flag is set
-template <int NOPS, bool WANT_LP, bool JAX = false, bool TOPC = false, bool FLAGGED = false>
+template <int NOPS, bool WANT_LP, bool JAX = false, int TOPC = 0, bool FLAGGED = false>      // TOPC: 1 = candidate epilogue, 2 = candidates + tile masses
 __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const uint16_t *__restrict__ A0, const uint16_t *__restrict__ W0,
                                                              const uint16_t *__restrict__ A1, const uint16_t *__restrict__ W1,
                                                              const float *__restrict__ bias1,
@@ -472,7 +512,7 @@ __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const
 #pragma unroll
                     for (int r = 0; r < 4; r++) z[i][j][r] += sp.beta * qmin[i][j][r];
         }
-        lm_topc_epilogue<false>(z, st_pre, m0, n0, tile_n, tiles_n, M, reinterpret_cast<uint32_t *>(partials), sp, smem);
+        lm_topc_epilogue<false, TOPC == 2>(z, st_pre, m0, n0, tile_n, tiles_n, M, reinterpret_cast<uint32_t *>(partials), sp, smem);
     }
     else lm_sample_epilogue<NOPS, WANT_LP, JAX, false>(z, qmin, st_pre, m0, n0, tile_n, tiles_n, M, partials, logits_out, ldo, sp, reinterpret_cast<float *>(smem));
     }
@@ -487,7 +527,7 @@ __global__ __launch_bounds__(kLmWM *kLmWN * 64) void lm_head_sample_kernel(const
 // and measured: 168 us against 138 us for this static form, back to back: the pulls' round trips under a streaming load cost more than the balance buys.)
 // Same arithmetic per tile, same association orders: bit-identical partials to the one-tile kernel (tests/test_gpu_timed_path.py).
 // LDS: 2 x 32 KB ring + 7.7 KB hand-off area = 2 workgroups per CU.
-template <bool WANT_LP, bool TOPC = false>
+template <bool WANT_LP, int TOPC = 0>
 __global__ __launch_bounds__(kLmWM *kLmWN * 64, 4) void lm_head_sample_persist_kernel(const uint16_t *__restrict__ A0, const uint16_t *__restrict__ W0,
                                                                                       const int32_t *__restrict__ steer_tok, float *__restrict__ partials,
                                                                                       float *__restrict__ logits_out, int M, int N, int K, int ldo,
@@ -528,7 +568,7 @@ __global__ __launch_bounds__(kLmWM *kLmWN * 64, 4) void lm_head_sample_persist_k
 #pragma unroll
             for (int j = 0; j < FM; j++) z[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         g8_stream_tile<BM, BN, WM, WN>(st, m0, n0, has_next, ntm * BM, ntn * BN, K, smem, z);
-        if (TOPC) lm_topc_epilogue<true>(z, st_pre, m0, n0, this_tile_n, tiles_n, M, reinterpret_cast<uint32_t *>(partials), sp, reinterpret_cast<char *>(xch));
+        if (TOPC) lm_topc_epilogue<true, TOPC == 2>(z, st_pre, m0, n0, this_tile_n, tiles_n, M, reinterpret_cast<uint32_t *>(partials), sp, reinterpret_cast<char *>(xch));
         else lm_sample_epilogue<1, WANT_LP, false, true>(z, z, st_pre, m0, n0, this_tile_n, tiles_n, M, partials, logits_out, ldo, sp, xch);
         if (!has_next) break;
         k = nk_; tile_m = ntm; tile_n = ntn;
@@ -635,6 +675,27 @@ __device__ __forceinline__ void topk_sample_row(int m, const float *__restrict__
         if (lane == 0) s_rowmax[wave] = rmax;
         __syncthreads();
         rmax = fmaxf(fmaxf(s_rowmax[0], s_rowmax[1]), fmaxf(s_rowmax[2], s_rowmax[3]));
+        // without top-k the total is formed TILE-WISE (tile_mass_rescaled: what the fused path can compute without the row); a wave per 128-column tile
+        __shared__ unsigned long long tile_total;
+        if (!topk_on) {
+            if (tid == 0) tile_total = 0ull;
+            __syncthreads();
+            unsigned long long tt = 0ull;
+            for (int t0 = wave * 128; t0 < vocab; t0 += 4 * 128) {
+                const int na = t0 + lane, nb = na + 64;
+                const float ra = na < vocab ? row[na] : -INFINITY, rb = nb < vocab ? row[nb] : -INFINITY;
+                float tmax = fmaxf(ra, rb);
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
+                unsigned long long sm = 0ull;
+                if (tmax != -INFINITY) sm = (na < vocab ? mass_fixed(ra, tmax, sp.inv_temperature) : 0ull) + (nb < vocab ? mass_fixed(rb, tmax, sp.inv_temperature) : 0ull);
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) sm += __shfl_xor(sm, o);
+                if (tmax != -INFINITY) tt += tile_mass_rescaled(sm, tmax, rmax, sp.inv_temperature);
+            }
+            if (lane == 0) atomicAdd(&tile_total, tt);
+            __syncthreads();
+        }
         uint32_t pprefix = 0;
         unsigned long long above = 0, target = 0;
         for (int pass = 0; pass < 4; pass++) {
@@ -656,6 +717,7 @@ __device__ __forceinline__ void topk_sample_row(int m, const float *__restrict__
                 if (pass == 0) {
                     unsigned long long tot = 0;
                     for (int b = 0; b < 256; b++) tot += mhist[b];
+                    if (!topk_on) tot = tile_total;
                     sel_total = (unsigned long long)((double)top_p * (double)tot);
                     if (sel_total == 0) sel_total = 1;
                 }
@@ -878,6 +940,38 @@ __device__ __forceinline__ void topk_sample_reg_row(int m, const float *__restri
 #pragma unroll
         for (int w = 1; w < 16; w++) rmax = fmaxf(rmax, red_f[w][0]);
         __syncthreads();
+        // without top-k: the tile-wise total (tile_mass_rescaled) — chunk c = tid + 1024 j holds 4 columns, so a 128-column tile is the 32 lanes of a half-wave
+        __shared__ unsigned long long tile_total;
+        if (!topk_on) {
+            if (tid == 0) tile_total = 0ull;
+            __syncthreads();
+            unsigned long long tt = 0ull;
+#pragma unroll
+            for (int j = 0; j < NV; j++) {
+                const int n4 = 4 * (tid + 1024 * j);
+                uint32_t tk = 0u;
+#pragma unroll
+                for (int r = 0; r < 4; r++) tk = (n4 + r < vocab && v[j][r] > tk) ? v[j][r] : tk;
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { const uint32_t ok = (uint32_t)__shfl_xor((int)tk, o); tk = ok > tk ? ok : tk; }
+                const float tmax = key_to_f32(tk);
+                const bool live = tk != 0u && tmax != -INFINITY;
+                unsigned long long sm = 0ull;
+                if (live) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (n4 + r < vocab) sm += mass_fixed(key_to_f32(v[j][r]), tmax, sp.inv_temperature);
+                }
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) sm += __shfl_xor(sm, o);
+                if (live && (lane & 31) == 0) tt += tile_mass_rescaled(sm, tmax, rmax, sp.inv_temperature);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) tt += __shfl_xor(tt, o);
+            if (lane == 0) atomicAdd(&tile_total, tt);
+            __syncthreads();
+        }
         uint32_t pprefix = 0;
         for (int pass = 0; pass < 4; pass++) {
             const int shift = 24 - 8 * pass;
@@ -899,6 +993,7 @@ __device__ __forceinline__ void topk_sample_reg_row(int m, const float *__restri
                     unsigned long long tot = mhist[4 * lane] + mhist[4 * lane + 1] + mhist[4 * lane + 2] + mhist[4 * lane + 3];
 #pragma unroll
                     for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
+                    if (!topk_on) tot = tile_total;
                     tgt = (unsigned long long)((double)top_p * (double)tot);
                     if (tgt == 0) tgt = 1;
                 }
@@ -987,7 +1082,7 @@ __global__ __launch_bounds__(1024) void topk_sample_reg_kernel(const float *__re
 // same 32.32 fixed-point mass histograms, same Philox word per column and same arg-max tie rule as topk_sample_kernel on the materialised row: whenever
 // the check passes the kept set is the row's true top-k (ties kept) and the sampled token is identical.  A row that fails the check is appended to the
 // list in `fb` ({count, -, ..., block flags [kFbMaxBlocks], rows [M]}) and left to the materialised path.
-template <int NT>
+template <int NT, bool NUC>
 __global__ __launch_bounds__(256) void topc_reduce_sample_kernel(const uint32_t *__restrict__ cand, int M, int tiles_n, int vocab, int top_k, float top_p,
                                                                  const uint8_t *__restrict__ active, int32_t *__restrict__ token,
                                                                  float *__restrict__ logprob, SampleParams sp, int pad_token, int32_t *__restrict__ fb) {
@@ -1004,6 +1099,7 @@ __global__ __launch_bounds__(256) void topc_reduce_sample_kernel(const uint32_t 
     uint32_t *hist = hist_s[wave], *ck = ck_s[wave], *cn = cn_s[wave];
     unsigned long long *mhist = mhist_s[wave];
 #define LMRL_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define LMRL_HAND_BACK() do { if (lane == 0) { const int idx_ = atomicAdd(&fb[0], 1); fb[kFbHeader + kFbMaxBlocks + idx_] = m; fb[kFbHeader + m / kLmBM] = 1; } return; } while (0)
     uint32_t key[NT][kTopC], colw[NT][2];
 #pragma unroll
     for (int q = 0; q < NT; q++) {
@@ -1028,19 +1124,39 @@ __global__ __launch_bounds__(256) void topc_reduce_sample_kernel(const uint32_t 
             if (k_ != 0u) { const int n = (lane + 64 * q_) * kLmBN + (int)((colw[q_][e_ >> 2] >> (8 * (e_ & 3))) & 255u); (void)n; BODY } \
         }                                                                                                      \
     }
-    // top-k threshold: radix select over the candidates, pre-filtered by the k-th largest per-lane maximum (k <= 64 lanes: a lower bound of the k-th
-    // largest candidate — those are k distinct candidates at or above it)
-    uint32_t tkey = 0;
-    LMRL_TC_FOREACH({ tkey = k_ > tkey ? k_ : tkey; })
+    // per tile: its largest key, and — what a FULL record hides — its smallest one: everything the tile did not report lies at or below that
+    uint32_t tmaxk[NT], hidden_max = 0, tkey = 0;
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+        uint32_t mn = key[q][0], mx = key[q][0];
+#pragma unroll
+        for (int e = 1; e < kTopC; e++) { mn = key[q][e] < mn ? key[q][e] : mn; mx = key[q][e] > mx ? key[q][e] : mx; }
+        hidden_max = mn > hidden_max ? mn : hidden_max;        // (a record with an empty slot hides nothing: mn = 0)
+        tmaxk[q] = mx;
+        tkey = mx > tkey ? mx : tkey;
+    }
     uint32_t floor_key = 0;
     {
-        uint32_t fp = 0, frem = (uint32_t)top_k;
+        // top-k threshold: radix select over the candidates, pre-filtered by a lower bound of the k-th largest candidate: the k-th largest of k or more
+        // DISTINCT candidates — the per-lane maxima (k <= 64 lanes), else the per-tile maxima (k <= kTopCMaxK; fewer tiles than k: the bound degrades to 0).
+        // Top-p alone: the nucleus of a peaked row is a few dozen tokens — the candidates at or above the 128th largest tile maximum (a few hundred)
+        // are searched; a nucleus that needs more is handed back like one that reaches a hidden bound
+        const int k_pre = NUC ? 128 : top_k;
+        uint32_t fp = 0, frem = (uint32_t)k_pre;
         for (int pass = 0; pass < 4; pass++) {
             const int shift = 24 - 8 * pass;
 #pragma unroll
             for (int i = 0; i < 4; i++) hist[4 * lane + i] = 0;
             LMRL_WAVE_SYNC();
-            if (tkey != 0u && (pass == 0 || (tkey >> (shift + 8)) == (fp >> (shift + 8)))) atomicAdd(&hist[(tkey >> shift) & 255u], 1u);
+            if (k_pre <= 64) {
+                if (tkey != 0u && (pass == 0 || (tkey >> (shift + 8)) == (fp >> (shift + 8)))) atomicAdd(&hist[(tkey >> shift) & 255u], 1u);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NT; q++) {
+                    const uint32_t t_ = tmaxk[q];
+                    if (t_ != 0u && (pass == 0 || (t_ >> (shift + 8)) == (fp >> (shift + 8)))) atomicAdd(&hist[(t_ >> shift) & 255u], 1u);
+                }
+            }
             LMRL_WAVE_SYNC();
             uint32_t b, above;
             wave_scan_from_top<uint32_t>(hist, frem, 0u, lane, b, above);
@@ -1048,6 +1164,12 @@ __global__ __launch_bounds__(256) void topc_reduce_sample_kernel(const uint32_t 
             LMRL_WAVE_SYNC();
         }
         floor_key = fp;
+    }
+    if (NUC) {
+        // top-p alone: only candidates ABOVE every tile's hidden bound can belong to an exactly known nucleus
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t oh = (uint32_t)__shfl_xor((int)hidden_max, o); hidden_max = oh > hidden_max ? oh : hidden_max; }
+        floor_key = floor_key > hidden_max + 1u ? floor_key : hidden_max + 1u;
     }
     // the candidates at or above the floor (a few multiples of k out of 8 x tiles), compacted into LDS: every later pass walks ceil(count / 64) of them per
     // lane instead of 8 x NT predicated slots (most of which hold a candidate in SOME lane, so none could be skipped)
@@ -1060,15 +1182,6 @@ __global__ __launch_bounds__(256) void topc_reduce_sample_kernel(const uint32_t 
         if (lane >= d) incl += o;
     }
     const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-    // exactness, part 1: a tile whose record is full reports its smallest key as the bound of what it did not report
-    uint32_t hidden_max = 0;
-#pragma unroll
-    for (int q = 0; q < NT; q++) {
-        uint32_t mn = key[q][0];
-#pragma unroll
-        for (int e = 1; e < kTopC; e++) mn = key[q][e] < mn ? key[q][e] : mn;
-        hidden_max = mn > hidden_max ? mn : hidden_max;        // (a record with an empty slot hides nothing: mn = 0)
-    }
     {
         uint32_t at = incl - mine_n;
         if (total <= (uint32_t)kTopcCompactCap)
@@ -1076,42 +1189,59 @@ __global__ __launch_bounds__(256) void topc_reduce_sample_kernel(const uint32_t 
     }
 #undef LMRL_TC_FOREACH
     LMRL_WAVE_SYNC();
-    uint32_t prefix = 0, remaining = (uint32_t)top_k;
-    if (total <= (uint32_t)kTopcCompactCap) {
-        for (int pass = 0; pass < 4; pass++) {
-            const int shift = 24 - 8 * pass;
+    uint32_t thr_key = floor_key;
+    if (!NUC) {
+        uint32_t prefix = 0, remaining = (uint32_t)top_k;
+        if (total <= (uint32_t)kTopcCompactCap) {
+            for (int pass = 0; pass < 4; pass++) {
+                const int shift = 24 - 8 * pass;
 #pragma unroll
-            for (int i = 0; i < 4; i++) hist[4 * lane + i] = 0;
-            LMRL_WAVE_SYNC();
-            for (uint32_t i = lane; i < total; i += 64) {
-                const uint32_t k_ = ck[i];
-                if (pass == 0 || (k_ >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(k_ >> shift) & 255u], 1u);
+                for (int i = 0; i < 4; i++) hist[4 * lane + i] = 0;
+                LMRL_WAVE_SYNC();
+                for (uint32_t i = lane; i < total; i += 64) {
+                    const uint32_t k_ = ck[i];
+                    if (pass == 0 || (k_ >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(k_ >> shift) & 255u], 1u);
+                }
+                LMRL_WAVE_SYNC();
+                uint32_t b, above;
+                wave_scan_from_top<uint32_t>(hist, remaining, 0u, lane, b, above);
+                prefix |= b << shift; remaining -= above;
+                LMRL_WAVE_SYNC();
             }
-            LMRL_WAVE_SYNC();
-            uint32_t b, above;
-            wave_scan_from_top<uint32_t>(hist, remaining, 0u, lane, b, above);
-            prefix |= b << shift; remaining -= above;
-            LMRL_WAVE_SYNC();
         }
-    }
-    uint32_t thr_key = prefix;                           // key of the k-th largest candidate
-    // exactness, part 2: a full record whose smallest key reaches the threshold may hide a logit at or above it (or: too many candidates to compact —
-    // degenerate rows, e.g. all logits equal)
-    if (__ballot(hidden_max >= thr_key && hidden_max != 0u) != 0ull || total > (uint32_t)kTopcCompactCap) {
-        if (lane == 0) {
-            const int idx = atomicAdd(&fb[0], 1);
-            fb[kFbHeader + kFbMaxBlocks + idx] = m;
-            fb[kFbHeader + m / kLmBM] = 1;
-        }
-        return;
-    }
-    if (top_p > 0.f && top_p < 1.f) {
+        thr_key = prefix;                                // key of the k-th largest candidate
+        // exactness: a full record whose smallest key reaches the threshold may hide a logit at or above it (or: too many candidates to compact —
+        // degenerate rows, e.g. all logits equal)
+        if (__ballot(hidden_max >= thr_key && hidden_max != 0u) != 0ull || total > (uint32_t)kTopcCompactCap) LMRL_HAND_BACK();
+    } else if (total > (uint32_t)kTopcCompactCap || total == 0u) LMRL_HAND_BACK();
+    if (NUC || (top_p > 0.f && top_p < 1.f)) {
         float rmax = -INFINITY;
-        for (uint32_t i = lane; i < total; i += 64) { const uint32_t k_ = ck[i]; if (k_ >= thr_key) rmax = fmaxf(rmax, f32_from_order_key(k_)); }
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o));
-        uint32_t pprefix = 0;
         unsigned long long tgt = 0, sabove = 0;
+        if (NUC) {
+            // the row maximum is a candidate of its tile; the total: every tile's mass, rescaled from the tile's maximum to the row's (tile_mass_rescaled —
+            // the same integers the materialised kernels form from the row itself)
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t ot = (uint32_t)__shfl_xor((int)tkey, o); tkey = ot > tkey ? ot : tkey; }
+            rmax = f32_from_order_key(tkey);
+            unsigned long long tot = 0ull;
+#pragma unroll
+            for (int q = 0; q < NT; q++) {
+                const int t = lane + 64 * q;
+                if (t < tiles_n && tmaxk[q] != 0u) {
+                    const float tm = f32_from_order_key(tmaxk[q]);
+                    if (tm != -INFINITY) tot += tile_mass_rescaled(sp.tile_mass[(size_t)m * tiles_n + t], tm, rmax, sp.inv_temperature);
+                }
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
+            tgt = (unsigned long long)((double)top_p * (double)tot);
+            if (tgt == 0) tgt = 1;
+        } else {
+            for (uint32_t i = lane; i < total; i += 64) { const uint32_t k_ = ck[i]; if (k_ >= thr_key) rmax = fmaxf(rmax, f32_from_order_key(k_)); }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o));
+        }
+        uint32_t pprefix = 0;
         for (int pass = 0; pass < 4; pass++) {
             const int shift = 24 - 8 * pass;
 #pragma unroll
@@ -1119,13 +1249,11 @@ __global__ __launch_bounds__(256) void topc_reduce_sample_kernel(const uint32_t 
             LMRL_WAVE_SYNC();
             for (uint32_t i = lane; i < total; i += 64) {
                 const uint32_t k_ = ck[i];
-                if (k_ >= thr_key && (pass == 0 || (k_ >> (shift + 8)) == (pprefix >> (shift + 8)))) {
-                    const float e = __expf((f32_from_order_key(k_) - rmax) * sp.inv_temperature);
-                    atomicAdd(&mhist[(k_ >> shift) & 255u], (unsigned long long)((double)e * 4294967296.0));
-                }
+                if (k_ >= thr_key && (pass == 0 || (k_ >> (shift + 8)) == (pprefix >> (shift + 8))))
+                    atomicAdd(&mhist[(k_ >> shift) & 255u], mass_fixed(f32_from_order_key(k_), rmax, sp.inv_temperature));
             }
             LMRL_WAVE_SYNC();
-            if (pass == 0) {
+            if (pass == 0 && !NUC) {
                 unsigned long long tot = mhist[4 * lane] + mhist[4 * lane + 1] + mhist[4 * lane + 2] + mhist[4 * lane + 3];
 #pragma unroll
                 for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d);
@@ -1138,21 +1266,33 @@ __global__ __launch_bounds__(256) void topc_reduce_sample_kernel(const uint32_t 
             sabove = ab; pprefix |= b << shift;
             LMRL_WAVE_SYNC();
         }
+        // top-p alone: the crossing key is the row's true one iff it lies above every hidden bound (then every key at or above it is a candidate and
+        // the masses summed down to it are complete); a nucleus that reaches into what the tiles did not report goes back to the materialised path
+        if (NUC && pprefix < floor_key) LMRL_HAND_BACK();
         if (pprefix > thr_key) thr_key = pprefix;
     }
 #undef LMRL_WAVE_SYNC
+#undef LMRL_HAND_BACK
     const uint32_t epoch = sp.epoch ? *sp.epoch : 0u;
+    const bool jax = sp.rng == LMRL_RNG_JAX;
     float pmax = -INFINITY, psum = 0.f, best = -INFINITY, best_z = 0.f;
     int best_col = 0x7fffffff;
     for (uint32_t i = lane; i < total; i += 64) {
         const uint32_t k_ = ck[i];
         if (k_ >= thr_key) {
             const int n = (int)cn[i];
-            uint32_t rnd[4];
-            philox4x32_10((uint32_t)m, (uint32_t)(n >> 2), sp.step, epoch, sp.seed_lo, sp.seed_hi, rnd);
-            const float vv = f32_from_order_key(k_) * sp.inv_temperature;
-            const uint32_t rw = (n & 3) == 0 ? rnd[0] : ((n & 3) == 1 ? rnd[1] : ((n & 3) == 2 ? rnd[2] : rnd[3]));
-            const float sc = vv + gumbel_from_bits(rw);
+            const float raw = f32_from_order_key(k_);
+            float vv, sc;
+            if (jax) {          // jax.random.categorical on logits / T: one key for the whole [M, vocab] noise array (word index = row * vocab + column)
+                vv = raw / sp.temperature;
+                sc = vv + gumbel_jax(sp.seed_hi, sp.seed_lo, (uint32_t)m * (uint32_t)vocab + (uint32_t)n, sp.jax_n);
+            } else {
+                uint32_t rnd[4];
+                philox4x32_10((uint32_t)m, (uint32_t)(n >> 2), sp.step, epoch, sp.seed_lo, sp.seed_hi, rnd);
+                vv = raw * sp.inv_temperature;
+                const uint32_t rw = (n & 3) == 0 ? rnd[0] : ((n & 3) == 1 ? rnd[1] : ((n & 3) == 2 ? rnd[2] : rnd[3]));
+                sc = vv + gumbel_from_bits(rw);
+            }
             if (sc > best || (sc == best && n < best_col)) { best = sc; best_col = n; best_z = vv; }
             const float nm = fmaxf(pmax, vv);
             psum = psum * ((pmax == -INFINITY) ? 0.f : __expf(pmax - nm)) + __expf(vv - nm);
@@ -1244,9 +1384,13 @@ int lmrl_gen_accept(const int32_t *sampled_d, uint8_t *active_d, int32_t *out_to
 size_t lmrl_sample_fb_offset(int m, int vocab_padded) {      // byte offset of the flagged-row header inside the workspace
     return (size_t)m * (size_t)(vocab_padded / kLmBN) * kCandWords * sizeof(uint32_t);
 }
+static size_t sample_tile_mass_offset(int m, int vocab_padded) {      // after the flagged-row list, 8-byte aligned: [m][tiles] tile masses of the fused top-p path
+    const size_t o = lmrl_sample_fb_offset(m, vocab_padded) + (size_t)(kFbHeader + kFbMaxBlocks + m) * sizeof(int32_t);
+    return (o + 7) & ~(size_t)7;
+}
 size_t lmrl_sample_ws_bytes(int m, int vocab_padded) {
     static_assert(kCandWords >= kPartialFloats, "the candidate records are the larger form");
-    return (size_t)m * (size_t)(vocab_padded / kLmBN) * kCandWords * sizeof(uint32_t) + (size_t)(kFbHeader + kFbMaxBlocks + m) * sizeof(int32_t);
+    return sample_tile_mass_offset(m, vocab_padded) + (size_t)m * (size_t)(vocab_padded / kLmBN) * sizeof(unsigned long long);
 }
 
 int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_hidden1_d, const void *q_w1_d,
@@ -1261,7 +1405,7 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     sp.inv_temperature = sp.greedy ? 1.f : 1.f / p->temperature;
     sp.seed_lo = (uint32_t)p->seed; sp.seed_hi = (uint32_t)(p->seed >> 32); sp.step = p->step; sp.epoch = p->epoch_d;
     sp.steer_strength = p->steer_strength; sp.beta = p->beta; sp.vocab = vocab;
-    sp.temperature = sp.greedy ? 1.f : p->temperature; sp.rng = p->rng;
+    sp.temperature = sp.greedy ? 1.f : p->temperature; sp.rng = p->rng; sp.tile_mass = nullptr;
     LMRL_REQUIRE(p->rng == LMRL_RNG_PHILOX || p->rng == LMRL_RNG_JAX, "lmrl_lm_head_sample: unknown rng mode");
     LMRL_REQUIRE(p->rng != LMRL_RNG_JAX || (double)m * vocab < 4294967296.0, "lmrl_lm_head_sample: LMRL_RNG_JAX needs rows * vocab < 2^32 (uint32 iota)");
     sp.jax_n = (uint32_t)m * (uint32_t)vocab;
@@ -1277,13 +1421,17 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
         const unsigned long long dev_bit = 1ull << (dev_id & 63);
         if (dev_id >= 64 || !(q_attr_set.load(std::memory_order_acquire) & dev_bit)) {
 #define LMRL_Q_OPTIN(...) LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
-            LMRL_Q_OPTIN(2, true, false); LMRL_Q_OPTIN(2, false, false); LMRL_Q_OPTIN(2, true, true); LMRL_Q_OPTIN(2, false, false, true); LMRL_Q_OPTIN(2, false, false, false, true);
-            LMRL_Q_OPTIN(3, true, false); LMRL_Q_OPTIN(3, false, false); LMRL_Q_OPTIN(3, true, true); LMRL_Q_OPTIN(3, false, false, true); LMRL_Q_OPTIN(3, false, false, false, true);
+            LMRL_Q_OPTIN(2, true, false); LMRL_Q_OPTIN(2, false, false); LMRL_Q_OPTIN(2, true, true); LMRL_Q_OPTIN(2, false, false, 1); LMRL_Q_OPTIN(2, false, false, 2); LMRL_Q_OPTIN(2, false, false, 0, true);
+            LMRL_Q_OPTIN(3, true, false); LMRL_Q_OPTIN(3, false, false); LMRL_Q_OPTIN(3, true, true); LMRL_Q_OPTIN(3, false, false, 1); LMRL_Q_OPTIN(3, false, false, 2); LMRL_Q_OPTIN(3, false, false, 0, true);
 #undef LMRL_Q_OPTIN
             q_attr_set.fetch_or(dev_bit, std::memory_order_release);
         }
     }
     float *partials = (float *)ws_d;
+    const int tiles_n = vocab_padded / kLmBN, tiles_m = (m + kLmBM - 1) / kLmBM;
+    const bool nucleus = p->top_p > 0.f && p->top_p < 1.f && !sp.greedy;
+    const bool topk_on = p->top_k > 0 && p->top_k < vocab;
+    const bool nuc_only = nucleus && !topk_on;
     bool topc = false;
     int32_t *fb = nullptr;
     const uint16_t *A0 = (const uint16_t *)hidden_d, *W0 = (const uint16_t *)wte_d;
@@ -1295,17 +1443,19 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
     hipLaunchKernelGGL((lm_head_sample_kernel<NOPS_, LP_, JAX_>), dim3(tiles), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, W1, q_b1_d, A2, W2, \
                        q_b2_d, steer_tok_d, partials, logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm, (const int32_t *)nullptr, (int32_t *)nullptr)
     const bool lp = logprob_d != nullptr;      // the log-sum-exp (one exp per logit) is computed only when the log-prob is wanted
-    // fused top-k (Philox stream, 0 < top_k <= 64; the policy-only head and — round 6 — the ILQL value policy's pi_beta + beta min(q1, q2),
-    // generation.py:97-119): candidate epilogue + reduce, no logits in HBM; `logits_out_d` stays the scratch of the rare rows the exactness check hands
-    // back to the materialised path.  LMRL_SAMPLE_WANT_LOGITS in `flags` (the caller reads logits_out_d afterwards) or g_sampler_variant 1 / 2 (tools,
-    // tests): always materialise.
-    const int tiles_n = vocab_padded / kLmBN, tiles_m = (m + kLmBM - 1) / kLmBM;
-    topc = sp.rng == LMRL_RNG_PHILOX && !sp.greedy && p->top_k > 0 && p->top_k <= kTopCMaxK && p->top_k < vocab && tiles_n <= 512 &&
+    // fused warpers (both random streams; the policy-only head and — round 6 — the ILQL value policy's pi_beta + beta min(q1, q2), generation.py:97-119):
+    // candidate epilogue + reduce, no logits in HBM, for 0 < top_k <= 256 (with or without top-p) and for top-p ALONE (per-tile probability masses beside
+    // the candidates: right for the peaked distributions of a trained policy — a nucleus that reaches past a tile's 8 candidates goes back);
+    // `logits_out_d` stays the scratch of the rows the exactness checks hand back to the materialised path.  LMRL_SAMPLE_WANT_LOGITS in `flags` (the
+    // caller reads logits_out_d afterwards) or g_sampler_variant 1 / 2 (tools, tests): always materialise.
+    topc = !sp.greedy && ((topk_on && p->top_k <= kTopCMaxK && (p->top_k <= 64 || p->top_k <= tiles_n)) || nuc_only) && tiles_n <= 512 &&      // (k > 64: pre-filter by tile maxima, needs k tiles)
            tiles_m <= kFbMaxBlocks && logits_out_d && g_sampler_variant == 0 && !(p->flags & LMRL_SAMPLE_WANT_LOGITS);
     fb = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(ws_d) + lmrl_sample_fb_offset(m, vocab_padded));
-    // policy-only sampling on the Philox / greedy path: the persistent kernel (ring running ahead across tiles); needs K / 64 even and enough tiles
-    // to give every one of the 512 resident workgroups at least two.  g_gemm_variant 301 (tools) forces the one-tile-per-workgroup kernel for the A/B.
-    const bool persist = nops == 1 && !(sp.rng == LMRL_RNG_JAX && !sp.greedy) && (d_model / 64) % 2 == 0 && d_model >= 128 && tiles >= 1024 &&
+    if (topc && nuc_only) sp.tile_mass = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ws_d) + sample_tile_mass_offset(m, vocab_padded));
+    // policy-only sampling on the Philox / greedy path (and the candidate form, which draws no noise): the persistent kernel (ring running ahead across
+    // tiles); needs K / 64 even and enough tiles to give every one of the 512 resident workgroups at least two.  g_gemm_variant 301 (tools) forces the
+    // one-tile-per-workgroup kernel for the A/B.
+    const bool persist = nops == 1 && (topc || !(sp.rng == LMRL_RNG_JAX && !sp.greedy)) && (d_model / 64) % 2 == 0 && d_model >= 128 && tiles >= 1024 &&
                          g_gemm_variant != 301;
     if (persist) {
         const int grid = 512;                                          // 2 workgroups per CU x 256 CUs (a multiple of 8: XCD affinity preserved)
@@ -1319,24 +1469,28 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
         LMRL_CHECK_HIP(hipGetDevice(&dev_id));
         const unsigned long long dev_bit = 1ull << (dev_id & 63);
         if (dev_id >= 64 || !(attr_set.load(std::memory_order_acquire) & dev_bit)) {
-            LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp_max));
-            LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp_max));
-            LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp_max));
+            LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp_max));
+            LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp_max));
+            LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp_max));
+            LMRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lm_head_sample_persist_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shp_max));
             attr_set.fetch_or(dev_bit, std::memory_order_release);
         }
         const int rounds = tiles / grid, n_tail = tiles - rounds * grid;          // ids: xcd_grid(xm) (a multiple of 8), a few of them surplus
-        if (topc) hipLaunchKernelGGL((lm_head_sample_persist_kernel<false, true>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,
-                                     (float *)nullptr, m, vocab_padded, d_model, vocab_padded, sp, xm, grid, rounds, fb);
-        else if (lp) hipLaunchKernelGGL((lm_head_sample_persist_kernel<true, false>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,
+        if (topc && nuc_only) hipLaunchKernelGGL((lm_head_sample_persist_kernel<false, 2>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,
+                                                 (float *)nullptr, m, vocab_padded, d_model, vocab_padded, sp, xm, grid, rounds, fb);
+        else if (topc) hipLaunchKernelGGL((lm_head_sample_persist_kernel<false, 1>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,
+                                          (float *)nullptr, m, vocab_padded, d_model, vocab_padded, sp, xm, grid, rounds, fb);
+        else if (lp) hipLaunchKernelGGL((lm_head_sample_persist_kernel<true, 0>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,
                                         logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm, grid, rounds, (int32_t *)nullptr);
-        else hipLaunchKernelGGL((lm_head_sample_persist_kernel<false, false>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,
+        else hipLaunchKernelGGL((lm_head_sample_persist_kernel<false, 0>), dim3(grid + n_tail), dim3(kLmWM * kLmWN * 64), shp, s, A0, W0, steer_tok_d, partials,
                                 logits_out_d, m, vocab_padded, d_model, vocab_padded, sp, xm, grid, rounds, (int32_t *)nullptr);
     }
     else if (topc) {
-#define LMRL_TOPC_LAUNCH(NOPS_) hipLaunchKernelGGL((lm_head_sample_kernel<NOPS_, false, false, true>), dim3(tiles), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, W1,  \
+#define LMRL_TOPC_LAUNCH(NOPS_, T_) hipLaunchKernelGGL((lm_head_sample_kernel<NOPS_, false, false, T_>), dim3(tiles), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, W1,  \
                                                    q_b1_d, A2, W2, q_b2_d, steer_tok_d, partials, (float *)nullptr, m, vocab_padded, d_model, vocab_padded, sp, xm,      \
                                                    (const int32_t *)nullptr, fb)
-        if (nops == 1) LMRL_TOPC_LAUNCH(1); else if (nops == 2) LMRL_TOPC_LAUNCH(2); else LMRL_TOPC_LAUNCH(3);
+        if (nuc_only) { if (nops == 1) LMRL_TOPC_LAUNCH(1, 2); else if (nops == 2) LMRL_TOPC_LAUNCH(2, 2); else LMRL_TOPC_LAUNCH(3, 2); }
+        else { if (nops == 1) LMRL_TOPC_LAUNCH(1, 1); else if (nops == 2) LMRL_TOPC_LAUNCH(2, 1); else LMRL_TOPC_LAUNCH(3, 1); }
 #undef LMRL_TOPC_LAUNCH
     }
     else if (sp.rng == LMRL_RNG_JAX && !sp.greedy) {       // parity mode: always with the log-sum-exp variant (one instantiation per operand count)
@@ -1348,19 +1502,18 @@ int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_h
 #undef LMRL_LM_LAUNCH
     }
     LMRL_CHECK_LAUNCH();
-    const bool nucleus = p->top_p > 0.f && p->top_p < 1.f && !sp.greedy;
     if (topc) {
-        const int tiles_n = vocab_padded / kLmBN;
-#define LMRL_TCR_LAUNCH(NT_) hipLaunchKernelGGL(topc_reduce_sample_kernel<NT_>, dim3((m + 3) / 4), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(ws_d), m, \
-                                               tiles_n, vocab, p->top_k, p->top_p, active_d, token_d, logprob_d, sp, p->pad_token, fb)
-        if (tiles_n <= 64) LMRL_TCR_LAUNCH(1); else if (tiles_n <= 128) LMRL_TCR_LAUNCH(2); else if (tiles_n <= 256) LMRL_TCR_LAUNCH(4); else LMRL_TCR_LAUNCH(8);
+#define LMRL_TCR_LAUNCH(NT_, NUC_) hipLaunchKernelGGL((topc_reduce_sample_kernel<NT_, NUC_>), dim3((m + 3) / 4), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(ws_d), m, \
+                                                     tiles_n, vocab, p->top_k, p->top_p, active_d, token_d, logprob_d, sp, p->pad_token, fb)
+        if (nuc_only) { if (tiles_n <= 64) LMRL_TCR_LAUNCH(1, true); else if (tiles_n <= 128) LMRL_TCR_LAUNCH(2, true); else if (tiles_n <= 256) LMRL_TCR_LAUNCH(4, true); else LMRL_TCR_LAUNCH(8, true); }
+        else { if (tiles_n <= 64) LMRL_TCR_LAUNCH(1, false); else if (tiles_n <= 128) LMRL_TCR_LAUNCH(2, false); else if (tiles_n <= 256) LMRL_TCR_LAUNCH(4, false); else LMRL_TCR_LAUNCH(8, false); }
 #undef LMRL_TCR_LAUNCH
         LMRL_CHECK_LAUNCH();
         // the rows the check flagged (a tile holding eight or more of the row's top k: ~1e-8 of rows for spread-out logits): their 128-row blocks' logits
         // from the SAME tile kernel (bit-identical logits, steer included; greedy flag: no noise is drawn), then the materialised selection on those rows
         SampleParams sg = sp;
         sg.greedy = 1;
-#define LMRL_FLAGGED_LAUNCH(NOPS_) hipLaunchKernelGGL((lm_head_sample_kernel<NOPS_, false, false, false, true>), dim3(tiles_n), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, \
+#define LMRL_FLAGGED_LAUNCH(NOPS_) hipLaunchKernelGGL((lm_head_sample_kernel<NOPS_, false, false, 0, true>), dim3(tiles_n), dim3(kLmWM * kLmWN * 64), shmem, s, A0, W0, A1, \
                                                       W1, q_b1_d, A2, W2, q_b2_d, steer_tok_d, (float *)nullptr, logits_out_d, m, vocab_padded, d_model, vocab_padded, sg, xm,   \
                                                       (const int32_t *)(fb + kFbHeader), (int32_t *)nullptr)
         if (nops == 1) LMRL_FLAGGED_LAUNCH(1); else if (nops == 2) LMRL_FLAGGED_LAUNCH(2); else LMRL_FLAGGED_LAUNCH(3);
@@ -1404,7 +1557,7 @@ int lmrl_sample_logits(const float *logits_d, int ld, int m, int vocab, const lm
     sp.greedy = (p->temperature <= 0.f) ? 1 : 0;
     sp.inv_temperature = sp.greedy ? 1.f : 1.f / p->temperature;
     sp.seed_lo = (uint32_t)p->seed; sp.seed_hi = (uint32_t)(p->seed >> 32); sp.step = p->step; sp.epoch = p->epoch_d;
-    sp.steer_strength = 0.f; sp.beta = 0.f; sp.vocab = vocab;
+    sp.steer_strength = 0.f; sp.beta = 0.f; sp.vocab = vocab; sp.tile_mass = nullptr;
     sp.temperature = sp.greedy ? 1.f : p->temperature; sp.rng = p->rng;
     LMRL_REQUIRE(p->rng == LMRL_RNG_PHILOX || p->rng == LMRL_RNG_JAX, "lmrl_sample_logits: unknown rng mode");
     LMRL_REQUIRE(p->rng != LMRL_RNG_JAX || (double)m * vocab < 4294967296.0, "lmrl_sample_logits: LMRL_RNG_JAX needs rows * vocab < 2^32");

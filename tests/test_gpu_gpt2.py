@@ -497,6 +497,71 @@ def test_fused_topk_for_the_ilql_value_policy_head(dev, B, vocab, d, nq):
             assert flagged > 0, "the clustered Q heads were meant to exercise the hand-back to the materialised three-operand path"
 
 
+@pytest.mark.parametrize("B,vocab,d,nq", [(1024, 50257, 128, 0), (200, 9000, 128, 2), (130, 300, 128, 0), (300, 20000, 256, 1)])
+def test_fused_remaining_warper_forms_equal_the_materialised_path(dev, B, vocab, d, nq):
+    """Round 6 (`train_ppo_gpt2.py:98-99, 218-227`: policy_top_k / policy_top_p, either alone): the candidate path for (a) top-p
+    WITHOUT top-k — the epilogue also writes every tile's probability mass, the reduce kernel forms the row total from them, selects the nucleus among
+    the candidates above every tile's hidden bound and hands a row back when its nucleus reaches further; (b) 64 < top_k <= 256 (pre-filter by the
+    per-tile maxima); (c) the LMRL_RNG_JAX stream (the draw happens in the reduce kernel: threefry words for the kept columns only).  Against the
+    materialised path (`lmrl_sampler_set_variant(2)`) on peaked logits (a trained policy's shape) and on flat ones (every top-p row goes back): every
+    sampled token identical, log-probs to fp32 rounding; policy-only head (persistent and one-tile kernels) and the ILQL value policy's heads."""
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.gpt2 import RNG_JAX, GPT2Config, GPT2Engine, SampleParams, init_hf_style_state_dict
+    L = _lib.lib()
+    cfg = GPT2Config(1, d // 64, d, 256, vocab, 32)
+    g = torch.Generator().manual_seed(vocab + nq)
+    hid = _bf(torch.randn(B, d, generator=g)).to(dev)
+    steer = torch.randint(0, vocab, (B,), generator=g).to(torch.int32); steer[::3] = -1
+    active = torch.ones(B, dtype=torch.uint8); active[5::17] = 0
+    steer, active = steer.to(dev), active.to(dev)
+    qh = [_bf(torch.relu(torch.randn(B, d, generator=g))).to(dev) for _ in range(nq)]
+    qw = [_bf(torch.randn(cfg.vocab_padded, d, generator=g) * 0.3).to(dev) for _ in range(nq)]
+    qb = [torch.randn(cfg.vocab_padded, generator=g).to(dev) for _ in range(nq)]
+    q1 = (qh[0], qw[0], qb[0]) if nq >= 1 else None
+    q2 = (qh[1], qw[1], qb[1]) if nq == 2 else None
+    fb_off = L.lmrl_sample_fb_offset(B, cfg.vocab_padded)
+    for scale, peaked in ((60.0, True), (8.0, False)):
+        sd = init_hf_style_state_dict(cfg, seed=3)
+        sd["wte.weight"] = (sd["wte.weight"] * scale).to(torch.bfloat16).float()
+        eng = GPT2Engine(cfg, sd, dev)
+        ses = eng.session(B, 8)
+        lo = torch.zeros(B, cfg.vocab_padded, device=dev)
+        cases = [(1.0, 0, 0.9, 0.0, 0), (0.7, 0, 0.5, 4.0, 0), (1.0, 0, 0.97, 0.0, RNG_JAX), (1.0, 128, 0.0, 0.0, 0), (0.9, 256, 0.95, 3.0, 0),
+                 (1.0, 40, 0.0, 0.0, RNG_JAX), (0.8, 100, 0.9, 0.0, RNG_JAX)]
+        handed = {}
+        for temp, top_k, top_p, strength, rng in cases:
+            if top_k >= vocab:
+                continue
+            outs = []
+            for variant in (2, 0):
+                L.lmrl_sampler_set_variant(variant)
+                try:
+                    lo.fill_(float("nan"))
+                    sp = SampleParams(temp, top_k, 0xD1CE, 4, strength, 2.0 if nq else 0.0, 9, None, top_p, rng)
+                    tok, lp = ses.sample(sp, hidden=hid, steer_tok=steer, active=active, logits_out=lo, q1=q1, q2=q2)
+                    torch.cuda.synchronize()
+                    outs.append((tok.cpu().numpy().copy(), lp.cpu().numpy().copy()))
+                    if variant == 0:
+                        touched = int((~torch.isnan(lo[:, 0])).sum().item())
+                        if top_k == 0 or top_k <= 64 or top_k <= cfg.vocab_padded // 128:
+                            fb = ses.sample_ws[fb_off:fb_off + 4 * (16 + 64 + B)].view(torch.int32)
+                            n_fb = int(fb[0].item())
+                            handed[(temp, top_k, top_p, rng)] = n_fb
+                            assert touched <= 128 * n_fb                   # logits exist only for handed-back rows' 128-row blocks
+                        else:                                              # more than 64 and more than the tile count: materialised by choice
+                            assert touched == B
+                finally:
+                    L.lmrl_sampler_set_variant(0)
+            assert np.array_equal(outs[0][0], outs[1][0]), (peaked, temp, top_k, top_p, rng)
+            np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=2e-5)
+            assert (outs[0][0][active.cpu().numpy() == 0] == 9).all()
+        n_act = int(active.sum().item())
+        if peaked and vocab > 5000:       # the fused forms did the work: few rows handed back
+            assert all(v <= n_act // 8 for v in handed.values()), handed
+        if not peaked and vocab > 5000 and nq == 0:   # flat logits (the Q heads' perturbation would peak them): a 0.9 nucleus is thousands of tokens — every active row went back, same tokens
+            assert handed[(1.0, 0, 0.9, 0)] == n_act, handed
+
+
 @pytest.mark.parametrize("ilql", [False, True])
 def test_fused_topk_at_bench_size_against_the_float64_oracle(dev, ilql):
     """The fused top-k path at the size the bench runs it (1024 rows x the GPT-2 vocabulary, d = 768), not against another HIP path but against
