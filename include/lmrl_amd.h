@@ -502,11 +502,13 @@ size_t lmrl_sample_fb_offset(int m, int vocab_padded);
 /* hidden_d bf16 [m][d] . wte_d bf16 [vocab_padded][d]^T -> token_d[m] (+ logprob_d[m] under the sampling
  * distribution).  Optional ILQL operands: q_hidden{1,2}_d bf16 [m][d] (= relu(dense1(h)) of each Q head),
  * q_w{1,2}_d bf16 [vocab_padded][d] (dense2 kernels, [out][in]), q_b{1,2}_d f32 [vocab_padded].
- * logits_out_d (optional f32 [m][vocab_padded]) receives the combined (untempered) logits — except on the fused top-k path
- * (policy-only operands, LMRL_RNG_PHILOX, temperature > 0, 0 < top_k <= 64: `FlaxTopKLogitsWarper` of train_ppo_gpt2.py:98-99, 218-227 inside
- * the LM-head epilogue): there the epilogue keeps the 8 largest logits of every (row, 128-column tile), a reduce kernel finds the row's k-th
- * largest among them, checks that no tile can hide a larger one, applies top_p and draws; logits_out_d is written only for the 128-row blocks of
- * rows that fail the check (they are re-done from materialised logits: same tokens as the materialised path in every case). */
+ * logits_out_d (optional f32 [m][vocab_padded]) receives the combined (untempered) logits — except on the fused warper path
+ * (either random stream, one to three operands, temperature > 0, and 0 < top_k <= 256 [above 64: top_k <= vocab_padded / 128] and / or
+ * 0 < top_p < 1: `FlaxTopKLogitsWarper` / `FlaxTopPLogitsWarper` of train_ppo_gpt2.py:98-99, 218-227 inside the LM-head epilogue): there the
+ * epilogue keeps the 8 largest logits of every (row, 128-column tile) — and, for top_p without top_k, the tile's probability mass —, a reduce
+ * kernel finds the row's k-th largest among them / the nucleus' crossing token, checks that no tile can hide a logit that matters, and draws;
+ * logits_out_d is written only for the 128-row blocks of rows that fail the check (they are re-done from materialised logits: same tokens as
+ * the materialised path in every case).  LMRL_SAMPLE_WANT_LOGITS in p->flags: always materialise. */
 int lmrl_lm_head_sample(const void *hidden_d, const void *wte_d, const void *q_hidden1_d, const void *q_w1_d,
                         const float *q_b1_d, const void *q_hidden2_d, const void *q_w2_d, const float *q_b2_d, int m,
                         int d_model, int vocab, int vocab_padded, const lmrl_sample_params *p, const int32_t *steer_tok_d,

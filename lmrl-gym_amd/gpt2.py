@@ -277,8 +277,8 @@ class KVSession:
     def sample(self, params: SampleParams, steer_tok=None, active=None, hidden=None, logits_out=None,
                q1=None, q2=None, want_logprob: bool = True):
         """Fused LM head + sampling of one token per env from `hidden` (default: last_hidden).
-        logits_out: with 0 < top_k <= 64 on the Philox stream the call keeps candidates, not logits (logits_out is then only scratch for rows handed
-        back to the materialised selection); set `params.flags = SAMPLE_WANT_LOGITS` to have the logits written there as well.
+        logits_out: with 0 < top_k <= 256 and / or 0 < top_p < 1 the call keeps candidates, not logits (logits_out is then only scratch for rows
+        handed back to the materialised selection); set `params.flags = SAMPLE_WANT_LOGITS` to have the logits written there as well.
         q1/q2: optional (q_hidden bf16 [B][d], w bf16 [Vp][d], bias f32 [Vp]) ILQL operands.
         want_logprob=False skips the log-sum-exp over the vocabulary (the reference's sampling step returns only the token;
         rollouts do not use the sampled token's log-probability) and returns (token, None)."""
