@@ -34,6 +34,8 @@ for i in range(warm, warm + steps):
     ro.replay_episode(seeds[i], guesses[i]); n += ro.traj["n_steps"].sum()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print("ILQL value-policy rollouts: %.1f env-steps/s  (%.2f ms per 1024-env episode, %d env steps)" % (int(n) / dt, dt * 1e3 / steps, int(n)))
+if "plain" in sys.argv[1:]:          # profiling: the plain-sampling leg alone
+    sys.exit(0)
 
 # round 6: the task script's sampler — top-k on the perturbed logits (train_ilql_gpt2.py:384-403 `policy_top_k`, generation.py:97-119) — on the FUSED
 # candidate path of the three-operand head (no [B, V] logits in HBM) vs the materialised path of the same head (lmrl_sampler_set_variant(2))
