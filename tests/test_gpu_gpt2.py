@@ -613,6 +613,60 @@ def test_fused_topk_at_bench_size_against_the_float64_oracle(dev, ilql):
     assert len(set(tok.tolist())) > 200                                     # a real spread of draws, not one dominant column
 
 
+def test_fused_top_p_at_bench_size_against_the_float64_oracle(dev):
+    """Top-p WITHOUT top-k on the candidate path (tile masses + nucleus among the candidates) at 1024 rows x the GPT-2 vocabulary, d = 768, against
+    the warper SEMANTICS on float64 logits (HF `TopPLogitsWarper` / `FlaxTopPLogitsWarper`, train_ppo_gpt2.py:98-99, 218-227: the descending-sorted
+    prefix whose cumulative probability reaches top_p) and the documented noise stream (oracle/gpt2.py::gumbel_noise) — not against another HIP path:
+    every sampled token lies in the oracle's nucleus (rows whose cumulative mass passes top_p within 1e-3 of a token boundary are skipped: bf16-product
+    rounding), its log-probability is the renormalised one, on the first 128 rows the token IS the oracle's arg-max of logit / T + Gumbel over the
+    nucleus; and the candidate path did the work (no row handed back to materialised logits on this peaked, trained-policy-like distribution)."""
+    from lmrl_gym_amd import _lib
+    from lmrl_gym_amd.gpt2 import GPT2Config, GPT2Engine, SampleParams, init_hf_style_state_dict
+    from oracle import gpt2 as O
+    B, d, top_p, temp = 1024, 768, 0.9, 0.8
+    cfg = GPT2Config(1, 12, d, 3072, 50257, 32)
+    V = cfg.vocab
+    g = torch.Generator().manual_seed(78)
+    sd = init_hf_style_state_dict(cfg, seed=9)
+    sd["wte.weight"] = (sd["wte.weight"] * 14).to(torch.bfloat16).float()
+    eng = GPT2Engine(cfg, sd, dev)
+    ses = eng.session(B, 8)
+    hid = _bf(torch.randn(B, d, generator=g))
+    z = hid.double() @ sd["wte.weight"].double().t()
+    lo = torch.full((B, cfg.vocab_padded), float("nan"), device=dev)
+    seed, step = 0xA5A6, 13
+    tok, lp = ses.sample(SampleParams(temp, 0, seed, step, 0.0, 0.0, 3, None, top_p, 0), hidden=hid.to(dev), logits_out=lo)
+    torch.cuda.synchronize()
+    tok, lp = tok.cpu().numpy(), lp.cpu().numpy()
+    fb = ses.sample_ws[_lib.lib().lmrl_sample_fb_offset(B, cfg.vocab_padded):][:64].view(torch.int32)
+    assert int(fb[0].item()) <= B // 50 and int(torch.isnan(lo[:, 0]).sum().item()) >= B - 128 * int(fb[0].item())
+    zt = (z / temp)
+    p = torch.softmax(zt, 1)
+    ps, order = p.sort(1, descending=True)
+    cum = ps.cumsum(1)
+    n_keep = (cum < top_p).sum(1) + 1                                        # HF: tokens kept while the mass BEFORE them is below top_p
+    assert 2.0 < n_keep.double().mean().item() < 200.0, n_keep.double().mean().item()
+    before = torch.where(n_keep > 1, cum.gather(1, (n_keep - 2).clamp(min=0)[:, None])[:, 0], torch.zeros(B, dtype=torch.float64))
+    at = cum.gather(1, (n_keep - 1)[:, None])[:, 0]
+    clear = (((top_p - before) > 1e-3) & ((at - top_p) > 1e-3)).numpy()       # the crossing is decided beyond the bf16-product / fp32-accumulation noise
+    assert clear.mean() > 0.9
+    rank = torch.empty_like(order); rank.scatter_(1, order, torch.arange(V)[None].expand(B, V))
+    kept = (rank < n_keep[:, None]).numpy()
+    assert kept[np.arange(B), tok][clear].all()
+    ztn = zt.numpy()
+    mx = ztn.max(1, keepdims=True)
+    logp = ztn - np.log(np.where(kept, np.exp(ztn - mx), 0.0).sum(1, keepdims=True)) - mx
+    np.testing.assert_allclose(lp[clear], logp[np.arange(B), tok][clear], rtol=0, atol=3e-3)
+    n = 128
+    noise = O.gumbel_noise(n, V, seed, step).astype(np.float64)
+    score = np.where(kept[:n], ztn[:n] + noise, -np.inf)
+    best = score.argmax(1)
+    top2 = -np.sort(-score, axis=1)[:, :2]
+    sure = clear[:n] & ((top2[:, 0] - top2[:, 1]) > 1e-3)
+    assert sure.mean() > 0.8 and (tok[:n][sure] == best[sure]).all()
+    assert len(set(tok.tolist())) > 100
+
+
 def test_sampler_steer_and_ilql_perturbation(dev):
     """logits = pi + beta * min(q1, q2)  (value_rl_base/gpt2/generation.py:112-117), greedy."""
     from lmrl_gym_amd.gpt2 import SampleParams
