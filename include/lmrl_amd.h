@@ -659,6 +659,21 @@ int lmrl_maze_tok_action(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, int n, 
 int lmrl_maze_tok_ppo_records(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, int n_envs, const int32_t *off_d, int newline_tok, int cap,
                               int32_t *tokens_d, uint8_t *is_action_d, float *reward_d, int32_t *n_tok_d, int32_t *chain_d, int32_t *pos_d, uint8_t *last_d,
                               uint8_t *done_d, int32_t *chain_total_d, void *stream);
+/* The same export for item windows (last_k > 1; run after an episode of the history-mode loop below), in the form of the partially observed online
+ * script (llm_rl_scripts/maze/ppo/partially_observed_ppo_online.py:372-398): per transition ONE non-action text — the window's item texts joined by
+ * single spaces — then the action text, reward on the action's last token; chained per episode.  The window of every turn is rebuilt from the record
+ * (tr->pos / action / kind: maze/env/env.py:179-184).  Token ids: the first item's own encoding, every later item's encoding behind the joining space
+ * (lmrl_maze_tok_set_spaced), a legal action as the encoding of its dict key (lmrl_maze_tok_set_actions), any other action string as its generated
+ * ids (as above) — or, with byte_ids != 0 (a tokenizer whose ids are the text's UTF-8 bytes), as the bytes of its decoded text, i.e. exactly
+ * tokenizer.encode(text) also when the policy spelled it with multi-byte tokens.  last_k <= 64.  tokens_d == NULL: first pass — only n_tok_d (untruncated lengths) .. chain_total_d are written, the caller sizes
+ * `cap` by the longest row and calls again. */
+int lmrl_maze_tok_ppo_records_hist(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, int n_envs, const int32_t *off_d, int last_k,
+                                   int newline_tok, int byte_ids, int cap, int32_t *tokens_d, uint8_t *is_action_d, float *reward_d, int32_t *n_tok_d, int32_t *chain_d,
+                                   int32_t *pos_d, uint8_t *last_d, uint8_t *done_d, int32_t *chain_total_d, void *stream);
+/* host tables for the above: obs_sp_tok [n_obs][obs_sp_cap] / obs_sp_len [n_obs] = tokenizer.encode(' ' + observation text) of every row of the
+ * observation table, act_sp_tok [4][act_sp_cap] = tokenizer.encode(' ' + action string), its length in the last slot */
+int lmrl_maze_tok_set_spaced(lmrl_maze_tok_ctx *c, const int32_t *obs_sp_tok, const int32_t *obs_sp_len, int obs_sp_cap, const int32_t *act_sp_tok,
+                             int act_sp_cap);
 /* Histories of more than one item (MazeEnv(last_k > 1): `(history + [action] + [observation])[-last_k:]`, maze/env/env.py:182-184; the prompt is the
  * window's text, left-truncated to max_input_length tokens, ppo/gpt2/interface.py:519-524; partially_observed_bc.py:241 runs last_k = 40) on a
  * persistent per-env KV cache.  Per env: the episode's token history, the token offset of every item, and which part of the history is in the

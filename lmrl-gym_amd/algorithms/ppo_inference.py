@@ -57,6 +57,22 @@ def text_trajectory_chains_from_transitions(raw_results):
     return chains
 
 
+def text_trajectory_chains_partially_observed(raw_results):
+    """The rollout -> chain step of the partially observed Maze script (llm_rl_scripts/maze/ppo/partially_observed_ppo_online.py:372-398): per
+    transition the texts of `post_action_history[:-1]` (the item window the policy saw) joined by single spaces into ONE non-action Text, then the
+    action, reward [0, r]; linked through `next` in episode order."""
+    from ..environment import Text, TextTrajectory, TextTrajectoryChain
+    chains = []
+    for raw in raw_results:
+        chain = None
+        for tr in reversed(list(raw)):
+            state = Text(" ".join(item.text for item in tr.post_action_history[:-1]), False)
+            chain = TextTrajectoryChain(TextTrajectory((state, tr.post_action_history[-1]), (0.0, float(tr.reward)), bool(tr.done)), chain)
+        if chain is not None:
+            chains.append(chain)
+    return chains
+
+
 class PPOForwardOutput(NamedTuple):
     initial_policy_logprobs: Optional[np.ndarray]   # [B, T-1] log p_init(ids[t+1] | ids[:t+1])
     policy_logprobs: np.ndarray                     # [B, T-1]

@@ -17,6 +17,10 @@ struct lmrl_maze_tok_ctx {
     uint8_t *tok_bytes_d = nullptr, *tok_blen_d = nullptr;
     int32_t *act_tok_d = nullptr;      // [4][act_cap] the tokenizer's encoding of the four action strings ('move left\n' ...), act_len in slot act_cap - 1 ... see lmrl_maze_tok_set_actions
     int act_cap = 0;
+    // the same texts encoded behind a joining space (' ' + text): the items of a window after the first one in the partially observed PPO script's
+    // state text (" ".join(...)), see lmrl_maze_tok_set_spaced
+    int32_t *obs_sp_tok_d = nullptr, *obs_sp_len_d = nullptr, *act_sp_tok_d = nullptr;
+    int obs_sp_cap = 0, act_sp_cap = 0;
     int n_obs = 0, obs_cap = 0, rows = 0, cols = 0, vocab = 0, max_new = 0, max_turns = 0;
 };
 
@@ -178,6 +182,127 @@ __global__ __launch_bounds__(256) void maze_ppo_records_kernel(lmrl_maze_traj tr
     }
 }
 
+// ---- the same export for item windows (last_k > 1), in the form the partially observed online script builds (llm_rl_scripts/maze/ppo/
+// partially_observed_ppo_online.py:372-398): per transition ONE non-action text — the window's item texts joined by single spaces — followed by the
+// action text, reward on the action's last token.  The window of turn t is rebuilt from the record: (history + [action] + [observation])[-last_k:] per
+// legal step, (observation,) alone after an action string outside the action dict (maze/env/env.py:179-184).  Token ids: the first item's own encoding,
+// every later item's encoding behind the joining space (host tables: lmrl_maze_tok_set_spaced — equal to tokenizer.encode(joined text) for tokenizers
+// whose encoding splits between an item's trailing newline and the space: checked on the host); the action: the tokenizer's encoding of a legal
+// action string (its text IS the dict key), else the generated ids as in maze_ppo_records_kernel.  One wave per env; a window item is an observation
+// table row (>= 0) or -(action code + 1), kept in a ring of last_k <= 64 entries.  count_only: lengths only (the host sizes `cap` by the longest row).
+__global__ __launch_bounds__(256) void maze_ppo_records_hist_kernel(lmrl_maze_traj tr, const int32_t *__restrict__ state, const int32_t *__restrict__ goal_slot,
+                                                                    const int32_t *__restrict__ obs_tok, const int32_t *__restrict__ obs_len, int obs_cap,
+                                                                    const int32_t *__restrict__ obs_sp_tok, const int32_t *__restrict__ obs_sp_len, int obs_sp_cap,
+                                                                    const int32_t *__restrict__ act_tok, int act_cap, const int32_t *__restrict__ act_sp_tok, int act_sp_cap,
+                                                                    const uint8_t *__restrict__ tok_bytes, const uint8_t *__restrict__ tok_blen, int vocab,
+                                                                    int rows, int cols, int max_new, int max_turns, int n, int pitch, const int32_t *__restrict__ off,
+                                                                    int last_k, int newline_tok, int cap, int count_only, int byte_ids, int32_t *__restrict__ tokens,
+                                                                    uint8_t *__restrict__ is_action, float *__restrict__ reward, int32_t *__restrict__ n_tok,
+                                                                    int32_t *__restrict__ chain, int32_t *__restrict__ pos, uint8_t *__restrict__ last,
+                                                                    uint8_t *__restrict__ done, int32_t *__restrict__ chain_total) {
+    __shared__ int32_t ring_s[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + wave;
+    if (e >= n) return;
+    int32_t *ring = ring_s[wave];
+    const int nt = tr.n_turns[e];
+    const int gr = state[2 * pitch + e], gc = state[3 * pitch + e];
+    const int slot = goal_slot[gr * cols + gc];
+    auto obs_row = [&](int t) {
+        const int pc = tr.pos[(size_t)e * max_turns + t];
+        return slot >= 0 ? (slot * rows + (pc >> 16)) * cols + (pc & 0xFFFF) : -1;
+    };
+    int start = 0, count = 0, offset = 0;
+    auto push = [&](int item) {                                      // wave-uniform; lane 0 writes, the wave reads after the fence below
+        if (count == last_k) start = (start + 1) & 63; else count++;
+        if (lane == 0) ring[(start + count - 1) & 63] = item;
+    };
+    for (int t = 0; t < nt; t++) {
+        const size_t row = (size_t)off[e] + t;
+        if (t == 0) push(obs_row(0));
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int len = 0;
+        for (int j = 0; j < count; j++) {
+            const int item = ring[(start + j) & 63];
+            const int32_t *src = nullptr;
+            int l = 0;
+            if (item >= 0) {
+                src = j == 0 ? obs_tok + (size_t)item * obs_cap : obs_sp_tok + (size_t)item * obs_sp_cap;
+                l = j == 0 ? obs_len[item] : obs_sp_len[item];
+            } else if (item > -6) {
+                const int code = -item - 1;
+                src = j == 0 ? act_tok + code * act_cap : act_sp_tok + code * act_sp_cap;
+                l = j == 0 ? act_tok[code * act_cap + act_cap - 1] : act_sp_tok[code * act_sp_cap + act_sp_cap - 1];
+            }
+            if (!count_only)
+                for (int k = lane; k < l; k += 64)
+                    if (len + k < cap) {
+                        tokens[row * cap + len + k] = src[k];
+                        is_action[row * cap + len + k] = 0;
+                        reward[row * cap + len + k] = 0.f;
+                    }
+            len += l;
+        }
+        const int code = tr.action[(size_t)e * max_turns + t];
+        int na = 0;
+        if (code < 4) {                                              // a legal action: its text is the dict key
+            na = act_tok[code * act_cap + act_cap - 1];
+            if (!count_only)
+                for (int k = lane; k < na; k += 64)
+                    if (len + k < cap) tokens[row * cap + len + k] = act_tok[code * act_cap + k];
+        } else {
+            const int gl = tr.gen_len[(size_t)e * max_turns + t];
+            int last_byte = -1;
+            for (int k = 0; k < gl; k++) {
+                const int tok = tr.gen[((size_t)e * max_turns + t) * max_new + k];
+                const int bl = (tok >= 0 && tok < vocab) ? tok_blen[tok] : 255;
+                if (bl == 0) continue;                               // skip_special_tokens
+                if (byte_ids && bl != 255) {                         // a tokenizer whose ids ARE the text's UTF-8 bytes: encode(decoded text), byte by byte
+                    if (!count_only && lane == 0)
+                        for (int b = 0; b < bl; b++)
+                            if (len + na + b < cap) tokens[row * cap + len + na + b] = tok_bytes[(size_t)tok * kTokBytes + b];
+                    last_byte = tok_bytes[(size_t)tok * kTokBytes + bl - 1];
+                    na += bl;
+                    continue;
+                }
+                if (!count_only && lane == 0 && len + na < cap) tokens[row * cap + len + na] = tok;
+                last_byte = bl == 255 ? -1 : tok_bytes[(size_t)tok * kTokBytes + bl - 1];
+                na++;
+            }
+            if (last_byte != '\n') {
+                if (!count_only && lane == 0 && len + na < cap) tokens[row * cap + len + na] = newline_tok;
+                na++;
+            }
+        }
+        const int full = len + na, total = count_only ? full : min(full, cap);
+        if (!count_only)
+            for (int k = len + lane; k < total; k += 64) {
+                is_action[row * cap + k] = 1;
+                reward[row * cap + k] = k == total - 1 ? tr.reward[(size_t)e * max_turns + t] : 0.f;
+            }
+        if (lane == 0) {
+            n_tok[row] = total;
+            chain[row] = e;
+            pos[row] = offset;
+            last[row] = t == nt - 1;
+        }
+        offset += total > 0 ? total - 1 : 0;
+        const int kind = tr.kind[(size_t)e * max_turns + t];
+        if (t + 1 < nt && kind != LMRL_MAZE_KIND_FAILURE && kind != LMRL_MAZE_KIND_SUCCESS) {
+            __builtin_amdgcn_wave_barrier();                         // (every lane is done reading the ring)
+            if (kind == LMRL_MAZE_KIND_OBS_ONLY) { start = 0; count = 0; }
+            else push(-(code + 1));
+            push(obs_row(t + 1));
+        }
+    }
+    if (lane == 0) {
+        const int k = nt > 0 ? tr.kind[(size_t)e * max_turns + nt - 1] : 0;
+        done[e] = (k == 1 || k == 2) ? 1 : 0;
+        chain_total[e] = offset;
+    }
+}
+
 // ---- histories longer than one item (round 6): `MazeEnv.step` returns (history + [action] + [observation])[-last_k:] (maze/env/env.py:182-184) and the
 // policy's prompt is the text of that window, left-truncated to max_input_length tokens (ppo/gpt2/interface.py:519-524; partially_observed_bc.py:241
 // runs last_k = 40).  While the window only GROWS — fewer than last_k items and max_input_length tokens — prompt t + 1 = prompt t ++ action ++ new
@@ -321,7 +446,8 @@ lmrl_maze_tok_ctx *lmrl_maze_tok_create(const int32_t *obs_tok, const int32_t *o
 
 void lmrl_maze_tok_destroy(lmrl_maze_tok_ctx *c) {
     if (!c) return;
-    for (void *p : {(void *)c->obs_tok_d, (void *)c->obs_len_d, (void *)c->goal_slot_d, (void *)c->tok_bytes_d, (void *)c->tok_blen_d, (void *)c->act_tok_d})
+    for (void *p : {(void *)c->obs_tok_d, (void *)c->obs_len_d, (void *)c->goal_slot_d, (void *)c->tok_bytes_d, (void *)c->tok_blen_d, (void *)c->act_tok_d,
+                    (void *)c->obs_sp_tok_d, (void *)c->obs_sp_len_d, (void *)c->act_sp_tok_d})
         if (p) (void)hipFree(p);
     delete c;
 }
@@ -418,6 +544,40 @@ int lmrl_maze_tok_ppo_records(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, co
     hipLaunchKernelGGL(maze_ppo_records_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, as_stream(stream), *tr, (const int32_t *)state_d, c->goal_slot_d,
                        c->obs_tok_d, c->obs_len_d, c->obs_cap, c->tok_bytes_d, c->tok_blen_d, c->vocab, c->rows, c->cols, c->max_new, c->max_turns, n, n_envs, off_d,
                        newline_tok, cap, tokens_d, is_action_d, reward_d, n_tok_d, chain_d, pos_d, last_d, done_d, chain_total_d);
+    LMRL_CHECK_LAUNCH();
+    return LMRL_OK;
+}
+
+int lmrl_maze_tok_set_spaced(lmrl_maze_tok_ctx *c, const int32_t *obs_sp_tok, const int32_t *obs_sp_len, int obs_sp_cap, const int32_t *act_sp_tok, int act_sp_cap) {
+    LMRL_REQUIRE(c && obs_sp_tok && obs_sp_len && obs_sp_cap > 0 && act_sp_tok && act_sp_cap >= 2, "lmrl_maze_tok_set_spaced: bad argument");
+    for (int i = 0; i < c->n_obs; i++) LMRL_REQUIRE(obs_sp_len[i] >= 0 && obs_sp_len[i] <= obs_sp_cap, "lmrl_maze_tok_set_spaced: observation length outside [0, cap]");
+    for (int a = 0; a < 4; a++)
+        LMRL_REQUIRE(act_sp_tok[a * act_sp_cap + act_sp_cap - 1] > 0 && act_sp_tok[a * act_sp_cap + act_sp_cap - 1] < act_sp_cap, "lmrl_maze_tok_set_spaced: action length outside (0, cap)");
+    for (void *p : {(void *)c->obs_sp_tok_d, (void *)c->obs_sp_len_d, (void *)c->act_sp_tok_d})
+        if (p) (void)hipFree(p);
+    c->obs_sp_tok_d = c->obs_sp_len_d = c->act_sp_tok_d = nullptr;
+    LMRL_CHECK_HIP(hipMalloc((void **)&c->obs_sp_tok_d, sizeof(int32_t) * (size_t)c->n_obs * obs_sp_cap));
+    LMRL_CHECK_HIP(hipMemcpy(c->obs_sp_tok_d, obs_sp_tok, sizeof(int32_t) * (size_t)c->n_obs * obs_sp_cap, hipMemcpyHostToDevice));
+    LMRL_CHECK_HIP(hipMalloc((void **)&c->obs_sp_len_d, sizeof(int32_t) * (size_t)c->n_obs));
+    LMRL_CHECK_HIP(hipMemcpy(c->obs_sp_len_d, obs_sp_len, sizeof(int32_t) * (size_t)c->n_obs, hipMemcpyHostToDevice));
+    LMRL_CHECK_HIP(hipMalloc((void **)&c->act_sp_tok_d, sizeof(int32_t) * 4 * (size_t)act_sp_cap));
+    LMRL_CHECK_HIP(hipMemcpy(c->act_sp_tok_d, act_sp_tok, sizeof(int32_t) * 4 * (size_t)act_sp_cap, hipMemcpyHostToDevice));
+    c->obs_sp_cap = obs_sp_cap; c->act_sp_cap = act_sp_cap;
+    return LMRL_OK;
+}
+
+int lmrl_maze_tok_ppo_records_hist(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, int n_envs, const int32_t *off_d, int last_k,
+                                   int newline_tok, int byte_ids, int cap, int32_t *tokens_d, uint8_t *is_action_d, float *reward_d, int32_t *n_tok_d, int32_t *chain_d,
+                                   int32_t *pos_d, uint8_t *last_d, uint8_t *done_d, int32_t *chain_total_d, void *stream) {
+    const bool count_only = tokens_d == nullptr;                    // first pass: n_tok_d only (the longest row sizes `cap`)
+    LMRL_REQUIRE(c && tr && state_d && n > 0 && n <= n_envs && off_d && last_k >= 1 && last_k <= 64 && n_tok_d && chain_d && pos_d && last_d && done_d && chain_total_d,
+                 "lmrl_maze_tok_ppo_records_hist: bad argument (last_k must be <= 64)");
+    LMRL_REQUIRE(count_only || (cap >= 2 && is_action_d && reward_d), "lmrl_maze_tok_ppo_records_hist: bad argument");
+    LMRL_REQUIRE(c->act_tok_d && c->obs_sp_tok_d, "lmrl_maze_tok_ppo_records_hist: call lmrl_maze_tok_set_actions and lmrl_maze_tok_set_spaced first");
+    hipLaunchKernelGGL(maze_ppo_records_hist_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, as_stream(stream), *tr, (const int32_t *)state_d, c->goal_slot_d,
+                       c->obs_tok_d, c->obs_len_d, c->obs_cap, c->obs_sp_tok_d, c->obs_sp_len_d, c->obs_sp_cap, c->act_tok_d, c->act_cap, c->act_sp_tok_d, c->act_sp_cap,
+                       c->tok_bytes_d, c->tok_blen_d, c->vocab, c->rows, c->cols, c->max_new, c->max_turns, n, n_envs, off_d, last_k, newline_tok, cap, count_only ? 1 : 0,
+                       byte_ids, tokens_d, is_action_d, reward_d, n_tok_d, chain_d, pos_d, last_d, done_d, chain_total_d);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

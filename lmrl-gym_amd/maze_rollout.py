@@ -1,4 +1,5 @@
-"""Lock-step Maze rollouts entirely on the device, for one-item histories (last_k = 1).
+"""Lock-step Maze rollouts entirely on the device: one-item histories (last_k = 1, below) and item windows (last_k > 1: `MazeRolloutEngine`'s
+docstring; both with the online PPO scripts' chains built from the device record, `ppo_records`).
 
 The MI355X counterpart of `interact_environment(maze_env, GPT2PPOPolicy(...), bsize=B)` (LLM_RL/environment.py:154-207 with
 ppo/gpt2/interface.py:507-546) on the reference's Maze harness (maze/bc/fully_observed_bc.py:230-283: `last_k=1`, `max_steps=100`).
@@ -461,7 +462,7 @@ class MazeRolloutEngine:
         from .algorithms.ppo_device import PPORecords
         t, L, sp = torch, self._L, _lib.stream_ptr()
         if self.last_k != 1:
-            raise ValueError("ppo_records: the per-transition chains of the Maze online script are built for one-item histories (last_k = 1)")
+            return self._ppo_records_history(n)
         if self.in_str_process("\x00probe") != "\x00probe" or self.obs_len_h.max() >= self._max_input_length:
             raise ValueError("ppo_records: the PPO chains tokenise the raw observation text — in_str_process must be the identity and prompts untruncated")
         B = self.B if n is None else int(n)
@@ -480,6 +481,79 @@ class MazeRolloutEngine:
         _lib.check(L.lmrl_maze_tok_ppo_records(self._tok, ctypes.byref(self._ctraj), _lib.ptr(self.env.state), B, self.B, _lib.ptr(off), int(nl[0]), cap, _lib.ptr(tokens),
                                                _lib.ptr(ia), _lib.ptr(rw), _lib.ptr(n_tok), _lib.ptr(chain), _lib.ptr(pos), _lib.ptr(last), _lib.ptr(done),
                                                _lib.ptr(total), sp), "lmrl_maze_tok_ppo_records")
+        return PPORecords(tokens, ia, rw, n_tok, done, chain, pos, last, n_chains=B, chain_len_bound=max(int(total.cpu().numpy().max()), 1))
+
+    def _ensure_spaced_tables(self):
+        """Host tables of `lmrl_maze_tok_set_spaced`: every observation / action text encoded behind the joining space of the partially observed
+        script's state text (" ".join(item texts), partially_observed_ppo_online.py:378-379).  Concatenating them is `tokenizer.encode(joined text)` only
+        for tokenizers that split between an item's end and the space: probed here on real item pairs (byte-level: always; GPT-2 BPE: items end in a
+        newline, the space goes with the next word)."""
+        if getattr(self, "_spaced_ready", False):
+            return
+        enc = lambda s_: list(self.tok.encode(s_))
+        C = self.env.maze.shape[1]
+        R = self.env.maze.shape[0]
+        n_rows = len(self.obs_len_h)
+        rows = [[] for _ in range(n_rows)]
+        for (gi, r, c), text in self._obs_text.items():
+            rows[(gi * R + r) * C + c] = enc(" " + text)
+        acts = ("move left\n", "move right\n", "move up\n", "move down\n")
+        sp_acts = [enc(" " + a) for a in acts]
+        some_obs = [self._obs_text[k] for k in list(self._obs_text)[:3]]
+        for a in some_obs + list(acts):
+            for b in some_obs + list(acts):
+                if enc(a + " " + b) != enc(a) + enc(" " + b):
+                    raise ValueError("ppo_records (last_k > 1): this tokenizer does not encode ' '.join(items) item by item — use the host text path")
+        cap = max(1, max(len(x) for x in rows))
+        ot, ol = np.zeros((n_rows, cap), dtype=np.int32), np.array([len(x) for x in rows], dtype=np.int32)
+        for i, x in enumerate(rows):
+            ot[i, :len(x)] = x
+        acap = max(len(a) for a in sp_acts) + 1
+        at = np.zeros((4, acap), dtype=np.int32)
+        for i, a in enumerate(sp_acts):
+            at[i, :len(a)] = a
+            at[i, acap - 1] = len(a)
+        _lib.check(self._L.lmrl_maze_tok_set_spaced(self._tok, ot.ctypes.data, ol.ctypes.data, cap, at.ctypes.data, acap), "lmrl_maze_tok_set_spaced")
+        # are this tokenizer's ids the text's UTF-8 bytes?  Then an action string outside the dict is exported as encode(its decoded text) exactly, also
+        # when the policy spelled it with multi-byte tokens; otherwise as its generated ids (equal whenever encode(decode(ids)) == ids)
+        probe = list(some_obs) + list(acts) + [_decode_one(self.tok, i) for i in range(min(self.eng.cfg.vocab, 1024))]
+        self._byte_ids = all(enc(x) == list(x.encode("utf-8")) for x in probe if x)
+        self._spaced_ready = True
+
+    def _ppo_records_history(self, n: Optional[int] = None):
+        """`ppo_records` for item windows (last_k > 1): the chains of the partially observed online script (llm_rl_scripts/maze/ppo/
+        partially_observed_ppo_online.py:372-398: `last_k = 40`) — per transition the window's item texts joined by single spaces as ONE non-action
+        text, then the action, reward [0, r] — built on the device from the episode record (`lmrl_maze_tok_ppo_records_hist`: the window of every turn
+        is rebuilt from the recorded cells, action codes and step kinds).  Two passes: the row lengths first (the longest row sizes the arrays)."""
+        import torch
+        from .algorithms.ppo_device import PPORecords
+        t, L, sp = torch, self._L, _lib.stream_ptr()
+        if self.in_str_process("\x00probe") != "\x00probe" or self.obs_len_h.max() >= self._max_input_length:
+            raise ValueError("ppo_records: the PPO chains tokenise the raw observation text — in_str_process must be the identity and observations untruncated")
+        if self.last_k > 64:
+            raise ValueError("ppo_records: item windows of at most 64 items on the device (last_k = %d)" % self.last_k)
+        if self.history_flags() != 0:
+            raise ValueError("ppo_records: the last episode violated its turn schedule (history_flags = %d)" % self.history_flags())
+        self._ensure_spaced_tables()
+        B = self.B if n is None else int(n)
+        off = t.empty(B + 1, dtype=t.int32, device=self.dev)
+        _lib.check(L.lmrl_exclusive_scan_i32(_lib.ptr(self.traj["n_turns"]), _lib.ptr(off), B, sp), "lmrl_exclusive_scan_i32")
+        N = int(off[B:].cpu().numpy()[0])
+        if N == 0:
+            raise ValueError("ppo_records: no transition recorded (run an episode first)")
+        nl = self.tok.encode("\n")
+        assert len(nl) == 1, "the newline must be one token"
+        z = lambda *s_, dt: t.zeros(*s_, dtype=dt, device=self.dev)
+        n_tok, chain, pos, last = z(N, dt=t.int32), z(N, dt=t.int32), z(N, dt=t.int32), z(N, dt=t.uint8)
+        done, total = z(B, dt=t.uint8), z(B, dt=t.int32)
+        call = lambda cap, tokens, ia, rw: _lib.check(L.lmrl_maze_tok_ppo_records_hist(
+            self._tok, ctypes.byref(self._ctraj), _lib.ptr(self.env.state), B, self.B, _lib.ptr(off), self.last_k, int(nl[0]), 1 if self._byte_ids else 0, cap,
+            _lib.ptr(tokens) if tokens is not None else None, _lib.ptr(ia) if ia is not None else None, _lib.ptr(rw) if rw is not None else None,
+            _lib.ptr(n_tok), _lib.ptr(chain), _lib.ptr(pos), _lib.ptr(last), _lib.ptr(done), _lib.ptr(total), sp), "lmrl_maze_tok_ppo_records_hist")
+        call(0, None, None, None)
+        cap = max(int(n_tok.max().item()), 2)
+        tokens, ia, rw = z(N, cap, dt=t.int32), z(N, cap, dt=t.uint8), z(N, cap, dt=t.float32)
+        call(cap, tokens, ia, rw)
         return PPORecords(tokens, ia, rw, n_tok, done, chain, pos, last, n_chains=B, chain_len_bound=max(int(total.cpu().numpy().max()), 1))
 
     def ppo_data(self, inference, *, gamma: float, lam: float, kl_weight: float, max_length: Optional[int] = None, n: Optional[int] = None, **kw):

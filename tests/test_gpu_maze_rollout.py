@@ -234,8 +234,83 @@ def test_history_windows_on_the_device_loop_equal_the_generic_text_path(last_k, 
         assert longest == min(last_k, 2 * max_steps + 1)             # legal moves all the way: the window reached its full size
     elif max_new == 3:
         assert longest == 1                                          # every action string was illegal: the window restarted every turn
+    # ---- the finished episodes as the partially observed online script's PPO chains (partially_observed_ppo_online.py:372-398: the window's item texts
+    # joined by single spaces as ONE non-action text, then the action), built on the device from the record == the script's loop on the host lists
+    from lmrl_gym_amd.algorithms.ppo_inference import text_trajectory_chains_partially_observed
+    chains = [E.TokenTrajectoryChain.from_text_trajectory_chain(c, tok) for c in text_trajectory_chains_partially_observed(mine)]
+    rec = eng.ppo_records()
+    flat = [tt for c in chains for tt in c.to_list()]
+    assert rec.n == len(flat) == n_steps and rec.n_chains == B == len(chains) and rec.cap == max(len(tt.tokens) for tt in flat)
+    h = {k: getattr(rec, k).cpu().numpy() for k in ("tokens", "is_action", "reward", "n_tok", "done", "chain", "pos", "last")}
+    k = 0
+    for c, ch in enumerate(chains):
+        lst, p = ch.to_list(), 0
+        for i, tt in enumerate(lst):
+            n = int(h["n_tok"][k])
+            assert n == len(tt.tokens) and h["tokens"][k, :n].tolist() == tt.tokens.tolist(), (c, i)
+            assert h["is_action"][k, :n].astype(bool).tolist() == tt.is_action.tolist() and np.array_equal(h["reward"][k, :n], tt.reward)
+            assert h["chain"][k] == c and h["pos"][k] == p and bool(h["last"][k]) == (i == len(lst) - 1)
+            p += n - 1
+            k += 1
+        assert bool(h["done"][c]) == bool(lst[-1].done)
+    eng.close()
+
+
+@pytest.mark.parametrize("last_k,max_new,max_steps", [(40, 1, 7), (4, 2, 6)])
+def test_history_window_ppo_data_on_the_device_equals_the_host_chain_path(last_k, max_new, max_steps):
+    """`MazeRolloutEngine.ppo_data` for item windows (partially_observed_ppo_online.py runs PPO with last_k = 40): the device PPO data built from
+    `lmrl_maze_tok_ppo_records_hist`'s chains (one joined-window state + action per transition, chained per episode) == the host-array
+    `get_ppo_data_from_token_trajectory_chain` on the chains the script's loop builds from the same episodes' host lists — ids and masks identical,
+    log-probs / values 1e-5, returns 1e-5, advantages 2e-5 (whitened over all transitions), KL list; growing 40-item windows with legal moves, and a
+    4-item sliding window with illegal action strings (window restarts)."""
+    from lmrl_gym_amd import _lib, environment as E
+    from lmrl_gym_amd.algorithms import ppo
+    from lmrl_gym_amd.algorithms.common import BlockingStrategy, Padding, Truncation
+    from lmrl_gym_amd.algorithms.ppo_inference import GPT2PPOInference, text_trajectory_chains_partially_observed
+    from lmrl_gym_amd.gpt2 import init_hf_style_state_dict
+    from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
+    dev = _lib.require_gpu()
+    B = 24
+    # (boost 14: the sampled ids stay inside the action pieces + newline — a stray byte >= 0x80 decodes to U+FFFD on the host, whose re-encoding is
+    # three bytes: the device exports an illegal action string as the bytes of its decoded tokens, exact for valid UTF-8)
+    eng, tok, pi, vb, head, env = _setup(dev, B, max_new, max_steps, "describe_observation_only_walls", boost=14.0 if max_new > 1 else 30.0, last_k=last_k,
+                                         max_input_length=1024 if last_k == 40 else 512, whole_actions_only=max_new == 1)
+    eng.run_episode([7 + 5 * i for i in range(B)], None, temperature=1.0, sample_seed=4, use_graph=True, sync_every=0)
+    torch.cuda.synchronize()
+    assert eng.history_flags() == 0
+    inter = eng.interactions()
+    chains = [E.TokenTrajectoryChain.from_text_trajectory_chain(c, tok) for c in text_trajectory_chains_partially_observed(inter)]
+    rec = eng.ppo_records()
+    assert rec.n == sum(len(x) for x in inter) and rec.n_chains == B
+    if max_new > 1:
+        assert any(len(tr.pre_action_history) == 1 for ep in inter for tr in ep[1:])          # a window restarted after an illegal action string
+    else:
+        assert max(len(tr.pre_action_history) for ep in inter for tr in ep) == min(last_k, 2 * max_steps + 1)
+    from lmrl_gym_amd.gpt2 import GPT2Config
+    cfg = GPT2Config(2, 2, 128, 256, pi.cfg.vocab, 1024)           # the data models: positions for the longest joined window
+    d = cfg.d_model
+    g = torch.Generator().manual_seed(16)
+    sd = init_hf_style_state_dict(cfg, seed=3)
+    sd2 = {kk: v + 0.02 * torch.randn(v.shape, generator=g) * v.abs().mean().clamp_min(1e-3) for kk, v in sd.items()}
+    pol, init = GPT2F32(sd2, cfg.n_head, device=dev), GPT2F32(sd, cfg.n_head, device=dev)
+    vh = LinearHeadF32(dict(kernel=torch.randn(d, 1, generator=g) * 0.05, bias=torch.tensor([0.2])), dev)
+    inf = GPT2PPOInference(pol, vh, tok.pad_token_id, initial_policy=init)
+    kw = dict(gamma=0.97, lam=0.9, kl_weight=0.05)
+    max_length = rec.cap + 1
+    assert max_length <= cfg.n_pos
+    ds, kls = eng.ppo_data(inf, max_length=max_length, bsize=32, **kw)
+    datas, kls_h = inf.get_ppo_data_from_token_trajectory_chain(chains, bsize=16, max_length=max_length, **kw)
+    host = ppo.PPODataset.from_ppo_data_list(datas, tok, BlockingStrategy(Padding.RIGHT, Truncation.RIGHT, max_length))
+    got = ds.to_host()
+    assert (got.input_ids == host.input_ids).all() and (got.should_take_action == host.should_take_action).all()
+    np.testing.assert_allclose(got.old_logprobs, host.old_logprobs, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got.old_values, host.old_values, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got.old_returns, host.old_returns, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got.old_advantages, host.old_advantages, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(kls.cpu().numpy(), kls_h, rtol=1e-5, atol=5e-6)
+    # a window that no longer fits max_length is the reference's truncation assert (base_interface.py:318-327), not a silent cut
     with pytest.raises(ValueError):
-        eng.ppo_records()
+        eng.ppo_data(inf, max_length=rec.cap - 2, bsize=32, **kw)
     eng.close()
 
 
