@@ -651,13 +651,15 @@ int lmrl_maze_tok_prompt(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, int j, 
 /* generated ids -> action code: text = concat(token bytes, special tokens skipped); `text.removesuffix('\n') + '\n'`
  * (the Maze scripts' out_str_process) compared with the four action strings; records ids and code */
 int lmrl_maze_tok_action(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, int n, void *stream);
-/* The finished episodes as PPO records (lmrl_ppo_records): one token trajectory per transition — observation ids ++ action ids (generated ids minus
- * special tokens, + newline_tok when the decoded text does not end in a newline), the step reward on the action's last token — chained per episode,
+/* The finished episodes as PPO records (lmrl_ppo_records): one token trajectory per transition — observation ids ++ action ids, the step reward on the
+ * action's last token.  Action ids: a legal action (its post-processed text is a key of the action dict) as the tokenizer's encoding of that key when
+ * lmrl_maze_tok_set_actions was called; otherwise the generated ids minus special tokens (byte_ids != 0 — a tokenizer whose ids are the text's UTF-8
+ * bytes: the bytes of every decoded token), + newline_tok when the decoded text does not end in a newline.  Chained per episode,
  * as the online scripts build them (llm_rl_scripts/maze/ppo/train_ppo_online.py:444-465 + LLM_RL/environment.py:359-370).  off_d [n + 1] =
  * exclusive scan of tr->n_turns (lmrl_exclusive_scan_i32); rows off_d[e] + t; outputs [off_d[n]][cap] / [off_d[n]], done_d / chain_total_d [n]
  * (a chain's concatenated length: the GAE row pitch is their maximum).  The first n of the engine's n_envs envs are exported. */
-int lmrl_maze_tok_ppo_records(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, int n_envs, const int32_t *off_d, int newline_tok, int cap,
-                              int32_t *tokens_d, uint8_t *is_action_d, float *reward_d, int32_t *n_tok_d, int32_t *chain_d, int32_t *pos_d, uint8_t *last_d,
+int lmrl_maze_tok_ppo_records(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, int n_envs, const int32_t *off_d, int newline_tok,
+                              int byte_ids, int cap, int32_t *tokens_d, uint8_t *is_action_d, float *reward_d, int32_t *n_tok_d, int32_t *chain_d, int32_t *pos_d, uint8_t *last_d,
                               uint8_t *done_d, int32_t *chain_total_d, void *stream);
 /* The same export for item windows (last_k > 1; run after an episode of the history-mode loop below), in the form of the partially observed online
  * script (llm_rl_scripts/maze/ppo/partially_observed_ppo_online.py:372-398): per transition ONE non-action text — the window's item texts joined by

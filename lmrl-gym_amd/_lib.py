@@ -58,7 +58,7 @@ _SIGS = {
     "lmrl_gather_rows_bytes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.c_long, c_void_p]),
     "lmrl_gpt2_refresh": (c_int, [c_void_p, c_void_p]),
     "lmrl_exclusive_scan_i32": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
-    "lmrl_maze_tok_ppo_records": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 10),
+    "lmrl_maze_tok_ppo_records": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int] + [c_void_p] * 10),
     "lmrl_maze_tok_ppo_records_hist": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 10),
     "lmrl_maze_tok_set_spaced": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]),
     "lmrl_gpt2_create": (c_void_p, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void maze_ppo_records_kernel(lmrl_maze_traj tr
                                                                const int32_t *__restrict__ obs_tok, const int32_t *__restrict__ obs_len, int obs_cap,
                                                                const uint8_t *__restrict__ tok_bytes, const uint8_t *__restrict__ tok_blen, int vocab,
                                                                int rows, int cols, int max_new, int max_turns, int n, int pitch, const int32_t *__restrict__ off,
+                                                               const int32_t *__restrict__ act_tok, int act_cap, int byte_ids,
                                                                int newline_tok, int cap, int32_t *__restrict__ tokens, uint8_t *__restrict__ is_action,
                                                                float *__restrict__ reward, int32_t *__restrict__ n_tok, int32_t *__restrict__ chain,
                                                                int32_t *__restrict__ pos, uint8_t *__restrict__ last, uint8_t *__restrict__ done,
@@ -147,16 +148,34 @@ __global__ __launch_bounds__(256) void maze_ppo_records_kernel(lmrl_maze_traj tr
             is_action[row * cap + k] = 0;
             reward[row * cap + k] = 0.f;
         }
-        // the action: generated ids minus special tokens (byte length 0), in order (wave-uniform walk: at most max_new ids)
+        // the action.  A legal one (its post-processed text IS a key of the action dict): the tokenizer's encoding of that key when the host supplied it
+        // (lmrl_maze_tok_set_actions) — the reference's re-tokenisation for ANY tokenizer.  Else: generated ids minus special tokens (byte length 0), in
+        // order (wave-uniform walk: at most max_new ids) — with byte_ids (ids = the text's UTF-8 bytes) the bytes of every decoded token instead
         const int gl = tr.gen_len[(size_t)e * max_turns + t];
+        const int code = tr.action[(size_t)e * max_turns + t];
         int na = 0, last_byte = -1;
-        for (int k = 0; k < gl; k++) {
-            const int tok = tr.gen[((size_t)e * max_turns + t) * max_new + k];
-            const int bl = (tok >= 0 && tok < vocab) ? tok_blen[tok] : 255;
-            if (bl == 0) continue;                                   // skip_special_tokens
-            if (lane == 0 && ol + na < cap) tokens[row * cap + ol + na] = tok;
-            last_byte = bl == 255 ? -1 : tok_bytes[(size_t)tok * kTokBytes + bl - 1];
-            na++;
+        if (act_tok && code < 4) {
+            na = act_tok[code * act_cap + act_cap - 1];
+            for (int k = lane; k < na; k += 64)
+                if (ol + k < cap) tokens[row * cap + ol + k] = act_tok[code * act_cap + k];
+            last_byte = '\n';
+        } else {
+            for (int k = 0; k < gl; k++) {
+                const int tok = tr.gen[((size_t)e * max_turns + t) * max_new + k];
+                const int bl = (tok >= 0 && tok < vocab) ? tok_blen[tok] : 255;
+                if (bl == 0) continue;                               // skip_special_tokens
+                if (byte_ids && bl != 255) {
+                    if (lane == 0)
+                        for (int b = 0; b < bl; b++)
+                            if (ol + na + b < cap) tokens[row * cap + ol + na + b] = tok_bytes[(size_t)tok * kTokBytes + b];
+                    last_byte = tok_bytes[(size_t)tok * kTokBytes + bl - 1];
+                    na += bl;
+                    continue;
+                }
+                if (lane == 0 && ol + na < cap) tokens[row * cap + ol + na] = tok;
+                last_byte = bl == 255 ? -1 : tok_bytes[(size_t)tok * kTokBytes + bl - 1];
+                na++;
+            }
         }
         if (last_byte != '\n') {                                     // removesuffix('\n') + '\n' on a text without a trailing newline
             if (lane == 0 && ol + na < cap) tokens[row * cap + ol + na] = newline_tok;
@@ -536,14 +555,14 @@ int lmrl_maze_hist_action(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const 
     return LMRL_OK;
 }
 
-int lmrl_maze_tok_ppo_records(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, int n_envs, const int32_t *off_d, int newline_tok, int cap,
-                              int32_t *tokens_d, uint8_t *is_action_d, float *reward_d, int32_t *n_tok_d, int32_t *chain_d, int32_t *pos_d, uint8_t *last_d,
+int lmrl_maze_tok_ppo_records(lmrl_maze_tok_ctx *c, const lmrl_maze_traj *tr, const void *state_d, int n, int n_envs, const int32_t *off_d, int newline_tok,
+                              int byte_ids, int cap, int32_t *tokens_d, uint8_t *is_action_d, float *reward_d, int32_t *n_tok_d, int32_t *chain_d, int32_t *pos_d, uint8_t *last_d,
                               uint8_t *done_d, int32_t *chain_total_d, void *stream) {
     LMRL_REQUIRE(c && tr && state_d && n > 0 && n <= n_envs && off_d && cap >= 2 && tokens_d && is_action_d && reward_d && n_tok_d && chain_d && pos_d && last_d && done_d &&
                      chain_total_d, "lmrl_maze_tok_ppo_records: bad argument");
     hipLaunchKernelGGL(maze_ppo_records_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, as_stream(stream), *tr, (const int32_t *)state_d, c->goal_slot_d,
                        c->obs_tok_d, c->obs_len_d, c->obs_cap, c->tok_bytes_d, c->tok_blen_d, c->vocab, c->rows, c->cols, c->max_new, c->max_turns, n, n_envs, off_d,
-                       newline_tok, cap, tokens_d, is_action_d, reward_d, n_tok_d, chain_d, pos_d, last_d, done_d, chain_total_d);
+                       c->act_tok_d, c->act_cap, byte_ids, newline_tok, cap, tokens_d, is_action_d, reward_d, n_tok_d, chain_d, pos_d, last_d, done_d, chain_total_d);
     LMRL_CHECK_LAUNCH();
     return LMRL_OK;
 }

@@ -177,18 +177,21 @@ class MazeRolloutEngine:
         self.episodes = 0                              # episode batches run by text_env_eval so far: successive calls draw fresh sampler noise
         if prefix_cache:
             self.refresh_prefix_cache()
+        # the tokenizer's encoding of the four action strings: what a legal action is in later prompts (last_k > 1: the next prompt is
+        # tokenizer.encode(window text)) and in the PPO chains (`ppo_records`: TokenTrajectory.from_text_trajectory re-encodes the action text), whatever
+        # ids the policy generated to spell it
+        acts = [list(tokenizer.encode(self.in_str_process(a))) for a in ("move left\n", "move right\n", "move up\n", "move down\n")]
+        act_len = max(len(a) for a in acts)
+        act_cap = act_len + 1
+        at = np.zeros((4, act_cap), dtype=np.int32)
+        for i, a in enumerate(acts):
+            at[i, :len(a)] = a
+            at[i, act_cap - 1] = len(a)
+        _lib.check(self._L.lmrl_maze_tok_set_actions(self._tok, at.ctypes.data, act_cap), "lmrl_maze_tok_set_actions")
+        self._act_len = act_len
         if self.last_k != 1:
-            # ---- item-window state: token history of the whole episode + item offsets (2 items per turn after the first observation)
-            # a legal action enters later prompts as the tokenizer's encoding of its text, whatever ids spelled it (the next prompt is
-            # tokenizer.encode(window text)); requires an encoding that is concatenative across items (byte level; BPE: items end in a newline)
-            acts = [list(tokenizer.encode(self.in_str_process(a))) for a in ("move left\n", "move right\n", "move up\n", "move down\n")]
-            act_len = max(len(a) for a in acts)
-            act_cap = act_len + 1
-            at = np.zeros((4, act_cap), dtype=np.int32)
-            for i, a in enumerate(acts):
-                at[i, :len(a)] = a
-                at[i, act_cap - 1] = len(a)
-            _lib.check(self._L.lmrl_maze_tok_set_actions(self._tok, at.ctypes.data, act_cap), "lmrl_maze_tok_set_actions")
+            # ---- item-window state: token history of the whole episode + item offsets (2 items per turn after the first observation);
+            # requires an encoding that is concatenative across items (byte level; BPE: items end in a newline)
             item_max = max(act_len, max_new_tokens)
             max_items = 2 * T + 2
             hcap = (T + 1) * (self.max_obs_len + item_max)
@@ -454,9 +457,10 @@ class MazeRolloutEngine:
         """The finished episodes (of the first `n` envs; default all) as `algorithms.ppo_device.PPORecords`: one token trajectory per transition (observation ids ++ action ids,
         reward on the action's last token), chained per episode — the chains the Maze / chess online scripts build from `raw_results`
         (llm_rl_scripts/maze/ppo/train_ppo_online.py:444-465) after `TokenTrajectory.from_text_trajectory`.  Two small readbacks (the number of
-        transitions, the longest chain) size the arrays.  The action ids are the generated ids (special tokens dropped, a newline id appended
-        when the text has no trailing newline): the reference's re-tokenisation of the post-processed action text whenever the tokenizer
-        encodes the decoded action as the generated sequence (byte-level tokenizers); the observation ids are the
+        transitions, the longest chain) size the arrays.  The action ids: a legal action as the tokenizer's encoding of its dict key (the
+        reference's re-tokenisation, any tokenizer); any other string as its generated ids (special tokens dropped, a newline id appended when
+        the text has no trailing newline) — the re-tokenisation whenever encode(decode(ids)) == ids — or, for a tokenizer whose ids are UTF-8
+        bytes, as the bytes of its decoded tokens (exact also for multi-byte tokens); the observation ids are the
         prompt table's rows (`in_str_process` must be the identity and no prompt may have been left-truncated: checked)."""
         import torch
         from .algorithms.ppo_device import PPORecords
@@ -473,12 +477,13 @@ class MazeRolloutEngine:
             raise ValueError("ppo_records: no transition recorded (run an episode first)")
         nl = self.tok.encode("\n")
         assert len(nl) == 1, "the newline must be one token"
-        cap = int(self.max_obs_len) + self.max_new + 1
+        byte_ids = self._ids_are_bytes()
+        cap = int(self.max_obs_len) + max(self.max_new * (_TOK_BYTES if byte_ids else 1), self._act_len) + 1
         z = lambda *s_, dt: t.zeros(*s_, dtype=dt, device=self.dev)
         tokens, ia, rw = z(N, cap, dt=t.int32), z(N, cap, dt=t.uint8), z(N, cap, dt=t.float32)
         n_tok, chain, pos, last = z(N, dt=t.int32), z(N, dt=t.int32), z(N, dt=t.int32), z(N, dt=t.uint8)
         done, total = z(B, dt=t.uint8), z(B, dt=t.int32)
-        _lib.check(L.lmrl_maze_tok_ppo_records(self._tok, ctypes.byref(self._ctraj), _lib.ptr(self.env.state), B, self.B, _lib.ptr(off), int(nl[0]), cap, _lib.ptr(tokens),
+        _lib.check(L.lmrl_maze_tok_ppo_records(self._tok, ctypes.byref(self._ctraj), _lib.ptr(self.env.state), B, self.B, _lib.ptr(off), int(nl[0]), 1 if byte_ids else 0, cap, _lib.ptr(tokens),
                                                _lib.ptr(ia), _lib.ptr(rw), _lib.ptr(n_tok), _lib.ptr(chain), _lib.ptr(pos), _lib.ptr(last), _lib.ptr(done),
                                                _lib.ptr(total), sp), "lmrl_maze_tok_ppo_records")
         return PPORecords(tokens, ia, rw, n_tok, done, chain, pos, last, n_chains=B, chain_len_bound=max(int(total.cpu().numpy().max()), 1))
@@ -514,11 +519,17 @@ class MazeRolloutEngine:
             at[i, :len(a)] = a
             at[i, acap - 1] = len(a)
         _lib.check(self._L.lmrl_maze_tok_set_spaced(self._tok, ot.ctypes.data, ol.ctypes.data, cap, at.ctypes.data, acap), "lmrl_maze_tok_set_spaced")
-        # are this tokenizer's ids the text's UTF-8 bytes?  Then an action string outside the dict is exported as encode(its decoded text) exactly, also
-        # when the policy spelled it with multi-byte tokens; otherwise as its generated ids (equal whenever encode(decode(ids)) == ids)
-        probe = list(some_obs) + list(acts) + [_decode_one(self.tok, i) for i in range(min(self.eng.cfg.vocab, 1024))]
-        self._byte_ids = all(enc(x) == list(x.encode("utf-8")) for x in probe if x)
         self._spaced_ready = True
+
+    def _ids_are_bytes(self) -> bool:
+        """Are this tokenizer's ids the text's UTF-8 bytes?  Then `ppo_records` exports an action string outside the dict as encode(its decoded text)
+        exactly, also when the policy spelled it with multi-byte tokens (valid UTF-8); otherwise as its generated ids (equal whenever
+        encode(decode(ids)) == ids)."""
+        if getattr(self, "_byte_ids", None) is None:
+            probe = [self._obs_text[k] for k in list(self._obs_text)[:3]] + ["move left\n", "move down\n"]
+            probe += [_decode_one(self.tok, i) for i in range(min(self.eng.cfg.vocab, 1024))]
+            self._byte_ids = all(list(self.tok.encode(x)) == list(x.encode("utf-8")) for x in probe if x)
+        return self._byte_ids
 
     def _ppo_records_history(self, n: Optional[int] = None):
         """`ppo_records` for item windows (last_k > 1): the chains of the partially observed online script (llm_rl_scripts/maze/ppo/
@@ -547,7 +558,7 @@ class MazeRolloutEngine:
         n_tok, chain, pos, last = z(N, dt=t.int32), z(N, dt=t.int32), z(N, dt=t.int32), z(N, dt=t.uint8)
         done, total = z(B, dt=t.uint8), z(B, dt=t.int32)
         call = lambda cap, tokens, ia, rw: _lib.check(L.lmrl_maze_tok_ppo_records_hist(
-            self._tok, ctypes.byref(self._ctraj), _lib.ptr(self.env.state), B, self.B, _lib.ptr(off), self.last_k, int(nl[0]), 1 if self._byte_ids else 0, cap,
+            self._tok, ctypes.byref(self._ctraj), _lib.ptr(self.env.state), B, self.B, _lib.ptr(off), self.last_k, int(nl[0]), 1 if self._ids_are_bytes() else 0, cap,
             _lib.ptr(tokens) if tokens is not None else None, _lib.ptr(ia) if ia is not None else None, _lib.ptr(rw) if rw is not None else None,
             _lib.ptr(n_tok), _lib.ptr(chain), _lib.ptr(pos), _lib.ptr(last), _lib.ptr(done), _lib.ptr(total), sp), "lmrl_maze_tok_ppo_records_hist")
         call(0, None, None, None)

@@ -256,6 +256,37 @@ def test_history_windows_on_the_device_loop_equal_the_generic_text_path(last_k, 
     eng.close()
 
 
+def test_ppo_records_re_encode_actions_spelled_with_merged_tokens():
+    """`ppo_records` (last_k = 1) with a tokenizer whose generated ids are NOT the encoding of the decoded action: the policy spells actions with
+    multi-byte tokens ("move left" as one id), the reference's chains hold `tokenizer.encode(action text)` (TokenTrajectory.from_text_trajectory,
+    LLM_RL/environment.py:359-370) — bytes for this tokenizer.  A legal action is exported as the encoding of its dict key, any other string as the
+    bytes of its decoded tokens: records == the script's loop (train_ppo_online.py:444-465) on the host lists, token for token."""
+    from lmrl_gym_amd import _lib, environment as E
+    from lmrl_gym_amd.algorithms.ppo_inference import text_trajectory_chains_from_transitions
+    dev = _lib.require_gpu()
+    B = 32
+    eng, tok, *_ = _setup(dev, B, 2, 7, "describe_observation_give_position", boost=14.0)
+    eng.run_episode([3 + 7 * i for i in range(B)], None, temperature=1.0, sample_seed=9, use_graph=True, sync_every=0)
+    torch.cuda.synchronize()
+    inter = eng.interactions()
+    chains = [E.TokenTrajectoryChain.from_text_trajectory_chain(c, tok) for c in text_trajectory_chains_from_transitions(inter)]
+    rec = eng.ppo_records()
+    h = {k: getattr(rec, k).cpu().numpy() for k in ("tokens", "is_action", "reward", "n_tok")}
+    gen = eng.traj["gen"].cpu().numpy()
+    assert (gen >= 256).any()                                       # multi-byte ids were generated
+    codes = eng.traj["action"].cpu().numpy()
+    k = legal = other = 0
+    for c, ch in enumerate(chains):
+        for i, tt in enumerate(ch.to_list()):
+            n = int(h["n_tok"][k])
+            assert n == len(tt.tokens) and h["tokens"][k, :n].tolist() == tt.tokens.tolist(), (c, i)
+            assert h["is_action"][k, :n].astype(bool).tolist() == tt.is_action.tolist() and np.array_equal(h["reward"][k, :n], tt.reward)
+            legal += int(codes[c, i] < 4); other += int(codes[c, i] >= 4)
+            k += 1
+    assert k == rec.n and legal > 3 and other > 10, (legal, other)
+    eng.close()
+
+
 @pytest.mark.parametrize("last_k,max_new,max_steps", [(40, 1, 7), (4, 2, 6)])
 def test_history_window_ppo_data_on_the_device_equals_the_host_chain_path(last_k, max_new, max_steps):
     """`MazeRolloutEngine.ppo_data` for item windows (partially_observed_ppo_online.py runs PPO with last_k = 40): the device PPO data built from
