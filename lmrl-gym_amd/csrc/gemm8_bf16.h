@@ -569,6 +569,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm8_kernel(GemmArgs g, XcdMap x
                 }
         };
         if constexpr (WD) g8_mainloop_wd<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, prefetch);
+        else if constexpr (PAIR) g8_mainloop_pair<BM, BN, WM, WN>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, prefetch);
         else g8_mainloop<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc, prefetch);
     } else {
         if constexpr (WD) g8_mainloop_wd<BM, BN, WM, WN, STAGES>(g.A, g.lda, g.W, g.ldw > 0 ? g.ldw : g.K, g.K, Mr, m0, n0, smem, acc);

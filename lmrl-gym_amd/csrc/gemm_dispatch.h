@@ -42,6 +42,8 @@ inline hipError_t gemm_launch_ln_nq(const GemmArgs &g, hipStream_t s) {
     // round 4 (with the MFMA results in VGPRs, build.py): the LONG-K residual producer (fc2: 192 tiles x 48 K-steps) on 8 waves (4 x 2, 16 x 32 per wave)
     // and a 4-slot ring: 48.2 -> 47.85 ms per episode in situ; the short-K one (proj, 12 K-steps) gains nothing from it (48.15), 3 slots lose (49.06).
     // Variant 116 = the 4-wave ring for both (A/B hook)
+    if (g.K >= 2048 && g.K % 128 == 0 && g_gemm_variant == 124) return gemm8_launch<64, 64, 4, 2, 4, EPI, NQ, true>(g, s);      // A/B (round 6): fc2 on paired K-steps (one barrier per two)
+    if (g.K < 2048 && g.K % 128 == 0 && g_gemm_variant == 125) return gemm8_launch<64, 64, 4, 2, 4, EPI, NQ, true>(g, s);       // A/B: proj likewise
     if (g.K >= 2048 && g_gemm_variant == 120) return gemm8_launch<64, 64, 4, 2, 6, EPI, NQ>(g, s);      // A/B (round 6): 6-slot ring (96 KB), 5 stages in flight
     if (g.K >= 2048 && g_gemm_variant == 121) return gemm8_launch<64, 64, 4, 2, 5, EPI, NQ>(g, s);
     if (g.K >= 2048 && g_gemm_variant != 116) return gemm8_launch<64, 64, 4, 2, 4, EPI, NQ>(g, s);
