@@ -124,3 +124,38 @@ def test_length_rule_equals_the_reference_loop():
             tt = TokenTrajectory.from_text_trajectory(ch.text_trajectory, CharTok())
             assert tt.tokens.tolist() == exp["tokens"] and [float(x) for x in tt.reward] == exp["reward"] and bool(tt.done) == exp["done"]
     assert n_short >= 20 and n_skip >= 20
+
+
+def test_partially_observed_chains_equal_the_reference_loop():
+    """tests/golden/ppo_po_chains.json = outputs of the partially observed Maze script's own rollout -> chain loop (llm_rl_scripts/maze/ppo/
+    partially_observed_ppo_online.py:372-398, executed on MazeEnv(last_k)-shaped interaction lists): the package's host function
+    (`text_trajectory_chains_partially_observed`, what `MazeRolloutEngine.ppo_records` builds on the device for last_k > 1) reproduces every token
+    trajectory of every chain — the window's item texts joined by single spaces as one non-action text, then the action, reward on its last token."""
+    import lmrl_gym_amd  # noqa: F401
+    from lmrl_gym_amd.algorithms.ppo_inference import text_trajectory_chains_partially_observed
+    from lmrl_gym_amd.environment import InteractionTransition, Text, TokenTrajectoryChain
+
+    class CharTok:
+        def encode(self, s):
+            return [ord(c) for c in s]
+    fx = load_golden("ppo_po_chains.json")
+    n_tt = longest = 0
+    for case in fx["cases"]:
+        raw = []
+        for ep in case["episodes"]:
+            trs = []
+            for tr in ep:
+                pa = tuple(Text(t, bool(a)) for t, a in tr["post_action_history"])
+                trs.append(InteractionTransition(pa[:-1], pa, (), tr["reward"], tr["done"]))
+            raw.append(trs)
+        chains = text_trajectory_chains_partially_observed(raw)
+        assert len(chains) == len(case["chains"])
+        for ch, exp in zip(chains, case["chains"]):
+            tts = TokenTrajectoryChain.from_text_trajectory_chain(ch, CharTok()).to_list()
+            assert len(tts) == len(exp)
+            for tt, e in zip(tts, exp):
+                assert tt.tokens.tolist() == e["tokens"] and tt.is_action.astype(int).tolist() == e["is_action"]
+                assert [float(x) for x in tt.reward] == e["reward"] and bool(tt.done) == e["done"]
+                n_tt += 1
+                longest = max(longest, len(e["tokens"]))
+    assert n_tt == 160 and longest > 200
