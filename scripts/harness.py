@@ -179,8 +179,8 @@ def cmd_ppo(a):
     from lmrl_gym_amd import _lib, datasets as DS, environment as E
     from lmrl_gym_amd.algorithms import ppo
     from lmrl_gym_amd.algorithms.common import BlockingStrategy, Padding, Truncation
-    from lmrl_gym_amd.algorithms.ppo_inference import (GPT2PPOInference, text_trajectory_chains_from_interactions,
-                                                       text_trajectory_chains_from_transitions)
+    from lmrl_gym_amd.algorithms.ppo_inference import (GPT2PPOInference, text_trajectory_chains_from_interactions, text_trajectory_chains_from_transitions,
+                                                       text_trajectory_chains_partially_observed)
     from lmrl_gym_amd.policies import GPT2PPOPolicy
     from lmrl_gym_amd.train.gpt2_f32 import GPT2F32, LinearHeadF32
     dev = _lib.require_gpu()
@@ -277,7 +277,10 @@ def cmd_ppo(a):
         else:
             raw, summary = E.text_env_eval(env, policy, n_rollouts=a.n_rollouts, bsize=a.rollout_bsize, seed_generator=iter(range(rnd * 10 ** 6, 10 ** 9)),
                                            verbose=False)
-        chains = text_trajectory_chains_from_transitions(raw) if a.env in ("chess", "maze") else text_trajectory_chains_from_interactions(raw, tok, max_len, a.gamma)
+        if a.env == "maze" and a.maze_last_k != 1:      # item windows: the partially observed script's joined-state chains (partially_observed_ppo_online.py:372-398)
+            chains = text_trajectory_chains_partially_observed(raw)
+        else:
+            chains = text_trajectory_chains_from_transitions(raw) if a.env in ("chess", "maze") else text_trajectory_chains_from_interactions(raw, tok, max_len, a.gamma)
         datas, kls = inf.get_ppo_data_from_text_trajectory_chain(chains, bsize=a.ppo_data_bsize, max_length=max_len, gamma=a.gamma, lam=a.lam,
                                                                  kl_weight=ctl.value, use_advantage_whitening=a.use_advantage_whitening)
         mean_kl = float(kls.mean()) if len(kls) else 0.0

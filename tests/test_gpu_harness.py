@@ -196,6 +196,10 @@ def test_harness_script_subcommands_at_toy_scale(tmp_path, capsys):
     H.main(mz)
     H.main(mz + ["--device-rollouts", "1", "--resident", "0"])
     H.main(mz + ["--device-rollouts", "1", "--n-rounds", "2", "--trim-batches", "1", "--bf16-activations", "1", "--policy-top-k", "40"])      # (fused top-k epilogue)
+    # the partially observed twin (maze/ppo/partially_observed_ppo_online.py: item windows, joined-state chains): host path and the device-resident loop
+    po = [x if x != "160" else "320" for x in mz] + ["--maze-last-k", "5", "--maze-describe-function", "describe_observation_only_walls"]
+    H.main(po)
+    H.main(po + ["--device-rollouts", "1", "--trim-batches", "1"])
     sf = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "stockfish")
     if os.path.exists(sf):
         H.main(["ppo", "--env", "chess", "--chess-engine", sf, "--chess-use-nnue", "false", "--chess-movetime-ms", "10", "--chess-max-moves", "2", "--n-rollouts", "2",
