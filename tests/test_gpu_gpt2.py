@@ -293,19 +293,11 @@ def test_sampler_top_p_and_top_k_warpers(dev):
     logits = base[None].repeat(B, 1).contiguous().to(dev)
     L = _lib.lib()
     for temp, top_k, top_p in [(1.0, 0, 0.8), (0.7, 0, 0.5), (1.2, 20, 0.9), (1.0, 5, 0.999)]:
-        # reference kept set
-        z = base.double() / temp
-        order = torch.argsort(z, descending=True, stable=True)
-        keep = torch.ones(V, dtype=torch.bool)
-        if top_k > 0:
-            kth = z[order[top_k - 1]]
-            keep &= z >= kth
-        zk = torch.where(keep, z, torch.tensor(float("-inf"), dtype=torch.float64))
-        probs = torch.softmax(zk, -1)
-        cum = torch.cumsum(probs[order], 0)
-        mask_sorted = torch.roll(cum < top_p, 1); mask_sorted[0] = True
-        keep2 = torch.zeros(V, dtype=torch.bool); keep2[order[mask_sorted]] = True
-        final = torch.softmax(torch.where(keep2, z, torch.tensor(float("-inf"), dtype=torch.float64)), -1).numpy()
+        # reference kept set: oracle/warpers.py (pinned to the HF logits processors in tests/test_oracle_warpers.py)
+        from oracle import warpers as OW
+        zo, keep_o = OW.warp(base.double().numpy(), temp, top_k, top_p)
+        keep2 = torch.from_numpy(keep_o)
+        final = np.exp(OW.log_probs(zo, keep_o))
         counts = np.zeros(V)
         for step in range(3):
             sp = SampleParams(temp, top_k, 11, step, 0.0, 0.0, 0, None, top_p)
@@ -595,13 +587,13 @@ def test_fused_topk_at_bench_size_against_the_float64_oracle(dev, ilql):
     tok, lp = ses.sample(sp, hidden=hid.to(dev), logits_out=lo, q1=q1, q2=q2)
     torch.cuda.synchronize()
     tok, lp = tok.cpu().numpy(), lp.cpu().numpy()
-    zt = (z / temp).numpy()
+    from oracle import warpers as OW
+    zt, kept = OW.warp(z.numpy(), temp, top_k, 0.0)                          # (pinned to the HF processors: tests/test_oracle_warpers.py)
     srt = -np.sort(-zt, axis=1)[:, :top_k + 1]
     clear = (srt[:, top_k - 1] - srt[:, top_k]) > 1e-3                       # the top-k boundary is decided beyond the fp32-accumulation noise (~3e-5 here)
     assert clear.mean() > 0.9
-    kept = zt >= srt[:, top_k - 1:top_k]
     assert kept[np.arange(B), tok][clear].all()
-    logp = zt - np.log(np.where(kept, np.exp(zt - srt[:, :1]), 0.0).sum(1, keepdims=True)) - srt[:, :1]
+    logp = OW.log_probs(zt, kept)
     np.testing.assert_allclose(lp[clear], logp[np.arange(B), tok][clear], rtol=0, atol=3e-3)
     n = 128
     noise = O.gumbel_noise(n, V, seed, step).astype(np.float64)
@@ -640,22 +632,18 @@ def test_fused_top_p_at_bench_size_against_the_float64_oracle(dev):
     tok, lp = tok.cpu().numpy(), lp.cpu().numpy()
     fb = ses.sample_ws[_lib.lib().lmrl_sample_fb_offset(B, cfg.vocab_padded):][:64].view(torch.int32)
     assert int(fb[0].item()) <= B // 50 and int(torch.isnan(lo[:, 0]).sum().item()) >= B - 128 * int(fb[0].item())
-    zt = (z / temp)
-    p = torch.softmax(zt, 1)
-    ps, order = p.sort(1, descending=True)
-    cum = ps.cumsum(1)
-    n_keep = (cum < top_p).sum(1) + 1                                        # HF: tokens kept while the mass BEFORE them is below top_p
+    from oracle import warpers as OW
+    ztn, kept = OW.warp(z.numpy(), temp, 0, top_p)                           # (pinned to the HF processors: tests/test_oracle_warpers.py)
+    n_keep = torch.from_numpy(kept.sum(1))
     assert 2.0 < n_keep.double().mean().item() < 200.0, n_keep.double().mean().item()
+    ps = torch.softmax(torch.from_numpy(ztn), 1).sort(1, descending=True).values
+    cum = ps.cumsum(1)
     before = torch.where(n_keep > 1, cum.gather(1, (n_keep - 2).clamp(min=0)[:, None])[:, 0], torch.zeros(B, dtype=torch.float64))
     at = cum.gather(1, (n_keep - 1)[:, None])[:, 0]
     clear = (((top_p - before) > 1e-3) & ((at - top_p) > 1e-3)).numpy()       # the crossing is decided beyond the bf16-product / fp32-accumulation noise
     assert clear.mean() > 0.9
-    rank = torch.empty_like(order); rank.scatter_(1, order, torch.arange(V)[None].expand(B, V))
-    kept = (rank < n_keep[:, None]).numpy()
     assert kept[np.arange(B), tok][clear].all()
-    ztn = zt.numpy()
-    mx = ztn.max(1, keepdims=True)
-    logp = ztn - np.log(np.where(kept, np.exp(ztn - mx), 0.0).sum(1, keepdims=True)) - mx
+    logp = OW.log_probs(ztn, kept)
     np.testing.assert_allclose(lp[clear], logp[np.arange(B), tok][clear], rtol=0, atol=3e-3)
     n = 128
     noise = O.gumbel_noise(n, V, seed, step).astype(np.float64)
